@@ -1,0 +1,94 @@
+/* oracle/ref_bench.c — TEST/BENCH INFRASTRUCTURE ONLY (bench.py's `cpu_baseline` leg, kind "reference").
+ *
+ * Times the REAL reference (oracle/_ref/libzstd_ref.so, built from /root/reference) on the host cores the
+ * same way programs/benchzstd.c does for `zstd -b# -B128K` (benchzstd.c:336-345, :567, benchfn.c:107-256):
+ * one ZSTD_compress2 call per chunk on a reused CCtx, repeated runs, fastest run kept, MB = 1e6 source bytes.
+ *
+ *   zref_bench bench  <level> <chunkSize> <totalBytes> <P%> <seed> <seconds> <threads>
+ *        input = RDG_genBuffer(totalBytes, P/100, 0.0, seed) (programs/datagen.c:144); with threads>1 each
+ *        thread compresses a disjoint contiguous shard of the chunks with its own CCtx.
+ *        prints one JSON line.
+ *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
+ */
+#define ZSTD_STATIC_LINKING_ONLY
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <pthread.h>
+#include "zstd.h"
+#include "datagen.h"
+
+static double now_s(void)
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+typedef struct {
+    int level; size_t chunk; const char* src; size_t n; char* dst; size_t dstCap; size_t csize; int err;
+} job_t;
+
+static void* worker(void* p)
+{
+    job_t* j = (job_t*)p;
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t off = 0, pos = 0;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, j->level);
+    while (off < j->n) {
+        size_t const len = j->n - off < j->chunk ? j->n - off : j->chunk;
+        size_t const r = ZSTD_compress2(c, j->dst + pos, j->dstCap - pos, j->src + off, len);
+        if (ZSTD_isError(r)) { j->err = 1; break; }
+        pos += r; off += len;
+    }
+    j->csize = pos;
+    ZSTD_freeCCtx(c);
+    return NULL;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 5 && !strcmp(argv[1], "stream")) {
+        RDG_genStdout(strtoull(argv[2], 0, 10), atof(argv[3]) / 100.0, 0.0, (unsigned)atoi(argv[4]));
+        return 0;
+    }
+    if (argc < 9 || strcmp(argv[1], "bench")) {
+        fprintf(stderr, "usage: %s bench level chunk total P seed seconds threads | stream total P seed\n", argv[0]);
+        return 2;
+    }
+    {   int const level = atoi(argv[2]);
+        size_t const chunk = strtoull(argv[3], 0, 10);
+        size_t const total = strtoull(argv[4], 0, 10);
+        double const P = atof(argv[5]) / 100.0;
+        unsigned const seed = (unsigned)atoi(argv[6]);
+        double const seconds = atof(argv[7]);
+        int const T = atoi(argv[8]) > 0 ? atoi(argv[8]) : 1;
+        char* src = (char*)malloc(total);
+        size_t const nChunks = (total + chunk - 1) / chunk;
+        size_t const cap = ZSTD_compressBound(chunk) * nChunks;
+        char* dst = (char*)malloc(cap);
+        job_t* jobs = (job_t*)calloc((size_t)T, sizeof(job_t));
+        pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+        double best = 1e30, t0 = now_s(); size_t csize = 0; int runs = 0, t;
+        if (!src || !dst || !jobs || !th) return 1;
+        RDG_genBuffer(src, total, P, 0.0, seed);
+        do {
+            double const a = now_s();
+            size_t c0 = 0;
+            for (t = 0; t < T; t++) {
+                size_t const k0 = nChunks * (size_t)t / (size_t)T, k1 = nChunks * (size_t)(t + 1) / (size_t)T;
+                size_t const b0 = k0 * chunk, b1 = (k1 * chunk < total) ? k1 * chunk : total;
+                jobs[t].level = level; jobs[t].chunk = chunk; jobs[t].src = src + b0; jobs[t].n = b1 - b0;
+                jobs[t].dst = dst + k0 * ZSTD_compressBound(chunk); jobs[t].dstCap = (k1 - k0) * ZSTD_compressBound(chunk);
+                if (T == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
+            }
+            for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; c0 += jobs[t].csize; }
+            {   double const d = now_s() - a; if (d < best) best = d; }
+            csize = c0; runs++;
+        } while (now_s() - t0 < seconds);
+        printf("{\"level\": %d, \"chunk\": %zu, \"bytes\": %zu, \"csize\": %zu, \"ratio\": %.4f, "
+               "\"best_s\": %.6f, \"MBps\": %.2f, \"runs\": %d, \"threads\": %d}\n",
+               level, chunk, total, csize, (double)total / (double)csize, best, (double)total / best / 1e6, runs, T);
+        return 0;
+    }
+}

@@ -1,0 +1,197 @@
+/* oracle/ref_shim.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin driver around the REAL reference (facebook/zstd, compiled from /root/reference into
+ * oracle/_ref/libzstd_ref.so by oracle/Makefile).  It exposes, with a flat C ABI that python/ctypes
+ * can call, exactly the reference entry points SURVEY.md §8(c) names as oracles:
+ *
+ *   O1  zref_compress_chunks    = ZSTD_compress2 per chunk on one reused CCtx   (what `zstd -b# -B<chunk>` times,
+ *                                 programs/benchzstd.c:336-345)
+ *   O2  zref_sequences          = ZSTD_generateSequences on a DEDICATED CCtx    (lib/compress/zstd_compress.c:3462;
+ *                                 the call poisons its CCtx)
+ *   O3  zref_huf_*, zref_fse_*  = stage functions exported by the static lib    (huf_compress.c, fse_compress.c)
+ *   O4  zref_decompress         = ZSTD_decompress                               (lib/decompress/zstd_decompress.c:1201)
+ *       zref_datagen / zref_datagen_stream / zref_lorem = programs/datagen.c, programs/lorem.c input generators
+ *       zref_get_cparams        = ZSTD_getCParams                               (lib/compress/zstd_compress.c:7150)
+ *
+ * Nothing here is linked by, imported by, or shipped with the product library.
+ */
+#define ZSTD_STATIC_LINKING_ONLY
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "zstd.h"
+#include "zstd_errors.h"
+#include "datagen.h"
+#include "lorem.h"
+#include "hist.h"
+#include "huf.h"
+#include "fse.h"
+
+static void set_level(ZSTD_CCtx* c, int level)
+{
+    ZSTD_CCtx_reset(c, ZSTD_reset_session_and_parameters);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, level);
+}
+
+/* O1: one frame per chunk; returns total bytes or (size_t)-1. sizes[i] = compressed size of chunk i. */
+size_t zref_compress_chunks(int level, size_t chunkSize, const void* src, size_t n,
+                            void* dst, size_t dstCap, size_t* sizes, size_t maxChunks)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0, k = 0;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    if (n == 0) {
+        size_t r = ZSTD_compress2(c, dst, dstCap, src, 0);
+        ZSTD_freeCCtx(c);
+        if (ZSTD_isError(r)) return (size_t)-1;
+        if (sizes && maxChunks) sizes[0] = r;
+        return r;
+    }
+    while (off < n) {
+        size_t const len = (n - off < chunkSize) ? n - off : chunkSize;
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, len);
+        if (ZSTD_isError(r)) { ZSTD_freeCCtx(c); return (size_t)-1; }
+        if (sizes && k < maxChunks) sizes[k] = r;
+        k++; pos += r; off += len;
+    }
+    ZSTD_freeCCtx(c);
+    return pos;
+}
+
+/* Same but with every cParam pinned explicitly (windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy). */
+size_t zref_compress_chunks_params(const int cp[7], size_t chunkSize, const void* src, size_t n,
+                                   void* dst, size_t dstCap, size_t* sizes, size_t maxChunks)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0, k = 0;
+    if (!c) return (size_t)-1;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_windowLog, cp[0]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_chainLog, cp[1]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_hashLog, cp[2]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_searchLog, cp[3]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_minMatch, cp[4]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_targetLength, cp[5]);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_strategy, cp[6]);
+    while (off < n) {
+        size_t const len = (n - off < chunkSize) ? n - off : chunkSize;
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, len);
+        if (ZSTD_isError(r)) { ZSTD_freeCCtx(c); return (size_t)-1; }
+        if (sizes && k < maxChunks) sizes[k] = r;
+        k++; pos += r; off += len;
+    }
+    ZSTD_freeCCtx(c);
+    return pos;
+}
+
+/* whole buffer as ONE frame (the conventional `zstd -b#` figure; NOT the parity target) */
+size_t zref_compress_frame(int level, const void* src, size_t n, void* dst, size_t dstCap)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    r = ZSTD_compress2(c, dst, dstCap, src, n);
+    ZSTD_freeCCtx(c);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
+/* O2: sequences of ONE unit (n <= 128 KB) from the internal block compressor. out = 4 u32 per sequence
+ * {offset, litLength, matchLength, rep}; block delimiter {0,lastLits,0,0} included. */
+size_t zref_sequences(int level, const void* src, size_t n, unsigned* out, size_t capSeqs)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();            /* dedicated: generateSequences poisons it */
+    ZSTD_Sequence* s = (ZSTD_Sequence*)malloc(sizeof(ZSTD_Sequence) * capSeqs);
+    size_t r, i;
+    if (!c || !s) return (size_t)-1;
+    set_level(c, level);
+    r = ZSTD_generateSequences(c, s, capSeqs, src, n);
+    if (ZSTD_isError(r)) { free(s); ZSTD_freeCCtx(c); return (size_t)-1; }
+    for (i = 0; i < r; i++) {
+        out[4*i+0] = s[i].offset; out[4*i+1] = s[i].litLength;
+        out[4*i+2] = s[i].matchLength; out[4*i+3] = s[i].rep;
+    }
+    free(s); ZSTD_freeCCtx(c);
+    return r;
+}
+
+size_t zref_decompress(void* dst, size_t dstCap, const void* src, size_t n)
+{
+    size_t const r = ZSTD_decompress(dst, dstCap, src, n);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
+unsigned long long zref_decompressed_size(const void* src, size_t n)
+{
+    return ZSTD_findDecompressedSize(src, n);
+}
+
+size_t zref_compress_bound(size_t n) { return ZSTD_compressBound(n); }
+
+void zref_get_cparams(int level, unsigned long long srcSize, size_t dictSize, int out[7])
+{
+    ZSTD_compressionParameters const p = ZSTD_getCParams(level, srcSize, dictSize);
+    out[0] = (int)p.windowLog; out[1] = (int)p.chainLog; out[2] = (int)p.hashLog; out[3] = (int)p.searchLog;
+    out[4] = (int)p.minMatch;  out[5] = (int)p.targetLength; out[6] = (int)p.strategy;
+}
+
+/* ---- input generators ---- */
+void zref_datagen(void* buf, size_t size, double matchProba, double litProba, unsigned seed)
+{
+    RDG_genBuffer(buf, size, matchProba, litProba, seed);
+}
+void zref_lorem(void* buf, size_t size, unsigned seed) { LOREM_genBuffer(buf, size, seed); }
+
+/* ---- O3 stage oracles ---- */
+/* histogram: returns largest count, writes count[256] and *maxSym */
+size_t zref_hist(unsigned* count, unsigned* maxSym, const void* src, size_t n)
+{
+    *maxSym = 255;
+    return HIST_count(count, maxSym, src, n);
+}
+
+/* Huffman code lengths the reference assigns for a histogram (HUF_buildCTable_wksp, huf_compress.c:756).
+ * nbBits[s] for s<=maxSym; returns tableLog (maxNbBits) or (size_t)-1 */
+size_t zref_huf_build(const unsigned* count, unsigned maxSym, unsigned maxNbBits, unsigned char* nbBits)
+{
+    HUF_CREATE_STATIC_CTABLE(ct, 255);
+    static unsigned wksp[HUF_WORKSPACE_SIZE_U64 * 2];
+    unsigned s;
+    size_t const r = HUF_buildCTable_wksp(ct, count, maxSym, maxNbBits, wksp, sizeof(wksp));
+    if (HUF_isError(r)) return (size_t)-1;
+    for (s = 0; s <= maxSym; s++) nbBits[s] = (unsigned char)HUF_getNbBitsFromCTable(ct, s);
+    return r;
+}
+
+/* Full literals-section body through HUF_compress4X_repeat / 1X with no previous table
+ * (huf_compress.c:1453): returns size, 0 (not compressible), 1 (rle) */
+size_t zref_huf_compress(void* dst, size_t dstCap, const void* src, size_t n, int fourStreams, int flags)
+{
+    static unsigned long long wksp[HUF_WORKSPACE_SIZE_U64];
+    HUF_CREATE_STATIC_CTABLE(ct, 255);
+    HUF_repeat rep = HUF_repeat_none;
+    size_t r;
+    memset(ct, 0, sizeof(ct));
+    r = fourStreams ? HUF_compress4X_repeat(dst, dstCap, src, n, 255, 11, wksp, sizeof(wksp), ct, &rep, flags)
+                    : HUF_compress1X_repeat(dst, dstCap, src, n, 255, 11, wksp, sizeof(wksp), ct, &rep, flags);
+    return HUF_isError(r) ? (size_t)-1 : r;
+}
+
+/* FSE_normalizeCount (fse_compress.c:465) */
+size_t zref_fse_normalize(short* norm, unsigned tableLog, const unsigned* count, size_t total,
+                          unsigned maxSym, unsigned useLowProb)
+{
+    size_t const r = FSE_normalizeCount(norm, tableLog, count, total, maxSym, useLowProb);
+    return FSE_isError(r) ? (size_t)-1 : r;
+}
+unsigned zref_fse_optimal_tablelog(unsigned maxLog, size_t n, unsigned maxSym)
+{
+    return FSE_optimalTableLog(maxLog, n, maxSym);
+}
+size_t zref_fse_write_ncount(void* dst, size_t cap, const short* norm, unsigned maxSym, unsigned tableLog)
+{
+    size_t const r = FSE_writeNCount(dst, cap, norm, maxSym, tableLog);
+    return FSE_isError(r) ? (size_t)-1 : r;
+}
+
+unsigned zref_version(void) { return ZSTD_versionNumber(); }

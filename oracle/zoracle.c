@@ -1,0 +1,1098 @@
+/* oracle/zoracle.c — TEST INFRASTRUCTURE ONLY (see zoracle.h).
+ *
+ * A deliberately plain, serial restatement of the reference's hot path.  Every function cites the reference
+ * lines it follows (paths relative to /root/reference).  Parity status: PINNED — byte-identical to the real
+ * reference (oracle/_ref) on the sweeps in tests/test_oracle_vs_reference.py and on tests/golden/ fixtures.
+ *
+ * Style notes: positions are 0-based offsets into the block (the reference uses window indices = pos + base
+ * offset; only differences ever reach the output).  Hash-table value 0 means "empty"; stored
+ * values are pos+1.
+ */
+#include "zoracle.h"
+#include <string.h>
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------ small helpers */
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static unsigned hb32(uint32_t v) { return 31u - (unsigned)__builtin_clz(v); }          /* lib/common/bits.h:177 */
+static void wr16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static void wr24(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); }
+static void wr32(uint8_t* p, uint32_t v) { wr16(p, v & 0xFFFF); wr16(p + 2, v >> 16); }
+
+/* ------------------------------------------------------------------ parameters */
+/* lib/compress/clevels.h:24-130, rows "base for negative levels" .. level 4 of the four size classes */
+static const zo_cparams kRows[4][5] = {
+  { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },  /* > 256 KB  */
+  { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,3} },  /* <= 256 KB */
+  { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },  /* <= 128 KB */
+  { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,3} },  /* <= 16 KB  */
+};
+
+/* zstd_compress.c:7123-7145 (row pick) then :1466-1602 (adjust) with dictSize 0 and a known srcSize */
+int zo_get_cparams(int level, unsigned long long srcSize, zo_cparams* out)
+{
+    unsigned const tableID = (srcSize <= 256u*1024) + (srcSize <= 128u*1024) + (srcSize <= 16u*1024);
+    int row = level;
+    zo_cparams cp;
+    if (level == 0) row = 3;                       /* ZSTD_CLEVEL_DEFAULT */
+    if (level < 0) row = 0;
+    if (row > 4) return -1;                        /* strategies above dfast are outside this oracle */
+    cp = kRows[tableID][row];
+    if (level < 0) {                               /* :7139-7142, ZSTD_minCLevel() = -(1<<17) */
+        int const clamped = level < -131072 ? -131072 : level;
+        cp.targetLength = (unsigned)(-clamped);
+    }
+    if (cp.strategy > 2) return -1;
+    if (srcSize <= (1ULL << 30)) {                 /* :1546-1553 */
+        uint32_t const tSize = (uint32_t)srcSize;
+        unsigned const srcLog = (tSize < 64) ? 6 : hb32(tSize - 1) + 1;
+        if (cp.windowLog > srcLog) cp.windowLog = srcLog;
+    }
+    if (cp.hashLog > cp.windowLog + 1) cp.hashLog = cp.windowLog + 1;            /* :1557 */
+    if (cp.chainLog > cp.windowLog) cp.chainLog = cp.windowLog;                  /* :1558-1559 (cycleLog == chainLog) */
+    if (cp.windowLog < 10) cp.windowLog = 10;                                    /* :1562 */
+    *out = cp;
+    return 0;
+}
+
+size_t zo_compress_bound(size_t n)   /* lib/zstd.h:235 */
+{
+    return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+/* ------------------------------------------------------------------ stage 1: match finders */
+/* zstd_compress_internal.h:820-862 */
+static uint32_t zo_hash(const uint8_t* p, unsigned hBits, unsigned mls)
+{
+    switch (mls) {
+    default:
+    case 4: return (rd32(p) * 2654435761U) >> (32 - hBits);
+    case 5: return (uint32_t)(((rd64(p) << 24) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (uint32_t)(((rd64(p) << 16) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (uint32_t)(((rd64(p) << 8) * 58295818150454627ULL) >> (64 - hBits));
+    case 8: return (uint32_t)((rd64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+    }
+}
+
+/* zstd_compress_internal.h:771 — common prefix length of src[a..) and src[b..), a bounded by n */
+static uint32_t zo_count(const uint8_t* src, size_t a, size_t b, size_t n)
+{
+    size_t const a0 = a;
+    while (a < n && src[a] == src[b]) { a++; b++; }
+    return (uint32_t)(a - a0);
+}
+
+typedef struct {
+    zo_seq* seqs; size_t nb, cap;
+    uint8_t* lits; size_t litSize;
+    int overflow;
+} zo_store;
+
+/* zstd_compress_internal.h:671 (literal copy + one seqDef) */
+static void zo_store_seq(zo_store* st, const uint8_t* src, size_t anchor, size_t litLength, uint32_t offBase, uint32_t ml)
+{
+    if (st->nb >= st->cap) { st->overflow = 1; return; }
+    memcpy(st->lits + st->litSize, src + anchor, litLength);
+    st->litSize += litLength;
+    st->seqs[st->nb].litLength = (uint32_t)litLength;
+    st->seqs[st->nb].matchLength = ml;
+    st->seqs[st->nb].offBase = offBase;
+    st->nb++;
+}
+
+/* zstd_fast.c:192-423  ZSTD_compressBlock_fast_noDict_generic, one block, empty history.
+ * T[] holds pos+1 (0 = empty).  Returns trailing-literal count; rep[] updated like :368-372. */
+static size_t zo_fast(const zo_cparams* cp, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hlog = cp->hashLog, mls = cp->minMatch;
+    size_t const stepSize = cp->targetLength + !cp->targetLength + 1;            /* :200 */
+    uint32_t* T = (uint32_t*)calloc((size_t)1 << hlog, sizeof(uint32_t));
+    size_t const ilimit = n - 8;                                                 /* :207, caller guarantees n >= 8 */
+    size_t anchor = 0, ip0 = 1, ip1, ip2, ip3, cur0 = 0, step, nextStep, match0 = 0, mLength;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, offBase;
+    uint32_t h0, h1, cand;                                                       /* cand = candidate pos+1 for ip0 */
+    {   uint32_t const maxRep = 1;                                               /* :238-244: ip0 = 1, window low = 0 */
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {   /* _start */
+        step = stepSize; nextStep = ip0 + 128;                                   /* :249-250, kStepIncr = 1<<7 */
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;                                                /* :257 */
+        h0 = zo_hash(src + ip0, hlog, mls); h1 = zo_hash(src + ip1, hlog, mls);
+        cand = T[h0];
+        for (;;) {
+            int found = 0;
+            uint32_t const rval = rep1 ? rd32(src + ip2 - rep1) : 0;
+            cur0 = ip0; T[h0] = (uint32_t)ip0 + 1;                               /* :271-272 */
+            if (rep1 > 0 && rd32(src + ip2) == rval) {                           /* :275-290 repcode at ip2 */
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = (src[ip0 - 1] == src[match0 - 1]);
+                ip0 -= mLength; match0 -= mLength;
+                offBase = 1; mLength += 4;
+                T[h1] = (uint32_t)ip1 + 1;
+                found = 2;
+            } else if (cand && rd32(src + ip0) == rd32(src + cand - 1)) {        /* :292-299 */
+                T[h1] = (uint32_t)ip1 + 1;
+                found = 1;
+            } else {
+                cand = T[h1]; h0 = h1; h1 = zo_hash(src + ip2, hlog, mls);       /* :302-311 */
+                ip0 = ip1; ip1 = ip2; ip2 = ip3;
+                cur0 = ip0; T[h0] = (uint32_t)ip0 + 1;                           /* :314-315 */
+                if (cand && rd32(src + ip0) == rd32(src + cand - 1)) {           /* :317-326 */
+                    if (step <= 4) T[h1] = (uint32_t)ip1 + 1;
+                    found = 1;
+                } else {
+                    cand = T[h1]; h0 = h1; h1 = zo_hash(src + ip2, hlog, mls);   /* :329-339 */
+                    ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+                    if (ip2 >= nextStep) { step++; nextStep += 128; }            /* :342-347 */
+                    if (ip3 < ilimit) continue;
+                    goto cleanup;
+                }
+            }
+            if (found == 1) {   /* _offset :377-391 */
+                match0 = cand - 1;
+                rep2 = rep1; rep1 = (uint32_t)(ip0 - match0);
+                offBase = rep1 + 3; mLength = 4;
+                while (ip0 > anchor && match0 > 0 && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+            }
+            /* _match :393-401 */
+            mLength += zo_count(src, ip0 + mLength, match0 + mLength, n);
+            zo_store_seq(st, src, anchor, ip0 - anchor, offBase, (uint32_t)mLength);
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {                                                 /* :404-420 */
+                T[zo_hash(src + cur0 + 2, hlog, mls)] = (uint32_t)cur0 + 2 + 1;
+                T[zo_hash(src + ip0 - 2, hlog, mls)] = (uint32_t)ip0 - 2 + 1;
+                if (rep2 > 0) {
+                    while (ip0 <= ilimit && rd32(src + ip0) == rd32(src + ip0 - rep2)) {
+                        uint32_t const rLength = zo_count(src, ip0 + 4, ip0 + 4 - rep2, n) + 4;
+                        uint32_t const t = rep2; rep2 = rep1; rep1 = t;
+                        T[zo_hash(src + ip0, hlog, mls)] = (uint32_t)ip0 + 1;
+                        ip0 += rLength;
+                        zo_store_seq(st, src, anchor, 0, 1, rLength);
+                        anchor = ip0;
+                    }
+                }
+            }
+            break;   /* goto _start */
+        }
+    }
+cleanup:
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;                       /* :368 */
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    free(T);
+    return n - anchor;
+}
+
+/* zstd_double_fast.c:105-323  ZSTD_compressBlock_doubleFast_noDict_generic, one block, empty history */
+static size_t zo_dfast(const zo_cparams* cp, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hL = cp->hashLog, hS = cp->chainLog, mls = cp->minMatch;
+    uint32_t* TL = (uint32_t*)calloc((size_t)1 << hL, sizeof(uint32_t));
+    uint32_t* TS = (uint32_t*)calloc((size_t)1 << hS, sizeof(uint32_t));
+    size_t const ilimit = n - 8;
+    size_t anchor = 0, ip = 1, ip1, step, nextStep, curr = 0, mLength = 0;
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0, offset = 0;
+    {   uint32_t const maxRep = 1;
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
+    }
+    for (;;) {
+        uint32_t hl0, hl1 = 0, idxl0, idxl1 = 0;      /* idx* are pos+1, 0 = empty */
+        int kind = 0;                                  /* 1 = repcode stored, 2 = match found */
+        step = 1; nextStep = ip + 256; ip1 = ip + step;                           /* :168-170, kStepIncr = 1<<8 */
+        if (ip1 > ilimit) break;
+        hl0 = zo_hash(src + ip, hL, 8); idxl0 = TL[hl0];
+        do {
+            uint32_t const hs0 = zo_hash(src + ip, hS, mls);
+            uint32_t const idxs0 = TS[hs0];
+            size_t matchs0;
+            curr = ip;
+            TL[hl0] = TS[hs0] = (uint32_t)ip + 1;                                /* :187 */
+            if (off1 > 0 && rd32(src + ip + 1 - off1) == rd32(src + ip + 1)) {   /* :190-195 */
+                mLength = zo_count(src, ip + 1 + 4, ip + 1 + 4 - off1, n) + 4;
+                ip++;
+                zo_store_seq(st, src, anchor, ip - anchor, 1, (uint32_t)mLength);
+                kind = 1; break;
+            }
+            hl1 = zo_hash(src + ip1, hL, 8);
+            if (idxl0 && rd64(src + idxl0 - 1) == rd64(src + ip)) {              /* :203-211 (idx >= prefixLowest) */
+                size_t m = idxl0 - 1;
+                mLength = zo_count(src, ip + 8, m + 8, n) + 8;
+                offset = (uint32_t)(ip - m);
+                while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+                kind = 2; break;
+            }
+            idxl1 = TL[hl1];
+            if (idxs0 && rd32(src + idxs0 - 1) == rd32(src + ip)) {              /* :217-222 -> _search_next_long :253-271 */
+                matchs0 = idxs0 - 1;
+                mLength = zo_count(src, ip + 4, matchs0 + 4, n) + 4;
+                offset = (uint32_t)(ip - matchs0);
+                if (idxl1 > 1 && rd64(src + idxl1 - 1) == rd64(src + ip1)) {     /* :260 idxl1 > prefixLowestIndex (strict) */
+                    size_t const m1 = idxl1 - 1;
+                    size_t const l1len = zo_count(src, ip1 + 8, m1 + 8, n) + 8;
+                    if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (uint32_t)(ip - m1); matchs0 = m1; }
+                }
+                while (ip > anchor && matchs0 > 0 && src[ip - 1] == src[matchs0 - 1]) { ip--; matchs0--; mLength++; }
+                kind = 2; break;
+            }
+            if (ip1 >= nextStep) { step++; nextStep += 256; }                    /* :224-229 */
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1;
+        } while (ip1 <= ilimit);
+        if (!kind) break;                                                        /* _cleanup */
+        if (kind == 2) {                                                         /* _match_found :275-290 */
+            off2 = off1; off1 = offset;
+            if (step < 4) TL[hl1] = (uint32_t)ip1 + 1;
+            zo_store_seq(st, src, anchor, ip - anchor, offset + 3, (uint32_t)mLength);
+        }
+        ip += mLength; anchor = ip;                                              /* _match_stored :292-321 */
+        if (ip <= ilimit) {
+            size_t const ins = curr + 2;
+            TL[zo_hash(src + ins, hL, 8)] = (uint32_t)ins + 1;
+            TL[zo_hash(src + ip - 2, hL, 8)] = (uint32_t)ip - 2 + 1;
+            TS[zo_hash(src + ins, hS, mls)] = (uint32_t)ins + 1;
+            TS[zo_hash(src + ip - 1, hS, mls)] = (uint32_t)ip - 1 + 1;
+            while (ip <= ilimit && off2 > 0 && rd32(src + ip) == rd32(src + ip - off2)) {
+                uint32_t const rLength = zo_count(src, ip + 4, ip + 4 - off2, n) + 4;
+                uint32_t const t = off2; off2 = off1; off1 = t;
+                TS[zo_hash(src + ip, hS, mls)] = (uint32_t)ip + 1;
+                TL[zo_hash(src + ip, hL, 8)] = (uint32_t)ip + 1;
+                zo_store_seq(st, src, anchor, 0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;                       /* :244-248 */
+    rep[0] = off1 ? off1 : saved1;
+    rep[1] = off2 ? off2 : saved2;
+    free(TL); free(TS);
+    return n - anchor;
+}
+
+/* zstd_compress.c:3207-3369 ZSTD_buildSeqStore for a history-less block (+ :3365 trailing literals) */
+size_t zo_parse_block(const zo_cparams* cp, const uint8_t* src, size_t n,
+                      zo_seq* seqs, size_t cap, uint8_t* lits, size_t* litSize, uint32_t repOut[3])
+{
+    zo_store st; uint32_t rep[3] = {1, 4, 8};                                    /* zstd_internal.h:69 */
+    size_t last;
+    st.seqs = seqs; st.nb = 0; st.cap = cap; st.lits = lits; st.litSize = 0; st.overflow = 0;
+    if (n < 8) last = n;                     /* the block compressors' loops need ilimit = n-8 >= 0; nothing found */
+    else if (cp->strategy == 1) last = zo_fast(cp, src, n, &st, rep);
+    else last = zo_dfast(cp, src, n, &st, rep);
+    memcpy(lits + st.litSize, src + n - last, last);
+    st.litSize += last;
+    *litSize = st.litSize;
+    if (repOut) { repOut[0] = rep[0]; repOut[1] = rep[1]; repOut[2] = rep[2]; }
+    return st.overflow ? ZO_ERROR : st.nb;
+}
+
+/* zstd_compress.c:3371-3454 ZSTD_copyBlockSequences; repcode resolution per zstd_compress_internal.h:735 */
+size_t zo_sequences_public(const zo_cparams* cp, const uint8_t* src, size_t n, uint32_t* out, size_t capSeqs)
+{
+    zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (n / 3 + 2));
+    uint8_t* lits = (uint8_t*)malloc(n + 8);
+    size_t litSize = 0, i, sumLit = 0;
+    uint32_t rep[3] = {1, 4, 8};
+    size_t const nb = zo_parse_block(cp, src, n, seqs, n / 3 + 2, lits, &litSize, NULL);
+    if (nb == ZO_ERROR || nb + 1 > capSeqs) { free(seqs); free(lits); return ZO_ERROR; }
+    for (i = 0; i < nb; i++) {
+        uint32_t const ob = seqs[i].offBase, ll = seqs[i].litLength;
+        uint32_t raw, repField = 0;
+        if (ob <= 3) {
+            repField = ob;
+            if (ll != 0) raw = rep[ob - 1];
+            else raw = (ob == 3) ? rep[0] - 1 : rep[ob];
+        } else raw = ob - 3;
+        out[4*i] = raw; out[4*i+1] = ll; out[4*i+2] = seqs[i].matchLength; out[4*i+3] = repField;
+        if (ob > 3) { rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = ob - 3; }
+        else {
+            uint32_t const rc = ob - 1 + (ll == 0);
+            if (rc > 0) {
+                uint32_t const cur = (rc == 3) ? rep[0] - 1 : rep[rc];
+                rep[2] = (rc >= 2) ? rep[1] : rep[2];
+                rep[1] = rep[0]; rep[0] = cur;
+            }
+        }
+        sumLit += ll;
+    }
+    out[4*nb] = 0; out[4*nb+1] = (uint32_t)(litSize - sumLit); out[4*nb+2] = 0; out[4*nb+3] = 0;
+    free(seqs); free(lits);
+    return nb + 1;
+}
+
+/* ------------------------------------------------------------------ bit writers */
+/* lib/common/bitstream.h:145-231: LSB-first stream, closed by a single 1 bit. */
+typedef struct { uint8_t* p; uint64_t acc; unsigned nb; } zo_bits;
+static void bw_init(zo_bits* b, uint8_t* dst) { b->p = dst; b->acc = 0; b->nb = 0; }
+static void bw_add(zo_bits* b, uint64_t v, unsigned n)
+{
+    if (n == 0) return;
+    b->acc |= (v & ((1ULL << n) - 1)) << b->nb;
+    b->nb += n;
+    while (b->nb >= 8) { *b->p++ = (uint8_t)b->acc; b->acc >>= 8; b->nb -= 8; }
+}
+static uint8_t* bw_close(zo_bits* b)            /* bitstream.h:222: add 1 bit, flush, +1 byte if bits pending */
+{
+    bw_add(b, 1, 1);
+    if (b->nb) { *b->p++ = (uint8_t)b->acc; b->acc = 0; b->nb = 0; }
+    return b->p;
+}
+
+/* ------------------------------------------------------------------ histogram */
+size_t zo_hist(unsigned count[256], unsigned* maxSym, const uint8_t* src, size_t n)   /* hist.c:29-59 */
+{
+    size_t i; unsigned largest = 0, m = 255, s;
+    memset(count, 0, 256 * sizeof(unsigned));
+    if (n == 0) { *maxSym = 0; return 0; }
+    for (i = 0; i < n; i++) count[src[i]]++;
+    while (!count[m]) m--;
+    for (s = 0; s <= m; s++) if (count[s] > largest) largest = count[s];
+    *maxSym = m;
+    return largest;
+}
+static size_t hist_small(unsigned* count, unsigned* maxSym, const uint8_t* src, size_t n)  /* same, alphabet <= *maxSym */
+{
+    size_t i; unsigned largest = 0, m = *maxSym, s;
+    memset(count, 0, (m + 1) * sizeof(unsigned));
+    if (n == 0) { *maxSym = 0; return 0; }
+    for (i = 0; i < n; i++) count[src[i]]++;
+    while (!count[m]) m--;
+    for (s = 0; s <= m; s++) if (count[s] > largest) largest = count[s];
+    *maxSym = m;
+    return largest;
+}
+
+/* ------------------------------------------------------------------ FSE */
+typedef struct {
+    unsigned tableLog;
+    uint16_t state[512];            /* next-state table, sorted by symbol (fse_compress.c:170-173) */
+    int32_t  dFind[64];             /* deltaFindState */
+    uint32_t dBits[64];             /* deltaNbBits    */
+} zo_fse;
+
+/* fse_compress.c:348-374 */
+static unsigned fse_min_log(size_t n, unsigned maxSym)
+{
+    unsigned const a = hb32((uint32_t)n) + 1, b = hb32(maxSym) + 2;
+    return a < b ? a : b;
+}
+static unsigned fse_optimal_log(unsigned maxLog, size_t n, unsigned maxSym, unsigned minus)
+{
+    unsigned const maxBitsSrc = hb32((uint32_t)(n - 1)) - minus;
+    unsigned log = maxLog, minBits = fse_min_log(n, maxSym);
+    if (maxBitsSrc < log) log = maxBitsSrc;
+    if (minBits > log) log = minBits;
+    if (log < 5) log = 5;
+    if (log > 12) log = 12;
+    return log;
+}
+
+/* fse_compress.c:379-463 */
+static int fse_normalize_m2(short* norm, unsigned tableLog, const unsigned* count, size_t total, unsigned maxSym, short lowProb)
+{
+    unsigned s, distributed = 0, toDistribute;
+    uint32_t const lowThreshold = (uint32_t)(total >> tableLog);
+    uint32_t lowOne = (uint32_t)((total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProb; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = -2;
+    }
+    toDistribute = (1u << tableLog) - distributed;
+    if (toDistribute == 0) return 0;
+    if ((total / toDistribute) > lowOne) {
+        lowOne = (uint32_t)((total * 3) / (toDistribute * 2));
+        for (s = 0; s <= maxSym; s++)
+            if (norm[s] == -2 && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        toDistribute = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSym + 1) {
+        unsigned maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (short)toDistribute;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; toDistribute > 0; s = (s + 1) % (maxSym + 1))
+            if (norm[s] > 0) { toDistribute--; norm[s]++; }
+        return 0;
+    }
+    {   uint64_t const vStepLog = 62 - tableLog;
+        uint64_t const mid = (1ULL << (vStepLog - 1)) - 1;
+        uint64_t const rStep = ((((uint64_t)1 << vStepLog) * toDistribute) + mid) / (uint32_t)total;
+        uint64_t tmpTotal = mid;
+        for (s = 0; s <= maxSym; s++) {
+            if (norm[s] == -2) {
+                uint64_t const end = tmpTotal + (count[s] * rStep);
+                uint32_t const sStart = (uint32_t)(tmpTotal >> vStepLog), sEnd = (uint32_t)(end >> vStepLog);
+                if (sEnd - sStart < 1) return -1;
+                norm[s] = (short)(sEnd - sStart);
+                tmpTotal = end;
+    }   }   }
+    return 0;
+}
+
+/* fse_compress.c:465-525; returns tableLog, 0 for the rle special case, -1 on error */
+int zo_fse_normalize(short* norm, unsigned tableLog, const unsigned* count, size_t total, unsigned maxSym, unsigned useLowProb)
+{
+    static const uint32_t rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    short const lowProb = useLowProb ? -1 : 1;
+    uint64_t const scale = 62 - tableLog;
+    uint64_t const step = ((uint64_t)1 << 62) / (uint32_t)total;
+    uint64_t const vStep = 1ULL << (scale - 20);
+    int still = 1 << tableLog;
+    unsigned s, largest = 0; short largestP = 0;
+    uint32_t const lowThreshold = (uint32_t)(total >> tableLog);
+    if (tableLog < 5 || tableLog > 12) return -1;
+    if (tableLog < fse_min_log(total, maxSym)) return -1;
+    for (s = 0; s <= maxSym; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProb; still--; }
+        else {
+            short proba = (short)((count[s] * step) >> scale);
+            if (proba < 8) {
+                uint64_t const restToBeat = vStep * rtb[proba];
+                proba += (count[s] * step) - ((uint64_t)proba << scale) > restToBeat;
+            }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba; still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) {
+        if (fse_normalize_m2(norm, tableLog, count, total, maxSym, lowProb) < 0) return -1;
+    } else norm[largest] += (short)still;
+    return (int)tableLog;
+}
+
+/* fse_compress.c:234-327 (writeIsSafe path; callers provide room). returns size or 0 on error */
+static size_t fse_write_ncount(uint8_t* out0, const short* norm, unsigned maxSym, unsigned tableLog)
+{
+    uint8_t* out = out0;
+    int const tableSize = 1 << tableLog;
+    int nbBits = (int)tableLog + 1, remaining = tableSize + 1, threshold = tableSize, bitCount = 4, previousIs0 = 0;
+    uint32_t bitStream = tableLog - 5;
+    unsigned symbol = 0; unsigned const alphabetSize = maxSym + 1;
+    while (symbol < alphabetSize && remaining > 1) {
+        if (previousIs0) {
+            unsigned start = symbol;
+            while (symbol < alphabetSize && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24; bitStream += 0xFFFFU << bitCount;
+                out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3U << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) {
+                out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+            }
+        }
+        {   int count = norm[symbol++];
+            int const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (uint32_t)count << bitCount;
+            bitCount += nbBits; bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) {
+            out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+        }
+    }
+    if (remaining != 1) return 0;
+    out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (size_t)(out - out0);
+}
+
+/* fse_compress.c:68-214 */
+static void fse_build(zo_fse* ct, const short* norm, unsigned maxSym, unsigned tableLog)
+{
+    uint32_t const tableSize = 1u << tableLog, mask = tableSize - 1;
+    uint32_t const step = (tableSize >> 1) + (tableSize >> 3) + 3;               /* FSE_TABLESTEP */
+    uint16_t cumul[66]; uint8_t sym[512];
+    uint32_t high = tableSize - 1, u, pos = 0; unsigned s, total = 0;
+    ct->tableLog = tableLog;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSym + 1; u++) {
+        if (norm[u-1] == -1) { cumul[u] = cumul[u-1] + 1; sym[high--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u-1] + (uint16_t)norm[u-1];
+    }
+    for (s = 0; s <= maxSym; s++) {
+        int i;
+        for (i = 0; i < norm[s]; i++) {
+            sym[pos] = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (u = 0; u < tableSize; u++) { uint8_t const c = sym[u]; ct->state[cumul[c]++] = (uint16_t)(tableSize + u); }
+    for (s = 0; s <= maxSym; s++) {
+        switch (norm[s]) {
+        case 0: ct->dBits[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct->dFind[s] = 0; break;
+        case -1: case 1:
+            ct->dBits[s] = (tableLog << 16) - (1u << tableLog);
+            ct->dFind[s] = (int)(total - 1); total++; break;
+        default: {
+            uint32_t const maxBitsOut = tableLog - hb32((uint32_t)norm[s] - 1);
+            uint32_t const minStatePlus = (uint32_t)norm[s] << maxBitsOut;
+            ct->dBits[s] = (maxBitsOut << 16) - minStatePlus;
+            ct->dFind[s] = (int)(total - (unsigned)norm[s]);
+            total += (unsigned)norm[s]; }
+        }
+    }
+}
+static void fse_build_rle(zo_fse* ct, unsigned symbol)                           /* fse_compress.c:528 */
+{
+    ct->tableLog = 0; ct->state[0] = 0; ct->state[1] = 0;
+    ct->dBits[symbol] = 0; ct->dFind[symbol] = 0;
+}
+
+/* lib/common/fse.h:452-476 */
+static uint32_t fse_init2(const zo_fse* ct, unsigned symbol)
+{
+    uint32_t const nbBitsOut = (ct->dBits[symbol] + (1 << 15)) >> 16;
+    uint32_t const v = (nbBitsOut << 16) - ct->dBits[symbol];
+    return ct->state[(v >> nbBitsOut) + ct->dFind[symbol]];
+}
+static uint32_t fse_encode(zo_bits* b, const zo_fse* ct, uint32_t state, unsigned symbol)
+{
+    uint32_t const nbBitsOut = (state + ct->dBits[symbol]) >> 16;
+    bw_add(b, state, nbBitsOut);
+    return ct->state[(state >> nbBitsOut) + ct->dFind[symbol]];
+}
+
+/* ------------------------------------------------------------------ Huffman */
+typedef struct { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; } zo_node;
+
+static unsigned huf_bucket(uint32_t c) { return c < 166 ? c : hb32(c) + 158; }   /* huf_compress.c:530 */
+
+static void huf_isort(zo_node* a, int low, int high)                             /* :555 */
+{
+    int i, size = high - low + 1; a += low;
+    for (i = 1; i < size; i++) {
+        zo_node const key = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j+1] = a[j]; j--; }
+        a[j+1] = key;
+    }
+}
+static int huf_partition(zo_node* a, int low, int high)                          /* :571 */
+{
+    uint32_t const pivot = a[high].count; int i = low - 1, j; zo_node t;
+    for (j = low; j < high; j++) if (a[j].count > pivot) { i++; t = a[i]; a[i] = a[j]; a[j] = t; }
+    t = a[i+1]; a[i+1] = a[high]; a[high] = t;
+    return i + 1;
+}
+static void huf_qsort(zo_node* a, int low, int high)                             /* :591 */
+{
+    if (high - low < 8) { huf_isort(a, low, high); return; }
+    while (low < high) {
+        int const idx = huf_partition(a, low, high);
+        if (idx - low < high - idx) { huf_qsort(a, low, idx - 1); low = idx + 1; }
+        else { huf_qsort(a, idx + 1, high); high = idx - 1; }
+    }
+}
+
+/* huf_compress.c:620-665 */
+static void huf_sort(zo_node* node, const unsigned* count, unsigned maxSym)
+{
+    struct { uint16_t base, curr; } rp[192];
+    unsigned n;
+    memset(rp, 0, sizeof(rp));
+    for (n = 0; n <= maxSym; n++) rp[huf_bucket(count[n])].base++;
+    for (n = 191; n > 0; n--) { rp[n-1].base += rp[n].base; rp[n-1].curr = rp[n-1].base; }
+    for (n = 0; n <= maxSym; n++) {
+        unsigned const r = huf_bucket(count[n]) + 1;
+        unsigned const pos = rp[r].curr++;
+        node[pos].count = count[n]; node[pos].byte = (uint8_t)n;
+    }
+    for (n = 166; n < 191; n++) {
+        int const sz = rp[n].curr - rp[n].base;
+        if (sz > 1) huf_qsort(node + rp[n].base, 0, sz - 1);
+    }
+}
+
+/* huf_compress.c:376-498 */
+static unsigned huf_set_max_height(zo_node* node, unsigned lastNonNull, unsigned target)
+{
+    unsigned const largestBits = node[lastNonNull].nbBits;
+    if (largestBits <= target) return largestBits;
+    {   int totalCost = 0, n = (int)lastNonNull;
+        unsigned const baseCost = 1u << (largestBits - target);
+        uint32_t rankLast[14]; unsigned const noSymbol = 0xF0F0F0F0;
+        while (node[n].nbBits > target) {
+            totalCost += (int)(baseCost - (1u << (largestBits - node[n].nbBits)));
+            node[n].nbBits = (uint8_t)target; n--;
+        }
+        while (node[n].nbBits == target) --n;
+        totalCost >>= (largestBits - target);
+        {   unsigned i; for (i = 0; i < 14; i++) rankLast[i] = noSymbol; }
+        {   unsigned cur = target; int pos;
+            for (pos = n; pos >= 0; pos--) {
+                if (node[pos].nbBits >= cur) continue;
+                cur = node[pos].nbBits;
+                rankLast[target - cur] = (uint32_t)pos;
+        }   }
+        while (totalCost > 0) {
+            unsigned nBitsToDecrease = hb32((uint32_t)totalCost) + 1;
+            for ( ; nBitsToDecrease > 1; nBitsToDecrease--) {
+                uint32_t const highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+                if (highPos == noSymbol) continue;
+                if (lowPos == noSymbol) break;
+                if (node[highPos].count <= 2 * node[lowPos].count) break;
+            }
+            while (nBitsToDecrease <= 12 && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+            totalCost -= 1 << (nBitsToDecrease - 1);
+            node[rankLast[nBitsToDecrease]].nbBits++;
+            if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+            if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+            else {
+                rankLast[nBitsToDecrease]--;
+                if (node[rankLast[nBitsToDecrease]].nbBits != target - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+            }
+        }
+        while (totalCost < 0) {
+            if (rankLast[1] == noSymbol) {
+                while (node[n].nbBits == target) n--;
+                node[n+1].nbBits--; rankLast[1] = (uint32_t)(n + 1); totalCost++;
+                continue;
+            }
+            node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+        }
+    }
+    return target;
+}
+
+/* huf_compress.c:756-791 (+ :681-718 tree, :730-753 canonical values). value[] = code, nbBits[] = length */
+static unsigned huf_build_full(const unsigned* count, unsigned maxSym, unsigned maxNbBits, uint8_t nbBits[256], uint16_t value[256])
+{
+    zo_node tbl[514]; zo_node* const node0 = tbl; zo_node* const node = tbl + 1;
+    int nonNull, lowS, lowN, nodeNb = 256, nodeRoot, n;
+    memset(tbl, 0, sizeof(tbl));
+    huf_sort(node, count, maxSym);
+    nonNull = (int)maxSym;
+    while (node[nonNull].count == 0) nonNull--;
+    lowS = nonNull; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+    node[nodeNb].count = node[lowS].count + node[lowS-1].count;
+    node[lowS].parent = node[lowS-1].parent = (uint16_t)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+    node0[0].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        int const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        int const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        node[nodeNb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (uint16_t)nodeNb;
+        nodeNb++;
+    }
+    node[nodeRoot].nbBits = 0;
+    for (n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    for (n = 0; n <= nonNull; n++) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    maxNbBits = huf_set_max_height(node, (unsigned)nonNull, maxNbBits);
+    {   uint16_t nbPerRank[13] = {0}, valPerRank[13] = {0}, min = 0;
+        for (n = 0; n <= nonNull; n++) nbPerRank[node[n].nbBits]++;
+        for (n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
+        memset(nbBits, 0, 256);
+        for (n = 0; n <= (int)maxSym; n++) nbBits[node[n].byte] = node[n].nbBits;
+        for (n = 0; n <= (int)maxSym; n++) value[n] = nbBits[n] ? valPerRank[nbBits[n]]++ : 0;
+    }
+    return maxNbBits;
+}
+unsigned zo_huf_build(const unsigned* count, unsigned maxSym, unsigned maxNbBits, uint8_t nbBits[256])
+{
+    uint16_t value[256];
+    return huf_build_full(count, maxSym, maxNbBits, nbBits, value);
+}
+
+/* huf_compress.c:147-186 HUF_compressWeights; fse_compress.c:551-608 for the 2-state coder. returns 0 = not compressible */
+static size_t huf_compress_weights(uint8_t* dst, const uint8_t* w, size_t n)
+{
+    unsigned count[13], maxSym = 12, tableLog;
+    short norm[13]; zo_fse ct; uint8_t* op = dst;
+    if (n <= 1) return 0;
+    if (n == 2) return w[0] == w[1];            /* maxCount == wtSize -> 1, maxCount == 1 -> 0 */
+    {   unsigned const maxCount = (unsigned)hist_small(count, &maxSym, w, n);
+        if (maxCount == n) return 1;
+        if (maxCount == 1) return 0;
+    }
+    tableLog = fse_optimal_log(6, n, maxSym, 2);
+    if (zo_fse_normalize(norm, tableLog, count, n, maxSym, 0) < 0) return 0;
+    {   size_t const h = fse_write_ncount(op, norm, maxSym, tableLog);
+        if (!h) return 0;
+        op += h;
+    }
+    fse_build(&ct, norm, maxSym, tableLog);
+    {   zo_bits b; size_t i = n; uint32_t s1, s2;      /* i = symbols not yet encoded; encode order is last -> first */
+        bw_init(&b, op);
+        if (n & 1) { s1 = fse_init2(&ct, w[i-1]); s2 = fse_init2(&ct, w[i-2]); s1 = fse_encode(&b, &ct, s1, w[i-3]); i -= 3; }
+        else       { s2 = fse_init2(&ct, w[i-1]); s1 = fse_init2(&ct, w[i-2]); i -= 2; }
+        if ((n - 2) & 2) { s2 = fse_encode(&b, &ct, s2, w[i-1]); s1 = fse_encode(&b, &ct, s1, w[i-2]); i -= 2; }
+        while (i >= 4) {
+            s2 = fse_encode(&b, &ct, s2, w[i-1]); s1 = fse_encode(&b, &ct, s1, w[i-2]);
+            s2 = fse_encode(&b, &ct, s2, w[i-3]); s1 = fse_encode(&b, &ct, s1, w[i-4]);
+            i -= 4;
+        }
+        bw_add(&b, s2, ct.tableLog); bw_add(&b, s1, ct.tableLog);
+        op = bw_close(&b);
+    }
+    return (size_t)(op - dst);
+}
+
+/* huf_compress.c:248-289 HUF_writeCTable_wksp; returns size, 0 on failure */
+static size_t huf_write_table(uint8_t* dst, const uint8_t nbBits[256], unsigned maxSym, unsigned huffLog)
+{
+    uint8_t w[256]; unsigned n;
+    for (n = 0; n < maxSym; n++) w[n] = nbBits[n] ? (uint8_t)(huffLog + 1 - nbBits[n]) : 0;
+    {   size_t const h = huf_compress_weights(dst + 1, w, maxSym);
+        if (h > 1 && h < maxSym / 2) { dst[0] = (uint8_t)h; return h + 1; }
+    }
+    if (maxSym > 128) return 0;
+    dst[0] = (uint8_t)(128 + (maxSym - 1));
+    w[maxSym] = 0;
+    for (n = 0; n < maxSym; n += 2) dst[n/2 + 1] = (uint8_t)((w[n] << 4) + w[n+1]);
+    return ((maxSym + 1) / 2) + 1;
+}
+
+/* huf_compress.c:1056-1118: one stream, symbols last->first, closed by a 1 bit (bytes independent of flush policy) */
+static size_t huf_encode_1x(uint8_t* dst, const uint8_t* src, size_t n, const uint8_t* nbBits, const uint16_t* value)
+{
+    zo_bits b; size_t i;
+    bw_init(&b, dst);
+    for (i = n; i-- > 0; ) bw_add(&b, value[src[i]], nbBits[src[i]]);
+    return (size_t)(bw_close(&b) - dst);
+}
+/* huf_compress.c:1168-1215 */
+static size_t huf_encode_4x(uint8_t* dst, const uint8_t* src, size_t n, const uint8_t* nbBits, const uint16_t* value)
+{
+    size_t const seg = (n + 3) / 4; uint8_t* op = dst + 6; int k;
+    if (n < 12) return 0;
+    for (k = 0; k < 4; k++) {
+        size_t const len = (k < 3) ? seg : n - 3 * seg;
+        size_t const c = huf_encode_1x(op, src + (size_t)k * seg, len, nbBits, value);
+        if (c == 0 || c > 65535) return 0;
+        if (k < 3) wr16(dst + 2 * k, (unsigned)c);
+        op += c;
+    }
+    return (size_t)(op - dst);
+}
+
+/* huf_compress.c:1333-1434 HUF_compress_internal with no previous table.
+ * returns compressed size (table + streams), 0 = not compressible, 1 = single symbol (dst[0] = symbol) */
+static size_t huf_compress(uint8_t* dst, const uint8_t* src, size_t n, int fourStreams, int suspect)
+{
+    unsigned count[256], maxSym = 255, huffLog; uint8_t nbBits[256]; uint16_t value[256];
+    uint8_t* op = dst;
+    if (!n) return 0;
+    if (suspect && n >= 4096 * 10) {                                             /* :1367-1379 */
+        unsigned c2[256], m2; size_t tot;
+        tot = zo_hist(c2, &m2, src, 4096);
+        tot += zo_hist(c2, &m2, src + n - 4096, 4096);
+        if (tot <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    {   size_t const largest = zo_hist(count, &maxSym, src, n);                  /* :1382-1385 */
+        if (largest == n) { dst[0] = src[0]; return 1; }
+        if (largest <= (n >> 7) + 4) return 0;
+    }
+    huffLog = fse_optimal_log(11, n, maxSym, 1);                                 /* :1284-1287 */
+    huffLog = huf_build_full(count, maxSym, huffLog, nbBits, value);             /* :1403-1409 */
+    {   size_t const h = huf_write_table(op, nbBits, maxSym, huffLog);           /* :1412-1430 */
+        if (!h) return ZO_ERROR;
+        if (h + 12 >= n) return 0;
+        op += h;
+    }
+    {   size_t const c = fourStreams ? huf_encode_4x(op, src, n, nbBits, value)
+                                     : huf_encode_1x(op, src, n, nbBits, value); /* :1224-1239 */
+        if (c == 0) return 0;
+        op += c;
+        if ((size_t)(op - dst) >= n - 1) return 0;
+    }
+    return (size_t)(op - dst);
+}
+
+/* zstd_compress_literals.c:39 / :81 */
+static size_t lits_raw(uint8_t* dst, const uint8_t* src, size_t n)
+{
+    unsigned const fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) dst[0] = (uint8_t)(0 + (n << 3));
+    else if (fl == 2) wr16(dst, (unsigned)(0 + (1 << 2) + (n << 4)));
+    else wr32(dst, (uint32_t)(0 + (3 << 2) + (n << 4)));
+    memcpy(dst + fl, src, n);
+    return n + fl;
+}
+static size_t lits_rle(uint8_t* dst, const uint8_t* src, size_t n)
+{
+    unsigned const fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) dst[0] = (uint8_t)(1 + (n << 3));
+    else if (fl == 2) wr16(dst, (unsigned)(1 + (1 << 2) + (n << 4)));
+    else wr32(dst, (uint32_t)(1 + (3 << 2) + (n << 4)));
+    dst[fl] = src[0];
+    return fl + 1;
+}
+
+/* zstd_compress_literals.c:129-235 with prevHuf->repeatMode == HUF_repeat_none */
+size_t zo_compress_literals(uint8_t* dst, size_t cap, const uint8_t* lits, size_t n, const zo_cparams* cp, int suspect)
+{
+    size_t const lh = 3 + (n >= 1024) + (n >= 16384);
+    int const single = n < 256;
+    size_t c;
+    (void)cap;
+    if (cp->strategy == 1 && cp->targetLength > 0) return lits_raw(dst, lits, n);   /* internal.h:621-634 */
+    {   int const shift = (9 - (int)cp->strategy) < 3 ? 9 - (int)cp->strategy : 3;  /* :115-127 */
+        if (n < ((size_t)8 << shift)) return lits_raw(dst, lits, n);
+    }
+    c = huf_compress(dst + lh, lits, n, !single, suspect);
+    {   size_t const minGain = (n >> 6) + 2;                                        /* internal.h:613 */
+        if (c == 0 || c == ZO_ERROR || c >= n - minGain) return lits_raw(dst, lits, n);
+    }
+    if (c == 1) return lits_rle(dst, lits, n);                                      /* :192-201 (n >= 64 here) */
+    if (lh == 3) wr24(dst, (uint32_t)(2 + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 14)));
+    else if (lh == 4) wr32(dst, (uint32_t)(2 + (2 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 18)));
+    else { wr32(dst, (uint32_t)(2 + (3 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 22))); dst[4] = (uint8_t)(c >> 10); }
+    return lh + c;
+}
+
+/* ------------------------------------------------------------------ sequences section */
+static const uint8_t kLLbits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+static const uint8_t kMLbits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                     1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+static const short kLLnorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+static const short kMLnorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                   1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+static const short kOFnorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+static unsigned ll_code(uint32_t ll)                                             /* internal.h:520 */
+{
+    static const uint8_t t[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+        22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
+    return ll > 63 ? hb32(ll) + 19 : t[ll];
+}
+static unsigned ml_code(uint32_t mlBase)                                         /* internal.h:537 */
+{
+    static const uint8_t t[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+        32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+        40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+        42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
+    return mlBase > 127 ? hb32(mlBase) + 36 : t[mlBase];
+}
+
+/* zstd_compress_sequences.c:157-235 for strategy < lazy with repeatMode none. returns set_* (0 basic,1 rle,2 compressed) */
+static int select_type(unsigned maxCount, size_t nbSeq, unsigned defaultNormLog, int defaultAllowed, unsigned strategy)
+{
+    if (maxCount == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+    if (defaultAllowed) {
+        size_t const mult = 10 - strategy;
+        size_t const dynMin = (((size_t)1 << defaultNormLog) * mult) >> 3;
+        if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) return 0;
+    }
+    return 2;
+}
+
+/* zstd_compress_sequences.c:243-288; returns bytes written to dst (NCount / rle byte), ZO_ERROR on failure */
+static size_t build_ctable(uint8_t* dst, zo_fse* ct, unsigned fseLog, int type, unsigned* count, unsigned max,
+                           const uint8_t* codes, size_t nbSeq, const short* defNorm, unsigned defLog, unsigned defMax)
+{
+    if (type == 1) { fse_build_rle(ct, max); dst[0] = codes[0]; return 1; }
+    if (type == 0) { fse_build(ct, defNorm, defMax, defLog); return 0; }
+    {   short norm[53]; size_t nbSeq1 = nbSeq;
+        unsigned const tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
+        if (count[codes[nbSeq-1]] > 1) { count[codes[nbSeq-1]]--; nbSeq1--; }
+        if (zo_fse_normalize(norm, tableLog, count, nbSeq1, max, nbSeq1 >= 2048) < 0) return ZO_ERROR;
+        {   size_t const h = fse_write_ncount(dst, norm, max, tableLog);
+            if (!h) return ZO_ERROR;
+            fse_build(ct, norm, max, tableLog);
+            return h;
+        }
+    }
+}
+
+/* zstd_compress.c:2934-2997 + :2756-2873 + zstd_compress_sequences.c:291-382 */
+size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp)
+{
+    uint8_t* op = dst; uint8_t* seqHead;
+    uint8_t *llc, *ofc, *mlc; size_t i, lastCount = 0;
+    static zo_fse ctLL, ctOF, ctML;
+    unsigned count[64], max; int tLL, tOF, tML;
+    (void)cap;
+    if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
+    else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
+    else { op[0] = 0xFF; wr16(op + 1, (unsigned)(nbSeq - 0x7F00)); op += 3; }
+    if (nbSeq == 0) return (size_t)(op - dst);
+    llc = (uint8_t*)malloc(3 * nbSeq); ofc = llc + nbSeq; mlc = ofc + nbSeq;
+    for (i = 0; i < nbSeq; i++) {                                                /* zstd_compress.c:2686-2712 */
+        llc[i] = (uint8_t)ll_code(seqs[i].litLength);
+        ofc[i] = (uint8_t)hb32(seqs[i].offBase);
+        mlc[i] = (uint8_t)ml_code(seqs[i].matchLength - 3);
+    }
+    seqHead = op++;
+    {   size_t h, mf;
+        max = 35; mf = hist_small(count, &max, llc, nbSeq);
+        tLL = select_type((unsigned)mf, nbSeq, 6, 1, cp->strategy);
+        h = build_ctable(op, &ctLL, 9, tLL, count, max, llc, nbSeq, kLLnorm, 6, 35);
+        if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
+        if (tLL == 2) lastCount = h;
+        op += h;
+        max = 31; mf = hist_small(count, &max, ofc, nbSeq);
+        tOF = select_type((unsigned)mf, nbSeq, 5, max <= 28, cp->strategy);
+        h = build_ctable(op, &ctOF, 8, tOF, count, max, ofc, nbSeq, kOFnorm, 5, 28);
+        if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
+        if (tOF == 2) lastCount = h;
+        op += h;
+        max = 52; mf = hist_small(count, &max, mlc, nbSeq);
+        tML = select_type((unsigned)mf, nbSeq, 6, 1, cp->strategy);
+        h = build_ctable(op, &ctML, 9, tML, count, max, mlc, nbSeq, kMLnorm, 6, 52);
+        if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
+        if (tML == 2) lastCount = h;
+        op += h;
+    }
+    *seqHead = (uint8_t)((tLL << 6) + (tOF << 4) + (tML << 2));
+    {   zo_bits b; uint32_t sML, sOF, sLL; size_t n = nbSeq - 1; uint8_t* end;     /* zstd_compress_sequences.c:291-382 */
+        bw_init(&b, op);
+        sML = fse_init2(&ctML, mlc[n]); sOF = fse_init2(&ctOF, ofc[n]); sLL = fse_init2(&ctLL, llc[n]);
+        bw_add(&b, seqs[n].litLength, kLLbits[llc[n]]);
+        bw_add(&b, seqs[n].matchLength - 3, kMLbits[mlc[n]]);
+        bw_add(&b, seqs[n].offBase, ofc[n]);
+        while (n-- > 0) {
+            sOF = fse_encode(&b, &ctOF, sOF, ofc[n]);
+            sML = fse_encode(&b, &ctML, sML, mlc[n]);
+            sLL = fse_encode(&b, &ctLL, sLL, llc[n]);
+            bw_add(&b, seqs[n].litLength, kLLbits[llc[n]]);
+            bw_add(&b, seqs[n].matchLength - 3, kMLbits[mlc[n]]);
+            bw_add(&b, seqs[n].offBase, ofc[n]);
+        }
+        bw_add(&b, sML, ctML.tableLog); bw_add(&b, sOF, ctOF.tableLog); bw_add(&b, sLL, ctLL.tableLog);
+        end = bw_close(&b);
+        {   size_t const bs = (size_t)(end - op);
+            op = end;
+            if (lastCount && lastCount + bs < 4) { free(llc); return 0; }         /* zstd_compress.c:2987 */
+        }
+    }
+    free(llc);
+    return (size_t)(op - dst);
+}
+
+/* ------------------------------------------------------------------ block + frame */
+/* zstd_compress.c:4626-4672 with defaults (content size on, no checksum, no dictID) */
+static size_t write_frame_header(uint8_t* op, const zo_cparams* cp, unsigned long long n)
+{
+    uint32_t const windowSize = 1u << cp->windowLog;
+    unsigned const single = windowSize >= n;
+    unsigned const fcs = (n >= 256) + (n >= 65536 + 256) + (n >= 0xFFFFFFFFU);
+    size_t pos = 4;
+    wr32(op, 0xFD2FB528U);
+    op[pos++] = (uint8_t)((single << 5) + (fcs << 6));
+    if (!single) op[pos++] = (uint8_t)((cp->windowLog - 10) << 3);
+    switch (fcs) {
+    case 0: if (single) op[pos++] = (uint8_t)n; break;
+    case 1: wr16(op + pos, (unsigned)(n - 256)); pos += 2; break;
+    case 2: wr32(op + pos, (uint32_t)n); pos += 4; break;
+    default: wr32(op + pos, (uint32_t)n); wr32(op + pos + 4, (uint32_t)(n >> 32)); pos += 8; break;
+    }
+    return pos;
+}
+
+size_t zo_compress_unit_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
+{
+    uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
+    uint8_t* op = dst; size_t cSize = 0;
+    if (n > ZO_BLOCK_MAX || cap < zo_compress_bound(n)) return ZO_ERROR;
+    op += write_frame_header(op, cp, n);
+    if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }                  /* zstd_compress.c:5270: empty last raw block */
+    if (n >= 7) {                                                                 /* :3216 MIN_CBLOCK_SIZE+3+1+1 */
+        zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (n / 3 + 2));
+        uint8_t* lits = (uint8_t*)malloc(n + 8);
+        size_t litSize = 0;
+        size_t const nb = zo_parse_block(cp, src, n, seqs, n / 3 + 2, lits, &litSize, NULL);
+        uint8_t* body = op + 3;
+        if (nb == ZO_ERROR) { free(seqs); free(lits); return ZO_ERROR; }
+        {   int const suspect = (nb == 0) || (litSize / nb >= 20);               /* :2918 */
+            size_t const l = zo_compress_literals(body, cap, lits, litSize, cp, suspect);
+            size_t const s = zo_compress_sequences(body + l, cap, seqs, nb, cp);
+            if (s == ZO_ERROR) { free(seqs); free(lits); return ZO_ERROR; }
+            cSize = (s == 0) ? 0 : l + s;
+            if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                           /* :3026 minGain */
+        }
+        free(seqs); free(lits);
+    }
+    if (cSize == 0) { wr24(op, (uint32_t)(1 + (0 << 1) + (n << 3))); memcpy(op + 3, src, n); return (size_t)(op + 3 + n - dst); }
+    wr24(op, (uint32_t)(1 + (2 << 1) + (cSize << 3)));                           /* :4586-4590 (first block: never RLE) */
+    return (size_t)(op + 3 + cSize - dst);
+}
+
+size_t zo_compress_unit(void* dst, size_t cap, const void* src, size_t n, int level)
+{
+    zo_cparams cp;
+    if (zo_get_cparams(level, n, &cp) < 0) return ZO_ERROR;
+    return zo_compress_unit_params(dst, cap, src, n, &cp);
+}
+
+size_t zo_compress_chunks(int level, size_t chunk, const void* src, size_t n, void* dst, size_t cap, size_t* sizes, size_t maxChunks)
+{
+    size_t off = 0, pos = 0, k = 0;
+    if (n == 0) { size_t const r = zo_compress_unit(dst, cap, src, 0, level); if (sizes && maxChunks) sizes[0] = r; return r; }
+    while (off < n) {
+        size_t const len = n - off < chunk ? n - off : chunk;
+        size_t const r = zo_compress_unit((uint8_t*)dst + pos, cap - pos, (const uint8_t*)src + off, len, level);
+        if (r == ZO_ERROR) return ZO_ERROR;
+        if (sizes && k < maxChunks) sizes[k] = r;
+        k++; pos += r; off += len;
+    }
+    return pos;
+}
+
+/* ------------------------------------------------------------------ datagen (programs/datagen.c:45-153) */
+static uint32_t rdg_rand(uint32_t* s)
+{
+    uint32_t r = *s; r *= 2654435761U; r ^= 2246822519U; r = (r << 13) | (r >> 19); *s = r; return r >> 5;
+}
+static uint32_t rdg_len(uint32_t* s) { if (rdg_rand(s) & 7) return rdg_rand(s) & 0xF; return (rdg_rand(s) & 0x1FF) + 0xF; }
+
+void zo_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed)
+{
+    uint8_t ldt[8192]; uint8_t* const b = (uint8_t*)buffer; uint32_t s = seed; size_t pos = 0;
+    uint32_t const mp32 = (uint32_t)(32768 * matchProba); uint32_t prevOffset = 1;
+    memset(ldt, '0', sizeof(ldt));
+    if (litProba <= 0.0) litProba = matchProba / 4.5;
+    {   uint32_t ld = (uint32_t)(litProba * 256 + 0.001), u;
+        uint8_t const first = ld ? '(' : 0, last = ld ? '}' : 255; uint8_t ch = ld ? '0' : 0;
+        for (u = 0; u < 8192; ) {
+            uint32_t const w = (((8192 - u) * ld) >> 8) + 1;
+            uint32_t const end = u + w < 8192 ? u + w : 8192;
+            while (u < end) ldt[u++] = ch;
+            ch++; if (ch > last) ch = first;
+        }
+    }
+    if (size == 0) return;
+    while (matchProba >= 1.0) {
+        size_t size0 = rdg_rand(&s) & 3;
+        size0 = (size_t)1 << (16 + size0 * 2);
+        size0 += rdg_rand(&s) & (size0 - 1);
+        if (size < pos + size0) { memset(b + pos, 0, size - pos); return; }
+        memset(b + pos, 0, size0); pos += size0;
+        b[pos-1] = ldt[rdg_rand(&s) & 8191];
+    }
+    b[0] = ldt[rdg_rand(&s) & 8191]; pos = 1;
+    while (pos < size) {
+        if ((rdg_rand(&s) & 0x7FFF) < mp32) {
+            uint32_t const length = rdg_len(&s) + 4;
+            uint32_t const d = (uint32_t)(pos + length < size ? pos + length : size);
+            uint32_t const repeatOffset = (rdg_rand(&s) & 15) == 2;
+            uint32_t const randOffset = (rdg_rand(&s) & 0x7FFF) + 1;
+            uint32_t const offset = repeatOffset ? prevOffset : (uint32_t)(randOffset < pos ? randOffset : pos);
+            size_t match = pos - offset;
+            while (pos < d) b[pos++] = b[match++];
+            prevOffset = offset;
+        } else {
+            uint32_t const length = rdg_len(&s);
+            uint32_t const d = (uint32_t)(pos + length < size ? pos + length : size);
+            while (pos < d) b[pos++] = ldt[rdg_rand(&s) & 8191];
+        }
+    }
+}

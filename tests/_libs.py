@@ -1,0 +1,133 @@
+"""ctypes loaders for the TEST-ONLY checkers: oracle/libzoracle.so (our C restatement) and
+oracle/_ref/libzref_shim.so (the real reference, prebuilt from /root/reference by oracle/Makefile)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ERR = C.c_size_t(-1).value
+u8p = C.POINTER(C.c_uint8)
+
+
+def _buf(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_oracle():
+    so = os.path.join(ORACLE_DIR, "libzoracle.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, "zoracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libzoracle.so"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    lib.zo_compress_bound.restype = C.c_size_t
+    lib.zo_compress_bound.argtypes = [C.c_size_t]
+    lib.zo_compress_unit.restype = C.c_size_t
+    lib.zo_compress_unit.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    lib.zo_compress_unit_params.restype = C.c_size_t
+    lib.zo_compress_unit_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.zo_compress_chunks.restype = C.c_size_t
+    lib.zo_compress_chunks.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t]
+    lib.zo_get_cparams.restype = C.c_int
+    lib.zo_get_cparams.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p]
+    lib.zo_sequences_public.restype = C.c_size_t
+    lib.zo_sequences_public.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zo_parse_block.restype = C.c_size_t
+    lib.zo_parse_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    lib.zo_datagen.restype = None
+    lib.zo_datagen.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint]
+    lib.zo_hist.restype = C.c_size_t
+    lib.zo_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.zo_huf_build.restype = C.c_uint
+    lib.zo_huf_build.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    lib.zo_fse_normalize.restype = C.c_int
+    lib.zo_fse_normalize.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
+    lib.zo_compress_literals.restype = C.c_size_t
+    lib.zo_compress_literals.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    return lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libzref_shim.so"))
+
+
+def load_ref():
+    lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libzref_shim.so"))
+    lib.zref_compress_chunks.restype = C.c_size_t
+    lib.zref_compress_chunks.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_size_t]
+    lib.zref_compress_chunks_params.restype = C.c_size_t
+    lib.zref_compress_chunks_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_compress_frame.restype = C.c_size_t
+    lib.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_sequences.restype = C.c_size_t
+    lib.zref_sequences.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_decompress.restype = C.c_size_t
+    lib.zref_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_decompressed_size.restype = C.c_ulonglong
+    lib.zref_decompressed_size.argtypes = [C.c_void_p, C.c_size_t]
+    lib.zref_compress_bound.restype = C.c_size_t
+    lib.zref_compress_bound.argtypes = [C.c_size_t]
+    lib.zref_get_cparams.restype = None
+    lib.zref_get_cparams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t, C.c_void_p]
+    lib.zref_datagen.restype = None
+    lib.zref_datagen.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint]
+    lib.zref_lorem.restype = None
+    lib.zref_lorem.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    lib.zref_hist.restype = C.c_size_t
+    lib.zref_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.zref_huf_build.restype = C.c_size_t
+    lib.zref_huf_build.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    lib.zref_huf_compress.restype = C.c_size_t
+    lib.zref_huf_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    lib.zref_fse_normalize.restype = C.c_size_t
+    lib.zref_fse_normalize.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
+    lib.zref_fse_optimal_tablelog.restype = C.c_uint
+    lib.zref_fse_optimal_tablelog.argtypes = [C.c_uint, C.c_size_t, C.c_uint]
+    return lib
+
+
+# ----------------------------------------------------------------------------- corpus (seeded, no files needed)
+def datagen(lib_o, n, P, seed=0, lit=0.0):
+    a = np.zeros(max(n, 1), dtype=np.uint8)
+    lib_o.zo_datagen(_buf(a), n, P / 100.0, lit, seed)
+    return a[:n]
+
+
+def text_like(n, seed):
+    """word-salad text (a lorem-ish stand-in that needs no reference code)."""
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(300)]
+    out = bytearray()
+    p = rng.zipf(1.3, size=n // 3 + 16) % len(words)
+    i = 0
+    while len(out) < n:
+        out += words[p[i]] + (b". " if i % 11 == 10 else b" ")
+        i += 1
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+def corpus_cases(lib_o, sizes=(131072,), seeds=(0,)):
+    """yield (name, np.uint8 array) covering compressible / incompressible / degenerate inputs."""
+    for n in sizes:
+        for s in seeds:
+            for P in (0, 10, 20, 50, 80, 95, 100):
+                yield f"datagen_P{P}_n{n}_s{s}", datagen(lib_o, n, P, s)
+            yield f"text_n{n}_s{s}", text_like(n, s)
+            rng = np.random.default_rng(1000 + s)
+            yield f"random_n{n}_s{s}", rng.integers(0, 256, size=n, dtype=np.uint8)
+            yield f"lowent_n{n}_s{s}", rng.integers(0, 4, size=n, dtype=np.uint8)
+            yield f"skew_n{n}_s{s}", (rng.geometric(0.3, size=n) % 256).astype(np.uint8)
+            yield f"zeros_n{n}", np.zeros(n, dtype=np.uint8)
+            yield f"period7_n{n}", (np.arange(n) % 7).astype(np.uint8)
+            yield f"ramp_n{n}", (np.arange(n) // 3 % 256).astype(np.uint8)
+            if n >= 4096:
+                a = rng.integers(0, 256, size=n, dtype=np.uint8)
+                a[n // 3: n // 3 + n // 4] = a[: n // 4]        # one long far match
+                yield f"farmatch_n{n}_s{s}", a
+                b = datagen(lib_o, n, 50, s + 7).copy()
+                b[n // 2:] = 65                                  # long literal-free tail run
+                yield f"halfrun_n{n}_s{s}", b

@@ -1,0 +1,167 @@
+"""Pins oracle/zoracle.c (our C restatement) against the REAL reference built from /root/reference
+(oracle/_ref).  CPU only.  Skipped when oracle/_ref is absent."""
+import ctypes as C
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, _buf, ERR
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return load_oracle(), load_ref()
+
+
+def ref_unit(lr, a, level):
+    cap = lr.zref_compress_bound(len(a)) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = lr.zref_compress_chunks(level, 1 << 17, _buf(a), len(a), _buf(dst), cap, None, 0)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+def ora_unit(lo, a, level):
+    cap = lo.zo_compress_bound(len(a)) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = lo.zo_compress_unit(_buf(dst), cap, _buf(a), len(a), level)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+def test_datagen_matches_reference(libs):
+    lo, lr = libs
+    for P in (0, 20, 50, 90, 100):
+        for seed in (0, 3):
+            for n in (0, 1, 1000, 200000):
+                a = datagen(lo, n, P, seed)
+                b = np.zeros(max(n, 1), dtype=np.uint8)
+                lr.zref_datagen(_buf(b), n, P / 100.0, 0.0, seed)
+                assert a.tobytes() == b[:n].tobytes(), (P, seed, n)
+
+
+def test_cparams_match_reference(libs):
+    lo, lr = libs
+    sizes = [1, 5, 63, 64, 65, 100, 255, 256, 257, 511, 512, 513, 1000, 1024, 4095, 4096, 16383, 16384, 16385,
+             65536, 131071, 131072, 131073, 262144, 262145, 1 << 20, 1 << 30, (1 << 30) + 1, 1 << 32]
+    for level in (-5, -1, 1, 2, 3, 4):
+        for n in sizes:
+            o = (C.c_uint * 7)()
+            r = (C.c_int * 7)()
+            rc = lo.zo_get_cparams(level, n, o)
+            lr.zref_get_cparams(level, n, 0, r)
+            if r[6] > 2:            # greedy+ rows are out of scope for the oracle
+                assert rc == -1
+                continue
+            assert rc == 0 and list(o) == list(r), (level, n, list(o), list(r))
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_unit_bytes_match_reference_128k(libs, level):
+    lo, lr = libs
+    for name, a in corpus_cases(lo, sizes=(131072,), seeds=(0, 1)):
+        assert ora_unit(lo, a, level) == ref_unit(lr, a, level), name
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, -1, -3])
+def test_unit_bytes_match_reference_small_and_ragged(libs, level):
+    lo, lr = libs
+    sizes = [0, 1, 2, 6, 7, 8, 9, 12, 15, 16, 17, 31, 32, 63, 64, 65, 100, 255, 256, 257, 300, 1000, 1023, 1024, 1025,
+             4095, 4096, 5000, 16383, 16384, 16385, 40000, 65535, 65536, 65537, 100000, 131071]
+    for n in sizes:
+        for name, a in corpus_cases(lo, sizes=(n,), seeds=(0,)):
+            o = (C.c_uint * 7)()
+            if lo.zo_get_cparams(level, n, o) != 0:
+                continue
+            assert ora_unit(lo, a, level) == ref_unit(lr, a, level), (name, level)
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_sequences_match_reference(libs, level):
+    lo, lr = libs
+    for name, a in corpus_cases(lo, sizes=(131072, 30000), seeds=(2,)):
+        n = len(a)
+        cap = n // 3 + 8
+        so = np.zeros(cap * 4, dtype=np.uint32)
+        sr = np.zeros(cap * 4, dtype=np.uint32)
+        cp = (C.c_uint * 7)()
+        assert lo.zo_get_cparams(level, n, cp) == 0
+        no = lo.zo_sequences_public(cp, _buf(a), n, _buf(so), cap)
+        nr = lr.zref_sequences(level, _buf(a), n, _buf(sr), cap)
+        assert no != ERR and nr != ERR
+        assert no == nr, name
+        sr[4 * nr - 1] = 0      # the reference leaves the delimiter's .rep uninitialised (zstd_compress.c:3445-3447)
+        assert np.array_equal(so[: 4 * no], sr[: 4 * nr]), name
+
+
+def test_chunks_stream_matches_reference_and_roundtrips(libs):
+    lo, lr = libs
+    n = 1_000_003
+    a = datagen(lo, n, 50, 11)
+    cap = lr.zref_compress_bound(131072) * (n // 131072 + 1)
+    do = np.zeros(cap, dtype=np.uint8)
+    dr = np.zeros(cap, dtype=np.uint8)
+    ro = lo.zo_compress_chunks(1, 131072, _buf(a), n, _buf(do), cap, None, 0)
+    rr = lr.zref_compress_chunks(1, 131072, _buf(a), n, _buf(dr), cap, None, 0)
+    assert ro == rr and do[:ro].tobytes() == dr[:rr].tobytes()
+    out = np.zeros(n, dtype=np.uint8)
+    assert lr.zref_decompress(_buf(out), n, _buf(do), ro) == n
+    assert out.tobytes() == a.tobytes()
+
+
+def test_stage_huffman_lengths_match_reference(libs):
+    lo, lr = libs
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        k = int(rng.integers(2, 257))
+        kind = trial % 4
+        if kind == 0:
+            cnt = rng.integers(1, 50, size=k)
+        elif kind == 1:
+            cnt = (rng.pareto(0.7, size=k) * 20 + 1).astype(np.int64)
+        elif kind == 2:
+            cnt = rng.integers(150, 700, size=k)          # straddles the 166 bucket cutoff + log2 buckets
+        else:
+            cnt = (2.0 ** rng.uniform(0, 16, size=k)).astype(np.int64)
+        cnt = np.minimum(cnt, 100000)
+        if rng.random() < 0.5:
+            cnt[rng.integers(0, k, size=k // 3)] = 0
+        cnt[k - 1] = max(cnt[k - 1], 1)
+        if (cnt > 0).sum() < 2:
+            cnt[0] = 3
+        count = np.zeros(256, dtype=np.uint32)
+        count[:k] = cnt
+        for maxbits in (11, 9, 8):
+            if (cnt > 0).sum() > (1 << maxbits):
+                continue
+            bo = np.zeros(256, dtype=np.uint8)
+            br = np.zeros(256, dtype=np.uint8)
+            to = lo.zo_huf_build(_buf(count), k - 1, maxbits, _buf(bo))
+            tr = lr.zref_huf_build(_buf(count), k - 1, maxbits, _buf(br))
+            assert tr != ERR
+            assert to == tr and np.array_equal(bo[:k], br[:k]), (trial, maxbits)
+
+
+def test_stage_fse_normalize_matches_reference(libs):
+    lo, lr = libs
+    rng = np.random.default_rng(6)
+    for trial in range(400):
+        maxsym = int(rng.integers(1, 53))
+        cnt = (rng.pareto(0.8, size=maxsym + 1) * 3).astype(np.int64)
+        cnt[maxsym] = max(cnt[maxsym], 1)
+        cnt[0] = max(cnt[0], 1)
+        total = int(cnt.sum())
+        if total < 2:
+            continue
+        count = np.zeros(64, dtype=np.uint32)
+        count[: maxsym + 1] = cnt
+        tl = lr.zref_fse_optimal_tablelog(9, total, maxsym)
+        for low in (0, 1):
+            no = np.zeros(64, dtype=np.int16)
+            nr = np.zeros(64, dtype=np.int16)
+            ro = lo.zo_fse_normalize(_buf(no), tl, _buf(count), total, maxsym, low)
+            rr = lr.zref_fse_normalize(_buf(nr), tl, _buf(count), total, maxsym, low)
+            if rr == ERR:
+                assert ro == -1
+                continue
+            assert ro == rr and np.array_equal(no[: maxsym + 1], nr[: maxsym + 1]), (trial, low)
