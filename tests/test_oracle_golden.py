@@ -25,4 +25,4 @@ def test_oracle_reproduces_golden_units():
                 assert r != ERR and r == g["csize"], (name, level)
                 assert hashlib.sha256(dst[:r].tobytes()).hexdigest() == g["dst_sha256"], (name, level)
                 seen += 1
-    assert seen == len(gold)
+    assert seen >= len(gold) > 400
