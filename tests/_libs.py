@@ -131,3 +131,55 @@ def corpus_cases(lib_o, sizes=(131072,), seeds=(0,)):
                 b = datagen(lib_o, n, 50, s + 7).copy()
                 b[n // 2:] = 65                                  # long literal-free tail run
                 yield f"halfrun_n{n}_s{s}", b
+
+
+# ----------------------------------------------------------------------------- host SIMT emulator of the product kernels
+UNIT_DT = np.dtype([("srcOff", "<u8"), ("srcLen", "<u4"), ("windowLog", "u1"), ("chainLog", "u1"), ("hashLog", "u1"),
+                    ("minMatch", "u1"), ("strategy", "u1"), ("searchLog", "u1"), ("litMode", "u1"), ("pad0", "u1"),
+                    ("targetLength", "<u4")])
+SEQ_DT = np.dtype([("offBase", "<u4"), ("litLength", "<u2"), ("mlBase", "<u2")])
+PARSE_DT = np.dtype([("nbSeq", "<u4"), ("lastLits", "<u4"), ("longPos", "<u4"), ("longType", "<u4"),
+                     ("rep", "<u4", (3,)), ("status", "<u4")])
+
+
+def load_emu():
+    d = os.path.join(ROOT, "tests", "simt")
+    so = os.path.join(d, "libzhip_emu.so")
+    srcs = [os.path.join(d, "emu_driver.cpp"), os.path.join(d, "simt_runtime.cpp"), os.path.join(d, "hip", "hip_runtime.h")]
+    srcs += [os.path.join(ROOT, "zstd_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "zstd_amd", "csrc"))
+             if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-I" + d,
+                               "-I" + os.path.join(ROOT, "zstd_amd", "csrc"), srcs[0], srcs[1], "-o", so, "-lpthread"])
+    lib = C.CDLL(so)
+    assert lib.emu_sizeof_unit() == UNIT_DT.itemsize and lib.emu_sizeof_parse() == PARSE_DT.itemsize
+    lib.emu_parse_fast.restype = None
+    lib.emu_parse_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
+    return lib
+
+
+def make_units(lo, sizes, level, unit=131072):
+    """unit table for buffers laid out back to back; sizes = list of unit lengths"""
+    units = np.zeros(len(sizes), dtype=UNIT_DT)
+    off = 0
+    for i, n in enumerate(sizes):
+        cp = (C.c_uint * 7)()
+        assert lo.zo_get_cparams(level, n, cp) == 0
+        units[i] = (off, n, cp[0], cp[1], cp[2], cp[4], cp[6], cp[3], 1 if (cp[6] == 1 and cp[5] > 0) else 0, 0, cp[5])
+        off += n
+    return units
+
+
+def oracle_parse(lo, a, level):
+    """-> (seqs[nb,3] = litLength, matchLength, offBase ; litSize, rep[3])"""
+    n = len(a)
+    cp = (C.c_uint * 7)()
+    assert lo.zo_get_cparams(level, n, cp) == 0
+    cap = n // 3 + 8
+    seqs = np.zeros((cap, 3), dtype=np.uint32)
+    lits = np.zeros(n + 64, dtype=np.uint8)
+    litSize = C.c_size_t(0)
+    rep = (C.c_uint * 3)()
+    nb = lo.zo_parse_block(cp, _buf(a), n, _buf(seqs), cap, _buf(lits), C.byref(litSize), rep)
+    assert nb != ERR
+    return seqs[:nb].copy(), litSize.value, list(rep)

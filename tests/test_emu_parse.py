@@ -1,0 +1,71 @@
+"""Product parse kernel (zstd_amd/csrc/zhip_parse.h) executed on the host SIMT emulator vs the oracle's sequences.
+CPU only: this checks the wave-parallel algorithm, not the GPU build."""
+import ctypes as C
+import numpy as np
+import pytest
+from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, _buf, SEQ_DT, PARSE_DT)
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return load_oracle(), load_emu()
+
+
+def emu_parse(le, lo, bufs, level):
+    sizes = [len(b) for b in bufs]
+    units = make_units(lo, sizes, level)
+    src = np.concatenate(bufs + [np.zeros(16, dtype=np.uint8)]) if bufs else np.zeros(16, dtype=np.uint8)
+    cap = le.emu_seq_cap()
+    seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT)
+    metas = np.zeros(len(bufs), dtype=PARSE_DT)
+    smem = 4 << int(units["hashLog"].max())
+    le.emu_parse_fast(_buf(src), _buf(units), len(bufs), _buf(seqs), _buf(metas), smem, 0)
+    out = []
+    for i in range(len(bufs)):
+        m = metas[i]
+        s = seqs[i * cap: i * cap + int(m["nbSeq"])]
+        ll = s["litLength"].astype(np.uint32)
+        ml = s["mlBase"].astype(np.uint32) + 3
+        if m["longType"] == 1:
+            ll[m["longPos"]] += 0x10000
+        if m["longType"] == 2:
+            ml[m["longPos"]] += 0x10000
+        out.append((np.stack([ll, ml, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32), m))
+    return out
+
+
+def check(le, lo, cases, level):
+    names = [c[0] for c in cases]
+    bufs = [c[1] for c in cases]
+    res = emu_parse(le, lo, bufs, level)
+    for name, a, (seqs, m) in zip(names, bufs, res):
+        oseqs, litSize, rep = oracle_parse(lo, a, level)
+        assert len(seqs) == len(oseqs), (name, len(seqs), len(oseqs))
+        if len(seqs):
+            bad = np.nonzero((seqs != oseqs).any(axis=1))[0]
+            assert len(bad) == 0, (name, int(bad[0]), seqs[bad[0]].tolist(), oseqs[bad[0]].tolist())
+        assert int(m["lastLits"]) == litSize - int(oseqs[:, 0].sum()), name
+        assert list(m["rep"][:2]) == rep[:2], name
+
+
+def test_fast_parse_small_sizes(libs):
+    lo, le = libs
+    cases = []
+    for n in (0, 1, 7, 8, 12, 13, 14, 20, 33, 64, 100, 129, 200, 257, 1000, 4097):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(0,)))
+    check(le, lo, cases, 1)
+
+
+def test_fast_parse_128k(libs):
+    lo, le = libs
+    check(le, lo, list(corpus_cases(lo, sizes=(131072,), seeds=(0,))), 1)
+
+
+def test_fast_parse_ragged_and_negative_levels(libs):
+    lo, le = libs
+    for level in (-1, -5, 2):
+        cases = []
+        for n in (5000, 16384, 40000, 100001):
+            cases += list(corpus_cases(lo, sizes=(n,), seeds=(3,)))
+        cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
+        check(le, lo, cases, level)

@@ -1,0 +1,40 @@
+// zhip_common.h — data layout shared by the gfx950 kernels and the host side of libzstd_hip.
+//
+// Domain vocabulary follows the reference (facebook/zstd): a *unit* is one independently compressed chunk of
+// source (<= 128 KB, the reference's ZSTD_BLOCKSIZE_MAX) that becomes one frame holding one block; a *sequence*
+// is (litLength, matchLength, offBase) exactly as lib/common/zstd_internal.h:281-311 (seqDef) stores it.
+#pragma once
+#include <stdint.h>
+
+#define ZHIP_UNIT_MAX        131072u          /* lib/zstd.h ZSTD_BLOCKSIZE_MAX */
+#define ZHIP_SEQ_CAP         (ZHIP_UNIT_MAX / 4 + 8)   /* fast/dfast matches are >= 4 bytes (zstd_compress.c:1690) */
+#define ZHIP_OUT_STRIDE      (ZHIP_UNIT_MAX + 512 + 32) /* >= ZSTD_compressBound(128 KB) + frame header */
+#define ZHIP_LIT_STRIDE      (ZHIP_UNIT_MAX + 64)
+
+enum { ZHIP_STRAT_FAST = 1, ZHIP_STRAT_DFAST = 2 };
+
+// one entry per unit, filled by the host, read by every kernel
+struct ZhipUnit {
+    uint64_t srcOff;        // byte offset of the unit in the source buffer
+    uint32_t srcLen;        // <= ZHIP_UNIT_MAX
+    uint8_t  windowLog, chainLog, hashLog, minMatch;
+    uint8_t  strategy, searchLog, litMode /* 1: literals stay raw (negative levels) */, pad0;
+    uint32_t targetLength;
+};
+
+// 8-byte sequence record (same packing as the reference's seqDef + its single long-length escape)
+struct ZhipSeq {
+    uint32_t offBase;       // 1..3 repcode id, else offset + 3
+    uint16_t litLength;     // low 16 bits (see ZhipParse.longPos)
+    uint16_t mlBase;        // matchLength - 3, low 16 bits
+};
+
+// written by the parse kernel, read by the entropy kernel
+struct ZhipParse {
+    uint32_t nbSeq;
+    uint32_t lastLits;      // literals after the last match
+    uint32_t longPos;       // index of the one sequence whose length overflowed 16 bits
+    uint32_t longType;      // 0 none, 1 literal length, 2 match length (zstd_internal.h:296-300)
+    uint32_t rep[3];        // repcode history after the unit
+    uint32_t status;        // 0 ok
+};
