@@ -1,0 +1,86 @@
+/* zstd_hip.h — C ABI of libzstd_hip.so: the MI355X (gfx950) Zstandard block-compression core.
+ *
+ * This is the drop-in boundary for the hot path only.  Everything is plain C: opaque handle,
+ * pointers and sizes; no C++/torch types.  Each entry point names the reference interface it stands in for
+ * (paths relative to facebook/zstd).
+ *
+ * Unit of work: a *unit* = one independently compressed chunk of <= 128 KB (ZSTD_BLOCKSIZE_MAX) that becomes one
+ * complete zstd frame holding one block — byte-identical to what the reference's
+ *      ZSTD_compress2(cctx(level), dst, cap, chunk, chunkSize)          lib/zstd.h:603
+ * emits for that chunk, i.e. to `zstd -b<level> -B<unitSize>` (programs/benchzstd.c:336-345).  Concatenated
+ * frames are a valid .zst stream (RFC 8878 §3.1; lib/decompress/zstd_decompress.c:1068 iterates frames).
+ *
+ * Error convention = zstd's: size_t results are either a size or (size_t)-ZSTD_ErrorCode
+ * (lib/common/error_private.h:55-60); test with zhip_isError().
+ */
+#ifndef ZSTD_HIP_H
+#define ZSTD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZHIP_UNIT_SIZE_MAX 131072          /* lib/zstd.h:141 ZSTD_BLOCKSIZE_MAX */
+#define ZHIP_SEQUENCE_PRODUCER_ERROR ((size_t)(-1))   /* lib/zstd.h:2836 ZSTD_SEQUENCE_PRODUCER_ERROR */
+
+typedef struct zhip_ctx_s zhip_ctx;
+
+/* same layout as ZSTD_Sequence, lib/zstd.h:1287-1322 */
+typedef struct { unsigned int offset, litLength, matchLength, rep; } zhip_Sequence;
+
+/* ---- lifetime (no reference counterpart: owns the HIP device state that ZSTD_CCtx owns on the CPU side,
+ *      lib/compress/zstd_compress.c:97 ZSTD_createCCtx) */
+int          zhip_device_count(void);
+zhip_ctx*    zhip_create(int device, size_t maxUnits);     /* scratch for up to maxUnits units per call */
+void         zhip_destroy(zhip_ctx* ctx);
+const char*  zhip_last_error(const zhip_ctx* ctx);
+
+/* ---- error helpers = ZSTD_isError / ZSTD_getErrorName / ZSTD_compressBound (lib/zstd.h:236-243) */
+unsigned     zhip_isError(size_t code);
+const char*  zhip_getErrorName(size_t code);
+size_t       zhip_compressBound(size_t srcSize, size_t unitSize);   /* sum of ZSTD_compressBound over the units */
+
+/* ---- parameters = ZSTD_getCParams (lib/zstd.h:1756; lib/compress/zstd_compress.c:7150) for the supported rows
+ * out[7] = windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy. returns 0, or -1 if the
+ * level/size maps to a strategy this library does not implement (greedy and above). */
+int          zhip_getCParams(int level, unsigned long long srcSize, unsigned out[7]);
+
+/* ---- frame-level drop-in for host buffers = ZSTD_compress2 per unit (lib/zstd.h:603), batch form.
+ * src is cut into units of unitSize (last one ragged); dst receives the frames back to back.
+ * unitSizes (optional, host, >= number of units) receives each frame's size. */
+size_t       zhip_compress(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                           int level, size_t unitSize, size_t* unitSizes);
+
+/* ---- same with device-resident buffers (HIP device pointers; hipStream_t passed as void*, NULL = ctx stream).
+ * dstDev receives the packed frames; the total size is returned after the stream has been synchronised.
+ * unitSizesDev (optional, device, uint32 per unit) receives frame sizes. */
+size_t       zhip_compress_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
+                                  int level, size_t unitSize, uint32_t* unitSizesDev, void* stream);
+
+/* ---- block-level plugin (B1) = ZSTD_sequenceProducer_F, lib/zstd.h:2838; contrib/externalSequenceProducer.
+ * zhip_sequence_producer has exactly that signature; pass the zhip_ctx as sequenceProducerState:
+ *      ZSTD_registerSequenceProducer(cctx, zhip_ctx, zhip_sequence_producer);        lib/zstd.h:2866
+ * One kernel launch per callback is latency-bound, so zhip_prepare_sequences() parses every block of a buffer in
+ * one launch beforehand; the callback then serves blocks of that buffer from the cache and launches only for
+ * blocks it has not seen.  Failures map to ZHIP_SEQUENCE_PRODUCER_ERROR so that
+ * ZSTD_c_enableSeqProducerFallback works (lib/compress/zstd_compress.c:3338-3356). */
+size_t       zhip_sequence_producer(void* sequenceProducerState, zhip_Sequence* outSeqs, size_t outSeqsCapacity,
+                                    const void* src, size_t srcSize, const void* dict, size_t dictSize,
+                                    int compressionLevel, size_t windowSize);
+size_t       zhip_prepare_sequences(zhip_ctx* ctx, const void* src, size_t srcSize, size_t blockSize, int level);
+
+/* Stage-1 only, device-resident: parse every unit, keep the result in ctx; fetch one unit's sequences in the
+ * ZSTD_generateSequences format (lib/zstd.h:1612; block delimiter {0,lastLits,0,0} appended). */
+size_t       zhip_parse_device(zhip_ctx* ctx, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream);
+size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* out, size_t capacity);
+
+/* ---- measurement: HIP-event durations (ms) of the kernels of the most recent call on this ctx
+ * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */
+void         zhip_last_timing(const zhip_ctx* ctx, double t[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+"""zstd_amd — MI355X (gfx950) Zstandard block-compression core.
+
+Python is plumbing only: this module binds the C ABI of zstd_amd/libzstd_hip.so (include/zstd_hip.h) with ctypes
+and uses torch solely for device buffers / streams.  There is NO CPU fallback: if the HIP library is missing or no
+GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzstd_hip.so")
+UNIT_SIZE_MAX = 131072
+_lib = None
+
+
+class ZhipError(RuntimeError):
+    pass
+
+
+def lib():
+    """load libzstd_hip.so (must have been built: python -m zstd_amd.build or __graft_entry__.build())"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZhipError(f"{LIB_PATH} is missing: build it with `python zstd_amd/build.py` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.zhip_device_count.restype = C.c_int
+        L.zhip_create.restype = C.c_void_p
+        L.zhip_create.argtypes = [C.c_int, C.c_size_t]
+        L.zhip_destroy.argtypes = [C.c_void_p]
+        L.zhip_last_error.restype = C.c_char_p
+        L.zhip_last_error.argtypes = [C.c_void_p]
+        L.zhip_isError.restype = C.c_uint
+        L.zhip_isError.argtypes = [C.c_size_t]
+        L.zhip_getErrorName.restype = C.c_char_p
+        L.zhip_getErrorName.argtypes = [C.c_size_t]
+        L.zhip_compressBound.restype = C.c_size_t
+        L.zhip_compressBound.argtypes = [C.c_size_t, C.c_size_t]
+        L.zhip_getCParams.restype = C.c_int
+        L.zhip_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p]
+        L.zhip_parse_device.restype = C.c_size_t
+        L.zhip_parse_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+        L.zhip_get_sequences.restype = C.c_size_t
+        L.zhip_get_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.zhip_last_timing.restype = None
+        L.zhip_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        for name, res, args in [
+            ("zhip_compress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]),
+            ("zhip_compress_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+            ("zhip_prepare_sequences", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+        ]:
+            if hasattr(L, name):
+                getattr(L, name).restype = res
+                getattr(L, name).argtypes = args
+        _lib = L
+    return _lib
+
+
+def get_cparams(level, src_size):
+    out = (C.c_uint * 7)()
+    if lib().zhip_getCParams(level, src_size, out) != 0:
+        raise ZhipError(f"level {level} / size {src_size}: strategy not implemented on device")
+    return list(out)
+
+
+def compress_bound(src_size, unit_size=UNIT_SIZE_MAX):
+    return lib().zhip_compressBound(src_size, unit_size)
+
+
+class Context:
+    """owns the device-side state for one GPU (the role ZSTD_CCtx plays for the CPU library)"""
+
+    def __init__(self, device=0, max_units=1024):
+        L = lib()
+        if L.zhip_device_count() <= 0:
+            raise ZhipError("no HIP device visible (zstd_amd has no CPU path)")
+        self._h = L.zhip_create(device, max_units)
+        if not self._h:
+            raise ZhipError(f"zhip_create(device={device}, max_units={max_units}) failed")
+        self.device = device
+        self.max_units = max_units
+
+    def close(self):
+        if self._h:
+            lib().zhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, r, what):
+        L = lib()
+        if L.zhip_isError(r):
+            raise ZhipError(f"{what}: {L.zhip_getErrorName(r).decode()} ({L.zhip_last_error(self._h).decode()})")
+        return r
+
+    def timing(self):
+        t = (C.c_double * 4)()
+        lib().zhip_last_timing(self._h, t)
+        return {"parse_ms": t[0], "entropy_ms": t[1], "gather_ms": t[2], "total_ms": t[3]}
+
+    # ---- stage 1 only (sequence-producer path)
+    def parse_device(self, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, stream=None):
+        return self._check(lib().zhip_parse_device(self._h, src_ptr, src_size, level, unit_size, stream), "zhip_parse_device")
+
+    def get_sequences(self, unit_index, cap=UNIT_SIZE_MAX // 3 + 8):
+        out = np.zeros((cap, 4), dtype=np.uint32)
+        n = self._check(lib().zhip_get_sequences(self._h, unit_index, out.ctypes.data_as(C.c_void_p), cap), "zhip_get_sequences")
+        return out[:n]
+
+    # ---- full pipeline
+    def compress_device(self, dst_ptr, dst_cap, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, sizes_ptr=None, stream=None):
+        return self._check(lib().zhip_compress_device(self._h, dst_ptr, dst_cap, src_ptr, src_size, level, unit_size,
+                                                      sizes_ptr, stream), "zhip_compress_device")
+
+    def compress(self, data, level=1, unit_size=UNIT_SIZE_MAX, return_sizes=False):
+        """host bytes -> concatenated frames (bytes)"""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = a.size
+        cap = compress_bound(n, unit_size)
+        dst = np.empty(cap, dtype=np.uint8)
+        nunits = max(1, -(-n // unit_size))
+        sizes = np.zeros(nunits, dtype=np.uint64)
+        r = self._check(lib().zhip_compress(self._h, dst.ctypes.data_as(C.c_void_p), cap,
+                                            a.ctypes.data_as(C.c_void_p) if n else None, n, level, unit_size,
+                                            sizes.ctypes.data_as(C.c_void_p)), "zhip_compress")
+        out = dst[:r].tobytes()
+        return (out, sizes) if return_sizes else out

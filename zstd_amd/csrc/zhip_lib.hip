@@ -1,0 +1,226 @@
+// zhip_lib.hip — host side of libzstd_hip.so (C ABI in include/zstd_hip.h) + kernel launches.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+#include <mutex>
+#include "../../include/zstd_hip.h"
+#include "zhip_common.h"
+#include "zhip_kernels.h"
+#include "zhip_host.h"
+
+// zstd's error numbering (lib/zstd_errors.h:60-101): results are (size_t)-code
+enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_memory_allocation = 64,
+       ZE_dstSize_tooSmall = 70, ZE_srcSize_wrong = 72, ZE_sequenceProducer_failed = 106 };
+#define ZERR(c) ((size_t)-(long)(c))
+
+struct zhip_ctx_s {
+    int device;
+    size_t maxUnits;
+    hipStream_t stream;
+    hipEvent_t ev[5];
+    // device scratch, one slot per unit
+    ZhipUnit*  dUnits;
+    ZhipSeq*   dSeqs;
+    ZhipParse* dParse;
+    uint8_t*   dLits;
+    uint8_t*   dOut;
+    uint32_t*  dOutSize;
+    uint64_t*  dOutOff;
+    // staging for the host-buffer API
+    uint8_t* dSrcStage; size_t srcStageCap;
+    uint8_t* dDstStage; size_t dstStageCap;
+    // pinned host mirrors
+    ZhipUnit* hUnits; uint32_t* hOutSize; ZhipParse* hParse;
+    // last call
+    size_t nUnits; double timing[4];
+    // sequence-producer cache
+    const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
+    std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
+    std::mutex mu;
+    char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return ZERR(ZE_GENERIC); } } while (0)
+
+extern "C" {
+
+int zhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+unsigned zhip_isError(size_t code) { return code > ZERR(120); }
+const char* zhip_getErrorName(size_t code)
+{
+    if (!zhip_isError(code)) return "No error detected";
+    switch ((int)(0 - code)) {
+    case ZE_GENERIC: return "Error (generic)";
+    case ZE_parameter_unsupported: return "Unsupported parameter";
+    case ZE_parameter_outOfBound: return "Parameter is out of bound";
+    case ZE_memory_allocation: return "Allocation error : not enough memory";
+    case ZE_dstSize_tooSmall: return "Destination buffer is too small";
+    case ZE_srcSize_wrong: return "Src size is incorrect";
+    case ZE_sequenceProducer_failed: return "Block-level external sequence producer returned an error code";
+    default: return "Unspecified error code";
+    }
+}
+
+size_t zhip_compressBound(size_t srcSize, size_t unitSize)
+{
+    if (unitSize == 0 || unitSize > ZHIP_UNIT_MAX) unitSize = ZHIP_UNIT_MAX;
+    size_t const full = srcSize / unitSize, tail = srcSize % unitSize;
+    size_t b = full * zhip::host_compress_bound(unitSize);
+    if (tail || srcSize == 0) b += zhip::host_compress_bound(tail);
+    return b;
+}
+
+int zhip_getCParams(int level, unsigned long long srcSize, unsigned out[7])
+{
+    zhip::CParams cp;
+    if (!zhip::host_get_cparams(level, srcSize, &cp)) return -1;
+    out[0] = cp.windowLog; out[1] = cp.chainLog; out[2] = cp.hashLog; out[3] = cp.searchLog;
+    out[4] = cp.minMatch; out[5] = cp.targetLength; out[6] = cp.strategy;
+    return 0;
+}
+
+const char* zhip_last_error(const zhip_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+void zhip_destroy(zhip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits);
+    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff);
+    (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
+    (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
+    for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+zhip_ctx* zhip_create(int device, size_t maxUnits)
+{
+    if (maxUnits == 0) maxUnits = 1;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zhip_ctx* c = new zhip_ctx_s();
+    c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
+    c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
+    c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
+    memset(c->timing, 0, sizeof(c->timing));
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dUnits, maxUnits * sizeof(ZhipUnit)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dSeqs, maxUnits * (size_t)ZHIP_SEQ_CAP * sizeof(ZhipSeq)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dParse, maxUnits * sizeof(ZhipParse)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dLits, maxUnits * (size_t)ZHIP_LIT_STRIDE) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dOut, maxUnits * (size_t)ZHIP_OUT_STRIDE) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dOutSize, (maxUnits + 1) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dOutOff, (maxUnits + 1) * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->hUnits, maxUnits * sizeof(ZhipUnit), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->hOutSize, (maxUnits + 1) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->hParse, maxUnits * sizeof(ZhipParse), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { zhip_destroy(c); return nullptr; }
+    return c;
+}
+
+void zhip_last_timing(const zhip_ctx* c, double t[4]) { for (int i = 0; i < 4; i++) t[i] = c->timing[i]; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ internals
+// fill ctx->hUnits for `srcSize` bytes cut into unitSize chunks; returns number of units or 0 with *err set
+static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int level, size_t* err, uint32_t* maxHashLog)
+{
+    if (unitSize == 0 || unitSize > ZHIP_UNIT_MAX) { *err = ZERR(ZE_parameter_outOfBound); return 0; }
+    size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
+    if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
+    zhip::CParams full, tail; bool haveFull = false;
+    uint32_t mh = 0;
+    for (size_t i = 0; i < nUnits; i++) {
+        size_t const off = i * unitSize;
+        size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
+        zhip::CParams* cp = &tail;
+        if (len == unitSize) { if (!haveFull) { if (!zhip::host_get_cparams(level, len, &full)) { *err = ZERR(ZE_parameter_unsupported); return 0; } haveFull = true; } cp = &full; }
+        else if (!zhip::host_get_cparams(level, len, &tail)) { *err = ZERR(ZE_parameter_unsupported); return 0; }
+        ZhipUnit& u = c->hUnits[i];
+        u.srcOff = off; u.srcLen = (uint32_t)len;
+        u.windowLog = (uint8_t)cp->windowLog; u.chainLog = (uint8_t)cp->chainLog; u.hashLog = (uint8_t)cp->hashLog;
+        u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
+        u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0; u.pad0 = 0;
+        u.targetLength = cp->targetLength;
+        if (cp->strategy != ZHIP_STRAT_FAST) { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device yet", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
+        if (cp->hashLog > mh) mh = cp->hashLog;
+    }
+    if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
+    *maxHashLog = mh;
+    return nUnits;
+}
+
+static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
+{
+    size_t const smem = (size_t)4 << maxHashLog;
+    HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+    if (smem > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
+                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dParse);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    return 0;
+}
+
+extern "C" {
+
+size_t zhip_parse_device(zhip_ctx* c, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    size_t err = 0; uint32_t mh = 0;
+    size_t const nUnits = build_units(c, srcSize, unitSize, level, &err, &mh);
+    if (!nUnits) return err;
+    size_t const r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
+    if (zhip_isError(r)) return r;
+    HIPCHK(c, hipMemcpyAsync(c->hParse, c->dParse, nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->timing[0] = ms; c->timing[1] = c->timing[2] = 0; c->timing[3] = ms;
+    c->nUnits = nUnits;
+    return nUnits;
+}
+
+// device seqDef records -> ZSTD_Sequence[] (lib/compress/zstd_compress.c:3371-3454)
+static size_t seqs_to_public(const ZhipSeq* s, const ZhipParse& m, zhip_Sequence* out, size_t cap)
+{
+    if ((size_t)m.nbSeq + 1 > cap) return ZERR(ZE_dstSize_tooSmall);
+    uint32_t rep[3] = {1, 4, 8};
+    for (uint32_t i = 0; i < m.nbSeq; i++) {
+        uint32_t ll = s[i].litLength, ml = (uint32_t)s[i].mlBase + 3, ob = s[i].offBase, raw, rf = 0;
+        if (m.longType == 1 && i == m.longPos) ll += 0x10000;
+        if (m.longType == 2 && i == m.longPos) ml += 0x10000;
+        if (ob <= 3) { rf = ob; raw = ll ? rep[ob - 1] : (ob == 3 ? rep[0] - 1 : rep[ob]); }
+        else raw = ob - 3;
+        out[i].offset = raw; out[i].litLength = ll; out[i].matchLength = ml; out[i].rep = rf;
+        if (ob > 3) { rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = ob - 3; }
+        else { uint32_t const rc = ob - 1 + (ll == 0);
+               if (rc) { uint32_t const cur = rc == 3 ? rep[0] - 1 : rep[rc]; rep[2] = rc >= 2 ? rep[1] : rep[2]; rep[1] = rep[0]; rep[0] = cur; } }
+    }
+    out[m.nbSeq].offset = 0; out[m.nbSeq].litLength = m.lastLits; out[m.nbSeq].matchLength = 0; out[m.nbSeq].rep = 0;
+    return (size_t)m.nbSeq + 1;
+}
+
+size_t zhip_get_sequences(zhip_ctx* c, size_t unitIndex, zhip_Sequence* out, size_t capacity)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (unitIndex >= c->nUnits) return ZERR(ZE_parameter_outOfBound);
+    HIPCHK(c, hipSetDevice(c->device));
+    ZhipParse const m = c->hParse[unitIndex];
+    std::vector<ZhipSeq> tmp(m.nbSeq ? m.nbSeq : 1);
+    if (m.nbSeq) HIPCHK(c, hipMemcpy(tmp.data(), c->dSeqs + unitIndex * (size_t)ZHIP_SEQ_CAP, m.nbSeq * sizeof(ZhipSeq), hipMemcpyDeviceToHost));
+    return seqs_to_public(tmp.data(), m, out, capacity);
+}
+
+}  // extern "C"
