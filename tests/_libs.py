@@ -183,3 +183,25 @@ def oracle_parse(lo, a, level):
     nb = lo.zo_parse_block(cp, _buf(a), n, _buf(seqs), cap, _buf(lits), C.byref(litSize), rep)
     assert nb != ERR
     return seqs[:nb].copy(), litSize.value, list(rep)
+
+
+def emu_compress_units(le, lo, bufs, level):
+    """run stage 1 + stage 2 of the product kernels on the emulator; returns list of frame bytes"""
+    le.emu_entropy.restype = None
+    le.emu_entropy.argtypes = [C.c_void_p] * 2 + [C.c_uint] + [C.c_void_p] * 6 + [C.c_int]
+    sizes = [len(b) for b in bufs]
+    units = make_units(lo, sizes, level)
+    src = np.concatenate(list(bufs) + [np.zeros(16, dtype=np.uint8)])
+    cap = le.emu_seq_cap()
+    nu = len(bufs)
+    seqs = np.zeros(nu * cap, dtype=SEQ_DT)
+    metas = np.zeros(nu, dtype=PARSE_DT)
+    smem = 4 << int(units["hashLog"].max())
+    le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), smem, 0)
+    ostride, lstride = le.emu_out_stride(), le.emu_lit_stride()
+    lits = np.full(nu * lstride, 0xEE, dtype=np.uint8)
+    stb = np.full(nu * 3 * cap, 0xEEEE, dtype=np.uint16)
+    out = np.full(nu * ostride, 0xEE, dtype=np.uint8)
+    osz = np.zeros(nu, dtype=np.uint32)
+    le.emu_entropy(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), _buf(lits), _buf(stb), _buf(out), _buf(osz), 0)
+    return [out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nu)]

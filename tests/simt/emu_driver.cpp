@@ -14,6 +14,17 @@ void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
                  [=] { zhip::k_parse_fast(src, units, nUnits, seqs, metas); }, osThreads);
 }
 
+// stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
+void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
+                 uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)
+{
+    simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
+                 [=] { zhip::k_entropy(src, units, nUnits, seqs, metas, lits, stBits, out, outSize); }, osThreads);
+}
+uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
+uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }
+uint32_t emu_ent_shared(void) { return (uint32_t)sizeof(zhip::EntShared); }
+
 uint32_t emu_seq_cap(void) { return ZHIP_SEQ_CAP; }
 uint32_t emu_sizeof_unit(void) { return sizeof(ZhipUnit); }
 uint32_t emu_sizeof_parse(void) { return sizeof(ZhipParse); }

@@ -162,3 +162,6 @@ template <typename T> static inline T atomicExch(T* p, T v) { return __atomic_ex
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; while (o < v && !__atomic_compare_exchange_n(p, &o, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; while (o > v && !__atomic_compare_exchange_n(p, &o, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 template <typename T> static inline T atomicCAS(T* p, T c, T v) { __atomic_compare_exchange_n(p, &c, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return c; }
+
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };

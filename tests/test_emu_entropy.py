@@ -1,0 +1,51 @@
+"""Product stage 1 + stage 2 kernels on the host SIMT emulator: complete frames vs the oracle, byte for byte."""
+import numpy as np
+import pytest
+from _libs import load_oracle, load_emu, corpus_cases, emu_compress_units, _buf, ERR
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return load_oracle(), load_emu()
+
+
+def oracle_unit(lo, a, level):
+    cap = lo.zo_compress_bound(len(a)) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = lo.zo_compress_unit(_buf(dst), cap, _buf(a), len(a), level)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+def check(lo, le, cases, level):
+    frames = emu_compress_units(le, lo, [c[1] for c in cases], level)
+    for (name, a), f in zip(cases, frames):
+        o = oracle_unit(lo, a, level)
+        if f != o:
+            k = next((i for i in range(min(len(f), len(o))) if f[i] != o[i]), min(len(f), len(o)))
+            raise AssertionError(f"{name} L{level}: got {len(f)} B, want {len(o)} B, first diff at {k}: "
+                                 f"{f[max(0,k-4):k+8].hex()} vs {o[max(0,k-4):k+8].hex()}")
+
+
+def test_frames_128k(libs):
+    lo, le = libs
+    check(lo, le, list(corpus_cases(lo, sizes=(131072,), seeds=(0,))), 1)
+
+
+def test_frames_small_and_ragged(libs):
+    lo, le = libs
+    cases = []
+    for n in (0, 1, 6, 7, 8, 13, 40, 63, 64, 65, 100, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 4096, 16383, 16384, 16385, 70000):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(1,)))
+    check(lo, le, cases, 1)
+
+
+def test_frames_negative_level_and_level2(libs):
+    lo, le = libs
+    for level in (-1, 2):
+        cases = []
+        for n in (5000, 50000, 131072):
+            cases += list(corpus_cases(lo, sizes=(n,), seeds=(2,)))
+        from _libs import make_units
+        cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
+        check(lo, le, cases, level)

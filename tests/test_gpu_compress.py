@@ -1,0 +1,135 @@
+"""-m gpu: full-pipeline parity on a real MI355X through the C ABI: frames are byte-identical to the oracle
+(oracle/zoracle.c, pinned to the reference), match the committed golden vectors made with the real reference, and
+decode bit-exactly with independent decoders (reference build in oracle/_ref when present, system libzstd)."""
+import ctypes as C
+import ctypes.util
+import hashlib, json, os
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, _buf, ERR
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import zstd_amd
+    assert torch.cuda.is_available(), "needs a GPU"
+    return load_oracle(), zstd_amd.Context(0, max_units=640), torch
+
+
+def oracle_chunks(lo, a, level, unit=131072):
+    n = len(a)
+    cap = lo.zo_compress_bound(unit) * (n // unit + 1) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    nu = max(1, -(-n // unit))
+    sizes = np.zeros(nu, dtype=np.uint64)
+    r = lo.zo_compress_chunks(level, unit, _buf(a), n, _buf(dst), cap, _buf(sizes), nu)
+    assert r != ERR
+    return dst[:r].tobytes(), sizes
+
+
+def system_decompress(blob, n):
+    path = ctypes.util.find_library("zstd") or "libzstd.so.1"
+    try:
+        L = C.CDLL(path)
+    except OSError:
+        return None
+    L.ZSTD_decompress.restype = C.c_size_t
+    L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    src = np.frombuffer(blob, dtype=np.uint8)
+    r = L.ZSTD_decompress(_buf(out), n, _buf(src), len(blob))
+    assert r == n, f"system libzstd decode failed: {r}"
+    return out[:n]
+
+
+def first_diff(a, b):
+    k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+    return f"len {len(a)} vs {len(b)}, first diff at {k}: {a[max(0,k-4):k+8].hex()} vs {b[max(0,k-4):k+8].hex()}"
+
+
+def test_units_128k_match_oracle_bytes(env):
+    lo, ctx, torch = env
+    cases = list(corpus_cases(lo, sizes=(131072,), seeds=(0, 1)))
+    flat = np.concatenate([c[1] for c in cases])
+    got, sizes = ctx.compress(flat, level=1, return_sizes=True)
+    want, wsizes = oracle_chunks(lo, flat, 1)
+    assert np.array_equal(sizes, wsizes), [(c[0], int(a), int(b)) for c, a, b in zip(cases, sizes, wsizes) if a != b]
+    assert got == want, first_diff(got, want)
+    dec = system_decompress(got, len(flat))
+    if dec is not None:
+        assert dec.tobytes() == flat.tobytes()
+
+
+@pytest.mark.parametrize("level", [1, 2, -1, -7])
+def test_ragged_units_match_oracle_bytes(env, level):
+    lo, ctx, torch = env
+    import zstd_amd
+    for n in (0, 1, 6, 7, 8, 13, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 4096, 16383, 16384, 16385, 70000, 131071):
+        try:
+            cp = zstd_amd.get_cparams(level, n)
+        except zstd_amd.ZhipError:
+            continue
+        if cp[6] != 1:
+            continue
+        for name, a in corpus_cases(lo, sizes=(n,), seeds=(3,)):
+            got = ctx.compress(a, level=level)
+            want, _ = oracle_chunks(lo, a, level)
+            assert got == want, (name, level, first_diff(got, want))
+
+
+def test_golden_vectors_from_the_real_reference(env):
+    lo, ctx, torch = env
+    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["units"] if g["level"] == 1}
+    sizes = sorted({g["n"] for g in gold.values()})
+    seen = 0
+    for n in sizes:
+        for name, a in corpus_cases(lo, sizes=(n,), seeds=(0, 5)):
+            g = gold.get((name, 1))
+            if g is None:
+                continue
+            assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"]
+            got = ctx.compress(a, level=1)
+            assert len(got) == g["csize"] and hashlib.sha256(got).hexdigest() == g["dst_sha256"], name
+            seen += 1
+    assert seen >= 200
+
+
+def test_multi_unit_stream_device_api_and_roundtrip(env):
+    lo, ctx, torch = env
+    import zstd_amd
+    n = 131072 * 300 + 4321
+    a = datagen(lo, n, 50, 21)
+    d = torch.from_numpy(np.concatenate([a, np.zeros(64, np.uint8)])).cuda()
+    cap = zstd_amd.compress_bound(n)
+    dst = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    usz = torch.zeros(301, dtype=torch.int32, device="cuda")
+    r = ctx.compress_device(dst.data_ptr(), cap, d.data_ptr(), n, 1, 131072, usz.data_ptr())
+    got = dst[:r].cpu().numpy().tobytes()
+    want, wsizes = oracle_chunks(lo, a, 1)
+    assert np.array_equal(usz.cpu().numpy().astype(np.uint64), wsizes)
+    assert got == want, first_diff(got, want)
+    if have_ref():
+        lr = load_ref()
+        out = np.zeros(n, dtype=np.uint8)
+        src = np.frombuffer(got, dtype=np.uint8)
+        assert lr.zref_decompress(_buf(out), n, _buf(src), len(got)) == n
+        assert out.tobytes() == a.tobytes()
+    dec = system_decompress(got, n)
+    if dec is not None:
+        assert dec.tobytes() == a.tobytes()
+
+
+def test_dst_too_small_and_unsupported_level_are_errors(env):
+    lo, ctx, torch = env
+    import zstd_amd
+    a = datagen(lo, 100000, 50, 1)
+    L = zstd_amd.lib()
+    dst = np.zeros(10, dtype=np.uint8)
+    r = L.zhip_compress(ctx._h, _buf(dst), 10, _buf(a), len(a), 1, 131072, None)
+    assert L.zhip_isError(r) and b"too small" in L.zhip_getErrorName(r)
+    with pytest.raises(zstd_amd.ZhipError):
+        ctx.compress(a, level=19)

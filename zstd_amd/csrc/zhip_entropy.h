@@ -1,0 +1,510 @@
+// zhip_entropy.h — gfx950 entropy stage + frame assembly: one 256-thread workgroup per unit.
+//
+// WHAT: from the match finder's sequences it produces the complete frame the reference's ZSTD_compress2 emits for
+// that unit: frame header (lib/compress/zstd_compress.c:4626-4672), block header (:4586-4590), literals section
+// (zstd_compress_literals.c:129-235 -> huf_compress.c), sequences section (zstd_compress.c:2934-2997 ->
+// zstd_compress_sequences.c, fse_compress.c), with every fallback (raw / RLE literals, predefined / RLE / FSE
+// tables, raw block) decided exactly as the reference decides it.
+//
+// HOW (CDNA4): the data-parallel parts run on all 4 wavefronts — literal gather + byte histogram with LDS atomics,
+// Huffman bit packing (one wavefront per huff0 stream: per-lane runs, wave prefix-scan of bit lengths, direct packing
+// into the output with atomicOr only on run-boundary words), sequence code histograms, sequence bit packing
+// (block prefix-scan of per-sequence bit counts).  The inherently ordered parts (code-length assignment, FSE
+// normalisation/table build, the three FSE state chains) run on single lanes of different wavefronts concurrently.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zhip_common.h"
+#include "zhip_tables.h"
+
+namespace zhip {
+
+#define ZHIP_ENT_THREADS 256
+
+// ------------------------------------------------------------------ constant tables (zstd_internal.h:123-168)
+__device__ static const uint8_t kLLbits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+__device__ static const uint8_t kMLbits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                                1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+__device__ static const int16_t kLLnorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+__device__ static const int16_t kMLnorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                                1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+__device__ static const int16_t kOFnorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+__device__ static const uint8_t kLLcode[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+    22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
+__device__ static const uint8_t kMLcode[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+    32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+    40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+    42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
+
+__device__ __forceinline__ uint32_t ll_code(uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : kLLcode[ll]; }          // internal.h:520
+__device__ __forceinline__ uint32_t ml_code(uint32_t mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : kMLcode[mlBase]; }   // :537
+
+// ------------------------------------------------------------------ LDS layout of the workgroup
+struct EntShared {
+    uint32_t hist[4][256];        // per-wavefront literal histograms, reduced into hist[0]
+    uint32_t code[256];           // huff0 code: value << 8 | nbBits
+    uint32_t scan[ZHIP_ENT_THREADS + 8];
+    uint32_t scan2[ZHIP_ENT_THREADS + 8];
+    uint32_t seqCount[3][64];     // LL / OF / ML code histograms
+    int16_t  norm[3][56];
+    FseCTable ct[3];              // LL, OF, ML
+    uint8_t  symScratch[3][512];
+    uint16_t cumul[3][64];
+    uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
+    uint32_t ncountSize[3];
+    uint32_t encType[3];          // set_basic 0 / set_rle 1 / set_compressed 2 (zstd_internal.h:102)
+    uint32_t maxCode[3];
+    uint32_t finalState[3];
+    uint8_t  hufHdr[136];
+    HufWork  huf;
+    // scalars broadcast through LDS
+    uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream;
+    uint32_t streamBits[4], streamBytes[4], streamOff[4];
+    uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
+    uint32_t sampleHist[2][256];
+};
+
+// ------------------------------------------------------------------ small block-wide helpers
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    int const lane = (int)(threadIdx.x & 63);
+    for (int d = 1; d < 64; d <<= 1) { uint32_t const o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
+    return v;
+}
+// exclusive prefix sum over the 256 threads (thread order); *total gets the grand total. uses sh->scan
+__device__ inline uint32_t block_excl_scan(EntShared* sh, uint32_t v, uint32_t* total)
+{
+    int const t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t const inc = wave_incl_scan(v);
+    if (lane == 63) sh->scan[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; i++) base += sh->scan[i];
+    *total = sh->scan[0] + sh->scan[1] + sh->scan[2] + sh->scan[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// zero exactly [p, p+nbytes) with all threads of the workgroup (neighbouring bytes belong to finished sections)
+__device__ inline void zero_bytes(uint8_t* p, uint32_t nbytes)
+{
+    uint32_t const t = threadIdx.x;
+    uint32_t head = (4u - (uint32_t)((uintptr_t)p & 3)) & 3u; if (head > nbytes) head = nbytes;
+    if (t < head) p[t] = 0;
+    uint32_t* const w = (uint32_t*)(p + head);
+    uint32_t const words = (nbytes - head) >> 2;
+    for (uint32_t i = t; i < words; i += ZHIP_ENT_THREADS) w[i] = 0;
+    uint32_t const tail = nbytes - head - 4 * words;
+    if (t < tail) p[head + 4 * words + t] = 0;
+}
+
+// OR `nbits` (<= 64 - (bitpos & 31)) bits of `v` into the LSB-first bit string that starts at word pointer `w32`
+// (bit 0 of the string = bit 0 of w32[0]).  Output words were zeroed beforehand; neighbouring lanes share boundary
+// words, hence atomics.  Used for run-boundary words only; interior words are written by plain stores.
+__device__ __forceinline__ void or_bits(uint32_t* w32, uint64_t bitpos, uint64_t v, uint32_t nbits)
+{
+    if (!nbits) return;
+    uint32_t* p = w32 + (bitpos >> 5);
+    uint32_t const sh = (uint32_t)(bitpos & 31);
+    atomicOr(p, (uint32_t)(v << sh));
+    if (sh + nbits > 32) {
+        uint64_t const rest = v >> (32 - sh);
+        atomicOr(p + 1, (uint32_t)rest);
+        if (sh + nbits > 64) atomicOr(p + 2, (uint32_t)(rest >> 32));
+    }
+}
+
+// A per-lane LSB-first packer that owns the bit range [start, start+len) of a shared bit string in global memory.
+// First and last (partial) words go through atomicOr, full interior words through plain stores.
+struct RunPacker {
+    uint32_t* w32; uint64_t pos; uint64_t acc; uint32_t nb; bool first;
+    __device__ __forceinline__ void init(uint32_t* base, uint64_t startBit) { w32 = base; pos = startBit; acc = 0; nb = 0; first = true; }
+    __device__ __forceinline__ void flushWords()
+    {
+        // emit while a full 32-bit word boundary can be crossed
+        while (true) {
+            uint32_t const sh = (uint32_t)(pos & 31);
+            uint32_t const room = 32 - sh;
+            if (nb < room) break;
+            uint32_t const chunk = (uint32_t)(acc & (room == 32 ? 0xFFFFFFFFu : ((1u << room) - 1)));
+            uint32_t* p = w32 + (pos >> 5);
+            if (first || sh) atomicOr(p, chunk << sh); else *p = chunk;
+            first = false;
+            acc >>= room; nb -= room; pos += room;
+        }
+    }
+    __device__ __forceinline__ void add(uint32_t v, uint32_t n) { acc |= (uint64_t)v << nb; nb += n; if (nb >= 32) flushWords(); }
+    __device__ __forceinline__ void finish() { flushWords(); if (nb) { atomicOr(w32 + (pos >> 5), (uint32_t)acc << (uint32_t)(pos & 31)); pos += nb; nb = 0; acc = 0; } }
+};
+
+// ------------------------------------------------------------------ sequence field access
+__device__ __forceinline__ void seq_fields(const ZhipSeq* seqs, const ZhipParse& m, uint32_t i, uint32_t& ll, uint32_t& mlBase, uint32_t& offBase)
+{
+    ZhipSeq const s = seqs[i];
+    ll = s.litLength; mlBase = s.mlBase; offBase = s.offBase;
+    if (i == m.longPos) { if (m.longType == 1) ll += 0x10000; else if (m.longType == 2) mlBase += 0x10000; }
+}
+
+// ------------------------------------------------------------------ frame / block headers
+__device__ inline uint32_t frame_header_size(uint32_t n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
+// zstd_compress.c:4626-4672 for a single-segment frame with content size, no checksum, no dictID (library defaults)
+__device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n)
+{
+    uint32_t const fcs = (n >= 256) + (n >= 65536 + 256);
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
+    op[4] = (uint8_t)((1u << 5) + (fcs << 6));
+    if (fcs == 0) { op[5] = (uint8_t)n; return 6; }
+    if (fcs == 1) { uint32_t const v = n - 256; op[5] = (uint8_t)v; op[6] = (uint8_t)(v >> 8); return 7; }
+    op[5] = (uint8_t)n; op[6] = (uint8_t)(n >> 8); op[7] = (uint8_t)(n >> 16); op[8] = (uint8_t)(n >> 24); return 9;
+}
+
+// ================================================================== the unit encoder
+__device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
+                                    const ZhipParse& pm, uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
+                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh)
+{
+    int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t const n = u.srcLen;
+    uint32_t const nbSeq = (n < 7) ? 0 : pm.nbSeq;
+    uint32_t const fh = frame_header_size(n);
+    uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
+    uint32_t const minGainBlock = (n >> 6) + 2;             // zstd_compress_internal.h:613
+
+    // ---------------- trivial units: empty frame, or too small to attempt compression (zstd_compress.c:3216, :5270)
+    if (n < 7) {
+        if (t == 0) {
+            write_frame_header(out, n);
+            uint32_t const bh = 1u + (0u << 1) + (n << 3);
+            out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
+            for (uint32_t i = 0; i < n; i++) out[fh + 3 + i] = src[i];
+            *outSize = fh + 3 + n;
+        }
+        return;
+    }
+
+    // ---------------- P1: literal gather + histogram.  Thread t owns a contiguous slice of sequences; the pseudo
+    // sequence index nbSeq carries the trailing literals.
+    for (int i = t; i < 4 * 256; i += ZHIP_ENT_THREADS) (&sh->hist[0][0])[i] = 0;
+    uint32_t const nItems = nbSeq + 1;
+    uint32_t const per = (nItems + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
+    uint32_t const s0 = (uint32_t)t * per, s1 = (s0 + per < nItems) ? s0 + per : nItems;
+    uint32_t sumLL = 0, sumAll = 0;
+    for (uint32_t i = s0; i < s1; i++) {
+        uint32_t ll, mlb, ob;
+        if (i < nbSeq) { seq_fields(seqs, pm, i, ll, mlb, ob); sumLL += ll; sumAll += ll + mlb + 3; }
+        else { sumLL += pm.lastLits; sumAll += pm.lastLits; }
+    }
+    uint32_t litSize, totAll;
+    uint32_t litOff = block_excl_scan(sh, sumLL, &litSize);
+    uint32_t srcPos = block_excl_scan(sh, sumAll, &totAll);
+    {   // each lane walks its slice; short literal runs are copied by the lane, long ones by the whole wavefront
+        uint32_t* const myHist = sh->hist[wv];
+        for (uint32_t k = 0; k < per; k++) {
+            uint32_t const i = s0 + k;
+            uint32_t ll = 0, adv = 0;
+            if (i < s1) {
+                uint32_t mlb, ob;
+                if (i < nbSeq) { seq_fields(seqs, pm, i, ll, mlb, ob); adv = ll + mlb + 3; }
+                else { ll = pm.lastLits; adv = ll; }
+            }
+            bool const isLong = ll > 32;
+            if (!isLong) for (uint32_t j = 0; j < ll; j++) { uint8_t const b = src[srcPos + j]; lits[litOff + j] = b; atomicAdd(&myHist[b], 1u); }
+            unsigned long long longMask = __ballot(isLong);
+            while (longMask) {
+                int const L = __ffsll((long long)longMask) - 1; longMask &= longMask - 1;
+                uint32_t const sp = __shfl(srcPos, L), lo = __shfl(litOff, L), len = __shfl(ll, L);
+                for (uint32_t j = (uint32_t)lane; j < len; j += 64) { uint8_t const b = src[sp + j]; lits[lo + j] = b; atomicAdd(&myHist[b], 1u); }
+            }
+            srcPos += adv; litOff += ll;
+        }
+    }
+    __syncthreads();
+    if (t < 256) sh->hist[0][t] += sh->hist[1][t] + sh->hist[2][t] + sh->hist[3][t];
+    __syncthreads();
+
+    // ---------------- P2: literals section (zstd_compress_literals.c:129-235 with no previous table)
+    uint8_t* const litDst = body;
+    uint32_t const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
+    bool const single = litSize < 256;
+    bool tryHuf = !(u.litMode) && litSize >= 64;            // minLiteralsToCompress = 8 << min(9-strategy,3) for fast/dfast
+    if (tryHuf) {
+        // suspect-uncompressible sampling (huf_compress.c:1367-1379); flag from zstd_compress.c:2918
+        bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
+        if (suspect && litSize >= 40960) {
+            for (int i = t; i < 512; i += ZHIP_ENT_THREADS) (&sh->sampleHist[0][0])[i] = 0;
+            __syncthreads();
+            for (uint32_t i = (uint32_t)t; i < 4096; i += ZHIP_ENT_THREADS) {
+                atomicAdd(&sh->sampleHist[0][lits[i]], 1u);
+                atomicAdd(&sh->sampleHist[1][lits[litSize - 4096 + i]], 1u);
+            }
+            __syncthreads();
+            if (t == 0) {
+                uint32_t a = 0, b = 0;
+                for (int s = 0; s < 256; s++) { if (sh->sampleHist[0][s] > a) a = sh->sampleHist[0][s]; if (sh->sampleHist[1][s] > b) b = sh->sampleHist[1][s]; }
+                sh->failRaw = (a + b <= ((2 * 4096) >> 7) + 4);
+            }
+            __syncthreads();
+            if (sh->failRaw) tryHuf = false;
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        uint32_t mode = 0;      // raw
+        sh->hufHdrSize = 0;
+        if (tryHuf) {
+            uint32_t maxSym = 255, largest = 0;
+            while (!sh->hist[0][maxSym]) maxSym--;
+            for (uint32_t s = 0; s <= maxSym; s++) if (sh->hist[0][s] > largest) largest = sh->hist[0][s];
+            if (largest == litSize) mode = 1;                                        // huf_compress.c:1383 -> RLE literals
+            else if (largest <= (litSize >> 7) + 4) mode = 0;                        // :1384
+            else {
+                uint32_t huffLog = fse_optimal_table_log(11, litSize, maxSym, 1);    // :1284-1287
+                huffLog = huf_build_codes(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
+                uint32_t const h = huf_write_table(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
+                if (h != 0 && h + 12 < litSize) { mode = 2; sh->hufHdrSize = h; sh->huffLog = huffLog; }   // :1425
+            }
+        }
+        sh->litMode = mode;
+    }
+    __syncthreads();
+    uint32_t litMode = sh->litMode;
+    if (litMode == 2) {
+        // stream geometry (huf_compress.c:1168-1215): 4 segments of (litSize+3)/4, or one stream
+        uint32_t const nStreams = single ? 1 : 4;
+        uint32_t const seg = single ? litSize : (litSize + 3) / 4;
+        // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols.
+        uint32_t myBits = 0, segStart = 0, segLen = 0, runStart = 0, runLen = 0;
+        if ((uint32_t)wv < nStreams) {
+            segStart = (uint32_t)wv * seg;
+            segLen = single ? litSize : ((wv < 3) ? seg : litSize - 3 * seg);
+            uint32_t const rper = (segLen + 63) / 64;
+            runStart = (uint32_t)lane * rper; if (runStart > segLen) runStart = segLen;
+            runLen = (runStart + rper <= segLen) ? rper : segLen - runStart;
+            const uint8_t* p = lits + segStart + runStart;
+            for (uint32_t i = 0; i < runLen; i++) myBits += sh->code[p[i]] & 0xFF;
+        }
+        uint32_t const incl = wave_incl_scan(myBits);
+        uint32_t const total = __shfl(incl, 63);
+        if (lane == 0 && (uint32_t)wv < nStreams) { sh->streamBits[wv] = total; sh->streamBytes[wv] = (total >> 3) + 1; }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t off = lhSize + sh->hufHdrSize + (single ? 0 : 6), tot = sh->hufHdrSize + (single ? 0 : 6);
+            bool ok = true;
+            for (uint32_t k = 0; k < nStreams; k++) { sh->streamOff[k] = off; off += sh->streamBytes[k]; tot += sh->streamBytes[k]; if (sh->streamBytes[k] > 65535) ok = false; }
+            // huf_compress.c:1237 (>= srcSize-1 -> 0) then zstd_compress_literals.c:187-191 (minGain)
+            if (!ok || tot >= litSize - 1 || tot >= litSize - ((litSize >> 6) + 2)) sh->litMode = 0;
+            sh->litSectionSize = lhSize + tot;
+        }
+        __syncthreads();
+        litMode = sh->litMode;
+        if (litMode == 2) {
+            uint32_t const cLit = sh->litSectionSize - lhSize;
+            // zero the stream bytes that will be OR-ed
+            zero_bytes(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
+            if (t == 0) {
+                // section header (zstd_compress_literals.c:209-232)
+                if (lhSize == 3) { uint32_t const lhc = 2 + ((uint32_t)(!single) << 2) + (litSize << 4) + (cLit << 14); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); }
+                else if (lhSize == 4) { uint32_t const lhc = 2 + (2 << 2) + (litSize << 4) + (cLit << 18); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); }
+                else { uint32_t const lhc = 2 + (3 << 2) + (litSize << 4) + (cLit << 22); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); litDst[4] = (uint8_t)(cLit >> 10); }
+                for (uint32_t i = 0; i < sh->hufHdrSize; i++) litDst[lhSize + i] = sh->hufHdr[i];
+                if (!single) for (int k = 0; k < 3; k++) { uint8_t* jt = litDst + lhSize + sh->hufHdrSize + 2 * k; jt[0] = (uint8_t)sh->streamBytes[k]; jt[1] = (uint8_t)(sh->streamBytes[k] >> 8); }
+            }
+            __syncthreads();      // zeroing + header byte stores are complete before any atomicOr touches a shared word
+            // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
+            // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
+            if ((uint32_t)wv < nStreams) {
+                uint8_t* const sbase = litDst + sh->streamOff[wv];
+                uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
+                uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
+                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total - incl));
+                const uint8_t* p = lits + segStart + runStart;
+                for (uint32_t i = runLen; i-- > 0; ) { uint32_t const c = sh->code[p[i]]; pk.add(c >> 8, c & 0xFF); }
+                if (lane == 0) pk.add(1, 1);              // lane 0 holds the FIRST symbols = the end of the stream: end mark
+                pk.finish();
+            }
+            __syncthreads();
+        }
+    }
+    if (litMode != 2) {
+        // raw (zstd_compress_literals.c:39) or RLE (:81) literals
+        uint32_t const fl = 1 + (litSize > 31) + (litSize > 4095);
+        if (t == 0) {
+            uint32_t const ty = (litMode == 1) ? 1u : 0u;
+            if (fl == 1) litDst[0] = (uint8_t)(ty + (litSize << 3));
+            else if (fl == 2) { uint32_t const v = ty + (1 << 2) + (litSize << 4); litDst[0] = (uint8_t)v; litDst[1] = (uint8_t)(v >> 8); }
+            else { uint32_t const v = ty + (3 << 2) + (litSize << 4); litDst[0] = (uint8_t)v; litDst[1] = (uint8_t)(v >> 8); litDst[2] = (uint8_t)(v >> 16); litDst[3] = (uint8_t)(v >> 24); }
+            if (litMode == 1) litDst[fl] = lits[0];
+            sh->litSectionSize = (litMode == 1) ? fl + 1 : fl + litSize;
+        }
+        if (litMode == 0) for (uint32_t i = (uint32_t)t; i < litSize; i += ZHIP_ENT_THREADS) litDst[fl + i] = lits[i];
+        __syncthreads();
+    }
+    uint32_t const litSection = sh->litSectionSize;
+
+    // ---------------- P3: sequences section (zstd_compress.c:2934-2997)
+    uint8_t* const seqDst = body + litSection;
+    uint32_t nbHdr = (nbSeq < 128) ? 1 : (nbSeq < 0x7F00 ? 2 : 3);
+    if (t == 0) {
+        if (nbSeq < 128) seqDst[0] = (uint8_t)nbSeq;
+        else if (nbSeq < 0x7F00) { seqDst[0] = (uint8_t)((nbSeq >> 8) + 0x80); seqDst[1] = (uint8_t)nbSeq; }
+        else { seqDst[0] = 0xFF; seqDst[1] = (uint8_t)(nbSeq - 0x7F00); seqDst[2] = (uint8_t)((nbSeq - 0x7F00) >> 8); }
+    }
+    __syncthreads();
+    uint32_t seqSection = nbHdr;
+    bool rawBlock = false;
+    if (nbSeq > 0) {
+        // code histograms (zstd_compress.c:2686-2712 + HIST_countFast)
+        for (int i = t; i < 3 * 64; i += ZHIP_ENT_THREADS) (&sh->seqCount[0][0])[i] = 0;
+        __syncthreads();
+        for (uint32_t i = (uint32_t)t; i < nbSeq; i += ZHIP_ENT_THREADS) {
+            uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
+            atomicAdd(&sh->seqCount[0][ll_code(ll)], 1u);
+            atomicAdd(&sh->seqCount[1][hb32(ob)], 1u);
+            atomicAdd(&sh->seqCount[2][ml_code(mlb)], 1u);
+        }
+        __syncthreads();
+        // table selection + construction: lane 0 of wavefronts 0,1,2 each build one table
+        if (lane == 0 && wv < 3) {
+            int const k = wv;                                      // 0 LL, 1 OF, 2 ML
+            uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
+            uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
+            uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
+            const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
+            uint32_t* cnt = sh->seqCount[k];
+            uint32_t max = maxPossible, mostFrequent = 0;
+            while (!cnt[max]) max--;
+            for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
+            bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
+            // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
+            uint32_t type;
+            if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+            else {
+                type = 2;
+                if (defaultAllowed) {
+                    uint32_t const mult = 10 - u.strategy;
+                    uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
+                    if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
+                }
+            }
+            // last sequence's code for the "-1" rule (zstd_compress_sequences.c:271-274)
+            uint32_t ll, mlb, ob; seq_fields(seqs, pm, nbSeq - 1, ll, mlb, ob);
+            uint32_t const lastCode = (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb));
+            uint32_t hsz = 0; bool fail = false;
+            if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
+                fse_build_ctable_rle(&sh->ct[k], max);
+                uint32_t l0, m0, o0; seq_fields(seqs, pm, 0, l0, m0, o0);
+                sh->ncount[k][0] = (uint8_t)((k == 0) ? ll_code(l0) : (k == 1 ? hb32(o0) : ml_code(m0)));
+                hsz = 1;
+            } else if (type == 0) {
+                for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
+                fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
+            } else {
+                uint32_t nbSeq1 = nbSeq;
+                uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
+                if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
+                if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
+                else {
+                    hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
+                    if (!hsz) fail = true;
+                    else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
+                }
+            }
+            sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
+        }
+        __syncthreads();
+        bool const tblFail = (sh->encType[0] == 9) | (sh->encType[1] == 9) | (sh->encType[2] == 9);
+        if (tblFail) rawBlock = true;          // cannot happen for valid histograms; keep the frame valid regardless
+        if (!rawBlock) {
+            // the three FSE state chains, last sequence -> first (zstd_compress_sequences.c:311-369): lane 0 of
+            // wavefronts 0..2 walk one table each and record (nbBits << 12 | value) per sequence.
+            if (lane == 0 && wv < 3) {
+                int const k = wv;
+                const FseCTable* ct = &sh->ct[k];
+                uint16_t* dstBits = stBits + (size_t)k * ZHIP_SEQ_CAP;
+                uint32_t ll, mlb, ob; seq_fields(seqs, pm, nbSeq - 1, ll, mlb, ob);
+                uint32_t state = fse_init_state2(ct, (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb)));
+                for (uint32_t i = nbSeq - 1; i-- > 0; ) {
+                    seq_fields(seqs, pm, i, ll, mlb, ob);
+                    uint32_t const sym = (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb));
+                    uint32_t const nbOut = (state + ct->dBits[sym]) >> 16;
+                    dstBits[i] = (uint16_t)((nbOut << 12) | (state & ((1u << nbOut) - 1)));
+                    state = ct->state[(state >> nbOut) + ct->dFind[sym]];
+                }
+                sh->finalState[k] = state;
+            }
+            __syncthreads();
+            // per-sequence bit counts -> positions.  Stream order (LSB first): sequence nbSeq-1 first, then nbSeq-2 ...;
+            // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra]
+            uint32_t const per2 = (nbSeq + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
+            uint32_t const a0 = (uint32_t)t * per2 < nbSeq ? (uint32_t)t * per2 : nbSeq;
+            uint32_t const a1 = a0 + per2 < nbSeq ? a0 + per2 : nbSeq;
+            const uint16_t* bLL = stBits; const uint16_t* bOF = stBits + ZHIP_SEQ_CAP; const uint16_t* bML = stBits + 2 * (size_t)ZHIP_SEQ_CAP;
+            uint32_t myBits = 0;
+            for (uint32_t i = a0; i < a1; i++) {
+                uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
+                myBits += kLLbits[ll_code(ll)] + kMLbits[ml_code(mlb)] + hb32(ob);
+                if (i + 1 < nbSeq) myBits += (bLL[i] >> 12) + (bOF[i] >> 12) + (bML[i] >> 12);
+            }
+            uint32_t totalSeqBits;
+            uint32_t const before = block_excl_scan(sh, myBits, &totalSeqBits);      // bits of sequences with LOWER index
+            uint32_t const tailBits = sh->ct[2].tableLog + sh->ct[1].tableLog + sh->ct[0].tableLog;
+            uint32_t const streamBits = totalSeqBits + tailBits;                       // + 1 end mark
+            uint32_t const streamBytes = (streamBits >> 3) + 1;
+            uint32_t const tblBytes = sh->ncountSize[0] + sh->ncountSize[1] + sh->ncountSize[2];
+            uint8_t* const bs = seqDst + nbHdr + 1 + tblBytes;
+            // zero the bytes of the bitstream; lane 0 writes the table headers in front of it
+            zero_bytes(bs, streamBytes);
+            if (t == 0) {
+                uint8_t* op = seqDst + nbHdr;
+                *op++ = (uint8_t)((sh->encType[0] << 6) + (sh->encType[1] << 4) + (sh->encType[2] << 2));
+                for (int k = 0; k < 3; k++) for (uint32_t i = 0; i < sh->ncountSize[k]; i++) *op++ = sh->ncount[k][i];
+            }
+            __syncthreads();
+            {   uint32_t* const w32 = (uint32_t*)((uintptr_t)bs & ~(uintptr_t)3);
+                uint64_t const bit0 = 8ull * ((uintptr_t)bs & 3);
+                // sequences a0..a1-1 of this thread occupy bits [total - before - myBits, total - before)
+                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(totalSeqBits - before - myBits));
+                for (uint32_t i = a1; i-- > a0; ) {
+                    uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
+                    uint32_t const llc = ll_code(ll), mlc = ml_code(mlb), ofc = hb32(ob);
+                    if (i + 1 < nbSeq) {
+                        uint32_t const x = bOF[i], y = bML[i], z = bLL[i];
+                        pk.add(x & 0xFFF, x >> 12); pk.add(y & 0xFFF, y >> 12); pk.add(z & 0xFFF, z >> 12);
+                    }
+                    pk.add(ll & ((1u << kLLbits[llc]) - 1), kLLbits[llc]);
+                    pk.add(mlb & ((1u << kMLbits[mlc]) - 1), kMLbits[mlc]);
+                    pk.add(ob & (uint32_t)((1ull << ofc) - 1), ofc);
+                }
+                pk.finish();
+                if (t == 0) {     // final states ML, OF, LL then the end mark (zstd_compress_sequences.c:371-381)
+                    RunPacker tl; tl.init(w32, bit0 + totalSeqBits);
+                    tl.add(sh->finalState[2] & ((1u << sh->ct[2].tableLog) - 1), sh->ct[2].tableLog);
+                    tl.add(sh->finalState[1] & ((1u << sh->ct[1].tableLog) - 1), sh->ct[1].tableLog);
+                    tl.add(sh->finalState[0] & ((1u << sh->ct[0].tableLog) - 1), sh->ct[0].tableLog);
+                    tl.add(1, 1);
+                    tl.finish();
+                }
+            }
+            seqSection = nbHdr + 1 + tblBytes + streamBytes;
+            // zstd_compress.c:2987: last FSE header + bitstream < 4 bytes -> emit the block uncompressed
+            uint32_t lastCount = 0;
+            for (int k = 0; k < 3; k++) if (sh->encType[k] == 2) lastCount = sh->ncountSize[k];
+            if (lastCount && lastCount + streamBytes < 4) rawBlock = true;
+            __syncthreads();
+        }
+    }
+
+    // ---------------- P4: block + frame headers (zstd_compress.c:3026, :4582-4590)
+    uint32_t const cSize = litSection + seqSection;
+    if (cSize >= n - minGainBlock) rawBlock = true;
+    if (rawBlock) {
+        for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
+    }
+    if (t == 0) {
+        write_frame_header(out, n);
+        uint32_t const bh = rawBlock ? (1u + (0u << 1) + (n << 3)) : (1u + (2u << 1) + (cSize << 3));
+        out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
+        *outSize = fh + 3 + (rawBlock ? n : cSize);
+    }
+}
+
+}  // namespace zhip

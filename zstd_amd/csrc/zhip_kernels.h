@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "zhip_common.h"
 #include "zhip_parse.h"
+#include "zhip_entropy.h"
 
 namespace zhip {
 
@@ -16,6 +17,61 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     parse_fast_unit(src + u.srcOff, u.srcLen, u, (uint32_t*)smem, seqs + (size_t)ui * ZHIP_SEQ_CAP, metas + ui);
+}
+
+// Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's
+// output slot (stride ZHIP_OUT_STRIDE).  Dynamic LDS = sizeof(EntShared).
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS)
+k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+          const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
+          uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    ZhipParse const pm = metas[ui];
+    entropy_unit(src + u.srcOff, u, seqs + (size_t)ui * ZHIP_SEQ_CAP, pm, lits + (size_t)ui * ZHIP_LIT_STRIDE,
+                 stBits + (size_t)ui * 3 * ZHIP_SEQ_CAP, out + (size_t)ui * ZHIP_OUT_STRIDE, outSize + ui, (EntShared*)smem);
+}
+
+// Stage 3: pack the per-unit slots into one contiguous stream.  offsets[] = exclusive prefix sum of outSize[].
+__global__ void __launch_bounds__(256)
+k_gather(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ outSize, const uint64_t* __restrict__ offsets,
+         uint32_t nUnits, uint8_t* __restrict__ dst)
+{
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    const uint8_t* s = slots + (size_t)ui * ZHIP_OUT_STRIDE;
+    uint8_t* d = dst + offsets[ui];
+    uint32_t const n = outSize[ui];
+    // destination alignment is arbitrary: peel to 16 bytes, then 16-byte vectors (source slots are 16-byte aligned)
+    uint32_t const head = (uint32_t)((16 - ((uintptr_t)d & 15)) & 15) < n ? (uint32_t)((16 - ((uintptr_t)d & 15)) & 15) : n;
+    for (uint32_t i = threadIdx.x; i < head; i += blockDim.x) d[i] = s[i];
+    uint32_t const vecs = (n - head) >> 4;
+    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) {
+        uint4 v; __builtin_memcpy(&v, s + head + 16 * (size_t)i, 16);
+        *(uint4*)(d + head + 16 * (size_t)i) = v;
+    }
+    for (uint32_t i = head + 16 * vecs + threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
+// exclusive prefix sum of outSize[0..nUnits) into offsets[0..nUnits] (single workgroup; nUnits is small)
+__global__ void __launch_bounds__(256)
+k_offsets(const uint32_t* __restrict__ outSize, uint32_t nUnits, uint64_t* __restrict__ offsets)
+{
+    __shared__ unsigned long long part[256];
+    uint32_t const t = threadIdx.x;
+    uint32_t const per = (nUnits + 255) / 256;
+    uint32_t const a = t * per < nUnits ? t * per : nUnits, b = a + per < nUnits ? a + per : nUnits;
+    unsigned long long s = 0;
+    for (uint32_t i = a; i < b; i++) s += outSize[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { unsigned long long acc = 0; for (int i = 0; i < 256; i++) { unsigned long long const v = part[i]; part[i] = acc; acc += v; } offsets[nUnits] = acc; }
+    __syncthreads();
+    unsigned long long run = part[t];
+    for (uint32_t i = a; i < b; i++) { offsets[i] = run; run += outSize[i]; }
 }
 
 }  // namespace zhip

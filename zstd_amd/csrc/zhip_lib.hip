@@ -25,6 +25,7 @@ struct zhip_ctx_s {
     ZhipSeq*   dSeqs;
     ZhipParse* dParse;
     uint8_t*   dLits;
+    uint16_t*  dStBits;
     uint8_t*   dOut;
     uint32_t*  dOutSize;
     uint64_t*  dOutOff;
@@ -91,7 +92,7 @@ void zhip_destroy(zhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits);
+    (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
@@ -105,6 +106,8 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     if (maxUnits == 0) maxUnits = 1;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zhip_ctx* c = new zhip_ctx_s();
+    c->dUnits = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
+    c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
@@ -115,6 +118,7 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     ok = ok && hipMalloc((void**)&c->dSeqs, maxUnits * (size_t)ZHIP_SEQ_CAP * sizeof(ZhipSeq)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dParse, maxUnits * sizeof(ZhipParse)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dLits, maxUnits * (size_t)ZHIP_LIT_STRIDE) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dStBits, maxUnits * (size_t)3 * ZHIP_SEQ_CAP * sizeof(uint16_t)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dOut, maxUnits * (size_t)ZHIP_OUT_STRIDE) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dOutSize, (maxUnits + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dOutOff, (maxUnits + 1) * sizeof(uint64_t)) == hipSuccess;
@@ -172,7 +176,87 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
     return 0;
 }
 
+// stages 2 + 3 on stream s; dstDev receives the packed frames
+static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint8_t* dstDev, hipStream_t s)
+{
+    static bool attrSet = false;
+    if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
+    hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
+                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
+    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    return 0;
+}
+
+static void read_timing(zhip_ctx* c)
+{
+    float a = 0, b = 0, g = 0, tot = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&g, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[3]);
+    c->timing[0] = a; c->timing[1] = b; c->timing[2] = g; c->timing[3] = tot;
+}
+
+// device pipeline; returns total compressed size (after synchronising s)
+static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
+                                     int level, size_t unitSize, uint32_t* unitSizesDev, hipStream_t s)
+{
+    size_t err = 0; uint32_t mh = 0;
+    size_t const nUnits = build_units(c, srcSize, unitSize, level, &err, &mh);
+    if (!nUnits) return err;
+    if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
+    size_t r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
+    if (zhip_isError(r)) return r;
+    r = launch_entropy_gather(c, (const uint8_t*)srcDev, nUnits, (uint8_t*)dstDev, s);
+    if (zhip_isError(r)) return r;
+    if (unitSizesDev) HIPCHK(c, hipMemcpyAsync(unitSizesDev, c->dOutSize, nUnits * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    uint64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(c->hOutSize, c->dOutSize, nUnits * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (size_t i = 0; i < nUnits; i++) total += c->hOutSize[i];
+    read_timing(c);
+    c->nUnits = nUnits;
+    return (size_t)total;
+}
+
 extern "C" {
+
+size_t zhip_compress_device(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
+                            int level, size_t unitSize, uint32_t* unitSizesDev, void* stream)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return compress_device_locked(c, dstDev, dstCapacity, srcDev, srcSize, level, unitSize, unitSizesDev,
+                                  stream ? (hipStream_t)stream : c->stream);
+}
+
+size_t zhip_compress(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                     int level, size_t unitSize, size_t* unitSizes)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t const bound = zhip_compressBound(srcSize, unitSize);
+    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    if (c->srcStageCap < srcSize + 64) {
+        (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64;
+    }
+    if (c->dstStageCap < bound + 64) {
+        (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dDstStage, bound + 64)); c->dstStageCap = bound + 64;
+    }
+    if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, src, srcSize, hipMemcpyHostToDevice, c->stream));
+    size_t const total = compress_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, srcSize, level, unitSize, nullptr, c->stream);
+    if (zhip_isError(total)) return total;
+    HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
+    if (unitSizes) for (size_t i = 0; i < c->nUnits; i++) unitSizes[i] = c->hOutSize[i];
+    return total;
+}
 
 size_t zhip_parse_device(zhip_ctx* c, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream)
 {
