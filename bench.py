@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X zstd block-compression core (contract: see the task statement).
+
+Workload (BASELINE.json configs[1]): `datagen -g1073741824 -P50 -s<rank>` (1 GiB, programs/datagen.c stream mode),
+level 1 (ZSTD_fast), 131072-byte independent units, one frame per unit, source and destination resident in HBM.
+One *step* = one pass of the whole device pipeline (match finder -> entropy/frame assembly -> compaction) over the
+1 GiB batch.  `value` = source MB (1e6 bytes, programs/benchzstd.h:32) per second, whole job over all ranks.
+
+N > 1: one process per GPU (torchrun), every rank compresses its own 1 GiB shard of independent units on its own
+GPU/stream; there is no data-path collective (units are independent) — torch.distributed only provides the
+barriers and the max-over-ranks time.  scaling = "weak".
+
+Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder), `pipeline`
+(all kernels, (S + C) bytes), `ratio`, `parity` (sha256 of the GPU stream == oracle stream on a bounded sample and a
+full-size round-trip property) and `cpu_baseline` (the REAL reference timed on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+UNIT = 131072
+
+
+def cpu_baseline(sample, seconds=8.0):
+    """time the reference (oracle/_ref/zref_bench, built from /root/reference) on the host: `zstd -b1 -B128K` semantics"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    tmp = "/tmp/zhip_bench_sample.bin"
+    if os.path.exists(exe):
+        sample.tofile(tmp)
+        try:
+            one = json.loads(subprocess.check_output([exe, "file", "1", str(UNIT), tmp, str(seconds), "1"], timeout=120))
+            ncores = os.cpu_count() or 1
+            allc = json.loads(subprocess.check_output([exe, "file", "1", str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
+            return {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
+                    "sample": f"first {len(sample) >> 20} MiB of the workload, level 1, {UNIT} B units, best of {one['runs']} runs "
+                              f"(oracle/_ref/zref_bench = ZSTD_compress2 per unit, programs/benchzstd.c semantics)",
+                    "all_cores": {"value": allc["MBps"], "cores": ncores}}
+        finally:
+            os.unlink(tmp)
+    # reference build absent: time our C restatement instead (slower than the real thing; say so)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import load_oracle, _buf
+    lo = load_oracle()
+    cap = lo.zo_compress_bound(UNIT) * (len(sample) // UNIT + 1)
+    dst = np.empty(cap, dtype=np.uint8)
+    t0 = time.time()
+    r = lo.zo_compress_chunks(1, UNIT, _buf(sample), len(sample), _buf(dst), cap, None, 0)
+    dt = time.time() - t0
+    return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port", "ratio": len(sample) / r,
+            "sample": f"first {len(sample) >> 20} MiB, oracle/zoracle.c single pass"}
+
+
+def parity_check(ctx, host, dev_out, total, sizes):
+    """bounded byte-parity vs the oracle + full-size structural properties of the GPU stream"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import load_oracle, _buf, ERR
+    lo = load_oracle()
+    nsamp = 64                                                    # first 64 units (8 MiB) byte-for-byte
+    sample = host[: nsamp * UNIT]
+    cap = lo.zo_compress_bound(UNIT) * nsamp
+    dst = np.empty(cap, dtype=np.uint8)
+    osz = np.zeros(nsamp, dtype=np.uint64)
+    r = lo.zo_compress_chunks(1, UNIT, _buf(sample), len(sample), _buf(dst), cap, _buf(osz), nsamp)
+    assert r != ERR
+    gpu_prefix = dev_out[: int(r)].cpu().numpy()
+    same = hashlib.sha256(gpu_prefix.tobytes()).hexdigest() == hashlib.sha256(dst[:r].tobytes()).hexdigest()
+    same = same and np.array_equal(sizes[:nsamp].astype(np.uint64), osz)
+    # full size: every frame starts with the zstd magic at the offset implied by the size table, sizes add up
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    import torch
+    idx = torch.from_numpy(offs[:-1]).to(dev_out.device)
+    magic_ok = bool(((dev_out[idx] == 0x28) & (dev_out[idx + 1] == 0xB5) & (dev_out[idx + 2] == 0x2F) & (dev_out[idx + 3] == 0xFD)).all())
+    return {"bytes_identical_to_oracle_first_64_units": bool(same), "frames_well_formed": magic_ok and int(offs[-1]) == int(total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mib", type=int, default=1024, help="source MiB per GPU (default = the 1 GiB of configs[1])")
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import zstd_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: zstd_amd has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = args.mib << 20
+    units = n // UNIT
+    host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)            # `datagen -g<n> -P50 -s<rank>`
+    src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    src[:n].copy_(torch.from_numpy(host))
+    cap = zstd_amd.compress_bound(n, UNIT)
+    dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    usz = torch.zeros(units, dtype=torch.int32, device=dev)
+    ctx = zstd_amd.Context(local, max_units=units)
+
+    def step():
+        return ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        total = step()
+    barrier()
+    t0 = time.perf_counter()
+    kparse = kent = kgat = ktot = 0.0
+    for _ in range(args.steps):
+        total = step()
+        tm = ctx.timing()
+        kparse += tm["parse_ms"]; kent += tm["entropy_ms"]; kgat += tm["gather_ms"]; ktot += tm["total_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ct = torch.tensor([float(total)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        total_all = float(ct.item())
+    else:
+        total_all = float(total)
+
+    if rank == 0:
+        st = ctx.stats()
+        sizes = usz.cpu().numpy()
+        K = args.steps
+        ms_step = dt / K * 1e3
+        parse_ms, ent_ms, gat_ms, tot_ms = kparse / K, kent / K, kgat / K, ktot / K
+        # algorithmic bytes: the unit is read once (S) and its result written once.  For the match
+        # finder alone the result is the 8-byte sequence records; for the pipeline it is the compressed stream (C).
+        parse_bytes = n + 8 * st["sequences"]
+        achieved = parse_bytes / (parse_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_parse_fast_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "compress_MBps_level1_datagenP50_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode), level {args.level} (ZSTD_fast wlog17 hlog13 mml6), "
+                                   f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
+                       "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
+            "ratio": round(world * n / total_all, 4),
+            "roofline": {"bound": "hbm", "kernel": "k_parse_fast", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3)},
+            "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "gather_ms": round(gat_ms, 3),
+                         "device_total_ms": round(tot_ms, 3), "algorithmic_bytes": n + int(total),
+                         "achieved_GBps": round((n + int(total)) / (tot_ms * 1e-3) / 1e9, 2),
+                         "frac_of_hbm_peak": round((n + int(total)) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        out["parity"] = parity_check(ctx, host, dst, total, sizes)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
  *        input = RDG_genBuffer(totalBytes, P/100, 0.0, seed) (programs/datagen.c:144); with threads>1 each
  *        thread compresses a disjoint contiguous shard of the chunks with its own CCtx.
  *        prints one JSON line.
+ *   zref_bench file   <level> <chunkSize> <path> <seconds> <threads>   : same, input read from a file
  *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
  */
 #define ZSTD_STATIC_LINKING_ONLY
@@ -46,11 +47,24 @@ static void* worker(void* p)
     return NULL;
 }
 
+static const char* g_file = NULL;
+
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !strcmp(argv[1], "stream")) {
         RDG_genStdout(strtoull(argv[2], 0, 10), atof(argv[3]) / 100.0, 0.0, (unsigned)atoi(argv[4]));
         return 0;
+    }
+    if (argc >= 7 && !strcmp(argv[1], "file")) {      /* rewrite argv into the bench form, input from file */
+        static char* nv[9]; static char szbuf[32];
+        FILE* f = fopen(argv[4], "rb"); long sz;
+        if (!f) { perror(argv[4]); return 1; }
+        fseek(f, 0, SEEK_END); sz = ftell(f); fclose(f);
+        snprintf(szbuf, sizeof(szbuf), "%ld", sz);
+        g_file = argv[4];
+        nv[0] = argv[0]; nv[1] = (char*)"bench"; nv[2] = argv[2]; nv[3] = argv[3]; nv[4] = szbuf; nv[5] = (char*)"0"; nv[6] = (char*)"0";
+        nv[7] = argv[5]; nv[8] = argv[6];
+        argv = nv; argc = 9;
     }
     if (argc < 9 || strcmp(argv[1], "bench")) {
         fprintf(stderr, "usage: %s bench level chunk total P seed seconds threads | stream total P seed\n", argv[0]);
@@ -71,7 +85,8 @@ int main(int argc, char** argv)
         pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
         double best = 1e30, t0 = now_s(); size_t csize = 0; int runs = 0, t;
         if (!src || !dst || !jobs || !th) return 1;
-        RDG_genBuffer(src, total, P, 0.0, seed);
+        if (g_file) { FILE* f = fopen(g_file, "rb"); if (!f || fread(src, 1, total, f) != total) return 1; fclose(f); }
+        else RDG_genBuffer(src, total, P, 0.0, seed);
         do {
             double const a = now_s();
             size_t c0 = 0;

@@ -46,6 +46,10 @@ def lib():
         L.zhip_get_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.zhip_last_timing.restype = None
         L.zhip_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhip_last_stats.restype = C.c_size_t
+        L.zhip_last_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhip_datagen.restype = None
+        L.zhip_datagen.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint, C.c_int]
         for name, res, args in [
             ("zhip_compress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]),
             ("zhip_compress_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -67,6 +71,13 @@ def get_cparams(level, src_size):
 
 def compress_bound(src_size, unit_size=UNIT_SIZE_MAX):
     return lib().zhip_compressBound(src_size, unit_size)
+
+
+def datagen(size, match_pct=50, seed=0, stream_mode=True, lit_proba=0.0):
+    """programs/datagen.c restated on the host (zstd_amd/csrc/zhip_datagen.h): `datagen -g<size> -P<pct> -s<seed>`"""
+    a = np.empty(max(size, 1), dtype=np.uint8)
+    lib().zhip_datagen(a.ctypes.data_as(C.c_void_p), size, match_pct / 100.0, lit_proba, seed, 1 if stream_mode else 0)
+    return a[:size]
 
 
 class Context:
@@ -103,6 +114,11 @@ class Context:
         t = (C.c_double * 4)()
         lib().zhip_last_timing(self._h, t)
         return {"parse_ms": t[0], "entropy_ms": t[1], "gather_ms": t[2], "total_ms": t[3]}
+
+    def stats(self):
+        s = (C.c_ulonglong * 4)()
+        self._check(lib().zhip_last_stats(self._h, s), "zhip_last_stats")
+        return {"units": s[0], "src_bytes": s[1], "dst_bytes": s[2], "sequences": s[3]}
 
     # ---- stage 1 only (sequence-producer path)
     def parse_device(self, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, stream=None):

@@ -9,6 +9,7 @@
 #include "zhip_common.h"
 #include "zhip_kernels.h"
 #include "zhip_host.h"
+#include "zhip_datagen.h"
 
 // zstd's error numbering (lib/zstd_errors.h:60-101): results are (size_t)-code
 enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_memory_allocation = 64,
@@ -35,7 +36,7 @@ struct zhip_ctx_s {
     // pinned host mirrors
     ZhipUnit* hUnits; uint32_t* hOutSize; ZhipParse* hParse;
     // last call
-    size_t nUnits; double timing[4];
+    size_t nUnits; double timing[4]; unsigned long long stats[4];
     // sequence-producer cache
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
@@ -131,6 +132,11 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
 
 void zhip_last_timing(const zhip_ctx* c, double t[4]) { for (int i = 0; i < 4; i++) t[i] = c->timing[i]; }
 
+void zhip_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed, int streamMode)
+{
+    zhip::datagen(buffer, size, matchProba, litProba, seed, streamMode);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------ internals
@@ -220,6 +226,7 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     HIPCHK(c, hipStreamSynchronize(s));
     for (size_t i = 0; i < nUnits; i++) total += c->hOutSize[i];
     read_timing(c);
+    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = total; c->stats[3] = 0;
     c->nUnits = nUnits;
     return (size_t)total;
 }
@@ -273,6 +280,7 @@ size_t zhip_parse_device(zhip_ctx* c, const void* srcDev, size_t srcSize, int le
     float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing[0] = ms; c->timing[1] = c->timing[2] = 0; c->timing[3] = ms;
     c->nUnits = nUnits;
+    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = 0; c->stats[3] = 0;
     return nUnits;
 }
 
@@ -294,6 +302,21 @@ static size_t seqs_to_public(const ZhipSeq* s, const ZhipParse& m, zhip_Sequence
     }
     out[m.nbSeq].offset = 0; out[m.nbSeq].litLength = m.lastLits; out[m.nbSeq].matchLength = 0; out[m.nbSeq].rep = 0;
     return (size_t)m.nbSeq + 1;
+}
+
+// stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences (fetched from the device on demand)
+size_t zhip_last_stats(zhip_ctx* c, unsigned long long stats[4])
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->nUnits) {
+        HIPCHK(c, hipMemcpy(c->hParse, c->dParse, c->nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost));
+        unsigned long long ns = 0;
+        for (size_t i = 0; i < c->nUnits; i++) ns += c->hParse[i].nbSeq;
+        c->stats[3] = ns;
+    }
+    for (int i = 0; i < 4; i++) stats[i] = c->stats[i];
+    return 0;
 }
 
 size_t zhip_get_sequences(zhip_ctx* c, size_t unitIndex, zhip_Sequence* out, size_t capacity)
