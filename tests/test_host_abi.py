@@ -1,0 +1,89 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol include/zstd_hip.h
+declares, parameter selection and the input generator agree with the oracle (and with the real reference when
+oracle/_ref is present).  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, _buf, ROOT
+
+
+@pytest.fixture(scope="module")
+def zlib_():
+    from zstd_amd import build as zb
+    import zstd_amd
+    zb.build()
+    return zstd_amd
+
+
+def test_every_declared_symbol_is_exported(zlib_):
+    hdr = open(os.path.join(ROOT, "include", "zstd_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(zhip_[a-zA-Z_]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    L = C.CDLL(zlib_.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_oracle_or_reference_in_the_product_binary(zlib_):
+    out = subprocess.check_output(["ldd", zlib_.LIB_PATH]).decode()
+    assert "zoracle" not in out and "zstd_ref" not in out and "zref" not in out
+    syms = subprocess.check_output(["nm", "-D", zlib_.LIB_PATH]).decode()
+    assert " zo_" not in syms and "ZSTD_compress" not in syms
+
+
+def test_cparams_match_oracle_and_reference(zlib_):
+    lo = load_oracle()
+    lr = load_ref() if have_ref() else None
+    sizes = [0, 1, 5, 63, 64, 65, 255, 256, 1000, 4096, 16384, 16385, 65536, 131071, 131072, 131073, 262144, 262145, 1 << 20]
+    for level in (-7, -1, 0, 1, 2, 3, 4, 5, 19):
+        for n in sizes:
+            mine = (C.c_uint * 7)()
+            rc = zlib_.lib().zhip_getCParams(level, n, mine)
+            o = (C.c_uint * 7)()
+            ro = lo.zo_get_cparams(level, n, o)
+            assert (rc == 0) == (ro == 0)
+            if rc == 0:
+                assert list(mine) == list(o), (level, n)
+                if lr is not None and n > 0:
+                    r = (C.c_int * 7)()
+                    lr.zref_get_cparams(level, n, 0, r)
+                    assert list(mine) == list(r), (level, n)
+
+
+def test_datagen_both_modes(zlib_):
+    lo = load_oracle()
+    for P in (0, 35, 50, 100):
+        a = zlib_.datagen(300001, P, seed=3, stream_mode=False)
+        b = np.zeros(300001, dtype=np.uint8)
+        lo.zo_datagen(_buf(b), 300001, P / 100.0, 0.0, 3)
+        assert a.tobytes() == b.tobytes()
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if os.path.exists(exe):
+        for n in (1, 131072, 500000):
+            want = subprocess.check_output([exe, "stream", str(n), "50", "2"])
+            assert zlib_.datagen(n, 50, seed=2, stream_mode=True).tobytes() == want
+
+
+def test_compress_bound_matches(zlib_):
+    lo = load_oracle()
+    for n in (0, 1, 1000, 131072, 131073, 1 << 20, (1 << 20) + 5):
+        want = 0
+        off = 0
+        while True:
+            ln = min(131072, n - off)
+            want += lo.zo_compress_bound(ln)
+            off += ln
+            if off >= n:
+                break
+        assert zlib_.compress_bound(n, 131072) == want
+
+
+def test_calls_fail_loudly_without_a_gpu(zlib_):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(zlib_.ZhipError):
+        zlib_.Context(0, 4)

@@ -25,6 +25,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ZhipError(f"{LIB_PATH} is missing: build it with `python zstd_amd/build.py` (no CPU fallback exists)")
+        try:
+            import torch  # noqa: F401  (torch bundles its own libamdhip64: load it FIRST so the process has ONE HIP runtime)
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.zhip_device_count.restype = C.c_int
         L.zhip_create.restype = C.c_void_p

@@ -331,3 +331,75 @@ size_t zhip_get_sequences(zhip_ctx* c, size_t unitIndex, zhip_Sequence* out, siz
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ block-level plugin (B1)
+// parse `srcSize` host bytes cut into blockSize blocks (each without history); results copied to the host cache
+static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
+{
+    if (blockSize == 0 || blockSize > ZHIP_UNIT_MAX) blockSize = ZHIP_UNIT_MAX;
+    size_t err = 0; uint32_t mh = 0;
+    size_t const nUnits = build_units(c, srcSize, blockSize, level, &err, &mh);
+    if (!nUnits) return err;
+    if (c->srcStageCap < srcSize + 64) {
+        (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64;
+    }
+    if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, src, srcSize, hipMemcpyHostToDevice, c->stream));
+    size_t const r = launch_parse(c, c->dSrcStage, nUnits, mh, c->stream);
+    if (zhip_isError(r)) return r;
+    HIPCHK(c, hipMemcpyAsync(c->hParse, c->dParse, nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cacheParse.assign(c->hParse, c->hParse + nUnits);
+    c->cacheUnits.assign(c->hUnits, c->hUnits + nUnits);
+    size_t totalSeq = 0;
+    for (size_t i = 0; i < nUnits; i++) totalSeq += c->hParse[i].nbSeq;
+    c->cacheSeqs.resize(totalSeq ? totalSeq : 1);
+    size_t pos = 0;
+    for (size_t i = 0; i < nUnits; i++) {
+        uint32_t const ns = c->hParse[i].nbSeq;
+        if (ns) HIPCHK(c, hipMemcpyAsync(c->cacheSeqs.data() + pos, c->dSeqs + i * (size_t)ZHIP_SEQ_CAP, ns * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
+        pos += ns;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cacheSrc = src; c->cacheSize = srcSize; c->cacheBlock = blockSize; c->cacheLevel = level;
+    c->nUnits = nUnits;
+    return nUnits;
+}
+
+extern "C" {
+
+size_t zhip_prepare_sequences(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return prepare_locked(c, src, srcSize, blockSize, level);
+}
+
+// ZSTD_sequenceProducer_F (lib/zstd.h:2838).  Any failure -> ZHIP_SEQUENCE_PRODUCER_ERROR (so the caller's
+// ZSTD_c_enableSeqProducerFallback decides what happens, lib/compress/zstd_compress.c:3338-3356).
+size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeqsCapacity,
+                              const void* src, size_t srcSize, const void* dict, size_t dictSize,
+                              int compressionLevel, size_t windowSize)
+{
+    zhip_ctx* c = (zhip_ctx*)state;
+    (void)windowSize;
+    if (!c || dict != nullptr || dictSize != 0 || srcSize > ZHIP_UNIT_MAX || srcSize == 0) return ZHIP_SEQUENCE_PRODUCER_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return ZHIP_SEQUENCE_PRODUCER_ERROR;
+    const uint8_t* p = (const uint8_t*)src; const uint8_t* base = (const uint8_t*)c->cacheSrc;
+    bool hit = base && c->cacheLevel == compressionLevel && p >= base && p + srcSize <= base + c->cacheSize
+               && ((size_t)(p - base) % c->cacheBlock) == 0;
+    size_t idx = hit ? (size_t)(p - base) / c->cacheBlock : 0;
+    if (hit && c->cacheUnits[idx].srcLen != srcSize) hit = false;
+    if (!hit) {                                  // not prepared: one launch for this block (latency-bound path)
+        size_t const r = prepare_locked(c, src, srcSize, srcSize, compressionLevel);
+        if (zhip_isError(r)) return ZHIP_SEQUENCE_PRODUCER_ERROR;
+        idx = 0;
+    }
+    size_t pos = 0;
+    for (size_t i = 0; i < idx; i++) pos += c->cacheParse[i].nbSeq;
+    size_t const r = seqs_to_public(c->cacheSeqs.data() + pos, c->cacheParse[idx], outSeqs, outSeqsCapacity);
+    return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
+}
+
+}  // extern "C"
