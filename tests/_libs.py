@@ -196,7 +196,7 @@ def emu_compress_units(le, lo, bufs, level):
     nu = len(bufs)
     seqs = np.zeros(nu * cap, dtype=SEQ_DT)
     metas = np.zeros(nu, dtype=PARSE_DT)
-    smem = 4 << int(units["hashLog"].max())
+    smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
     le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), smem, 0)
     ostride, lstride = le.emu_out_stride(), le.emu_lit_stride()
     lits = np.full(nu * lstride, 0xEE, dtype=np.uint8)

@@ -92,6 +92,12 @@ static inline int first_alive_lane()
 }  // namespace simt
 
 // ---------------------------------------------------------------- language surface used by zstd_amd/csrc
+#define ZHIP_LDS                      /* LDS address-space qualifier of the product headers: plain memory here */
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or(p, v, order)
+#define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and(p, v, order)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
 #define __global__
 #define __device__
 #define __host__

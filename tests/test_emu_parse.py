@@ -18,7 +18,7 @@ def emu_parse(le, lo, bufs, level):
     cap = le.emu_seq_cap()
     seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT)
     metas = np.zeros(len(bufs), dtype=PARSE_DT)
-    smem = 4 << int(units["hashLog"].max())
+    smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
     le.emu_parse_fast(_buf(src), _buf(units), len(bufs), _buf(seqs), _buf(metas), smem, 0)
     out = []
     for i in range(len(bufs)):

@@ -7,7 +7,7 @@
 
 namespace zhip {
 
-// Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = 4 << hashLog bytes (hash table).
+// Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
 __global__ void __launch_bounds__(64)
 k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
              ZhipSeq* __restrict__ seqs, ZhipParse* __restrict__ metas)
@@ -16,7 +16,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
-    parse_fast_unit(src + u.srcOff, u.srcLen, u, (uint32_t*)smem, seqs + (size_t)ui * ZHIP_SEQ_CAP, metas + ui);
+    parse_fast_unit(src + u.srcOff, u.srcLen, u, smem, seqs + (size_t)ui * ZHIP_SEQ_CAP, metas + ui);
 }
 
 // Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's

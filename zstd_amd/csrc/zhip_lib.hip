@@ -170,7 +170,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
 
 static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
 {
-    size_t const smem = (size_t)4 << maxHashLog;
+    size_t const smem = zhip::fast_lds_bytes(maxHashLog);
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     if (smem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

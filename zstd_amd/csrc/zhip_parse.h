@@ -3,24 +3,39 @@
 // WHAT it computes: exactly the sequences the reference's ZSTD_compressBlock_fast_noDict_generic
 // (lib/compress/zstd_fast.c:192-423) emits for a unit with no history (fresh table, rep = {1,4,8}).
 //
-// HOW (CDNA4 design, not a translation): the reference walks positions one or two at a time because each lookup
+// HOW (CDNA4 design, not a translation).  The reference walks positions one or two at a time because each lookup
 // sees the table writes of the positions before it.  Here one 64-lane wavefront owns the unit and evaluates a
-// *batch* of up to 62 consecutive search positions at once:
-//   * the positions the reference would visit from the current point are a data-independent schedule
-//     (pairs A_k, A_k+1 with a step that grows every 128 bytes, zstd_fast.c:232-347); lane j takes the j-th one;
-//   * every lane hashes its position, gathers the table entry from LDS (the table lives in LDS: 4 B x 2^hashLog),
-//     loads the candidate's 4 bytes from the source in HBM/L2 and tests it; A-lanes also test the repcode;
+// *batch* of 32 reference iterations (64 search positions) at once:
+//   * the positions the reference would visit from the current point are a data-independent schedule (pairs
+//     A_k, A_k+1 with a gap that grows every 128 bytes, zstd_fast.c:232-347); lane 2k+b takes A_k+b, even lanes also
+//     carry the repcode probe of iteration k (at A_{k+1});
+//   * every lane hashes its position and gathers the table entry from LDS.  The table is wave-private LDS:
+//     16-bit entries + a 1-bit plane for bit 16 of the position = 17 KB for hashLog 13, so NINE units are resident
+//     per CU (LDS is allocated in 1280-byte granules on gfx950: 9 x 14 granules);
+//   * lanes of one batch that hash alike must see each other's inserts in lane order.  A 512-byte LDS scratch
+//     (write lane id / read back) finds the colliding lanes, ballots turn them into exact per-hash lane groups, and
+//     each lane takes the position of its closest earlier group member as its candidate — so ONE pass is exact;
 //   * ballots give the first event in the reference's own order (repcode at ip2, match at ip0, match at ip1);
-//   * only the lanes the reference would have inserted before that event write the table.  A later lane must see
-//     the insert of an earlier lane with the same hash: that case is detected with a write/read-back on the table
-//     itself and resolved by committing the conflict-free prefix and re-gathering (rare);
-//   * match extension (backward + forward) is one 512-byte wide compare across the wave.
-// All control flow is wave-uniform (derived from ballots), LDS traffic is wave-private, so no s_barrier is needed.
+//     the lanes the reference would have inserted before that event write the table (last lane of a group only);
+//   * the unit is latency-bound (dependent global loads), so the code is organised around global round trips:
+//     per batch ONE (candidate bytes; the next batch's source bytes are loaded speculatively in its shadow), per
+//     match TWO: forward+backward extension in one wave-wide compare (48 x 8 B forward, 16 x 8 B backward), then one
+//     round that fetches the bytes for the two complementary inserts, the immediate-repcode probe+count and the
+//     next batch.
+// All control flow is wave-uniform (derived from ballots); LDS traffic is wave-private, so no s_barrier is needed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "zhip_common.h"
 
+#ifndef ZHIP_LDS
+#define ZHIP_LDS __attribute__((address_space(3)))          /* the host SIMT emulator (tests/simt) defines it empty */
+#endif
+
 namespace zhip {
+
+typedef ZHIP_LDS uint8_t  lds_u8;
+typedef ZHIP_LDS uint16_t lds_u16;
+typedef ZHIP_LDS uint32_t lds_u32;
 
 // ------------------------------------------------------------------ unaligned source access (HBM through L1/L2)
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -29,6 +44,11 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t v; __built
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }   // -> SGPR
 __device__ __forceinline__ int first_lane(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    return (uint64_t)__builtin_amdgcn_readlane((uint32_t)v, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l) << 32);
+}
+__device__ __forceinline__ unsigned long long below_mask(int l) { return l >= 64 ? ~0ull : (l <= 0 ? 0ull : ((1ull << l) - 1)); }
 
 // multiplicative hashes of lib/compress/zstd_compress_internal.h:820-862, evaluated with 32-bit multiplies:
 // only the top hBits of the low 64 bits of the product are needed.
@@ -49,29 +69,52 @@ __device__ __forceinline__ uint32_t hash_pos(uint64_t bytes, uint32_t hBits, uin
     }
 }
 
-// Wave-private LDS cells that one lane writes and another lane of the same wave reads back: DS instructions of a
-// wave execute in order, so only the compiler must be kept from forwarding/reordering -> volatile accesses.
-__device__ __forceinline__ uint32_t lds_get(const uint32_t* T, uint32_t i) { return ((const volatile uint32_t*)T)[i]; }
-__device__ __forceinline__ void lds_put(uint32_t* T, uint32_t i, uint32_t v) { ((volatile uint32_t*)T)[i] = v; }
+// ------------------------------------------------------------------ the wave-private hash table in LDS
+// value = position in the unit, 0 = empty (position 0 is never inserted, zstd_fast.c:238).  Positions are < 2^17:
+// lo[] holds bits 0..15, one bit per entry in hi[] holds bit 16.  Positions are inserted in increasing order, so
+// once a position >= 65536 exists every later insert sets its hi bit: the plane only ever needs OR.
+#define ZHIP_FAST_SCRATCH 512u
+struct FastTab {
+    lds_u16* lo;
+    lds_u32* hi;
+    lds_u8*  scr;        // ZHIP_FAST_SCRATCH bytes: duplicate-hash detection inside a batch
+    bool     useHi;      // unit longer than 64 KB
+};
+__host__ __device__ inline uint32_t fast_hi_bytes(uint32_t hlog) { uint32_t const b = (1u << hlog) >> 3; return b < 4 ? 4 : b; }
+__host__ __device__ inline uint32_t fast_lds_bytes(uint32_t hlog) { return (2u << hlog) + fast_hi_bytes(hlog) + ZHIP_FAST_SCRATCH; }
+
+__device__ __forceinline__ uint32_t tab_get(const FastTab& T, uint32_t h)
+{
+    uint32_t v = T.lo[h];
+    if (T.useHi) v |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+    return v;
+}
+__device__ __forceinline__ void tab_put(const FastTab& T, uint32_t h, uint32_t pos)
+{
+    T.lo[h] = (uint16_t)pos;
+    if (pos >> 16) __hip_atomic_fetch_or(&T.hi[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 
 // ------------------------------------------------------------------ wave-wide match extension
 // Common-prefix length of src[a..) and src[b..) (b < a), a bounded by n — ZSTD_count (zstd_compress_internal.h:771).
-// 64 lanes x 8 bytes per round.
+// `lanes` lanes x 8 bytes per call; returns true when a mismatch (or the end) was found inside the window.
+__device__ __forceinline__ uint32_t lane_same_fwd(const uint8_t* src, uint32_t q, uint32_t off, uint32_t n)
+{   // equal leading bytes (0..8) of the 8-byte windows at q and q-off, bounded by n
+    uint32_t const room = q < n ? n - q : 0;
+    if (room >= 8) {
+        uint64_t const x = ld64(src + q) ^ ld64(src + (q - off));
+        return x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+    }
+    uint32_t same = 0;
+    while (same < room && src[q + same] == src[q - off + same]) same++;
+    return same;
+}
 __device__ __forceinline__ uint32_t wave_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_t n)
 {
     int const lane = lane_id();
     uint32_t total = 0;
     for (;;) {
-        uint32_t const q = a + 8u * (uint32_t)lane;
-        uint32_t const room = q < n ? n - q : 0;           // valid bytes at q
-        uint32_t same;                                     // equal leading bytes of this lane's 8-byte window
-        if (room >= 8) {
-            uint64_t const x = ld64(src + q) ^ ld64(src + (q - (a - b)));
-            same = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
-        } else {
-            same = 0;
-            while (same < room && src[q + same] == src[q - (a - b) + same]) same++;
-        }
+        uint32_t const same = lane_same_fwd(src, a + 8u * (uint32_t)lane, a - b, n);
         unsigned long long const stop = __ballot(same < 8);
         if (stop) {
             int const f = first_lane(stop);
@@ -95,6 +138,35 @@ __device__ __forceinline__ uint32_t wave_count_back(const uint8_t* src, uint32_t
     }
 }
 
+// Backward (at most `lim` bytes before mpos / cand) and forward (from mpos+4 / cand+4) extension of a 4-byte match in
+// ONE round of loads: lanes 0..47 compare 8 bytes forward each, lanes 48..63 8 bytes backward each.
+__device__ __forceinline__ void wave_extend(const uint8_t* src, uint32_t n, uint32_t mpos, uint32_t cand, uint32_t lim,
+                                            uint32_t& backLen, uint32_t& fwdLen)
+{
+    int const lane = lane_id();
+    uint32_t const off = mpos - cand;
+    uint32_t same;
+    if (lane < 48) {
+        same = lane_same_fwd(src, mpos + 4 + 8u * (uint32_t)lane, off, n);
+    } else {
+        uint32_t const j8 = 8u * (uint32_t)(lane - 48);
+        uint32_t const r = lim > j8 ? (lim - j8 < 8 ? lim - j8 : 8) : 0;      // bytes this lane may compare (0..8)
+        same = 0;
+        if (r) {
+            uint32_t const s = mpos - j8 - r;                                  // window [s, s+8): its first r bytes count
+            uint64_t x = ld64(src + s) ^ ld64(src + (s - off));
+            x <<= 8 * (8 - r);                                                 // byte r-1 (closest to mpos) -> top byte
+            same = x ? (uint32_t)__clzll((long long)x) >> 3 : r;
+        }
+    }
+    unsigned long long const stop = __ballot(same < 8);
+    unsigned long long const stopF = stop & 0x0000FFFFFFFFFFFFull, stopB = stop >> 48;
+    if (stopF) { int const f = first_lane(stopF); fwdLen = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+    else fwdLen = 384 + wave_count_fwd(src, mpos + 4 + 384, cand + 4 + 384, n);
+    if (stopB) { int const f = first_lane(stopB); backLen = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f + 48); }
+    else backLen = 128 + wave_count_back(src, mpos - 128, cand - 128, lim - 128);
+}
+
 // ------------------------------------------------------------------ the parser
 struct FastOut {
     ZhipSeq* seqs;          // global, capacity ZHIP_SEQ_CAP
@@ -113,156 +185,205 @@ __device__ __forceinline__ void store_seq(FastOut& o, uint32_t litLength, uint32
     o.nbSeq++;
 }
 
-// T: wave-private hash table in LDS, 1<<hlog entries, value = position (0 = empty; position 0 is never inserted).
+// source bytes one batch needs, per lane: lane 2k+b searches A_k+b; even lanes also probe the repcode at A_{k+1}
+struct FastBatch {
+    uint64_t bytes;         // 8 bytes at pos
+    uint64_t rbytes;        // even lanes: 8 bytes at rpos = A_{k+1}
+    uint32_t rv;            // even lanes: 4 bytes at rpos - rep1
+};
+__device__ __forceinline__ void batch_positions(uint32_t ip0, uint32_t g0, uint32_t step, uint32_t& pos, uint32_t& rpos)
+{
+    uint32_t const lane = (uint32_t)lane_id(), k = lane >> 1;
+    pos = ip0 + (k ? g0 + (k - 1) * step : 0) + (lane & 1);
+    rpos = ip0 + g0 + k * step;
+}
+__device__ __forceinline__ FastBatch batch_load(const uint8_t* src, uint32_t n, uint32_t ip0, uint32_t g0, uint32_t step, uint32_t rep1)
+{
+    uint32_t pos, rpos; batch_positions(ip0, g0, step, pos, rpos);
+    bool const even = (lane_id() & 1) == 0;
+    FastBatch b;
+    b.bytes = (pos + 8 <= n) ? ld64(src + pos) : 0;
+    bool const rok = even && rpos + 8 <= n;
+    b.rbytes = rok ? ld64(src + rpos) : 0;
+    b.rv = (rok && rep1 > 0 && rep1 <= rpos) ? ld32(src + rpos - rep1) : 0;
+    return b;
+}
+
+// smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
 __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
-                                       uint32_t* T, ZhipSeq* seqs, ZhipParse* meta)
+                                       unsigned char* smem, ZhipSeq* seqs, ZhipParse* meta)
 {
     int const lane = lane_id();
     uint32_t const hlog = u.hashLog, mls = u.minMatch;
     uint32_t const stepSize = u.targetLength + !u.targetLength + 1;         // zstd_fast.c:200
     FastOut out; out.seqs = seqs; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
 
-    for (uint32_t i = (uint32_t)lane; i < (1u << hlog); i += 64) lds_put(T, i, 0);     // fresh table (zstd_compress.c:2020)
+    FastTab T;
+    T.lo = (lds_u16*)(uintptr_t)smem;
+    T.hi = (lds_u32*)(uintptr_t)(smem + (2u << hlog));
+    T.scr = (lds_u8*)(uintptr_t)(smem + (2u << hlog) + fast_hi_bytes(hlog));
+    T.useHi = n > 65536;
+    {   // fresh table (zstd_compress.c:2020): lo[] and hi[] are contiguous
+        lds_u32* const z = (lds_u32*)(uintptr_t)smem;
+        uint32_t const words = ((2u << hlog) + fast_hi_bytes(hlog)) >> 2;
+        for (uint32_t i = (uint32_t)lane; i < words; i += 64) z[i] = 0;
+    }
     __builtin_amdgcn_wave_barrier();
 
     uint32_t anchor = 0, rep1 = 1, rep2 = 4, saved1 = 0, saved2 = 0;
-    {
-        int32_t const ilimit = (int32_t)n - 8;                               // may be negative for tiny units
-        uint32_t ip0 = 1;
-        // :238-244  ip0 = 1, lowest index 0 -> maxRep = 1
-        if (rep2 > 1) { saved2 = rep2; rep2 = 0; }
-        if (rep1 > 1) { saved1 = rep1; rep1 = 0; }
+    int32_t const ilimit = (int32_t)n - 8;                                   // may be negative for tiny units
+    uint32_t ip0 = 1;
+    // :238-244  ip0 = 1, lowest index 0 -> maxRep = 1
+    if (rep2 > 1) { saved2 = rep2; rep2 = 0; }
+    if (rep1 > 1) { saved1 = rep1; rep1 = 0; }
 
-        bool more = true;
-        while (more) {                                                       // one turn per `_start`
-            uint32_t step = stepSize, g0 = stepSize, nextStep = ip0 + 128;
-            if ((int32_t)(ip0 + g0 + 1) >= ilimit) break;                    // :257
-            // ---- scan batches until an event or the end of the unit
-            int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode
-            uint32_t evPos = 0, evCand = 0, cur0 = 0;
-            for (;;) {
-                // how many reference iterations (pairs) this batch covers
-                int32_t const X = ilimit - 1 - (int32_t)(ip0 + g0);          // end:  (k+1)*step >= X
-                int32_t const Y = (int32_t)nextStep - (int32_t)(ip0 + g0);   // step++: (k+1)*step >= Y
-                int32_t kEnd = X <= 0 ? 0 : (int32_t)((X + (int32_t)step - 1) / (int32_t)step) - 1;
-                int32_t kInc = Y <= 0 ? 0 : (int32_t)((Y + (int32_t)step - 1) / (int32_t)step) - 1;
-                int32_t K = 31;
-                if (kEnd + 1 < K) K = kEnd + 1;
-                if (kInc + 1 < K) K = kInc + 1;
-                int const nLanes = 2 * K;                                    // search lanes; lane 2K = repcode-only
+    bool have = false;                      // `cur` already holds the bytes of the batch that starts at ip0
+    FastBatch cur; cur.bytes = 0; cur.rbytes = 0; cur.rv = 0;
+    for (;;) {                                                               // one turn per `_start`
+        uint32_t step = stepSize, g0 = stepSize, nextStep = ip0 + 128;
+        if ((int32_t)(ip0 + g0 + 1) >= ilimit) break;                        // :257
+        if (!have) cur = batch_load(src, n, ip0, g0, step, rep1);
+        have = false;
 
-                int const k = lane >> 1;
-                uint32_t const pos = (k == 0 ? ip0 : ip0 + g0 + (uint32_t)(k - 1) * step) + (uint32_t)(lane & 1);
-                bool const live = lane <= nLanes;
-                uint64_t const bytes = live ? ld64(src + pos) : 0;
-                uint32_t const cur32 = (uint32_t)bytes;
-                uint32_t const h = hash_pos(bytes, hlog, mls);
-                bool const isRepLane = live && ((lane & 1) == 0) && lane >= 2 && rep1 > 0;
-                uint32_t const rv = isRepLane ? ld32(src + pos - rep1) : 0;
-                unsigned long long const repMask = __ballot(isRepLane && rv == cur32);
-                int const jr = repMask ? first_lane(repMask) : 64;
-                int const rankR = jr < 64 ? 3 * ((jr >> 1) - 1) : 0x7fffffff;
+        // ---- scan batches until an event or the end of the unit
+        int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode
+        uint32_t mpos = 0, cand0 = 0, cur0 = 0;
+        for (;;) {
+            // iterations this batch covers: iteration k+1 runs iff A_{k+2}+1 < ilimit (:347); the gap grows after the
+            // iteration whose A_{k+2} reaches nextStep (:342-346) — a batch ends there
+            uint32_t pos, rpos; batch_positions(ip0, g0, step, pos, rpos);
+            uint32_t const A2 = rpos + step;
+            unsigned long long const mEnd = __ballot((int32_t)(A2 + 1) >= ilimit);
+            unsigned long long const mInc = __ballot((int32_t)A2 >= (int32_t)nextStep);
+            int const kEnd = mEnd ? first_lane(mEnd) >> 1 : 64;
+            int const kInc = mInc ? first_lane(mInc) >> 1 : 64;
+            int K = 32;
+            if (kEnd + 1 < K) K = kEnd + 1;
+            if (kInc + 1 < K) K = kInc + 1;
+            int const nLanes = 2 * K;
+            bool const live = lane < nLanes;
 
-                int done = 0, Ltest = 0, Lcommit = 0, jm = 64;
-                uint32_t old = 0;
-                for (;;) {                                                   // conflict-resolution passes (usually 1)
-                    bool const act = live && lane >= done;
-                    old = act ? lds_get(T, h) : 0;
-                    bool hit = false;
-                    if (act && lane < nLanes && old != 0) hit = (ld32(src + old) == cur32);
-                    unsigned long long const mMask = __ballot(hit);
-                    jm = mMask ? first_lane(mMask) : 64;
-                    int const rankM = jm < 64 ? 3 * (jm >> 1) + 1 + (jm & 1) : 0x7fffffff;
-                    if (rankR < rankM)      { evKind = 2; Ltest = jr - 2; Lcommit = jr; }
-                    else if (jm < 64)       { evKind = 1; Ltest = jm + 1; Lcommit = (jm & 1) ? jm + 1 + (step <= 4 ? 1 : 0) : jm + 2; }
-                    else                    { evKind = 0; Ltest = nLanes; Lcommit = nLanes; }
-                    bool const inC = lane >= done && lane < Lcommit;
-                    if (inC) lds_put(T, h, pos);
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t const back = inC ? lds_get(T, h) : pos;
-                    if (!__ballot(inC && back != pos)) break;                // no two committed lanes share a slot
-                    // ---- rare: two lanes of the committed range hash alike.  Undo, find the first duplicate.
-                    if (inC) lds_put(T, h, old);
-                    __builtin_amdgcn_wave_barrier();
-                    int jstar = Lcommit;
-                    for (int x = done + 1; x < Lcommit; x++) {
-                        uint32_t const hx = __builtin_amdgcn_readlane(h, x);
-                        if (__ballot(lane >= done && lane < x && h == hx)) { jstar = x; break; }
-                    }
-                    if (lane >= done && lane < jstar) lds_put(T, h, pos);            // conflict-free prefix
-                    __builtin_amdgcn_wave_barrier();
-                    if (jstar >= Ltest) {                                    // only insert-only lanes collide: keep order
-                        for (int x = jstar; x < Lcommit; x++) {
-                            if (lane == x) lds_put(T, h, pos);
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        break;
-                    }
-                    done = jstar;                                            // lane jstar now sees its true candidate
-                }
-                if (evKind == 1) {
-                    evPos = __builtin_amdgcn_readlane(pos, jm);
-                    evCand = __builtin_amdgcn_readlane(old, jm);
-                    cur0 = evPos;
-                    break;
-                }
-                if (evKind == 2) {
-                    evPos = __builtin_amdgcn_readlane(pos, jr);
-                    cur0 = __builtin_amdgcn_readlane(pos, jr - 2);
-                    break;
-                }
-                // no event in this batch: advance like the end of iteration K-1 (:336-348)
-                ip0 = ip0 + g0 + (uint32_t)(K - 1) * step;
-                g0 = step;
-                if (K - 1 == kEnd) break;                                    // ip3 >= ilimit: unit finished
-                if (K - 1 == kInc) { step++; nextStep += 128; }
+            uint32_t const cur32 = (uint32_t)cur.bytes;
+            uint32_t const h = hash_pos(cur.bytes, hlog, mls);
+            uint32_t const old = live ? tab_get(T, h) : 0;
+            uint32_t const si = h & (ZHIP_FAST_SCRATCH - 1);
+            if (live) T.scr[si] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            bool const loser = live && T.scr[si] != (uint8_t)lane;
+
+            // speculative loads for the next batch (valid if this one has no event)
+            uint32_t const nip0 = ip0 + g0 + (uint32_t)(K - 1) * step;
+            uint32_t const nstep = step + (uint32_t)(K - 1 == kInc);
+            FastBatch const nxt = batch_load(src, n, nip0, step, nstep, rep1);
+
+            // exact groups of lanes with equal hash (scratch collisions of different hashes give 1-lane groups)
+            unsigned long long grp = 0;
+            unsigned long long ML = __ballot(loser);
+            while (ML) {
+                int const j = first_lane(ML);
+                uint32_t const hj = __builtin_amdgcn_readlane(h, j);
+                unsigned long long const G = __ballot(live && h == hj);
+                if (h == hj) grp = G;
+                ML &= ~G;
             }
-            if (evKind == 0) break;
+            unsigned long long const prevMask = grp & below_mask(lane);
+            int const pd = prevMask ? 63 - __clzll((long long)prevMask) : lane;        // closest earlier lane, same hash
+            uint32_t const dpos = __shfl(pos, pd), d32 = __shfl(cur32, pd);
+            bool const hasDup = prevMask != 0;
+            uint32_t const cand = hasDup ? dpos : old;
+            uint32_t cb = d32;
+            if (!hasDup && old != 0) cb = ld32(src + old);
+            bool const hit = live && cand != 0 && cb == cur32;
+            bool const repHit = live && (lane & 1) == 0 && rep1 > 0 && (uint32_t)cur.rbytes == cur.rv;
+            unsigned long long const mMask = __ballot(hit), rMask = __ballot(repHit);
+            int const jm = mMask ? first_lane(mMask) : 64, jr = rMask ? first_lane(rMask) : 64;
+            int const rankM = jm < 64 ? 3 * (jm >> 1) + 1 + (jm & 1) : 0x7fffffff;
+            int const rankR = jr < 64 ? 3 * (jr >> 1) : 0x7fffffff;
+            int Lcommit;
+            if (rankR < rankM)      { evKind = 2; Lcommit = jr + 2; }
+            else if (jm < 64)       { evKind = 1; Lcommit = (jm & 1) ? jm + 1 : jm + 2; }
+            else                    { evKind = 0; Lcommit = nLanes; }
+            // inserts of the iterations before the event, in lane order: the last lane of each hash group wins
+            bool const lastOfGroup = (grp & below_mask(Lcommit) & ~below_mask(lane + 1)) == 0;
+            if (lane < Lcommit && lastOfGroup) tab_put(T, h, pos);
+            __builtin_amdgcn_wave_barrier();
 
-            // ---- _offset / _match (:377-401)
-            uint32_t mLength, offBase, match0;
-            ip0 = evPos;
             if (evKind == 1) {
-                match0 = evCand;
-                rep2 = rep1; rep1 = ip0 - match0;
-                offBase = rep1 + 3;
-                uint32_t const lim = (ip0 - anchor) < match0 ? (ip0 - anchor) : match0;
-                uint32_t const backLen = wave_count_back(src, ip0, match0, lim);
-                ip0 -= backLen; match0 -= backLen;
-                mLength = 4 + backLen;
-            } else {
-                match0 = ip0 - rep1;
-                uint32_t const b1 = uni((uint32_t)(src[ip0 - 1] == src[match0 - 1]));
-                ip0 -= b1; match0 -= b1;
-                offBase = 1;
-                mLength = 4 + b1;
+                mpos = __builtin_amdgcn_readlane(pos, jm);
+                cand0 = __builtin_amdgcn_readlane(cand, jm);
+                cur0 = mpos;
+                if ((jm & 1) && step <= 4) {                                 // :318-324 hashTable[hash1] = ip1 (= A_{k+1})
+                    uint64_t const rb = readlane64(cur.rbytes, jm - 1);
+                    uint32_t const rp = __builtin_amdgcn_readlane(rpos, jm - 1);
+                    if (lane == 0) tab_put(T, hash_pos(rb, hlog, mls), rp);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                break;
             }
-            mLength += wave_count_fwd(src, ip0 + mLength, match0 + mLength, n);
+            if (evKind == 2) {
+                mpos = __builtin_amdgcn_readlane(rpos, jr);
+                cur0 = __builtin_amdgcn_readlane(pos, jr);
+                break;
+            }
+            // no event in this batch: advance like the end of iteration K-1 (:336-348)
+            ip0 = nip0; g0 = step;
+            if (K - 1 == kEnd) break;                                        // ip3 >= ilimit: unit finished
+            if (K - 1 == kInc) { step++; nextStep += 128; }
+            cur = nxt;
+        }
+        if (evKind == 0) break;
+
+        // ---- _offset / _match (:377-401)
+        uint32_t offBase, lim;
+        if (evKind == 1) {
+            rep2 = rep1; rep1 = mpos - cand0;
+            offBase = rep1 + 3;
+            lim = (mpos - anchor) < cand0 ? (mpos - anchor) : cand0;
+        } else {
+            cand0 = mpos - rep1;
+            offBase = 1;
+            lim = 1;                                                         // :271 mLength = ip0[-1] == match0[-1]
+        }
+        uint64_t const bA = (lane == 0) ? ld64(src + cur0 + 2) : 0;          // for the insert of current0+2 (:407)
+        uint32_t backLen, fwdLen;
+        wave_extend(src, n, mpos, cand0, lim, backLen, fwdLen);
+        ip0 = mpos - backLen;
+        {   uint32_t const mLength = 4 + backLen + fwdLen;
             store_seq(out, ip0 - anchor, offBase, mLength);
             ip0 += mLength; anchor = ip0;
+        }
 
-            // ---- :403-420 complementary inserts + immediate repcode
-            if ((int32_t)ip0 <= ilimit) {
-                uint32_t const pA = cur0 + 2, pB = ip0 - 2;
-                uint64_t const by = ld64(src + (lane == 0 ? pA : pB));
-                uint32_t const hh = hash_pos(by, hlog, mls);
-                if (lane == 0) lds_put(T, hh, pA);
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 1) lds_put(T, hh, pB);
-                __builtin_amdgcn_wave_barrier();
-                if (rep2 > 0) {
-                    while ((int32_t)ip0 <= ilimit) {
-                        uint64_t const b0 = ld64(src + ip0);
-                        if ((uint32_t)b0 != ld32(src + ip0 - rep2)) break;
-                        uint32_t const rLength = wave_count_fwd(src, ip0 + 4, ip0 + 4 - rep2, n) + 4;
-                        uint32_t const t = rep2; rep2 = rep1; rep1 = t;
-                        if (lane == 0) lds_put(T, hash_pos(b0, hlog, mls), ip0);
-                        __builtin_amdgcn_wave_barrier();
-                        ip0 += rLength;
-                        store_seq(out, 0, 1, rLength);
-                        anchor = ip0;
-                    }
+        // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along
+        if ((int32_t)ip0 <= ilimit) {
+            uint64_t const bB = (lane == 1) ? ld64(src + ip0 - 2) : 0;
+            bool first = true;
+            for (;;) {
+                uint32_t same = 0;
+                if (rep2 > 0) same = lane_same_fwd(src, ip0 + 8u * (uint32_t)lane, rep2, n);
+                FastBatch const nxt = batch_load(src, n, ip0, stepSize, stepSize, rep1);
+                if (first) {
+                    uint64_t const by = lane == 0 ? bA : bB;
+                    uint32_t const hh = hash_pos(by, hlog, mls);
+                    if (lane == 0) tab_put(T, hh, cur0 + 2);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 1) tab_put(T, hh, ip0 - 2);
+                    __builtin_amdgcn_wave_barrier();
+                    first = false;
                 }
+                uint32_t rLength = 0;
+                if (rep2 > 0) {
+                    unsigned long long const stop = __ballot(same < 8);
+                    if (stop) { int const f = first_lane(stop); rLength = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+                    else rLength = 512 + wave_count_fwd(src, ip0 + 512, ip0 + 512 - rep2, n);
+                }
+                if (rLength < 4) { cur = nxt; have = true; break; }          // :411 MEM_read32(ip0) != MEM_read32(ip0 - rep2)
+                {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
+                if (lane == 0) tab_put(T, hash_pos(ld64(src + ip0), hlog, mls), ip0);
+                __builtin_amdgcn_wave_barrier();
+                ip0 += rLength;
+                store_seq(out, 0, 1, rLength);
+                anchor = ip0;
+                if ((int32_t)ip0 > ilimit) break;
             }
         }
     }
