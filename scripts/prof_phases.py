@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""scripts/prof_phases.py — measurement helper (not product): builds zstd_amd/libzstd_hip_prof.so (-DZHIP_PROF) and prints
+the per-phase s_memtime breakdown of k_parse_fast / k_entropy on the bench workload.  Build part runs anywhere
+(`python scripts/prof_phases.py build`), the measurement needs a GPU."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "zstd_amd", "libzstd_hip_prof.so")
+
+
+def build():
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZHIP_PROF",
+           "-Wno-unused-result", os.path.join(ROOT, "zstd_amd", "csrc", "zhip_lib.hip"), "-o", LIB]
+    subprocess.check_call(cmd)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+        return
+    import torch
+    import zstd_amd
+    zstd_amd.LIB_PATH = LIB
+    L = zstd_amd.lib()
+    mib = int(os.environ.get("MIB", "1024"))
+    level = int(os.environ.get("LEVEL", "1"))
+    n = mib << 20
+    host = zstd_amd.datagen(n, 50, seed=0, stream_mode=True)
+    dev = torch.device("cuda", 0)
+    src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    src[:n].copy_(torch.from_numpy(host))
+    cap = zstd_amd.compress_bound(n, 131072)
+    dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    ctx = zstd_amd.Context(0, max_units=n // 131072)
+    out = (C.c_ulonglong * 32)()
+    for it in range(3):
+        ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, 131072)
+        L.zhip_prof_read(out, 1)
+    v = list(out)
+    units = n // 131072
+    tm = ctx.timing()
+    names_p = ["init", "front(sched,hash,tab,scratch,spec-loads)", "dup groups+shfl", "cand load+ballots", "decide+commit",
+               "event setup", "extension", "post-match(E2)", "tail"]
+    names_e = ["gather+hist", "huf table build", "huf sizing+hdr", "huf pack", "seq hist+tables", "fse state chains",
+               "seq bit pack", "headers"]
+    res = {"timing_ms": tm, "units": units,
+           "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(9)},
+           "parse_batches_per_unit": v[10] / units, "parse_events_per_unit": v[11] / units,
+           "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)}}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -38,3 +38,20 @@ struct ZhipParse {
     uint32_t rep[3];        // repcode history after the unit
     uint32_t status;        // 0 ok
 };
+
+// ------------------------------------------------------------------ optional phase profiling (scripts/prof_phases.py)
+// Compiled only into the measurement variant of the library (-DZHIP_PROF, zstd_amd/libzstd_hip_prof.so): thread 0 of
+// each workgroup accumulates s_memtime deltas per phase and adds them to g_prof at the end.  The product build
+// expands all of this to nothing.
+#ifdef ZHIP_PROF
+namespace zhip { __device__ unsigned long long g_prof[32]; }
+#define ZPROF_DECL uint64_t zp_last_ = __builtin_amdgcn_s_memtime(); uint64_t zp_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define ZPROF(i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); zp_acc_[i] += t_ - zp_last_; zp_last_ = t_; } while (0)
+#define ZPROF_COUNT(i, v) do { zp_acc_[i] += (uint64_t)(v); } while (0)
+#define ZPROF_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&zhip::g_prof[(base) + i_], (unsigned long long)zp_acc_[i_]); } while (0)
+#else
+#define ZPROF_DECL
+#define ZPROF(i) do { } while (0)
+#define ZPROF_COUNT(i, v) do { } while (0)
+#define ZPROF_FLUSH(base) do { } while (0)
+#endif

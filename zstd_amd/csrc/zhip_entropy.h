@@ -168,6 +168,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     uint32_t const fh = frame_header_size(n);
     uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
     uint32_t const minGainBlock = (n >> 6) + 2;             // zstd_compress_internal.h:613
+    ZPROF_DECL
 
     // ---------------- trivial units: empty frame, or too small to attempt compression (zstd_compress.c:3216, :5270)
     if (n < 7) {
@@ -220,6 +221,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     __syncthreads();
     if (t < 256) sh->hist[0][t] += sh->hist[1][t] + sh->hist[2][t] + sh->hist[3][t];
     __syncthreads();
+    ZPROF(0);
 
     // ---------------- P2: literals section (zstd_compress_literals.c:129-235 with no previous table)
     uint8_t* const litDst = body;
@@ -266,6 +268,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         sh->litMode = mode;
     }
     __syncthreads();
+    ZPROF(1);
     uint32_t litMode = sh->litMode;
     if (litMode == 2) {
         // stream geometry (huf_compress.c:1168-1215): 4 segments of (litSize+3)/4, or one stream
@@ -309,6 +312,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 if (!single) for (int k = 0; k < 3; k++) { uint8_t* jt = litDst + lhSize + sh->hufHdrSize + 2 * k; jt[0] = (uint8_t)sh->streamBytes[k]; jt[1] = (uint8_t)(sh->streamBytes[k] >> 8); }
             }
             __syncthreads();      // zeroing + header byte stores are complete before any atomicOr touches a shared word
+            ZPROF(2);
             // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
             // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
             if ((uint32_t)wv < nStreams) {
@@ -338,6 +342,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         if (litMode == 0) for (uint32_t i = (uint32_t)t; i < litSize; i += ZHIP_ENT_THREADS) litDst[fl + i] = lits[i];
         __syncthreads();
     }
+    ZPROF(3);
     uint32_t const litSection = sh->litSectionSize;
 
     // ---------------- P3: sequences section (zstd_compress.c:2934-2997)
@@ -411,6 +416,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
         }
         __syncthreads();
+        ZPROF(4);
         bool const tblFail = (sh->encType[0] == 9) | (sh->encType[1] == 9) | (sh->encType[2] == 9);
         if (tblFail) rawBlock = true;          // cannot happen for valid histograms; keep the frame valid regardless
         if (!rawBlock) {
@@ -432,6 +438,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 sh->finalState[k] = state;
             }
             __syncthreads();
+            ZPROF(5);
             // per-sequence bit counts -> positions.  Stream order (LSB first): sequence nbSeq-1 first, then nbSeq-2 ...;
             // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra]
             uint32_t const per2 = (nbSeq + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
@@ -490,6 +497,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             for (int k = 0; k < 3; k++) if (sh->encType[k] == 2) lastCount = sh->ncountSize[k];
             if (lastCount && lastCount + streamBytes < 4) rawBlock = true;
             __syncthreads();
+            ZPROF(6);
         }
     }
 
@@ -505,6 +513,8 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
         *outSize = fh + 3 + (rawBlock ? n : cSize);
     }
+    ZPROF(7);
+    ZPROF_FLUSH(16);
 }
 
 }  // namespace zhip

@@ -16,7 +16,15 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
-    parse_fast_unit(src + u.srcOff, u.srcLen, u, smem, seqs + (size_t)ui * ZHIP_SEQ_CAP, metas + ui);
+    const uint8_t* const p = src + u.srcOff;
+    ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
+    switch (u.minMatch) {               // wave-uniform: the hash width is a compile-time constant inside the parser
+    case 5:  parse_fast_unit<5>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    case 6:  parse_fast_unit<6>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    case 7:  parse_fast_unit<7>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    case 8:  parse_fast_unit<8>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    default: parse_fast_unit<4>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    }
 }
 
 // Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's

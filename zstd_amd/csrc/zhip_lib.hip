@@ -332,6 +332,16 @@ size_t zhip_get_sequences(zhip_ctx* c, size_t unitIndex, zhip_Sequence* out, siz
 
 }  // extern "C"
 
+#ifdef ZHIP_PROF
+// measurement variant only: sums of per-phase s_memtime ticks over all workgroups since the last reset
+extern "C" void zhip_prof_read(unsigned long long out[32], int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zhip::g_prof), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[32]; memset(z, 0, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(zhip::g_prof), z, sizeof(z)); }
+}
+#endif
+
 // ------------------------------------------------------------------ block-level plugin (B1)
 // parse `srcSize` host bytes cut into blockSize blocks (each without history); results copied to the host cache
 static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
