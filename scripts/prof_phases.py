@@ -51,7 +51,10 @@ def main():
     res = {"timing_ms": tm, "units": units,
            "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(9)},
            "parse_batches_per_unit": v[10] / units, "parse_events_per_unit": v[11] / units,
-           "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)}}
+           "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)},
+           "entropy_extra": [round(v[16 + i] / units) for i in range(8, 12)],
+           "phaseB_jobs_ticks_per_unit": {"huf_build_codes": round(v[28] / units), "huf other (mode, write table)": round(v[31] / units),
+                                          "fse table build (sum of 3)": round(v[29] / units), "fse chains (sum of 3)": round(v[30] / units)}}
     print(json.dumps(res, indent=1))
 
 

@@ -139,7 +139,7 @@ UNIT_DT = np.dtype([("srcOff", "<u8"), ("srcLen", "<u4"), ("windowLog", "u1"), (
                     ("targetLength", "<u4")])
 SEQ_DT = np.dtype([("offBase", "<u4"), ("litLength", "<u2"), ("mlBase", "<u2")])
 PARSE_DT = np.dtype([("nbSeq", "<u4"), ("lastLits", "<u4"), ("longPos", "<u4"), ("longType", "<u4"),
-                     ("rep", "<u4", (3,)), ("status", "<u4")])
+                     ("rep", "<u4", (3,)), ("status", "<u4"), ("litSize", "<u4"), ("pad0", "<u4")])
 
 
 def load_emu():
@@ -154,7 +154,8 @@ def load_emu():
     lib = C.CDLL(so)
     assert lib.emu_sizeof_unit() == UNIT_DT.itemsize and lib.emu_sizeof_parse() == PARSE_DT.itemsize
     lib.emu_parse_fast.restype = None
-    lib.emu_parse_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
+    lib.emu_parse_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
+    lib.emu_lit_stride.restype = C.c_uint
     return lib
 
 
@@ -170,8 +171,8 @@ def make_units(lo, sizes, level, unit=131072):
     return units
 
 
-def oracle_parse(lo, a, level):
-    """-> (seqs[nb,3] = litLength, matchLength, offBase ; litSize, rep[3])"""
+def oracle_parse(lo, a, level, want_lits=False):
+    """-> (seqs[nb,3] = litLength, matchLength, offBase ; litSize, rep[3] [, literal bytes])"""
     n = len(a)
     cp = (C.c_uint * 7)()
     assert lo.zo_get_cparams(level, n, cp) == 0
@@ -182,6 +183,8 @@ def oracle_parse(lo, a, level):
     rep = (C.c_uint * 3)()
     nb = lo.zo_parse_block(cp, _buf(a), n, _buf(seqs), cap, _buf(lits), C.byref(litSize), rep)
     assert nb != ERR
+    if want_lits:
+        return seqs[:nb].copy(), litSize.value, list(rep), lits[:litSize.value].copy()
     return seqs[:nb].copy(), litSize.value, list(rep)
 
 
@@ -197,9 +200,9 @@ def emu_compress_units(le, lo, bufs, level):
     seqs = np.zeros(nu * cap, dtype=SEQ_DT)
     metas = np.zeros(nu, dtype=PARSE_DT)
     smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
-    le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), smem, 0)
     ostride, lstride = le.emu_out_stride(), le.emu_lit_stride()
     lits = np.full(nu * lstride, 0xEE, dtype=np.uint8)
+    le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
     stb = np.full(nu * 3 * cap, 0xEEEE, dtype=np.uint16)
     out = np.full(nu * ostride, 0xEE, dtype=np.uint8)
     osz = np.zeros(nu, dtype=np.uint32)

@@ -7,16 +7,16 @@
 extern "C" {
 
 // parse `nUnits` units with the strategy-fast kernel. seqs: nUnits*ZHIP_SEQ_CAP records, metas: nUnits
-void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, ZhipParse* metas,
+void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas,
                     uint32_t smemBytes, int osThreads)
 {
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, smemBytes,
-                 [=] { zhip::k_parse_fast(src, units, nUnits, seqs, metas); }, osThreads);
+                 [=] { zhip::k_parse_fast(src, units, nUnits, seqs, lits, metas); }, osThreads);
 }
 
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
-                 uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)
+                 const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)
 {
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
                  [=] { zhip::k_entropy(src, units, nUnits, seqs, metas, lits, stBits, out, outSize); }, osThreads);

@@ -19,10 +19,13 @@ def emu_parse(le, lo, bufs, level):
     seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT)
     metas = np.zeros(len(bufs), dtype=PARSE_DT)
     smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
-    le.emu_parse_fast(_buf(src), _buf(units), len(bufs), _buf(seqs), _buf(metas), smem, 0)
+    lstride = le.emu_lit_stride()
+    lits = np.full(max(1, len(bufs)) * lstride, 0xEE, dtype=np.uint8)
+    le.emu_parse_fast(_buf(src), _buf(units), len(bufs), _buf(seqs), _buf(lits), _buf(metas), smem, 0)
     out = []
     for i in range(len(bufs)):
         m = metas[i]
+        m_lits = lits[i * lstride: i * lstride + int(m["litSize"])]
         s = seqs[i * cap: i * cap + int(m["nbSeq"])]
         ll = s["litLength"].astype(np.uint32)
         ml = s["mlBase"].astype(np.uint32) + 3
@@ -30,7 +33,7 @@ def emu_parse(le, lo, bufs, level):
             ll[m["longPos"]] += 0x10000
         if m["longType"] == 2:
             ml[m["longPos"]] += 0x10000
-        out.append((np.stack([ll, ml, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32), m))
+        out.append((np.stack([ll, ml, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32), m, m_lits))
     return out
 
 
@@ -38,8 +41,9 @@ def check(le, lo, cases, level):
     names = [c[0] for c in cases]
     bufs = [c[1] for c in cases]
     res = emu_parse(le, lo, bufs, level)
-    for name, a, (seqs, m) in zip(names, bufs, res):
-        oseqs, litSize, rep = oracle_parse(lo, a, level)
+    for name, a, (seqs, m, glits) in zip(names, bufs, res):
+        oseqs, litSize, rep, olits = oracle_parse(lo, a, level, want_lits=True)
+        assert int(m["litSize"]) == litSize and np.array_equal(glits, olits), (name, "literal buffer differs")
         assert len(seqs) == len(oseqs), (name, len(seqs), len(oseqs))
         if len(seqs):
             bad = np.nonzero((seqs != oseqs).any(axis=1))[0]

@@ -37,6 +37,8 @@ struct ZhipParse {
     uint32_t longType;      // 0 none, 1 literal length, 2 match length (zstd_internal.h:296-300)
     uint32_t rep[3];        // repcode history after the unit
     uint32_t status;        // 0 ok
+    uint32_t litSize;       // literals the match finder copied to the unit's literal buffer (incl. lastLits)
+    uint32_t pad0;
 };
 
 // ------------------------------------------------------------------ optional phase profiling (scripts/prof_phases.py)
@@ -49,7 +51,11 @@ namespace zhip { __device__ unsigned long long g_prof[32]; }
 #define ZPROF(i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); zp_acc_[i] += t_ - zp_last_; zp_last_ = t_; } while (0)
 #define ZPROF_COUNT(i, v) do { zp_acc_[i] += (uint64_t)(v); } while (0)
 #define ZPROF_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&zhip::g_prof[(base) + i_], (unsigned long long)zp_acc_[i_]); } while (0)
+#define ZPROF_JOB_BEGIN uint64_t zj_ = __builtin_amdgcn_s_memtime();
+#define ZPROF_JOB_MARK(slot) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&zhip::g_prof[slot], (unsigned long long)(t_ - zj_)); zj_ = t_; } while (0)
 #else
+#define ZPROF_JOB_BEGIN
+#define ZPROF_JOB_MARK(slot) do { } while (0)
 #define ZPROF_DECL
 #define ZPROF(i) do { } while (0)
 #define ZPROF_COUNT(i, v) do { } while (0)

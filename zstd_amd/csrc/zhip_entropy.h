@@ -157,9 +157,35 @@ __device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n)
     op[5] = (uint8_t)n; op[6] = (uint8_t)(n >> 8); op[7] = (uint8_t)(n >> 16); op[8] = (uint8_t)(n >> 24); return 9;
 }
 
+// ------------------------------------------------------------------ wide memory helpers
+__device__ __forceinline__ uint64_t eld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void est64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+// the (at most 8) bytes of src[pos .. n) as a little-endian word, never reading outside src[0 .. n)
+__device__ __forceinline__ uint64_t eld64_in(const uint8_t* src, uint32_t pos, uint32_t n)
+{
+    if (pos + 8 <= n) return eld64(src + pos);
+    if (n >= 8) { uint32_t const sh = pos + 8 - n; return sh >= 8 ? 0 : eld64(src + (n - 8)) >> (8 * sh); }
+    uint64_t v = 0;
+    for (uint32_t i = pos; i < n; i++) v |= (uint64_t)src[i] << (8 * (i - pos));
+    return v;
+}
+__device__ __forceinline__ void hist8(uint32_t* h, uint64_t v, uint32_t cnt)
+{
+    for (uint32_t b = 0; b < cnt; b++) atomicAdd(&h[(uint32_t)(v >> (8 * b)) & 0xFF], 1u);
+}
+
+// one step of an FSE state chain: records (nbBits << 12 | low bits of the state) for symbol `sym`, returns the new state
+__device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t& state, uint32_t sym)
+{
+    uint32_t const nbOut = (state + ct->dBits[sym]) >> 16;
+    uint32_t const rec = (nbOut << 12) | (state & ((1u << nbOut) - 1));
+    state = ct->state[(state >> nbOut) + ct->dFind[sym]];
+    return rec;
+}
+
 // ================================================================== the unit encoder
 __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
-                                    const ZhipParse& pm, uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
+                                    const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
                                     uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh)
 {
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -181,75 +207,64 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         }
         return;
     }
+    uint16_t* const bLL = stBits; uint16_t* const bOF = stBits + ZHIP_SEQ_CAP; uint16_t* const bML = stBits + 2 * (size_t)ZHIP_SEQ_CAP;
 
-    // ---------------- P1: literal gather + histogram.  Thread t owns a contiguous slice of sequences; the pseudo
-    // sequence index nbSeq carries the trailing literals.
+    // ================ phase A (all threads): byte histogram of the literals; sequence codes + code histograms
     for (int i = t; i < 4 * 256; i += ZHIP_ENT_THREADS) (&sh->hist[0][0])[i] = 0;
-    uint32_t const nItems = nbSeq + 1;
-    uint32_t const per = (nItems + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
-    uint32_t const s0 = (uint32_t)t * per, s1 = (s0 + per < nItems) ? s0 + per : nItems;
-    uint32_t sumLL = 0, sumAll = 0;
-    for (uint32_t i = s0; i < s1; i++) {
-        uint32_t ll, mlb, ob;
-        if (i < nbSeq) { seq_fields(seqs, pm, i, ll, mlb, ob); sumLL += ll; sumAll += ll + mlb + 3; }
-        else { sumLL += pm.lastLits; sumAll += pm.lastLits; }
-    }
-    uint32_t litSize, totAll;
-    uint32_t litOff = block_excl_scan(sh, sumLL, &litSize);
-    uint32_t srcPos = block_excl_scan(sh, sumAll, &totAll);
-    {   // each lane walks its slice; short literal runs are copied by the lane, long ones by the whole wavefront
-        uint32_t* const myHist = sh->hist[wv];
-        for (uint32_t k = 0; k < per; k++) {
-            uint32_t const i = s0 + k;
-            uint32_t ll = 0, adv = 0;
-            if (i < s1) {
-                uint32_t mlb, ob;
-                if (i < nbSeq) { seq_fields(seqs, pm, i, ll, mlb, ob); adv = ll + mlb + 3; }
-                else { ll = pm.lastLits; adv = ll; }
-            }
-            bool const isLong = ll > 32;
-            if (!isLong) for (uint32_t j = 0; j < ll; j++) { uint8_t const b = src[srcPos + j]; lits[litOff + j] = b; atomicAdd(&myHist[b], 1u); }
-            unsigned long long longMask = __ballot(isLong);
-            while (longMask) {
-                int const L = __ffsll((long long)longMask) - 1; longMask &= longMask - 1;
-                uint32_t const sp = __shfl(srcPos, L), lo = __shfl(litOff, L), len = __shfl(ll, L);
-                for (uint32_t j = (uint32_t)lane; j < len; j += 64) { uint8_t const b = src[sp + j]; lits[lo + j] = b; atomicAdd(&myHist[b], 1u); }
-            }
-            srcPos += adv; litOff += ll;
+    for (int i = t; i < 3 * 64; i += ZHIP_ENT_THREADS) (&sh->seqCount[0][0])[i] = 0;
+    __syncthreads();
+    // byte histogram of the literals the match finder left in lits[] (HIST_count_wksp, hist.c:154): 16 bytes per thread
+    // per step, coalesced; one histogram per wavefront to spread the LDS atomics
+    uint32_t const litSize = pm.litSize;
+    {   uint32_t* const myHist = sh->hist[wv];
+        for (uint32_t i = 16u * (uint32_t)t; i < litSize; i += 16u * ZHIP_ENT_THREADS) {
+            uint4 v; __builtin_memcpy(&v, lits + i, 16);                  // lits has >= 64 bytes of slack
+            uint32_t const c = litSize - i < 16 ? litSize - i : 16;
+            uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            for (uint32_t b = 0; b < 16; b++) if (b < c) atomicAdd(&myHist[(w[b >> 2] >> (8 * (b & 3))) & 0xFF], 1u);
         }
     }
-    __syncthreads();
-    if (t < 256) sh->hist[0][t] += sh->hist[1][t] + sh->hist[2][t] + sh->hist[3][t];
-    __syncthreads();
-    ZPROF(0);
-
-    // ---------------- P2: literals section (zstd_compress_literals.c:129-235 with no previous table)
+    ZPROF(9);
+    // sequence codes (zstd_compress.c:2686-2712) -> stBits arrays (replaced by the FSE records in phase B) + histograms
+    for (uint32_t i = (uint32_t)t; i < nbSeq; i += ZHIP_ENT_THREADS) {
+        uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
+        uint32_t const llc = ll_code(ll), ofc = hb32(ob), mlc = ml_code(mlb);
+        bLL[i] = (uint16_t)llc; bOF[i] = (uint16_t)ofc; bML[i] = (uint16_t)mlc;
+        atomicAdd(&sh->seqCount[0][llc], 1u);
+        atomicAdd(&sh->seqCount[1][ofc], 1u);
+        atomicAdd(&sh->seqCount[2][mlc], 1u);
+    }
+    // literals-section geometry and the sampling heuristic's two histograms (huf_compress.c:1367-1379)
+    ZPROF(10);
     uint8_t* const litDst = body;
     uint32_t const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     bool const single = litSize < 256;
-    bool tryHuf = !(u.litMode) && litSize >= 64;            // minLiteralsToCompress = 8 << min(9-strategy,3) for fast/dfast
-    if (tryHuf) {
-        // suspect-uncompressible sampling (huf_compress.c:1367-1379); flag from zstd_compress.c:2918
-        bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-        if (suspect && litSize >= 40960) {
-            for (int i = t; i < 512; i += ZHIP_ENT_THREADS) (&sh->sampleHist[0][0])[i] = 0;
-            __syncthreads();
-            for (uint32_t i = (uint32_t)t; i < 4096; i += ZHIP_ENT_THREADS) {
-                atomicAdd(&sh->sampleHist[0][lits[i]], 1u);
-                atomicAdd(&sh->sampleHist[1][lits[litSize - 4096 + i]], 1u);
-            }
-            __syncthreads();
-            if (t == 0) {
-                uint32_t a = 0, b = 0;
-                for (int s = 0; s < 256; s++) { if (sh->sampleHist[0][s] > a) a = sh->sampleHist[0][s]; if (sh->sampleHist[1][s] > b) b = sh->sampleHist[1][s]; }
-                sh->failRaw = (a + b <= ((2 * 4096) >> 7) + 4);
-            }
-            __syncthreads();
-            if (sh->failRaw) tryHuf = false;
-            __syncthreads();
+    bool const tryHuf0 = !(u.litMode) && litSize >= 64;     // minLiteralsToCompress = 8 << min(9-strategy,3) for fast/dfast
+    bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);                      // zstd_compress.c:2918
+    bool const sampling = tryHuf0 && suspect && litSize >= 40960;
+    if (sampling) for (int i = t; i < 512; i += ZHIP_ENT_THREADS) (&sh->sampleHist[0][0])[i] = 0;
+    __syncthreads();                                        // lits[] complete, histograms complete
+    if (t < 256) sh->hist[0][t] += sh->hist[1][t] + sh->hist[2][t] + sh->hist[3][t];
+    if (sampling) {
+        for (uint32_t i = (uint32_t)t; i < 4096; i += ZHIP_ENT_THREADS) {
+            atomicAdd(&sh->sampleHist[0][lits[i]], 1u);
+            atomicAdd(&sh->sampleHist[1][lits[litSize - 4096 + i]], 1u);
         }
     }
-    if (t == 0) {
+    __syncthreads();
+    ZPROF(0);
+
+    // ================ phase B (four single lanes, concurrently): wave 0 builds the literals code, waves 1..3 select
+    // and build one sequence table each (LL, OF, ML) and then run that table's state chain
+    if (lane == 0 && wv == 0) {
+        // literals (zstd_compress_literals.c:129-235 with no previous table)
+        ZPROF_JOB_BEGIN
+        bool tryHuf = tryHuf0;
+        if (sampling) {
+            uint32_t a = 0, b = 0;
+            for (int s = 0; s < 256; s++) { if (sh->sampleHist[0][s] > a) a = sh->sampleHist[0][s]; if (sh->sampleHist[1][s] > b) b = sh->sampleHist[1][s]; }
+            if (a + b <= ((2 * 4096) >> 7) + 4) tryHuf = false;
+        }
         uint32_t mode = 0;      // raw
         sh->hufHdrSize = 0;
         if (tryHuf) {
@@ -260,21 +275,99 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             else if (largest <= (litSize >> 7) + 4) mode = 0;                        // :1384
             else {
                 uint32_t huffLog = fse_optimal_table_log(11, litSize, maxSym, 1);    // :1284-1287
+                ZPROF_JOB_MARK(31);
                 huffLog = huf_build_codes(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
+                ZPROF_JOB_MARK(28);
                 uint32_t const h = huf_write_table(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
                 if (h != 0 && h + 12 < litSize) { mode = 2; sh->hufHdrSize = h; sh->huffLog = huffLog; }   // :1425
             }
         }
         sh->litMode = mode;
+        ZPROF_JOB_MARK(31);
+    }
+    if (lane == 0 && wv >= 1 && nbSeq > 0) {
+        ZPROF_JOB_BEGIN
+        int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
+        uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
+        uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
+        uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
+        const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
+        uint16_t* const arr = stBits + (size_t)k * ZHIP_SEQ_CAP;
+        uint32_t* cnt = sh->seqCount[k];
+        uint32_t max = maxPossible, mostFrequent = 0;
+        while (!cnt[max]) max--;
+        for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
+        bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
+        // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
+        uint32_t type;
+        if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+        else {
+            type = 2;
+            if (defaultAllowed) {
+                uint32_t const mult = 10 - u.strategy;
+                uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
+                if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
+            }
+        }
+        uint32_t const lastCode = arr[nbSeq - 1];                  // for the "-1" rule (zstd_compress_sequences.c:271-274)
+        uint32_t hsz = 0; bool fail = false;
+        if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
+            fse_build_ctable_rle(&sh->ct[k], max);
+            sh->ncount[k][0] = (uint8_t)arr[0];
+            hsz = 1;
+        } else if (type == 0) {
+            for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
+            fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
+        } else {
+            uint32_t nbSeq1 = nbSeq;
+            uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
+            if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
+            if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
+            else {
+                hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
+                if (!hsz) fail = true;
+                else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
+            }
+        }
+        sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
+        ZPROF_JOB_MARK(29);
+        if (!fail) {
+            // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
+            // becomes (nbBits << 12 | value).  Codes are read four at a time, one group ahead of their use.
+            const FseCTable* ct = &sh->ct[k];
+            uint32_t state = fse_init_state2(ct, lastCode);
+            uint32_t i = nbSeq - 1;
+            while (i & 3) { i--; arr[i] = (uint16_t)fse_chain_step(ct, state, arr[i]); }
+            if (i) {
+                unsigned long long cur4; __builtin_memcpy(&cur4, arr + (i - 4), 8);
+                while (i) {
+                    i -= 4;
+                    unsigned long long nxt4 = 0;
+                    if (i) __builtin_memcpy(&nxt4, arr + (i - 4), 8);
+                    unsigned long long res = 0;
+                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 48) & 0xFFFF) << 48;
+                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 32) & 0xFFFF) << 32;
+                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 16) & 0xFFFF) << 16;
+                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)cur4 & 0xFFFF);
+                    __builtin_memcpy(arr + i, &res, 8);
+                    cur4 = nxt4;
+                }
+            }
+            sh->finalState[k] = state;
+        }
+        ZPROF_JOB_MARK(30);
     }
     __syncthreads();
     ZPROF(1);
+
+    // ================ phase C: literals section
     uint32_t litMode = sh->litMode;
     if (litMode == 2) {
         // stream geometry (huf_compress.c:1168-1215): 4 segments of (litSize+3)/4, or one stream
         uint32_t const nStreams = single ? 1 : 4;
         uint32_t const seg = single ? litSize : (litSize + 3) / 4;
-        // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols.
+        // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols, read 8 at a time
+        // (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so an 8-byte read may run past the run).
         uint32_t myBits = 0, segStart = 0, segLen = 0, runStart = 0, runLen = 0;
         if ((uint32_t)wv < nStreams) {
             segStart = (uint32_t)wv * seg;
@@ -283,7 +376,11 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             runStart = (uint32_t)lane * rper; if (runStart > segLen) runStart = segLen;
             runLen = (runStart + rper <= segLen) ? rper : segLen - runStart;
             const uint8_t* p = lits + segStart + runStart;
-            for (uint32_t i = 0; i < runLen; i++) myBits += sh->code[p[i]] & 0xFF;
+            for (uint32_t i = 0; i < runLen; i += 8) {
+                uint64_t const v = eld64(p + i);
+                uint32_t const c = runLen - i < 8 ? runLen - i : 8;
+                for (uint32_t b = 0; b < c; b++) myBits += sh->code[(uint32_t)(v >> (8 * b)) & 0xFF] & 0xFF;
+            }
         }
         uint32_t const incl = wave_incl_scan(myBits);
         uint32_t const total = __shfl(incl, 63);
@@ -321,7 +418,17 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
                 RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total - incl));
                 const uint8_t* p = lits + segStart + runStart;
-                for (uint32_t i = runLen; i-- > 0; ) { uint32_t const c = sh->code[p[i]]; pk.add(c >> 8, c & 0xFF); }
+                uint32_t i = runLen;
+                uint32_t const headCnt = runLen & 7;                  // the run is consumed from its end in 8-byte groups
+                while (i > headCnt) {
+                    i -= 8;
+                    uint64_t const v = eld64(p + i);
+                    for (int b = 7; b >= 0; b--) { uint32_t const c = sh->code[(uint32_t)(v >> (8 * b)) & 0xFF]; pk.add(c >> 8, c & 0xFF); }
+                }
+                if (headCnt) {
+                    uint64_t const v = eld64(p);
+                    for (int b = (int)headCnt - 1; b >= 0; b--) { uint32_t const c = sh->code[(uint32_t)(v >> (8 * b)) & 0xFF]; pk.add(c >> 8, c & 0xFF); }
+                }
                 if (lane == 0) pk.add(1, 1);              // lane 0 holds the FIRST symbols = the end of the stream: end mark
                 pk.finish();
             }
@@ -345,7 +452,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     ZPROF(3);
     uint32_t const litSection = sh->litSectionSize;
 
-    // ---------------- P3: sequences section (zstd_compress.c:2934-2997)
+    // ---------------- sequences section (zstd_compress.c:2934-2997)
     uint8_t* const seqDst = body + litSection;
     uint32_t nbHdr = (nbSeq < 128) ? 1 : (nbSeq < 0x7F00 ? 2 : 3);
     if (t == 0) {
@@ -353,98 +460,17 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         else if (nbSeq < 0x7F00) { seqDst[0] = (uint8_t)((nbSeq >> 8) + 0x80); seqDst[1] = (uint8_t)nbSeq; }
         else { seqDst[0] = 0xFF; seqDst[1] = (uint8_t)(nbSeq - 0x7F00); seqDst[2] = (uint8_t)((nbSeq - 0x7F00) >> 8); }
     }
-    __syncthreads();
     uint32_t seqSection = nbHdr;
     bool rawBlock = false;
     if (nbSeq > 0) {
-        // code histograms (zstd_compress.c:2686-2712 + HIST_countFast)
-        for (int i = t; i < 3 * 64; i += ZHIP_ENT_THREADS) (&sh->seqCount[0][0])[i] = 0;
-        __syncthreads();
-        for (uint32_t i = (uint32_t)t; i < nbSeq; i += ZHIP_ENT_THREADS) {
-            uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
-            atomicAdd(&sh->seqCount[0][ll_code(ll)], 1u);
-            atomicAdd(&sh->seqCount[1][hb32(ob)], 1u);
-            atomicAdd(&sh->seqCount[2][ml_code(mlb)], 1u);
-        }
-        __syncthreads();
-        // table selection + construction: lane 0 of wavefronts 0,1,2 each build one table
-        if (lane == 0 && wv < 3) {
-            int const k = wv;                                      // 0 LL, 1 OF, 2 ML
-            uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
-            uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
-            uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
-            const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
-            uint32_t* cnt = sh->seqCount[k];
-            uint32_t max = maxPossible, mostFrequent = 0;
-            while (!cnt[max]) max--;
-            for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
-            bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
-            // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
-            uint32_t type;
-            if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
-            else {
-                type = 2;
-                if (defaultAllowed) {
-                    uint32_t const mult = 10 - u.strategy;
-                    uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
-                    if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
-                }
-            }
-            // last sequence's code for the "-1" rule (zstd_compress_sequences.c:271-274)
-            uint32_t ll, mlb, ob; seq_fields(seqs, pm, nbSeq - 1, ll, mlb, ob);
-            uint32_t const lastCode = (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb));
-            uint32_t hsz = 0; bool fail = false;
-            if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
-                fse_build_ctable_rle(&sh->ct[k], max);
-                uint32_t l0, m0, o0; seq_fields(seqs, pm, 0, l0, m0, o0);
-                sh->ncount[k][0] = (uint8_t)((k == 0) ? ll_code(l0) : (k == 1 ? hb32(o0) : ml_code(m0)));
-                hsz = 1;
-            } else if (type == 0) {
-                for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
-                fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
-            } else {
-                uint32_t nbSeq1 = nbSeq;
-                uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
-                if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
-                if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
-                else {
-                    hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
-                    if (!hsz) fail = true;
-                    else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
-                }
-            }
-            sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
-        }
-        __syncthreads();
-        ZPROF(4);
         bool const tblFail = (sh->encType[0] == 9) | (sh->encType[1] == 9) | (sh->encType[2] == 9);
         if (tblFail) rawBlock = true;          // cannot happen for valid histograms; keep the frame valid regardless
         if (!rawBlock) {
-            // the three FSE state chains, last sequence -> first (zstd_compress_sequences.c:311-369): lane 0 of
-            // wavefronts 0..2 walk one table each and record (nbBits << 12 | value) per sequence.
-            if (lane == 0 && wv < 3) {
-                int const k = wv;
-                const FseCTable* ct = &sh->ct[k];
-                uint16_t* dstBits = stBits + (size_t)k * ZHIP_SEQ_CAP;
-                uint32_t ll, mlb, ob; seq_fields(seqs, pm, nbSeq - 1, ll, mlb, ob);
-                uint32_t state = fse_init_state2(ct, (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb)));
-                for (uint32_t i = nbSeq - 1; i-- > 0; ) {
-                    seq_fields(seqs, pm, i, ll, mlb, ob);
-                    uint32_t const sym = (k == 0) ? ll_code(ll) : (k == 1 ? hb32(ob) : ml_code(mlb));
-                    uint32_t const nbOut = (state + ct->dBits[sym]) >> 16;
-                    dstBits[i] = (uint16_t)((nbOut << 12) | (state & ((1u << nbOut) - 1)));
-                    state = ct->state[(state >> nbOut) + ct->dFind[sym]];
-                }
-                sh->finalState[k] = state;
-            }
-            __syncthreads();
-            ZPROF(5);
             // per-sequence bit counts -> positions.  Stream order (LSB first): sequence nbSeq-1 first, then nbSeq-2 ...;
             // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra]
             uint32_t const per2 = (nbSeq + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
             uint32_t const a0 = (uint32_t)t * per2 < nbSeq ? (uint32_t)t * per2 : nbSeq;
             uint32_t const a1 = a0 + per2 < nbSeq ? a0 + per2 : nbSeq;
-            const uint16_t* bLL = stBits; const uint16_t* bOF = stBits + ZHIP_SEQ_CAP; const uint16_t* bML = stBits + 2 * (size_t)ZHIP_SEQ_CAP;
             uint32_t myBits = 0;
             for (uint32_t i = a0; i < a1; i++) {
                 uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
@@ -501,7 +527,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         }
     }
 
-    // ---------------- P4: block + frame headers (zstd_compress.c:3026, :4582-4590)
+    // ---------------- block + frame headers (zstd_compress.c:3026, :4582-4590)
     uint32_t const cSize = litSection + seqSection;
     if (cSize >= n - minGainBlock) rawBlock = true;
     if (rawBlock) {

@@ -10,7 +10,7 @@ namespace zhip {
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
 __global__ void __launch_bounds__(64)
 k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
-             ZhipSeq* __restrict__ seqs, ZhipParse* __restrict__ metas)
+             ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
@@ -18,12 +18,13 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     ZhipUnit const u = units[ui];
     const uint8_t* const p = src + u.srcOff;
     ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
+    uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
     switch (u.minMatch) {               // wave-uniform: the hash width is a compile-time constant inside the parser
-    case 5:  parse_fast_unit<5>(p, u.srcLen, u, smem, sq, metas + ui); break;
-    case 6:  parse_fast_unit<6>(p, u.srcLen, u, smem, sq, metas + ui); break;
-    case 7:  parse_fast_unit<7>(p, u.srcLen, u, smem, sq, metas + ui); break;
-    case 8:  parse_fast_unit<8>(p, u.srcLen, u, smem, sq, metas + ui); break;
-    default: parse_fast_unit<4>(p, u.srcLen, u, smem, sq, metas + ui); break;
+    case 5:  parse_fast_unit<5>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
+    case 6:  parse_fast_unit<6>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
+    case 7:  parse_fast_unit<7>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
+    case 8:  parse_fast_unit<8>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
+    default: parse_fast_unit<4>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
     }
 }
 
@@ -32,7 +33,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
 k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
-          uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize)
+          const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;

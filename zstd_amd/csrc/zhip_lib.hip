@@ -176,7 +176,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
-                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dParse);
+                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     return 0;

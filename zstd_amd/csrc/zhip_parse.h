@@ -167,8 +167,42 @@ __device__ __forceinline__ void wave_extend(const uint8_t* src, uint32_t nm8, ui
 // ------------------------------------------------------------------ the parser
 struct FastOut {
     ZhipSeq* seqs;          // global, capacity ZHIP_SEQ_CAP
+    uint8_t* lits;          // global, the unit's literal buffer (ZHIP_LIT_STRIDE bytes)
     uint32_t nbSeq, longPos, longType;
+    uint32_t litPos;        // literals emitted so far
+    uint64_t pendV;         // per lane: 8 loaded literal bytes of the most recent run, stored at the next call
+    uint32_t pendOff, pendLen;
 };
+
+__device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+// Literal copy (the job of ZSTD_storeSeq's wildcopy, zstd_compress_internal.h:684-700), kept off the parser's
+// critical path: a run's first 512 bytes are LOADED when the sequence is emitted (they are hot in L1/L2: the
+// scan just read them) and STORED at the next call, so nobody waits for the load.  Like the reference's wildcopy the
+// last 8-byte chunk of a run may spill up to 7 bytes past it; the next run (stored later) overwrites them, and the
+// buffer has slack after the last one.
+__device__ __forceinline__ void lits_flush(FastOut& o)
+{
+    uint32_t const lane8 = 8u * (uint32_t)lane_id();
+    if (lane8 < o.pendLen) st64(o.lits + o.pendOff + lane8, o.pendV);
+    o.pendLen = 0;
+    __builtin_amdgcn_wave_barrier();        // later runs overwrite this run's spill: keep the stores in program order
+}
+__device__ __forceinline__ void lits_copy(FastOut& o, const uint8_t* src, uint32_t nm8, uint32_t from, uint32_t len)
+{
+    lits_flush(o);
+    if (len == 0) return;
+    uint32_t const lane8 = 8u * (uint32_t)lane_id();
+    {   uint32_t const q = from + lane8, qc = q < nm8 ? q : nm8, sh = q - qc;      // sh <= 7 whenever lane8 < len
+        if (lane8 < len) o.pendV = ld64(src + qc) >> (8 * (sh & 7));
+        o.pendOff = o.litPos; o.pendLen = len < 512 ? len : 512;
+    }
+    for (uint32_t off = 512; off < len; off += 512) {
+        uint32_t const q = from + off + lane8, qc = q < nm8 ? q : nm8, sh = q - qc;
+        if (off + lane8 < len) st64(o.lits + o.litPos + off + lane8, ld64(src + qc) >> (8 * (sh & 7)));
+    }
+    o.litPos += len;
+}
 
 __device__ __forceinline__ void store_seq(FastOut& o, uint32_t litLength, uint32_t offBase, uint32_t matchLength)
 {   // zstd_compress_internal.h:671-728 minus the literal copy (literals are gathered by the entropy kernel)
@@ -210,12 +244,13 @@ __device__ __forceinline__ FastBatch batch_load(const uint8_t* src, uint32_t nm8
 // smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
 template <uint32_t MLS>
 __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
-                                       unsigned char* smem, ZhipSeq* seqs, ZhipParse* meta)
+                                       unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const hlog = u.hashLog, hshift = 32 - hlog;
     uint32_t const stepSize = u.targetLength + !u.targetLength + 1;         // zstd_fast.c:200
-    FastOut out; out.seqs = seqs; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
+    FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
+    out.litPos = 0; out.pendV = 0; out.pendOff = 0; out.pendLen = 0;
     ZPROF_DECL
 
     FastTab T;
@@ -378,6 +413,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         ZPROF_COUNT(11, 1);
         ip0 = mpos - backLen;
         {   uint32_t const mLength = 4 + backLen + fwdLen;
+            lits_copy(out, src, nm8, anchor, ip0 - anchor);
             store_seq(out, ip0 - anchor, offBase, mLength);
             ip0 += mLength; anchor = ip0;
         }
@@ -424,6 +460,11 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         }
         ZPROF(7);
     }
+    lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
+    lits_flush(out);
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];           // tiny unit: everything is a literal
+        out.litPos = n;
     }
     // ---- _cleanup (:368-375)
     ZPROF(8);
@@ -433,7 +474,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
         meta->longPos = out.longPos; meta->longType = out.longType;
         meta->rep[0] = rep1 ? rep1 : saved1; meta->rep[1] = rep2 ? rep2 : saved2; meta->rep[2] = 8;
-        meta->status = 0;
+        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
     }
 }
 
