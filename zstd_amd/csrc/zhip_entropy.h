@@ -35,8 +35,10 @@ __device__ static const uint8_t kMLcode[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13
     40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
     42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
 
-__device__ __forceinline__ uint32_t ll_code(uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : kLLcode[ll]; }          // internal.h:520
-__device__ __forceinline__ uint32_t ml_code(uint32_t mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : kMLcode[mlBase]; }   // :537
+// the four small tables are copied to LDS once per workgroup (a lookup in the global copy costs an HBM/L2 round trip)
+struct CodeTabs { uint8_t llCode[64]; uint8_t mlCode[128]; uint8_t llBits[36]; uint8_t mlBits[56]; };
+__device__ __forceinline__ uint32_t ll_code(const CodeTabs& T, uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : T.llCode[ll]; }          // internal.h:520
+__device__ __forceinline__ uint32_t ml_code(const CodeTabs& T, uint32_t mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : T.mlCode[mlBase]; }   // :537
 
 // ------------------------------------------------------------------ LDS layout of the workgroup
 struct EntShared {
@@ -48,6 +50,7 @@ struct EntShared {
     int16_t  norm[3][56];
     FseCTable ct[3];              // LL, OF, ML
     uint8_t  symScratch[3][512];
+    alignas(8) uint16_t chainTile[3][256];   // LDS window of the code / state-record arrays while a chain walks it
     uint16_t cumul[3][64];
     uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
     uint32_t ncountSize[3];
@@ -61,6 +64,7 @@ struct EntShared {
     uint32_t streamBits[4], streamBytes[4], streamOff[4];
     uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
     uint32_t sampleHist[2][256];
+    CodeTabs tabs;
 };
 
 // ------------------------------------------------------------------ small block-wide helpers
@@ -113,33 +117,34 @@ __device__ __forceinline__ void or_bits(uint32_t* w32, uint64_t bitpos, uint64_t
     }
 }
 
-// A per-lane LSB-first packer that owns the bit range [start, start+len) of a shared bit string in global memory.
-// First and last (partial) words go through atomicOr, full interior words through plain stores.
+// A per-lane LSB-first packer that owns the bit range [start, start+len) of a shared bit string in global memory
+// (words zeroed beforehand).  The accumulator starts with (start & 31) zero bits, so every flush is a whole 32-bit word
+// at a word-aligned position: the first and the last (partial) words are shared with the neighbouring lanes' ranges
+// and go through atomicOr, the words in between are plain stores.  add() takes at most 31 bits.
 struct RunPacker {
-    uint32_t* w32; uint64_t pos; uint64_t acc; uint32_t nb; bool first;
-    __device__ __forceinline__ void init(uint32_t* base, uint64_t startBit) { w32 = base; pos = startBit; acc = 0; nb = 0; first = true; }
-    __device__ __forceinline__ void flushWords()
+    uint32_t* wp; uint64_t acc; uint32_t nb; bool first;
+    __device__ __forceinline__ void init(uint32_t* base, uint64_t startBit) { wp = base + (startBit >> 5); nb = (uint32_t)startBit & 31; acc = 0; first = true; }
+    __device__ __forceinline__ void add(uint32_t v, uint32_t n)
     {
-        // emit while a full 32-bit word boundary can be crossed
-        while (true) {
-            uint32_t const sh = (uint32_t)(pos & 31);
-            uint32_t const room = 32 - sh;
-            if (nb < room) break;
-            uint32_t const chunk = (uint32_t)(acc & (room == 32 ? 0xFFFFFFFFu : ((1u << room) - 1)));
-            uint32_t* p = w32 + (pos >> 5);
-            if (first || sh) atomicOr(p, chunk << sh); else *p = chunk;
-            first = false;
-            acc >>= room; nb -= room; pos += room;
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) {
+            if (first) atomicOr(wp, (uint32_t)acc); else *wp = (uint32_t)acc;
+            first = false; wp++; acc >>= 32; nb -= 32;
         }
     }
-    __device__ __forceinline__ void add(uint32_t v, uint32_t n) { acc |= (uint64_t)v << nb; nb += n; if (nb >= 32) flushWords(); }
-    __device__ __forceinline__ void finish() { flushWords(); if (nb) { atomicOr(w32 + (pos >> 5), (uint32_t)acc << (uint32_t)(pos & 31)); pos += nb; nb = 0; acc = 0; } }
+    __device__ __forceinline__ void finish() { if (nb) atomicOr(wp, (uint32_t)acc); nb = 0; acc = 0; }
 };
 
 // ------------------------------------------------------------------ sequence field access
 __device__ __forceinline__ void seq_fields(const ZhipSeq* seqs, const ZhipParse& m, uint32_t i, uint32_t& ll, uint32_t& mlBase, uint32_t& offBase)
 {
     ZhipSeq const s = seqs[i];
+    ll = s.litLength; mlBase = s.mlBase; offBase = s.offBase;
+    if (i == m.longPos) { if (m.longType == 1) ll += 0x10000; else if (m.longType == 2) mlBase += 0x10000; }
+}
+
+__device__ __forceinline__ void seq_unpack(const ZhipSeq& s, const ZhipParse& m, uint32_t i, uint32_t& ll, uint32_t& mlBase, uint32_t& offBase)
+{
     ll = s.litLength; mlBase = s.mlBase; offBase = s.offBase;
     if (i == m.longPos) { if (m.longType == 1) ll += 0x10000; else if (m.longType == 2) mlBase += 0x10000; }
 }
@@ -174,12 +179,14 @@ __device__ __forceinline__ void hist8(uint32_t* h, uint64_t v, uint32_t cnt)
     for (uint32_t b = 0; b < cnt; b++) atomicAdd(&h[(uint32_t)(v >> (8 * b)) & 0xFF], 1u);
 }
 
-// one step of an FSE state chain: records (nbBits << 12 | low bits of the state) for symbol `sym`, returns the new state
-__device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t& state, uint32_t sym)
+// one step of an FSE state chain (FSE_encodeSymbol, lib/common/fse.h:463): returns the record
+// (nbBits << 12 | low bits of the state) and advances the state.  dBits/dFind are the symbol's transform, fetched by
+// the caller ahead of time so that the state-table read is the only LDS access on the dependent path.
+__device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t& state, uint32_t dBits, int32_t dFind)
 {
-    uint32_t const nbOut = (state + ct->dBits[sym]) >> 16;
+    uint32_t const nbOut = (state + dBits) >> 16;
     uint32_t const rec = (nbOut << 12) | (state & ((1u << nbOut) - 1));
-    state = ct->state[(state >> nbOut) + ct->dFind[sym]];
+    state = ct->state[(state >> nbOut) + dFind];
     return rec;
 }
 
@@ -212,23 +219,34 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     // ================ phase A (all threads): byte histogram of the literals; sequence codes + code histograms
     for (int i = t; i < 4 * 256; i += ZHIP_ENT_THREADS) (&sh->hist[0][0])[i] = 0;
     for (int i = t; i < 3 * 64; i += ZHIP_ENT_THREADS) (&sh->seqCount[0][0])[i] = 0;
+    if (t < 64) sh->tabs.llCode[t] = kLLcode[t];
+    if (t < 128) sh->tabs.mlCode[t] = kMLcode[t];
+    if (t < 36) sh->tabs.llBits[t] = kLLbits[t];
+    if (t < 53) sh->tabs.mlBits[t] = kMLbits[t];
+    const CodeTabs& TB = sh->tabs;
     __syncthreads();
     // byte histogram of the literals the match finder left in lits[] (HIST_count_wksp, hist.c:154): 16 bytes per thread
     // per step, coalesced; one histogram per wavefront to spread the LDS atomics
     uint32_t const litSize = pm.litSize;
     {   uint32_t* const myHist = sh->hist[wv];
-        for (uint32_t i = 16u * (uint32_t)t; i < litSize; i += 16u * ZHIP_ENT_THREADS) {
-            uint4 v; __builtin_memcpy(&v, lits + i, 16);                  // lits has >= 64 bytes of slack
-            uint32_t const c = litSize - i < 16 ? litSize - i : 16;
-            uint32_t w[4] = { v.x, v.y, v.z, v.w };
-            for (uint32_t b = 0; b < 16; b++) if (b < c) atomicAdd(&myHist[(w[b >> 2] >> (8 * (b & 3))) & 0xFF], 1u);
+        uint32_t const strideB = 16u * ZHIP_ENT_THREADS;
+        for (uint32_t i0 = 16u * (uint32_t)t; i0 < litSize; i0 += 4 * strideB) {      // 4 loads in flight per thread
+            uint4 v[4];
+            for (int q = 0; q < 4; q++) { uint32_t const i = i0 + (uint32_t)q * strideB; if (i < litSize) __builtin_memcpy(&v[q], lits + i, 16); }   // lits has >= 64 bytes of slack
+            for (int q = 0; q < 4; q++) {
+                uint32_t const i = i0 + (uint32_t)q * strideB;
+                if (i >= litSize) break;
+                uint32_t const c = litSize - i < 16 ? litSize - i : 16;
+                uint32_t const w[4] = { v[q].x, v[q].y, v[q].z, v[q].w };
+                for (uint32_t b = 0; b < 16; b++) if (b < c) atomicAdd(&myHist[(w[b >> 2] >> (8 * (b & 3))) & 0xFF], 1u);
+            }
         }
     }
     ZPROF(9);
     // sequence codes (zstd_compress.c:2686-2712) -> stBits arrays (replaced by the FSE records in phase B) + histograms
     for (uint32_t i = (uint32_t)t; i < nbSeq; i += ZHIP_ENT_THREADS) {
         uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
-        uint32_t const llc = ll_code(ll), ofc = hb32(ob), mlc = ml_code(mlb);
+        uint32_t const llc = ll_code(TB, ll), ofc = hb32(ob), mlc = ml_code(TB, mlb);
         bLL[i] = (uint16_t)llc; bOF[i] = (uint16_t)ofc; bML[i] = (uint16_t)mlc;
         atomicAdd(&sh->seqCount[0][llc], 1u);
         atomicAdd(&sh->seqCount[1][ofc], 1u);
@@ -285,75 +303,109 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         sh->litMode = mode;
         ZPROF_JOB_MARK(31);
     }
-    if (lane == 0 && wv >= 1 && nbSeq > 0) {
-        ZPROF_JOB_BEGIN
+    if (wv >= 1 && nbSeq > 0) {
         int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
-        uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
-        uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
-        uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
-        const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
         uint16_t* const arr = stBits + (size_t)k * ZHIP_SEQ_CAP;
-        uint32_t* cnt = sh->seqCount[k];
-        uint32_t max = maxPossible, mostFrequent = 0;
-        while (!cnt[max]) max--;
-        for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
-        bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
-        // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
-        uint32_t type;
-        if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
-        else {
-            type = 2;
-            if (defaultAllowed) {
-                uint32_t const mult = 10 - u.strategy;
-                uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
-                if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
-            }
-        }
         uint32_t const lastCode = arr[nbSeq - 1];                  // for the "-1" rule (zstd_compress_sequences.c:271-274)
-        uint32_t hsz = 0; bool fail = false;
-        if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
-            fse_build_ctable_rle(&sh->ct[k], max);
-            sh->ncount[k][0] = (uint8_t)arr[0];
-            hsz = 1;
-        } else if (type == 0) {
-            for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
-            fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
-        } else {
-            uint32_t nbSeq1 = nbSeq;
-            uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
-            if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
-            if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
+        ZPROF_JOB_BEGIN
+        if (lane == 0) {
+            uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
+            uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
+            uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
+            const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
+            uint32_t* cnt = sh->seqCount[k];
+            uint32_t max = maxPossible, mostFrequent = 0;
+            while (!cnt[max]) max--;
+            for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
+            bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
+            // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
+            uint32_t type;
+            if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
             else {
-                hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
-                if (!hsz) fail = true;
-                else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
-            }
-        }
-        sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
-        ZPROF_JOB_MARK(29);
-        if (!fail) {
-            // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
-            // becomes (nbBits << 12 | value).  Codes are read four at a time, one group ahead of their use.
-            const FseCTable* ct = &sh->ct[k];
-            uint32_t state = fse_init_state2(ct, lastCode);
-            uint32_t i = nbSeq - 1;
-            while (i & 3) { i--; arr[i] = (uint16_t)fse_chain_step(ct, state, arr[i]); }
-            if (i) {
-                unsigned long long cur4; __builtin_memcpy(&cur4, arr + (i - 4), 8);
-                while (i) {
-                    i -= 4;
-                    unsigned long long nxt4 = 0;
-                    if (i) __builtin_memcpy(&nxt4, arr + (i - 4), 8);
-                    unsigned long long res = 0;
-                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 48) & 0xFFFF) << 48;
-                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 32) & 0xFFFF) << 32;
-                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)(cur4 >> 16) & 0xFFFF) << 16;
-                    res |= (unsigned long long)fse_chain_step(ct, state, (uint32_t)cur4 & 0xFFFF);
-                    __builtin_memcpy(arr + i, &res, 8);
-                    cur4 = nxt4;
+                type = 2;
+                if (defaultAllowed) {
+                    uint32_t const mult = 10 - u.strategy;
+                    uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
+                    if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
                 }
             }
-            sh->finalState[k] = state;
+            uint32_t hsz = 0; bool fail = false;
+            if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
+                fse_build_ctable_rle(&sh->ct[k], max);
+                sh->ncount[k][0] = (uint8_t)max;
+                hsz = 1;
+            } else if (type == 0) {
+                for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
+                fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
+            } else {
+                uint32_t nbSeq1 = nbSeq;
+                uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
+                if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
+                if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
+                else {
+                    hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
+                    if (!hsz) fail = true;
+                    else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
+                }
+            }
+            sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ZPROF_JOB_MARK(29);
+        if (sh->encType[k] != 9) {
+            // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
+            // becomes (nbBits << 12 | value).  The wavefront moves tiles of 256 entries between HBM and LDS (coalesced,
+            // the next tile's loads in flight during the walk); lane 0 walks the tile in LDS, so the serial path sees
+            // LDS latency only.
+            const FseCTable* ct = &sh->ct[k];
+            uint16_t* const tile = sh->chainTile[k];
+            uint32_t state = fse_init_state2(ct, lastCode);
+            uint32_t hi = nbSeq - 1;                               // entries [0, hi) remain, processed downwards
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            {   uint32_t const lo0 = hi > 256 ? hi - 256 : 0, c = hi - lo0, e = 4u * (uint32_t)lane;
+                if (e + 0 < c) r0 = arr[lo0 + e + 0];
+                if (e + 1 < c) r1 = arr[lo0 + e + 1];
+                if (e + 2 < c) r2 = arr[lo0 + e + 2];
+                if (e + 3 < c) r3 = arr[lo0 + e + 3];
+            }
+            while (hi) {
+                uint32_t const lo_ = hi > 256 ? hi - 256 : 0, cnt = hi - lo_, e4 = 4u * (uint32_t)lane;
+                tile[e4 + 0] = (uint16_t)r0; tile[e4 + 1] = (uint16_t)r1; tile[e4 + 2] = (uint16_t)r2; tile[e4 + 3] = (uint16_t)r3;
+                __builtin_amdgcn_wave_barrier();
+                {   // next tile's codes: in flight while lane 0 walks this one
+                    uint32_t const nlo = lo_ > 256 ? lo_ - 256 : 0, c = lo_ - nlo;
+                    if (e4 + 0 < c) r0 = arr[nlo + e4 + 0];
+                    if (e4 + 1 < c) r1 = arr[nlo + e4 + 1];
+                    if (e4 + 2 < c) r2 = arr[nlo + e4 + 2];
+                    if (e4 + 3 < c) r3 = arr[nlo + e4 + 3];
+                }
+                if (lane == 0) {
+                    uint32_t e = cnt;
+                    while (e & 3) { e--; uint32_t const sy = tile[e]; tile[e] = (uint16_t)fse_chain_step(ct, state, ct->dBits[sy], ct->dFind[sy]); }
+                    while (e) {
+                        e -= 4;
+                        unsigned long long c4; __builtin_memcpy(&c4, tile + e, 8);
+                        uint32_t const y3 = (uint32_t)(c4 >> 48) & 0xFFFF, y2 = (uint32_t)(c4 >> 32) & 0xFFFF;
+                        uint32_t const y1 = (uint32_t)(c4 >> 16) & 0xFFFF, y0 = (uint32_t)c4 & 0xFFFF;
+                        uint32_t const b3 = ct->dBits[y3], b2 = ct->dBits[y2], b1 = ct->dBits[y1], b0 = ct->dBits[y0];
+                        int32_t const f3 = ct->dFind[y3], f2 = ct->dFind[y2], f1 = ct->dFind[y1], f0 = ct->dFind[y0];
+                        unsigned long long res = 0;
+                        res |= (unsigned long long)fse_chain_step(ct, state, b3, f3) << 48;
+                        res |= (unsigned long long)fse_chain_step(ct, state, b2, f2) << 32;
+                        res |= (unsigned long long)fse_chain_step(ct, state, b1, f1) << 16;
+                        res |= (unsigned long long)fse_chain_step(ct, state, b0, f0);
+                        __builtin_memcpy(tile + e, &res, 8);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (e4 + 0 < cnt) arr[lo_ + e4 + 0] = tile[e4 + 0];
+                if (e4 + 1 < cnt) arr[lo_ + e4 + 1] = tile[e4 + 1];
+                if (e4 + 2 < cnt) arr[lo_ + e4 + 2] = tile[e4 + 2];
+                if (e4 + 3 < cnt) arr[lo_ + e4 + 3] = tile[e4 + 3];
+                __builtin_amdgcn_wave_barrier();
+                hi = lo_;
+            }
+            if (lane == 0) sh->finalState[k] = state;
         }
         ZPROF_JOB_MARK(30);
     }
@@ -376,10 +428,11 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             runStart = (uint32_t)lane * rper; if (runStart > segLen) runStart = segLen;
             runLen = (runStart + rper <= segLen) ? rper : segLen - runStart;
             const uint8_t* p = lits + segStart + runStart;
-            for (uint32_t i = 0; i < runLen; i += 8) {
-                uint64_t const v = eld64(p + i);
-                uint32_t const c = runLen - i < 8 ? runLen - i : 8;
-                for (uint32_t b = 0; b < c; b++) myBits += sh->code[(uint32_t)(v >> (8 * b)) & 0xFF] & 0xFF;
+            for (uint32_t i = 0; i < runLen; i += 32) {
+                uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
+                uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
+                uint32_t const c = runLen - i;
+                for (uint32_t b = 0; b < 32; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
             }
         }
         uint32_t const incl = wave_incl_scan(myBits);
@@ -418,16 +471,19 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
                 RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total - incl));
                 const uint8_t* p = lits + segStart + runStart;
+                // the run is consumed from its end, 32 bytes per round; the first round takes the odd part
                 uint32_t i = runLen;
-                uint32_t const headCnt = runLen & 7;                  // the run is consumed from its end in 8-byte groups
-                while (i > headCnt) {
-                    i -= 8;
-                    uint64_t const v = eld64(p + i);
-                    for (int b = 7; b >= 0; b--) { uint32_t const c = sh->code[(uint32_t)(v >> (8 * b)) & 0xFF]; pk.add(c >> 8, c & 0xFF); }
-                }
-                if (headCnt) {
-                    uint64_t const v = eld64(p);
-                    for (int b = (int)headCnt - 1; b >= 0; b--) { uint32_t const c = sh->code[(uint32_t)(v >> (8 * b)) & 0xFF]; pk.add(c >> 8, c & 0xFF); }
+                while (i) {
+                    uint32_t const c = (i & 31) ? (i & 31) : 32;
+                    i -= c;
+                    uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
+                    uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
+                    for (int b = 31; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per packer step
+                        uint32_t const c1 = (uint32_t)b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0;
+                        uint32_t const c0 = (uint32_t)(b - 1) < c ? sh->code[(w[(b - 1) >> 2] >> (8 * ((b - 1) & 3))) & 0xFF] : 0;
+                        uint32_t const n1 = c1 & 0xFF;
+                        pk.add((c1 >> 8) | ((c0 >> 8) << n1), n1 + (c0 & 0xFF));
+                    }
                 }
                 if (lane == 0) pk.add(1, 1);              // lane 0 holds the FIRST symbols = the end of the stream: end mark
                 pk.finish();
@@ -472,10 +528,14 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             uint32_t const a0 = (uint32_t)t * per2 < nbSeq ? (uint32_t)t * per2 : nbSeq;
             uint32_t const a1 = a0 + per2 < nbSeq ? a0 + per2 : nbSeq;
             uint32_t myBits = 0;
-            for (uint32_t i = a0; i < a1; i++) {
-                uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
-                myBits += kLLbits[ll_code(ll)] + kMLbits[ml_code(mlb)] + hb32(ob);
-                if (i + 1 < nbSeq) myBits += (bLL[i] >> 12) + (bOF[i] >> 12) + (bML[i] >> 12);
+            for (uint32_t i = a0; i < a1; i += 4) {                     // four sequences' loads in flight at a time
+                ZhipSeq sq[4]; uint32_t nb[4];
+                for (uint32_t q = 0; q < 4; q++) if (i + q < a1) { sq[q] = seqs[i + q]; nb[q] = (uint32_t)(bLL[i + q] >> 12) + (bOF[i + q] >> 12) + (bML[i + q] >> 12); }
+                for (uint32_t q = 0; q < 4; q++) if (i + q < a1) {
+                    uint32_t ll, mlb, ob; seq_unpack(sq[q], pm, i + q, ll, mlb, ob);
+                    myBits += TB.llBits[ll_code(TB, ll)] + TB.mlBits[ml_code(TB, mlb)] + hb32(ob);
+                    if (i + q + 1 < nbSeq) myBits += nb[q];
+                }
             }
             uint32_t totalSeqBits;
             uint32_t const before = block_excl_scan(sh, myBits, &totalSeqBits);      // bits of sequences with LOWER index
@@ -496,16 +556,20 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 uint64_t const bit0 = 8ull * ((uintptr_t)bs & 3);
                 // sequences a0..a1-1 of this thread occupy bits [total - before - myBits, total - before)
                 RunPacker pk; pk.init(w32, bit0 + (uint64_t)(totalSeqBits - before - myBits));
-                for (uint32_t i = a1; i-- > a0; ) {
-                    uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
-                    uint32_t const llc = ll_code(ll), mlc = ml_code(mlb), ofc = hb32(ob);
-                    if (i + 1 < nbSeq) {
-                        uint32_t const x = bOF[i], y = bML[i], z = bLL[i];
-                        pk.add(x & 0xFFF, x >> 12); pk.add(y & 0xFFF, y >> 12); pk.add(z & 0xFFF, z >> 12);
+                for (uint32_t top = a1; top > a0; ) {                     // downwards, four sequences' loads in flight
+                    uint32_t const c = top - a0 < 4 ? top - a0 : 4;
+                    top -= c;
+                    ZhipSeq sq[4]; uint32_t x[4], y[4], z[4];
+                    for (uint32_t q = 0; q < 4; q++) if (q < c) { sq[q] = seqs[top + q]; x[q] = bOF[top + q]; y[q] = bML[top + q]; z[q] = bLL[top + q]; }
+                    for (int q = 3; q >= 0; q--) if ((uint32_t)q < c) {
+                        uint32_t const i = top + (uint32_t)q;
+                        uint32_t ll, mlb, ob; seq_unpack(sq[q], pm, i, ll, mlb, ob);
+                        uint32_t const llc = ll_code(TB, ll), mlc = ml_code(TB, mlb), ofc = hb32(ob);
+                        if (i + 1 < nbSeq) { pk.add(x[q] & 0xFFF, x[q] >> 12); pk.add(y[q] & 0xFFF, y[q] >> 12); pk.add(z[q] & 0xFFF, z[q] >> 12); }
+                        { uint32_t const lb = TB.llBits[llc], mb = TB.mlBits[mlc];
+                          pk.add(ll & ((1u << lb) - 1), lb); pk.add(mlb & ((1u << mb) - 1), mb); }
+                        pk.add(ob & (uint32_t)((1ull << ofc) - 1), ofc);
                     }
-                    pk.add(ll & ((1u << kLLbits[llc]) - 1), kLLbits[llc]);
-                    pk.add(mlb & ((1u << kMLbits[mlc]) - 1), kMLbits[mlc]);
-                    pk.add(ob & (uint32_t)((1ull << ofc) - 1), ofc);
                 }
                 pk.finish();
                 if (t == 0) {     // final states ML, OF, LL then the end mark (zstd_compress_sequences.c:371-381)

@@ -171,6 +171,7 @@ struct FastOut {
     uint32_t nbSeq, longPos, longType;
     uint32_t litPos;        // literals emitted so far
     uint64_t pendV;         // per lane: 8 loaded literal bytes of the most recent run, stored at the next call
+    uint32_t pendSh;        // per lane: bits to shift pendV right by (loads are clamped to the unit)
     uint32_t pendOff, pendLen;
 };
 
@@ -184,7 +185,7 @@ __device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { __builtin_memcpy(
 __device__ __forceinline__ void lits_flush(FastOut& o)
 {
     uint32_t const lane8 = 8u * (uint32_t)lane_id();
-    if (lane8 < o.pendLen) st64(o.lits + o.pendOff + lane8, o.pendV);
+    if (lane8 < o.pendLen) st64(o.lits + o.pendOff + lane8, o.pendV >> o.pendSh);
     o.pendLen = 0;
     __builtin_amdgcn_wave_barrier();        // later runs overwrite this run's spill: keep the stores in program order
 }
@@ -194,7 +195,7 @@ __device__ __forceinline__ void lits_copy(FastOut& o, const uint8_t* src, uint32
     if (len == 0) return;
     uint32_t const lane8 = 8u * (uint32_t)lane_id();
     {   uint32_t const q = from + lane8, qc = q < nm8 ? q : nm8, sh = q - qc;      // sh <= 7 whenever lane8 < len
-        if (lane8 < len) o.pendV = ld64(src + qc) >> (8 * (sh & 7));
+        if (lane8 < len) { o.pendV = ld64(src + qc); o.pendSh = 8 * (sh & 7); }          // not consumed here: no wait
         o.pendOff = o.litPos; o.pendLen = len < 512 ? len : 512;
     }
     for (uint32_t off = 512; off < len; off += 512) {
@@ -250,7 +251,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const hlog = u.hashLog, hshift = 32 - hlog;
     uint32_t const stepSize = u.targetLength + !u.targetLength + 1;         // zstd_fast.c:200
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
-    out.litPos = 0; out.pendV = 0; out.pendOff = 0; out.pendLen = 0;
+    out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
     ZPROF_DECL
 
     FastTab T;
@@ -375,8 +376,9 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
                 cand0 = __builtin_amdgcn_readlane(cand, jm);
                 cur0 = mpos;
                 if ((jm & 1) && step <= 4) {                                 // :318-324 hashTable[hash1] = ip1 (= A_{k+1})
-                    uint32_t const rp = __builtin_amdgcn_readlane(rpos, jm - 1);
-                    if (lane == 0) tab_put(T, hash_pos<MLS>(ld64(src + rp), hshift), rp);
+                    // A_{k+1} is lane jm+1's position (its hash is at hand); for jm == 63 it opens the next batch
+                    if (jm < 63) { if ((int)lane == jm + 1) tab_put(T, h, pos); }
+                    else if (lane == 0) tab_put(T, hash_pos<MLS>(nxt.bytes, hshift), nip0);
                     __builtin_amdgcn_wave_barrier();
                 }
                 break;
