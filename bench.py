@@ -10,9 +10,13 @@ N > 1: one process per GPU (torchrun), every rank compresses its own 1 GiB shard
 GPU/stream; there is no data-path collective (units are independent) — torch.distributed only provides the
 barriers and the max-over-ranks time.  scaling = "weak".
 
-Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder), `pipeline`
-(all kernels, (S + C) bytes), `ratio`, `parity` (sha256 of the GPU stream == oracle stream on a bounded sample and a
-full-size round-trip property) and `cpu_baseline` (the REAL reference timed on this box's host cores).
+Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder k_parse_fast: algorithmic
+bytes = source read once + 8-byte sequence records + literals written once, divided by the kernel's average launch
+duration from HIP events recorded by the library on the stream it launches on), `pipeline` (all kernels, (S + C) bytes),
+`ratio`, `parity` (sha256 of the GPU stream == oracle stream on a bounded sample and a full-size structural property),
+`cpu_baseline` (the REAL reference timed on this box's host cores) and `pipelined` (an extra, shorter measurement with
+the library's optional 4-chunk stream pipelining, in which a chunk's entropy stage overlaps the match finder of the next
+chunks; per-kernel durations are not separable there, so the headline numbers come from the sequential launches).
 """
 import argparse
 import ctypes as C
@@ -156,7 +160,7 @@ def main():
         parse_ms, ent_ms, gat_ms, tot_ms = kparse / K, kent / K, kgat / K, ktot / K
         # algorithmic bytes: the unit is read once (S) and its result written once.  For the match
         # finder alone the result is the 8-byte sequence records; for the pipeline it is the compressed stream (C).
-        parse_bytes = n + 8 * st["sequences"]
+        parse_bytes = n + 8 * st["sequences"] + st["literals"]
         achieved = parse_bytes / (parse_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
@@ -182,6 +186,20 @@ def main():
                          "frac_of_hbm_peak": round((n + int(total)) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
         out["parity"] = parity_check(ctx, host, dst, total, sizes)
+        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None:
+            # optional stream pipelining of the same workload (a second context: the knob is read at creation)
+            os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
+            ctx2 = zstd_amd.Context(local, max_units=units)
+            del os.environ["ZHIP_PIPELINE_CHUNKS"]
+            for _ in range(2):
+                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+            torch.cuda.synchronize(); q0 = time.perf_counter()
+            for _ in range(3):
+                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+            torch.cuda.synchronize(); q1 = time.perf_counter()
+            out["pipelined"] = {"chunks": 4, "value": round(n / ((q1 - q0) / 3) / 1e6, 1), "unit": "MB/s", "steps": 3,
+                                "same_bytes": bool(int(t2) == int(total))}
+            ctx2.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host)
         print(json.dumps(out))

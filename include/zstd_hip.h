@@ -80,8 +80,8 @@ size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* 
  * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */
 void         zhip_last_timing(const zhip_ctx* ctx, double t[4]);
 
-/* stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences of the most recent call */
-size_t       zhip_last_stats(zhip_ctx* ctx, unsigned long long stats[4]);
+/* stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences, [4] literal bytes of the most recent call */
+size_t       zhip_last_stats(zhip_ctx* ctx, unsigned long long stats[5]);
 
 /* ---- synthetic input = programs/datagen.c (RDG_genBuffer :144 when streamMode == 0, RDG_genStdout :155 i.e.
  * `datagen -g<size> -P<pct> -s<seed>` when streamMode == 1).  Host buffer. */

@@ -120,9 +120,9 @@ class Context:
         return {"parse_ms": t[0], "entropy_ms": t[1], "gather_ms": t[2], "total_ms": t[3]}
 
     def stats(self):
-        s = (C.c_ulonglong * 4)()
+        s = (C.c_ulonglong * 5)()
         self._check(lib().zhip_last_stats(self._h, s), "zhip_last_stats")
-        return {"units": s[0], "src_bytes": s[1], "dst_bytes": s[2], "sequences": s[3]}
+        return {"units": s[0], "src_bytes": s[1], "dst_bytes": s[2], "sequences": s[3], "literals": s[4]}
 
     # ---- stage 1 only (sequence-producer path)
     def parse_device(self, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, stream=None):

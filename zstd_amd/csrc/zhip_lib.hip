@@ -16,11 +16,15 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
        ZE_dstSize_tooSmall = 70, ZE_srcSize_wrong = 72, ZE_sequenceProducer_failed = 106 };
 #define ZERR(c) ((size_t)-(long)(c))
 
+#define ZHIP_MAX_CHUNKS 8
 struct zhip_ctx_s {
     int device;
     size_t maxUnits;
     hipStream_t stream;
     hipEvent_t ev[5];
+    // optional pipelining: the batch is cut into chunks whose match-finder / entropy kernels run on separate streams
+    // (earlier chunks at higher priority), so a chunk's entropy stage overlaps the match finder of the later chunks
+    int nChunks; hipStream_t cs[ZHIP_MAX_CHUNKS]; hipEvent_t cev[ZHIP_MAX_CHUNKS];
     // device scratch, one slot per unit
     ZhipUnit*  dUnits;
     ZhipSeq*   dSeqs;
@@ -36,7 +40,7 @@ struct zhip_ctx_s {
     // pinned host mirrors
     ZhipUnit* hUnits; uint32_t* hOutSize; ZhipParse* hParse;
     // last call
-    size_t nUnits; double timing[4]; unsigned long long stats[4];
+    size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
@@ -98,6 +102,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]); if (c->cev[i]) (void)hipEventDestroy(c->cev[i]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -112,9 +117,21 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
+    for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { c->cs[i] = nullptr; c->cev[i] = nullptr; }
     memset(c->timing, 0, sizeof(c->timing));
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 5 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    {   const char* e = getenv("ZHIP_PIPELINE_CHUNKS");
+        c->nChunks = e ? atoi(e) : 1;
+        if (c->nChunks < 1) c->nChunks = 1;
+        if (c->nChunks > ZHIP_MAX_CHUNKS) c->nChunks = ZHIP_MAX_CHUNKS;
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
+        for (int i = 0; i < c->nChunks && ok && c->nChunks > 1; i++) {
+            int pr = hi + i; if (pr > lo) pr = lo;
+            ok = hipStreamCreateWithPriority(&c->cs[i], hipStreamNonBlocking, pr) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->cev[i], hipEventDisableTiming) == hipSuccess;
+        }
+    }
     ok = ok && hipMalloc((void**)&c->dUnits, maxUnits * sizeof(ZhipUnit)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dSeqs, maxUnits * (size_t)ZHIP_SEQ_CAP * sizeof(ZhipSeq)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dParse, maxUnits * sizeof(ZhipParse)) == hipSuccess;
@@ -170,7 +187,11 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
 
 static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
 {
-    size_t const smem = zhip::fast_lds_bytes(maxHashLog);
+    size_t smem = zhip::fast_lds_bytes(maxHashLog);
+    {   // measurement knob (scripts/): extra LDS bytes per unit lower the number of resident units per CU
+        static long const pad = getenv("ZHIP_PARSE_LDS_PAD") ? atol(getenv("ZHIP_PARSE_LDS_PAD")) : 0;
+        if (pad > 0) smem += (size_t)pad;
+    }
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     if (smem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -198,6 +219,42 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
     return 0;
 }
 
+// chunked variant of launch_parse + launch_entropy_gather (see zhip_ctx_s::nChunks).  ev[1] is not meaningful here:
+// the stages of different chunks overlap, so timing[] reports the match finder + entropy time as one figure.
+static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, uint8_t* dstDev, hipStream_t s)
+{
+    size_t const smem = zhip::fast_lds_bytes(maxHashLog);
+    static bool attrSet = false;
+    if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
+    if (smem > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    size_t const per = (nUnits + c->nChunks - 1) / c->nChunks;
+    for (int i = 0; i < c->nChunks; i++) {
+        size_t const u0 = (size_t)i * per, u1 = u0 + per < nUnits ? u0 + per : nUnits;
+        if (u0 >= u1) break;
+        unsigned const nu = (unsigned)(u1 - u0);
+        hipStream_t q = c->cs[i];
+        HIPCHK(c, hipStreamWaitEvent(q, c->ev[0], 0));
+        hipLaunchKernelGGL(zhip::k_parse_fast, dim3(nu), dim3(64), smem, q, srcDev, c->dUnits + u0, nu,
+                           c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dLits + u0 * ZHIP_LIT_STRIDE, c->dParse + u0);
+        hipLaunchKernelGGL(zhip::k_entropy, dim3(nu), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), q,
+                           srcDev, c->dUnits + u0, nu, c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dParse + u0, c->dLits + u0 * ZHIP_LIT_STRIDE,
+                           c->dStBits + u0 * 3 * ZHIP_SEQ_CAP, c->dOut + u0 * ZHIP_OUT_STRIDE, c->dOutSize + u0);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->cev[i], q));
+        HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
+    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    return 0;
+}
+
 static void read_timing(zhip_ctx* c)
 {
     float a = 0, b = 0, g = 0, tot = 0;
@@ -216,9 +273,13 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     size_t const nUnits = build_units(c, srcSize, unitSize, level, &err, &mh);
     if (!nUnits) return err;
     if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
-    size_t r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
-    if (zhip_isError(r)) return r;
-    r = launch_entropy_gather(c, (const uint8_t*)srcDev, nUnits, (uint8_t*)dstDev, s);
+    size_t r;
+    if (c->nChunks > 1 && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
+    else {
+        r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
+        if (zhip_isError(r)) return r;
+        r = launch_entropy_gather(c, (const uint8_t*)srcDev, nUnits, (uint8_t*)dstDev, s);
+    }
     if (zhip_isError(r)) return r;
     if (unitSizesDev) HIPCHK(c, hipMemcpyAsync(unitSizesDev, c->dOutSize, nUnits * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     uint64_t total = 0;
@@ -226,7 +287,7 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     HIPCHK(c, hipStreamSynchronize(s));
     for (size_t i = 0; i < nUnits; i++) total += c->hOutSize[i];
     read_timing(c);
-    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = total; c->stats[3] = 0;
+    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = total; c->stats[3] = 0; c->stats[4] = 0;
     c->nUnits = nUnits;
     return (size_t)total;
 }
@@ -280,7 +341,7 @@ size_t zhip_parse_device(zhip_ctx* c, const void* srcDev, size_t srcSize, int le
     float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->timing[0] = ms; c->timing[1] = c->timing[2] = 0; c->timing[3] = ms;
     c->nUnits = nUnits;
-    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = 0; c->stats[3] = 0;
+    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = 0; c->stats[3] = 0; c->stats[4] = 0;
     return nUnits;
 }
 
@@ -304,18 +365,18 @@ static size_t seqs_to_public(const ZhipSeq* s, const ZhipParse& m, zhip_Sequence
     return (size_t)m.nbSeq + 1;
 }
 
-// stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences (fetched from the device on demand)
-size_t zhip_last_stats(zhip_ctx* c, unsigned long long stats[4])
+// stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences, [4] literal bytes (fetched from the device on demand)
+size_t zhip_last_stats(zhip_ctx* c, unsigned long long stats[5])
 {
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->nUnits) {
         HIPCHK(c, hipMemcpy(c->hParse, c->dParse, c->nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost));
-        unsigned long long ns = 0;
-        for (size_t i = 0; i < c->nUnits; i++) ns += c->hParse[i].nbSeq;
-        c->stats[3] = ns;
+        unsigned long long ns = 0, nl = 0;
+        for (size_t i = 0; i < c->nUnits; i++) { ns += c->hParse[i].nbSeq; nl += c->hParse[i].litSize; }
+        c->stats[3] = ns; c->stats[4] = nl;
     }
-    for (int i = 0; i < 4; i++) stats[i] = c->stats[i];
+    for (int i = 0; i < 5; i++) stats[i] = c->stats[i];
     return 0;
 }
 
