@@ -35,18 +35,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 UNIT = 131072
 
 
-def cpu_baseline(sample, seconds=8.0):
+def cpu_baseline(sample, seconds=8.0, level=1):
     """time the reference (oracle/_ref/zref_bench, built from /root/reference) on the host: `zstd -b1 -B128K` semantics"""
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     tmp = "/tmp/zhip_bench_sample.bin"
     if os.path.exists(exe):
         sample.tofile(tmp)
         try:
-            one = json.loads(subprocess.check_output([exe, "file", "1", str(UNIT), tmp, str(seconds), "1"], timeout=120))
+            one = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds), "1"], timeout=120))
             ncores = os.cpu_count() or 1
-            allc = json.loads(subprocess.check_output([exe, "file", "1", str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
+            allc = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
             return {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
-                    "sample": f"first {len(sample) >> 20} MiB of the workload, level 1, {UNIT} B units, best of {one['runs']} runs "
+                    "sample": f"first {len(sample) >> 20} MiB of the workload, level {level}, {UNIT} B units, best of {one['runs']} runs "
                               f"(oracle/_ref/zref_bench = ZSTD_compress2 per unit, programs/benchzstd.c semantics)",
                     "all_cores": {"value": allc["MBps"], "cores": ncores}}
         finally:
@@ -58,13 +58,13 @@ def cpu_baseline(sample, seconds=8.0):
     cap = lo.zo_compress_bound(UNIT) * (len(sample) // UNIT + 1)
     dst = np.empty(cap, dtype=np.uint8)
     t0 = time.time()
-    r = lo.zo_compress_chunks(1, UNIT, _buf(sample), len(sample), _buf(dst), cap, None, 0)
+    r = lo.zo_compress_chunks(level, UNIT, _buf(sample), len(sample), _buf(dst), cap, None, 0)
     dt = time.time() - t0
     return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port", "ratio": len(sample) / r,
             "sample": f"first {len(sample) >> 20} MiB, oracle/zoracle.c single pass"}
 
 
-def parity_check(ctx, host, dev_out, total, sizes):
+def parity_check(ctx, host, dev_out, total, sizes, level=1):
     """bounded byte-parity vs the oracle + full-size structural properties of the GPU stream"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import load_oracle, _buf, ERR
@@ -74,7 +74,7 @@ def parity_check(ctx, host, dev_out, total, sizes):
     cap = lo.zo_compress_bound(UNIT) * nsamp
     dst = np.empty(cap, dtype=np.uint8)
     osz = np.zeros(nsamp, dtype=np.uint64)
-    r = lo.zo_compress_chunks(1, UNIT, _buf(sample), len(sample), _buf(dst), cap, _buf(osz), nsamp)
+    r = lo.zo_compress_chunks(level, UNIT, _buf(sample), len(sample), _buf(dst), cap, _buf(osz), nsamp)
     assert r != ERR
     gpu_prefix = dev_out[: int(r)].cpu().numpy()
     same = hashlib.sha256(gpu_prefix.tobytes()).hexdigest() == hashlib.sha256(dst[:r].tobytes()).hexdigest()
@@ -169,15 +169,19 @@ def main():
                 traffic = json.load(open(tpath)).get("k_parse_fast_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        cp = zstd_amd.get_cparams(args.level, UNIT)
+        cpdesc = f"{'ZSTD_fast' if cp[6] == 1 else 'ZSTD_dfast'} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} mml{cp[4]}"
+        if cp[6] != 1:
+            traffic = None                                        # the committed counters are for the level-1 kernel
         out = {
-            "metric": "compress_MBps_level1_datagenP50_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
+            "metric": f"compress_MBps_level{args.level}_datagenP50_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode), level {args.level} (ZSTD_fast wlog17 hlog13 mml6), "
+            "config": {"workload": f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode), level {args.level} ({cpdesc}), "
                                    f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
                        "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
             "ratio": round(world * n / total_all, 4),
-            "roofline": {"bound": "hbm", "kernel": "k_parse_fast", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_parse_fast" if cp[6] == 1 else "k_parse_dfast", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3)},
             "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "gather_ms": round(gat_ms, 3),
@@ -185,7 +189,7 @@ def main():
                          "achieved_GBps": round((n + int(total)) / (tot_ms * 1e-3) / 1e9, 2),
                          "frac_of_hbm_peak": round((n + int(total)) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
-        out["parity"] = parity_check(ctx, host, dst, total, sizes)
+        out["parity"] = parity_check(ctx, host, dst, total, sizes, args.level)
         if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)
             os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
@@ -201,7 +205,7 @@ def main():
                                 "same_bytes": bool(int(t2) == int(total))}
             ctx2.close()
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host)
+            out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host, level=args.level)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

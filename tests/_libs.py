@@ -188,6 +188,24 @@ def oracle_parse(lo, a, level, want_lits=False):
     return seqs[:nb].copy(), litSize.value, list(rep)
 
 
+def emu_parse_units(le, src, units, seqs, lits, metas):
+    """stage 1 on the emulator: fast or dfast kernel according to the units' strategy (all units alike)"""
+    nu = len(units)
+    strat = int(units["strategy"][0]) if nu else 1
+    assert (units["strategy"] == strat).all()
+    if strat == 1:
+        smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
+        le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
+    else:
+        le.emu_dfast_table_bytes.restype = C.c_uint64
+        stride = max(int(le.emu_dfast_table_bytes(int(h), int(c))) for h, c in zip(units["hashLog"], units["chainLog"])) // 4
+        stride = (stride + 3) & ~3
+        tabs = np.full(nu * stride + 4, 0xEEEEEEEE, dtype=np.uint32)
+        le.emu_parse_dfast.restype = None
+        le.emu_parse_dfast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        le.emu_parse_dfast(_buf(src), _buf(units), nu, _buf(tabs), stride, _buf(seqs), _buf(lits), _buf(metas), 0)
+
+
 def emu_compress_units(le, lo, bufs, level):
     """run stage 1 + stage 2 of the product kernels on the emulator; returns list of frame bytes"""
     le.emu_entropy.restype = None
@@ -199,10 +217,9 @@ def emu_compress_units(le, lo, bufs, level):
     nu = len(bufs)
     seqs = np.zeros(nu * cap, dtype=SEQ_DT)
     metas = np.zeros(nu, dtype=PARSE_DT)
-    smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
     ostride, lstride = le.emu_out_stride(), le.emu_lit_stride()
     lits = np.full(nu * lstride, 0xEE, dtype=np.uint8)
-    le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
+    emu_parse_units(le, src, units, seqs, lits, metas)
     stb = np.full(nu * 3 * cap, 0xEEEE, dtype=np.uint16)
     out = np.full(nu * ostride, 0xEE, dtype=np.uint8)
     osz = np.zeros(nu, dtype=np.uint32)

@@ -14,6 +14,14 @@ void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
                  [=] { zhip::k_parse_fast(src, units, nUnits, seqs, lits, metas); }, osThreads);
 }
 
+void emu_parse_dfast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride,
+                     ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
+{
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::dfast_lds_bytes(),
+                 [=] { zhip::k_parse_dfast(src, units, nUnits, tabs, tabStride, seqs, lits, metas); }, osThreads);
+}
+uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhip::dfast_table_bytes(hashLog, chainLog); }
+
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
                  const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)

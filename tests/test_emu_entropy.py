@@ -40,6 +40,14 @@ def test_frames_small_and_ragged(libs):
     check(lo, le, cases, 1)
 
 
+def test_frames_level3_dfast(libs):
+    lo, le = libs
+    cases = []
+    for n in (9, 10, 100, 1000, 20000, 131072):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(6,)))
+    check(lo, le, cases, 3)
+
+
 def test_frames_negative_level_and_level2(libs):
     lo, le = libs
     for level in (-1, 2):

@@ -3,7 +3,7 @@ CPU only: this checks the wave-parallel algorithm, not the GPU build."""
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, _buf, SEQ_DT, PARSE_DT)
+from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT)
 
 
 @pytest.fixture(scope="module")
@@ -18,10 +18,9 @@ def emu_parse(le, lo, bufs, level):
     cap = le.emu_seq_cap()
     seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT)
     metas = np.zeros(len(bufs), dtype=PARSE_DT)
-    smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
     lstride = le.emu_lit_stride()
     lits = np.full(max(1, len(bufs)) * lstride, 0xEE, dtype=np.uint8)
-    le.emu_parse_fast(_buf(src), _buf(units), len(bufs), _buf(seqs), _buf(lits), _buf(metas), smem, 0)
+    emu_parse_units(le, src, units, seqs, lits, metas)
     out = []
     for i in range(len(bufs)):
         m = metas[i]
@@ -72,4 +71,18 @@ def test_fast_parse_ragged_and_negative_levels(libs):
         for n in (5000, 16384, 40000, 100001):
             cases += list(corpus_cases(lo, sizes=(n,), seeds=(3,)))
         cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
+        check(le, lo, cases, level)
+
+
+def test_dfast_parse_levels_3_4(libs):
+    lo, le = libs
+    for level in (3, 4):
+        cases = []
+        for n in (0, 9, 10, 11, 20, 100, 1000, 5000, 40000, 131072):
+            cases += list(corpus_cases(lo, sizes=(n,), seeds=(level,)))
+        def strat(nn):
+            cp = (C.c_uint * 7)()
+            return cp[6] if lo.zo_get_cparams(level, nn, cp) == 0 else -1       # level 4 below 16 KB is greedy: not ours
+        cases = [c for c in cases if strat(len(c[1])) == 2]
+        assert cases
         check(le, lo, cases, level)

@@ -64,7 +64,7 @@ def test_units_128k_match_oracle_bytes(env):
         assert dec.tobytes() == flat.tobytes()
 
 
-@pytest.mark.parametrize("level", [1, 2, -1, -7])
+@pytest.mark.parametrize("level", [1, 2, -1, -7, 3, 4])
 def test_ragged_units_match_oracle_bytes(env, level):
     lo, ctx, torch = env
     import zstd_amd
@@ -73,7 +73,7 @@ def test_ragged_units_match_oracle_bytes(env, level):
             cp = zstd_amd.get_cparams(level, n)
         except zstd_amd.ZhipError:
             continue
-        if cp[6] != 1:
+        if cp[6] not in (1, 2):
             continue
         for name, a in corpus_cases(lo, sizes=(n,), seeds=(3,)):
             got = ctx.compress(a, level=level)
@@ -81,21 +81,33 @@ def test_ragged_units_match_oracle_bytes(env, level):
             assert got == want, (name, level, first_diff(got, want))
 
 
-def test_golden_vectors_from_the_real_reference(env):
+@pytest.mark.parametrize("level,minseen", [(1, 200), (3, 100)])
+def test_golden_vectors_from_the_real_reference(env, level, minseen):
     lo, ctx, torch = env
-    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["units"] if g["level"] == 1}
+    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["units"] if g["level"] == level}
     sizes = sorted({g["n"] for g in gold.values()})
     seen = 0
     for n in sizes:
         for name, a in corpus_cases(lo, sizes=(n,), seeds=(0, 5)):
-            g = gold.get((name, 1))
+            g = gold.get((name, level))
             if g is None:
                 continue
             assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"]
-            got = ctx.compress(a, level=1)
+            got = ctx.compress(a, level=level)
             assert len(got) == g["csize"] and hashlib.sha256(got).hexdigest() == g["dst_sha256"], name
             seen += 1
-    assert seen >= 200
+    assert seen >= minseen
+
+
+def test_level3_128k_units_match_oracle_bytes(env):
+    """strategy dfast (level 3, the reference's default level): full-size units, frames byte-identical to the oracle"""
+    lo, ctx, torch = env
+    cases = list(corpus_cases(lo, sizes=(131072,), seeds=(0,)))
+    flat = np.concatenate([c[1] for c in cases])
+    got, sizes = ctx.compress(flat, level=3, return_sizes=True)
+    want, wsizes = oracle_chunks(lo, flat, 3)
+    assert np.array_equal(sizes, wsizes), [(c[0], int(a), int(b)) for c, a, b in zip(cases, sizes, wsizes) if a != b]
+    assert got == want, first_diff(got, want)
 
 
 def test_multi_unit_stream_device_api_and_roundtrip(env):

@@ -35,7 +35,7 @@ def gpu_seqs(ctx, torch, bufs, level, unit):
     return [ctx.get_sequences(i) for i in range(len(bufs))]
 
 
-@pytest.mark.parametrize("level", [1])
+@pytest.mark.parametrize("level", [1, 3])
 def test_parse_128k_units_match_oracle(env, level):
     lo, ctx, torch = env
     cases = list(corpus_cases(lo, sizes=(131072,), seeds=(0, 1)))
@@ -45,7 +45,7 @@ def test_parse_128k_units_match_oracle(env, level):
         assert s.shape == o.shape and np.array_equal(s, o), name
 
 
-@pytest.mark.parametrize("level", [1, -1, 2])
+@pytest.mark.parametrize("level", [1, -1, 2, 3, 4])
 def test_parse_ragged_units_match_oracle(env, level):
     lo, ctx, torch = env
     import zstd_amd
@@ -54,7 +54,7 @@ def test_parse_ragged_units_match_oracle(env, level):
             cp = zstd_amd.get_cparams(level, n)
         except zstd_amd.ZhipError:
             continue
-        if cp[6] != 1:
+        if cp[6] not in (1, 2):
             continue
         for name, a in corpus_cases(lo, sizes=(n,), seeds=(4,)):
             s = gpu_seqs(ctx, torch, [a], level, 131072)[0]

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "zhip_common.h"
 #include "zhip_parse.h"
+#include "zhip_parse_dfast.h"
 #include "zhip_entropy.h"
 
 namespace zhip {
@@ -25,6 +26,31 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     case 7:  parse_fast_unit<7>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
     case 8:  parse_fast_unit<8>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
     default: parse_fast_unit<4>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
+    }
+}
+
+// Stage 1 for strategy dfast: one wavefront per unit, the unit's two hash tables live in HBM/L2 (tabs + ui * tabStride
+// words: long table, then short table).  Dynamic LDS = dfast_lds_bytes().
+__global__ void __launch_bounds__(64)
+k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+              uint32_t* __restrict__ tabs, size_t tabStride,
+              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    const uint8_t* const p = src + u.srcOff;
+    ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
+    uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
+    uint32_t* const tL = tabs + (size_t)ui * tabStride;
+    uint32_t* const tS = tL + ((size_t)1 << u.hashLog);
+    switch (u.minMatch) {
+    case 5:  parse_dfast_unit<5>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    case 6:  parse_dfast_unit<6>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    case 7:  parse_dfast_unit<7>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    case 8:  parse_dfast_unit<8>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    default: parse_dfast_unit<4>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
     }
 }
 

@@ -32,6 +32,9 @@ struct zhip_ctx_s {
     uint8_t*   dLits;
     uint16_t*  dStBits;
     uint8_t*   dOut;
+    uint32_t*  dTabs; size_t tabsCap;          // dfast: per-unit hash tables (long + short), grown on demand
+    size_t     tabStride;                      // words per unit of the current call (0 = strategy fast)
+    int        strategy;                       // strategy of the current call's units
     uint32_t*  dOutSize;
     uint64_t*  dOutOff;
     // staging for the host-buffer API
@@ -98,7 +101,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
-    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff);
+    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
@@ -114,6 +117,7 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     zhip_ctx* c = new zhip_ctx_s();
     c->dUnits = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
+    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = ZHIP_STRAT_FAST;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
@@ -164,7 +168,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
-    uint32_t mh = 0;
+    uint32_t mh = 0; size_t tabWords = 0; int strat = 0;
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -177,10 +181,19 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
         u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0; u.pad0 = 0;
         u.targetLength = cp->targetLength;
-        if (cp->strategy != ZHIP_STRAT_FAST) { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device yet", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
+        if (cp->strategy != ZHIP_STRAT_FAST && cp->strategy != ZHIP_STRAT_DFAST) { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device yet", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
+        if (strat == 0) strat = (int)cp->strategy;
+        if (strat != (int)cp->strategy) { snprintf(c->err, sizeof(c->err), "units of one call must share a strategy (%d vs %u)", strat, cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
         if (cp->hashLog > mh) mh = cp->hashLog;
+        if (cp->strategy == ZHIP_STRAT_DFAST) { size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
     }
-    if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
+    if (strat == ZHIP_STRAT_FAST && mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
+    c->strategy = strat ? strat : ZHIP_STRAT_FAST; c->tabStride = (tabWords + 3) & ~(size_t)3;
+    if (c->strategy == ZHIP_STRAT_DFAST && c->tabsCap < nUnits * c->tabStride) {
+        (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
+        if (hipMalloc((void**)&c->dTabs, nUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of dfast tables", nUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
+        c->tabsCap = nUnits * c->tabStride;
+    }
     *maxHashLog = mh;
     return nUnits;
 }
@@ -193,9 +206,13 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         if (pad > 0) smem += (size_t)pad;
     }
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
-    if (smem > 64 * 1024)
+    if (smem > 64 * 1024 && c->strategy == ZHIP_STRAT_FAST)
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (c->strategy == ZHIP_STRAT_DFAST)
+        hipLaunchKernelGGL(zhip::k_parse_dfast, dim3((unsigned)nUnits), dim3(64), zhip::dfast_lds_bytes(), s,
+                           srcDev, c->dUnits, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
+    else
     hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
                        srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     HIPCHK(c, hipGetLastError());
@@ -274,7 +291,7 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     if (!nUnits) return err;
     if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
     size_t r;
-    if (c->nChunks > 1 && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
+    if (c->nChunks > 1 && c->strategy == ZHIP_STRAT_FAST && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
     else {
         r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
         if (zhip_isError(r)) return r;

@@ -1,0 +1,221 @@
+// zhip_parse_dfast.h — gfx950 match finder for strategy ZSTD_dfast (levels 3-4), one wavefront per unit.
+//
+// WHAT it computes: exactly the sequences the reference's ZSTD_compressBlock_doubleFast_noDict_generic
+// (lib/compress/zstd_double_fast.c:105-323) emits for a unit with no history (fresh tables, rep = {1,4,8}).
+//
+// HOW.  Same batch scheme as zhip_parse.h: the positions the reference would visit from the current point
+// (ip, ip+step, ip+2*step, ... — zstd_double_fast.c:171-246; the gap grows every 256 bytes) are searched by the lanes
+// of one wavefront at once, and the first event in the reference's own order (per position: repcode at ip+1, long
+// match, short match) is found with ballots.  Differences that shape the kernel:
+//   * two tables (8-byte "long" hash with hashLog bits, mls-byte "short" hash with chainLog bits).  For the 128 KB
+//     parameter row they hold 2^16 + 2^15 entries — more than the 160 KB of LDS — so they live in HBM/L2 as plain
+//     32-bit arrays, one private pair per unit; with no LDS table the kernel runs at full wave occupancy instead;
+//   * lanes of one batch that hash alike (in either table) must see each other's inserts in lane order: two small LDS
+//     scratch arrays (lane id written / read back at hash & 1023) flag the candidates, ballots make the exact groups;
+//   * a short match also looks at the long candidate of the NEXT position (:251-264) — lane K of a K-lane batch is a
+//     helper that carries that position's bytes, long hash and candidate.
+// All control flow is wave-uniform; the only LDS use is the 2 KB scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zhip_common.h"
+#include "zhip_parse.h"
+
+namespace zhip {
+
+#define ZHIP_DF_SCRATCH 1024u                       /* entries per scratch array */
+__host__ __device__ inline uint32_t dfast_lds_bytes() { return 2u * ZHIP_DF_SCRATCH; }
+// bytes of table memory one unit needs (long + short, 32-bit entries)
+__host__ __device__ inline size_t dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return ((size_t)4 << hashLog) + ((size_t)4 << chainLog); }
+
+// exact groups of live lanes with equal key, given the lanes whose scratch slot was taken by another lane
+__device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned long long losers, unsigned long long liveMask)
+{
+    unsigned long long grp = 0;
+    while (losers) {
+        int const j = first_lane(losers);
+        uint32_t const kj = __builtin_amdgcn_readlane(key, j);
+        unsigned long long const G = __ballot(key == kj) & liveMask;
+        if (key == kj) grp = G;
+        losers &= ~G;
+    }
+    return grp;
+}
+
+template <uint32_t MLS>
+__device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
+                                        uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS,
+                                        ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const shL = 32 - u.hashLog, shS = 32 - u.chainLog;
+    FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
+    out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
+    lds_u8* const scrL = (lds_u8*)(uintptr_t)smem;
+    lds_u8* const scrS = (lds_u8*)(uintptr_t)(smem + ZHIP_DF_SCRATCH);
+
+    {   // fresh tables (zstd_compress.c:2020): the long and the short table are contiguous
+        uint32_t const words = (uint32_t)(dfast_table_bytes(u.hashLog, u.chainLog) >> 2);
+        uint4 const z = {0, 0, 0, 0};
+        for (uint32_t i = 4 * lane; i < words; i += 256) *(uint4*)(tabL + i) = z;      // tables are 16-byte aligned, sizes multiples of 16 words
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;
+    // :158-164  ip = 1, lowest index 0 -> maxRep = 1
+    if (off2 > 1) { saved2 = off2; off2 = 0; }
+    if (off1 > 1) { saved1 = off1; off1 = 0; }
+
+    if (n >= 10) {                          // shortest unit whose first iteration runs (ip1 = 2 <= n - 8)
+    uint32_t const nm8 = n - 8;
+    int32_t const ilimit = (int32_t)nm8;
+    uint32_t ip = 1;
+    for (;;) {                                                               // one turn per match (:167)
+        uint32_t step = 1, nextStep = ip + 256;
+        if ((int32_t)(ip + 1) > ilimit) break;                               // :172
+        int evKind = 0;                      // 0 none (unit finished), 1 repcode, 2 long, 3 short
+        uint32_t curr = 0, candE = 0, ip1 = 0, cand1 = 0; bool long1 = false;
+        for (;;) {
+            // lanes 0..K-1 search p_j = ip + j*step; lane K is the helper for position p_K (= ip1 of lane K-1)
+            uint32_t const p = ip + lane * step;
+            bool const inc = (int32_t)(p + step) >= (int32_t)nextStep;                    // :232 step++ after this position
+            bool const endAfter = (int32_t)(p + 2 * step + (inc ? 1u : 0u)) > ilimit;     // :246 next position does not run
+            unsigned long long const mStop = __ballot(inc || endAfter);
+            int K = mStop ? first_lane(mStop) + 1 : 64;
+            if (K > 63) K = 63;
+            bool const lastInc = (__ballot(inc) >> (K - 1)) & 1, lastEnd = (__ballot(endAfter) >> (K - 1)) & 1;
+            unsigned long long const liveMask = below_mask(K + 1), searchMask = below_mask(K);
+            bool const live = (int)lane <= K;
+
+            uint32_t const pc = p < nm8 ? p : nm8;
+            uint64_t const bytes = ld64(src + pc);
+            uint32_t const rv = ld32(src + (pc + 1 - off1));                 // off1 <= pc always; off1 == 0 is masked below
+            uint32_t const hl = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL) >> shL;
+            uint32_t const hs = hash_pos<MLS>(bytes, shS);
+            uint32_t const oldL = live ? tabL[hl] : 0, oldS = live ? tabS[hs] : 0;
+            uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
+            if (live) { scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane; }
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long const loseL = __ballot(live && scrL[sl] != (uint8_t)lane);
+            unsigned long long const loseS = __ballot(live && scrS[ss] != (uint8_t)lane);
+            __builtin_amdgcn_wave_barrier();
+
+            uint64_t cbL = ld64(src + (oldL < nm8 ? oldL : nm8));           // table values are <= n-8 by construction
+            uint32_t cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+            uint32_t candL = oldL, candS = oldS;
+            unsigned long long grpL = 0, grpS = 0;
+            if (loseL) {
+                grpL = lane_groups(hl, loseL, liveMask);
+                unsigned long long const prev = grpL & below_mask((int)lane);
+                uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
+                uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd), dhi = __shfl((uint32_t)(bytes >> 32), (int)pd);
+                if (prev) { candL = dp; cbL = ((uint64_t)dhi << 32) | dlo; }
+            }
+            if (loseS) {
+                grpS = lane_groups(hs, loseS, liveMask);
+                unsigned long long const prev = grpS & below_mask((int)lane);
+                uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
+                uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd);
+                if (prev) { candS = dp; cbS = dlo; }
+            }
+            bool const hitL = candL != 0 && cbL == bytes;                    // :203 MEM_read64 equal
+            bool const hitS = candS != 0 && cbS == (uint32_t)bytes;          // :218 MEM_read32 equal
+            bool const hitR = off1 > 0 && rv == (uint32_t)(bytes >> 8);      // :190 repcode at ip+1
+            unsigned long long const mL = __ballot(hitL), mR = __ballot(hitR) & searchMask, mS = __ballot(hitS) & searchMask;
+            unsigned long long const mAny = (mL & searchMask) | mR | mS;
+            int const jE = mAny ? first_lane(mAny) : 64;
+            int const Lcommit = jE < 64 ? jE + 1 : K;
+            if (jE < 64) evKind = ((mR >> jE) & 1) ? 1 : (((mL >> jE) & 1) ? 2 : 3);
+            // :187 hashLong[hl0] = hashSmall[hs0] = curr for every position up to the event: last lane of a group wins
+            {   bool const inC = (int)lane < Lcommit;
+                unsigned long long const cm = below_mask(Lcommit) & ~below_mask((int)lane + 1);
+                if (inC && (grpL & cm) == 0) tabL[hl] = p;
+                if (inC && (grpS & cm) == 0) tabS[hs] = p;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (evKind) {
+                curr = __builtin_amdgcn_readlane(p, jE);
+                candE = __builtin_amdgcn_readlane(evKind == 2 ? candL : candS, jE);
+                ip1 = __builtin_amdgcn_readlane(p, jE + 1);                  // lane jE+1 <= K is live
+                cand1 = __builtin_amdgcn_readlane(candL, jE + 1);
+                long1 = (mL >> (jE + 1)) & 1;                                // :253 long match at ip1 (8 bytes equal, valid index)
+                if (evKind != 1 && step < 4) {                               // :283-291 hashLong[hl1] = ip1
+                    if ((int)lane == jE + 1) tabL[hl] = p;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                break;
+            }
+            ip = ip + (uint32_t)K * step;                                    // :236-237
+            if (lastEnd) break;
+            if (lastInc) { step++; nextStep += 256; }
+        }
+        if (evKind == 0) break;
+
+        uint32_t mLength, offBase;
+        uint32_t mstart = curr;
+        if (evKind == 1) {                                                   // :190-195
+            mstart = curr + 1;
+            mLength = 4 + wave_count_fwd(src, mstart + 4, mstart + 4 - off1, nm8);
+            offBase = 1;
+        } else {
+            uint32_t match = candE;
+            if (evKind == 2) {                                               // :203-209
+                mLength = 8 + wave_count_fwd(src, curr + 8, match + 8, nm8);
+            } else {                                                         // :248-264 _search_next_long
+                mLength = 4 + wave_count_fwd(src, curr + 4, match + 4, nm8);
+                if (long1) {
+                    uint32_t const l1len = 8 + wave_count_fwd(src, ip1 + 8, cand1 + 8, nm8);
+                    if (l1len > mLength) { mstart = ip1; mLength = l1len; match = cand1; }
+                }
+            }
+            uint32_t const offset = mstart - match;
+            {   uint32_t const lim = (mstart - anchor) < match ? (mstart - anchor) : match;      // :207, :267 catch up
+                uint32_t const back = wave_count_back(src, mstart, match, lim);
+                mstart -= back; mLength += back;
+            }
+            off2 = off1; off1 = offset;
+            offBase = offset + 3;
+        }
+        lits_copy(out, src, nm8, anchor, mstart - anchor);
+        store_seq(out, mstart - anchor, offBase, mLength);
+        ip = mstart + mLength; anchor = ip;
+
+        if ((int32_t)ip <= ilimit) {                                         // :300-320
+            {   // complementary inserts: long[curr+2], long[ip-2], short[curr+2], short[ip-1] — in this order
+                uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
+                uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
+                uint32_t const hL = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL, hS = hash_pos<MLS>(b, shS);
+                if (lane == 0) { tabL[hL] = q; tabS[hS] = q; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 1) tabL[hL] = q;
+                if (lane == 2) tabS[hS] = q;
+                __builtin_amdgcn_wave_barrier();
+            }
+            while ((int32_t)ip <= ilimit && off2 > 0) {
+                uint64_t const b = ld64(src + ip);
+                if ((uint32_t)b != ld32(src + ip - off2)) break;
+                uint32_t const rLength = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
+                {   uint32_t const t = off2; off2 = off1; off1 = t; }
+                if (lane == 0) { tabS[hash_pos<MLS>(b, shS)] = ip; tabL[mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL] = ip; }
+                __builtin_amdgcn_wave_barrier();
+                store_seq(out, 0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+    lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals
+    lits_flush(out);
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];
+        out.litPos = n;
+    }
+    // ---- _cleanup (:248-256)
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+    if (lane == 0) {
+        meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
+        meta->longPos = out.longPos; meta->longType = out.longType;
+        meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = 8;
+        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
+    }
+}
+
+}  // namespace zhip
