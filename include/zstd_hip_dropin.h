@@ -1,0 +1,49 @@
+/* zstd_hip_dropin.h — the ZSTD_* entry points libzstd_hipshim.so exports (frame-level boundary B2).
+ *
+ * The prototypes are the reference's own (facebook/zstd lib/zstd.h, line cited per function): a program written
+ * against zstd.h compiles unchanged and links -lzstd_hipshim instead of -lzstd for the calls below.  Everything is
+ * served by the gfx950 kernels of libzstd_hip.so; there is NO CPU path, so a parameter set the device core does not
+ * implement returns the reference's own error code (ZSTD_error_parameter_unsupported, lib/zstd_errors.h:74) instead
+ * of silently compressing on the host.
+ *
+ * Output contract
+ *   srcSize <= 128 KB : ONE frame, byte-identical to the reference's ZSTD_compress2 at the same level.
+ *   srcSize  > 128 KB : the source is cut into 128 KB units, each an independent frame (content size in every frame
+ *                       header), emitted back to back.  That is a valid zstd stream (RFC 8878 3.1: frames may be
+ *                       concatenated; ZSTD_decompress decodes it, lib/decompress/zstd_decompress.c:1068) and equals
+ *                       `zstd -b<level> -B128K` chunking, but it is NOT the reference's single shared-window frame.
+ *                       ZSTD_getFrameContentSize() of the stream reports the first unit only; use
+ *                       ZSTD_findDecompressedSize() (lib/zstd.h:1492) for the total.
+ */
+#ifndef ZSTD_HIP_DROPIN_H
+#define ZSTD_HIP_DROPIN_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ZSTD_CCtx_s ZSTD_CCtx;                                   /* lib/zstd.h:262 */
+typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_reset_session_and_parameters = 3 } ZSTD_ResetDirective;   /* :569 */
+/* ZSTD_cParameter values this shim understands (lib/zstd.h:331-507); all others -> parameter_unsupported */
+enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
+       ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
+       ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400 };
+
+ZSTD_CCtx*  ZSTD_createCCtx(void);                                                                 /* lib/zstd.h:263 */
+size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                                        /* :264 */
+size_t      ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);                         /* :534 */
+size_t      ZSTD_CCtx_reset(ZSTD_CCtx* cctx, ZSTD_ResetDirective reset);                           /* :590 */
+size_t      ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* :603 */
+size_t      ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* :274 */
+size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* :160 */
+size_t      ZSTD_compressBound(size_t srcSize);                                                    /* :236 (here: the bound of the frame-per-unit stream, >= the reference's) */
+unsigned    ZSTD_isError(size_t code);                                                             /* :243 */
+const char* ZSTD_getErrorName(size_t code);                                                        /* :244 */
+int         ZSTD_minCLevel(void);                                                                  /* :245 */
+int         ZSTD_maxCLevel(void);                                                                  /* :246 (highest level the device core implements) */
+int         ZSTD_defaultCLevel(void);                                                              /* :247 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+"""-m gpu: the ZSTD_*-named drop-in (libzstd_hipshim.so, include/zstd_hip_dropin.h = boundary B2 of SURVEY.md 8b).
+A caller written against zstd.h: createCCtx / setParameter / compress2 / compressCCtx / compress.  Checked against
+the REAL reference when oracle/_ref is present (bytes for <= 128 KB inputs, ZSTD_decompress round trip for larger
+ones), else against the oracle restatement."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, _buf, ROOT, ERR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import zstd_amd                                    # loads torch's HIP runtime first, then libzstd_hip
+    zstd_amd.lib()
+    from zstd_amd import build as zb
+    S = C.CDLL(zb.SHIM)
+    S.ZSTD_createCCtx.restype = C.c_void_p
+    S.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    S.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    S.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    S.ZSTD_CCtx_reset.restype = C.c_size_t
+    S.ZSTD_CCtx_reset.argtypes = [C.c_void_p, C.c_int]
+    for f in ("ZSTD_compress2",):
+        getattr(S, f).restype = C.c_size_t
+        getattr(S, f).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    S.ZSTD_compressCCtx.restype = C.c_size_t
+    S.ZSTD_compressCCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    S.ZSTD_compress.restype = C.c_size_t
+    S.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    S.ZSTD_compressBound.restype = C.c_size_t
+    S.ZSTD_compressBound.argtypes = [C.c_size_t]
+    S.ZSTD_isError.argtypes = [C.c_size_t]
+    S.ZSTD_getErrorName.restype = C.c_char_p
+    S.ZSTD_getErrorName.argtypes = [C.c_size_t]
+    return S, load_oracle(), (load_ref() if have_ref() else None)
+
+
+def expect_unit(lo, lr, a, level):
+    """the reference's ZSTD_compress2 of one <= 128 KB input (real library if present, else the oracle)"""
+    cap = lo.zo_compress_bound(len(a)) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    if lr is not None:
+        r = lr.zref_compress_frame(level, _buf(a), len(a), _buf(dst), cap)
+    else:
+        r = lo.zo_compress_unit(_buf(dst), cap, _buf(a), len(a), level)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+def shim_compress2(S, a, level=None, cap=None):
+    c = S.ZSTD_createCCtx()
+    if level is not None:
+        assert S.ZSTD_CCtx_setParameter(c, 100, level) == 0
+    cap = S.ZSTD_compressBound(len(a)) if cap is None else cap
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a) if len(a) else None, len(a))
+    S.ZSTD_freeCCtx(c)
+    return r, dst
+
+
+@pytest.mark.parametrize("level", [1, 3, None, -5])
+def test_single_unit_is_byte_identical_to_the_reference(env, level):
+    S, lo, lr = env
+    for n in (0, 5, 100, 4096, 70000, 131072):
+        for name, a in list(corpus_cases(lo, sizes=(n,), seeds=(9,)))[:6]:
+            r, dst = shim_compress2(S, a, level)
+            assert not S.ZSTD_isError(r), (name, S.ZSTD_getErrorName(r))
+            assert dst[:r].tobytes() == expect_unit(lo, lr, a, 3 if level is None else level), (name, level)
+
+
+def test_large_input_is_a_valid_stream_of_unit_frames(env):
+    S, lo, lr = env
+    n = 5 * 131072 + 4321
+    a = datagen(lo, n, 50, 11)
+    r, dst = shim_compress2(S, a, 1)
+    assert not S.ZSTD_isError(r)
+    # equals the reference run per 128 KB chunk (zstd -b1 -B128K) ...
+    cap = lo.zo_compress_bound(131072) * 6
+    want = np.zeros(cap, dtype=np.uint8)
+    w = lo.zo_compress_chunks(1, 131072, _buf(a), n, _buf(want), cap, None, 0)
+    assert dst[:r].tobytes() == want[:w].tobytes()
+    # ... and the reference decoder restores the input from the concatenated frames
+    if lr is not None:
+        out = np.zeros(n, dtype=np.uint8)
+        d = lr.zref_decompress(_buf(out), n, _buf(dst), r)
+        assert d == n and out.tobytes() == a.tobytes()
+
+
+def test_compressCCtx_ignores_cctx_level_and_one_shot_works(env):
+    S, lo, lr = env
+    a = datagen(lo, 50000, 60, 12)
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_CCtx_setParameter(c, 100, 3) == 0
+    cap = S.ZSTD_compressBound(len(a))
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = S.ZSTD_compressCCtx(c, _buf(dst), cap, _buf(a), len(a), 1)
+    assert dst[:r].tobytes() == expect_unit(lo, lr, a, 1)
+    r2 = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), len(a))         # the cctx still holds level 3
+    assert dst[:r2].tobytes() == expect_unit(lo, lr, a, 3)
+    S.ZSTD_freeCCtx(c)
+    r3 = S.ZSTD_compress(_buf(dst), cap, _buf(a), len(a), 2)
+    assert dst[:r3].tobytes() == expect_unit(lo, lr, a, 2)
+
+
+def test_errors_use_the_reference_codes_and_nothing_falls_back_to_the_host(env):
+    S, lo, lr = env
+    a = datagen(lo, 20000, 50, 13)
+    r, _ = shim_compress2(S, a, 19)                                    # btultra2: not on the device, no CPU fallback
+    assert S.ZSTD_isError(r) and r == C.c_size_t(-40).value            # parameter_unsupported
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 201, 1))         # checksumFlag
+    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 400, 2))         # nbWorkers
+    assert S.ZSTD_CCtx_setParameter(c, 101, 0) == 0                    # windowLog 0 = default
+    S.ZSTD_freeCCtx(c)
+    r, dst = shim_compress2(S, a, 1, cap=64)                           # far too small
+    assert S.ZSTD_isError(r) and r == C.c_size_t(-70).value            # dstSize_tooSmall
+    want = expect_unit(lo, lr, a, 1)
+    r, dst = shim_compress2(S, a, 1, cap=len(want))                    # exactly enough, below ZSTD_compressBound
+    assert not S.ZSTD_isError(r) and dst[:r].tobytes() == want

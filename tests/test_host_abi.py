@@ -27,9 +27,31 @@ def test_every_declared_symbol_is_exported(zlib_):
     assert not missing, missing
 
 
+def test_dropin_shim_exports_every_declared_symbol(zlib_):
+    """libzstd_hipshim.so: the ZSTD_* names of include/zstd_hip_dropin.h, all present, all backed by libzstd_hip only"""
+    from zstd_amd import build as zb
+    hdr = open(os.path.join(ROOT, "include", "zstd_hip_dropin.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                      # declarations only, not the prose
+    names = sorted(set(re.findall(r"\b(ZSTD_[a-zA-Z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 12 and "ZSTD_compress2" in names
+    L = C.CDLL(zb.SHIM)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    out = subprocess.check_output(["ldd", zb.SHIM]).decode()
+    assert "libzstd_hip.so" in out and "zoracle" not in out and "zstd_ref" not in out
+    # host-only entry points behave like the reference's
+    L.ZSTD_compressBound.restype = C.c_size_t
+    L.ZSTD_compressBound.argtypes = [C.c_size_t]
+    L.ZSTD_isError.argtypes = [C.c_size_t]
+    assert L.ZSTD_compressBound(131072) == 131072 + 512 and L.ZSTD_isError(C.c_size_t(-40).value) == 1 and L.ZSTD_isError(1000) == 0
+    assert L.ZSTD_defaultCLevel() == 3
+
+
 def test_no_oracle_or_reference_in_the_product_binary(zlib_):
-    out = subprocess.check_output(["ldd", zlib_.LIB_PATH]).decode()
-    assert "zoracle" not in out and "zstd_ref" not in out and "zref" not in out
+    from zstd_amd import build as zb
+    for lib in (zlib_.LIB_PATH, zb.SHIM):
+        out = subprocess.check_output(["ldd", lib]).decode()
+        assert "zoracle" not in out and "zstd_ref" not in out and "zref" not in out
     syms = subprocess.check_output(["nm", "-D", zlib_.LIB_PATH]).decode()
     assert " zo_" not in syms and "ZSTD_compress" not in syms
 
