@@ -59,6 +59,34 @@ size_t zref_compress_chunks(int level, size_t chunkSize, const void* src, size_t
     return pos;
 }
 
+/* O1 for the hash-chain strategies: as above with ZSTD_c_useRowMatchFinder = ZSTD_ps_disable, so that greedy / lazy /
+ * lazy2 use ZSTD_HcFindBestMatch (zstd_lazy.c:667) instead of the row-hash matcher. */
+size_t zref_compress_chunks_norow(int level, size_t chunkSize, const void* src, size_t n,
+                                  void* dst, size_t dstCap, size_t* sizes, size_t maxChunks)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0, k = 0;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+    if (n == 0) {
+        size_t r = ZSTD_compress2(c, dst, dstCap, src, 0);
+        ZSTD_freeCCtx(c);
+        if (ZSTD_isError(r)) return (size_t)-1;
+        if (sizes && maxChunks) sizes[0] = r;
+        return r;
+    }
+    while (off < n) {
+        size_t const len = (n - off < chunkSize) ? n - off : chunkSize;
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, len);
+        if (ZSTD_isError(r)) { ZSTD_freeCCtx(c); return (size_t)-1; }
+        if (sizes && k < maxChunks) sizes[k] = r;
+        k++; pos += r; off += len;
+    }
+    ZSTD_freeCCtx(c);
+    return pos;
+}
+
 /* Same but with every cParam pinned explicitly (windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy). */
 size_t zref_compress_chunks_params(const int cp[7], size_t chunkSize, const void* src, size_t n,
                                    void* dst, size_t dstCap, size_t* sizes, size_t maxChunks)
@@ -105,6 +133,7 @@ size_t zref_sequences(int level, const void* src, size_t n, unsigned* out, size_
     size_t r, i;
     if (!c || !s) return (size_t)-1;
     set_level(c, level);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);   /* no effect below greedy */
     r = ZSTD_generateSequences(c, s, capSeqs, src, n);
     if (ZSTD_isError(r)) { free(s); ZSTD_freeCCtx(c); return (size_t)-1; }
     for (i = 0; i < r; i++) {

@@ -21,12 +21,21 @@ static void wr24(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v
 static void wr32(uint8_t* p, uint32_t v) { wr16(p, v & 0xFFFF); wr16(p + 2, v >> 16); }
 
 /* ------------------------------------------------------------------ parameters */
-/* lib/compress/clevels.h:24-130, rows "base for negative levels" .. level 4 of the four size classes */
-static const zo_cparams kRows[4][5] = {
-  { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2} },  /* > 256 KB  */
-  { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,3} },  /* <= 256 KB */
-  { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2} },  /* <= 128 KB */
-  { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,3} },  /* <= 16 KB  */
+/* lib/compress/clevels.h:24-130, rows "base for negative levels" .. level 12 of the four size classes
+ * (strategy: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; 6+ = binary-tree strategies, outside this oracle) */
+static const zo_cparams kRows[4][13] = {
+  { {19,12,13,1,6,1,1}, {19,13,14,1,7,0,1}, {20,15,16,1,6,0,1}, {21,16,17,1,5,0,2}, {21,18,18,1,5,0,2},      /* > 256 KB  */
+    {21,18,19,3,5,2,3}, {21,18,19,3,5,4,4}, {21,19,20,4,5,8,4}, {21,19,20,4,5,16,5}, {22,20,21,4,5,16,5},
+    {22,21,22,5,5,16,5}, {22,21,22,6,5,16,5}, {22,22,23,6,5,32,5} },
+  { {18,12,13,1,5,1,1}, {18,13,14,1,6,0,1}, {18,14,14,1,5,0,2}, {18,16,16,1,4,0,2}, {18,16,17,3,5,2,3},      /* <= 256 KB */
+    {18,17,18,5,5,2,3}, {18,18,19,3,5,4,4}, {18,18,19,4,4,4,4}, {18,18,19,4,4,8,5}, {18,18,19,5,4,8,5},
+    {18,18,19,6,4,8,5}, {18,18,19,5,4,12,6}, {18,19,19,7,4,12,6} },
+  { {17,12,12,1,5,1,1}, {17,12,13,1,6,0,1}, {17,13,15,1,5,0,1}, {17,15,16,2,5,0,2}, {17,17,17,2,4,0,2},      /* <= 128 KB */
+    {17,16,17,3,4,2,3}, {17,16,17,3,4,4,4}, {17,16,17,3,4,8,5}, {17,16,17,4,4,8,5}, {17,16,17,5,4,8,5},
+    {17,16,17,6,4,8,5}, {17,17,17,5,4,8,6}, {17,18,17,7,4,12,6} },
+  { {14,12,13,1,5,1,1}, {14,14,15,1,5,0,1}, {14,14,15,1,4,0,1}, {14,14,15,2,4,0,2}, {14,14,14,4,4,2,3},      /* <= 16 KB  */
+    {14,14,14,3,4,4,4}, {14,14,14,4,4,8,5}, {14,14,14,6,4,8,5}, {14,14,14,8,4,8,5}, {14,15,14,5,4,8,6},
+    {14,15,14,9,4,8,6}, {14,15,14,3,4,12,7}, {14,15,14,4,3,24,7} },
 };
 
 /* zstd_compress.c:7123-7145 (row pick) then :1466-1602 (adjust) with dictSize 0 and a known srcSize */
@@ -37,13 +46,13 @@ int zo_get_cparams(int level, unsigned long long srcSize, zo_cparams* out)
     zo_cparams cp;
     if (level == 0) row = 3;                       /* ZSTD_CLEVEL_DEFAULT */
     if (level < 0) row = 0;
-    if (row > 4) return -1;                        /* strategies above dfast are outside this oracle */
+    if (row > 12) return -1;                       /* only binary-tree strategies up there */
     cp = kRows[tableID][row];
     if (level < 0) {                               /* :7139-7142, ZSTD_minCLevel() = -(1<<17) */
         int const clamped = level < -131072 ? -131072 : level;
         cp.targetLength = (unsigned)(-clamped);
     }
-    if (cp.strategy > 2) return -1;
+    if (cp.strategy > 5) return -1;                /* btlazy2 and up are outside this oracle */
     if (srcSize <= (1ULL << 30)) {                 /* :1546-1553 */
         uint32_t const tSize = (uint32_t)srcSize;
         unsigned const srcLog = (tSize < 64) ? 6 : hb32(tSize - 1) + 1;
@@ -272,6 +281,142 @@ static size_t zo_dfast(const zo_cparams* cp, const uint8_t* src, size_t n, zo_st
     return n - anchor;
 }
 
+/* ---- hash-chain match finder + lazy parser (strategies greedy / lazy / lazy2 with the row matcher disabled) ---- */
+typedef struct {
+    uint32_t* head;        /* hashTable: pos+1 of the most recent inserted position per hash, 0 = empty */
+    uint32_t* chain;       /* chainTable[pos & mask]: pos+1 of the previous head at insertion time      */
+    unsigned hlog, clog, slog, mls;
+    size_t nextToUpdate;   /* zstd_compress_internal.h:232 */
+    int lazySkipping;      /* :253 */
+} zo_hc;
+
+/* zstd_lazy.c:632-657 ZSTD_insertAndFindFirstIndex_internal + :667-773 ZSTD_HcFindBestMatch (noDict).
+ * Returns the best match length (>= 4) at ip, or 3 when nothing was found; *offBase = offset + 3. */
+static size_t zo_hc_best(zo_hc* hc, const uint8_t* src, size_t n, size_t ip, uint32_t* offBase)
+{
+    uint32_t const cmask = (1u << hc->clog) - 1;
+    size_t const chainSize = (size_t)1 << hc->clog;
+    unsigned nbAttempts = 1u << hc->slog;
+    size_t ml = 4 - 1, idx = hc->nextToUpdate;
+    uint32_t m;
+    while (idx < ip) {                                                           /* :645-653 catch up */
+        uint32_t const h = zo_hash(src + idx, hc->hlog, hc->mls);
+        hc->chain[idx & cmask] = hc->head[h];
+        hc->head[h] = (uint32_t)idx + 1;
+        idx++;
+        if (hc->lazySkipping) break;
+    }
+    hc->nextToUpdate = ip;
+    m = hc->head[zo_hash(src + ip, hc->hlog, hc->mls)];
+    /* lowLimit = start of the unit (:688-692: the window is never exceeded inside one <= 128 KB unit) */
+    for (; m != 0 && nbAttempts > 0; nbAttempts--) {                             /* :711 */
+        size_t const mp = m - 1;
+        size_t cur = 0;
+        if (rd32(src + mp + ml - 3) == rd32(src + ip + ml - 3)) cur = zo_count(src, ip, mp, n);   /* :716-717 */
+        if (cur > ml) {                                                          /* :726-730 */
+            ml = cur; *offBase = (uint32_t)(ip - mp) + 3;
+            if (ip + cur == n) break;
+        }
+        if (ip >= chainSize && mp <= ip - chainSize) break;                      /* :732 matchIndex <= minChain */
+        m = hc->chain[mp & cmask];
+    }
+    return ml;
+}
+
+static unsigned zo_gain_bits(uint32_t offBase) { return hb32(offBase); }
+
+/* zstd_lazy.c:1516-1779 ZSTD_compressBlock_lazy_generic(search_hashChain, depth, ZSTD_noDict), one block, empty history */
+static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3], unsigned depth)
+{
+    zo_hc hc;
+    size_t const ilimit = n - 8;                                                 /* :1528 */
+    size_t ip = 0, anchor = 0;
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
+    hc.hlog = cp->hashLog; hc.clog = cp->chainLog; hc.slog = cp->searchLog;
+    hc.mls = cp->minMatch < 4 ? 4 : (cp->minMatch > 6 ? 6 : cp->minMatch);      /* :1531 */
+    hc.head = (uint32_t*)calloc((size_t)1 << hc.hlog, sizeof(uint32_t));
+    hc.chain = (uint32_t*)calloc((size_t)1 << hc.clog, sizeof(uint32_t));
+    hc.nextToUpdate = 0; hc.lazySkipping = 0;                                    /* :1567 */
+    ip += 1;                                                                     /* :1552 dictAndPrefixLength == 0 */
+    {   uint32_t const maxRep = 1;                                               /* :1553-1559 */
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
+    }
+    while (ip < ilimit) {                                                        /* :1581 */
+        size_t matchLength = 0, start = ip + 1;
+        uint32_t offBase = 1;                                                    /* REPCODE1_TO_OFFBASE */
+        int direct = 0;
+        if (off1 > 0 && rd32(src + ip + 1 - off1) == rd32(src + ip + 1)) {       /* :1600-1604 */
+            matchLength = zo_count(src, ip + 1 + 4, ip + 1 + 4 - off1, n) + 4;
+            if (depth == 0) direct = 1;
+        }
+        if (!direct) {
+            {   uint32_t found = 999999999;                                      /* :1607-1611 */
+                size_t const ml2 = zo_hc_best(&hc, src, n, ip, &found);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+            }
+            if (matchLength < 4) {                                               /* :1613-1625 */
+                size_t const step = ((ip - anchor) >> 8) + 1;                    /* kSearchStrength = 8 */
+                ip += step;
+                hc.lazySkipping = step > 8;                                      /* kLazySkippingStep = 8 */
+                continue;
+            }
+            if (depth >= 1)
+            while (ip < ilimit) {                                                /* :1628-1700 */
+                ip++;
+                if (offBase && off1 > 0 && rd32(src + ip) == rd32(src + ip - off1)) {
+                    size_t const mlRep = zo_count(src, ip + 4, ip + 4 - off1, n) + 4;
+                    int const gain2 = (int)(mlRep * 3);
+                    int const gain1 = (int)(matchLength * 3 - zo_gain_bits(offBase) + 1);
+                    if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                }
+                {   uint32_t cand = 999999999;
+                    size_t const ml2 = zo_hc_best(&hc, src, n, ip, &cand);
+                    int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                    int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 4);
+                    if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                }
+                if (depth == 2 && ip < ilimit) {                                 /* :1663-1698 */
+                    ip++;
+                    if (offBase && off1 > 0 && rd32(src + ip) == rd32(src + ip - off1)) {
+                        size_t const mlRep = zo_count(src, ip + 4, ip + 4 - off1, n) + 4;
+                        int const gain2 = (int)(mlRep * 4);
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 1);
+                        if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                    {   uint32_t cand = 999999999;
+                        size_t const ml2 = zo_hc_best(&hc, src, n, ip, &cand);
+                        int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 7);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3) {                                                   /* :1707-1714 catch up */
+                uint32_t const off = offBase - 3;
+                while (start > anchor && start - off > 0 && src[start - 1] == src[start - off - 1]) { start--; matchLength++; }
+                off2 = off1; off1 = off;
+            }
+        }
+        zo_store_seq(st, src, anchor, start - anchor, offBase, (uint32_t)matchLength);   /* :1727-1731 */
+        anchor = ip = start + matchLength;
+        hc.lazySkipping = 0;                                                     /* :1732-1738 */
+        while (ip <= ilimit && off2 > 0 && rd32(src + ip) == rd32(src + ip - off2)) {    /* :1763-1773 */
+            uint32_t const t = off2;
+            matchLength = zo_count(src, ip + 4, ip + 4 - off2, n) + 4;
+            off2 = off1; off1 = t;
+            zo_store_seq(st, src, anchor, 0, 1, (uint32_t)matchLength);
+            ip += matchLength; anchor = ip;
+        }
+    }
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;                       /* :1777-1783 */
+    rep[0] = off1 ? off1 : saved1;
+    rep[1] = off2 ? off2 : saved2;
+    free(hc.head); free(hc.chain);
+    return n - anchor;
+}
+
 /* zstd_compress.c:3207-3369 ZSTD_buildSeqStore for a history-less block (+ :3365 trailing literals) */
 size_t zo_parse_block(const zo_cparams* cp, const uint8_t* src, size_t n,
                       zo_seq* seqs, size_t cap, uint8_t* lits, size_t* litSize, uint32_t repOut[3])
@@ -281,7 +426,8 @@ size_t zo_parse_block(const zo_cparams* cp, const uint8_t* src, size_t n,
     st.seqs = seqs; st.nb = 0; st.cap = cap; st.lits = lits; st.litSize = 0; st.overflow = 0;
     if (n < 8) last = n;                     /* the block compressors' loops need ilimit = n-8 >= 0; nothing found */
     else if (cp->strategy == 1) last = zo_fast(cp, src, n, &st, rep);
-    else last = zo_dfast(cp, src, n, &st, rep);
+    else if (cp->strategy == 2) last = zo_dfast(cp, src, n, &st, rep);
+    else last = zo_lazy(cp, src, n, &st, rep, cp->strategy - 3);                 /* greedy 3 / lazy 4 / lazy2 5 */
     memcpy(lits + st.litSize, src + n - last, last);
     st.litSize += last;
     *litSize = st.litSize;
@@ -883,16 +1029,71 @@ static unsigned ml_code(uint32_t mlBase)                                        
     return mlBase > 127 ? hb32(mlBase) + 36 : t[mlBase];
 }
 
-/* zstd_compress_sequences.c:157-235 for strategy < lazy with repeatMode none. returns set_* (0 basic,1 rle,2 compressed) */
-static int select_type(unsigned maxCount, size_t nbSeq, unsigned defaultNormLog, int defaultAllowed, unsigned strategy)
+/* zstd_compress_sequences.c:21-44 */
+static const unsigned kInvProbLog256[256] = {
+    0,    2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+    1024, 1001, 980,  960,  941,  923,  906,  889,  874,  859,  844,  830,  817,  804,  791,  779,
+    768,  756,  745,  734,  724,  714,  704,  694,  685,  676,  667,  658,  650,  642,  633,  626,
+    618,  610,  603,  595,  588,  581,  574,  567,  561,  554,  548,  542,  535,  529,  523,  517,
+    512,  506,  500,  495,  489,  484,  478,  473,  468,  463,  458,  453,  448,  443,  438,  434,
+    429,  424,  420,  415,  411,  407,  402,  398,  394,  390,  386,  382,  377,  373,  370,  366,
+    362,  358,  354,  350,  347,  343,  339,  336,  332,  329,  325,  322,  318,  315,  311,  308,
+    305,  302,  298,  295,  292,  289,  286,  282,  279,  276,  273,  270,  267,  264,  261,  258,
+    256,  253,  250,  247,  244,  241,  239,  236,  233,  230,  228,  225,  222,  220,  217,  215,
+    212,  209,  207,  204,  202,  199,  197,  194,  192,  190,  187,  185,  182,  180,  178,  175,
+    173,  171,  168,  166,  164,  162,  159,  157,  155,  153,  151,  149,  146,  144,  142,  140,
+    138,  136,  134,  132,  130,  128,  126,  123,  121,  119,  117,  115,  114,  112,  110,  108,
+    106,  104,  102,  100,  98,   96,   94,   93,   91,   89,   87,   85,   83,   82,   80,   78,
+    76,   74,   73,   71,   69,   67,   66,   64,   62,   61,   59,   57,   55,   54,   52,   50,
+    49,   47,   46,   44,   42,   41,   39,   37,   36,   34,   33,   31,   30,   28,   26,   25,
+    23,   22,   20,   19,   17,   16,   14,   13,   11,   10,   8,    7,    5,    4,    2,    1,
+};
+
+static unsigned fse_optimal_log(unsigned maxLog, size_t n, unsigned maxSym, unsigned minus);
+static size_t fse_write_ncount(uint8_t* out0, const short* norm, unsigned maxSym, unsigned tableLog);
+
+/* zstd_compress_sequences.c:157-235 with repeatMode none. returns set_* (0 basic,1 rle,2 compressed) */
+static int select_type(const unsigned* count, unsigned max, unsigned maxCount, size_t nbSeq, unsigned fseLog,
+                       const short* defNorm, unsigned defaultNormLog, int defaultAllowed, unsigned strategy)
 {
     if (maxCount == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
-    if (defaultAllowed) {
-        size_t const mult = 10 - strategy;
-        size_t const dynMin = (((size_t)1 << defaultNormLog) * mult) >> 3;
-        if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) return 0;
+    if (strategy < 4) {                                                          /* :179-204, strategy < ZSTD_lazy */
+        if (defaultAllowed) {
+            size_t const mult = 10 - strategy;
+            size_t const dynMin = (((size_t)1 << defaultNormLog) * mult) >> 3;
+            if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) return 0;
+        }
+        return 2;
     }
-    return 2;
+    {   /* :205-231: estimated costs in bits; the repeat cost is an error (= huge) without a previous table */
+        size_t basicCost = (size_t)-1, ncountCost, compressedCost;
+        unsigned s;
+        if (defaultAllowed) {                                                    /* :141-155 ZSTD_crossEntropyCost */
+            unsigned const shift = 8 - defaultNormLog;
+            size_t cost = 0;
+            for (s = 0; s <= max; s++) {
+                unsigned const normAcc = defNorm[s] != -1 ? (unsigned)defNorm[s] : 1;
+                cost += (size_t)count[s] * kInvProbLog256[normAcc << shift];
+            }
+            basicCost = cost >> 8;
+        }
+        {   short norm[53]; uint8_t wksp[512];                                   /* :70-77 ZSTD_NCountCost */
+            unsigned const tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
+            if (zo_fse_normalize(norm, tableLog, count, nbSeq, max, nbSeq >= 2048) < 0) return -1;
+            ncountCost = fse_write_ncount(wksp, norm, max, tableLog);
+            if (!ncountCost) return -1;
+        }
+        {   unsigned cost = 0;                                                   /* :83-97 ZSTD_entropyCost */
+            for (s = 0; s <= max; s++) {
+                unsigned norm = (unsigned)((256 * count[s]) / nbSeq);
+                if (count[s] != 0 && norm == 0) norm = 1;
+                cost += count[s] * kInvProbLog256[norm];
+            }
+            compressedCost = (ncountCost << 3) + (cost >> 8);
+        }
+        if (basicCost <= compressedCost) return 0;                               /* :217-222 (repeatCost = error >= everything) */
+        return 2;
+    }
 }
 
 /* zstd_compress_sequences.c:243-288; returns bytes written to dst (NCount / rle byte), ZO_ERROR on failure */
@@ -934,19 +1135,22 @@ size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_
     seqHead = op++;
     {   size_t h, mf;
         max = 35; mf = hist_small(count, &max, llc, nbSeq);
-        tLL = select_type((unsigned)mf, nbSeq, 6, 1, cp->strategy);
+        tLL = select_type(count, max, (unsigned)mf, nbSeq, 9, kLLnorm, 6, 1, cp->strategy);
+        if (tLL < 0) { free(llc); return ZO_ERROR; }
         h = build_ctable(op, &ctLL, 9, tLL, count, max, llc, nbSeq, kLLnorm, 6, 35);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tLL == 2) lastCount = h;
         op += h;
         max = 31; mf = hist_small(count, &max, ofc, nbSeq);
-        tOF = select_type((unsigned)mf, nbSeq, 5, max <= 28, cp->strategy);
+        tOF = select_type(count, max, (unsigned)mf, nbSeq, 8, kOFnorm, 5, max <= 28, cp->strategy);
+        if (tOF < 0) { free(llc); return ZO_ERROR; }
         h = build_ctable(op, &ctOF, 8, tOF, count, max, ofc, nbSeq, kOFnorm, 5, 28);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tOF == 2) lastCount = h;
         op += h;
         max = 52; mf = hist_small(count, &max, mlc, nbSeq);
-        tML = select_type((unsigned)mf, nbSeq, 6, 1, cp->strategy);
+        tML = select_type(count, max, (unsigned)mf, nbSeq, 9, kMLnorm, 6, 1, cp->strategy);
+        if (tML < 0) { free(llc); return ZO_ERROR; }
         h = build_ctable(op, &ctML, 9, tML, count, max, mlc, nbSeq, kMLnorm, 6, 52);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tML == 2) lastCount = h;

@@ -58,6 +58,9 @@ def load_ref():
     lib.zref_compress_chunks.restype = C.c_size_t
     lib.zref_compress_chunks.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_size_t]
+    lib.zref_compress_chunks_norow.restype = C.c_size_t
+    lib.zref_compress_chunks_norow.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_size_t]
     lib.zref_compress_chunks_params.restype = C.c_size_t
     lib.zref_compress_chunks_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                                 C.c_size_t, C.c_void_p, C.c_size_t]

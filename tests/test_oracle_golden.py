@@ -7,14 +7,26 @@ from _libs import load_oracle, corpus_cases, _buf, ERR
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
 
 
+GOLD_HC = os.path.join(os.path.dirname(__file__), "golden", "units_v2_hashchain.json")
+
+
 def test_oracle_reproduces_golden_units():
+    _check(GOLD, (1, 3), 400)
+
+
+def test_oracle_reproduces_golden_hashchain_units():
+    """greedy / lazy / lazy2 with the hash-chain matcher (the reference run with useRowMatchFinder disabled)"""
+    _check(GOLD_HC, (5, 6, 7), 600)
+
+
+def _check(path, levels, atleast):
     lo = load_oracle()
-    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["units"]}
+    gold = {(g["case"], g["level"]): g for g in json.load(open(path))["units"]}
     sizes = sorted({g["n"] for g in gold.values()})
     seen = 0
     for n in sizes:
         for name, a in corpus_cases(lo, sizes=(n,), seeds=(0, 5)):
-            for level in (1, 3):
+            for level in levels:
                 g = gold.get((name, level))
                 if g is None:
                     continue
@@ -25,4 +37,4 @@ def test_oracle_reproduces_golden_units():
                 assert r != ERR and r == g["csize"], (name, level)
                 assert hashlib.sha256(dst[:r].tobytes()).hexdigest() == g["dst_sha256"], (name, level)
                 seen += 1
-    assert seen >= len(gold) > 400
+    assert seen >= len(gold) > atleast
