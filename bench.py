@@ -45,7 +45,14 @@ def cpu_baseline(sample, seconds=8.0, level=1):
             one = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds), "1"], timeout=120))
             ncores = os.cpu_count() or 1
             allc = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
-            return {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
+            extra = {}
+            if level >= 5:      # the reference's default matcher for greedy/lazy/lazy2 is the row hash; ours is byte-identical to its hash-chain mode
+                env = dict(os.environ, ZREF_NOROW="1")
+                hc1 = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), "1"], timeout=120, env=env))
+                hca = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120, env=env))
+                extra = {"hash_chain_mode": {"value": hc1["MBps"], "cores": 1, "ratio": hc1["ratio"], "all_cores": hca["MBps"],
+                                             "note": "ZSTD_c_useRowMatchFinder=disable: the mode whose bytes the GPU reproduces; `value` above is the reference default (row matcher)"}}
+            return {**extra, "value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
                     "sample": f"first {len(sample) >> 20} MiB of the workload, level {level}, {UNIT} B units, best of {one['runs']} runs "
                               f"(oracle/_ref/zref_bench = ZSTD_compress2 per unit, programs/benchzstd.c semantics)",
                     "all_cores": {"value": allc["MBps"], "cores": ncores}}
@@ -136,10 +143,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kparse = kent = kgat = ktot = 0.0
+    hc = {"chain_ms": 0.0, "search_ms": 0.0, "parse_ms": 0.0}
     for _ in range(args.steps):
         total = step()
         tm = ctx.timing()
         kparse += tm["parse_ms"]; kent += tm["entropy_ms"]; kgat += tm["gather_ms"]; ktot += tm["total_ms"]
+        for k, v in ctx.hc_timing().items():
+            hc[k] += v
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -170,7 +180,9 @@ def main():
             except Exception:
                 traffic = None
         cp = zstd_amd.get_cparams(args.level, UNIT)
-        cpdesc = f"{'ZSTD_fast' if cp[6] == 1 else 'ZSTD_dfast'} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} mml{cp[4]}"
+        sname = {1: "ZSTD_fast", 2: "ZSTD_dfast", 3: "ZSTD_greedy (hash chain)", 4: "ZSTD_lazy (hash chain)", 5: "ZSTD_lazy2 (hash chain)"}[cp[6]]
+        cpdesc = f"{sname} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} slog{cp[3]} mml{cp[4]}"
+        kname = {1: "k_parse_fast", 2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
         if cp[6] != 1:
             traffic = None                                        # the committed counters are for the level-1 kernel
         out = {
@@ -181,7 +193,7 @@ def main():
                                    f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
                        "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
             "ratio": round(world * n / total_all, 4),
-            "roofline": {"bound": "hbm", "kernel": "k_parse_fast" if cp[6] == 1 else "k_parse_dfast", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3)},
             "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "gather_ms": round(gat_ms, 3),
@@ -189,6 +201,8 @@ def main():
                          "achieved_GBps": round((n + int(total)) / (tot_ms * 1e-3) / 1e9, 2),
                          "frac_of_hbm_peak": round((n + int(total)) / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        if cp[6] >= 3:      # the match-finder stage is three kernels; the roofline figures above are for their sum
+            out["roofline"]["kernels_ms"] = {k: round(v / K, 3) for k, v in hc.items()}
         out["parity"] = parity_check(ctx, host, dst, total, sizes, args.level)
         if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)

@@ -79,6 +79,9 @@ size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* 
 /* ---- measurement: HIP-event durations (ms) of the kernels of the most recent call on this ctx
  * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */
 void         zhip_last_timing(const zhip_ctx* ctx, double t[4]);
+/* hash-chain strategies (levels 5+): the match-finder stage of the most recent call split by kernel, ms summed over
+ * its chunks: [0] k_hc_chain (links), [1] k_hc_search (best match per position), [2] k_parse_lazy (parser) */
+void         zhip_last_hc_timing(zhip_ctx* ctx, double t[3]);
 
 /* stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences, [4] literal bytes of the most recent call */
 size_t       zhip_last_stats(zhip_ctx* ctx, unsigned long long stats[5]);

@@ -36,6 +36,7 @@ static void* worker(void* p)
     ZSTD_CCtx* c = ZSTD_createCCtx();
     size_t off = 0, pos = 0;
     ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, j->level);
+    if (getenv("ZREF_NOROW")) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);   /* hash-chain matcher */
     while (off < j->n) {
         size_t const len = j->n - off < j->chunk ? j->n - off : j->chunk;
         size_t const r = ZSTD_compress2(c, j->dst + pos, j->dstCap - pos, j->src + off, len);

@@ -195,10 +195,18 @@ def emu_parse_units(le, src, units, seqs, lits, metas):
     """stage 1 on the emulator: fast or dfast kernel according to the units' strategy (all units alike)"""
     nu = len(units)
     strat = int(units["strategy"][0]) if nu else 1
-    assert (units["strategy"] == strat).all()
+    assert (units["strategy"] == strat).all() or ((units["strategy"] >= 3) & (units["strategy"] <= 5)).all()
     if strat == 1:
         smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
         le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
+    elif strat >= 3:
+        le.emu_hc_table_words.restype = C.c_uint64
+        stride = (int(le.emu_hc_table_words(int(units["hashLog"].max()))) + 3) & ~3
+        tabs = np.full(nu * stride + 4, 0xEEEEEEEE, dtype=np.uint32)
+        best = np.full(nu * 131072 + 4, 0xEEEEEEEEEEEEEEEE, dtype=np.uint64)
+        le.emu_parse_lazy.restype = None
+        le.emu_parse_lazy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        le.emu_parse_lazy(_buf(src), _buf(units), nu, _buf(tabs), stride, _buf(best), _buf(seqs), _buf(lits), _buf(metas), 0)
     else:
         le.emu_dfast_table_bytes.restype = C.c_uint64
         stride = max(int(le.emu_dfast_table_bytes(int(h), int(c))) for h, c in zip(units["hashLog"], units["chainLog"])) // 4

@@ -22,6 +22,22 @@ void emu_parse_dfast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits,
 }
 uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhip::dfast_table_bytes(hashLog, chainLog); }
 
+// hash-chain strategies (greedy / lazy / lazy2): the three launches of zhip_parse_lazy.h
+void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride, uint64_t* best,
+                    ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
+{
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::dfast_lds_bytes(),
+                 [=] { zhip::k_hc_chain(src, units, nUnits, tabs, tabStride); }, osThreads);
+    uint32_t maxLen = 1;
+    for (uint32_t i = 0; i < nUnits; i++) if (units[i].srcLen > maxLen) maxLen = units[i].srcLen;
+    uint32_t const bpu = (maxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
+    simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,
+                 [=] { zhip::k_hc_search(src, units, nUnits, bpu, tabs, tabStride, best); }, osThreads);
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0,
+                 [=] { zhip::k_parse_lazy(src, units, nUnits, tabs, tabStride, best, seqs, lits, metas); }, osThreads);
+}
+uint64_t emu_hc_table_words(uint32_t hashLog) { return zhip::hc_table_words(hashLog); }
+
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
                  const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)

@@ -57,3 +57,19 @@ def test_frames_negative_level_and_level2(libs):
         from _libs import make_units
         cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
         check(lo, le, cases, level)
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 10])
+def test_frames_hashchain_levels(libs, level):
+    """greedy / lazy / lazy2 frames (cost-based FSE table selection from lazy upwards) vs the oracle"""
+    lo, le = libs
+    import ctypes as C
+    def strat(nn):
+        cp = (C.c_uint * 7)()
+        return cp[6] if lo.zo_get_cparams(level, nn, cp) == 0 else -1            # small units at level 10 are btlazy2: not ours
+    cases = []
+    for n in (9, 10, 100, 1000, 20000, 131072):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(level,)))
+    cases = [c for c in cases if 3 <= strat(len(c[1])) <= 5]
+    assert cases
+    check(lo, le, cases, level)

@@ -86,3 +86,38 @@ def test_dfast_parse_levels_3_4(libs):
         cases = [c for c in cases if strat(len(c[1])) == 2]
         assert cases
         check(le, lo, cases, level)
+
+
+def _strat(lo, level, nn):
+    cp = (C.c_uint * 7)()
+    return cp[6] if lo.zo_get_cparams(level, nn, cp) == 0 else -1
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 9])
+def test_hashchain_parse_small(libs, level):
+    """greedy / lazy / lazy2 (hash chain) on the emulator vs the oracle: small and ragged units"""
+    lo, le = libs
+    cases = []
+    for n in (0, 9, 10, 11, 12, 20, 100, 1000, 5000, 20000):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(level,)))
+    cases = [c for c in cases if 3 <= _strat(lo, level, len(c[1])) <= 5]
+    assert cases
+    check(le, lo, cases, level)
+
+
+@pytest.mark.parametrize("level", [5, 6, 8])
+def test_hashchain_parse_128k(libs, level):
+    lo, le = libs
+    check(le, lo, list(corpus_cases(lo, sizes=(131072,), seeds=(1,))), level)
+
+
+@pytest.mark.parametrize("level", [5, 7])
+def test_hashchain_parse_skip_regions_then_matches(libs, level):
+    """lazy-skipping stretches (positions never inserted) followed by compressible data that points back into them"""
+    lo, le = libs
+    from _libs import datagen
+    rng = np.random.default_rng(level)
+    r1 = rng.integers(0, 256, size=20000, dtype=np.uint8)
+    mixed = np.concatenate([r1, datagen(lo, 30000, 60, level), r1[3000:15000], rng.integers(0, 256, size=9000, dtype=np.uint8),
+                            r1[:9000], datagen(lo, 21072, 30, level + 1)])
+    check(le, lo, [("mixed", mixed), ("mixed_short", mixed[:70001])], level)

@@ -10,6 +10,7 @@ from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, _buf, 
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
+GOLD_HC = os.path.join(os.path.dirname(__file__), "golden", "units_v2_hashchain.json")
 
 
 @pytest.fixture(scope="module")
@@ -64,7 +65,7 @@ def test_units_128k_match_oracle_bytes(env):
         assert dec.tobytes() == flat.tobytes()
 
 
-@pytest.mark.parametrize("level", [1, 2, -1, -7, 3, 4])
+@pytest.mark.parametrize("level", [1, 2, -1, -7, 3, 4, 5, 6, 8])
 def test_ragged_units_match_oracle_bytes(env, level):
     lo, ctx, torch = env
     import zstd_amd
@@ -73,7 +74,7 @@ def test_ragged_units_match_oracle_bytes(env, level):
             cp = zstd_amd.get_cparams(level, n)
         except zstd_amd.ZhipError:
             continue
-        if cp[6] not in (1, 2):
+        if cp[6] not in (1, 2, 3, 4, 5):
             continue
         for name, a in corpus_cases(lo, sizes=(n,), seeds=(3,)):
             got = ctx.compress(a, level=level)
@@ -81,10 +82,11 @@ def test_ragged_units_match_oracle_bytes(env, level):
             assert got == want, (name, level, first_diff(got, want))
 
 
-@pytest.mark.parametrize("level,minseen", [(1, 200), (3, 100)])
+@pytest.mark.parametrize("level,minseen", [(1, 200), (3, 100), (5, 200), (6, 200), (7, 200)])
 def test_golden_vectors_from_the_real_reference(env, level, minseen):
     lo, ctx, torch = env
-    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["units"] if g["level"] == level}
+    path = GOLD if level < 5 else GOLD_HC          # levels 5-7: the reference with the row matcher disabled (hash chain)
+    gold = {(g["case"], g["level"]): g for g in json.load(open(path))["units"] if g["level"] == level}
     sizes = sorted({g["n"] for g in gold.values()})
     seen = 0
     for n in sizes:
@@ -107,6 +109,33 @@ def test_level3_128k_units_match_oracle_bytes(env):
     got, sizes = ctx.compress(flat, level=3, return_sizes=True)
     want, wsizes = oracle_chunks(lo, flat, 3)
     assert np.array_equal(sizes, wsizes), [(c[0], int(a), int(b)) for c, a, b in zip(cases, sizes, wsizes) if a != b]
+    assert got == want, first_diff(got, want)
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 10])
+def test_hashchain_128k_units_match_oracle_bytes(env, level):
+    """strategies greedy / lazy / lazy2 (hash chain; levels 5-10 of the <= 128 KB row): frames byte-identical to the oracle"""
+    lo, ctx, torch = env
+    cases = list(corpus_cases(lo, sizes=(131072,), seeds=(level,)))
+    rng = np.random.default_rng(level)
+    mixed = np.concatenate([rng.integers(0, 256, size=20000, dtype=np.uint8), datagen(lo, 40000, 60, level),
+                            rng.integers(0, 256, size=30000, dtype=np.uint8), datagen(lo, 41072, 30, level + 1)])
+    cases.append(("mixed_skip_then_match", mixed))          # lazy-skipping stretches followed by compressible data
+    flat = np.concatenate([c[1] for c in cases])
+    got, sizes = ctx.compress(flat, level=level, return_sizes=True)
+    want, wsizes = oracle_chunks(lo, flat, level)
+    assert np.array_equal(sizes, wsizes), [(c[0], int(a), int(b)) for c, a, b in zip(cases, sizes, wsizes) if a != b]
+    assert got == want, first_diff(got, want)
+    dec = system_decompress(got, len(flat))
+    if dec is not None:
+        assert dec.tobytes() == flat.tobytes()
+
+
+def test_level4_mixes_dfast_units_with_a_greedy_tail(env):
+    lo, ctx, torch = env
+    a = datagen(lo, 2 * 131072 + 9000, 50, 4)
+    got = ctx.compress(a, level=4)
+    want, _ = oracle_chunks(lo, a, 4)
     assert got == want, first_diff(got, want)
 
 

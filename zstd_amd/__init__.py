@@ -50,6 +50,8 @@ def lib():
         L.zhip_get_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.zhip_last_timing.restype = None
         L.zhip_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.zhip_last_hc_timing.restype = None
+        L.zhip_last_hc_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.zhip_last_stats.restype = C.c_size_t
         L.zhip_last_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.zhip_datagen.restype = None
@@ -118,6 +120,12 @@ class Context:
         t = (C.c_double * 4)()
         lib().zhip_last_timing(self._h, t)
         return {"parse_ms": t[0], "entropy_ms": t[1], "gather_ms": t[2], "total_ms": t[3]}
+
+    def hc_timing(self):
+        """hash-chain levels: the match-finder stage of the last call split by kernel (ms)"""
+        t = (C.c_double * 3)()
+        lib().zhip_last_hc_timing(self._h, t)
+        return {"chain_ms": t[0], "search_ms": t[1], "parse_ms": t[2]}
 
     def stats(self):
         s = (C.c_ulonglong * 5)()

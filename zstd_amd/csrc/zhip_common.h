@@ -11,7 +11,7 @@
 #define ZHIP_OUT_STRIDE      (ZHIP_UNIT_MAX + 512 + 32) /* >= ZSTD_compressBound(128 KB) + frame header */
 #define ZHIP_LIT_STRIDE      (ZHIP_UNIT_MAX + 64)
 
-enum { ZHIP_STRAT_FAST = 1, ZHIP_STRAT_DFAST = 2 };
+enum { ZHIP_STRAT_FAST = 1, ZHIP_STRAT_DFAST = 2, ZHIP_STRAT_GREEDY = 3, ZHIP_STRAT_LAZY = 4, ZHIP_STRAT_LAZY2 = 5 };   /* lib/zstd.h:328-337 */
 
 // one entry per unit, filled by the host, read by every kernel
 struct ZhipUnit {

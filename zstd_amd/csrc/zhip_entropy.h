@@ -36,6 +36,25 @@ __device__ static const uint8_t kMLcode[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13
     42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
 
 // the four small tables are copied to LDS once per workgroup (a lookup in the global copy costs an HBM/L2 round trip)
+// -log2(x / 256) in 1/256 bit units, x = 1..255 (lib/compress/zstd_compress_sequences.c:21-44 kInverseProbabilityLog256)
+__device__ static const uint16_t kInvProbLog256[256] = {
+    0,    2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+    1024, 1001, 980,  960,  941,  923,  906,  889,  874,  859,  844,  830,  817,  804,  791,  779,
+    768,  756,  745,  734,  724,  714,  704,  694,  685,  676,  667,  658,  650,  642,  633,  626,
+    618,  610,  603,  595,  588,  581,  574,  567,  561,  554,  548,  542,  535,  529,  523,  517,
+    512,  506,  500,  495,  489,  484,  478,  473,  468,  463,  458,  453,  448,  443,  438,  434,
+    429,  424,  420,  415,  411,  407,  402,  398,  394,  390,  386,  382,  377,  373,  370,  366,
+    362,  358,  354,  350,  347,  343,  339,  336,  332,  329,  325,  322,  318,  315,  311,  308,
+    305,  302,  298,  295,  292,  289,  286,  282,  279,  276,  273,  270,  267,  264,  261,  258,
+    256,  253,  250,  247,  244,  241,  239,  236,  233,  230,  228,  225,  222,  220,  217,  215,
+    212,  209,  207,  204,  202,  199,  197,  194,  192,  190,  187,  185,  182,  180,  178,  175,
+    173,  171,  168,  166,  164,  162,  159,  157,  155,  153,  151,  149,  146,  144,  142,  140,
+    138,  136,  134,  132,  130,  128,  126,  123,  121,  119,  117,  115,  114,  112,  110,  108,
+    106,  104,  102,  100,  98,   96,   94,   93,   91,   89,   87,   85,   83,   82,   80,   78,
+    76,   74,   73,   71,   69,   67,   66,   64,   62,   61,   59,   57,   55,   54,   52,   50,
+    49,   47,   46,   44,   42,   41,   39,   37,   36,   34,   33,   31,   30,   28,   26,   25,
+    23,   22,   20,   19,   17,   16,   14,   13,   11,   10,   8,    7,    5,    4,    2,    1,
+};
 struct CodeTabs { uint8_t llCode[64]; uint8_t mlCode[128]; uint8_t llBits[36]; uint8_t mlBits[56]; };
 __device__ __forceinline__ uint32_t ll_code(const CodeTabs& T, uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : T.llCode[ll]; }          // internal.h:520
 __device__ __forceinline__ uint32_t ml_code(const CodeTabs& T, uint32_t mlBase) { return mlBase > 127 ? hb32(mlBase) + 36 : T.mlCode[mlBase]; }   // :537
@@ -320,16 +339,41 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
             // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
             uint32_t type;
+            uint32_t hsz = 0; bool fail = false;
             if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
-            else {
+            else if (u.strategy < ZHIP_STRAT_LAZY) {
                 type = 2;
                 if (defaultAllowed) {
                     uint32_t const mult = 10 - u.strategy;
                     uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
                     if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
                 }
+            } else {
+                // strategy >= lazy (:205-231): estimated costs in bits; without a previous table the repeat cost is an
+                // error (= larger than everything)
+                uint64_t basicCost = ~0ull;
+                if (defaultAllowed) {                                                  // :141-155 ZSTD_crossEntropyCost
+                    uint32_t const shift = 8 - defLog;
+                    uint64_t cost = 0;
+                    for (uint32_t s = 0; s <= max; s++) {
+                        uint32_t const normAcc = defNorm[s] != -1 ? (uint32_t)defNorm[s] : 1;
+                        cost += (uint64_t)cnt[s] * kInvProbLog256[normAcc << shift];
+                    }
+                    basicCost = cost >> 8;
+                }
+                uint32_t const tl = fse_optimal_table_log(fseLog, nbSeq, max, 2);        // :70-77 ZSTD_NCountCost
+                uint32_t ncountCost = 0;
+                if (fse_normalize(sh->norm[k], tl, cnt, nbSeq, max, nbSeq >= 2048) < 0) fail = true;
+                else { ncountCost = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tl); if (!ncountCost) fail = true; }
+                uint32_t ecost = 0;                                                    // :83-97 ZSTD_entropyCost
+                for (uint32_t s = 0; s <= max; s++) {
+                    uint32_t nrm = (256 * cnt[s]) / nbSeq;
+                    if (cnt[s] != 0 && nrm == 0) nrm = 1;
+                    ecost += cnt[s] * kInvProbLog256[nrm];
+                }
+                uint64_t const compressedCost = ((uint64_t)ncountCost << 3) + (ecost >> 8);
+                type = basicCost <= compressedCost ? 0 : 2;                            // :217-222
             }
-            uint32_t hsz = 0; bool fail = false;
             if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
                 fse_build_ctable_rle(&sh->ct[k], max);
                 sh->ncount[k][0] = (uint8_t)max;

@@ -7,24 +7,33 @@ namespace zhip {
 
 struct CParams { unsigned windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; };
 
-// Level -> parameters for the strategies this library implements (fast = 1, dfast = 2).
-// Values are the reference's rows (lib/compress/clevels.h:24-130: "base for negative levels", levels 1..4) for
+// Level -> parameters for the strategies this library implements (fast 1, dfast 2, greedy 3, lazy 4, lazy2 5 — the
+// last three with the hash-chain matcher, i.e. the reference with ZSTD_c_useRowMatchFinder = ZSTD_ps_disable).
+// Values are the reference's rows (lib/compress/clevels.h:24-130: "base for negative levels", levels 1..12) for
 // its four source-size classes; the selection + adjustment logic mirrors ZSTD_getCParams_internal
 // (lib/compress/zstd_compress.c:7123-7145) and ZSTD_adjustCParams_internal (:1466-1602) for a known source size
 // and no dictionary.  tests/test_host_params.py sweeps this against the real reference.
 static inline bool host_get_cparams(int level, unsigned long long srcSize, CParams* out)
 {
-    static const CParams rows[4][5] = {
-        /* srcSize > 256 KB */ {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2}},
-        /* <= 256 KB       */ {{18,12,13,1,5,1,1},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,3,5,2,3}},
-        /* <= 128 KB       */ {{17,12,12,1,5,1,1},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2}},
-        /* <= 16 KB        */ {{14,12,13,1,5,1,1},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3}},
+    static const CParams rows[4][13] = {     // [size class][0 = negative-level base, 1..12 = level]; strategy 6+ = binary tree (not ours)
+        /* srcSize > 256 KB */ {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},
+                                {21,18,19,3,5,2,3},{21,18,19,3,5,4,4},{21,19,20,4,5,8,4},{21,19,20,4,5,16,5},{22,20,21,4,5,16,5},
+                                {22,21,22,5,5,16,5},{22,21,22,6,5,16,5},{22,22,23,6,5,32,5}},
+        /* <= 256 KB       */ {{18,12,13,1,5,1,1},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,3,5,2,3},
+                                {18,17,18,5,5,2,3},{18,18,19,3,5,4,4},{18,18,19,4,4,4,4},{18,18,19,4,4,8,5},{18,18,19,5,4,8,5},
+                                {18,18,19,6,4,8,5},{18,18,19,5,4,12,6},{18,19,19,7,4,12,6}},
+        /* <= 128 KB       */ {{17,12,12,1,5,1,1},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2},
+                                {17,16,17,3,4,2,3},{17,16,17,3,4,4,4},{17,16,17,3,4,8,5},{17,16,17,4,4,8,5},{17,16,17,5,4,8,5},
+                                {17,16,17,6,4,8,5},{17,17,17,5,4,8,6},{17,18,17,7,4,12,6}},
+        /* <= 16 KB        */ {{14,12,13,1,5,1,1},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3},
+                                {14,14,14,3,4,4,4},{14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},
+                                {14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7}},
     };
     unsigned const cls = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
     int row = level == 0 ? 3 : (level < 0 ? 0 : level);
-    if (row > 4) return false;
+    if (row > 12) return false;
     CParams cp = rows[cls][row];
-    if (cp.strategy > 2) return false;
+    if (cp.strategy > 5) return false;       // btlazy2 and up: not implemented
     if (level < 0) { long const lv = level < -131072 ? -131072 : level; cp.targetLength = (unsigned)(-lv); }
     if (srcSize <= (1ULL << 30)) {
         uint32_t const t = (uint32_t)srcSize;

@@ -4,6 +4,7 @@
 #include "zhip_common.h"
 #include "zhip_parse.h"
 #include "zhip_parse_dfast.h"
+#include "zhip_parse_lazy.h"
 #include "zhip_entropy.h"
 
 namespace zhip {
@@ -17,6 +18,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
+    if (u.strategy != ZHIP_STRAT_FAST) return;          // another family's kernel handles it
     const uint8_t* const p = src + u.srcOff;
     ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
     uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
@@ -40,6 +42,7 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
+    if (u.strategy != ZHIP_STRAT_DFAST) return;
     const uint8_t* const p = src + u.srcOff;
     ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
     uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
@@ -52,6 +55,57 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     case 8:  parse_dfast_unit<8>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
     default: parse_dfast_unit<4>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
     }
+}
+
+// Stage 1 for strategies greedy / lazy / lazy2 (hash chain), three launches — see zhip_parse_lazy.h.
+// tabs + ui * tabStride words: head[2^hashLog], prev[ZHIP_UNIT_MAX]; best + ui * ZHIP_UNIT_MAX records.
+__global__ void __launch_bounds__(64)
+k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+           uint32_t* __restrict__ tabs, size_t tabStride)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    if (u.strategy < ZHIP_STRAT_GREEDY) return;
+    uint32_t* const head = tabs + (size_t)ui * tabStride;
+    uint32_t* const prev = head + ((size_t)1 << u.hashLog);
+    const uint8_t* const p = src + u.srcOff;
+    switch (u.minMatch) {                               // zstd_lazy.c:1531 mls = BOUNDED(4, minMatch, 6)
+    case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, head, prev); break;
+    case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, head, prev); break;
+    default: hc_chain_unit<4>(p, u.srcLen, u, smem, head, prev); break;
+    }
+}
+
+// one thread per position; workgroup b works on unit (b / 8 / blocksPerUnit) * 8 + b % 8 — consecutive workgroup ids
+// go round-robin over the 8 XCDs, so all workgroups of one unit land on the same XCD and share its L2
+__global__ void __launch_bounds__(ZHIP_HC_SEARCH_THREADS)
+k_hc_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits, uint32_t blocksPerUnit,
+            const uint32_t* __restrict__ tabs, size_t tabStride, uint64_t* __restrict__ best)
+{
+    uint32_t const b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    uint32_t const ui = (slot / blocksPerUnit) * 8 + xcd, chunk = slot % blocksPerUnit;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    uint32_t const n = u.srcLen, p = chunk * ZHIP_HC_SEARCH_THREADS + threadIdx.x;
+    if (u.strategy < ZHIP_STRAT_GREEDY || n < 10 || p > n - 8) return;
+    const uint32_t* const prev = tabs + (size_t)ui * tabStride + ((size_t)1 << u.hashLog);
+    best[(size_t)ui * ZHIP_UNIT_MAX + p] = hc_search_pos(src + u.srcOff, n, p, prev, u.searchLog, u.chainLog);
+}
+
+__global__ void __launch_bounds__(64)
+k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+             uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,
+             ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    if (u.strategy < ZHIP_STRAT_GREEDY) return;
+    uint32_t* const prev = tabs + (size_t)ui * tabStride + ((size_t)1 << u.hashLog);
+    parse_lazy_unit(src + u.srcOff, u.srcLen, u, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
+                    seqs + (size_t)ui * ZHIP_SEQ_CAP, lits + (size_t)ui * ZHIP_LIT_STRIDE, metas + ui);
 }
 
 // Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's

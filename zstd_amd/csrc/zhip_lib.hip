@@ -32,9 +32,13 @@ struct zhip_ctx_s {
     uint8_t*   dLits;
     uint16_t*  dStBits;
     uint8_t*   dOut;
-    uint32_t*  dTabs; size_t tabsCap;          // dfast: per-unit hash tables (long + short), grown on demand
-    size_t     tabStride;                      // words per unit of the current call (0 = strategy fast)
-    int        strategy;                       // strategy of the current call's units
+    uint32_t*  dTabs; size_t tabsCap;          // dfast / hash chain: per-unit tables in HBM, grown on demand
+    size_t     tabStride;                      // words per unit of the current call (0 = strategy fast only)
+    uint64_t*  dBest; size_t bestCap;          // hash chain: best[] records, ZHIP_UNIT_MAX per unit of a chunk
+    size_t     hcChunk;                        // hash chain: units per pass over dTabs / dBest
+    uint32_t   hcMaxLen;                       // hash chain: longest unit of the call
+    std::vector<hipEvent_t> hcEv; size_t hcEvUsed;   // hash chain: 4 events per chunk of the last call
+    int        strategy;                       // family mask of the current call's units: bit 0 fast, 1 dfast, 2 hash chain
     uint32_t*  dOutSize;
     uint64_t*  dOutOff;
     // staging for the host-buffer API
@@ -101,10 +105,11 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
-    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs);
+    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->hcEv) (void)hipEventDestroy(e);
     for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]); if (c->cev[i]) (void)hipEventDestroy(c->cev[i]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -117,7 +122,7 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     zhip_ctx* c = new zhip_ctx_s();
     c->dUnits = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
-    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = ZHIP_STRAT_FAST;
+    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
@@ -153,6 +158,14 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
 
 void zhip_last_timing(const zhip_ctx* c, double t[4]) { for (int i = 0; i < 4; i++) t[i] = c->timing[i]; }
 
+void zhip_last_hc_timing(zhip_ctx* c, double t[3])
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    t[0] = t[1] = t[2] = 0;
+    for (size_t i = 0; i + 4 <= c->hcEvUsed; i += 4)
+        for (int k = 0; k < 3; k++) { float ms = 0; if (hipEventElapsedTime(&ms, c->hcEv[i + k], c->hcEv[i + k + 1]) == hipSuccess) t[k] += ms; }
+}
+
 void zhip_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed, int streamMode)
 {
     zhip::datagen(buffer, size, matchProba, litProba, seed, streamMode);
@@ -168,7 +181,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
-    uint32_t mh = 0; size_t tabWords = 0; int strat = 0;
+    uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0;
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -181,18 +194,36 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
         u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0; u.pad0 = 0;
         u.targetLength = cp->targetLength;
-        if (cp->strategy != ZHIP_STRAT_FAST && cp->strategy != ZHIP_STRAT_DFAST) { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device yet", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
-        if (strat == 0) strat = (int)cp->strategy;
-        if (strat != (int)cp->strategy) { snprintf(c->err, sizeof(c->err), "units of one call must share a strategy (%d vs %u)", strat, cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
-        if (cp->hashLog > mh) mh = cp->hashLog;
-        if (cp->strategy == ZHIP_STRAT_DFAST) { size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
+        // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
+        if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
+        else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
+        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; }
+        else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
     }
-    if (strat == ZHIP_STRAT_FAST && mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
-    c->strategy = strat ? strat : ZHIP_STRAT_FAST; c->tabStride = (tabWords + 3) & ~(size_t)3;
-    if (c->strategy == ZHIP_STRAT_DFAST && c->tabsCap < nUnits * c->tabStride) {
+    if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
+    c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen;
+    {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
+        static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 4096;
+        size_t const chunk = envChunk > 0 ? (size_t)envChunk : 4096;
+        c->hcChunk = nUnits < chunk ? nUnits : chunk;
+    }
+    size_t const tabUnits = (fam & 4) ? c->hcChunk : nUnits;
+    if ((fam & 6) && c->tabsCap < tabUnits * c->tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
-        if (hipMalloc((void**)&c->dTabs, nUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of dfast tables", nUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
-        c->tabsCap = nUnits * c->tabStride;
+        if (hipMalloc((void**)&c->dTabs, tabUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match-finder tables", tabUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
+        c->tabsCap = tabUnits * c->tabStride;
+    }
+    if ((fam & 4) && c->bestCap < c->hcChunk * (size_t)ZHIP_UNIT_MAX) {
+        (void)hipFree(c->dBest); c->dBest = nullptr; c->bestCap = 0;
+        if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
+        c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
+    }
+    if ((fam & 2) && (fam & 4)) {              // the dfast kernel indexes dTabs by the global unit id
+        if (c->tabsCap < nUnits * c->tabStride) {
+            (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
+            if (hipMalloc((void**)&c->dTabs, nUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { *err = ZERR(ZE_memory_allocation); return 0; }
+            c->tabsCap = nUnits * c->tabStride;
+        }
     }
     *maxHashLog = mh;
     return nUnits;
@@ -206,15 +237,36 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         if (pad > 0) smem += (size_t)pad;
     }
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
-    if (smem > 64 * 1024 && c->strategy == ZHIP_STRAT_FAST)
+    if (smem > 64 * 1024 && (c->strategy & 1))
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (c->strategy == ZHIP_STRAT_DFAST)
+    // one launch per strategy family present; every kernel skips the units of the other families
+    if (c->strategy & 2)
         hipLaunchKernelGGL(zhip::k_parse_dfast, dim3((unsigned)nUnits), dim3(64), zhip::dfast_lds_bytes(), s,
                            srcDev, c->dUnits, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
-    else
-    hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
-                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
+    if (c->strategy & 1)
+        hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
+                           srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
+    if (c->strategy & 4) {
+        uint32_t const bpu = (c->hcMaxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
+        c->hcEvUsed = 0;
+        for (size_t u0 = 0; u0 < nUnits; u0 += c->hcChunk) {
+            unsigned const nu = (unsigned)(nUnits - u0 < c->hcChunk ? nUnits - u0 : c->hcChunk);
+            while (c->hcEv.size() < c->hcEvUsed + 4) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->hcEv.push_back(e); }
+            hipEvent_t* const he = &c->hcEv[c->hcEvUsed]; c->hcEvUsed += 4;
+            HIPCHK(c, hipEventRecord(he[0], s));
+            hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::dfast_lds_bytes(), s,
+                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride);
+            HIPCHK(c, hipEventRecord(he[1], s));
+            hipLaunchKernelGGL(zhip::k_hc_search, dim3(((nu + 7) / 8) * 8 * bpu), dim3(ZHIP_HC_SEARCH_THREADS), 0, s,
+                               srcDev, c->dUnits + u0, nu, bpu, c->dTabs, c->tabStride, c->dBest);
+            HIPCHK(c, hipEventRecord(he[2], s));
+            hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), 0, s,
+                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest,
+                               c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dLits + u0 * ZHIP_LIT_STRIDE, c->dParse + u0);
+            HIPCHK(c, hipEventRecord(he[3], s));
+        }
+    } else c->hcEvUsed = 0;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     return 0;
@@ -291,7 +343,7 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     if (!nUnits) return err;
     if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
     size_t r;
-    if (c->nChunks > 1 && c->strategy == ZHIP_STRAT_FAST && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
+    if (c->nChunks > 1 && c->strategy == 1 && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
     else {
         r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
         if (zhip_isError(r)) return r;

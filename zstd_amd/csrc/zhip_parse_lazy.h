@@ -1,0 +1,330 @@
+// zhip_parse_lazy.h — gfx950 hash-chain match finder + greedy / lazy / lazy2 parser (strategies 3..5), in three kernels.
+//
+// WHAT it computes: exactly the sequences the reference's ZSTD_compressBlock_greedy / _lazy / _lazy2
+// (lib/compress/zstd_lazy.c:1516-1779 with search_hashChain = ZSTD_HcFindBestMatch :667-773 and
+// ZSTD_insertAndFindFirstIndex_internal :632-657) emit for a unit with no history.
+//
+// HOW (CDNA4 design, not a translation).  The reference interleaves three things per searched position: insert the
+// positions passed so far into a hash table + chain table, walk up to 2^searchLog chain candidates, and decide.  Two
+// of them do not depend on the parse:
+//   * unless the parser is in its "lazy skipping" mode (:1613-1624, incompressible stretches), EVERY position before
+//     the searched one has been inserted, so the chain link of position p is simply "the closest earlier position with
+//     the same hash": one array prev[p] per unit, built once               -> k_hc_chain  (one wavefront per unit);
+//   * with all links known, ZSTD_HcFindBestMatch(p) is a pure function of p: best[p] = (length, offset) for every
+//     position of the unit, one GPU thread per position, no ordering at all -> k_hc_search (256 positions per workgroup,
+//     workgroups of one unit kept on one XCD so that the unit's source + links stay in that XCD's L2);
+//   * what remains sequential is the parser proper: repcode probes, the lazy "is the next position better" comparisons,
+//     catch-up, the immediate-repcode loop and the sequence store        -> k_parse_lazy (one wavefront per unit): 64
+//     lanes look at the next 64 scheduled positions at once (best[] record + repcode probe per lane), a ballot finds
+//     the first event in the reference's order, and the lazy look-ahead reads its neighbours' records from registers.
+// Exactness in the two cases where best[] is not what the reference would have found:
+//   * lazy-skipping leaves positions un-inserted.  The parser flags them in prev[] (top bit) and remembers the highest
+//     one; a record whose walk reached down to a flagged region (its lowest candidate <= that mark) is redone live,
+//     walking prev[] and stepping over flagged positions without counting them as attempts;
+//   * k_hc_search caps its byte compares at ZHIP_HC_CAP per candidate (a unit of zeros would otherwise cost n^2);
+//     a capped record is flagged and redone live by the parser with wave-wide compares.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zhip_common.h"
+#include "zhip_parse.h"
+#include "zhip_parse_dfast.h"
+#include "zhip_tables.h"
+
+namespace zhip {
+
+#ifndef ZHIP_HC_CAP
+#define ZHIP_HC_CAP 256u
+#endif
+#define ZHIP_HC_NONE     0x1FFFFu            /* "no candidate" in the minCand field */
+#define ZHIP_HC_SKIPPED  0x80000000u         /* prev[] flag: position was never inserted (lazy skipping) */
+#define ZHIP_HC_SEARCH_THREADS 256
+
+// per-unit table memory in 32-bit words: head[2^hashLog] then prev[ZHIP_UNIT_MAX]
+__host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { return ((size_t)1 << hashLog) + ZHIP_UNIT_MAX; }
+
+// best[] record: offset (17 bits) | length << 17 (17 bits) | live << 34 | lowest candidate examined << 35 (17 bits)
+__device__ __forceinline__ uint64_t hc_pack(uint32_t ml, uint32_t off, uint32_t minCand, bool live)
+{
+    return (uint64_t)off | ((uint64_t)ml << 17) | ((uint64_t)(live ? 1u : 0u) << 34) | ((uint64_t)minCand << 35);
+}
+__device__ __forceinline__ uint32_t hc_rec_off(uint64_t r) { return (uint32_t)r & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t hc_rec_ml(uint64_t r) { return (uint32_t)(r >> 17) & 0x1FFFFu; }
+__device__ __forceinline__ bool hc_rec_live(uint64_t r) { return (r >> 34) & 1; }
+__device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r >> 35) & 0x1FFFFu; }
+
+// ------------------------------------------------------------------ kernel A: chain links, one wavefront per unit
+// prev[p] = 1 + the closest q < p with hash(q) == hash(p), 0 if none — what chainTable[p & mask] holds after
+// ZSTD_insertAndFindFirstIndex_internal inserted p with every earlier position present (zstd_lazy.c:645-653).
+template <uint32_t MLS>
+__device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
+                                     uint32_t* __restrict__ head, uint32_t* __restrict__ prev)
+{
+    if (n < 10) return;                                   // no position is ever searched (ip = 1 < n - 8 fails)
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const nm8 = n - 8, sh = 32 - u.hashLog;
+    lds_u8* const scr = (lds_u8*)(uintptr_t)smem;
+    {   uint32_t const words = 1u << u.hashLog;           // fresh table (zstd_compress.c:2020); >= 64 words (hashLog >= 6)
+        uint4 const z = {0, 0, 0, 0};
+        for (uint32_t i = 4 * lane; i < words; i += 256) *(uint4*)(head + i) = z;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base <= nm8; base += 64) {        // positions 0 .. n-8: the lazy look-ahead searches up to n-8 (:1628)
+        uint32_t const p = base + lane;
+        bool const live = p <= nm8;
+        uint64_t const bytes = ld64(src + (live ? p : nm8));
+        uint32_t const h = hash_pos<MLS>(bytes, sh);
+        uint32_t const old = live ? head[h] : 0;
+        uint32_t const s = h & (ZHIP_DF_SCRATCH - 1);
+        if (live) scr[s] = (uint8_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long const lose = __ballot(live && scr[s] != (uint8_t)lane);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cand = old;
+        unsigned long long grp = 0;
+        if (lose) {
+            unsigned long long const liveMask = __ballot(live);
+            grp = lane_groups(h, lose, liveMask);
+            unsigned long long const before = grp & below_mask((int)lane);
+            if (before) cand = base + (63u - (uint32_t)__clzll((long long)before)) + 1;
+        }
+        if (live) {
+            prev[p] = cand;
+            if ((grp & ~below_mask((int)lane + 1)) == 0) head[h] = p + 1;      // the last lane of a hash group wins
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ kernel B: best match per position, one thread each
+// ZSTD_HcFindBestMatch (zstd_lazy.c:667-773, noDict) at position p with every earlier position inserted.
+__device__ inline uint64_t hc_search_pos(const uint8_t* __restrict__ src, uint32_t n, uint32_t p,
+                                         const uint32_t* __restrict__ prev, uint32_t searchLog, uint32_t chainLog)
+{
+    uint32_t const nm8 = n - 8, chainSize = 1u << chainLog;
+    uint32_t attempts = 1u << searchLog;
+    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE;
+    bool live = false;
+    uint32_t m = prev[p];
+    while (m != 0 && attempts) {
+        uint32_t const mp = m - 1;
+        uint32_t const nx = prev[mp];                                           // independent of the compare below
+        minCand = mp;
+        if (ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {                // :714 quick reject at the current best length
+            uint32_t cur = 0;
+            for (;;) {
+                uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
+                cur += same;
+                if (same < 8) break;
+                if (cur >= ZHIP_HC_CAP) { live = true; break; }
+            }
+            if (live) break;
+            if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }    // :724-728
+        }
+        if (p >= chainSize && mp <= p - chainSize) break;                       // :732 matchIndex <= minChain
+        m = nx; attempts--;
+    }
+    return hc_pack(ml, off, minCand, live);
+}
+
+// ------------------------------------------------------------------ kernel C: the parser, one wavefront per unit
+struct HcState {
+    uint32_t ntu;           // ms->nextToUpdate (zstd_compress_internal.h:232)
+    uint32_t skipping;      // ms->lazySkipping (:253)
+    uint32_t gapEnd;        // highest position flagged ZHIP_HC_SKIPPED so far, 0 = none (position 0 is always inserted)
+};
+
+// the search the reference would run at x with positions flagged in prev[] missing from the chains (all values uniform)
+__device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
+                                      uint32_t searchLog, uint32_t chainLog, uint32_t& mlOut, uint32_t& offOut)
+{
+    uint32_t const nm8 = n - 8, chainSize = 1u << chainLog;
+    uint32_t attempts = 1u << searchLog;
+    uint32_t ml = 3, off = 0;
+    uint32_t m = uni(prev[x]) & ~ZHIP_HC_SKIPPED;
+    while (m != 0) {
+        uint32_t const mp = m - 1;
+        uint32_t const w = uni(prev[mp]);
+        if (w & ZHIP_HC_SKIPPED) { m = w & ~ZHIP_HC_SKIPPED; continue; }         // never inserted: not a candidate
+        if (uni(ld32(src + mp + ml - 3)) == uni(ld32(src + x + ml - 3))) {
+            uint32_t const cur = wave_count_fwd(src, x, mp, nm8);
+            if (cur > ml) { ml = cur; off = x - mp; if (x + cur == n) break; }
+        }
+        if (--attempts == 0) break;
+        if (x >= chainSize && mp <= x - chainSize) break;
+        m = w;
+    }
+    mlOut = ml; offOut = off;
+}
+
+// one ZSTD_HcFindBestMatch call of the reference at x: insertion bookkeeping + the (pre)computed result
+__device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st,
+                                 uint32_t x, uint64_t rec, uint32_t& ml, uint32_t& offBase)
+{
+    if (st.skipping && st.ntu + 1 < x) {                  // :651 only nextToUpdate itself is inserted; the rest never will be
+        for (uint32_t q = st.ntu + 1 + (uint32_t)lane_id(); q < x; q += 64) prev[q] |= ZHIP_HC_SKIPPED;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        st.gapEnd = x - 1;
+    }
+    st.ntu = x;
+    uint32_t off;
+    uint32_t const minCand = hc_rec_min(rec);
+    if (hc_rec_live(rec) || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd))
+        hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
+    else { ml = hc_rec_ml(rec); off = hc_rec_off(rec); }
+    offBase = off + 3;
+}
+
+__device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
+                                       uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
+                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const depth = (uint32_t)u.strategy - 3;      // greedy 0, lazy 1, lazy2 2
+    FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
+    out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
+
+    uint32_t anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;
+    // zstd_lazy.c:1552-1559  ip = 1, lowest index 0 -> maxRep = 1
+    if (off2 > 1) { saved2 = off2; off2 = 0; }
+    if (off1 > 1) { saved1 = off1; off1 = 0; }
+
+    if (n >= 10) {
+    uint32_t const nm8 = n - 8, ilimit = n - 8;           // :1528
+    uint32_t ip = 1;
+    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0;
+    while (ip < ilimit) {                                                    // :1581
+        uint32_t const step = ((ip - anchor) >> 8) + 1;                      // :1614 kSearchStrength = 8
+        // ---- the next position where something happens (repcode hit at x+1, or a search that needs a closer look)
+        uint32_t x, K = 0, ip0 = ip;
+        uint64_t recj = 0; bool repj = false;
+        bool repHit; uint64_t rec;
+        if (step <= 8) {
+            // lanes take the positions the reference visits next while nothing is found: ip, ip+step, ... (same step)
+            uint32_t const xj = ip + lane * step;
+            bool const valid = xj < ilimit && ((xj - anchor) >> 8) + 1 == step;
+            uint32_t const xc = xj < nm8 ? xj : nm8;
+            recj = valid ? best[xj] : 0;
+            uint32_t const cur4 = ld32(src + xc + 1), rv = ld32(src + (xc + 1 - off1));
+            repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
+            uint32_t const minCand = hc_rec_min(recj);
+            bool const needLive = valid && (hc_rec_live(recj) || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd));
+            bool const found = valid && hc_rec_ml(recj) >= 4;
+            K = (uint32_t)__popcll(__ballot(valid));
+            unsigned long long const ev = __ballot(repj || needLive || found);
+            if (!ev) {                                                       // K failed searches (:1613-1624), lazySkipping = 0
+                st.ntu = ip + (K - 1) * step; st.skipping = 0;
+                ip = st.ntu + step;
+                continue;
+            }
+            int const e = first_lane(ev);
+            x = ip + (uint32_t)e * step;
+            if (e > 0) { st.ntu = x - step; st.skipping = 0; }
+            repHit = (__ballot(repj) >> e) & 1;
+            rec = readlane64(recj, e);
+        } else {
+            x = ip;
+            rec = best[x];
+            rec = readlane64(rec, 0);
+            repHit = off1 > 0 && uni(ld32(src + x + 1)) == uni(ld32(src + (x + 1 - off1)));
+        }
+        // records / repcode probes of the positions after x, from the batch registers when they are there
+        bool const window = step == 1;
+        auto rec_at = [&](uint32_t q) -> uint64_t {
+            if (window && q - ip0 < K) return readlane64(recj, (int)(q - ip0));
+            uint64_t const r = best[q];
+            return readlane64(r, 0);
+        };
+        auto rep_at = [&](uint32_t q) -> bool {           // MEM_read32(q) == MEM_read32(q - off1), off1 > 0
+            if (window && q - 1 - ip0 < K) return (__ballot(repj) >> (q - 1 - ip0)) & 1;
+            return uni(ld32(src + q)) == uni(ld32(src + (q - off1)));
+        };
+
+        uint32_t matchLength = 0, start = x + 1, offBase = 1;
+        bool direct = false;
+        if (repHit) {                                                        // :1600-1604
+            matchLength = 4 + wave_count_fwd(src, x + 5, x + 5 - off1, nm8);
+            if (depth == 0) direct = true;
+        }
+        ip = x;
+        if (!direct) {
+            {   uint32_t ml2, ob2;                                           // :1607-1611
+                hc_search(src, n, u, prev, st, x, rec, ml2, ob2);
+                if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
+            }
+            if (matchLength < 4) {                                           // :1613-1625
+                uint32_t const stp = ((x - anchor) >> 8) + 1;
+                ip = x + stp;
+                st.skipping = stp > 8;                                       // kLazySkippingStep = 8
+                continue;
+            }
+            if (depth >= 1) {
+                while (ip < ilimit) {                                        // :1628-1700
+                    ip++;
+                    if (off1 > 0 && rep_at(ip)) {
+                        uint32_t const mlRep = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off1, nm8);
+                        int const gain2 = (int)(mlRep * 3);
+                        int const gain1 = (int)(matchLength * 3 - hb32(offBase) + 1);
+                        if (gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                    {   uint32_t ml2, ob2;
+                        hc_search(src, n, u, prev, st, ip, rec_at(ip), ml2, ob2);
+                        int const gain2 = (int)(ml2 * 4 - hb32(ob2));
+                        int const gain1 = (int)(matchLength * 4 - hb32(offBase) + 4);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = ob2; start = ip; continue; }
+                    }
+                    if (depth == 2 && ip < ilimit) {                         // :1663-1698
+                        ip++;
+                        if (off1 > 0 && rep_at(ip)) {
+                            uint32_t const mlRep = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off1, nm8);
+                            int const gain2 = (int)(mlRep * 4);
+                            int const gain1 = (int)(matchLength * 4 - hb32(offBase) + 1);
+                            if (gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                        }
+                        {   uint32_t ml2, ob2;
+                            hc_search(src, n, u, prev, st, ip, rec_at(ip), ml2, ob2);
+                            int const gain2 = (int)(ml2 * 4 - hb32(ob2));
+                            int const gain1 = (int)(matchLength * 4 - hb32(offBase) + 7);
+                            if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = ob2; start = ip; continue; }
+                        }
+                    }
+                    break;
+                }
+            }
+            if (offBase > 3) {                                               // :1707-1714 catch up
+                uint32_t const off = offBase - 3, match = start - off;
+                uint32_t const lim = (start - anchor) < match ? (start - anchor) : match;
+                uint32_t const back = wave_count_back(src, start, match, lim);
+                start -= back; matchLength += back;
+                off2 = off1; off1 = off;
+            }
+        }
+        lits_copy(out, src, nm8, anchor, start - anchor);                    // :1727-1731
+        store_seq(out, start - anchor, offBase, matchLength);
+        anchor = ip = start + matchLength;
+        st.skipping = 0;                                                     // :1732-1738
+        while (ip <= ilimit && off2 > 0) {                                   // :1763-1773
+            if (uni(ld32(src + ip)) != uni(ld32(src + (ip - off2)))) break;
+            uint32_t const rl = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
+            {   uint32_t const t = off2; off2 = off1; off1 = t; }
+            store_seq(out, 0, 1, rl);
+            ip += rl; anchor = ip;
+        }
+    }
+    lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
+    lits_flush(out);
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];
+        out.litPos = n;
+    }
+    // :1777-1783
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+    if (lane == 0) {
+        meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
+        meta->longPos = out.longPos; meta->longType = out.longType;
+        meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = 8;
+        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
+    }
+}
+
+}  // namespace zhip
