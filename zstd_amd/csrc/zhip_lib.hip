@@ -203,8 +203,8 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
     c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen;
     {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
-        static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 4096;
-        size_t const chunk = envChunk > 0 ? (size_t)envChunk : 4096;
+        static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 8192;
+        size_t const chunk = envChunk > 0 ? (size_t)envChunk : 8192;
         c->hcChunk = nUnits < chunk ? nUnits : chunk;
     }
     size_t const tabUnits = (fam & 4) ? c->hcChunk : nUnits;
@@ -248,7 +248,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
                            srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     if (c->strategy & 4) {
-        uint32_t const bpu = (c->hcMaxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
+        uint32_t const bpu = c->hcMaxLen ? (c->hcMaxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS : 1;   // an empty unit still gets a grid
         c->hcEvUsed = 0;
         for (size_t u0 = 0; u0 < nUnits; u0 += c->hcChunk) {
             unsigned const nu = (unsigned)(nUnits - u0 < c->hcChunk ? nUnits - u0 : c->hcChunk);
