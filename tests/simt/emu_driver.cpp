@@ -26,10 +26,10 @@ uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhi
 void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride, uint64_t* best,
                     ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
 {
-    simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::dfast_lds_bytes(),
+    uint32_t maxLen = 1, maxHlog = 6;
+    for (uint32_t i = 0; i < nUnits; i++) { if (units[i].srcLen > maxLen) maxLen = units[i].srcLen; if (units[i].hashLog > maxHlog) maxHlog = units[i].hashLog; }
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::hc_chain_lds_bytes(maxHlog),
                  [=] { zhip::k_hc_chain(src, units, nUnits, tabs, tabStride); }, osThreads);
-    uint32_t maxLen = 1;
-    for (uint32_t i = 0; i < nUnits; i++) if (units[i].srcLen > maxLen) maxLen = units[i].srcLen;
     uint32_t const bpu = (maxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
     simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,
                  [=] { zhip::k_hc_search(src, units, nUnits, bpu, tabs, tabStride, best); }, osThreads);

@@ -58,7 +58,8 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
 }
 
 // Stage 1 for strategies greedy / lazy / lazy2 (hash chain), three launches — see zhip_parse_lazy.h.
-// tabs + ui * tabStride words: head[2^hashLog], prev[ZHIP_UNIT_MAX]; best + ui * ZHIP_UNIT_MAX records.
+// tabs + ui * tabStride words: prev[ZHIP_UNIT_MAX]; best + ui * ZHIP_UNIT_MAX records.
+// k_hc_chain: dynamic LDS = hc_chain_lds_bytes(max hashLog).
 __global__ void __launch_bounds__(64)
 k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
            uint32_t* __restrict__ tabs, size_t tabStride)
@@ -68,13 +69,12 @@ k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
-    uint32_t* const head = tabs + (size_t)ui * tabStride;
-    uint32_t* const prev = head + ((size_t)1 << u.hashLog);
+    uint32_t* const prev = tabs + (size_t)ui * tabStride;
     const uint8_t* const p = src + u.srcOff;
     switch (u.minMatch) {                               // zstd_lazy.c:1531 mls = BOUNDED(4, minMatch, 6)
-    case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, head, prev); break;
-    case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, head, prev); break;
-    default: hc_chain_unit<4>(p, u.srcLen, u, smem, head, prev); break;
+    case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, prev); break;
+    case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, prev); break;
+    default: hc_chain_unit<4>(p, u.srcLen, u, smem, prev); break;
     }
 }
 
@@ -90,7 +90,7 @@ k_hc_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
     ZhipUnit const u = units[ui];
     uint32_t const n = u.srcLen, p = chunk * ZHIP_HC_SEARCH_THREADS + threadIdx.x;
     if (u.strategy < ZHIP_STRAT_GREEDY || n < 10 || p > n - 8) return;
-    const uint32_t* const prev = tabs + (size_t)ui * tabStride + ((size_t)1 << u.hashLog);
+    const uint32_t* const prev = tabs + (size_t)ui * tabStride;
     best[(size_t)ui * ZHIP_UNIT_MAX + p] = hc_search_pos(src + u.srcOff, n, p, prev, u.searchLog, u.chainLog);
 }
 
@@ -103,7 +103,7 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
-    uint32_t* const prev = tabs + (size_t)ui * tabStride + ((size_t)1 << u.hashLog);
+    uint32_t* const prev = tabs + (size_t)ui * tabStride;
     parse_lazy_unit(src + u.srcOff, u.srcLen, u, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
                     seqs + (size_t)ui * ZHIP_SEQ_CAP, lits + (size_t)ui * ZHIP_LIT_STRIDE, metas + ui);
 }

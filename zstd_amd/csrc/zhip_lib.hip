@@ -36,7 +36,7 @@ struct zhip_ctx_s {
     size_t     tabStride;                      // words per unit of the current call (0 = strategy fast only)
     uint64_t*  dBest; size_t bestCap;          // hash chain: best[] records, ZHIP_UNIT_MAX per unit of a chunk
     size_t     hcChunk;                        // hash chain: units per pass over dTabs / dBest
-    uint32_t   hcMaxLen;                       // hash chain: longest unit of the call
+    uint32_t   hcMaxLen, hcHashLog;            // hash chain: longest unit / largest hashLog of the call
     std::vector<hipEvent_t> hcEv; size_t hcEvUsed;   // hash chain: 4 events per chunk of the last call
     int        strategy;                       // family mask of the current call's units: bit 0 fast, 1 dfast, 2 hash chain
     uint32_t*  dOutSize;
@@ -181,7 +181,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
-    uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0;
+    uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -197,11 +197,11 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
-        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; }
+        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
     }
     if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
-    c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen;
+    c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen; c->hcHashLog = hcHlog;
     {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
         static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 8192;
         size_t const chunk = envChunk > 0 ? (size_t)envChunk : 8192;
@@ -255,7 +255,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             while (c->hcEv.size() < c->hcEvUsed + 4) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->hcEv.push_back(e); }
             hipEvent_t* const he = &c->hcEv[c->hcEvUsed]; c->hcEvUsed += 4;
             HIPCHK(c, hipEventRecord(he[0], s));
-            hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::dfast_lds_bytes(), s,
+            hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::hc_chain_lds_bytes(c->hcHashLog), s,
                                srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride);
             HIPCHK(c, hipEventRecord(he[1], s));
             hipLaunchKernelGGL(zhip::k_hc_search, dim3(((nu + 7) / 8) * 8 * bpu), dim3(ZHIP_HC_SEARCH_THREADS), 0, s,

@@ -12,6 +12,7 @@
 //     32-bit arrays, one private pair per unit; with no LDS table the kernel runs at full wave occupancy instead;
 //   * lanes of one batch that hash alike (in either table) must see each other's inserts in lane order: two small LDS
 //     scratch arrays (lane id written / read back at hash & 1023) flag the candidates, ballots make the exact groups;
+//   * entries carry a 15-bit tag of the bytes the reference would compare, so only candidates that can match are fetched;
 //   * a short match also looks at the long candidate of the NEXT position (:251-264) — lane K of a K-lane batch is a
 //     helper that carries that position's bytes, long hash and candidate.
 // All control flow is wave-uniform; the only LDS use is the 2 KB scratch.
@@ -26,6 +27,13 @@ namespace zhip {
 __host__ __device__ inline uint32_t dfast_lds_bytes() { return 2u * ZHIP_DF_SCRATCH; }
 // bytes of table memory one unit needs (long + short, 32-bit entries)
 __host__ __device__ inline size_t dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return ((size_t)4 << hashLog) + ((size_t)4 << chainLog); }
+
+// Table entries are private to this kernel: position (17 bits) | 15-bit tag << 17.  The tag is a function of exactly the
+// bytes the reference compares at a candidate (8 for the long table, 4 for the short one), so a tag mismatch proves the
+// compare fails and the candidate's source bytes — a random HBM sector — need not be fetched at all.
+#define ZHIP_DF_POS 0x1FFFFu
+__device__ __forceinline__ uint32_t df_tag_long(uint32_t v /* mulhi64_top32(bytes, prime8) */) { return v & 0x7FFFu; }   // the hash's spare low bits
+__device__ __forceinline__ uint32_t df_tag_short(uint32_t first4) { return (first4 * 2654435761U) >> 17; }
 
 // exact groups of live lanes with equal key, given the lanes whose scratch slot was taken by another lane
 __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned long long losers, unsigned long long liveMask)
@@ -69,6 +77,10 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
     uint32_t const nm8 = n - 8;
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip = 1;
+    // Batch width.  Every searched lane costs two random table gathers (HBM/L2 sectors), and everything after the first
+    // event of a batch is thrown away, so the batch is only as wide as events have recently been far apart: twice the
+    // running mean distance (x16 fixed point) + 8, doubled after a batch without an event.  Any width is exact.
+    uint32_t evAvg16 = 12u << 4, kCap = 32;
     for (;;) {                                                               // one turn per match (:167)
         uint32_t step = 1, nextStep = ip + 256;
         if ((int32_t)(ip + 1) > ilimit) break;                               // :172
@@ -82,6 +94,7 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             unsigned long long const mStop = __ballot(inc || endAfter);
             int K = mStop ? first_lane(mStop) + 1 : 64;
             if (K > 63) K = 63;
+            if (K > (int)kCap) K = (int)kCap;
             bool const lastInc = (__ballot(inc) >> (K - 1)) & 1, lastEnd = (__ballot(endAfter) >> (K - 1)) & 1;
             unsigned long long const liveMask = below_mask(K + 1), searchMask = below_mask(K);
             bool const live = (int)lane <= K;
@@ -89,9 +102,11 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             uint32_t const pc = p < nm8 ? p : nm8;
             uint64_t const bytes = ld64(src + pc);
             uint32_t const rv = ld32(src + (pc + 1 - off1));                 // off1 <= pc always; off1 == 0 is masked below
-            uint32_t const hl = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL) >> shL;
-            uint32_t const hs = hash_pos<MLS>(bytes, shS);
-            uint32_t const oldL = live ? tabL[hl] : 0, oldS = live ? tabS[hs] : 0;
+            uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
+            uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
+            uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short((uint32_t)bytes);
+            uint32_t const eL = live ? tabL[hl] : 0, eS = live ? tabS[hs] : 0;
+            uint32_t const oldL = eL & ZHIP_DF_POS, oldS = eS & ZHIP_DF_POS;
             uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
             if (live) { scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane; }
             __builtin_amdgcn_wave_barrier();
@@ -99,8 +114,10 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             unsigned long long const loseS = __ballot(live && scrS[ss] != (uint8_t)lane);
             __builtin_amdgcn_wave_barrier();
 
-            uint64_t cbL = ld64(src + (oldL < nm8 ? oldL : nm8));           // table values are <= n-8 by construction
-            uint32_t cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+            // candidate bytes are only fetched where the entry's tag says they can match (a random sector each)
+            uint64_t cbL = ~bytes; uint32_t cbS = ~(uint32_t)bytes;
+            if (oldL != 0 && (eL >> 17) == tgL) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));     // table values are <= n-8 by construction
+            if (oldS != 0 && (eS >> 17) == tgS) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
             uint32_t candL = oldL, candS = oldS;
             unsigned long long grpL = 0, grpS = 0;
             if (loseL) {
@@ -128,23 +145,26 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             // :187 hashLong[hl0] = hashSmall[hs0] = curr for every position up to the event: last lane of a group wins
             {   bool const inC = (int)lane < Lcommit;
                 unsigned long long const cm = below_mask(Lcommit) & ~below_mask((int)lane + 1);
-                if (inC && (grpL & cm) == 0) tabL[hl] = p;
-                if (inC && (grpS & cm) == 0) tabS[hs] = p;
+                if (inC && (grpL & cm) == 0) tabL[hl] = p | (tgL << 17);
+                if (inC && (grpS & cm) == 0) tabS[hs] = p | (tgS << 17);
             }
             __builtin_amdgcn_wave_barrier();
             if (evKind) {
+                evAvg16 = (3 * evAvg16 + (((uint32_t)jE + 1) << 4)) >> 2;
+                kCap = (evAvg16 >> 3) + 8; if (kCap > 63) kCap = 63;
                 curr = __builtin_amdgcn_readlane(p, jE);
                 candE = __builtin_amdgcn_readlane(evKind == 2 ? candL : candS, jE);
                 ip1 = __builtin_amdgcn_readlane(p, jE + 1);                  // lane jE+1 <= K is live
                 cand1 = __builtin_amdgcn_readlane(candL, jE + 1);
                 long1 = (mL >> (jE + 1)) & 1;                                // :253 long match at ip1 (8 bytes equal, valid index)
                 if (evKind != 1 && step < 4) {                               // :283-291 hashLong[hl1] = ip1
-                    if ((int)lane == jE + 1) tabL[hl] = p;
+                    if ((int)lane == jE + 1) tabL[hl] = p | (tgL << 17);
                     __builtin_amdgcn_wave_barrier();
                 }
                 break;
             }
             ip = ip + (uint32_t)K * step;                                    // :236-237
+            kCap = kCap * 2 > 63 ? 63 : kCap * 2;
             if (lastEnd) break;
             if (lastInc) { step++; nextStep += 256; }
         }
@@ -183,11 +203,13 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             {   // complementary inserts: long[curr+2], long[ip-2], short[curr+2], short[ip-1] — in this order
                 uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
                 uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
-                uint32_t const hL = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL, hS = hash_pos<MLS>(b, shS);
-                if (lane == 0) { tabL[hL] = q; tabS[hS] = q; }
+                uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
+                uint32_t const hL = vv >> shL, hS = hash_pos<MLS>(b, shS);
+                uint32_t const qL = q | (df_tag_long(vv) << 17), qS = q | (df_tag_short((uint32_t)b) << 17);
+                if (lane == 0) { tabL[hL] = qL; tabS[hS] = qS; }
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 1) tabL[hL] = q;
-                if (lane == 2) tabS[hS] = q;
+                if (lane == 1) tabL[hL] = qL;
+                if (lane == 2) tabS[hS] = qS;
                 __builtin_amdgcn_wave_barrier();
             }
             while ((int32_t)ip <= ilimit && off2 > 0) {
@@ -195,7 +217,11 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 if ((uint32_t)b != ld32(src + ip - off2)) break;
                 uint32_t const rLength = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
                 {   uint32_t const t = off2; off2 = off1; off1 = t; }
-                if (lane == 0) { tabS[hash_pos<MLS>(b, shS)] = ip; tabL[mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL] = ip; }
+                if (lane == 0) {
+                    uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
+                    tabS[hash_pos<MLS>(b, shS)] = ip | (df_tag_short((uint32_t)b) << 17);
+                    tabL[vv >> shL] = ip | (df_tag_long(vv) << 17);
+                }
                 __builtin_amdgcn_wave_barrier();
                 store_seq(out, 0, 1, rLength);
                 ip += rLength; anchor = ip;

@@ -9,7 +9,8 @@
 // of them do not depend on the parse:
 //   * unless the parser is in its "lazy skipping" mode (:1613-1624, incompressible stretches), EVERY position before
 //     the searched one has been inserted, so the chain link of position p is simply "the closest earlier position with
-//     the same hash": one array prev[p] per unit, built once               -> k_hc_chain  (one wavefront per unit);
+//     the same hash": one array prev[p] per unit, built once               -> k_hc_chain  (one wavefront per unit,
+//     the hash heads in LDS, one slice of the hash space per sweep);
 //   * with all links known, ZSTD_HcFindBestMatch(p) is a pure function of p: best[p] = (length, offset) for every
 //     position of the unit, one GPU thread per position, no ordering at all -> k_hc_search (256 positions per workgroup,
 //     workgroups of one unit kept on one XCD so that the unit's source + links stay in that XCD's L2);
@@ -39,8 +40,8 @@ namespace zhip {
 #define ZHIP_HC_SKIPPED  0x80000000u         /* prev[] flag: position was never inserted (lazy skipping) */
 #define ZHIP_HC_SEARCH_THREADS 256
 
-// per-unit table memory in 32-bit words: head[2^hashLog] then prev[ZHIP_UNIT_MAX]
-__host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { return ((size_t)1 << hashLog) + ZHIP_UNIT_MAX; }
+// per-unit table memory in 32-bit words: prev[ZHIP_UNIT_MAX] (the chain links; the hash heads only ever live in LDS)
+__host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { (void)hashLog; return ZHIP_UNIT_MAX; }
 
 // best[] record: offset (17 bits) | length << 17 (17 bits) | live << 34 | lowest candidate examined << 35 (17 bits)
 __device__ __forceinline__ uint64_t hc_pack(uint32_t ml, uint32_t off, uint32_t minCand, bool live)
@@ -55,43 +56,103 @@ __device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r
 // ------------------------------------------------------------------ kernel A: chain links, one wavefront per unit
 // prev[p] = 1 + the closest q < p with hash(q) == hash(p), 0 if none — what chainTable[p & mask] holds after
 // ZSTD_insertAndFindFirstIndex_internal inserted p with every earlier position present (zstd_lazy.c:645-653).
+//
+// The "most recent position per hash" table has 2^hashLog (2^17) entries of 17 bits: too big for LDS, and in HBM every
+// lookup / update is a random 64-byte sector (that version ran at the HBM random-access rate: 50 ms per GiB).  So the
+// unit is swept once per slice of the hash space instead: a pass keeps the table of ONE slice (2^14 hashes: 16-bit
+// entries + a bit plane for bit 16, 34 KB) in LDS, scans all positions (coalesced source reads, L2-resident after the
+// first pass), compacts the positions whose hash falls into the slice — in order — into a small LDS queue, and runs
+// the table step on full 64-entry batches from that queue.  Lanes of one batch with equal hash are put in order with
+// the slot-as-detector trick of zhip_parse.h (write the lane id, read it back, ballot the groups).
+#define ZHIP_HC_SLICE_LOG 14u
+__host__ __device__ inline uint32_t hc_chain_lds_bytes(uint32_t hashLog)
+{
+    uint32_t const e = 1u << (hashLog < ZHIP_HC_SLICE_LOG ? hashLog : ZHIP_HC_SLICE_LOG);
+    uint32_t const plane = (e >> 3) < 4 ? 4 : (e >> 3);
+    return 2u * e + plane + 128u * 4u;                    // lo16[e], bit plane, queue[128]
+}
+
 template <uint32_t MLS>
 __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
-                                     uint32_t* __restrict__ head, uint32_t* __restrict__ prev)
+                                     uint32_t* __restrict__ prev)
 {
     if (n < 10) return;                                   // no position is ever searched (ip = 1 < n - 8 fails)
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const nm8 = n - 8, sh = 32 - u.hashLog;
-    lds_u8* const scr = (lds_u8*)(uintptr_t)smem;
-    {   uint32_t const words = 1u << u.hashLog;           // fresh table (zstd_compress.c:2020); >= 64 words (hashLog >= 6)
-        uint4 const z = {0, 0, 0, 0};
-        for (uint32_t i = 4 * lane; i < words; i += 256) *(uint4*)(head + i) = z;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base <= nm8; base += 64) {        // positions 0 .. n-8: the lazy look-ahead searches up to n-8 (:1628)
-        uint32_t const p = base + lane;
-        bool const live = p <= nm8;
-        uint64_t const bytes = ld64(src + (live ? p : nm8));
-        uint32_t const h = hash_pos<MLS>(bytes, sh);
-        uint32_t const old = live ? head[h] : 0;
-        uint32_t const s = h & (ZHIP_DF_SCRATCH - 1);
-        if (live) scr[s] = (uint8_t)lane;
+    uint32_t const sliceLog = u.hashLog < ZHIP_HC_SLICE_LOG ? u.hashLog : ZHIP_HC_SLICE_LOG;
+    uint32_t const E = 1u << sliceLog, passes = 1u << (u.hashLog - sliceLog);
+    uint32_t const planeBytes = (E >> 3) < 4 ? 4 : (E >> 3);
+    lds_u16* const lo = (lds_u16*)(uintptr_t)smem;
+    lds_u32* const hi = (lds_u32*)(uintptr_t)(smem + 2u * E);
+    lds_u32* const queue = (lds_u32*)(uintptr_t)(smem + 2u * E + planeBytes);
+    unsigned long long const laneBelow = below_mask((int)lane);
+
+    // one table step on `cnt` (<= 64) queue entries starting at ring index qh; entries = position | slice index << 17
+    auto table_step = [&](uint32_t qh, uint32_t cnt, bool anyHigh) {
+        bool const live = lane < cnt;
+        uint32_t const e = queue[(qh + lane) & 127];
+        uint32_t const p = e & 0x1FFFFu, idx = live ? e >> 17 : 0;
+        uint32_t old = lo[idx];
+        if (anyHigh) old |= ((hi[idx >> 5] >> (idx & 31)) & 1u) << 16;
         __builtin_amdgcn_wave_barrier();
-        unsigned long long const lose = __ballot(live && scr[s] != (uint8_t)lane);
+        if (live) lo[idx] = (uint16_t)lane;
         __builtin_amdgcn_wave_barrier();
+        unsigned long long const liveMask = below_mask((int)cnt);
+        unsigned long long const lose = __ballot(live && lo[idx] != (uint16_t)lane);
         uint32_t cand = old;
         unsigned long long grp = 0;
         if (lose) {
-            unsigned long long const liveMask = __ballot(live);
-            grp = lane_groups(h, lose, liveMask);
-            unsigned long long const before = grp & below_mask((int)lane);
-            if (before) cand = base + (63u - (uint32_t)__clzll((long long)before)) + 1;
-        }
-        if (live) {
-            prev[p] = cand;
-            if ((grp & ~below_mask((int)lane + 1)) == 0) head[h] = p + 1;      // the last lane of a hash group wins
+            grp = lane_groups(idx, lose, liveMask);
+            unsigned long long const before = grp & laneBelow;
+            uint32_t const pd = before ? 63u - (uint32_t)__clzll((long long)before) : lane;
+            uint32_t const dp = __shfl(p, (int)pd);
+            if (before) cand = dp + 1;
         }
         __builtin_amdgcn_wave_barrier();
+        if (live) {
+            prev[p] = cand;
+            if ((grp & ~below_mask((int)lane + 1)) == 0) {                      // the last lane of a hash group wins
+                uint32_t const v = p + 1;
+                lo[idx] = (uint16_t)v;
+                if (v >> 16) __hip_atomic_fetch_or(&hi[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;                       // fresh slice (zstd_compress.c:2020)
+            uint32_t const words = (2u * E + planeBytes) >> 2;
+            for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t qh = 0, qn = 0;
+        // positions 0 .. n-8 (the lazy look-ahead searches up to n-8, :1628), eight 64-position batches per turn with
+        // all eight source loads issued up front: the scan is otherwise one exposed memory latency per batch
+        for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {
+            uint64_t bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t const p = base0 + 64u * (uint32_t)j + lane, pc = p <= nm8 ? p : nm8;
+                bv[j] = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t const base = base0 + 64u * (uint32_t)j, p = base + lane;
+                bool const live = p <= nm8;
+                uint32_t const h = hash_pos<MLS>(bv[j], sh);
+                bool const mine = live && (h >> sliceLog) == pass;
+                unsigned long long const m = __ballot(mine);
+                if (m) {
+                    uint32_t const rank = (uint32_t)__popcll(m & laneBelow);
+                    if (mine) queue[(qh + qn + rank) & 127] = p | ((h & (E - 1)) << 17);
+                    qn += (uint32_t)__popcll(m);
+                    __builtin_amdgcn_wave_barrier();
+                    if (qn >= 64) { table_step(qh, 64, base + 64 >= 65535u); qh = (qh + 64) & 127; qn -= 64; }
+                }
+            }
+        }
+        if (qn) table_step(qh, qn, nm8 >= 65535u);
     }
 }
 
@@ -193,6 +254,15 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const nm8 = n - 8, ilimit = n - 8;           // :1528
     uint32_t ip = 1;
     HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0;
+    // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
+    // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
+    uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
+    auto prefetch = [&](uint32_t at, uint32_t o1) {
+        uint32_t const xj = at + lane, xc = xj < nm8 ? xj : nm8;
+        pfRec = xj < ilimit ? best[xj] : 0;
+        pfCur4 = ld32(src + xc + 1); pfRv = ld32(src + (xc + 1 - o1));
+        pfIp = at; pfOff1 = o1;
+    };
     while (ip < ilimit) {                                                    // :1581
         uint32_t const step = ((ip - anchor) >> 8) + 1;                      // :1614 kSearchStrength = 8
         // ---- the next position where something happens (repcode hit at x+1, or a search that needs a closer look)
@@ -204,8 +274,9 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             uint32_t const xj = ip + lane * step;
             bool const valid = xj < ilimit && ((xj - anchor) >> 8) + 1 == step;
             uint32_t const xc = xj < nm8 ? xj : nm8;
-            recj = valid ? best[xj] : 0;
-            uint32_t const cur4 = ld32(src + xc + 1), rv = ld32(src + (xc + 1 - off1));
+            uint32_t cur4, rv;
+            if (pfIp == ip && pfOff1 == off1 && step == 1) { recj = pfRec; cur4 = pfCur4; rv = pfRv; }   // loaded while the last sequence was finished
+            else { recj = valid ? best[xj] : 0; cur4 = ld32(src + xc + 1); rv = ld32(src + (xc + 1 - off1)); }
             repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
             uint32_t const minCand = hc_rec_min(recj);
             bool const needLive = valid && (hc_rec_live(recj) || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd));
@@ -244,7 +315,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         bool direct = false;
         if (repHit) {                                                        // :1600-1604
             matchLength = 4 + wave_count_fwd(src, x + 5, x + 5 - off1, nm8);
-            if (depth == 0) direct = true;
+            if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1); }
         }
         ip = x;
         if (!direct) {
@@ -291,6 +362,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
                     break;
                 }
             }
+            if (start + matchLength < ilimit) prefetch(start + matchLength, offBase > 3 ? offBase - 3 : off1);
             if (offBase > 3) {                                               // :1707-1714 catch up
                 uint32_t const off = offBase - 3, match = start - off;
                 uint32_t const lim = (start - anchor) < match ? (start - anchor) : match;
