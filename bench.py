@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mib", type=int, default=1024, help="source MiB per GPU (default = the 1 GiB of configs[1])")
     ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--workload", choices=["datagen", "silesia", "text"], default="datagen",
+                    help="datagen = BASELINE configs[1] (default); silesia / text = synthetic stand-ins for configs[2] / configs[3]")
+    ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
+    ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,11 +124,40 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    n = args.mib << 20
-    units = n // UNIT
-    host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)            # `datagen -g<n> -P50 -s<rank>`
-    src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
-    src[:n].copy_(torch.from_numpy(host))
+    scaling = "weak"
+    if args.workload == "datagen":
+        n = args.mib << 20
+        host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)        # `datagen -g<n> -P50 -s<rank>`
+        src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        src[:n].copy_(torch.from_numpy(host))
+        wdesc = f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)"
+    else:
+        from zstd_amd import workloads as W
+        if args.workload == "silesia":                                      # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in
+            base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
+            n = len(base) * args.copies
+            wdesc = f"Silesia-shaped synthetic mix ({len(base)} B: text / structured / tables / runs / incompressible, zstd_amd/workloads.py) x{args.copies} copies"
+        else:                                                               # configs[3]: enwik9 is not on disk -> Zipf word-salad text
+            base = W.text_corpus(64 << 20, seed=rank)
+            if args.total_bytes:
+                n = args.total_bytes // world                               # frame-per-shard: a fixed total cut into one shard per GPU
+                scaling = "strong"
+            else:
+                n = args.mib << 20
+            wdesc = f"Zipf word-salad text (64 MiB generated, tiled to {n} B per GPU, zstd_amd/workloads.py), enwik9 stand-in"
+        bdev = torch.from_numpy(base).to(dev)
+        src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        pos, c, L = 0, 0, len(base)
+        while pos < n:                                                      # copy c starts at offset c*9973: units of different copies differ
+            s0 = (c * 9973) % L
+            for a0, a1 in ((s0, L), (0, s0)):
+                take = min(a1 - a0, n - pos)
+                if take > 0:
+                    src[pos:pos + take].copy_(bdev[a0:a0 + take]); pos += take
+            c += 1
+        del bdev
+        host = base[: min(len(base), n)]
+    units = (n + UNIT - 1) // UNIT
     cap = zstd_amd.compress_bound(n, UNIT)
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
     usz = torch.zeros(units, dtype=torch.int32, device=dev)
@@ -186,10 +219,10 @@ def main():
         if cp[6] != 1:
             traffic = None                                        # the committed counters are for the level-1 kernel
         out = {
-            "metric": f"compress_MBps_level{args.level}_datagenP50_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
+            "metric": f"compress_MBps_level{args.level}_{'datagenP50' if args.workload == 'datagen' else args.workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode), level {args.level} ({cpdesc}), "
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": f"{wdesc}, level {args.level} ({cpdesc}), "
                                    f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
                        "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
             "ratio": round(world * n / total_all, 4),
@@ -204,7 +237,7 @@ def main():
         if cp[6] >= 3:      # the match-finder stage is three kernels; the roofline figures above are for their sum
             out["roofline"]["kernels_ms"] = {k: round(v / K, 3) for k, v in hc.items()}
         out["parity"] = parity_check(ctx, host, dst, total, sizes, args.level)
-        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None:
+        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)
             os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
             ctx2 = zstd_amd.Context(local, max_units=units)

@@ -192,7 +192,8 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.srcOff = off; u.srcLen = (uint32_t)len;
         u.windowLog = (uint8_t)cp->windowLog; u.chainLog = (uint8_t)cp->chainLog; u.hashLog = (uint8_t)cp->hashLog;
         u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
-        u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0; u.pad0 = 0;
+        u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0;
+        {   static int const knob = getenv("ZHIP_DF_WIDTH") ? atoi(getenv("ZHIP_DF_WIDTH")) : 0; u.pad0 = (uint8_t)knob; }   // dfast batch-width knob (scripts/)
         u.targetLength = cp->targetLength;
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }

@@ -78,8 +78,9 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip = 1;
     // Batch width.  Every searched lane costs two random table gathers (HBM/L2 sectors), and everything after the first
-    // event of a batch is thrown away, so the batch is only as wide as events have recently been far apart: twice the
-    // running mean distance (x16 fixed point) + 8, doubled after a batch without an event.  Any width is exact.
+    // event of a batch is thrown away, so the batch is only as wide as events have recently been far apart: the running
+    // mean distance (x16 fixed point) + 4 (best of the sweep in scripts/df_sweep.sh), doubled after a batch without an event.  Any width is exact.
+    uint32_t const kMul = u.pad0 ? (uint32_t)(u.pad0 >> 4) : 8u, kAdd = u.pad0 ? (uint32_t)(u.pad0 & 15) : 4u;   // width = mean * kMul/8 + kAdd (measurement knob, any value is exact)
     uint32_t evAvg16 = 12u << 4, kCap = 32;
     for (;;) {                                                               // one turn per match (:167)
         uint32_t step = 1, nextStep = ip + 256;
@@ -151,7 +152,7 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             __builtin_amdgcn_wave_barrier();
             if (evKind) {
                 evAvg16 = (3 * evAvg16 + (((uint32_t)jE + 1) << 4)) >> 2;
-                kCap = (evAvg16 >> 3) + 8; if (kCap > 63) kCap = 63;
+                kCap = ((evAvg16 * kMul) >> 7) + kAdd; if (kCap > 63) kCap = 63; if (kCap < 2) kCap = 2;
                 curr = __builtin_amdgcn_readlane(p, jE);
                 candE = __builtin_amdgcn_readlane(evKind == 2 ? candL : candS, jE);
                 ip1 = __builtin_amdgcn_readlane(p, jE + 1);                  // lane jE+1 <= K is live
