@@ -30,7 +30,13 @@ def main():
     mib = int(os.environ.get("MIB", "1024"))
     level = int(os.environ.get("LEVEL", "1"))
     n = mib << 20
-    host = zstd_amd.datagen(n, 50, seed=0, stream_mode=True)
+    if os.environ.get("WORKLOAD", "datagen") == "text":
+        from zstd_amd import workloads as W
+        import numpy as np
+        base = W.text_corpus(64 << 20, seed=0)
+        host = np.concatenate([base] * (n // len(base) + 1))[:n]
+    else:
+        host = zstd_amd.datagen(n, 50, seed=0, stream_mode=True)
     dev = torch.device("cuda", 0)
     src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
     src[:n].copy_(torch.from_numpy(host))
