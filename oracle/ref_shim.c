@@ -112,6 +112,36 @@ size_t zref_compress_chunks_params(const int cp[7], size_t chunkSize, const void
     return pos;
 }
 
+/* records[] (sizes in recSizes[nRec], laid out back to back in src) each compressed as its own frame with a CDict made from
+ * `dict` at `level` — ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the contrib/largeNbDicts / `zstd -D` shape).
+ * outSizes[nRec] receives the frame sizes; returns the total, (size_t)-1 on error. */
+size_t zref_compress_records_cdict(int level, const void* dict, size_t dictSize, const void* src, const size_t* recSizes, size_t nRec,
+                                   void* dst, size_t dstCap, size_t* outSizes)
+{
+    ZSTD_CDict* cd = ZSTD_createCDict(dict, dictSize, level);
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0, k;
+    if (!cd || !c) { ZSTD_freeCDict(cd); ZSTD_freeCCtx(c); return (size_t)-1; }
+    if (ZSTD_isError(ZSTD_CCtx_refCDict(c, cd))) { ZSTD_freeCDict(cd); ZSTD_freeCCtx(c); return (size_t)-1; }
+    for (k = 0; k < nRec; k++) {
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, recSizes[k]);
+        if (ZSTD_isError(r)) { ZSTD_freeCDict(cd); ZSTD_freeCCtx(c); return (size_t)-1; }
+        if (outSizes) outSizes[k] = r;
+        pos += r; off += recSizes[k];
+    }
+    ZSTD_freeCDict(cd); ZSTD_freeCCtx(c);
+    return pos;
+}
+
+/* decode one frame with a dictionary (validator) */
+size_t zref_decompress_dict(void* dst, size_t cap, const void* src, size_t n, const void* dict, size_t dictSize)
+{
+    ZSTD_DCtx* d = ZSTD_createDCtx();
+    size_t const r = ZSTD_decompress_usingDict(d, dst, cap, src, n, dict, dictSize);
+    ZSTD_freeDCtx(d);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
 /* whole buffer as ONE frame (the conventional `zstd -b#` figure; NOT the parity target) */
 size_t zref_compress_frame(int level, const void* src, size_t n, void* dst, size_t dstCap)
 {
@@ -141,6 +171,25 @@ size_t zref_sequences(int level, const void* src, size_t n, unsigned* out, size_
         out[4*i+2] = s[i].matchLength; out[4*i+3] = s[i].rep;
     }
     free(s); ZSTD_freeCCtx(c);
+    return r;
+}
+
+/* sequences of ONE source compressed with a CDict attached (dedicated CCtx, see N5) */
+size_t zref_sequences_cdict(int level, const void* dict, size_t dictSize, const void* src, size_t n, unsigned* out, size_t capSeqs)
+{
+    ZSTD_CDict* cd = ZSTD_createCDict(dict, dictSize, level);
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    ZSTD_Sequence* s = (ZSTD_Sequence*)malloc(sizeof(ZSTD_Sequence) * capSeqs);
+    size_t r, i;
+    if (!c || !s || !cd) return (size_t)-1;
+    ZSTD_CCtx_refCDict(c, cd);
+    r = ZSTD_generateSequences(c, s, capSeqs, src, n);
+    if (ZSTD_isError(r)) { free(s); ZSTD_freeCCtx(c); ZSTD_freeCDict(cd); return (size_t)-1; }
+    for (i = 0; i < r; i++) {
+        out[4*i+0] = s[i].offset; out[4*i+1] = s[i].litLength;
+        out[4*i+2] = s[i].matchLength; out[4*i+3] = s[i].rep;
+    }
+    free(s); ZSTD_freeCCtx(c); ZSTD_freeCDict(cd);
     return r;
 }
 

@@ -38,10 +38,40 @@ static const zo_cparams kRows[4][13] = {
     {14,15,14,9,4,8,6}, {14,15,14,3,4,12,7}, {14,15,14,4,3,24,7} },
 };
 
-/* zstd_compress.c:7123-7145 (row pick) then :1466-1602 (adjust) with dictSize 0 and a known srcSize */
-int zo_get_cparams(int level, unsigned long long srcSize, zo_cparams* out)
+/* zstd_compress.c:1466-1602 ZSTD_adjustCParams_internal.  mode: 0 = noAttachDict / unknown, 1 = attachDict, 2 = createCDict */
+#define ZO_SRCSIZE_UNKNOWN (~0ULL)
+static void zo_adjust_cparams(zo_cparams* cp, unsigned long long srcSize, unsigned long long dictSize, int mode)
 {
-    unsigned const tableID = (srcSize <= 256u*1024) + (srcSize <= 128u*1024) + (srcSize <= 16u*1024);
+    if (mode == 2 && dictSize && srcSize == ZO_SRCSIZE_UNKNOWN) srcSize = 513;   /* :1524-1531 minSrcSize */
+    if (mode == 1) dictSize = 0;                                                 /* :1532-1538 the dictionary has its own tables */
+    if (srcSize <= (1ULL << 30) && dictSize <= (1ULL << 30)) {                   /* :1546-1553 */
+        uint32_t const tSize = (uint32_t)(srcSize + dictSize);
+        unsigned const srcLog = (tSize < 64) ? 6 : hb32(tSize - 1) + 1;
+        if (cp->windowLog > srcLog) cp->windowLog = srcLog;
+    }
+    if (srcSize != ZO_SRCSIZE_UNKNOWN) {                                         /* :1554-1560 */
+        unsigned dawl = cp->windowLog;                                           /* :1432-1456 ZSTD_dictAndWindowLog */
+        if (dictSize) {
+            unsigned long long const windowSize = 1ULL << cp->windowLog;
+            if (windowSize < dictSize + srcSize) dawl = (dictSize + windowSize >= (1ULL << 31)) ? 31 : hb32((uint32_t)(dictSize + windowSize) - 1) + 1;
+        }
+        if (cp->hashLog > dawl + 1) cp->hashLog = dawl + 1;
+        if (cp->chainLog > dawl) cp->chainLog = dawl;                            /* cycleLog == chainLog below btlazy2 */
+    }
+    if (cp->windowLog < 10) cp->windowLog = 10;                                  /* :1562 */
+    if (mode == 2 && cp->strategy <= 2) {                                        /* :1568-1576 tagged CDict tables: 24 bits of hash at most */
+        if (cp->hashLog > 24) cp->hashLog = 24;
+        if (cp->chainLog > 24) cp->chainLog = 24;
+    }
+}
+
+/* zstd_compress.c:7098-7145 ZSTD_getCParamRowSize + ZSTD_getCParams_internal */
+static int zo_get_cparams_mode(int level, unsigned long long srcSize, unsigned long long dictSize, int mode, zo_cparams* out)
+{
+    unsigned long long const rowDict = (mode == 1) ? 0 : dictSize;
+    int const unknown = srcSize == ZO_SRCSIZE_UNKNOWN;
+    unsigned long long const rSize = (unknown && rowDict == 0) ? ZO_SRCSIZE_UNKNOWN : srcSize + rowDict + ((unknown && rowDict > 0) ? 500 : 0);
+    unsigned const tableID = (rSize <= 256u*1024) + (rSize <= 128u*1024) + (rSize <= 16u*1024);
     int row = level;
     zo_cparams cp;
     if (level == 0) row = 3;                       /* ZSTD_CLEVEL_DEFAULT */
@@ -53,16 +83,15 @@ int zo_get_cparams(int level, unsigned long long srcSize, zo_cparams* out)
         cp.targetLength = (unsigned)(-clamped);
     }
     if (cp.strategy > 5) return -1;                /* btlazy2 and up are outside this oracle */
-    if (srcSize <= (1ULL << 30)) {                 /* :1546-1553 */
-        uint32_t const tSize = (uint32_t)srcSize;
-        unsigned const srcLog = (tSize < 64) ? 6 : hb32(tSize - 1) + 1;
-        if (cp.windowLog > srcLog) cp.windowLog = srcLog;
-    }
-    if (cp.hashLog > cp.windowLog + 1) cp.hashLog = cp.windowLog + 1;            /* :1557 */
-    if (cp.chainLog > cp.windowLog) cp.chainLog = cp.windowLog;                  /* :1558-1559 (cycleLog == chainLog) */
-    if (cp.windowLog < 10) cp.windowLog = 10;                                    /* :1562 */
+    zo_adjust_cparams(&cp, srcSize, dictSize, mode);
     *out = cp;
     return 0;
+}
+
+/* no dictionary, known srcSize */
+int zo_get_cparams(int level, unsigned long long srcSize, zo_cparams* out)
+{
+    return zo_get_cparams_mode(level, srcSize, 0, 0, out);
 }
 
 size_t zo_compress_bound(size_t n)   /* lib/zstd.h:235 */
@@ -415,6 +444,342 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
     rep[1] = off2 ? off2 : saved2;
     free(hc.head); free(hc.chain);
     return n - anchor;
+}
+
+/* ================================================================== dictionary (CDict, attach mode) ==================
+ * SURVEY.md §3.4 / §8 rows a7, a9, a11.  A CDict holds the dictionary content, its own tagged hash tables
+ * ("short cache": index << 8 | 8-bit tag, zstd_compress_internal.h:1399-1417) built with the CDict's own parameters,
+ * and the block state the first block starts from (repcodes; entropy tables for ZDICT-format dictionaries).
+ * Index spaces follow the reference: dictionary byte j has index j + 2 (ZSTD_WINDOW_START_INDEX), the attached working
+ * context continues at prefixStart = dictLen + 2 (zstd_compress.c:2352-2362), so dictIndexDelta is 0. */
+struct zo_cdict_s {
+    uint8_t* content; size_t len;          /* dictionary content (what matches may reference) */
+    zo_cparams cp;                         /* CDict parameters (ZSTD_cpm_createCDict) */
+    uint32_t* tabL; uint32_t* tabS;        /* fast: tabL only (hashLog); dfast: long (hashLog) + short (chainLog) */
+    uint32_t dictID; uint32_t rep[3];
+    int level;
+};
+
+static void zo_put_tagged(uint32_t* t, uint32_t hashAndTag, uint32_t index)     /* internal.h:1404 ZSTD_writeTaggedIndex */
+{
+    t[hashAndTag >> 8] = (index << 8) | (hashAndTag & 0xFF);
+}
+
+/* zstd_fast.c:16-49 ZSTD_fillHashTableForCDict / zstd_double_fast.c:18-54 ZSTD_fillDoubleHashTableForCDict (dtlm_full) */
+static void zo_cdict_fill(zo_cdict* cd)
+{
+    const uint8_t* const base = cd->content - 2;              /* index -> byte */
+    size_t const endIdx = cd->len + 2;
+    unsigned const mls = cd->cp.minMatch;
+    size_t ip, first = 2;
+    {   /* zstd_compress.c:4888-4896: a dictionary larger than the tables can reasonably index only has its SUFFIX indexed
+         * (all of it stays referenceable) */
+        unsigned const m = cd->cp.hashLog > cd->cp.chainLog ? cd->cp.hashLog : cd->cp.chainLog;
+        size_t const maxDictSize = (size_t)8 << (m < 28 ? m : 28);
+        if (cd->len > maxDictSize) first = 2 + (cd->len - maxDictSize);
+    }
+    if (endIdx - first <= 8) return;                          /* :4903 srcSize <= HASH_READ_SIZE */
+    if (cd->cp.strategy == 1) {
+        unsigned const hb = cd->cp.hashLog + 8;
+        for (ip = first; ip + 3 < (endIdx - 8) + 2; ip += 3) {    /* :37 ip + step < iend + 2 */
+            unsigned p;
+            zo_put_tagged(cd->tabL, zo_hash(base + ip, hb, mls), (uint32_t)ip);
+            for (p = 1; p < 3; p++) {
+                uint32_t const ht = zo_hash(base + ip + p, hb, mls);
+                if (cd->tabL[ht >> 8] == 0) zo_put_tagged(cd->tabL, ht, (uint32_t)(ip + p));
+            }
+        }
+    } else {
+        unsigned const hbL = cd->cp.hashLog + 8, hbS = cd->cp.chainLog + 8;
+        for (ip = first; ip + 3 - 1 <= endIdx - 8; ip += 3) { /* :36 */
+            unsigned i;
+            for (i = 0; i < 3; i++) {
+                uint32_t const sm = zo_hash(base + ip + i, hbS, mls), lg = zo_hash(base + ip + i, hbL, 8);
+                if (i == 0) zo_put_tagged(cd->tabS, sm, (uint32_t)(ip + i));
+                if (i == 0 || cd->tabL[lg >> 8] == 0) zo_put_tagged(cd->tabL, lg, (uint32_t)(ip + i));
+            }
+        }
+    }
+}
+
+void zo_cdict_free(zo_cdict* cd)
+{
+    if (!cd) return;
+    free(cd->content ? cd->content - 16 : NULL); free(cd->tabL); free(cd->tabS); free(cd);
+}
+
+/* ZSTD_createCDict (zstd_compress.c:5648): parameters for (level, unknown source, dictSize) in createCDict mode,
+ * raw-content dictionaries (no ZDICT magic: zstd_compress.c:5138-5148) — repcodes {1,4,8}, no entropy tables, dictID 0 */
+zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
+{
+    zo_cdict* cd = (zo_cdict*)calloc(1, sizeof(zo_cdict));
+    uint8_t* buf;
+    if (!cd) return NULL;
+    if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 2) { free(cd); return NULL; }
+    cd->level = level == 0 ? 3 : level;
+    if (dictSize >= 4 && rd32((const uint8_t*)dict) == 0xEC30A437U) { free(cd); return NULL; }   /* ZDICT format: not restated yet */
+    if (dictSize < 8) dictSize = 0;                           /* :5130 dictionaries below 8 bytes are ignored */
+    buf = (uint8_t*)calloc(dictSize + 64, 1);
+    cd->content = buf + 16; cd->len = dictSize;
+    memcpy(cd->content, dict, dictSize);
+    cd->tabL = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t));
+    cd->tabS = (uint32_t*)calloc((size_t)1 << cd->cp.chainLog, sizeof(uint32_t));
+    cd->dictID = 0; cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
+    zo_cdict_fill(cd);
+    return cd;
+}
+
+/* zstd_compress_internal.h:797 ZSTD_count_2segments: the match may run off the end of the dictionary into the source */
+static size_t zo_count_2seg(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd, const uint8_t* mEnd, const uint8_t* iStart)
+{
+    const uint8_t* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
+    size_t k = 0;
+    while (ip + k < vEnd && ip[k] == match[k]) k++;
+    if (match + k != mEnd) return k;
+    {   size_t j = 0;
+        while (ip + k + j < iEnd && ip[k + j] == iStart[j]) j++;
+        return k + j;
+    }
+}
+static size_t zo_count_ptr(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd)
+{
+    size_t k = 0;
+    while (ip + k < iEnd && ip[k] == match[k]) k++;
+    return k;
+}
+
+/* zstd_double_fast.c:328-547 ZSTD_compressBlock_doubleFast_dictMatchState_generic */
+static size_t zo_dfast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
+    unsigned const dHBitsL = cd->cp.hashLog + 8, dHBitsS = cd->cp.chainLog + 8;
+    uint32_t* const hashLong = (uint32_t*)calloc((size_t)1 << hBitsL, sizeof(uint32_t));
+    uint32_t* const hashSmall = (uint32_t*)calloc((size_t)1 << hBitsS, sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2;                  /* prefixLowestIndex */
+    const uint8_t* const base = src - P;                       /* index -> source byte (index >= P) */
+    const uint8_t* const dictBase = cd->content - 2;           /* index -> dictionary byte (index < P) */
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixLowest = src;
+    const uint8_t* ip = istart, * anchor = istart;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1];
+#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(litLen), (offBase), (uint32_t)(ml))
+    while (ip < ilimit) {
+        size_t mLength; uint32_t offset;
+        uint32_t const h2 = zo_hash(ip, hBitsL, 8), h = zo_hash(ip, hBitsS, mls);
+        uint32_t const dL = zo_hash(ip, dHBitsL, 8), dS = zo_hash(ip, dHBitsS, mls);
+        uint32_t const dEntL = cd->tabL[dL >> 8], dEntS = cd->tabS[dS >> 8];
+        int const tagL = (dEntL & 0xFF) == (dL & 0xFF), tagS = (dEntS & 0xFF) == (dS & 0xFF);
+        uint32_t const curr = (uint32_t)(ip - base);
+        uint32_t const matchIndexL = hashLong[h2];
+        uint32_t matchIndexS = hashSmall[h];
+        const uint8_t* matchLong = base + matchIndexL;
+        const uint8_t* match = base + matchIndexS;
+        uint32_t const repIndex = curr + 1 - offset_1;
+        const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
+        hashLong[h2] = hashSmall[h] = curr;
+        if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip + 1)) {        /* :398 ZSTD_index_overlap_check */
+            const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
+            mLength = zo_count_2seg(ip + 1 + 4, repMatch + 4, iend, repEnd, prefixLowest) + 4;
+            ip++;
+            SEQ(ip - anchor, 1, mLength);
+            goto _match_stored;
+        }
+        if (matchIndexL >= P && rd64(matchLong) == rd64(ip)) {                                /* :407 */
+            mLength = zo_count_ptr(ip + 8, matchLong + 8, iend) + 8;
+            offset = (uint32_t)(ip - matchLong);
+            while (ip > anchor && matchLong > prefixLowest && ip[-1] == matchLong[-1]) { ip--; matchLong--; mLength++; }
+            goto _match_found;
+        } else if (tagL) {                                                                    /* :413 */
+            uint32_t const dIdx = dEntL >> 8;
+            const uint8_t* dm = dictBase + dIdx;
+            if (dm > dictStart && rd64(dm) == rd64(ip)) {
+                mLength = zo_count_2seg(ip + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
+                offset = curr - dIdx;
+                while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
+                goto _match_found;
+            }
+        }
+        if (matchIndexS > P) {                                                                /* :427 */
+            if (rd32(match) == rd32(ip)) goto _search_next_long;
+        } else if (tagS) {
+            uint32_t const dIdx = dEntS >> 8;
+            match = dictBase + dIdx;
+            matchIndexS = dIdx;
+            if (match > dictStart && rd32(match) == rd32(ip)) goto _search_next_long;
+        }
+        ip += ((ip - anchor) >> 8) + 1;                                                      /* :443 */
+        continue;
+_search_next_long:
+        {   uint32_t const hl3 = zo_hash(ip + 1, hBitsL, 8), dL3 = zo_hash(ip + 1, dHBitsL, 8);
+            uint32_t const matchIndexL3 = hashLong[hl3], dEntL3 = cd->tabL[dL3 >> 8];
+            int const tagL3 = (dEntL3 & 0xFF) == (dL3 & 0xFF);
+            const uint8_t* matchL3 = base + matchIndexL3;
+            hashLong[hl3] = curr + 1;
+            if (matchIndexL3 >= P && rd64(matchL3) == rd64(ip + 1)) {                         /* :459 */
+                mLength = zo_count_ptr(ip + 9, matchL3 + 8, iend) + 8;
+                ip++;
+                offset = (uint32_t)(ip - matchL3);
+                while (ip > anchor && matchL3 > prefixLowest && ip[-1] == matchL3[-1]) { ip--; matchL3--; mLength++; }
+                goto _match_found;
+            } else if (tagL3) {
+                uint32_t const dIdx = dEntL3 >> 8;
+                const uint8_t* dm = dictBase + dIdx;
+                if (dm > dictStart && rd64(dm) == rd64(ip + 1)) {
+                    mLength = zo_count_2seg(ip + 1 + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
+                    ip++;
+                    offset = curr + 1 - dIdx;
+                    while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
+                    goto _match_found;
+                }
+            }
+        }
+        if (matchIndexS < P) {                                                                /* :481 */
+            mLength = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, prefixLowest) + 4;
+            offset = curr - matchIndexS;
+            while (ip > anchor && match > dictStart && ip[-1] == match[-1]) { ip--; match--; mLength++; }
+        } else {
+            mLength = zo_count_ptr(ip + 4, match + 4, iend) + 4;
+            offset = (uint32_t)(ip - match);
+            while (ip > anchor && match > prefixLowest && ip[-1] == match[-1]) { ip--; match--; mLength++; }
+        }
+_match_found:
+        offset_2 = offset_1; offset_1 = offset;
+        SEQ(ip - anchor, offset + 3, mLength);
+_match_stored:
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {                                                                   /* :503 */
+            uint32_t const ins = curr + 2;
+            hashLong[zo_hash(base + ins, hBitsL, 8)] = ins;
+            hashLong[zo_hash(ip - 2, hBitsL, 8)] = (uint32_t)(ip - 2 - base);
+            hashSmall[zo_hash(base + ins, hBitsS, mls)] = ins;
+            hashSmall[zo_hash(ip - 1, hBitsS, mls)] = (uint32_t)(ip - 1 - base);
+            while (ip <= ilimit) {                                                            /* :514 */
+                uint32_t const current2 = (uint32_t)(ip - base), repIndex2 = current2 - offset_2;
+                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
+                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip + 4, repMatch2 + 4, iend, repEnd2, prefixLowest) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    SEQ(0, 1, rl);
+                    hashSmall[zo_hash(ip, hBitsS, mls)] = current2;
+                    hashLong[zo_hash(ip, hBitsL, 8)] = current2;
+                    ip += rl; anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    rep[0] = offset_1; rep[1] = offset_2;
+    free(hashLong); free(hashSmall);
+    return (size_t)(iend - anchor);
+}
+
+/* zstd_fast.c:483-678 ZSTD_compressBlock_fast_dictMatchState_generic */
+static size_t zo_fast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hlog = cp->hashLog, mls = cp->minMatch, dHBits = cd->cp.hashLog + 8;
+    size_t const stepSize = cp->targetLength + !cp->targetLength;
+    uint32_t* const hashTable = (uint32_t*)calloc((size_t)1 << hlog, sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* ip0 = istart, * ip1 = ip0 + stepSize, * anchor = istart;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1];
+    while (ip1 <= ilimit) {
+        size_t mLength;
+        uint32_t hash0 = zo_hash(ip0, hlog, mls);
+        uint32_t dHT0 = zo_hash(ip0, dHBits, mls);
+        uint32_t dEnt = cd->tabL[dHT0 >> 8];
+        int dTags = (dEnt & 0xFF) == (dHT0 & 0xFF);
+        uint32_t matchIndex = hashTable[hash0];
+        uint32_t curr = (uint32_t)(ip0 - base);
+        size_t step = stepSize;
+        const uint8_t* nextStep = ip0 + 256;
+        for (;;) {
+            const uint8_t* match = base + matchIndex;
+            uint32_t const repIndex = curr + 1 - offset_1;
+            const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
+            uint32_t const hash1 = zo_hash(ip1, hlog, mls), dHT1 = zo_hash(ip1, dHBits, mls);
+            hashTable[hash0] = curr;
+            if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip0 + 1)) {   /* :566 */
+                const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
+                mLength = zo_count_2seg(ip0 + 1 + 4, repMatch + 4, iend, repEnd, prefixStart) + 4;
+                ip0++;
+                SEQ(ip0 - anchor, 1, mLength);
+                break;
+            }
+            if (dTags) {                                                                      /* :575 */
+                uint32_t const dIdx = dEnt >> 8;
+                const uint8_t* dm = dictBase + dIdx;
+                if (dIdx > 2 && rd32(dm) == rd32(ip0) && matchIndex <= P) {
+                    uint32_t const offset = curr - dIdx;
+                    mLength = zo_count_2seg(ip0 + 4, dm + 4, iend, dictEnd, prefixStart) + 4;
+                    while (ip0 > anchor && dm > dictStart && ip0[-1] == dm[-1]) { ip0--; dm--; mLength++; }
+                    offset_2 = offset_1; offset_1 = offset;
+                    SEQ(ip0 - anchor, offset + 3, mLength);
+                    break;
+                }
+            }
+            if (matchIndex >= P && rd32(ip0) == rd32(match)) {                                /* :598 ZSTD_match4Found_cmov */
+                uint32_t const offset = (uint32_t)(ip0 - match);
+                mLength = zo_count_ptr(ip0 + 4, match + 4, iend) + 4;
+                while (ip0 > anchor && match > prefixStart && ip0[-1] == match[-1]) { ip0--; match--; mLength++; }
+                offset_2 = offset_1; offset_1 = offset;
+                SEQ(ip0 - anchor, offset + 3, mLength);
+                break;
+            }
+            dEnt = cd->tabL[dHT1 >> 8];                                                       /* :614 */
+            dTags = (dEnt & 0xFF) == (dHT1 & 0xFF);
+            matchIndex = hashTable[hash1];
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip0 = ip1; ip1 = ip1 + step;
+            if (ip1 > ilimit) goto _cleanup;
+            curr = (uint32_t)(ip0 - base);
+            hash0 = hash1;
+        }
+        ip0 += mLength; anchor = ip0;                                                         /* :631 */
+        if (ip0 <= ilimit) {
+            hashTable[zo_hash(base + curr + 2, hlog, mls)] = curr + 2;
+            hashTable[zo_hash(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                uint32_t const current2 = (uint32_t)(ip0 - base), repIndex2 = current2 - offset_2;
+                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
+                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip0)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    SEQ(0, 1, rl);
+                    hashTable[zo_hash(ip0, hlog, mls)] = current2;
+                    ip0 += rl; anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+        ip1 = ip0 + stepSize;
+    }
+_cleanup:
+    rep[0] = offset_1; rep[1] = offset_2;
+    free(hashTable);
+    return (size_t)(iend - anchor);
+}
+#undef SEQ
+
+/* working-context parameters for a source of n bytes compressed with `cd` attached, or -1 if the reference would copy the
+ * dictionary instead (zstd_compress.c:2289-2315) — only the attach path is restated */
+int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
+{
+    static const size_t cutoff[6] = { 8192, 8192, 16384, 32768, 32768, 32768 };
+    zo_cparams p, w;
+    if (n > cutoff[cd->cp.strategy]) return -1;
+    if (zo_get_cparams_mode(cd->level, n, cd->len, 1, &p) < 0) return -1;        /* :6289-6292 requested params, attach mode */
+    w = cd->cp;                                                                  /* :2331-2335 */
+    zo_adjust_cparams(&w, n, cd->len, 1);
+    w.windowLog = p.windowLog;
+    *out = w;
+    return 0;
 }
 
 /* zstd_compress.c:3207-3369 ZSTD_buildSeqStore for a history-less block (+ :3365 trailing literals) */
@@ -1184,15 +1549,22 @@ size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_
 
 /* ------------------------------------------------------------------ block + frame */
 /* zstd_compress.c:4626-4672 with defaults (content size on, no checksum, no dictID) */
-static size_t write_frame_header(uint8_t* op, const zo_cparams* cp, unsigned long long n)
+static size_t write_frame_header_dict(uint8_t* op, const zo_cparams* cp, unsigned long long n, uint32_t dictID)
 {
     uint32_t const windowSize = 1u << cp->windowLog;
     unsigned const single = windowSize >= n;
     unsigned const fcs = (n >= 256) + (n >= 65536 + 256) + (n >= 0xFFFFFFFFU);
+    unsigned const dcode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);   /* :4634 dictIDSizeCode */
     size_t pos = 4;
     wr32(op, 0xFD2FB528U);
-    op[pos++] = (uint8_t)((single << 5) + (fcs << 6));
+    op[pos++] = (uint8_t)(dcode + (single << 5) + (fcs << 6));
     if (!single) op[pos++] = (uint8_t)((cp->windowLog - 10) << 3);
+    switch (dcode) {                                                             /* :4651-4657 */
+    case 1: op[pos++] = (uint8_t)dictID; break;
+    case 2: wr16(op + pos, dictID); pos += 2; break;
+    case 3: wr32(op + pos, dictID); pos += 4; break;
+    default: break;
+    }
     switch (fcs) {
     case 0: if (single) op[pos++] = (uint8_t)n; break;
     case 1: wr16(op + pos, (unsigned)(n - 256)); pos += 2; break;
@@ -1201,6 +1573,8 @@ static size_t write_frame_header(uint8_t* op, const zo_cparams* cp, unsigned lon
     }
     return pos;
 }
+
+static size_t write_frame_header(uint8_t* op, const zo_cparams* cp, unsigned long long n) { return write_frame_header_dict(op, cp, n, 0); }
 
 size_t zo_compress_unit_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
 {
@@ -1227,6 +1601,58 @@ size_t zo_compress_unit_params(void* dstv, size_t cap, const void* srcv, size_t 
     }
     if (cSize == 0) { wr24(op, (uint32_t)(1 + (0 << 1) + (n << 3))); memcpy(op + 3, src, n); return (size_t)(op + 3 + n - dst); }
     wr24(op, (uint32_t)(1 + (2 << 1) + (cSize << 3)));                           /* :4586-4590 (first block: never RLE) */
+    return (size_t)(op + 3 + cSize - dst);
+}
+
+/* debugging aid for the tests: (litLength, matchLength, offBase) of one source parsed with `cd` attached */
+size_t zo_parse_cdict(const zo_cdict* cd, const void* srcv, size_t n, uint32_t* out, size_t capSeqs)
+{
+    const uint8_t* const src = (const uint8_t*)srcv;
+    zo_cparams cp; zo_store st; uint32_t rep[3]; size_t i;
+    zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (n / 3 + 2));
+    uint8_t* lits = (uint8_t*)malloc(n + 8);
+    if (zo_cdict_params(cd, n, &cp) < 0 || n < 8) { free(seqs); free(lits); return ZO_ERROR; }
+    rep[0] = cd->rep[0]; rep[1] = cd->rep[1]; rep[2] = cd->rep[2];
+    st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
+    if (cp.strategy == 1) zo_fast_dms(&cp, cd, src, n, &st, rep); else zo_dfast_dms(&cp, cd, src, n, &st, rep);
+    for (i = 0; i < st.nb && i < capSeqs; i++) { out[3*i] = seqs[i].litLength; out[3*i+1] = seqs[i].matchLength; out[3*i+2] = seqs[i].offBase; }
+    free(seqs); free(lits);
+    return st.nb;
+}
+
+/* ZSTD_compress2 with ZSTD_CCtx_refCDict(cd) on one source of n bytes (n <= the attach cutoff): one frame, one block */
+size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cdict* cd)
+{
+    uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
+    uint8_t* op = dst; size_t cSize = 0;
+    zo_cparams cp;
+    if (zo_cdict_params(cd, n, &cp) < 0 || cap < zo_compress_bound(n)) return ZO_ERROR;
+    if (cd->len == 0) return zo_compress_unit_params(dstv, cap, srcv, n, &cp);  /* :2354 an empty dictionary is not attached, its parameters still apply */
+    op += write_frame_header_dict(op, &cp, n, cd->dictID);
+    if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
+    if (n >= 7) {
+        zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (n / 3 + 2));
+        uint8_t* lits = (uint8_t*)malloc(n + 8);
+        zo_store st; uint32_t rep[3]; size_t last;
+        uint8_t* body = op + 3;
+        rep[0] = cd->rep[0]; rep[1] = cd->rep[1]; rep[2] = cd->rep[2];
+        st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
+        if (n < 8) last = n;
+        else if (cp.strategy == 1) last = zo_fast_dms(&cp, cd, src, n, &st, rep);
+        else last = zo_dfast_dms(&cp, cd, src, n, &st, rep);
+        memcpy(lits + st.litSize, src + n - last, last);
+        st.litSize += last;
+        {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);
+            size_t const l = zo_compress_literals(body, cap, lits, st.litSize, &cp, suspect);
+            size_t const q = zo_compress_sequences(body + l, cap, seqs, st.nb, &cp);
+            if (q == ZO_ERROR || st.overflow) { free(seqs); free(lits); return ZO_ERROR; }
+            cSize = (q == 0) ? 0 : l + q;
+            if (cSize >= n - ((n >> 6) + 2)) cSize = 0;
+        }
+        free(seqs); free(lits);
+    }
+    if (cSize == 0) { wr24(op, (uint32_t)(1 + (0 << 1) + (n << 3))); memcpy(op + 3, src, n); return (size_t)(op + 3 + n - dst); }
+    wr24(op, (uint32_t)(1 + (2 << 1) + (cSize << 3)));
     return (size_t)(op + 3 + cSize - dst);
 }
 

@@ -67,6 +67,15 @@ size_t zo_compress_unit_params(void* dst, size_t cap, const void* src, size_t n,
 size_t zo_compress_chunks(int level, size_t chunkSize, const void* src, size_t n,
                           void* dst, size_t cap, size_t* sizes, size_t maxChunks);
 
+/* Dictionary compression, attach mode (zstd_fast.c:483-678, zstd_double_fast.c:328-547, fill functions
+ * zstd_fast.c:16-49 / zstd_double_fast.c:18-54, parameters zstd_compress.c:1466-1602 + :2318-2376): what
+ * ZSTD_createCDict(dict, size, level) + ZSTD_CCtx_refCDict + ZSTD_compress2 emit for one small source. */
+typedef struct zo_cdict_s zo_cdict;
+zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level);
+void      zo_cdict_free(zo_cdict* cd);
+int       zo_cdict_params(const zo_cdict* cd, size_t srcSize, zo_cparams* out);   /* -1: the reference would not attach */
+size_t    zo_compress_unit_cdict(void* dst, size_t cap, const void* src, size_t n, const zo_cdict* cd);
+
 /* programs/datagen.c:144 RDG_genBuffer and :155 RDG_genStdout restated (input generators for tests/bench) */
 void zo_datagen(void* buf, size_t size, double matchProba, double litProba, unsigned seed);
 
