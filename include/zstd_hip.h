@@ -76,6 +76,30 @@ size_t       zhip_prepare_sequences(zhip_ctx* ctx, const void* src, size_t srcSi
 size_t       zhip_parse_device(zhip_ctx* ctx, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream);
 size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* out, size_t capacity);
 
+/* ---- dictionary compression of many small records (BASELINE configs[4]): what
+ *      cdict = ZSTD_createCDict(dict, dictSize, level);                      lib/zstd.h:1006
+ *      ZSTD_CCtx_refCDict(cctx, cdict); ZSTD_compress2(cctx, ..record..)     lib/zstd.h:1180, :603    per record
+ * produces — one frame per record, byte-identical — for records up to the reference's attach cut-off (8 KB for strategy
+ * fast, 16 KB for dfast: lib/compress/zstd_compress.c:2289-2315).  The CDict's tables are built once on the host exactly
+ * like ZSTD_createCDict builds them (zstd_fast.c:16-49, zstd_double_fast.c:18-54) and uploaded.
+ * This round: raw-content dictionaries (ZSTD_dct_rawContent / no ZDICT magic) with levels whose CDict row is dfast
+ * (level 3-4 class); anything else returns NULL / parameter_unsupported — there is no CPU fallback. */
+typedef struct zhip_cdict_s zhip_cdict;
+zhip_cdict*  zhip_create_cdict(int device, const void* dict, size_t dictSize, int level);
+void         zhip_free_cdict(zhip_cdict* cdict);
+/* a context whose scratch is sized for `maxRecords` records of `maxTotalBytes` source bytes in one call */
+zhip_ctx*    zhip_create_for_records(int device, size_t maxRecords, size_t maxTotalBytes);
+/* sum of ZSTD_compressBound over the records; recOffsets has nRec+1 entries (record i = [recOffsets[i], recOffsets[i+1])) */
+size_t       zhip_records_bound(const unsigned long long* recOffsets, size_t nRec);
+/* records and destination resident in HBM; recOffsets is a HOST array; frameSizesDev (optional) gets nRec u32 sizes;
+ * frames are packed back to back into dstDev.  Returns the total compressed size. */
+size_t       zhip_compress_records_device(zhip_ctx* ctx, const zhip_cdict* cdict, void* dstDev, size_t dstCapacity,
+                                          const void* srcDev, const unsigned long long* recOffsets, size_t nRec,
+                                          uint32_t* frameSizesDev, void* stream);
+/* host buffers (staged over PCIe); frameSizes (optional) gets nRec sizes */
+size_t       zhip_compress_records(zhip_ctx* ctx, const zhip_cdict* cdict, void* dst, size_t dstCapacity,
+                                   const void* src, const unsigned long long* recOffsets, size_t nRec, size_t* frameSizes);
+
 /* ---- measurement: HIP-event durations (ms) of the kernels of the most recent call on this ctx
  * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */
 void         zhip_last_timing(const zhip_ctx* ctx, double t[4]);

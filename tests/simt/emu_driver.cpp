@@ -3,6 +3,16 @@
 // wave-level logic can be checked against the oracle without a GPU.  Built by tests/_libs.py with g++.
 #include <hip/hip_runtime.h>
 #include "zhip_kernels.h"
+#include "zhip_cdict_host.h"
+
+#include <vector>
+// full-size slots (fixed strides), what the host library fills for 128 KB units
+static std::vector<ZhipSlot> fixed_slots(uint32_t nUnits)
+{
+    std::vector<ZhipSlot> v(nUnits ? nUnits : 1);
+    for (uint32_t i = 0; i < nUnits; i++) { v[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; v[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; v[i].outOff = (uint64_t)i * ZHIP_OUT_STRIDE; v[i].seqCap = ZHIP_SEQ_CAP; v[i].pad0 = 0; }
+    return v;
+}
 
 extern "C" {
 
@@ -10,15 +20,17 @@ extern "C" {
 void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas,
                     uint32_t smemBytes, int osThreads)
 {
+    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, smemBytes,
-                 [=] { zhip::k_parse_fast(src, units, nUnits, seqs, lits, metas); }, osThreads);
+                 [=] { zhip::k_parse_fast(src, units, slots, nUnits, seqs, lits, metas); }, osThreads);
 }
 
 void emu_parse_dfast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride,
                      ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
 {
+    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::dfast_lds_bytes(),
-                 [=] { zhip::k_parse_dfast(src, units, nUnits, tabs, tabStride, seqs, lits, metas); }, osThreads);
+                 [=] { zhip::k_parse_dfast(src, units, slots, nUnits, tabs, tabStride, seqs, lits, metas); }, osThreads);
 }
 uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhip::dfast_table_bytes(hashLog, chainLog); }
 
@@ -26,6 +38,7 @@ uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhi
 void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride, uint64_t* best,
                     ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
 {
+    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     uint32_t maxLen = 1, maxHlog = 6;
     for (uint32_t i = 0; i < nUnits; i++) { if (units[i].srcLen > maxLen) maxLen = units[i].srcLen; if (units[i].hashLog > maxHlog) maxHlog = units[i].hashLog; }
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::hc_chain_lds_bytes(maxHlog),
@@ -34,16 +47,47 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,
                  [=] { zhip::k_hc_search(src, units, nUnits, bpu, tabs, tabStride, best); }, osThreads);
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0,
-                 [=] { zhip::k_parse_lazy(src, units, nUnits, tabs, tabStride, best, seqs, lits, metas); }, osThreads);
+                 [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas); }, osThreads);
 }
 uint64_t emu_hc_table_words(uint32_t hashLog) { return zhip::hc_table_words(hashLog); }
+
+// dictionary path: build the CDict with the product's host code, fill the records' working parameters, parse them with
+// k_parse_dict.  Records lie back to back in src (offsets[nRec+1]); slots are the fixed full-size ones (test harness).
+// returns 0 ok, >0 = host_cdict_build error, -1 = some record is above the attach cut-off
+int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, const uint8_t* dict, size_t dictSize, int level,
+                   ZhipUnit* unitsOut, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
+{
+    zhip::HostCDict cd;
+    int const e = zhip::host_cdict_build(cd, dict, dictSize, level);
+    if (e) return e;
+    if (cd.cp.strategy != 2 || cd.len == 0) return 9;
+    uint32_t mh = 6, mc = 6;
+    for (uint32_t i = 0; i < nRec; i++) {
+        zhip::CParams cp; size_t const n = (size_t)(offsets[i + 1] - offsets[i]);
+        if (!zhip::host_cdict_unit_params(cd, n, &cp)) return -1;
+        ZhipUnit& u = unitsOut[i];
+        u.srcOff = offsets[i]; u.srcLen = (uint32_t)n; u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
+        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog; u.litMode = 0; u.pad0 = 0; u.targetLength = cp.targetLength;
+        if (cp.hashLog > mh) mh = cp.hashLog;
+        if (cp.chainLog > mc) mc = cp.chainLog;
+    }
+    zhip::ZhipCDictDev dv;
+    dv.content = cd.content.data(); dv.len = (uint32_t)cd.len; dv.hashLog = cd.cp.hashLog; dv.chainLog = cd.cp.chainLog; dv.minMatch = cd.cp.minMatch;
+    dv.strategy = cd.cp.strategy; dv.tabL = cd.tabL.data(); dv.tabS = cd.tabS.data(); dv.rep[0] = cd.rep[0]; dv.rep[1] = cd.rep[1]; dv.rep[2] = cd.rep[2]; dv.dictID = cd.dictID;
+    std::vector<ZhipSlot> const sv = fixed_slots(nRec); const ZhipSlot* const slots = sv.data();
+    const ZhipUnit* units = unitsOut;
+    simt::launch({nRec, 1, 1}, {64, 1, 1}, zhip::dict_lds_bytes(mh, mc),
+                 [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
+    return 0;
+}
 
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
                  const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)
 {
+    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
-                 [=] { zhip::k_entropy(src, units, nUnits, seqs, metas, lits, stBits, out, outSize); }, osThreads);
+                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize); }, osThreads);
 }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }

@@ -3,7 +3,7 @@ CPU only: this checks the wave-parallel algorithm, not the GPU build."""
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT)
+from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_)
 
 
 @pytest.fixture(scope="module")
@@ -121,3 +121,50 @@ def test_hashchain_parse_skip_regions_then_matches(libs, level):
     mixed = np.concatenate([r1, datagen(lo, 30000, 60, level), r1[3000:15000], rng.integers(0, 256, size=9000, dtype=np.uint8),
                             r1[:9000], datagen(lo, 21072, 30, level + 1)])
     check(le, lo, [("mixed", mixed), ("mixed_short", mixed[:70001])], level)
+
+
+def test_dict_dfast_records_parse_like_the_oracle(libs):
+    """k_parse_dict (dfast with an attached dictionary) on the emulator vs the oracle's dictMatchState restatement"""
+    lo, le = libs
+    from _libs import datagen, text_like
+    lo.zo_cdict_create.restype = C.c_void_p
+    lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_cdict_free.argtypes = [C.c_void_p]
+    lo.zo_parse_cdict.restype = C.c_size_t
+    lo.zo_parse_cdict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    le.emu_parse_dict.restype = C.c_int
+    le.emu_parse_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
+    rng = np.random.default_rng(5)
+    for kind, level in (("text", 3), ("datagen", 3), ("text", 4)):
+        corpus = text_like(200000, 3) if kind == "text" else datagen(lo, 200000, 60, 3)
+        dict_ = corpus[:110000 if level == 3 else 60000].copy()
+        recs = []
+        for n in (8, 9, 10, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 16384, 12000, 300, 64):
+            s = int(rng.integers(0, len(corpus) - n))
+            r = corpus[s:s + n].copy()
+            if n > 50:
+                k = rng.integers(0, n, size=max(1, n // 40))
+                r[k] = rng.integers(0, 256, size=len(k), dtype=np.uint8)
+            recs.append(r)
+        recs.append(dict_[-300:].copy())                 # ends exactly like the dictionary: matches that run off its end
+        recs.append(np.concatenate([dict_[-40:], dict_[:200], dict_[-40:]]))
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+        src = np.concatenate(recs + [np.zeros(16, np.uint8)])
+        nrec = len(recs)
+        cap = le.emu_seq_cap(); lstride = le.emu_lit_stride()
+        units = np.zeros(nrec, dtype=UNIT_DT_)
+        seqs = np.zeros(nrec * cap, dtype=SEQ_DT); metas = np.zeros(nrec, dtype=PARSE_DT)
+        lits = np.full(nrec * lstride, 0xEE, dtype=np.uint8)
+        rc = le.emu_parse_dict(_buf(src), _buf(offs), nrec, _buf(dict_), len(dict_), level, _buf(units), _buf(seqs), _buf(lits), _buf(metas), 0)
+        assert rc == 0, rc
+        cd = lo.zo_cdict_create(_buf(dict_), len(dict_), level)
+        for i, r in enumerate(recs):
+            want = np.zeros((len(r) // 3 + 8, 3), dtype=np.uint32)
+            nw = lo.zo_parse_cdict(cd, _buf(r), len(r), _buf(want), len(want))
+            m = metas[i]
+            s = seqs[i * cap: i * cap + int(m["nbSeq"])]
+            got = np.stack([s["litLength"].astype(np.uint32), s["mlBase"].astype(np.uint32) + 3, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32)
+            assert len(got) == nw, (kind, level, len(r), len(got), nw)
+            bad = np.nonzero((got != want[:nw]).any(axis=1))[0]
+            assert len(bad) == 0, (kind, level, len(r), int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
+        lo.zo_cdict_free(cd)

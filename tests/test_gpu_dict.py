@@ -1,0 +1,95 @@
+"""-m gpu: dictionary path (records compressed with an attached CDict) through the C ABI: every frame byte-identical to the
+oracle's restatement of ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (pinned to the real reference by
+tests/test_oracle_dict.py), and decoded with the dictionary by the reference build when it is present."""
+import ctypes as C
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, datagen, text_like, _buf, ERR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import zstd_amd
+    assert torch.cuda.is_available(), "needs a GPU"
+    lo = load_oracle()
+    lo.zo_cdict_create.restype = C.c_void_p
+    lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_cdict_free.argtypes = [C.c_void_p]
+    lo.zo_compress_unit_cdict.restype = C.c_size_t
+    lo.zo_compress_unit_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    return lo, zstd_amd, torch
+
+
+def records_of(corpus, rng, sizes):
+    recs = []
+    for n in sizes:
+        s = int(rng.integers(0, len(corpus) - n))
+        r = corpus[s:s + n].copy()
+        if n > 50:
+            k = rng.integers(0, n, size=max(1, n // 40))
+            r[k] = rng.integers(0, 256, size=len(k), dtype=np.uint8)
+        recs.append(r)
+    return recs
+
+
+def oracle_frames(lo, dict_, recs, level):
+    cd = lo.zo_cdict_create(_buf(dict_), len(dict_), level)
+    assert cd
+    out = []
+    for r in recs:
+        buf = np.zeros(len(r) + 700, dtype=np.uint8)
+        k = lo.zo_compress_unit_cdict(_buf(buf), len(buf), _buf(r), len(r), cd)
+        assert k != ERR
+        out.append(buf[:k].tobytes())
+    lo.zo_cdict_free(cd)
+    return out
+
+
+@pytest.mark.parametrize("kind,level,dsize", [("text", 3, 110000), ("datagen", 3, 40000), ("text", 4, 60000), ("text", 3, 9), ("text", 3, 5)])
+def test_records_with_dictionary_match_oracle_bytes(env, kind, level, dsize):
+    lo, zstd_amd, torch = env
+    rng = np.random.default_rng(level * 100 + dsize % 97)
+    corpus = text_like(300000, 3) if kind == "text" else datagen(lo, 300000, 60, 3)
+    dict_ = corpus[:dsize].copy()
+    sizes = [0, 1, 6, 7, 8, 9, 10, 17, 64, 100, 300, 500, 1000, 1024, 1500, 2000, 4000, 8000, 12000, 16384] + [int(x) for x in rng.integers(200, 2000, size=200)]
+    recs = records_of(corpus, rng, sizes)
+    recs.append(dict_[-300:].copy() if dsize > 300 else dict_.copy())
+    ctx = zstd_amd.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
+    cd = zstd_amd.CDict(dict_, level=level)
+    got, fs = ctx.compress_records(cd, recs, return_sizes=True)
+    want = oracle_frames(lo, dict_, recs, level)
+    pos = 0
+    for i, (r, w) in enumerate(zip(recs, want)):
+        g = got[pos:pos + int(fs[i])]
+        pos += int(fs[i])
+        assert g == w, (kind, level, dsize, i, len(r), len(g), len(w))
+    assert pos == len(got)
+    if have_ref() and dsize >= 8:
+        lr = load_ref()
+        lr.zref_decompress_dict.restype = C.c_size_t
+        lr.zref_decompress_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        pos = 0
+        for i, r in enumerate(recs):
+            f = np.frombuffer(got[pos:pos + int(fs[i])], dtype=np.uint8)
+            pos += int(fs[i])
+            out = np.zeros(max(1, len(r)), dtype=np.uint8)
+            k = lr.zref_decompress_dict(_buf(out), len(r), _buf(f), len(f), _buf(dict_), len(dict_))
+            assert k == len(r) and out[:len(r)].tobytes() == r.tobytes(), i
+    cd.close(); ctx.close()
+
+
+def test_unsupported_dictionaries_are_errors(env):
+    lo, zstd_amd, torch = env
+    zd = np.zeros(200, dtype=np.uint8)
+    zd[:4] = np.frombuffer((0xEC30A437).to_bytes(4, "little"), dtype=np.uint8)
+    with pytest.raises(zstd_amd.ZhipError):
+        zstd_amd.CDict(zd, level=3)                          # ZDICT-format dictionaries: entropy tables not implemented yet
+    with pytest.raises(zstd_amd.ZhipError):
+        zstd_amd.CDict(text_like(5000, 1), level=9)          # CDict row is a lazy strategy
+    cd = zstd_amd.CDict(text_like(50000, 1), level=3)
+    ctx = zstd_amd.Context(0, max_units=4, records_total_bytes=100000)
+    with pytest.raises(zstd_amd.ZhipError):
+        ctx.compress_records(cd, [text_like(20000, 2)])      # above the 16 KB attach cut-off: the reference copies the dictionary

@@ -60,6 +60,12 @@ def lib():
             ("zhip_compress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]),
             ("zhip_compress_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
             ("zhip_prepare_sequences", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+            ("zhip_create_cdict", C.c_void_p, [C.c_int, C.c_void_p, C.c_size_t, C.c_int]),
+            ("zhip_free_cdict", None, [C.c_void_p]),
+            ("zhip_create_for_records", C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t]),
+            ("zhip_records_bound", C.c_size_t, [C.c_void_p, C.c_size_t]),
+            ("zhip_compress_records_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+            ("zhip_compress_records", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
         ]:
             if hasattr(L, name):
                 getattr(L, name).restype = res
@@ -86,14 +92,40 @@ def datagen(size, match_pct=50, seed=0, stream_mode=True, lit_proba=0.0):
     return a[:size]
 
 
+class CDict:
+    """a dictionary digested for one GPU (the role ZSTD_CDict plays): parameters + tagged hash tables built on the host
+    like ZSTD_createCDict builds them, uploaded once"""
+
+    def __init__(self, dict_bytes, level=3, device=0):
+        a = np.frombuffer(dict_bytes, dtype=np.uint8) if not isinstance(dict_bytes, np.ndarray) else dict_bytes
+        self._keep = np.ascontiguousarray(a)
+        self._h = lib().zhip_create_cdict(device, self._keep.ctypes.data_as(C.c_void_p), self._keep.size, level)
+        if not self._h:
+            raise ZhipError(f"zhip_create_cdict(level={level}, {self._keep.size} B): not supported on device (ZDICT entropy tables, or a "
+                            "CDict strategy above dfast) or no GPU")
+        self.level, self.device = level, device
+
+    def close(self):
+        if self._h:
+            lib().zhip_free_cdict(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """owns the device-side state for one GPU (the role ZSTD_CCtx plays for the CPU library)"""
 
-    def __init__(self, device=0, max_units=1024):
+    def __init__(self, device=0, max_units=1024, records_total_bytes=None):
+        """max_units 128 KB units per call; or, for the dictionary path, max_units small records of records_total_bytes in all"""
         L = lib()
         if L.zhip_device_count() <= 0:
             raise ZhipError("no HIP device visible (zstd_amd has no CPU path)")
-        self._h = L.zhip_create(device, max_units)
+        self._h = L.zhip_create(device, max_units) if records_total_bytes is None else L.zhip_create_for_records(device, max_units, records_total_bytes)
         if not self._h:
             raise ZhipError(f"zhip_create(device={device}, max_units={max_units}) failed")
         self.device = device
@@ -140,6 +172,26 @@ class Context:
         out = np.zeros((cap, 4), dtype=np.uint32)
         n = self._check(lib().zhip_get_sequences(self._h, unit_index, out.ctypes.data_as(C.c_void_p), cap), "zhip_get_sequences")
         return out[:n]
+
+    # ---- dictionary path: many small records, one frame each
+    def compress_records(self, cdict, records, return_sizes=False):
+        """records: list of bytes / uint8 arrays -> concatenated frames (bytes)"""
+        arrs = [np.frombuffer(r, dtype=np.uint8) if not isinstance(r, np.ndarray) else r for r in records]
+        offs = np.concatenate([[0], np.cumsum([a.size for a in arrs])]).astype(np.uint64)
+        flat = np.concatenate(arrs + [np.zeros(8, np.uint8)]) if arrs else np.zeros(8, np.uint8)
+        cap = lib().zhip_records_bound(offs.ctypes.data_as(C.c_void_p), len(arrs)) + 64
+        dst = np.empty(cap, dtype=np.uint8)
+        sizes = np.zeros(max(1, len(arrs)), dtype=np.uint64)
+        r = self._check(lib().zhip_compress_records(self._h, cdict._h, dst.ctypes.data_as(C.c_void_p), cap, flat.ctypes.data_as(C.c_void_p),
+                                                    offs.ctypes.data_as(C.c_void_p), len(arrs), sizes.ctypes.data_as(C.c_void_p)), "zhip_compress_records")
+        out = dst[:r].tobytes()
+        return (out, sizes[:len(arrs)]) if return_sizes else out
+
+    def compress_records_device(self, cdict, dst_ptr, dst_cap, src_ptr, offsets, sizes_ptr=None, stream=None):
+        """offsets: host np.uint64 array with nRec+1 entries; src/dst are device pointers"""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return self._check(lib().zhip_compress_records_device(self._h, cdict._h, dst_ptr, dst_cap, src_ptr, offs.ctypes.data_as(C.c_void_p),
+                                                              len(offs) - 1, sizes_ptr, stream), "zhip_compress_records_device")
 
     # ---- full pipeline
     def compress_device(self, dst_ptr, dst_cap, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, sizes_ptr=None, stream=None):

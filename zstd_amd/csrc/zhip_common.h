@@ -22,6 +22,17 @@ struct ZhipUnit {
     uint32_t targetLength;
 };
 
+// where a unit's intermediate results live: offsets into the context's arenas, filled by the host.  Full-size units use the
+// fixed strides above; small records (dictionary path) are packed back to back.
+struct ZhipSlot {
+    uint64_t seqOff;        // ZhipSeq index into the sequence arena; the unit's three code arrays start at 3*seqOff in the
+                            // code arena (uint16_t), each seqCap entries long
+    uint64_t litOff;        // byte offset into the literal arena
+    uint64_t outOff;        // byte offset into the output-slot arena (16-byte aligned)
+    uint32_t seqCap;        // capacity in sequences
+    uint32_t pad0;
+};
+
 // 8-byte sequence record (same packing as the reference's seqDef + its single long-length escape)
 struct ZhipSeq {
     uint32_t offBase;       // 1..3 repcode id, else offset + 3

@@ -211,7 +211,7 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
 
 // ================================================================== the unit encoder
 __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
-                                    const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
+                                    const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
                                     uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh)
 {
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -233,7 +233,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         }
         return;
     }
-    uint16_t* const bLL = stBits; uint16_t* const bOF = stBits + ZHIP_SEQ_CAP; uint16_t* const bML = stBits + 2 * (size_t)ZHIP_SEQ_CAP;
+    uint16_t* const bLL = stBits; uint16_t* const bOF = stBits + seqCap; uint16_t* const bML = stBits + 2 * (size_t)seqCap;
 
     // ================ phase A (all threads): byte histogram of the literals; sequence codes + code histograms
     for (int i = t; i < 4 * 256; i += ZHIP_ENT_THREADS) (&sh->hist[0][0])[i] = 0;
@@ -324,7 +324,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     }
     if (wv >= 1 && nbSeq > 0) {
         int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
-        uint16_t* const arr = stBits + (size_t)k * ZHIP_SEQ_CAP;
+        uint16_t* const arr = stBits + (size_t)k * seqCap;
         uint32_t const lastCode = arr[nbSeq - 1];                  // for the "-1" rule (zstd_compress_sequences.c:271-274)
         ZPROF_JOB_BEGIN
         if (lane == 0) {

@@ -13,7 +13,37 @@ struct CParams { unsigned windowLog, chainLog, hashLog, searchLog, minMatch, tar
 // its four source-size classes; the selection + adjustment logic mirrors ZSTD_getCParams_internal
 // (lib/compress/zstd_compress.c:7123-7145) and ZSTD_adjustCParams_internal (:1466-1602) for a known source size
 // and no dictionary.  tests/test_host_params.py sweeps this against the real reference.
-static inline bool host_get_cparams(int level, unsigned long long srcSize, CParams* out)
+enum { HOST_CPM_NONE = 0, HOST_CPM_ATTACH = 1, HOST_CPM_CREATE_CDICT = 2 };       // ZSTD_cParamMode_e (zstd_compress_internal.h:176-191)
+#define HOST_SRCSIZE_UNKNOWN (~0ULL)
+
+// ZSTD_adjustCParams_internal (zstd_compress.c:1466-1602) for the strategies implemented here
+static inline void host_adjust_cparams(CParams* cp, unsigned long long srcSize, unsigned long long dictSize, int mode)
+{
+    if (mode == HOST_CPM_CREATE_CDICT && dictSize && srcSize == HOST_SRCSIZE_UNKNOWN) srcSize = 513;   // :1524-1531
+    if (mode == HOST_CPM_ATTACH) dictSize = 0;                                                           // :1532-1538
+    if (srcSize <= (1ULL << 30) && dictSize <= (1ULL << 30)) {                                           // :1546-1553
+        uint32_t const t = (uint32_t)(srcSize + dictSize);
+        unsigned const srcLog = t < 64 ? 6 : 32 - (unsigned)__builtin_clz(t - 1);
+        if (cp->windowLog > srcLog) cp->windowLog = srcLog;
+    }
+    if (srcSize != HOST_SRCSIZE_UNKNOWN) {                                                               // :1554-1560
+        unsigned dawl = cp->windowLog;                                                                   // ZSTD_dictAndWindowLog :1432
+        if (dictSize) {
+            unsigned long long const windowSize = 1ULL << cp->windowLog;
+            if (windowSize < dictSize + srcSize)
+                dawl = (dictSize + windowSize >= (1ULL << 31)) ? 31 : 32 - (unsigned)__builtin_clz((uint32_t)(dictSize + windowSize) - 1);
+        }
+        if (cp->hashLog > dawl + 1) cp->hashLog = dawl + 1;
+        if (cp->chainLog > dawl) cp->chainLog = dawl;
+    }
+    if (cp->windowLog < 10) cp->windowLog = 10;
+    if (mode == HOST_CPM_CREATE_CDICT && cp->strategy <= 2) {                                            // :1568-1576 tagged tables
+        if (cp->hashLog > 24) cp->hashLog = 24;
+        if (cp->chainLog > 24) cp->chainLog = 24;
+    }
+}
+
+static inline bool host_get_cparams_mode(int level, unsigned long long srcSize, unsigned long long dictSize, int mode, CParams* out)
 {
     static const CParams rows[4][13] = {     // [size class][0 = negative-level base, 1..12 = level]; strategy 6+ = binary tree (not ours)
         /* srcSize > 256 KB */ {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},
@@ -29,22 +59,25 @@ static inline bool host_get_cparams(int level, unsigned long long srcSize, CPara
                                 {14,14,14,3,4,4,4},{14,14,14,4,4,8,5},{14,14,14,6,4,8,5},{14,14,14,8,4,8,5},{14,15,14,5,4,8,6},
                                 {14,15,14,9,4,8,6},{14,15,14,3,4,12,7},{14,15,14,4,3,24,7}},
     };
-    unsigned const cls = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
+    // ZSTD_getCParamRowSize (zstd_compress.c:7098-7116): attach mode ignores the dictionary; an unknown source with a
+    // dictionary is taken as dictSize + 500 (the sum wraps exactly like the reference's U64 arithmetic)
+    unsigned long long const rowDict = mode == HOST_CPM_ATTACH ? 0 : dictSize;
+    bool const unknown = srcSize == HOST_SRCSIZE_UNKNOWN;
+    unsigned long long const rSize = (unknown && rowDict == 0) ? HOST_SRCSIZE_UNKNOWN : srcSize + rowDict + ((unknown && rowDict > 0) ? 500 : 0);
+    unsigned const cls = (rSize <= 256u * 1024) + (rSize <= 128u * 1024) + (rSize <= 16u * 1024);
     int row = level == 0 ? 3 : (level < 0 ? 0 : level);
     if (row > 12) return false;
     CParams cp = rows[cls][row];
     if (cp.strategy > 5) return false;       // btlazy2 and up: not implemented
     if (level < 0) { long const lv = level < -131072 ? -131072 : level; cp.targetLength = (unsigned)(-lv); }
-    if (srcSize <= (1ULL << 30)) {
-        uint32_t const t = (uint32_t)srcSize;
-        unsigned const srcLog = t < 64 ? 6 : 32 - (unsigned)__builtin_clz(t - 1);
-        if (cp.windowLog > srcLog) cp.windowLog = srcLog;
-    }
-    if (cp.hashLog > cp.windowLog + 1) cp.hashLog = cp.windowLog + 1;
-    if (cp.chainLog > cp.windowLog) cp.chainLog = cp.windowLog;
-    if (cp.windowLog < 10) cp.windowLog = 10;
+    host_adjust_cparams(&cp, srcSize, dictSize, mode);
     *out = cp;
     return true;
+}
+
+static inline bool host_get_cparams(int level, unsigned long long srcSize, CParams* out)
+{
+    return host_get_cparams_mode(level, srcSize, 0, HOST_CPM_NONE, out);
 }
 
 // ZSTD_COMPRESSBOUND, lib/zstd.h:235

@@ -5,13 +5,14 @@
 #include "zhip_parse.h"
 #include "zhip_parse_dfast.h"
 #include "zhip_parse_lazy.h"
+#include "zhip_parse_dict.h"
 #include "zhip_entropy.h"
 
 namespace zhip {
 
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
 __global__ void __launch_bounds__(64)
-k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
@@ -20,8 +21,9 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     ZhipUnit const u = units[ui];
     if (u.strategy != ZHIP_STRAT_FAST) return;          // another family's kernel handles it
     const uint8_t* const p = src + u.srcOff;
-    ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
-    uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
+    ZhipSlot const sl = slots[ui];
+    ZhipSeq* const sq = seqs + sl.seqOff;
+    uint8_t* const lt = lits + sl.litOff;
     switch (u.minMatch) {               // wave-uniform: the hash width is a compile-time constant inside the parser
     case 5:  parse_fast_unit<5>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
     case 6:  parse_fast_unit<6>(p, u.srcLen, u, smem, sq, lt, metas + ui); break;
@@ -34,7 +36,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 // Stage 1 for strategy dfast: one wavefront per unit, the unit's two hash tables live in HBM/L2 (tabs + ui * tabStride
 // words: long table, then short table).  Dynamic LDS = dfast_lds_bytes().
 __global__ void __launch_bounds__(64)
-k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
               uint32_t* __restrict__ tabs, size_t tabStride,
               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
@@ -44,8 +46,9 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     ZhipUnit const u = units[ui];
     if (u.strategy != ZHIP_STRAT_DFAST) return;
     const uint8_t* const p = src + u.srcOff;
-    ZhipSeq* const sq = seqs + (size_t)ui * ZHIP_SEQ_CAP;
-    uint8_t* const lt = lits + (size_t)ui * ZHIP_LIT_STRIDE;
+    ZhipSlot const sl = slots[ui];
+    ZhipSeq* const sq = seqs + sl.seqOff;
+    uint8_t* const lt = lits + sl.litOff;
     uint32_t* const tL = tabs + (size_t)ui * tabStride;
     uint32_t* const tS = tL + ((size_t)1 << u.hashLog);
     switch (u.minMatch) {
@@ -54,6 +57,28 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     case 7:  parse_dfast_unit<7>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
     case 8:  parse_dfast_unit<8>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
     default: parse_dfast_unit<4>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    }
+}
+
+// Stage 1 for records compressed with an attached dictionary (strategy dfast), one wavefront per record.
+// Dynamic LDS = dict_lds_bytes(max hashLog, max chainLog of the records).
+__global__ void __launch_bounds__(64)
+k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+             ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    if (u.strategy != ZHIP_STRAT_DFAST) return;
+    const uint8_t* const p = src + u.srcOff;
+    ZhipSlot const sl = slots[ui];
+    switch (u.minMatch) {
+    case 5:  parse_dfast_dms_unit<5>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 6:  parse_dfast_dms_unit<6>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 7:  parse_dfast_dms_unit<7>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 8:  parse_dfast_dms_unit<8>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    default: parse_dfast_dms_unit<4>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
     }
 }
 
@@ -95,7 +120,7 @@ k_hc_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
 }
 
 __global__ void __launch_bounds__(64)
-k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
@@ -105,13 +130,13 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
     parse_lazy_unit(src + u.srcOff, u.srcLen, u, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
-                    seqs + (size_t)ui * ZHIP_SEQ_CAP, lits + (size_t)ui * ZHIP_LIT_STRIDE, metas + ui);
+                    seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui);
 }
 
 // Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's
-// output slot (stride ZHIP_OUT_STRIDE).  Dynamic LDS = sizeof(EntShared).
+// output slot.  Dynamic LDS = sizeof(EntShared).
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
-k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
           const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize)
 {
@@ -120,18 +145,19 @@ k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, u
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     ZhipParse const pm = metas[ui];
-    entropy_unit(src + u.srcOff, u, seqs + (size_t)ui * ZHIP_SEQ_CAP, pm, lits + (size_t)ui * ZHIP_LIT_STRIDE,
-                 stBits + (size_t)ui * 3 * ZHIP_SEQ_CAP, out + (size_t)ui * ZHIP_OUT_STRIDE, outSize + ui, (EntShared*)smem);
+    ZhipSlot const sl = slots[ui];
+    entropy_unit(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
+                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem);
 }
 
 // Stage 3: pack the per-unit slots into one contiguous stream.  offsets[] = exclusive prefix sum of outSize[].
 __global__ void __launch_bounds__(256)
-k_gather(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ outSize, const uint64_t* __restrict__ offsets,
-         uint32_t nUnits, uint8_t* __restrict__ dst)
+k_gather(const uint8_t* __restrict__ outArena, const ZhipSlot* __restrict__ slots, const uint32_t* __restrict__ outSize,
+         const uint64_t* __restrict__ offsets, uint32_t nUnits, uint8_t* __restrict__ dst)
 {
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
-    const uint8_t* s = slots + (size_t)ui * ZHIP_OUT_STRIDE;
+    const uint8_t* s = outArena + slots[ui].outOff;
     uint8_t* d = dst + offsets[ui];
     uint32_t const n = outSize[ui];
     // destination alignment is arbitrary: peel to 16 bytes, then 16-byte vectors (source slots are 16-byte aligned)

@@ -9,6 +9,7 @@
 #include "zhip_common.h"
 #include "zhip_kernels.h"
 #include "zhip_host.h"
+#include "zhip_cdict_host.h"
 #include "zhip_datagen.h"
 
 // zstd's error numbering (lib/zstd_errors.h:60-101): results are (size_t)-code
@@ -27,6 +28,7 @@ struct zhip_ctx_s {
     int nChunks; hipStream_t cs[ZHIP_MAX_CHUNKS]; hipEvent_t cev[ZHIP_MAX_CHUNKS];
     // device scratch, one slot per unit
     ZhipUnit*  dUnits;
+    ZhipSlot*  dSlots;                         // per unit: where its sequences / literals / output slot live
     ZhipSeq*   dSeqs;
     ZhipParse* dParse;
     uint8_t*   dLits;
@@ -39,13 +41,14 @@ struct zhip_ctx_s {
     uint32_t   hcMaxLen, hcHashLog;            // hash chain: longest unit / largest hashLog of the call
     std::vector<hipEvent_t> hcEv; size_t hcEvUsed;   // hash chain: 4 events per chunk of the last call
     int        strategy;                       // family mask of the current call's units: bit 0 fast, 1 dfast, 2 hash chain
+    size_t     seqArena, litArena, outArena;   // arena capacities: sequences (entries), literal bytes, output-slot bytes
     uint32_t*  dOutSize;
     uint64_t*  dOutOff;
     // staging for the host-buffer API
     uint8_t* dSrcStage; size_t srcStageCap;
     uint8_t* dDstStage; size_t dstStageCap;
     // pinned host mirrors
-    ZhipUnit* hUnits; uint32_t* hOutSize; ZhipParse* hParse;
+    ZhipUnit* hUnits; uint32_t* hOutSize; ZhipParse* hParse; ZhipSlot* hSlots;
     // last call
     size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
@@ -104,10 +107,10 @@ void zhip_destroy(zhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->dUnits); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
+    (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
-    (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse);
+    (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse); (void)hipHostFree(c->hSlots);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->hcEv) (void)hipEventDestroy(e);
     for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]); if (c->cev[i]) (void)hipEventDestroy(c->cev[i]); }
@@ -115,14 +118,15 @@ void zhip_destroy(zhip_ctx* c)
     delete c;
 }
 
-zhip_ctx* zhip_create(int device, size_t maxUnits)
+static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_t litArena, size_t outArena)
 {
     if (maxUnits == 0) maxUnits = 1;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zhip_ctx* c = new zhip_ctx_s();
-    c->dUnits = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
+    c->dUnits = nullptr; c->dSlots = nullptr; c->hSlots = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
     c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0;
+    c->seqArena = seqArena; c->litArena = litArena; c->outArena = outArena;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
@@ -142,11 +146,13 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
         }
     }
     ok = ok && hipMalloc((void**)&c->dUnits, maxUnits * sizeof(ZhipUnit)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->dSeqs, maxUnits * (size_t)ZHIP_SEQ_CAP * sizeof(ZhipSeq)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dSlots, maxUnits * sizeof(ZhipSlot)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->hSlots, maxUnits * sizeof(ZhipSlot), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dSeqs, seqArena * sizeof(ZhipSeq)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dParse, maxUnits * sizeof(ZhipParse)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->dLits, maxUnits * (size_t)ZHIP_LIT_STRIDE) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->dStBits, maxUnits * (size_t)3 * ZHIP_SEQ_CAP * sizeof(uint16_t)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->dOut, maxUnits * (size_t)ZHIP_OUT_STRIDE) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dLits, litArena) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dStBits, seqArena * 3 * sizeof(uint16_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dOut, outArena) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dOutSize, (maxUnits + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dOutOff, (maxUnits + 1) * sizeof(uint64_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->hUnits, maxUnits * sizeof(ZhipUnit), hipHostMallocDefault) == hipSuccess;
@@ -154,6 +160,24 @@ zhip_ctx* zhip_create(int device, size_t maxUnits)
     ok = ok && hipHostMalloc((void**)&c->hParse, maxUnits * sizeof(ZhipParse), hipHostMallocDefault) == hipSuccess;
     if (!ok) { zhip_destroy(c); return nullptr; }
     return c;
+}
+
+zhip_ctx* zhip_create(int device, size_t maxUnits)
+{
+    if (maxUnits == 0) maxUnits = 1;
+    return create_impl(device, maxUnits, maxUnits * (size_t)ZHIP_SEQ_CAP, maxUnits * (size_t)ZHIP_LIT_STRIDE, maxUnits * (size_t)ZHIP_OUT_STRIDE);
+}
+
+// per-record slot sizes of the packed layout (records path)
+static inline size_t rec_seq_cap(size_t n) { return n / 4 + 8; }
+static inline size_t rec_lit_bytes(size_t n) { return (n + 64 + 15) & ~(size_t)15; }
+static inline size_t rec_out_bytes(size_t n) { return (zhip::host_compress_bound(n) + 32 + 15) & ~(size_t)15; }
+
+zhip_ctx* zhip_create_for_records(int device, size_t maxRecords, size_t maxTotalBytes)
+{
+    if (maxRecords == 0) maxRecords = 1;
+    return create_impl(device, maxRecords, maxTotalBytes / 4 + 8 * maxRecords + 64, maxTotalBytes + 80 * maxRecords + 64,
+                       maxTotalBytes + (maxTotalBytes >> 8) + 128 * maxRecords + 64);
 }
 
 void zhip_last_timing(const zhip_ctx* c, double t[4]) { for (int i = 0; i < 4; i++) t[i] = c->timing[i]; }
@@ -190,6 +214,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         else if (!zhip::host_get_cparams(level, len, &tail)) { *err = ZERR(ZE_parameter_unsupported); return 0; }
         ZhipUnit& u = c->hUnits[i];
         u.srcOff = off; u.srcLen = (uint32_t)len;
+        {   ZhipSlot& sl = c->hSlots[i]; sl.seqOff = i * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = i * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = i * (uint64_t)ZHIP_OUT_STRIDE; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0; }
         u.windowLog = (uint8_t)cp->windowLog; u.chainLog = (uint8_t)cp->chainLog; u.hashLog = (uint8_t)cp->hashLog;
         u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
         u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0;
@@ -238,16 +263,17 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         if (pad > 0) smem += (size_t)pad;
     }
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nUnits * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     if (smem > 64 * 1024 && (c->strategy & 1))
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // one launch per strategy family present; every kernel skips the units of the other families
     if (c->strategy & 2)
         hipLaunchKernelGGL(zhip::k_parse_dfast, dim3((unsigned)nUnits), dim3(64), zhip::dfast_lds_bytes(), s,
-                           srcDev, c->dUnits, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
     if (c->strategy & 1)
         hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
-                           srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     if (c->strategy & 4) {
         uint32_t const bpu = c->hcMaxLen ? (c->hcMaxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS : 1;   // an empty unit still gets a grid
         c->hcEvUsed = 0;
@@ -263,8 +289,8 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                                srcDev, c->dUnits + u0, nu, bpu, c->dTabs, c->tabStride, c->dBest);
             HIPCHK(c, hipEventRecord(he[2], s));
             hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), 0, s,
-                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest,
-                               c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dLits + u0 * ZHIP_LIT_STRIDE, c->dParse + u0);
+                               srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
+                               c->dSeqs, c->dLits, c->dParse + u0);
             HIPCHK(c, hipEventRecord(he[3], s));
         }
     } else c->hcEvUsed = 0;
@@ -279,11 +305,11 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
     static bool attrSet = false;
     if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
     hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
-                       srcDev, c->dUnits, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize);
+                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
-    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
+    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     return 0;
@@ -299,6 +325,7 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
     if (smem > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nUnits * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     size_t const per = (nUnits + c->nChunks - 1) / c->nChunks;
@@ -308,18 +335,18 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
         unsigned const nu = (unsigned)(u1 - u0);
         hipStream_t q = c->cs[i];
         HIPCHK(c, hipStreamWaitEvent(q, c->ev[0], 0));
-        hipLaunchKernelGGL(zhip::k_parse_fast, dim3(nu), dim3(64), smem, q, srcDev, c->dUnits + u0, nu,
-                           c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dLits + u0 * ZHIP_LIT_STRIDE, c->dParse + u0);
+        hipLaunchKernelGGL(zhip::k_parse_fast, dim3(nu), dim3(64), smem, q, srcDev, c->dUnits + u0, c->dSlots + u0, nu,
+                           c->dSeqs, c->dLits, c->dParse + u0);
         hipLaunchKernelGGL(zhip::k_entropy, dim3(nu), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), q,
-                           srcDev, c->dUnits + u0, nu, c->dSeqs + u0 * ZHIP_SEQ_CAP, c->dParse + u0, c->dLits + u0 * ZHIP_LIT_STRIDE,
-                           c->dStBits + u0 * 3 * ZHIP_SEQ_CAP, c->dOut + u0 * ZHIP_OUT_STRIDE, c->dOutSize + u0);
+                           srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dSeqs, c->dParse + u0, c->dLits,
+                           c->dStBits, c->dOut, c->dOutSize + u0);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->cev[i], q));
         HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
-    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
+    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     return 0;
@@ -396,6 +423,155 @@ size_t zhip_compress(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src
     return total;
 }
 
+// ------------------------------------------------------------------ dictionary path (records)
+struct zhip_cdict_s {
+    zhip::HostCDict h;
+    int device;
+    uint8_t* dContent; uint32_t* dTabL; uint32_t* dTabS;
+};
+
+void zhip_free_cdict(zhip_cdict* cd)
+{
+    if (!cd) return;
+    (void)hipSetDevice(cd->device);
+    (void)hipFree(cd->dContent); (void)hipFree(cd->dTabL); (void)hipFree(cd->dTabS);
+    delete cd;
+}
+
+zhip_cdict* zhip_create_cdict(int device, const void* dict, size_t dictSize, int level)
+{
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zhip_cdict* cd = new zhip_cdict_s();
+    cd->device = device; cd->dContent = nullptr; cd->dTabL = nullptr; cd->dTabS = nullptr;
+    if (zhip::host_cdict_build(cd->h, dict, dictSize, level) != 0) { delete cd; return nullptr; }
+    bool ok = hipMalloc((void**)&cd->dContent, cd->h.content.size()) == hipSuccess;
+    ok = ok && hipMalloc((void**)&cd->dTabL, cd->h.tabL.size() * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&cd->dTabS, cd->h.tabS.size() * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(cd->dContent, cd->h.content.data(), cd->h.content.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(cd->dTabL, cd->h.tabL.data(), cd->h.tabL.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(cd->dTabS, cd->h.tabS.data(), cd->h.tabS.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { zhip_free_cdict(cd); return nullptr; }
+    return cd;
+}
+
+size_t zhip_records_bound(const unsigned long long* recOffsets, size_t nRec)
+{
+    size_t b = 0;
+    for (size_t i = 0; i < nRec; i++) b += zhip::host_compress_bound((size_t)(recOffsets[i + 1] - recOffsets[i]));
+    return b;
+}
+
+static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* dstDev, size_t dstCapacity, const void* srcDev,
+                                      const unsigned long long* recOffsets, size_t nRec, uint32_t* frameSizesDev, hipStream_t s)
+{
+    if (nRec == 0) return 0;
+    if (nRec > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu records > context capacity %zu", nRec, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
+    if (dstCapacity < zhip_records_bound(recOffsets, nRec)) return ZERR(ZE_dstSize_tooSmall);
+    uint64_t seqOff = 0, litOff = 0, outOff = 0;
+    uint32_t mhL = 6, mhS = 6, mhFast = 0; int fam = 0;
+    bool const attached = cd->h.len != 0;                // dictionaries below 8 bytes are not attached, their parameters still apply
+    for (size_t i = 0; i < nRec; i++) {
+        size_t const n = (size_t)(recOffsets[i + 1] - recOffsets[i]);
+        zhip::CParams cp;
+        if (n > ZHIP_UNIT_MAX || !zhip::host_cdict_unit_params(cd->h, n, &cp)) {
+            snprintf(c->err, sizeof(c->err), "record %zu (%zu bytes) is above the attach cut-off of this dictionary's strategy: the copy path is not implemented", i, n);
+            return ZERR(ZE_parameter_unsupported);
+        }
+        ZhipUnit& u = c->hUnits[i];
+        u.srcOff = recOffsets[i]; u.srcLen = (uint32_t)n;
+        u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
+        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
+        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength;
+        ZhipSlot& sl = c->hSlots[i];
+        sl.seqOff = seqOff; sl.litOff = litOff; sl.outOff = outOff; sl.seqCap = (uint32_t)rec_seq_cap(n); sl.pad0 = 0;
+        seqOff += rec_seq_cap(n); litOff += rec_lit_bytes(n); outOff += rec_out_bytes(n);
+        if (cp.strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp.hashLog > mhFast) mhFast = cp.hashLog; }
+        else { fam |= 2; if (cp.hashLog > mhL) mhL = cp.hashLog; if (cp.chainLog > mhS) mhS = cp.chainLog; }
+    }
+    if (seqOff > c->seqArena || litOff > c->litArena || outOff > c->outArena) {
+        snprintf(c->err, sizeof(c->err), "records need %llu sequence slots / %llu literal bytes / %llu output bytes: context too small (zhip_create_for_records)",
+                 (unsigned long long)seqOff, (unsigned long long)litOff, (unsigned long long)outOff);
+        return ZERR(ZE_srcSize_wrong);
+    }
+    if (attached && (fam & 1)) { snprintf(c->err, sizeof(c->err), "strategy fast with an attached dictionary is not implemented on device yet"); return ZERR(ZE_parameter_unsupported); }
+    size_t r;
+    if (!attached) {
+        // no dictionary content: the ordinary kernels with the CDict-derived parameters
+        c->strategy = fam; c->tabStride = 0; c->hcMaxLen = 0;
+        if (fam & 2) {
+            size_t w = zhip::dfast_table_bytes(mhL, mhS) >> 2; w = (w + 3) & ~(size_t)3;
+            c->tabStride = w;
+            if (c->tabsCap < nRec * w) {
+                (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->dTabs, nRec * w * sizeof(uint32_t))); c->tabsCap = nRec * w;
+            }
+        }
+        r = launch_parse(c, (const uint8_t*)srcDev, nRec, mhFast, s);
+    } else {
+        zhip::ZhipCDictDev dv;
+        dv.content = cd->dContent; dv.len = (uint32_t)cd->h.len; dv.hashLog = cd->h.cp.hashLog; dv.chainLog = cd->h.cp.chainLog;
+        dv.minMatch = cd->h.cp.minMatch; dv.strategy = cd->h.cp.strategy; dv.tabL = cd->dTabL; dv.tabS = cd->dTabS;
+        dv.rep[0] = cd->h.rep[0]; dv.rep[1] = cd->h.rep[1]; dv.rep[2] = cd->h.rep[2]; dv.dictID = cd->h.dictID;
+        size_t const smem = zhip::dict_lds_bytes(mhL, mhS);
+        HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nRec * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nRec * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
+        if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIPCHK(c, hipEventRecord(c->ev[0], s));
+        hipLaunchKernelGGL(zhip::k_parse_dict, dim3((unsigned)nRec), dim3(64), smem, s,
+                           (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[1], s));
+        c->hcEvUsed = 0;
+        r = 0;
+    }
+    if (zhip_isError(r)) return r;
+    r = launch_entropy_gather(c, (const uint8_t*)srcDev, nRec, (uint8_t*)dstDev, s);
+    if (zhip_isError(r)) return r;
+    if (frameSizesDev) HIPCHK(c, hipMemcpyAsync(frameSizesDev, c->dOutSize, nRec * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->hOutSize, c->dOutSize, nRec * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    uint64_t total = 0;
+    for (size_t i = 0; i < nRec; i++) total += c->hOutSize[i];
+    read_timing(c);
+    c->stats[0] = nRec; c->stats[1] = (unsigned long long)(recOffsets[nRec] - recOffsets[0]); c->stats[2] = total; c->stats[3] = 0; c->stats[4] = 0;
+    c->nUnits = nRec;
+    return (size_t)total;
+}
+
+size_t zhip_compress_records_device(zhip_ctx* c, const zhip_cdict* cd, void* dstDev, size_t dstCapacity, const void* srcDev,
+                                    const unsigned long long* recOffsets, size_t nRec, uint32_t* frameSizesDev, void* stream)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!cd || cd->device != c->device) { snprintf(c->err, sizeof(c->err), "dictionary belongs to another device"); return ZERR(ZE_GENERIC); }
+    return compress_records_locked(c, cd, dstDev, dstCapacity, srcDev, recOffsets, nRec, frameSizesDev, stream ? (hipStream_t)stream : c->stream);
+}
+
+size_t zhip_compress_records(zhip_ctx* c, const zhip_cdict* cd, void* dst, size_t dstCapacity, const void* src,
+                             const unsigned long long* recOffsets, size_t nRec, size_t* frameSizes)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!cd || cd->device != c->device) { snprintf(c->err, sizeof(c->err), "dictionary belongs to another device"); return ZERR(ZE_GENERIC); }
+    if (nRec == 0) return 0;
+    size_t const bound = zhip_records_bound(recOffsets, nRec), srcSize = (size_t)recOffsets[nRec];
+    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    if (c->srcStageCap < srcSize + 64) {
+        (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64;
+    }
+    if (c->dstStageCap < bound + 64) {
+        (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dDstStage, bound + 64)); c->dstStageCap = bound + 64;
+    }
+    if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, src, srcSize, hipMemcpyHostToDevice, c->stream));
+    size_t const total = compress_records_locked(c, cd, c->dDstStage, c->dstStageCap, c->dSrcStage, recOffsets, nRec, nullptr, c->stream);
+    if (zhip_isError(total)) return total;
+    HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
+    if (frameSizes) for (size_t i = 0; i < nRec; i++) frameSizes[i] = c->hOutSize[i];
+    return total;
+}
+
 size_t zhip_parse_device(zhip_ctx* c, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream)
 {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -457,7 +633,7 @@ size_t zhip_get_sequences(zhip_ctx* c, size_t unitIndex, zhip_Sequence* out, siz
     HIPCHK(c, hipSetDevice(c->device));
     ZhipParse const m = c->hParse[unitIndex];
     std::vector<ZhipSeq> tmp(m.nbSeq ? m.nbSeq : 1);
-    if (m.nbSeq) HIPCHK(c, hipMemcpy(tmp.data(), c->dSeqs + unitIndex * (size_t)ZHIP_SEQ_CAP, m.nbSeq * sizeof(ZhipSeq), hipMemcpyDeviceToHost));
+    if (m.nbSeq) HIPCHK(c, hipMemcpy(tmp.data(), c->dSeqs + c->hSlots[unitIndex].seqOff, m.nbSeq * sizeof(ZhipSeq), hipMemcpyDeviceToHost));
     return seqs_to_public(tmp.data(), m, out, capacity);
 }
 
@@ -498,7 +674,7 @@ static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_
     size_t pos = 0;
     for (size_t i = 0; i < nUnits; i++) {
         uint32_t const ns = c->hParse[i].nbSeq;
-        if (ns) HIPCHK(c, hipMemcpyAsync(c->cacheSeqs.data() + pos, c->dSeqs + i * (size_t)ZHIP_SEQ_CAP, ns * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
+        if (ns) HIPCHK(c, hipMemcpyAsync(c->cacheSeqs.data() + pos, c->dSeqs + c->hSlots[i].seqOff, ns * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
         pos += ns;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
