@@ -10,6 +10,9 @@
  *        prints one JSON line.
  *   zref_bench file   <level> <chunkSize> <path> <seconds> <threads>   : same, input read from a file
  *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
+ *   zref_bench dict   <level> <dictPath> <recordsPath> <offsetsPath(u64 LE, nRec+1)> <seconds> <threads>
+ *        one frame per record with ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the `zstd -b# -D dict` /
+ *        contrib/largeNbDicts shape); threads split the records.
  */
 #define ZSTD_STATIC_LINKING_ONLY
 #include <stdio.h>
@@ -50,8 +53,67 @@ static void* worker(void* p)
 
 static const char* g_file = NULL;
 
+typedef struct { const ZSTD_CDict* cd; const char* src; const unsigned long long* offs; size_t r0, r1; char* dst; size_t dstCap; size_t csize; int err; } djob_t;
+static void* dworker(void* p)
+{
+    djob_t* j = (djob_t*)p;
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, k;
+    ZSTD_CCtx_refCDict(c, j->cd);
+    for (k = j->r0; k < j->r1; k++) {
+        size_t const r = ZSTD_compress2(c, j->dst + pos, j->dstCap - pos, j->src + j->offs[k], (size_t)(j->offs[k + 1] - j->offs[k]));
+        if (ZSTD_isError(r)) { j->err = 1; break; }
+        pos += r;
+    }
+    j->csize = pos;
+    ZSTD_freeCCtx(c);
+    return NULL;
+}
+static void* slurp(const char* path, size_t* n)
+{
+    FILE* f = fopen(path, "rb"); long sz; void* b;
+    if (!f) { perror(path); exit(1); }
+    fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET);
+    b = malloc((size_t)sz + 16);
+    if (!b || fread(b, 1, (size_t)sz, f) != (size_t)sz) exit(1);
+    fclose(f); *n = (size_t)sz;
+    return b;
+}
+static int dict_main(char** argv)
+{
+    int const level = atoi(argv[2]);
+    size_t dn, rn, on; double const seconds = atof(argv[6]); int const T = atoi(argv[7]) > 0 ? atoi(argv[7]) : 1;
+    void* dict = slurp(argv[3], &dn); char* src = (char*)slurp(argv[4], &rn);
+    unsigned long long* offs = (unsigned long long*)slurp(argv[5], &on);
+    size_t const nRec = on / 8 - 1;
+    ZSTD_CDict* cd = ZSTD_createCDict(dict, dn, level);
+    size_t const cap = rn + rn / 128 + 128 * nRec + 1024;
+    char* dst = (char*)malloc(cap);
+    djob_t* jobs = (djob_t*)calloc((size_t)T, sizeof(djob_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    double best = 1e30, t0 = now_s(); size_t csize = 0; int runs = 0, t;
+    if (!cd || !dst) return 1;
+    do {
+        double const a = now_s(); size_t c0 = 0;
+        for (t = 0; t < T; t++) {
+            size_t const r0 = nRec * (size_t)t / (size_t)T, r1 = nRec * (size_t)(t + 1) / (size_t)T;
+            size_t const b0 = (size_t)offs[r0] + (size_t)offs[r0] / 128 + 128 * r0;
+            jobs[t].cd = cd; jobs[t].src = src; jobs[t].offs = offs; jobs[t].r0 = r0; jobs[t].r1 = r1;
+            jobs[t].dst = dst + b0; jobs[t].dstCap = cap - b0;
+            if (T == 1) dworker(&jobs[t]); else pthread_create(&th[t], NULL, dworker, &jobs[t]);
+        }
+        for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; c0 += jobs[t].csize; }
+        {   double const d = now_s() - a; if (d < best) best = d; }
+        csize = c0; runs++;
+    } while (now_s() - t0 < seconds);
+    printf("{\"level\": %d, \"records\": %zu, \"bytes\": %zu, \"csize\": %zu, \"ratio\": %.4f, \"best_s\": %.6f, \"MBps\": %.2f, \"runs\": %d, \"threads\": %d}\n",
+           level, nRec, rn, csize, (double)rn / (double)csize, best, (double)rn / best / 1e6, runs, T);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
     if (argc >= 5 && !strcmp(argv[1], "stream")) {
         RDG_genStdout(strtoull(argv[2], 0, 10), atof(argv[3]) / 100.0, 0.0, (unsigned)atoi(argv[4]));
         return 0;
