@@ -26,6 +26,7 @@
 #include "hist.h"
 #include "huf.h"
 #include "fse.h"
+#include "zdict.h"
 
 static void set_level(ZSTD_CCtx* c, int level)
 {
@@ -140,6 +141,13 @@ size_t zref_decompress_dict(void* dst, size_t cap, const void* src, size_t n, co
     size_t const r = ZSTD_decompress_usingDict(d, dst, cap, src, n, dict, dictSize);
     ZSTD_freeDCtx(d);
     return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
+/* ZDICT_trainFromBuffer (lib/zdict.h:210): the dictionary `zstd --train` builds; returns its size or (size_t)-1 */
+size_t zref_train_dict(void* dictBuf, size_t dictCap, const void* samples, const size_t* sampleSizes, unsigned nbSamples)
+{
+    size_t const r = ZDICT_trainFromBuffer(dictBuf, dictCap, samples, sampleSizes, nbSamples);
+    return ZDICT_isError(r) ? (size_t)-1 : r;
 }
 
 /* whole buffer as ONE frame (the conventional `zstd -b#` figure; NOT the parity target) */

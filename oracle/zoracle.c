@@ -446,342 +446,6 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
     return n - anchor;
 }
 
-/* ================================================================== dictionary (CDict, attach mode) ==================
- * SURVEY.md §3.4 / §8 rows a7, a9, a11.  A CDict holds the dictionary content, its own tagged hash tables
- * ("short cache": index << 8 | 8-bit tag, zstd_compress_internal.h:1399-1417) built with the CDict's own parameters,
- * and the block state the first block starts from (repcodes; entropy tables for ZDICT-format dictionaries).
- * Index spaces follow the reference: dictionary byte j has index j + 2 (ZSTD_WINDOW_START_INDEX), the attached working
- * context continues at prefixStart = dictLen + 2 (zstd_compress.c:2352-2362), so dictIndexDelta is 0. */
-struct zo_cdict_s {
-    uint8_t* content; size_t len;          /* dictionary content (what matches may reference) */
-    zo_cparams cp;                         /* CDict parameters (ZSTD_cpm_createCDict) */
-    uint32_t* tabL; uint32_t* tabS;        /* fast: tabL only (hashLog); dfast: long (hashLog) + short (chainLog) */
-    uint32_t dictID; uint32_t rep[3];
-    int level;
-};
-
-static void zo_put_tagged(uint32_t* t, uint32_t hashAndTag, uint32_t index)     /* internal.h:1404 ZSTD_writeTaggedIndex */
-{
-    t[hashAndTag >> 8] = (index << 8) | (hashAndTag & 0xFF);
-}
-
-/* zstd_fast.c:16-49 ZSTD_fillHashTableForCDict / zstd_double_fast.c:18-54 ZSTD_fillDoubleHashTableForCDict (dtlm_full) */
-static void zo_cdict_fill(zo_cdict* cd)
-{
-    const uint8_t* const base = cd->content - 2;              /* index -> byte */
-    size_t const endIdx = cd->len + 2;
-    unsigned const mls = cd->cp.minMatch;
-    size_t ip, first = 2;
-    {   /* zstd_compress.c:4888-4896: a dictionary larger than the tables can reasonably index only has its SUFFIX indexed
-         * (all of it stays referenceable) */
-        unsigned const m = cd->cp.hashLog > cd->cp.chainLog ? cd->cp.hashLog : cd->cp.chainLog;
-        size_t const maxDictSize = (size_t)8 << (m < 28 ? m : 28);
-        if (cd->len > maxDictSize) first = 2 + (cd->len - maxDictSize);
-    }
-    if (endIdx - first <= 8) return;                          /* :4903 srcSize <= HASH_READ_SIZE */
-    if (cd->cp.strategy == 1) {
-        unsigned const hb = cd->cp.hashLog + 8;
-        for (ip = first; ip + 3 < (endIdx - 8) + 2; ip += 3) {    /* :37 ip + step < iend + 2 */
-            unsigned p;
-            zo_put_tagged(cd->tabL, zo_hash(base + ip, hb, mls), (uint32_t)ip);
-            for (p = 1; p < 3; p++) {
-                uint32_t const ht = zo_hash(base + ip + p, hb, mls);
-                if (cd->tabL[ht >> 8] == 0) zo_put_tagged(cd->tabL, ht, (uint32_t)(ip + p));
-            }
-        }
-    } else {
-        unsigned const hbL = cd->cp.hashLog + 8, hbS = cd->cp.chainLog + 8;
-        for (ip = first; ip + 3 - 1 <= endIdx - 8; ip += 3) { /* :36 */
-            unsigned i;
-            for (i = 0; i < 3; i++) {
-                uint32_t const sm = zo_hash(base + ip + i, hbS, mls), lg = zo_hash(base + ip + i, hbL, 8);
-                if (i == 0) zo_put_tagged(cd->tabS, sm, (uint32_t)(ip + i));
-                if (i == 0 || cd->tabL[lg >> 8] == 0) zo_put_tagged(cd->tabL, lg, (uint32_t)(ip + i));
-            }
-        }
-    }
-}
-
-void zo_cdict_free(zo_cdict* cd)
-{
-    if (!cd) return;
-    free(cd->content ? cd->content - 16 : NULL); free(cd->tabL); free(cd->tabS); free(cd);
-}
-
-/* ZSTD_createCDict (zstd_compress.c:5648): parameters for (level, unknown source, dictSize) in createCDict mode,
- * raw-content dictionaries (no ZDICT magic: zstd_compress.c:5138-5148) — repcodes {1,4,8}, no entropy tables, dictID 0 */
-zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
-{
-    zo_cdict* cd = (zo_cdict*)calloc(1, sizeof(zo_cdict));
-    uint8_t* buf;
-    if (!cd) return NULL;
-    if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 2) { free(cd); return NULL; }
-    cd->level = level == 0 ? 3 : level;
-    if (dictSize >= 4 && rd32((const uint8_t*)dict) == 0xEC30A437U) { free(cd); return NULL; }   /* ZDICT format: not restated yet */
-    if (dictSize < 8) dictSize = 0;                           /* :5130 dictionaries below 8 bytes are ignored */
-    buf = (uint8_t*)calloc(dictSize + 64, 1);
-    cd->content = buf + 16; cd->len = dictSize;
-    memcpy(cd->content, dict, dictSize);
-    cd->tabL = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t));
-    cd->tabS = (uint32_t*)calloc((size_t)1 << cd->cp.chainLog, sizeof(uint32_t));
-    cd->dictID = 0; cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
-    zo_cdict_fill(cd);
-    return cd;
-}
-
-/* zstd_compress_internal.h:797 ZSTD_count_2segments: the match may run off the end of the dictionary into the source */
-static size_t zo_count_2seg(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd, const uint8_t* mEnd, const uint8_t* iStart)
-{
-    const uint8_t* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
-    size_t k = 0;
-    while (ip + k < vEnd && ip[k] == match[k]) k++;
-    if (match + k != mEnd) return k;
-    {   size_t j = 0;
-        while (ip + k + j < iEnd && ip[k + j] == iStart[j]) j++;
-        return k + j;
-    }
-}
-static size_t zo_count_ptr(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd)
-{
-    size_t k = 0;
-    while (ip + k < iEnd && ip[k] == match[k]) k++;
-    return k;
-}
-
-/* zstd_double_fast.c:328-547 ZSTD_compressBlock_doubleFast_dictMatchState_generic */
-static size_t zo_dfast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
-{
-    unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
-    unsigned const dHBitsL = cd->cp.hashLog + 8, dHBitsS = cd->cp.chainLog + 8;
-    uint32_t* const hashLong = (uint32_t*)calloc((size_t)1 << hBitsL, sizeof(uint32_t));
-    uint32_t* const hashSmall = (uint32_t*)calloc((size_t)1 << hBitsS, sizeof(uint32_t));
-    uint32_t const P = (uint32_t)cd->len + 2;                  /* prefixLowestIndex */
-    const uint8_t* const base = src - P;                       /* index -> source byte (index >= P) */
-    const uint8_t* const dictBase = cd->content - 2;           /* index -> dictionary byte (index < P) */
-    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
-    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixLowest = src;
-    const uint8_t* ip = istart, * anchor = istart;
-    uint32_t offset_1 = rep[0], offset_2 = rep[1];
-#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(litLen), (offBase), (uint32_t)(ml))
-    while (ip < ilimit) {
-        size_t mLength; uint32_t offset;
-        uint32_t const h2 = zo_hash(ip, hBitsL, 8), h = zo_hash(ip, hBitsS, mls);
-        uint32_t const dL = zo_hash(ip, dHBitsL, 8), dS = zo_hash(ip, dHBitsS, mls);
-        uint32_t const dEntL = cd->tabL[dL >> 8], dEntS = cd->tabS[dS >> 8];
-        int const tagL = (dEntL & 0xFF) == (dL & 0xFF), tagS = (dEntS & 0xFF) == (dS & 0xFF);
-        uint32_t const curr = (uint32_t)(ip - base);
-        uint32_t const matchIndexL = hashLong[h2];
-        uint32_t matchIndexS = hashSmall[h];
-        const uint8_t* matchLong = base + matchIndexL;
-        const uint8_t* match = base + matchIndexS;
-        uint32_t const repIndex = curr + 1 - offset_1;
-        const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
-        hashLong[h2] = hashSmall[h] = curr;
-        if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip + 1)) {        /* :398 ZSTD_index_overlap_check */
-            const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
-            mLength = zo_count_2seg(ip + 1 + 4, repMatch + 4, iend, repEnd, prefixLowest) + 4;
-            ip++;
-            SEQ(ip - anchor, 1, mLength);
-            goto _match_stored;
-        }
-        if (matchIndexL >= P && rd64(matchLong) == rd64(ip)) {                                /* :407 */
-            mLength = zo_count_ptr(ip + 8, matchLong + 8, iend) + 8;
-            offset = (uint32_t)(ip - matchLong);
-            while (ip > anchor && matchLong > prefixLowest && ip[-1] == matchLong[-1]) { ip--; matchLong--; mLength++; }
-            goto _match_found;
-        } else if (tagL) {                                                                    /* :413 */
-            uint32_t const dIdx = dEntL >> 8;
-            const uint8_t* dm = dictBase + dIdx;
-            if (dm > dictStart && rd64(dm) == rd64(ip)) {
-                mLength = zo_count_2seg(ip + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
-                offset = curr - dIdx;
-                while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
-                goto _match_found;
-            }
-        }
-        if (matchIndexS > P) {                                                                /* :427 */
-            if (rd32(match) == rd32(ip)) goto _search_next_long;
-        } else if (tagS) {
-            uint32_t const dIdx = dEntS >> 8;
-            match = dictBase + dIdx;
-            matchIndexS = dIdx;
-            if (match > dictStart && rd32(match) == rd32(ip)) goto _search_next_long;
-        }
-        ip += ((ip - anchor) >> 8) + 1;                                                      /* :443 */
-        continue;
-_search_next_long:
-        {   uint32_t const hl3 = zo_hash(ip + 1, hBitsL, 8), dL3 = zo_hash(ip + 1, dHBitsL, 8);
-            uint32_t const matchIndexL3 = hashLong[hl3], dEntL3 = cd->tabL[dL3 >> 8];
-            int const tagL3 = (dEntL3 & 0xFF) == (dL3 & 0xFF);
-            const uint8_t* matchL3 = base + matchIndexL3;
-            hashLong[hl3] = curr + 1;
-            if (matchIndexL3 >= P && rd64(matchL3) == rd64(ip + 1)) {                         /* :459 */
-                mLength = zo_count_ptr(ip + 9, matchL3 + 8, iend) + 8;
-                ip++;
-                offset = (uint32_t)(ip - matchL3);
-                while (ip > anchor && matchL3 > prefixLowest && ip[-1] == matchL3[-1]) { ip--; matchL3--; mLength++; }
-                goto _match_found;
-            } else if (tagL3) {
-                uint32_t const dIdx = dEntL3 >> 8;
-                const uint8_t* dm = dictBase + dIdx;
-                if (dm > dictStart && rd64(dm) == rd64(ip + 1)) {
-                    mLength = zo_count_2seg(ip + 1 + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
-                    ip++;
-                    offset = curr + 1 - dIdx;
-                    while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
-                    goto _match_found;
-                }
-            }
-        }
-        if (matchIndexS < P) {                                                                /* :481 */
-            mLength = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, prefixLowest) + 4;
-            offset = curr - matchIndexS;
-            while (ip > anchor && match > dictStart && ip[-1] == match[-1]) { ip--; match--; mLength++; }
-        } else {
-            mLength = zo_count_ptr(ip + 4, match + 4, iend) + 4;
-            offset = (uint32_t)(ip - match);
-            while (ip > anchor && match > prefixLowest && ip[-1] == match[-1]) { ip--; match--; mLength++; }
-        }
-_match_found:
-        offset_2 = offset_1; offset_1 = offset;
-        SEQ(ip - anchor, offset + 3, mLength);
-_match_stored:
-        ip += mLength; anchor = ip;
-        if (ip <= ilimit) {                                                                   /* :503 */
-            uint32_t const ins = curr + 2;
-            hashLong[zo_hash(base + ins, hBitsL, 8)] = ins;
-            hashLong[zo_hash(ip - 2, hBitsL, 8)] = (uint32_t)(ip - 2 - base);
-            hashSmall[zo_hash(base + ins, hBitsS, mls)] = ins;
-            hashSmall[zo_hash(ip - 1, hBitsS, mls)] = (uint32_t)(ip - 1 - base);
-            while (ip <= ilimit) {                                                            /* :514 */
-                uint32_t const current2 = (uint32_t)(ip - base), repIndex2 = current2 - offset_2;
-                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
-                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip)) {
-                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
-                    size_t const rl = zo_count_2seg(ip + 4, repMatch2 + 4, iend, repEnd2, prefixLowest) + 4;
-                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
-                    SEQ(0, 1, rl);
-                    hashSmall[zo_hash(ip, hBitsS, mls)] = current2;
-                    hashLong[zo_hash(ip, hBitsL, 8)] = current2;
-                    ip += rl; anchor = ip;
-                    continue;
-                }
-                break;
-            }
-        }
-    }
-    rep[0] = offset_1; rep[1] = offset_2;
-    free(hashLong); free(hashSmall);
-    return (size_t)(iend - anchor);
-}
-
-/* zstd_fast.c:483-678 ZSTD_compressBlock_fast_dictMatchState_generic */
-static size_t zo_fast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
-{
-    unsigned const hlog = cp->hashLog, mls = cp->minMatch, dHBits = cd->cp.hashLog + 8;
-    size_t const stepSize = cp->targetLength + !cp->targetLength;
-    uint32_t* const hashTable = (uint32_t*)calloc((size_t)1 << hlog, sizeof(uint32_t));
-    uint32_t const P = (uint32_t)cd->len + 2;
-    const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
-    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
-    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
-    const uint8_t* ip0 = istart, * ip1 = ip0 + stepSize, * anchor = istart;
-    uint32_t offset_1 = rep[0], offset_2 = rep[1];
-    while (ip1 <= ilimit) {
-        size_t mLength;
-        uint32_t hash0 = zo_hash(ip0, hlog, mls);
-        uint32_t dHT0 = zo_hash(ip0, dHBits, mls);
-        uint32_t dEnt = cd->tabL[dHT0 >> 8];
-        int dTags = (dEnt & 0xFF) == (dHT0 & 0xFF);
-        uint32_t matchIndex = hashTable[hash0];
-        uint32_t curr = (uint32_t)(ip0 - base);
-        size_t step = stepSize;
-        const uint8_t* nextStep = ip0 + 256;
-        for (;;) {
-            const uint8_t* match = base + matchIndex;
-            uint32_t const repIndex = curr + 1 - offset_1;
-            const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
-            uint32_t const hash1 = zo_hash(ip1, hlog, mls), dHT1 = zo_hash(ip1, dHBits, mls);
-            hashTable[hash0] = curr;
-            if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip0 + 1)) {   /* :566 */
-                const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
-                mLength = zo_count_2seg(ip0 + 1 + 4, repMatch + 4, iend, repEnd, prefixStart) + 4;
-                ip0++;
-                SEQ(ip0 - anchor, 1, mLength);
-                break;
-            }
-            if (dTags) {                                                                      /* :575 */
-                uint32_t const dIdx = dEnt >> 8;
-                const uint8_t* dm = dictBase + dIdx;
-                if (dIdx > 2 && rd32(dm) == rd32(ip0) && matchIndex <= P) {
-                    uint32_t const offset = curr - dIdx;
-                    mLength = zo_count_2seg(ip0 + 4, dm + 4, iend, dictEnd, prefixStart) + 4;
-                    while (ip0 > anchor && dm > dictStart && ip0[-1] == dm[-1]) { ip0--; dm--; mLength++; }
-                    offset_2 = offset_1; offset_1 = offset;
-                    SEQ(ip0 - anchor, offset + 3, mLength);
-                    break;
-                }
-            }
-            if (matchIndex >= P && rd32(ip0) == rd32(match)) {                                /* :598 ZSTD_match4Found_cmov */
-                uint32_t const offset = (uint32_t)(ip0 - match);
-                mLength = zo_count_ptr(ip0 + 4, match + 4, iend) + 4;
-                while (ip0 > anchor && match > prefixStart && ip0[-1] == match[-1]) { ip0--; match--; mLength++; }
-                offset_2 = offset_1; offset_1 = offset;
-                SEQ(ip0 - anchor, offset + 3, mLength);
-                break;
-            }
-            dEnt = cd->tabL[dHT1 >> 8];                                                       /* :614 */
-            dTags = (dEnt & 0xFF) == (dHT1 & 0xFF);
-            matchIndex = hashTable[hash1];
-            if (ip1 >= nextStep) { step++; nextStep += 256; }
-            ip0 = ip1; ip1 = ip1 + step;
-            if (ip1 > ilimit) goto _cleanup;
-            curr = (uint32_t)(ip0 - base);
-            hash0 = hash1;
-        }
-        ip0 += mLength; anchor = ip0;                                                         /* :631 */
-        if (ip0 <= ilimit) {
-            hashTable[zo_hash(base + curr + 2, hlog, mls)] = curr + 2;
-            hashTable[zo_hash(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
-            while (ip0 <= ilimit) {
-                uint32_t const current2 = (uint32_t)(ip0 - base), repIndex2 = current2 - offset_2;
-                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
-                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip0)) {
-                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
-                    size_t const rl = zo_count_2seg(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
-                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
-                    SEQ(0, 1, rl);
-                    hashTable[zo_hash(ip0, hlog, mls)] = current2;
-                    ip0 += rl; anchor = ip0;
-                    continue;
-                }
-                break;
-            }
-        }
-        ip1 = ip0 + stepSize;
-    }
-_cleanup:
-    rep[0] = offset_1; rep[1] = offset_2;
-    free(hashTable);
-    return (size_t)(iend - anchor);
-}
-#undef SEQ
-
-/* working-context parameters for a source of n bytes compressed with `cd` attached, or -1 if the reference would copy the
- * dictionary instead (zstd_compress.c:2289-2315) — only the attach path is restated */
-int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
-{
-    static const size_t cutoff[6] = { 8192, 8192, 16384, 32768, 32768, 32768 };
-    zo_cparams p, w;
-    if (n > cutoff[cd->cp.strategy]) return -1;
-    if (zo_get_cparams_mode(cd->level, n, cd->len, 1, &p) < 0) return -1;        /* :6289-6292 requested params, attach mode */
-    w = cd->cp;                                                                  /* :2331-2335 */
-    zo_adjust_cparams(&w, n, cd->len, 1);
-    w.windowLog = p.windowLog;
-    *out = w;
-    return 0;
-}
-
 /* zstd_compress.c:3207-3369 ZSTD_buildSeqStore for a history-less block (+ :3365 trailing literals) */
 size_t zo_parse_block(const zo_cparams* cp, const uint8_t* src, size_t n,
                       zo_seq* seqs, size_t cap, uint8_t* lits, size_t* litSize, uint32_t repOut[3])
@@ -1328,6 +992,146 @@ static size_t huf_compress(uint8_t* dst, const uint8_t* src, size_t n, int fourS
     return (size_t)(op - dst);
 }
 
+/* ------------------------------------------------------------------ previous-block entropy state (dictionaries)
+ * What a ZDICT-format dictionary puts into the CDict's block state (zstd_compress.c:4986-5076 ZSTD_loadCEntropy): a Huffman
+ * table for literals, FSE tables for offset / match-length / literal-length codes, each with a repeat mode (1 = "check":
+ * usable only if it covers the block's symbols, 2 = "valid": covers every symbol). */
+typedef struct {
+    int hufRepeat; unsigned hufMaxSym; uint8_t hufNbBits[256]; uint16_t hufValue[256];
+    int llRepeat, ofRepeat, mlRepeat;
+    zo_fse ll, of, ml;
+} zo_prev;
+
+/* LSB-first forward bit reader for headers */
+typedef struct { const uint8_t* p; size_t size; size_t bit; } zo_fbits;
+static uint32_t fb_peek(const zo_fbits* b, unsigned n)
+{
+    uint64_t v = 0; size_t const byte = b->bit >> 3; unsigned i;
+    for (i = 0; i < 8; i++) if (byte + i < b->size) v |= (uint64_t)b->p[byte + i] << (8 * i);
+    return (uint32_t)((v >> (b->bit & 7)) & ((1ULL << n) - 1));
+}
+/* lib/common/entropy_common.c:42-214 FSE_readNCount (format: doc/zstd_compression_format.md "FSE Table Description").
+ * returns bytes consumed, 0 on error */
+static size_t fse_read_ncount(short* norm, unsigned* maxSym, unsigned* tableLog, const uint8_t* src, size_t size)
+{
+    zo_fbits b; int remaining, threshold, nbBits; unsigned charnum = 0, maxSV1 = *maxSym + 1; int previous0 = 0;
+    b.p = src; b.size = size; b.bit = 0;
+    memset(norm, 0, sizeof(short) * maxSV1);
+    nbBits = (int)fb_peek(&b, 4) + 5; b.bit += 4;
+    if (nbBits > 15) return 0;
+    *tableLog = (unsigned)nbBits;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    while (remaining > 1 && charnum < maxSV1) {
+        if (previous0) {
+            for (;;) { uint32_t const r = fb_peek(&b, 2); b.bit += 2; charnum += r; if (r != 3) break; }
+            if (charnum >= maxSV1) break;
+        }
+        {   int const max = (2 * threshold - 1) - remaining;
+            uint32_t const bits = fb_peek(&b, (unsigned)nbBits);
+            int count;
+            if ((int)(bits & (uint32_t)(threshold - 1)) < max) { count = (int)(bits & (uint32_t)(threshold - 1)); b.bit += (size_t)nbBits - 1; }
+            else { count = (int)(bits & (uint32_t)(2 * threshold - 1)); if (count >= threshold) count -= max; b.bit += (size_t)nbBits; }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            norm[charnum++] = (short)count;
+            previous0 = !count;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+    }
+    if (remaining != 1 || charnum > maxSV1) return 0;
+    *maxSym = charnum - 1;
+    return (b.bit + 7) >> 3;
+}
+
+/* nb bits of a backward bitstream whose lowest bit sits at position `at` (positions below 0 read as 0) */
+static unsigned bs_bits(const uint8_t* bs, long at, unsigned nb)
+{
+    unsigned v = 0, k;
+    for (k = 0; k < nb; k++) { long const q = at + (long)k; if (q >= 0 && ((bs[q >> 3] >> (q & 7)) & 1)) v |= 1u << k; }
+    return v;
+}
+
+/* FSE decoding of Huffman weights (lib/common/fse_decompress.c:58-277; format doc "FSE Decoding"): dst receives at most cap
+ * symbols; returns their number, 0 on error.  The bitstream is read backwards from its end mark. */
+static size_t fse_decompress_weights(uint8_t* dst, size_t cap, const uint8_t* src, size_t size)
+{
+    short norm[256]; unsigned maxSym = 255, tl; size_t const h = fse_read_ncount(norm, &maxSym, &tl, src, size);
+    uint8_t symT[64]; uint8_t nbT[64]; uint16_t newT[64]; unsigned next[256];
+    if (!h || tl > 6 || h >= size) return 0;
+    {   unsigned const tsz = 1u << tl, mask = tsz - 1, step = (tsz >> 1) + (tsz >> 3) + 3; unsigned high = tsz - 1, pos = 0, sy, u;
+        for (sy = 0; sy <= maxSym; sy++) { if (norm[sy] == -1) { symT[high--] = (uint8_t)sy; next[sy] = 1; } else next[sy] = (unsigned)norm[sy]; }
+        for (sy = 0; sy <= maxSym; sy++) { int i; for (i = 0; i < norm[sy]; i++) { symT[pos] = (uint8_t)sy; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; } }
+        if (pos != 0) return 0;
+        for (u = 0; u < tsz; u++) { unsigned const ns = next[symT[u]]++; nbT[u] = (uint8_t)(tl - hb32(ns)); newT[u] = (uint16_t)((ns << nbT[u]) - tsz); }
+    }
+    {   const uint8_t* const bs = src + h; size_t const bsz = size - h;
+        long cursor; size_t n = 0; unsigned s1, s2; int which = 0;
+        if (bs[bsz - 1] == 0) return 0;
+        cursor = (long)(8 * (bsz - 1) + hb32(bs[bsz - 1]));                       /* position of the end mark; bits below it are data */
+        cursor -= (long)tl; s1 = bs_bits(bs, cursor, tl);
+        cursor -= (long)tl; s2 = bs_bits(bs, cursor, tl);
+        for (;;) {
+            unsigned* const st = which ? &s2 : &s1; unsigned const other = which ? s1 : s2;
+            unsigned const nb = nbT[*st];
+            if (n + 2 > cap) return 0;
+            dst[n++] = symT[*st];
+            cursor -= (long)nb;
+            *st = newT[*st] + bs_bits(bs, cursor, nb);
+            if (cursor < 0) { dst[n++] = symT[other]; break; }                   /* BIT_DStream_overflow: the other state holds the last symbol */
+            which ^= 1;
+        }
+        return n;
+    }
+}
+
+/* huf_compress.c:291-339 HUF_readCTable + entropy_common.c:248-320 HUF_readStats: table description -> code lengths/values.
+ * returns bytes consumed (0 on error) */
+static size_t huf_read_table(zo_prev* pv, const uint8_t* src, size_t size)
+{
+    uint8_t w[256]; unsigned rank[16], nbSym, tableLog, n; size_t iSize, oSize; uint32_t total = 0;
+    if (!size) return 0;
+    iSize = src[0];
+    if (iSize >= 128) {
+        oSize = iSize - 127; iSize = (oSize + 1) / 2;
+        if (iSize + 1 > size || oSize >= 256) return 0;
+        for (n = 0; n < oSize; n += 2) { w[n] = src[1 + n / 2] >> 4; w[n + 1] = src[1 + n / 2] & 15; }
+    } else {
+        if (iSize + 1 > size) return 0;
+        oSize = fse_decompress_weights(w, 255, src + 1, iSize);
+        if (!oSize) return 0;
+    }
+    memset(rank, 0, sizeof(rank));
+    for (n = 0; n < oSize; n++) { if (w[n] > 12) return 0; rank[w[n]]++; total += (1u << w[n]) >> 1; }
+    if (!total) return 0;
+    tableLog = hb32(total) + 1;
+    if (tableLog > 12) return 0;
+    {   uint32_t const rest = (1u << tableLog) - total; unsigned const last = hb32(rest) + 1;
+        if ((1u << hb32(rest)) != rest) return 0;
+        w[oSize] = (uint8_t)last; rank[last]++;
+    }
+    if (rank[1] < 2 || (rank[1] & 1)) return 0;
+    nbSym = (unsigned)oSize + 1;
+    pv->hufMaxSym = nbSym - 1;
+    pv->hufRepeat = (rank[0] == 0 && nbSym == 256) ? 2 : 1;                     /* zstd_compress.c:5002-5006 */
+    memset(pv->hufNbBits, 0, 256); memset(pv->hufValue, 0, sizeof(pv->hufValue));
+    for (n = 0; n < nbSym; n++) pv->hufNbBits[n] = w[n] ? (uint8_t)(tableLog + 1 - w[n]) : 0;
+    {   uint16_t nbPerRank[16] = {0}, valPerRank[16] = {0}; uint16_t min = 0;
+        for (n = 0; n < nbSym; n++) nbPerRank[pv->hufNbBits[n]]++;
+        for (n = tableLog; n > 0; n--) { valPerRank[n] = min; min = (uint16_t)(min + nbPerRank[n]); min >>= 1; }
+        for (n = 0; n < nbSym; n++) pv->hufValue[n] = pv->hufNbBits[n] ? valPerRank[pv->hufNbBits[n]]++ : 0;
+    }
+    return iSize + 1;
+}
+
+/* zstd_compress.c:4966-4981 ZSTD_dictNCountRepeat */
+static int dict_ncount_repeat(const short* norm, unsigned dictMax, unsigned maxSym)
+{
+    unsigned s;
+    if (dictMax < maxSym) return 1;
+    for (s = 0; s <= maxSym; s++) if (norm[s] == 0) return 1;
+    return 2;
+}
+
 /* zstd_compress_literals.c:39 / :81 */
 static size_t lits_raw(uint8_t* dst, const uint8_t* src, size_t n)
 {
@@ -1349,25 +1153,94 @@ static size_t lits_rle(uint8_t* dst, const uint8_t* src, size_t n)
 }
 
 /* zstd_compress_literals.c:129-235 with prevHuf->repeatMode == HUF_repeat_none */
-size_t zo_compress_literals(uint8_t* dst, size_t cap, const uint8_t* lits, size_t n, const zo_cparams* cp, int suspect)
+/* huf_compress.c:1224-1239 HUF_compressCTable_internal with a given code */
+static size_t huf_encode_with(uint8_t* dst0, uint8_t* op, const uint8_t* src, size_t n, int fourStreams, const uint8_t* nbBits, const uint16_t* value)
+{
+    size_t const c = fourStreams ? huf_encode_4x(op, src, n, nbBits, value) : huf_encode_1x(op, src, n, nbBits, value);
+    if (c == 0) return 0;
+    op += c;
+    if ((size_t)(op - dst0) >= n - 1) return 0;
+    return (size_t)(op - dst0);
+}
+
+/* huf_compress.c:1333-1434 HUF_compress_internal WITH a previous table (*repeat: 0 none, 1 check, 2 valid; set to 0 when a new
+ * table is emitted) */
+static size_t huf_compress_prev(uint8_t* dst, const uint8_t* src, size_t n, int fourStreams, int suspect,
+                                const zo_prev* pv, int* repeat, int preferRepeat)
+{
+    unsigned count[256], maxSym = 255, huffLog, sy; uint8_t nbBits[256]; uint16_t value[256];
+    uint8_t* op = dst;
+    if (!n) return 0;
+    if (preferRepeat && *repeat == 2) return huf_encode_with(dst, op, src, n, fourStreams, pv->hufNbBits, pv->hufValue);   /* :1359-1363 */
+    if (suspect && n >= 4096 * 10) {
+        unsigned c2[256], m2; size_t tot;
+        tot = zo_hist(c2, &m2, src, 4096);
+        tot += zo_hist(c2, &m2, src + n - 4096, 4096);
+        if (tot <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    {   size_t const largest = zo_hist(count, &maxSym, src, n);
+        if (largest == n) { dst[0] = src[0]; return 1; }
+        if (largest <= (n >> 7) + 4) return 0;
+    }
+    if (*repeat == 1) {                                                          /* :1389-1393 HUF_validateCTable (:860-873) */
+        int bad = pv->hufMaxSym < maxSym;
+        for (sy = 0; sy <= maxSym && !bad; sy++) bad |= (count[sy] != 0) & (pv->hufNbBits[sy] == 0);
+        if (bad) *repeat = 0;
+    }
+    if (preferRepeat && *repeat != 0) return huf_encode_with(dst, op, src, n, fourStreams, pv->hufNbBits, pv->hufValue);   /* :1395-1399 */
+    huffLog = fse_optimal_log(11, n, maxSym, 1);
+    huffLog = huf_build_full(count, maxSym, huffLog, nbBits, value);
+    {   size_t const h = huf_write_table(op, nbBits, maxSym, huffLog);
+        if (!h) return ZO_ERROR;
+        if (*repeat != 0) {                                                      /* :1415-1421 */
+            size_t oldSize = 0, newSize = 0;
+            for (sy = 0; sy <= maxSym; sy++) { oldSize += (size_t)pv->hufNbBits[sy] * count[sy]; newSize += (size_t)nbBits[sy] * count[sy]; }
+            oldSize >>= 3; newSize >>= 3;
+            if (oldSize <= h + newSize || h + 12 >= n) return huf_encode_with(dst, op, src, n, fourStreams, pv->hufNbBits, pv->hufValue);
+        }
+        if (h + 12 >= n) return 0;
+        op += h;
+        *repeat = 0;
+    }
+    return huf_encode_with(dst, op, src, n, fourStreams, nbBits, value);
+}
+
+size_t zo_compress_literals_prev(uint8_t* dst, size_t cap, const uint8_t* lits, size_t n, const zo_cparams* cp, int suspect, const zo_prev* pv)
 {
     size_t const lh = 3 + (n >= 1024) + (n >= 16384);
-    int const single = n < 256;
+    int single = n < 256;
+    int repeat = pv ? pv->hufRepeat : 0;
+    unsigned hType = 2;
     size_t c;
     (void)cap;
     if (cp->strategy == 1 && cp->targetLength > 0) return lits_raw(dst, lits, n);   /* internal.h:621-634 */
     {   int const shift = (9 - (int)cp->strategy) < 3 ? 9 - (int)cp->strategy : 3;  /* :115-127 */
-        if (n < ((size_t)8 << shift)) return lits_raw(dst, lits, n);
+        size_t const mintc = (repeat == 2) ? 6 : ((size_t)8 << shift);
+        if (n < mintc) return lits_raw(dst, lits, n);
     }
-    c = huf_compress(dst + lh, lits, n, !single, suspect);
+    if (repeat == 2 && lh == 3) single = 1;                                         /* :170 */
+    if (pv) {
+        int const preferRepeat = cp->strategy < 4 && n <= 1024;                    /* :165 */
+        c = huf_compress_prev(dst + lh, lits, n, !single, suspect, pv, &repeat, preferRepeat);
+        if (repeat != 0) hType = 3;                                                 /* :180-184 set_repeat */
+    } else c = huf_compress(dst + lh, lits, n, !single, suspect);
     {   size_t const minGain = (n >> 6) + 2;                                        /* internal.h:613 */
         if (c == 0 || c == ZO_ERROR || c >= n - minGain) return lits_raw(dst, lits, n);
     }
-    if (c == 1) return lits_rle(dst, lits, n);                                      /* :192-201 (n >= 64 here) */
-    if (lh == 3) wr24(dst, (uint32_t)(2 + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 14)));
-    else if (lh == 4) wr32(dst, (uint32_t)(2 + (2 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 18)));
-    else { wr32(dst, (uint32_t)(2 + (3 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 22))); dst[4] = (uint8_t)(c >> 10); }
+    if (c == 1) {                                                                   /* :192-201 */
+        size_t i; int same = 1;
+        for (i = 1; i < n; i++) if (lits[i] != lits[0]) { same = 0; break; }
+        if (n >= 8 || same) return lits_rle(dst, lits, n);
+    }
+    if (lh == 3) wr24(dst, (uint32_t)(hType + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 14)));
+    else if (lh == 4) wr32(dst, (uint32_t)(hType + (2 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 18)));
+    else { wr32(dst, (uint32_t)(hType + (3 << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 22))); dst[4] = (uint8_t)(c >> 10); }
     return lh + c;
+}
+
+size_t zo_compress_literals(uint8_t* dst, size_t cap, const uint8_t* lits, size_t n, const zo_cparams* cp, int suspect)
+{
+    return zo_compress_literals_prev(dst, cap, lits, n, cp, suspect, NULL);
 }
 
 /* ------------------------------------------------------------------ sequences section */
@@ -1419,13 +1292,14 @@ static size_t fse_write_ncount(uint8_t* out0, const short* norm, unsigned maxSym
 
 /* zstd_compress_sequences.c:157-235 with repeatMode none. returns set_* (0 basic,1 rle,2 compressed) */
 static int select_type(const unsigned* count, unsigned max, unsigned maxCount, size_t nbSeq, unsigned fseLog,
-                       const short* defNorm, unsigned defaultNormLog, int defaultAllowed, unsigned strategy)
+                       const short* defNorm, unsigned defaultNormLog, int defaultAllowed, unsigned strategy, int repeatMode)
 {
     if (maxCount == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (strategy < 4) {                                                          /* :179-204, strategy < ZSTD_lazy */
         if (defaultAllowed) {
             size_t const mult = 10 - strategy;
             size_t const dynMin = (((size_t)1 << defaultNormLog) * mult) >> 3;
+            if (repeatMode == 2 && nbSeq < 1000) return 3;                       /* :187-191 set_repeat with a VALID previous table */
             if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) return 0;
         }
         return 2;
@@ -1480,7 +1354,12 @@ static size_t build_ctable(uint8_t* dst, zo_fse* ct, unsigned fseLog, int type, 
 }
 
 /* zstd_compress.c:2934-2997 + :2756-2873 + zstd_compress_sequences.c:291-382 */
+size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp, const zo_prev* pv);
 size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp)
+{
+    return zo_compress_sequences_prev(dst, cap, seqs, nbSeq, cp, NULL);
+}
+size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp, const zo_prev* pv)
 {
     uint8_t* op = dst; uint8_t* seqHead;
     uint8_t *llc, *ofc, *mlc; size_t i, lastCount = 0;
@@ -1500,22 +1379,25 @@ size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_
     seqHead = op++;
     {   size_t h, mf;
         max = 35; mf = hist_small(count, &max, llc, nbSeq);
-        tLL = select_type(count, max, (unsigned)mf, nbSeq, 9, kLLnorm, 6, 1, cp->strategy);
+        tLL = select_type(count, max, (unsigned)mf, nbSeq, 9, kLLnorm, 6, 1, cp->strategy, pv ? pv->llRepeat : 0);
         if (tLL < 0) { free(llc); return ZO_ERROR; }
+        if (tLL == 3) { ctLL = pv->ll; h = 0; } else
         h = build_ctable(op, &ctLL, 9, tLL, count, max, llc, nbSeq, kLLnorm, 6, 35);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tLL == 2) lastCount = h;
         op += h;
         max = 31; mf = hist_small(count, &max, ofc, nbSeq);
-        tOF = select_type(count, max, (unsigned)mf, nbSeq, 8, kOFnorm, 5, max <= 28, cp->strategy);
+        tOF = select_type(count, max, (unsigned)mf, nbSeq, 8, kOFnorm, 5, max <= 28, cp->strategy, pv ? pv->ofRepeat : 0);
         if (tOF < 0) { free(llc); return ZO_ERROR; }
+        if (tOF == 3) { ctOF = pv->of; h = 0; } else
         h = build_ctable(op, &ctOF, 8, tOF, count, max, ofc, nbSeq, kOFnorm, 5, 28);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tOF == 2) lastCount = h;
         op += h;
         max = 52; mf = hist_small(count, &max, mlc, nbSeq);
-        tML = select_type(count, max, (unsigned)mf, nbSeq, 9, kMLnorm, 6, 1, cp->strategy);
+        tML = select_type(count, max, (unsigned)mf, nbSeq, 9, kMLnorm, 6, 1, cp->strategy, pv ? pv->mlRepeat : 0);
         if (tML < 0) { free(llc); return ZO_ERROR; }
+        if (tML == 3) { ctML = pv->ml; h = 0; } else
         h = build_ctable(op, &ctML, 9, tML, count, max, mlc, nbSeq, kMLnorm, 6, 52);
         if (h == ZO_ERROR) { free(llc); return ZO_ERROR; }
         if (tML == 2) lastCount = h;
@@ -1545,6 +1427,367 @@ size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_
     }
     free(llc);
     return (size_t)(op - dst);
+}
+
+/* ================================================================== dictionary (CDict, attach mode) ==================
+ * SURVEY.md §3.4 / §8 rows a7, a9, a11.  A CDict holds the dictionary content, its own tagged hash tables
+ * ("short cache": index << 8 | 8-bit tag, zstd_compress_internal.h:1399-1417) built with the CDict's own parameters,
+ * and the block state the first block starts from (repcodes; entropy tables for ZDICT-format dictionaries).
+ * Index spaces follow the reference: dictionary byte j has index j + 2 (ZSTD_WINDOW_START_INDEX), the attached working
+ * context continues at prefixStart = dictLen + 2 (zstd_compress.c:2352-2362), so dictIndexDelta is 0. */
+struct zo_cdict_s {
+    uint8_t* content; size_t len;          /* dictionary content (what matches may reference) */
+    zo_cparams cp;                         /* CDict parameters (ZSTD_cpm_createCDict) */
+    uint32_t* tabL; uint32_t* tabS;        /* fast: tabL only (hashLog); dfast: long (hashLog) + short (chainLog) */
+    uint32_t dictID; uint32_t rep[3];
+    int level;
+    int hasEntropy; zo_prev prev;          /* ZDICT-format dictionaries: the entropy tables the first block starts from */
+};
+
+static void zo_put_tagged(uint32_t* t, uint32_t hashAndTag, uint32_t index)     /* internal.h:1404 ZSTD_writeTaggedIndex */
+{
+    t[hashAndTag >> 8] = (index << 8) | (hashAndTag & 0xFF);
+}
+
+/* zstd_fast.c:16-49 ZSTD_fillHashTableForCDict / zstd_double_fast.c:18-54 ZSTD_fillDoubleHashTableForCDict (dtlm_full) */
+static void zo_cdict_fill(zo_cdict* cd)
+{
+    const uint8_t* const base = cd->content - 2;              /* index -> byte */
+    size_t const endIdx = cd->len + 2;
+    unsigned const mls = cd->cp.minMatch;
+    size_t ip, first = 2;
+    {   /* zstd_compress.c:4888-4896: a dictionary larger than the tables can reasonably index only has its SUFFIX indexed
+         * (all of it stays referenceable) */
+        unsigned const m = cd->cp.hashLog > cd->cp.chainLog ? cd->cp.hashLog : cd->cp.chainLog;
+        size_t const maxDictSize = (size_t)8 << (m < 28 ? m : 28);
+        if (cd->len > maxDictSize) first = 2 + (cd->len - maxDictSize);
+    }
+    if (endIdx - first <= 8) return;                          /* :4903 srcSize <= HASH_READ_SIZE */
+    if (cd->cp.strategy == 1) {
+        unsigned const hb = cd->cp.hashLog + 8;
+        for (ip = first; ip + 3 < (endIdx - 8) + 2; ip += 3) {    /* :37 ip + step < iend + 2 */
+            unsigned p;
+            zo_put_tagged(cd->tabL, zo_hash(base + ip, hb, mls), (uint32_t)ip);
+            for (p = 1; p < 3; p++) {
+                uint32_t const ht = zo_hash(base + ip + p, hb, mls);
+                if (cd->tabL[ht >> 8] == 0) zo_put_tagged(cd->tabL, ht, (uint32_t)(ip + p));
+            }
+        }
+    } else {
+        unsigned const hbL = cd->cp.hashLog + 8, hbS = cd->cp.chainLog + 8;
+        for (ip = first; ip + 3 - 1 <= endIdx - 8; ip += 3) { /* :36 */
+            unsigned i;
+            for (i = 0; i < 3; i++) {
+                uint32_t const sm = zo_hash(base + ip + i, hbS, mls), lg = zo_hash(base + ip + i, hbL, 8);
+                if (i == 0) zo_put_tagged(cd->tabS, sm, (uint32_t)(ip + i));
+                if (i == 0 || cd->tabL[lg >> 8] == 0) zo_put_tagged(cd->tabL, lg, (uint32_t)(ip + i));
+            }
+        }
+    }
+}
+
+void zo_cdict_free(zo_cdict* cd)
+{
+    if (!cd) return;
+    free(cd->content ? cd->content - 16 : NULL); free(cd->tabL); free(cd->tabS); free(cd);
+}
+
+/* ZSTD_createCDict (zstd_compress.c:5648): parameters for (level, unknown source, dictSize) in createCDict mode,
+ * raw-content dictionaries (no ZDICT magic: zstd_compress.c:5138-5148) — repcodes {1,4,8}, no entropy tables, dictID 0 */
+zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
+{
+    zo_cdict* cd = (zo_cdict*)calloc(1, sizeof(zo_cdict));
+    uint8_t* buf;
+    if (!cd) return NULL;
+    if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 2) { free(cd); return NULL; }
+    cd->level = level == 0 ? 3 : level;
+    cd->dictID = 0; cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8; cd->hasEntropy = 0;
+    if (dictSize < 8) dictSize = 0;                           /* :5130 dictionaries below 8 bytes are ignored */
+    if (dictSize >= 8 && rd32((const uint8_t*)dict) == 0xEC30A437U) {
+        /* ZSTD_loadZstdDictionary (zstd_compress.c:5087-5118) + ZSTD_loadCEntropy (:4986-5076); the parameters above were
+         * computed from the WHOLE dictionary size, like ZSTD_createCDict does */
+        const uint8_t* const d0 = (const uint8_t*)dict; const uint8_t* p = d0 + 8; const uint8_t* const dEnd = d0 + dictSize;
+        short ofN[32], mlN[53], llN[36]; unsigned ofMax = 31, ofLog, mlMax = 52, mlLog, llMax = 35, llLog; size_t h;
+        cd->dictID = rd32(d0 + 4);
+        h = huf_read_table(&cd->prev, p, (size_t)(dEnd - p)); if (!h) { free(cd); return NULL; } p += h;
+        h = fse_read_ncount(ofN, &ofMax, &ofLog, p, (size_t)(dEnd - p)); if (!h || ofLog > 8) { free(cd); return NULL; } p += h;
+        fse_build(&cd->prev.of, ofN, 31, ofLog);                                /* :5016 all offset symbols, MaxOff */
+        h = fse_read_ncount(mlN, &mlMax, &mlLog, p, (size_t)(dEnd - p)); if (!h || mlLog > 9) { free(cd); return NULL; } p += h;
+        fse_build(&cd->prev.ml, mlN, mlMax, mlLog);
+        cd->prev.mlRepeat = dict_ncount_repeat(mlN, mlMax, 52);
+        h = fse_read_ncount(llN, &llMax, &llLog, p, (size_t)(dEnd - p)); if (!h || llLog > 9) { free(cd); return NULL; } p += h;
+        fse_build(&cd->prev.ll, llN, llMax, llLog);
+        cd->prev.llRepeat = dict_ncount_repeat(llN, llMax, 35);
+        if (p + 12 > dEnd) { free(cd); return NULL; }
+        cd->rep[0] = rd32(p); cd->rep[1] = rd32(p + 4); cd->rep[2] = rd32(p + 8); p += 12;
+        {   size_t const contentSize = (size_t)(dEnd - p);
+            unsigned offcodeMax = hb32((uint32_t)contentSize + 131072);         /* :5058-5064 */
+            cd->prev.ofRepeat = dict_ncount_repeat(ofN, ofMax, offcodeMax < 31 ? offcodeMax : 31);
+            if (!cd->rep[0] || !cd->rep[1] || !cd->rep[2] || cd->rep[0] > contentSize || cd->rep[1] > contentSize || cd->rep[2] > contentSize) { free(cd); return NULL; }
+            dict = p; dictSize = contentSize;
+        }
+        cd->hasEntropy = 1;
+    }
+    buf = (uint8_t*)calloc(dictSize + 64, 1);
+    cd->content = buf + 16; cd->len = dictSize;
+    memcpy(cd->content, dict, dictSize);
+    cd->tabL = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t));
+    cd->tabS = (uint32_t*)calloc((size_t)1 << cd->cp.chainLog, sizeof(uint32_t));
+    zo_cdict_fill(cd);
+    return cd;
+}
+
+/* zstd_compress_internal.h:797 ZSTD_count_2segments: the match may run off the end of the dictionary into the source */
+static size_t zo_count_2seg(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd, const uint8_t* mEnd, const uint8_t* iStart)
+{
+    const uint8_t* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
+    size_t k = 0;
+    while (ip + k < vEnd && ip[k] == match[k]) k++;
+    if (match + k != mEnd) return k;
+    {   size_t j = 0;
+        while (ip + k + j < iEnd && ip[k + j] == iStart[j]) j++;
+        return k + j;
+    }
+}
+static size_t zo_count_ptr(const uint8_t* ip, const uint8_t* match, const uint8_t* iEnd)
+{
+    size_t k = 0;
+    while (ip + k < iEnd && ip[k] == match[k]) k++;
+    return k;
+}
+
+/* zstd_double_fast.c:328-547 ZSTD_compressBlock_doubleFast_dictMatchState_generic */
+static size_t zo_dfast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
+    unsigned const dHBitsL = cd->cp.hashLog + 8, dHBitsS = cd->cp.chainLog + 8;
+    uint32_t* const hashLong = (uint32_t*)calloc((size_t)1 << hBitsL, sizeof(uint32_t));
+    uint32_t* const hashSmall = (uint32_t*)calloc((size_t)1 << hBitsS, sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2;                  /* prefixLowestIndex */
+    const uint8_t* const base = src - P;                       /* index -> source byte (index >= P) */
+    const uint8_t* const dictBase = cd->content - 2;           /* index -> dictionary byte (index < P) */
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixLowest = src;
+    const uint8_t* ip = istart, * anchor = istart;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1];
+#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(litLen), (offBase), (uint32_t)(ml))
+    while (ip < ilimit) {
+        size_t mLength; uint32_t offset;
+        uint32_t const h2 = zo_hash(ip, hBitsL, 8), h = zo_hash(ip, hBitsS, mls);
+        uint32_t const dL = zo_hash(ip, dHBitsL, 8), dS = zo_hash(ip, dHBitsS, mls);
+        uint32_t const dEntL = cd->tabL[dL >> 8], dEntS = cd->tabS[dS >> 8];
+        int const tagL = (dEntL & 0xFF) == (dL & 0xFF), tagS = (dEntS & 0xFF) == (dS & 0xFF);
+        uint32_t const curr = (uint32_t)(ip - base);
+        uint32_t const matchIndexL = hashLong[h2];
+        uint32_t matchIndexS = hashSmall[h];
+        const uint8_t* matchLong = base + matchIndexL;
+        const uint8_t* match = base + matchIndexS;
+        uint32_t const repIndex = curr + 1 - offset_1;
+        const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
+        hashLong[h2] = hashSmall[h] = curr;
+        if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip + 1)) {        /* :398 ZSTD_index_overlap_check */
+            const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
+            mLength = zo_count_2seg(ip + 1 + 4, repMatch + 4, iend, repEnd, prefixLowest) + 4;
+            ip++;
+            SEQ(ip - anchor, 1, mLength);
+            goto _match_stored;
+        }
+        if (matchIndexL >= P && rd64(matchLong) == rd64(ip)) {                                /* :407 */
+            mLength = zo_count_ptr(ip + 8, matchLong + 8, iend) + 8;
+            offset = (uint32_t)(ip - matchLong);
+            while (ip > anchor && matchLong > prefixLowest && ip[-1] == matchLong[-1]) { ip--; matchLong--; mLength++; }
+            goto _match_found;
+        } else if (tagL) {                                                                    /* :413 */
+            uint32_t const dIdx = dEntL >> 8;
+            const uint8_t* dm = dictBase + dIdx;
+            if (dm > dictStart && rd64(dm) == rd64(ip)) {
+                mLength = zo_count_2seg(ip + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
+                offset = curr - dIdx;
+                while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
+                goto _match_found;
+            }
+        }
+        if (matchIndexS > P) {                                                                /* :427 */
+            if (rd32(match) == rd32(ip)) goto _search_next_long;
+        } else if (tagS) {
+            uint32_t const dIdx = dEntS >> 8;
+            match = dictBase + dIdx;
+            matchIndexS = dIdx;
+            if (match > dictStart && rd32(match) == rd32(ip)) goto _search_next_long;
+        }
+        ip += ((ip - anchor) >> 8) + 1;                                                      /* :443 */
+        continue;
+_search_next_long:
+        {   uint32_t const hl3 = zo_hash(ip + 1, hBitsL, 8), dL3 = zo_hash(ip + 1, dHBitsL, 8);
+            uint32_t const matchIndexL3 = hashLong[hl3], dEntL3 = cd->tabL[dL3 >> 8];
+            int const tagL3 = (dEntL3 & 0xFF) == (dL3 & 0xFF);
+            const uint8_t* matchL3 = base + matchIndexL3;
+            hashLong[hl3] = curr + 1;
+            if (matchIndexL3 >= P && rd64(matchL3) == rd64(ip + 1)) {                         /* :459 */
+                mLength = zo_count_ptr(ip + 9, matchL3 + 8, iend) + 8;
+                ip++;
+                offset = (uint32_t)(ip - matchL3);
+                while (ip > anchor && matchL3 > prefixLowest && ip[-1] == matchL3[-1]) { ip--; matchL3--; mLength++; }
+                goto _match_found;
+            } else if (tagL3) {
+                uint32_t const dIdx = dEntL3 >> 8;
+                const uint8_t* dm = dictBase + dIdx;
+                if (dm > dictStart && rd64(dm) == rd64(ip + 1)) {
+                    mLength = zo_count_2seg(ip + 1 + 8, dm + 8, iend, dictEnd, prefixLowest) + 8;
+                    ip++;
+                    offset = curr + 1 - dIdx;
+                    while (ip > anchor && dm > dictStart && ip[-1] == dm[-1]) { ip--; dm--; mLength++; }
+                    goto _match_found;
+                }
+            }
+        }
+        if (matchIndexS < P) {                                                                /* :481 */
+            mLength = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, prefixLowest) + 4;
+            offset = curr - matchIndexS;
+            while (ip > anchor && match > dictStart && ip[-1] == match[-1]) { ip--; match--; mLength++; }
+        } else {
+            mLength = zo_count_ptr(ip + 4, match + 4, iend) + 4;
+            offset = (uint32_t)(ip - match);
+            while (ip > anchor && match > prefixLowest && ip[-1] == match[-1]) { ip--; match--; mLength++; }
+        }
+_match_found:
+        offset_2 = offset_1; offset_1 = offset;
+        SEQ(ip - anchor, offset + 3, mLength);
+_match_stored:
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {                                                                   /* :503 */
+            uint32_t const ins = curr + 2;
+            hashLong[zo_hash(base + ins, hBitsL, 8)] = ins;
+            hashLong[zo_hash(ip - 2, hBitsL, 8)] = (uint32_t)(ip - 2 - base);
+            hashSmall[zo_hash(base + ins, hBitsS, mls)] = ins;
+            hashSmall[zo_hash(ip - 1, hBitsS, mls)] = (uint32_t)(ip - 1 - base);
+            while (ip <= ilimit) {                                                            /* :514 */
+                uint32_t const current2 = (uint32_t)(ip - base), repIndex2 = current2 - offset_2;
+                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
+                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip + 4, repMatch2 + 4, iend, repEnd2, prefixLowest) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    SEQ(0, 1, rl);
+                    hashSmall[zo_hash(ip, hBitsS, mls)] = current2;
+                    hashLong[zo_hash(ip, hBitsL, 8)] = current2;
+                    ip += rl; anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    rep[0] = offset_1; rep[1] = offset_2;
+    free(hashLong); free(hashSmall);
+    return (size_t)(iend - anchor);
+}
+
+/* zstd_fast.c:483-678 ZSTD_compressBlock_fast_dictMatchState_generic */
+static size_t zo_fast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hlog = cp->hashLog, mls = cp->minMatch, dHBits = cd->cp.hashLog + 8;
+    size_t const stepSize = cp->targetLength + !cp->targetLength;
+    uint32_t* const hashTable = (uint32_t*)calloc((size_t)1 << hlog, sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* ip0 = istart, * ip1 = ip0 + stepSize, * anchor = istart;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1];
+    while (ip1 <= ilimit) {
+        size_t mLength;
+        uint32_t hash0 = zo_hash(ip0, hlog, mls);
+        uint32_t dHT0 = zo_hash(ip0, dHBits, mls);
+        uint32_t dEnt = cd->tabL[dHT0 >> 8];
+        int dTags = (dEnt & 0xFF) == (dHT0 & 0xFF);
+        uint32_t matchIndex = hashTable[hash0];
+        uint32_t curr = (uint32_t)(ip0 - base);
+        size_t step = stepSize;
+        const uint8_t* nextStep = ip0 + 256;
+        for (;;) {
+            const uint8_t* match = base + matchIndex;
+            uint32_t const repIndex = curr + 1 - offset_1;
+            const uint8_t* repMatch = repIndex < P ? dictBase + repIndex : base + repIndex;
+            uint32_t const hash1 = zo_hash(ip1, hlog, mls), dHT1 = zo_hash(ip1, dHBits, mls);
+            hashTable[hash0] = curr;
+            if ((uint32_t)((P - 1) - repIndex) >= 3 && rd32(repMatch) == rd32(ip0 + 1)) {   /* :566 */
+                const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
+                mLength = zo_count_2seg(ip0 + 1 + 4, repMatch + 4, iend, repEnd, prefixStart) + 4;
+                ip0++;
+                SEQ(ip0 - anchor, 1, mLength);
+                break;
+            }
+            if (dTags) {                                                                      /* :575 */
+                uint32_t const dIdx = dEnt >> 8;
+                const uint8_t* dm = dictBase + dIdx;
+                if (dIdx > 2 && rd32(dm) == rd32(ip0) && matchIndex <= P) {
+                    uint32_t const offset = curr - dIdx;
+                    mLength = zo_count_2seg(ip0 + 4, dm + 4, iend, dictEnd, prefixStart) + 4;
+                    while (ip0 > anchor && dm > dictStart && ip0[-1] == dm[-1]) { ip0--; dm--; mLength++; }
+                    offset_2 = offset_1; offset_1 = offset;
+                    SEQ(ip0 - anchor, offset + 3, mLength);
+                    break;
+                }
+            }
+            if (matchIndex >= P && rd32(ip0) == rd32(match)) {                                /* :598 ZSTD_match4Found_cmov */
+                uint32_t const offset = (uint32_t)(ip0 - match);
+                mLength = zo_count_ptr(ip0 + 4, match + 4, iend) + 4;
+                while (ip0 > anchor && match > prefixStart && ip0[-1] == match[-1]) { ip0--; match--; mLength++; }
+                offset_2 = offset_1; offset_1 = offset;
+                SEQ(ip0 - anchor, offset + 3, mLength);
+                break;
+            }
+            dEnt = cd->tabL[dHT1 >> 8];                                                       /* :614 */
+            dTags = (dEnt & 0xFF) == (dHT1 & 0xFF);
+            matchIndex = hashTable[hash1];
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip0 = ip1; ip1 = ip1 + step;
+            if (ip1 > ilimit) goto _cleanup;
+            curr = (uint32_t)(ip0 - base);
+            hash0 = hash1;
+        }
+        ip0 += mLength; anchor = ip0;                                                         /* :631 */
+        if (ip0 <= ilimit) {
+            hashTable[zo_hash(base + curr + 2, hlog, mls)] = curr + 2;
+            hashTable[zo_hash(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                uint32_t const current2 = (uint32_t)(ip0 - base), repIndex2 = current2 - offset_2;
+                const uint8_t* repMatch2 = repIndex2 < P ? dictBase + repIndex2 : base + repIndex2;
+                if ((uint32_t)((P - 1) - repIndex2) >= 3 && rd32(repMatch2) == rd32(ip0)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    SEQ(0, 1, rl);
+                    hashTable[zo_hash(ip0, hlog, mls)] = current2;
+                    ip0 += rl; anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+        ip1 = ip0 + stepSize;
+    }
+_cleanup:
+    rep[0] = offset_1; rep[1] = offset_2;
+    free(hashTable);
+    return (size_t)(iend - anchor);
+}
+#undef SEQ
+
+/* working-context parameters for a source of n bytes compressed with `cd` attached, or -1 if the reference would copy the
+ * dictionary instead (zstd_compress.c:2289-2315) — only the attach path is restated */
+int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
+{
+    static const size_t cutoff[6] = { 8192, 8192, 16384, 32768, 32768, 32768 };
+    zo_cparams p, w;
+    if (n > cutoff[cd->cp.strategy]) return -1;
+    if (zo_get_cparams_mode(cd->level, n, cd->len, 1, &p) < 0) return -1;        /* :6289-6292 requested params, attach mode */
+    w = cd->cp;                                                                  /* :2331-2335 */
+    zo_adjust_cparams(&w, n, cd->len, 1);
+    w.windowLog = p.windowLog;
+    *out = w;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ block + frame */
@@ -1643,8 +1886,9 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
         memcpy(lits + st.litSize, src + n - last, last);
         st.litSize += last;
         {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);
-            size_t const l = zo_compress_literals(body, cap, lits, st.litSize, &cp, suspect);
-            size_t const q = zo_compress_sequences(body + l, cap, seqs, st.nb, &cp);
+            const zo_prev* const pv = cd->hasEntropy ? &cd->prev : NULL;
+            size_t const l = zo_compress_literals_prev(body, cap, lits, st.litSize, &cp, suspect, pv);
+            size_t const q = zo_compress_sequences_prev(body + l, cap, seqs, st.nb, &cp, pv);
             if (q == ZO_ERROR || st.overflow) { free(seqs); free(lits); return ZO_ERROR; }
             cSize = (q == 0) ? 0 : l + q;
             if (cSize >= n - ((n >> 6) + 2)) cSize = 0;

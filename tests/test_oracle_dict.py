@@ -72,3 +72,55 @@ def test_cdict_records_match_the_reference(level, kind):
             checked += 1
         assert checked >= len(recs) // 2
         lo.zo_cdict_free(cd)
+
+
+def train_zdict(lr, samples, cap=112640):
+    lr.zref_train_dict.restype = C.c_size_t
+    lr.zref_train_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint]
+    flat = np.concatenate(samples)
+    sizes = (C.c_size_t * len(samples))(*[len(s) for s in samples])
+    buf = np.zeros(cap, dtype=np.uint8)
+    r = lr.zref_train_dict(_buf(buf), cap, _buf(flat), sizes, len(samples))
+    assert r != ERR, "ZDICT_trainFromBuffer failed"
+    return buf[:r].copy()
+
+
+@pytest.mark.parametrize("level", [1, 3, 4])
+@pytest.mark.parametrize("kind", ["json", "text"])
+def test_zdict_trained_dictionary_records_match_the_reference(level, kind):
+    """ZDICT-format dictionary (entropy tables + repcodes + content): repeat-mode literals / FSE tables, byte for byte"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from zstd_amd import workloads as W
+    lo, lr = load_oracle(), load_ref()
+    bind(lo, lr)
+    rng = np.random.default_rng(level)
+    if kind == "json":
+        flat, offs = W.github_like_records(3000, seed=level)
+        recs = [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(len(offs) - 1)]
+    else:
+        corpus = text_like(600000, 5)
+        recs = [corpus[s:s + int(n)].copy() for s, n in zip(rng.integers(0, 590000, size=3000), rng.integers(50, 3000, size=3000))]
+    for cap in (112640, 20000):
+        zd = train_zdict(lr, recs[:2000], cap)
+        assert zd[:4].tobytes() == (0xEC30A437).to_bytes(4, "little")
+        cd = lo.zo_cdict_create(_buf(zd), len(zd), level)
+        assert cd
+        test = recs[2000:2300] + [np.zeros(0, np.uint8), recs[0][:5], recs[1][:7], recs[2][:8], recs[3][:20], recs[4][:64], np.concatenate(recs[5:11])[:8000],
+                                  rng.integers(0, 256, size=1500, dtype=np.uint8), np.full(900, 65, np.uint8)]
+        flat2 = np.concatenate(test + [np.zeros(8, np.uint8)])
+        sizes = (C.c_size_t * len(test))(*[len(r) for r in test])
+        capd = sum(len(r) + 64 for r in test) + 4096
+        dst = np.zeros(capd, dtype=np.uint8)
+        osz = (C.c_size_t * len(test))()
+        tot = lr.zref_compress_records_cdict(level, _buf(zd), len(zd), _buf(flat2), sizes, len(test), _buf(dst), capd, osz)
+        assert tot != ERR
+        pos = 0
+        for i, (r, cs) in enumerate(zip(test, osz)):
+            want = dst[pos:pos + cs].tobytes()
+            pos += cs
+            mine = np.zeros(len(r) + 600, dtype=np.uint8)
+            got = lo.zo_compress_unit_cdict(_buf(mine), len(mine), _buf(r), len(r), cd)
+            assert got != ERR
+            assert mine[:got].tobytes() == want, (kind, level, cap, i, len(r), got, cs, mine[:12].tobytes().hex(), want[:12].hex())
+        lo.zo_cdict_free(cd)
