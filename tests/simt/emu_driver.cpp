@@ -87,7 +87,7 @@ void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, con
 {
     std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
-                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize); }, osThreads);
+                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u); }, osThreads);
 }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }

@@ -81,12 +81,52 @@ def test_records_with_dictionary_match_oracle_bytes(env, kind, level, dsize):
     cd.close(); ctx.close()
 
 
+@pytest.mark.parametrize("level", [3, 4])
+def test_zdict_trained_dictionary_records_match_oracle_bytes(env, level):
+    """ZDICT-format dictionary (tests/golden/github_like_110k.zdict, trained with the real reference): dictID in the frame
+    header, repcodes from the dictionary, treeless literals and set_repeat FSE tables — byte-identical to the oracle"""
+    import os, sys
+    lo, zstd_amd, torch = env
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from zstd_amd import workloads as W
+    zd = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    flat, offs = W.github_like_records(400, seed=7)
+    recs = [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(400)]
+    rng = np.random.default_rng(level)
+    recs += [np.zeros(0, np.uint8), recs[0][:5], recs[1][:6], recs[2][:7], recs[3][:8], recs[4][:9], recs[5][:30], recs[6][:64], recs[7][:100],
+             np.concatenate(recs[8:14])[:8000], np.concatenate(recs[20:40])[:16384], rng.integers(0, 256, size=1500, dtype=np.uint8),
+             np.full(900, 65, np.uint8), np.full(7, 66, np.uint8), text_like(3000, 4)]
+    ctx = zstd_amd.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
+    cd = zstd_amd.CDict(zd, level=level)
+    got, fs = ctx.compress_records(cd, recs, return_sizes=True)
+    want = oracle_frames(lo, zd, recs, level)
+    pos = 0
+    kinds = set()
+    for i, (r, w) in enumerate(zip(recs, want)):
+        g = got[pos:pos + int(fs[i])]
+        pos += int(fs[i])
+        assert g == w, (level, i, len(r), len(g), len(w), g[:16].hex(), w[:16].hex())
+    assert pos == len(got)
+    if have_ref():
+        lr = load_ref()
+        lr.zref_decompress_dict.restype = C.c_size_t
+        lr.zref_decompress_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        pos = 0
+        for i, r in enumerate(recs):
+            f = np.frombuffer(got[pos:pos + int(fs[i])], dtype=np.uint8)
+            pos += int(fs[i])
+            out = np.zeros(max(1, len(r)), dtype=np.uint8)
+            k = lr.zref_decompress_dict(_buf(out), len(r), _buf(f), len(f), _buf(zd), len(zd))
+            assert k == len(r) and out[:len(r)].tobytes() == r.tobytes(), i
+    cd.close(); ctx.close()
+
+
 def test_unsupported_dictionaries_are_errors(env):
     lo, zstd_amd, torch = env
     zd = np.zeros(200, dtype=np.uint8)
     zd[:4] = np.frombuffer((0xEC30A437).to_bytes(4, "little"), dtype=np.uint8)
     with pytest.raises(zstd_amd.ZhipError):
-        zstd_amd.CDict(zd, level=3)                          # ZDICT-format dictionaries: entropy tables not implemented yet
+        zstd_amd.CDict(zd, level=3)                          # malformed ZDICT-format dictionary
     with pytest.raises(zstd_amd.ZhipError):
         zstd_amd.CDict(text_like(5000, 1), level=9)          # CDict row is a lazy strategy
     cd = zstd_amd.CDict(text_like(50000, 1), level=3)

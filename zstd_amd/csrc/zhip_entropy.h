@@ -73,13 +73,13 @@ struct EntShared {
     uint16_t cumul[3][64];
     uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
     uint32_t ncountSize[3];
-    uint32_t encType[3];          // set_basic 0 / set_rle 1 / set_compressed 2 (zstd_internal.h:102)
+    uint32_t encType[3];          // set_basic 0 / set_rle 1 / set_compressed 2 / set_repeat 3 (zstd_internal.h:102)
     uint32_t maxCode[3];
     uint32_t finalState[3];
     uint8_t  hufHdr[136];
     HufWork  huf;
     // scalars broadcast through LDS
-    uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream;
+    uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream, litType /*2 compressed, 3 repeat*/;
     uint32_t streamBits[4], streamBytes[4], streamOff[4];
     uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
     uint32_t sampleHist[2][256];
@@ -169,16 +169,20 @@ __device__ __forceinline__ void seq_unpack(const ZhipSeq& s, const ZhipParse& m,
 }
 
 // ------------------------------------------------------------------ frame / block headers
-__device__ inline uint32_t frame_header_size(uint32_t n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
-// zstd_compress.c:4626-4672 for a single-segment frame with content size, no checksum, no dictID (library defaults)
-__device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n)
+__device__ inline uint32_t dict_id_bytes(uint32_t dictID) { uint32_t const c = (dictID > 0) + (dictID >= 256) + (dictID >= 65536); return c == 3 ? 4 : c; }
+__device__ inline uint32_t frame_header_size(uint32_t n, uint32_t dictID) { return 4 + 1 + dict_id_bytes(dictID) + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
+// zstd_compress.c:4626-4672 for a single-segment frame with content size, no checksum (library defaults), optional dictID
+__device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n, uint32_t dictID)
 {
     uint32_t const fcs = (n >= 256) + (n >= 65536 + 256);
+    uint32_t const dcode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
+    uint32_t pos = 5;
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
-    op[4] = (uint8_t)((1u << 5) + (fcs << 6));
-    if (fcs == 0) { op[5] = (uint8_t)n; return 6; }
-    if (fcs == 1) { uint32_t const v = n - 256; op[5] = (uint8_t)v; op[6] = (uint8_t)(v >> 8); return 7; }
-    op[5] = (uint8_t)n; op[6] = (uint8_t)(n >> 8); op[7] = (uint8_t)(n >> 16); op[8] = (uint8_t)(n >> 24); return 9;
+    op[4] = (uint8_t)(dcode + (1u << 5) + (fcs << 6));
+    for (uint32_t i = 0; i < dict_id_bytes(dictID); i++) op[pos++] = (uint8_t)(dictID >> (8 * i));     // :4651-4657
+    if (fcs == 0) { op[pos] = (uint8_t)n; return pos + 1; }
+    if (fcs == 1) { uint32_t const v = n - 256; op[pos] = (uint8_t)v; op[pos + 1] = (uint8_t)(v >> 8); return pos + 2; }
+    op[pos] = (uint8_t)n; op[pos + 1] = (uint8_t)(n >> 8); op[pos + 2] = (uint8_t)(n >> 16); op[pos + 3] = (uint8_t)(n >> 24); return pos + 4;
 }
 
 // ------------------------------------------------------------------ wide memory helpers
@@ -212,12 +216,13 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
 // ================================================================== the unit encoder
 __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
                                     const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
-                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh)
+                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh,
+                                    const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID)
 {
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t const n = u.srcLen;
     uint32_t const nbSeq = (n < 7) ? 0 : pm.nbSeq;
-    uint32_t const fh = frame_header_size(n);
+    uint32_t const fh = frame_header_size(n, dictID);
     uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
     uint32_t const minGainBlock = (n >> 6) + 2;             // zstd_compress_internal.h:613
     ZPROF_DECL
@@ -225,7 +230,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     // ---------------- trivial units: empty frame, or too small to attempt compression (zstd_compress.c:3216, :5270)
     if (n < 7) {
         if (t == 0) {
-            write_frame_header(out, n);
+            write_frame_header(out, n, dictID);
             uint32_t const bh = 1u + (0u << 1) + (n << 3);
             out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
             for (uint32_t i = 0; i < n; i++) out[fh + 3 + i] = src[i];
@@ -275,8 +280,9 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     ZPROF(10);
     uint8_t* const litDst = body;
     uint32_t const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
-    bool const single = litSize < 256;
-    bool const tryHuf0 = !(u.litMode) && litSize >= 64;     // minLiteralsToCompress = 8 << min(9-strategy,3) for fast/dfast
+    uint32_t const hufRep0 = de ? de->hufRepeat : 0;        // previous Huffman table: 0 none, 1 check, 2 valid (dictionary)
+    bool const single = litSize < 256 || (hufRep0 == 2 && lhSize == 3);                // zstd_compress_literals.c:142, :170
+    bool const tryHuf0 = !(u.litMode) && litSize >= (hufRep0 == 2 ? 6u : 64u);        // :115-127 minLiteralsToCompress (strategy <= lazy2)
     bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);                      // zstd_compress.c:2918
     bool const sampling = tryHuf0 && suspect && litSize >= 40960;
     if (sampling) for (int i = t; i < 512; i += ZHIP_ENT_THREADS) (&sh->sampleHist[0][0])[i] = 0;
@@ -303,22 +309,41 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             if (a + b <= ((2 * 4096) >> 7) + 4) tryHuf = false;
         }
         uint32_t mode = 0;      // raw
-        sh->hufHdrSize = 0;
-        if (tryHuf) {
+        sh->hufHdrSize = 0; sh->litType = 2;
+        // HUF_compress_internal (huf_compress.c:1333-1434) with the dictionary's table as the previous one when there is one
+        uint32_t rep = hufRep0;
+        bool const preferRepeat = u.strategy < ZHIP_STRAT_LAZY && litSize <= 1024;   // zstd_compress_literals.c:165
+        bool useOld = false;
+        if (tryHuf0 && preferRepeat && rep == 2) { mode = 2; useOld = true; }        // :1359-1363 valid table, small input: no statistics at all
+        else if (tryHuf) {
             uint32_t maxSym = 255, largest = 0;
             while (!sh->hist[0][maxSym]) maxSym--;
             for (uint32_t s = 0; s <= maxSym; s++) if (sh->hist[0][s] > largest) largest = sh->hist[0][s];
             if (largest == litSize) mode = 1;                                        // huf_compress.c:1383 -> RLE literals
             else if (largest <= (litSize >> 7) + 4) mode = 0;                        // :1384
             else {
-                uint32_t huffLog = fse_optimal_table_log(11, litSize, maxSym, 1);    // :1284-1287
-                ZPROF_JOB_MARK(31);
-                huffLog = huf_build_codes(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
-                ZPROF_JOB_MARK(28);
-                uint32_t const h = huf_write_table(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
-                if (h != 0 && h + 12 < litSize) { mode = 2; sh->hufHdrSize = h; sh->huffLog = huffLog; }   // :1425
+                if (rep == 1) {                                                      // :1389-1393 HUF_validateCTable
+                    bool bad = de->hufMaxSym < maxSym;
+                    for (uint32_t s = 0; s <= maxSym && !bad; s++) bad = sh->hist[0][s] != 0 && (de->hufCode[s] & 0xFF) == 0;
+                    if (bad) rep = 0;
+                }
+                if (preferRepeat && rep != 0) { mode = 2; useOld = true; }           // :1395-1399
+                else {
+                    uint32_t huffLog = fse_optimal_table_log(11, litSize, maxSym, 1);    // :1284-1287
+                    ZPROF_JOB_MARK(31);
+                    huffLog = huf_build_codes(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
+                    ZPROF_JOB_MARK(28);
+                    uint32_t const h = huf_write_table(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
+                    if (h != 0 && rep != 0) {                                        // :1415-1421 is the previous table cheaper?
+                        uint32_t oldSize = 0, newSize = 0;
+                        for (uint32_t s = 0; s <= maxSym; s++) { oldSize += (de->hufCode[s] & 0xFF) * sh->hist[0][s]; newSize += (sh->code[s] & 0xFF) * sh->hist[0][s]; }
+                        if ((oldSize >> 3) <= h + (newSize >> 3) || h + 12 >= litSize) { mode = 2; useOld = true; }
+                    }
+                    if (!useOld && h != 0 && h + 12 < litSize) { mode = 2; sh->hufHdrSize = h; sh->huffLog = huffLog; }   // :1425
+                }
             }
         }
+        if (useOld) { for (int s = 0; s < 256; s++) sh->code[s] = de->hufCode[s]; sh->hufHdrSize = 0; sh->litType = 3; }   // set_repeat: treeless literals
         sh->litMode = mode;
         ZPROF_JOB_MARK(31);
     }
@@ -346,7 +371,8 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 if (defaultAllowed) {
                     uint32_t const mult = 10 - u.strategy;
                     uint32_t const dynMin = ((1u << defLog) * mult) >> 3;
-                    if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
+                    if (de && de->fseRepeat[k] == 2 && nbSeq < 1000) type = 3;        // :187-191 set_repeat: the dictionary's VALID table
+                    else if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) type = 0;
                 }
             } else {
                 // strategy >= lazy (:205-231): estimated costs in bits; without a previous table the repeat cost is an
@@ -374,7 +400,9 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 uint64_t const compressedCost = ((uint64_t)ncountCost << 3) + (ecost >> 8);
                 type = basicCost <= compressedCost ? 0 : 2;                            // :217-222
             }
-            if (type == 1) {           // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
+            if (type == 3) {           // zstd_compress_sequences.c:264-266: the previous table as it is, no header bytes
+                sh->ct[k] = de->ct[k];
+            } else if (type == 1) {    // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
                 fse_build_ctable_rle(&sh->ct[k], max);
                 sh->ncount[k][0] = (uint8_t)max;
                 hsz = 1;
@@ -489,6 +517,11 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             for (uint32_t k = 0; k < nStreams; k++) { sh->streamOff[k] = off; off += sh->streamBytes[k]; tot += sh->streamBytes[k]; if (sh->streamBytes[k] > 65535) ok = false; }
             // huf_compress.c:1237 (>= srcSize-1 -> 0) then zstd_compress_literals.c:187-191 (minGain)
             if (!ok || tot >= litSize - 1 || tot >= litSize - ((litSize >> 6) + 2)) sh->litMode = 0;
+            else if (tot == 1 && litSize < 8) {           // zstd_compress_literals.c:192-201: a 1-byte result of identical bytes is RLE
+                bool same = true;
+                for (uint32_t i = 1; i < litSize; i++) same = same && lits[i] == lits[0];
+                if (same) sh->litMode = 1;
+            }
             sh->litSectionSize = lhSize + tot;
         }
         __syncthreads();
@@ -499,9 +532,9 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             zero_bytes(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
             if (t == 0) {
                 // section header (zstd_compress_literals.c:209-232)
-                if (lhSize == 3) { uint32_t const lhc = 2 + ((uint32_t)(!single) << 2) + (litSize << 4) + (cLit << 14); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); }
-                else if (lhSize == 4) { uint32_t const lhc = 2 + (2 << 2) + (litSize << 4) + (cLit << 18); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); }
-                else { uint32_t const lhc = 2 + (3 << 2) + (litSize << 4) + (cLit << 22); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); litDst[4] = (uint8_t)(cLit >> 10); }
+                if (lhSize == 3) { uint32_t const lhc = sh->litType + ((uint32_t)(!single) << 2) + (litSize << 4) + (cLit << 14); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); }
+                else if (lhSize == 4) { uint32_t const lhc = sh->litType + (2 << 2) + (litSize << 4) + (cLit << 18); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); }
+                else { uint32_t const lhc = sh->litType + (3 << 2) + (litSize << 4) + (cLit << 22); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); litDst[3] = (uint8_t)(lhc >> 24); litDst[4] = (uint8_t)(cLit >> 10); }
                 for (uint32_t i = 0; i < sh->hufHdrSize; i++) litDst[lhSize + i] = sh->hufHdr[i];
                 if (!single) for (int k = 0; k < 3; k++) { uint8_t* jt = litDst + lhSize + sh->hufHdrSize + 2 * k; jt[0] = (uint8_t)sh->streamBytes[k]; jt[1] = (uint8_t)(sh->streamBytes[k] >> 8); }
             }
@@ -642,7 +675,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
     }
     if (t == 0) {
-        write_frame_header(out, n);
+        write_frame_header(out, n, dictID);
         uint32_t const bh = rawBlock ? (1u + (0u << 1) + (n << 3)) : (1u + (2u << 1) + (cSize << 3));
         out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
         *outSize = fh + 3 + (rawBlock ? n : cSize);

@@ -138,7 +138,8 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
 k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
-          const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize)
+          const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize,
+          const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
@@ -147,7 +148,7 @@ k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, c
     ZhipParse const pm = metas[ui];
     ZhipSlot const sl = slots[ui];
     entropy_unit(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
-                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem);
+                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem, dictEntropy, dictID);
 }
 
 // Stage 3: pack the per-unit slots into one contiguous stream.  offsets[] = exclusive prefix sum of outSize[].

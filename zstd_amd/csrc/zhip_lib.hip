@@ -40,6 +40,7 @@ struct zhip_ctx_s {
     size_t     hcChunk;                        // hash chain: units per pass over dTabs / dBest
     uint32_t   hcMaxLen, hcHashLog;            // hash chain: longest unit / largest hashLog of the call
     std::vector<hipEvent_t> hcEv; size_t hcEvUsed;   // hash chain: 4 events per chunk of the last call
+    const zhip::ZhipDictEntropy* curDictEntropy; uint32_t curDictID;   // dictionary entropy state of the current call (records path)
     int        strategy;                       // family mask of the current call's units: bit 0 fast, 1 dfast, 2 hash chain
     size_t     seqArena, litArena, outArena;   // arena capacities: sequences (entries), literal bytes, output-slot bytes
     uint32_t*  dOutSize;
@@ -125,7 +126,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     zhip_ctx* c = new zhip_ctx_s();
     c->dUnits = nullptr; c->dSlots = nullptr; c->hSlots = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
-    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0;
+    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0; c->curDictEntropy = nullptr; c->curDictID = 0;
     c->seqArena = seqArena; c->litArena = litArena; c->outArena = outArena;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
@@ -305,7 +306,7 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
     static bool attrSet = false;
     if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
     hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
-                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize);
+                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
@@ -339,7 +340,7 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
                            c->dSeqs, c->dLits, c->dParse + u0);
         hipLaunchKernelGGL(zhip::k_entropy, dim3(nu), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), q,
                            srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dSeqs, c->dParse + u0, c->dLits,
-                           c->dStBits, c->dOut, c->dOutSize + u0);
+                           c->dStBits, c->dOut, c->dOutSize + u0, (const zhip::ZhipDictEntropy*)nullptr, 0u);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->cev[i], q));
         HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
@@ -427,14 +428,14 @@ size_t zhip_compress(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src
 struct zhip_cdict_s {
     zhip::HostCDict h;
     int device;
-    uint8_t* dContent; uint32_t* dTabL; uint32_t* dTabS;
+    uint8_t* dContent; uint32_t* dTabL; uint32_t* dTabS; zhip::ZhipDictEntropy* dEntropy;
 };
 
 void zhip_free_cdict(zhip_cdict* cd)
 {
     if (!cd) return;
     (void)hipSetDevice(cd->device);
-    (void)hipFree(cd->dContent); (void)hipFree(cd->dTabL); (void)hipFree(cd->dTabS);
+    (void)hipFree(cd->dContent); (void)hipFree(cd->dTabL); (void)hipFree(cd->dTabS); (void)hipFree(cd->dEntropy);
     delete cd;
 }
 
@@ -442,7 +443,7 @@ zhip_cdict* zhip_create_cdict(int device, const void* dict, size_t dictSize, int
 {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zhip_cdict* cd = new zhip_cdict_s();
-    cd->device = device; cd->dContent = nullptr; cd->dTabL = nullptr; cd->dTabS = nullptr;
+    cd->device = device; cd->dContent = nullptr; cd->dTabL = nullptr; cd->dTabS = nullptr; cd->dEntropy = nullptr;
     if (zhip::host_cdict_build(cd->h, dict, dictSize, level) != 0) { delete cd; return nullptr; }
     bool ok = hipMalloc((void**)&cd->dContent, cd->h.content.size()) == hipSuccess;
     ok = ok && hipMalloc((void**)&cd->dTabL, cd->h.tabL.size() * sizeof(uint32_t)) == hipSuccess;
@@ -450,6 +451,10 @@ zhip_cdict* zhip_create_cdict(int device, const void* dict, size_t dictSize, int
     ok = ok && hipMemcpy(cd->dContent, cd->h.content.data(), cd->h.content.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(cd->dTabL, cd->h.tabL.data(), cd->h.tabL.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(cd->dTabS, cd->h.tabS.data(), cd->h.tabS.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && cd->h.hasEntropy) {
+        ok = hipMalloc((void**)&cd->dEntropy, sizeof(zhip::ZhipDictEntropy)) == hipSuccess;
+        ok = ok && hipMemcpy(cd->dEntropy, &cd->h.ent, sizeof(zhip::ZhipDictEntropy), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) { zhip_free_cdict(cd); return nullptr; }
     return cd;
 }
@@ -525,7 +530,9 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         r = 0;
     }
     if (zhip_isError(r)) return r;
+    c->curDictEntropy = cd->dEntropy; c->curDictID = cd->h.dictID;           // the first block of every frame starts from the dictionary's entropy state
     r = launch_entropy_gather(c, (const uint8_t*)srcDev, nRec, (uint8_t*)dstDev, s);
+    c->curDictEntropy = nullptr; c->curDictID = 0;
     if (zhip_isError(r)) return r;
     if (frameSizesDev) HIPCHK(c, hipMemcpyAsync(frameSizesDev, c->dOutSize, nRec * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->hOutSize, c->dOutSize, nRec * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

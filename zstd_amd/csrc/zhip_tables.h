@@ -10,7 +10,7 @@
 
 namespace zhip {
 
-__device__ __forceinline__ uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }   // lib/common/bits.h:177
+__host__ __device__ __forceinline__ uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }   // lib/common/bits.h:177
 
 // ------------------------------------------------------------------ FSE
 struct FseCTable {            // encoder view of one FSE table (lib/common/fse.h:437-476 FSE_symbolCompressionTransform)
@@ -18,6 +18,16 @@ struct FseCTable {            // encoder view of one FSE table (lib/common/fse.h
     int32_t  dFind[56];       // deltaFindState
     uint32_t dBits[56];       // deltaNbBits
     uint32_t tableLog;
+};
+
+// The entropy state a ZDICT-format dictionary gives the first block of every frame (ZSTD_loadCEntropy,
+// lib/compress/zstd_compress.c:4986-5076): built once on the host (zhip_cdict_host.h), read by k_entropy.
+// repeat modes: 0 none, 1 "check" (usable only if it covers the block's symbols), 2 "valid" (covers every symbol).
+struct ZhipDictEntropy {
+    uint32_t hufRepeat, hufMaxSym;
+    uint32_t hufCode[256];        // value << 8 | nbBits, as EntShared::code
+    uint32_t fseRepeat[3];        // LL, OF, ML
+    FseCTable ct[3];              // LL, OF, ML
 };
 
 // lib/compress/fse_compress.c:348-369
@@ -160,7 +170,7 @@ __device__ inline uint32_t fse_write_ncount(uint8_t* out0, const int16_t* norm, 
 }
 
 // lib/compress/fse_compress.c:68-214. symScratch: >= 1<<tableLog bytes, cumul: >= maxSym+2 u16
-__device__ inline void fse_build_ctable(FseCTable* ct, const int16_t* norm, uint32_t maxSym, uint32_t tableLog,
+__host__ __device__ inline void fse_build_ctable(FseCTable* ct, const int16_t* norm, uint32_t maxSym, uint32_t tableLog,
                                         uint8_t* symScratch, uint16_t* cumul)
 {
     uint32_t const tableSize = 1u << tableLog, mask = tableSize - 1;
