@@ -96,13 +96,19 @@ def parity_check(ctx, host, dev_out, total, sizes, level=1):
 
 def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
     """BASELINE configs[4] stand-in: many ~1.2 KB JSON records (GitHub-user shaped), each its own frame, compressed with a
-    dictionary attached (ZSTD_createCDict + refCDict + compress2 per record).  Dictionary = the first ~110 KB of records as
-    raw content (ZDICT-trained entropy tables are not implemented on device yet).  One step = every record once."""
+    dictionary attached (ZSTD_createCDict + refCDict + compress2 per record).  Dictionary = the committed ZDICT-trained fixture
+    (or, with --raw-dict, the first ~110 KB of records as raw content).  One step = every record once."""
     from zstd_amd import workloads as W
     level = args.level if args.level != 1 else 3                       # configs[4] is level 3; --level 1 is the bench default
     flat, offs = W.github_like_records(args.base_records, seed=rank)
-    ndict = int(np.searchsorted(offs, 110 * 1024))
-    dict_ = flat[: int(offs[ndict])].copy()
+    zpath = os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict")
+    if os.path.exists(zpath) and not args.raw_dict:
+        dict_ = np.fromfile(zpath, dtype=np.uint8)                      # ZDICT_trainFromBuffer on 4 000 such records (tests/golden/make_dict.py)
+        ddesc = f"ZDICT-trained dictionary of {len(dict_)} B (tests/golden/github_like_110k.zdict, made with the reference's ZDICT_trainFromBuffer)"
+    else:
+        ndict = int(np.searchsorted(offs, 110 * 1024))
+        dict_ = flat[: int(offs[ndict])].copy()
+        ddesc = f"raw-content dictionary of {len(dict_)} B (the first records)"
     base_n, L = len(offs) - 1, int(offs[-1])
     copies = max(1, (args.mib << 20) // L)
     n = L * copies
@@ -163,7 +169,7 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
                "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
                "config": {"workload": f"{nrec} JSON records (GitHub-user shaped, mean {L // base_n} B; {base_n} distinct, tiled x{copies}), one frame per record, "
-                                      f"level {level}, raw-content dictionary of {len(dict_)} B attached (ZSTD_createCDict + refCDict + compress2 semantics), src+dst in HBM",
+                                      f"level {level}, {ddesc} attached (ZSTD_createCDict + refCDict + compress2 semantics), src+dst in HBM",
                           "records_per_gpu": nrec, "parallelism": f"{world} x (one process per GPU, independent records, no collective)"},
                "ratio": round(n / float(total), 4),
                "roofline": {"bound": "hbm", "kernel": "k_parse_dict", "achieved": round(algo / (parse_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -196,6 +202,7 @@ def main():
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--workload", choices=["datagen", "silesia", "text", "records"], default="datagen",
                     help="datagen = BASELINE configs[1] (default); silesia / text / records = synthetic stand-ins for configs[2] / [3] / [4]")
+    ap.add_argument("--raw-dict", action="store_true", help="records: use the first ~110 KB of records as a raw-content dictionary instead of the trained fixture")
     ap.add_argument("--base-records", type=int, default=50000, help="records: distinct ~1.2 KB records generated on the host before tiling to --mib")
     ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
     ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
