@@ -82,8 +82,10 @@ size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* 
  * produces — one frame per record, byte-identical — for records up to the reference's attach cut-off (8 KB for strategy
  * fast, 16 KB for dfast: lib/compress/zstd_compress.c:2289-2315).  The CDict's tables are built once on the host exactly
  * like ZSTD_createCDict builds them (zstd_fast.c:16-49, zstd_double_fast.c:18-54) and uploaded.
- * This round: raw-content dictionaries (ZSTD_dct_rawContent / no ZDICT magic) with levels whose CDict row is dfast
- * (level 3-4 class); anything else returns NULL / parameter_unsupported — there is no CPU fallback. */
+ * Raw-content and ZDICT-format dictionaries (entropy tables, repcodes, dictID: zstd_compress.c:4986-5118); levels whose
+ * CDict row is strategy fast or dfast (levels -N..4; zstd_fast.c:483-678, zstd_double_fast.c:328-547).  Lazy-strategy
+ * dictionaries and records above the attach cut-off (the reference's copy / extDict path) return NULL /
+ * parameter_unsupported — there is no CPU fallback. */
 typedef struct zhip_cdict_s zhip_cdict;
 zhip_cdict*  zhip_create_cdict(int device, const void* dict, size_t dictSize, int level);
 void         zhip_free_cdict(zhip_cdict* cdict);

@@ -60,7 +60,7 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
     zhip::HostCDict cd;
     int const e = zhip::host_cdict_build(cd, dict, dictSize, level);
     if (e) return e;
-    if (cd.cp.strategy != 2 || cd.len == 0) return 9;
+    if (cd.len == 0) return 9;
     uint32_t mh = 6, mc = 6;
     for (uint32_t i = 0; i < nRec; i++) {
         zhip::CParams cp; size_t const n = (size_t)(offsets[i + 1] - offsets[i]);
@@ -76,7 +76,7 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
     dv.strategy = cd.cp.strategy; dv.tabL = cd.tabL.data(); dv.tabS = cd.tabS.data(); dv.rep[0] = cd.rep[0]; dv.rep[1] = cd.rep[1]; dv.rep[2] = cd.rep[2]; dv.dictID = cd.dictID;
     std::vector<ZhipSlot> const sv = fixed_slots(nRec); const ZhipSlot* const slots = sv.data();
     const ZhipUnit* units = unitsOut;
-    simt::launch({nRec, 1, 1}, {64, 1, 1}, zhip::dict_lds_bytes(mh, mc),
+    simt::launch({nRec, 1, 1}, {64, 1, 1}, cd.cp.strategy == 1 ? zhip::dict_fast_lds_bytes(mh) : zhip::dict_lds_bytes(mh, mc),
                  [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
     return 0;
 }

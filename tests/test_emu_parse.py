@@ -123,7 +123,7 @@ def test_hashchain_parse_skip_regions_then_matches(libs, level):
     check(le, lo, [("mixed", mixed), ("mixed_short", mixed[:70001])], level)
 
 
-def test_dict_dfast_records_parse_like_the_oracle(libs):
+def test_dict_records_parse_like_the_oracle(libs):
     """k_parse_dict (dfast with an attached dictionary) on the emulator vs the oracle's dictMatchState restatement"""
     lo, le = libs
     from _libs import datagen, text_like
@@ -135,11 +135,11 @@ def test_dict_dfast_records_parse_like_the_oracle(libs):
     le.emu_parse_dict.restype = C.c_int
     le.emu_parse_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
     rng = np.random.default_rng(5)
-    for kind, level in (("text", 3), ("datagen", 3), ("text", 4)):
+    for kind, level in (("text", 3), ("datagen", 3), ("text", 4), ("text", 1), ("datagen", 1), ("text", 2), ("text", -3)):
         corpus = text_like(200000, 3) if kind == "text" else datagen(lo, 200000, 60, 3)
-        dict_ = corpus[:110000 if level == 3 else 60000].copy()
+        dict_ = corpus[:110000 if level in (3, 1) else 60000].copy()
         recs = []
-        for n in (8, 9, 10, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 16384, 12000, 300, 64):
+        for n in ((8, 9, 10, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 16384, 12000, 300, 64) if level >= 3 else (8, 9, 10, 12, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 8192, 300, 64)):
             s = int(rng.integers(0, len(corpus) - n))
             r = corpus[s:s + n].copy()
             if n > 50:

@@ -48,13 +48,16 @@ def oracle_frames(lo, dict_, recs, level):
     return out
 
 
-@pytest.mark.parametrize("kind,level,dsize", [("text", 3, 110000), ("datagen", 3, 40000), ("text", 4, 60000), ("text", 3, 9), ("text", 3, 5)])
+@pytest.mark.parametrize("kind,level,dsize", [("text", 3, 110000), ("datagen", 3, 40000), ("text", 4, 60000), ("text", 3, 9), ("text", 3, 5),
+                                              ("text", 1, 110000), ("datagen", 1, 30000), ("text", 2, 50000), ("text", -1, 20000), ("text", 1, 6)])
 def test_records_with_dictionary_match_oracle_bytes(env, kind, level, dsize):
     lo, zstd_amd, torch = env
     rng = np.random.default_rng(level * 100 + dsize % 97)
     corpus = text_like(300000, 3) if kind == "text" else datagen(lo, 300000, 60, 3)
     dict_ = corpus[:dsize].copy()
-    sizes = [0, 1, 6, 7, 8, 9, 10, 17, 64, 100, 300, 500, 1000, 1024, 1500, 2000, 4000, 8000, 12000, 16384] + [int(x) for x in rng.integers(200, 2000, size=200)]
+    sizes = [0, 1, 6, 7, 8, 9, 10, 17, 64, 100, 300, 500, 1000, 1024, 1500, 2000, 4000, 8000, 8192] + [int(x) for x in rng.integers(200, 2000, size=200)]
+    if zstd_amd.lib().zhip_getCParams(level, 200000, (C.c_uint * 7)()) == 0 and level >= 3:
+        sizes += [12000, 16384]                               # strategy dfast attaches up to 16 KB, fast up to 8 KB
     recs = records_of(corpus, rng, sizes)
     recs.append(dict_[-300:].copy() if dsize > 300 else dict_.copy())
     ctx = zstd_amd.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
@@ -81,7 +84,7 @@ def test_records_with_dictionary_match_oracle_bytes(env, kind, level, dsize):
     cd.close(); ctx.close()
 
 
-@pytest.mark.parametrize("level", [3, 4])
+@pytest.mark.parametrize("level", [3, 4, 1])
 def test_zdict_trained_dictionary_records_match_oracle_bytes(env, level):
     """ZDICT-format dictionary (tests/golden/github_like_110k.zdict, trained with the real reference): dictID in the frame
     header, repcodes from the dictionary, treeless literals and set_repeat FSE tables — byte-identical to the oracle"""
@@ -94,7 +97,7 @@ def test_zdict_trained_dictionary_records_match_oracle_bytes(env, level):
     recs = [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(400)]
     rng = np.random.default_rng(level)
     recs += [np.zeros(0, np.uint8), recs[0][:5], recs[1][:6], recs[2][:7], recs[3][:8], recs[4][:9], recs[5][:30], recs[6][:64], recs[7][:100],
-             np.concatenate(recs[8:14])[:8000], np.concatenate(recs[20:40])[:16384], rng.integers(0, 256, size=1500, dtype=np.uint8),
+             np.concatenate(recs[8:14])[:8000], np.concatenate(recs[20:40])[:16384 if level >= 3 else 8192], rng.integers(0, 256, size=1500, dtype=np.uint8),
              np.full(900, 65, np.uint8), np.full(7, 66, np.uint8), text_like(3000, 4)]
     ctx = zstd_amd.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
     cd = zstd_amd.CDict(zd, level=level)

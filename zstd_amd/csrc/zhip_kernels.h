@@ -60,8 +60,8 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     }
 }
 
-// Stage 1 for records compressed with an attached dictionary (strategy dfast), one wavefront per record.
-// Dynamic LDS = dict_lds_bytes(max hashLog, max chainLog of the records).
+// Stage 1 for records compressed with an attached dictionary (strategies fast and dfast), one wavefront per record.
+// Dynamic LDS = max(dict_lds_bytes(hashLog, chainLog), dict_fast_lds_bytes(hashLog)) over the records.
 __global__ void __launch_bounds__(64)
 k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
@@ -70,9 +70,18 @@ k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
-    if (u.strategy != ZHIP_STRAT_DFAST) return;
     const uint8_t* const p = src + u.srcOff;
     ZhipSlot const sl = slots[ui];
+    if (u.strategy == ZHIP_STRAT_FAST) {
+        switch (u.minMatch) {
+        case 5:  parse_fast_dms_unit<5>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        case 6:  parse_fast_dms_unit<6>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        case 7: case 8: parse_fast_dms_unit<7>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        default: parse_fast_dms_unit<4>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        }
+        return;
+    }
+    if (u.strategy != ZHIP_STRAT_DFAST) return;
     switch (u.minMatch) {
     case 5:  parse_dfast_dms_unit<5>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
     case 6:  parse_dfast_dms_unit<6>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;

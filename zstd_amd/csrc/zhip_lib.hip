@@ -498,7 +498,6 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
                  (unsigned long long)seqOff, (unsigned long long)litOff, (unsigned long long)outOff);
         return ZERR(ZE_srcSize_wrong);
     }
-    if (attached && (fam & 1)) { snprintf(c->err, sizeof(c->err), "strategy fast with an attached dictionary is not implemented on device yet"); return ZERR(ZE_parameter_unsupported); }
     size_t r;
     if (!attached) {
         // no dictionary content: the ordinary kernels with the CDict-derived parameters
@@ -517,7 +516,7 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         dv.content = cd->dContent; dv.len = (uint32_t)cd->h.len; dv.hashLog = cd->h.cp.hashLog; dv.chainLog = cd->h.cp.chainLog;
         dv.minMatch = cd->h.cp.minMatch; dv.strategy = cd->h.cp.strategy; dv.tabL = cd->dTabL; dv.tabS = cd->dTabS;
         dv.rep[0] = cd->h.rep[0]; dv.rep[1] = cd->h.rep[1]; dv.rep[2] = cd->h.rep[2]; dv.dictID = cd->h.dictID;
-        size_t const smem = zhip::dict_lds_bytes(mhL, mhS);
+        size_t const smem = (fam & 1) ? zhip::dict_fast_lds_bytes(mhFast) : zhip::dict_lds_bytes(mhL, mhS);
         HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nRec * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nRec * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
         if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -333,4 +333,174 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
     }
 }
 
+// ------------------------------------------------------------------ strategy fast with an attached dictionary
+// ZSTD_compressBlock_fast_dictMatchState_generic (lib/compress/zstd_fast.c:483-678).  One table for the record (LDS, 16-bit),
+// one tagged table of the dictionary; per position, in the reference's order: repcode at p+1 (:566), dictionary match — used
+// only when the record's own entry is invalid (:575-596) — then the record's own match (:598).  Positions advance like the
+// noDict dfast loop (step grows every 256 bytes without a match, :618-625), so the batching is the one of zhip_parse_dfast.h.
+__host__ __device__ inline uint32_t dict_fast_lds_bytes(uint32_t hashLog) { return (2u << hashLog) + ZHIP_DF_SCRATCH; }
+
+template <uint32_t MLS>
+__device__ inline void parse_fast_dms_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipCDictDev& cd,
+                                           unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const sh = 32 - u.hashLog, dSh = 32 - (cd.hashLog + 8);
+    uint32_t const stepSize = u.targetLength + !u.targetLength;                 // :491
+    uint32_t const dictLen = cd.len, P = dictLen + 2;
+    const uint8_t* const dict = cd.content;
+    FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
+    out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
+    lds_u16* const tab = (lds_u16*)(uintptr_t)smem;                                      // position + 1, 0 = empty
+    lds_u8* const scr = (lds_u8*)(uintptr_t)(smem + (2u << u.hashLog));
+    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
+        uint32_t const words = (2u << u.hashLog) >> 2;
+        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t anchor = 0, off1 = cd.rep[0], off2 = cd.rep[1];
+
+    if (n >= 8 + stepSize) {                 // ip1 = stepSize <= ilimit = n - 8
+    uint32_t const nm8 = n - 8;
+    int32_t const ilimit = (int32_t)nm8;
+    uint32_t ip = 0;
+    uint32_t evAvg16 = 12u << 4, kCap = 16;
+    auto rep_ptr = [&](uint32_t q, uint32_t off) -> const uint8_t* { return off > q ? dict + (dictLen + q - off) : src + (q - off); };
+    auto rep_ok = [&](uint32_t q, uint32_t off) -> bool { return (uint32_t)((P - 1) - (P + q - off)) >= 3; };
+    for (;;) {                                                               // one turn per match (:537 while (ip1 <= ilimit))
+        uint32_t step = stepSize, nextStep = ip + 256;
+        if ((int32_t)(ip + stepSize) > ilimit) break;
+        int evKind = 0;                      // 0 none, 1 repcode, 2 dictionary match, 3 record match
+        uint32_t curr = 0, candE = 0;
+        for (;;) {
+            uint32_t const p = ip + lane * step;
+            bool const inc = (int32_t)(p + step) >= (int32_t)nextStep;                    // :618 step++ after this position
+            bool const endAfter = (int32_t)(p + 2 * step + (inc ? 1u : 0u)) > ilimit;     // :624 the next position does not run
+            unsigned long long const mStop = __ballot(inc || endAfter);
+            int K = mStop ? first_lane(mStop) + 1 : 64;
+            if (K > (int)kCap) K = (int)kCap;
+            bool const lastInc = (__ballot(inc) >> (K - 1)) & 1, lastEnd = (__ballot(endAfter) >> (K - 1)) & 1;
+            unsigned long long const liveMask = below_mask(K);
+            bool const live = (int)lane < K;
+
+            uint32_t const pc = p < nm8 ? p : nm8;
+            uint64_t const bytes = ld64(src + pc);
+            uint32_t const h = hash_pos<MLS>(bytes, sh), dHT = hash_pos<MLS>(bytes, dSh);
+            uint32_t const old = live ? (uint32_t)tab[h] : 0;
+            uint32_t const dE = live ? cd.tabL[dHT >> 8] : 0;
+            uint32_t const rv = ld32(rep_ptr(pc + 1, off1));
+            uint32_t const ss = h & (ZHIP_DF_SCRATCH - 1);
+            if (live) scr[ss] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long const lose = __ballot(live && scr[ss] != (uint8_t)lane);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t cand = old;
+            uint32_t cb = old ? ld32(src + (old - 1)) : ~(uint32_t)bytes;
+            unsigned long long grp = 0;
+            if (lose) {
+                grp = lane_groups(h, lose, liveMask);
+                unsigned long long const prev = grp & below_mask((int)lane);
+                uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
+                uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd);
+                if (prev) { cand = dp + 1; cb = dlo; }
+            }
+            uint32_t const dIdx = dE >> 8;
+            bool const tagOk = live && (dE & 0xFF) == (dHT & 0xFF);
+            uint32_t db = ~(uint32_t)bytes;
+            if (tagOk && dIdx > 2) db = ld32(dict + (dIdx - 2));
+            bool const hitR = live && rep_ok(p + 1, off1) && rv == (uint32_t)(bytes >> 8);                 // :566
+            bool const hitD = tagOk && dIdx > 2 && db == (uint32_t)bytes && cand <= 1;                      // :575-583 matchIndex <= prefixStartIndex
+            bool const hitM = live && cand != 0 && cb == (uint32_t)bytes;                                   // :598 ZSTD_match4Found_cmov
+            unsigned long long const mR = __ballot(hitR), mD = __ballot(hitD), mM = __ballot(hitM);
+            unsigned long long const mAny = mR | mD | mM;
+            int const jE = mAny ? first_lane(mAny) : 64;
+            int const Lcommit = jE < 64 ? jE + 1 : K;
+            if (jE < 64) evKind = ((mR >> jE) & 1) ? 1 : (((mD >> jE) & 1) ? 2 : 3);
+            {   bool const inC = (int)lane < Lcommit;                        // :564 hashTable[hash0] = curr up to and including the event
+                unsigned long long const cm = below_mask(Lcommit) & ~below_mask((int)lane + 1);
+                if (inC && (grp & cm) == 0) tab[h] = (uint16_t)(p + 1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (evKind) {
+                evAvg16 = (3 * evAvg16 + (((uint32_t)jE + 1) << 4)) >> 2;
+                kCap = (evAvg16 >> 4) + 4; if (kCap > 64) kCap = 64;
+                curr = ip + (uint32_t)jE * step;
+                candE = __builtin_amdgcn_readlane(evKind == 2 ? dIdx : cand, jE);
+                break;
+            }
+            ip = ip + (uint32_t)K * step;
+            kCap = kCap * 2 > 64 ? 64 : kCap * 2;
+            if (lastEnd) break;
+            if (lastInc) { step++; nextStep += 256; }
+        }
+        if (evKind == 0) break;
+
+        uint32_t mLength, offBase, mstart = curr;
+        if (evKind == 1) {                                                   // :566-573
+            mstart = curr + 1;
+            uint32_t const q = mstart + 4;
+            if (off1 > mstart) mLength = 4 + wave_count_2seg(src, n, q, dict, dictLen, dictLen + mstart - off1 + 4);
+            else mLength = 4 + wave_count_cross(src + q, n - q, src + (q - off1), n - (q - off1));
+            offBase = 1;
+        } else {
+            uint32_t offset;
+            if (evKind == 2) {                                               // :584-595 dictionary match
+                uint32_t const dPos = candE - 2;
+                mLength = 4 + wave_count_2seg(src, n, curr + 4, dict, dictLen, dPos + 4);
+                offset = (P + curr) - candE;
+                uint32_t const lim = (curr - anchor) < dPos ? (curr - anchor) : dPos;
+                uint32_t const back = wave_count_back_cross(src, curr, dict, dPos, lim);
+                mstart = curr - back; mLength += back;
+            } else {                                                         // :598-611
+                uint32_t const m = candE - 1;
+                mLength = 4 + wave_count_cross(src + curr + 4, n - curr - 4, src + m + 4, n - m - 4);
+                offset = curr - m;
+                uint32_t const lim = (curr - anchor) < m ? (curr - anchor) : m;
+                uint32_t const back = wave_count_back(src, curr, m, lim);
+                mstart = curr - back; mLength += back;
+            }
+            off2 = off1; off1 = offset;
+            offBase = offset + 3;
+        }
+        lits_copy(out, src, nm8, anchor, mstart - anchor);
+        store_seq(out, mstart - anchor, offBase, mLength);
+        ip = mstart + mLength; anchor = ip;
+
+        if ((int32_t)ip <= ilimit) {                                         // :635-663
+            {   uint32_t const q = lane == 0 ? curr + 2 : ip - 2;
+                uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
+                uint32_t const hh = hash_pos<MLS>(b, sh);
+                if (lane == 0) tab[hh] = (uint16_t)(q + 1);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 1) tab[hh] = (uint16_t)(q + 1);
+                __builtin_amdgcn_wave_barrier();
+            }
+            while ((int32_t)ip <= ilimit) {
+                uint64_t const b = ld64(src + ip);
+                if (!rep_ok(ip, off2) || (uint32_t)b != uni(ld32(rep_ptr(ip, off2)))) break;
+                uint32_t rl;
+                if (off2 > ip) rl = 4 + wave_count_2seg(src, n, ip + 4, dict, dictLen, dictLen + ip - off2 + 4);
+                else rl = 4 + wave_count_cross(src + ip + 4, n - ip - 4, src + (ip + 4 - off2), n - (ip + 4 - off2));
+                {   uint32_t const t = off2; off2 = off1; off1 = t; }
+                if (lane == 0) tab[hash_pos<MLS>(b, sh)] = (uint16_t)(ip + 1);
+                __builtin_amdgcn_wave_barrier();
+                store_seq(out, 0, 1, rl);
+                ip += rl; anchor = ip;
+            }
+        }
+    }
+    lits_copy(out, src, nm8, anchor, n - anchor);
+    lits_flush(out);
+    } else {
+        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];
+        out.litPos = n;
+    }
+    if (lane == 0) {
+        meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
+        meta->longPos = out.longPos; meta->longType = out.longType;
+        meta->rep[0] = off1; meta->rep[1] = off2; meta->rep[2] = cd.rep[2];
+        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
+    }
+}
+
 }  // namespace zhip
