@@ -52,7 +52,7 @@ def oracle_frames(lo, dict_, recs, level):
                                               ("text", 1, 110000), ("datagen", 1, 30000), ("text", 2, 50000), ("text", -1, 20000), ("text", 1, 6)])
 def test_records_with_dictionary_match_oracle_bytes(env, kind, level, dsize):
     lo, zstd_amd, torch = env
-    rng = np.random.default_rng(level * 100 + dsize % 97)
+    rng = np.random.default_rng(abs(level) * 100 + dsize % 97)
     corpus = text_like(300000, 3) if kind == "text" else datagen(lo, 300000, 60, 3)
     dict_ = corpus[:dsize].copy()
     sizes = [0, 1, 6, 7, 8, 9, 10, 17, 64, 100, 300, 500, 1000, 1024, 1500, 2000, 4000, 8000, 8192] + [int(x) for x in rng.integers(200, 2000, size=200)]
