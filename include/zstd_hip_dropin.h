@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 typedef struct ZSTD_CCtx_s ZSTD_CCtx;                                   /* lib/zstd.h:262 */
+typedef struct ZSTD_CDict_s ZSTD_CDict;                                 /* lib/zstd.h:998 */
 typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_reset_session_and_parameters = 3 } ZSTD_ResetDirective;   /* :569 */
 /* ZSTD_cParameter values this shim understands (lib/zstd.h:331-507); all others -> parameter_unsupported */
 enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
@@ -39,6 +40,12 @@ size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t
 size_t      ZSTD_compressBound(size_t srcSize);                                                    /* :236 (here: the bound of the frame-per-unit stream, >= the reference's) */
 unsigned    ZSTD_isError(size_t code);                                                             /* :243 */
 const char* ZSTD_getErrorName(size_t code);                                                        /* :244 */
+/* dictionaries: raw-content and ZDICT-format, CDict levels whose row is fast/dfast, sources up to the reference's attach
+ * cut-off (8 KB fast / 16 KB dfast) — byte-identical to the reference; anything else -> NULL / parameter_unsupported */
+ZSTD_CDict* ZSTD_createCDict(const void* dictBuffer, size_t dictSize, int compressionLevel);       /* :979 */
+size_t      ZSTD_freeCDict(ZSTD_CDict* CDict);                                                     /* :985 */
+size_t      ZSTD_CCtx_refCDict(ZSTD_CCtx* cctx, const ZSTD_CDict* cdict);                          /* :1102 */
+size_t      ZSTD_compress_usingCDict(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_CDict* cdict);   /* :992 */
 int         ZSTD_minCLevel(void);                                                                  /* :245 */
 int         ZSTD_maxCLevel(void);                                                                  /* :246 (highest level the device core implements) */
 int         ZSTD_defaultCLevel(void);                                                              /* :247 */

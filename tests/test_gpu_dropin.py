@@ -122,3 +122,47 @@ def test_errors_use_the_reference_codes_and_nothing_falls_back_to_the_host(env):
     want = expect_unit(lo, lr, a, 1)
     r, dst = shim_compress2(S, a, 1, cap=len(want))                    # exactly enough, below ZSTD_compressBound
     assert not S.ZSTD_isError(r) and dst[:r].tobytes() == want
+
+
+def test_cdict_entry_points_match_the_reference(env):
+    """ZSTD_createCDict / ZSTD_CCtx_refCDict / ZSTD_compress2 / ZSTD_compress_usingCDict of the shim vs the real library
+    (or the oracle where oracle/_ref is absent): trained ZDICT fixture, JSON records"""
+    import sys
+    S, lo, lr = env
+    sys.path.insert(0, ROOT)
+    from zstd_amd import workloads as W
+    S.ZSTD_createCDict.restype = C.c_void_p
+    S.ZSTD_createCDict.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    S.ZSTD_freeCDict.argtypes = [C.c_void_p]
+    S.ZSTD_CCtx_refCDict.restype = C.c_size_t
+    S.ZSTD_CCtx_refCDict.argtypes = [C.c_void_p, C.c_void_p]
+    S.ZSTD_compress_usingCDict.restype = C.c_size_t
+    S.ZSTD_compress_usingCDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    zd = np.fromfile(os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    flat, offs = W.github_like_records(40, seed=11)
+    recs = [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(40)]
+    lo.zo_cdict_create.restype = C.c_void_p
+    lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_compress_unit_cdict.restype = C.c_size_t
+    lo.zo_compress_unit_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    ocd = lo.zo_cdict_create(_buf(zd), len(zd), 3)
+    cd = S.ZSTD_createCDict(_buf(zd), len(zd), 3)
+    assert cd
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_CCtx_refCDict(c, cd) == 0
+    for i, r in enumerate(recs):
+        cap = S.ZSTD_compressBound(len(r))
+        dst = np.zeros(cap, dtype=np.uint8)
+        k = S.ZSTD_compress2(c, _buf(dst), cap, _buf(r), len(r)) if i % 2 == 0 else S.ZSTD_compress_usingCDict(c, _buf(dst), cap, _buf(r), len(r), cd)
+        assert not S.ZSTD_isError(k), S.ZSTD_getErrorName(k)
+        want = np.zeros(len(r) + 700, dtype=np.uint8)
+        w = lo.zo_compress_unit_cdict(_buf(want), len(want), _buf(r), len(r), ocd)
+        assert dst[:k].tobytes() == want[:w].tobytes(), i
+    big = np.concatenate(recs)[:30000]
+    dst = np.zeros(S.ZSTD_compressBound(len(big)), dtype=np.uint8)
+    k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))       # above the attach cut-off: no copy path on device
+    assert S.ZSTD_isError(k) and b"Unsupported" in S.ZSTD_getErrorName(k)
+    assert S.ZSTD_CCtx_reset(c, 3) == 0                                     # parameters reset: the dictionary is dropped
+    k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))
+    assert not S.ZSTD_isError(k)
+    S.ZSTD_freeCCtx(c); S.ZSTD_freeCDict(cd)

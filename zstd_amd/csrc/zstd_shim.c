@@ -11,10 +11,12 @@
 #define SHIM_ERR(code) ((size_t)-(long)(code))
 enum { E_GENERIC = 1, E_parameter_unsupported = 40, E_parameter_outOfBound = 42, E_stage_wrong = 60, E_memory_allocation = 64 };   /* lib/zstd_errors.h:60-101 */
 
+struct ZSTD_CDict_s { zhip_cdict* d; };
 struct ZSTD_CCtx_s {
     zhip_ctx* z;
     size_t    zUnits;
     int       level;                 /* ZSTD_c_compressionLevel; 0 means default (3), lib/zstd.h:337-349 */
+    const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
 
 static int shim_device(void) { const char* e = getenv("ZHIP_DEVICE"); return e ? atoi(e) : 0; }
@@ -33,7 +35,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 {
     if (!c) return SHIM_ERR(E_GENERIC);
-    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) c->level = 3;
+    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; }
     return 0;
 }
 size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
@@ -53,11 +55,8 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     }
 }
 
-static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
+static size_t shim_ensure(ZSTD_CCtx* c, size_t units)
 {
-    size_t const units = n ? (n + SHIM_UNIT - 1) / SHIM_UNIT : 1;
-    if (!c) return SHIM_ERR(E_GENERIC);
-    if (level == 0) level = 3;
     if (!c->z || c->zUnits < units) {
         size_t want = units < 64 ? 64 : units;
         if (c->z) { zhip_destroy(c->z); c->z = NULL; }
@@ -65,6 +64,35 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
         if (!c->z) return SHIM_ERR(E_memory_allocation);
         c->zUnits = want;
     }
+    return 0;
+}
+
+/* one source compressed with an attached dictionary = one record of the device's records path (include/zstd_hip.h);
+ * sources above the reference's attach cut-off would take its copy path, which the device core lacks -> parameter_unsupported */
+static size_t shim_compress_cdict(ZSTD_CCtx* c, const ZSTD_CDict* cd, void* dst, size_t cap, const void* src, size_t n)
+{
+    unsigned long long offs[2];
+    size_t need, r;
+    if (!c || !cd || !cd->d) return SHIM_ERR(E_GENERIC);
+    {   size_t const e = shim_ensure(c, 1); if (zhip_isError(e)) return e; }
+    offs[0] = 0; offs[1] = n;
+    need = zhip_records_bound(offs, 1);
+    if (cap >= need) return zhip_compress_records(c->z, cd->d, dst, cap, src, offs, 1, NULL);
+    {   void* tmp = malloc(need ? need : 1);
+        if (!tmp) return SHIM_ERR(E_memory_allocation);
+        r = zhip_compress_records(c->z, cd->d, tmp, need, src, offs, 1, NULL);
+        if (!zhip_isError(r)) { if (r <= cap) memcpy(dst, tmp, r); else r = SHIM_ERR(70 /* dstSize_tooSmall */); }
+        free(tmp);
+        return r;
+    }
+}
+
+static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
+{
+    size_t const units = n ? (n + SHIM_UNIT - 1) / SHIM_UNIT : 1;
+    if (!c) return SHIM_ERR(E_GENERIC);
+    if (level == 0) level = 3;
+    {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
     /* zhip_compress wants room for its own bound; the reference only needs ZSTD_compressBound(n) for a guaranteed
        success and otherwise tries — give the device a private bounce buffer when the caller's is smaller */
     {   size_t const need = zhip_compressBound(n, SHIM_UNIT);
@@ -80,7 +108,36 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
     }
 }
 
-size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n) { return shim_compress(c, dst, cap, src, n, c ? c->level : 3); }
+size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n)
+{
+    if (c && c->cdict) return shim_compress_cdict(c, c->cdict, dst, cap, src, n);   /* the CDict's level takes priority (zstd_compress.c:6276-6282) */
+    return shim_compress(c, dst, cap, src, n, c ? c->level : 3);
+}
+
+/* ---- dictionaries (lib/zstd.h:979-995, :1102) */
+ZSTD_CDict* ZSTD_createCDict(const void* dict, size_t dictSize, int level)
+{
+    ZSTD_CDict* cd = (ZSTD_CDict*)calloc(1, sizeof(*cd));
+    if (!cd) return NULL;
+    cd->d = zhip_create_cdict(shim_device(), dict, dictSize, level);
+    if (!cd->d) { free(cd); return NULL; }
+    return cd;
+}
+size_t ZSTD_freeCDict(ZSTD_CDict* cd)
+{
+    if (cd) { zhip_free_cdict(cd->d); free(cd); }
+    return 0;
+}
+size_t ZSTD_CCtx_refCDict(ZSTD_CCtx* c, const ZSTD_CDict* cd)
+{
+    if (!c) return SHIM_ERR(E_GENERIC);
+    c->cdict = cd;
+    return 0;
+}
+size_t ZSTD_compress_usingCDict(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, const ZSTD_CDict* cd)
+{
+    return shim_compress_cdict(c, cd, dst, cap, src, n);
+}
 size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level) { return shim_compress(c, dst, cap, src, n, level); }   /* ignores the cctx's parameters, like the reference (zstd_compress.c:5428) */
 size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level)
 {
@@ -95,5 +152,6 @@ size_t ZSTD_compressBound(size_t n) { return zhip_compressBound(n, SHIM_UNIT); }
 unsigned ZSTD_isError(size_t code) { return zhip_isError(code); }
 const char* ZSTD_getErrorName(size_t code) { return zhip_getErrorName(code); }
 int ZSTD_minCLevel(void) { return -131072; }                      /* -ZSTD_TARGETLENGTH_MAX, lib/zstd.h:1269 */
-int ZSTD_maxCLevel(void) { return 4; }                            /* fast + dfast rows; level 4 below 16 KB is greedy and fails with parameter_unsupported */
+int ZSTD_maxCLevel(void) { return 10; }                           /* fast, dfast and the hash-chain greedy/lazy/lazy2 rows of units <= 128 KB; levels >= 5 reproduce the
+                                                                      reference with ZSTD_c_useRowMatchFinder = ZSTD_ps_disable; small units at 9-10 (btlazy2) -> parameter_unsupported */
 int ZSTD_defaultCLevel(void) { return 3; }
