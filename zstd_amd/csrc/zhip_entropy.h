@@ -343,9 +343,13 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 }
             }
         }
-        if (useOld) { for (int s = 0; s < 256; s++) sh->code[s] = de->hufCode[s]; sh->hufHdrSize = 0; sh->litType = 3; }   // set_repeat: treeless literals
+        if (useOld) { sh->hufHdrSize = 0; sh->litType = 3; }                 // set_repeat: treeless literals; the wave copies the code below
         sh->litMode = mode;
         ZPROF_JOB_MARK(31);
+    }
+    if (wv == 0 && de) {                     // the dictionary's Huffman code, copied by the whole wavefront when lane 0 chose it
+        __builtin_amdgcn_wave_barrier();
+        if (sh->litMode == 2 && sh->litType == 3) for (int s = lane; s < 256; s += 64) sh->code[s] = de->hufCode[s];
     }
     if (wv >= 1 && nbSeq > 0) {
         int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
@@ -401,7 +405,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 type = basicCost <= compressedCost ? 0 : 2;                            // :217-222
             }
             if (type == 3) {           // zstd_compress_sequences.c:264-266: the previous table as it is, no header bytes
-                sh->ct[k] = de->ct[k];
+                                       // (copied below by the whole wavefront)
             } else if (type == 1) {    // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
                 fse_build_ctable_rle(&sh->ct[k], max);
                 sh->ncount[k][0] = (uint8_t)max;
@@ -423,6 +427,12 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
         }
         __builtin_amdgcn_wave_barrier();
+        if (sh->encType[k] == 3) {
+            const uint32_t* const from = (const uint32_t*)&de->ct[k];
+            uint32_t* const to = (uint32_t*)&sh->ct[k];
+            for (uint32_t i = (uint32_t)lane; i < sizeof(FseCTable) / 4; i += 64) to[i] = from[i];
+            __builtin_amdgcn_wave_barrier();
+        }
         ZPROF_JOB_MARK(29);
         if (sh->encType[k] != 9) {
             // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
