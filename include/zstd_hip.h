@@ -76,6 +76,22 @@ size_t       zhip_prepare_sequences(zhip_ctx* ctx, const void* src, size_t srcSi
 size_t       zhip_parse_device(zhip_ctx* ctx, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream);
 size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* out, size_t capacity);
 
+/* ---- ZSTD_c_checksumFlag (lib/zstd.h:449; what the zstd CLI turns on by default, programs/fileio.c:287): when enabled every
+ * frame this context emits carries the 32-bit content checksum (low half of XXH64, computed on the device: k_xxh64) and the
+ * descriptor bit, exactly as lib/compress/zstd_compress.c:4637 / :5297-5303 write them.  Sticky until changed.  Returns 0. */
+int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
+
+/* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a
+ * skippable frame holding the seek table — the natural on-disk form of frame-per-unit output; the reference's
+ * ZSTD_seekable_decompress (contrib/seekable_format/zstdseek_decompress.c) reads it.  zhip_write_seek_table emits exactly
+ * the bytes ZSTD_seekable_writeSeekTable (zstdseek_compress.c) does for the same frame log. */
+size_t       zhip_seek_table_bound(size_t nFrames, int withChecksum);
+size_t       zhip_write_seek_table(void* dst, size_t dstCapacity, const unsigned* compressedSizes, const unsigned* decompressedSizes,
+                                   const unsigned* checksums /* NULL = no checksum column */, size_t nFrames);
+/* zhip_compress (host buffers) + the seek table appended; per-frame checksums go into the table when
+ * zhip_set_frame_checksum is on.  dstCapacity >= zhip_compressBound(..) + zhip_seek_table_bound(nUnits, 1). */
+size_t       zhip_compress_seekable(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, size_t unitSize);
+
 /* ---- dictionary compression of many small records (BASELINE configs[4]): what
  *      cdict = ZSTD_createCDict(dict, dictSize, level);                      lib/zstd.h:1006
  *      ZSTD_CCtx_refCDict(cctx, cdict); ZSTD_compress2(cctx, ..record..)     lib/zstd.h:1180, :603    per record

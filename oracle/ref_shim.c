@@ -27,6 +27,7 @@
 #include "huf.h"
 #include "fse.h"
 #include "zdict.h"
+#include "zstd_seekable.h"
 
 static void set_level(ZSTD_CCtx* c, int level)
 {
@@ -148,6 +149,47 @@ size_t zref_train_dict(void* dictBuf, size_t dictCap, const void* samples, const
 {
     size_t const r = ZDICT_trainFromBuffer(dictBuf, dictCap, samples, sampleSizes, nbSamples);
     return ZDICT_isError(r) ? (size_t)-1 : r;
+}
+
+/* O1 with ZSTD_c_checksumFlag = 1 (what the zstd CLI does by default, programs/fileio.c:287) */
+size_t zref_compress_chunks_checksum(int level, size_t chunkSize, const void* src, size_t n, void* dst, size_t dstCap, size_t* sizes, size_t maxChunks)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0, k = 0;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, 1);
+    do {
+        size_t const len = (n - off < chunkSize) ? n - off : chunkSize;
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, len);
+        if (ZSTD_isError(r)) { ZSTD_freeCCtx(c); return (size_t)-1; }
+        if (sizes && k < maxChunks) sizes[k] = r;
+        k++; pos += r; off += len;
+    } while (off < n);
+    ZSTD_freeCCtx(c);
+    return pos;
+}
+
+/* contrib/seekable_format: the reference's own seek-table writer (frame log API) and seekable decoder */
+size_t zref_seek_table(void* dst, size_t cap, const unsigned* cs, const unsigned* ds, const unsigned* ck, unsigned n)
+{
+    ZSTD_frameLog* fl = ZSTD_seekable_createFrameLog(ck != NULL);
+    ZSTD_outBuffer out = { dst, cap, 0 };
+    unsigned i; size_t r;
+    for (i = 0; i < n; i++) ZSTD_seekable_logFrame(fl, cs[i], ds[i], ck ? ck[i] : 0);
+    r = ZSTD_seekable_writeSeekTable(fl, &out);
+    ZSTD_seekable_freeFrameLog(fl);
+    return (ZSTD_isError(r) || r != 0) ? (size_t)-1 : out.pos;
+}
+size_t zref_seekable_read(void* dst, size_t len, const void* src, size_t n, unsigned long long offset, unsigned* nFrames)
+{
+    ZSTD_seekable* zs = ZSTD_seekable_create();
+    size_t r = ZSTD_seekable_initBuff(zs, src, n);
+    if (ZSTD_isError(r)) { ZSTD_seekable_free(zs); return (size_t)-1; }
+    if (nFrames) *nFrames = ZSTD_seekable_getNumFrames(zs);
+    r = ZSTD_seekable_decompress(zs, dst, len, offset);
+    ZSTD_seekable_free(zs);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
 }
 
 /* whole buffer as ONE frame (the conventional `zstd -b#` figure; NOT the parity target) */

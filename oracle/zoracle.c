@@ -1900,6 +1900,39 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
     return (size_t)(op + 3 + cSize - dst);
 }
 
+/* XXH64 (lib/common/xxhash.h, the public-domain algorithm of the xxHash specification, seed = 0 for zstd frames) */
+static uint64_t xxh_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * 0xC2B2AE3D27D4EB4FULL; return xxh_rotl(acc, 31) * 0x9E3779B185EBCA87ULL; }
+uint64_t zo_xxh64(const void* srcv, size_t n, uint64_t seed)
+{
+    uint64_t const P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    const uint8_t* p = (const uint8_t*)srcv; const uint8_t* const end = p + n;
+    uint64_t h;
+    if (n >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do { v1 = xxh_round(v1, rd64(p)); v2 = xxh_round(v2, rd64(p + 8)); v3 = xxh_round(v3, rd64(p + 16)); v4 = xxh_round(v4, rd64(p + 24)); p += 32; } while (p + 32 <= end);
+        h = xxh_rotl(v1, 1) + xxh_rotl(v2, 7) + xxh_rotl(v3, 12) + xxh_rotl(v4, 18);
+        h = (h ^ xxh_round(0, v1)) * P1 + P4; h = (h ^ xxh_round(0, v2)) * P1 + P4;
+        h = (h ^ xxh_round(0, v3)) * P1 + P4; h = (h ^ xxh_round(0, v4)) * P1 + P4;
+    } else h = seed + P5;
+    h += (uint64_t)n;
+    while (p + 8 <= end) { h ^= xxh_round(0, rd64(p)); h = xxh_rotl(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = xxh_rotl(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p++) * P5; h = xxh_rotl(h, 11) * P1; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+/* ZSTD_c_checksumFlag = 1 (zstd_compress.c:4637, :5297-5303): descriptor bit 2 + LE32 of the low half of XXH64(content) after
+ * the last block; nothing else in the frame changes */
+size_t zo_frame_add_checksum(void* framev, size_t frameSize, const void* src, size_t n)
+{
+    uint8_t* const f = (uint8_t*)framev;
+    f[4] |= 1u << 2;
+    wr32(f + frameSize, (uint32_t)zo_xxh64(src, n, 0));
+    return frameSize + 4;
+}
+
 size_t zo_compress_unit(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     zo_cparams cp;

@@ -67,6 +67,11 @@ size_t zo_compress_unit_params(void* dst, size_t cap, const void* src, size_t n,
 size_t zo_compress_chunks(int level, size_t chunkSize, const void* src, size_t n,
                           void* dst, size_t cap, size_t* sizes, size_t maxChunks);
 
+/* frame checksum (ZSTD_c_checksumFlag): XXH64 restated; zo_frame_add_checksum turns a frame made by the functions above into
+ * the one the reference emits with the flag set (needs 4 spare bytes after frameSize) */
+uint64_t zo_xxh64(const void* src, size_t n, uint64_t seed);
+size_t   zo_frame_add_checksum(void* frame, size_t frameSize, const void* src, size_t n);
+
 /* Dictionary compression, attach mode (zstd_fast.c:483-678, zstd_double_fast.c:328-547, fill functions
  * zstd_fast.c:16-49 / zstd_double_fast.c:18-54, parameters zstd_compress.c:1466-1602 + :2318-2376): what
  * ZSTD_createCDict(dict, size, level) + ZSTD_CCtx_refCDict + ZSTD_compress2 emit for one small source. */

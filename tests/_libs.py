@@ -217,7 +217,7 @@ def emu_parse_units(le, src, units, seqs, lits, metas):
         le.emu_parse_dfast(_buf(src), _buf(units), nu, _buf(tabs), stride, _buf(seqs), _buf(lits), _buf(metas), 0)
 
 
-def emu_compress_units(le, lo, bufs, level):
+def emu_compress_units(le, lo, bufs, level, checksum=False):
     """run stage 1 + stage 2 of the product kernels on the emulator; returns list of frame bytes"""
     le.emu_entropy.restype = None
     le.emu_entropy.argtypes = [C.c_void_p] * 2 + [C.c_uint] + [C.c_void_p] * 6 + [C.c_int]
@@ -234,5 +234,14 @@ def emu_compress_units(le, lo, bufs, level):
     stb = np.full(nu * 3 * cap, 0xEEEE, dtype=np.uint16)
     out = np.full(nu * ostride, 0xEE, dtype=np.uint8)
     osz = np.zeros(nu, dtype=np.uint32)
-    le.emu_entropy(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), _buf(lits), _buf(stb), _buf(out), _buf(osz), 0)
+    if checksum:
+        chk = np.zeros(nu + 16, dtype=np.uint32)
+        le.emu_xxh64.restype = None
+        le.emu_xxh64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64(_buf(src), _buf(units), nu, _buf(chk), 0)
+        le.emu_entropy_ck.restype = None
+        le.emu_entropy_ck.argtypes = [C.c_void_p] * 2 + [C.c_uint] + [C.c_void_p] * 7 + [C.c_int]
+        le.emu_entropy_ck(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), _buf(lits), _buf(stb), _buf(out), _buf(osz), _buf(chk), 0)
+    else:
+        le.emu_entropy(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), _buf(lits), _buf(stb), _buf(out), _buf(osz), 0)
     return [out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nu)]

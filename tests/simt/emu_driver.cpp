@@ -82,12 +82,25 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
 }
 
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
+// XXH64 of every unit (frame checksums)
+void emu_xxh64(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* checks, int osThreads)
+{
+    simt::launch({(nUnits + 15) / 16, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_xxh64(src, units, nUnits, checks); }, osThreads);
+}
+
+void emu_entropy_ck(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
+                    const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, const uint32_t* checks, int osThreads);
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
                  const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, int osThreads)
 {
+    emu_entropy_ck(src, units, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, osThreads);
+}
+void emu_entropy_ck(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
+                    const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, const uint32_t* checks, int osThreads)
+{
     std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
-                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u); }, osThreads);
+                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u, checks); }, osThreads);
 }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }

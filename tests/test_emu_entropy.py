@@ -73,3 +73,21 @@ def test_frames_hashchain_levels(libs, level):
     cases = [c for c in cases if 3 <= strat(len(c[1])) <= 5]
     assert cases
     check(lo, le, cases, level)
+
+
+def test_frames_with_content_checksum(libs):
+    """ZSTD_c_checksumFlag: k_xxh64 + the checksum epilogue, vs the oracle's XXH64 restatement (pinned to the reference)"""
+    import ctypes as C
+    lo, le = libs
+    lo.zo_frame_add_checksum.restype = C.c_size_t
+    lo.zo_frame_add_checksum.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    cases = []
+    for n in (0, 1, 3, 4, 7, 8, 12, 31, 32, 33, 63, 64, 100, 129, 1000, 4099, 70001, 131072):
+        cases += list(corpus_cases(lo, sizes=(n,), seeds=(9,)))[:5]
+    frames = emu_compress_units(le, lo, [c[1] for c in cases], 1, checksum=True)
+    for (name, a), f in zip(cases, frames):
+        cap = lo.zo_compress_bound(len(a)) + 64
+        dst = np.zeros(cap, dtype=np.uint8)
+        r = lo.zo_compress_unit(_buf(dst), cap, _buf(a), len(a), 1)
+        r = lo.zo_frame_add_checksum(_buf(dst), r, _buf(a), len(a))
+        assert f == dst[:r].tobytes(), name

@@ -139,6 +139,67 @@ def test_level4_mixes_dfast_units_with_a_greedy_tail(env):
     assert got == want, first_diff(got, want)
 
 
+def test_frame_checksum_flag(env):
+    """ZSTD_c_checksumFlag: every frame ends with XXH64's low 32 bits; bytes = oracle (+ the real reference when present)"""
+    lo, ctx, torch = env
+    lo.zo_frame_add_checksum.restype = C.c_size_t
+    lo.zo_frame_add_checksum.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    a = np.concatenate([datagen(lo, 131072 * 5 + 777, 50, 8)])
+    ctx.set_checksum(True)
+    try:
+        got, sizes = ctx.compress(a, level=3, return_sizes=True)
+    finally:
+        ctx.set_checksum(False)
+    want = b""
+    for off in range(0, len(a), 131072):
+        u = a[off:off + 131072]
+        dst = np.zeros(len(u) + 700, dtype=np.uint8)
+        r = lo.zo_compress_unit(_buf(dst), len(dst), _buf(u), len(u), 3)
+        r = lo.zo_frame_add_checksum(_buf(dst), r, _buf(u), len(u))
+        want += dst[:r].tobytes()
+    assert got == want, first_diff(got, want)
+    if have_ref():
+        lr = load_ref()
+        lr.zref_compress_chunks_checksum.restype = C.c_size_t
+        lr.zref_compress_chunks_checksum.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        ref = np.zeros(len(a) + 4096, dtype=np.uint8)
+        k = lr.zref_compress_chunks_checksum(3, 131072, _buf(a), len(a), _buf(ref), len(ref), None, 0)
+        assert got == ref[:k].tobytes()
+    dec = system_decompress(got, len(a))          # the decoder verifies the checksums
+    if dec is not None:
+        assert dec.tobytes() == a.tobytes()
+    assert ctx.compress(a[:1000], level=1) == oracle_chunks(lo, a[:1000], 1)[0]      # flag is off again
+
+
+@pytest.mark.parametrize("checksum", [False, True])
+def test_seekable_container_reads_back_through_the_reference_decoder(env, checksum):
+    """frames + seek table (contrib/seekable_format): random-access reads with the reference's ZSTD_seekable_decompress"""
+    lo, ctx, torch = env
+    if not have_ref():
+        pytest.skip("reference build (oracle/_ref) not present")
+    lr = load_ref()
+    lr.zref_seekable_read.restype = C.c_size_t
+    lr.zref_seekable_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_ulonglong, C.c_void_p]
+    a = datagen(lo, 131072 * 7 + 4321, 50, 12)
+    ctx.set_checksum(checksum)
+    try:
+        blob = ctx.compress_seekable(a, level=1)
+    finally:
+        ctx.set_checksum(False)
+    src = np.frombuffer(blob, dtype=np.uint8)
+    assert blob[-4:] == (0x8F92EAB1).to_bytes(4, "little")
+    nf = C.c_uint(0)
+    rng = np.random.default_rng(1)
+    for off, ln in [(0, 100), (131072 - 50, 100), (131072 * 3 + 17, 300000), (len(a) - 77, 77)] + [(int(o), 5000) for o in rng.integers(0, len(a) - 5000, size=6)]:
+        out = np.zeros(ln, dtype=np.uint8)
+        r = lr.zref_seekable_read(_buf(out), ln, _buf(src), len(src), off, C.byref(nf))
+        assert r == ln and out.tobytes() == a[off:off + ln].tobytes(), (off, ln, r)
+    assert nf.value == 8
+    dec = system_decompress(blob, len(a))          # a plain decoder skips the skippable frame
+    if dec is not None:
+        assert dec.tobytes() == a.tobytes()
+
+
 def test_multi_unit_stream_device_api_and_roundtrip(env):
     lo, ctx, torch = env
     import zstd_amd

@@ -7,7 +7,7 @@ import re
 import subprocess
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, _buf, ROOT
+from _libs import load_oracle, load_ref, have_ref, _buf, ROOT, ERR
 
 
 @pytest.fixture(scope="module")
@@ -109,3 +109,26 @@ def test_calls_fail_loudly_without_a_gpu(zlib_):
         pytest.skip("GPU present")
     with pytest.raises(zlib_.ZhipError):
         zlib_.Context(0, 4)
+
+
+def test_seek_table_bytes_match_the_reference_writer(zlib_):
+    """zhip_write_seek_table == ZSTD_seekable_writeSeekTable (contrib/seekable_format/zstdseek_compress.c) on the same frame log"""
+    if not have_ref():
+        pytest.skip("reference build (oracle/_ref) not present")
+    lr = load_ref()
+    lr.zref_seek_table.restype = C.c_size_t
+    lr.zref_seek_table.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+    L = zlib_.lib()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 17, 1000):
+        cs = rng.integers(10, 140000, size=max(n, 1), dtype=np.uint32)
+        ds = rng.integers(0, 131073, size=max(n, 1), dtype=np.uint32)
+        ck = rng.integers(0, 2**32, size=max(n, 1), dtype=np.uint64).astype(np.uint32)
+        for with_ck in (False, True):
+            cap = L.zhip_seek_table_bound(n, 1)
+            mine = np.zeros(cap, dtype=np.uint8)
+            ref = np.zeros(cap + 64, dtype=np.uint8)
+            r = L.zhip_write_seek_table(_buf(mine), cap, _buf(cs), _buf(ds), _buf(ck) if with_ck else None, n)
+            k = lr.zref_seek_table(_buf(ref), len(ref), _buf(cs), _buf(ds), _buf(ck) if with_ck else None, n)
+            assert k != ERR and r == k == L.zhip_seek_table_bound(n, int(with_ck))
+            assert mine[:r].tobytes() == ref[:k].tobytes(), (n, with_ck)

@@ -60,6 +60,10 @@ def lib():
             ("zhip_compress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]),
             ("zhip_compress_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
             ("zhip_prepare_sequences", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+            ("zhip_set_frame_checksum", C.c_int, [C.c_void_p, C.c_int]),
+            ("zhip_seek_table_bound", C.c_size_t, [C.c_size_t, C.c_int]),
+            ("zhip_write_seek_table", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+            ("zhip_compress_seekable", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]),
             ("zhip_create_cdict", C.c_void_p, [C.c_int, C.c_void_p, C.c_size_t, C.c_int]),
             ("zhip_free_cdict", None, [C.c_void_p]),
             ("zhip_create_for_records", C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t]),
@@ -153,6 +157,10 @@ class Context:
         lib().zhip_last_timing(self._h, t)
         return {"parse_ms": t[0], "entropy_ms": t[1], "gather_ms": t[2], "total_ms": t[3]}
 
+    def set_checksum(self, enable=True):
+        """ZSTD_c_checksumFlag: every frame carries XXH64's low 32 bits of its content"""
+        lib().zhip_set_frame_checksum(self._h, 1 if enable else 0)
+
     def hc_timing(self):
         """hash-chain levels: the match-finder stage of the last call split by kernel (ms)"""
         t = (C.c_double * 3)()
@@ -172,6 +180,17 @@ class Context:
         out = np.zeros((cap, 4), dtype=np.uint32)
         n = self._check(lib().zhip_get_sequences(self._h, unit_index, out.ctypes.data_as(C.c_void_p), cap), "zhip_get_sequences")
         return out[:n]
+
+    def compress_seekable(self, data, level=1, unit_size=UNIT_SIZE_MAX):
+        """host bytes -> frames + seek table (contrib/seekable_format); checksums go into the table when set_checksum is on"""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = a.size
+        nunits = max(1, -(-n // unit_size))
+        cap = compress_bound(n, unit_size) + lib().zhip_seek_table_bound(nunits, 1)
+        dst = np.empty(cap, dtype=np.uint8)
+        r = self._check(lib().zhip_compress_seekable(self._h, dst.ctypes.data_as(C.c_void_p), cap, a.ctypes.data_as(C.c_void_p) if n else None,
+                                                     n, level, unit_size), "zhip_compress_seekable")
+        return dst[:r].tobytes()
 
     # ---- dictionary path: many small records, one frame each
     def compress_records(self, cdict, records, return_sizes=False):

@@ -172,13 +172,13 @@ __device__ __forceinline__ void seq_unpack(const ZhipSeq& s, const ZhipParse& m,
 __device__ inline uint32_t dict_id_bytes(uint32_t dictID) { uint32_t const c = (dictID > 0) + (dictID >= 256) + (dictID >= 65536); return c == 3 ? 4 : c; }
 __device__ inline uint32_t frame_header_size(uint32_t n, uint32_t dictID) { return 4 + 1 + dict_id_bytes(dictID) + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
 // zstd_compress.c:4626-4672 for a single-segment frame with content size, no checksum (library defaults), optional dictID
-__device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n, uint32_t dictID)
+__device__ inline uint32_t write_frame_header(uint8_t* op, uint32_t n, uint32_t dictID, bool checksum = false)
 {
     uint32_t const fcs = (n >= 256) + (n >= 65536 + 256);
     uint32_t const dcode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     uint32_t pos = 5;
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
-    op[4] = (uint8_t)(dcode + (1u << 5) + (fcs << 6));
+    op[4] = (uint8_t)(dcode + ((checksum ? 1u : 0u) << 2) + (1u << 5) + (fcs << 6));       // :4637
     for (uint32_t i = 0; i < dict_id_bytes(dictID); i++) op[pos++] = (uint8_t)(dictID >> (8 * i));     // :4651-4657
     if (fcs == 0) { op[pos] = (uint8_t)n; return pos + 1; }
     if (fcs == 1) { uint32_t const v = n - 256; op[pos] = (uint8_t)v; op[pos + 1] = (uint8_t)(v >> 8); return pos + 2; }
@@ -217,7 +217,8 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
 __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
                                     const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
                                     uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh,
-                                    const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID)
+                                    const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID,
+                                    bool withChecksum, uint32_t checksum /* low 32 bits of XXH64(content), zstd_compress.c:5297 */)
 {
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t const n = u.srcLen;
@@ -230,11 +231,13 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     // ---------------- trivial units: empty frame, or too small to attempt compression (zstd_compress.c:3216, :5270)
     if (n < 7) {
         if (t == 0) {
-            write_frame_header(out, n, dictID);
+            write_frame_header(out, n, dictID, withChecksum);
             uint32_t const bh = 1u + (0u << 1) + (n << 3);
             out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
             for (uint32_t i = 0; i < n; i++) out[fh + 3 + i] = src[i];
-            *outSize = fh + 3 + n;
+            uint32_t end = fh + 3 + n;
+            if (withChecksum) { for (int b = 0; b < 4; b++) out[end + b] = (uint8_t)(checksum >> (8 * b)); end += 4; }
+            *outSize = end;
         }
         return;
     }
@@ -685,10 +688,12 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
     }
     if (t == 0) {
-        write_frame_header(out, n, dictID);
+        write_frame_header(out, n, dictID, withChecksum);
         uint32_t const bh = rawBlock ? (1u + (0u << 1) + (n << 3)) : (1u + (2u << 1) + (cSize << 3));
         out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
-        *outSize = fh + 3 + (rawBlock ? n : cSize);
+        uint32_t end = fh + 3 + (rawBlock ? n : cSize);
+        if (withChecksum) { for (int b = 0; b < 4; b++) out[end + b] = (uint8_t)(checksum >> (8 * b)); end += 4; }   // zstd_compress.c:5297-5303
+        *outSize = end;
     }
     ZPROF(7);
     ZPROF_FLUSH(16);

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
 k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
           const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize,
-          const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID)
+          const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID, const uint32_t* __restrict__ checks /* frame checksums or nullptr */)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
@@ -157,7 +157,54 @@ k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, c
     ZhipParse const pm = metas[ui];
     ZhipSlot const sl = slots[ui];
     entropy_unit(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
-                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem, dictEntropy, dictID);
+                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem, dictEntropy, dictID, checks != nullptr, checks ? checks[ui] : 0u);
+}
+
+// Frame checksum (ZSTD_c_checksumFlag): XXH64 of each unit's content, low 32 bits (zstd_compress.c:5297-5303).  XXH64 has four
+// independent 64-bit lanes over 32-byte stripes and a strictly sequential round per lane (rotate-multiply, not
+// associative), so a unit gets 4 GPU lanes — one per accumulator — and a wavefront hashes 16 units at once; the finish
+// (merge, tail bytes, avalanche) runs on the group's first lane.
+__device__ __forceinline__ uint64_t xxh_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * 0xC2B2AE3D27D4EB4FULL; return xxh_rotl(acc, 31) * 0x9E3779B185EBCA87ULL; }
+__global__ void __launch_bounds__(64)
+k_xxh64(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits, uint32_t* __restrict__ checks)
+{
+    uint64_t const P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    uint32_t const lane = threadIdx.x & 63, j = lane & 3;
+    uint32_t const ui = blockIdx.x * 16 + (lane >> 2);
+    bool const on = ui < nUnits;
+    ZhipUnit const u = units[on ? ui : 0];
+    const uint8_t* const p = src + u.srcOff;
+    uint32_t const n = on ? u.srcLen : 0, stripes = n >> 5;
+    uint64_t v = j == 0 ? P1 + P2 : (j == 1 ? P2 : (j == 2 ? 0 : 0 - P1));
+    uint32_t s = 0;
+    for (; s + 4 <= stripes; s += 4) {                      // four loads in flight per lane
+        uint64_t a[4];
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&a[q], p + 32u * (s + (uint32_t)q) + 8u * j, 8);
+        for (int q = 0; q < 4; q++) v = xxh_round(v, a[q]);
+    }
+    for (; s < stripes; s++) { uint64_t a; __builtin_memcpy(&a, p + 32u * s + 8u * j, 8); v = xxh_round(v, a); }
+    // gather the four accumulators on the group's first lane
+    uint32_t const g0 = lane & ~3u;
+    uint64_t vv[4];
+    for (int q = 0; q < 4; q++) {
+        uint32_t const lo = __shfl((uint32_t)v, (int)(g0 + (uint32_t)q)), hi = __shfl((uint32_t)(v >> 32), (int)(g0 + (uint32_t)q));
+        vv[q] = ((uint64_t)hi << 32) | lo;
+    }
+    if (j == 0 && on) {
+        uint64_t h;
+        if (n >= 32) {
+            h = xxh_rotl(vv[0], 1) + xxh_rotl(vv[1], 7) + xxh_rotl(vv[2], 12) + xxh_rotl(vv[3], 18);
+            for (int q = 0; q < 4; q++) h = (h ^ xxh_round(0, vv[q])) * P1 + P4;
+        } else h = P5;
+        h += (uint64_t)n;
+        uint32_t pos = stripes << 5;
+        while (pos + 8 <= n) { uint64_t a; __builtin_memcpy(&a, p + pos, 8); h ^= xxh_round(0, a); h = xxh_rotl(h, 27) * P1 + P4; pos += 8; }
+        if (pos + 4 <= n) { uint32_t a; __builtin_memcpy(&a, p + pos, 4); h ^= (uint64_t)a * P1; h = xxh_rotl(h, 23) * P2 + P3; pos += 4; }
+        while (pos < n) { h ^= (uint64_t)p[pos++] * P5; h = xxh_rotl(h, 11) * P1; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+        checks[ui] = (uint32_t)h;
+    }
 }
 
 // Stage 3: pack the per-unit slots into one contiguous stream.  offsets[] = exclusive prefix sum of outSize[].

@@ -40,6 +40,7 @@ struct zhip_ctx_s {
     size_t     hcChunk;                        // hash chain: units per pass over dTabs / dBest
     uint32_t   hcMaxLen, hcHashLog;            // hash chain: longest unit / largest hashLog of the call
     std::vector<hipEvent_t> hcEv; size_t hcEvUsed;   // hash chain: 4 events per chunk of the last call
+    int checksum; uint32_t* dChecks;           // ZSTD_c_checksumFlag: per-unit XXH64 (low 32 bits), computed by k_xxh64 before the entropy stage
     const zhip::ZhipDictEntropy* curDictEntropy; uint32_t curDictID;   // dictionary entropy state of the current call (records path)
     int        strategy;                       // family mask of the current call's units: bit 0 fast, 1 dfast, 2 hash chain
     size_t     seqArena, litArena, outArena;   // arena capacities: sequences (entries), literal bytes, output-slot bytes
@@ -109,7 +110,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
-    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest);
+    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse); (void)hipHostFree(c->hSlots);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
@@ -126,7 +127,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     zhip_ctx* c = new zhip_ctx_s();
     c->dUnits = nullptr; c->dSlots = nullptr; c->hSlots = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;
-    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0; c->curDictEntropy = nullptr; c->curDictID = 0;
+    c->dTabs = nullptr; c->tabsCap = 0; c->tabStride = 0; c->strategy = 1; c->dBest = nullptr; c->bestCap = 0; c->hcChunk = 0; c->hcMaxLen = 0; c->hcEvUsed = 0; c->curDictEntropy = nullptr; c->curDictID = 0; c->checksum = 0; c->dChecks = nullptr;
     c->seqArena = seqArena; c->litArena = litArena; c->outArena = outArena;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
@@ -179,6 +180,13 @@ zhip_ctx* zhip_create_for_records(int device, size_t maxRecords, size_t maxTotal
     if (maxRecords == 0) maxRecords = 1;
     return create_impl(device, maxRecords, maxTotalBytes / 4 + 8 * maxRecords + 64, maxTotalBytes + 80 * maxRecords + 64,
                        maxTotalBytes + (maxTotalBytes >> 8) + 128 * maxRecords + 64);
+}
+
+int zhip_set_frame_checksum(zhip_ctx* c, int enable)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->checksum = enable ? 1 : 0;
+    return 0;
 }
 
 void zhip_last_timing(const zhip_ctx* c, double t[4]) { for (int i = 0; i < 4; i++) t[i] = c->timing[i]; }
@@ -305,8 +313,12 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
 {
     static bool attrSet = false;
     if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
+    if (c->checksum) {                          // ZSTD_c_checksumFlag: XXH64 of every unit's content, 16 units per wavefront
+        if (!c->dChecks) HIPCHK(c, hipMalloc((void**)&c->dChecks, (c->maxUnits + 16) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(zhip::k_xxh64, dim3((unsigned)((nUnits + 15) / 16)), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dChecks);
+    }
     hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
-                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID);
+                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, c->checksum ? c->dChecks : (const uint32_t*)nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
@@ -340,7 +352,7 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
                            c->dSeqs, c->dLits, c->dParse + u0);
         hipLaunchKernelGGL(zhip::k_entropy, dim3(nu), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), q,
                            srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dSeqs, c->dParse + u0, c->dLits,
-                           c->dStBits, c->dOut, c->dOutSize + u0, (const zhip::ZhipDictEntropy*)nullptr, 0u);
+                           c->dStBits, c->dOut, c->dOutSize + u0, (const zhip::ZhipDictEntropy*)nullptr, 0u, (const uint32_t*)nullptr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->cev[i], q));
         HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
@@ -372,7 +384,7 @@ static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapaci
     if (!nUnits) return err;
     if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
     size_t r;
-    if (c->nChunks > 1 && c->strategy == 1 && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
+    if (c->nChunks > 1 && c->strategy == 1 && !c->checksum && nUnits >= (size_t)64 * c->nChunks) r = launch_pipelined(c, (const uint8_t*)srcDev, nUnits, mh, (uint8_t*)dstDev, s);
     else {
         r = launch_parse(c, (const uint8_t*)srcDev, nUnits, mh, s);
         if (zhip_isError(r)) return r;
@@ -422,6 +434,42 @@ size_t zhip_compress(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src
     HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
     if (unitSizes) for (size_t i = 0; i < c->nUnits; i++) unitSizes[i] = c->hOutSize[i];
     return total;
+}
+
+// ------------------------------------------------------------------ seekable container
+size_t zhip_seek_table_bound(size_t nFrames, int withChecksum) { return 8 + nFrames * (withChecksum ? 12 : 8) + 9; }
+
+static inline void put32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+size_t zhip_write_seek_table(void* dstv, size_t cap, const unsigned* cSizes, const unsigned* dSizes, const unsigned* checksums, size_t nFrames)
+{
+    size_t const entry = checksums ? 12 : 8, total = 8 + nFrames * entry + 9;
+    uint8_t* op = (uint8_t*)dstv;
+    if (cap < total) return ZERR(ZE_dstSize_tooSmall);
+    if (nFrames > 0x8000000u) return ZERR(ZE_parameter_outOfBound);          // ZSTD_SEEKABLE_MAXFRAMES (zstd_seekable.h:22)
+    put32(op, 0x184D2A5Eu); put32(op + 4, (uint32_t)(total - 8)); op += 8;   // skippable frame header
+    for (size_t i = 0; i < nFrames; i++) {
+        put32(op, cSizes[i]); put32(op + 4, dSizes[i]); op += 8;
+        if (checksums) { put32(op, checksums[i]); op += 4; }
+    }
+    put32(op, (uint32_t)nFrames); op[4] = (uint8_t)((checksums ? 1u : 0u) << 7); put32(op + 5, 0x8F92EAB1u);   // footer
+    return total;
+}
+
+size_t zhip_compress_seekable(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, size_t unitSize)
+{
+    size_t const nUnitsMax = srcSize ? (srcSize + (unitSize ? unitSize : 1) - 1) / (unitSize ? unitSize : 1) : 1;
+    if (dstCapacity < zhip_compressBound(srcSize, unitSize) + zhip_seek_table_bound(nUnitsMax, 1)) return ZERR(ZE_dstSize_tooSmall);
+    size_t const total = zhip_compress(c, dst, dstCapacity, src, srcSize, level, unitSize, nullptr);
+    if (zhip_isError(total)) return total;
+    std::lock_guard<std::mutex> lk(c->mu);
+    size_t const n = c->nUnits;
+    std::vector<unsigned> cs(n), ds(n), ck;
+    for (size_t i = 0; i < n; i++) { cs[i] = c->hOutSize[i]; ds[i] = c->hUnits[i].srcLen; }
+    if (c->checksum) { ck.resize(n); HIPCHK(c, hipMemcpy(ck.data(), c->dChecks, n * sizeof(uint32_t), hipMemcpyDeviceToHost)); }
+    size_t const t = zhip_write_seek_table((uint8_t*)dst + total, dstCapacity - total, cs.data(), ds.data(), c->checksum ? ck.data() : nullptr, n);
+    if (zhip_isError(t)) return t;
+    return total + t;
 }
 
 // ------------------------------------------------------------------ dictionary path (records)

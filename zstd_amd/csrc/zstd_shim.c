@@ -16,6 +16,7 @@ struct ZSTD_CCtx_s {
     zhip_ctx* z;
     size_t    zUnits;
     int       level;                 /* ZSTD_c_compressionLevel; 0 means default (3), lib/zstd.h:337-349 */
+    int       checksum;              /* ZSTD_c_checksumFlag */
     const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
 
@@ -35,7 +36,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 {
     if (!c) return SHIM_ERR(E_GENERIC);
-    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; }
+    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; }
     return 0;
 }
 size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
@@ -48,7 +49,7 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
         return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
     case ZSTD_c_contentSizeFlag: return value == 1 ? 0 : SHIM_ERR(E_parameter_unsupported);
-    case ZSTD_c_checksumFlag:    return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
+    case ZSTD_c_checksumFlag:    c->checksum = value != 0; return 0;
     case ZSTD_c_dictIDFlag:      return 0;                        /* no dictionary can be attached: the flag has no effect */
     case ZSTD_c_nbWorkers:       return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
     default: return SHIM_ERR(E_parameter_unsupported);
@@ -64,6 +65,7 @@ static size_t shim_ensure(ZSTD_CCtx* c, size_t units)
         if (!c->z) return SHIM_ERR(E_memory_allocation);
         c->zUnits = want;
     }
+    zhip_set_frame_checksum(c->z, c->checksum);
     return 0;
 }
 
@@ -138,7 +140,14 @@ size_t ZSTD_compress_usingCDict(ZSTD_CCtx* c, void* dst, size_t cap, const void*
 {
     return shim_compress_cdict(c, cd, dst, cap, src, n);
 }
-size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level) { return shim_compress(c, dst, cap, src, n, level); }   /* ignores the cctx's parameters, like the reference (zstd_compress.c:5428) */
+size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
+{   /* ignores the cctx's parameters (checksum flag included), like the reference (zstd_compress.c:5428) */
+    int const ck = c ? c->checksum : 0; size_t r;
+    if (c) c->checksum = 0;
+    r = shim_compress(c, dst, cap, src, n, level);
+    if (c) c->checksum = ck;
+    return r;
+}
 size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     ZSTD_CCtx* c = ZSTD_createCCtx();
