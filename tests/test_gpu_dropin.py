@@ -113,7 +113,17 @@ def test_errors_use_the_reference_codes_and_nothing_falls_back_to_the_host(env):
     r, _ = shim_compress2(S, a, 19)                                    # btultra2: not on the device, no CPU fallback
     assert S.ZSTD_isError(r) and r == C.c_size_t(-40).value            # parameter_unsupported
     c = S.ZSTD_createCCtx()
-    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 201, 1))         # checksumFlag
+    assert S.ZSTD_CCtx_setParameter(c, 201, 1) == 0                    # checksumFlag: XXH64 on the device
+    if lr is not None:
+        lr.zref_compress_chunks_checksum.restype = C.c_size_t
+        lr.zref_compress_chunks_checksum.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        assert S.ZSTD_CCtx_setParameter(c, 100, 3) == 0
+        cap = S.ZSTD_compressBound(len(a)); d1 = np.zeros(cap, dtype=np.uint8); d2 = np.zeros(cap + 64, dtype=np.uint8)
+        k1 = S.ZSTD_compress2(c, _buf(d1), cap, _buf(a), len(a))
+        k2 = lr.zref_compress_chunks_checksum(3, 131072, _buf(a), len(a), _buf(d2), len(d2), None, 0)
+        assert not S.ZSTD_isError(k1) and d1[:k1].tobytes() == d2[:k2].tobytes()
+        k3 = S.ZSTD_compressCCtx(c, _buf(d1), cap, _buf(a), len(a), 3)          # ignores the flag, like the reference
+        assert d1[:k3].tobytes() == expect_unit(lo, lr, a, 3)
     assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 400, 2))         # nbWorkers
     assert S.ZSTD_CCtx_setParameter(c, 101, 0) == 0                    # windowLog 0 = default
     S.ZSTD_freeCCtx(c)
