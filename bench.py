@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
     ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
     args = ap.parse_args()
 
     import torch
@@ -340,7 +341,7 @@ def main():
         if cp[6] >= 3:      # the match-finder stage is three kernels; the roofline figures above are for their sum
             out["roofline"]["kernels_ms"] = {k: round(v / K, 3) for k, v in hc.items()}
         out["parity"] = parity_check(ctx, host, dst, total, sizes, args.level)
-        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384:
+        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384 and not args.no_pipelined_extra:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)
             os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
             ctx2 = zstd_amd.Context(local, max_units=units)
