@@ -103,3 +103,15 @@ def test_plugin_failure_maps_to_error_or_fallback(env):
     r, dst = compress_with_plugin(Z, zstd_amd, ctx, a, 1, prepare=False, fallback=1, state=C.c_void_p(0))
     assert not Z.ZSTD_isError(r)
     roundtrip(Z, a, r, dst)
+
+
+@pytest.mark.parametrize("level", [3, 5, 7])
+def test_plugin_higher_levels_roundtrip_and_compress_better(env, level):
+    """dfast and the hash-chain parsers behind ZSTD_registerSequenceProducer: valid frames, and a better ratio than level 1"""
+    Z, zstd_amd, ctx, lo = env
+    a = text_like(600_000, 5)
+    r1, _ = compress_with_plugin(Z, zstd_amd, ctx, a, 1, max_block=65536, prepare=True)
+    r, dst = compress_with_plugin(Z, zstd_amd, ctx, a, level, max_block=65536, prepare=True)
+    assert not Z.ZSTD_isError(r)
+    roundtrip(Z, a, r, dst)
+    assert r < r1
