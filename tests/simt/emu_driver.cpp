@@ -6,6 +6,7 @@
 #include "zhip_cdict_host.h"
 
 #include <vector>
+#include <stdlib.h>
 // full-size slots (fixed strides), what the host library fills for 128 KB units
 static std::vector<ZhipSlot> fixed_slots(uint32_t nUnits)
 {
@@ -44,8 +45,12 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::hc_chain_lds_bytes(maxHlog),
                  [=] { zhip::k_hc_chain(src, units, nUnits, tabs, tabStride); }, osThreads);
     uint32_t const bpu = (maxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
-    simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,
-                 [=] { zhip::k_hc_search(src, units, nUnits, bpu, tabs, tabStride, best); }, osThreads);
+    if (getenv("ZHIP_EMU_HC_GLOBAL"))          // the L2-resident variant (kept for comparison runs)
+        simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,
+                     [=] { zhip::k_hc_search(src, units, nUnits, bpu, tabs, tabStride, best); }, osThreads);
+    else
+        simt::launch({nUnits, 1, 1}, {ZHIP_HC_SEARCH_LDS_THREADS, 1, 1}, ((maxLen + 15) & ~15u) + 32,
+                     [=] { zhip::k_hc_search_lds(src, units, nUnits, tabs, tabStride, best); }, osThreads);
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0,
                  [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas); }, osThreads);
 }

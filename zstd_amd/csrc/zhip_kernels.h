@@ -128,6 +128,32 @@ k_hc_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
     best[(size_t)ui * ZHIP_UNIT_MAX + p] = hc_search_pos(src + u.srcOff, n, p, prev, u.searchLog, u.chainLog);
 }
 
+// k_hc_search with the unit staged in LDS: one 1024-thread workgroup per unit, dynamic LDS = longest unit + 16.
+__global__ void __launch_bounds__(ZHIP_HC_SEARCH_LDS_THREADS)
+k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
+                const uint32_t* __restrict__ tabs, size_t tabStride, uint64_t* __restrict__ best)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x, t = threadIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    uint32_t const n = u.srcLen;
+    if (u.strategy < ZHIP_STRAT_GREEDY || n < 10) return;
+    const uint8_t* const p0 = src + u.srcOff;
+    lds_u8* const lsrc = (lds_u8*)(uintptr_t)smem;
+    uint32_t const full = n & ~15u;
+    for (uint32_t i = 16u * t; i < full; i += 16u * ZHIP_HC_SEARCH_LDS_THREADS) {
+        uint4 v; __builtin_memcpy(&v, p0 + i, 16);
+        lds_u32* const d = (lds_u32*)(lsrc + i);                               // 16-byte aligned: merged into one ds_write_b128
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (t < 32) { uint32_t const i = full + t; lsrc[i] = i < n ? p0[i] : 0; }      // ragged tail + 16 zero bytes of padding
+    __syncthreads();
+    const uint32_t* const prev = tabs + (size_t)ui * tabStride;
+    uint64_t* const b = best + (size_t)ui * ZHIP_UNIT_MAX;
+    for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = hc_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.chainLog);
+}
+
 __global__ void __launch_bounds__(64)
 k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,

@@ -294,8 +294,17 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::hc_chain_lds_bytes(c->hcHashLog), s,
                                srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride);
             HIPCHK(c, hipEventRecord(he[1], s));
-            hipLaunchKernelGGL(zhip::k_hc_search, dim3(((nu + 7) / 8) * 8 * bpu), dim3(ZHIP_HC_SEARCH_THREADS), 0, s,
-                               srcDev, c->dUnits + u0, nu, bpu, c->dTabs, c->tabStride, c->dBest);
+            {   static int const useGlobal = getenv("ZHIP_HC_SEARCH_GLOBAL") ? atoi(getenv("ZHIP_HC_SEARCH_GLOBAL")) : 0;   // measurement knob: the L2-resident variant
+                size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
+                if (useGlobal)
+                    hipLaunchKernelGGL(zhip::k_hc_search, dim3(((nu + 7) / 8) * 8 * bpu), dim3(ZHIP_HC_SEARCH_THREADS), 0, s,
+                                       srcDev, c->dUnits + u0, nu, bpu, c->dTabs, c->tabStride, c->dBest);
+                else {
+                    if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_search_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
+                                       srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
+                }
+            }
             HIPCHK(c, hipEventRecord(he[2], s));
             hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), 0, s,
                                srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,

@@ -39,6 +39,7 @@ namespace zhip {
 #define ZHIP_HC_NONE     0x1FFFFu            /* "no candidate" in the minCand field */
 #define ZHIP_HC_SKIPPED  0x80000000u         /* prev[] flag: position was never inserted (lazy skipping) */
 #define ZHIP_HC_SEARCH_THREADS 256
+#define ZHIP_HC_SEARCH_LDS_THREADS 1024
 
 // per-unit table memory in 32-bit words: prev[ZHIP_UNIT_MAX] (the chain links; the hash heads only ever live in LDS)
 __host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { (void)hashLog; return ZHIP_UNIT_MAX; }
@@ -182,6 +183,50 @@ __device__ inline uint64_t hc_search_pos(const uint8_t* __restrict__ src, uint32
             if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }    // :724-728
         }
         if (p >= chainSize && mp <= p - chainSize) break;                       // :732 matchIndex <= minChain
+        m = nx; attempts--;
+    }
+    return hc_pack(ml, off, minCand, live);
+}
+
+// The same search with the unit's source staged in LDS (k_hc_search_lds: one 1024-thread workgroup per unit, the whole
+// <= 128 KB window in the CU's 160 KB of LDS).  The three byte compares per chain step then cost LDS reads instead of fully
+// divergent global gathers — the texture-addresser work that bounded the first version; only the chain links stay in L2/HBM.
+typedef ZHIP_LDS uint32_t __attribute__((aligned(1))) lds_u32_unal;
+typedef ZHIP_LDS uint64_t __attribute__((aligned(1))) lds_u64_unal;
+__device__ __forceinline__ uint32_t lds_ld32(const lds_u8* p) { return *(const lds_u32_unal*)p; }
+__device__ __forceinline__ uint64_t lds_ld64(const lds_u8* p) { return *(const lds_u64_unal*)p; }
+// equal leading bytes (0..8) of the 8-byte windows at q and q-off; the LDS copy has 16 zero bytes after the unit's end
+__device__ __forceinline__ uint32_t lds_same_fwd(const lds_u8* lsrc, uint32_t q, uint32_t off, uint32_t n)
+{
+    uint64_t const x = lds_ld64(lsrc + q) ^ lds_ld64(lsrc + (q - off));
+    uint32_t const lim = n - q < 8 ? n - q : 8;                            // q < n
+    uint32_t const same = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+    return same < lim ? same : lim;
+}
+__device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uint32_t p, const uint32_t* __restrict__ prev,
+                                             uint32_t searchLog, uint32_t chainLog)
+{
+    uint32_t const chainSize = 1u << chainLog;
+    uint32_t attempts = 1u << searchLog;
+    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE;
+    bool live = false;
+    uint32_t m = prev[p];
+    while (m != 0 && attempts) {
+        uint32_t const mp = m - 1;
+        uint32_t const nx = prev[mp];
+        minCand = mp;
+        if (lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+            uint32_t cur = 0;
+            for (;;) {
+                uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
+                cur += same;
+                if (same < 8) break;
+                if (cur >= ZHIP_HC_CAP) { live = true; break; }
+            }
+            if (live) break;
+            if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }
+        }
+        if (p >= chainSize && mp <= p - chainSize) break;
         m = nx; attempts--;
     }
     return hc_pack(ml, off, minCand, live);
