@@ -38,3 +38,40 @@ def _check(path, levels, atleast):
                 assert hashlib.sha256(dst[:r].tobytes()).hexdigest() == g["dst_sha256"], (name, level)
                 seen += 1
     assert seen >= len(gold) > atleast
+
+
+def test_oracle_reproduces_golden_dictionary_frames():
+    """dictionary path (CDict attach mode, raw-content + ZDICT-trained): the oracle vs fixtures made with the real reference"""
+    import ctypes as C, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from zstd_amd import workloads as W
+    from _libs import text_like
+    lo = load_oracle()
+    lo.zo_cdict_create.restype = C.c_void_p
+    lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_cdict_free.argtypes = [C.c_void_p]
+    lo.zo_compress_unit_cdict.restype = C.c_size_t
+    lo.zo_compress_unit_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dict_v1.json")))["cases"]
+    zd = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    raw = W.github_like_records(100, seed=5)[0][:60000].copy()
+    flat, offs = W.github_like_records(120, seed=31)
+    recs = [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(120)]
+    t = text_like(40000, 31)
+    recs += [np.zeros(0, np.uint8), recs[0][:6], recs[1][:7], recs[2][:8], recs[3][:9], recs[4][:100], np.concatenate(recs[5:12])[:8000], t[:3000], t[3000:3300]]
+    assert len(gold) == 6
+    for g in gold:
+        d = zd if g["dict"] == "zdict" else raw
+        assert hashlib.sha256(d.tobytes()).hexdigest() == g["dict_sha256"]
+        assert hashlib.sha256(np.concatenate(recs).tobytes()).hexdigest() == g["records_sha256"]
+        cd = lo.zo_cdict_create(_buf(d), len(d), g["level"])
+        assert cd
+        frames = b""
+        for r, want in zip(recs, g["frame_sizes"]):
+            buf = np.zeros(len(r) + 700, dtype=np.uint8)
+            k = lo.zo_compress_unit_cdict(_buf(buf), len(buf), _buf(r), len(r), cd)
+            assert k == want, (g["dict"], g["level"], len(r))
+            frames += buf[:k].tobytes()
+        assert hashlib.sha256(frames).hexdigest() == g["frames_sha256"], (g["dict"], g["level"])
+        lo.zo_cdict_free(cd)
