@@ -36,6 +36,8 @@ struct ZhipCDictDev {
 
 __host__ __device__ inline uint32_t dict_lds_bytes(uint32_t hashLog, uint32_t chainLog) { return (2u << hashLog) + (2u << chainLog) + 2u * ZHIP_DF_SCRATCH; }
 
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return readlane64(v, 0); }
+
 // 8 bytes of p[o .. o+8) where only p[0 .. l) may be touched (l >= 8); bytes past l read as the buffer's last bytes shifted out
 __device__ __forceinline__ uint64_t ld64_lim(const uint8_t* p, uint32_t o, uint32_t l)
 {
@@ -86,6 +88,44 @@ __device__ inline uint32_t wave_count_back_cross(const uint8_t* a, uint32_t pa, 
     }
 }
 
+// Forward and backward extension in ONE round of loads: lanes 0..47 compare 8 bytes each of a[0..la) / b[0..lb) (384 bytes),
+// lanes 48..63 one byte each walking back from ba[pa-1] / bb[pb-1] (at most backLim bytes); longer runs fall back to the loops.
+__device__ inline void wave_extend_cross(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb,
+                                         const uint8_t* ba, uint32_t pa, const uint8_t* bb, uint32_t pb, uint32_t backLim,
+                                         uint32_t& fwd, uint32_t& back)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const lim = la < lb ? la : lb;
+    uint32_t same;
+    if (lane < 48) {
+        uint32_t const o = 8u * lane;
+        same = 0;
+        if (o < lim) {
+            uint64_t const x = ld64_lim(a, o, la) ^ ld64_lim(b, o, lb);
+            uint32_t const avail = lim - o;
+            same = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+            if (same > avail) same = avail;
+        }
+    } else {
+        uint32_t const i = lane - 48;
+        bool const stopHere = (i >= backLim) || (ba[pa - 1 - i] != bb[pb - 1 - i]);
+        same = stopHere ? 0 : 8;
+    }
+    unsigned long long const stop = __ballot(same < 8);
+    unsigned long long const stopF = stop & 0x0000FFFFFFFFFFFFull, stopB = stop >> 48;
+    if (stopF) { int const f = first_lane(stopF); fwd = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+    else fwd = 384 + wave_count_cross(a + 384, la - 384, b + 384, lb - 384);
+    if (stopB) back = (uint32_t)first_lane(stopB);
+    else back = 16 + wave_count_back_cross(ba, pa - 16, bb, pb - 16, backLim - 16);
+}
+// the same for a match whose other side starts in the dictionary at dPos (forward part = ZSTD_count_2segments)
+__device__ inline void wave_extend_dict(const uint8_t* src, uint32_t n, uint32_t ipPos, uint32_t backPos, const uint8_t* dict, uint32_t dictLen,
+                                        uint32_t dPos, uint32_t dBackPos, uint32_t backLim, uint32_t& fwd, uint32_t& back)
+{
+    wave_extend_cross(src + ipPos, n - ipPos, dict + dPos, dictLen - dPos, src, backPos, dict, dBackPos, backLim, fwd, back);
+    if (dPos + fwd == dictLen && ipPos + fwd < n) fwd += wave_count_cross(src + ipPos + fwd, n - ipPos - fwd, src, n);
+}
+
 template <uint32_t MLS>
 __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipCDictDev& cd,
                                             unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
@@ -114,6 +154,7 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip = 0;                         // :373 ip += (dictAndPrefixLength == 0): a dictionary is attached, so no skip
     uint32_t evAvg16 = 12u << 4, kCap = 16;
+    uint32_t nbIp = 0xFFFFFFFFu, nbOff1 = 0, nbRv = 0; uint64_t nbBytes = 0;     // the next batch's source bytes, fetched early
     // bytes of the repcode candidate of record position q (index P + q - off): in the dictionary or in the record
     auto rep_ptr = [&](uint32_t q, uint32_t off) -> const uint8_t* { return off > q ? dict + (dictLen + q - off) : src + (q - off); };
     auto rep_ok = [&](uint32_t q, uint32_t off) -> bool { return (uint32_t)((P - 1) - (P + q - off)) >= 3; };   // ZSTD_index_overlap_check
@@ -136,13 +177,14 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
             bool const live = (int)lane <= K;                                // lane K = helper for position p_K (ip+1 of lane K-1 when step == 1)
 
             uint32_t const pc = p < nm8 ? p : nm8;
-            uint64_t const bytes = ld64(src + pc);
+            bool const pre = nbIp == ip && nbOff1 == off1 && step == 1;      // loaded while the previous sequence was finished
+            uint64_t const bytes = pre ? nbBytes : ld64(src + pc);
             uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
             uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
             uint32_t const dHTL = vL >> dShL, dHTS = hash_pos<MLS>(bytes, dShS);
             uint32_t const oldL = live ? (uint32_t)tabL[hl] : 0, oldS = live ? (uint32_t)tabS[hs] : 0;
             uint32_t const dEL = live ? cd.tabL[dHTL >> 8] : 0, dES = live ? cd.tabS[dHTS >> 8] : 0;
-            uint32_t const rv = ld32(rep_ptr(pc + 1, off1));
+            uint32_t const rv = pre ? nbRv : ld32(rep_ptr(pc + 1, off1));
             uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
             if (live) { scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane; }
             __builtin_amdgcn_wave_barrier();
@@ -246,46 +288,46 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
             uint32_t offset;
             if (evKind == 2) {                                               // :407-412 record long match
                 uint32_t const m = candE - 1;
-                mLength = 8 + wave_count_cross(src + curr + 8, n - curr - 8, src + m + 8, n - m - 8);
                 offset = curr - m;
                 uint32_t const lim = (curr - anchor) < m ? (curr - anchor) : m;
-                uint32_t const back = wave_count_back(src, curr, m, lim);
-                mstart = curr - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_cross(src + curr + 8, n - curr - 8, src + m + 8, n - m - 8, src, curr, src, m, lim, fwd, back);
+                mstart = curr - back; mLength = 8 + fwd + back;
             } else if (evKind == 3) {                                        // :413-424 dictionary long match
                 uint32_t const dPos = dcandE - 2;
-                mLength = 8 + wave_count_2seg(src, n, curr + 8, dict, dictLen, dPos + 8);
                 offset = (P + curr) - dcandE;
                 uint32_t const lim = (curr - anchor) < dPos ? (curr - anchor) : dPos;           // dm > dictStart
-                uint32_t const back = wave_count_back_cross(src, curr, dict, dPos, lim);
-                mstart = curr - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_dict(src, n, curr + 8, curr, dict, dictLen, dPos + 8, dPos, lim, fwd, back);
+                mstart = curr - back; mLength = 8 + fwd + back;
             } else if (long1) {                                              // :459-464 record long match at curr + 1
                 uint32_t const q = curr + 1, m = cand1 - 1;
-                mLength = 8 + wave_count_cross(src + q + 8, n - q - 8, src + m + 8, n - m - 8);
                 offset = q - m;
                 uint32_t const lim = (q - anchor) < m ? (q - anchor) : m;
-                uint32_t const back = wave_count_back(src, q, m, lim);
-                mstart = q - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_cross(src + q + 8, n - q - 8, src + m + 8, n - m - 8, src, q, src, m, lim, fwd, back);
+                mstart = q - back; mLength = 8 + fwd + back;
             } else if (dlong1) {                                             // :465-477 dictionary long match at curr + 1
                 uint32_t const q = curr + 1, dPos = dcand1 - 2;
-                mLength = 8 + wave_count_2seg(src, n, q + 8, dict, dictLen, dPos + 8);
                 offset = (P + q) - dcand1;
                 uint32_t const lim = (q - anchor) < dPos ? (q - anchor) : dPos;
-                uint32_t const back = wave_count_back_cross(src, q, dict, dPos, lim);
-                mstart = q - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_dict(src, n, q + 8, q, dict, dictLen, dPos + 8, dPos, lim, fwd, back);
+                mstart = q - back; mLength = 8 + fwd + back;
             } else if (shortDict) {                                          // :481-484 the short match lies in the dictionary
                 uint32_t const dPos = dcandE - 2;
-                mLength = 4 + wave_count_2seg(src, n, curr + 4, dict, dictLen, dPos + 4);
                 offset = (P + curr) - dcandE;
                 uint32_t const lim = (curr - anchor) < dPos ? (curr - anchor) : dPos;
-                uint32_t const back = wave_count_back_cross(src, curr, dict, dPos, lim);
-                mstart = curr - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_dict(src, n, curr + 4, curr, dict, dictLen, dPos + 4, dPos, lim, fwd, back);
+                mstart = curr - back; mLength = 4 + fwd + back;
             } else {                                                         // :485-489
                 uint32_t const m = candE - 1;
-                mLength = 4 + wave_count_cross(src + curr + 4, n - curr - 4, src + m + 4, n - m - 4);
                 offset = curr - m;
                 uint32_t const lim = (curr - anchor) < m ? (curr - anchor) : m;
-                uint32_t const back = wave_count_back(src, curr, m, lim);
-                mstart = curr - back; mLength += back;
+                uint32_t fwd, back;
+                wave_extend_cross(src + curr + 4, n - curr - 4, src + m + 4, n - m - 4, src, curr, src, m, lim, fwd, back);
+                mstart = curr - back; mLength = 4 + fwd + back;
             }
             off2 = off1; off1 = offset;
             offBase = offset + 3;
@@ -295,10 +337,17 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
         ip = mstart + mLength; anchor = ip;
 
         if ((int32_t)ip <= ilimit) {                                         // :503-535
+            // ONE round of loads: the bytes of the four complementary inserts, the immediate-repcode probe and the next batch
+            uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
+            uint64_t const bq = ld64(src + (q < nm8 ? q : nm8));
+            uint64_t bIp = uni64(ld64(src + ip));
+            bool r2ok = rep_ok(ip, off2);
+            uint32_t r2 = r2ok ? uni(ld32(rep_ptr(ip, off2))) : 0;
+            {   uint32_t const np = ip + lane, npc = np < nm8 ? np : nm8;
+                nbBytes = ld64(src + npc); nbRv = ld32(rep_ptr(npc + 1, off1)); nbIp = ip; nbOff1 = off1;
+            }
             {   // complementary inserts: long[curr+2], long[ip-2], short[curr+2], short[ip-1] — in this order
-                uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
-                uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
-                uint32_t const hL = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL, hS = hash_pos<MLS>(b, shS);
+                uint32_t const hL = mulhi64_top32(bq, 0xCF1BBCDCB7A56463ULL) >> shL, hS = hash_pos<MLS>(bq, shS);
                 if (lane == 0) { tabL[hL] = (uint16_t)(q + 1); tabS[hS] = (uint16_t)(q + 1); }
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 1) tabL[hL] = (uint16_t)(q + 1);
@@ -306,16 +355,19 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
                 __builtin_amdgcn_wave_barrier();
             }
             while ((int32_t)ip <= ilimit) {
-                uint64_t const b = ld64(src + ip);
-                if (!rep_ok(ip, off2) || (uint32_t)b != uni(ld32(rep_ptr(ip, off2)))) break;
+                if (!r2ok || (uint32_t)bIp != r2) break;
                 uint32_t rl;
                 if (off2 > ip) rl = 4 + wave_count_2seg(src, n, ip + 4, dict, dictLen, dictLen + ip - off2 + 4);
                 else rl = 4 + wave_count_cross(src + ip + 4, n - ip - 4, src + (ip + 4 - off2), n - (ip + 4 - off2));
                 {   uint32_t const t = off2; off2 = off1; off1 = t; }
-                if (lane == 0) { tabS[hash_pos<MLS>(b, shS)] = (uint16_t)(ip + 1); tabL[mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> shL] = (uint16_t)(ip + 1); }
+                if (lane == 0) { tabS[hash_pos<MLS>(bIp, shS)] = (uint16_t)(ip + 1); tabL[mulhi64_top32(bIp, 0xCF1BBCDCB7A56463ULL) >> shL] = (uint16_t)(ip + 1); }
                 __builtin_amdgcn_wave_barrier();
                 store_seq(out, 0, 1, rl);
                 ip += rl; anchor = ip;
+                if ((int32_t)ip > ilimit) break;
+                bIp = uni64(ld64(src + ip));
+                r2ok = rep_ok(ip, off2);
+                r2 = r2ok ? uni(ld32(rep_ptr(ip, off2))) : 0;
             }
         }
     }
