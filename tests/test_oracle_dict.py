@@ -124,3 +124,45 @@ def test_zdict_trained_dictionary_records_match_the_reference(level, kind):
             assert got != ERR
             assert mine[:got].tobytes() == want, (kind, level, cap, i, len(r), got, cs, mine[:12].tobytes().hex(), want[:12].hex())
         lo.zo_cdict_free(cd)
+
+
+def test_fuzzed_dictionaries_and_records_match_the_reference():
+    """structured-random dictionaries / records (tests/test_fuzz_emu.gen), raw content, levels -3..4"""
+    import os
+    from test_fuzz_emu import gen
+    lo, lr = load_oracle(), load_ref()
+    bind(lo, lr)
+    rounds = int(os.environ.get("ZHIP_DICT_FUZZ_ROUNDS", "40"))
+    for rd in range(rounds):
+        rng = np.random.default_rng(4000 + rd)
+        level = (-3, 1, 2, 3, 4)[rd % 5]
+        d = gen(rng, int(rng.integers(8, 70000)))
+        cd = lo.zo_cdict_create(_buf(d), len(d), level)
+        if not cd:
+            continue
+        recs = []
+        for _ in range(10):
+            n = int(rng.integers(0, 5000))
+            r = gen(rng, n)
+            for _ in range(int(rng.integers(0, 6))):
+                ln = min(int(rng.integers(4, 200)), n, len(d))
+                if ln == 0:
+                    continue
+                s = len(d) - ln if rng.random() < 0.2 else int(rng.integers(0, len(d) - ln + 1))
+                o = int(rng.integers(0, n - ln + 1))
+                r[o:o + ln] = d[s:s + ln]
+            recs.append(r)
+        flat = np.concatenate(recs + [np.zeros(8, np.uint8)])
+        sizes = (C.c_size_t * len(recs))(*[len(r) for r in recs])
+        cap = sum(len(r) + 64 for r in recs) + 4096
+        dst = np.zeros(cap, dtype=np.uint8)
+        osz = (C.c_size_t * len(recs))()
+        tot = lr.zref_compress_records_cdict(level, _buf(d), len(d), _buf(flat), sizes, len(recs), _buf(dst), cap, osz)
+        assert tot != ERR
+        pos = 0
+        for r, cs in zip(recs, osz):
+            want = dst[pos:pos + cs].tobytes(); pos += cs
+            mine = np.zeros(len(r) + 600, dtype=np.uint8)
+            got = lo.zo_compress_unit_cdict(_buf(mine), len(mine), _buf(r), len(r), cd)
+            assert got != ERR and mine[:got].tobytes() == want, (rd, level, len(r), len(d))
+        lo.zo_cdict_free(cd)
