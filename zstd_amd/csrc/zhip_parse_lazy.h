@@ -22,8 +22,10 @@
 //   * lazy-skipping leaves positions un-inserted.  The parser flags them in prev[] (top bit) and remembers the highest
 //     one; a record whose walk reached down to a flagged region (its lowest candidate <= that mark) is redone live,
 //     walking prev[] and stepping over flagged positions without counting them as attempts;
-//   * k_hc_search caps its byte compares at ZHIP_HC_CAP per candidate (a unit of zeros would otherwise cost n^2);
-//     a capped record is flagged and redone live by the parser with wave-wide compares.
+//   * k_hc_search caps its byte compares at ZHIP_HC_CAP (32) bytes per candidate — the compare loops of 64 unrelated
+//     positions diverge and every lane pays for the longest one, and a unit of zeros would cost n^2.  A candidate that
+//     reaches the cap beats every shorter one, so the record just names the (one or two) capped candidates and the parser
+//     measures them with wave-wide compares; three or more (runs) -> the parser redoes the walk live.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "zhip_common.h"
@@ -34,7 +36,7 @@
 namespace zhip {
 
 #ifndef ZHIP_HC_CAP
-#define ZHIP_HC_CAP 256u
+#define ZHIP_HC_CAP 32u
 #endif
 #define ZHIP_HC_NONE     0x1FFFFu            /* "no candidate" in the minCand field */
 #define ZHIP_HC_SKIPPED  0x80000000u         /* prev[] flag: position was never inserted (lazy skipping) */
@@ -44,15 +46,20 @@ namespace zhip {
 // per-unit table memory in 32-bit words: prev[ZHIP_UNIT_MAX] (the chain links; the hash heads only ever live in LDS)
 __host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { (void)hashLog; return ZHIP_UNIT_MAX; }
 
-// best[] record: offset (17 bits) | length << 17 (17 bits) | live << 34 | lowest candidate examined << 35 (17 bits)
-__device__ __forceinline__ uint64_t hc_pack(uint32_t ml, uint32_t off, uint32_t minCand, bool live)
+// best[] record (64 bits): A (17) | B << 17 (17) | mode << 34 (2) | lowest candidate examined << 36 (17)
+//   mode 0 exact     : A = offset, B = match length (3 = nothing found)
+//   mode 1 / 2 capped: one / two candidates matched at least ZHIP_HC_CAP bytes (A, B = their positions, in chain order) — they
+//                      beat every shorter candidate, so the parser only has to measure them (wave-wide compare) and keep the
+//                      first longest, exactly what the reference's `if (currentMl > ml)` walk does;
+//   mode 3 live      : three or more such candidates (runs, highly repetitive data): the parser redoes the walk
+__device__ __forceinline__ uint64_t hc_pack(uint32_t a, uint32_t b, uint32_t mode, uint32_t minCand)
 {
-    return (uint64_t)off | ((uint64_t)ml << 17) | ((uint64_t)(live ? 1u : 0u) << 34) | ((uint64_t)minCand << 35);
+    return (uint64_t)a | ((uint64_t)b << 17) | ((uint64_t)mode << 34) | ((uint64_t)minCand << 36);
 }
-__device__ __forceinline__ uint32_t hc_rec_off(uint64_t r) { return (uint32_t)r & 0x1FFFFu; }
-__device__ __forceinline__ uint32_t hc_rec_ml(uint64_t r) { return (uint32_t)(r >> 17) & 0x1FFFFu; }
-__device__ __forceinline__ bool hc_rec_live(uint64_t r) { return (r >> 34) & 1; }
-__device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r >> 35) & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t hc_rec_a(uint64_t r) { return (uint32_t)r & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t hc_rec_b(uint64_t r) { return (uint32_t)(r >> 17) & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t hc_rec_mode(uint64_t r) { return (uint32_t)(r >> 34) & 3u; }
+__device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r >> 36) & 0x1FFFFu; }
 
 // ------------------------------------------------------------------ kernel A: chain links, one wavefront per unit
 // prev[p] = 1 + the closest q < p with hash(q) == hash(p), 0 if none — what chainTable[p & mask] holds after
@@ -164,28 +171,28 @@ __device__ inline uint64_t hc_search_pos(const uint8_t* __restrict__ src, uint32
 {
     uint32_t const nm8 = n - 8, chainSize = 1u << chainLog;
     uint32_t attempts = 1u << searchLog;
-    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE;
-    bool live = false;
+    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE, nCap = 0, capA = 0, capB = 0;
     uint32_t m = prev[p];
     while (m != 0 && attempts) {
         uint32_t const mp = m - 1;
         uint32_t const nx = prev[mp];                                           // independent of the compare below
         minCand = mp;
-        if (ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {                // :714 quick reject at the current best length
+        if (p + ml < n && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {   // :714 quick reject at the current best length (a longer match needs byte ml)
             uint32_t cur = 0;
             for (;;) {
                 uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
                 cur += same;
-                if (same < 8) break;
-                if (cur >= ZHIP_HC_CAP) { live = true; break; }
+                if (same < 8 || cur >= ZHIP_HC_CAP) break;
             }
-            if (live) break;
-            if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }    // :724-728
+            if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
+            else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }    // :724-728
         }
         if (p >= chainSize && mp <= p - chainSize) break;                       // :732 matchIndex <= minChain
         m = nx; attempts--;
     }
-    return hc_pack(ml, off, minCand, live);
+    if (nCap == 0) return hc_pack(off, ml, 0, minCand);
+    if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand);
+    return hc_pack(0, 0, 3, minCand);
 }
 
 // The same search with the unit's source staged in LDS (k_hc_search_lds: one 1024-thread workgroup per unit, the whole
@@ -208,28 +215,28 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
 {
     uint32_t const chainSize = 1u << chainLog;
     uint32_t attempts = 1u << searchLog;
-    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE;
-    bool live = false;
+    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE, nCap = 0, capA = 0, capB = 0;
     uint32_t m = prev[p];
     while (m != 0 && attempts) {
         uint32_t const mp = m - 1;
         uint32_t const nx = prev[mp];
         minCand = mp;
-        if (lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+        if (p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
             uint32_t cur = 0;
             for (;;) {
                 uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
                 cur += same;
-                if (same < 8) break;
-                if (cur >= ZHIP_HC_CAP) { live = true; break; }
+                if (same < 8 || cur >= ZHIP_HC_CAP) break;
             }
-            if (live) break;
-            if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }
+            if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
+            else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) break; }
         }
         if (p >= chainSize && mp <= p - chainSize) break;
         m = nx; attempts--;
     }
-    return hc_pack(ml, off, minCand, live);
+    if (nCap == 0) return hc_pack(off, ml, 0, minCand);
+    if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand);
+    return hc_pack(0, 0, 3, minCand);
 }
 
 // ------------------------------------------------------------------ kernel C: the parser, one wavefront per unit
@@ -274,10 +281,19 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     }
     st.ntu = x;
     uint32_t off;
-    uint32_t const minCand = hc_rec_min(rec);
-    if (hc_rec_live(rec) || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd))
+    uint32_t const minCand = hc_rec_min(rec), mode = hc_rec_mode(rec);
+    if (mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd))
         hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
-    else { ml = hc_rec_ml(rec); off = hc_rec_off(rec); }
+    else if (mode == 0) { ml = hc_rec_b(rec); off = hc_rec_a(rec); }
+    else {                                                // one or two candidates ran into the compare cap: measure them
+        uint32_t const nm8 = n - 8, cA = hc_rec_a(rec);
+        ml = wave_count_fwd(src, x, cA, nm8); off = x - cA;
+        if (mode == 2 && x + ml != n) {                   // :726-728 the walk stops at a match that reaches the end of the block
+            uint32_t const cB = hc_rec_b(rec);
+            uint32_t const l2 = wave_count_fwd(src, x, cB, nm8);
+            if (l2 > ml) { ml = l2; off = x - cB; }
+        }
+    }
     offBase = off + 3;
 }
 
@@ -324,8 +340,8 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             else { recj = valid ? best[xj] : 0; cur4 = ld32(src + xc + 1); rv = ld32(src + (xc + 1 - off1)); }
             repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
             uint32_t const minCand = hc_rec_min(recj);
-            bool const needLive = valid && (hc_rec_live(recj) || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd));
-            bool const found = valid && hc_rec_ml(recj) >= 4;
+            bool const needLive = valid && (hc_rec_mode(recj) == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd));
+            bool const found = valid && (hc_rec_mode(recj) != 0 || hc_rec_b(recj) >= 4);
             K = (uint32_t)__popcll(__ballot(valid));
             unsigned long long const ev = __ballot(repj || needLive || found);
             if (!ev) {                                                       // K failed searches (:1613-1624), lazySkipping = 0
