@@ -43,7 +43,7 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     uint32_t maxLen = 1, maxHlog = 6;
     for (uint32_t i = 0; i < nUnits; i++) { if (units[i].srcLen > maxLen) maxLen = units[i].srcLen; if (units[i].hashLog > maxHlog) maxHlog = units[i].hashLog; }
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::hc_chain_lds_bytes(maxHlog),
-                 [=] { zhip::k_hc_chain(src, units, nUnits, tabs, tabStride); }, osThreads);
+                 [=] { zhip::k_hc_chain(src, units, nUnits, tabs, tabStride, best); }, osThreads);
     uint32_t const bpu = (maxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS;
     if (getenv("ZHIP_EMU_HC_GLOBAL"))          // the L2-resident variant (kept for comparison runs)
         simt::launch({((nUnits + 7) / 8) * 8 * bpu, 1, 1}, {ZHIP_HC_SEARCH_THREADS, 1, 1}, 0,

@@ -96,7 +96,7 @@ k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 // k_hc_chain: dynamic LDS = hc_chain_lds_bytes(max hashLog).
 __global__ void __launch_bounds__(64)
 k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
-           uint32_t* __restrict__ tabs, size_t tabStride)
+           uint32_t* __restrict__ tabs, size_t tabStride, uint64_t* __restrict__ best /* used as scratch here */)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
@@ -104,11 +104,12 @@ k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
     ZhipUnit const u = units[ui];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
+    uint32_t* const queue = (uint32_t*)(best + (size_t)ui * ZHIP_UNIT_MAX);
     const uint8_t* const p = src + u.srcOff;
     switch (u.minMatch) {                               // zstd_lazy.c:1531 mls = BOUNDED(4, minMatch, 6)
-    case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, prev); break;
-    case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, prev); break;
-    default: hc_chain_unit<4>(p, u.srcLen, u, smem, prev); break;
+    case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, prev, queue); break;
+    case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, prev, queue); break;
+    default: hc_chain_unit<4>(p, u.srcLen, u, smem, prev, queue); break;
     }
 }
 

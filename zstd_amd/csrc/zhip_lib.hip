@@ -292,7 +292,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             hipEvent_t* const he = &c->hcEv[c->hcEvUsed]; c->hcEvUsed += 4;
             HIPCHK(c, hipEventRecord(he[0], s));
             hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::hc_chain_lds_bytes(c->hcHashLog), s,
-                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride);
+                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
             HIPCHK(c, hipEventRecord(he[1], s));
             {   static int const useGlobal = getenv("ZHIP_HC_SEARCH_GLOBAL") ? atoi(getenv("ZHIP_HC_SEARCH_GLOBAL")) : 0;   // measurement knob: the L2-resident variant
                 size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;

@@ -67,100 +67,125 @@ __device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r
 //
 // The "most recent position per hash" table has 2^hashLog (2^17) entries of 17 bits: too big for LDS, and in HBM every
 // lookup / update is a random 64-byte sector (that version ran at the HBM random-access rate: 50 ms per GiB).  So the
-// unit is swept once per slice of the hash space instead: a pass keeps the table of ONE slice (2^14 hashes: 16-bit
-// entries + a bit plane for bit 16, 34 KB) in LDS, scans all positions (coalesced source reads, L2-resident after the
-// first pass), compacts the positions whose hash falls into the slice — in order — into a small LDS queue, and runs
-// the table step on full 64-entry batches from that queue.  Lanes of one batch with equal hash are put in order with
-// the slot-as-detector trick of zhip_parse.h (write the lane id, read it back, ballot the groups).
+// hash space is cut into slices of 2^14 hashes whose table (16-bit entries + a bit plane for bit 16, 34 KB) fits LDS:
+//   1. two cheap scans over the unit (coalesced source reads) bucket the positions by slice, in order, into a queue in
+//      global memory (the unit's best[] area, which k_hc_search only writes afterwards): scan one counts, scan two
+//      places each entry at its slice's running offset (same-slice rank inside a batch from three ballots);
+//   2. one pass per slice streams its queue (coalesced) through the LDS table, 64 entries per step; lanes of a step with
+//      equal hash are put in order with the slot-as-detector trick of zhip_parse.h.
+// (The version that re-scanned the unit once per slice spent most of its instructions on those scans: 25 ms per GiB.)
 #define ZHIP_HC_SLICE_LOG 14u
 __host__ __device__ inline uint32_t hc_chain_lds_bytes(uint32_t hashLog)
 {
     uint32_t const e = 1u << (hashLog < ZHIP_HC_SLICE_LOG ? hashLog : ZHIP_HC_SLICE_LOG);
     uint32_t const plane = (e >> 3) < 4 ? 4 : (e >> 3);
-    return 2u * e + plane + 128u * 4u;                    // lo16[e], bit plane, queue[128]
+    return 2u * e + plane + 64u * 4u;                     // lo16[e], bit plane, slice counters / cursors
 }
 
 template <uint32_t MLS>
 __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
-                                     uint32_t* __restrict__ prev)
+                                     uint32_t* __restrict__ prev, uint32_t* __restrict__ queue /* >= n entries of scratch */)
 {
     if (n < 10) return;                                   // no position is ever searched (ip = 1 < n - 8 fails)
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const nm8 = n - 8, sh = 32 - u.hashLog;
     uint32_t const sliceLog = u.hashLog < ZHIP_HC_SLICE_LOG ? u.hashLog : ZHIP_HC_SLICE_LOG;
-    uint32_t const E = 1u << sliceLog, passes = 1u << (u.hashLog - sliceLog);
+    uint32_t const E = 1u << sliceLog, passes = 1u << (u.hashLog - sliceLog);         // passes <= 8 (hashLog <= 17)
     uint32_t const planeBytes = (E >> 3) < 4 ? 4 : (E >> 3);
     lds_u16* const lo = (lds_u16*)(uintptr_t)smem;
     lds_u32* const hi = (lds_u32*)(uintptr_t)(smem + 2u * E);
-    lds_u32* const queue = (lds_u32*)(uintptr_t)(smem + 2u * E + planeBytes);
+    lds_u32* const ctr = (lds_u32*)(uintptr_t)(smem + 2u * E + planeBytes);            // [0..7] counts, [8..15] start offsets, [16..23] cursors
     unsigned long long const laneBelow = below_mask((int)lane);
 
-    // one table step on `cnt` (<= 64) queue entries starting at ring index qh; entries = position | slice index << 17
-    auto table_step = [&](uint32_t qh, uint32_t cnt, bool anyHigh) {
-        bool const live = lane < cnt;
-        uint32_t const e = queue[(qh + lane) & 127];
-        uint32_t const p = e & 0x1FFFFu, idx = live ? e >> 17 : 0;
-        uint32_t old = lo[idx];
-        if (anyHigh) old |= ((hi[idx >> 5] >> (idx & 31)) & 1u) << 16;
-        __builtin_amdgcn_wave_barrier();
-        if (live) lo[idx] = (uint16_t)lane;
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long const liveMask = below_mask((int)cnt);
-        unsigned long long const lose = __ballot(live && lo[idx] != (uint16_t)lane);
-        uint32_t cand = old;
-        unsigned long long grp = 0;
-        if (lose) {
-            grp = lane_groups(idx, lose, liveMask);
-            unsigned long long const before = grp & laneBelow;
-            uint32_t const pd = before ? 63u - (uint32_t)__clzll((long long)before) : lane;
-            uint32_t const dp = __shfl(p, (int)pd);
-            if (before) cand = dp + 1;
+    // ---- 1. bucket the positions 0 .. n-8 by hash slice (the lazy look-ahead searches up to n-8, :1628)
+    if (lane < 24) ctr[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {                   // scan one: slice sizes
+        uint64_t bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t const p = base0 + 64u * (uint32_t)j + lane, pc = p <= nm8 ? p : nm8;
+            bv[j] = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (live) {
-            prev[p] = cand;
-            if ((grp & ~below_mask((int)lane + 1)) == 0) {                      // the last lane of a hash group wins
-                uint32_t const v = p + 1;
-                lo[idx] = (uint16_t)v;
-                if (v >> 16) __hip_atomic_fetch_or(&hi[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t const p = base0 + 64u * (uint32_t)j + lane;
+            if (p <= nm8) __hip_atomic_fetch_add(&ctr[hash_pos<MLS>(bv[j], sh) >> sliceLog], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < 8; k++) { ctr[8 + k] = acc; ctr[16 + k] = acc; acc += ctr[k]; } }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {                   // scan two: entries = position | slice index << 17
+        uint64_t bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t const p = base0 + 64u * (uint32_t)j + lane, pc = p <= nm8 ? p : nm8;
+            bv[j] = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t const p = base0 + 64u * (uint32_t)j + lane;
+            bool const live = p <= nm8;
+            uint32_t const h = hash_pos<MLS>(bv[j], sh), sl = h >> sliceLog;
+            // lanes of this batch in the same slice, from three ballots over the slice id's bits
+            unsigned long long const b0 = __ballot(sl & 1), b1 = __ballot(sl & 2), b2 = __ballot(sl & 4);
+            unsigned long long same = __ballot(live);
+            same &= (sl & 1) ? b0 : ~b0; same &= (sl & 2) ? b1 : ~b1; same &= (sl & 4) ? b2 : ~b2;
+            uint32_t const rank = (uint32_t)__popcll(same & laneBelow);
+            uint32_t const cur = ctr[16 + sl];
+            __builtin_amdgcn_wave_barrier();
+            if (live) {
+                queue[cur + rank] = p | ((h & (E - 1)) << 17);
+                if ((same & ~below_mask((int)lane + 1)) == 0) ctr[16 + sl] = cur + rank + 1;     // the slice's last lane moves its cursor
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-    };
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
 
+    // ---- 2. one pass per slice: its queue through the LDS table
     for (uint32_t pass = 0; pass < passes; pass++) {
         {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;                       // fresh slice (zstd_compress.c:2020)
             uint32_t const words = (2u * E + planeBytes) >> 2;
             for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t qh = 0, qn = 0;
-        // positions 0 .. n-8 (the lazy look-ahead searches up to n-8, :1628), eight 64-position batches per turn with
-        // all eight source loads issued up front: the scan is otherwise one exposed memory latency per batch
-        for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {
-            uint64_t bv[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint32_t const p = base0 + 64u * (uint32_t)j + lane, pc = p <= nm8 ? p : nm8;
-                bv[j] = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
+        uint32_t const q0 = ctr[8 + pass], q1 = q0 + ctr[pass];
+        for (uint32_t qb = q0; qb < q1; qb += 64) {
+            uint32_t const cnt = q1 - qb < 64 ? q1 - qb : 64;
+            bool const live = lane < cnt;
+            uint32_t const e = live ? queue[qb + lane] : 0;
+            uint32_t const p = e & 0x1FFFFu, idx = e >> 17;
+            bool const anyHigh = __builtin_amdgcn_readlane(p, (int)cnt - 1) >= 65535u;     // positions ascend inside a slice queue
+            uint32_t old = lo[idx];
+            if (anyHigh) old |= ((hi[idx >> 5] >> (idx & 31)) & 1u) << 16;
+            __builtin_amdgcn_wave_barrier();
+            if (live) lo[idx] = (uint16_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long const liveMask = below_mask((int)cnt);
+            unsigned long long const lose = __ballot(live && lo[idx] != (uint16_t)lane);
+            uint32_t cand = old;
+            unsigned long long grp = 0;
+            if (lose) {
+                grp = lane_groups(idx, lose, liveMask);
+                unsigned long long const before = grp & laneBelow;
+                uint32_t const pd = before ? 63u - (uint32_t)__clzll((long long)before) : lane;
+                uint32_t const dp = __shfl(p, (int)pd);
+                if (before) cand = dp + 1;
             }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint32_t const base = base0 + 64u * (uint32_t)j, p = base + lane;
-                bool const live = p <= nm8;
-                uint32_t const h = hash_pos<MLS>(bv[j], sh);
-                bool const mine = live && (h >> sliceLog) == pass;
-                unsigned long long const m = __ballot(mine);
-                if (m) {
-                    uint32_t const rank = (uint32_t)__popcll(m & laneBelow);
-                    if (mine) queue[(qh + qn + rank) & 127] = p | ((h & (E - 1)) << 17);
-                    qn += (uint32_t)__popcll(m);
-                    __builtin_amdgcn_wave_barrier();
-                    if (qn >= 64) { table_step(qh, 64, base + 64 >= 65535u); qh = (qh + 64) & 127; qn -= 64; }
+            __builtin_amdgcn_wave_barrier();
+            if (live) {
+                prev[p] = cand;
+                if ((grp & ~below_mask((int)lane + 1)) == 0) {                      // the last lane of a hash group wins
+                    uint32_t const v = p + 1;
+                    lo[idx] = (uint16_t)v;
+                    if (v >> 16) __hip_atomic_fetch_or(&hi[idx >> 5], 1u << (idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (qn) table_step(qh, qn, nm8 >= 65535u);
     }
 }
 
