@@ -1441,6 +1441,7 @@ struct zo_cdict_s {
     uint32_t* tabL; uint32_t* tabS;        /* fast: tabL only (hashLog); dfast: long (hashLog) + short (chainLog) */
     uint32_t dictID; uint32_t rep[3];
     int level;
+    size_t fullSize;                       /* size of the dictionary buffer as given (cdict->dictContentSize) */
     int hasEntropy; zo_prev prev;          /* ZDICT-format dictionaries: the entropy tables the first block starts from */
 };
 
@@ -1501,6 +1502,7 @@ zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
     if (!cd) return NULL;
     if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 2) { free(cd); return NULL; }
     cd->level = level == 0 ? 3 : level;
+    cd->fullSize = dictSize;
     cd->dictID = 0; cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8; cd->hasEntropy = 0;
     if (dictSize < 8) dictSize = 0;                           /* :5130 dictionaries below 8 bytes are ignored */
     if (dictSize >= 8 && rd32((const uint8_t*)dict) == 0xEC30A437U) {
@@ -1775,13 +1777,213 @@ _cleanup:
 }
 #undef SEQ
 
+/* zstd_fast.c:709-960 ZSTD_compressBlock_fast_extDict_generic — strategy fast in COPY mode (same window layout as
+ * zo_dfast_ext below: dictionary = indices 2 .. P-1, source = indices P ..). */
+static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hlog = cp->hashLog, mls = cp->minMatch;
+    size_t const stepSize = cp->targetLength + !cp->targetLength + 1;
+    size_t const sz = (size_t)1 << hlog;
+    uint32_t* const T = (uint32_t*)malloc(sz * sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
+    const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* anchor = istart, * ip0 = istart, * ip1, * ip2, * ip3, * nextStep, * match0 = NULL, * matchEnd = NULL;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0, current0 = 0, idx, offcode = 0;
+    uint32_t hash0, hash1;
+    size_t step, mLength = 0, i;
+#define PTR(k) ((k) < P ? dictBase + (k) : base + (k))
+    for (i = 0; i < sz; i++) T[i] = cd->tabL[i] >> 8;                             /* :2379-2393 tags removed */
+    {   uint32_t const maxRep = (uint32_t)(ip0 - base) - dictStartIndex;          /* :764-768 */
+        if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
+        if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
+    }
+    for (;;) {   /* _start */
+        int found = 0;
+        step = stepSize; nextStep = ip0 + 128;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        hash0 = zo_hash(ip0, hlog, mls); hash1 = zo_hash(ip1, hlog, mls);
+        idx = T[hash0];
+        do {
+            {   uint32_t const current2 = (uint32_t)(ip2 - base), repIndex = current2 - offset_1;             /* :790-817 */
+                uint32_t rval;
+                if (((uint32_t)(P - repIndex) >= 4) & (offset_1 > 0)) rval = rd32(PTR(repIndex)); else rval = rd32(ip2) ^ 1;
+                current0 = (uint32_t)(ip0 - base); T[hash0] = current0;
+                if (rd32(ip2) == rval) {
+                    ip0 = ip2; match0 = PTR(repIndex); matchEnd = repIndex < P ? dictEnd : iend;
+                    mLength = ip0[-1] == match0[-1];
+                    ip0 -= mLength; match0 -= mLength;
+                    offcode = 1; mLength += 4;
+                    found = 2; break;
+                }
+            }
+            if (idx >= dictStartIndex && rd32(PTR(idx)) == rd32(ip0)) { found = 1; break; }                  /* :819-829 */
+            idx = T[hash1];                                                                                    /* :831-846 */
+            hash0 = hash1; hash1 = zo_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = (uint32_t)(ip0 - base); T[hash0] = current0;
+            if (idx >= dictStartIndex && rd32(PTR(idx)) == rd32(ip0)) { found = 1; break; }                  /* :848-858 */
+            idx = T[hash1];                                                                                    /* :860-880 */
+            hash0 = hash1; hash1 = zo_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;                                                                                     /* _cleanup */
+        if (found == 1) {                                                                                      /* _offset :899-915 */
+            uint32_t const offset = current0 - idx;
+            const uint8_t* const low = idx < P ? dictStart : prefixStart;
+            matchEnd = idx < P ? dictEnd : iend;
+            match0 = PTR(idx);
+            offset_2 = offset_1; offset_1 = offset;
+            offcode = offset + 3; mLength = 4;
+            while (((ip0 > anchor) & (match0 > low)) && ip0[-1] == match0[-1]) { ip0--; match0--; mLength++; }
+        }
+        mLength += zo_count_2seg(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);              /* _match :917-957 */
+        zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(ip0 - anchor), offcode, (uint32_t)mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip1 < ip0) T[hash1] = (uint32_t)(ip1 - base);
+        if (ip0 <= ilimit) {
+            T[zo_hash(base + current0 + 2, hlog, mls)] = current0 + 2;
+            T[zo_hash(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
+            while (ip0 <= ilimit) {
+                uint32_t const repIndex2 = (uint32_t)(ip0 - base) - offset_2;
+                const uint8_t* const repMatch2 = PTR(repIndex2);
+                if ((((uint32_t)((P - 1) - repIndex2) >= 3) & (offset_2 > 0)) && rd32(repMatch2) == rd32(ip0)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    zo_store_seq(st, src, (size_t)(anchor - istart), 0, 1, (uint32_t)rl);
+                    T[zo_hash(ip0, hlog, mls)] = (uint32_t)(ip0 - base);
+                    ip0 += rl; anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+#undef PTR
+    offsetSaved2 = (offsetSaved1 != 0 && offset_1 != 0) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
+    free(T);
+    return (size_t)(iend - anchor);
+}
+
+/* zstd_double_fast.c:551-759 ZSTD_compressBlock_doubleFast_extDict_generic — the COPY mode of a CDict (zstd_compress.c:2395-2470):
+ * the working tables start as copies of the CDict's (tags removed, :2379-2393), the dictionary content is the window's
+ * extDict segment (indices 2 .. P-1), the source the prefix (indices P ..); one table pair serves both segments. */
+#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(litLen), (offBase), (uint32_t)(ml))
+#define PTR(idx) ((idx) < P ? dictBase + (idx) : base + (idx))
+static size_t zo_dfast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
+    size_t const szL = (size_t)1 << hBitsL, szS = (size_t)1 << hBitsS;
+    uint32_t* const hashLong = (uint32_t*)malloc(szL * sizeof(uint32_t));
+    uint32_t* const hashSmall = (uint32_t*)malloc(szS * sizeof(uint32_t));
+    uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
+    const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
+    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* ip = istart, * anchor = istart;
+    uint32_t offset_1 = rep[0], offset_2 = rep[1];
+    size_t i;
+    for (i = 0; i < szL; i++) hashLong[i] = cd->tabL[i] >> 8;
+    for (i = 0; i < szS; i++) hashSmall[i] = cd->tabS[i] >> 8;
+    while (ip < ilimit) {
+        uint32_t const hSmall = zo_hash(ip, hBitsS, mls), hLong = zo_hash(ip, hBitsL, 8);
+        uint32_t const matchIndex = hashSmall[hSmall], matchLongIndex = hashLong[hLong];
+        const uint8_t* match = PTR(matchIndex); const uint8_t* matchLong = PTR(matchLongIndex);
+        uint32_t const curr = (uint32_t)(ip - base), repIndex = curr + 1 - offset_1;
+        const uint8_t* const repMatch = PTR(repIndex);
+        size_t mLength;
+        hashSmall[hSmall] = hashLong[hLong] = curr;
+        if (((uint32_t)((P - 1) - repIndex) >= 3) && (offset_1 <= curr + 1 - dictStartIndex) && rd32(repMatch) == rd32(ip + 1)) {   /* :613 */
+            const uint8_t* const repEnd = repIndex < P ? dictEnd : iend;
+            mLength = zo_count_2seg(ip + 1 + 4, repMatch + 4, iend, repEnd, prefixStart) + 4;
+            ip++;
+            SEQ(ip - anchor, 1, mLength);
+        } else {
+            if (matchLongIndex > dictStartIndex && rd64(matchLong) == rd64(ip)) {             /* :621 */
+                const uint8_t* const matchEnd = matchLongIndex < P ? dictEnd : iend;
+                const uint8_t* const low = matchLongIndex < P ? dictStart : prefixStart;
+                uint32_t offset;
+                mLength = zo_count_2seg(ip + 8, matchLong + 8, iend, matchEnd, prefixStart) + 8;
+                offset = curr - matchLongIndex;
+                while (ip > anchor && matchLong > low && ip[-1] == matchLong[-1]) { ip--; matchLong--; mLength++; }
+                offset_2 = offset_1; offset_1 = offset;
+                SEQ(ip - anchor, offset + 3, mLength);
+            } else if (matchIndex > dictStartIndex && rd32(match) == rd32(ip)) {              /* :633 */
+                uint32_t const h3 = zo_hash(ip + 1, hBitsL, 8), matchIndex3 = hashLong[h3];
+                const uint8_t* match3 = PTR(matchIndex3);
+                uint32_t offset;
+                hashLong[h3] = curr + 1;
+                if (matchIndex3 > dictStartIndex && rd64(match3) == rd64(ip + 1)) {
+                    const uint8_t* const matchEnd = matchIndex3 < P ? dictEnd : iend;
+                    const uint8_t* const low = matchIndex3 < P ? dictStart : prefixStart;
+                    mLength = zo_count_2seg(ip + 9, match3 + 8, iend, matchEnd, prefixStart) + 8;
+                    ip++;
+                    offset = curr + 1 - matchIndex3;
+                    while (ip > anchor && match3 > low && ip[-1] == match3[-1]) { ip--; match3--; mLength++; }
+                } else {
+                    const uint8_t* const matchEnd = matchIndex < P ? dictEnd : iend;
+                    const uint8_t* const low = matchIndex < P ? dictStart : prefixStart;
+                    mLength = zo_count_2seg(ip + 4, match + 4, iend, matchEnd, prefixStart) + 4;
+                    offset = curr - matchIndex;
+                    while (ip > anchor && match > low && ip[-1] == match[-1]) { ip--; match--; mLength++; }
+                }
+                offset_2 = offset_1; offset_1 = offset;
+                SEQ(ip - anchor, offset + 3, mLength);
+            } else { ip += ((ip - anchor) >> 8) + 1; continue; }
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {                                                                   /* :677 */
+            uint32_t const ins = curr + 2;
+            hashLong[zo_hash(base + ins, hBitsL, 8)] = ins;
+            hashLong[zo_hash(ip - 2, hBitsL, 8)] = (uint32_t)(ip - 2 - base);
+            hashSmall[zo_hash(base + ins, hBitsS, mls)] = ins;
+            hashSmall[zo_hash(ip - 1, hBitsS, mls)] = (uint32_t)(ip - 1 - base);
+            while (ip <= ilimit) {
+                uint32_t const current2 = (uint32_t)(ip - base), repIndex2 = current2 - offset_2;
+                const uint8_t* repMatch2 = PTR(repIndex2);
+                if (((uint32_t)((P - 1) - repIndex2) >= 3) && (offset_2 <= current2 - dictStartIndex) && rd32(repMatch2) == rd32(ip)) {
+                    const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
+                    size_t const rl = zo_count_2seg(ip + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
+                    SEQ(0, 1, rl);
+                    hashSmall[zo_hash(ip, hBitsS, mls)] = current2;
+                    hashLong[zo_hash(ip, hBitsL, 8)] = current2;
+                    ip += rl; anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    rep[0] = offset_1; rep[1] = offset_2;
+    free(hashLong); free(hashSmall);
+    return (size_t)(iend - anchor);
+}
+#undef PTR
+#undef SEQ
+
 /* working-context parameters for a source of n bytes compressed with `cd` attached, or -1 if the reference would copy the
  * dictionary instead (zstd_compress.c:2289-2315) — only the attach path is restated */
 int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
 {
     static const size_t cutoff[6] = { 8192, 8192, 16384, 32768, 32768, 32768 };
     zo_cparams p, w;
-    if (n > cutoff[cd->cp.strategy]) return -1;
+    if (n > cutoff[cd->cp.strategy]) {
+        /* COPY mode (zstd_compress.c:2395-2419): the CDict's table parameters as they are, windowLog from the parameters
+         * requested for (level, srcSize, dictSize) with the dictionary counted in (ZSTD_cpm_noAttachDict, :6289-6292).
+         * Strategies fast and dfast are restated (ZSTD_compressBlock_{fast,doubleFast}_extDict). */
+        if (cd->cp.strategy > 2 || n > ZO_BLOCK_MAX) return -1;
+        if (zo_get_cparams_mode(cd->level, n, cd->fullSize, 0, &p) < 0) return -1;
+        w = cd->cp; w.windowLog = p.windowLog;
+        *out = w;
+        return 1;
+    }
     if (zo_get_cparams_mode(cd->level, n, cd->len, 1, &p) < 0) return -1;        /* :6289-6292 requested params, attach mode */
     w = cd->cp;                                                                  /* :2331-2335 */
     zo_adjust_cparams(&w, n, cd->len, 1);
@@ -1854,10 +2056,12 @@ size_t zo_parse_cdict(const zo_cdict* cd, const void* srcv, size_t n, uint32_t* 
     zo_cparams cp; zo_store st; uint32_t rep[3]; size_t i;
     zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (n / 3 + 2));
     uint8_t* lits = (uint8_t*)malloc(n + 8);
-    if (zo_cdict_params(cd, n, &cp) < 0 || n < 8) { free(seqs); free(lits); return ZO_ERROR; }
+    int const mode = zo_cdict_params(cd, n, &cp);
+    if (mode < 0 || n < 8) { free(seqs); free(lits); return ZO_ERROR; }
     rep[0] = cd->rep[0]; rep[1] = cd->rep[1]; rep[2] = cd->rep[2];
     st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
-    if (cp.strategy == 1) zo_fast_dms(&cp, cd, src, n, &st, rep); else zo_dfast_dms(&cp, cd, src, n, &st, rep);
+    if (mode == 1) { if (cp.strategy == 1) zo_fast_ext(&cp, cd, src, n, &st, rep); else zo_dfast_ext(&cp, cd, src, n, &st, rep); }
+    else if (cp.strategy == 1) zo_fast_dms(&cp, cd, src, n, &st, rep); else zo_dfast_dms(&cp, cd, src, n, &st, rep);
     for (i = 0; i < st.nb && i < capSeqs; i++) { out[3*i] = seqs[i].litLength; out[3*i+1] = seqs[i].matchLength; out[3*i+2] = seqs[i].offBase; }
     free(seqs); free(lits);
     return st.nb;
@@ -1869,7 +2073,8 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
     uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
     uint8_t* op = dst; size_t cSize = 0;
     zo_cparams cp;
-    if (zo_cdict_params(cd, n, &cp) < 0 || cap < zo_compress_bound(n)) return ZO_ERROR;
+    int const mode = zo_cdict_params(cd, n, &cp);                                /* 0 attach, 1 copy */
+    if (mode < 0 || cap < zo_compress_bound(n)) return ZO_ERROR;
     if (cd->len == 0) return zo_compress_unit_params(dstv, cap, srcv, n, &cp);  /* :2354 an empty dictionary is not attached, its parameters still apply */
     op += write_frame_header_dict(op, &cp, n, cd->dictID);
     if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
@@ -1881,6 +2086,7 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
         rep[0] = cd->rep[0]; rep[1] = cd->rep[1]; rep[2] = cd->rep[2];
         st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
         if (n < 8) last = n;
+        else if (mode == 1) last = cp.strategy == 1 ? zo_fast_ext(&cp, cd, src, n, &st, rep) : zo_dfast_ext(&cp, cd, src, n, &st, rep);
         else if (cp.strategy == 1) last = zo_fast_dms(&cp, cd, src, n, &st, rep);
         else last = zo_dfast_dms(&cp, cd, src, n, &st, rep);
         memcpy(lits + st.litSize, src + n - last, last);

@@ -65,8 +65,8 @@ def test_cdict_records_match_the_reference(level, kind):
             pos += cs
             mine = np.zeros(len(r) + 600, dtype=np.uint8)
             got = lo.zo_compress_unit_cdict(_buf(mine), len(mine), _buf(r), len(r), cd)
-            if got == ERR:      # above the attach cutoff of this strategy: the reference copies the dictionary (not restated)
-                assert len(r) > 8192
+            if got == ERR:      # a strategy whose dictionary path is not restated
+                assert False, (kind, level, len(r))
                 continue
             assert mine[:got].tobytes() == want, (kind, level, dsize, len(r), got, cs)
             checked += 1
@@ -163,6 +163,46 @@ def test_fuzzed_dictionaries_and_records_match_the_reference():
         for r, cs in zip(recs, osz):
             want = dst[pos:pos + cs].tobytes(); pos += cs
             mine = np.zeros(len(r) + 600, dtype=np.uint8)
+            got = lo.zo_compress_unit_cdict(_buf(mine), len(mine), _buf(r), len(r), cd)
+            assert got != ERR and mine[:got].tobytes() == want, (rd, level, len(r), len(d))
+        lo.zo_cdict_free(cd)
+
+
+def test_copy_mode_records_above_the_attach_cutoff_match_the_reference():
+    """records above the attach cut-off (8 KB fast / 16 KB dfast): the reference copies the CDict's tables and runs the
+    _extDict block compressors (zstd_compress.c:2395, zstd_fast.c:709, zstd_double_fast.c:551)"""
+    import os
+    from test_fuzz_emu import gen
+    lo, lr = load_oracle(), load_ref()
+    bind(lo, lr)
+    zd = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    for rd in range(int(os.environ.get("ZHIP_DICT_FUZZ_ROUNDS", "15"))):
+        rng = np.random.default_rng(555 + rd)
+        level = (3, 1, 4, 2, -3)[rd % 5]
+        d = zd if rd % 4 == 0 else text_like(int(rng.integers(20000, 120000)), rd) if rd % 4 == 1 else gen(rng, int(rng.integers(9, 100000)))
+        cd = lo.zo_cdict_create(_buf(d), len(d), level)
+        if not cd:
+            continue
+        recs = []
+        for _ in range(4):
+            n = int(rng.integers(8193, 131073))
+            r = (text_like(n, rd + 7) if rd % 2 == 0 else gen(rng, n)).copy()
+            for _ in range(int(rng.integers(0, 30))):
+                ln = min(int(rng.integers(8, 3000)), len(d), n)
+                s0 = int(rng.integers(0, len(d) - ln + 1)); o = int(rng.integers(0, n - ln + 1))
+                r[o:o + ln] = d[s0:s0 + ln]
+            recs.append(r)
+        flat = np.concatenate(recs + [np.zeros(8, np.uint8)])
+        sizes = (C.c_size_t * len(recs))(*[len(r) for r in recs])
+        cap = sum(len(r) + 700 for r in recs) + 4096
+        dst = np.zeros(cap, dtype=np.uint8)
+        osz = (C.c_size_t * len(recs))()
+        tot = lr.zref_compress_records_cdict(level, _buf(d), len(d), _buf(flat), sizes, len(recs), _buf(dst), cap, osz)
+        assert tot != ERR
+        pos = 0
+        for r, cs in zip(recs, osz):
+            want = dst[pos:pos + cs].tobytes(); pos += cs
+            mine = np.zeros(len(r) + 700, dtype=np.uint8)
             got = lo.zo_compress_unit_cdict(_buf(mine), len(mine), _buf(r), len(r), cd)
             assert got != ERR and mine[:got].tobytes() == want, (rd, level, len(r), len(d))
         lo.zo_cdict_free(cd)
