@@ -17,7 +17,8 @@ def _buf(a):
 
 def load_oracle():
     so = os.path.join(ORACLE_DIR, "libzoracle.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, "zoracle.c")):
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, f))
+                                     for f in ("zoracle.c", "zoracle_dec.c")):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libzoracle.so"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.zo_compress_bound.restype = C.c_size_t
@@ -46,7 +47,26 @@ def load_oracle():
     lib.zo_fse_normalize.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
     lib.zo_compress_literals.restype = C.c_size_t
     lib.zo_compress_literals.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    # decoder restatement (oracle/zoracle_dec.c)
+    lib.zo_decompress.restype = C.c_size_t
+    lib.zo_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zo_decompress_dict.restype = C.c_size_t
+    lib.zo_decompress_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zo_frame_info.restype = C.c_int
+    lib.zo_frame_info.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     return lib
+
+
+def oracle_decompress(lo, frames, cap, dictionary=None):
+    """bytes -> bytes through the oracle decoder, or None when it reports an error"""
+    src = np.frombuffer(bytes(frames), dtype=np.uint8)
+    dst = np.empty(max(cap, 1), dtype=np.uint8)
+    if dictionary is None:
+        r = lo.zo_decompress(_buf(dst), cap, _buf(src), len(src))
+    else:
+        d = np.frombuffer(bytes(dictionary), dtype=np.uint8)
+        r = lo.zo_decompress_dict(_buf(dst), cap, _buf(src), len(src), _buf(d), len(d))
+    return None if r == ERR else dst[:r].tobytes()
 
 
 def have_ref():
@@ -70,6 +90,11 @@ def load_ref():
     lib.zref_sequences.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.zref_decompress.restype = C.c_size_t
     lib.zref_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_decompress_dict.restype = C.c_size_t
+    lib.zref_decompress_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.zref_compress_records_cdict.restype = C.c_size_t
+    lib.zref_compress_records_cdict.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p, C.c_size_t, C.c_void_p]
     lib.zref_decompressed_size.restype = C.c_ulonglong
     lib.zref_decompressed_size.argtypes = [C.c_void_p, C.c_size_t]
     lib.zref_compress_bound.restype = C.c_size_t
