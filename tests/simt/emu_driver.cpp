@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "zhip_kernels.h"
 #include "zhip_cdict_host.h"
+#include "zhip_ddict_host.h"
 
 #include <vector>
 #include <stdlib.h>
@@ -85,6 +86,34 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
                  [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
     return 0;
 }
+
+// decoder: frames[] describe where each frame lies in src and where its content goes in dst; a dictionary is optional.
+// returns 0, or the host_ddict_build error
+int emu_decode(const uint8_t* src, const ZhipDFrame* frames, uint32_t nFrames, uint8_t* dst, const uint8_t* dict, size_t dictSize,
+               ZhipDResult* results, uint32_t nGroups, int osThreads)
+{
+    zhip::HostDDict dd; ZhipDDictDev dv; memset(&dv, 0, sizeof(dv));
+    if (dict) {
+        int const e = zhip::host_ddict_build(dd, dict, dictSize);
+        if (e) return e;
+        dv.len = (uint32_t)dd.content.size();
+        if (dd.content.empty()) dd.content.push_back(0);
+        dv.content = dd.content.data();
+        dv.dictID = dd.dictID; dv.hasEntropy = dd.hasEntropy; dv.hufLog = dd.hufLog; dv.huf = dd.huf.data(); dv.fse = dd.fse.data();
+        for (int k = 0; k < 3; k++) { dv.log[k] = dd.log[k]; dv.rep[k] = dd.rep[k]; }
+    }
+    uint64_t defTabs[160]; zhip::host_dec_default_tables(defTabs);
+    if (nGroups == 0 || nGroups > nFrames) nGroups = nFrames ? nFrames : 1;
+    std::vector<uint8_t> lit((size_t)nGroups * ZHIP_DEC_LIT_STRIDE, 0xEE);
+    std::vector<ZhipDSeq> recs((size_t)nGroups * 2 * (ZHIP_DEC_CHUNK + 1));
+    uint32_t counter = 0; uint32_t* const cp = &counter;
+    uint8_t* const lp = lit.data(); ZhipDSeq* const rp = recs.data(); const uint64_t* const dt = defTabs;
+    simt::launch({nGroups, 1, 1}, {ZHIP_DEC_THREADS, 1, 1}, sizeof(zhip::DecShared),
+                 [=] { zhip::k_decode(src, frames, nFrames, dst, lp, rp, cp, dv, dt, results); }, osThreads);
+    return 0;
+}
+uint32_t emu_sizeof_dframe(void) { return sizeof(ZhipDFrame); }
+uint32_t emu_dec_shared(void) { return (uint32_t)sizeof(zhip::DecShared); }
 
 // stage 2 for `nUnits` units: out slots of ZHIP_OUT_STRIDE bytes, outSize[nUnits]
 // XXH64 of every unit (frame checksums)

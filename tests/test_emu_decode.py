@@ -1,0 +1,151 @@
+"""The device decoder (zstd_amd/csrc/zhip_decode.h, unmodified) on the host SIMT emulator, checked against the oracle decoder
+and the committed decode vectors: the wave-level logic (bit readers, table builds, producer/consumer hand-over, lane-parallel
+copies) without a GPU."""
+import base64, ctypes as C, hashlib, json, os, zlib
+import numpy as np
+import pytest
+from _libs import load_oracle, load_emu, load_ref, have_ref, _buf, ERR, datagen, text_like, oracle_decompress, corpus_cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode_v1.json")
+DFRAME_DT = np.dtype([("srcOff", "<u8"), ("dstOff", "<u8"), ("srcLen", "<u4"), ("dstCap", "<u4")])
+DRESULT_DT = np.dtype([("status", "<u4"), ("size", "<u4"), ("hasChecksum", "<u4"), ("checksum", "<u4")])
+
+
+def unpack(s):
+    return zlib.decompress(base64.b64decode(s))
+
+
+@pytest.fixture(scope="module")
+def libs():
+    lo, le = load_oracle(), load_emu()
+    assert le.emu_sizeof_dframe() == DFRAME_DT.itemsize
+    le.emu_decode.restype = C.c_int
+    le.emu_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_int]
+    return lo, le
+
+
+def emu_decode(le, frames, caps, dictionary=None, groups=0):
+    """frames: list of bytes, caps: room per frame -> list of (status, bytes)"""
+    src = np.frombuffer(b"".join(frames) + b"\x00" * 16, dtype=np.uint8).copy()
+    fr = np.zeros(len(frames), dtype=DFRAME_DT)
+    so = do = 0
+    for i, (f, c) in enumerate(zip(frames, caps)):
+        fr[i] = (so, do, len(f), c)
+        so += len(f); do += c
+    dst = np.full(do + 64, 0xEE, dtype=np.uint8)
+    res = np.zeros(len(frames), dtype=DRESULT_DT)
+    d = None if dictionary is None else np.frombuffer(bytes(dictionary), dtype=np.uint8)
+    e = le.emu_decode(_buf(src), _buf(fr), len(frames), _buf(dst), None if d is None else _buf(d), 0 if d is None else len(d),
+                      _buf(res), groups, 0)
+    assert e == 0
+    out = []
+    for i in range(len(frames)):
+        o = int(fr["dstOff"][i])
+        out.append((int(res["status"][i]), dst[o:o + int(res["size"][i])].tobytes(), res[i]))
+    assert (dst[do:] == 0xEE).all(), "wrote past the destination"
+    return out
+
+
+def test_golden_vectors_on_the_emulator(libs):
+    lo, le = libs
+    g = json.load(open(GOLD))
+    vs = g["fixtures"] + g["frames"]
+    frames = [unpack(v["zst"]) for v in vs]
+    got = emu_decode(le, frames, [v["size"] for v in vs], groups=3)
+    for v, (st, data, _) in zip(vs, got):
+        assert st == 0, (v["name"], st)
+        assert len(data) == v["size"] and hashlib.sha256(data).hexdigest() == v["sha256"], v["name"]
+    bad = emu_decode(le, [unpack(v["zst"]) for v in g["errors"]], [4096] * len(g["errors"]))
+    for v, (st, _, _) in zip(g["errors"], bad):
+        assert st != 0, v["name"]
+
+
+def test_own_frames_round_trip(libs):
+    """frames of the oracle's compressor (= the product's byte stream) at all implemented levels, ragged sizes"""
+    lo, _ = libs
+    le = libs[1]
+    frames, want = [], []
+    for n in (0, 1, 6, 7, 64, 1000, 4097, 70000, 131072):
+        for name, a in (corpus_cases(lo, sizes=(n,), seeds=(2,)) if n else [("empty", np.zeros(0, dtype=np.uint8))]):
+            if n >= 70000 and not any(k in name for k in ("P50", "text", "zeros", "random", "period7", "farmatch", "halfrun", "lowent")):
+                continue
+            for level in (1, 3, 5):
+                cap = lo.zo_compress_bound(max(n, 1)) + 64
+                dst = np.empty(cap, dtype=np.uint8)
+                r = lo.zo_compress_unit(_buf(dst), cap, _buf(a) if n else None, n, level)
+                assert r != ERR
+                frames.append(dst[:r].tobytes()); want.append(a.tobytes())
+    got = emu_decode(le, frames, [len(w) for w in want], groups=0)
+    for i, ((st, data, _), w) in enumerate(zip(got, want)):
+        assert st == 0 and data == w, (i, st, len(w))
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_reference_frames_and_corruptions(libs):
+    lo, le = libs
+    lr = load_ref()
+    from test_oracle_decode import ref_frame
+    rng = np.random.default_rng(21)
+    frames, want = [], []
+    for kind, n, level in (("text", 300000, 3), ("P50", 200000, 1), ("text", 50000, 19), ("P80", 140000, -3), ("text", 9000, 7), ("P50", 131072, 12)):
+        a = text_like(n, 5) if kind == "text" else datagen(lo, n, int(kind[1:]), 6)
+        frames.append(ref_frame(lr, a, level)); want.append(a.tobytes())
+    got = emu_decode(le, frames, [len(w) for w in want])
+    for (st, data, _), w in zip(got, want):
+        assert st == 0 and data == w
+    # corrupted frames: the device rejects whatever the oracle rejects and decodes alike otherwise
+    base = ref_frame(lr, text_like(5000, 9), 3)
+    muts = []
+    for _ in range(120):
+        b = bytearray(base)
+        k = rng.integers(0, 3)
+        if k == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            del b[int(rng.integers(9, len(b))):]
+        muts.append(bytes(b))
+    got = emu_decode(le, muts, [8192] * len(muts))
+    nerr = 0
+    for m, (st, data, _) in zip(muts, got):
+        w = oracle_decompress(lo, m, 8192)
+        if w is None:
+            assert st != 0, m.hex()[:60]
+            nerr += 1
+        else:
+            assert st == 0 and data == w, (st, m.hex()[:60])
+    assert nerr > 30
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_dictionary_frames_on_the_emulator(libs):
+    lo, le = libs
+    lr = load_ref()
+    zd = np.fromfile(os.path.join(os.path.dirname(GOLD), "github_like_110k.zdict"), dtype=np.uint8)
+    rng = np.random.default_rng(8)
+    raw = text_like(20000, 31)
+    for dict_ in (zd, raw):
+        recs = []
+        for i in range(24):
+            n = int(rng.integers(20, 2500))
+            st = int(rng.integers(0, len(dict_) - n))
+            r = dict_[st:st + n].copy()
+            r[rng.integers(0, n, size=max(1, n // 40))] = rng.integers(32, 127, size=max(1, n // 40), dtype=np.uint8)
+            recs.append(r)
+        src = np.concatenate(recs)
+        sizes = (C.c_size_t * len(recs))(*[len(r) for r in recs])
+        outs = (C.c_size_t * len(recs))()
+        cap = int(lr.zref_compress_bound(len(src))) + 64 * len(recs)
+        dst = np.empty(cap, dtype=np.uint8)
+        tot = lr.zref_compress_records_cdict(3, _buf(dict_), len(dict_), _buf(src), sizes, len(recs), _buf(dst), cap, outs)
+        assert tot != ERR
+        frames, off = [], 0
+        for i in range(len(recs)):
+            frames.append(dst[off:off + outs[i]].tobytes()); off += outs[i]
+        got = emu_decode(le, frames, [len(r) for r in recs], dictionary=dict_.tobytes(), groups=2)
+        for (st, data, _), r in zip(got, recs):
+            assert st == 0 and data == r.tobytes()
+        if dict_ is zd:                                        # the frames name their dictionary: decoding without it is refused
+            st, _, _ = emu_decode(le, frames[:1], [4096])[0]
+            assert st == 32

@@ -1,0 +1,778 @@
+// zhip_decode.h — gfx950 frame decoder: the step on the other side of the block-compression path.
+//
+// WHAT it computes: for every frame of a batch exactly what the reference's ZSTD_decompress (lib/decompress/
+// zstd_decompress.c:951-1064 ZSTD_decompressFrame) regenerates — any RFC 8878 frame (raw / RLE / compressed blocks,
+// several blocks per frame with repeat / treeless modes, optional checksum, optional dictionary), i.e. the frames this
+// library emits and the frames the reference emits.  Corrupted input is reported per frame with zstd's error codes.
+//
+// HOW (CDNA4 design).  Entropy decoding is serial per bitstream (a Huffman stream or the interleaved FSE stream cannot be
+// entered in the middle), so parallelism comes from the batch: one 128-thread workgroup (two wavefronts) per frame, eight
+// workgroups resident per CU (20 KB of LDS each), workgroups fetch frames from a queue.  Inside a workgroup the two
+// wavefronts are a producer / consumer pair:
+//   * wave 0: the literals section — Huffman table from the tree description into LDS (HUF_readStats + HUF_readDTableX1,
+//     lib/common/entropy_common.c:236-320, lib/decompress/huf_decompress.c:385-500), then the four streams decoded by
+//     four lanes in lockstep (one LDS lookup per symbol; the compressed bytes are streamed 8 at a time one load ahead so
+//     the serial chain never waits on HBM);
+//   * wave 1: the sequences section — the three FSE decoding tables into LDS (ZSTD_buildFSETable,
+//     zstd_decompress_block.c:484-585; three lanes build LL / OF / ML concurrently), then one lane walks the interleaved
+//     bitstream (ZSTD_decodeSequence :1228-1345) and hands over records {output position, literal position, offset,
+//     match length} in chunks of ZHIP_DEC_CHUNK through an L2-resident buffer;
+//   * wave 0 then executes a chunk (ZSTD_execSequence :1001-1095) while wave 1 decodes the next one: literals of 64
+//     sequences are copied lane-parallel (their positions are known from the records), matches in order, each with a
+//     wave-wide copy (512 B per step); a match whose source was written since the last `s_waitcnt vmcnt(0)` waits, all
+//     others stream.  Overlapping matches (offset < length) are a periodic pattern of bytes that already exist, so they
+//     are copied lane-parallel too (source index modulo the offset).
+// Bound: latency of the serial chains (LDS lookups, one L2 round trip per dependent match); HBM traffic is the compressed
+// bytes in, the content out, plus 32 B per sequence of hand-over records that stay in L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zhip_common.h"
+#include "zhip_parse.h"
+
+#define ZHIP_DEC_THREADS 128
+#define ZHIP_DEC_CHUNK   2048u                 /* sequences per hand-over buffer */
+#define ZHIP_DEC_LIT_STRIDE (ZHIP_UNIT_MAX + 64)
+
+// zstd error codes (lib/zstd_errors.h) used as per-frame status
+enum { ZHIP_DE_OK = 0, ZHIP_DE_PREFIX = 10, ZHIP_DE_UNSUPPORTED = 14, ZHIP_DE_WINDOW = 16, ZHIP_DE_CORRUPT = 20, ZHIP_DE_CHECKSUM = 22,
+       ZHIP_DE_DICT_CORRUPT = 30, ZHIP_DE_DICT_WRONG = 32, ZHIP_DE_DST_SMALL = 70, ZHIP_DE_SRC_WRONG = 72 };
+
+struct ZhipDFrame {          // one per frame, filled by the host
+    uint64_t srcOff;         // where the frame starts in the compressed buffer
+    uint64_t dstOff;         // where its content goes in the destination buffer
+    uint32_t srcLen;         // compressed size of the frame (header .. checksum)
+    uint32_t dstCap;         // room at dstOff (the content size when the frame header states it)
+};
+struct ZhipDResult {         // one per frame, written by the device
+    uint32_t status;         // 0 or a zstd error code
+    uint32_t size;           // decoded bytes
+    uint32_t hasChecksum;    // frame carries a content checksum ...
+    uint32_t checksum;       // ... this one (verified by k_xxh64 + k_dec_verify)
+};
+struct ZhipDSeq { uint32_t outPos, litPos, off, ml; };      // positions are frame- resp. block-relative
+
+// a dictionary as the decoder needs it (host-built, zhip_ddict_host.h): content + the entropy tables in decoding form
+struct ZhipDDictDev {
+    const uint8_t*  content; uint32_t len; uint32_t dictID;
+    uint32_t hasEntropy, hufLog;
+    const uint16_t* huf;                     // 1 << hufLog entries: symbol | nbBits << 8
+    const uint64_t* fse;                     // LL[512] OF[256] ML[512] in ZhipFseD packing
+    uint32_t log[3];                         // LL, OF, ML table logs
+    uint32_t rep[3];
+};
+
+namespace zhip {
+
+// ------------------------------------------------------------------ tables of the format (doc/zstd_compression_format.md;
+// lib/common/zstd_internal.h:123-160, lib/decompress/zstd_decompress_block.c:347-470)
+__device__ __host__ inline uint32_t dec_ll_base(uint32_t c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : 1u << (c - 19); }
+__device__ __host__ inline uint32_t dec_ll_bits(uint32_t c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
+__device__ __host__ inline uint32_t dec_ml_base(uint32_t c) { return c < 32 ? c + 3 : c < 36 ? 35 + 2 * (c - 32) : c < 38 ? 43 + 4 * (c - 36) : c < 40 ? 51 + 8 * (c - 38) : c < 42 ? 67 + 16 * (c - 40) : c == 42 ? 99 : (1u << (c - 36)) + 3; }
+__device__ __host__ inline uint32_t dec_ml_bits(uint32_t c) { return c < 32 ? 0 : c < 36 ? 1 : c < 38 ? 2 : c < 40 ? 3 : c < 42 ? 4 : c == 42 ? 5 : c - 36; }
+__device__ __host__ inline uint32_t dec_of_base(uint32_t c) { return c == 0 ? 0 : c == 1 ? 1 : (1u << c) - 3; }
+// default distributions (zstd_internal.h:150-190): LL log 6, OF log 5, ML log 6
+__device__ __host__ inline int dec_default_norm(int kind, uint32_t s)
+{
+    if (kind == 0) return s == 0 ? 4 : s == 1 ? 3 : s <= 12 ? 2 : s <= 15 ? 1 : s <= 24 ? 2 : s == 25 ? 3 : s == 26 ? 2 : s <= 31 ? 1 : -1;
+    if (kind == 1) return s <= 5 ? 1 : s <= 8 ? 2 : s <= 23 ? 1 : -1;
+    return s == 0 ? 1 : s == 1 ? 4 : s == 2 ? 3 : s <= 8 ? 2 : s <= 45 ? 1 : -1;
+}
+__device__ __host__ inline uint32_t dec_max_sym(int kind) { return kind == 0 ? 35u : kind == 1 ? 31u : 52u; }
+__device__ __host__ inline uint32_t dec_max_log(int kind) { return kind == 1 ? 8u : 9u; }
+__device__ __host__ inline uint32_t dec_hb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// FSE decoding entry = ZSTD_seqSymbol (zstd_decompress_block.h): nextState u16 | nbAdditionalBits u8 << 16 | nbBits u8 << 24 | baseValue << 32
+__device__ __host__ inline uint64_t fse_d_pack(uint32_t next, uint32_t nbAdd, uint32_t nb, uint32_t base) { return (uint64_t)next | ((uint64_t)nbAdd << 16) | ((uint64_t)nb << 24) | ((uint64_t)base << 32); }
+__device__ __host__ inline void dec_base_bits(int kind, uint32_t s, uint32_t* base, uint32_t* bits)
+{
+    if (kind == 0) { *base = dec_ll_base(s); *bits = dec_ll_bits(s); }
+    else if (kind == 1) { *base = dec_of_base(s); *bits = s; }
+    else { *base = dec_ml_base(s); *bits = dec_ml_bits(s); }
+}
+
+// ZSTD_buildFSETable_body (zstd_decompress_block.c:484-585), serial; T has 1 << tableLog entries, symOf/next are scratch.
+// TT / TS / TN are pointer types so that the same code serves LDS (device) and plain memory (host-built dictionary tables).
+template <typename TT, typename TS, typename TN, typename TNORM>
+__device__ __host__ inline void fse_d_build(TT T, TS symOf, TN next, TNORM norm, uint32_t maxSym, int kind, uint32_t tableLog)
+{
+    uint32_t const tsz = 1u << tableLog, mask = tsz - 1, step = (tsz >> 1) + (tsz >> 3) + 3;
+    uint32_t high = tsz - 1, pos = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) { int const c = norm[s]; if (c == -1) { symOf[high--] = (uint8_t)s; next[s] = 1; } else next[s] = (uint16_t)c; }
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        int const c = norm[s];
+        for (int i = 0; i < c; i++) { symOf[pos] = (uint8_t)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
+    }
+    for (uint32_t u = 0; u < tsz; u++) {
+        uint32_t const sy = symOf[u]; uint32_t const ns = next[sy]; next[sy] = (uint16_t)(ns + 1);
+        uint32_t const nb = tableLog - dec_hb(ns);
+        uint32_t base, bits; dec_base_bits(kind, sy, &base, &bits);
+        T[u] = fse_d_pack(((ns << nb) - tsz) & 0xFFFFu, bits, nb, base);
+    }
+}
+
+// FSE_readNCount (lib/common/entropy_common.c:42-214) from a byte pointer readable up to `size`; returns bytes consumed or 0
+template <typename TNORM>
+__device__ __host__ inline uint32_t fse_d_read_ncount(TNORM norm, uint32_t* maxSymIO, uint32_t* tableLog, const uint8_t* src, uint32_t size)
+{
+    uint32_t const maxSV1 = *maxSymIO + 1;
+    uint32_t bit = 0, charnum = 0; int remaining, threshold, nbBits; bool previous0 = false;
+    auto peek = [&](uint32_t at, uint32_t n) -> uint32_t {
+        uint64_t v = 0; uint32_t const byte = at >> 3;
+        for (uint32_t i = 0; i < 5; i++) if (byte + i < size) v |= (uint64_t)src[byte + i] << (8 * i);
+        return (uint32_t)((v >> (at & 7)) & ((1ull << n) - 1));
+    };
+    if (size == 0) return 0;
+    for (uint32_t s = 0; s < maxSV1; s++) norm[s] = 0;
+    nbBits = (int)peek(bit, 4) + 5; bit += 4;
+    if (nbBits > 15) return 0;
+    *tableLog = (uint32_t)nbBits;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    while (remaining > 1 && charnum < maxSV1) {
+        if (previous0) {
+            for (;;) { uint32_t const r = peek(bit, 2); bit += 2; charnum += r; if (r != 3) break; if (bit > 8 * size + 64) return 0; }
+            if (charnum >= maxSV1) break;
+        }
+        int const mx = (2 * threshold - 1) - remaining;
+        uint32_t const bits = peek(bit, (uint32_t)nbBits);
+        int count;
+        if ((int)(bits & (uint32_t)(threshold - 1)) < mx) { count = (int)(bits & (uint32_t)(threshold - 1)); bit += (uint32_t)nbBits - 1; }
+        else { count = (int)(bits & (uint32_t)(2 * threshold - 1)); if (count >= threshold) count -= mx; bit += (uint32_t)nbBits; }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        norm[charnum++] = (int16_t)count;
+        previous0 = !count;
+        while (remaining < threshold) { nbBits--; threshold >>= 1; }
+    }
+    if (remaining != 1 || charnum > maxSV1 || bit > 8 * size) return 0;
+    *maxSymIO = charnum - 1;
+    return (bit + 7) >> 3;
+}
+
+#ifndef ZHIP_DECODE_HOST_ONLY
+// ------------------------------------------------------------------ LDS of one workgroup
+struct DecShared {
+    uint64_t fseAll[1280];           // LL[512] OF[256] ML[512] decoding tables (dec_tab())
+    uint16_t huf[4096];              // symbol | nbBits << 8, 1 << hufLog entries
+    int16_t  norm[3][64];
+    uint16_t next[3][64];
+    uint8_t  symOf[3][512];
+    uint8_t  weights[256];
+    uint16_t wNew[64]; uint8_t wSym[64], wNb[64];    // FSE table of the Huffman weights (table log <= 6)
+    uint16_t hufStart[256];          // first table entry of each symbol while the Huffman table is being filled
+    uint32_t frame;                  // queue ticket
+    uint32_t status;                 // first error of the frame
+    uint32_t hufLog, hufValid, fseValid;
+    uint32_t log[3];
+    uint32_t rep[3];
+    uint32_t litSize, litMode, litByte, litSecSize;   // litMode 0: decoded into the literal buffer, 1: raw (in the source), 2: RLE
+    uint32_t litSrcOff;              // raw literals: offset of the first literal in the block
+    uint32_t nbSeq, seqDone;
+    uint32_t cnt[2];                 // records in each hand-over buffer
+    uint32_t endOut, endLit;         // positions after the last decoded sequence
+};
+
+__device__ __forceinline__ uint64_t* dec_tab(DecShared* S, uint32_t k) { return S->fseAll + (k == 0 ? 0u : k == 1 ? 512u : 768u); }
+
+// ------------------------------------------------------------------ backward bit reader (lib/common/bitstream.h:250-420)
+// Stream bytes [base, base+size); the last byte holds the end mark.  Bits are consumed from just below the mark downwards.
+// `acc` holds upcoming bits at its top; refills come from `stash` (64 bits, loaded earlier) in 32-bit halves, and the next
+// 8 bytes are requested the moment the stash is replaced, a whole 64 bits of decoding before they are needed.  Bytes
+// before `base` read as zero; `used` against `total` is BIT_endOfDStream's test.  Every stream of a frame is preceded by at
+// least 8 bytes of that frame (magic, descriptor, block header), so the 8-byte loads never leave the buffer.
+struct BitsRev {
+    const uint8_t* base; int32_t ptr;        // bytes [0, ptr) not requested yet
+    uint64_t acc, stash, pend; int32_t n, half; int32_t loaded, total;
+};
+__device__ __forceinline__ uint64_t br_load(const uint8_t* base, int32_t& ptr)
+{
+    if (ptr >= 8) { ptr -= 8; return ld64(base + ptr); }
+    if (ptr <= 0) return 0;
+    uint64_t const v = ld64(base + ptr - 8) & (~0ull << (8 * (8 - ptr)));
+    ptr = 0;
+    return v;
+}
+// false = empty stream or missing end mark (bitstream.h:262, :284)
+__device__ __forceinline__ bool br_init(BitsRev& b, const uint8_t* base, uint32_t size)
+{
+    b.base = base; b.ptr = (int32_t)size; b.n = 0; b.half = 0; b.loaded = 0; b.total = 0; b.acc = b.stash = b.pend = 0;
+    if (size == 0) return false;
+    uint32_t const last = base[size - 1];
+    if (last == 0) return false;
+    uint32_t const hb = dec_hb(last);
+    uint64_t const first = br_load(base, b.ptr);            // the stream's top 8 bytes (zero-extended below its start)
+    b.total = (int32_t)(8 * (size - 1) + hb);
+    b.acc = (first << (7 - hb)) << 1;                       // drop the mark and what lies above it
+    b.n = (int32_t)(56 + hb); b.loaded = b.n;
+    b.stash = br_load(base, b.ptr);
+    b.pend = br_load(base, b.ptr);
+    return true;
+}
+__device__ __forceinline__ void br_refill(BitsRev& b)       // call when n <= 32; afterwards 32 < n <= 64
+{
+    b.acc |= (b.stash >> 32) << (32 - b.n);
+    b.n += 32; b.loaded += 32;
+    b.stash <<= 32;
+    if (b.half) { b.stash = b.pend; b.pend = br_load(b.base, b.ptr); }
+    b.half ^= 1;
+}
+__device__ __forceinline__ uint32_t br_read(BitsRev& b, uint32_t nb)     // nb <= 32, nb <= n
+{
+    uint32_t const v = nb ? (uint32_t)(b.acc >> (64 - nb)) : 0u;
+    b.acc = nb >= 64 ? 0 : b.acc << nb; b.n -= (int32_t)nb;
+    return v;
+}
+__device__ __forceinline__ int32_t br_used(const BitsRev& b) { return b.loaded - b.n; }
+
+// ------------------------------------------------------------------ frame header (zstd_decompress.c:438-545)
+struct DecHeader { uint32_t size; uint32_t checksum, single; uint32_t dictID; uint64_t fcs; uint32_t blockMax; uint32_t err; };
+__device__ inline DecHeader dec_frame_header(const uint8_t* p, uint32_t n)
+{
+    DecHeader h; h.size = 0; h.checksum = 0; h.single = 0; h.dictID = 0; h.fcs = ~0ull; h.blockMax = ZHIP_UNIT_MAX; h.err = 0;
+    if (n < 5 + 3) { h.err = ZHIP_DE_SRC_WRONG; return h; }
+    if (ld32(p) != 0xFD2FB528u) { h.err = ZHIP_DE_PREFIX; return h; }
+    uint32_t const fhd = p[4], didCode = fhd & 3, fcsCode = fhd >> 6;
+    h.checksum = (fhd >> 2) & 1; h.single = (fhd >> 5) & 1;
+    if (fhd & 8) { h.err = ZHIP_DE_UNSUPPORTED; return h; }
+    uint32_t const didB = didCode == 3 ? 4 : didCode, fcsB = fcsCode == 0 ? (h.single ? 1u : 0u) : (1u << fcsCode);
+    h.size = 5 + (h.single ? 0u : 1u) + didB + fcsB;
+    if (n < h.size + 3) { h.err = ZHIP_DE_SRC_WRONG; return h; }
+    uint32_t pos = 5; uint64_t window = 0;
+    if (!h.single) {
+        uint32_t const wl = (p[pos] >> 3) + 10;
+        if (wl > 31) { h.err = ZHIP_DE_WINDOW; return h; }
+        window = 1ull << wl; window += (window >> 3) * (p[pos] & 7); pos++;
+    }
+    for (uint32_t i = 0; i < didB; i++) h.dictID |= (uint32_t)p[pos + i] << (8 * i);
+    pos += didB;
+    if (fcsB) { uint64_t v = 0; for (uint32_t i = 0; i < fcsB; i++) v |= (uint64_t)p[pos + i] << (8 * i); if (fcsCode == 1) v += 256; h.fcs = v; }
+    if (h.single) window = h.fcs;
+    h.blockMax = window < ZHIP_UNIT_MAX ? (uint32_t)window : ZHIP_UNIT_MAX;
+    return h;
+}
+
+// ------------------------------------------------------------------ literals section, wave 0
+// header fields (zstd_decompress_block.c:134-345), computed by every lane that needs them
+struct LitHeader { uint32_t type, lh, litSize, cSize, single, err; };
+__device__ inline LitHeader dec_lit_header(const uint8_t* ip, uint32_t size, uint32_t blockMax)
+{
+    LitHeader h; h.err = 0; h.single = 0; h.cSize = 0; h.lh = 0; h.litSize = 0; h.type = 0;
+    if (size < 2) { h.err = ZHIP_DE_CORRUPT; return h; }
+    uint32_t const b0 = ip[0], sf = (b0 >> 2) & 3;
+    h.type = b0 & 3;
+    if (h.type >= 2) {
+        if (size < 5) { h.err = ZHIP_DE_CORRUPT; return h; }
+        uint32_t const lhc = ld32(ip);
+        if (sf < 2) { h.single = !sf; h.lh = 3; h.litSize = (lhc >> 4) & 0x3FF; h.cSize = (lhc >> 14) & 0x3FF; }
+        else if (sf == 2) { h.lh = 4; h.litSize = (lhc >> 4) & 0x3FFF; h.cSize = lhc >> 18; }
+        else { h.lh = 5; h.litSize = (lhc >> 4) & 0x3FFFF; h.cSize = (lhc >> 22) + ((uint32_t)ip[4] << 10); }
+        if (h.litSize > blockMax || (!h.single && h.litSize < 6) || h.cSize + h.lh > size) h.err = ZHIP_DE_CORRUPT;
+    } else {
+        if (sf == 0 || sf == 2) { h.lh = 1; h.litSize = b0 >> 3; }
+        else if (sf == 1) { h.lh = 2; h.litSize = (ld32(ip) & 0xFFFF) >> 4; }
+        else { h.lh = 3; if (size < 3) { h.err = ZHIP_DE_CORRUPT; return h; } h.litSize = (ld32(ip) & 0xFFFFFF) >> 4; }
+        h.cSize = h.type == 0 ? h.litSize : 1;
+        if (h.litSize > blockMax || h.lh + h.cSize > size) h.err = ZHIP_DE_CORRUPT;
+    }
+    return h;
+}
+
+// Huffman weights compressed with FSE (lib/common/fse_decompress.c:58-277): lane 0 only. returns the number of weights, 0 = error
+__device__ inline uint32_t dec_fse_weights(DecShared* S, const uint8_t* src, uint32_t size)
+{
+    uint32_t maxSym = 255, tl;
+    int16_t norm[256];
+    uint32_t const h = fse_d_read_ncount(norm, &maxSym, &tl, src, size);
+    if (!h || tl > 6 || h >= size) return 0;
+    {   uint32_t const tsz = 1u << tl, mask = tsz - 1, step = (tsz >> 1) + (tsz >> 3) + 3; uint32_t high = tsz - 1, pos = 0;
+        uint16_t nx[256];
+        for (uint32_t s = 0; s <= maxSym; s++) { if (norm[s] == -1) { S->wSym[high--] = (uint8_t)s; nx[s] = 1; } else nx[s] = (uint16_t)norm[s]; }
+        for (uint32_t s = 0; s <= maxSym; s++) for (int i = 0; i < norm[s]; i++) { S->wSym[pos] = (uint8_t)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
+        if (pos != 0) return 0;
+        for (uint32_t u = 0; u < tsz; u++) { uint32_t const ns = nx[S->wSym[u]]++; uint32_t const nb = tl - dec_hb(ns); S->wNb[u] = (uint8_t)nb; S->wNew[u] = (uint16_t)((ns << nb) - tsz); }
+    }
+    BitsRev b;
+    if (!br_init(b, src + h, size - h)) return 0;
+    uint32_t s1 = br_read(b, tl), s2 = br_read(b, tl), n = 0; bool which = false;
+    for (;;) {                                                 // fse_decompress.c:207-233
+        if (b.n <= 32) br_refill(b);
+        uint32_t const st = which ? s2 : s1, other = which ? s1 : s2;
+        uint32_t const nb = S->wNb[st];
+        if (n + 2 > 255) return 0;
+        S->weights[n++] = S->wSym[st];
+        uint32_t const ns = S->wNew[st] + br_read(b, nb);
+        if (which) s2 = ns; else s1 = ns;
+        if (br_used(b) > b.total) { S->weights[n++] = S->wSym[other]; break; }
+        which = !which;
+    }
+    return n;
+}
+
+// tree description -> decoding table in LDS (HUF_readStats + HUF_readDTableX1_wksp); whole wave 0, control on lane 0.
+// returns bytes consumed, 0 = error
+__device__ inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint32_t size)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t ok = 0, consumed = 0, nbSym = 0, tableLog = 0;
+    if (lane == 0 && size) {
+        uint32_t iSize = src[0], oSize = 0; bool good = true;
+        if (iSize >= 128) {
+            oSize = iSize - 127; iSize = (oSize + 1) / 2;
+            if (iSize + 1 > size) good = false;
+            else for (uint32_t n = 0; n < oSize; n += 2) { S->weights[n] = src[1 + n / 2] >> 4; S->weights[n + 1] = src[1 + n / 2] & 15; }
+        } else {
+            if (iSize + 1 > size) good = false;
+            else { oSize = dec_fse_weights(S, src + 1, iSize); if (!oSize) good = false; }
+        }
+        if (good) {
+            uint32_t rank[16], total = 0;
+            for (int i = 0; i < 16; i++) rank[i] = 0;
+            for (uint32_t n = 0; n < oSize; n++) { uint32_t const w = S->weights[n]; if (w > 12) { good = false; break; } rank[w]++; total += (1u << w) >> 1; }
+            if (good && total) {
+                tableLog = dec_hb(total) + 1;
+                uint32_t const rest = (1u << tableLog) - total;
+                if (tableLog > 12 || (1u << dec_hb(rest)) != rest) good = false;
+                else {
+                    uint32_t const last = dec_hb(rest) + 1;
+                    S->weights[oSize] = (uint8_t)last; rank[last]++;
+                    if (rank[1] < 2 || (rank[1] & 1)) good = false;
+                }
+            } else good = false;
+            if (good) {
+                // table ranges: weight 1 symbols first, then weight 2, ... each in symbol order (huf_decompress.c:427-480)
+                uint32_t start[14], pos = 0;
+                for (uint32_t w = 1; w <= tableLog; w++) { start[w] = pos; pos += rank[w] << (w - 1); }
+                nbSym = oSize + 1;
+                for (uint32_t n = 0; n < nbSym; n++) {
+                    uint32_t const w = S->weights[n];
+                    uint32_t st = 0;
+                    if (w) { st = start[w]; start[w] += (1u << w) >> 1; }
+                    S->hufStart[n] = (uint16_t)st;
+                }
+                ok = 1; consumed = iSize + 1;
+            }
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    if (!ok) return 0;
+    consumed = __builtin_amdgcn_readfirstlane(consumed); nbSym = __builtin_amdgcn_readfirstlane(nbSym); tableLog = __builtin_amdgcn_readfirstlane(tableLog);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t n = 0; n < nbSym; n++) {                     // wave-uniform loop; lanes fill the symbol's range
+        uint32_t const w = S->weights[n];
+        if (!w) continue;
+        uint32_t const len = (1u << w) >> 1, st = S->hufStart[n];
+        uint16_t const e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
+        for (uint32_t k = lane; k < len; k += 64) S->huf[st + k] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { S->hufLog = tableLog; S->hufValid = 1; }
+    __builtin_amdgcn_wave_barrier();
+    return consumed;
+}
+
+// the four (or one) Huffman streams -> the literal buffer; lanes 0..3 each own a stream (huf_decompress.c:560-700).
+// returns 0 ok / error code (wave-uniform)
+__device__ inline uint32_t dec_huf_streams(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const tl = S->hufLog;
+    const lds_u16* const T = (const lds_u16*)(uintptr_t)S->huf;
+    uint32_t sOff = 0, sLen = size, oOff = 0, oLen = litSize;
+    bool active = lane == 0;
+    if (!single) {
+        if (size < 10) return ZHIP_DE_CORRUPT;
+        uint32_t const l1 = src[0] | (src[1] << 8), l2 = src[2] | (src[3] << 8), l3 = src[4] | (src[5] << 8);
+        if (6 + l1 + l2 + l3 > size) return ZHIP_DE_CORRUPT;
+        uint32_t const seg = (litSize + 3) / 4;
+        if (3 * seg > litSize) return ZHIP_DE_CORRUPT;
+        active = lane < 4;
+        sOff = 6 + (lane >= 1 ? l1 : 0) + (lane >= 2 ? l2 : 0) + (lane >= 3 ? l3 : 0);
+        sLen = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : size - 6 - l1 - l2 - l3;
+        oOff = seg * (lane < 4 ? lane : 0); oLen = lane < 3 ? seg : litSize - 3 * seg;
+    }
+    bool bad = false;
+    if (active) {
+        BitsRev b;
+        if (!br_init(b, src + sOff, sLen)) bad = true;
+        else {
+            uint8_t* o = lit + oOff; uint32_t i = 0;
+            uint32_t const sh = 64 - tl;
+            while (i + 4 <= oLen) {
+                uint32_t w = 0;
+                for (int k = 0; k < 2; k++) {
+                    if (b.n <= 32) br_refill(b);
+                    uint32_t e = T[(uint32_t)(b.acc >> sh)];
+                    b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+                    w |= (e & 0xFF) << (16 * k);
+                    e = T[(uint32_t)(b.acc >> sh)];
+                    b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+                    w |= (e & 0xFF) << (16 * k + 8);
+                }
+                __builtin_memcpy(o + i, &w, 4);
+                i += 4;
+            }
+            for (; i < oLen; i++) {
+                if (b.n <= 32) br_refill(b);
+                uint32_t const e = T[(uint32_t)(b.acc >> sh)];
+                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+                o[i] = (uint8_t)e;
+            }
+            if (br_used(b) != b.total) bad = true;              // BIT_endOfDStream
+        }
+    }
+    return __any(bad) ? ZHIP_DE_CORRUPT : 0;
+}
+
+// literals section of one block: wave 0.  Publishes litMode / litSize / litByte / litSrcOff in S (lane 0).
+__device__ inline void dec_literals(DecShared* S, const uint8_t* blk, uint32_t bsize, uint32_t blockMax, uint8_t* lit, uint32_t dstRoom)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    LitHeader const h = dec_lit_header(blk, bsize, blockMax);
+    uint32_t err = h.err;
+    if (!err && h.litSize > dstRoom) err = ZHIP_DE_DST_SMALL;
+    uint32_t mode = 0;
+    if (!err) {
+        if (h.type >= 2) {
+            const uint8_t* hs = blk + h.lh; uint32_t hn = h.cSize;
+            if (h.type == 3) { if (!S->hufValid) err = ZHIP_DE_DICT_CORRUPT; }
+            else {
+                uint32_t const t = dec_huf_table(S, hs, hn);
+                if (!t || t >= hn) err = ZHIP_DE_CORRUPT; else { hs += t; hn -= t; }
+            }
+            if (!err) err = dec_huf_streams(S, hs, hn, h.litSize, h.single != 0, lit);
+        } else mode = h.type == 0 ? 1 : 2;
+    }
+    if (lane == 0) {
+        if (err) atomicMax(&S->status, err);
+        S->litMode = mode; S->litSize = h.litSize; S->litSecSize = h.lh + h.cSize;
+        S->litSrcOff = h.lh; S->litByte = mode == 2 && !err ? blk[h.lh] : 0;
+    }
+}
+
+// ------------------------------------------------------------------ sequences section, wave 1
+struct SeqDec {                     // lives in wave 1's registers across hand-over chunks (lane 0's copy is the real one)
+    BitsRev b; uint32_t sLL, sOF, sML; uint32_t rep0, rep1, rep2; uint32_t outPos, litPos; uint32_t done;
+};
+
+// header + the three tables (ZSTD_decodeSeqHeaders :662-745, ZSTD_buildSeqTable :625-660).  seq = the sequences section.
+// Publishes nbSeq; on success initialises D.  Wave-uniform result: error code or 0.
+__device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint32_t size, SeqDec& D, const uint64_t* defTabs)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t err = 0, nbSeq = 0, pos = 0, modes = 0;
+    uint32_t hdr[3] = {0, 0, 0};            // per table: 0 = nothing to build, 1 = build from S->norm, 2 = RLE symbol in rle[], 3 = copy the predefined table
+    uint32_t rle[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, lg[3] = {0, 0, 0};
+    if (lane == 0) {
+        if (size < 1) err = ZHIP_DE_SRC_WRONG;
+        else {
+            nbSeq = seq[pos++];
+            if (nbSeq > 0x7F) {
+                if (nbSeq == 0xFF) { if (pos + 2 > size) err = ZHIP_DE_SRC_WRONG; else { nbSeq = (seq[pos] | (seq[pos + 1] << 8)) + 0x7F00; pos += 2; } }
+                else { if (pos >= size) err = ZHIP_DE_SRC_WRONG; else { nbSeq = ((nbSeq - 0x80) << 8) + seq[pos++]; } }
+            }
+        }
+        if (!err && nbSeq == 0 && pos != size) err = ZHIP_DE_CORRUPT;
+        if (!err && nbSeq) {
+            if (pos + 1 > size) err = ZHIP_DE_SRC_WRONG;
+            else {
+                modes = seq[pos++];
+                if (modes & 3) err = ZHIP_DE_CORRUPT;
+                for (int k = 0; k < 3 && !err; k++) {
+                    uint32_t const type = (modes >> (6 - 2 * k)) & 3;
+                    if (type == 0) { hdr[k] = 3; lg[k] = k == 1 ? 5 : 6; }
+                    else if (type == 1) {
+                        if (pos >= size || seq[pos] > dec_max_sym(k)) err = ZHIP_DE_CORRUPT;
+                        else { hdr[k] = 2; rle[k] = seq[pos++]; lg[k] = 0; }
+                    } else if (type == 3) { if (!S->fseValid) err = ZHIP_DE_CORRUPT; else lg[k] = S->log[k]; }
+                    else {
+                        uint32_t m = dec_max_sym(k), tl = 0;
+                        uint32_t const h = fse_d_read_ncount(S->norm[k], &m, &tl, seq + pos, size - pos);
+                        if (!h || tl > dec_max_log(k)) err = ZHIP_DE_CORRUPT;
+                        else { hdr[k] = 1; mx[k] = m; lg[k] = tl; pos += h; }
+                    }
+                }
+            }
+        }
+    }
+    err = __builtin_amdgcn_readfirstlane(err);
+    nbSeq = __builtin_amdgcn_readfirstlane(nbSeq);
+    if (lane == 0) { S->nbSeq = err ? 0 : nbSeq; }
+    if (err) return err;
+    if (!nbSeq) return 0;
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    // build: lane k (k < 3) builds table k; predefined tables are copied by the whole wave afterwards
+    uint32_t myHdr = 0, myRle = 0, myMax = 0, myLog = 0;
+    for (int k = 0; k < 3; k++) {
+        uint32_t const a = __builtin_amdgcn_readfirstlane(hdr[k]), r = __builtin_amdgcn_readfirstlane(rle[k]);
+        uint32_t const m = __builtin_amdgcn_readfirstlane(mx[k]), l = __builtin_amdgcn_readfirstlane(lg[k]);
+        if (lane == (uint32_t)k) { myHdr = a; myRle = r; myMax = m; myLog = l; }
+        if (a == 3) {                                          // predefined table: 64 / 32 entries from the constant copy
+            uint32_t const n = 1u << l; const uint64_t* const src = defTabs + (k == 0 ? 0 : k == 1 ? 64 : 96);
+            for (uint32_t i = lane; i < n; i += 64) dec_tab(S, (uint32_t)k)[i] = src[i];
+        }
+    }
+    if (lane < 3) {
+        if (myHdr == 1) fse_d_build(dec_tab(S, lane), S->symOf[lane], S->next[lane], S->norm[lane], myMax, (int)lane, myLog);
+        else if (myHdr == 2) { uint32_t base, bits; dec_base_bits((int)lane, myRle, &base, &bits); dec_tab(S, lane)[0] = fse_d_pack(0, bits, 0, base); }
+        S->log[lane] = myLog;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) S->fseValid = 1;
+    // bitstream + initial states (zstd_decompress_block.c:1636-1643)
+    uint32_t bad = 0;
+    if (lane == 0) {
+        if (!br_init(D.b, seq + pos, size - pos)) bad = 1;
+        else {
+            uint32_t const l0 = S->log[0], l1 = S->log[1], l2 = S->log[2];
+            D.sLL = br_read(D.b, l0); if (D.b.n <= 32) br_refill(D.b);
+            D.sOF = br_read(D.b, l1);
+            D.sML = br_read(D.b, l2); if (D.b.n <= 32) br_refill(D.b);
+            D.rep0 = S->rep[0]; D.rep1 = S->rep[1]; D.rep2 = S->rep[2];
+            D.litPos = 0; D.done = 0;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(bad) ? ZHIP_DE_CORRUPT : 0;
+}
+
+// decode up to ZHIP_DEC_CHUNK sequences into recs (+ a sentinel record); lane 0 of wave 1 (ZSTD_decodeSequence :1228-1345)
+__device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, int buf, uint32_t nbSeq, uint32_t litSize,
+                                     uint32_t dstCap, uint32_t dictLen)
+{
+    if (lane_id() != 0) return;
+    const lds_u32* const TL = (const lds_u32*)(uintptr_t)dec_tab(S, 0);     // entries as two dwords: [next | nbAdd << 16 | nb << 24], [base]
+    const lds_u32* const TO = (const lds_u32*)(uintptr_t)dec_tab(S, 1);
+    const lds_u32* const TM = (const lds_u32*)(uintptr_t)dec_tab(S, 2);
+    uint32_t n = 0, err = 0;
+    uint32_t const want = nbSeq - D.done < ZHIP_DEC_CHUNK ? nbSeq - D.done : ZHIP_DEC_CHUNK;
+    BitsRev b = D.b;
+    uint32_t sLL = D.sLL, sOF = D.sOF, sML = D.sML, rep0 = D.rep0, rep1 = D.rep1, rep2 = D.rep2, outPos = D.outPos, litPos = D.litPos;
+    for (; n < want; n++) {
+        uint32_t const eL0 = TL[2 * sLL], bL = TL[2 * sLL + 1];
+        uint32_t const eO0 = TO[2 * sOF], bO = TO[2 * sOF + 1];
+        uint32_t const eM0 = TM[2 * sML], bM = TM[2 * sML + 1];
+        uint32_t const aL = (eL0 >> 16) & 0xFF, aO = (eO0 >> 16) & 0xFF, aM = (eM0 >> 16) & 0xFF;
+        uint32_t offset;
+        if (b.n <= 32) br_refill(b);
+        if (aO > 1) {
+            offset = bO + br_read(b, aO);
+            rep2 = rep1; rep1 = rep0; rep0 = offset;
+        } else {
+            uint32_t const ll0 = bL == 0;
+            if (aO == 0) { offset = ll0 ? rep1 : rep0; rep1 = ll0 ? rep0 : rep1; rep0 = offset; }
+            else {
+                uint32_t const v = bO + ll0 + br_read(b, 1);
+                uint32_t t = v == 3 ? rep0 - 1 : (v == 1 ? rep1 : v == 2 ? rep2 : rep0);
+                if (t == 0) t = 0xFFFFFFFFu;
+                if (v != 1) rep2 = rep1;
+                rep1 = rep0; rep0 = t; offset = t;
+            }
+        }
+        if (b.n <= 32) br_refill(b);
+        uint32_t const ml = bM + br_read(b, aM);
+        uint32_t const ll = bL + br_read(b, aL);
+        if (b.n <= 32) br_refill(b);
+        if (D.done + n + 1 < nbSeq) {
+            sLL = (eL0 & 0xFFFF) + br_read(b, eL0 >> 24);
+            sML = (eM0 & 0xFFFF) + br_read(b, eM0 >> 24);
+            sOF = (eO0 & 0xFFFF) + br_read(b, eO0 >> 24);
+        }
+        // ZSTD_execSequence's checks (:1025-1054), here so that the executing wave only ever sees valid records
+        if (ll > litSize - litPos) { err = ZHIP_DE_CORRUPT; break; }
+        if ((uint64_t)outPos + ll + ml > dstCap) { err = ZHIP_DE_DST_SMALL; break; }
+        if ((uint64_t)offset > (uint64_t)outPos + ll + dictLen) { err = ZHIP_DE_CORRUPT; break; }
+        ZhipDSeq r; r.outPos = outPos; r.litPos = litPos; r.off = offset; r.ml = ml;
+        recs[n] = r;
+        outPos += ll + ml; litPos += ll;
+    }
+    if (!err && D.done + n == nbSeq && br_used(b) != b.total) err = ZHIP_DE_CORRUPT;      // BIT_endOfDStream (:1677)
+    {   ZhipDSeq r; r.outPos = outPos; r.litPos = litPos; r.off = 0; r.ml = 0; recs[n] = r; }
+    D.b = b; D.sLL = sLL; D.sOF = sOF; D.sML = sML; D.rep0 = rep0; D.rep1 = rep1; D.rep2 = rep2; D.outPos = outPos; D.litPos = litPos;
+    D.done += n;
+    S->cnt[buf] = n; S->endOut = outPos; S->endLit = litPos;
+    if (D.done == nbSeq && !err) { S->rep[0] = rep0; S->rep[1] = rep1; S->rep[2] = rep2; }
+    if (err) atomicMax(&S->status, err);
+    __threadfence_block();
+}
+
+// ------------------------------------------------------------------ sequence execution, wave 0
+struct LitSrc { const uint8_t* p; uint32_t mode; uint32_t byte; };      // mode 2: RLE (byte repeated)
+
+// exact copy of n bytes by ONE lane (n small)
+__device__ __forceinline__ void lane_copy(uint8_t* d, const uint8_t* s, uint32_t n)
+{
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
+    if (i + 4 <= n) { uint32_t v; __builtin_memcpy(&v, s + i, 4); __builtin_memcpy(d + i, &v, 4); i += 4; }
+    for (; i < n; i++) d[i] = s[i];
+}
+__device__ __forceinline__ void lane_fill(uint8_t* d, uint32_t byte, uint32_t n)
+{
+    uint64_t const v = 0x0101010101010101ull * byte; uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) __builtin_memcpy(d + i, &v, 8);
+    for (; i < n; i++) d[i] = (uint8_t)byte;
+}
+// exact copy of n bytes by the whole wave (no overlap between source and destination)
+__device__ __forceinline__ void wave_copy(uint8_t* d, const uint8_t* s, uint32_t n)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const full = n & ~7u;
+    for (uint32_t i = 8 * lane; i < full; i += 512) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
+    if (lane < (n & 7)) d[full + lane] = s[full + lane];
+}
+__device__ __forceinline__ void wave_fill(uint8_t* d, uint32_t byte, uint32_t n)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint64_t const v = 0x0101010101010101ull * byte; uint32_t const full = n & ~7u;
+    for (uint32_t i = 8 * lane; i < full; i += 512) __builtin_memcpy(d + i, &v, 8);
+    if (lane < (n & 7)) d[full + lane] = (uint8_t)byte;
+}
+// periodic copy: d[k] = s[k % period], k < n (the overlapping-match case: the period bytes at s already exist)
+__device__ __forceinline__ void wave_copy_periodic(uint8_t* d, const uint8_t* s, uint32_t period, uint32_t n)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t m = lane % period; uint32_t const stepm = 64 % period;
+    for (uint32_t k = lane; k < n; k += 64) { d[k] = s[m]; m += stepm; if (m >= period) m -= period; }
+}
+
+// one hand-over chunk: literals of 64 sequences lane-parallel, then their matches in order (ZSTD_execSequence :1001-1095).
+// out = start of the frame's content; positions in the records are relative to it.
+__device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_t* out, LitSrc L, const uint8_t* dictEnd)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
+        uint32_t const nb = cnt - b0 < 64 ? cnt - b0 : 64;
+        bool const on = lane < nb;
+        ZhipDSeq r, rn;
+        {   uint4 v = *(const uint4*)(recs + b0 + (on ? lane : 0)); r.outPos = v.x; r.litPos = v.y; r.off = v.z; r.ml = v.w;
+            uint4 w = *(const uint4*)(recs + b0 + (on ? lane : 0) + 1); rn.outPos = w.x; rn.litPos = w.y; rn.off = w.z; rn.ml = w.w; }
+        uint32_t const ll = on ? rn.litPos - r.litPos : 0;
+        // literals: short runs by their own lane, long runs by the whole wave
+        if (ll && ll <= 64) { if (L.mode == 2) lane_fill(out + r.outPos, L.byte, ll); else lane_copy(out + r.outPos, L.p + r.litPos, ll); }
+        unsigned long long longs = __ballot(ll > 64);
+        while (longs) {
+            int const j = first_lane(longs); longs &= longs - 1;
+            uint32_t const o = __builtin_amdgcn_readlane(r.outPos, j), lp = __builtin_amdgcn_readlane(r.litPos, j), n = __builtin_amdgcn_readlane(ll, j);
+            if (L.mode == 2) wave_fill(out + o, L.byte, n); else wave_copy(out + o, L.p + lp, n);
+        }
+        __threadfence_block();                                  // every byte below the batch's first match, and all its literals, are now readable
+        uint32_t unsafeFrom = 0xFFFFFFFFu;                      // lowest position written by a match since the last fence
+        for (uint32_t j = 0; j < nb; j++) {
+            uint32_t const o = __builtin_amdgcn_readlane(r.outPos, (int)j) + __builtin_amdgcn_readlane(ll, (int)j);
+            uint32_t const off = __builtin_amdgcn_readlane(r.off, (int)j), ml = __builtin_amdgcn_readlane(r.ml, (int)j);
+            uint8_t* const d = out + o;
+            if (off > o) {                                      // starts in the dictionary (:1052-1066): byte k of the match is
+                // dict[dictLen - back + k] for k < back, then out[k - back] (k < off, existing bytes), then periodic with period off
+                uint32_t const back = off - o, nA = ml < back ? ml : back;
+                wave_copy(d, dictEnd - back, nA);
+                if (ml > back) {
+                    uint32_t const nB = (ml < off ? ml : off) - back;
+                    if (unsafeFrom < nB) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; }
+                    wave_copy(d + back, out, nB);
+                }
+                if (ml > off) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; wave_copy_periodic(d + off, d, off, ml - off); }
+                if (o < unsafeFrom) unsafeFrom = o;
+                continue;
+            }
+            uint32_t const s = o - off, e = off < ml ? o : s + ml;          // source range [s, e)
+            if (e > unsafeFrom) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; }
+            if (off >= ml) wave_copy(d, out + s, ml); else wave_copy_periodic(d, out + s, off, ml);
+            if (o < unsafeFrom) unsafeFrom = o;
+        }
+    }
+    __threadfence_block();
+}
+
+// ------------------------------------------------------------------ one frame, whole workgroup
+__device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t srcLen, uint8_t* out, uint32_t dstCap,
+                                    uint8_t* litBuf, ZhipDSeq* recBuf, const ZhipDDictDev* dict /* nullptr: none */, const uint64_t* defTabs, ZhipDResult* res)
+{
+    uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    DecHeader const H = dec_frame_header(src, srcLen);
+    uint32_t const dictLen = dict ? dict->len : 0;
+    const uint8_t* const dictEnd = dict ? dict->content + dict->len : nullptr;
+    if (tid == 0) {
+        uint32_t err = H.err;
+        if (!err && H.dictID && (!dict || dict->dictID != H.dictID)) err = ZHIP_DE_DICT_WRONG;
+        S->status = err; S->hufValid = 0; S->fseValid = 0; S->rep[0] = 1; S->rep[1] = 4; S->rep[2] = 8;
+        if (dict && dict->hasEntropy) { S->hufValid = 1; S->fseValid = 1; S->hufLog = dict->hufLog; for (int k = 0; k < 3; k++) { S->log[k] = dict->log[k]; S->rep[k] = dict->rep[k]; } }
+    }
+    if (dict && dict->hasEntropy) {
+        for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
+        for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
+    }
+    __syncthreads();
+    uint32_t status = S->status;
+    uint32_t ip = H.size, op = 0;
+    SeqDec D; D.done = 0; D.outPos = 0; D.litPos = 0; D.sLL = D.sOF = D.sML = 0; D.rep0 = D.rep1 = D.rep2 = 0; D.b.n = 0;
+    bool last = false;
+    while (!status && !last) {
+        if (srcLen - ip < 3) { status = ZHIP_DE_SRC_WRONG; break; }
+        uint32_t const bh = src[ip] | (src[ip + 1] << 8) | (src[ip + 2] << 16);
+        uint32_t const type = (bh >> 1) & 3, bsize = bh >> 3;
+        last = bh & 1;
+        ip += 3;
+        if (type == 3) { status = ZHIP_DE_CORRUPT; break; }
+        uint32_t const csize = type == 1 ? 1 : bsize;
+        if (csize > srcLen - ip) { status = ZHIP_DE_SRC_WRONG; break; }
+        if (type != 2) {                                       // raw / RLE block: the whole workgroup
+            if (bsize > dstCap - op) { status = ZHIP_DE_DST_SMALL; break; }
+            if (type == 0) {
+                uint32_t const full = bsize & ~7u;
+                for (uint32_t i = 8 * tid; i < full; i += 8 * ZHIP_DEC_THREADS) { uint64_t v; __builtin_memcpy(&v, src + ip + i, 8); __builtin_memcpy(out + op + i, &v, 8); }
+                if (tid < (bsize & 7)) out[op + full + tid] = src[ip + full + tid];
+            } else {
+                uint64_t const v = 0x0101010101010101ull * src[ip]; uint32_t const full = bsize & ~7u;
+                for (uint32_t i = 8 * tid; i < full; i += 8 * ZHIP_DEC_THREADS) __builtin_memcpy(out + op + i, &v, 8);
+                if (tid < (bsize & 7)) out[op + full + tid] = src[ip];
+            }
+            __threadfence_block();
+            __syncthreads();
+            op += bsize; ip += csize;
+            continue;
+        }
+        // compressed block (ZSTD_decompressBlock_internal, zstd_decompress_block.c:2072-2180)
+        if (csize > H.blockMax) { status = ZHIP_DE_SRC_WRONG; break; }
+        const uint8_t* const blk = src + ip;
+        if (wave == 0) dec_literals(S, blk, csize, H.blockMax, litBuf, dstCap - op);
+        else {
+            LitHeader const lh = dec_lit_header(blk, csize, H.blockMax);
+            uint32_t err = lh.err ? 1u : 0u;                    // wave 0 reports the literal header's own errors
+            if (!err) {
+                uint32_t const secOff = lh.lh + lh.cSize;
+                D.outPos = op; D.done = 0;
+                uint32_t const e2 = dec_seq_setup(S, blk + secOff, csize - secOff, D, defTabs);
+                if (e2) { if (lane == 0) atomicMax(&S->status, e2); }
+                else if (S->nbSeq) dec_seq_chunk(S, D, recBuf, 0, S->nbSeq, lh.litSize, dstCap, dictLen);
+            } else if (lane == 0) S->nbSeq = 0;
+        }
+        __syncthreads();
+        status = S->status;
+        if (status) break;
+        uint32_t const nbSeq = S->nbSeq, litSize = S->litSize;
+        LitSrc L; L.mode = S->litMode; L.byte = S->litByte; L.p = L.mode == 1 ? blk + S->litSrcOff : litBuf;
+        uint32_t const nChunks = (nbSeq + ZHIP_DEC_CHUNK - 1) / ZHIP_DEC_CHUNK;
+        for (uint32_t c = 0; c < nChunks && !status; c++) {
+            if (wave == 0) dec_exec_chunk(recBuf + (size_t)(c & 1) * (ZHIP_DEC_CHUNK + 1), S->cnt[c & 1], out, L, dictEnd);
+            else if (c + 1 < nChunks) dec_seq_chunk(S, D, recBuf + (size_t)((c + 1) & 1) * (ZHIP_DEC_CHUNK + 1), (int)((c + 1) & 1), nbSeq, litSize, dstCap, dictLen);
+            __syncthreads();
+            status = S->status;
+        }
+        if (status) break;
+        {   // last literals (zstd_decompress_block.c:1681-1690)
+            uint32_t const endOut = nbSeq ? S->endOut : op, endLit = nbSeq ? S->endLit : 0;
+            uint32_t const rest = litSize - endLit;
+            if (rest > dstCap - endOut) { status = ZHIP_DE_DST_SMALL; break; }
+            if (wave == 0) { if (L.mode == 2) wave_fill(out + endOut, L.byte, rest); else wave_copy(out + endOut, L.p + endLit, rest); __threadfence_block(); }
+            op = endOut + rest;
+        }
+        ip += csize;
+        __syncthreads();
+    }
+    if (!status && H.fcs != ~0ull && H.fcs != (uint64_t)op) status = ZHIP_DE_CORRUPT;
+    uint32_t ck = 0;
+    if (!status && H.checksum) { if (srcLen - ip < 4) status = ZHIP_DE_CHECKSUM; else ck = ld32(src + ip); }
+    __syncthreads();
+    if (tid == 0) { res->status = status; res->size = status ? 0 : op; res->hasChecksum = !status && H.checksum; res->checksum = ck; }
+}
+#endif  // ZHIP_DECODE_HOST_ONLY
+
+}  // namespace zhip

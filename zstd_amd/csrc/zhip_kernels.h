@@ -7,6 +7,7 @@
 #include "zhip_parse_lazy.h"
 #include "zhip_parse_dict.h"
 #include "zhip_entropy.h"
+#include "zhip_decode.h"
 
 namespace zhip {
 
@@ -271,6 +272,36 @@ k_offsets(const uint32_t* __restrict__ outSize, uint32_t nUnits, uint64_t* __res
     __syncthreads();
     unsigned long long run = part[t];
     for (uint32_t i = a; i < b; i++) { offsets[i] = run; run += outSize[i]; }
+}
+
+// Decoder: persistent 128-thread workgroups, each takes frames from a queue (counter) until it is empty; per workgroup a
+// literal buffer and two hand-over buffers of sequence records in HBM/L2.  Dynamic LDS = sizeof(DecShared).
+__global__ void __launch_bounds__(ZHIP_DEC_THREADS)
+k_decode(const uint8_t* __restrict__ src, const ZhipDFrame* __restrict__ frames, uint32_t nFrames, uint8_t* __restrict__ dst,
+         uint8_t* __restrict__ litArena, ZhipDSeq* __restrict__ recArena, uint32_t* __restrict__ counter,
+         ZhipDDictDev dict, const uint64_t* __restrict__ defTabs, ZhipDResult* __restrict__ results)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    DecShared* const S = (DecShared*)smem;
+    uint8_t* const litBuf = litArena + (size_t)blockIdx.x * ZHIP_DEC_LIT_STRIDE;
+    ZhipDSeq* const recBuf = recArena + (size_t)blockIdx.x * 2 * (ZHIP_DEC_CHUNK + 1);
+    for (;;) {
+        if (threadIdx.x == 0) S->frame = atomicAdd(counter, 1u);
+        __syncthreads();
+        uint32_t const f = S->frame;
+        __syncthreads();
+        if (f >= nFrames) break;
+        ZhipDFrame const fr = frames[f];
+        decode_frame(S, src + fr.srcOff, fr.srcLen, dst + fr.dstOff, fr.dstCap, litBuf, recBuf, dict.content ? &dict : nullptr, defTabs, results + f);
+    }
+}
+
+// content checksums: checks[] = XXH64 low words of the decoded frames (k_xxh64 over the destination)
+__global__ void __launch_bounds__(256)
+k_dec_verify(ZhipDResult* __restrict__ results, const uint32_t* __restrict__ checks, uint32_t nFrames)
+{
+    uint32_t const i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nFrames && results[i].status == 0 && results[i].hasChecksum && results[i].checksum != checks[i]) { results[i].status = ZHIP_DE_CHECKSUM; results[i].size = 0; }
 }
 
 }  // namespace zhip
