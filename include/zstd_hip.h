@@ -118,6 +118,39 @@ size_t       zhip_compress_records_device(zhip_ctx* ctx, const zhip_cdict* cdict
 size_t       zhip_compress_records(zhip_ctx* ctx, const zhip_cdict* cdict, void* dst, size_t dstCapacity,
                                    const void* src, const unsigned long long* recOffsets, size_t nRec, size_t* frameSizes);
 
+/* ---- decompression: the step on the other side of the path, batch form of
+ *      ZSTD_decompress (lib/zstd.h:205) / ZSTD_decompressDCtx (:299) / ZSTD_decompress_usingDDict (:1046).
+ * Any RFC 8878 frame is accepted (what this library emits and what the reference emits: several blocks per frame, repeat /
+ * treeless modes, checksums, dictionaries); frames are independent work items, one workgroup each.  Per-frame failures
+ * carry zstd's error codes (corruption_detected 20, checksum_wrong 22, dictionary_wrong 32, dstSize_tooSmall 70, ...). */
+typedef struct zhip_dctx_s  zhip_dctx;                      /* device state the way ZSTD_DCtx owns it, lib/zstd.h:288 */
+typedef struct zhip_ddict_s zhip_ddict;                     /* = ZSTD_DDict, lib/zstd.h:1035: content + entropy tables in decoding form */
+zhip_dctx*   zhip_create_dctx(int device);
+void         zhip_free_dctx(zhip_dctx* dctx);
+const char*  zhip_dctx_last_error(const zhip_dctx* dctx);
+zhip_ddict*  zhip_create_ddict(int device, const void* dict, size_t dictSize);   /* raw-content or ZDICT format (zstd_decompress.c:1476-1500) */
+void         zhip_free_ddict(zhip_ddict* ddict);
+unsigned     zhip_ddict_id(const zhip_ddict* ddict);        /* = ZSTD_getDictID_fromDDict, lib/zstd.h:1100 */
+/* frame walker over a HOST buffer of concatenated frames = ZSTD_findFrameCompressedSize (lib/zstd.h:254) +
+ * ZSTD_getFrameContentSize (:215) + ZSTD_decompressBound's per-frame term (:1520); skippable frames are stepped over.
+ * Arrays are optional, filled for the first maxFrames frames; contentSizes[i] = ~0ull when the header does not state it.
+ * returns the number of frames, or an error (srcSize_wrong when the buffer does not end on a frame boundary). */
+size_t       zhip_find_frames(const void* src, size_t srcSize, unsigned long long* srcOffsets, unsigned long long* srcSizes,
+                              unsigned long long* contentSizes, unsigned long long* contentBounds, size_t maxFrames);
+size_t       zhip_frame_compressed_size(const void* src, size_t srcSize);   /* = ZSTD_findFrameCompressedSize: the first frame of src */
+/* device-resident buffers; the four descriptor arrays are HOST arrays of nFrames entries: frame i occupies
+ * srcDev[srcOffsets[i] .. +srcSizes[i]) and decodes to dstDev[dstOffsets[i] .. +dstCapacities[i]).  statusOut / sizesOut
+ * (optional, host) receive each frame's zstd error code (0 = ok) and decoded size.  Returns the total decoded size after
+ * the stream has been synchronised, or the first frame's error. */
+size_t       zhip_decompress_frames_device(zhip_dctx* dctx, const zhip_ddict* ddict, void* dstDev, const unsigned long long* dstOffsets,
+                                           const unsigned long long* dstCapacities, const void* srcDev, const unsigned long long* srcOffsets,
+                                           const unsigned long long* srcSizes, size_t nFrames, unsigned* statusOut,
+                                           unsigned long long* sizesOut, void* stream);
+/* host buffers = ZSTD_decompress(dst, cap, src, srcSize): every frame of src, contents back to back (ddict may be NULL) */
+size_t       zhip_decompress(zhip_dctx* dctx, const zhip_ddict* ddict, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* HIP-event durations (ms) of the most recent call: t[0] = k_decode, t[1] = checksum verification (0 when no frame has one) */
+void         zhip_dctx_last_timing(const zhip_dctx* dctx, double t[2]);
+
 /* ---- measurement: HIP-event durations (ms) of the kernels of the most recent call on this ctx
  * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */
 void         zhip_last_timing(const zhip_ctx* ctx, double t[4]);

@@ -46,6 +46,22 @@ ZSTD_CDict* ZSTD_createCDict(const void* dictBuffer, size_t dictSize, int compre
 size_t      ZSTD_freeCDict(ZSTD_CDict* CDict);                                                     /* :985 */
 size_t      ZSTD_CCtx_refCDict(ZSTD_CCtx* cctx, const ZSTD_CDict* cdict);                          /* :1102 */
 size_t      ZSTD_compress_usingCDict(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_CDict* cdict);   /* :992 */
+/* decompression (served by k_decode; any RFC 8878 frame — this library's and the reference's) */
+typedef struct ZSTD_DCtx_s ZSTD_DCtx;                                                              /* :288 */
+typedef struct ZSTD_DDict_s ZSTD_DDict;                                                            /* :1035 */
+#define ZSTD_CONTENTSIZE_UNKNOWN 0xFFFFFFFFFFFFFFFFULL                                                       /* :211 */
+#define ZSTD_CONTENTSIZE_ERROR   0xFFFFFFFFFFFFFFFEULL                                                       /* :212 */
+size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);   /* :205 every frame of src */
+ZSTD_DCtx*  ZSTD_createDCtx(void);                                                                 /* :289 */
+size_t      ZSTD_freeDCtx(ZSTD_DCtx* dctx);                                                        /* :290 */
+size_t      ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* :299 */
+ZSTD_DDict* ZSTD_createDDict(const void* dictBuffer, size_t dictSize);                             /* :1037 */
+size_t      ZSTD_freeDDict(ZSTD_DDict* ddict);                                                     /* :1042 */
+size_t      ZSTD_decompress_usingDDict(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_DDict* ddict);   /* :1046 */
+unsigned    ZSTD_getDictID_fromDDict(const ZSTD_DDict* ddict);                                     /* :1100 */
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);                      /* :215 first frame only */
+unsigned long long ZSTD_findDecompressedSize(const void* src, size_t srcSize);                     /* :1492 all frames */
+size_t      ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);                         /* :254 */
 int         ZSTD_minCLevel(void);                                                                  /* :245 */
 int         ZSTD_maxCLevel(void);                                                                  /* :246 (highest level the device core implements) */
 int         ZSTD_defaultCLevel(void);                                                              /* :247 */

@@ -1,0 +1,175 @@
+"""GPU parity of the decoder through the C ABI (zhip_decompress / zhip_decompress_frames_device / the ZSTD_* shim):
+decoded bytes == the original input == what the oracle decoder (and, where oracle/_ref travelled, the real reference) returns."""
+import base64, ctypes as C, hashlib, json, os, zlib
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, _buf, ERR, datagen, text_like, oracle_decompress, corpus_cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode_v1.json")
+
+
+def unpack(s):
+    return zlib.decompress(base64.b64decode(s))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import zstd_amd
+    assert torch.cuda.is_available()
+    return zstd_amd, load_oracle(), zstd_amd.DContext(0), torch
+
+
+def test_golden_decode_vectors(env):
+    z, lo, dctx, _ = env
+    g = json.load(open(GOLD))
+    vs = g["fixtures"] + g["frames"]
+    for v in vs:
+        out = dctx.decompress(unpack(v["zst"]), capacity=v["size"])
+        assert len(out) == v["size"] and hashlib.sha256(out).hexdigest() == v["sha256"], v["name"]
+    # all of them as ONE stream of concatenated frames (with a skippable frame in between)
+    stream = b"".join(unpack(v["zst"]) for v in vs[:6]) + b"\x5a\x2a\x4d\x18\x03\x00\x00\x00abc" + b"".join(unpack(v["zst"]) for v in vs[6:])
+    out = dctx.decompress(stream, capacity=sum(v["size"] for v in vs))
+    assert hashlib.sha256(out).hexdigest() == hashlib.sha256(b"".join(oracle_decompress(lo, unpack(v["zst"]), v["size"] + 8) for v in vs)).hexdigest()
+    for v in g["errors"]:
+        with pytest.raises(z.ZhipError):
+            dctx.decompress(unpack(v["zst"]), capacity=1 << 16)
+
+
+def test_round_trip_of_the_product_frames(env):
+    z, lo, dctx, _ = env
+    ctx = z.Context(0, max_units=64)
+    for level in (1, 3, 5, 7, -3):
+        parts = [a for n in (1, 7, 1000, 70000, 131072) for _, a in corpus_cases(lo, sizes=(n,), seeds=(3,))]
+        for a in parts[:: 3 if level not in (1, 3) else 1]:
+            frames = ctx.compress(a, level=level)
+            assert dctx.decompress(frames, capacity=len(a)) == a.tobytes(), (level, len(a))
+    big = np.concatenate([datagen(lo, 3_000_000, 50, 4), text_like(2_000_000, 5), np.zeros(300_000, np.uint8), np.random.default_rng(1).integers(0, 256, 500_000, dtype=np.uint8)])
+    for level in (1, 3):
+        frames = ctx.compress(big, level=level)
+        out = dctx.decompress(frames)
+        assert out == big.tobytes()
+    ctx.set_checksum(True)
+    frames = ctx.compress(big[:1_000_000], level=1)
+    assert dctx.decompress(frames) == big[:1_000_000].tobytes()
+    bad = bytearray(frames); bad[-2] ^= 0x40                     # the last frame's checksum
+    with pytest.raises(z.ZhipError, match="22"):
+        dctx.decompress(bytes(bad))
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (travels to the GPU box as a binary)")
+def test_reference_frames_and_corruptions(env):
+    z, lo, dctx, _ = env
+    lr = load_ref()
+    from test_oracle_decode import ref_frame
+    rng = np.random.default_rng(33)
+    for kind, n, level in (("text", 3_000_000, 3), ("P50", 2_000_000, 1), ("text", 200_000, 19), ("P80", 1_400_000, -3), ("text", 90_000, 7),
+                           ("P50", 600_000, 12), ("P20", 400_000, 16), ("text", 5, 3)):
+        a = text_like(n, 5) if kind == "text" else datagen(lo, n, int(kind[1:]), 6)
+        assert dctx.decompress(ref_frame(lr, a, level), capacity=n) == a.tobytes(), (kind, n, level)
+    base = ref_frame(lr, text_like(20000, 9), 3)
+    muts = []
+    for _ in range(300):
+        b = bytearray(base)
+        k = rng.integers(0, 3)
+        if k == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            del b[int(rng.integers(9, len(b))):]
+        muts.append(bytes(b))
+    nerr = 0
+    for m in muts:
+        w = oracle_decompress(lo, m, 32768)
+        try:
+            got = dctx.decompress(m, capacity=32768)
+        except z.ZhipError:
+            got = None
+        if w is None:
+            assert got is None, m.hex()[:60]
+            nerr += 1
+        else:
+            assert got == w
+    assert nerr > 80
+
+
+def test_dictionary_round_trip(env):
+    z, lo, dctx, _ = env
+    zd = np.fromfile(os.path.join(os.path.dirname(GOLD), "github_like_110k.zdict"), dtype=np.uint8)
+    rng = np.random.default_rng(12)
+    for dict_ in (zd, text_like(30000, 41)):
+        recs = []
+        for i in range(500):
+            n = int(rng.integers(20, 4000))
+            st = int(rng.integers(0, len(dict_) - n))
+            r = dict_[st:st + n].copy()
+            r[rng.integers(0, n, size=max(1, n // 40))] = rng.integers(32, 127, size=max(1, n // 40), dtype=np.uint8)
+            recs.append(r)
+        ctx = z.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
+        cd = z.CDict(dict_, level=3)
+        frames = ctx.compress_records(cd, recs)
+        dd = z.DDict(dict_)
+        assert dctx.decompress(frames, ddict=dd) == b"".join(r.tobytes() for r in recs)
+        if dict_ is zd:
+            assert dd.dict_id != 0
+            with pytest.raises(z.ZhipError, match="32"):         # dictionary_wrong: the frames name a dictionary we did not give
+                dctx.decompress(frames)
+
+
+def test_device_buffers_full_size(env):
+    """256 MiB of datagen: compress on the device, decode on the device, compare on the device"""
+    z, lo, dctx, torch = env
+    n = 256 << 20
+    host = z.datagen(n, 50, seed=3, stream_mode=True)
+    src = torch.from_numpy(host).cuda()
+    units = n // 131072
+    ctx = z.Context(0, max_units=units)
+    cap = z.compress_bound(n)
+    comp = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    sizes = torch.empty(units, dtype=torch.int32, device="cuda")
+    total = ctx.compress_device(comp.data_ptr(), cap, src.data_ptr(), n, level=1, sizes_ptr=sizes.data_ptr())
+    csz = sizes.cpu().numpy().astype(np.uint64)
+    assert int(csz.sum()) == total
+    so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
+    do = (np.arange(units, dtype=np.uint64) * 131072)
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    r, status, dsz = dctx.decompress_frames_device(out.data_ptr(), do, np.full(units, 131072, np.uint64), comp.data_ptr(), so, csz)
+    assert r == n and not status.any() and (dsz == 131072).all()
+    assert torch.equal(out, src)
+    t = dctx.timing()
+    print(f"decode {n >> 20} MiB: {t['decode_ms']:.2f} ms = {n / t['decode_ms'] / 1e6:.1f} GB/s")
+
+
+def test_shim_decompress(env):
+    z, lo, _, _ = env
+    shim = C.CDLL(os.path.join(os.path.dirname(z.LIB_PATH), "libzstd_hipshim.so"))
+    shim.ZSTD_compress.restype = C.c_size_t
+    shim.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    shim.ZSTD_decompress.restype = C.c_size_t
+    shim.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    shim.ZSTD_compressBound.restype = C.c_size_t
+    shim.ZSTD_compressBound.argtypes = [C.c_size_t]
+    shim.ZSTD_findDecompressedSize.restype = C.c_ulonglong
+    shim.ZSTD_findDecompressedSize.argtypes = [C.c_void_p, C.c_size_t]
+    shim.ZSTD_getFrameContentSize.restype = C.c_ulonglong
+    shim.ZSTD_getFrameContentSize.argtypes = [C.c_void_p, C.c_size_t]
+    shim.ZSTD_findFrameCompressedSize.restype = C.c_size_t
+    shim.ZSTD_findFrameCompressedSize.argtypes = [C.c_void_p, C.c_size_t]
+    shim.ZSTD_isError.restype = C.c_uint
+    shim.ZSTD_isError.argtypes = [C.c_size_t]
+    a = text_like(500000, 17)
+    cap = shim.ZSTD_compressBound(len(a))
+    dst = np.empty(cap, dtype=np.uint8)
+    r = shim.ZSTD_compress(_buf(dst), cap, _buf(a), len(a), 3)
+    assert not shim.ZSTD_isError(r)
+    assert shim.ZSTD_findDecompressedSize(_buf(dst), r) == len(a)
+    assert shim.ZSTD_getFrameContentSize(_buf(dst), r) == 131072
+    first = shim.ZSTD_findFrameCompressedSize(_buf(dst), r)
+    assert 0 < first < r
+    out = np.empty(len(a), dtype=np.uint8)
+    k = shim.ZSTD_decompress(_buf(out), len(a), _buf(dst), r)
+    assert k == len(a) and (out == a).all()
+    k = shim.ZSTD_decompress(_buf(out), len(a) - 1, _buf(dst), r)          # dstSize_tooSmall
+    assert shim.ZSTD_isError(k) and (1 << 64) - k == 70

@@ -70,6 +70,17 @@ def lib():
             ("zhip_records_bound", C.c_size_t, [C.c_void_p, C.c_size_t]),
             ("zhip_compress_records_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
             ("zhip_compress_records", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+            ("zhip_create_dctx", C.c_void_p, [C.c_int]),
+            ("zhip_free_dctx", None, [C.c_void_p]),
+            ("zhip_dctx_last_error", C.c_char_p, [C.c_void_p]),
+            ("zhip_create_ddict", C.c_void_p, [C.c_int, C.c_void_p, C.c_size_t]),
+            ("zhip_free_ddict", None, [C.c_void_p]),
+            ("zhip_ddict_id", C.c_uint, [C.c_void_p]),
+            ("zhip_find_frames", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+            ("zhip_decompress_frames_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+            ("zhip_decompress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+            ("zhip_dctx_last_timing", None, [C.c_void_p, C.c_void_p]),
         ]:
             if hasattr(L, name):
                 getattr(L, name).restype = res
@@ -230,3 +241,104 @@ class Context:
                                             sizes.ctypes.data_as(C.c_void_p)), "zhip_compress")
         out = dst[:r].tobytes()
         return (out, sizes) if return_sizes else out
+
+
+# ---------------------------------------------------------------------------------------------------------------- decompression
+def find_frames(data):
+    """walk concatenated frames in host bytes -> dict of uint64 arrays: src_off, src_size, content (2**64-1 = not stated), bound"""
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    L = lib()
+    p = a.ctypes.data_as(C.c_void_p) if a.size else None
+    n = L.zhip_find_frames(p, a.size, None, None, None, None, 0)
+    if L.zhip_isError(n):
+        raise ZhipError(f"zhip_find_frames: {L.zhip_getErrorName(n).decode()} (code {(1 << 64) - n})")
+    out = {k: np.zeros(max(n, 1), dtype=np.uint64) for k in ("src_off", "src_size", "content", "bound")}
+    if n:
+        L.zhip_find_frames(p, a.size, *[out[k].ctypes.data_as(C.c_void_p) for k in ("src_off", "src_size", "content", "bound")], n)
+    return {k: v[:n] for k, v in out.items()}
+
+
+class DDict:
+    """a dictionary digested for decoding on one GPU (the role ZSTD_DDict plays): content + entropy tables in decoding form"""
+
+    def __init__(self, dict_bytes, device=0):
+        a = np.frombuffer(dict_bytes, dtype=np.uint8) if not isinstance(dict_bytes, np.ndarray) else dict_bytes
+        a = np.ascontiguousarray(a)
+        self._h = lib().zhip_create_ddict(device, a.ctypes.data_as(C.c_void_p), a.size)
+        if not self._h:
+            raise ZhipError(f"zhip_create_ddict({a.size} B): malformed dictionary or no GPU")
+        self.device = device
+        self.dict_id = lib().zhip_ddict_id(self._h)
+
+    def close(self):
+        if self._h:
+            lib().zhip_free_ddict(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DContext:
+    """owns the decoder's device state for one GPU (the role ZSTD_DCtx plays)"""
+
+    def __init__(self, device=0):
+        L = lib()
+        if L.zhip_device_count() <= 0:
+            raise ZhipError("no HIP device visible (zstd_amd has no CPU path)")
+        self._h = L.zhip_create_dctx(device)
+        if not self._h:
+            raise ZhipError(f"zhip_create_dctx(device={device}) failed")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().zhip_free_dctx(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def timing(self):
+        t = (C.c_double * 2)()
+        lib().zhip_dctx_last_timing(self._h, t)
+        return {"decode_ms": t[0], "verify_ms": t[1]}
+
+    def _err(self, r, what):
+        L = lib()
+        raise ZhipError(f"{what}: zstd error {(1 << 64) - r} ({L.zhip_dctx_last_error(self._h).decode()})")
+
+    def decompress(self, data, capacity=None, ddict=None):
+        """host bytes holding concatenated frames -> their contents back to back (= ZSTD_decompress)"""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        if capacity is None:
+            fr = find_frames(a)
+            capacity = int(sum(int(c) if c != np.uint64(2**64 - 1) else int(b) for c, b in zip(fr["content"], fr["bound"])))
+        dst = np.empty(max(capacity, 1), dtype=np.uint8)
+        L = lib()
+        r = L.zhip_decompress(self._h, ddict._h if ddict else None, dst.ctypes.data_as(C.c_void_p), capacity,
+                              a.ctypes.data_as(C.c_void_p) if a.size else None, a.size)
+        if L.zhip_isError(r):
+            self._err(r, "zhip_decompress")
+        return dst[:r].tobytes()
+
+    def decompress_frames_device(self, dst_ptr, dst_offsets, dst_caps, src_ptr, src_offsets, src_sizes, ddict=None, stream=None, check=True):
+        """device buffers; descriptor arrays are host uint64 arrays. returns (total, status[uint32], sizes[uint64])"""
+        n = len(src_offsets)
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (dst_offsets, dst_caps, src_offsets, src_sizes)]
+        status = np.zeros(max(n, 1), dtype=np.uint32)
+        sizes = np.zeros(max(n, 1), dtype=np.uint64)
+        L = lib()
+        r = L.zhip_decompress_frames_device(self._h, ddict._h if ddict else None, dst_ptr, arrs[0].ctypes.data_as(C.c_void_p),
+                                            arrs[1].ctypes.data_as(C.c_void_p), src_ptr, arrs[2].ctypes.data_as(C.c_void_p),
+                                            arrs[3].ctypes.data_as(C.c_void_p), n, status.ctypes.data_as(C.c_void_p),
+                                            sizes.ctypes.data_as(C.c_void_p), stream)
+        if check and L.zhip_isError(r):
+            self._err(r, "zhip_decompress_frames_device")
+        return r, status[:n], sizes[:n]

@@ -1,0 +1,273 @@
+// zhip_declib.h — host side of the decoder entry points of libzstd_hip.so (include/zstd_hip.h, "decompression"); included
+// at the end of zhip_lib.hip (one translation unit owns the kernels).  The per-frame work is k_decode (zhip_decode.h); this
+// file walks frame headers, sizes the scratch, launches and collects.
+#pragma once
+#include "zhip_ddict_host.h"
+
+#define DERR(c) ((size_t)-(long)(c))
+
+struct zhip_ddict_s {
+    int device;
+    zhip::HostDDict h;
+    uint8_t* dContent; uint16_t* dHuf; uint64_t* dFse;
+    ZhipDDictDev dev;
+};
+
+struct zhip_dctx_s {
+    int device; int nCU;
+    hipStream_t stream; hipEvent_t ev[4];
+    uint32_t grid;                             // resident workgroups = scratch slots
+    uint8_t* dLit; ZhipDSeq* dRecs; uint32_t* dCounter; uint64_t* dDefTabs;
+    ZhipDFrame* dFrames; ZhipDResult* dResults; ZhipUnit* dUnits; uint32_t* dChecks; size_t framesCap;
+    ZhipDFrame* hFrames; ZhipDResult* hResults; ZhipUnit* hUnits;
+    uint8_t* dSrcStage; size_t srcStageCap; uint8_t* dDstStage; size_t dstStageCap;
+    double timing[2];
+    std::mutex mu;
+    char err[256];
+};
+
+#define DCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return DERR(1); } } while (0)
+
+extern "C" {
+
+void zhip_free_ddict(zhip_ddict* d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipFree(d->dContent); (void)hipFree(d->dHuf); (void)hipFree(d->dFse);
+    delete d;
+}
+
+zhip_ddict* zhip_create_ddict(int device, const void* dict, size_t dictSize)
+{
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zhip_ddict* d = new zhip_ddict_s();
+    d->device = device; d->dContent = nullptr; d->dHuf = nullptr; d->dFse = nullptr;
+    if (zhip::host_ddict_build(d->h, dict, dictSize) != 0) { delete d; return nullptr; }
+    size_t const n = d->h.content.size();
+    bool ok = hipMalloc((void**)&d->dContent, n + 16) == hipSuccess;
+    ok = ok && hipMalloc((void**)&d->dHuf, 4096 * sizeof(uint16_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&d->dFse, 1280 * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && (n == 0 || hipMemcpy(d->dContent, d->h.content.data(), n, hipMemcpyHostToDevice) == hipSuccess);
+    ok = ok && hipMemcpy(d->dHuf, d->h.huf.data(), 4096 * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d->dFse, d->h.fse.data(), 1280 * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { zhip_free_ddict(d); return nullptr; }
+    memset(&d->dev, 0, sizeof(d->dev));
+    d->dev.content = d->dContent; d->dev.len = (uint32_t)n; d->dev.dictID = d->h.dictID; d->dev.hasEntropy = d->h.hasEntropy; d->dev.hufLog = d->h.hufLog;
+    d->dev.huf = d->dHuf; d->dev.fse = d->dFse;
+    for (int k = 0; k < 3; k++) { d->dev.log[k] = d->h.log[k]; d->dev.rep[k] = d->h.rep[k]; }
+    return d;
+}
+
+unsigned zhip_ddict_id(const zhip_ddict* d) { return d ? d->h.dictID : 0; }
+
+void zhip_free_dctx(zhip_dctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->dLit); (void)hipFree(c->dRecs); (void)hipFree(c->dCounter); (void)hipFree(c->dDefTabs);
+    (void)hipFree(c->dFrames); (void)hipFree(c->dResults); (void)hipFree(c->dUnits); (void)hipFree(c->dChecks);
+    (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
+    (void)hipHostFree(c->hFrames); (void)hipHostFree(c->hResults); (void)hipHostFree(c->hUnits);
+    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+zhip_dctx* zhip_create_dctx(int device)
+{
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zhip_dctx* c = new zhip_dctx_s();
+    c->device = device; c->stream = nullptr; c->err[0] = 0; c->timing[0] = c->timing[1] = 0;
+    c->dLit = nullptr; c->dRecs = nullptr; c->dCounter = nullptr; c->dDefTabs = nullptr; c->dFrames = nullptr; c->dResults = nullptr; c->dUnits = nullptr; c->dChecks = nullptr;
+    c->hFrames = nullptr; c->hResults = nullptr; c->hUnits = nullptr; c->framesCap = 0;
+    c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
+    for (int i = 0; i < 4; i++) c->ev[i] = nullptr;
+    hipDeviceProp_t prop;
+    bool ok = hipGetDeviceProperties(&prop, device) == hipSuccess;
+    c->nCU = ok ? prop.multiProcessorCount : 256;
+    // resident workgroups per CU: what registers and LDS (sizeof(DecShared) of 160 KB) allow; ZHIP_DEC_WG_PER_CU lowers it (measurement knob)
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zhip::k_decode, ZHIP_DEC_THREADS, sizeof(zhip::DecShared)) != hipSuccess || perCU < 1) perCU = 4;
+    {   const char* e = getenv("ZHIP_DEC_WG_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }
+    c->grid = (uint32_t)(c->nCU * perCU);
+    ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dLit, (size_t)c->grid * ZHIP_DEC_LIT_STRIDE) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dRecs, (size_t)c->grid * 2 * (ZHIP_DEC_CHUNK + 1) * sizeof(ZhipDSeq)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dCounter, 64) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->dDefTabs, 160 * sizeof(uint64_t)) == hipSuccess;
+    if (ok) { uint64_t t[160]; zhip::host_dec_default_tables(t); ok = hipMemcpy(c->dDefTabs, t, sizeof(t), hipMemcpyHostToDevice) == hipSuccess; }
+    if (!ok) { zhip_free_dctx(c); return nullptr; }
+    return c;
+}
+
+const char* zhip_dctx_last_error(const zhip_dctx* c) { return c ? c->err : "null context"; }
+void zhip_dctx_last_timing(const zhip_dctx* c, double t[2]) { t[0] = c->timing[0]; t[1] = c->timing[1]; }
+
+// = ZSTD_findFrameCompressedSize (lib/zstd.h:254): the frame (or skippable frame) at the start of src, which may hold more
+size_t zhip_frame_compressed_size(const void* srcv, size_t srcSize)
+{
+    const uint8_t* const src = (const uint8_t*)srcv;
+    if (srcSize >= 8) { uint32_t magic, sk; memcpy(&magic, src, 4); memcpy(&sk, src + 4, 4); if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) return (size_t)sk + 8 <= srcSize ? (size_t)sk + 8 : DERR(72); }
+    size_t cs; uint64_t content, bound;
+    int const e = zhip::host_frame_extent(src, srcSize, &cs, &content, &bound);
+    return e ? DERR(e) : cs;
+}
+
+// = ZSTD_findFrameCompressedSize + ZSTD_getFrameContentSize over concatenated frames (lib/zstd.h:254, :215), skippable
+// frames (magic 0x184D2A5?) are stepped over like ZSTD_decompress does (zstd_decompress.c:1100-1110).
+size_t zhip_find_frames(const void* srcv, size_t srcSize, unsigned long long* srcOffsets, unsigned long long* srcSizes,
+                        unsigned long long* contentSizes, unsigned long long* contentBounds, size_t maxFrames)
+{
+    const uint8_t* const src = (const uint8_t*)srcv; size_t pos = 0, n = 0;
+    while (srcSize - pos >= 5) {
+        uint32_t magic; memcpy(&magic, src + pos, 4);
+        if (srcSize - pos >= 8 && (magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            uint32_t sk; memcpy(&sk, src + pos + 4, 4);
+            if ((size_t)sk + 8 > srcSize - pos) return DERR(72);
+            pos += (size_t)sk + 8; continue;
+        }
+        size_t cs; uint64_t content, bound;
+        int const e = zhip::host_frame_extent(src + pos, srcSize - pos, &cs, &content, &bound);
+        if (e) return DERR(e);
+        if (n < maxFrames) {
+            if (srcOffsets) srcOffsets[n] = pos;
+            if (srcSizes) srcSizes[n] = cs;
+            if (contentSizes) contentSizes[n] = content;
+            if (contentBounds) contentBounds[n] = bound;
+        }
+        n++; pos += cs;
+    }
+    if (pos != srcSize) return DERR(72);                        // zstd_decompress.c:1195 "input not entirely consumed"
+    return n;
+}
+
+}  // extern "C"
+
+static size_t ensure_frames(zhip_dctx* c, size_t n)
+{
+    if (c->framesCap >= n) return 0;
+    size_t const cap = n + n / 2 + 64;
+    (void)hipFree(c->dFrames); (void)hipFree(c->dResults); (void)hipFree(c->dUnits); (void)hipFree(c->dChecks);
+    (void)hipHostFree(c->hFrames); (void)hipHostFree(c->hResults); (void)hipHostFree(c->hUnits);
+    c->dFrames = nullptr; c->dResults = nullptr; c->dUnits = nullptr; c->dChecks = nullptr; c->hFrames = nullptr; c->hResults = nullptr; c->hUnits = nullptr; c->framesCap = 0;
+    DCHK(c, hipMalloc((void**)&c->dFrames, cap * sizeof(ZhipDFrame)));
+    DCHK(c, hipMalloc((void**)&c->dResults, cap * sizeof(ZhipDResult)));
+    DCHK(c, hipMalloc((void**)&c->dUnits, cap * sizeof(ZhipUnit)));
+    DCHK(c, hipMalloc((void**)&c->dChecks, (cap + 16) * sizeof(uint32_t)));
+    DCHK(c, hipHostMalloc((void**)&c->hFrames, cap * sizeof(ZhipDFrame), hipHostMallocDefault));
+    DCHK(c, hipHostMalloc((void**)&c->hResults, cap * sizeof(ZhipDResult), hipHostMallocDefault));
+    DCHK(c, hipHostMalloc((void**)&c->hUnits, cap * sizeof(ZhipUnit), hipHostMallocDefault));
+    c->framesCap = cap;
+    return 0;
+}
+
+// frames already described in c->hFrames[0..n); returns total decoded bytes or the first frame error
+static size_t decode_locked(zhip_dctx* c, const zhip_ddict* dd, uint8_t* dstDev, const uint8_t* srcDev, size_t n, unsigned* statusOut,
+                            unsigned long long* sizesOut, hipStream_t s)
+{
+    if (dd && dd->device != c->device) { snprintf(c->err, sizeof(c->err), "dictionary belongs to another device"); return DERR(1); }
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return DERR(72);
+    ZhipDDictDev dv; memset(&dv, 0, sizeof(dv));
+    if (dd) dv = dd->dev;
+    DCHK(c, hipMemcpyAsync(c->dFrames, c->hFrames, n * sizeof(ZhipDFrame), hipMemcpyHostToDevice, s));
+    DCHK(c, hipMemsetAsync(c->dCounter, 0, 4, s));
+    uint32_t const grid = n < c->grid ? (uint32_t)n : c->grid;
+    DCHK(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(zhip::k_decode, dim3(grid), dim3(ZHIP_DEC_THREADS), sizeof(zhip::DecShared), s,
+                       srcDev, c->dFrames, (uint32_t)n, dstDev, c->dLit, c->dRecs, c->dCounter, dv, c->dDefTabs, c->dResults);
+    DCHK(c, hipGetLastError());
+    DCHK(c, hipEventRecord(c->ev[1], s));
+    DCHK(c, hipMemcpyAsync(c->hResults, c->dResults, n * sizeof(ZhipDResult), hipMemcpyDeviceToHost, s));
+    DCHK(c, hipStreamSynchronize(s));
+    bool anyCheck = false;
+    for (size_t i = 0; i < n; i++) if (c->hResults[i].hasChecksum) { anyCheck = true; break; }
+    c->timing[1] = 0;
+    if (anyCheck) {                                             // content checksums: XXH64 of every decoded frame, compared on the device
+        for (size_t i = 0; i < n; i++) { ZhipUnit u; memset(&u, 0, sizeof(u)); u.srcOff = c->hFrames[i].dstOff; u.srcLen = c->hResults[i].hasChecksum ? c->hResults[i].size : 0; c->hUnits[i] = u; }
+        DCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, n * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+        DCHK(c, hipEventRecord(c->ev[2], s));
+        hipLaunchKernelGGL(zhip::k_xxh64, dim3((uint32_t)((n + 15) / 16)), dim3(64), 0, s, (const uint8_t*)dstDev, c->dUnits, (uint32_t)n, c->dChecks);
+        hipLaunchKernelGGL(zhip::k_dec_verify, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, c->dResults, c->dChecks, (uint32_t)n);
+        DCHK(c, hipGetLastError());
+        DCHK(c, hipEventRecord(c->ev[3], s));
+        DCHK(c, hipMemcpyAsync(c->hResults, c->dResults, n * sizeof(ZhipDResult), hipMemcpyDeviceToHost, s));
+        DCHK(c, hipStreamSynchronize(s));
+        float ms = 0; if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->timing[1] = ms;
+    }
+    {   float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->timing[0] = ms; }
+    uint64_t total = 0; size_t firstErr = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (statusOut) statusOut[i] = c->hResults[i].status;
+        if (sizesOut) sizesOut[i] = c->hResults[i].size;
+        if (c->hResults[i].status && !firstErr) { firstErr = DERR(c->hResults[i].status); snprintf(c->err, sizeof(c->err), "frame %zu: zstd error %u", i, c->hResults[i].status); }
+        total += c->hResults[i].size;
+    }
+    return firstErr ? firstErr : (size_t)total;
+}
+
+extern "C" {
+
+size_t zhip_decompress_frames_device(zhip_dctx* c, const zhip_ddict* dd, void* dstDev, const unsigned long long* dstOffsets,
+                                     const unsigned long long* dstCapacities, const void* srcDev, const unsigned long long* srcOffsets,
+                                     const unsigned long long* srcSizes, size_t nFrames, unsigned* statusOut, unsigned long long* sizesOut, void* stream)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    DCHK(c, hipSetDevice(c->device));
+    size_t const e = ensure_frames(c, nFrames);
+    if (e) return e;
+    for (size_t i = 0; i < nFrames; i++) {
+        if (srcSizes[i] > 0xFFFFFFFFull) return DERR(72);
+        ZhipDFrame f; f.srcOff = srcOffsets[i]; f.dstOff = dstOffsets[i]; f.srcLen = (uint32_t)srcSizes[i];
+        f.dstCap = dstCapacities[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dstCapacities[i];
+        c->hFrames[i] = f;
+    }
+    return decode_locked(c, dd, (uint8_t*)dstDev, (const uint8_t*)srcDev, nFrames, statusOut, sizesOut, stream ? (hipStream_t)stream : c->stream);
+}
+
+// = ZSTD_decompress / ZSTD_decompress_usingDDict (lib/zstd.h:205, :1046) for host buffers: every frame of src, contents back to back in dst
+size_t zhip_decompress(zhip_dctx* c, const zhip_ddict* dd, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    DCHK(c, hipSetDevice(c->device));
+    size_t const n = zhip_find_frames(src, srcSize, nullptr, nullptr, nullptr, nullptr, 0);
+    if (zhip_isError(n)) return n;
+    if (n == 0) return 0;
+    std::vector<unsigned long long> so(n), ss(n), cs(n), cb(n);
+    (void)zhip_find_frames(src, srcSize, so.data(), ss.data(), cs.data(), cb.data(), n);
+    size_t const e = ensure_frames(c, n);
+    if (e) return e;
+    // destination slots: the stated content size, or the frame's bound when the header does not hold it
+    uint64_t total = 0; bool exact = true;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t const room = cs[i] != ~0ull ? cs[i] : cb[i];
+        if (cs[i] == ~0ull) exact = false;
+        if (room > 0xFFFFFFFFull || ss[i] > 0xFFFFFFFFull) return DERR(14);
+        ZhipDFrame f; f.srcOff = so[i]; f.dstOff = total; f.srcLen = (uint32_t)ss[i]; f.dstCap = (uint32_t)room;
+        c->hFrames[i] = f; total += room;
+    }
+    if (exact && total > dstCapacity) return DERR(70);
+    if (c->srcStageCap < srcSize + 64) { (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0; DCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64; }
+    if (c->dstStageCap < total + 64) { (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0; DCHK(c, hipMalloc((void**)&c->dDstStage, total + 64)); c->dstStageCap = total + 64; }
+    DCHK(c, hipMemcpyAsync(c->dSrcStage, src, srcSize, hipMemcpyHostToDevice, c->stream));
+    size_t const r = decode_locked(c, dd, c->dDstStage, c->dSrcStage, n, nullptr, nullptr, c->stream);
+    if (zhip_isError(r)) return r;
+    if (r > dstCapacity) return DERR(70);
+    if (exact) { if (r) DCHK(c, hipMemcpy(dst, c->dDstStage, r, hipMemcpyDeviceToHost)); }
+    else {                                                      // frames without a stated size were decoded into bound-sized slots: pack
+        size_t pos = 0;
+        for (size_t i = 0; i < n; i++) {
+            size_t const sz = c->hResults[i].size;
+            if (sz) DCHK(c, hipMemcpy((uint8_t*)dst + pos, c->dDstStage + c->hFrames[i].dstOff, sz, hipMemcpyDeviceToHost));
+            pos += sz;
+        }
+    }
+    return r;
+}
+
+}  // extern "C"

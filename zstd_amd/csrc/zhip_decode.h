@@ -159,6 +159,7 @@ struct DecShared {
     uint8_t  weights[256];
     uint16_t wNew[64]; uint8_t wSym[64], wNb[64];    // FSE table of the Huffman weights (table log <= 6)
     uint16_t hufStart[256];          // first table entry of each symbol while the Huffman table is being filled
+    int16_t  wNorm[256]; uint16_t wNext[256];        // weights' FSE distribution while its table is built
     uint32_t frame;                  // queue ticket
     uint32_t status;                 // first error of the frame
     uint32_t hufLog, hufValid, fseValid;
@@ -280,11 +281,11 @@ __device__ inline LitHeader dec_lit_header(const uint8_t* ip, uint32_t size, uin
 __device__ inline uint32_t dec_fse_weights(DecShared* S, const uint8_t* src, uint32_t size)
 {
     uint32_t maxSym = 255, tl;
-    int16_t norm[256];
+    int16_t* const norm = S->wNorm;
     uint32_t const h = fse_d_read_ncount(norm, &maxSym, &tl, src, size);
     if (!h || tl > 6 || h >= size) return 0;
     {   uint32_t const tsz = 1u << tl, mask = tsz - 1, step = (tsz >> 1) + (tsz >> 3) + 3; uint32_t high = tsz - 1, pos = 0;
-        uint16_t nx[256];
+        uint16_t* const nx = S->wNext;
         for (uint32_t s = 0; s <= maxSym; s++) { if (norm[s] == -1) { S->wSym[high--] = (uint8_t)s; nx[s] = 1; } else nx[s] = (uint16_t)norm[s]; }
         for (uint32_t s = 0; s <= maxSym; s++) for (int i = 0; i < norm[s]; i++) { S->wSym[pos] = (uint8_t)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; }
         if (pos != 0) return 0;

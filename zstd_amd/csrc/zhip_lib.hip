@@ -783,3 +783,5 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
 }
 
 }  // extern "C"
+
+#include "zhip_declib.h"     // decoder entry points (zhip_create_dctx, zhip_decompress, ...)

@@ -157,6 +157,64 @@ size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level
     ZSTD_freeCCtx(c);
     return r;
 }
+
+/* ---- decompression (lib/zstd.h:205-299, :1035-1046): host buffers through zhip_decompress */
+struct ZSTD_DCtx_s { zhip_dctx* z; };
+struct ZSTD_DDict_s { zhip_ddict* d; };
+ZSTD_DCtx* ZSTD_createDCtx(void) { return (ZSTD_DCtx*)calloc(1, sizeof(ZSTD_DCtx)); }
+size_t ZSTD_freeDCtx(ZSTD_DCtx* d) { if (d) { if (d->z) zhip_free_dctx(d->z); free(d); } return 0; }
+static size_t shim_decompress(ZSTD_DCtx* d, void* dst, size_t cap, const void* src, size_t n, const ZSTD_DDict* dd)
+{
+    if (!d) return SHIM_ERR(E_GENERIC);
+    if (!d->z) { d->z = zhip_create_dctx(shim_device()); if (!d->z) return SHIM_ERR(E_memory_allocation); }
+    return zhip_decompress(d->z, dd ? dd->d : NULL, dst, cap, src, n);
+}
+size_t ZSTD_decompressDCtx(ZSTD_DCtx* d, void* dst, size_t cap, const void* src, size_t n) { return shim_decompress(d, dst, cap, src, n, NULL); }
+size_t ZSTD_decompress_usingDDict(ZSTD_DCtx* d, void* dst, size_t cap, const void* src, size_t n, const ZSTD_DDict* dd) { return shim_decompress(d, dst, cap, src, n, dd); }
+size_t ZSTD_decompress(void* dst, size_t cap, const void* src, size_t n)
+{
+    ZSTD_DCtx* d = ZSTD_createDCtx(); size_t r;
+    if (!d) return SHIM_ERR(E_memory_allocation);
+    r = shim_decompress(d, dst, cap, src, n, NULL);
+    ZSTD_freeDCtx(d);
+    return r;
+}
+ZSTD_DDict* ZSTD_createDDict(const void* dict, size_t dictSize)
+{
+    ZSTD_DDict* dd = (ZSTD_DDict*)calloc(1, sizeof(*dd));
+    if (!dd) return NULL;
+    dd->d = zhip_create_ddict(shim_device(), dict, dictSize);
+    if (!dd->d) { free(dd); return NULL; }
+    return dd;
+}
+size_t ZSTD_freeDDict(ZSTD_DDict* dd) { if (dd) { zhip_free_ddict(dd->d); free(dd); } return 0; }
+unsigned ZSTD_getDictID_fromDDict(const ZSTD_DDict* dd) { return dd ? zhip_ddict_id(dd->d) : 0; }
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t n)
+{   /* first frame only, like the reference (zstd_decompress.c:630-650); needs the header, not the whole frame */
+    unsigned long long content = 0; const unsigned char* p = (const unsigned char*)src;
+    static const unsigned did[4] = { 0, 1, 2, 4 }, fcsB[4] = { 0, 2, 4, 8 };
+    unsigned fhd, single, fcsCode, nb, i; size_t pos;
+    if (n < 5 || !(p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD)) return ZSTD_CONTENTSIZE_ERROR;
+    fhd = p[4]; single = (fhd >> 5) & 1; fcsCode = fhd >> 6;
+    pos = 5 + !single + did[fhd & 3]; nb = fcsB[fcsCode] + (single && !fcsCode);
+    if (pos + nb > n) return ZSTD_CONTENTSIZE_ERROR;
+    if (!nb) return ZSTD_CONTENTSIZE_UNKNOWN;
+    for (i = 0; i < nb; i++) content |= (unsigned long long)p[pos + i] << (8 * i);
+    return fcsCode == 1 ? content + 256 : content;
+}
+size_t ZSTD_findFrameCompressedSize(const void* src, size_t n) { return zhip_frame_compressed_size(src, n); }
+unsigned long long ZSTD_findDecompressedSize(const void* src, size_t n)
+{
+    size_t const k = zhip_find_frames(src, n, NULL, NULL, NULL, NULL, 0); unsigned long long total = 0, *cs; size_t i;
+    if (zhip_isError(k)) return ZSTD_CONTENTSIZE_ERROR;
+    if (!k) return 0;
+    cs = (unsigned long long*)malloc(k * sizeof(*cs));
+    if (!cs) return ZSTD_CONTENTSIZE_ERROR;
+    (void)zhip_find_frames(src, n, NULL, NULL, cs, NULL, k);
+    for (i = 0; i < k; i++) { if (cs[i] == ZSTD_CONTENTSIZE_UNKNOWN) { free(cs); return ZSTD_CONTENTSIZE_UNKNOWN; } total += cs[i]; }
+    free(cs);
+    return total;
+}
 size_t ZSTD_compressBound(size_t n) { return zhip_compressBound(n, SHIM_UNIT); }
 unsigned ZSTD_isError(size_t code) { return zhip_isError(code); }
 const char* ZSTD_getErrorName(size_t code) { return zhip_getErrorName(code); }
