@@ -423,6 +423,136 @@ __device__ inline uint32_t dec_huf_streams(DecShared* S, const uint8_t* src, uin
     return __any(bad) ? ZHIP_DE_CORRUPT : 0;
 }
 
+// ---- the same streams decoded by ALL lanes: 16 lanes per stream, each owning a contiguous range of the stream's bits.
+// A prefix code resynchronises: two decoders started at different bit positions fall onto the same codeword boundaries
+// after a few symbols.  So (1) every lane decodes a short run-in (ZHIP_HUF_RUNIN bits above its range) from a guessed
+// position to find where the true chain enters its successor's range, (2) every lane decodes its own range from the entry
+// its predecessor reported, counting symbols and reporting its exit — repeated until no entry changes (the first lane's
+// entry is the stream's top, so a fixed point IS the serial decode), (3) a prefix sum of the counts gives each lane its
+// output offset and it decodes once more, storing symbols.  Exactness: same symbols as the serial decoder; the stream is
+// accepted iff the chain ends on bit 0 with exactly the expected number of symbols (BIT_endOfDStream + op == oend).
+#define ZHIP_HUF_RUNIN 192
+struct BitsAt { const uint8_t* base; int32_t ptr; uint64_t acc, stash, pend; int32_t n, half; int32_t pos; };   // pos = bits of the stream below the read point
+__device__ __forceinline__ void ba_init(BitsAt& b, const uint8_t* base, int32_t pos)
+{
+    b.base = base; b.pos = pos; b.half = 0;
+    int32_t const bytes = (pos + 7) >> 3, pad = (8 - (pos & 7)) & 7;
+    b.ptr = bytes;
+    uint64_t const first = br_load(base, b.ptr);
+    b.acc = first << pad; b.n = 64 - pad;
+    b.stash = br_load(base, b.ptr);
+    b.pend = br_load(base, b.ptr);
+}
+__device__ __forceinline__ void ba_refill(BitsAt& b)
+{
+    b.acc |= (b.stash >> 32) << (32 - b.n);
+    b.n += 32;
+    b.stash <<= 32;
+    if (b.half) { b.stash = b.pend; b.pend = br_load(b.base, b.ptr); }
+    b.half ^= 1;
+}
+// decode from b.pos down to (and possibly past) `lo`; returns the number of symbols, leaves the exit position in b.pos
+__device__ __forceinline__ uint32_t huf_run(BitsAt& b, const lds_u16* T, uint32_t sh, int32_t lo)
+{
+    uint32_t cnt = 0;
+    while (b.pos > lo) {
+        if (b.n <= 32) ba_refill(b);
+        uint32_t e = T[(uint32_t)(b.acc >> sh)];
+        b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8); b.pos -= (int32_t)(e >> 8); cnt++;
+        if (b.pos > lo) {
+            e = T[(uint32_t)(b.acc >> sh)];
+            b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8); b.pos -= (int32_t)(e >> 8); cnt++;
+        }
+    }
+    return cnt;
+}
+__device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
+{
+    uint32_t const lane = (uint32_t)lane_id(), grp = lane >> 4, j = lane & 15;
+    uint32_t const tl = S->hufLog, sh = 64 - tl;
+    const lds_u16* const T = (const lds_u16*)(uintptr_t)S->huf;
+    uint32_t sOff = 0, sLen = size, oOff = 0, oLen = litSize;
+    bool mine = grp == 0;                                      // this lane's stream exists
+    if (!single) {
+        if (size < 10) return ZHIP_DE_CORRUPT;
+        uint32_t const l1 = src[0] | (src[1] << 8), l2 = src[2] | (src[3] << 8), l3 = src[4] | (src[5] << 8);
+        if (6 + l1 + l2 + l3 > size) return ZHIP_DE_CORRUPT;
+        uint32_t const seg = (litSize + 3) / 4;
+        if (3 * seg > litSize) return ZHIP_DE_CORRUPT;
+        mine = true;
+        sOff = 6 + (grp >= 1 ? l1 : 0) + (grp >= 2 ? l2 : 0) + (grp >= 3 ? l3 : 0);
+        sLen = grp == 0 ? l1 : grp == 1 ? l2 : grp == 2 ? l3 : size - 6 - l1 - l2 - l3;
+        oOff = seg * grp; oLen = grp < 3 ? seg : litSize - 3 * seg;
+    }
+    const uint8_t* const base = src + sOff;
+    bool bad = false; int32_t B = 0;
+    if (mine) {
+        uint32_t const last = sLen ? base[sLen - 1] : 0;
+        if (!last) bad = true; else B = (int32_t)(8 * (sLen - 1) + dec_hb(last));
+    }
+    if (__any(bad)) return ZHIP_DE_CORRUPT;
+    int32_t const per = ((B + 15) >> 4) < 64 ? 64 : ((B + 15) >> 4);          // bits per lane (short streams use fewer lanes)
+    int32_t const hi = B - (int32_t)j * per, lo = hi - per > 0 ? hi - per : 0;
+    bool const on = mine && (hi > 0 || (j == 0));              // lane 0 of a stream is always on (B may be 0: no data bits)
+    // (1) run-in: where does a chain started a little above my range leave it?  (guess for my successor's entry)
+    int32_t exitPos = hi;
+    if (on && hi > 0) {
+        if (j == 0) exitPos = B;                                // the true start; decoded in step (2)
+        else { int32_t const st = hi + ZHIP_HUF_RUNIN < B ? hi + ZHIP_HUF_RUNIN : B; BitsAt b; ba_init(b, base, st); (void)huf_run(b, T, sh, hi); exitPos = b.pos; }
+    }
+    // after the run-in lane j holds a guess for ITS OWN entry (the chain's first position <= hi); lane 0's is exact
+    int32_t entry = exitPos;
+    uint32_t cnt = 0; int32_t myExit = entry;
+    bool dirty = on;
+    for (int round = 0; round < 20; round++) {
+        if (dirty) {
+            if (entry > lo) { BitsAt b; ba_init(b, base, entry); cnt = huf_run(b, T, sh, lo); myExit = b.pos; }
+            else { cnt = 0; myExit = entry; }
+        }
+        int32_t const predExit = __shfl(myExit, (int)(lane - 1));
+        bool const changed = on && j > 0 && predExit != entry;
+        if (changed) entry = predExit;
+        dirty = changed;
+        if (!__any(changed)) break;
+        if (round == 19) return ZHIP_DE_CORRUPT;                // never observed: chains that refuse to merge for 20 rounds
+    }
+    // validity: the chain must end exactly on bit 0 and hold exactly oLen symbols
+    uint32_t pre = 0, tot = 0;
+    {   uint32_t c = on ? cnt : 0;
+        for (int k = 0; k < 16; k++) { uint32_t const ck = __shfl(c, (int)((lane & ~15u) + (uint32_t)k)); if ((uint32_t)k < j) pre += ck; tot += ck; }
+    }
+    bool const isLast = on && lo == 0;                          // the lane whose range reaches the stream's start
+    if (mine && tot != oLen) bad = true;
+    if (isLast && myExit != 0) bad = true;
+    if (__any(bad)) return ZHIP_DE_CORRUPT;
+    // (3) output
+    if (on && cnt) {
+        BitsAt b; ba_init(b, base, entry);
+        uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
+        while (i + 4 <= cnt) {
+            uint32_t w = 0;
+            for (int k = 0; k < 2; k++) {
+                if (b.n <= 32) ba_refill(b);
+                uint32_t e = T[(uint32_t)(b.acc >> sh)];
+                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+                w |= (e & 0xFF) << (16 * k);
+                e = T[(uint32_t)(b.acc >> sh)];
+                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+                w |= (e & 0xFF) << (16 * k + 8);
+            }
+            __builtin_memcpy(o + i, &w, 4);
+            i += 4;
+        }
+        for (; i < cnt; i++) {
+            if (b.n <= 32) ba_refill(b);
+            uint32_t const e = T[(uint32_t)(b.acc >> sh)];
+            b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
+            o[i] = (uint8_t)e;
+        }
+    }
+    return 0;
+}
+
 // literals section of one block: wave 0.  Publishes litMode / litSize / litByte / litSrcOff in S (lane 0).
 __device__ inline void dec_literals(DecShared* S, const uint8_t* blk, uint32_t bsize, uint32_t blockMax, uint8_t* lit, uint32_t dstRoom)
 {
@@ -439,7 +569,7 @@ __device__ inline void dec_literals(DecShared* S, const uint8_t* blk, uint32_t b
                 uint32_t const t = dec_huf_table(S, hs, hn);
                 if (!t || t >= hn) err = ZHIP_DE_CORRUPT; else { hs += t; hn -= t; }
             }
-            if (!err) err = dec_huf_streams(S, hs, hn, h.litSize, h.single != 0, lit);
+            if (!err) err = dec_huf_streams_par(S, hs, hn, h.litSize, h.single != 0, lit);
         } else mode = h.type == 0 ? 1 : 2;
     }
     if (lane == 0) {
@@ -682,11 +812,23 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
     __threadfence_block();
 }
 
+// optional phase profile (scripts/prof_decode.py, -DZHIP_PROF builds only): lane 0 of each wave adds s_memtime deltas to g_prof
+#ifdef ZHIP_PROF
+#define DPROF_BEGIN uint64_t dp_t_ = __builtin_amdgcn_s_memtime();
+#define DPROF(slot) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(t_ - dp_t_)); dp_t_ = t_; } while (0)
+#define DPROF_ADD(slot, v) do { if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define DPROF_BEGIN
+#define DPROF(slot) do { } while (0)
+#define DPROF_ADD(slot, v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ one frame, whole workgroup
 __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t srcLen, uint8_t* out, uint32_t dstCap,
                                     uint8_t* litBuf, ZhipDSeq* recBuf, const ZhipDDictDev* dict /* nullptr: none */, const uint64_t* defTabs, ZhipDResult* res)
 {
     uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    DPROF_BEGIN
     DecHeader const H = dec_frame_header(src, srcLen);
     uint32_t const dictLen = dict ? dict->len : 0;
     const uint8_t* const dictEnd = dict ? dict->content + dict->len : nullptr;
@@ -701,6 +843,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
     }
     __syncthreads();
+    DPROF(wave ? 16 : 0);                                       // frame setup
     uint32_t status = S->status;
     uint32_t ip = H.size, op = 0;
     SeqDec D; D.done = 0; D.outPos = 0; D.litPos = 0; D.sLL = D.sOF = D.sML = 0; D.rep0 = D.rep1 = D.rep2 = 0; D.b.n = 0;
@@ -733,7 +876,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         // compressed block (ZSTD_decompressBlock_internal, zstd_decompress_block.c:2072-2180)
         if (csize > H.blockMax) { status = ZHIP_DE_SRC_WRONG; break; }
         const uint8_t* const blk = src + ip;
-        if (wave == 0) dec_literals(S, blk, csize, H.blockMax, litBuf, dstCap - op);
+        if (wave == 0) { dec_literals(S, blk, csize, H.blockMax, litBuf, dstCap - op); DPROF(1); }
         else {
             LitHeader const lh = dec_lit_header(blk, csize, H.blockMax);
             uint32_t err = lh.err ? 1u : 0u;                    // wave 0 reports the literal header's own errors
@@ -741,11 +884,14 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
                 uint32_t const secOff = lh.lh + lh.cSize;
                 D.outPos = op; D.done = 0;
                 uint32_t const e2 = dec_seq_setup(S, blk + secOff, csize - secOff, D, defTabs);
+                DPROF(17);
                 if (e2) { if (lane == 0) atomicMax(&S->status, e2); }
                 else if (S->nbSeq) dec_seq_chunk(S, D, recBuf, 0, S->nbSeq, lh.litSize, dstCap, dictLen);
+                DPROF(18);
             } else if (lane == 0) S->nbSeq = 0;
         }
         __syncthreads();
+        DPROF(wave ? 19 : 2);                                   // waiting for the other wave
         status = S->status;
         if (status) break;
         uint32_t const nbSeq = S->nbSeq, litSize = S->litSize;
@@ -754,7 +900,9 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         for (uint32_t c = 0; c < nChunks && !status; c++) {
             if (wave == 0) dec_exec_chunk(recBuf + (size_t)(c & 1) * (ZHIP_DEC_CHUNK + 1), S->cnt[c & 1], out, L, dictEnd);
             else if (c + 1 < nChunks) dec_seq_chunk(S, D, recBuf + (size_t)((c + 1) & 1) * (ZHIP_DEC_CHUNK + 1), (int)((c + 1) & 1), nbSeq, litSize, dstCap, dictLen);
+            DPROF(wave ? 20 : 3);                               // executing / decoding a chunk
             __syncthreads();
+            DPROF(wave ? 21 : 4);
             status = S->status;
         }
         if (status) break;
@@ -766,13 +914,16 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
             op = endOut + rest;
         }
         ip += csize;
+        DPROF_ADD(8, nbSeq); DPROF_ADD(9, litSize);
         __syncthreads();
+        DPROF(wave ? 22 : 5);                                   // last literals
     }
     if (!status && H.fcs != ~0ull && H.fcs != (uint64_t)op) status = ZHIP_DE_CORRUPT;
     uint32_t ck = 0;
     if (!status && H.checksum) { if (srcLen - ip < 4) status = ZHIP_DE_CHECKSUM; else ck = ld32(src + ip); }
     __syncthreads();
     if (tid == 0) { res->status = status; res->size = status ? 0 : op; res->hasChecksum = !status && H.checksum; res->checksum = ck; }
+    DPROF(wave ? 23 : 6);
 }
 #endif  // ZHIP_DECODE_HOST_ONLY
 
