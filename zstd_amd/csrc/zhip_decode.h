@@ -727,13 +727,23 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
 // ------------------------------------------------------------------ sequence execution, wave 0
 struct LitSrc { const uint8_t* p; uint32_t mode; uint32_t byte; };      // mode 2: RLE (byte repeated)
 
-// exact copy of n bytes by ONE lane (n small)
+// exact copy of n <= 64 bytes by ONE lane, source and destination disjoint: every load is issued before the first store
+// (one memory round trip, not one per 8 bytes); the last chunk is re-based to end exactly at n (it rewrites equal bytes)
 __device__ __forceinline__ void lane_copy(uint8_t* d, const uint8_t* s, uint32_t n)
 {
-    uint32_t i = 0;
-    for (; i + 8 <= n; i += 8) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
-    if (i + 4 <= n) { uint32_t v; __builtin_memcpy(&v, s + i, 4); __builtin_memcpy(d + i, &v, 4); i += 4; }
-    for (; i < n; i++) d[i] = s[i];
+    if (n >= 8) {
+        uint64_t v[8]; uint32_t const lastOff = n - 8;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) { uint32_t const o = 8 * k < lastOff ? 8 * k : lastOff; v[k] = 8 * k < n ? ld64(s + o) : 0; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) { uint32_t const o = 8 * k < lastOff ? 8 * k : lastOff; if (8 * k < n) __builtin_memcpy(d + o, &v[k], 8); }
+    } else if (n >= 4) {
+        uint32_t const a = ld32(s), b2 = ld32(s + n - 4);
+        __builtin_memcpy(d, &a, 4); __builtin_memcpy(d + n - 4, &b2, 4);
+    } else if (n) {
+        uint8_t const a = s[0], b2 = s[n >> 1], c = s[n - 1];
+        d[0] = a; d[n >> 1] = b2; d[n - 1] = c;
+    }
 }
 __device__ __forceinline__ void lane_fill(uint8_t* d, uint32_t byte, uint32_t n)
 {
@@ -764,7 +774,13 @@ __device__ __forceinline__ void wave_copy_periodic(uint8_t* d, const uint8_t* s,
     for (uint32_t k = lane; k < n; k += 64) { d[k] = s[m]; m += stepm; if (m >= period) m -= period; }
 }
 
-// one hand-over chunk: literals of 64 sequences lane-parallel, then their matches in order (ZSTD_execSequence :1001-1095).
+// one hand-over chunk (ZSTD_execSequence :1001-1095), 64 sequences per step, one lane per sequence:
+//   * every lane copies its own literals (their source and destination are known from the records);
+//   * matches in rounds: a match is READY when its source lies entirely below the output of the first match that is still
+//     pending (everything below that point is final) — ready matches are copied at once, each by its own lane (<= 64 bytes)
+//     or by the whole wave (long, periodic = offset < length, or starting in the dictionary), then one s_waitcnt makes them
+//     visible and the next round looks again.  The first pending match is always ready, so a round retires at least one;
+//     far offsets retire a whole batch in one round.
 // out = start of the frame's content; positions in the records are relative to it.
 __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_t* out, LitSrc L, const uint8_t* dictEnd)
 {
@@ -772,10 +788,10 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
     for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
         uint32_t const nb = cnt - b0 < 64 ? cnt - b0 : 64;
         bool const on = lane < nb;
-        ZhipDSeq r, rn;
+        ZhipDSeq r; uint32_t nextLit;
         {   uint4 v = *(const uint4*)(recs + b0 + (on ? lane : 0)); r.outPos = v.x; r.litPos = v.y; r.off = v.z; r.ml = v.w;
-            uint4 w = *(const uint4*)(recs + b0 + (on ? lane : 0) + 1); rn.outPos = w.x; rn.litPos = w.y; rn.off = w.z; rn.ml = w.w; }
-        uint32_t const ll = on ? rn.litPos - r.litPos : 0;
+            nextLit = recs[b0 + (on ? lane : 0) + 1].litPos; }
+        uint32_t const ll = on ? nextLit - r.litPos : 0;
         // literals: short runs by their own lane, long runs by the whole wave
         if (ll && ll <= 64) { if (L.mode == 2) lane_fill(out + r.outPos, L.byte, ll); else lane_copy(out + r.outPos, L.p + r.litPos, ll); }
         unsigned long long longs = __ballot(ll > 64);
@@ -784,32 +800,37 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
             uint32_t const o = __builtin_amdgcn_readlane(r.outPos, j), lp = __builtin_amdgcn_readlane(r.litPos, j), n = __builtin_amdgcn_readlane(ll, j);
             if (L.mode == 2) wave_fill(out + o, L.byte, n); else wave_copy(out + o, L.p + lp, n);
         }
-        __threadfence_block();                                  // every byte below the batch's first match, and all its literals, are now readable
-        uint32_t unsafeFrom = 0xFFFFFFFFu;                      // lowest position written by a match since the last fence
-        for (uint32_t j = 0; j < nb; j++) {
-            uint32_t const o = __builtin_amdgcn_readlane(r.outPos, (int)j) + __builtin_amdgcn_readlane(ll, (int)j);
-            uint32_t const off = __builtin_amdgcn_readlane(r.off, (int)j), ml = __builtin_amdgcn_readlane(r.ml, (int)j);
-            uint8_t* const d = out + o;
-            if (off > o) {                                      // starts in the dictionary (:1052-1066): byte k of the match is
-                // dict[dictLen - back + k] for k < back, then out[k - back] (k < off, existing bytes), then periodic with period off
-                uint32_t const back = off - o, nA = ml < back ? ml : back;
-                wave_copy(d, dictEnd - back, nA);
-                if (ml > back) {
-                    uint32_t const nB = (ml < off ? ml : off) - back;
-                    if (unsafeFrom < nB) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; }
-                    wave_copy(d + back, out, nB);
-                }
-                if (ml > off) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; wave_copy_periodic(d + off, d, off, ml - off); }
-                if (o < unsafeFrom) unsafeFrom = o;
-                continue;
+        __threadfence_block();                                  // the batch's literals and everything before the batch are readable
+        uint32_t const o = r.outPos + ll, off = r.off, ml = r.ml;           // my match: out[o .. o+ml) = virtual[o-off ..]
+        bool const inDict = on && off > o;                      // starts before the frame (validated against the dictionary's length)
+        uint32_t const back = inDict ? off - o : 0;
+        // srcEnd: first position of out[] my match does NOT read (periodic matches read right up to their own start)
+        uint32_t const srcEnd = !on ? 0 : inDict ? (ml > back ? ((ml < off ? ml : off) - back) : 0) : (off < ml ? o : o - off + ml);
+        bool const simple = on && !inDict && off >= ml && ml <= 64;         // one lane, one round trip
+        unsigned long long pending = __ballot(on);
+        while (pending) {
+            int const f = first_lane(pending);
+            uint32_t const limit = __builtin_amdgcn_readlane(o, f);
+            bool const ready = ((pending >> lane) & 1) && ((int)lane == f || srcEnd <= limit);
+            if (ready && simple) lane_copy(out + o, out + o - off, ml);
+            unsigned long long coop = __ballot(ready && !simple);
+            while (coop) {
+                int const j = first_lane(coop); coop &= coop - 1;
+                uint32_t const oj = __builtin_amdgcn_readlane(o, j), offj = __builtin_amdgcn_readlane(off, j), mlj = __builtin_amdgcn_readlane(ml, j);
+                uint8_t* const d = out + oj;
+                if (offj > oj) {                                // starts in the dictionary (:1052-1066): byte k of the match is dict[dictLen - back + k]
+                    // for k < back, then out[k - back] (k < off: bytes that exist), then periodic with period off
+                    uint32_t const bk = offj - oj, nA = mlj < bk ? mlj : bk;
+                    wave_copy(d, dictEnd - bk, nA);
+                    if (mlj > bk) wave_copy(d + bk, out, (mlj < offj ? mlj : offj) - bk);
+                    if (mlj > offj) { __threadfence_block(); wave_copy_periodic(d + offj, d, offj, mlj - offj); }
+                } else if (offj >= mlj) wave_copy(d, d - offj, mlj);
+                else wave_copy_periodic(d, d - offj, offj, mlj);
             }
-            uint32_t const s = o - off, e = off < ml ? o : s + ml;          // source range [s, e)
-            if (e > unsafeFrom) { __threadfence_block(); unsafeFrom = 0xFFFFFFFFu; }
-            if (off >= ml) wave_copy(d, out + s, ml); else wave_copy_periodic(d, out + s, off, ml);
-            if (o < unsafeFrom) unsafeFrom = o;
+            pending &= ~__ballot(ready);
+            __threadfence_block();
         }
     }
-    __threadfence_block();
 }
 
 // optional phase profile (scripts/prof_decode.py, -DZHIP_PROF builds only): lane 0 of each wave adds s_memtime deltas to g_prof
