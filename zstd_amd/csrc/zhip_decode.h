@@ -32,6 +32,7 @@
 #define ZHIP_DEC_THREADS 128
 #define ZHIP_DEC_CHUNK   2048u                 /* sequences per hand-over buffer */
 #define ZHIP_DEC_LIT_STRIDE (ZHIP_UNIT_MAX + 64)
+#define ZHIP_DEC_RING_WORDS 512u                /* dwords of the sequence bitstream staged in LDS (two halves) */
 
 // zstd error codes (lib/zstd_errors.h) used as per-frame status
 enum { ZHIP_DE_OK = 0, ZHIP_DE_PREFIX = 10, ZHIP_DE_UNSUPPORTED = 14, ZHIP_DE_WINDOW = 16, ZHIP_DE_CORRUPT = 20, ZHIP_DE_CHECKSUM = 22,
@@ -160,6 +161,8 @@ struct DecShared {
     uint16_t wNew[64]; uint8_t wSym[64], wNb[64];    // FSE table of the Huffman weights (table log <= 6)
     uint16_t hufStart[256];          // first table entry of each symbol while the Huffman table is being filled
     int16_t  wNorm[256]; uint16_t wNext[256];        // weights' FSE distribution while its table is built
+    uint32_t ring[ZHIP_DEC_RING_WORDS];             // the sequence bitstream, staged: word w = the 32 bits consumed w-th (seq_ring_fill)
+    uint32_t bat[64][2];             // pass 1 -> pass 2: bit position and packed states of each sequence of a batch
     uint32_t frame;                  // queue ticket
     uint32_t status;                 // first error of the frame
     uint32_t hufLog, hufValid, fseValid;
@@ -580,13 +583,42 @@ __device__ inline void dec_literals(DecShared* S, const uint8_t* blk, uint32_t b
 }
 
 // ------------------------------------------------------------------ sequences section, wave 1
-struct SeqDec {                     // lives in wave 1's registers across hand-over chunks (lane 0's copy is the real one)
-    BitsRev b; uint32_t sLL, sOF, sML; uint32_t rep0, rep1, rep2; uint32_t outPos, litPos; uint32_t done;
+// The interleaved bitstream is consumed from its last byte downwards.  D = "down position": the number of bits consumed so
+// far counting from the top bit of the last byte; word w of the ring holds the bits D in [32w, 32w+32), most significant
+// first, which is simply the little-endian dword that ends 4w bytes below the stream's end.  Any field can then be
+// extracted at any D with two aligned LDS reads — no sequential container, so the three next-state fields of a sequence are
+// fetched at once and the value bits can be fetched by other lanes later.
+struct SeqDec {                     // wave 1's registers across hand-over chunks; every field is wave-uniform
+    const uint8_t* base; uint32_t size;     // the bitstream
+    uint32_t Dpos;                  // down position of the next sequence
+    uint32_t wLoaded;               // ring holds words [wLoaded - ZHIP_DEC_RING_WORDS, wLoaded)
+    uint32_t sLL, sOF, sML; uint32_t rep0, rep1, rep2; uint32_t outPos, litPos; uint32_t done;
 };
+// load ring words [w0, w0 + count) (count a multiple of 64), whole wave
+__device__ __forceinline__ void seq_ring_fill(DecShared* S, const SeqDec& D, uint32_t w0, uint32_t count)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    for (uint32_t w = w0 + lane; w < w0 + count; w += 64) {
+        int32_t const at = (int32_t)D.size - 4 * (int32_t)(w + 1);              // byte offset of the dword in the stream
+        uint32_t v = 0;
+        if (at > -4) {                                                           // at least one byte inside the stream; bytes before
+            v = ld32(D.base + at);                                               // its start belong to the same frame (>= 8 of them)
+            if (at < 0) v &= ~0u << (8 * (uint32_t)(-at));
+        }
+        S->ring[w & (ZHIP_DEC_RING_WORDS - 1)] = v;
+    }
+}
+// nb <= 32 bits at down position d
+__device__ __forceinline__ uint32_t seq_field(const lds_u32* R, uint32_t d, uint32_t nb)
+{
+    uint32_t const w = d >> 5;
+    uint64_t const x = ((uint64_t)R[w & (ZHIP_DEC_RING_WORDS - 1)] << 32) | R[(w + 1) & (ZHIP_DEC_RING_WORDS - 1)];
+    return (uint32_t)(((x << (d & 31)) >> 32) >> (32 - nb));
+}
 
 // header + the three tables (ZSTD_decodeSeqHeaders :662-745, ZSTD_buildSeqTable :625-660).  seq = the sequences section.
 // Publishes nbSeq; on success initialises D.  Wave-uniform result: error code or 0.
-__device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint32_t size, SeqDec& D, const uint64_t* defTabs)
+__device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint32_t size, SeqDec& D, const uint64_t* defTabs, uint32_t* nbSeqOut)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t err = 0, nbSeq = 0, pos = 0, modes = 0;
@@ -627,6 +659,7 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
     err = __builtin_amdgcn_readfirstlane(err);
     nbSeq = __builtin_amdgcn_readfirstlane(nbSeq);
     if (lane == 0) { S->nbSeq = err ? 0 : nbSeq; }
+    *nbSeqOut = err ? 0 : nbSeq;                                // wave-uniform copy for the calling wave (S->nbSeq is for the other one, after the barrier)
     if (err) return err;
     if (!nbSeq) return 0;
     pos = __builtin_amdgcn_readfirstlane(pos);
@@ -649,78 +682,146 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) S->fseValid = 1;
     // bitstream + initial states (zstd_decompress_block.c:1636-1643)
-    uint32_t bad = 0;
-    if (lane == 0) {
-        if (!br_init(D.b, seq + pos, size - pos)) bad = 1;
-        else {
-            uint32_t const l0 = S->log[0], l1 = S->log[1], l2 = S->log[2];
-            D.sLL = br_read(D.b, l0); if (D.b.n <= 32) br_refill(D.b);
-            D.sOF = br_read(D.b, l1);
-            D.sML = br_read(D.b, l2); if (D.b.n <= 32) br_refill(D.b);
-            D.rep0 = S->rep[0]; D.rep1 = S->rep[1]; D.rep2 = S->rep[2];
-            D.litPos = 0; D.done = 0;
-        }
+    uint32_t const bsz = size - pos;
+    if (bsz == 0) return ZHIP_DE_CORRUPT;
+    uint32_t const lastByte = seq[size - 1];
+    if (lastByte == 0) return ZHIP_DE_CORRUPT;                  // no end mark (bitstream.h:284)
+    D.base = seq + pos; D.size = bsz;
+    D.wLoaded = ZHIP_DEC_RING_WORDS;
+    seq_ring_fill(S, D, 0, ZHIP_DEC_RING_WORDS);
+    __builtin_amdgcn_wave_barrier();
+    {   const lds_u32* const R = (const lds_u32*)(uintptr_t)S->ring;
+        uint32_t const l0 = S->log[0], l1 = S->log[1], l2 = S->log[2];
+        uint32_t d = 8 - dec_hb(lastByte);                      // the mark and the zero bits above it
+        D.sLL = seq_field(R, d, l0); d += l0;
+        D.sOF = seq_field(R, d, l1); d += l1;
+        D.sML = seq_field(R, d, l2); d += l2;
+        D.Dpos = d;
     }
-    return __builtin_amdgcn_readfirstlane(bad) ? ZHIP_DE_CORRUPT : 0;
+    D.rep0 = S->rep[0]; D.rep1 = S->rep[1]; D.rep2 = S->rep[2];
+    D.litPos = 0; D.done = 0;
+    return 0;
 }
 
-// decode up to ZHIP_DEC_CHUNK sequences into recs (+ a sentinel record); lane 0 of wave 1 (ZSTD_decodeSequence :1228-1345)
+// decode up to ZHIP_DEC_CHUNK sequences into recs (+ a sentinel record); whole wave 1 (ZSTD_decodeSequence :1228-1345).
+// Per batch of 64 sequences:
+//   pass 1, one lane: only what is inherently serial — look the three states up, add up the bits the sequence takes, fetch
+//     the three next-state fields, note (position, states) in LDS: two dependent LDS round trips per sequence;
+//   pass 2, one lane per sequence: value bits, literal / match lengths, raw offset codes; then the repeat-offset history is
+//     resolved in order (a short wave-uniform loop), positions come from two wave prefix sums, every record is validated
+//     (ZSTD_execSequence's checks :1025-1054) and stored.
 __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, int buf, uint32_t nbSeq, uint32_t litSize,
                                      uint32_t dstCap, uint32_t dictLen)
 {
-    if (lane_id() != 0) return;
+    uint32_t const lane = (uint32_t)lane_id();
     const lds_u32* const TL = (const lds_u32*)(uintptr_t)dec_tab(S, 0);     // entries as two dwords: [next | nbAdd << 16 | nb << 24], [base]
     const lds_u32* const TO = (const lds_u32*)(uintptr_t)dec_tab(S, 1);
     const lds_u32* const TM = (const lds_u32*)(uintptr_t)dec_tab(S, 2);
-    uint32_t n = 0, err = 0;
+    const lds_u32* const R = (const lds_u32*)(uintptr_t)S->ring;
     uint32_t const want = nbSeq - D.done < ZHIP_DEC_CHUNK ? nbSeq - D.done : ZHIP_DEC_CHUNK;
-    BitsRev b = D.b;
-    uint32_t sLL = D.sLL, sOF = D.sOF, sML = D.sML, rep0 = D.rep0, rep1 = D.rep1, rep2 = D.rep2, outPos = D.outPos, litPos = D.litPos;
-    for (; n < want; n++) {
-        uint32_t const eL0 = TL[2 * sLL], bL = TL[2 * sLL + 1];
-        uint32_t const eO0 = TO[2 * sOF], bO = TO[2 * sOF + 1];
-        uint32_t const eM0 = TM[2 * sML], bM = TM[2 * sML + 1];
-        uint32_t const aL = (eL0 >> 16) & 0xFF, aO = (eO0 >> 16) & 0xFF, aM = (eM0 >> 16) & 0xFF;
-        uint32_t offset;
-        if (b.n <= 32) br_refill(b);
-        if (aO > 1) {
-            offset = bO + br_read(b, aO);
-            rep2 = rep1; rep1 = rep0; rep0 = offset;
-        } else {
-            uint32_t const ll0 = bL == 0;
-            if (aO == 0) { offset = ll0 ? rep1 : rep0; rep1 = ll0 ? rep0 : rep1; rep0 = offset; }
-            else {
-                uint32_t const v = bO + ll0 + br_read(b, 1);
-                uint32_t t = v == 3 ? rep0 - 1 : (v == 1 ? rep1 : v == 2 ? rep2 : rep0);
-                if (t == 0) t = 0xFFFFFFFFu;
-                if (v != 1) rep2 = rep1;
-                rep1 = rep0; rep0 = t; offset = t;
+    uint32_t n = 0, err = 0;
+    uint32_t const endD = 8 * D.size;
+    while (n < want && !err) {
+        uint32_t const nb = want - n < 64 ? want - n : 64;
+        // the batch reads at most 64 * 89 bits + one word beyond: keep that much staged, never overwrite what is still ahead
+        if ((D.Dpos >> 5) + ZHIP_DEC_RING_WORDS / 2 >= D.wLoaded) {
+            __builtin_amdgcn_wave_barrier();
+            seq_ring_fill(S, D, D.wLoaded, ZHIP_DEC_RING_WORDS / 2);
+            D.wLoaded += ZHIP_DEC_RING_WORDS / 2;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- pass 1 (lane 0)
+        uint32_t d = D.Dpos, sLL = D.sLL, sOF = D.sOF, sML = D.sML;
+        if (lane == 0) {
+            bool const chunkHasLast = D.done + n + nb == nbSeq;
+            for (uint32_t j = 0; j < nb; j++) {
+                uint32_t const eL = TL[2 * sLL], eO = TO[2 * sOF], eM = TM[2 * sML];
+                S->bat[j][0] = d; S->bat[j][1] = sLL | (sOF << 9) | (sML << 17);
+                uint32_t const nL = eL >> 24, nM = eM >> 24, nO = eO >> 24;
+                uint32_t const ds = d + ((eL >> 16) & 0xFF) + ((eM >> 16) & 0xFF) + ((eO >> 16) & 0xFF);   // state bits start here
+                if (chunkHasLast && j + 1 == nb) { d = ds; break; }          // the last sequence updates no state (:1335)
+                sLL = (eL & 0xFFFF) + seq_field(R, ds, nL);
+                sML = (eM & 0xFFFF) + seq_field(R, ds + nL, nM);
+                sOF = (eO & 0xFFFF) + seq_field(R, ds + nL + nM, nO);
+                d = ds + nL + nM + nO;
             }
         }
-        if (b.n <= 32) br_refill(b);
-        uint32_t const ml = bM + br_read(b, aM);
-        uint32_t const ll = bL + br_read(b, aL);
-        if (b.n <= 32) br_refill(b);
-        if (D.done + n + 1 < nbSeq) {
-            sLL = (eL0 & 0xFFFF) + br_read(b, eL0 >> 24);
-            sML = (eM0 & 0xFFFF) + br_read(b, eM0 >> 24);
-            sOF = (eO0 & 0xFFFF) + br_read(b, eO0 >> 24);
+        D.Dpos = __builtin_amdgcn_readfirstlane(d); D.sLL = __builtin_amdgcn_readfirstlane(sLL);
+        D.sOF = __builtin_amdgcn_readfirstlane(sOF); D.sML = __builtin_amdgcn_readfirstlane(sML);
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 2 (lane j = sequence j)
+        bool const on = lane < nb;
+        uint32_t ll = 0, ml = 0, offv = 0, sel = 4;            // sel: 4 = new offset in offv; 0..3 = repeat-offset selector (0: code 0)
+        uint32_t ll0 = 0;
+        if (on) {
+            uint32_t const dj = S->bat[lane][0], st = S->bat[lane][1];
+            uint32_t const a = st & 511, b2 = (st >> 9) & 255, c = st >> 17;
+            uint32_t const eL = TL[2 * a], bL = TL[2 * a + 1], eO = TO[2 * b2], bO = TO[2 * b2 + 1], eM = TM[2 * c], bM = TM[2 * c + 1];
+            uint32_t const aL = (eL >> 16) & 0xFF, aO = (eO >> 16) & 0xFF, aM = (eM >> 16) & 0xFF;
+            uint32_t const xo = seq_field(R, dj, aO);
+            ml = bM + seq_field(R, dj + aO, aM);
+            ll = bL + seq_field(R, dj + aO + aM, aL);
+            ll0 = bL == 0;
+            if (aO > 1) { offv = bO + xo; sel = 4; }
+            else if (aO == 0) sel = 0;
+            else sel = bO + ll0 + xo;                          // 1..3
         }
-        // ZSTD_execSequence's checks (:1025-1054), here so that the executing wave only ever sees valid records
-        if (ll > litSize - litPos) { err = ZHIP_DE_CORRUPT; break; }
-        if ((uint64_t)outPos + ll + ml > dstCap) { err = ZHIP_DE_DST_SMALL; break; }
-        if ((uint64_t)offset > (uint64_t)outPos + ll + dictLen) { err = ZHIP_DE_CORRUPT; break; }
-        ZhipDSeq r; r.outPos = outPos; r.litPos = litPos; r.off = offset; r.ml = ml;
-        recs[n] = r;
-        outPos += ll + ml; litPos += ll;
+        // repeat-offset history in order (:1277-1300); all values wave-uniform
+        uint32_t rep0 = D.rep0, rep1 = D.rep1, rep2 = D.rep2;
+        unsigned long long const reps = __ballot(on && sel != 4);
+        if (reps == 0 && nb) {                                  // no repeat codes in the batch: the history is the last three offsets
+            uint32_t const o1 = __builtin_amdgcn_readlane(offv, (int)nb - 1);
+            uint32_t const o2 = nb >= 2 ? __builtin_amdgcn_readlane(offv, (int)nb - 2) : rep0;
+            uint32_t const o3 = nb >= 3 ? __builtin_amdgcn_readlane(offv, (int)nb - 3) : (nb == 2 ? rep0 : rep1);
+            rep0 = o1; rep1 = o2; rep2 = o3;
+        } else {
+            for (uint32_t j = 0; j < nb; j++) {
+                uint32_t const sj = __builtin_amdgcn_readlane(sel, (int)j);
+                uint32_t off;
+                if (sj == 4) { off = __builtin_amdgcn_readlane(offv, (int)j); rep2 = rep1; rep1 = rep0; rep0 = off; }
+                else if (sj == 0) {
+                    uint32_t const z = __builtin_amdgcn_readlane(ll0, (int)j);
+                    off = z ? rep1 : rep0; rep1 = z ? rep0 : rep1; rep0 = off;
+                    if (lane == j) offv = off;
+                } else {
+                    uint32_t t = sj == 3 ? rep0 - 1 : (sj == 1 ? rep1 : rep2);
+                    if (t == 0) t = 0xFFFFFFFFu;               // 0 is invalid: rejected by the offset check below
+                    if (sj != 1) rep2 = rep1;
+                    rep1 = rep0; rep0 = t; off = t;
+                    if (lane == j) offv = off;
+                }
+            }
+        }
+        D.rep0 = rep0; D.rep1 = rep1; D.rep2 = rep2;
+        // positions: exclusive prefix sums of ll and ll + ml over the batch
+        uint32_t incL = ll, incT = ll + ml;
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            uint32_t const a = __shfl_up(incL, (unsigned)sft), b2 = __shfl_up(incT, (unsigned)sft);
+            if ((int)lane >= sft) { incL += a; incT += b2; }
+        }
+        uint32_t const litPos = D.litPos + incL - ll;
+        uint64_t const outPos64 = (uint64_t)D.outPos + (incT - (ll + ml));          // 64 * 2^18 fits, D.outPos may be near 2^32
+        uint32_t e = 0;
+        if (on) {
+            if (ll > litSize || litPos > litSize - ll) e = ZHIP_DE_CORRUPT;
+            else if (outPos64 + ll + ml > dstCap) e = ZHIP_DE_DST_SMALL;
+            else if ((uint64_t)offv > outPos64 + ll + dictLen) e = ZHIP_DE_CORRUPT;
+        }
+        unsigned long long const bads = __ballot(e != 0);
+        if (bads) { err = __builtin_amdgcn_readlane(e, first_lane(bads)); break; }
+        if (on) { ZhipDSeq r; r.outPos = (uint32_t)outPos64; r.litPos = litPos; r.off = offv; r.ml = ml; recs[n + lane] = r; }
+        D.litPos += __builtin_amdgcn_readlane(incL, (int)nb - 1);
+        D.outPos += __builtin_amdgcn_readlane(incT, (int)nb - 1);
+        n += nb;
     }
-    if (!err && D.done + n == nbSeq && br_used(b) != b.total) err = ZHIP_DE_CORRUPT;      // BIT_endOfDStream (:1677)
-    {   ZhipDSeq r; r.outPos = outPos; r.litPos = litPos; r.off = 0; r.ml = 0; recs[n] = r; }
-    D.b = b; D.sLL = sLL; D.sOF = sOF; D.sML = sML; D.rep0 = rep0; D.rep1 = rep1; D.rep2 = rep2; D.outPos = outPos; D.litPos = litPos;
+    if (!err && D.done + n == nbSeq && D.Dpos != endD) err = ZHIP_DE_CORRUPT;          // BIT_endOfDStream (:1677)
     D.done += n;
-    S->cnt[buf] = n; S->endOut = outPos; S->endLit = litPos;
-    if (D.done == nbSeq && !err) { S->rep[0] = rep0; S->rep[1] = rep1; S->rep[2] = rep2; }
-    if (err) atomicMax(&S->status, err);
+    if (lane == 0) {
+        ZhipDSeq r; r.outPos = D.outPos; r.litPos = D.litPos; r.off = 0; r.ml = 0; recs[err ? 0 : n] = r;
+        S->cnt[buf] = err ? 0 : n; S->endOut = D.outPos; S->endLit = D.litPos;
+        if (D.done == nbSeq && !err) { S->rep[0] = D.rep0; S->rep[1] = D.rep1; S->rep[2] = D.rep2; }
+        if (err) atomicMax(&S->status, err);
+    }
     __threadfence_block();
 }
 
@@ -867,7 +968,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
     DPROF(wave ? 16 : 0);                                       // frame setup
     uint32_t status = S->status;
     uint32_t ip = H.size, op = 0;
-    SeqDec D; D.done = 0; D.outPos = 0; D.litPos = 0; D.sLL = D.sOF = D.sML = 0; D.rep0 = D.rep1 = D.rep2 = 0; D.b.n = 0;
+    SeqDec D; D.done = 0; D.outPos = 0; D.litPos = 0; D.sLL = D.sOF = D.sML = 0; D.rep0 = D.rep1 = D.rep2 = 0; D.base = src; D.size = 0; D.Dpos = 0; D.wLoaded = 0;
     bool last = false;
     while (!status && !last) {
         if (srcLen - ip < 3) { status = ZHIP_DE_SRC_WRONG; break; }
@@ -904,10 +1005,11 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
             if (!err) {
                 uint32_t const secOff = lh.lh + lh.cSize;
                 D.outPos = op; D.done = 0;
-                uint32_t const e2 = dec_seq_setup(S, blk + secOff, csize - secOff, D, defTabs);
+                uint32_t nbSeqW = 0;
+                uint32_t const e2 = dec_seq_setup(S, blk + secOff, csize - secOff, D, defTabs, &nbSeqW);
                 DPROF(17);
                 if (e2) { if (lane == 0) atomicMax(&S->status, e2); }
-                else if (S->nbSeq) dec_seq_chunk(S, D, recBuf, 0, S->nbSeq, lh.litSize, dstCap, dictLen);
+                else if (nbSeqW) dec_seq_chunk(S, D, recBuf, 0, nbSeqW, lh.litSize, dstCap, dictLen);
                 DPROF(18);
             } else if (lane == 0) S->nbSeq = 0;
         }
