@@ -51,6 +51,8 @@ def main():
         w1 = ["setup", "seq tables", "decode chunk0", "wait(literals)", "decode chunk", "wait(exec)", "last", "finish"]
         res["wave0_ticks_per_unit"] = {w0[i]: round(v[i] / units) for i in range(7)}
         res["wave1_ticks_per_unit"] = {w1[i]: round(v[16 + i] / units) for i in range(8)}
+        names = ["ring refill+loop", "pass1 serial chain", "pass2 values", "repeat offsets", "scan+validate+store"]
+        res["seq_chunk_ticks_per_unit"] = {names[i]: round(v[24 + i] / units) for i in range(5)}
         res["seqs_per_unit"] = v[8] / units; res["lits_per_unit"] = v[9] / units
     print(json.dumps(res, indent=1))
 

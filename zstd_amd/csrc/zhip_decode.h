@@ -150,6 +150,23 @@ __device__ __host__ inline uint32_t fse_d_read_ncount(TNORM norm, uint32_t* maxS
 }
 
 #ifndef ZHIP_DECODE_HOST_ONLY
+// optional phase profile (scripts/prof_decode.py, -DZHIP_PROF builds only): lane 0 of each wave adds s_memtime deltas to g_prof
+#ifdef ZHIP_PROF
+#define DPROF_BEGIN uint64_t dp_t_ = __builtin_amdgcn_s_memtime();
+#define DPROF(slot) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(t_ - dp_t_)); dp_t_ = t_; } while (0)
+#define DPROF_ADD(slot, v) do { if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(v)); } while (0)
+#define DPROF_LOCAL uint64_t dl_t_ = __builtin_amdgcn_s_memtime(); uint64_t dl_a_[6] = {0, 0, 0, 0, 0, 0};
+#define DPROF_L(i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); dl_a_[i] += t_ - dl_t_; dl_t_ = t_; } while (0)
+#define DPROF_LFLUSH(base) do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&zhip::g_prof[(base) + i_], (unsigned long long)dl_a_[i_]); } while (0)
+#else
+#define DPROF_LOCAL
+#define DPROF_L(i) do { } while (0)
+#define DPROF_LFLUSH(base) do { } while (0)
+#define DPROF_BEGIN
+#define DPROF(slot) do { } while (0)
+#define DPROF_ADD(slot, v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ LDS of one workgroup
 struct DecShared {
     uint64_t fseAll[1280];           // LL[512] OF[256] ML[512] decoding tables (dec_tab())
@@ -161,7 +178,8 @@ struct DecShared {
     uint16_t wNew[64]; uint8_t wSym[64], wNb[64];    // FSE table of the Huffman weights (table log <= 6)
     uint16_t hufStart[256];          // first table entry of each symbol while the Huffman table is being filled
     int16_t  wNorm[256]; uint16_t wNext[256];        // weights' FSE distribution while its table is built
-    uint32_t ring[ZHIP_DEC_RING_WORDS];             // the sequence bitstream, staged: word w = the 32 bits consumed w-th (seq_ring_fill)
+    uint32_t ring[ZHIP_DEC_RING_WORDS + 4];         // the sequence bitstream, staged: word w = the 32 bits consumed w-th (seq_ring_fill);
+                                                    // the last 4 words mirror the first 4 so that a window never wraps
     uint32_t bat[64][2];             // pass 1 -> pass 2: bit position and packed states of each sequence of a batch
     uint32_t frame;                  // queue ticket
     uint32_t status;                 // first error of the frame
@@ -605,14 +623,16 @@ __device__ __forceinline__ void seq_ring_fill(DecShared* S, const SeqDec& D, uin
             v = ld32(D.base + at);                                               // its start belong to the same frame (>= 8 of them)
             if (at < 0) v &= ~0u << (8 * (uint32_t)(-at));
         }
-        S->ring[w & (ZHIP_DEC_RING_WORDS - 1)] = v;
+        uint32_t const ri = w & (ZHIP_DEC_RING_WORDS - 1);
+        S->ring[ri] = v;
+        if (ri < 4) S->ring[ZHIP_DEC_RING_WORDS + ri] = v;
     }
 }
 // nb <= 32 bits at down position d
 __device__ __forceinline__ uint32_t seq_field(const lds_u32* R, uint32_t d, uint32_t nb)
 {
-    uint32_t const w = d >> 5;
-    uint64_t const x = ((uint64_t)R[w & (ZHIP_DEC_RING_WORDS - 1)] << 32) | R[(w + 1) & (ZHIP_DEC_RING_WORDS - 1)];
+    uint32_t const w = (d >> 5) & (ZHIP_DEC_RING_WORDS - 1);
+    uint64_t const x = ((uint64_t)R[w] << 32) | R[w + 1];
     return (uint32_t)(((x << (d & 31)) >> 32) >> (32 - nb));
 }
 
@@ -721,6 +741,7 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
     uint32_t const want = nbSeq - D.done < ZHIP_DEC_CHUNK ? nbSeq - D.done : ZHIP_DEC_CHUNK;
     uint32_t n = 0, err = 0;
     uint32_t const endD = 8 * D.size;
+    DPROF_LOCAL
     while (n < want && !err) {
         uint32_t const nb = want - n < 64 ? want - n : 64;
         // the batch reads at most 64 * 89 bits + one word beyond: keep that much staged, never overwrite what is still ahead
@@ -730,25 +751,40 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
             D.wLoaded += ZHIP_DEC_RING_WORDS / 2;
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- pass 1 (lane 0)
+        DPROF_L(0);
+        // ---- pass 1 (lane 0): ONE LDS round trip per sequence — the three table entries and a 96-bit window of the stream at
+        // the sequence's start are requested together (both addresses are known from the previous sequence); the window covers
+        // value bits + state bits unless the offset's extra bits are unusually many, then a second window is fetched.
         uint32_t d = D.Dpos, sLL = D.sLL, sOF = D.sOF, sML = D.sML;
         if (lane == 0) {
             bool const chunkHasLast = D.done + n + nb == nbSeq;
             for (uint32_t j = 0; j < nb; j++) {
+                uint32_t const w = (d >> 5) & (ZHIP_DEC_RING_WORDS - 1), sh = d & 31;
                 uint32_t const eL = TL[2 * sLL], eO = TO[2 * sOF], eM = TM[2 * sML];
+                uint32_t const r0 = R[w], r1 = R[w + 1], r2 = R[w + 2];
                 S->bat[j][0] = d; S->bat[j][1] = sLL | (sOF << 9) | (sML << 17);
-                uint32_t const nL = eL >> 24, nM = eM >> 24, nO = eO >> 24;
-                uint32_t const ds = d + ((eL >> 16) & 0xFF) + ((eM >> 16) & 0xFF) + ((eO >> 16) & 0xFF);   // state bits start here
-                if (chunkHasLast && j + 1 == nb) { d = ds; break; }          // the last sequence updates no state (:1335)
-                sLL = (eL & 0xFFFF) + seq_field(R, ds, nL);
-                sML = (eM & 0xFFFF) + seq_field(R, ds + nL, nM);
-                sOF = (eO & 0xFFFF) + seq_field(R, ds + nL + nM, nO);
-                d = ds + nL + nM + nO;
+                uint32_t const sum = eL + eO + eM;                           // fields add without carrying into each other: next < 2^9, nbAdd sum <= 63, nb sum <= 26
+                uint32_t const aSum = (sum >> 16) & 0xFF, nL = eL >> 24, nM = eM >> 24, nO = eO >> 24;
+                if (chunkHasLast && j + 1 == nb) { d += aSum; break; }       // the last sequence updates no state (:1335)
+                uint32_t const k = sh + aSum;                                // state bits start k bits into the window
+                uint32_t t;                                                  // 32 bits starting there
+                if (k + 26 <= 96) {
+                    uint32_t const hi = k < 32 ? r0 : (k < 64 ? r1 : r2), lo = k < 32 ? r1 : (k < 64 ? r2 : 0u);
+                    t = (uint32_t)(((((uint64_t)hi << 32) | lo) << (k & 31)) >> 32);
+                } else {
+                    uint32_t const d2 = d + aSum, w2 = (d2 >> 5) & (ZHIP_DEC_RING_WORDS - 1);
+                    t = (uint32_t)(((((uint64_t)R[w2] << 32) | R[w2 + 1]) << (d2 & 31)) >> 32);
+                }
+                sLL = (eL & 0xFFFF) + ((t >> 1) >> (31 - nL)); t <<= nL;
+                sML = (eM & 0xFFFF) + ((t >> 1) >> (31 - nM)); t <<= nM;
+                sOF = (eO & 0xFFFF) + ((t >> 1) >> (31 - nO));
+                d += aSum + nL + nM + nO;
             }
         }
         D.Dpos = __builtin_amdgcn_readfirstlane(d); D.sLL = __builtin_amdgcn_readfirstlane(sLL);
         D.sOF = __builtin_amdgcn_readfirstlane(sOF); D.sML = __builtin_amdgcn_readfirstlane(sML);
         __builtin_amdgcn_wave_barrier();
+        DPROF_L(1);
         // ---- pass 2 (lane j = sequence j)
         bool const on = lane < nb;
         uint32_t ll = 0, ml = 0, offv = 0, sel = 4;            // sel: 4 = new offset in offv; 0..3 = repeat-offset selector (0: code 0)
@@ -766,33 +802,40 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
             else if (aO == 0) sel = 0;
             else sel = bO + ll0 + xo;                          // 1..3
         }
+        DPROF_L(2);
         // repeat-offset history in order (:1277-1300); all values wave-uniform
         uint32_t rep0 = D.rep0, rep1 = D.rep1, rep2 = D.rep2;
-        unsigned long long const reps = __ballot(on && sel != 4);
-        if (reps == 0 && nb) {                                  // no repeat codes in the batch: the history is the last three offsets
-            uint32_t const o1 = __builtin_amdgcn_readlane(offv, (int)nb - 1);
-            uint32_t const o2 = nb >= 2 ? __builtin_amdgcn_readlane(offv, (int)nb - 2) : rep0;
-            uint32_t const o3 = nb >= 3 ? __builtin_amdgcn_readlane(offv, (int)nb - 3) : (nb == 2 ? rep0 : rep1);
-            rep0 = o1; rep1 = o2; rep2 = o3;
-        } else {
-            for (uint32_t j = 0; j < nb; j++) {
+        {   // only sequences that USE the history are visited; the new offsets between two of them are pushed in one step
+            unsigned long long reps = __ballot(on && sel != 4);
+            uint32_t h = 0;                                     // history is current up to (not including) sequence h
+            for (;;) {
+                uint32_t const j = reps ? (uint32_t)first_lane(reps) : nb;
+                uint32_t const m = j - h;                       // new offsets h .. j-1
+                if (m) {
+                    uint32_t const o1 = __builtin_amdgcn_readlane(offv, (int)j - 1);
+                    uint32_t const o2 = m >= 2 ? __builtin_amdgcn_readlane(offv, (int)j - 2) : rep0;
+                    uint32_t const o3 = m >= 3 ? __builtin_amdgcn_readlane(offv, (int)j - 3) : (m == 2 ? rep0 : rep1);
+                    rep0 = o1; rep1 = o2; rep2 = o3;
+                }
+                if (!reps) break;
+                reps &= reps - 1;
                 uint32_t const sj = __builtin_amdgcn_readlane(sel, (int)j);
                 uint32_t off;
-                if (sj == 4) { off = __builtin_amdgcn_readlane(offv, (int)j); rep2 = rep1; rep1 = rep0; rep0 = off; }
-                else if (sj == 0) {
+                if (sj == 0) {
                     uint32_t const z = __builtin_amdgcn_readlane(ll0, (int)j);
                     off = z ? rep1 : rep0; rep1 = z ? rep0 : rep1; rep0 = off;
-                    if (lane == j) offv = off;
                 } else {
                     uint32_t t = sj == 3 ? rep0 - 1 : (sj == 1 ? rep1 : rep2);
                     if (t == 0) t = 0xFFFFFFFFu;               // 0 is invalid: rejected by the offset check below
                     if (sj != 1) rep2 = rep1;
                     rep1 = rep0; rep0 = t; off = t;
-                    if (lane == j) offv = off;
                 }
+                if (lane == j) offv = off;
+                h = j + 1;
             }
         }
         D.rep0 = rep0; D.rep1 = rep1; D.rep2 = rep2;
+        DPROF_L(3);
         // positions: exclusive prefix sums of ll and ll + ml over the batch
         uint32_t incL = ll, incT = ll + ml;
         for (int sft = 1; sft < 64; sft <<= 1) {
@@ -813,7 +856,9 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
         D.litPos += __builtin_amdgcn_readlane(incL, (int)nb - 1);
         D.outPos += __builtin_amdgcn_readlane(incT, (int)nb - 1);
         n += nb;
+        DPROF_L(4);
     }
+    DPROF_LFLUSH(24);
     if (!err && D.done + n == nbSeq && D.Dpos != endD) err = ZHIP_DE_CORRUPT;          // BIT_endOfDStream (:1677)
     D.done += n;
     if (lane == 0) {
@@ -933,17 +978,6 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
         }
     }
 }
-
-// optional phase profile (scripts/prof_decode.py, -DZHIP_PROF builds only): lane 0 of each wave adds s_memtime deltas to g_prof
-#ifdef ZHIP_PROF
-#define DPROF_BEGIN uint64_t dp_t_ = __builtin_amdgcn_s_memtime();
-#define DPROF(slot) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(t_ - dp_t_)); dp_t_ = t_; } while (0)
-#define DPROF_ADD(slot, v) do { if (lane == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(v)); } while (0)
-#else
-#define DPROF_BEGIN
-#define DPROF(slot) do { } while (0)
-#define DPROF_ADD(slot, v) do { } while (0)
-#endif
 
 // ------------------------------------------------------------------ one frame, whole workgroup
 __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t srcLen, uint8_t* out, uint32_t dstCap,
