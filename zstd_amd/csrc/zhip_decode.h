@@ -453,36 +453,50 @@ __device__ inline uint32_t dec_huf_streams(DecShared* S, const uint8_t* src, uin
 // output offset and it decodes once more, storing symbols.  Exactness: same symbols as the serial decoder; the stream is
 // accepted iff the chain ends on bit 0 with exactly the expected number of symbols (BIT_endOfDStream + op == oend).
 #define ZHIP_HUF_RUNIN 192
-struct BitsAt { const uint8_t* base; int32_t ptr; uint64_t acc, stash, pend; int32_t n, half; int32_t pos; };   // pos = bits of the stream below the read point
-__device__ __forceinline__ void ba_init(BitsAt& b, const uint8_t* base, int32_t pos)
+// Bit reader of the parallel decoder.  All lanes reload at the SAME moments (every four symbols), so the wave never runs a
+// refill path for the sake of one lane, and the bytes of reload k+1 are requested at reload k: the next read point is at most
+// 6 bytes below the current one (4 symbols x <= 12 bits), so a 16-byte window that starts 8 bytes below the current chunk
+// always contains the next chunk.  pos = bits of the stream below the read point; bits below the stream's start read as the
+// bytes that precede it (never consumed by a valid stream: its chain ends exactly on bit 0, anything else is rejected).
+struct BitsAt { const uint8_t* base; int32_t pos; int32_t wa; uint64_t wlo, whi; int32_t okLo, okHi; };   // window = 16 bytes at byte offset wa
+__device__ __forceinline__ void ba_window(BitsAt& b, int32_t chunkAt)
 {
-    b.base = base; b.pos = pos; b.half = 0;
-    int32_t const bytes = (pos + 7) >> 3, pad = (8 - (pos & 7)) & 7;
-    b.ptr = bytes;
-    uint64_t const first = br_load(base, b.ptr);
-    b.acc = first << pad; b.n = 64 - pad;
-    b.stash = br_load(base, b.ptr);
-    b.pend = br_load(base, b.ptr);
+    int32_t a = chunkAt - 8; if (a < -8) a = -8;
+    uint64_t v[2];
+    if (a >= b.okLo && a + 16 <= b.okHi) __builtin_memcpy(v, b.base + a, 16);
+    else {                                                      // a window that would leave the frame (tiny streams): byte by byte
+        v[0] = v[1] = 0;
+        for (int i = 0; i < 16; i++) { int32_t const q = a + i; if (q >= b.okLo && q < b.okHi) v[i >> 3] |= (uint64_t)b.base[q] << (8 * (i & 7)); }
+    }
+    b.wa = a; b.wlo = v[0]; b.whi = v[1];
 }
-__device__ __forceinline__ void ba_refill(BitsAt& b)
+// [okLo, okHi) = byte offsets around base that are known to lie inside the frame
+__device__ __forceinline__ void ba_init(BitsAt& b, const uint8_t* base, int32_t pos, int32_t okLo, int32_t okHi)
 {
-    b.acc |= (b.stash >> 32) << (32 - b.n);
-    b.n += 32;
-    b.stash <<= 32;
-    if (b.half) { b.stash = b.pend; b.pend = br_load(b.base, b.ptr); }
-    b.half ^= 1;
+    b.base = base; b.pos = pos; b.okLo = okLo; b.okHi = okHi; ba_window(b, ((pos + 7) >> 3) - 8);
+}
+// the 8-byte chunk that ends at the byte holding bit pos-1, left-aligned on that bit; requests the next window
+__device__ __forceinline__ uint64_t ba_chunk(BitsAt& b)
+{
+    int32_t const top = (b.pos + 7) >> 3, at = top - 8;        // chunk = bytes [at, at + 8)
+    int32_t off = at - b.wa; if (off < 0) off = 0;             // 0..8 (below 0 only once the stream is exhausted)
+    uint32_t const sh = 8u * (uint32_t)off;
+    uint64_t const chunk = sh == 0 ? b.wlo : (sh >= 64 ? b.whi : ((b.wlo >> sh) | (b.whi << (64 - sh))));
+    ba_window(b, at);
+    return chunk << ((uint32_t)(8 * top - b.pos) & 63);
 }
 // decode from b.pos down to (and possibly past) `lo`; returns the number of symbols, leaves the exit position in b.pos
 __device__ __forceinline__ uint32_t huf_run(BitsAt& b, const lds_u16* T, uint32_t sh, int32_t lo)
 {
     uint32_t cnt = 0;
     while (b.pos > lo) {
-        if (b.n <= 32) ba_refill(b);
-        uint32_t e = T[(uint32_t)(b.acc >> sh)];
-        b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8); b.pos -= (int32_t)(e >> 8); cnt++;
-        if (b.pos > lo) {
-            e = T[(uint32_t)(b.acc >> sh)];
-            b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8); b.pos -= (int32_t)(e >> 8); cnt++;
+        uint64_t acc = ba_chunk(b);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t const e = T[(uint32_t)(acc >> sh)];
+            bool const live = b.pos > lo;
+            acc <<= (e >> 8);
+            if (live) { b.pos -= (int32_t)(e >> 8); cnt++; }
         }
     }
     return cnt;
@@ -506,6 +520,7 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
         oOff = seg * grp; oLen = grp < 3 ? seg : litSize - 3 * seg;
     }
     const uint8_t* const base = src + sOff;
+    int32_t const okLo = -(int32_t)sOff - 8, okHi = (int32_t)size - (int32_t)sOff;     // the literal payload and the 8 bytes of headers before it
     bool bad = false; int32_t B = 0;
     if (mine) {
         uint32_t const last = sLen ? base[sLen - 1] : 0;
@@ -519,7 +534,7 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     int32_t exitPos = hi;
     if (on && hi > 0) {
         if (j == 0) exitPos = B;                                // the true start; decoded in step (2)
-        else { int32_t const st = hi + ZHIP_HUF_RUNIN < B ? hi + ZHIP_HUF_RUNIN : B; BitsAt b; ba_init(b, base, st); (void)huf_run(b, T, sh, hi); exitPos = b.pos; }
+        else { int32_t const st = hi + ZHIP_HUF_RUNIN < B ? hi + ZHIP_HUF_RUNIN : B; BitsAt b; ba_init(b, base, st, okLo, okHi); (void)huf_run(b, T, sh, hi); exitPos = b.pos; }
     }
     // after the run-in lane j holds a guess for ITS OWN entry (the chain's first position <= hi); lane 0's is exact
     int32_t entry = exitPos;
@@ -527,7 +542,7 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     bool dirty = on;
     for (int round = 0; round < 20; round++) {
         if (dirty) {
-            if (entry > lo) { BitsAt b; ba_init(b, base, entry); cnt = huf_run(b, T, sh, lo); myExit = b.pos; }
+            if (entry > lo) { BitsAt b; ba_init(b, base, entry, okLo, okHi); cnt = huf_run(b, T, sh, lo); myExit = b.pos; }
             else { cnt = 0; myExit = entry; }
         }
         int32_t const predExit = __shfl(myExit, (int)(lane - 1));
@@ -548,27 +563,23 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     if (__any(bad)) return ZHIP_DE_CORRUPT;
     // (3) output
     if (on && cnt) {
-        BitsAt b; ba_init(b, base, entry);
+        BitsAt b; ba_init(b, base, entry, okLo, okHi);
         uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
         while (i + 4 <= cnt) {
+            uint64_t acc = ba_chunk(b);
             uint32_t w = 0;
-            for (int k = 0; k < 2; k++) {
-                if (b.n <= 32) ba_refill(b);
-                uint32_t e = T[(uint32_t)(b.acc >> sh)];
-                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-                w |= (e & 0xFF) << (16 * k);
-                e = T[(uint32_t)(b.acc >> sh)];
-                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-                w |= (e & 0xFF) << (16 * k + 8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t const e = T[(uint32_t)(acc >> sh)];
+                acc <<= (e >> 8); b.pos -= (int32_t)(e >> 8);
+                w |= (e & 0xFF) << (8 * k);
             }
             __builtin_memcpy(o + i, &w, 4);
             i += 4;
         }
-        for (; i < cnt; i++) {
-            if (b.n <= 32) ba_refill(b);
-            uint32_t const e = T[(uint32_t)(b.acc >> sh)];
-            b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-            o[i] = (uint8_t)e;
+        if (i < cnt) {
+            uint64_t acc = ba_chunk(b);
+            for (; i < cnt; i++) { uint32_t const e = T[(uint32_t)(acc >> sh)]; acc <<= (e >> 8); o[i] = (uint8_t)e; }
         }
     }
     return 0;
