@@ -71,6 +71,66 @@ def cpu_baseline(sample, seconds=8.0, level=1):
             "sample": f"first {len(sample) >> 20} MiB, oracle/zoracle.c single pass"}
 
 
+def cpu_decode_baseline(sample, seconds=6.0, level=1):
+    """the reference's DECODE speed on the host (`zstd -b#` second figure): oracle/_ref/zref_bench dfile"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if not os.path.exists(exe):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _libs import load_oracle, _buf
+        lo = load_oracle()
+        sample = sample[: 32 << 20]
+        cap = lo.zo_compress_bound(UNIT) * (len(sample) // UNIT + 1)
+        comp = np.empty(cap, dtype=np.uint8)
+        r = lo.zo_compress_chunks(level, UNIT, _buf(sample), len(sample), _buf(comp), cap, None, 0)
+        out = np.empty(len(sample), dtype=np.uint8)
+        t0 = time.time()
+        k = lo.zo_decompress(_buf(out), len(out), _buf(comp), r)
+        dt = time.time() - t0
+        assert k == len(sample)
+        return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port", "sample": f"first {len(sample) >> 20} MiB, oracle/zoracle_dec.c single pass"}
+    tmp = "/tmp/zhip_bench_dsample.bin"
+    sample.tofile(tmp)
+    try:
+        one = json.loads(subprocess.check_output([exe, "dfile", str(level), str(UNIT), tmp, str(seconds), "1"], timeout=120))
+        ncores = os.cpu_count() or 1
+        allc = json.loads(subprocess.check_output([exe, "dfile", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
+        return {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference",
+                "sample": f"first {len(sample) >> 20} MiB of the workload compressed at level {level} into {UNIT} B-unit frames, ZSTD_decompressDCtx per frame, best of "
+                          f"{one['runs']} runs (oracle/_ref/zref_bench dfile; the reference is built with ZSTD_DISABLE_ASM, its Huffman loops are the C ones)",
+                "all_cores": {"value": allc["MBps"], "cores": ncores}}
+    finally:
+        os.unlink(tmp)
+
+
+def decode_measure(torch, zstd_amd, local, src, n, dst, sizes, steps, warmup, barrier):
+    """decode the frames in dst (sizes = per-unit compressed sizes) back into a fresh buffer; returns (seconds for `steps` passes,
+    mean k_decode ms, parity flag)"""
+    units = len(sizes)
+    csz = sizes.astype(np.uint64)
+    so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
+    do = np.arange(units, dtype=np.uint64) * UNIT
+    dcap = np.full(units, UNIT, dtype=np.uint64)
+    dcap[-1] = n - (units - 1) * UNIT
+    out = torch.empty(n + 64, dtype=torch.uint8, device=src.device)
+    dctx = zstd_amd.DContext(local)
+
+    def dstep():
+        return dctx.decompress_frames_device(out.data_ptr(), do, dcap, dst.data_ptr(), so, csz)
+    for _ in range(warmup):
+        dstep()
+    barrier()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(steps):
+        r, status, dsz = dstep()
+        kms += dctx.timing()["decode_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(r == n and not status.any() and torch.equal(out[:n], src[:n]))
+    dctx.close()
+    return dt, kms / steps, ok
+
+
 def parity_check(ctx, host, dev_out, total, sizes, level=1):
     """bounded byte-parity vs the oracle + full-size structural properties of the GPU stream"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -206,6 +266,8 @@ def main():
     ap.add_argument("--base-records", type=int, default=50000, help="records: distinct ~1.2 KB records generated on the host before tiling to --mib")
     ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
     ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
+    ap.add_argument("--mode", choices=["compress", "decode"], default="compress",
+                    help="decode: the headline value is the DECODER's throughput on the frames the compressor just made (same workload, same units)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
     args = ap.parse_args()
@@ -299,9 +361,18 @@ def main():
     else:
         total_all = float(total)
 
+    sizes_all = usz.cpu().numpy()
+    ddt, dkms, dok = (None, None, None)
+    if args.mode == "decode" or world == 1:
+        dsteps = args.steps if args.mode == "decode" else max(2, min(args.steps, 4))
+        ddt, dkms, dok = decode_measure(torch, zstd_amd, local, src, n, dst, sizes_all, dsteps, args.warmup if args.mode == "decode" else 1, barrier)
+        if dist is not None:
+            tt = torch.tensor([ddt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ddt = float(tt.item())
     if rank == 0:
         st = ctx.stats()
-        sizes = usz.cpu().numpy()
+        sizes = sizes_all
         K = args.steps
         ms_step = dt / K * 1e3
         parse_ms, ent_ms, gat_ms, tot_ms = kparse / K, kent / K, kgat / K, ktot / K
@@ -357,6 +428,26 @@ def main():
             ctx2.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host, level=args.level)
+        if ddt is not None:
+            dK = args.steps if args.mode == "decode" else max(2, min(args.steps, 4))
+            dbytes = n + int(total)                             # algorithmic bytes of k_decode: the frames in, their content out
+            dec = {"metric": f"decompress_MBps_level{args.level}_{'datagenP50' if args.workload == 'datagen' else args.workload}_128KB_units",
+                   "value": round(world * n / ddt * dK / 1e6, 1), "unit": "MB/s", "steps": dK, "ms_per_step": round(ddt / dK * 1e3, 3),
+                   "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(dbytes / (dkms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(dbytes / (dkms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                                "algorithmic_bytes_per_launch": dbytes, "avg_launch_ms": round(dkms, 3)},
+                   "parity": {"decoded_equals_source_full_size": dok}}
+            if not args.no_cpu_baseline and world == 1:
+                dec["cpu_baseline"] = cpu_decode_baseline(host[: 256 << 20] if n >= (256 << 20) else host, level=args.level)
+            if args.mode == "decode":                           # the decoder is the headline: same contract fields, the compressor's line rides along
+                comp_line = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "ratio", "roofline", "parity") if k in out}
+                out.update({"metric": dec["metric"], "value": dec["value"], "ms_per_step": dec["ms_per_step"], "steps": dK, "roofline": dec["roofline"],
+                            "parity": dec["parity"], "compress": comp_line})
+                if "cpu_baseline" in dec:
+                    out["cpu_baseline"] = dec["cpu_baseline"]
+                out.pop("pipeline", None); out.pop("pipelined", None)
+            else:
+                out["decode"] = dec
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

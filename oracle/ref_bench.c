@@ -9,6 +9,9 @@
  *        thread compresses a disjoint contiguous shard of the chunks with its own CCtx.
  *        prints one JSON line.
  *   zref_bench file   <level> <chunkSize> <path> <seconds> <threads>   : same, input read from a file
+ *   zref_bench dfile  <level> <chunkSize> <path> <seconds> <threads>   : DECODE speed (`zstd -b#` second figure,
+ *        benchzstd.c:380-420): the file is compressed once into one frame per chunk, then ZSTD_decompressDCtx per frame on a
+ *        reused DCtx is timed; threads split the frames.
  *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
  *   zref_bench dict   <level> <dictPath> <recordsPath> <offsetsPath(u64 LE, nRec+1)> <seconds> <threads>
  *        one frame per record with ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the `zstd -b# -D dict` /
@@ -52,6 +55,63 @@ static void* worker(void* p)
 }
 
 static const char* g_file = NULL;
+
+/* decode timing: frames[] laid out at k * bound in dst */
+typedef struct { const char* comp; const size_t* csz; size_t bound; size_t k0, k1; char* out; size_t chunk; size_t n; int err; } ujob_t;
+static void* uworker(void* p)
+{
+    ujob_t* j = (ujob_t*)p;
+    ZSTD_DCtx* d = ZSTD_createDCtx();
+    size_t k;
+    for (k = j->k0; k < j->k1; k++) {
+        size_t const want = (k + 1) * j->chunk <= j->n ? j->chunk : j->n - k * j->chunk;
+        size_t const r = ZSTD_decompressDCtx(d, j->out + k * j->chunk, want, j->comp + k * j->bound, j->csz[k]);
+        if (ZSTD_isError(r) || r != want) { j->err = 1; break; }
+    }
+    ZSTD_freeDCtx(d);
+    return NULL;
+}
+static int dfile_main(char** argv)
+{
+    int const level = atoi(argv[2]); size_t const chunk = strtoull(argv[3], 0, 10); double const seconds = atof(argv[5]);
+    int const T = atoi(argv[6]) > 0 ? atoi(argv[6]) : 1;
+    FILE* f = fopen(argv[4], "rb"); long sz; char* src; char* comp; char* out; size_t* csz; size_t nChunks, bound, k, ctot = 0;
+    ujob_t* jobs; pthread_t* th; double best = 1e30, t0; int runs = 0, t;
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    if (!f) { perror(argv[4]); return 1; }
+    fseek(f, 0, SEEK_END); sz = ftell(f); fseek(f, 0, SEEK_SET);
+    src = (char*)malloc((size_t)sz); out = (char*)malloc((size_t)sz + 64);
+    if (!src || !out || fread(src, 1, (size_t)sz, f) != (size_t)sz) return 1;
+    fclose(f);
+    nChunks = ((size_t)sz + chunk - 1) / chunk; bound = ZSTD_compressBound(chunk);
+    comp = (char*)malloc(bound * nChunks); csz = (size_t*)calloc(nChunks, sizeof(size_t));
+    jobs = (ujob_t*)calloc((size_t)T, sizeof(ujob_t)); th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    if (!comp || !csz || !jobs || !th || !c) return 1;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, level);
+    for (k = 0; k < nChunks; k++) {
+        size_t const len = (k + 1) * chunk <= (size_t)sz ? chunk : (size_t)sz - k * chunk;
+        csz[k] = ZSTD_compress2(c, comp + k * bound, bound, src + k * chunk, len);
+        if (ZSTD_isError(csz[k])) return 1;
+        ctot += csz[k];
+    }
+    ZSTD_freeCCtx(c);
+    t0 = now_s();
+    do {
+        double const a = now_s();
+        for (t = 0; t < T; t++) {
+            jobs[t].comp = comp; jobs[t].csz = csz; jobs[t].bound = bound; jobs[t].k0 = nChunks * (size_t)t / (size_t)T; jobs[t].k1 = nChunks * (size_t)(t + 1) / (size_t)T;
+            jobs[t].out = out; jobs[t].chunk = chunk; jobs[t].n = (size_t)sz; jobs[t].err = 0;
+            if (T == 1) uworker(&jobs[t]); else pthread_create(&th[t], NULL, uworker, &jobs[t]);
+        }
+        for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; }
+        {   double const d = now_s() - a; if (d < best) best = d; }
+        runs++;
+    } while (now_s() - t0 < seconds);
+    if (memcmp(src, out, (size_t)sz)) return 1;
+    printf("{\"level\": %d, \"chunk\": %zu, \"bytes\": %ld, \"csize\": %zu, \"ratio\": %.4f, \"best_s\": %.6f, \"MBps\": %.2f, \"runs\": %d, \"threads\": %d, \"mode\": \"decode\"}\n",
+           level, chunk, sz, ctot, (double)sz / (double)ctot, best, (double)sz / best / 1e6, runs, T);
+    return 0;
+}
 
 typedef struct { const ZSTD_CDict* cd; const char* src; const unsigned long long* offs; size_t r0, r1; char* dst; size_t dstCap; size_t csize; int err; } djob_t;
 static void* dworker(void* p)
@@ -114,6 +174,7 @@ static int dict_main(char** argv)
 int main(int argc, char** argv)
 {
     if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
+    if (argc >= 7 && !strcmp(argv[1], "dfile")) return dfile_main(argv);
     if (argc >= 5 && !strcmp(argv[1], "stream")) {
         RDG_genStdout(strtoull(argv[2], 0, 10), atof(argv[3]) / 100.0, 0.0, (unsigned)atoi(argv[4]));
         return 0;

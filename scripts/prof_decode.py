@@ -11,7 +11,9 @@ LIB = os.path.join(ROOT, "zstd_amd", "libzstd_hip_prof.so")
 def main():
     import torch
     import zstd_amd
-    if os.path.exists(LIB) and not os.environ.get("NOPROF"):
+    if os.environ.get("PROFLIB"):
+        zstd_amd.LIB_PATH = os.path.join(ROOT, "zstd_amd", os.environ["PROFLIB"])
+    elif os.path.exists(LIB) and not os.environ.get("NOPROF"):
         zstd_amd.LIB_PATH = LIB
     L = zstd_amd.lib()
     mib = int(os.environ.get("MIB", "256")); level = int(os.environ.get("LEVEL", "1"))

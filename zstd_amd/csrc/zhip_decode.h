@@ -452,7 +452,9 @@ __device__ inline uint32_t dec_huf_streams(DecShared* S, const uint8_t* src, uin
 // entry is the stream's top, so a fixed point IS the serial decode), (3) a prefix sum of the counts gives each lane its
 // output offset and it decodes once more, storing symbols.  Exactness: same symbols as the serial decoder; the stream is
 // accepted iff the chain ends on bit 0 with exactly the expected number of symbols (BIT_endOfDStream + op == oend).
+#ifndef ZHIP_HUF_RUNIN
 #define ZHIP_HUF_RUNIN 192
+#endif
 // Bit reader of the parallel decoder.  All lanes reload at the SAME moments (every four symbols), so the wave never runs a
 // refill path for the sake of one lane, and the bytes of reload k+1 are requested at reload k: the next read point is at most
 // 6 bytes below the current one (4 symbols x <= 12 bits), so a 16-byte window that starts 8 bytes below the current chunk
