@@ -925,6 +925,24 @@ __device__ __forceinline__ void wave_fill(uint8_t* d, uint32_t byte, uint32_t n)
     for (uint32_t i = 8 * lane; i < full; i += 512) __builtin_memcpy(d + i, &v, 8);
     if (lane < (n & 7)) d[full + lane] = (uint8_t)byte;
 }
+// up to ZHIP_DEC_GROUP disjoint copies (each n >= 8 or n == 0 = unused slot) with every lane's loads of all of them in flight
+// before the first store: one memory round trip for the group instead of one per copy.  The first 512 bytes of each; longer tails follow.
+#define ZHIP_DEC_GROUP 4
+__device__ __forceinline__ void wave_copy_x4(uint8_t* const d[ZHIP_DEC_GROUP], const uint8_t* const s[ZHIP_DEC_GROUP], const uint32_t n[ZHIP_DEC_GROUP])
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint64_t v[ZHIP_DEC_GROUP]; uint32_t o[ZHIP_DEC_GROUP]; bool has[ZHIP_DEC_GROUP];
+#pragma unroll
+    for (int g = 0; g < ZHIP_DEC_GROUP; g++) {
+        has[g] = 8 * lane < n[g];
+        o[g] = has[g] ? (8 * lane + 8 <= n[g] ? 8 * lane : n[g] - 8) : 0;     // the last chunk is re-based to end exactly at n
+        v[g] = has[g] ? ld64(s[g] + o[g]) : 0;
+    }
+#pragma unroll
+    for (int g = 0; g < ZHIP_DEC_GROUP; g++) if (has[g]) __builtin_memcpy(d[g] + o[g], &v[g], 8);
+#pragma unroll
+    for (int g = 0; g < ZHIP_DEC_GROUP; g++) if (n[g] > 512) wave_copy(d[g] + 512, s[g] + 512, n[g] - 512);
+}
 // periodic copy: d[k] = s[k % period], k < n (the overlapping-match case: the period bytes at s already exist)
 __device__ __forceinline__ void wave_copy_periodic(uint8_t* d, const uint8_t* s, uint32_t period, uint32_t n)
 {
@@ -955,9 +973,20 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
         if (ll && ll <= 64) { if (L.mode == 2) lane_fill(out + r.outPos, L.byte, ll); else lane_copy(out + r.outPos, L.p + r.litPos, ll); }
         unsigned long long longs = __ballot(ll > 64);
         while (longs) {
-            int const j = first_lane(longs); longs &= longs - 1;
-            uint32_t const o = __builtin_amdgcn_readlane(r.outPos, j), lp = __builtin_amdgcn_readlane(r.litPos, j), n = __builtin_amdgcn_readlane(ll, j);
-            if (L.mode == 2) wave_fill(out + o, L.byte, n); else wave_copy(out + o, L.p + lp, n);
+            if (L.mode == 2) {
+                int const j = first_lane(longs); longs &= longs - 1;
+                wave_fill(out + __builtin_amdgcn_readlane(r.outPos, j), L.byte, __builtin_amdgcn_readlane(ll, j));
+                continue;
+            }
+            uint8_t* d4[ZHIP_DEC_GROUP]; const uint8_t* s4[ZHIP_DEC_GROUP]; uint32_t n4[ZHIP_DEC_GROUP];
+#pragma unroll
+            for (int g = 0; g < ZHIP_DEC_GROUP; g++) {
+                if (longs) {
+                    int const j = first_lane(longs); longs &= longs - 1;
+                    d4[g] = out + __builtin_amdgcn_readlane(r.outPos, j); s4[g] = L.p + __builtin_amdgcn_readlane(r.litPos, j); n4[g] = __builtin_amdgcn_readlane(ll, j);
+                } else { d4[g] = out; s4[g] = L.p; n4[g] = 0; }
+            }
+            wave_copy_x4(d4, s4, n4);
         }
         __threadfence_block();                                  // the batch's literals and everything before the batch are readable
         uint32_t const o = r.outPos + ll, off = r.off, ml = r.ml;           // my match: out[o .. o+ml) = virtual[o-off ..]
@@ -972,7 +1001,20 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
             uint32_t const limit = __builtin_amdgcn_readlane(o, f);
             bool const ready = ((pending >> lane) & 1) && ((int)lane == f || srcEnd <= limit);
             if (ready && simple) lane_copy(out + o, out + o - off, ml);
-            unsigned long long coop = __ballot(ready && !simple);
+            unsigned long long plain = __ballot(ready && !simple && !inDict && off >= ml);     // long, not periodic, inside the frame
+            unsigned long long coop = __ballot(ready && !simple) & ~plain;
+            while (plain) {
+                uint8_t* d4[ZHIP_DEC_GROUP]; const uint8_t* s4[ZHIP_DEC_GROUP]; uint32_t n4[ZHIP_DEC_GROUP];
+#pragma unroll
+                for (int g = 0; g < ZHIP_DEC_GROUP; g++) {
+                    if (plain) {
+                        int const j = first_lane(plain); plain &= plain - 1;
+                        uint32_t const oj = __builtin_amdgcn_readlane(o, j), offj = __builtin_amdgcn_readlane(off, j);
+                        d4[g] = out + oj; s4[g] = out + oj - offj; n4[g] = __builtin_amdgcn_readlane(ml, j);
+                    } else { d4[g] = out; s4[g] = out; n4[g] = 0; }
+                }
+                wave_copy_x4(d4, s4, n4);
+            }
             while (coop) {
                 int const j = first_lane(coop); coop &= coop - 1;
                 uint32_t const oj = __builtin_amdgcn_readlane(o, j), offj = __builtin_amdgcn_readlane(off, j), mlj = __builtin_amdgcn_readlane(ml, j);

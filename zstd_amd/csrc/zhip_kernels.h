@@ -276,7 +276,10 @@ k_offsets(const uint32_t* __restrict__ outSize, uint32_t nUnits, uint64_t* __res
 
 // Decoder: persistent 128-thread workgroups, each takes frames from a queue (counter) until it is empty; per workgroup a
 // literal buffer and two hand-over buffers of sequence records in HBM/L2.  Dynamic LDS = sizeof(DecShared).
-__global__ void __launch_bounds__(ZHIP_DEC_THREADS)
+#ifndef ZHIP_DEC_WAVES_PER_EU
+#define ZHIP_DEC_WAVES_PER_EU 3          /* 6 workgroups per CU = what the 25 KB of LDS per workgroup allow; keeps the register allocator at <= 168 VGPRs */
+#endif
+__global__ void __launch_bounds__(ZHIP_DEC_THREADS) __attribute__((amdgpu_waves_per_eu(ZHIP_DEC_WAVES_PER_EU, ZHIP_DEC_WAVES_PER_EU)))
 k_decode(const uint8_t* __restrict__ src, const ZhipDFrame* __restrict__ frames, uint32_t nFrames, uint8_t* __restrict__ dst,
          uint8_t* __restrict__ litArena, ZhipDSeq* __restrict__ recArena, uint32_t* __restrict__ counter,
          ZhipDDictDev dict, const uint64_t* __restrict__ defTabs, ZhipDResult* __restrict__ results)
