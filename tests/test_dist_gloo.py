@@ -29,9 +29,19 @@ def _worker(rank, world, port, n, q):
         return dst[:r].tobytes(), sizes
 
     stream, sizes = shard.compress_sharded(data, oracle_compress, dist, 1, 131072)
+    want, wsizes = oracle_compress(data, 1, 131072)
+
+    # the decode direction: frames are sharded the same way (frame ranges per rank, ordered gather of the contents);
+    # frame walking is the product's host code (zhip_find_frames), the per-rank decoder a test double (the oracle)
+    def oracle_decompress(buf):
+        buf = np.frombuffer(bytes(buf), dtype=np.uint8)
+        out = np.empty(n + 64, dtype=np.uint8)
+        r = lo.zo_decompress(_buf(out), len(out), _buf(buf), len(buf))
+        assert r != ERR
+        return out[:r].tobytes()
+    content = shard.decompress_sharded(want, oracle_decompress, dist)
     if rank == 0:
-        want, wsizes = oracle_compress(data, 1, 131072)
-        q.put((stream == want, bool(np.array_equal(sizes, wsizes)), len(stream)))
+        q.put((stream == want and content == data.tobytes(), bool(np.array_equal(sizes, wsizes)), len(stream)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -132,3 +132,38 @@ def test_seek_table_bytes_match_the_reference_writer(zlib_):
             k = lr.zref_seek_table(_buf(ref), len(ref), _buf(cs), _buf(ds), _buf(ck) if with_ck else None, n)
             assert k != ERR and r == k == L.zhip_seek_table_bound(n, int(with_ck))
             assert mine[:r].tobytes() == ref[:k].tobytes(), (n, with_ck)
+
+
+def test_frame_walker_matches_the_oracle(zlib_):
+    """zhip_find_frames / zhip_frame_compressed_size (host code of the decoder) against oracle/zoracle_dec.c's zo_frame_info"""
+    lo = load_oracle()
+    from _libs import datagen, text_like
+    parts = [datagen(lo, 300000, 50, 1), text_like(5000, 2), np.zeros(0, dtype=np.uint8), text_like(131072, 3)]
+    stream = b""
+    want = []
+    for i, a in enumerate(parts):
+        n = len(a)
+        cap = lo.zo_compress_bound(131072) * (n // 131072 + 1) + 64
+        dst = np.empty(cap, dtype=np.uint8)
+        r = lo.zo_compress_chunks(1 + 2 * (i & 1), 131072, _buf(a) if n else None, n, _buf(dst), cap, None, 0)
+        assert r != ERR
+        pos = 0
+        while pos < r:
+            cs, ds = C.c_size_t(0), C.c_ulonglong(0)
+            assert lo.zo_frame_info(_buf(dst[pos:r]), r - pos, C.byref(cs), C.byref(ds)) == 0
+            want.append((len(stream) + pos, cs.value, ds.value)); pos += cs.value
+        stream += dst[:r].tobytes()
+        if i == 1:
+            stream += b"\x50\x2a\x4d\x18\x04\x00\x00\x00skip"           # a skippable frame between two frames
+    fr = zlib_.find_frames(stream)
+    got = list(zip(fr["src_off"].tolist(), fr["src_size"].tolist(), fr["content"].tolist()))
+    assert got == want and (fr["bound"] >= fr["content"]).all()
+    L = zlib_.lib()
+    L.zhip_frame_compressed_size.restype = C.c_size_t
+    L.zhip_frame_compressed_size.argtypes = [C.c_void_p, C.c_size_t]
+    b = np.frombuffer(stream, dtype=np.uint8)
+    assert L.zhip_frame_compressed_size(_buf(b), len(b)) == want[0][1]
+    with pytest.raises(zlib_.ZhipError):
+        zlib_.find_frames(stream + b"\x00")                               # trailing garbage: srcSize_wrong
+    with pytest.raises(zlib_.ZhipError):
+        zlib_.find_frames(stream[:-3])                                     # truncated last frame

@@ -37,3 +37,27 @@ def compress_sharded(data, compress_fn, dist=None, level=1, unit_size=UNIT):
     if rank != 0:
         return None, None
     return b"".join(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+
+
+def decompress_sharded(stream, decompress_fn, dist=None, find_frames_fn=None):
+    """Every rank holds the whole host stream of concatenated frames; frames are independent work items, so rank r decodes the
+    contiguous frame range unit_range(nFrames, world, r) with decompress_fn(bytes_like) -> bytes and rank 0 concatenates the
+    contents in frame order (no data-path collective).  find_frames_fn(stream) -> dict with 'src_off', 'src_size' (uint64
+    arrays) — zstd_amd.find_frames by default.  Rank 0 returns the content; other ranks None."""
+    if find_frames_fn is None:
+        from zstd_amd import find_frames as find_frames_fn
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    fr = find_frames_fn(stream)
+    n = len(fr["src_off"])
+    lo, hi = unit_range(n, world, rank)
+    if hi > lo:
+        b0 = int(fr["src_off"][lo]); b1 = int(fr["src_off"][hi - 1] + fr["src_size"][hi - 1])
+        part = decompress_fn(stream[b0:b1])
+    else:
+        part = b""
+    if dist is None or world == 1:
+        return part
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(part, parts, dst=0)
+    return b"".join(parts) if rank == 0 else None
