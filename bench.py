@@ -248,6 +248,22 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
                 out["cpu_baseline"] = {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
                                        "sample": f"the {base_n} distinct records, same dictionary, ZSTD_createCDict + refCDict + compress2 per record (oracle/_ref/zref_bench dict)",
                                        "all_cores": {"value": allc["MBps"], "cores": nc}}
+        if world == 1:                                          # the way back: every record frame decoded with the dictionary (ZSTD_decompress_usingDDict per record)
+            dd = zstd_amd.DDict(dict_, device=local)
+            dctx = zstd_amd.DContext(local)
+            csz = sizes.astype(np.uint64)
+            so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
+            rsz = np.diff(all_offs).astype(np.uint64)
+            back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+            best = 1e9
+            for _ in range(3):
+                r, status, dsz = dctx.decompress_frames_device(back.data_ptr(), all_offs[:-1], rsz, dst.data_ptr(), so, csz, ddict=dd)
+                best = min(best, dctx.timing()["decode_ms"])
+            okd = bool(r == n and not status.any() and torch.equal(back[:n], src[:n]))
+            out["decode"] = {"metric": "decompress_MBps_records_with_dictionary", "value": round(n / best / 1e3, 1), "unit": "MB/s", "k_decode_ms": round(best, 3),
+                             "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
+                             "parity": {"decoded_equals_source_full_size": okd}}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

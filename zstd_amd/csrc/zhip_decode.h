@@ -184,6 +184,7 @@ struct DecShared {
     uint32_t frame;                  // queue ticket
     uint32_t status;                 // first error of the frame
     uint32_t hufLog, hufValid, fseValid;
+    uint32_t dictHufIn, dictFseIn;   // the tables in LDS are still the dictionary's (survives from frame to frame of one launch)
     uint32_t log[3];
     uint32_t rep[3];
     uint32_t litSize, litMode, litByte, litSecSize;   // litMode 0: decoded into the literal buffer, 1: raw (in the source), 2: RLE
@@ -290,8 +291,8 @@ __device__ inline LitHeader dec_lit_header(const uint8_t* ip, uint32_t size, uin
         if (h.litSize > blockMax || (!h.single && h.litSize < 6) || h.cSize + h.lh > size) h.err = ZHIP_DE_CORRUPT;
     } else {
         if (sf == 0 || sf == 2) { h.lh = 1; h.litSize = b0 >> 3; }
-        else if (sf == 1) { h.lh = 2; h.litSize = (ld32(ip) & 0xFFFF) >> 4; }
-        else { h.lh = 3; if (size < 3) { h.err = ZHIP_DE_CORRUPT; return h; } h.litSize = (ld32(ip) & 0xFFFFFF) >> 4; }
+        else if (sf == 1) { h.lh = 2; h.litSize = (b0 | ((uint32_t)ip[1] << 8)) >> 4; }               // byte loads: the block may end right here
+        else { h.lh = 3; if (size < 3) { h.err = ZHIP_DE_CORRUPT; return h; } h.litSize = (b0 | ((uint32_t)ip[1] << 8) | ((uint32_t)ip[2] << 16)) >> 4; }
         h.cSize = h.type == 0 ? h.litSize : 1;
         if (h.litSize > blockMax || h.lh + h.cSize > size) h.err = ZHIP_DE_CORRUPT;
     }
@@ -386,7 +387,7 @@ __device__ inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint3
         for (uint32_t k = lane; k < len; k += 64) S->huf[st + k] = e;
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { S->hufLog = tableLog; S->hufValid = 1; }
+    if (lane == 0) { S->hufLog = tableLog; S->hufValid = 1; S->dictHufIn = 0; }
     __builtin_amdgcn_wave_barrier();
     return consumed;
 }
@@ -707,6 +708,7 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
             for (uint32_t i = lane; i < n; i += 64) dec_tab(S, (uint32_t)k)[i] = src[i];
         }
     }
+    if (lane < 3 && myHdr) S->dictFseIn = 0;
     if (lane < 3) {
         if (myHdr == 1) fse_d_build(dec_tab(S, lane), S->symOf[lane], S->next[lane], S->norm[lane], myMax, (int)lane, myLog);
         else if (myHdr == 2) { uint32_t base, bits; dec_base_bits((int)lane, myRle, &base, &bits); dec_tab(S, lane)[0] = fse_d_pack(0, bits, 0, base); }
@@ -721,7 +723,11 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
     if (lastByte == 0) return ZHIP_DE_CORRUPT;                  // no end mark (bitstream.h:284)
     D.base = seq + pos; D.size = bsz;
     D.wLoaded = ZHIP_DEC_RING_WORDS;
-    seq_ring_fill(S, D, 0, ZHIP_DEC_RING_WORDS);
+    {   // short streams (small frames) need only their own words; what lies beyond the stream's start reads as zero anyway, but
+        // the first batch may look 3 words past its last bit, so round up generously to whole 64-word steps
+        uint32_t const need = (((bsz + 3) >> 2) + 4 + 63) & ~63u;
+        seq_ring_fill(S, D, 0, need < ZHIP_DEC_RING_WORDS ? need : ZHIP_DEC_RING_WORDS);
+    }
     __builtin_amdgcn_wave_barrier();
     {   const lds_u32* const R = (const lds_u32*)(uintptr_t)S->ring;
         uint32_t const l0 = S->log[0], l1 = S->log[1], l2 = S->log[2];
@@ -1049,9 +1055,12 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         S->status = err; S->hufValid = 0; S->fseValid = 0; S->rep[0] = 1; S->rep[1] = 4; S->rep[2] = 8;
         if (dict && dict->hasEntropy) { S->hufValid = 1; S->fseValid = 1; S->hufLog = dict->hufLog; for (int k = 0; k < 3; k++) { S->log[k] = dict->log[k]; S->rep[k] = dict->rep[k]; } }
     }
-    if (dict && dict->hasEntropy) {
-        for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
-        for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
+    if (dict && dict->hasEntropy) {                            // the dictionary's tables, unless the previous frame left them untouched
+        bool const needHuf = !S->dictHufIn, needFse = !S->dictFseIn;
+        __syncthreads();
+        if (needHuf) for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
+        if (needFse) for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
+        if (tid == 0) { S->dictHufIn = 1; S->dictFseIn = 1; }
     }
     __syncthreads();
     DPROF(wave ? 16 : 0);                                       // frame setup

@@ -288,6 +288,7 @@ k_decode(const uint8_t* __restrict__ src, const ZhipDFrame* __restrict__ frames,
     DecShared* const S = (DecShared*)smem;
     uint8_t* const litBuf = litArena + (size_t)blockIdx.x * ZHIP_DEC_LIT_STRIDE;
     ZhipDSeq* const recBuf = recArena + (size_t)blockIdx.x * 2 * (ZHIP_DEC_CHUNK + 1);
+    if (threadIdx.x == 0) { S->dictHufIn = 0; S->dictFseIn = 0; }
     for (;;) {
         if (threadIdx.x == 0) S->frame = atomicAdd(counter, 1u);
         __syncthreads();
