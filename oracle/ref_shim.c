@@ -204,6 +204,22 @@ size_t zref_compress_frame(int level, const void* src, size_t n, void* dst, size
     return ZSTD_isError(r) ? (size_t)-1 : r;
 }
 
+/* one frame with chosen frame parameters: contentSizeFlag (0 = the header does not state the size, what streaming without a
+ * pledged size emits), checksumFlag, windowLog (0 = level default) — for the decoder tests */
+size_t zref_compress_frame_params(int level, int contentSizeFlag, int checksumFlag, int windowLog, const void* src, size_t n, void* dst, size_t dstCap)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_contentSizeFlag, contentSizeFlag);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, checksumFlag);
+    if (windowLog) ZSTD_CCtx_setParameter(c, ZSTD_c_windowLog, windowLog);
+    r = ZSTD_compress2(c, dst, dstCap, src, n);
+    ZSTD_freeCCtx(c);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
 /* O2: sequences of ONE unit (n <= 128 KB) from the internal block compressor. out = 4 u32 per sequence
  * {offset, litLength, matchLength, rep}; block delimiter {0,lastLits,0,0} included. */
 size_t zref_sequences(int level, const void* src, size_t n, unsigned* out, size_t capSeqs)

@@ -95,6 +95,9 @@ def load_ref():
     lib.zref_compress_records_cdict.restype = C.c_size_t
     lib.zref_compress_records_cdict.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(lib, "zref_compress_frame_params"):
+        lib.zref_compress_frame_params.restype = C.c_size_t
+        lib.zref_compress_frame_params.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.zref_decompressed_size.restype = C.c_ulonglong
     lib.zref_decompressed_size.argtypes = [C.c_void_p, C.c_size_t]
     lib.zref_compress_bound.restype = C.c_size_t

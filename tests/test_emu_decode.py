@@ -149,3 +149,20 @@ def test_dictionary_frames_on_the_emulator(libs):
         if dict_ is zd:                                        # the frames name their dictionary: decoding without it is refused
             st, _, _ = emu_decode(le, frames[:1], [4096])[0]
             assert st == 32
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_frame_parameter_variants_on_the_emulator(libs):
+    """no content size in the header, small windows (hundreds of small blocks per frame), checksums"""
+    lo, le = libs
+    lr = load_ref()
+    if not hasattr(lr, "zref_compress_frame_params"):
+        pytest.skip("oracle/_ref predates zref_compress_frame_params")
+    from test_oracle_decode import ref_frame_params
+    frames, want = [], []
+    for a, level in ((text_like(150000, 2), 3), (datagen(lo, 90000, 50, 3), 1), (np.zeros(70000, np.uint8), 3), (text_like(3, 5), 1)):
+        for cs, ck, wl in ((0, 0, 0), (0, 1, 0), (1, 1, 10), (0, 1, 12), (1, 0, 16)):
+            frames.append(ref_frame_params(lr, a, level, cs, ck, wl)); want.append(a.tobytes())
+    got = emu_decode(le, frames, [len(w) + 5 for w in want], groups=4)
+    for (st, data, res), w in zip(got, want):
+        assert st == 0 and data == w

@@ -173,3 +173,22 @@ def test_shim_decompress(env):
     assert k == len(a) and (out == a).all()
     k = shim.ZSTD_decompress(_buf(out), len(a) - 1, _buf(dst), r)          # dstSize_tooSmall
     assert shim.ZSTD_isError(k) and (1 << 64) - k == 70
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (travels to the GPU box as a binary)")
+def test_frames_without_content_size_small_windows_checksums(env):
+    """zhip_decompress on frames whose header does not state the content size (decoded into bound-sized slots, then packed),
+    small windows, checksums — alone and as a stream of several such frames"""
+    z, lo, dctx, _ = env
+    lr = load_ref()
+    if not hasattr(lr, "zref_compress_frame_params"):
+        pytest.skip("oracle/_ref predates zref_compress_frame_params")
+    from test_oracle_decode import ref_frame_params
+    cases = [(text_like(500000, 2), 3), (datagen(lo, 300000, 50, 3), 1), (text_like(40000, 4), 9), (np.zeros(200000, np.uint8), 3), (text_like(3, 5), 1)]
+    stream, want = b"", b""
+    for a, level in cases:
+        for cs, ck, wl in ((0, 0, 0), (0, 1, 0), (1, 1, 10), (0, 1, 12), (1, 0, 16), (0, 0, 27)):
+            f = ref_frame_params(lr, a, level, cs, ck, wl)
+            assert dctx.decompress(f) == a.tobytes(), (len(a), level, cs, ck, wl)
+            stream += f; want += a.tobytes()
+    assert dctx.decompress(stream) == want

@@ -158,3 +158,29 @@ def test_corrupted_frames_agree_with_reference(lo):
                 assert want == got
                 agree_ok += 1
     assert agree_err > 500 and agree_ok > 20 and lenient < agree_err // 3, (agree_err, agree_ok, lenient)
+
+
+def ref_frame_params(lr, a, level, content_size=1, checksum=0, window_log=0):
+    cap = int(lr.zref_compress_bound(len(a))) + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    r = lr.zref_compress_frame_params(level, content_size, checksum, window_log, _buf(a), len(a), _buf(dst), cap)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_frames_without_content_size_small_windows_checksums(lo):
+    """frame-parameter variants of the real reference: no content size in the header (window descriptor instead), windows smaller
+    than the content (blocks of windowSize bytes, offsets up to the window), checksum on — all decode like the reference"""
+    lr = load_ref()
+    if not hasattr(lr, "zref_compress_frame_params"):
+        pytest.skip("oracle/_ref predates zref_compress_frame_params")
+    cases = [(text_like(500000, 2), 3), (datagen(lo, 300000, 50, 3), 1), (text_like(40000, 4), 9), (np.zeros(200000, np.uint8), 3), (text_like(3, 5), 1)]
+    for a, level in cases:
+        for cs, ck, wl in ((0, 0, 0), (0, 1, 0), (1, 1, 10), (0, 1, 12), (1, 0, 16), (0, 0, 27)):
+            z = ref_frame_params(lr, a, level, cs, ck, wl)
+            assert oracle_decompress(lo, z, len(a) + 8) == a.tobytes(), (len(a), level, cs, ck, wl)
+            cs_, ds_ = C.c_size_t(0), C.c_ulonglong(0)
+            zb = np.frombuffer(z, dtype=np.uint8)
+            assert lo.zo_frame_info(_buf(zb), len(zb), C.byref(cs_), C.byref(ds_)) == 0 and cs_.value == len(z)
+            assert ds_.value == (len(a) if cs else 2**64 - 1)
