@@ -95,12 +95,14 @@ size_t       zhip_compress_seekable(zhip_ctx* ctx, void* dst, size_t dstCapacity
 /* ---- dictionary compression of many small records (BASELINE configs[4]): what
  *      cdict = ZSTD_createCDict(dict, dictSize, level);                      lib/zstd.h:1006
  *      ZSTD_CCtx_refCDict(cctx, cdict); ZSTD_compress2(cctx, ..record..)     lib/zstd.h:1180, :603    per record
- * produces — one frame per record, byte-identical — for records up to the reference's attach cut-off (8 KB for strategy
- * fast, 16 KB for dfast: lib/compress/zstd_compress.c:2289-2315).  The CDict's tables are built once on the host exactly
- * like ZSTD_createCDict builds them (zstd_fast.c:16-49, zstd_double_fast.c:18-54) and uploaded.
+ * produces — one frame per record, byte-identical.  Records up to the reference's attach cut-off (8 KB for strategy fast,
+ * 16 KB for dfast: lib/compress/zstd_compress.c:2289-2315) take its ATTACH mode (zstd_fast.c:483-678,
+ * zstd_double_fast.c:328-547); larger ones, up to 128 KB, its COPY mode: private copies of the CDict's tables and the
+ * extDict block compressors (zstd_compress.c:2395-2470, zstd_fast.c:709-960, zstd_double_fast.c:551-759), one source per GPU
+ * lane.  The CDict's tables are built once on the host exactly like ZSTD_createCDict builds them (zstd_fast.c:16-49,
+ * zstd_double_fast.c:18-54) and uploaded.
  * Raw-content and ZDICT-format dictionaries (entropy tables, repcodes, dictID: zstd_compress.c:4986-5118); levels whose
- * CDict row is strategy fast or dfast (levels -N..4; zstd_fast.c:483-678, zstd_double_fast.c:328-547).  Lazy-strategy
- * dictionaries and records above the attach cut-off (the reference's copy / extDict path) return NULL /
+ * CDict row is strategy fast or dfast (levels -N..4).  Lazy-strategy dictionaries return NULL, records above 128 KB
  * parameter_unsupported — there is no CPU fallback. */
 typedef struct zhip_cdict_s zhip_cdict;
 zhip_cdict*  zhip_create_cdict(int device, const void* dict, size_t dictSize, int level);

@@ -40,8 +40,9 @@ size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t
 size_t      ZSTD_compressBound(size_t srcSize);                                                    /* :236 (here: the bound of the frame-per-unit stream, >= the reference's) */
 unsigned    ZSTD_isError(size_t code);                                                             /* :243 */
 const char* ZSTD_getErrorName(size_t code);                                                        /* :244 */
-/* dictionaries: raw-content and ZDICT-format, CDict levels whose row is fast/dfast, sources up to the reference's attach
- * cut-off (8 KB fast / 16 KB dfast) — byte-identical to the reference; anything else -> NULL / parameter_unsupported */
+/* dictionaries: raw-content and ZDICT-format, CDict levels whose row is fast/dfast, sources up to 128 KB (attach mode below
+ * the reference's cut-off of 8 KB fast / 16 KB dfast, copy mode above it) — byte-identical to the reference; anything else ->
+ * NULL / parameter_unsupported */
 ZSTD_CDict* ZSTD_createCDict(const void* dictBuffer, size_t dictSize, int compressionLevel);       /* :979 */
 size_t      ZSTD_freeCDict(ZSTD_CDict* CDict);                                                     /* :985 */
 size_t      ZSTD_CCtx_refCDict(ZSTD_CCtx* cctx, const ZSTD_CDict* cdict);                          /* :1102 */

@@ -68,12 +68,15 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
     if (e) return e;
     if (cd.len == 0) return 9;
     uint32_t mh = 6, mc = 6;
+    std::vector<uint32_t> extIdx;
     for (uint32_t i = 0; i < nRec; i++) {
         zhip::CParams cp; size_t const n = (size_t)(offsets[i + 1] - offsets[i]);
-        if (!zhip::host_cdict_unit_params(cd, n, &cp)) return -1;
+        bool const copyMode = zhip::host_cdict_is_copy_mode(cd, n);
+        if (!(copyMode ? zhip::host_cdict_copy_params(cd, n, &cp) : zhip::host_cdict_unit_params(cd, n, &cp))) return -1;
         ZhipUnit& u = unitsOut[i];
         u.srcOff = offsets[i]; u.srcLen = (uint32_t)n; u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
-        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog; u.litMode = 0; u.pad0 = 0; u.targetLength = cp.targetLength;
+        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog; u.litMode = 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength;
+        if (copyMode) { extIdx.push_back(i); continue; }
         if (cp.hashLog > mh) mh = cp.hashLog;
         if (cp.chainLog > mc) mc = cp.chainLog;
     }
@@ -82,8 +85,20 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
     dv.strategy = cd.cp.strategy; dv.tabL = cd.tabL.data(); dv.tabS = cd.tabS.data(); dv.rep[0] = cd.rep[0]; dv.rep[1] = cd.rep[1]; dv.rep[2] = cd.rep[2]; dv.dictID = cd.dictID;
     std::vector<ZhipSlot> const sv = fixed_slots(nRec); const ZhipSlot* const slots = sv.data();
     const ZhipUnit* units = unitsOut;
-    simt::launch({nRec, 1, 1}, {64, 1, 1}, cd.cp.strategy == 1 ? zhip::dict_fast_lds_bytes(mh) : zhip::dict_lds_bytes(mh, mc),
-                 [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
+    if (extIdx.size() < nRec)
+        simt::launch({nRec, 1, 1}, {64, 1, 1}, cd.cp.strategy == 1 ? zhip::dict_fast_lds_bytes(mh) : zhip::dict_lds_bytes(mh, mc),
+                     [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
+    if (!extIdx.empty()) {                                     // copy mode (sources above the attach cut-off), like the host library launches it
+        uint32_t const nExt = (uint32_t)extIdx.size();
+        size_t stride = zhip::ext_table_words(cd.cp.hashLog, cd.cp.chainLog, cd.cp.strategy); stride = (stride + 3) & ~(size_t)3;
+        std::vector<uint32_t> tabs((size_t)nExt * stride, 0xEEEEEEEEu);
+        uint32_t* const tp = tabs.data(); const uint32_t* const ip = extIdx.data();
+        uint32_t const wordsL = 1u << cd.cp.hashLog, wordsS = cd.cp.strategy == 2 ? 1u << cd.cp.chainLog : 0u;
+        const uint32_t* const tl = cd.tabL.data(); const uint32_t* const ts = cd.tabS.data();
+        simt::launch({8, nExt, 1}, {256, 1, 1}, 0, [=] { zhip::k_ext_init(tl, ts, wordsL, wordsS, tp, stride); }, osThreads);
+        simt::launch({(nExt + 63) / 64, 1, 1}, {64, 1, 1}, 0,
+                     [=] { zhip::k_parse_ext(src, units, slots, ip, nExt, dv, tp, stride, seqs, lits, metas); }, osThreads);
+    }
     return 0;
 }
 

@@ -139,7 +139,8 @@ def test_dict_records_parse_like_the_oracle(libs):
         corpus = text_like(200000, 3) if kind == "text" else datagen(lo, 200000, 60, 3)
         dict_ = corpus[:110000 if level in (3, 1) else 60000].copy()
         recs = []
-        for n in ((8, 9, 10, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 16384, 12000, 300, 64) if level >= 3 else (8, 9, 10, 12, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 8192, 300, 64)):
+        # sizes above the attach cut-off (16 KB dfast / 8 KB fast) take the reference's COPY mode: k_ext_init + k_parse_ext
+        for n in ((8, 9, 10, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 16384, 12000, 300, 64, 16385, 20000, 50000, 131072) if level >= 3 else (8, 9, 10, 12, 17, 100, 500, 1000, 1024, 1500, 4000, 8000, 8192, 300, 64, 8193, 9000, 40000, 131072)):
             s = int(rng.integers(0, len(corpus) - n))
             r = corpus[s:s + n].copy()
             if n > 50:
@@ -148,6 +149,7 @@ def test_dict_records_parse_like_the_oracle(libs):
             recs.append(r)
         recs.append(dict_[-300:].copy())                 # ends exactly like the dictionary: matches that run off its end
         recs.append(np.concatenate([dict_[-40:], dict_[:200], dict_[-40:]]))
+        recs.append(np.concatenate([dict_[-9000:], dict_[:9000], dict_[-40:]]))          # copy mode: 2-segment matches off the dictionary's end
         offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
         src = np.concatenate(recs + [np.zeros(16, np.uint8)])
         nrec = len(recs)

@@ -135,4 +135,32 @@ def test_unsupported_dictionaries_are_errors(env):
     cd = zstd_amd.CDict(text_like(50000, 1), level=3)
     ctx = zstd_amd.Context(0, max_units=4, records_total_bytes=100000)
     with pytest.raises(zstd_amd.ZhipError):
-        ctx.compress_records(cd, [text_like(20000, 2)])      # above the 16 KB attach cut-off: the reference copies the dictionary
+        ctx.compress_records(cd, [text_like(140000, 2)])     # above 128 KB: not a single-block frame
+
+
+@pytest.mark.parametrize("kind,level,dsize", [("text", 3, 110000), ("datagen", 3, 40000), ("text", 1, 110000), ("text", 4, 60000), ("text", -1, 20000), ("text", 3, 5)])
+def test_copy_mode_sources_match_oracle_bytes(env, kind, level, dsize):
+    """sources above the attach cut-off (8 KB for a strategy-fast CDict, 16 KB for dfast): the reference copies the dictionary's
+    tables and runs its extDict block compressors; k_ext_init + k_parse_ext do the same, mixed with attach-mode records in one call"""
+    lo, zstd_amd, torch = env
+    rng = np.random.default_rng(abs(level) * 131 + dsize % 89)
+    corpus = text_like(400000, 5) if kind == "text" else datagen(lo, 400000, 60, 5)
+    dict_ = corpus[:dsize].copy()
+    sizes = [8193, 9000, 16385, 20000, 50000, 100000, 131072, 500, 16384, 8192, 70000] + [int(x) for x in rng.integers(8193, 60000, size=40)]
+    recs = records_of(corpus, rng, sizes)
+    if dsize > 20000:
+        recs.append(np.concatenate([dict_[-9000:], dict_[:9000], dict_[-40:]]))      # runs off the dictionary's end into the source
+    recs.append(np.zeros(30000, np.uint8))
+    recs.append(rng.integers(0, 256, size=20000, dtype=np.uint8))
+    ctx = zstd_amd.Context(0, max_units=len(recs), records_total_bytes=sum(len(r) for r in recs))
+    cd = zstd_amd.CDict(dict_, level=level)
+    got, fs = ctx.compress_records(cd, recs, return_sizes=True)
+    want = oracle_frames(lo, dict_, recs, level)
+    pos = 0
+    for i, (r, w) in enumerate(zip(recs, want)):
+        g = got[pos:pos + int(fs[i])]
+        pos += int(fs[i])
+        assert g == w, (kind, level, dsize, i, len(r), len(g), len(w))
+    assert pos == len(got)
+    dd = zstd_amd.DDict(dict_)
+    assert zstd_amd.DContext(0).decompress(got, ddict=dd) == b"".join(r.tobytes() for r in recs)

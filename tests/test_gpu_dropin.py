@@ -170,7 +170,14 @@ def test_cdict_entry_points_match_the_reference(env):
         assert dst[:k].tobytes() == want[:w].tobytes(), i
     big = np.concatenate(recs)[:30000]
     dst = np.zeros(S.ZSTD_compressBound(len(big)), dtype=np.uint8)
-    k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))       # above the attach cut-off: no copy path on device
+    k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))       # above the attach cut-off: the dictionary's copy mode
+    assert not S.ZSTD_isError(k), S.ZSTD_getErrorName(k)
+    want = np.zeros(len(big) + 700, dtype=np.uint8)
+    w = lo.zo_compress_unit_cdict(_buf(want), len(want), _buf(big), len(big), ocd)
+    assert dst[:k].tobytes() == want[:w].tobytes()
+    huge = np.concatenate([np.concatenate(recs)] * 4)[:140000]
+    dst2 = np.zeros(S.ZSTD_compressBound(len(huge)), dtype=np.uint8)
+    k = S.ZSTD_compress2(c, _buf(dst2), len(dst2), _buf(huge), len(huge))   # above 128 KB with a dictionary: not a single-block frame
     assert S.ZSTD_isError(k) and b"Unsupported" in S.ZSTD_getErrorName(k)
     assert S.ZSTD_CCtx_reset(c, 3) == 0                                     # parameters reset: the dictionary is dropped
     k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))

@@ -14,6 +14,7 @@ namespace zhip {
 struct HostCDict {
     std::vector<uint8_t> content;       // dictionary content + 16 zero bytes of padding
     size_t len;                         // content bytes (0: dictionaries below 8 bytes are ignored, zstd_compress.c:5130)
+    size_t fullSize;                    // the dictionary buffer as given (cdict->dictContentSize): sizes the window in copy mode
     CParams cp;                         // the CDict's parameters (ZSTD_cpm_createCDict)
     std::vector<uint32_t> tabL, tabS;   // index << 8 | tag; fast: tabL only
     uint32_t dictID; uint32_t rep[3];
@@ -217,6 +218,7 @@ static inline int host_cdict_build(HostCDict& cd, const void* dict, size_t dictS
 {
     if (!host_get_cparams_mode(level, HOST_SRCSIZE_UNKNOWN, dictSize, HOST_CPM_CREATE_CDICT, &cd.cp) || cd.cp.strategy > 2) return 1;
     cd.level = level == 0 ? 3 : level;
+    cd.fullSize = dictSize;
     cd.dictID = 0; cd.rep[0] = 1; cd.rep[1] = 4; cd.rep[2] = 8; cd.hasEntropy = false;
     memset(&cd.ent, 0, sizeof(cd.ent));
     const uint8_t* content = (const uint8_t*)dict;
@@ -238,8 +240,24 @@ static inline int host_cdict_build(HostCDict& cd, const void* dict, size_t dictS
     return 0;
 }
 
+// COPY mode (zstd_compress.c:2395-2419): sources above the attach cut-off.  The CDict's table parameters as they are, windowLog
+// from the parameters requested for (level, srcSize, dictSize) with the dictionary counted in (ZSTD_cpm_noAttachDict, :6289-6292)
+static inline bool host_cdict_copy_params(const HostCDict& cd, size_t n, CParams* out)
+{
+    CParams p, w;
+    if (!host_get_cparams_mode(cd.level, n, cd.fullSize, HOST_CPM_NONE, &p)) return false;
+    w = cd.cp; w.windowLog = p.windowLog;
+    *out = w;
+    return true;
+}
+static inline bool host_cdict_is_copy_mode(const HostCDict& cd, size_t n)
+{
+    static const size_t cutoff[3] = { 8192, 8192, 16384 };
+    return n > cutoff[cd.cp.strategy];
+}
+
 // working-context parameters for a record of n bytes with `cd` attached (zstd_compress.c:6289-6292, :2318-2338);
-// false when the reference would copy the dictionary instead of attaching it (:2289-2315) — not implemented
+// false when the reference would copy the dictionary instead of attaching it (:2289-2315): host_cdict_copy_params then
 static inline bool host_cdict_unit_params(const HostCDict& cd, size_t n, CParams* out)
 {
     static const size_t cutoff[3] = { 8192, 8192, 16384 };

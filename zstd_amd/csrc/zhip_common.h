@@ -10,6 +10,7 @@
 #define ZHIP_SEQ_CAP         (ZHIP_UNIT_MAX / 4 + 8)   /* fast/dfast matches are >= 4 bytes (zstd_compress.c:1690) */
 #define ZHIP_OUT_STRIDE      (ZHIP_UNIT_MAX + 512 + 32) /* >= ZSTD_compressBound(128 KB) + frame header */
 #define ZHIP_LIT_STRIDE      (ZHIP_UNIT_MAX + 64)
+#define ZHIP_UNIT_COPYMODE    0xC0u
 
 enum { ZHIP_STRAT_FAST = 1, ZHIP_STRAT_DFAST = 2, ZHIP_STRAT_GREEDY = 3, ZHIP_STRAT_LAZY = 4, ZHIP_STRAT_LAZY2 = 5 };   /* lib/zstd.h:328-337 */
 
@@ -18,7 +19,7 @@ struct ZhipUnit {
     uint64_t srcOff;        // byte offset of the unit in the source buffer
     uint32_t srcLen;        // <= ZHIP_UNIT_MAX
     uint8_t  windowLog, chainLog, hashLog, minMatch;
-    uint8_t  strategy, searchLog, litMode /* 1: literals stay raw (negative levels) */, pad0;
+    uint8_t  strategy, searchLog, litMode /* 1: literals stay raw (negative levels) */, pad0 /* records path: ZHIP_UNIT_COPYMODE = the dictionary is copied, not attached */;
     uint32_t targetLength;
 };
 

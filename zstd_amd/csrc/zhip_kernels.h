@@ -6,6 +6,7 @@
 #include "zhip_parse_dfast.h"
 #include "zhip_parse_lazy.h"
 #include "zhip_parse_dict.h"
+#include "zhip_parse_ext.h"
 #include "zhip_entropy.h"
 #include "zhip_decode.h"
 
@@ -71,6 +72,7 @@ k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
+    if (u.pad0 == ZHIP_UNIT_COPYMODE) return;             // above the attach cut-off: k_parse_ext's
     const uint8_t* const p = src + u.srcOff;
     ZhipSlot const sl = slots[ui];
     if (u.strategy == ZHIP_STRAT_FAST) {
@@ -168,6 +170,29 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
     parse_lazy_unit(src + u.srcOff, u.srcLen, u, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
                     seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui);
+}
+
+// Copy mode of a dictionary (sources above the attach cut-off): k_ext_init gives every such source a private copy of the
+// CDict's tables with the tags stripped (zstd_compress.c:2379-2393), k_parse_ext runs one source per LANE (zhip_parse_ext.h).
+__global__ void __launch_bounds__(256)
+k_ext_init(const uint32_t* __restrict__ cdTabL, const uint32_t* __restrict__ cdTabS, uint32_t wordsL, uint32_t wordsS,
+           uint32_t* __restrict__ tabs, size_t tabStride)
+{
+    uint32_t* const t = tabs + (size_t)blockIdx.y * tabStride;
+    uint32_t const total = wordsL + wordsS;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) t[i] = (i < wordsL ? cdTabL[i] : cdTabS[i - wordsL]) >> 8;
+}
+__global__ void __launch_bounds__(64)
+k_parse_ext(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, const uint32_t* __restrict__ extIdx,
+            uint32_t nExt, ZhipCDictDev cd, uint32_t* __restrict__ tabs, size_t tabStride,
+            ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    uint32_t const i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nExt) return;
+    uint32_t const ui = extIdx[i];
+    ZhipUnit const u = units[ui];
+    ZhipSlot const sl = slots[ui];
+    parse_ext_source(src + u.srcOff, u, cd, tabs + (size_t)i * tabStride, seqs + sl.seqOff, sl.seqCap, lits + sl.litOff, metas + ui);
 }
 
 // Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's

@@ -532,21 +532,25 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
     uint64_t seqOff = 0, litOff = 0, outOff = 0;
     uint32_t mhL = 6, mhS = 6, mhFast = 0; int fam = 0;
     bool const attached = cd->h.len != 0;                // dictionaries below 8 bytes are not attached, their parameters still apply
+    std::vector<uint32_t> extIdx;                        // sources above the attach cut-off: the reference copies the dictionary (zstd_compress.c:2289-2315)
     for (size_t i = 0; i < nRec; i++) {
         size_t const n = (size_t)(recOffsets[i + 1] - recOffsets[i]);
         zhip::CParams cp;
-        if (n > ZHIP_UNIT_MAX || !zhip::host_cdict_unit_params(cd->h, n, &cp)) {
-            snprintf(c->err, sizeof(c->err), "record %zu (%zu bytes) is above the attach cut-off of this dictionary's strategy: the copy path is not implemented", i, n);
+        bool const copyParams = zhip::host_cdict_is_copy_mode(cd->h, n);     // the parameter rule also applies to an ignored (< 8 byte) dictionary
+        bool const copyMode = attached && copyParams;
+        if (n > ZHIP_UNIT_MAX || !(copyParams ? zhip::host_cdict_copy_params(cd->h, n, &cp) : zhip::host_cdict_unit_params(cd->h, n, &cp))) {
+            snprintf(c->err, sizeof(c->err), "record %zu (%zu bytes): no parameter row (sources above 128 KB are not single-block frames)", i, n);
             return ZERR(ZE_parameter_unsupported);
         }
         ZhipUnit& u = c->hUnits[i];
         u.srcOff = recOffsets[i]; u.srcLen = (uint32_t)n;
         u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
         u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength;
+        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength;
         ZhipSlot& sl = c->hSlots[i];
         sl.seqOff = seqOff; sl.litOff = litOff; sl.outOff = outOff; sl.seqCap = (uint32_t)rec_seq_cap(n); sl.pad0 = 0;
         seqOff += rec_seq_cap(n); litOff += rec_lit_bytes(n); outOff += rec_out_bytes(n);
+        if (copyMode) { extIdx.push_back((uint32_t)i); continue; }          // its tables are the CDict's geometry, in HBM
         if (cp.strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp.hashLog > mhFast) mhFast = cp.hashLog; }
         else { fam |= 2; if (cp.hashLog > mhL) mhL = cp.hashLog; if (cp.chainLog > mhS) mhS = cp.chainLog; }
     }
@@ -578,9 +582,28 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nRec * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
         if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         HIPCHK(c, hipEventRecord(c->ev[0], s));
-        hipLaunchKernelGGL(zhip::k_parse_dict, dim3((unsigned)nRec), dim3(64), smem, s,
-                           (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse);
+        if (extIdx.size() < nRec)
+            hipLaunchKernelGGL(zhip::k_parse_dict, dim3((unsigned)nRec), dim3(64), smem, s,
+                               (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse);
         HIPCHK(c, hipGetLastError());
+        if (!extIdx.empty()) {                                  // copy mode: private table copies + one lane per source
+            size_t const nExt = extIdx.size();
+            size_t stride = zhip::ext_table_words(cd->h.cp.hashLog, cd->h.cp.chainLog, cd->h.cp.strategy); stride = (stride + 3) & ~(size_t)3;
+            size_t const idxWords = (nExt + 3) & ~(size_t)3;
+            if (c->tabsCap < nExt * stride + idxWords) {
+                (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->dTabs, (nExt * stride + idxWords) * sizeof(uint32_t))); c->tabsCap = nExt * stride + idxWords;
+            }
+            uint32_t* const dIdx = c->dTabs + nExt * stride;      // the index list rides behind the tables
+            HIPCHK(c, hipMemcpyAsync(dIdx, extIdx.data(), nExt * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            uint32_t const wordsL = 1u << cd->h.cp.hashLog, wordsS = cd->h.cp.strategy == ZHIP_STRAT_DFAST ? 1u << cd->h.cp.chainLog : 0u;
+            hipLaunchKernelGGL(zhip::k_ext_init, dim3(64, (unsigned)nExt), dim3(256), 0, s, cd->dTabL, cd->dTabS, wordsL, wordsS, c->dTabs, stride);
+            hipLaunchKernelGGL(zhip::k_parse_ext, dim3((unsigned)((nExt + 63) / 64)), dim3(64), 0, s,
+                               (const uint8_t*)srcDev, c->dUnits, c->dSlots, dIdx, (uint32_t)nExt, dv, c->dTabs, stride, c->dSeqs, c->dLits, c->dParse);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev[1], s));               // the match-finder time of the call includes them
+            HIPCHK(c, hipStreamSynchronize(s));                   // extIdx (host vector) must outlive the copy
+        }
         HIPCHK(c, hipEventRecord(c->ev[1], s));
         c->hcEvUsed = 0;
         r = 0;

@@ -70,7 +70,7 @@ static size_t shim_ensure(ZSTD_CCtx* c, size_t units)
 }
 
 /* one source compressed with an attached dictionary = one record of the device's records path (include/zstd_hip.h);
- * sources above the reference's attach cut-off would take its copy path, which the device core lacks -> parameter_unsupported */
+ * sources above the reference's attach cut-off take its copy path (k_parse_ext); above 128 KB -> parameter_unsupported */
 static size_t shim_compress_cdict(ZSTD_CCtx* c, const ZSTD_CDict* cd, void* dst, size_t cap, const void* src, size_t n)
 {
     unsigned long long offs[2];
