@@ -88,8 +88,10 @@ def run_dict(seed0, rounds, per_round):
         dict_ = gen(rng, int(rng.integers(8, 70000)))
         cutoff = 8192 if level < 3 else 16384
         recs = []
-        for _ in range(per_round):
+        for k in range(per_round):
             n = int(rng.integers(8, min(cutoff, 5000)))
+            if k % 6 == 5:
+                n = int(rng.integers(cutoff + 1, cutoff + 30000))      # above the attach cut-off: the dictionary's COPY mode (k_parse_ext)
             r = gen(rng, n)
             for _ in range(int(rng.integers(0, 6))):          # splice in pieces of the dictionary (incl. its very end)
                 ln = int(rng.integers(4, 200)); ln = min(ln, n, len(dict_))
@@ -122,3 +124,24 @@ def run_dict(seed0, rounds, per_round):
 def test_fuzz_dictionary_records():
     bad = run_dict(7000, 25, 12)
     assert not bad, bad[:10]
+
+
+def test_fuzz_decoder_on_the_emulator():
+    """the device decoder on frames of the oracle's compressor (all implemented levels): structured-random inputs, ragged sizes"""
+    import ctypes as C
+    from test_emu_decode import emu_decode, DFRAME_DT
+    lo, le = load_oracle(), load_emu()
+    le.emu_decode.restype = C.c_int
+    le.emu_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_int]
+    for rd in range(30):
+        rng = np.random.default_rng(31000 + rd)
+        level = LEVELS[rd % len(LEVELS)]
+        bufs = [gen(rng, int(rng.integers(0, 9000))) for _ in range(20)] + ([gen(rng, int(rng.integers(60000, 131073)))] if rd % 5 == 0 else [])
+        frames, want = [], []
+        for b in bufs:
+            f = oracle_unit(lo, b, level)
+            if f is not None:
+                frames.append(f); want.append(b.tobytes())
+        got = emu_decode(le, frames, [len(w) for w in want], groups=5)
+        for i, ((st, data, _), w) in enumerate(zip(got, want)):
+            assert st == 0 and data == w, (rd, level, i, len(w), st)

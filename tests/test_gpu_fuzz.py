@@ -15,6 +15,7 @@ def test_fuzz_units_through_the_c_abi(level):
     assert torch.cuda.is_available()
     lo = load_oracle()
     ctx = zstd_amd.Context(0, max_units=4096)
+    dctx = zstd_amd.DContext(0)
     for unit, count, seed in ((700, 900, 1), (3000, 500, 2), (17000, 120, 3), (70000, 24, 4)):
         try:
             zstd_amd.get_cparams(level, unit)
@@ -37,4 +38,5 @@ def test_fuzz_units_through_the_c_abi(level):
         if got != dst[:r].tobytes():
             bad = [i for i in range(len(osz)) if int(sizes[i]) != int(osz[i])]
             raise AssertionError(f"level {level} unit {unit}: frames differ; first size mismatch at units {bad[:5]}")
-    ctx.close()
+        assert dctx.decompress(got, capacity=len(a)) == a.tobytes(), f"level {level} unit {unit}: the device decoder does not return the source"
+    ctx.close(); dctx.close()
