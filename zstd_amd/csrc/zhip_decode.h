@@ -650,6 +650,68 @@ __device__ __forceinline__ uint32_t seq_field(const lds_u32* R, uint32_t d, uint
     return (uint32_t)(((x << (d & 31)) >> 32) >> (32 - nb));
 }
 
+// ZSTD_buildFSETable_body (zstd_decompress_block.c:484-585) by the whole wavefront, same table as the serial fse_d_build:
+//   * symbols (<= 53, one lane each): low-probability symbols take the top cells, a wave scan gives the others their first rank;
+//   * cells in the reference's visiting order i -> (i * step) & mask, 64 at a time: the visit's rank among the cells below the
+//     low-probability area (ballot + popcount) names its symbol by a binary search in the ranks;
+//   * cells in table order, 64 at a time: a cell's state number is its symbol's count plus the symbol's cells before it — lanes of
+//     one symbol are grouped with ballots, the running count per symbol lives in LDS.
+__device__ inline void fse_d_build_wave(DecShared* S, uint32_t k, uint32_t maxSym, uint32_t tableLog)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const tsz = 1u << tableLog, mask = tsz - 1, step = (tsz >> 1) + (tsz >> 3) + 3;
+    uint64_t* const T = dec_tab(S, k);
+    uint8_t* const symOf = S->symOf[k]; uint16_t* const nextArr = S->next[k];
+    uint32_t* const cum = &S->bat[0][0];                       // 64 exclusive ranks (the hand-over area is free during table builds)
+    int const c = lane <= maxSym ? (int)S->norm[k][lane] : 0;
+    bool const low = c == -1;
+    unsigned long long const lowMask = __ballot(low);
+    uint32_t const nLow = (uint32_t)__popcll(lowMask), high = tsz - 1 - nLow;
+    if (low) symOf[tsz - 1 - (uint32_t)__popcll(lowMask & below_mask((int)lane))] = (uint8_t)lane;
+    uint32_t const cnt = c > 0 ? (uint32_t)c : 0;
+    uint32_t inc = cnt;
+    for (int sft = 1; sft < 64; sft <<= 1) { uint32_t const a = __shfl_up(inc, (unsigned)sft); if ((int)lane >= sft) inc += a; }
+    cum[lane] = inc - cnt;
+    if (lane <= maxSym) nextArr[lane] = (uint16_t)(low ? 1u : cnt);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rankBase = 0;
+    for (uint32_t i0 = 0; i0 < tsz; i0 += 64) {
+        uint32_t const i = i0 + lane, p = (i * step) & mask;
+        bool const ok = i < tsz && p <= high;
+        unsigned long long const okMask = __ballot(ok);
+        uint32_t const rank = rankBase + (uint32_t)__popcll(okMask & below_mask((int)lane));
+        rankBase += (uint32_t)__popcll(okMask);
+        if (ok) {                                               // last symbol whose first rank is <= rank
+            uint32_t lo = 0, hi = 63;
+            while (lo < hi) { uint32_t const mid = (lo + hi + 1) >> 1; if (cum[mid] <= rank) lo = mid; else hi = mid - 1; }
+            symOf[p] = (uint8_t)lo;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t u0 = 0; u0 < tsz; u0 += 64) {
+        uint32_t const u = u0 + lane; bool const on = u < tsz;
+        uint32_t const sy = on ? symOf[u] : 0xFFu;
+        uint32_t ns = 0;
+        unsigned long long rest = __ballot(on);
+        while (rest) {
+            uint32_t const sL = __builtin_amdgcn_readlane(sy, first_lane(rest));
+            unsigned long long const m = __ballot(on && sy == sL);
+            uint32_t const base = nextArr[sL];
+            if (on && sy == sL) ns = base + (uint32_t)__popcll(m & below_mask((int)lane));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) nextArr[sL] = (uint16_t)(base + (uint32_t)__popcll(m));
+            __builtin_amdgcn_wave_barrier();
+            rest &= ~m;
+        }
+        if (on) {
+            uint32_t const nb = tableLog - dec_hb(ns);
+            uint32_t bs, bits; dec_base_bits((int)k, sy, &bs, &bits);
+            T[u] = fse_d_pack(((ns << nb) - tsz) & 0xFFFFu, bits, nb, bs);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // header + the three tables (ZSTD_decodeSeqHeaders :662-745, ZSTD_buildSeqTable :625-660).  seq = the sequences section.
 // Publishes nbSeq; on success initialises D.  Wave-uniform result: error code or 0.
 __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint32_t size, SeqDec& D, const uint64_t* defTabs, uint32_t* nbSeqOut)
@@ -697,22 +759,16 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
     if (err) return err;
     if (!nbSeq) return 0;
     pos = __builtin_amdgcn_readfirstlane(pos);
-    // build: lane k (k < 3) builds table k; predefined tables are copied by the whole wave afterwards
-    uint32_t myHdr = 0, myRle = 0, myMax = 0, myLog = 0;
+    // build, table by table, the whole wave on each (fse_d_build_wave); predefined tables are copied from the constant
     for (int k = 0; k < 3; k++) {
         uint32_t const a = __builtin_amdgcn_readfirstlane(hdr[k]), r = __builtin_amdgcn_readfirstlane(rle[k]);
         uint32_t const m = __builtin_amdgcn_readfirstlane(mx[k]), l = __builtin_amdgcn_readfirstlane(lg[k]);
-        if (lane == (uint32_t)k) { myHdr = a; myRle = r; myMax = m; myLog = l; }
-        if (a == 3) {                                          // predefined table: 64 / 32 entries from the constant copy
+        if (a == 3) {                                          // predefined table: 64 / 32 entries
             uint32_t const n = 1u << l; const uint64_t* const src = defTabs + (k == 0 ? 0 : k == 1 ? 64 : 96);
             for (uint32_t i = lane; i < n; i += 64) dec_tab(S, (uint32_t)k)[i] = src[i];
-        }
-    }
-    if (lane < 3 && myHdr) S->dictFseIn = 0;
-    if (lane < 3) {
-        if (myHdr == 1) fse_d_build(dec_tab(S, lane), S->symOf[lane], S->next[lane], S->norm[lane], myMax, (int)lane, myLog);
-        else if (myHdr == 2) { uint32_t base, bits; dec_base_bits((int)lane, myRle, &base, &bits); dec_tab(S, lane)[0] = fse_d_pack(0, bits, 0, base); }
-        S->log[lane] = myLog;
+        } else if (a == 1) fse_d_build_wave(S, (uint32_t)k, m, l);
+        else if (a == 2) { if (lane == 0) { uint32_t base, bits; dec_base_bits(k, r, &base, &bits); dec_tab(S, (uint32_t)k)[0] = fse_d_pack(0, bits, 0, base); } }
+        if (lane == 0) { S->log[k] = l; if (a) S->dictFseIn = 0; }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) S->fseValid = 1;
