@@ -30,7 +30,9 @@
 #include "zhip_parse.h"
 
 #define ZHIP_DEC_THREADS 128
-#define ZHIP_DEC_CHUNK   2048u                 /* sequences per hand-over buffer */
+#ifndef ZHIP_DEC_CHUNK
+#define ZHIP_DEC_CHUNK   1024u                 /* sequences per hand-over buffer */
+#endif
 #define ZHIP_DEC_LIT_STRIDE (ZHIP_UNIT_MAX + 64)
 #define ZHIP_DEC_RING_WORDS 512u                /* dwords of the sequence bitstream staged in LDS (two halves) */
 
@@ -180,7 +182,7 @@ struct DecShared {
     int16_t  wNorm[256]; uint16_t wNext[256];        // weights' FSE distribution while its table is built
     uint32_t ring[ZHIP_DEC_RING_WORDS + 4];         // the sequence bitstream, staged: word w = the 32 bits consumed w-th (seq_ring_fill);
                                                     // the last 4 words mirror the first 4 so that a window never wraps
-    uint32_t bat[64][2];             // pass 1 -> pass 2: bit position and packed states of each sequence of a batch
+    uint32_t bat[64][4];             // pass 1 -> pass 2: bit position and the three states of each sequence of a batch
     uint32_t frame;                  // queue ticket
     uint32_t status;                 // first error of the frame
     uint32_t hufLog, hufValid, fseValid;
@@ -827,33 +829,34 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
             __builtin_amdgcn_wave_barrier();
         }
         DPROF_L(0);
-        // ---- pass 1 (lane 0): ONE LDS round trip per sequence — the three table entries and a 96-bit window of the stream at
-        // the sequence's start are requested together (both addresses are known from the previous sequence); the window covers
-        // value bits + state bits unless the offset's extra bits are unusually many, then a second window is fetched.
+        // ---- pass 1: only what is inherently serial, ONE LDS round trip per sequence — the three table entries and a 128-bit
+        // window of the stream at the sequence's start are requested together (both addresses are known from the previous
+        // sequence); value bits (<= 63) + state bits (<= 26) + the start's bit offset (<= 31) always fit the window.  Every lane
+        // runs the same chain on the same addresses (LDS broadcasts), so there is no divergence to manage and the loop counter
+        // stays scalar; lane 0's copy is taken afterwards.
         uint32_t d = D.Dpos, sLL = D.sLL, sOF = D.sOF, sML = D.sML;
-        if (lane == 0) {
+        {
             bool const chunkHasLast = D.done + n + nb == nbSeq;
-            for (uint32_t j = 0; j < nb; j++) {
-                uint32_t const w = (d >> 5) & (ZHIP_DEC_RING_WORDS - 1), sh = d & 31;
+            uint32_t const steps = chunkHasLast ? nb - 1 : nb;     // the block's last sequence updates no state (:1335)
+            for (uint32_t j = 0; j < steps; j++) {
+                uint32_t const w = (d >> 5) & (ZHIP_DEC_RING_WORDS - 1);
                 uint32_t const eL = TL[2 * sLL], eO = TO[2 * sOF], eM = TM[2 * sML];
-                uint32_t const r0 = R[w], r1 = R[w + 1], r2 = R[w + 2];
-                S->bat[j][0] = d; S->bat[j][1] = sLL | (sOF << 9) | (sML << 17);
+                uint32_t const r0 = R[w], r1 = R[w + 1], r2 = R[w + 2], r3 = R[w + 3];
+                S->bat[j][0] = d; S->bat[j][1] = sLL; S->bat[j][2] = sOF; S->bat[j][3] = sML;
                 uint32_t const sum = eL + eO + eM;                           // fields add without carrying into each other: next < 2^9, nbAdd sum <= 63, nb sum <= 26
                 uint32_t const aSum = (sum >> 16) & 0xFF, nL = eL >> 24, nM = eM >> 24, nO = eO >> 24;
-                if (chunkHasLast && j + 1 == nb) { d += aSum; break; }       // the last sequence updates no state (:1335)
-                uint32_t const k = sh + aSum;                                // state bits start k bits into the window
-                uint32_t t;                                                  // 32 bits starting there
-                if (k + 26 <= 96) {
-                    uint32_t const hi = k < 32 ? r0 : (k < 64 ? r1 : r2), lo = k < 32 ? r1 : (k < 64 ? r2 : 0u);
-                    t = (uint32_t)(((((uint64_t)hi << 32) | lo) << (k & 31)) >> 32);
-                } else {
-                    uint32_t const d2 = d + aSum, w2 = (d2 >> 5) & (ZHIP_DEC_RING_WORDS - 1);
-                    t = (uint32_t)(((((uint64_t)R[w2] << 32) | R[w2 + 1]) << (d2 & 31)) >> 32);
-                }
+                uint32_t const k = (d & 31) + aSum;                          // state bits start k bits into the window, k <= 94
+                uint32_t const hi = k < 32 ? r0 : (k < 64 ? r1 : r2), lo = k < 32 ? r1 : (k < 64 ? r2 : r3);
+                uint32_t t = (uint32_t)(((((uint64_t)hi << 32) | lo) << (k & 31)) >> 32);
                 sLL = (eL & 0xFFFF) + ((t >> 1) >> (31 - nL)); t <<= nL;
                 sML = (eM & 0xFFFF) + ((t >> 1) >> (31 - nM)); t <<= nM;
                 sOF = (eO & 0xFFFF) + ((t >> 1) >> (31 - nO));
-                d += aSum + nL + nM + nO;
+                d += aSum + (sum >> 24);
+            }
+            if (chunkHasLast) {
+                uint32_t const sum = TL[2 * sLL] + TO[2 * sOF] + TM[2 * sML];
+                S->bat[steps][0] = d; S->bat[steps][1] = sLL; S->bat[steps][2] = sOF; S->bat[steps][3] = sML;
+                d += (sum >> 16) & 0xFF;
             }
         }
         D.Dpos = __builtin_amdgcn_readfirstlane(d); D.sLL = __builtin_amdgcn_readfirstlane(sLL);
@@ -865,8 +868,8 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
         uint32_t ll = 0, ml = 0, offv = 0, sel = 4;            // sel: 4 = new offset in offv; 0..3 = repeat-offset selector (0: code 0)
         uint32_t ll0 = 0;
         if (on) {
-            uint32_t const dj = S->bat[lane][0], st = S->bat[lane][1];
-            uint32_t const a = st & 511, b2 = (st >> 9) & 255, c = st >> 17;
+            uint32_t const dj = S->bat[lane][0];
+            uint32_t const a = S->bat[lane][1], b2 = S->bat[lane][2], c = S->bat[lane][3];
             uint32_t const eL = TL[2 * a], bL = TL[2 * a + 1], eO = TO[2 * b2], bO = TO[2 * b2 + 1], eM = TM[2 * c], bM = TM[2 * c + 1];
             uint32_t const aL = (eL >> 16) & 0xFF, aO = (eO >> 16) & 0xFF, aM = (eM >> 16) & 0xFF;
             uint32_t const xo = seq_field(R, dj, aO);
