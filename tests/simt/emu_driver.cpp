@@ -114,7 +114,7 @@ int emu_decode(const uint8_t* src, const ZhipDFrame* frames, uint32_t nFrames, u
         dv.len = (uint32_t)dd.content.size();
         if (dd.content.empty()) dd.content.push_back(0);
         dv.content = dd.content.data();
-        dv.dictID = dd.dictID; dv.hasEntropy = dd.hasEntropy; dv.hufLog = dd.hufLog; dv.huf = dd.huf.data(); dv.fse = dd.fse.data();
+        dv.dictID = dd.dictID; dv.hasEntropy = dd.hasEntropy; dv.hufLog = dd.hufLog; dv.huf = dd.huf.data(); dv.huf2 = dd.huf2.data(); dv.fse = dd.fse.data();
         for (int k = 0; k < 3; k++) { dv.log[k] = dd.log[k]; dv.rep[k] = dd.rep[k]; }
     }
     uint64_t defTabs[160]; zhip::host_dec_default_tables(defTabs);

@@ -66,6 +66,7 @@ struct HostDDict {
     std::vector<uint8_t> content;            // raw content (what virtually precedes every frame)
     uint32_t dictID = 0, hasEntropy = 0, hufLog = 0;
     std::vector<uint16_t> huf;               // 4096 entries
+    std::vector<uint32_t> huf2;              // 2048 entries: the double-symbol form when hufLog <= 11
     std::vector<uint64_t> fse;               // LL[512] OF[256] ML[512]
     uint32_t log[3] = {0, 0, 0}, rep[3] = {1, 4, 8};
 };
@@ -110,7 +111,7 @@ static inline size_t host_huf_dtable(std::vector<uint16_t>& T, uint32_t* logOut,
 static inline int host_ddict_build(HostDDict& d, const void* dictv, size_t dictSize)
 {
     const uint8_t* const dict = (const uint8_t*)dictv;
-    d.fse.assign(1280, 0); d.huf.assign(4096, 0);
+    d.fse.assign(1280, 0); d.huf.assign(4096, 0); d.huf2.assign(2048, 0);
     uint32_t magic = 0; if (dictSize >= 8) memcpy(&magic, dict, 4);
     if (dictSize < 8 || magic != 0xEC30A437u) { d.content.assign(dict, dict + dictSize); return 0; }       // raw-content dictionary
     memcpy(&d.dictID, dict + 4, 4);
@@ -128,6 +129,8 @@ static inline int host_ddict_build(HostDDict& d, const void* dictv, size_t dictS
     memcpy(d.rep, p, 12); p += 12;
     size_t const contentSize = (size_t)(end - p);
     for (int i = 0; i < 3; i++) if (d.rep[i] == 0 || d.rep[i] > contentSize) return 30;
+    d.huf2.assign(2048, 0);
+    if (d.hufLog <= 11) for (uint32_t i = 0; i < (1u << d.hufLog); i++) d.huf2[i] = huf_double_entry(d.huf.data(), d.hufLog, i);
     d.content.assign(p, end);
     d.hasEntropy = 1;
     return 0;

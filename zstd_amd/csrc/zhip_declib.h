@@ -9,7 +9,7 @@
 struct zhip_ddict_s {
     int device;
     zhip::HostDDict h;
-    uint8_t* dContent; uint16_t* dHuf; uint64_t* dFse;
+    uint8_t* dContent; uint16_t* dHuf; uint32_t* dHuf2; uint64_t* dFse;
     ZhipDDictDev dev;
 };
 
@@ -36,7 +36,7 @@ void zhip_free_ddict(zhip_ddict* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    (void)hipFree(d->dContent); (void)hipFree(d->dHuf); (void)hipFree(d->dFse);
+    (void)hipFree(d->dContent); (void)hipFree(d->dHuf); (void)hipFree(d->dHuf2); (void)hipFree(d->dFse);
     delete d;
 }
 
@@ -44,19 +44,21 @@ zhip_ddict* zhip_create_ddict(int device, const void* dict, size_t dictSize)
 {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zhip_ddict* d = new zhip_ddict_s();
-    d->device = device; d->dContent = nullptr; d->dHuf = nullptr; d->dFse = nullptr;
+    d->device = device; d->dContent = nullptr; d->dHuf = nullptr; d->dHuf2 = nullptr; d->dFse = nullptr;
     if (zhip::host_ddict_build(d->h, dict, dictSize) != 0) { delete d; return nullptr; }
     size_t const n = d->h.content.size();
     bool ok = hipMalloc((void**)&d->dContent, n + 16) == hipSuccess;
     ok = ok && hipMalloc((void**)&d->dHuf, 4096 * sizeof(uint16_t)) == hipSuccess;
     ok = ok && hipMalloc((void**)&d->dFse, 1280 * sizeof(uint64_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&d->dHuf2, 2048 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(d->dHuf2, d->h.huf2.data(), 2048 * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && (n == 0 || hipMemcpy(d->dContent, d->h.content.data(), n, hipMemcpyHostToDevice) == hipSuccess);
     ok = ok && hipMemcpy(d->dHuf, d->h.huf.data(), 4096 * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(d->dFse, d->h.fse.data(), 1280 * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { zhip_free_ddict(d); return nullptr; }
     memset(&d->dev, 0, sizeof(d->dev));
     d->dev.content = d->dContent; d->dev.len = (uint32_t)n; d->dev.dictID = d->h.dictID; d->dev.hasEntropy = d->h.hasEntropy; d->dev.hufLog = d->h.hufLog;
-    d->dev.huf = d->dHuf; d->dev.fse = d->dFse;
+    d->dev.huf = d->dHuf; d->dev.huf2 = d->dHuf2; d->dev.fse = d->dFse;
     for (int k = 0; k < 3; k++) { d->dev.log[k] = d->h.log[k]; d->dev.rep[k] = d->h.rep[k]; }
     return d;
 }

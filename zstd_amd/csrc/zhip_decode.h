@@ -59,6 +59,7 @@ struct ZhipDDictDev {
     const uint8_t*  content; uint32_t len; uint32_t dictID;
     uint32_t hasEntropy, hufLog;
     const uint16_t* huf;                     // 1 << hufLog entries: symbol | nbBits << 8
+    const uint32_t* huf2;                    // hufLog <= 11: the same table in double-symbol form (huf_double_entry)
     const uint64_t* fse;                     // LL[512] OF[256] ML[512] in ZhipFseD packing
     uint32_t log[3];                         // LL, OF, ML table logs
     uint32_t rep[3];
@@ -149,6 +150,19 @@ __device__ __host__ inline uint32_t fse_d_read_ncount(TNORM norm, uint32_t* maxS
     if (remaining != 1 || charnum > maxSV1 || bit > 8 * size) return 0;
     *maxSymIO = charnum - 1;
     return (bit + 7) >> 3;
+}
+
+// Double-symbol Huffman decoding entry for table index i (table log tl <= 11), from the single-symbol table T1 (symbol | nbBits << 8):
+// the first code of the tl bits, and the second one when it also lies completely inside them (the idea of the reference's X2
+// decoder, huf_decompress.c:953-1100, in a layout of our own): sym1 | sym2 << 8 | len1 << 16 | lenBoth << 20 | count << 28.
+template <typename TP>
+__device__ __host__ inline uint32_t huf_double_entry(TP T1, uint32_t tl, uint32_t i)
+{
+    uint32_t const e1 = T1[i], l1 = e1 >> 8;
+    uint32_t const i2 = (i << l1) & ((1u << tl) - 1);          // the bits after the first code, zero-filled
+    uint32_t const e2 = T1[i2], l2 = e2 >> 8;
+    if (l1 + l2 <= tl) return (e1 & 0xFF) | ((e2 & 0xFF) << 8) | (l1 << 16) | ((l1 + l2) << 20) | (2u << 28);
+    return (e1 & 0xFF) | (l1 << 16) | (l1 << 20) | (1u << 28);
 }
 
 #ifndef ZHIP_DECODE_HOST_ONLY
@@ -389,65 +403,21 @@ __device__ inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint3
         for (uint32_t k = lane; k < len; k += 64) S->huf[st + k] = e;
     }
     __builtin_amdgcn_wave_barrier();
+    if (tableLog <= 11) {                                       // double-symbol form, in place: every lane computes its entries from the
+        uint32_t regs[32]; uint32_t const tsz = 1u << tableLog;  // single-symbol table first, then they are written over it
+#pragma unroll
+        for (int r = 0; r < 32; r++) { uint32_t const i = (uint32_t)r * 64 + lane; regs[r] = i < tsz ? huf_double_entry(S->huf, tableLog, i) : 0; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 32; r++) { uint32_t const i = (uint32_t)r * 64 + lane; if (i < tsz) ((uint32_t*)S->huf)[i] = regs[r]; }
+        __builtin_amdgcn_wave_barrier();
+    }
     if (lane == 0) { S->hufLog = tableLog; S->hufValid = 1; S->dictHufIn = 0; }
     __builtin_amdgcn_wave_barrier();
     return consumed;
 }
 
-// the four (or one) Huffman streams -> the literal buffer; lanes 0..3 each own a stream (huf_decompress.c:560-700).
-// returns 0 ok / error code (wave-uniform)
-__device__ inline uint32_t dec_huf_streams(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
-{
-    uint32_t const lane = (uint32_t)lane_id();
-    uint32_t const tl = S->hufLog;
-    const lds_u16* const T = (const lds_u16*)(uintptr_t)S->huf;
-    uint32_t sOff = 0, sLen = size, oOff = 0, oLen = litSize;
-    bool active = lane == 0;
-    if (!single) {
-        if (size < 10) return ZHIP_DE_CORRUPT;
-        uint32_t const l1 = src[0] | (src[1] << 8), l2 = src[2] | (src[3] << 8), l3 = src[4] | (src[5] << 8);
-        if (6 + l1 + l2 + l3 > size) return ZHIP_DE_CORRUPT;
-        uint32_t const seg = (litSize + 3) / 4;
-        if (3 * seg > litSize) return ZHIP_DE_CORRUPT;
-        active = lane < 4;
-        sOff = 6 + (lane >= 1 ? l1 : 0) + (lane >= 2 ? l2 : 0) + (lane >= 3 ? l3 : 0);
-        sLen = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : size - 6 - l1 - l2 - l3;
-        oOff = seg * (lane < 4 ? lane : 0); oLen = lane < 3 ? seg : litSize - 3 * seg;
-    }
-    bool bad = false;
-    if (active) {
-        BitsRev b;
-        if (!br_init(b, src + sOff, sLen)) bad = true;
-        else {
-            uint8_t* o = lit + oOff; uint32_t i = 0;
-            uint32_t const sh = 64 - tl;
-            while (i + 4 <= oLen) {
-                uint32_t w = 0;
-                for (int k = 0; k < 2; k++) {
-                    if (b.n <= 32) br_refill(b);
-                    uint32_t e = T[(uint32_t)(b.acc >> sh)];
-                    b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-                    w |= (e & 0xFF) << (16 * k);
-                    e = T[(uint32_t)(b.acc >> sh)];
-                    b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-                    w |= (e & 0xFF) << (16 * k + 8);
-                }
-                __builtin_memcpy(o + i, &w, 4);
-                i += 4;
-            }
-            for (; i < oLen; i++) {
-                if (b.n <= 32) br_refill(b);
-                uint32_t const e = T[(uint32_t)(b.acc >> sh)];
-                b.acc <<= (e >> 8); b.n -= (int32_t)(e >> 8);
-                o[i] = (uint8_t)e;
-            }
-            if (br_used(b) != b.total) bad = true;              // BIT_endOfDStream
-        }
-    }
-    return __any(bad) ? ZHIP_DE_CORRUPT : 0;
-}
-
-// ---- the same streams decoded by ALL lanes: 16 lanes per stream, each owning a contiguous range of the stream's bits.
+// ---- the four (or one) Huffman streams -> the literal buffer (huf_decompress.c:560-700), decoded by ALL lanes: 16 lanes per stream, each owning a contiguous range of the stream's bits.
 // A prefix code resynchronises: two decoders started at different bit positions fall onto the same codeword boundaries
 // after a few symbols.  So (1) every lane decodes a short run-in (ZHIP_HUF_RUNIN bits above its range) from a guessed
 // position to find where the true chain enters its successor's range, (2) every lane decodes its own range from the entry
@@ -506,11 +476,32 @@ __device__ __forceinline__ uint32_t huf_run(BitsAt& b, const lds_u16* T, uint32_
     }
     return cnt;
 }
+// the same with the double-symbol table (table log <= 11): up to two symbols per lookup; the second one is taken only when it
+// starts above `lo`, so the exit position is the same codeword boundary the single-symbol walk finds
+__device__ __forceinline__ uint32_t huf_run2(BitsAt& b, const lds_u32* T2, uint32_t sh, int32_t lo)
+{
+    uint32_t cnt = 0;
+    while (b.pos > lo) {
+        uint64_t acc = ba_chunk(b);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t const e = T2[(uint32_t)(acc >> sh)];
+            int32_t const l1 = (int32_t)((e >> 16) & 15), lt = (int32_t)((e >> 20) & 31);
+            bool const live = b.pos > lo, two = (e >> 28) == 2 && b.pos - l1 > lo;
+            int32_t const used = two ? lt : l1;
+            acc <<= (uint32_t)used;
+            if (live) { b.pos -= used; cnt += two ? 2u : 1u; }
+        }
+    }
+    return cnt;
+}
 __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
 {
     uint32_t const lane = (uint32_t)lane_id(), grp = lane >> 4, j = lane & 15;
     uint32_t const tl = S->hufLog, sh = 64 - tl;
     const lds_u16* const T = (const lds_u16*)(uintptr_t)S->huf;
+    const lds_u32* const T2 = (const lds_u32*)(uintptr_t)S->huf;
+    bool const dbl = tl <= 11;                                 // which form the table in LDS has (dec_huf_table / dictionary copy)
     uint32_t sOff = 0, sLen = size, oOff = 0, oLen = litSize;
     bool mine = grp == 0;                                      // this lane's stream exists
     if (!single) {
@@ -539,7 +530,7 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     int32_t exitPos = hi;
     if (on && hi > 0) {
         if (j == 0) exitPos = B;                                // the true start; decoded in step (2)
-        else { int32_t const st = hi + ZHIP_HUF_RUNIN < B ? hi + ZHIP_HUF_RUNIN : B; BitsAt b; ba_init(b, base, st, okLo, okHi); (void)huf_run(b, T, sh, hi); exitPos = b.pos; }
+        else { int32_t const st = hi + ZHIP_HUF_RUNIN < B ? hi + ZHIP_HUF_RUNIN : B; BitsAt b; ba_init(b, base, st, okLo, okHi); if (dbl) (void)huf_run2(b, T2, sh, hi); else (void)huf_run(b, T, sh, hi); exitPos = b.pos; }
     }
     // after the run-in lane j holds a guess for ITS OWN entry (the chain's first position <= hi); lane 0's is exact
     int32_t entry = exitPos;
@@ -547,7 +538,7 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     bool dirty = on;
     for (int round = 0; round < 20; round++) {
         if (dirty) {
-            if (entry > lo) { BitsAt b; ba_init(b, base, entry, okLo, okHi); cnt = huf_run(b, T, sh, lo); myExit = b.pos; }
+            if (entry > lo) { BitsAt b; ba_init(b, base, entry, okLo, okHi); cnt = dbl ? huf_run2(b, T2, sh, lo) : huf_run(b, T, sh, lo); myExit = b.pos; }
             else { cnt = 0; myExit = entry; }
         }
         int32_t const predExit = __shfl(myExit, (int)(lane - 1));
@@ -567,7 +558,24 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     if (isLast && myExit != 0) bad = true;
     if (__any(bad)) return ZHIP_DE_CORRUPT;
     // (3) output
-    if (on && cnt) {
+    if (on && cnt && dbl) {
+        BitsAt b; ba_init(b, base, entry, okLo, okHi);
+        uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
+        while (i < cnt) {
+            uint64_t acc = ba_chunk(b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t const e = T2[(uint32_t)(acc >> sh)];
+                bool const live = i < cnt, two = (e >> 28) == 2 && i + 1 < cnt;
+                uint32_t const used = two ? (e >> 20) & 31 : (e >> 16) & 15;
+                acc <<= used; b.pos -= (int32_t)used;
+                if (live) {
+                    if (two) { uint16_t const w = (uint16_t)e; __builtin_memcpy(o + i, &w, 2); i += 2; }
+                    else { o[i] = (uint8_t)e; i += 1; }
+                }
+            }
+        }
+    } else if (on && cnt) {
         BitsAt b; ba_init(b, base, entry, okLo, okHi);
         uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
         while (i + 4 <= cnt) {
@@ -1117,7 +1125,10 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
     if (dict && dict->hasEntropy) {                            // the dictionary's tables, unless the previous frame left them untouched
         bool const needHuf = !S->dictHufIn, needFse = !S->dictFseIn;
         __syncthreads();
-        if (needHuf) for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
+        if (needHuf) {
+            if (dict->hufLog <= 11) { for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) ((uint32_t*)S->huf)[i] = dict->huf2[i]; }
+            else for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
+        }
         if (needFse) for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
         if (tid == 0) { S->dictHufIn = 1; S->dictFseIn = 1; }
     }
