@@ -55,6 +55,7 @@ def main():
         res["wave1_ticks_per_unit"] = {w1[i]: round(v[16 + i] / units) for i in range(8)}
         names = ["ring refill+loop", "pass1 serial chain", "pass2 values", "repeat offsets", "scan+validate+store"]
         res["seq_chunk_ticks_per_unit"] = {names[i]: round(v[24 + i] / units) for i in range(5)}
+        res["exec_rounds_per_batch"] = v[29] / max(1, v[30])
         res["seqs_per_unit"] = v[8] / units; res["lits_per_unit"] = v[9] / units
     print(json.dumps(res, indent=1))
 

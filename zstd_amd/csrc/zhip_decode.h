@@ -1069,7 +1069,9 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
         uint32_t const srcEnd = !on ? 0 : inDict ? (ml > back ? ((ml < off ? ml : off) - back) : 0) : (off < ml ? o : o - off + ml);
         bool const simple = on && !inDict && off >= ml && ml <= 64;         // one lane, one round trip
         unsigned long long pending = __ballot(on);
+        DPROF_ADD(30, 1);
         while (pending) {
+            DPROF_ADD(29, 1);
             int const f = first_lane(pending);
             uint32_t const limit = __builtin_amdgcn_readlane(o, f);
             bool const ready = ((pending >> lane) & 1) && ((int)lane == f || srcEnd <= limit);
