@@ -94,10 +94,11 @@ def test_reference_frames_and_corruptions(libs):
     for (st, data, _), w in zip(got, want):
         assert st == 0 and data == w
     # corrupted frames: the device rejects whatever the oracle rejects and decodes alike otherwise
-    base = ref_frame(lr, text_like(5000, 9), 3)
+    bases = [ref_frame(lr, text_like(5000, 9), 3), ref_frame(lr, datagen(lo, 7000, 50, 3), 1), ref_frame(lr, text_like(2500, 4), 19),
+             ref_frame(lr, (rng.geometric(0.25, size=6000) % 256).astype(np.uint8), 5), ref_frame(lr, text_like(300, 6), 1)]
     muts = []
-    for _ in range(120):
-        b = bytearray(base)
+    for it in range(int(os.environ.get("ZHIP_EMU_MUTANTS", "300"))):
+        b = bytearray(bases[it % len(bases)])
         k = rng.integers(0, 3)
         if k == 0:
             b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))

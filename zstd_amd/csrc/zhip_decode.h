@@ -1137,6 +1137,8 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
     __syncthreads();
     DPROF(wave ? 16 : 0);                                       // frame setup
     uint32_t status = S->status;
+    __syncthreads();                                            // everybody has read the status before anybody may raise it again (a wave that
+                                                                // ran ahead and flagged an error must not split the workgroup's control flow)
     uint32_t ip = H.size, op = 0;
     SeqDec D; D.done = 0; D.outPos = 0; D.litPos = 0; D.sLL = D.sOF = D.sML = 0; D.rep0 = D.rep1 = D.rep2 = 0; D.base = src; D.size = 0; D.Dpos = 0; D.wLoaded = 0;
     bool last = false;
@@ -1186,6 +1188,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         __syncthreads();
         DPROF(wave ? 19 : 2);                                   // waiting for the other wave
         status = S->status;
+        __syncthreads();                                        // (same rule: read, then barrier, then the next writer)
         if (status) break;
         uint32_t const nbSeq = S->nbSeq, litSize = S->litSize;
         LitSrc L; L.mode = S->litMode; L.byte = S->litByte; L.p = L.mode == 1 ? blk + S->litSrcOff : litBuf;
@@ -1197,6 +1200,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
             __syncthreads();
             DPROF(wave ? 21 : 4);
             status = S->status;
+            __syncthreads();
         }
         if (status) break;
         {   // last literals (zstd_decompress_block.c:1681-1690)
