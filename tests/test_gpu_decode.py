@@ -93,6 +93,35 @@ def test_reference_frames_and_corruptions(env):
         else:
             assert got == w
     assert nerr > 80
+    # the same mutants (and more families) as ONE batch: good and bad frames interleaved on the same workgroups, per-frame status
+    _, _, _, torch = env
+    bases = [base, ref_frame(lr, datagen(lo, 30000, 50, 3), 1), ref_frame(lr, text_like(9000, 4), 19), ref_frame(lr, text_like(400, 6), 1)]
+    batch = list(muts)
+    for it in range(1500):
+        b = bytearray(bases[it % len(bases)])
+        k = rng.integers(0, 4)
+        if k == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif k == 2:
+            del b[int(rng.integers(9, len(b))):]
+        batch.append(bytes(b))                                  # k == 3: an intact frame between the broken ones
+    cap = 32768
+    blob = np.frombuffer(b"".join(batch) + b"\x00" * 64, dtype=np.uint8)
+    src = torch.from_numpy(blob.copy()).cuda()
+    out = torch.zeros(len(batch) * cap + 64, dtype=torch.uint8, device="cuda")
+    ssz = np.array([len(m) for m in batch], dtype=np.uint64)
+    so = np.concatenate([[0], np.cumsum(ssz)[:-1]]).astype(np.uint64)
+    do = np.arange(len(batch), dtype=np.uint64) * cap
+    r, status, dsz = dctx.decompress_frames_device(out.data_ptr(), do, np.full(len(batch), cap, np.uint64), src.data_ptr(), so, ssz, check=False)
+    host = out.cpu().numpy()
+    for i, m in enumerate(batch):
+        w = oracle_decompress(lo, m, cap)
+        if w is None:
+            assert status[i] != 0, (i, m.hex()[:60])
+        else:
+            assert status[i] == 0 and host[i * cap: i * cap + int(dsz[i])].tobytes() == w, (i, int(status[i]))
 
 
 def test_dictionary_round_trip(env):
