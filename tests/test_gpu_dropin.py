@@ -183,3 +183,21 @@ def test_cdict_entry_points_match_the_reference(env):
     k = S.ZSTD_compress2(c, _buf(dst), len(dst), _buf(big), len(big))
     assert not S.ZSTD_isError(k)
     S.ZSTD_freeCCtx(c); S.ZSTD_freeCDict(cd)
+
+
+def test_c_program_against_the_shim(tmp_path):
+    """examples/roundtrip.c: plain C against the reference's names, linked with -lzstd_hipshim; compiled here with gcc (with the
+    reference's own zstd.h when /root/reference exists, else include/zstd_hip_dropin.h) and run on the GPU"""
+    import subprocess, shutil
+    import zstd_amd
+    from _libs import ROOT
+    libdir = os.path.dirname(zstd_amd.LIB_PATH)
+    exe = str(tmp_path / "roundtrip")
+    ref_hdr = "/root/reference/lib/zstd.h"
+    cmd = ["gcc", "-O2", "-Wall", "-Werror"]
+    cmd += ["-DUSE_REFERENCE_HEADER", "-I/root/reference/lib"] if os.path.exists(ref_hdr) else ["-I" + os.path.join(ROOT, "include")]
+    cmd += [os.path.join(ROOT, "examples", "roundtrip.c"), "-L" + libdir, "-lzstd_hipshim", "-lzstd_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.check_call(cmd)
+    for n, level in ((5 << 20, 3), (100, 1), (131072, 5), (0, 1), (3_000_000, 1)):
+        out = subprocess.run([exe, str(n), str(level)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "roundtrip ok" in out.stdout, (n, level, out.stdout, out.stderr)
