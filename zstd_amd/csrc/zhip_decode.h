@@ -481,6 +481,17 @@ __device__ __forceinline__ uint32_t huf_run(BitsAt& b, const lds_u16* T, uint32_
 __device__ __forceinline__ uint32_t huf_run2(BitsAt& b, const lds_u32* T2, uint32_t sh, int32_t lo)
 {
     uint32_t cnt = 0;
+    // far from the range's end nothing needs checking: four lookups take at most 44 bits, every one of them is inside the range
+    // and both of its symbols count (the entry's total length and count fields are used as they are)
+    while (b.pos - 44 > lo) {
+        uint64_t acc = ba_chunk(b);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t const e = T2[(uint32_t)(acc >> sh)];
+            uint32_t const lt = (e >> 20) & 31;
+            acc <<= lt; b.pos -= (int32_t)lt; cnt += e >> 28;
+        }
+    }
     while (b.pos > lo) {
         uint64_t acc = ba_chunk(b);
 #pragma unroll
@@ -561,6 +572,19 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     if (on && cnt && dbl) {
         BitsAt b; ba_init(b, base, entry, okLo, okHi);
         uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
+        // while at least 8 symbols remain, four lookups (<= 8 symbols) cannot overrun the lane's region: each stores two bytes, a
+        // single-symbol entry's second byte is overwritten by the next store
+        while (i + 8 <= cnt) {
+            uint64_t acc = ba_chunk(b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t const e = T2[(uint32_t)(acc >> sh)];
+                uint32_t const lt = (e >> 20) & 31;
+                acc <<= lt; b.pos -= (int32_t)lt;
+                uint16_t const w = (uint16_t)e; __builtin_memcpy(o + i, &w, 2);
+                i += e >> 28;
+            }
+        }
         while (i < cnt) {
             uint64_t acc = ba_chunk(b);
 #pragma unroll
