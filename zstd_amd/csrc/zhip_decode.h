@@ -430,7 +430,7 @@ __device__ inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint3
 #endif
 // Bit reader of the parallel decoder.  All lanes reload at the SAME moments (every four symbols), so the wave never runs a
 // refill path for the sake of one lane, and the bytes of reload k+1 are requested at reload k: the next read point is at most
-// 6 bytes below the current one (4 symbols x <= 12 bits), so a 16-byte window that starts 8 bytes below the current chunk
+// 7 bytes below the current one (5 lookups x <= 11 bits, or 4 x 12), so a 16-byte window that starts 8 bytes below the current chunk
 // always contains the next chunk.  pos = bits of the stream below the read point; bits below the stream's start read as the
 // bytes that precede it (never consumed by a valid stream: its chain ends exactly on bit 0, anything else is rejected).
 struct BitsAt { const uint8_t* base; int32_t pos; int32_t wa; uint64_t wlo, whi; int32_t okLo, okHi; };   // window = 16 bytes at byte offset wa
@@ -481,12 +481,12 @@ __device__ __forceinline__ uint32_t huf_run(BitsAt& b, const lds_u16* T, uint32_
 __device__ __forceinline__ uint32_t huf_run2(BitsAt& b, const lds_u32* T2, uint32_t sh, int32_t lo)
 {
     uint32_t cnt = 0;
-    // far from the range's end nothing needs checking: four lookups take at most 44 bits, every one of them is inside the range
-    // and both of its symbols count (the entry's total length and count fields are used as they are)
-    while (b.pos - 44 > lo) {
+    // far from the range's end nothing needs checking: five lookups take at most 55 of the chunk's >= 57 bits, every one of them
+    // is inside the range and both of its symbols count (the entry's total length and count fields are used as they are)
+    while (b.pos - 55 > lo) {
         uint64_t acc = ba_chunk(b);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             uint32_t const e = T2[(uint32_t)(acc >> sh)];
             uint32_t const lt = (e >> 20) & 31;
             acc <<= lt; b.pos -= (int32_t)lt; cnt += e >> 28;
@@ -572,12 +572,12 @@ __device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src,
     if (on && cnt && dbl) {
         BitsAt b; ba_init(b, base, entry, okLo, okHi);
         uint8_t* const o = lit + oOff + pre; uint32_t i = 0;
-        // while at least 8 symbols remain, four lookups (<= 8 symbols) cannot overrun the lane's region: each stores two bytes, a
+        // while at least 10 symbols remain, five lookups (<= 10 symbols) cannot overrun the lane's region: each stores two bytes, a
         // single-symbol entry's second byte is overwritten by the next store
-        while (i + 8 <= cnt) {
+        while (i + 10 <= cnt) {
             uint64_t acc = ba_chunk(b);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 5; k++) {
                 uint32_t const e = T2[(uint32_t)(acc >> sh)];
                 uint32_t const lt = (e >> 20) & 31;
                 acc <<= lt; b.pos -= (int32_t)lt;
