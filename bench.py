@@ -260,10 +260,25 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
                 r, status, dsz = dctx.decompress_frames_device(back.data_ptr(), all_offs[:-1], rsz, dst.data_ptr(), so, csz, ddict=dd)
                 best = min(best, dctx.timing()["decode_ms"])
             okd = bool(r == n and not status.any() and torch.equal(back[:n], src[:n]))
+            dcpu = None
+            if not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "zref_bench")):
+                exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+                dict_.tofile("/tmp/zb_d.bin"); flat.tofile("/tmp/zb_r.bin"); offs.astype("<u8").tofile("/tmp/zb_o.bin")
+                try:
+                    one = json.loads(subprocess.check_output([exe, "ddict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "4", "1"], timeout=120))
+                    nc = os.cpu_count() or 1
+                    allc = json.loads(subprocess.check_output([exe, "ddict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "3", str(nc)], timeout=120))
+                    dcpu = {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference",
+                            "sample": f"the {base_n} distinct record frames, ZSTD_createDDict + ZSTD_decompress_usingDDict per record (oracle/_ref/zref_bench ddict)",
+                            "all_cores": {"value": allc["MBps"], "cores": nc}}
+                except Exception:
+                    dcpu = None
             out["decode"] = {"metric": "decompress_MBps_records_with_dictionary", "value": round(n / best / 1e3, 1), "unit": "MB/s", "k_decode_ms": round(best, 3),
                              "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
                              "parity": {"decoded_equals_source_full_size": okd}}
+            if dcpu:
+                out["decode"]["cpu_baseline"] = dcpu
         print(json.dumps(out))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

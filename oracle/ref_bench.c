@@ -12,6 +12,8 @@
  *   zref_bench dfile  <level> <chunkSize> <path> <seconds> <threads>   : DECODE speed (`zstd -b#` second figure,
  *        benchzstd.c:380-420): the file is compressed once into one frame per chunk, then ZSTD_decompressDCtx per frame on a
  *        reused DCtx is timed; threads split the frames.
+ *   zref_bench ddict  <level> <dictPath> <recordsPath> <offsetsPath> <seconds> <threads> : DECODE speed of the same record frames
+ *        (ZSTD_createDDict + ZSTD_decompress_usingDDict per record)
  *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
  *   zref_bench dict   <level> <dictPath> <recordsPath> <offsetsPath(u64 LE, nRec+1)> <seconds> <threads>
  *        one frame per record with ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the `zstd -b# -D dict` /
@@ -171,9 +173,66 @@ static int dict_main(char** argv)
     return 0;
 }
 
+/* ddict: the records compressed once (one frame each, CDict attached), then ZSTD_decompress_usingDDict per record is timed */
+typedef struct { const ZSTD_DDict* dd; const char* comp; const size_t* coff; const unsigned long long* offs; size_t r0, r1; char* out; int err; } xjob_t;
+static void* xworker(void* p)
+{
+    xjob_t* j = (xjob_t*)p;
+    ZSTD_DCtx* d = ZSTD_createDCtx();
+    size_t k;
+    for (k = j->r0; k < j->r1; k++) {
+        size_t const want = (size_t)(j->offs[k + 1] - j->offs[k]);
+        size_t const r = ZSTD_decompress_usingDDict(d, j->out + j->offs[k], want, j->comp + j->coff[k], j->coff[k + 1] - j->coff[k], j->dd);
+        if (ZSTD_isError(r) || r != want) { j->err = 1; break; }
+    }
+    ZSTD_freeDCtx(d);
+    return NULL;
+}
+static int ddict_main(char** argv)
+{
+    int const level = atoi(argv[2]);
+    size_t dn, rn, on; double const seconds = atof(argv[6]); int const T = atoi(argv[7]) > 0 ? atoi(argv[7]) : 1;
+    void* dict = slurp(argv[3], &dn); char* src = (char*)slurp(argv[4], &rn);
+    unsigned long long* offs = (unsigned long long*)slurp(argv[5], &on);
+    size_t const nRec = on / 8 - 1;
+    ZSTD_CDict* cd = ZSTD_createCDict(dict, dn, level);
+    ZSTD_DDict* dd = ZSTD_createDDict(dict, dn);
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t const cap = rn + rn / 128 + 128 * nRec + 1024;
+    char* comp = (char*)malloc(cap); char* out = (char*)malloc(rn + 64);
+    size_t* coff = (size_t*)calloc(nRec + 1, sizeof(size_t));
+    xjob_t* jobs = (xjob_t*)calloc((size_t)T, sizeof(xjob_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    double best = 1e30, t0; int runs = 0, t; size_t k;
+    if (!cd || !dd || !c || !comp || !out || !coff) return 1;
+    ZSTD_CCtx_refCDict(c, cd);
+    for (k = 0; k < nRec; k++) {
+        size_t const r = ZSTD_compress2(c, comp + coff[k], cap - coff[k], src + offs[k], (size_t)(offs[k + 1] - offs[k]));
+        if (ZSTD_isError(r)) return 1;
+        coff[k + 1] = coff[k] + r;
+    }
+    t0 = now_s();
+    do {
+        double const a = now_s();
+        for (t = 0; t < T; t++) {
+            jobs[t].dd = dd; jobs[t].comp = comp; jobs[t].coff = coff; jobs[t].offs = offs; jobs[t].out = out; jobs[t].err = 0;
+            jobs[t].r0 = nRec * (size_t)t / (size_t)T; jobs[t].r1 = nRec * (size_t)(t + 1) / (size_t)T;
+            if (T == 1) xworker(&jobs[t]); else pthread_create(&th[t], NULL, xworker, &jobs[t]);
+        }
+        for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; }
+        {   double const d = now_s() - a; if (d < best) best = d; }
+        runs++;
+    } while (now_s() - t0 < seconds);
+    if (memcmp(src, out, rn)) return 1;
+    printf("{\"level\": %d, \"records\": %zu, \"bytes\": %zu, \"csize\": %zu, \"best_s\": %.6f, \"MBps\": %.2f, \"runs\": %d, \"threads\": %d, \"mode\": \"decode\"}\n",
+           level, nRec, rn, coff[nRec], best, (double)rn / best / 1e6, runs, T);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
+    if (argc >= 8 && !strcmp(argv[1], "ddict")) return ddict_main(argv);
     if (argc >= 7 && !strcmp(argv[1], "dfile")) return dfile_main(argv);
     if (argc >= 5 && !strcmp(argv[1], "stream")) {
         RDG_genStdout(strtoull(argv[2], 0, 10), atof(argv[3]) / 100.0, 0.0, (unsigned)atoi(argv[4]));
