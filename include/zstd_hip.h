@@ -150,6 +150,10 @@ size_t       zhip_decompress_frames_device(zhip_dctx* dctx, const zhip_ddict* dd
                                            unsigned long long* sizesOut, void* stream);
 /* host buffers = ZSTD_decompress(dst, cap, src, srcSize): every frame of src, contents back to back (ddict may be NULL) */
 size_t       zhip_decompress(zhip_dctx* dctx, const zhip_ddict* ddict, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* = ZSTD_seekable_decompress (contrib/seekable_format/zstd_seekable.h:166): len bytes of the decompressed data at `offset` from
+ * a seekable file (frames + seek table, what zhip_compress_seekable or the reference's seekable compressor writes) in a HOST
+ * buffer; only the frames overlapping the request are decoded (one batch), the table's checksums are verified when present. */
+size_t       zhip_seekable_read(zhip_dctx* dctx, void* dst, size_t len, const void* src, size_t srcSize, unsigned long long offset);
 /* HIP-event durations (ms) of the most recent call: t[0] = k_decode, t[1] = checksum verification (0 when no frame has one) */
 void         zhip_dctx_last_timing(const zhip_dctx* dctx, double t[2]);
 

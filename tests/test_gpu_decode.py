@@ -221,3 +221,36 @@ def test_frames_without_content_size_small_windows_checksums(env):
             assert dctx.decompress(f) == a.tobytes(), (len(a), level, cs, ck, wl)
             stream += f; want += a.tobytes()
     assert dctx.decompress(stream) == want
+
+
+@pytest.mark.parametrize("checksum", [False, True])
+def test_seekable_random_access(env, checksum):
+    """zhip_seekable_read == ZSTD_seekable_decompress: random-access reads into a seekable file (frames + seek table) decode only
+    the frames they touch; the same reads through the reference's seekable decoder where oracle/_ref travelled"""
+    z, lo, dctx, _ = env
+    ctx = z.Context(0, max_units=64)
+    a = np.concatenate([datagen(lo, 131072 * 5 + 777, 50, 12), text_like(131072 * 4 + 4321, 3)])
+    ctx.set_checksum(checksum)
+    blob = ctx.compress_seekable(a, level=3)
+    ctx.set_checksum(False)
+    lr = load_ref() if have_ref() else None
+    if lr is not None:
+        lr.zref_seekable_read.restype = C.c_size_t
+        lr.zref_seekable_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_ulonglong, C.c_void_p]
+    src = np.frombuffer(blob, dtype=np.uint8)
+    rng = np.random.default_rng(2)
+    reads = [(0, 100), (131072 - 50, 100), (131072 * 3 + 17, 300000), (len(a) - 77, 77), (0, len(a)), (131072 * 2, 131072)] + [(int(o), 70000) for o in rng.integers(0, len(a) - 70000, size=8)]
+    for off, ln in reads:
+        got = dctx.seekable_read(blob, off, ln)
+        assert got == a[off:off + ln].tobytes(), (off, ln)
+        if lr is not None:
+            out = np.zeros(ln, dtype=np.uint8)
+            assert lr.zref_seekable_read(_buf(out), ln, _buf(src), len(src), off, None) == ln and out.tobytes() == got
+    with pytest.raises(z.ZhipError):
+        dctx.seekable_read(blob, len(a) - 10, 11)               # beyond the end
+    with pytest.raises(z.ZhipError):
+        dctx.seekable_read(blob[:-1], 0, 10)                    # no footer
+    if checksum:
+        bad = bytearray(blob); bad[len(blob) - 9 - 4] ^= 1      # the last frame's checksum in the table
+        with pytest.raises(z.ZhipError, match="22"):
+            dctx.seekable_read(bytes(bad), len(a) - 100, 100)

@@ -81,6 +81,7 @@ def lib():
                                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
             ("zhip_decompress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
             ("zhip_dctx_last_timing", None, [C.c_void_p, C.c_void_p]),
+            ("zhip_seekable_read", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_ulonglong]),
         ]:
             if hasattr(L, name):
                 getattr(L, name).restype = res
@@ -326,6 +327,16 @@ class DContext:
                               a.ctypes.data_as(C.c_void_p) if a.size else None, a.size)
         if L.zhip_isError(r):
             self._err(r, "zhip_decompress")
+        return dst[:r].tobytes()
+
+    def seekable_read(self, blob, offset, length):
+        """random access into a seekable file (host bytes): only the frames overlapping [offset, offset+length) are decoded"""
+        a = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        dst = np.empty(max(length, 1), dtype=np.uint8)
+        L = lib()
+        r = L.zhip_seekable_read(self._h, dst.ctypes.data_as(C.c_void_p), length, a.ctypes.data_as(C.c_void_p), a.size, offset)
+        if L.zhip_isError(r):
+            self._err(r, "zhip_seekable_read")
         return dst[:r].tobytes()
 
     def decompress_frames_device(self, dst_ptr, dst_offsets, dst_caps, src_ptr, src_offsets, src_sizes, ddict=None, stream=None, check=True):

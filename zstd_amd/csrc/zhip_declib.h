@@ -232,6 +232,63 @@ size_t zhip_decompress_frames_device(zhip_dctx* c, const zhip_ddict* dd, void* d
     return decode_locked(c, dd, (uint8_t*)dstDev, (const uint8_t*)srcDev, nFrames, statusOut, sizesOut, stream ? (hipStream_t)stream : c->stream);
 }
 
+// = ZSTD_seekable_decompress (contrib/seekable_format/zstd_seekable.h, zstdseek_decompress.c:ZSTD_seekable_decompress): `len`
+// bytes of the decompressed data starting at `offset`, from a seekable file held in a HOST buffer.  The seek table (the
+// skippable frame at the end, contrib/seekable_format/zstd_seekable_compression_format.md) names every frame's compressed and
+// decompressed size; only the frames that overlap the request are staged and decoded — as one batch, one workgroup each —
+// and their stored checksums (XXH64 low words, when the table has them) are verified against the decoded content.
+size_t zhip_seekable_read(zhip_dctx* c, void* dst, size_t len, const void* srcv, size_t srcSize, unsigned long long offset)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    DCHK(c, hipSetDevice(c->device));
+    const uint8_t* const src = (const uint8_t*)srcv;
+    auto rd32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    if (srcSize < 17 || rd32(src + srcSize - 4) != 0x8F92EAB1u) return DERR(10);                    // no seek table footer: prefix_unknown
+    uint32_t const nFrames = rd32(src + srcSize - 9); uint8_t const desc = src[srcSize - 5];
+    if (desc & 0x7C) return DERR(20);                                                                 // reserved bits (zstdseek_decompress.c)
+    size_t const entry = (desc & 0x80) ? 12 : 8, tableSize = 8 + (size_t)nFrames * entry + 9;
+    if (tableSize > srcSize) return DERR(20);
+    const uint8_t* const tab = src + srcSize - tableSize;
+    if (rd32(tab) != 0x184D2A5Eu || rd32(tab + 4) != (uint32_t)(tableSize - 8)) return DERR(20);
+    if (len == 0) return 0;
+    // frames overlapping [offset, offset + len)
+    uint64_t cpos = 0, dpos = 0; size_t first = nFrames, last = 0; uint64_t firstC = 0, firstD = 0;
+    for (size_t i = 0; i < nFrames; i++) {
+        uint32_t const cs = rd32(tab + 8 + i * entry), ds = rd32(tab + 8 + i * entry + 4);
+        if (dpos + ds > offset && dpos < offset + len && ds) { if (first == nFrames) { first = i; firstC = cpos; firstD = dpos; } last = i + 1; }
+        cpos += cs; dpos += ds;
+    }
+    if (cpos + tableSize > srcSize) return DERR(20);
+    if (offset + len > dpos || first == nFrames) return DERR(72);                                     // request beyond the end: srcSize_wrong
+    size_t const n = last - first;
+    size_t const e = ensure_frames(c, n);
+    if (e) return e;
+    uint64_t so = 0, d0 = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t const cs = rd32(tab + 8 + (first + i) * entry), ds = rd32(tab + 8 + (first + i) * entry + 4);
+        ZhipDFrame f; f.srcOff = so; f.dstOff = d0; f.srcLen = cs; f.dstCap = ds;
+        c->hFrames[i] = f; so += cs; d0 += ds;
+    }
+    if (c->srcStageCap < so + 64) { (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0; DCHK(c, hipMalloc((void**)&c->dSrcStage, so + 64)); c->srcStageCap = so + 64; }
+    if (c->dstStageCap < d0 + 64) { (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0; DCHK(c, hipMalloc((void**)&c->dDstStage, d0 + 64)); c->dstStageCap = d0 + 64; }
+    DCHK(c, hipMemcpyAsync(c->dSrcStage, src + firstC, so, hipMemcpyHostToDevice, c->stream));
+    size_t const r = decode_locked(c, nullptr, c->dDstStage, c->dSrcStage, n, nullptr, nullptr, c->stream);
+    if (zhip_isError(r)) return r;
+    for (size_t i = 0; i < n; i++) if (c->hResults[i].size != c->hFrames[i].dstCap) return DERR(20);      // the table and the frame disagree
+    if (desc & 0x80) {                                                                                // the table's own checksums
+        for (size_t i = 0; i < n; i++) { ZhipUnit u; memset(&u, 0, sizeof(u)); u.srcOff = c->hFrames[i].dstOff; u.srcLen = c->hResults[i].size; c->hUnits[i] = u; }
+        DCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, n * sizeof(ZhipUnit), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(zhip::k_xxh64, dim3((uint32_t)((n + 15) / 16)), dim3(64), 0, c->stream, (const uint8_t*)c->dDstStage, c->dUnits, (uint32_t)n, c->dChecks);
+        DCHK(c, hipGetLastError());
+        std::vector<uint32_t> ck(n);
+        DCHK(c, hipMemcpyAsync(ck.data(), c->dChecks, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        DCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; i++) if (ck[i] != rd32(tab + 8 + (first + i) * entry + 8)) return DERR(22);
+    }
+    DCHK(c, hipMemcpy(dst, c->dDstStage + (offset - firstD), len, hipMemcpyDeviceToHost));
+    return len;
+}
+
 // = ZSTD_decompress / ZSTD_decompress_usingDDict (lib/zstd.h:205, :1046) for host buffers: every frame of src, contents back to back in dst
 size_t zhip_decompress(zhip_dctx* c, const zhip_ddict* dd, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
