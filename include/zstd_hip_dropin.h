@@ -63,6 +63,9 @@ unsigned    ZSTD_getDictID_fromDDict(const ZSTD_DDict* ddict);                  
 unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);                      /* :215 first frame only */
 unsigned long long ZSTD_findDecompressedSize(const void* src, size_t srcSize);                     /* :1492 all frames */
 size_t      ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);                         /* :254 */
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);                          /* :1520 upper bound of all frames' content */
+unsigned    ZSTD_isFrame(const void* buffer, size_t size);                                         /* :1466 zstd or skippable frame magic */
+unsigned    ZSTD_getDictID_fromFrame(const void* src, size_t srcSize);                             /* :1112 0 = not stated */
 int         ZSTD_minCLevel(void);                                                                  /* :245 */
 int         ZSTD_maxCLevel(void);                                                                  /* :246 (highest level the device core implements) */
 int         ZSTD_defaultCLevel(void);                                                              /* :247 */

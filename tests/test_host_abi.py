@@ -167,3 +167,39 @@ def test_frame_walker_matches_the_oracle(zlib_):
         zlib_.find_frames(stream + b"\x00")                               # trailing garbage: srcSize_wrong
     with pytest.raises(zlib_.ZhipError):
         zlib_.find_frames(stream[:-3])                                     # truncated last frame
+
+
+def test_shim_frame_inspection_matches_the_reference(zlib_):
+    """host-only ZSTD_* inspectors of the shim (no GPU needed) against the real reference on its own frames"""
+    if not have_ref():
+        pytest.skip("needs oracle/_ref")
+    from zstd_amd import build as zb
+    from _libs import text_like
+    lr = load_ref(); lo = load_oracle()
+    S = C.CDLL(zb.SHIM)
+    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libzstd_ref.so"))
+    for L in (S, R):
+        L.ZSTD_decompressBound.restype = C.c_ulonglong; L.ZSTD_decompressBound.argtypes = [C.c_void_p, C.c_size_t]
+        L.ZSTD_findDecompressedSize.restype = C.c_ulonglong; L.ZSTD_findDecompressedSize.argtypes = [C.c_void_p, C.c_size_t]
+        L.ZSTD_getFrameContentSize.restype = C.c_ulonglong; L.ZSTD_getFrameContentSize.argtypes = [C.c_void_p, C.c_size_t]
+        L.ZSTD_findFrameCompressedSize.restype = C.c_size_t; L.ZSTD_findFrameCompressedSize.argtypes = [C.c_void_p, C.c_size_t]
+        L.ZSTD_isFrame.restype = C.c_uint; L.ZSTD_isFrame.argtypes = [C.c_void_p, C.c_size_t]
+        L.ZSTD_getDictID_fromFrame.restype = C.c_uint; L.ZSTD_getDictID_fromFrame.argtypes = [C.c_void_p, C.c_size_t]
+    a = text_like(300000, 7)
+    streams = []
+    for cs, ck, wl in ((1, 0, 0), (0, 1, 0), (0, 0, 12)):
+        cap = int(lr.zref_compress_bound(len(a))) + 64
+        dst = np.empty(cap, dtype=np.uint8)
+        r = lr.zref_compress_frame_params(3, cs, ck, wl, _buf(a), len(a), _buf(dst), cap)
+        assert r != ERR
+        streams.append(dst[:r].tobytes())
+    streams.append(streams[0] + b"\x52\x2a\x4d\x18\x02\x00\x00\x00zz" + streams[1])
+    zd = np.fromfile(os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    sizes = (C.c_size_t * 1)(2000); outs = (C.c_size_t * 1)()
+    dst = np.empty(4096, dtype=np.uint8)
+    assert lr.zref_compress_records_cdict(3, _buf(zd), len(zd), _buf(a), sizes, 1, _buf(dst), 4096, outs) != ERR
+    streams.append(dst[:outs[0]].tobytes())
+    for z in streams:
+        b = np.frombuffer(z + b"\x00" * 8, dtype=np.uint8); n = len(z)
+        for fn in ("ZSTD_decompressBound", "ZSTD_findDecompressedSize", "ZSTD_getFrameContentSize", "ZSTD_findFrameCompressedSize", "ZSTD_isFrame", "ZSTD_getDictID_fromFrame"):
+            assert getattr(S, fn)(_buf(b), n) == getattr(R, fn)(_buf(b), n), fn

@@ -215,6 +215,36 @@ unsigned long long ZSTD_findDecompressedSize(const void* src, size_t n)
     free(cs);
     return total;
 }
+unsigned long long ZSTD_decompressBound(const void* src, size_t n)
+{   /* stated content sizes where present, nbBlocks * blockSizeMax otherwise (zstd_decompress.c:ZSTD_decompressBound) */
+    size_t const k = zhip_find_frames(src, n, NULL, NULL, NULL, NULL, 0); unsigned long long total = 0, *cs, *cb; size_t i;
+    if (zhip_isError(k)) return ZSTD_CONTENTSIZE_ERROR;
+    if (!k) return 0;
+    cs = (unsigned long long*)malloc(2 * k * sizeof(*cs));
+    if (!cs) return ZSTD_CONTENTSIZE_ERROR;
+    cb = cs + k;
+    (void)zhip_find_frames(src, n, NULL, NULL, cs, cb, k);
+    for (i = 0; i < k; i++) total += cs[i] != ZSTD_CONTENTSIZE_UNKNOWN ? cs[i] : cb[i];
+    free(cs);
+    return total;
+}
+unsigned ZSTD_isFrame(const void* buffer, size_t size)
+{
+    const unsigned char* p = (const unsigned char*)buffer;
+    if (size < 4) return 0;
+    if (p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD) return 1;
+    return (p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18;                  /* 0x184D2A5? skippable */
+}
+unsigned ZSTD_getDictID_fromFrame(const void* src, size_t n)
+{
+    const unsigned char* p = (const unsigned char*)src; unsigned fhd, single, code, id = 0, i; size_t pos;
+    static const unsigned did[4] = { 0, 1, 2, 4 };
+    if (n < 5 || !(p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD)) return 0;
+    fhd = p[4]; single = (fhd >> 5) & 1; code = fhd & 3; pos = 5 + !single;
+    if (pos + did[code] > n) return 0;
+    for (i = 0; i < did[code]; i++) id |= (unsigned)p[pos + i] << (8 * i);
+    return id;
+}
 size_t ZSTD_compressBound(size_t n) { return zhip_compressBound(n, SHIM_UNIT); }
 unsigned ZSTD_isError(size_t code) { return zhip_isError(code); }
 const char* ZSTD_getErrorName(size_t code) { return zhip_getErrorName(code); }
