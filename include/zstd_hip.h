@@ -1,4 +1,5 @@
-/* zstd_hip.h — C ABI of libzstd_hip.so: the MI355X (gfx950) Zstandard block-compression core.
+/* zstd_hip.h — C ABI of libzstd_hip.so: the MI355X (gfx950) Zstandard block-compression core and, on the other side of the
+ * same path, the batch frame decoder (section "decompression" below).
  *
  * This is the drop-in boundary for the hot path only.  Everything is plain C: opaque handle,
  * pointers and sizes; no C++/torch types.  Each entry point names the reference interface it stands in for
