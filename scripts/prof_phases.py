@@ -50,13 +50,14 @@ def main():
     v = list(out)
     units = n // 131072
     tm = ctx.timing()
-    names_p = ["init", "front(sched,hash,tab,scratch,spec-loads)", "dup groups+shfl", "cand load+ballots", "decide+commit",
-               "event setup", "extension", "post-match(E2)", "tail"]
+    names_p = ["init", "window front (loads, hash, table + candidate gather, groups)", "window event search", "window match (E load, extension)",
+               "window emit + inserts + repcode loop", "window end (table, sequences, literals)", "schedule-shaped batch", "its event (extension, post-match)", "tail",
+               "window long match (post-match by loads)"]
     names_e = ["gather+hist", "huf table build", "huf sizing+hdr", "huf pack", "seq hist+tables", "fse state chains",
                "seq bit pack", "headers"]
     res = {"timing_ms": tm, "units": units,
-           "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(9)},
-           "parse_batches_per_unit": v[10] / units, "parse_events_per_unit": v[11] / units,
+           "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(10)},
+           "parse_windows_per_unit": v[10] / units, "parse_window_events_per_unit": v[11] / units,
            "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)},
            "entropy_extra": [round(v[16 + i] / units) for i in range(8, 12)],
            "phaseB_jobs_ticks_per_unit": {"huf_build_codes": round(v[28] / units), "huf other (mode, write table)": round(v[31] / units),

@@ -124,6 +124,9 @@ template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return 
 static inline unsigned __builtin_amdgcn_readlane(unsigned v, int lane) { return simt::shfl_impl(v, lane); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return simt::shfl_impl(v, simt::first_alive_lane()); }
 static inline unsigned __builtin_amdgcn_ds_bpermute(int byteAddr, unsigned v) { return simt::shfl_impl(v, (byteAddr >> 2) & 63); }
+static inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> simt::cur->lane) & 1; }
+#define ZHIP_SBFM64(width, offset) ((((width) & 63) ? (~0ull >> (64 - ((width) & 63))) : 0ull) << ((offset) & 63))    /* s_bfm_b64 */
+#define ZHIP_WRITELANE(v, l, old) (simt::cur->lane == (int)(l) ? (unsigned)(v) : (unsigned)(old))    /* v_writelane_b32 */
 static inline void __builtin_amdgcn_wave_barrier() { simt::wave_rendezvous(simt::K_WBAR, nullptr); }
 static inline void __builtin_amdgcn_s_barrier();
 static inline void __builtin_amdgcn_s_sleep(int) {}

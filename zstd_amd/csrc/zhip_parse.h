@@ -43,6 +43,10 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t v; __built
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }   // -> SGPR
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    return (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+}
 __device__ __forceinline__ int first_lane(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 {
@@ -173,7 +177,17 @@ struct FastOut {
     uint64_t pendV;         // per lane: 8 loaded literal bytes of the most recent run, stored at the next call
     uint32_t pendSh;        // per lane: bits to shift pendV right by (loads are clamped to the unit)
     uint32_t pendOff, pendLen;
+#ifdef ZHIP_PROF
+    uint64_t* zp; uint64_t* zlast;   // the caller's phase accumulators (measurement build only)
+#endif
 };
+#ifdef ZHIP_PROF
+#define ZWPROF(o, i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); (o).zp[i] += t_ - *(o).zlast; *(o).zlast = t_; } while (0)
+#define ZWPROF_COUNT(o, i, v) do { (o).zp[i] += (uint64_t)(v); } while (0)
+#else
+#define ZWPROF(o, i) do { } while (0)
+#define ZWPROF_COUNT(o, i, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 
@@ -242,6 +256,316 @@ __device__ __forceinline__ FastBatch batch_load(const uint8_t* src, uint32_t nm8
     return b;
 }
 
+// ------------------------------------------------------------------ after a match: zstd_fast.c:403-420 by loads
+// The two complementary inserts (when `first`) and the immediate-repcode loop; one round of loads per repcode match:
+// lanes 0..61 compare 8 bytes at ip0+8*lane with the bytes rep2 back, lane 62 fetches the bytes of cur0+2, lane 63 those
+// of ip0-2 (the two inserts of :407-408).  With NEXT the bytes of the batch that starts at the final ip0 ride along
+// (returned in `cur`, result true).  Requires ip0 <= ilimit (= nm8).
+template <uint32_t MLS, bool NEXT>
+__device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const FastTab& T, FastOut& out,
+                                           uint32_t& ip0, uint32_t& anchor, uint32_t& rep1, uint32_t& rep2, uint32_t cur0, bool first,
+                                           uint32_t startPosOff, uint32_t startRposOff, FastBatch& cur)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    int32_t const ilimit = (int32_t)nm8;
+    for (;;) {
+        uint32_t const q = ip0 + 8u * lane;
+        uint32_t qc = q < nm8 ? q : nm8;
+        uint32_t const sh = q - qc;
+        if (first) { if (lane == 62) qc = cur0 + 2; if (lane == 63) qc = ip0 - 2; }
+        uint64_t const a = ld64(src + qc);
+        uint64_t x = a ^ ld64(src + (qc - rep2));
+        FastBatch nxt; nxt.bytes = 0; nxt.rcur = 0; nxt.rv = 0;
+        if (NEXT) nxt = batch_load(src, nm8, ip0, startPosOff, startRposOff, rep1);
+        uint32_t const hh = hash_pos<MLS>(a, hshift);
+        if (first) {
+            if (lane == 62) tab_put(T, hh, cur0 + 2);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 63) tab_put(T, hh, ip0 - 2);
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t rLength = 0;
+        if (rep2 > 0) {
+            x >>= 8 * (sh & 7);
+            uint32_t const s = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8 - sh;
+            uint32_t const same = sh >= 8 ? 0 : s;
+            unsigned long long const stop = __ballot(same < 8) & below_mask(62);
+            if (stop) { int const f = first_lane(stop); rLength = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+            else rLength = 496 + wave_count_fwd(src, ip0 + 496, ip0 + 496 - rep2, nm8);
+        }
+        if (rLength < 4) { cur = nxt; return NEXT; }                     // :411 MEM_read32(ip0) != MEM_read32(ip0 - rep2)
+        {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
+        if (lane == 0) tab_put(T, hh, ip0);                              // lane 0 hashed the bytes at ip0
+        __builtin_amdgcn_wave_barrier();
+        ip0 += rLength;
+        store_seq(out, 0, 1, rLength);
+        anchor = ip0;
+        first = false;
+        if ((int32_t)ip0 > ilimit) return false;
+    }
+}
+
+// ------------------------------------------------------------------ the dense-scan WINDOW: many events per gather
+// While the gap between searched pairs is 2 (the reference restarts at 2 after every match and keeps it for 128 bytes,
+// zstd_fast.c:232-236, :342-347) every position is searched, so lane l simply takes position B+l.  One window costs one
+// table gather (LDS) and one candidate gather (HBM/L2), and then resolves EVERY event among its lanes in the reference's
+// order with wave-uniform mask arithmetic:
+//   * M   — lanes whose table candidate matches 4 bytes (valid for the lanes whose hash no earlier lane of the window
+//           shares: their candidate cannot depend on what the window itself inserts; the first lane D that does share
+//           one is resolved exactly from its group's first lane a, the window ends before the second such lane);
+//   * E1/E2 — per repcode offset, which lanes equal the byte (…b) / the 4 bytes (…q) that offset back: ONE coalesced
+//           load per offset.  Repcode probes (:268), the one-byte backward step of a repcode match (:271), forward and
+//           backward extension (:387-391, ZSTD_count) and the immediate-repcode loop (:410-420) are bit scans of these
+//           masks; only a match with a NEW offset needs a load (its E mask), and only a match that runs past the window
+//           goes back to wave-wide compares;
+//   * inserts are collected in a mask and written once (their hashes are distinct by construction); inserts of lanes
+//     beyond the exact prefix follow one by one in position order;
+//   * literals: every lane not covered by a match stores its own byte at (position - bytes matched so far).
+enum { ZW_CONT = 0, ZW_INC = 1, ZW_RESTART = 2 };
+#define ZHIP_WIN_NEED 80u            /* a window at B needs B + 80 <= n: 64 positions x 8-byte reads, all iterations inside ilimit */
+#define ZHIP_WIN_LANES 60            /* events are taken from lanes below this (their +2/+4 neighbours stay inside the window) */
+
+#ifndef ZHIP_SBFM64                  /* s_bfm_b64: `width` (0..63) lanes from lane `offset` (0..63) on (the emulator brings its own) */
+__device__ __forceinline__ unsigned long long zhip_sbfm64(uint32_t width, uint32_t offset)
+{
+    unsigned long long r;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(r) : "s"(width), "s"(offset));
+    return r;
+}
+#define ZHIP_SBFM64(width, offset) zhip_sbfm64(__builtin_amdgcn_readfirstlane(width), __builtin_amdgcn_readfirstlane(offset))
+#endif
+#ifndef ZHIP_WRITELANE               /* v_writelane_b32: lane `l` of `old` := the wave-uniform `v` (the emulator brings its own) */
+extern "C" __device__ unsigned zhip_llvm_writelane(unsigned, unsigned, unsigned) __asm("llvm.amdgcn.writelane.i32");
+#define ZHIP_WRITELANE(v, l, old) zhip_llvm_writelane(v, l, old)
+#endif
+
+// lane masks from shifts; every index is in 0..63 by construction (no range checks: this is the serial part of the parser)
+__device__ __forceinline__ unsigned long long lanes_from(uint32_t l) { return ~0ull << l; }           // lanes l .. 63
+__device__ __forceinline__ unsigned long long lanes_below(uint32_t l) { return ~(~0ull << l); }       // lanes 0 .. l-1
+__device__ __forceinline__ uint32_t ff1u(unsigned long long m) { return (uint32_t)(__ffsll((long long)m) - 1); }   // 0xFFFFFFFF when empty
+
+// equal bytes from lane s0 on according to Eb (bit l: src[B+l] == src[B+l-off]); beyond the window by wave-wide compares
+__device__ __forceinline__ uint32_t fwd_run(const uint8_t* src, uint32_t nm8, uint32_t B, unsigned long long Eb, uint32_t s0, uint32_t off)
+{
+    uint32_t base = 0, from = B + s0;
+    if (s0 < 64) {
+        unsigned long long const inv = ~Eb >> s0;
+        if (inv) return ff1u(inv);
+        base = 64 - s0; from = B + 64;
+    }
+    return base + wave_count_fwd(src, from, from - off, nm8);
+}
+
+template <uint32_t MLS>
+__device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const FastTab& T, FastOut& out,
+                                            uint32_t& ip0_, uint32_t& anchor_, uint32_t& rep1_, uint32_t& rep2_, uint32_t& nextStep)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const B = ip0_;
+    uint32_t anchor = anchor_, rep1 = rep1_, rep2 = rep2_;
+    uint32_t const P = B + lane;
+    if (out.pendLen) lits_flush(out);                                     // an earlier run's deferred store (and its spill) goes first
+    uint64_t const cur8 = ld64(src + P);
+    uint32_t const cur32 = (uint32_t)cur8;
+    uint32_t x1 = 1, x2 = 1;                                              // a repcode offset never exceeds the position it is used at
+    if (rep1) x1 = cur32 ^ ld32(src + (P - rep1));
+    if (rep2) x2 = cur32 ^ ld32(src + (P - rep2));
+    uint32_t const h = hash_pos<MLS>(cur8, hshift);
+
+    // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
+    // lanes of one hash hold the same old value)
+    uint32_t old = T.lo[h];
+    if (B > 65536) old |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+    uint32_t const cb = ld32(src + old);                                  // old == 0 reads the unit's first bytes: harmless; in flight
+    __builtin_amdgcn_wave_barrier();                                      // during the duplicate detection below
+    T.lo[h] = (uint16_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t const backId = T.lo[h];
+    __builtin_amdgcn_wave_barrier();
+    T.lo[h] = (uint16_t)old;
+    __builtin_amdgcn_wave_barrier();
+
+    unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
+    unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
+
+    // NF: lanes that share their hash with an earlier lane (exact per group; after 6 groups everything from the first
+    // unresolved flagged lane on counts as sharing — a group's unflagged winner lies above its lowest flagged member)
+    unsigned long long NF = 0;
+    {   unsigned long long ML = __ballot(backId != lane);
+        int it = 0;
+        while (ML) {
+            uint32_t const j = ff1u(ML);
+            if (it == 6) { NF |= lanes_from(j); break; }
+            uint32_t const hj = __builtin_amdgcn_readlane(h, (int)j);
+            unsigned long long const G = __ballot(h == hj);
+            NF |= G & (G - 1);
+            ML &= ~G; it++;
+        }
+    }
+    // D: first sharing lane (resolved exactly below), Dn: the second one = end of the exact prefix
+    uint32_t D = 64, Dw = ZHIP_WIN_LANES, a = 64, MDa = 0;
+    if (NF) {
+        D = ff1u(NF);
+        unsigned long long const NF2 = NF & (NF - 1);
+        uint32_t const Dn = NF2 ? ff1u(NF2) : 64;
+        if (Dn < Dw) Dw = Dn;                                             // >= 2
+        if (D < Dw) {
+            uint32_t const hD = __builtin_amdgcn_readlane(h, (int)D);
+            a = ff1u(__ballot(h == hD));                                  // the group's first lane; == D only after the 6-group cut
+            if (a != D) { MDa = __builtin_amdgcn_readlane(cur32, (int)a) == __builtin_amdgcn_readlane(cur32, (int)D); NF &= ~(1ull << D); }
+            else a = 64;
+        }
+    }
+    unsigned long long const M = __ballot(old != 0 && cb == cur32) & lanes_below(Dw);
+    ZWPROF(out, 1);
+
+    // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
+    // one by one after the others, in position order, and end the window (the pair a/D shares a slot, D stays)
+    unsigned long long INS = 0, COV = 0;
+    uint32_t evA = 0, evB = 0, nEv = ~0u;                                 // event registers: sequence t of this window in lane t
+    uint32_t const nbSeq0 = out.nbSeq;
+    uint32_t backBefore = 0, sumLit = 0;
+    uint32_t const anchorEntry = anchor;
+#define ZW_EMIT(ll, ob, ml) do { uint32_t const mb_ = (ml) - 3;                                                   \
+        if (((ll) | mb_) > 0xFFFF) {                                                                              \
+            if ((ll) > 0xFFFF) { out.longType = 1; out.longPos = out.nbSeq; }                                     \
+            if (mb_ > 0xFFFF) { out.longType = 2; out.longPos = out.nbSeq; } }                                    \
+        uint32_t const slot_ = out.nbSeq - nbSeq0;                                                                \
+        evA = ZHIP_WRITELANE((ob), slot_, evA); evB = ZHIP_WRITELANE(((ll) & 0xFFFFu) | (mb_ << 16), slot_, evB); \
+        out.nbSeq++; } while (0)
+    // the window's table writes: the lanes of INS outside NF together, then its NF lanes one by one
+#define ZW_TABLE_FLUSH() do {                                                                                    \
+        unsigned long long late_ = INS & NF, CM = INS ^ late_;                                                    \
+        if (a < 64 && ((INS >> a) & (INS >> D) & 1)) CM &= ~(1ull << a);   /* same slot: the later position stays */ \
+        if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put(T, h, P);                                            \
+        __builtin_amdgcn_wave_barrier();                                                                          \
+        while (late_) { if (lane == ff1u(late_)) tab_put(T, h, P); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
+        INS = 0; } while (0)
+
+    uint32_t i = 0;
+    int status = ZW_RESTART;
+    int kLim;                                                             // iterations before the gap grows (:342-346), entry scan only
+    {   int32_t const d = (int32_t)(nextStep - B) - 4;
+        kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
+    for (;;) {
+        int Kw = ((int)Dw - (int)i) >> 1;
+        if (Kw > kLim) Kw = kLim;
+        if (Kw <= 0 || (INS & NF)) break;                                 // ZW_RESTART
+        uint32_t const hiLane = i + 2u * (uint32_t)Kw;                    // searched lanes i .. hiLane-1 (<= 60), probes up to hiLane
+        unsigned long long const span = ZHIP_SBFM64(hiLane - i, i);
+        unsigned long long Me = M;
+        uint32_t effA = 0;
+        if (a < 64) {
+            effA = (uint32_t)(a >= i) | (uint32_t)((INS >> a) & 1);       // a's insert precedes D's lookup
+            if (effA) Me = (Me & ~(1ull << D)) | ((unsigned long long)MDa << D);
+        }
+        unsigned long long const MM = Me & span;
+        unsigned long long const RP = E1q & ((i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull) & (span << 2);
+        uint32_t const jm = ff1u(MM), jr = ff1u(RP);
+        if ((int32_t)(jm & jr) < 0) {                                     // neither
+            INS |= span;
+            i = hiLane;
+            status = (Kw == kLim) ? ZW_INC : ZW_CONT;
+            break;
+        }
+        ZWPROF(out, 2);
+        ZWPROF_COUNT(out, 11, 1);
+        // the repcode probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326)
+        uint32_t const isRep = ((jr - i - 2) >> 1) <= ((jm - i) >> 1) ? 1u : 0u;
+        uint32_t const j = isRep ? jr : jm;
+        uint32_t c = __builtin_amdgcn_readlane(old, (int)j);
+        if (j == D && effA) c = B + a;
+        uint32_t const off = isRep ? rep1 : B + j - c;
+        // lanes i .. j are inserted (hash0 = ip0); a repcode is found at ip2 = j, i.e. up to j-1 = ip1 (:283); a match
+        // also inserts ip1 = j+1 (:296, :323 step <= 4)
+        INS |= ZHIP_SBFM64(j + 1 - isRep - i, i);
+        if (!isRep) {
+            INS |= 1ull << (j + 1);
+            rep2 = rep1; E2q = E1q; E2b = E1b; rep1 = off;
+            uint32_t x = 1;
+            if (P >= off) x = cur32 ^ ld32(src + (P - off));
+            E1q = __ballot(x == 0); E1b = __ballot((x & 0xFFu) == 0);
+        }
+        uint32_t const room = B + j - anchor;
+        uint32_t const limit = isRep ? 1u : (room < c ? room : c);        // :271 / :387
+        uint32_t run = 0;
+        if (j) {
+            unsigned long long const t = ~E1b << (64 - j);
+            run = t ? (uint32_t)__clzll((long long)t) : j;
+        }
+        if (run == j && limit > run) run += wave_count_back(src, B, B - off, limit - run);
+        uint32_t const back = run < limit ? run : limit;
+        uint32_t const fl = fwd_run(src, nm8, B, E1b, j + 4, off);
+        uint32_t const mLength = 4 + back + fl;
+        ZWPROF(out, 3);
+        uint32_t const ll = room - back;
+        ZW_EMIT(ll, isRep ? 1u : off + 3, mLength);
+        sumLit += ll;
+        uint32_t sL = j - back;
+        if (back > j) { backBefore = back - j; sL = 0; }
+        uint32_t e = j + 4 + fl;
+        anchor = B + e;
+        uint32_t const cur0L = j - 2 * isRep;
+        if (e >= 64) {                                                    // ran past the window: :403-420 by loads
+            COV |= lanes_from(sL);
+            nEv = out.nbSeq - nbSeq0;                                     // post_match stores its sequences itself
+            ZW_TABLE_FLUSH();
+            uint32_t ip0n = anchor;
+            if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, B + cur0L, true, 0, 0, dummy); }
+            i = ip0n - B;
+            ZWPROF(out, 9);
+            break;
+        }
+        COV |= ZHIP_SBFM64(e - sL, sL);
+        INS |= (1ull << (cur0L + 2)) | (1ull << (e - 2));                 // :407-408 (ip0 <= ilimit inside a window)
+        if (rep2 && ((E2q >> e) & 1)) {                                   // :410-420
+            do {
+                uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, e + 4, rep2);
+                {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
+                {   unsigned long long t = E2q; E2q = E1q; E1q = t; t = E2b; E2b = E1b; E1b = t; }
+                INS |= 1ull << e;
+                ZW_EMIT(0u, 1u, rl);
+                uint32_t const en = e + rl;
+                COV |= en < 64 ? (lanes_from(e) & lanes_below(en)) : lanes_from(e);
+                e = en; anchor = B + e;
+            } while (e < 64 && ((E2q >> e) & 1));
+            if (e >= 64) {                                                // the loop goes on beyond the window, by loads
+                nEv = out.nbSeq - nbSeq0;
+                ZW_TABLE_FLUSH();
+                uint32_t ip0n = anchor;
+                if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, 0, false, 0, 0, dummy); }
+                i = ip0n - B;
+                break;
+            }
+        }
+        i = e;
+        kLim = 64; nextStep = B + e + 128;                                // _start: a fresh scan inside the window
+        ZWPROF(out, 4);
+    }
+    ZWPROF(out, 2);
+#undef ZW_EMIT
+    ZW_TABLE_FLUSH();
+#undef ZW_TABLE_FLUSH
+    // its sequences
+    if (nEv == ~0u) nEv = out.nbSeq - nbSeq0;
+    if (lane < nEv) {
+        ZhipSeq q; q.offBase = evA; q.litLength = (uint16_t)evB; q.mlBase = (uint16_t)(evB >> 16);
+        out.seqs[nbSeq0 + lane] = q;
+    }
+    {   // its literals: the lanes behind the new scan position that no match covers (the tail after the last match is
+        // tentative: a later backward extension may take it back, its bytes are then simply overwritten)
+        unsigned long long const LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
+        if (__builtin_amdgcn_inverse_ballot_w64(LIT)) {
+            uint32_t const before = __builtin_amdgcn_mbcnt_hi((uint32_t)(COV >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)COV, 0));
+            out.lits[out.litPos + (B - anchorEntry) + lane - before - backBefore] = (uint8_t)cur8;
+        }
+    }
+    out.litPos += sumLit;
+    ip0_ = B + i; anchor_ = anchor; rep1_ = rep1; rep2_ = rep2;
+    ZWPROF(out, 5);
+    return status;
+}
+
 // smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
 template <uint32_t MLS>
 __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
@@ -253,6 +577,9 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
     ZPROF_DECL
+#ifdef ZHIP_PROF
+    out.zp = zp_acc_; out.zlast = &zp_last_;
+#endif
 
     FastTab T;
     T.lo = (lds_u16*)(uintptr_t)smem;
@@ -274,6 +601,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const nm8 = n - 8;
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip0 = 1;
+    if (lane == 0) lits[0] = src[0];                                         // position 0 is never searched (:238): windows only store their own lanes
     uint32_t startPosOff, startRposOff; batch_offsets(stepSize, stepSize, startPosOff, startRposOff);
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
@@ -283,13 +611,21 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         uint32_t step = stepSize, g0 = stepSize, nextStep = ip0 + 128;
         if ((int32_t)(ip0 + g0 + 1) >= ilimit) break;                        // :257
         uint32_t posOff = startPosOff, rposOff = startRposOff;
-        if (!have) cur = batch_load(src, nm8, ip0, posOff, rposOff, rep1);
-        have = false;
 
-        // ---- scan batches until an event or the end of the unit
-        int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode
+        // ---- scan until an event or the end of the unit: windows while the gap is 2, schedule-shaped batches otherwise
+        int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode, 3 the window handled its events
         uint32_t mpos = 0, cand0 = 0, cur0 = 0;
         for (;;) {
+            if (stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
+                int const st = window_batch<MLS>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep);
+                have = false;
+                ZPROF_COUNT(10, 1);
+                if (st == ZW_RESTART) { evKind = 3; break; }
+                if (st == ZW_INC) { step = 3; nextStep += 128; batch_offsets(g0, step, posOff, rposOff); }
+                continue;
+            }
+            if (!have) cur = batch_load(src, nm8, ip0, posOff, rposOff, rep1);
+            have = false;
             // iterations this batch covers: iteration k+1 runs iff A_{k+2}+1 < ilimit (:347); the gap grows after the
             // iteration whose A_{k+2} reaches nextStep (:342-346) — a batch ends there
             uint32_t const pos = ip0 + posOff, rpos = ip0 + rposOff;
@@ -315,7 +651,6 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
             if (live) T.lo[h] = (uint16_t)lane;
             __builtin_amdgcn_wave_barrier();
             uint32_t const back = T.lo[h];
-            ZPROF_COUNT(10, 1);
 
             // speculative loads for the next batch (used if this one has no event)
             uint32_t const nip0 = ip0 + g0 + (uint32_t)(K - 1) * step;
@@ -327,7 +662,6 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
             uint32_t cb = ld32(src + old);                                   // old == 0 reads the unit's first bytes: harmless
             uint32_t cand = old;
             unsigned long long const dupMask = __ballot(back != lane) & liveMask;
-            ZPROF(1);
             unsigned long long grp = 0;
             if (dupMask) {
                 // exact groups of live lanes with equal hash; a lane's candidate is its closest earlier group member
@@ -344,11 +678,9 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
                 uint32_t const dpos = __shfl(pos, (int)pd), d32 = __shfl(cur32, (int)pd);
                 if (prevMask) { cand = dpos; cb = d32; }
             }
-            ZPROF(2);
             unsigned long long const mMask = __ballot(cand != 0 && cb == cur32) & liveMask;
             unsigned long long const rMask = rep1 ? (__ballot(cur.rcur == cur.rv) & liveMask & evenLanes) : 0ull;
             int const jm = mMask ? first_lane(mMask) : 64, jr = rMask ? first_lane(rMask) : 64;
-            ZPROF(3);
             int const rankM = jm < 64 ? 3 * (jm >> 1) + 1 + (jm & 1) : 0x7fffffff;
             int const rankR = jr < 64 ? 3 * (jr >> 1) : 0x7fffffff;
             int Lcommit;
@@ -369,7 +701,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
                 if (we && inC && (pos >> 16)) __hip_atomic_fetch_or(&T.hi[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             __builtin_amdgcn_wave_barrier();
-            ZPROF(4);
+            ZPROF(6);
 
             if (evKind == 1) {
                 mpos = __builtin_amdgcn_readlane(pos, jm);
@@ -393,9 +725,10 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
             if (K - 1 == kEnd) break;                                        // ip3 >= ilimit: unit finished
             if (K - 1 == kInc) { step++; nextStep += 128; }
             posOff = nposOff; rposOff = nrposOff;
-            cur = nxt;
+            cur = nxt; have = true;
         }
         if (evKind == 0) break;
+        if (evKind == 3) continue;                                           // the window left ip0 at the next `_start`
 
         // ---- _offset / _match (:377-401)
         uint32_t offBase, lim;
@@ -409,57 +742,18 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
             lim = 1;                                                         // :271 mLength = ip0[-1] == match0[-1]
         }
         uint32_t backLen, fwdLen;
-        ZPROF(5);
-        wave_extend(src, nm8, mpos, cand0, lim, backLen, fwdLen);
         ZPROF(6);
-        ZPROF_COUNT(11, 1);
+        wave_extend(src, nm8, mpos, cand0, lim, backLen, fwdLen);
         ip0 = mpos - backLen;
         {   uint32_t const mLength = 4 + backLen + fwdLen;
             lits_copy(out, src, nm8, anchor, ip0 - anchor);
             store_seq(out, ip0 - anchor, offBase, mLength);
             ip0 += mLength; anchor = ip0;
         }
-
-        // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along.
-        // One round of loads: lanes 0..61 compare 8 bytes at ip0+8*lane with the bytes rep2 back, lane 62 fetches
-        // the bytes of current0+2, lane 63 those of ip0-2 (the two inserts of :407-408).
-        if ((int32_t)ip0 <= ilimit) {
-            bool first = true;
-            for (;;) {
-                uint32_t const q = ip0 + 8u * lane;
-                uint32_t qc = q < nm8 ? q : nm8;
-                uint32_t const sh = q - qc;
-                if (first) { if (lane == 62) qc = cur0 + 2; if (lane == 63) qc = ip0 - 2; }
-                uint64_t const a = ld64(src + qc);
-                uint64_t x = a ^ ld64(src + (qc - rep2));
-                FastBatch const nxt = batch_load(src, nm8, ip0, startPosOff, startRposOff, rep1);
-                uint32_t const hh = hash_pos<MLS>(a, hshift);
-                if (first) {
-                    if (lane == 62) tab_put(T, hh, cur0 + 2);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 63) tab_put(T, hh, ip0 - 2);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                uint32_t rLength = 0;
-                if (rep2 > 0) {
-                    x >>= 8 * (sh & 7);
-                    uint32_t const s = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8 - sh;
-                    uint32_t const same = sh >= 8 ? 0 : s;
-                    unsigned long long const stop = __ballot(same < 8) & below_mask(62);
-                    if (stop) { int const f = first_lane(stop); rLength = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
-                    else rLength = 496 + wave_count_fwd(src, ip0 + 496, ip0 + 496 - rep2, nm8);
-                }
-                if (rLength < 4) { cur = nxt; have = true; break; }          // :411 MEM_read32(ip0) != MEM_read32(ip0 - rep2)
-                {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
-                if (lane == 0) tab_put(T, hh, ip0);                          // lane 0 hashed the bytes at ip0
-                __builtin_amdgcn_wave_barrier();
-                ip0 += rLength;
-                store_seq(out, 0, 1, rLength);
-                anchor = ip0;
-                first = false;
-                if ((int32_t)ip0 > ilimit) break;
-            }
-        }
+        // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along
+        have = false;
+        if ((int32_t)ip0 <= ilimit)
+            have = post_match<MLS, true>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, startPosOff, startRposOff, cur);
         ZPROF(7);
     }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
