@@ -6,7 +6,7 @@ level 1 (ZSTD_fast), 131072-byte independent units, one frame per unit, source a
 One *step* = one pass of the whole device pipeline (match finder -> entropy/frame assembly -> compaction) over the
 1 GiB batch.  `value` = source MB (1e6 bytes, programs/benchzstd.h:32) per second, whole job over all ranks.
 
-N > 1: one process per GPU (torchrun), every rank compresses its own 1 GiB shard of independent units on its own
+N > 1: one process per GPU — under torchrun, or started by bench.py itself when `--gpus N` is given without a launcher — every rank compresses its own 1 GiB shard of independent units on its own
 GPU/stream; there is no data-path collective (units are independent) — torch.distributed only provides the
 barriers and the max-over-ranks time.  scaling = "weak".
 
@@ -131,27 +131,52 @@ def decode_measure(torch, zstd_amd, local, src, n, dst, sizes, steps, warmup, ba
     return dt, kms / steps, ok
 
 
-def parity_check(ctx, host, dev_out, total, sizes, level=1):
-    """bounded byte-parity vs the oracle + full-size structural properties of the GPU stream"""
+def parity_check(host, n, dev_out, total, sizes, level=1):
+    """byte parity of the GPU stream.  With oracle/_ref present: the WHOLE workload is compressed once by the real reference on all
+    host cores (zref_bench cfile) and the SHA-256 of that stream is compared with the SHA-256 of the whole GPU stream — full size.
+    Always: the first 64 units byte for byte against the C restatement, and the structure of every frame (magic at the offset the
+    size table implies, sizes add up).  `host` may be shorter than n when the workload is tiled on the device (then the full-size
+    hash is taken over what the host holds: whole units only)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import load_oracle, _buf, ERR
     lo = load_oracle()
-    nsamp = 64                                                    # first 64 units (8 MiB) byte-for-byte
+    nsamp = min(64, len(host) // UNIT)
     sample = host[: nsamp * UNIT]
-    cap = lo.zo_compress_bound(UNIT) * nsamp
+    cap = lo.zo_compress_bound(UNIT) * max(1, nsamp)
     dst = np.empty(cap, dtype=np.uint8)
-    osz = np.zeros(nsamp, dtype=np.uint64)
-    r = lo.zo_compress_chunks(level, UNIT, _buf(sample), len(sample), _buf(dst), cap, _buf(osz), nsamp)
+    osz = np.zeros(max(1, nsamp), dtype=np.uint64)
+    r = lo.zo_compress_chunks(level, UNIT, _buf(sample), len(sample), _buf(dst), cap, _buf(osz), nsamp) if nsamp else 0
     assert r != ERR
     gpu_prefix = dev_out[: int(r)].cpu().numpy()
     same = hashlib.sha256(gpu_prefix.tobytes()).hexdigest() == hashlib.sha256(dst[:r].tobytes()).hexdigest()
-    same = same and np.array_equal(sizes[:nsamp].astype(np.uint64), osz)
-    # full size: every frame starts with the zstd magic at the offset implied by the size table, sizes add up
+    same = same and np.array_equal(sizes[:nsamp].astype(np.uint64), osz[:nsamp])
     offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
-    import torch
     idx = torch.from_numpy(offs[:-1]).to(dev_out.device)
     magic_ok = bool(((dev_out[idx] == 0x28) & (dev_out[idx + 1] == 0xB5) & (dev_out[idx + 2] == 0x2F) & (dev_out[idx + 3] == 0xFD)).all())
-    return {"bytes_identical_to_oracle_first_64_units": bool(same), "frames_well_formed": magic_ok and int(offs[-1]) == int(total)}
+    res = {"bytes_identical_to_oracle_first_64_units": bool(same), "frames_well_formed": magic_ok and int(offs[-1]) == int(total)}
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if os.path.exists(exe) and level < 5:      # levels >= 5: the reference's default matcher (row hash) is not the mode the device reproduces
+        full = min(len(host), n) // UNIT * UNIT if len(host) < n else min(len(host), n)
+        tin, tout = f"/tmp/zhip_parity_in_{os.getpid()}.bin", f"/tmp/zhip_parity_out_{os.getpid()}.bin"
+        try:
+            host[:full].tofile(tin)
+            info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(UNIT), tin, tout, str(os.cpu_count() or 1)], timeout=300))
+            h = hashlib.sha256()
+            with open(tout, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            nu = (full + UNIT - 1) // UNIT
+            glen = int(offs[nu])
+            g = hashlib.sha256(dev_out[:glen].cpu().numpy().tobytes()).hexdigest()
+            res["full_size"] = {"sha256_equals_reference_stream": bool(g == h.hexdigest() and glen == info["csize"]), "source_bytes": int(full),
+                                "compressed_bytes": glen, "units": int(nu), "sha256": g,
+                                "reference": f"oracle/_ref/zref_bench cfile = ZSTD_compress2 per unit on {info['threads']} host threads, {info['seconds']} s"}
+        finally:
+            for t in (tin, tout):
+                if os.path.exists(t):
+                    os.unlink(t)
+    return res
 
 
 def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
@@ -284,76 +309,48 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
         dist.barrier(); dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mib", type=int, default=1024, help="source MiB per GPU (default = the 1 GiB of configs[1])")
-    ap.add_argument("--level", type=int, default=1)
-    ap.add_argument("--workload", choices=["datagen", "silesia", "text", "records"], default="datagen",
-                    help="datagen = BASELINE configs[1] (default); silesia / text / records = synthetic stand-ins for configs[2] / [3] / [4]")
-    ap.add_argument("--raw-dict", action="store_true", help="records: use the first ~110 KB of records as a raw-content dictionary instead of the trained fixture")
-    ap.add_argument("--base-records", type=int, default=50000, help="records: distinct ~1.2 KB records generated on the host before tiling to --mib")
-    ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
-    ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
-    ap.add_argument("--mode", choices=["compress", "decode"], default="compress",
-                    help="decode: the headline value is the DECODER's throughput on the frames the compressor just made (same workload, same units)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
-    args = ap.parse_args()
-
-    import torch
-    import zstd_amd
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: zstd_amd has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    if args.workload == "records":
-        return records_main(args, torch, zstd_amd, dev, local, rank, world, dist)
+def make_workload(torch, zstd_amd, dev, workload, rank, world, mib, copies, total_bytes):
+    """-> (host array for the CPU legs, device source tensor, n, description, scaling)"""
     scaling = "weak"
-    if args.workload == "datagen":
-        n = args.mib << 20
+    if workload == "datagen":
+        n = mib << 20
         host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)        # `datagen -g<n> -P50 -s<rank>`
         src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
         src[:n].copy_(torch.from_numpy(host))
-        wdesc = f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)"
-    else:
-        from zstd_amd import workloads as W
-        if args.workload == "silesia":                                      # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in
-            base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
-            n = len(base) * args.copies
-            wdesc = f"Silesia-shaped synthetic mix ({len(base)} B: text / structured / tables / runs / incompressible, zstd_amd/workloads.py) x{args.copies} copies"
-        else:                                                               # configs[3]: enwik9 is not on disk -> Zipf word-salad text
-            base = W.text_corpus(64 << 20, seed=rank)
-            if args.total_bytes:
-                n = args.total_bytes // world                               # frame-per-shard: a fixed total cut into one shard per GPU
-                scaling = "strong"
-            else:
-                n = args.mib << 20
-            wdesc = f"Zipf word-salad text (64 MiB generated, tiled to {n} B per GPU, zstd_amd/workloads.py), enwik9 stand-in"
-        bdev = torch.from_numpy(base).to(dev)
-        src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
-        pos, c, L = 0, 0, len(base)
-        while pos < n:                                                      # copy c starts at offset c*9973: units of different copies differ
-            s0 = (c * 9973) % L
-            for a0, a1 in ((s0, L), (0, s0)):
-                take = min(a1 - a0, n - pos)
-                if take > 0:
-                    src[pos:pos + take].copy_(bdev[a0:a0 + take]); pos += take
-            c += 1
-        del bdev
-        host = base[: min(len(base), n)]
+        return host, src, n, f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)", scaling
+    from zstd_amd import workloads as W
+    if workload == "silesia":                                               # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in
+        base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
+        n = len(base) * copies
+        wdesc = f"Silesia-shaped synthetic mix ({len(base)} B: text / structured / tables / runs / incompressible, zstd_amd/workloads.py) x{copies} copies"
+    else:                                                                   # configs[3]: enwik9 is not on disk -> Zipf word-salad text
+        base = W.text_corpus(64 << 20, seed=rank)
+        if total_bytes:
+            n = total_bytes // world                                        # frame-per-shard: a fixed total cut into one shard per GPU
+            scaling = "strong"
+        else:
+            n = mib << 20
+        wdesc = f"Zipf word-salad text (64 MiB generated, tiled to {n} B per GPU, zstd_amd/workloads.py), enwik9 stand-in"
+    bdev = torch.from_numpy(base).to(dev)
+    src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    pos, c, L = 0, 0, len(base)
+    while pos < n:                                                          # copy c starts at offset c*9973: units of different copies differ
+        s0 = (c * 9973) % L
+        for a0, a1 in ((s0, L), (0, s0)):
+            take = min(a1 - a0, n - pos)
+            if take > 0:
+                src[pos:pos + take].copy_(bdev[a0:a0 + take]); pos += take
+        c += 1
+    del bdev
+    host = src[:n].cpu().numpy() if n <= (3 << 30) else base[: min(len(base), n)]     # the CPU legs see exactly what the device compresses
+    return host, src, n, wdesc, scaling
+
+
+def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload, level, steps, warmup, copies, total_bytes,
+                 want_decode, want_pipelined, want_cpu, cpu_seconds=8.0):
+    """one workload through the device pipeline: K timed steps bracketed by barrier + synchronize, max over ranks; rank 0 returns the
+    JSON object (contract fields + roofline + pipeline + parity + cpu_baseline [+ decode, pipelined]), other ranks None"""
+    host, src, n, wdesc, scaling = make_workload(torch, zstd_amd, dev, workload, rank, world, args.mib, copies, total_bytes)
     units = (n + UNIT - 1) // UNIT
     cap = zstd_amd.compress_bound(n, UNIT)
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
@@ -361,20 +358,20 @@ def main():
     ctx = zstd_amd.Context(local, max_units=units)
 
     def step():
-        return ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+        return ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, UNIT, usz.data_ptr())
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         total = step()
     barrier()
     t0 = time.perf_counter()
     kparse = kent = kgat = ktot = 0.0
     hc = {"chain_ms": 0.0, "search_ms": 0.0, "parse_ms": 0.0}
-    for _ in range(args.steps):
+    for _ in range(steps):
         total = step()
         tm = ctx.timing()
         kparse += tm["parse_ms"]; kent += tm["entropy_ms"]; kgat += tm["gather_ms"]; ktot += tm["total_ms"]
@@ -394,46 +391,47 @@ def main():
 
     sizes_all = usz.cpu().numpy()
     ddt, dkms, dok = (None, None, None)
-    if args.mode == "decode" or world == 1:
-        dsteps = args.steps if args.mode == "decode" else max(2, min(args.steps, 4))
-        ddt, dkms, dok = decode_measure(torch, zstd_amd, local, src, n, dst, sizes_all, dsteps, args.warmup if args.mode == "decode" else 1, barrier)
+    if want_decode:
+        dsteps = steps if args.mode == "decode" else max(2, min(steps, 4))
+        ddt, dkms, dok = decode_measure(torch, zstd_amd, local, src, n, dst, sizes_all, dsteps, warmup if args.mode == "decode" else 1, barrier)
         if dist is not None:
             tt = torch.tensor([ddt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ddt = float(tt.item())
+    out = None
     if rank == 0:
         st = ctx.stats()
         sizes = sizes_all
-        K = args.steps
+        K = steps
         ms_step = dt / K * 1e3
         parse_ms, ent_ms, gat_ms, tot_ms = kparse / K, kent / K, kgat / K, ktot / K
         # algorithmic bytes: the unit is read once (S) and its result written once.  For the match
         # finder alone the result is the 8-byte sequence records; for the pipeline it is the compressed stream (C).
         parse_bytes = n + 8 * st["sequences"] + st["literals"]
         achieved = parse_bytes / (parse_ms * 1e-3) / 1e9
-        traffic = None
+        cp = zstd_amd.get_cparams(level, UNIT)
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_parse_fast_hbm_bytes_per_launch")
+        if os.path.exists(tpath) and workload == "datagen" and level == 1 and n == (1 << 30):
+            try:                                                # PMC passes of this very configuration, committed with their summaries
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_parse_fast_hbm_bytes_per_launch")
+                tsrc = "profiles/latest_traffic.json <- " + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (not measured in this run)"))
             except Exception:
-                traffic = None
-        cp = zstd_amd.get_cparams(args.level, UNIT)
+                traffic, tsrc = None, None
         sname = {1: "ZSTD_fast", 2: "ZSTD_dfast", 3: "ZSTD_greedy (hash chain)", 4: "ZSTD_lazy (hash chain)", 5: "ZSTD_lazy2 (hash chain)"}[cp[6]]
         cpdesc = f"{sname} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} slog{cp[3]} mml{cp[4]}"
         kname = {1: "k_parse_fast", 2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
-        if cp[6] != 1:
-            traffic = None                                        # the committed counters are for the level-1 kernel
         out = {
-            "metric": f"compress_MBps_level{args.level}_{'datagenP50' if args.workload == 'datagen' else args.workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "metric": f"compress_MBps_level{level}_{'datagenP50' if workload == 'datagen' else workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"{wdesc}, level {args.level} ({cpdesc}), "
+            "config": {"workload": f"{wdesc}, level {level} ({cpdesc}), "
                                    f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
                        "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
             "ratio": round(world * n / total_all, 4),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3)},
             "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "gather_ms": round(gat_ms, 3),
                          "device_total_ms": round(tot_ms, 3), "algorithmic_bytes": n + int(total),
@@ -442,40 +440,40 @@ def main():
         }
         if cp[6] >= 3:      # the match-finder stage is three kernels; the roofline figures above are for their sum
             out["roofline"]["kernels_ms"] = {k: round(v / K, 3) for k, v in hc.items()}
-        out["parity"] = parity_check(ctx, host, dst, total, sizes, args.level)
-        if world == 1 and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384 and not args.no_pipelined_extra:
+        out["parity"] = parity_check(host, n, dst, total, sizes, level)
+        if want_pipelined and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)
             os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
             ctx2 = zstd_amd.Context(local, max_units=units)
             del os.environ["ZHIP_PIPELINE_CHUNKS"]
             for _ in range(2):
-                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, UNIT, usz.data_ptr())
             torch.cuda.synchronize(); q0 = time.perf_counter()
             for _ in range(3):
-                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, args.level, UNIT, usz.data_ptr())
+                t2 = ctx2.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, UNIT, usz.data_ptr())
             torch.cuda.synchronize(); q1 = time.perf_counter()
             out["pipelined"] = {"chunks": 4, "value": round(n / ((q1 - q0) / 3) / 1e6, 1), "unit": "MB/s", "steps": 3,
                                 "same_bytes": bool(int(t2) == int(total))}
             ctx2.close()
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if n >= (256 << 20) else host, level=args.level)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(host[: 256 << 20] if len(host) >= (256 << 20) else host, seconds=cpu_seconds, level=level)
         if ddt is not None:
-            dK = args.steps if args.mode == "decode" else max(2, min(args.steps, 4))
+            dK = steps if args.mode == "decode" else max(2, min(steps, 4))
             dbytes = n + int(total)                             # algorithmic bytes of k_decode: the frames in, their content out
             dtraffic = None
-            if os.path.exists(tpath) and args.workload == "datagen" and args.level == 1 and n == (1 << 30):
+            if traffic is not None:
                 try:
-                    dtraffic = json.load(open(tpath)).get("k_decode_hbm_bytes_per_launch")      # PMC passes of this very configuration
+                    dtraffic = json.load(open(tpath)).get("k_decode_hbm_bytes_per_launch")
                 except Exception:
                     dtraffic = None
-            dec = {"metric": f"decompress_MBps_level{args.level}_{'datagenP50' if args.workload == 'datagen' else args.workload}_128KB_units",
+            dec = {"metric": f"decompress_MBps_level{level}_{'datagenP50' if workload == 'datagen' else workload}_128KB_units",
                    "value": round(world * n / ddt * dK / 1e6, 1), "unit": "MB/s", "steps": dK, "ms_per_step": round(ddt / dK * 1e3, 3),
                    "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(dbytes / (dkms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(dbytes / (dkms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": dtraffic,
+                                "frac": round(dbytes / (dkms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": dtraffic, "traffic_source": tsrc if dtraffic is not None else None,
                                 "algorithmic_bytes_per_launch": dbytes, "avg_launch_ms": round(dkms, 3)},
                    "parity": {"decoded_equals_source_full_size": dok}}
-            if not args.no_cpu_baseline and world == 1:
-                dec["cpu_baseline"] = cpu_decode_baseline(host[: 256 << 20] if n >= (256 << 20) else host, level=args.level)
+            if want_cpu and world == 1:
+                dec["cpu_baseline"] = cpu_decode_baseline(host[: 256 << 20] if len(host) >= (256 << 20) else host, level=level)
             if args.mode == "decode":                           # the decoder is the headline: same contract fields, the compressor's line rides along
                 comp_line = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "ratio", "roofline", "parity") if k in out}
                 out.update({"metric": dec["metric"], "value": dec["value"], "ms_per_step": dec["ms_per_step"], "steps": dK, "roofline": dec["roofline"],
@@ -485,6 +483,125 @@ def main():
                 out.pop("pipeline", None); out.pop("pipelined", None)
             else:
                 out["decode"] = dec
+    ctx.close()
+    del dst, usz
+    return out, (host, src, n, int(total))
+
+
+def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
+    """SURVEY.md §8(d) second timing: host buffers in, host bytes out (H2D + kernels + D2H + gather) through zhip_compress —
+    PCIe-inclusive, never `value`"""
+    units = (len(host) + UNIT - 1) // UNIT
+    ctx = zstd_amd.Context(local, max_units=units)
+    best = 1e9
+    got = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = ctx.compress(host, level=level)
+        best = min(best, time.perf_counter() - t0)
+    ctx.close()
+    return {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "best_of": 3, "source_bytes": int(len(host)),
+            "same_bytes_as_device_path": bool(len(got) == int(total_expected)),
+            "path": "zhip_compress: pageable host source -> H2D -> k_parse_fast, k_entropy, k_gather -> D2H -> host bytes (PCIe-inclusive; bounded by the two copies, not by the kernels)"}
+
+
+def stub_main(args, rank, world):
+    """ZHIP_BENCH_STUB=1: no GPU, no compression — exercises only the launch / barrier / max-over-ranks / one-line contract of the
+    N-rank path with the gloo backend (tests/test_dist_gloo.py); the line says data = "stub" and must never be read as a measurement"""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    n = 1 << 20
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = 0
+    for _ in range(args.steps):
+        acc += int(np.arange(n, dtype=np.uint8).sum())
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(world * n * args.steps / dt / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u8", "data": "stub", "config": {"workload": "stub (no GPU work)"}}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mib", type=int, default=1024, help="source MiB per GPU (default = the 1 GiB of configs[1])")
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--workload", choices=["datagen", "silesia", "text", "records"], default="datagen",
+                    help="datagen = BASELINE configs[1] (default); silesia / text / records = synthetic stand-ins for configs[2] / [3] / [4]")
+    ap.add_argument("--raw-dict", action="store_true", help="records: use the first ~110 KB of records as a raw-content dictionary instead of the trained fixture")
+    ap.add_argument("--base-records", type=int, default=50000, help="records: distinct ~1.2 KB records generated on the host before tiling to --mib")
+    ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
+    ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
+    ap.add_argument("--mode", choices=["compress", "decode"], default="compress",
+                    help="decode: the headline value is the DECODER's throughput on the frames the compressor just made (same workload, same units)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="default line only: skip the Silesia-shaped level-1 leg and the end-to-end (PCIe-inclusive) figure")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) and let rank 0 print the line
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or "1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} (launch N ranks for --gpus N, or omit the launcher)")
+    if os.environ.get("ZHIP_BENCH_STUB") == "1":
+        return stub_main(args, rank, world)
+
+    import torch
+    import zstd_amd
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: zstd_amd has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if args.workload == "records":
+        return records_main(args, torch, zstd_amd, dev, local, rank, world, dist)
+    out, (host, src, n, total) = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
+                                       args.copies, args.total_bytes, want_decode=(args.mode == "decode" or world == 1),
+                                       want_pipelined=(world == 1 and not args.no_pipelined_extra), want_cpu=not args.no_cpu_baseline)
+    default_line = (args.workload == "datagen" and args.level == 1 and args.mode == "compress" and world == 1 and not args.no_extra_legs)
+    if default_line and rank == 0:
+        # PCIe-inclusive figure of the same workload, then the metric's own data shape: Silesia-shaped mix at level 1
+        out["end_to_end"] = end_to_end_leg(torch, zstd_amd, local, host, total, args.level)
+    del src, host
+    if default_line:
+        torch.cuda.empty_cache()
+        sil, _ = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
+                              want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=6.0)
+        if rank == 0:
+            out["silesia_shaped_level1"] = {k: sil[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline") if k in sil}
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -9,6 +9,8 @@
  *        thread compresses a disjoint contiguous shard of the chunks with its own CCtx.
  *        prints one JSON line.
  *   zref_bench file   <level> <chunkSize> <path> <seconds> <threads>   : same, input read from a file
+ *   zref_bench cfile  <level> <chunkSize> <inPath> <outPath> <threads> : the file compressed ONCE, one frame per chunk, on
+ *        `threads` cores, the frames written back to back to outPath (bench.py hashes that stream: full-size parity)
  *   zref_bench dfile  <level> <chunkSize> <path> <seconds> <threads>   : DECODE speed (`zstd -b#` second figure,
  *        benchzstd.c:380-420): the file is compressed once into one frame per chunk, then ZSTD_decompressDCtx per frame on a
  *        reused DCtx is timed; threads split the frames.
@@ -229,8 +231,37 @@ static int ddict_main(char** argv)
     return 0;
 }
 
+/* cfile: compress once with T threads, write the frames in chunk order */
+static int cfile_main(char** argv)
+{
+    int const level = atoi(argv[2]); size_t const chunk = strtoull(argv[3], 0, 10);
+    int const T = atoi(argv[6]) > 0 ? atoi(argv[6]) : 1;
+    size_t total; char* src = (char*)slurp(argv[4], &total);
+    size_t const nChunks = (total + chunk - 1) / chunk, bound = ZSTD_compressBound(chunk);
+    char* dst = (char*)malloc(bound * (nChunks ? nChunks : 1));
+    job_t* jobs = (job_t*)calloc((size_t)T, sizeof(job_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    FILE* o; size_t csize = 0; int t; double const a = now_s();
+    if (!dst || !jobs || !th) return 1;
+    for (t = 0; t < T; t++) {
+        size_t const k0 = nChunks * (size_t)t / (size_t)T, k1 = nChunks * (size_t)(t + 1) / (size_t)T;
+        size_t const b0 = k0 * chunk, b1 = (k1 * chunk < total) ? k1 * chunk : total;
+        jobs[t].level = level; jobs[t].chunk = chunk; jobs[t].src = src + b0; jobs[t].n = b1 - b0;
+        jobs[t].dst = dst + k0 * bound; jobs[t].dstCap = (k1 - k0) * bound;
+        if (T == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; }
+    o = fopen(argv[5], "wb");
+    if (!o) { perror(argv[5]); return 1; }
+    for (t = 0; t < T; t++) { if (fwrite(jobs[t].dst, 1, jobs[t].csize, o) != jobs[t].csize) return 1; csize += jobs[t].csize; }
+    fclose(o);
+    printf("{\"level\": %d, \"chunk\": %zu, \"bytes\": %zu, \"csize\": %zu, \"seconds\": %.3f, \"threads\": %d}\n", level, chunk, total, csize, now_s() - a, T);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 7 && !strcmp(argv[1], "cfile")) return cfile_main(argv);
     if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
     if (argc >= 8 && !strcmp(argv[1], "ddict")) return ddict_main(argv);
     if (argc >= 7 && !strcmp(argv[1], "dfile")) return dfile_main(argv);

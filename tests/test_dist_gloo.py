@@ -75,3 +75,22 @@ def test_unit_ranges_partition():
                 assert 0 <= lo <= hi <= n_units
                 got += list(range(lo, hi))
             assert got == list(range(n_units))
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself and print ONE line with n_gpus = 2
+    (stub context: gloo, no GPU work — ZHIP_BENCH_STUB=1); a --gpus that disagrees with WORLD_SIZE must fail loudly"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ZHIP_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["data"] == "stub"
+    env["WORLD_SIZE"] = "1"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "disagrees" in (r.stderr + r.stdout)

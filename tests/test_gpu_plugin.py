@@ -115,3 +115,28 @@ def test_plugin_higher_levels_roundtrip_and_compress_better(env, level):
     assert not Z.ZSTD_isError(r)
     roundtrip(Z, a, r, dst)
     assert r < r1
+
+
+def test_plugin_reused_buffer_with_new_content_is_reparsed(env):
+    """the producer's host cache is keyed by address range — a caller that refills the SAME buffer with
+    different bytes of the same size must not be served the old parse (zstd does not validate producer sequences by
+    default, so a stale parse would silently decode to the wrong data)."""
+    Z, zstd_amd, ctx, lo = env
+    buf = datagen(lo, 4 * 65536, 50, 11).copy()
+    for prepare_first, prepare_second in ((True, False), (True, True), (False, False)):
+        r, dst = compress_with_plugin(Z, zstd_amd, ctx, buf, 1, max_block=65536, prepare=prepare_first)
+        assert not Z.ZSTD_isError(r)
+        roundtrip(Z, buf, r, dst)
+        buf[:] = datagen(lo, len(buf), 35, 12 + int(prepare_second))      # same address, same size, new content
+        cctx = Z.ZSTD_createCCtx()
+        Z.ZSTD_CCtx_setParameter(cctx, ZSTD_c_compressionLevel, 1)
+        Z.ZSTD_CCtx_setParameter(cctx, ZSTD_c_maxBlockSize, 65536)       # validateSequences stays OFF: nothing else would catch it
+        Z.ZSTD_registerSequenceProducer(cctx, ctx._h, C.cast(zstd_amd.lib().zhip_sequence_producer, C.c_void_p))
+        if prepare_second:
+            assert not zstd_amd.lib().zhip_isError(zstd_amd.lib().zhip_prepare_sequences(ctx._h, _buf(buf), len(buf), 65536, 1))
+        cap = Z.ZSTD_compressBound(len(buf))
+        dst2 = np.zeros(cap, dtype=np.uint8)
+        r2 = Z.ZSTD_compress2(cctx, _buf(dst2), cap, _buf(buf), len(buf))
+        Z.ZSTD_freeCCtx(cctx)
+        assert not Z.ZSTD_isError(r2)
+        roundtrip(Z, buf, r2, dst2)

@@ -54,7 +54,7 @@ static inline size_t host_read_ncount(int16_t* norm, unsigned* maxSym, unsigned*
         previous0 = count == 0;
         while (remaining < threshold) { nbBits--; threshold >>= 1; }
     }
-    if (remaining != 1 || charnum > maxSV1) return 0;
+    if (remaining != 1 || charnum > maxSV1 || bit > 8 * size) return 0;    // bits past the input read as zero: a table they complete is an overrun
     *maxSym = charnum - 1;
     return (bit + 7) >> 3;
 }

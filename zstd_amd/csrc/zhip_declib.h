@@ -301,32 +301,42 @@ size_t zhip_decompress(zhip_dctx* c, const zhip_ddict* dd, void* dst, size_t dst
     (void)zhip_find_frames(src, srcSize, so.data(), ss.data(), cs.data(), cb.data(), n);
     size_t const e = ensure_frames(c, n);
     if (e) return e;
-    // destination slots: the stated content size, or the frame's bound when the header does not hold it
-    uint64_t total = 0; bool exact = true;
-    for (size_t i = 0; i < n; i++) {
-        uint64_t const room = cs[i] != ~0ull ? cs[i] : cb[i];
-        if (cs[i] == ~0ull) exact = false;
-        if (room > 0xFFFFFFFFull || ss[i] > 0xFFFFFFFFull) return DERR(14);
-        ZhipDFrame f; f.srcOff = so[i]; f.dstOff = total; f.srcLen = (uint32_t)ss[i]; f.dstCap = (uint32_t)room;
-        c->hFrames[i] = f; total += room;
-    }
-    if (exact && total > dstCapacity) return DERR(70);
+    // destination slots: the stated content size, or the frame's bound when the header does not hold it — but never more than
+    // the caller's buffer could take (a hostile 1 MB input of tiny RLE blocks "bounds" to tens of GB: the reference never
+    // allocates beyond dst, neither does this), and frames without a stated size are decoded in groups of bounded staging
+    bool exact = true;
+    for (size_t i = 0; i < n; i++) if (cs[i] == ~0ull) exact = false;
     if (c->srcStageCap < srcSize + 64) { (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0; DCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64; }
-    if (c->dstStageCap < total + 64) { (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0; DCHK(c, hipMalloc((void**)&c->dDstStage, total + 64)); c->dstStageCap = total + 64; }
     DCHK(c, hipMemcpyAsync(c->dSrcStage, src, srcSize, hipMemcpyHostToDevice, c->stream));
-    size_t const r = decode_locked(c, dd, c->dDstStage, c->dSrcStage, n, nullptr, nullptr, c->stream);
-    if (zhip_isError(r)) return r;
-    if (r > dstCapacity) return DERR(70);
-    if (exact) { if (r) DCHK(c, hipMemcpy(dst, c->dDstStage, r, hipMemcpyDeviceToHost)); }
-    else {                                                      // frames without a stated size were decoded into bound-sized slots: pack
-        size_t pos = 0;
-        for (size_t i = 0; i < n; i++) {
-            size_t const sz = c->hResults[i].size;
-            if (sz) DCHK(c, hipMemcpy((uint8_t*)dst + pos, c->dDstStage + c->hFrames[i].dstOff, sz, hipMemcpyDeviceToHost));
-            pos += sz;
+    uint64_t const budget = exact ? ~0ull : (2 * (uint64_t)dstCapacity > ((uint64_t)1 << 20) ? 2 * (uint64_t)dstCapacity : ((uint64_t)1 << 20));
+    size_t pos = 0, i0 = 0;
+    while (i0 < n) {
+        uint64_t total = 0; size_t g = 0;
+        while (i0 + g < n) {
+            size_t const i = i0 + g;
+            uint64_t room = cs[i] != ~0ull ? cs[i] : cb[i];
+            if (cs[i] == ~0ull && room > dstCapacity) room = dstCapacity;          // a frame that needs more gets dstSize_tooSmall from the kernel
+            if (room > 0xFFFFFFFFull || ss[i] > 0xFFFFFFFFull) return DERR(14);
+            if (g && total + room > budget) break;
+            ZhipDFrame f; f.srcOff = so[i]; f.dstOff = total; f.srcLen = (uint32_t)ss[i]; f.dstCap = (uint32_t)room;
+            c->hFrames[g] = f; total += room; g++;
         }
+        if (exact && total > dstCapacity) return DERR(70);
+        if (c->dstStageCap < total + 64) { (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0; DCHK(c, hipMalloc((void**)&c->dDstStage, total + 64)); c->dstStageCap = total + 64; }
+        size_t const r = decode_locked(c, dd, c->dDstStage, c->dSrcStage, g, nullptr, nullptr, c->stream);
+        if (zhip_isError(r)) return r;
+        if (r > dstCapacity - pos) return DERR(70);
+        if (exact) { if (r) DCHK(c, hipMemcpy((uint8_t*)dst + pos, c->dDstStage, r, hipMemcpyDeviceToHost)); pos += r; }
+        else {                                                  // bound-sized slots: pack
+            for (size_t k = 0; k < g; k++) {
+                size_t const sz = c->hResults[k].size;
+                if (sz) DCHK(c, hipMemcpy((uint8_t*)dst + pos, c->dDstStage + c->hFrames[k].dstOff, sz, hipMemcpyDeviceToHost));
+                pos += sz;
+            }
+        }
+        i0 += g;
     }
-    return r;
+    return pos;
 }
 
 }  // extern "C"

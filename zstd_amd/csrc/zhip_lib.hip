@@ -55,6 +55,7 @@ struct zhip_ctx_s {
     size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
+    std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
     std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
     std::mutex mu;
     char err[256];
@@ -736,6 +737,23 @@ extern "C" void zhip_prof_read(unsigned long long out[32], int reset)
 #endif
 
 // ------------------------------------------------------------------ block-level plugin (B1)
+// content fingerprint of a prepared block (two independent multiply-xor lanes over 8-byte words): a cached parse is only
+// served when the bytes at that address are still the bytes that were parsed — callers refill and reuse buffers
+static void block_fingerprint(const uint8_t* p, size_t n, uint64_t out[2])
+{
+    uint64_t a = 0x9E3779B97F4A7C15ull ^ n, b = 0xC2B2AE3D27D4EB4Full + n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w; memcpy(&w, p + i, 8);
+        a = (a ^ w) * 0xFF51AFD7ED558CCDull; a ^= a >> 32;
+        b = (b + w) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 29;
+    }
+    uint64_t w = 0; memcpy(&w, p + i, n - i);
+    a = (a ^ w) * 0xFF51AFD7ED558CCDull; a ^= a >> 33;
+    b = (b + w) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 31;
+    out[0] = a; out[1] = b;
+}
+
 // parse `srcSize` host bytes cut into blockSize blocks (each without history); results copied to the host cache
 static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
 {
@@ -764,6 +782,9 @@ static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_
         pos += ns;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cacheHash.resize(2 * nUnits);
+    for (size_t i = 0; i < nUnits; i++)
+        block_fingerprint((const uint8_t*)src + c->hUnits[i].srcOff, c->hUnits[i].srcLen, &c->cacheHash[2 * i]);
     c->cacheSrc = src; c->cacheSize = srcSize; c->cacheBlock = blockSize; c->cacheLevel = level;
     c->nUnits = nUnits;
     return nUnits;
@@ -794,6 +815,11 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
                && ((size_t)(p - base) % c->cacheBlock) == 0;
     size_t idx = hit ? (size_t)(p - base) / c->cacheBlock : 0;
     if (hit && c->cacheUnits[idx].srcLen != srcSize) hit = false;
+    if (hit) {                                   // same address range is not enough: the bytes must be the ones that were parsed
+        uint64_t fp[2]; block_fingerprint(p, srcSize, fp);
+        if (fp[0] != c->cacheHash[2 * idx] || fp[1] != c->cacheHash[2 * idx + 1]) hit = false;
+    }
+    bool const oneShot = !hit;
     if (!hit) {                                  // not prepared: one launch for this block (latency-bound path)
         size_t const r = prepare_locked(c, src, srcSize, srcSize, compressionLevel);
         if (zhip_isError(r)) return ZHIP_SEQUENCE_PRODUCER_ERROR;
@@ -802,6 +828,7 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
     size_t pos = 0;
     for (size_t i = 0; i < idx; i++) pos += c->cacheParse[i].nbSeq;
     size_t const r = seqs_to_public(c->cacheSeqs.data() + pos, c->cacheParse[idx], outSeqs, outSeqsCapacity);
+    if (oneShot) c->cacheSrc = nullptr;          // the unprepared path never leaves a cache behind
     return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
 }
 
