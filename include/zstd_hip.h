@@ -168,9 +168,18 @@ void         zhip_last_hc_timing(zhip_ctx* ctx, double t[3]);
 /* stats[0] units, [1] source bytes, [2] compressed bytes, [3] sequences, [4] literal bytes of the most recent call */
 size_t       zhip_last_stats(zhip_ctx* ctx, unsigned long long stats[5]);
 
-/* ---- synthetic input = programs/datagen.c (RDG_genBuffer :144 when streamMode == 0, RDG_genStdout :155 i.e.
- * `datagen -g<size> -P<pct> -s<seed>` when streamMode == 1).  Host buffer. */
-void         zhip_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed, int streamMode);
+/* ---- stage-test hooks (tests/test_gpu_tables.py): the device's wave-wide entropy-table builders run on caller-supplied
+ * histograms, one 64-thread workgroup per case, so that each stage can be compared with the reference's own stage function —
+ * HUF_buildCTable_wksp + HUF_writeCTable_wksp (lib/compress/huf_compress.c:756, :248) and FSE_normalizeCount + FSE_writeNCount +
+ * FSE_buildCTable_wksp (lib/compress/fse_compress.c:465, :329, :68).  Host buffers; 0 or an error code.
+ *   huf: counts[nCases][256], maxSyms[nCases] -> codes[nCases][256] (value << 8 | nbBits), hdrs[nCases][136], meta[nCases][2] = {tableLog, header size}
+ *   fse: counts[nCases][64], params[nCases][4] = {total, maxSym, tableLog, useLowProbCount} -> norms[nCases][64], ncounts[nCases][64],
+ *        meta[nCases][2] = {normalize result 1 / 0 (single symbol) / -1, NCount size}, tables[nCases] of tableStride bytes each:
+ *        {u16 state[512]; i32 deltaFindState[56]; u32 deltaNbBits[56]; u32 tableLog} */
+size_t       zhip_test_huf_tables(zhip_ctx* ctx, const unsigned* counts, const unsigned* maxSyms, unsigned nCases, unsigned maxNbBits,
+                                  unsigned* codes, unsigned char* hdrs, unsigned* meta);
+size_t       zhip_test_fse_tables(zhip_ctx* ctx, const unsigned* counts, const unsigned* params, unsigned nCases,
+                                  short* norms, unsigned char* ncounts, int* meta, void* tables, size_t tableStride);
 
 #ifdef __cplusplus
 }

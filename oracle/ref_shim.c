@@ -338,4 +338,31 @@ size_t zref_fse_write_ncount(void* dst, size_t cap, const short* norm, unsigned 
     return FSE_isError(r) ? (size_t)-1 : r;
 }
 
+/* HUF_buildCTable_wksp + HUF_writeCTable_wksp: the tree description the literals section starts with (huf_compress.c:248-289) */
+size_t zref_huf_write_table(void* dst, size_t cap, const unsigned* count, unsigned maxSym, unsigned maxNbBits, unsigned* logOut)
+{
+    HUF_CREATE_STATIC_CTABLE(ct, 255);
+    static unsigned wksp[HUF_WORKSPACE_SIZE_U64 * 2];
+    size_t const log = HUF_buildCTable_wksp(ct, count, maxSym, maxNbBits, wksp, sizeof(wksp));
+    size_t r;
+    if (HUF_isError(log)) return (size_t)-1;
+    *logOut = (unsigned)log;
+    r = HUF_writeCTable_wksp(dst, cap, ct, maxSym, (unsigned)log, wksp, sizeof(wksp));
+    return HUF_isError(r) ? (size_t)-1 : r;
+}
+/* FSE_buildCTable_wksp (fse_compress.c:68-214): the state table and the per-symbol transforms of the encoding table */
+size_t zref_fse_build_ctable(unsigned short* stateOut, int* dFind, unsigned* dBits, const short* norm, unsigned maxSym, unsigned tableLog)
+{
+    static unsigned ct[FSE_CTABLE_SIZE_U32(12, 255)];
+    static unsigned wksp[FSE_BUILD_CTABLE_WORKSPACE_SIZE_U32(255, 12)];
+    unsigned const tableSize = 1u << tableLog; unsigned s;
+    size_t const r = FSE_buildCTable_wksp(ct, norm, maxSym, tableLog, wksp, sizeof(wksp));
+    if (FSE_isError(r)) return (size_t)-1;
+    memcpy(stateOut, ((const unsigned short*)ct) + 2, tableSize * 2);
+    {   const FSE_symbolCompressionTransform* const tt = (const FSE_symbolCompressionTransform*)(ct + 1 + (tableLog ? tableSize >> 1 : 1));
+        for (s = 0; s <= maxSym; s++) { dFind[s] = tt[s].deltaFindState; dBits[s] = tt[s].deltaNbBits; }
+    }
+    return 0;
+}
+
 unsigned zref_version(void) { return ZSTD_versionNumber(); }

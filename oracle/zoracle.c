@@ -748,7 +748,8 @@ static uint32_t fse_encode(zo_bits* b, const zo_fse* ct, uint32_t state, unsigne
 /* ------------------------------------------------------------------ Huffman */
 typedef struct { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; } zo_node;
 
-static unsigned huf_bucket(uint32_t c) { return c < 166 ? c : hb32(c) + 158; }   /* huf_compress.c:530 */
+/* huf_compress.c:524-533: RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) = 165 (the reference's comment says 166) */
+static unsigned huf_bucket(uint32_t c) { return c < 165 ? c : hb32(c) + 158; }
 
 static void huf_isort(zo_node* a, int low, int high)                             /* :555 */
 {
@@ -789,7 +790,7 @@ static void huf_sort(zo_node* node, const unsigned* count, unsigned maxSym)
         unsigned const pos = rp[r].curr++;
         node[pos].count = count[n]; node[pos].byte = (uint8_t)n;
     }
-    for (n = 166; n < 191; n++) {
+    for (n = 165; n < 191; n++) {       /* from the cutoff: rp[165] holds the symbols whose count is exactly 164 */
         int const sz = rp[n].curr - rp[n].base;
         if (sz > 1) huf_qsort(node + rp[n].base, 0, sz - 1);
     }

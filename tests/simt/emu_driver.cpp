@@ -160,4 +160,16 @@ uint32_t emu_seq_cap(void) { return ZHIP_SEQ_CAP; }
 uint32_t emu_sizeof_unit(void) { return sizeof(ZhipUnit); }
 uint32_t emu_sizeof_parse(void) { return sizeof(ZhipParse); }
 
+
+// stage hooks: the wave-wide table builders on caller-supplied histograms (one case per workgroup)
+void emu_test_huf(const uint32_t* counts, const uint32_t* maxSyms, uint32_t nCases, uint32_t maxNbBits, uint32_t* codes, uint8_t* hdrs, uint32_t* meta)
+{
+    simt::launch({nCases, 1, 1}, {64, 1, 1}, sizeof(zhip::ZhipTestHufShared), [=] { zhip::k_test_huf(counts, maxSyms, maxNbBits, codes, hdrs, meta); }, 0);
+}
+void emu_test_fse(const uint32_t* counts, const uint32_t* params, uint32_t nCases, int16_t* norms, uint8_t* ncounts, int32_t* meta, zhip::FseCTable* tables)
+{
+    simt::launch({nCases, 1, 1}, {64, 1, 1}, sizeof(zhip::ZhipTestFseShared), [=] { zhip::k_test_fse(counts, params, norms, ncounts, meta, tables); }, 0);
+}
+uint32_t emu_sizeof_fse_ctable(void) { return (uint32_t)sizeof(zhip::FseCTable); }
+
 }

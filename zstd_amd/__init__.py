@@ -54,8 +54,6 @@ def lib():
         L.zhip_last_hc_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.zhip_last_stats.restype = C.c_size_t
         L.zhip_last_stats.argtypes = [C.c_void_p, C.c_void_p]
-        L.zhip_datagen.restype = None
-        L.zhip_datagen.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint, C.c_int]
         for name, res, args in [
             ("zhip_compress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]),
             ("zhip_compress_device", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -101,10 +99,21 @@ def compress_bound(src_size, unit_size=UNIT_SIZE_MAX):
     return lib().zhip_compressBound(src_size, unit_size)
 
 
+_WL = None
+
+
 def datagen(size, match_pct=50, seed=0, stream_mode=True, lit_proba=0.0):
-    """programs/datagen.c restated on the host (zstd_amd/csrc/zhip_datagen.h): `datagen -g<size> -P<pct> -s<seed>`"""
+    """bench / test input: programs/datagen.c restated on the host (zstd_amd/workloads_src/zhip_datagen.h, built into
+    libzhip_workloads.so — not part of the product library): `datagen -g<size> -P<pct> -s<seed>`"""
+    global _WL
+    if _WL is None:
+        from . import build as _b
+        _b.build()
+        _WL = C.CDLL(_b.WORKLOADS)
+        _WL.zhip_wl_datagen.restype = None
+        _WL.zhip_wl_datagen.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_uint, C.c_int]
     a = np.empty(max(size, 1), dtype=np.uint8)
-    lib().zhip_datagen(a.ctypes.data_as(C.c_void_p), size, match_pct / 100.0, lit_proba, seed, 1 if stream_mode else 0)
+    _WL.zhip_wl_datagen(a.ctypes.data_as(C.c_void_p), size, match_pct / 100.0, lit_proba, seed, 1 if stream_mode else 0)
     return a[:size]
 
 

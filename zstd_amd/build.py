@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzstd_hip.so")
 SHIM = os.path.join(HERE, "libzstd_hipshim.so")      # ZSTD_*-named drop-in (plain C) on top of LIB
+WORKLOADS = os.path.join(HERE, "libzhip_workloads.so")   # bench / test input generators (host C++, NOT part of the product library)
 
 
 def _stale(target, deps):
@@ -35,6 +36,13 @@ def build(force=False, verbose=False):
     if force or _stale(SHIM, [shim_src, LIB, os.path.join(HERE, "..", "include", "zstd_hip_dropin.h")]):
         cmd = [os.environ.get("CC", "gcc"), "-O2", "-std=c99", "-Wall", "-Wextra", "-fPIC", "-shared", shim_src, "-o", SHIM,
                "-L" + HERE, "-lzstd_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    wl_dir = os.path.join(HERE, "workloads_src")
+    wl_src = [os.path.join(wl_dir, f) for f in sorted(os.listdir(wl_dir))]
+    if force or _stale(WORKLOADS, wl_src):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", os.path.join(wl_dir, "workloads_lib.cpp"), "-o", WORKLOADS]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -139,16 +139,15 @@ static inline size_t host_load_entropy(HostCDict& cd, const uint8_t* dict, size_
 {
     const uint8_t* p = dict + 8; const uint8_t* const dEnd = dict + dictSize;
     int16_t ofN[32], mlN[53], llN[36]; unsigned ofMax = 31, ofLog, mlMax = 52, mlLog, llMax = 35, llLog; size_t h;
-    uint8_t scratch[512]; uint16_t cumul[64];
     memcpy(&cd.dictID, dict + 4, 4);
     h = host_read_huf(cd.ent, p, (size_t)(dEnd - p)); if (!h) return 0; p += h;
     h = host_read_ncount(ofN, &ofMax, &ofLog, p, (size_t)(dEnd - p)); if (!h || ofLog > 8) return 0; p += h;
-    fse_build_ctable(&cd.ent.ct[1], ofN, 31, ofLog, scratch, cumul);                 // all offset symbols (MaxOff)
+    fse_build_ctable_host(&cd.ent.ct[1], ofN, 31, ofLog);                 // all offset symbols (MaxOff)
     h = host_read_ncount(mlN, &mlMax, &mlLog, p, (size_t)(dEnd - p)); if (!h || mlLog > 9) return 0; p += h;
-    fse_build_ctable(&cd.ent.ct[2], mlN, mlMax, mlLog, scratch, cumul);
+    fse_build_ctable_host(&cd.ent.ct[2], mlN, mlMax, mlLog);
     cd.ent.fseRepeat[2] = host_ncount_repeat(mlN, mlMax, 52);
     h = host_read_ncount(llN, &llMax, &llLog, p, (size_t)(dEnd - p)); if (!h || llLog > 9) return 0; p += h;
-    fse_build_ctable(&cd.ent.ct[0], llN, llMax, llLog, scratch, cumul);
+    fse_build_ctable_host(&cd.ent.ct[0], llN, llMax, llLog);
     cd.ent.fseRepeat[0] = host_ncount_repeat(llN, llMax, 35);
     if (p + 12 > dEnd) return 0;
     memcpy(cd.rep, p, 12); p += 12;

@@ -72,6 +72,7 @@ struct EntShared {
     alignas(8) uint16_t chainTile[3][256];   // LDS window of the code / state-record arrays while a chain walks it
     uint16_t cumul[3][64];
     uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
+    uint32_t ncWords[3][16];      // their bit-level assembly area (fse_write_ncount_wave)
     uint32_t ncountSize[3];
     uint32_t encType[3];          // set_basic 0 / set_rle 1 / set_compressed 2 / set_repeat 3 (zstd_internal.h:102)
     uint32_t maxCode[3];
@@ -300,76 +301,76 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     __syncthreads();
     ZPROF(0);
 
-    // ================ phase B (four single lanes, concurrently): wave 0 builds the literals code, waves 1..3 select
-    // and build one sequence table each (LL, OF, ML) and then run that table's state chain
-    if (lane == 0 && wv == 0) {
+    // ================ phase B (four wavefronts, concurrently): wave 0 decides the literals mode and builds the Huffman code,
+    // waves 1..3 select and build one sequence table each (LL, OF, ML) and then run that table's state chain.  The table
+    // builders of zhip_tables.h are wave-wide: one lane per symbol, all decisions wave-uniform.
+    if (wv == 0) {
         // literals (zstd_compress_literals.c:129-235 with no previous table)
         ZPROF_JOB_BEGIN
         bool tryHuf = tryHuf0;
         if (sampling) {
             uint32_t a = 0, b = 0;
-            for (int s = 0; s < 256; s++) { if (sh->sampleHist[0][s] > a) a = sh->sampleHist[0][s]; if (sh->sampleHist[1][s] > b) b = sh->sampleHist[1][s]; }
+            for (int s0 = lane; s0 < 256; s0 += 64) { if (sh->sampleHist[0][s0] > a) a = sh->sampleHist[0][s0]; if (sh->sampleHist[1][s0] > b) b = sh->sampleHist[1][s0]; }
+            a = tw_max(a); b = tw_max(b);
             if (a + b <= ((2 * 4096) >> 7) + 4) tryHuf = false;
         }
-        uint32_t mode = 0;      // raw
-        sh->hufHdrSize = 0; sh->litType = 2;
+        uint32_t mode = 0, hdrSize = 0, litType = 2, logOut = 0;      // raw
         // HUF_compress_internal (huf_compress.c:1333-1434) with the dictionary's table as the previous one when there is one
         uint32_t rep = hufRep0;
         bool const preferRepeat = u.strategy < ZHIP_STRAT_LAZY && litSize <= 1024;   // zstd_compress_literals.c:165
         bool useOld = false;
         if (tryHuf0 && preferRepeat && rep == 2) { mode = 2; useOld = true; }        // :1359-1363 valid table, small input: no statistics at all
         else if (tryHuf) {
-            uint32_t maxSym = 255, largest = 0;
-            while (!sh->hist[0][maxSym]) maxSym--;
-            for (uint32_t s = 0; s <= maxSym; s++) if (sh->hist[0][s] > largest) largest = sh->hist[0][s];
+            uint32_t hq[4], big = 0, topSym = 0;
+            for (int q = 0; q < 4; q++) { hq[q] = sh->hist[0][lane + 64 * q]; if (hq[q] > big) big = hq[q]; if (hq[q]) topSym = (uint32_t)(lane + 64 * q) + 1; }
+            uint32_t const maxSym = tw_max(topSym) - 1, largest = tw_max(big);
             if (largest == litSize) mode = 1;                                        // huf_compress.c:1383 -> RLE literals
             else if (largest <= (litSize >> 7) + 4) mode = 0;                        // :1384
             else {
                 if (rep == 1) {                                                      // :1389-1393 HUF_validateCTable
-                    bool bad = de->hufMaxSym < maxSym;
-                    for (uint32_t s = 0; s <= maxSym && !bad; s++) bad = sh->hist[0][s] != 0 && (de->hufCode[s] & 0xFF) == 0;
-                    if (bad) rep = 0;
+                    bool miss = false;
+                    for (int q = 0; q < 4; q++) { uint32_t const sy = (uint32_t)(lane + 64 * q); miss = miss || (sy <= maxSym && hq[q] != 0 && (de->hufCode[sy] & 0xFF) == 0); }
+                    if (de->hufMaxSym < maxSym || __ballot(miss)) rep = 0;
                 }
                 if (preferRepeat && rep != 0) { mode = 2; useOld = true; }           // :1395-1399
                 else {
                     uint32_t huffLog = fse_optimal_table_log(11, litSize, maxSym, 1);    // :1284-1287
                     ZPROF_JOB_MARK(31);
-                    huffLog = huf_build_codes(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
+                    huffLog = huf_build_codes_wave(&sh->huf, sh->hist[0], maxSym, huffLog, sh->code);
                     ZPROF_JOB_MARK(28);
-                    uint32_t const h = huf_write_table(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
+                    uint32_t const h = huf_write_table_wave(&sh->huf, sh->hufHdr, sh->code, maxSym, huffLog);
                     if (h != 0 && rep != 0) {                                        // :1415-1421 is the previous table cheaper?
                         uint32_t oldSize = 0, newSize = 0;
-                        for (uint32_t s = 0; s <= maxSym; s++) { oldSize += (de->hufCode[s] & 0xFF) * sh->hist[0][s]; newSize += (sh->code[s] & 0xFF) * sh->hist[0][s]; }
+                        for (int q = 0; q < 4; q++) { uint32_t const sy = (uint32_t)(lane + 64 * q); if (sy <= maxSym) { oldSize += (de->hufCode[sy] & 0xFF) * hq[q]; newSize += (sh->code[sy] & 0xFF) * hq[q]; } }
+                        oldSize = tw_sum(oldSize); newSize = tw_sum(newSize);
                         if ((oldSize >> 3) <= h + (newSize >> 3) || h + 12 >= litSize) { mode = 2; useOld = true; }
                     }
-                    if (!useOld && h != 0 && h + 12 < litSize) { mode = 2; sh->hufHdrSize = h; sh->huffLog = huffLog; }   // :1425
+                    if (!useOld && h != 0 && h + 12 < litSize) { mode = 2; hdrSize = h; logOut = huffLog; }   // :1425
                 }
             }
         }
-        if (useOld) { sh->hufHdrSize = 0; sh->litType = 3; }                 // set_repeat: treeless literals; the wave copies the code below
-        sh->litMode = mode;
-        ZPROF_JOB_MARK(31);
-    }
-    if (wv == 0 && de) {                     // the dictionary's Huffman code, copied by the whole wavefront when lane 0 chose it
+        if (useOld) { hdrSize = 0; litType = 3; }                            // set_repeat: treeless literals, the dictionary's code
+        if (lane == 0) { sh->hufHdrSize = hdrSize; sh->litType = litType; sh->huffLog = logOut; sh->litMode = mode; }
         __builtin_amdgcn_wave_barrier();
-        if (sh->litMode == 2 && sh->litType == 3) for (int s = lane; s < 256; s += 64) sh->code[s] = de->hufCode[s];
+        if (de && mode == 2 && litType == 3) for (int s0 = lane; s0 < 256; s0 += 64) sh->code[s0] = de->hufCode[s0];
+        ZPROF_JOB_MARK(31);
     }
     if (wv >= 1 && nbSeq > 0) {
         int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
         uint16_t* const arr = stBits + (size_t)k * seqCap;
         uint32_t const lastCode = arr[nbSeq - 1];                  // for the "-1" rule (zstd_compress_sequences.c:271-274)
         ZPROF_JOB_BEGIN
-        if (lane == 0) {
+        {
             uint32_t const maxPossible = (k == 0) ? 35 : (k == 1 ? 31 : 52);
             uint32_t const defLog = (k == 1) ? 5 : 6, fseLog = (k == 1) ? 8 : 9;
             uint32_t const defMax = (k == 0) ? 35 : (k == 1 ? 28 : 52);
             const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
             uint32_t* cnt = sh->seqCount[k];
-            uint32_t max = maxPossible, mostFrequent = 0;
-            while (!cnt[max]) max--;
-            for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
+            uint32_t const myCnt = (uint32_t)lane <= maxPossible ? cnt[lane] : 0;        // lane = code
+            uint32_t const max = 63u - (uint32_t)__clzll((long long)__ballot(myCnt != 0));
+            uint32_t const mostFrequent = tw_max(myCnt);
             bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
-            // ZSTD_selectEncodingType, strategy < lazy, no repeat (zstd_compress_sequences.c:157-235)
+            // ZSTD_selectEncodingType (zstd_compress_sequences.c:157-235)
             uint32_t type;
             uint32_t hsz = 0; bool fail = false;
             if (mostFrequent == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
@@ -387,47 +388,47 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                 uint64_t basicCost = ~0ull;
                 if (defaultAllowed) {                                                  // :141-155 ZSTD_crossEntropyCost
                     uint32_t const shift = 8 - defLog;
-                    uint64_t cost = 0;
-                    for (uint32_t s = 0; s <= max; s++) {
-                        uint32_t const normAcc = defNorm[s] != -1 ? (uint32_t)defNorm[s] : 1;
-                        cost += (uint64_t)cnt[s] * kInvProbLog256[normAcc << shift];
-                    }
-                    basicCost = cost >> 8;
+                    uint32_t mine = 0;
+                    if ((uint32_t)lane <= max) { uint32_t const normAcc = defNorm[lane] != -1 ? (uint32_t)defNorm[lane] : 1; mine = myCnt * kInvProbLog256[normAcc << shift]; }
+                    basicCost = tw_sum(mine) >> 8;
                 }
                 uint32_t const tl = fse_optimal_table_log(fseLog, nbSeq, max, 2);        // :70-77 ZSTD_NCountCost
                 uint32_t ncountCost = 0;
-                if (fse_normalize(sh->norm[k], tl, cnt, nbSeq, max, nbSeq >= 2048) < 0) fail = true;
-                else { ncountCost = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tl); if (!ncountCost) fail = true; }
-                uint32_t ecost = 0;                                                    // :83-97 ZSTD_entropyCost
-                for (uint32_t s = 0; s <= max; s++) {
-                    uint32_t nrm = (256 * cnt[s]) / nbSeq;
-                    if (cnt[s] != 0 && nrm == 0) nrm = 1;
-                    ecost += cnt[s] * kInvProbLog256[nrm];
+                if (fse_normalize_wave(sh->norm[k], tl, cnt, nbSeq, max, nbSeq >= 2048) < 0) fail = true;
+                else { ncountCost = fse_write_ncount_wave(sh->ncWords[k], sh->ncount[k], sh->norm[k], max, tl); if (!ncountCost) fail = true; }
+                uint32_t mineE = 0;                                                    // :83-97 ZSTD_entropyCost
+                if ((uint32_t)lane <= max) {
+                    uint32_t nrm = (256 * myCnt) / nbSeq;
+                    if (myCnt != 0 && nrm == 0) nrm = 1;
+                    mineE = myCnt * kInvProbLog256[nrm];
                 }
+                uint32_t const ecost = tw_sum(mineE);
                 uint64_t const compressedCost = ((uint64_t)ncountCost << 3) + (ecost >> 8);
                 type = basicCost <= compressedCost ? 0 : 2;                            // :217-222
             }
             if (type == 3) {           // zstd_compress_sequences.c:264-266: the previous table as it is, no header bytes
                                        // (copied below by the whole wavefront)
             } else if (type == 1) {    // set_rle: the single symbol is `max`; byte = code of the first sequence (= same)
-                fse_build_ctable_rle(&sh->ct[k], max);
-                sh->ncount[k][0] = (uint8_t)max;
+                fse_build_ctable_rle_wave(&sh->ct[k], max);
+                if (lane == 0) sh->ncount[k][0] = (uint8_t)max;
                 hsz = 1;
             } else if (type == 0) {
-                for (uint32_t s = 0; s <= defMax; s++) sh->norm[k][s] = defNorm[s];
-                fse_build_ctable(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
+                if ((uint32_t)lane <= defMax) sh->norm[k][lane] = defNorm[lane];
+                __builtin_amdgcn_wave_barrier();
+                fse_build_ctable_wave(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
             } else {
                 uint32_t nbSeq1 = nbSeq;
                 uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
-                if (cnt[lastCode] > 1) { cnt[lastCode]--; nbSeq1--; }
-                if (fse_normalize(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
+                if (__builtin_amdgcn_readlane(myCnt, (int)lastCode) > 1) { if ((uint32_t)lane == lastCode) cnt[lastCode]--; nbSeq1--; }
+                __builtin_amdgcn_wave_barrier();
+                if (fse_normalize_wave(sh->norm[k], tableLog, cnt, nbSeq1, max, nbSeq1 >= 2048) < 0) fail = true;
                 else {
-                    hsz = fse_write_ncount(sh->ncount[k], sh->norm[k], max, tableLog);
+                    hsz = fse_write_ncount_wave(sh->ncWords[k], sh->ncount[k], sh->norm[k], max, tableLog);
                     if (!hsz) fail = true;
-                    else fse_build_ctable(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
+                    else fse_build_ctable_wave(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
                 }
             }
-            sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max;
+            if (lane == 0) { sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max; }
         }
         __builtin_amdgcn_wave_barrier();
         if (sh->encType[k] == 3) {
@@ -683,8 +684,12 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
 
     // ---------------- block + frame headers (zstd_compress.c:3026, :4582-4590)
     uint32_t const cSize = litSection + seqSection;
+#ifdef ZHIP_ENT_DEBUG
+    if (t == 0) printf("ENT n=%u nbSeq=%u litSize=%u litMode=%u litSection=%u seqSection=%u enc=%u,%u,%u hufHdr=%u rawBlock=%d\n", n, nbSeq, litSize, sh->litMode, litSection, seqSection, sh->encType[0], sh->encType[1], sh->encType[2], sh->hufHdrSize, (int)rawBlock);
+#endif
     if (cSize >= n - minGainBlock) rawBlock = true;
     if (rawBlock) {
+        __syncthreads();                                        // thread 0's section-header bytes land before the copy overwrites them
         for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
     }
     if (t == 0) {

@@ -333,4 +333,48 @@ k_dec_verify(ZhipDResult* __restrict__ results, const uint32_t* __restrict__ che
     if (i < nFrames && results[i].status == 0 && results[i].hasChecksum && results[i].checksum != checks[i]) { results[i].status = ZHIP_DE_CHECKSUM; results[i].size = 0; }
 }
 
+// ---- stage-test hooks (tests/test_emu_tables.py, tests/test_gpu_tables.py): the wave-wide table builders of zhip_tables.h
+// on caller-supplied histograms, one 64-thread workgroup per case, so that each stage is pinned to the reference's own stage
+// function (HUF_buildCTable_wksp / HUF_writeCTable_wksp, FSE_normalizeCount / FSE_writeNCount / FSE_buildCTable_wksp).
+struct ZhipTestHufShared { HufWork w; uint32_t count[256]; uint32_t code[256]; uint8_t hdr[136]; };
+__global__ void __launch_bounds__(64)
+k_test_huf(const uint32_t* __restrict__ counts /* nCases x 256 */, const uint32_t* __restrict__ maxSyms, uint32_t maxNbBits,
+           uint32_t* __restrict__ codes /* nCases x 256 */, uint8_t* __restrict__ hdrs /* nCases x 136 */, uint32_t* __restrict__ meta /* nCases x 2: table log, header size */)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    ZhipTestHufShared* const S = (ZhipTestHufShared*)smem;
+    uint32_t const c = blockIdx.x, lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) S->count[i] = counts[(size_t)c * 256 + i];
+    __builtin_amdgcn_wave_barrier();
+    uint32_t const log = huf_build_codes_wave(&S->w, S->count, maxSyms[c], maxNbBits, S->code);
+    uint32_t const h = huf_write_table_wave(&S->w, S->hdr, S->code, maxSyms[c], log);
+    for (uint32_t i = lane; i < 256; i += 64) codes[(size_t)c * 256 + i] = S->code[i];
+    for (uint32_t i = lane; i < 136; i += 64) hdrs[(size_t)c * 136 + i] = i < h ? S->hdr[i] : 0;
+    if (lane == 0) { meta[2 * c] = log; meta[2 * c + 1] = h; }
+}
+struct ZhipTestFseShared { FseCTable ct; uint32_t count[64]; int16_t norm[64]; uint32_t words[16]; uint8_t ncount[64]; uint8_t cellSym[4096]; uint16_t first[64]; };
+__global__ void __launch_bounds__(64)
+k_test_fse(const uint32_t* __restrict__ counts /* nCases x 64 */, const uint32_t* __restrict__ params /* nCases x 4: total, maxSym, tableLog, useLowProb */,
+           int16_t* __restrict__ norms /* nCases x 64 */, uint8_t* __restrict__ ncounts /* nCases x 64 */, int32_t* __restrict__ meta /* nCases x 2: normalize rc, NCount size */,
+           FseCTable* __restrict__ tables)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    ZhipTestFseShared* const S = (ZhipTestFseShared*)smem;
+    uint32_t const c = blockIdx.x, lane = threadIdx.x;
+    uint32_t const total = params[4 * c], maxSym = params[4 * c + 1], tableLog = params[4 * c + 2], lowProb = params[4 * c + 3];
+    S->count[lane] = counts[(size_t)c * 64 + lane]; S->norm[lane] = 0; S->ncount[lane] = 0;
+    {   uint32_t* const z = (uint32_t*)&S->ct; for (uint32_t i = lane; i < sizeof(FseCTable) / 4; i += 64) z[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    int const rc = fse_normalize_wave(S->norm, tableLog, S->count, total, maxSym, lowProb != 0);
+    uint32_t sz = 0;
+    if (rc == 1) {
+        sz = fse_write_ncount_wave(S->words, S->ncount, S->norm, maxSym, tableLog);
+        if (sz) fse_build_ctable_wave(&S->ct, S->norm, maxSym, tableLog, S->cellSym, S->first);
+    }
+    norms[(size_t)c * 64 + lane] = S->norm[lane];
+    ncounts[(size_t)c * 64 + lane] = lane < sz ? S->ncount[lane] : 0;
+    if (lane == 0) { meta[2 * c] = rc; meta[2 * c + 1] = (int32_t)sz; }
+    {   const uint32_t* const f = (const uint32_t*)&S->ct; uint32_t* const t = (uint32_t*)&tables[c]; for (uint32_t i = lane; i < sizeof(FseCTable) / 4; i += 64) t[i] = f[i]; }
+}
+
 }  // namespace zhip

@@ -10,7 +10,6 @@
 #include "zhip_kernels.h"
 #include "zhip_host.h"
 #include "zhip_cdict_host.h"
-#include "zhip_datagen.h"
 
 // zstd's error numbering (lib/zstd_errors.h:60-101): results are (size_t)-code
 enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_memory_allocation = 64,
@@ -200,9 +199,41 @@ void zhip_last_hc_timing(zhip_ctx* c, double t[3])
         for (int k = 0; k < 3; k++) { float ms = 0; if (hipEventElapsedTime(&ms, c->hcEv[i + k], c->hcEv[i + k + 1]) == hipSuccess) t[k] += ms; }
 }
 
-void zhip_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed, int streamMode)
+// ---- stage-test hooks: the wave-wide entropy-table builders on caller-supplied histograms (host buffers in and out)
+static size_t test_copy_back(zhip_ctx* c, void* h, const void* d, size_t n) { HIPCHK(c, hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return 0; }
+size_t zhip_test_huf_tables(zhip_ctx* c, const unsigned* counts, const unsigned* maxSyms, unsigned nCases, unsigned maxNbBits,
+                            unsigned* codes, unsigned char* hdrs, unsigned* meta)
 {
-    zhip::datagen(buffer, size, matchProba, litProba, seed, streamMode);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t *dC = nullptr, *dM = nullptr, *dCode = nullptr, *dMeta = nullptr; uint8_t* dH = nullptr;
+    size_t const n = nCases;
+    HIPCHK(c, hipMalloc((void**)&dC, n * 1024)); HIPCHK(c, hipMalloc((void**)&dM, n * 4 + 4)); HIPCHK(c, hipMalloc((void**)&dCode, n * 1024));
+    HIPCHK(c, hipMalloc((void**)&dH, n * 136 + 4)); HIPCHK(c, hipMalloc((void**)&dMeta, n * 8 + 4));
+    HIPCHK(c, hipMemcpy(dC, counts, n * 1024, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dM, maxSyms, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(zhip::k_test_huf, dim3(nCases), dim3(64), sizeof(zhip::ZhipTestHufShared), c->stream, dC, dM, maxNbBits, dCode, dH, dMeta);
+    HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t e = test_copy_back(c, codes, dCode, n * 1024); if (!e) e = test_copy_back(c, hdrs, dH, n * 136); if (!e) e = test_copy_back(c, meta, dMeta, n * 8);
+    (void)hipFree(dC); (void)hipFree(dM); (void)hipFree(dCode); (void)hipFree(dH); (void)hipFree(dMeta);
+    return e;
+}
+size_t zhip_test_fse_tables(zhip_ctx* c, const unsigned* counts, const unsigned* params, unsigned nCases,
+                            short* norms, unsigned char* ncounts, int* meta, void* tables, size_t tableStride)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (tableStride != sizeof(zhip::FseCTable)) return ZERR(ZE_GENERIC);
+    uint32_t *dC = nullptr, *dP = nullptr; int16_t* dN = nullptr; uint8_t* dH = nullptr; int32_t* dMeta = nullptr; zhip::FseCTable* dT = nullptr;
+    size_t const n = nCases;
+    HIPCHK(c, hipMalloc((void**)&dC, n * 256)); HIPCHK(c, hipMalloc((void**)&dP, n * 16)); HIPCHK(c, hipMalloc((void**)&dN, n * 128));
+    HIPCHK(c, hipMalloc((void**)&dH, n * 64)); HIPCHK(c, hipMalloc((void**)&dMeta, n * 8)); HIPCHK(c, hipMalloc((void**)&dT, n * sizeof(zhip::FseCTable)));
+    HIPCHK(c, hipMemcpy(dC, counts, n * 256, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(dP, params, n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(zhip::k_test_fse, dim3(nCases), dim3(64), sizeof(zhip::ZhipTestFseShared), c->stream, dC, dP, dN, dH, dMeta, dT);
+    HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t e = test_copy_back(c, norms, dN, n * 128); if (!e) e = test_copy_back(c, ncounts, dH, n * 64); if (!e) e = test_copy_back(c, meta, dMeta, n * 8);
+    if (!e) e = test_copy_back(c, tables, dT, n * sizeof(zhip::FseCTable));
+    (void)hipFree(dC); (void)hipFree(dP); (void)hipFree(dN); (void)hipFree(dH); (void)hipFree(dMeta); (void)hipFree(dT);
+    return e;
 }
 
 }  // extern "C"

@@ -323,6 +323,9 @@ __device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint
 //   * literals: every lane not covered by a match stores its own byte at (position - bytes matched so far).
 enum { ZW_CONT = 0, ZW_INC = 1, ZW_RESTART = 2 };
 #define ZHIP_WIN_NEED 80u            /* a window at B needs B + 80 <= n: 64 positions x 8-byte reads, all iterations inside ilimit */
+#ifndef ZHIP_WIN_DENSE_ONLY
+#define ZHIP_WIN_DENSE_ONLY 0       /* 1: a scan leaves window mode after its first event-less window */
+#endif
 #define ZHIP_WIN_LANES 60            /* events are taken from lanes below this (their +2/+4 neighbours stay inside the window) */
 
 #ifndef ZHIP_SBFM64                  /* s_bfm_b64: `width` (0..63) lanes from lane `offset` (0..63) on (the emulator brings its own) */
@@ -615,13 +618,16 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         // ---- scan until an event or the end of the unit: windows while the gap is 2, schedule-shaped batches otherwise
         int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode, 3 the window handled its events
         uint32_t mpos = 0, cand0 = 0, cur0 = 0;
+        bool dense = ZHIP_WIN_DENSE_ONLY == 0;   // windows right behind an event; a scan that found nothing in a whole window goes on in
+        dense = true;                            // schedule-shaped batches (cheaper per position when events are far apart)
         for (;;) {
-            if (stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
+            if (dense && stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
                 int const st = window_batch<MLS>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep);
                 have = false;
                 ZPROF_COUNT(10, 1);
                 if (st == ZW_RESTART) { evKind = 3; break; }
                 if (st == ZW_INC) { step = 3; nextStep += 128; batch_offsets(g0, step, posOff, rposOff); }
+                if (ZHIP_WIN_DENSE_ONLY) dense = false;
                 continue;
             }
             if (!have) cur = batch_load(src, nm8, ip0, posOff, rposOff, rep1);
