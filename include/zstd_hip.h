@@ -47,6 +47,11 @@ size_t       zhip_compressBound(size_t srcSize, size_t unitSize);   /* sum of ZS
  * out[7] = windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy. returns 0, or -1 if the
  * level/size maps to a strategy this library does not implement (greedy and above). */
 int          zhip_getCParams(int level, unsigned long long srcSize, unsigned out[7]);
+/* the same with explicitly set parameters = what a CCtx holds after ZSTD_CCtx_setParameter(ZSTD_c_windowLog / chainLog / hashLog /
+ * searchLog / minMatch / targetLength / strategy) (lib/compress/zstd_compress.c:710-768): cparams[7] in ZSTD_compressionParameters
+ * order, 0 = "use the level's"; they replace the level's row BEFORE the source-size adjustment, as ZSTD_getCParamsFromCCtxParams
+ * does (:1617-1644).  0 ok, 1 strategy not implemented on the device, 2 a value outside ZSTD_cParam_getBounds */
+int          zhip_getCParams_explicit(int level, unsigned long long srcSize, const unsigned cparams[7], unsigned out[7]);
 
 /* ---- frame-level drop-in for host buffers = ZSTD_compress2 per unit (lib/zstd.h:603), batch form.
  * src is cut into units of unitSize (last one ragged); dst receives the frames back to back.
@@ -59,6 +64,15 @@ size_t       zhip_compress(zhip_ctx* ctx, void* dst, size_t dstCapacity, const v
  * unitSizesDev (optional, device, uint32 per unit) receives frame sizes. */
 size_t       zhip_compress_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
                                   int level, size_t unitSize, uint32_t* unitSizesDev, void* stream);
+
+/* ---- both with explicit compression parameters (see zhip_getCParams_explicit): = ZSTD_compress2 on a CCtx whose advanced
+ * parameters were set (lib/compress/zstd_compress.c:710-768).  cparams may be NULL (= the plain calls above).  Not implemented on
+ * the device -> parameter_unsupported: strategies above lazy2, ZSTD_fast with hashLog > 15 (the table must fit LDS), a windowLog
+ * smaller than the unit it is applied to; values outside ZSTD_cParam_getBounds -> parameter_outOfBound. */
+size_t       zhip_compress_params(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                  int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes);
+size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
+                                         int level, const unsigned cparams[7], size_t unitSize, uint32_t* unitSizesDev, void* stream);
 
 /* ---- block-level plugin (B1) = ZSTD_sequenceProducer_F, lib/zstd.h:2838; contrib/externalSequenceProducer.
  * zhip_sequence_producer has exactly that signature; pass the zhip_ctx as sequenceProducerState:

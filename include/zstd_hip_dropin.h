@@ -7,7 +7,17 @@
  * of silently compressing on the host.
  *
  * Output contract
- *   srcSize <= 128 KB : ONE frame, byte-identical to the reference's ZSTD_compress2 at the same level.
+ *   srcSize <= 128 KB : ONE frame, byte-identical to the reference's ZSTD_compress2 with the same parameters set on its CCtx —
+ *                       ZSTD_c_compressionLevel and the advanced parameters ZSTD_c_windowLog / chainLog / hashLog / searchLog /
+ *                       minMatch / targetLength / strategy (applied as ZSTD_getCParamsFromCCtxParams applies them,
+ *                       lib/compress/zstd_compress.c:1617-1644).
+ *                       CAVEAT for the strategies greedy / lazy / lazy2 (default at levels 5-12): the device runs the
+ *                       reference's HASH-CHAIN match finder, i.e. the bytes equal the reference run with
+ *                       ZSTD_c_useRowMatchFinder = ZSTD_ps_disable; the reference's default there is the row-hash matcher
+ *                       (zstd_compress.c:237-253), whose frames differ (same format, same decoder, a few bytes of ratio).
+ *                       Not implemented on the device -> parameter_unsupported: strategies above lazy2, ZSTD_fast with
+ *                       hashLog > 15 (the table lives in LDS), a windowLog smaller than the input, a dictionary whose CDict
+ *                       row is a lazy strategy, dictionary + source above 128 KB.
  *   srcSize  > 128 KB : the source is cut into 128 KB units, each an independent frame (content size in every frame
  *                       header), emitted back to back.  That is a valid zstd stream (RFC 8878 3.1: frames may be
  *                       concatenated; ZSTD_decompress decodes it, lib/decompress/zstd_decompress.c:1068) and equals

@@ -114,6 +114,27 @@ size_t zref_compress_chunks_params(const int cp[7], size_t chunkSize, const void
     return pos;
 }
 
+/* a level plus explicitly set parameters (0 = leave the level's), optionally with the row matcher disabled */
+size_t zref_compress_chunks_level_params(int level, const int cp[7], int noRow, size_t chunkSize, const void* src, size_t n, void* dst, size_t dstCap)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t pos = 0, off = 0;
+    static const ZSTD_cParameter ids[7] = { ZSTD_c_windowLog, ZSTD_c_chainLog, ZSTD_c_hashLog, ZSTD_c_searchLog, ZSTD_c_minMatch, ZSTD_c_targetLength, ZSTD_c_strategy };
+    int i;
+    if (!c) return (size_t)-1;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, level);
+    for (i = 0; i < 7; i++) if (cp[i]) { if (ZSTD_isError(ZSTD_CCtx_setParameter(c, ids[i], cp[i]))) { ZSTD_freeCCtx(c); return (size_t)-1; } }
+    if (noRow) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+    do {
+        size_t const len = (n - off < chunkSize) ? n - off : chunkSize;
+        size_t const r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, len);
+        if (ZSTD_isError(r)) { ZSTD_freeCCtx(c); return (size_t)-1; }
+        pos += r; off += len;
+    } while (off < n);
+    ZSTD_freeCCtx(c);
+    return pos;
+}
+
 /* records[] (sizes in recSizes[nRec], laid out back to back in src) each compressed as its own frame with a CDict made from
  * `dict` at `level` — ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the contrib/largeNbDicts / `zstd -D` shape).
  * outSizes[nRec] receives the frame sizes; returns the total, (size_t)-1 on error. */

@@ -170,3 +170,36 @@ def test_dict_records_parse_like_the_oracle(libs):
             bad = np.nonzero((got != want[:nw]).any(axis=1))[0]
             assert len(bad) == 0, (kind, level, len(r), int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
         lo.zo_cdict_free(cd)
+
+
+def test_fast_parse_explicit_parameters(libs):
+    """explicit cParams (B2: ZSTD_c_hashLog / minMatch / targetLength set on the CCtx) reach the kernel through ZhipUnit: the
+    reference's default level-1 row applied to 128 KB units (hashLog 14, minMatch 7), a 15-bit table with a 4-byte hash, and an
+    accelerated scan (targetLength 3 -> step 4: the schedule-shaped batches only)"""
+    lo, le = libs
+    for cpv in ([17, 13, 14, 1, 7, 0, 1], [17, 12, 15, 1, 4, 0, 1], [17, 12, 13, 1, 5, 3, 1]):
+        cases = list(corpus_cases(lo, sizes=(131072, 40000), seeds=(5,)))[:8]
+        bufs = [c[1] for c in cases]
+        units = make_units(lo, [len(b) for b in bufs], 1)
+        for k, f in enumerate(("windowLog", "chainLog", "hashLog", "searchLog", "minMatch", "targetLength", "strategy")):
+            units[f] = cpv[k]
+        units["litMode"] = 1 if cpv[5] > 0 else 0
+        src = np.concatenate(bufs + [np.zeros(16, dtype=np.uint8)])
+        cap = le.emu_seq_cap()
+        seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT); metas = np.zeros(len(bufs), dtype=PARSE_DT)
+        lstride = le.emu_lit_stride()
+        lits = np.full(len(bufs) * lstride, 0xEE, dtype=np.uint8)
+        emu_parse_units(le, src, units, seqs, lits, metas)
+        for i, a in enumerate(bufs):
+            cp = (C.c_uint * 7)(*cpv)
+            n = len(a)
+            oseq = np.zeros((n // 3 + 8, 3), dtype=np.uint32); olit = np.zeros(n + 64, dtype=np.uint8)
+            litSize = C.c_size_t(0); rep = (C.c_uint * 3)()
+            nb = lo.zo_parse_block(cp, _buf(a), n, _buf(oseq), len(oseq), _buf(olit), C.byref(litSize), rep)
+            m = metas[i]
+            s = seqs[i * cap: i * cap + int(m["nbSeq"])]
+            assert int(m["nbSeq"]) == nb and int(m["litSize"]) == litSize.value, (cpv, cases[i][0])
+            got = np.stack([s["litLength"].astype(np.uint32), s["mlBase"].astype(np.uint32) + 3, s["offBase"]], axis=1) if nb else np.zeros((0, 3), np.uint32)
+            want = oseq[:nb].copy(); want[:, 0] &= 0xFFFF; want[:, 1] = ((want[:, 1] - 3) & 0xFFFF) + 3
+            assert np.array_equal(got, want), (cpv, cases[i][0])
+            assert np.array_equal(lits[i * lstride: i * lstride + litSize.value], olit[:litSize.value]), (cpv, cases[i][0])

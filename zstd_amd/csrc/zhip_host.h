@@ -43,7 +43,9 @@ static inline void host_adjust_cparams(CParams* cp, unsigned long long srcSize, 
     }
 }
 
-static inline bool host_get_cparams_mode(int level, unsigned long long srcSize, unsigned long long dictSize, int mode, CParams* out)
+// `overrides`: the explicitly set compression parameters of a CCtx (ZSTD_c_windowLog ... ZSTD_c_strategy), 0 = not set — they
+// replace the level's row before the adjustment, exactly as ZSTD_getCParamsFromCCtxParams does (zstd_compress.c:1617-1644)
+static inline bool host_get_cparams_mode(int level, unsigned long long srcSize, unsigned long long dictSize, int mode, CParams* out, const unsigned* overrides = nullptr)
 {
     static const CParams rows[4][13] = {     // [size class][0 = negative-level base, 1..12 = level]; strategy 6+ = binary tree (not ours)
         /* srcSize > 256 KB */ {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2},
@@ -68,16 +70,28 @@ static inline bool host_get_cparams_mode(int level, unsigned long long srcSize, 
     int row = level == 0 ? 3 : (level < 0 ? 0 : level);
     if (row > 12) return false;
     CParams cp = rows[cls][row];
-    if (cp.strategy > 5) return false;       // btlazy2 and up: not implemented
     if (level < 0) { long const lv = level < -131072 ? -131072 : level; cp.targetLength = (unsigned)(-lv); }
+    if (overrides) {
+        unsigned* const f = &cp.windowLog;       // the seven fields in ZSTD_compressionParameters order
+        for (int i = 0; i < 7; i++) if (overrides[i]) f[i] = overrides[i];
+    }
+    if (cp.strategy > 5) return false;       // btlazy2 and up: not implemented
     host_adjust_cparams(&cp, srcSize, dictSize, mode);
     *out = cp;
     return true;
 }
 
-static inline bool host_get_cparams(int level, unsigned long long srcSize, CParams* out)
+static inline bool host_get_cparams(int level, unsigned long long srcSize, CParams* out, const unsigned* overrides = nullptr)
 {
-    return host_get_cparams_mode(level, srcSize, 0, HOST_CPM_NONE, out);
+    return host_get_cparams_mode(level, srcSize, 0, HOST_CPM_NONE, out, overrides);
+}
+
+// ZSTD_checkCParams / ZSTD_cParam_getBounds (zstd_compress.c:433-470, lib/zstd.h:1236-1252) for explicitly set values (0 = not set)
+static inline bool host_check_overrides(const unsigned ov[7])
+{
+    static const unsigned lo[7] = { 10, 6, 6, 1, 3, 0, 1 }, hi[7] = { 31, 30, 30, 30, 7, 131072, 9 };
+    for (int i = 0; i < 7; i++) if (ov[i] && (ov[i] < lo[i] || ov[i] > hi[i])) return false;
+    return true;
 }
 
 // ZSTD_COMPRESSBOUND, lib/zstd.h:235

@@ -53,6 +53,7 @@ struct zhip_ctx_s {
     // last call
     size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
+    unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
     std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
@@ -131,6 +132,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->seqArena = seqArena; c->litArena = litArena; c->outArena = outArena;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
+    memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { c->cs[i] = nullptr; c->cev[i] = nullptr; }
     memset(c->timing, 0, sizeof(c->timing));
@@ -251,8 +253,11 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
         zhip::CParams* cp = &tail;
-        if (len == unitSize) { if (!haveFull) { if (!zhip::host_get_cparams(level, len, &full)) { *err = ZERR(ZE_parameter_unsupported); return 0; } haveFull = true; } cp = &full; }
-        else if (!zhip::host_get_cparams(level, len, &tail)) { *err = ZERR(ZE_parameter_unsupported); return 0; }
+        const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
+        if (len == unitSize) { if (!haveFull) { if (!zhip::host_get_cparams(level, len, &full, ov)) { *err = ZERR(ZE_parameter_unsupported); return 0; } haveFull = true; } cp = &full; }
+        else if (!zhip::host_get_cparams(level, len, &tail, ov)) { *err = ZERR(ZE_parameter_unsupported); return 0; }
+        if (len > 1 && ((size_t)1 << cp->windowLog) < len) {       // an explicit window smaller than the unit: matches would have to respect it
+            snprintf(c->err, sizeof(c->err), "windowLog %u is smaller than a %zu-byte unit: not implemented on device", cp->windowLog, len); *err = ZERR(ZE_parameter_unsupported); return 0; }
         ZhipUnit& u = c->hUnits[i];
         u.srcOff = off; u.srcLen = (uint32_t)len;
         {   ZhipSlot& sl = c->hSlots[i]; sl.seqOff = i * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = i * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = i * (uint64_t)ZHIP_OUT_STRIDE; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0; }
@@ -454,11 +459,50 @@ size_t zhip_compress_device(zhip_ctx* c, void* dstDev, size_t dstCapacity, const
                                   stream ? (hipStream_t)stream : c->stream);
 }
 
+// explicit compression parameters (ZSTD_c_windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; 0 = the
+// level's own): set for the duration of one call
+struct OvrScope {
+    zhip_ctx* c;
+    OvrScope(zhip_ctx* c_, const unsigned* cp) : c(c_) { if (cp) { memcpy(c->ovr, cp, sizeof(c->ovr)); c->haveOvr = true; } }
+    ~OvrScope() { c->haveOvr = false; }
+};
+size_t zhip_compress_params_device(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
+                                   int level, const unsigned cparams[7], size_t unitSize, uint32_t* unitSizesDev, void* stream)
+{
+    if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    OvrScope scope(c, cparams);
+    return compress_device_locked(c, dstDev, dstCapacity, srcDev, srcSize, level, unitSize, unitSizesDev, stream ? (hipStream_t)stream : c->stream);
+}
+static size_t compress_host_locked(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, size_t unitSize, size_t* unitSizes);
+size_t zhip_compress_params(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                            int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes)
+{
+    if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    OvrScope scope(c, cparams);
+    return compress_host_locked(c, dst, dstCapacity, src, srcSize, level, unitSize, unitSizes);
+}
+int zhip_getCParams_explicit(int level, unsigned long long srcSize, const unsigned cparams[7], unsigned out[7])
+{
+    zhip::CParams cp;
+    if (cparams && !zhip::host_check_overrides(cparams)) return 2;
+    if (!zhip::host_get_cparams(level, srcSize, &cp, cparams)) return 1;
+    out[0] = cp.windowLog; out[1] = cp.chainLog; out[2] = cp.hashLog; out[3] = cp.searchLog; out[4] = cp.minMatch; out[5] = cp.targetLength; out[6] = cp.strategy;
+    return 0;
+}
+
 size_t zhip_compress(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                      int level, size_t unitSize, size_t* unitSizes)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    return compress_host_locked(c, dst, dstCapacity, src, srcSize, level, unitSize, unitSizes);
+}
+static size_t compress_host_locked(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, size_t unitSize, size_t* unitSizes)
+{
     size_t const bound = zhip_compressBound(srcSize, unitSize);
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
     if (c->srcStageCap < srcSize + 64) {

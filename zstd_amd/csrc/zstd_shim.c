@@ -17,6 +17,7 @@ struct ZSTD_CCtx_s {
     size_t    zUnits;
     int       level;                 /* ZSTD_c_compressionLevel; 0 means default (3), lib/zstd.h:337-349 */
     int       checksum;              /* ZSTD_c_checksumFlag */
+    unsigned  cp[7];                 /* ZSTD_c_windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; 0 = the level's */
     const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
 
@@ -36,7 +37,13 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 {
     if (!c) return SHIM_ERR(E_GENERIC);
-    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; }
+    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; memset(c->cp, 0, sizeof(c->cp)); }
+    return 0;
+}
+static size_t shim_set_cp(ZSTD_CCtx* c, int idx, int value, int lo, int hi)
+{
+    if (value != 0 && (value < lo || value > hi)) return SHIM_ERR(E_parameter_outOfBound);
+    c->cp[idx] = (unsigned)value;
     return 0;
 }
 size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
@@ -44,10 +51,15 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     if (!c) return SHIM_ERR(E_GENERIC);
     switch (param) {
     case ZSTD_c_compressionLevel: c->level = value; return 0;     /* validated when used (clamping is the reference's behaviour for out-of-range levels; unsupported strategies fail at compress time) */
-    /* advanced parameters: only "0 = use the level's default" is representable on the device */
-    case ZSTD_c_windowLog: case ZSTD_c_hashLog: case ZSTD_c_chainLog: case ZSTD_c_searchLog:
-    case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
-        return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
+    /* advanced parameters (lib/compress/zstd_compress.c:710-768): kept on the CCtx, 0 = use the level's; bounds as
+       ZSTD_cParam_getBounds (:433-470); what the device cannot run fails at compress time with parameter_unsupported */
+    case ZSTD_c_windowLog:    return shim_set_cp(c, 0, value, 10, 31);
+    case ZSTD_c_chainLog:     return shim_set_cp(c, 1, value, 6, 30);
+    case ZSTD_c_hashLog:      return shim_set_cp(c, 2, value, 6, 30);
+    case ZSTD_c_searchLog:    return shim_set_cp(c, 3, value, 1, 30);
+    case ZSTD_c_minMatch:     return shim_set_cp(c, 4, value, 3, 7);
+    case ZSTD_c_targetLength: return shim_set_cp(c, 5, value, 0, 131072);
+    case ZSTD_c_strategy:     return shim_set_cp(c, 6, value, 1, 9);
     case ZSTD_c_contentSizeFlag: return value == 1 ? 0 : SHIM_ERR(E_parameter_unsupported);
     case ZSTD_c_checksumFlag:    c->checksum = value != 0; return 0;
     case ZSTD_c_dictIDFlag:      return 0;                        /* no dictionary can be attached: the flag has no effect */
@@ -98,11 +110,11 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
     /* zhip_compress wants room for its own bound; the reference only needs ZSTD_compressBound(n) for a guaranteed
        success and otherwise tries — give the device a private bounce buffer when the caller's is smaller */
     {   size_t const need = zhip_compressBound(n, SHIM_UNIT);
-        if (cap >= need) return zhip_compress(c->z, dst, cap, src, n, level, SHIM_UNIT, NULL);
+        if (cap >= need) return zhip_compress_params(c->z, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
         {   void* tmp = malloc(need ? need : 1);
             size_t r;
             if (!tmp) return SHIM_ERR(E_memory_allocation);
-            r = zhip_compress(c->z, tmp, need, src, n, level, SHIM_UNIT, NULL);
+            r = zhip_compress_params(c->z, tmp, need, src, n, level, c->cp, SHIM_UNIT, NULL);
             if (!zhip_isError(r)) { if (r <= cap) memcpy(dst, tmp, r); else r = SHIM_ERR(70 /* dstSize_tooSmall */); }
             free(tmp);
             return r;
@@ -142,10 +154,10 @@ size_t ZSTD_compress_usingCDict(ZSTD_CCtx* c, void* dst, size_t cap, const void*
 }
 size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
 {   /* ignores the cctx's parameters (checksum flag included), like the reference (zstd_compress.c:5428) */
-    int const ck = c ? c->checksum : 0; size_t r;
-    if (c) c->checksum = 0;
+    int const ck = c ? c->checksum : 0; size_t r; unsigned cp[7];
+    if (c) { c->checksum = 0; memcpy(cp, c->cp, sizeof(cp)); memset(c->cp, 0, sizeof(c->cp)); }
     r = shim_compress(c, dst, cap, src, n, level);
-    if (c) c->checksum = ck;
+    if (c) { c->checksum = ck; memcpy(c->cp, cp, sizeof(cp)); }
     return r;
 }
 size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level)
