@@ -495,14 +495,25 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
     ctx = zstd_amd.Context(local, max_units=units)
     best = 1e9
     got = None
-    for _ in range(3):
+    for _ in range(2):
         t0 = time.perf_counter()
         got = ctx.compress(host, level=level)
         best = min(best, time.perf_counter() - t0)
     ctx.close()
-    return {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "best_of": 3, "source_bytes": int(len(host)),
-            "same_bytes_as_device_path": bool(len(got) == int(total_expected)),
-            "path": "zhip_compress: pageable host source -> H2D -> k_parse_fast, k_entropy, k_gather -> D2H -> host bytes (PCIe-inclusive; bounded by the two copies, not by the kernels)"}
+    m = zstd_amd.MultiContext([local])
+    dst = np.empty(zstd_amd.compress_bound(len(host)), dtype=np.uint8)
+    bestm, k = 1e9, 0
+    for _ in range(4):
+        t0 = time.perf_counter()
+        k = m.compress_into(dst, host, level=level)
+        bestm = min(bestm, time.perf_counter() - t0)
+    same = bool(k == int(total_expected) and dst[:k].tobytes() == got)
+    m.close()
+    return {"value": round(len(host) / bestm / 1e6, 1), "unit": "MB/s", "best_of": 4, "source_bytes": int(len(host)),
+            "same_bytes_as_device_path": same,
+            "path": "zhip_compress_multi on this one device: four lanes (host thread + stream + pinned staging each), 64 MB chunks: memcpy -> H2D -> kernels -> D2H -> "
+                    "ordered host gather into the caller's buffer; PCIe- and host-memcpy-inclusive, never `value`",
+            "synchronous_single_stream": {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "path": "zhip_compress: pageable source, blocking H2D / kernels / D2H on one stream"}}
 
 
 def stub_main(args, rank, world):

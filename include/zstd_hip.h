@@ -74,6 +74,20 @@ size_t       zhip_compress_params(zhip_ctx* ctx, void* dst, size_t dstCapacity, 
 size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
                                          int level, const unsigned cparams[7], size_t unitSize, uint32_t* unitSizesDev, void* stream);
 
+/* ---- host buffers over SEVERAL devices in one process: independent units shard across the GPUs of a node, one
+ * HIP stream + pinned staging per lane ($ZHIP_MULTI_LANES lanes per device, default 4: some lanes' copies overlap another's kernels), no collective;
+ * finished chunks are gathered on the host in source order (destination offset = exclusive prefix sum of the sizes before).
+ * devices[] may name the same device more than once (more lanes on it).  chunkUnits = units per chunk (0 = 512 = 64 MB).
+ * The stream written to dst is byte-identical to zhip_compress's.  cparams may be NULL. */
+typedef struct zhip_multi_s zhip_multi;
+zhip_multi*  zhip_multi_create(const int* devices, int nDevices, size_t chunkUnits);
+void         zhip_multi_destroy(zhip_multi* m);
+int          zhip_multi_set_frame_checksum(zhip_multi* m, int enable);
+size_t       zhip_compress_multi(zhip_multi* m, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                 int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes);
+const char*  zhip_multi_last_error(const zhip_multi* m);
+double       zhip_multi_last_seconds(const zhip_multi* m);      /* wall time of the most recent zhip_compress_multi call */
+
 /* ---- block-level plugin (B1) = ZSTD_sequenceProducer_F, lib/zstd.h:2838; contrib/externalSequenceProducer.
  * zhip_sequence_producer has exactly that signature; pass the zhip_ctx as sequenceProducerState:
  *      ZSTD_registerSequenceProducer(cctx, zhip_ctx, zhip_sequence_producer);        lib/zstd.h:2866

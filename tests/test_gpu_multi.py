@@ -1,0 +1,61 @@
+"""In-process multi-device host path (zhip_compress_multi): lanes on separate streams, pinned double buffers, ordered
+host gather.  One GPU is visible here, so the device list names it several times — the sharding, the lane threads and the gather
+are the same code that runs over 8 devices; the stream must be byte-identical to the single-context path and to the oracle."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+from _libs import load_oracle, datagen, text_like, _buf, ERR, ROOT
+
+pytestmark = pytest.mark.gpu
+UNIT = 131072
+
+
+def test_multi_lane_stream_equals_single_context_and_oracle():
+    import zstd_amd
+    lo = load_oracle()
+    a = np.concatenate([datagen(lo, 37 * UNIT + 777, 50, 4), text_like(11 * UNIT, 9)])
+    single = zstd_amd.Context(0, max_units=64).compress(a, level=1)
+    cap = lo.zo_compress_bound(UNIT) * 50
+    want = np.empty(cap, dtype=np.uint8)
+    r = lo.zo_compress_chunks(1, UNIT, _buf(a), len(a), _buf(want), cap, None, 0)
+    assert r != ERR and single == want[:r].tobytes()
+    for devices, chunk in (([0], 0), ([0, 0], 3), ([0, 0, 0], 1), ([0], 5)):          # 2..6 lanes, chunks of 1..256 units: many gather orders
+        m = zstd_amd.MultiContext(devices, chunk_units=chunk)
+        sizes = np.zeros(64, dtype=np.uint64)
+        dst = np.empty(zstd_amd.compress_bound(len(a)), dtype=np.uint8)
+        for rep in range(3):
+            k = m.compress_into(dst, a, level=1, sizes=sizes)
+            assert dst[:k].tobytes() == single, (devices, chunk, rep)
+        assert int(sizes[:49].sum()) == k
+        got3 = m.compress(a[: 5 * UNIT + 1], level=3)
+        assert got3 == zstd_amd.Context(0, max_units=8).compress(a[: 5 * UNIT + 1], level=3)
+        assert m.compress(np.zeros(0, dtype=np.uint8), level=1) == zstd_amd.Context(0, max_units=1).compress(np.zeros(0, dtype=np.uint8), level=1)
+        m.close()
+
+
+def test_shim_uses_the_multi_device_path_when_asked(tmp_path):
+    """ZHIP_DEVICES=0,0: ZSTD_compress2 of a 3 MiB source through libzstd_hipshim.so runs on the lanes of zhip_compress_multi"""
+    import zstd_amd
+    from zstd_amd import build as zbuild
+    lo = load_oracle()
+    a = datagen(lo, 24 * UNIT + 5, 50, 8)
+    want = zstd_amd.Context(0, max_units=32).compress(a, level=1)
+    code = f'''
+import ctypes as C, numpy as np, sys
+S = C.CDLL({zbuild.SHIM!r})
+S.ZSTD_createCCtx.restype = C.c_void_p
+S.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+S.ZSTD_compress2.restype = C.c_size_t; S.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+S.ZSTD_compressBound.restype = C.c_size_t; S.ZSTD_compressBound.argtypes = [C.c_size_t]
+a = np.fromfile({str(tmp_path / "in.bin")!r}, dtype=np.uint8)
+c = S.ZSTD_createCCtx(); S.ZSTD_CCtx_setParameter(c, 100, 1)
+cap = S.ZSTD_compressBound(len(a)); dst = np.zeros(cap, dtype=np.uint8)
+r = S.ZSTD_compress2(c, dst.ctypes.data_as(C.c_void_p), cap, a.ctypes.data_as(C.c_void_p), len(a))
+dst[:r].tofile({str(tmp_path / "out.bin")!r})
+'''
+    a.tofile(tmp_path / "in.bin")
+    env = dict(os.environ, ZHIP_DEVICES="0,0")
+    subprocess.check_call([os.sys.executable, "-c", code], env=env)
+    assert open(tmp_path / "out.bin", "rb").read() == want

@@ -117,6 +117,56 @@ def datagen(size, match_pct=50, seed=0, stream_mode=True, lit_proba=0.0):
     return a[:size]
 
 
+class MultiContext:
+    """host buffers over several devices in one process (zhip_compress_multi): pinned double-buffered lanes, ordered host gather"""
+
+    def __init__(self, devices, chunk_units=0):
+        L = lib()
+        L.zhip_multi_create.restype = C.c_void_p
+        L.zhip_multi_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.zhip_multi_destroy.restype = None
+        L.zhip_multi_destroy.argtypes = [C.c_void_p]
+        L.zhip_compress_multi.restype = C.c_size_t
+        L.zhip_compress_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.zhip_multi_last_error.restype = C.c_char_p
+        L.zhip_multi_last_error.argtypes = [C.c_void_p]
+        L.zhip_multi_last_seconds.restype = C.c_double
+        L.zhip_multi_last_seconds.argtypes = [C.c_void_p]
+        L.zhip_multi_set_frame_checksum.argtypes = [C.c_void_p, C.c_int]
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = L.zhip_multi_create(arr, len(devices), chunk_units)
+        if not self._h:
+            raise ZhipError("zhip_multi_create failed")
+
+    def compress_into(self, dst, data, level=1, unit_size=UNIT_SIZE_MAX, cparams=None, sizes=None):
+        """data, dst: numpy uint8 arrays (dst >= compress_bound); returns the compressed size"""
+        L = lib()
+        cp = (C.c_uint * 7)(*cparams) if cparams is not None else None
+        r = L.zhip_compress_multi(self._h, dst.ctypes.data_as(C.c_void_p), dst.nbytes, data.ctypes.data_as(C.c_void_p), data.nbytes, level, cp, unit_size,
+                                  sizes.ctypes.data_as(C.c_void_p) if sizes is not None else None)
+        if L.zhip_isError(r):
+            raise ZhipError(f"zhip_compress_multi: {L.zhip_getErrorName(r).decode()} ({L.zhip_multi_last_error(self._h).decode()})")
+        return int(r)
+
+    def compress(self, data, level=1, unit_size=UNIT_SIZE_MAX, cparams=None):
+        data = np.ascontiguousarray(data)
+        dst = np.empty(compress_bound(data.nbytes, unit_size), dtype=np.uint8)
+        return dst[: self.compress_into(dst, data, level, unit_size, cparams)].tobytes()
+
+    def last_seconds(self):
+        return float(lib().zhip_multi_last_seconds(self._h))
+
+    def close(self):
+        if self._h:
+            lib().zhip_multi_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CDict:
     """a dictionary digested for one GPU (the role ZSTD_CDict plays): parameters + tagged hash tables built on the host
     like ZSTD_createCDict builds them, uploaded once"""

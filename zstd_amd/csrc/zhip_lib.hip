@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
+#include <chrono>
 #include "../../include/zstd_hip.h"
 #include "zhip_common.h"
 #include "zhip_kernels.h"
@@ -909,4 +910,5 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
 
 }  // extern "C"
 
+#include "zhip_multi.h"      // zhip_compress_multi: host buffers over several devices, pinned double-buffered lanes, ordered gather
 #include "zhip_declib.h"     // decoder entry points (zhip_create_dctx, zhip_decompress, ...)

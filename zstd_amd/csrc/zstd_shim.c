@@ -13,6 +13,7 @@ enum { E_GENERIC = 1, E_parameter_unsupported = 40, E_parameter_outOfBound = 42,
 
 struct ZSTD_CDict_s { zhip_cdict* d; };
 struct ZSTD_CCtx_s {
+    zhip_multi* zm;                  /* $ZHIP_DEVICES=0,1,...: sources are sharded over those devices (zhip_compress_multi) */
     zhip_ctx* z;
     size_t    zUnits;
     int       level;                 /* ZSTD_c_compressionLevel; 0 means default (3), lib/zstd.h:337-349 */
@@ -31,7 +32,7 @@ ZSTD_CCtx* ZSTD_createCCtx(void)
 }
 size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 {
-    if (c) { if (c->z) zhip_destroy(c->z); free(c); }
+    if (c) { if (c->z) zhip_destroy(c->z); if (c->zm) zhip_multi_destroy(c->zm); free(c); }
     return 0;
 }
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
@@ -101,11 +102,26 @@ static size_t shim_compress_cdict(ZSTD_CCtx* c, const ZSTD_CDict* cd, void* dst,
     }
 }
 
+/* $ZHIP_DEVICES: comma-separated device ordinals -> the multi-device host path (created on first use) */
+static zhip_multi* shim_multi(ZSTD_CCtx* c)
+{
+    const char* e = getenv("ZHIP_DEVICES");
+    int dev[64]; int n = 0;
+    if (c->zm || !e || !*e) return c->zm;
+    while (*e && n < 64) { dev[n++] = atoi(e); while (*e && *e != ',') e++; if (*e == ',') e++; }
+    if (n) c->zm = zhip_multi_create(dev, n, 0);
+    return c->zm;
+}
+
 static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
 {
     size_t const units = n ? (n + SHIM_UNIT - 1) / SHIM_UNIT : 1;
     if (!c) return SHIM_ERR(E_GENERIC);
     if (level == 0) level = 3;
+    if (units > 1 && shim_multi(c)) {            /* big sources: sharded over $ZHIP_DEVICES with overlapped copies; gathers straight into dst */
+        zhip_multi_set_frame_checksum(c->zm, c->checksum);
+        return zhip_compress_multi(c->zm, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
+    }
     {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
     /* zhip_compress wants room for its own bound; the reference only needs ZSTD_compressBound(n) for a guaranteed
        success and otherwise tries — give the device a private bounce buffer when the caller's is smaller */
