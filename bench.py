@@ -46,12 +46,12 @@ def cpu_baseline(sample, seconds=8.0, level=1):
             ncores = os.cpu_count() or 1
             allc = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
             extra = {}
-            if level >= 5:      # the reference's default matcher for greedy/lazy/lazy2 is the row hash; ours is byte-identical to its hash-chain mode
+            if level >= 5:      # both matchers exist on the device; `value` is the reference default (row hash), the extra figure its hash-chain mode
                 env = dict(os.environ, ZREF_NOROW="1")
                 hc1 = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), "1"], timeout=120, env=env))
                 hca = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120, env=env))
                 extra = {"hash_chain_mode": {"value": hc1["MBps"], "cores": 1, "ratio": hc1["ratio"], "all_cores": hca["MBps"],
-                                             "note": "ZSTD_c_useRowMatchFinder=disable: the mode whose bytes the GPU reproduces; `value` above is the reference default (row matcher)"}}
+                                             "note": "ZSTD_c_useRowMatchFinder=disable (ZHIP_ROW_MATCHER=disable on the device); `value` above is the reference default (row matcher), which the device reproduces by default"}}
             return {**extra, "value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
                     "sample": f"first {len(sample) >> 20} MiB of the workload, level {level}, {UNIT} B units, best of {one['runs']} runs "
                               f"(oracle/_ref/zref_bench = ZSTD_compress2 per unit, programs/benchzstd.c semantics)",
@@ -141,6 +141,8 @@ def parity_check(host, n, dev_out, total, sizes, level=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import load_oracle, _buf, ERR
     lo = load_oracle()
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(0 if os.environ.get("ZHIP_ROW_MATCHER") in ("disable", "0") else 1)     # the matcher the device context uses
     nsamp = min(64, len(host) // UNIT)
     sample = host[: nsamp * UNIT]
     cap = lo.zo_compress_bound(UNIT) * max(1, nsamp)
@@ -156,12 +158,15 @@ def parity_check(host, n, dev_out, total, sizes, level=1):
     magic_ok = bool(((dev_out[idx] == 0x28) & (dev_out[idx + 1] == 0xB5) & (dev_out[idx + 2] == 0x2F) & (dev_out[idx + 3] == 0xFD)).all())
     res = {"bytes_identical_to_oracle_first_64_units": bool(same), "frames_well_formed": magic_ok and int(offs[-1]) == int(total)}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
-    if os.path.exists(exe) and level < 5:      # levels >= 5: the reference's default matcher (row hash) is not the mode the device reproduces
+    if os.path.exists(exe):
         full = min(len(host), n) // UNIT * UNIT if len(host) < n else min(len(host), n)
         tin, tout = f"/tmp/zhip_parity_in_{os.getpid()}.bin", f"/tmp/zhip_parity_out_{os.getpid()}.bin"
         try:
             host[:full].tofile(tin)
-            info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(UNIT), tin, tout, str(os.cpu_count() or 1)], timeout=300))
+            # levels >= 5 (row-hash matcher): a new CCtx per unit — the salt of a reused CCtx depends on what it compressed before
+            env = dict(os.environ, ZREF_FRESH_CCTX="1") if level >= 5 else dict(os.environ)
+            env.pop("ZREF_NOROW", None)
+            info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(UNIT), tin, tout, str(os.cpu_count() or 1)], timeout=600, env=env))
             h = hashlib.sha256()
             with open(tout, "rb") as f:
                 for blk in iter(lambda: f.read(1 << 24), b""):

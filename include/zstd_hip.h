@@ -109,6 +109,12 @@ size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* 
  * frame this context emits carries the 32-bit content checksum (low half of XXH64, computed on the device: k_xxh64) and the
  * descriptor bit, exactly as lib/compress/zstd_compress.c:4637 / :5297-5303 write them.  Sticky until changed.  Returns 0. */
 int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
+/* = ZSTD_c_useRowMatchFinder (lib/zstd.h, experimental): which match finder the strategies greedy / lazy / lazy2 use.
+ * 0 (default, ZSTD_ps_auto) and 1 (ZSTD_ps_enable): the reference's default — the row-hash matcher when windowLog > 14
+ * (lib/compress/zstd_compress.c:237-253), with the hash salt of a FRESH CCtx (bytes = ZSTD_compress2 on a fresh CCtx per unit;
+ * a reused reference CCtx mixes the previous frames' hashes into its salt, :1964-1975); 2 (ZSTD_ps_disable): the hash-chain matcher.
+ * The environment variable ZHIP_ROW_MATCHER=disable sets 2 as a context's initial mode.  Returns 0, or 1 for another value. */
+int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 
 /* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a
  * skippable frame holding the seek table — the natural on-disk form of frame-per-unit output; the reference's

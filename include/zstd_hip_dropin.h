@@ -11,10 +11,12 @@
  *                       ZSTD_c_compressionLevel and the advanced parameters ZSTD_c_windowLog / chainLog / hashLog / searchLog /
  *                       minMatch / targetLength / strategy (applied as ZSTD_getCParamsFromCCtxParams applies them,
  *                       lib/compress/zstd_compress.c:1617-1644).
- *                       CAVEAT for the strategies greedy / lazy / lazy2 (default at levels 5-12): the device runs the
- *                       reference's HASH-CHAIN match finder, i.e. the bytes equal the reference run with
- *                       ZSTD_c_useRowMatchFinder = ZSTD_ps_disable; the reference's default there is the row-hash matcher
- *                       (zstd_compress.c:237-253), whose frames differ (same format, same decoder, a few bytes of ratio).
+ *                       Strategies greedy / lazy / lazy2 (default at levels 5-12): both of the reference's match finders run on
+ *                       the device — the row-hash matcher where the reference picks it by default (windowLog > 14,
+ *                       zstd_compress.c:237-253) and the hash chain otherwise or with ZSTD_c_useRowMatchFinder = disable.
+ *                       The row matcher's hash is SALTED per CCtx reset (zstd_compress.c:1964-1975): the device uses the salt
+ *                       of a fresh CCtx, so the bytes equal ZSTD_compress() / ZSTD_compress2 on a NEW CCtx; a reference CCtx
+ *                       that already compressed something else has another salt and may pick other (equally valid) matches.
  *                       Not implemented on the device -> parameter_unsupported: strategies above lazy2, ZSTD_fast with
  *                       hashLog > 15 (the table lives in LDS), a windowLog smaller than the input, a dictionary whose CDict
  *                       row is a lazy strategy, dictionary + source above 128 KB.
@@ -38,7 +40,8 @@ typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_rese
 /* ZSTD_cParameter values this shim understands (lib/zstd.h:331-507); all others -> parameter_unsupported */
 enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
        ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
-       ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400 };
+       ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400,
+       ZSTD_c_useRowMatchFinder = 1011 /* = ZSTD_c_experimentalParam14: 0 auto, 1 enable, 2 disable */ };
 
 ZSTD_CCtx*  ZSTD_createCCtx(void);                                                                 /* lib/zstd.h:263 */
 size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                                        /* :264 */

@@ -49,7 +49,14 @@ static void* worker(void* p)
     if (getenv("ZREF_NOROW")) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);   /* hash-chain matcher */
     while (off < j->n) {
         size_t const len = j->n - off < j->chunk ? j->n - off : j->chunk;
-        size_t const r = ZSTD_compress2(c, j->dst + pos, j->dstCap - pos, j->src + off, len);
+        size_t r;
+        if (getenv("ZREF_FRESH_CCTX")) {          /* a new CCtx per chunk: the row matcher's hash salt is then the same for every chunk
+                                                     (a reused CCtx mixes the previous frames' hashes into it, zstd_compress.c:1964-1975) */
+            ZSTD_freeCCtx(c); c = ZSTD_createCCtx();
+            ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, j->level);
+            if (getenv("ZREF_NOROW")) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+        }
+        r = ZSTD_compress2(c, j->dst + pos, j->dstCap - pos, j->src + off, len);
         if (ZSTD_isError(r)) { j->err = 1; break; }
         pos += r; off += len;
     }

@@ -241,6 +241,21 @@ size_t zref_compress_frame_params(int level, int contentSizeFlag, int checksumFl
     return ZSTD_isError(r) ? (size_t)-1 : r;
 }
 
+/* the same with the reference's DEFAULT matcher selection (row hash for greedy / lazy / lazy2 when windowLog > 14) on a fresh CCtx */
+size_t zref_sequences_default(int level, const void* src, size_t n, unsigned* out, size_t capSeqs)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    ZSTD_Sequence* s = (ZSTD_Sequence*)malloc(sizeof(ZSTD_Sequence) * capSeqs);
+    size_t r, i;
+    if (!c || !s) return (size_t)-1;
+    set_level(c, level);
+    r = ZSTD_generateSequences(c, s, capSeqs, src, n);
+    if (ZSTD_isError(r)) { free(s); ZSTD_freeCCtx(c); return (size_t)-1; }
+    for (i = 0; i < r; i++) { out[4*i+0] = s[i].offset; out[4*i+1] = s[i].litLength; out[4*i+2] = s[i].matchLength; out[4*i+3] = s[i].rep; }
+    free(s); ZSTD_freeCCtx(c);
+    return r;
+}
+
 /* O2: sequences of ONE unit (n <= 128 KB) from the internal block compressor. out = 4 u32 per sequence
  * {offset, litLength, matchLength, rep}; block delimiter {0,lastLits,0,0} included. */
 size_t zref_sequences(int level, const void* src, size_t n, unsigned* out, size_t capSeqs)

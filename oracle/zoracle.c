@@ -352,13 +352,114 @@ static size_t zo_hc_best(zo_hc* hc, const uint8_t* src, size_t n, size_t ip, uin
     return ml;
 }
 
+/* ---- row-hash match finder (the reference's DEFAULT for greedy / lazy / lazy2 when windowLog > 14, zstd_compress.c:237-253) ----
+ * zstd_lazy.c:778-960 (rows, tags, head rotation, update with the 384-position skip rule), :1141-1340 ZSTD_RowFindBestMatch (noDict).
+ * The hash is salted (zstd_compress_internal.h:865-879); a FRESH CCtx starts from salt 0 / entropy 0 and advances the salt once
+ * in ZSTD_reset_matchState before its first frame (zstd_compress.c:1964-1975, :2027-2033) — that constant is the salt here: the
+ * parity target is ZSTD_compress2 on a fresh CCtx per unit (a reused CCtx mixes the previous frames' hashes into the salt). */
+static int g_zo_row_matcher = 1;              /* 1 = reference default (auto), 0 = ZSTD_c_useRowMatchFinder = ZSTD_ps_disable */
+void zo_set_row_matcher(int enable) { g_zo_row_matcher = enable; }
+static uint64_t zo_rotr64(uint64_t v, unsigned c) { return (v >> c) | (v << (64 - c)); }
+static uint64_t zo_bitmix(uint64_t val, uint64_t len)                            /* zstd_compress.c:1964-1970 */
+{
+    val ^= zo_rotr64(val, 49) ^ zo_rotr64(val, 24);
+    val *= 0x9FB21C651E98DF25ULL;
+    val ^= (val >> 35) + len;
+    val *= 0x9FB21C651E98DF25ULL;
+    return val ^ (val >> 28);
+}
+unsigned long long zo_fresh_hash_salt(void) { return zo_bitmix(0, 8) ^ zo_bitmix(0, 4); }   /* ZSTD_advanceHashSalt from (0, 0) */
+static uint32_t zo_hash_salted(const uint8_t* p, unsigned hBits, unsigned mls, uint64_t salt)   /* internal.h:820-879 */
+{
+    switch (mls) {
+    default:
+    case 4: return ((rd32(p) * 2654435761U) ^ (uint32_t)salt) >> (32 - hBits);
+    case 5: return (uint32_t)((((rd64(p) << 24) * 889523592379ULL) ^ salt) >> (64 - hBits));
+    case 6: return (uint32_t)((((rd64(p) << 16) * 227718039650203ULL) ^ salt) >> (64 - hBits));
+    }
+}
+typedef struct {
+    uint32_t* row;         /* hashTable: rows of 1 << rowLog entries, pos+1, 0 = empty */
+    uint8_t* tag;          /* tagTable: byte 0 of every row is its head */
+    unsigned rowHashLog, rowLog, slog, mls;
+    uint64_t salt;
+    size_t nextToUpdate;
+    int lazySkipping;
+} zo_row;
+static unsigned zo_row_next_index(uint8_t* tagRow, unsigned rowMask)              /* zstd_lazy.c:797-803 */
+{
+    unsigned next = ((unsigned)tagRow[0] - 1) & rowMask;
+    next += (next == 0) ? rowMask : 0;
+    tagRow[0] = (uint8_t)next;
+    return next;
+}
+static void zo_row_insert_range(zo_row* r, const uint8_t* src, size_t from, size_t to)   /* :880-910 */
+{
+    unsigned const rowMask = (1u << r->rowLog) - 1;
+    for (; from < to; from++) {
+        uint32_t const h = zo_hash_salted(src + from, r->rowHashLog + 8, r->mls, r->salt);
+        size_t const rel = (size_t)(h >> 8) << r->rowLog;
+        unsigned const pos = zo_row_next_index(r->tag + rel, rowMask);
+        r->tag[rel + pos] = (uint8_t)h;
+        r->row[rel + pos] = (uint32_t)from + 1;
+    }
+}
+static void zo_row_update(zo_row* r, const uint8_t* src, size_t target)          /* :916-947 (useCache) */
+{
+    size_t idx = r->nextToUpdate;
+    if (target - idx > 384) {                                                    /* kSkipThreshold: only the first 96 and the last 32 */
+        zo_row_insert_range(r, src, idx, idx + 96);
+        idx = target - 32;
+    }
+    zo_row_insert_range(r, src, idx, target);
+    r->nextToUpdate = target;
+}
+static size_t zo_row_best(zo_row* r, const uint8_t* src, size_t n, size_t ip, uint32_t* offBase)   /* :1141-1340 */
+{
+    unsigned const rowEntries = 1u << r->rowLog, rowMask = rowEntries - 1;
+    unsigned const capped = r->slog < r->rowLog ? r->slog : r->rowLog;
+    unsigned nbAttempts = 1u << capped, numMatches = 0, k;
+    uint32_t buf[64];
+    size_t ml = 4 - 1;
+    uint32_t h;
+    if (!r->lazySkipping) zo_row_update(r, src, ip);
+    else r->nextToUpdate = ip;
+    h = zo_hash_salted(src + ip, r->rowHashLog + 8, r->mls, r->salt);
+    {   size_t const rel = (size_t)(h >> 8) << r->rowLog;
+        uint8_t* const tagRow = r->tag + rel; uint32_t* const row = r->row + rel;
+        unsigned const head = tagRow[0] & rowMask;
+        for (k = 0; k < rowEntries && nbAttempts > 0; k++) {                      /* :1232-1247 entries from the most recent on */
+            unsigned const pos = (head + k) & rowMask;
+            if (tagRow[pos] != (uint8_t)h) continue;
+            if (pos == 0) continue;
+            if (row[pos] == 0) break;                                            /* matchIndex < lowLimit: an empty slot */
+            buf[numMatches++] = row[pos] - 1;
+            nbAttempts--;
+        }
+        {   unsigned const pos = zo_row_next_index(tagRow, rowMask);             /* :1251-1255 the searched position goes in too */
+            tagRow[pos] = (uint8_t)h;
+            row[pos] = (uint32_t)r->nextToUpdate + 1;
+            r->nextToUpdate++;
+        }
+    }
+    for (k = 0; k < numMatches; k++) {                                            /* :1258-1285 */
+        size_t const mp = buf[k];
+        size_t cur = 0;
+        if (rd32(src + mp + ml - 3) == rd32(src + ip + ml - 3)) cur = zo_count(src, ip, mp, n);
+        if (cur > ml) { ml = cur; *offBase = (uint32_t)(ip - mp) + 3; if (ip + cur == n) break; }
+    }
+    return ml;
+}
+
 static unsigned zo_gain_bits(uint32_t offBase) { return hb32(offBase); }
 
 /* zstd_lazy.c:1516-1779 ZSTD_compressBlock_lazy_generic(search_hashChain, depth, ZSTD_noDict), one block, empty history */
 static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3], unsigned depth)
 {
-    zo_hc hc;
-    size_t const ilimit = n - 8;                                                 /* :1528 */
+    zo_hc hc; zo_row rw;
+    int const useRow = g_zo_row_matcher && cp->windowLog > 14;                   /* zstd_compress.c:237-253 ZSTD_resolveRowMatchFinderMode */
+    if (useRow && n < 16) return n;                                              /* ilimit = n - 16 < 0: nothing is searched */
+    size_t const ilimit = useRow ? n - 16 : n - 8;                               /* :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier */
     size_t ip = 0, anchor = 0;
     uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
     hc.hlog = cp->hashLog; hc.clog = cp->chainLog; hc.slog = cp->searchLog;
@@ -366,6 +467,12 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
     hc.head = (uint32_t*)calloc((size_t)1 << hc.hlog, sizeof(uint32_t));
     hc.chain = (uint32_t*)calloc((size_t)1 << hc.clog, sizeof(uint32_t));
     hc.nextToUpdate = 0; hc.lazySkipping = 0;                                    /* :1567 */
+    rw.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog); /* zstd_compress.c:2042 */
+    rw.rowHashLog = cp->hashLog - rw.rowLog; rw.slog = cp->searchLog; rw.mls = hc.mls;
+    rw.row = (uint32_t*)calloc((size_t)1 << cp->hashLog, sizeof(uint32_t));
+    rw.tag = (uint8_t*)calloc((size_t)1 << cp->hashLog, 1);
+    rw.salt = zo_fresh_hash_salt(); rw.nextToUpdate = 0; rw.lazySkipping = 0;
+#define ZO_BEST(ipx, ob) (useRow ? zo_row_best(&rw, src, n, (ipx), (ob)) : zo_hc_best(&hc, src, n, (ipx), (ob)))
     ip += 1;                                                                     /* :1552 dictAndPrefixLength == 0 */
     {   uint32_t const maxRep = 1;                                               /* :1553-1559 */
         if (off2 > maxRep) { saved2 = off2; off2 = 0; }
@@ -381,13 +488,13 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
         }
         if (!direct) {
             {   uint32_t found = 999999999;                                      /* :1607-1611 */
-                size_t const ml2 = zo_hc_best(&hc, src, n, ip, &found);
+                size_t const ml2 = ZO_BEST(ip, &found);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
             }
             if (matchLength < 4) {                                               /* :1613-1625 */
                 size_t const step = ((ip - anchor) >> 8) + 1;                    /* kSearchStrength = 8 */
                 ip += step;
-                hc.lazySkipping = step > 8;                                      /* kLazySkippingStep = 8 */
+                hc.lazySkipping = rw.lazySkipping = step > 8;                    /* kLazySkippingStep = 8 */
                 continue;
             }
             if (depth >= 1)
@@ -400,7 +507,7 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
                     if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {   uint32_t cand = 999999999;
-                    size_t const ml2 = zo_hc_best(&hc, src, n, ip, &cand);
+                    size_t const ml2 = ZO_BEST(ip, &cand);
                     int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
                     int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 4);
                     if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
@@ -414,7 +521,7 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
                         if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {   uint32_t cand = 999999999;
-                        size_t const ml2 = zo_hc_best(&hc, src, n, ip, &cand);
+                        size_t const ml2 = ZO_BEST(ip, &cand);
                         int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
                         int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 7);
                         if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
@@ -430,7 +537,7 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
         }
         zo_store_seq(st, src, anchor, start - anchor, offBase, (uint32_t)matchLength);   /* :1727-1731 */
         anchor = ip = start + matchLength;
-        hc.lazySkipping = 0;                                                     /* :1732-1738 */
+        hc.lazySkipping = rw.lazySkipping = 0;                                   /* :1732-1738 */
         while (ip <= ilimit && off2 > 0 && rd32(src + ip) == rd32(src + ip - off2)) {    /* :1763-1773 */
             uint32_t const t = off2;
             matchLength = zo_count(src, ip + 4, ip + 4 - off2, n) + 4;
@@ -442,7 +549,8 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
     saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;                       /* :1777-1783 */
     rep[0] = off1 ? off1 : saved1;
     rep[1] = off2 ? off2 : saved2;
-    free(hc.head); free(hc.chain);
+    free(hc.head); free(hc.chain); free(rw.row); free(rw.tag);
+#undef ZO_BEST
     return n - anchor;
 }
 

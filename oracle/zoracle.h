@@ -87,4 +87,9 @@ void zo_datagen(void* buf, size_t size, double matchProba, double litProba, unsi
 #ifdef __cplusplus
 }
 #endif
+/* strategies greedy / lazy / lazy2: 1 (default) = the reference's default matcher selection (row hash when windowLog > 14, with the
+ * salt of a fresh CCtx), 0 = ZSTD_c_useRowMatchFinder = ZSTD_ps_disable (hash chain) */
+void zo_set_row_matcher(int enable);
+unsigned long long zo_fresh_hash_salt(void);
+
 #endif

@@ -167,7 +167,7 @@ def corpus_cases(lib_o, sizes=(131072,), seeds=(0,)):
 # ----------------------------------------------------------------------------- host SIMT emulator of the product kernels
 UNIT_DT = np.dtype([("srcOff", "<u8"), ("srcLen", "<u4"), ("windowLog", "u1"), ("chainLog", "u1"), ("hashLog", "u1"),
                     ("minMatch", "u1"), ("strategy", "u1"), ("searchLog", "u1"), ("litMode", "u1"), ("pad0", "u1"),
-                    ("targetLength", "<u4")])
+                    ("targetLength", "<u4"), ("rowLog", "<u4"), ("pad1", "<u4")])
 SEQ_DT = np.dtype([("offBase", "<u4"), ("litLength", "<u2"), ("mlBase", "<u2")])
 PARSE_DT = np.dtype([("nbSeq", "<u4"), ("lastLits", "<u4"), ("longPos", "<u4"), ("longType", "<u4"),
                      ("rep", "<u4", (3,)), ("status", "<u4"), ("litSize", "<u4"), ("pad0", "<u4")])
@@ -190,14 +190,16 @@ def load_emu():
     return lib
 
 
-def make_units(lo, sizes, level, unit=131072):
-    """unit table for buffers laid out back to back; sizes = list of unit lengths"""
+def make_units(lo, sizes, level, unit=131072, row=False):
+    """unit table for buffers laid out back to back; sizes = list of unit lengths.  row: greedy / lazy / lazy2 units with
+    windowLog > 14 use the row-hash matcher (the reference's default), else the hash chain"""
     units = np.zeros(len(sizes), dtype=UNIT_DT)
     off = 0
     for i, n in enumerate(sizes):
         cp = (C.c_uint * 7)()
         assert lo.zo_get_cparams(level, n, cp) == 0
-        units[i] = (off, n, cp[0], cp[1], cp[2], cp[4], cp[6], cp[3], 1 if (cp[6] == 1 and cp[5] > 0) else 0, 0, cp[5])
+        rowLog = min(6, max(4, cp[3])) if (row and 3 <= cp[6] <= 5 and cp[0] > 14) else 0
+        units[i] = (off, n, cp[0], cp[1], cp[2], cp[4], cp[6], cp[3], 1 if (cp[6] == 1 and cp[5] > 0) else 0, 0, cp[5], rowLog, 0)
         off += n
     return units
 

@@ -52,7 +52,7 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     else
         simt::launch({nUnits, 1, 1}, {ZHIP_HC_SEARCH_LDS_THREADS, 1, 1}, ((maxLen + 15) & ~15u) + 32,
                      [=] { zhip::k_hc_search_lds(src, units, nUnits, tabs, tabStride, best); }, osThreads);
-    simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0,
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
                  [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas); }, osThreads);
 }
 uint64_t emu_hc_table_words(uint32_t hashLog) { return zhip::hc_table_words(hashLog); }

@@ -203,3 +203,44 @@ def test_fast_parse_explicit_parameters(libs):
             want = oseq[:nb].copy(); want[:, 0] &= 0xFFFF; want[:, 1] = ((want[:, 1] - 3) & 0xFFFF) + 3
             assert np.array_equal(got, want), (cpv, cases[i][0])
             assert np.array_equal(lits[i * lstride: i * lstride + litSize.value], olit[:litSize.value]), (cpv, cases[i][0])
+
+
+def test_rowhash_parse_matches_oracle(libs):
+    """strategies greedy / lazy / lazy2 with the ROW-HASH matcher (the reference's default for windowLog > 14): k_hc_chain builds the
+    per-row links, k_hc_search_lds walks them with the tag filter, k_parse_lazy applies the 384-position skip rule and lazy
+    skipping — against the oracle's row matcher (itself pinned to the reference with a fresh CCtx per unit)"""
+    lo, le = libs
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(1)
+    try:
+        for level in (5, 6, 7, 9, 10):
+            cases = list(corpus_cases(lo, sizes=(131072, 40000), seeds=(1,)))
+            rng = np.random.default_rng(level)
+            big = np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 190)[:131072].copy()       # matches of > 384 bytes: the skip rule
+            big[rng.integers(0, 131072, 40)] ^= 0xFF
+            cases.append(("period700", big))
+            cases.append(("incompressible_then_text", np.concatenate([rng.integers(0, 256, 60000, dtype=np.uint8), cases[3][1][:71072]])))   # lazy skipping
+            bufs = [c[1] for c in cases]
+            units = make_units(lo, [len(b) for b in bufs], level, row=True)
+            assert (units["rowLog"] > 0).all()
+            src = np.concatenate(bufs + [np.zeros(16, dtype=np.uint8)])
+            cap = le.emu_seq_cap()
+            seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT); metas = np.zeros(len(bufs), dtype=PARSE_DT)
+            lstride = le.emu_lit_stride()
+            lits = np.full(len(bufs) * lstride, 0xEE, dtype=np.uint8)
+            emu_parse_units(le, src, units, seqs, lits, metas)
+            for i, (name, a) in enumerate(cases):
+                oseqs, litSize, rep, olits = oracle_parse(lo, a, level, want_lits=True)
+                m = metas[i]
+                s = seqs[i * cap: i * cap + int(m["nbSeq"])]
+                ll = s["litLength"].astype(np.uint32); ml = s["mlBase"].astype(np.uint32) + 3
+                if m["longType"] == 1: ll[m["longPos"]] += 0x10000
+                if m["longType"] == 2: ml[m["longPos"]] += 0x10000
+                got = np.stack([ll, ml, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32)
+                assert len(got) == len(oseqs), (level, name, len(got), len(oseqs))
+                bad = np.nonzero((got != oseqs).any(axis=1))[0]
+                assert len(bad) == 0, (level, name, int(bad[0]), got[bad[0]].tolist(), oseqs[bad[0]].tolist())
+                assert int(m["litSize"]) == litSize and np.array_equal(lits[i * lstride: i * lstride + litSize], olits), (level, name)
+                assert list(m["rep"][:2]) == rep[:2], (level, name)
+    finally:
+        lo.zo_set_row_matcher(0)

@@ -19,6 +19,34 @@ def test_oracle_reproduces_golden_hashchain_units():
     _check(GOLD_HC, (5, 6, 7), 600)
 
 
+GOLD_ROW = os.path.join(os.path.dirname(__file__), "golden", "units_v3_rowhash.json")
+
+
+def test_oracle_reproduces_golden_rowhash_units():
+    """greedy / lazy / lazy2 with the reference's DEFAULT matcher (row hash when windowLog > 14, fresh-CCtx salt)"""
+    import ctypes as C
+    lo = load_oracle()
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(1)
+    try:
+        gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD_ROW))["units"]}
+        seen = 0
+        for n in (131072, 100001, 40000, 20000):
+            for name, a in corpus_cases(lo, sizes=(n,), seeds=(0,)):
+                for level in (5, 6, 7, 8, 9, 10):
+                    g = gold.get((name, level))
+                    if g is None:
+                        continue
+                    assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"], name
+                    dst = np.zeros(n + 1024, dtype=np.uint8)
+                    r = lo.zo_compress_unit(_buf(dst), len(dst), _buf(a), n, level)
+                    assert r != ERR and r == g["csize"] and hashlib.sha256(dst[:r].tobytes()).hexdigest() == g["dst_sha256"], (name, level)
+                    seen += 1
+        assert seen == len(gold) > 300
+    finally:
+        lo.zo_set_row_matcher(0)
+
+
 def _check(path, levels, atleast):
     lo = load_oracle()
     gold = {(g["case"], g["level"]): g for g in json.load(open(path))["units"]}

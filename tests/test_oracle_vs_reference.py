@@ -166,3 +166,25 @@ def test_stage_fse_normalize_matches_reference(libs):
                 assert ro == -1
                 continue
             assert ro == rr and np.array_equal(no[: maxsym + 1], nr[: maxsym + 1]), (trial, low)
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 8, 9, 10])
+def test_rowhash_unit_bytes_match_reference_fresh_cctx(libs, level):
+    """the reference's DEFAULT matcher for greedy / lazy / lazy2 (row hash, windowLog > 14): ZSTD_compress2 on a FRESH CCtx per unit
+    (its hash salt is then the constant a new context starts with, zstd_compress.c:1964-1975, :2027-2033)"""
+    lo, lr = libs
+    lr.zref_compress_frame.restype = C.c_size_t
+    lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(1)
+    try:
+        for n in (131072, 70001, 20000, 16385, 16384):
+            for name, a in corpus_cases(lo, sizes=(n,), seeds=(0, 3)):
+                o = (C.c_uint * 7)()
+                if lo.zo_get_cparams(level, n, o) != 0:
+                    continue
+                want = np.zeros(n + 1024, dtype=np.uint8)
+                k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
+                assert k != ERR and ora_unit(lo, a, level) == want[:k].tobytes(), (name, level)
+    finally:
+        lo.zo_set_row_matcher(0)

@@ -284,6 +284,14 @@ class Context:
                                                               len(offs) - 1, sizes_ptr, stream), "zhip_compress_records_device")
 
     # ---- full pipeline
+    def set_row_matcher(self, mode):
+        """greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14, salt of a fresh CCtx),
+        2 = hash-chain matcher (ZSTD_c_useRowMatchFinder = ZSTD_ps_disable)"""
+        L = lib()
+        L.zhip_set_row_matcher.argtypes = [C.c_void_p, C.c_int]
+        if L.zhip_set_row_matcher(self._h, int(mode)) != 0:
+            raise ZhipError("zhip_set_row_matcher: bad mode")
+
     def compress_device(self, dst_ptr, dst_cap, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, sizes_ptr=None, stream=None):
         return self._check(lib().zhip_compress_device(self._h, dst_ptr, dst_cap, src_ptr, src_size, level, unit_size,
                                                       sizes_ptr, stream), "zhip_compress_device")

@@ -21,6 +21,8 @@ struct ZhipUnit {
     uint8_t  windowLog, chainLog, hashLog, minMatch;
     uint8_t  strategy, searchLog, litMode /* 1: literals stay raw (negative levels) */, pad0 /* records path: ZHIP_UNIT_COPYMODE = the dictionary is copied, not attached */;
     uint32_t targetLength;
+    uint32_t rowLog;        // greedy / lazy / lazy2: 0 = hash-chain matcher, 4 / 5 / 6 = row-hash matcher with rows of 2^rowLog entries
+    uint32_t pad1;
 };
 
 // where a unit's intermediate results live: offsets into the context's arenas, filled by the host.  Full-size units use the

@@ -109,6 +109,14 @@ k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
     uint32_t* const queue = (uint32_t*)(best + (size_t)ui * ZHIP_UNIT_MAX);
     const uint8_t* const p = src + u.srcOff;
+    if (u.rowLog) {                                     // row-hash matcher: links keyed by the row index, heads in LDS
+        switch (u.minMatch) {
+        case 5:  rh_chain_unit<5>(p, u.srcLen, u, smem, prev); break;
+        case 6: case 7: case 8: rh_chain_unit<6>(p, u.srcLen, u, smem, prev); break;
+        default: rh_chain_unit<4>(p, u.srcLen, u, smem, prev); break;
+        }
+        return;
+    }
     switch (u.minMatch) {                               // zstd_lazy.c:1531 mls = BOUNDED(4, minMatch, 6)
     case 5:  hc_chain_unit<5>(p, u.srcLen, u, smem, prev, queue); break;
     case 6: case 7: case 8: hc_chain_unit<6>(p, u.srcLen, u, smem, prev, queue); break;
@@ -155,7 +163,8 @@ k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
     __syncthreads();
     const uint32_t* const prev = tabs + (size_t)ui * tabStride;
     uint64_t* const b = best + (size_t)ui * ZHIP_UNIT_MAX;
-    for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = hc_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.chainLog);
+    if (u.rowLog) { for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = rh_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.rowLog); }
+    else for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = hc_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.chainLog);
 }
 
 __global__ void __launch_bounds__(64)
@@ -163,12 +172,13 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
              uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
+    HIP_DYNAMIC_SHARED(unsigned char, smem)                // ZHIP_RH_DIRTY_BYTES: the row matcher's dirty-row bits
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
-    parse_lazy_unit(src + u.srcOff, u.srcLen, u, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
+    parse_lazy_unit(src + u.srcOff, u.srcLen, u, smem, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
                     seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui);
 }
 

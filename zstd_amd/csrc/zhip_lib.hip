@@ -54,6 +54,7 @@ struct zhip_ctx_s {
     // last call
     size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
+    int rowMode;                         // greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14), 2 = hash chain (ZSTD_ps_disable)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -134,6 +135,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
+    {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { c->cs[i] = nullptr; c->cev[i] = nullptr; }
     memset(c->timing, 0, sizeof(c->timing));
@@ -183,6 +185,14 @@ zhip_ctx* zhip_create_for_records(int device, size_t maxRecords, size_t maxTotal
     if (maxRecords == 0) maxRecords = 1;
     return create_impl(device, maxRecords, maxTotalBytes / 4 + 8 * maxRecords + 64, maxTotalBytes + 80 * maxRecords + 64,
                        maxTotalBytes + (maxTotalBytes >> 8) + 128 * maxRecords + 64);
+}
+
+int zhip_set_row_matcher(zhip_ctx* c, int mode)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (mode != 0 && mode != 1 && mode != 2) return 1;
+    c->rowMode = mode == 2 ? 2 : 0;      // enable (1) = auto here: the device has no row matcher for windowLog <= 14 either way the reference resolves it
+    return 0;
 }
 
 int zhip_set_frame_checksum(zhip_ctx* c, int enable)
@@ -267,6 +277,10 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0;
         {   static int const knob = getenv("ZHIP_DF_WIDTH") ? atoi(getenv("ZHIP_DF_WIDTH")) : 0; u.pad0 = (uint8_t)knob; }   // dfast batch-width knob (scripts/)
         u.targetLength = cp->targetLength;
+        // ZSTD_resolveRowMatchFinderMode (zstd_compress.c:237-253): greedy / lazy / lazy2 use the row-hash matcher when windowLog > 14
+        u.rowLog = 0; u.pad1 = 0;
+        if (cp->strategy >= ZHIP_STRAT_GREEDY && cp->strategy <= ZHIP_STRAT_LAZY2 && c->rowMode != 2 && cp->windowLog > 14)
+            u.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog);       // :2042 BOUNDED(4, searchLog, 6)
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
@@ -344,7 +358,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 }
             }
             HIPCHK(c, hipEventRecord(he[2], s));
-            hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), 0, s,
+            hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
                                srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
                                c->dSeqs, c->dLits, c->dParse + u0);
             HIPCHK(c, hipEventRecord(he[3], s));
@@ -623,7 +637,7 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         u.srcOff = recOffsets[i]; u.srcLen = (uint32_t)n;
         u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
         u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength;
+        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
         ZhipSlot& sl = c->hSlots[i];
         sl.seqOff = seqOff; sl.litOff = litOff; sl.outOff = outOff; sl.seqCap = (uint32_t)rec_seq_cap(n); sl.pad0 = 0;
         seqOff += rec_seq_cap(n); litOff += rec_lit_bytes(n); outOff += rec_out_bytes(n);

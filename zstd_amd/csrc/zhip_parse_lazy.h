@@ -264,12 +264,159 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
     return hc_pack(0, 0, 3, minCand);
 }
 
+// ------------------------------------------------------------------ the row-hash matcher (zstd_lazy.c:778-960, :1141-1340)
+// the reference's DEFAULT for greedy / lazy / lazy2 when windowLog > 14 (zstd_compress.c:237-253).  A row keeps the
+// (2^rowLog - 1) most recently inserted positions whose salted hash has the same upper bits, with the hash's low 8 bits as a
+// tag; a search looks at the row's entries with its own tag, most recent first, at most 2^min(searchLog, rowLog) of them.
+// With every earlier position inserted that is again a pure function of the position: "the previous position of the same row"
+// is a chain link (prev[], built like the hash-chain links but keyed by the row index — 2^(hashLog - rowLog) <= 2^13 heads, so
+// the head table is the 17-bit LDS table of zhip_parse.h and needs no slicing), the tag rides in the link word, and the
+// search walks at most 2^rowLog - 1 links.  The salt is the one a fresh CCtx has on its first frame.
+//   prev[p] = (1 + previous position of p's row) | tag(p) << 18   (| ZHIP_HC_SKIPPED once the parser knows p was never inserted)
+#define ZHIP_RH_LINK_MASK 0x3FFFFu
+__host__ __device__ inline uint64_t rh_bitmix(uint64_t val, uint64_t len)            // zstd_compress.c:1964-1970
+{
+    val ^= ((val >> 49) | (val << 15)) ^ ((val >> 24) | (val << 40));
+    val *= 0x9FB21C651E98DF25ULL;
+    val ^= (val >> 35) + len;
+    val *= 0x9FB21C651E98DF25ULL;
+    return val ^ (val >> 28);
+}
+__host__ __device__ inline uint64_t rh_fresh_salt() { return rh_bitmix(0, 8) ^ rh_bitmix(0, 4); }   // ZSTD_advanceHashSalt from (0, 0), :1973
+// ZSTD_hashPtrSalted (zstd_compress_internal.h:820-879), hBits <= 32: the top hBits of (product ^ salt)
+template <uint32_t MLS>
+__device__ __forceinline__ uint32_t hash_pos_salted(uint64_t bytes, uint32_t hBits, uint64_t salt)
+{
+    if (MLS <= 4) return (((uint32_t)bytes * 2654435761U) ^ (uint32_t)salt) >> (32 - hBits);
+    uint32_t const top = MLS == 5 ? mulhi64_top32(bytes, 889523592379ULL << 24) : mulhi64_top32(bytes, 227718039650203ULL << 16);
+    return (top ^ (uint32_t)(salt >> 32)) >> (32 - hBits);
+}
+__host__ __device__ inline uint32_t rh_chain_lds_bytes(uint32_t rowHashLog) { return fast_lds_bytes(rowHashLog < 5 ? 5 : rowHashLog); }
+
+template <uint32_t MLS>
+__device__ inline void rh_chain_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem, uint32_t* __restrict__ prev)
+{
+    if (n < 10) return;
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const nm8 = n - 8, rowHashLog = (uint32_t)u.hashLog - u.rowLog, hBits = rowHashLog + 8;
+    uint64_t const salt = rh_fresh_salt();
+    FastTab T;
+    T.lo = (lds_u16*)(uintptr_t)smem;
+    T.hi = (lds_u32*)(uintptr_t)(smem + (2u << rowHashLog));
+    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
+        uint32_t const words = fast_lds_bytes(rowHashLog) >> 2;
+        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long const laneBelow = below_mask((int)lane);
+    for (uint32_t p0 = 0; p0 <= nm8; p0 += 64) {                              // positions in order, 64 per step; heads hold position + 1
+        uint32_t const p = p0 + lane; bool const live = p <= nm8;
+        uint32_t const pc = live ? p : nm8;
+        uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
+        uint32_t const h = hash_pos_salted<MLS>(bytes, hBits, salt), row = h >> 8, tag = h & 0xFFu;
+        uint32_t old = T.lo[row];
+        if (p0 + 64 > 65535u) old |= ((T.hi[row >> 5] >> (row & 31)) & 1u) << 16;
+        __builtin_amdgcn_wave_barrier();
+        if (live) T.lo[row] = (uint16_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long const liveMask = __ballot(live);
+        unsigned long long const lose = __ballot(live && T.lo[row] != (uint16_t)lane);
+        uint32_t link = old;
+        unsigned long long grp = 0;
+        if (lose) {
+            grp = lane_groups(row, lose, liveMask);
+            unsigned long long const before = grp & laneBelow;
+            uint32_t const pd = before ? 63u - (uint32_t)__clzll((long long)before) : lane;
+            uint32_t const dp = __shfl(p, (int)pd);
+            if (before) link = dp + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            prev[p] = link | (tag << 18);
+            if ((grp & ~below_mask((int)lane + 1)) == 0) tab_put(T, row, p + 1);     // the last lane of a row group leaves the head
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340, noDict) at p with every earlier position inserted; the unit staged in LDS
+__device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uint32_t p, const uint32_t* __restrict__ prev,
+                                             uint32_t searchLog, uint32_t rowLog)
+{
+    uint32_t const capped = searchLog < rowLog ? searchLog : rowLog;
+    uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;             // a row holds 2^rowLog - 1 positions (slot 0 is its head byte)
+    uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE, nCap = 0, capA = 0, capB = 0;
+    uint32_t const w0 = prev[p], myTag = (w0 >> 18) & 0xFFu;
+    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
+    bool done = false;
+    while (m != 0 && attempts && room) {
+        uint32_t const mp = m - 1;
+        uint32_t const w = prev[mp];
+        minCand = mp; room--;
+        if (((w >> 18) & 0xFFu) == myTag) {
+            attempts--;
+            if (!done && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+                uint32_t cur = 0;
+                for (;;) {
+                    uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
+                    cur += same;
+                    if (same < 8 || cur >= ZHIP_HC_CAP) break;
+                }
+                if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
+                else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) done = true; }      // :1281 best possible: evaluation stops, the row was read anyway
+            }
+        }
+        m = w & ZHIP_RH_LINK_MASK;
+    }
+    if (nCap == 0) return hc_pack(off, ml, 0, minCand);
+    if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand);
+    return hc_pack(0, 0, 3, minCand);
+}
+
 // ------------------------------------------------------------------ kernel C: the parser, one wavefront per unit
 struct HcState {
     uint32_t ntu;           // ms->nextToUpdate (zstd_compress_internal.h:232)
     uint32_t skipping;      // ms->lazySkipping (:253)
     uint32_t gapEnd;        // highest position flagged ZHIP_HC_SKIPPED so far, 0 = none (position 0 is always inserted)
+    lds_u32* dirty;         // row matcher: one bit per row, set when a position of that row was flagged (2^(hashLog - rowLog) bits of LDS)
 };
+#define ZHIP_RH_DIRTY_BYTES 2048u      /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
+
+// row matcher: mark the rows of the never-inserted positions [f0, f1): only searches in such a row can differ from their record
+template <uint32_t MLS>
+__device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t f0, uint32_t f1)
+{
+    uint32_t const nm8 = n - 8, hBits = (uint32_t)u.hashLog - u.rowLog + 8;
+    uint64_t const salt = rh_fresh_salt();
+    for (uint32_t q = f0 + (uint32_t)lane_id(); q < f1; q += 64) {
+        prev[q] |= ZHIP_HC_SKIPPED;
+        uint32_t const qc = q < nm8 ? q : nm8;
+        uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + qc) : ld64(src + qc);
+        uint32_t const row = hash_pos_salted<MLS>(bytes, hBits, salt) >> 8;
+        __hip_atomic_fetch_or(&st.dirty[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    st.gapEnd = f1 - 1;
+}
+__device__ inline void rh_flag_range(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t f0, uint32_t f1)
+{
+    uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
+    if (mls == 4) rh_flag_range_t<4>(src, n, u, prev, st, f0, f1);
+    else if (mls == 5) rh_flag_range_t<5>(src, n, u, prev, st, f0, f1);
+    else rh_flag_range_t<6>(src, n, u, prev, st, f0, f1);
+}
+// is the row of position x dirty?  (uniform x: every lane computes the same)
+__device__ inline bool rh_row_dirty(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const HcState& st, uint32_t x)
+{
+    uint32_t const nm8 = n - 8, hBits = (uint32_t)u.hashLog - u.rowLog + 8, xc = x < nm8 ? x : nm8;
+    uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
+    uint64_t const salt = rh_fresh_salt();
+    uint64_t const bytes = mls == 4 ? (uint64_t)ld32(src + xc) : ld64(src + xc);
+    uint32_t const h = mls == 4 ? hash_pos_salted<4>(bytes, hBits, salt) : (mls == 5 ? hash_pos_salted<5>(bytes, hBits, salt) : hash_pos_salted<6>(bytes, hBits, salt));
+    uint32_t const row = h >> 8;
+    return (st.dirty[row >> 5] >> (row & 31)) & 1u;
+}
 
 // the search the reference would run at x with positions flagged in prev[] missing from the chains (all values uniform)
 __device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
@@ -294,10 +441,94 @@ __device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t 
     mlOut = ml; offOut = off;
 }
 
-// one ZSTD_HcFindBestMatch call of the reference at x: insertion bookkeeping + the (pre)computed result
+// (measured, datagen P50 level 5, 8192 units resident: refreshing whole batches costs 616 ms per GiB against 324 ms for one
+// wave-wide live search per stale search — 64 lanes x ~20 random sectors per batch is HBM traffic without any locality; the
+// real fix is to run the search kernel again with the flags of a first parse applied — see DESIGN.md)
+#ifndef ZHIP_RH_BATCH_REFRESH
+#define ZHIP_RH_BATCH_REFRESH 0
+#endif
+// the same search redone by ONE LANE for its own position with the never-inserted positions (flagged in prev[]) left out of the
+// rows: the parser refreshes the stale records of a whole batch with it, 64 positions at a time (a stale record per search would
+// otherwise mean a serial walk of dependent loads per search — gaps of more than 384 positions are common in long-match data)
+__device__ inline uint64_t rh_search_lane(const uint8_t* __restrict__ src, uint32_t n, uint32_t p, const uint32_t* __restrict__ prev,
+                                          uint32_t searchLog, uint32_t rowLog)
+{
+    uint32_t const nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
+    uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
+    uint32_t ml = 3, off = 0, nCap = 0, capA = 0, capB = 0;
+    uint32_t const w0 = prev[p], myTag = (w0 >> 18) & 0xFFu;
+    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
+    bool done = false;
+    while (m != 0 && attempts && room) {
+        uint32_t const mp = m - 1;
+        uint32_t const w = prev[mp];
+        m = w & ZHIP_RH_LINK_MASK;
+        if (w & ZHIP_HC_SKIPPED) continue;
+        room--;
+        if (((w >> 18) & 0xFFu) != myTag) continue;
+        attempts--;
+        if (!done && p + ml < n && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
+            uint32_t cur = 0;
+            for (;;) {
+                uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
+                cur += same;
+                if (same < 8 || cur >= ZHIP_HC_CAP) break;
+            }
+            if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
+            else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) done = true; }
+        }
+    }
+    // minCand = NONE: this record already accounts for every flag raised so far
+    if (nCap == 0) return hc_pack(off, ml, 0, ZHIP_HC_NONE);
+    if (nCap <= 2) return hc_pack(capA, capB, nCap, ZHIP_HC_NONE);
+    return hc_pack(0, 0, 3, ZHIP_HC_NONE);
+}
+
+// the row search the reference would run at x with the positions flagged in prev[] missing from the rows (all values uniform)
+__device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
+                                      uint32_t searchLog, uint32_t rowLog, uint32_t& mlOut, uint32_t& offOut)
+{
+    uint32_t const nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
+    uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
+    uint32_t ml = 3, off = 0;
+    uint32_t const w0 = uni(prev[x]), myTag = (w0 >> 18) & 0xFFu;
+    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
+    bool done = false;
+    while (m != 0 && attempts && room) {
+        uint32_t const mp = m - 1;
+        uint32_t const w = uni(prev[mp]);
+        m = w & ZHIP_RH_LINK_MASK;
+        if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
+        room--;
+        if (((w >> 18) & 0xFFu) != myTag) continue;
+        attempts--;
+        if (!done && uni(ld32(src + mp + ml - 3)) == uni(ld32(src + x + ml - 3))) {
+            uint32_t const cur = wave_count_fwd(src, x, mp, nm8);
+            if (cur > ml) { ml = cur; off = x - mp; if (x + cur == n) done = true; }
+        }
+    }
+    mlOut = ml; offOut = off;
+}
+
+// row matcher, a search at x that is NOT in lazy-skipping mode (zstd_lazy.c:916-947): of a gap of more than 384 positions since
+// nextToUpdate only the first 96 and the last 32 are inserted — the rest is flagged as never inserted
+__device__ inline void rh_gap_rule(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t x)
+{
+    if (x > st.ntu && x - st.ntu > 384) rh_flag_range(src, n, u, prev, st, st.ntu + 96, x - 32);
+}
+
+// one ZSTD_HcFindBestMatch / ZSTD_RowFindBestMatch call of the reference at x: insertion bookkeeping + the (pre)computed result
 __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st,
                                  uint32_t x, uint64_t rec, uint32_t& ml, uint32_t& offBase)
 {
+    if (u.rowLog) {
+        // row matcher (zstd_lazy.c:916-947, :1199-1209): ntu = ms->nextToUpdate.  Lazy skipping inserts nothing but the searched
+        // position; otherwise everything since ntu goes in — except the middle of a gap of more than 384 positions, of which
+        // only the first 96 and the last 32 are inserted
+        if (!st.skipping) rh_gap_rule(src, n, u, prev, st, x);
+        else if (st.ntu < x) rh_flag_range(src, n, u, prev, st, st.ntu, x);
+        st.ntu = x + 1;                                   // the searched position is inserted by the search itself (:1251-1255)
+    } else {
     if (st.skipping && st.ntu + 1 < x) {                  // :651 only nextToUpdate itself is inserted; the rest never will be
         for (uint32_t q = st.ntu + 1 + (uint32_t)lane_id(); q < x; q += 64) prev[q] |= ZHIP_HC_SKIPPED;
         __threadfence_block();
@@ -305,10 +536,15 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
         st.gapEnd = x - 1;
     }
     st.ntu = x;
+    }
     uint32_t off;
     uint32_t const minCand = hc_rec_min(rec), mode = hc_rec_mode(rec);
-    if (mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd))
-        hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
+    bool live = mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd);
+    if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x);      // a record only depends on its own row
+    if (live) {
+        if (u.rowLog) rh_search_live(src, n, x, prev, u.searchLog, u.rowLog, ml, off);
+        else hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
+    }
     else if (mode == 0) { ml = hc_rec_b(rec); off = hc_rec_a(rec); }
     else {                                                // one or two candidates ran into the compare cap: measure them
         uint32_t const nm8 = n - 8, cA = hc_rec_a(rec);
@@ -322,11 +558,15 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     offBase = off + 3;
 }
 
-__device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
+__device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem /* ZHIP_RH_DIRTY_BYTES */,
                                        uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
                                        ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
+    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
+        for (uint32_t i = lane; i < ZHIP_RH_DIRTY_BYTES / 4; i += 64) z[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
     uint32_t const depth = (uint32_t)u.strategy - 3;      // greedy 0, lazy 1, lazy2 2
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
@@ -336,10 +576,11 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     if (off2 > 1) { saved2 = off2; off2 = 0; }
     if (off1 > 1) { saved1 = off1; off1 = 0; }
 
-    if (n >= 10) {
-    uint32_t const nm8 = n - 8, ilimit = n - 8;           // :1528
+    uint32_t const rowBias = u.rowLog ? 1u : 0u;          // the row matcher's nextToUpdate sits one past the last searched position
+    if (n >= (u.rowLog ? 18u : 10u)) {
+    uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
-    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0;
+    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
@@ -356,6 +597,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         uint64_t recj = 0; bool repj = false;
         bool repHit; uint64_t rec;
         if (step <= 8) {
+            if (u.rowLog) rh_gap_rule(src, n, u, prev, st, ip);       // the batch's first search (at ip, not lazy-skipping) meets the gap since nextToUpdate
             // lanes take the positions the reference visits next while nothing is found: ip, ip+step, ... (same step)
             uint32_t const xj = ip + lane * step;
             bool const valid = xj < ilimit && ((xj - anchor) >> 8) + 1 == step;
@@ -365,18 +607,26 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             else { recj = valid ? best[xj] : 0; cur4 = ld32(src + xc + 1); rv = ld32(src + (xc + 1 - off1)); }
             repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
             uint32_t const minCand = hc_rec_min(recj);
-            bool const needLive = valid && (hc_rec_mode(recj) == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd));
+            bool stale = st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd;
+            if (u.rowLog && st.gapEnd != 0) {
+                stale = valid && stale && rh_row_dirty(src, n, u, st, xc);      // per lane: a record only depends on its own row
+#if ZHIP_RH_BATCH_REFRESH
+                if (stale) recj = rh_search_lane(src, n, xj, prev, u.searchLog, u.rowLog);     // refreshed in place, all stale lanes at once
+                stale = false;
+#endif
+            }
+            bool const needLive = valid && (hc_rec_mode(recj) == 3 || stale);
             bool const found = valid && (hc_rec_mode(recj) != 0 || hc_rec_b(recj) >= 4);
             K = (uint32_t)__popcll(__ballot(valid));
             unsigned long long const ev = __ballot(repj || needLive || found);
             if (!ev) {                                                       // K failed searches (:1613-1624), lazySkipping = 0
-                st.ntu = ip + (K - 1) * step; st.skipping = 0;
-                ip = st.ntu + step;
+                st.ntu = ip + (K - 1) * step + rowBias; st.skipping = 0;
+                ip = ip + K * step;
                 continue;
             }
             int const e = first_lane(ev);
             x = ip + (uint32_t)e * step;
-            if (e > 0) { st.ntu = x - step; st.skipping = 0; }
+            if (e > 0) { st.ntu = x - step + rowBias; st.skipping = 0; }
             repHit = (__ballot(repj) >> e) & 1;
             rec = readlane64(recj, e);
         } else {

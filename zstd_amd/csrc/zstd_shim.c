@@ -18,6 +18,7 @@ struct ZSTD_CCtx_s {
     size_t    zUnits;
     int       level;                 /* ZSTD_c_compressionLevel; 0 means default (3), lib/zstd.h:337-349 */
     int       checksum;              /* ZSTD_c_checksumFlag */
+    int       rowMode;               /* ZSTD_c_useRowMatchFinder: 0 auto, 1 enable, 2 disable (lib/zstd.h ZSTD_paramSwitch_e) */
     unsigned  cp[7];                 /* ZSTD_c_windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; 0 = the level's */
     const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
@@ -38,7 +39,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 {
     if (!c) return SHIM_ERR(E_GENERIC);
-    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; memset(c->cp, 0, sizeof(c->cp)); }
+    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; c->rowMode = 0; memset(c->cp, 0, sizeof(c->cp)); }
     return 0;
 }
 static size_t shim_set_cp(ZSTD_CCtx* c, int idx, int value, int lo, int hi)
@@ -61,6 +62,7 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     case ZSTD_c_minMatch:     return shim_set_cp(c, 4, value, 3, 7);
     case ZSTD_c_targetLength: return shim_set_cp(c, 5, value, 0, 131072);
     case ZSTD_c_strategy:     return shim_set_cp(c, 6, value, 1, 9);
+    case ZSTD_c_useRowMatchFinder: if (value < 0 || value > 2) return SHIM_ERR(E_parameter_outOfBound); c->rowMode = value; return 0;
     case ZSTD_c_contentSizeFlag: return value == 1 ? 0 : SHIM_ERR(E_parameter_unsupported);
     case ZSTD_c_checksumFlag:    c->checksum = value != 0; return 0;
     case ZSTD_c_dictIDFlag:      return 0;                        /* no dictionary can be attached: the flag has no effect */
@@ -79,6 +81,7 @@ static size_t shim_ensure(ZSTD_CCtx* c, size_t units)
         c->zUnits = want;
     }
     zhip_set_frame_checksum(c->z, c->checksum);
+    if (c->rowMode) zhip_set_row_matcher(c->z, c->rowMode);     /* 0 = keep the context's own default ($ZHIP_ROW_MATCHER) */
     return 0;
 }
 
