@@ -1274,6 +1274,7 @@ static size_t huf_encode_with(uint8_t* dst0, uint8_t* op, const uint8_t* src, si
 
 /* huf_compress.c:1333-1434 HUF_compress_internal WITH a previous table (*repeat: 0 none, 1 check, 2 valid; set to 0 when a new
  * table is emitted) */
+static zo_prev* g_huf_next = NULL;   /* when set: receives the Huffman table huf_compress_prev builds and uses (multi-block frames) */
 static size_t huf_compress_prev(uint8_t* dst, const uint8_t* src, size_t n, int fourStreams, int suspect,
                                 const zo_prev* pv, int* repeat, int preferRepeat)
 {
@@ -1311,6 +1312,7 @@ static size_t huf_compress_prev(uint8_t* dst, const uint8_t* src, size_t n, int 
         op += h;
         *repeat = 0;
     }
+    if (g_huf_next) { memcpy(g_huf_next->hufNbBits, nbBits, 256); memcpy(g_huf_next->hufValue, value, sizeof(value)); g_huf_next->hufMaxSym = maxSym; g_huf_next->hufRepeat = 1; }
     return huf_encode_with(dst, op, src, n, fourStreams, nbBits, value);
 }
 
@@ -2246,6 +2248,171 @@ size_t zo_frame_add_checksum(void* framev, size_t frameSize, const void* src, si
     f[4] |= 1u << 2;
     wr32(f + frameSize, (uint32_t)zo_xxh64(src, n, 0));
     return frameSize + 4;
+}
+
+/* ------------------------------------------------------------------ multi-block frames
+ * ZSTD_compress2 of a source of any size as ONE frame: ZSTD_compress_frameChunk (zstd_compress.c:4527-4623) with the blind
+ * 92 KB split (:4494-4518), blocks sharing window, hash table, repcodes and the previous Huffman table
+ * (ZSTD_blockState_confirmRepcodesAndEntropyTables :3549, only after a block that was emitted compressed :4379-4381).
+ * Strategy ZSTD_fast (zstd_fast.c:192-423 with a prefix): positions are relative to the frame start; T[] holds pos+1. */
+static size_t zo_fast_block(const zo_cparams* cp, const uint8_t* src /* frame start */, size_t bStart, size_t bLen, uint32_t* T,
+                            zo_store* st, uint32_t rep[3])
+{
+    unsigned const hlog = cp->hashLog, mls = cp->minMatch;
+    size_t const stepSize = cp->targetLength + !cp->targetLength + 1;
+    size_t const maxDist = (size_t)1 << cp->windowLog;
+    size_t const iend = bStart + bLen, ilimit = iend - 8;
+    size_t const dictLimit = bStart > maxDist ? bStart - maxDist : 0;            /* ZSTD_window_enforceMaxDist (:1107) from the block START */
+    size_t const prefixLow = (iend - dictLimit > maxDist) ? iend - maxDist : dictLimit;   /* ZSTD_getLowestPrefixIndex(endIndex) :1206 */
+    size_t anchor = bStart, ip0 = bStart, ip1, ip2, ip3, cur0 = 0, step, nextStep, match0 = 0, mLength;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, offBase;
+    uint32_t h0, h1, cand;
+    ip0 += (ip0 == prefixLow);                                                   /* :238 */
+    {   size_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;   /* :239-244 */
+        size_t const maxRep = ip0 - windowLow;
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+#define ZO_VALID(c) ((c) != 0 && (size_t)(c) - 1 >= prefixLow)
+    for (;;) {
+        step = stepSize; nextStep = ip0 + 128;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        h0 = zo_hash(src + ip0, hlog, mls); h1 = zo_hash(src + ip1, hlog, mls);
+        cand = T[h0];
+        for (;;) {
+            int found = 0;
+            uint32_t const rval = rep1 ? rd32(src + ip2 - rep1) : 0;
+            cur0 = ip0; T[h0] = (uint32_t)ip0 + 1;
+            if (rep1 > 0 && rd32(src + ip2) == rval) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = (src[ip0 - 1] == src[match0 - 1]);
+                ip0 -= mLength; match0 -= mLength;
+                offBase = 1; mLength += 4;
+                T[h1] = (uint32_t)ip1 + 1;
+                found = 2;
+            } else if (ZO_VALID(cand) && rd32(src + ip0) == rd32(src + cand - 1)) {
+                T[h1] = (uint32_t)ip1 + 1;
+                found = 1;
+            } else {
+                cand = T[h1]; h0 = h1; h1 = zo_hash(src + ip2, hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip3;
+                cur0 = ip0; T[h0] = (uint32_t)ip0 + 1;
+                if (ZO_VALID(cand) && rd32(src + ip0) == rd32(src + cand - 1)) {
+                    if (step <= 4) T[h1] = (uint32_t)ip1 + 1;
+                    found = 1;
+                } else {
+                    cand = T[h1]; h0 = h1; h1 = zo_hash(src + ip2, hlog, mls);
+                    ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+                    if (ip2 >= nextStep) { step++; nextStep += 128; }
+                    if (ip3 < ilimit) continue;
+                    goto cleanup;
+                }
+            }
+            if (found == 1) {
+                match0 = cand - 1;
+                rep2 = rep1; rep1 = (uint32_t)(ip0 - match0);
+                offBase = rep1 + 3; mLength = 4;
+                while (ip0 > anchor && match0 > prefixLow && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+            }
+            {   size_t a = ip0 + mLength, b = match0 + mLength;                  /* ZSTD_count up to the BLOCK end */
+                while (a < iend && src[a] == src[b]) { a++; b++; }
+                mLength = a - ip0;
+            }
+            zo_store_seq(st, src, anchor, ip0 - anchor, offBase, (uint32_t)mLength);
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {
+                T[zo_hash(src + cur0 + 2, hlog, mls)] = (uint32_t)cur0 + 2 + 1;
+                T[zo_hash(src + ip0 - 2, hlog, mls)] = (uint32_t)ip0 - 2 + 1;
+                if (rep2 > 0) {
+                    while (ip0 <= ilimit && rd32(src + ip0) == rd32(src + ip0 - rep2)) {
+                        size_t a = ip0 + 4, b = ip0 + 4 - rep2;
+                        uint32_t rLength;
+                        while (a < iend && src[a] == src[b]) { a++; b++; }
+                        rLength = (uint32_t)(a - ip0);
+                        {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
+                        T[zo_hash(src + ip0, hlog, mls)] = (uint32_t)ip0 + 1;
+                        ip0 += rLength;
+                        zo_store_seq(st, src, anchor, 0, 1, rLength);
+                        anchor = ip0;
+                    }
+                }
+            }
+            break;
+        }
+    }
+cleanup:
+#undef ZO_VALID
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return iend - anchor;
+}
+
+size_t zo_frame_bound(size_t n) { return n + (n >> 8) + 64 + 3 * (n / 8192 + 2); }
+
+size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
+{
+    uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
+    uint8_t* op = dst;
+    size_t pos = 0; long long savings = 0; int isFirst = 1;
+    uint32_t rep[3] = {1, 4, 8};
+    uint32_t* T; zo_seq* seqs; uint8_t* lits; uint8_t* body;
+    zo_prev prev, next;
+    if (cp->strategy != 1 || cap < zo_frame_bound(n)) return ZO_ERROR;
+    op += write_frame_header(op, cp, n);
+    if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
+    T = (uint32_t*)calloc((size_t)1 << cp->hashLog, sizeof(uint32_t));
+    seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 2));
+    lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 8);
+    body = (uint8_t*)malloc(ZO_BLOCK_MAX + 1024);
+    memset(&prev, 0, sizeof(prev));
+    while (pos < n) {
+        size_t const remaining = n - pos;
+        size_t bLen = remaining < ZO_BLOCK_MAX ? remaining : ZO_BLOCK_MAX;       /* :4494-4518 ZSTD_optimalBlockSize, strategies below lazy2 */
+        size_t cSize = 0; int last;
+        if (remaining >= ZO_BLOCK_MAX && savings >= 3) bLen = 92 * 1024;
+        last = bLen == remaining;
+        if (bLen >= 7) {                                                         /* :3216 */
+            zo_store st; uint32_t nrep[3] = { rep[0], rep[1], rep[2] };
+            size_t lastLits;
+            st.seqs = seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
+            lastLits = zo_fast_block(cp, src, pos, bLen, T, &st, nrep);
+            memcpy(lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
+            next = prev;
+            {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);
+                size_t l, sq;
+                g_huf_next = &next;
+                l = zo_compress_literals_prev(body, ZO_BLOCK_MAX + 1024, lits, st.litSize, cp, suspect, &prev);
+                g_huf_next = NULL;
+                if (l >= 1 && (body[0] & 3) < 2) next = prev;                    /* raw / RLE literals: the previous table stays (literals.c:186, :199) */
+                sq = zo_compress_sequences(body + l, ZO_BLOCK_MAX + 1024 - l, seqs, st.nb, cp);
+                if (sq == ZO_ERROR || st.overflow) { free(T); free(seqs); free(lits); free(body); return ZO_ERROR; }
+                cSize = (sq == 0) ? 0 : l + sq;
+                if (cSize >= bLen - ((bLen >> 6) + 2)) cSize = 0;                /* :3026 */
+            }
+            if (!isFirst && cSize < 25) {                                        /* :4365-4376 an RLE block, never the first */
+                size_t i; int same = 1;
+                for (i = 1; i < bLen; i++) if (src[pos + i] != src[pos]) { same = 0; break; }
+                if (same) { cSize = 1; body[0] = src[pos]; }
+            }
+            if (cSize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2]; prev = next; }   /* :4379-4381 */
+        }
+        if (cSize == 0) { wr24(op, (uint32_t)(last + (0 << 1) + (bLen << 3))); memcpy(op + 3, src + pos, bLen); cSize = 3 + bLen; }
+        else if (cSize == 1) { wr24(op, (uint32_t)(last + (1 << 1) + (bLen << 3))); op[3] = body[0]; cSize = 4; }
+        else { wr24(op, (uint32_t)(last + (2 << 1) + (cSize << 3))); memcpy(op + 3, body, cSize); cSize += 3; }
+        op += cSize;
+        savings += (long long)bLen - (long long)cSize;
+        pos += bLen; isFirst = 0;
+    }
+    free(T); free(seqs); free(lits); free(body);
+    return (size_t)(op - dst);
+}
+size_t zo_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level)
+{
+    zo_cparams cp;
+    if (zo_get_cparams(level, n, &cp) != 0) return ZO_ERROR;
+    return zo_compress_frame_params(dst, cap, src, n, &cp);
 }
 
 size_t zo_compress_unit(void* dst, size_t cap, const void* src, size_t n, int level)

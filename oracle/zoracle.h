@@ -92,4 +92,10 @@ void zo_datagen(void* buf, size_t size, double matchProba, double litProba, unsi
 void zo_set_row_matcher(int enable);
 unsigned long long zo_fresh_hash_salt(void);
 
+/* ONE frame for a source of any size (multi-block: shared window, hash table, repcodes, previous Huffman table; 92 KB blind split) =
+ * ZSTD_compress2 on the whole source.  Strategy ZSTD_fast only (else ZO_ERROR).  cap >= zo_frame_bound(n). */
+size_t zo_frame_bound(size_t n);
+size_t zo_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level);
+size_t zo_compress_frame_params(void* dst, size_t cap, const void* src, size_t n, const zo_cparams* cp);
+
 #endif

@@ -89,6 +89,26 @@ __device__ __forceinline__ void tab_put(const FastTab& T, uint32_t h, uint32_t p
     T.lo[h] = (uint16_t)pos;
     if (pos >> 16) __hip_atomic_fetch_or(&T.hi[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
+// entry of slot h; `high`: positions >= 65536 may exist (only then is the bit plane read)
+__device__ __forceinline__ uint32_t tab_get(const FastTab& T, uint32_t h, bool high)
+{
+    uint32_t v = T.lo[h];
+    if (high) v |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+    return v;
+}
+// the slot as duplicate detector: leave a small marker (a lane id), read it back, put the old entry back
+__device__ __forceinline__ void tab_mark(const FastTab& T, uint32_t h, uint32_t v) { T.lo[h] = (uint16_t)v; }
+__device__ __forceinline__ uint32_t tab_peek(const FastTab& T, uint32_t h) { return T.lo[h]; }
+__device__ __forceinline__ void tab_unmark(const FastTab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
+
+// the same table with full 32-bit positions, for blocks that share one table across a multi-block frame (positions are relative
+// to the frame start and exceed 2^17); a flat pointer: LDS when 4 << hashLog bytes fit, else global memory
+struct WideTab { uint32_t* w; };
+__device__ __forceinline__ void tab_put(const WideTab& T, uint32_t h, uint32_t pos) { T.w[h] = pos; }
+__device__ __forceinline__ uint32_t tab_get(const WideTab& T, uint32_t h, bool) { return T.w[h]; }
+__device__ __forceinline__ void tab_mark(const WideTab& T, uint32_t h, uint32_t v) { T.w[h] = v; }
+__device__ __forceinline__ uint32_t tab_peek(const WideTab& T, uint32_t h) { return T.w[h]; }
+__device__ __forceinline__ void tab_unmark(const WideTab& T, uint32_t h, uint32_t old) { T.w[h] = old; }
 
 // ------------------------------------------------------------------ wave-wide match extension
 // Every load below is clamped to [0, n-8] so that no lane ever reads outside the unit; `sh` bytes are then shifted out.
@@ -261,8 +281,8 @@ __device__ __forceinline__ FastBatch batch_load(const uint8_t* src, uint32_t nm8
 // lanes 0..61 compare 8 bytes at ip0+8*lane with the bytes rep2 back, lane 62 fetches the bytes of cur0+2, lane 63 those
 // of ip0-2 (the two inserts of :407-408).  With NEXT the bytes of the batch that starts at the final ip0 ride along
 // (returned in `cur`, result true).  Requires ip0 <= ilimit (= nm8).
-template <uint32_t MLS, bool NEXT>
-__device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const FastTab& T, FastOut& out,
+template <uint32_t MLS, bool NEXT, typename TAB>
+__device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const TAB& T, FastOut& out,
                                            uint32_t& ip0, uint32_t& anchor, uint32_t& rep1, uint32_t& rep2, uint32_t cur0, bool first,
                                            uint32_t startPosOff, uint32_t startRposOff, FastBatch& cur)
 {
@@ -359,9 +379,10 @@ __device__ __forceinline__ uint32_t fwd_run(const uint8_t* src, uint32_t nm8, ui
     return base + wave_count_fwd(src, from, from - off, nm8);
 }
 
-template <uint32_t MLS>
-__device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const FastTab& T, FastOut& out,
-                                            uint32_t& ip0_, uint32_t& anchor_, uint32_t& rep1_, uint32_t& rep2_, uint32_t& nextStep)
+template <uint32_t MLS, typename TAB>
+__device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const TAB& T, FastOut& out,
+                                            uint32_t& ip0_, uint32_t& anchor_, uint32_t& rep1_, uint32_t& rep2_, uint32_t& nextStep,
+                                            uint32_t prefixLow /* lowest valid match position (0 for a unit) */)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const B = ip0_;
@@ -377,15 +398,14 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
 
     // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
     // lanes of one hash hold the same old value)
-    uint32_t old = T.lo[h];
-    if (B > 65536) old |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+    uint32_t const old = tab_get(T, h, B > 65536);
     uint32_t const cb = ld32(src + old);                                  // old == 0 reads the unit's first bytes: harmless; in flight
     __builtin_amdgcn_wave_barrier();                                      // during the duplicate detection below
-    T.lo[h] = (uint16_t)lane;
+    tab_mark(T, h, lane);
     __builtin_amdgcn_wave_barrier();
-    uint32_t const backId = T.lo[h];
+    uint32_t const backId = tab_peek(T, h);
     __builtin_amdgcn_wave_barrier();
-    T.lo[h] = (uint16_t)old;
+    tab_unmark(T, h, old);
     __builtin_amdgcn_wave_barrier();
 
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
@@ -419,7 +439,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             else a = 64;
         }
     }
-    unsigned long long const M = __ballot(old != 0 && cb == cur32) & lanes_below(Dw);
+    unsigned long long const M = __ballot(old != 0 && old >= prefixLow && cb == cur32) & lanes_below(Dw);
     ZWPROF(out, 1);
 
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
@@ -490,7 +510,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             E1q = __ballot(x == 0); E1b = __ballot((x & 0xFFu) == 0);
         }
         uint32_t const room = B + j - anchor;
-        uint32_t const limit = isRep ? 1u : (room < c ? room : c);        // :271 / :387
+        uint32_t const limit = isRep ? 1u : (room < c - prefixLow ? room : c - prefixLow);        // :271 / :387 (match0 > prefixStart)
         uint32_t run = 0;
         if (j) {
             unsigned long long const t = ~E1b << (64 - j);
@@ -514,7 +534,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             nEv = out.nbSeq - nbSeq0;                                     // post_match stores its sequences itself
             ZW_TABLE_FLUSH();
             uint32_t ip0n = anchor;
-            if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, B + cur0L, true, 0, 0, dummy); }
+            if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false, TAB>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, B + cur0L, true, 0, 0, dummy); }
             i = ip0n - B;
             ZWPROF(out, 9);
             break;
@@ -536,7 +556,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
                 nEv = out.nbSeq - nbSeq0;
                 ZW_TABLE_FLUSH();
                 uint32_t ip0n = anchor;
-                if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, 0, false, 0, 0, dummy); }
+                if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false, TAB>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, 0, false, 0, 0, dummy); }
                 i = ip0n - B;
                 break;
             }
@@ -569,10 +589,13 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     return status;
 }
 
-// smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
-template <uint32_t MLS>
-__device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
-                                       unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+// One block of ZSTD_fast over src[b0, n) with the table T as the previous blocks of the same frame left it (a unit: b0 = 0 and
+// a fresh table).  Matches may start anywhere in [prefixLow, position): prefixLow = max(0, n - 2^windowLog) is where
+// ZSTD_window_enforceMaxDist (zstd_compress.c:4686) leaves the window for this block; maxRep = ip0 - windowLow (:238-244).
+template <uint32_t MLS, typename TAB>
+__device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
+                                        uint32_t repIn1, uint32_t repIn2, uint32_t repIn3, const ZhipUnit& u,
+                                        const TAB& T, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const hlog = u.hashLog, hshift = 32 - hlog;
@@ -583,28 +606,18 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
 #ifdef ZHIP_PROF
     out.zp = zp_acc_; out.zlast = &zp_last_;
 #endif
-
-    FastTab T;
-    T.lo = (lds_u16*)(uintptr_t)smem;
-    T.hi = (lds_u32*)(uintptr_t)(smem + (2u << hlog));
-    {   // fresh table (zstd_compress.c:2020): lo[] and hi[] are contiguous
-        lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = fast_lds_bytes(hlog) >> 2;
-        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
-    }
-    __builtin_amdgcn_wave_barrier();
     ZPROF(0);
 
-    uint32_t anchor = 0, rep1 = 1, rep2 = 4, saved1 = 0, saved2 = 0;
-    // :238-244  ip0 = 1, lowest index 0 -> maxRep = 1
-    if (rep2 > 1) { saved2 = rep2; rep2 = 0; }
-    if (rep1 > 1) { saved1 = rep1; rep1 = 0; }
+    uint32_t anchor = b0, rep1 = repIn1, rep2 = repIn2, saved1 = 0, saved2 = 0;
+    // :238-244  a repcode that reaches below the window is set aside for the block
+    if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+    if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
 
-    if (n >= 13) {                          // shortest unit whose first iteration runs (ip3 = 1 + 2 + 1 < n - 8)
+    if (n - b0 >= 12) {                     // shorter blocks never run an iteration (ip3 = ip0 + 2 + 1 < n - 8); keeps n - 8 >= b0
     uint32_t const nm8 = n - 8;
     int32_t const ilimit = (int32_t)nm8;
-    uint32_t ip0 = 1;
-    if (lane == 0) lits[0] = src[0];                                         // position 0 is never searched (:238): windows only store their own lanes
+    uint32_t ip0 = b0 + (b0 == prefixLow);                                   // :238 ip0 += (ip0 == prefixStart)
+    if (ip0 != b0 && lane == 0) lits[0] = src[b0];                           // that position is never searched: windows only store their own lanes
     uint32_t startPosOff, startRposOff; batch_offsets(stepSize, stepSize, startPosOff, startRposOff);
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
@@ -622,7 +635,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         dense = true;                            // schedule-shaped batches (cheaper per position when events are far apart)
         for (;;) {
             if (dense && stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
-                int const st = window_batch<MLS>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep);
+                int const st = window_batch<MLS, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep, prefixLow);
                 have = false;
                 ZPROF_COUNT(10, 1);
                 if (st == ZW_RESTART) { evKind = 3; break; }
@@ -651,12 +664,11 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
             // Each live lane rewrites its slot below (new position, or the old value), so nothing leaks.
             uint32_t const cur32 = (uint32_t)cur.bytes;
             uint32_t const h = hash_pos<MLS>(cur.bytes, hshift);
-            uint32_t old = T.lo[h];
-            if (ip0 > 65536) old |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+            uint32_t const old = tab_get(T, h, ip0 > 65536);
             __builtin_amdgcn_wave_barrier();
-            if (live) T.lo[h] = (uint16_t)lane;
+            if (live) tab_mark(T, h, lane);
             __builtin_amdgcn_wave_barrier();
-            uint32_t const back = T.lo[h];
+            uint32_t const back = tab_peek(T, h);
 
             // speculative loads for the next batch (used if this one has no event)
             uint32_t const nip0 = ip0 + g0 + (uint32_t)(K - 1) * step;
@@ -684,7 +696,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
                 uint32_t const dpos = __shfl(pos, (int)pd), d32 = __shfl(cur32, (int)pd);
                 if (prevMask) { cand = dpos; cb = d32; }
             }
-            unsigned long long const mMask = __ballot(cand != 0 && cb == cur32) & liveMask;
+            unsigned long long const mMask = __ballot(cand != 0 && cand >= prefixLow && cb == cur32) & liveMask;
             unsigned long long const rMask = rep1 ? (__ballot(cur.rcur == cur.rv) & liveMask & evenLanes) : 0ull;
             int const jm = mMask ? first_lane(mMask) : 64, jr = rMask ? first_lane(rMask) : 64;
             int const rankM = jm < 64 ? 3 * (jm >> 1) + 1 + (jm & 1) : 0x7fffffff;
@@ -702,10 +714,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
                 unsigned long long const later = inside & ~below_mask((int)lane + 1);
                 we = live && (inC ? later == 0 : inside == 0);
             }
-            if (we) T.lo[h] = (uint16_t)(inC ? pos : old);
-            if (nip0 > 65536) {
-                if (we && inC && (pos >> 16)) __hip_atomic_fetch_or(&T.hi[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
+            if (we) { if (inC) tab_put(T, h, pos); else tab_unmark(T, h, old); }
             __builtin_amdgcn_wave_barrier();
             ZPROF(6);
 
@@ -741,7 +750,7 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         if (evKind == 1) {
             rep2 = rep1; rep1 = mpos - cand0;
             offBase = rep1 + 3;
-            lim = (mpos - anchor) < cand0 ? (mpos - anchor) : cand0;
+            lim = (mpos - anchor) < cand0 - prefixLow ? (mpos - anchor) : cand0 - prefixLow;       // :387 match0 > prefixStart
         } else {
             cand0 = mpos - rep1;
             offBase = 1;
@@ -759,14 +768,14 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
         // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along
         have = false;
         if ((int32_t)ip0 <= ilimit)
-            have = post_match<MLS, true>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, startPosOff, startRposOff, cur);
+            have = post_match<MLS, true, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, startPosOff, startRposOff, cur);
         ZPROF(7);
     }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
     lits_flush(out);
     } else {
-        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];           // tiny unit: everything is a literal
-        out.litPos = n;
+        for (uint32_t i = lane; i < n - b0; i += 64) lits[i] = src[b0 + i]; // tiny block: everything is a literal
+        out.litPos = n - b0;
     }
     // ---- _cleanup (:368-375)
     ZPROF(8);
@@ -775,9 +784,28 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
     if (lane == 0) {
         meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
         meta->longPos = out.longPos; meta->longType = out.longType;
-        meta->rep[0] = rep1 ? rep1 : saved1; meta->rep[1] = rep2 ? rep2 : saved2; meta->rep[2] = 8;
+        meta->rep[0] = rep1 ? rep1 : saved1; meta->rep[1] = rep2 ? rep2 : saved2; meta->rep[2] = repIn3;
         meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
     }
+}
+
+// One unit = one block with a fresh table.  smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
+template <uint32_t MLS>
+__device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
+                                       unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const hlog = u.hashLog;
+    FastTab T;
+    T.lo = (lds_u16*)(uintptr_t)smem;
+    T.hi = (lds_u32*)(uintptr_t)(smem + (2u << hlog));
+    {   // fresh table (zstd_compress.c:2020): lo[] and hi[] are contiguous
+        lds_u32* const z = (lds_u32*)(uintptr_t)smem;
+        uint32_t const words = fast_lds_bytes(hlog) >> 2;
+        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    parse_fast_block<MLS, FastTab>(src, 0, n, 0, 1, 1, 4, 8, u, T, seqs, lits, meta);   // lowest index 0, ip0 = 1 -> maxRep = 1
 }
 
 }  // namespace zhip
