@@ -74,6 +74,19 @@ size_t       zhip_compress_params(zhip_ctx* ctx, void* dst, size_t dstCapacity, 
 size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
                                          int level, const unsigned cparams[7], size_t unitSize, uint32_t* unitSizesDev, void* stream);
 
+/* ---- multi-block frames: input i = src[srcOffsets[i], srcOffsets[i+1]) becomes ONE standard frame holding
+ * the blocks ZSTD_compress2 / ZSTD_compress emit for it on a fresh CCtx (lib/compress/zstd_compress.c:4520-4640 ZSTD_compress_frameChunk:
+ * 128 KB blocks, 92 KB once the frame has saved 3 bytes; table, window, repcodes and Huffman table carried from block to block) —
+ * byte-identical to the reference's single frame.  The block chain of a frame is serial: a frame is one workgroup, so the batch,
+ * not the frame, is what fills the GPU (the per-unit calls above are the throughput path).  Implemented for strategy ZSTD_fast
+ * (levels <= 2 by size class and the negative levels; other strategies -> parameter_unsupported), inputs below 2 GiB each,
+ * nFrames <= the context's maxUnits.  dstCapacity >= zhip_frames_bound().  frameSizes (optional) receives each frame's size. */
+size_t       zhip_frames_bound(const unsigned long long* srcOffsets /* nFrames + 1 */, size_t nFrames);
+size_t       zhip_compress_frames(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
+                                  size_t nFrames, int level, const unsigned cparams[7] /* or NULL */, size_t* frameSizes);
+size_t       zhip_compress_frames_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* srcOffsets,
+                                         size_t nFrames, int level, const unsigned cparams[7], uint32_t* frameSizesDev, void* stream);
+
 /* ---- host buffers over SEVERAL devices in one process: independent units shard across the GPUs of a node, one
  * HIP stream + pinned staging per lane ($ZHIP_MULTI_LANES lanes per device, default 4: some lanes' copies overlap another's kernels), no collective;
  * finished chunks are gathered on the host in source order (destination offset = exclusive prefix sum of the sizes before).

@@ -26,6 +26,12 @@
  *                       `zstd -b<level> -B128K` chunking, but it is NOT the reference's single shared-window frame.
  *                       ZSTD_getFrameContentSize() of the stream reports the first unit only; use
  *                       ZSTD_findDecompressedSize() (lib/zstd.h:1492) for the total.
+ *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and strategy ZSTD_fast (levels 1-2 by size
+ *                       class, negative levels) the output IS the reference's single frame, byte for byte: one frame header,
+ *                       128 KB / 92 KB blocks sharing the window, the hash table, the repcodes and the Huffman table
+ *                       (zstd_compress.c:4520-4640; zhip_compress_frames).  The block chain of one frame is serial — one
+ *                       workgroup — so this is the fidelity mode, not the throughput mode; other strategies keep the
+ *                       frame-per-unit stream.
  */
 #ifndef ZSTD_HIP_DROPIN_H
 #define ZSTD_HIP_DROPIN_H
@@ -41,7 +47,8 @@ typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_rese
 enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
        ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
        ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400,
-       ZSTD_c_useRowMatchFinder = 1011 /* = ZSTD_c_experimentalParam14: 0 auto, 1 enable, 2 disable */ };
+       ZSTD_c_useRowMatchFinder = 1011 /* = ZSTD_c_experimentalParam14: 0 auto, 1 enable, 2 disable */,
+       ZHIP_c_singleFrame = 100001 /* not a reference parameter: 1 = sources above 128 KB as one multi-block frame (see above) */ };
 
 ZSTD_CCtx*  ZSTD_createCCtx(void);                                                                 /* lib/zstd.h:263 */
 size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                                        /* :264 */

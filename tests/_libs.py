@@ -275,3 +275,54 @@ def emu_compress_units(le, lo, bufs, level, checksum=False):
     else:
         le.emu_entropy(_buf(src), _buf(units), nu, _buf(seqs), _buf(metas), _buf(lits), _buf(stb), _buf(out), _buf(osz), 0)
     return [out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nu)]
+
+
+def oracle_frame(lo, a, level):
+    """the oracle's multi-block single frame (strategy fast) for one input"""
+    lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
+    lo.zo_compress_frame.restype = C.c_size_t
+    lo.zo_compress_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    cap = lo.zo_frame_bound(len(a))
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = lo.zo_compress_frame(_buf(dst), cap, _buf(a) if len(a) else None, len(a), level)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+def emu_compress_frames(le, lo, bufs, level, checksum=False):
+    """the frame kernel (one workgroup per multi-block frame) on the emulator; returns list of frame bytes"""
+    sizes = [len(b) for b in bufs]
+    frames = make_units(lo, sizes, level)                  # parameters come from the whole input's size class
+    src = np.concatenate(list(bufs) + [np.zeros(16, dtype=np.uint8)])
+    nf = len(bufs)
+    ostride = (max(sizes) + (max(sizes) >> 8) + 2048 + 15) & ~15
+    out = np.full(nf * ostride, 0xEE, dtype=np.uint8)
+    osz = np.zeros(nf, dtype=np.uint32)
+    chk = None
+    if checksum:
+        chk = np.zeros(nf + 16, dtype=np.uint32)
+        le.emu_xxh64.restype = None
+        le.emu_xxh64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64(_buf(src), _buf(frames), nf, _buf(chk), 0)
+    le.emu_frame_fast.restype = None
+    le.emu_frame_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    le.emu_frame_fast(_buf(src), _buf(frames), nf, _buf(out), ostride, _buf(osz), _buf(chk) if checksum else None, 0)
+    return [out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nf)]
+
+
+def frame_cases(lo):
+    """inputs for the multi-block frame tests (tests/golden/frames_v1.json pins the reference's output for each)"""
+    rng = np.random.default_rng(77)
+    yield "dg_131073", datagen(lo, 131073, 50, 4)
+    yield "dg_400000", datagen(lo, 400000, 50, 5)
+    yield "dg_1m", datagen(lo, 1 << 20, 50, 6)
+    yield "dg_p90_3m", datagen(lo, 3 << 20, 90, 7)                    # > 2^19: matches past the level-1 window are refused
+    yield "text_700k", text_like(700000, 3)
+    yield "random_300k", rng.integers(0, 256, size=300000, dtype=np.uint8)
+    yield "zeros_500k", np.zeros(500000, np.uint8)
+    yield "lowent_400k", rng.integers(0, 4, size=400000, dtype=np.uint8)
+    yield "mixed_640k", np.concatenate([datagen(lo, 150000, 50, 1), rng.integers(0, 256, size=140000, dtype=np.uint8),
+                                        np.full(200000, 7, np.uint8), text_like(150000, 9)])
+    b = datagen(lo, 262144 + 50, 50, 8).copy(); b[131072:262144] = b[:131072]      # a block that is one long match into the previous one
+    yield "repeat_block", b
+    yield "tail_6", datagen(lo, 131072 + 6, 50, 9)                    # last block below the 7-byte minimum

@@ -151,6 +151,27 @@ void emu_entropy_ck(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
                  [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u, checks); }, osThreads);
 }
+// multi-block frames: frames[i] describes one whole input; out holds outStride bytes per frame
+void emu_frame_fast(const uint8_t* src, const ZhipUnit* frames, uint32_t nFrames, uint8_t* out, uint64_t outStride, uint32_t* outSize,
+                    const uint32_t* checks, int osThreads)
+{
+    std::vector<ZhipSlot> sv(nFrames ? nFrames : 1);
+    uint32_t maxLog = 0;
+    for (uint32_t i = 0; i < nFrames; i++) {
+        sv[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; sv[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; sv[i].outOff = (uint64_t)i * outStride; sv[i].seqCap = ZHIP_SEQ_CAP; sv[i].pad0 = 0;
+        if (frames[i].hashLog > maxLog) maxLog = frames[i].hashLog;
+    }
+    const ZhipSlot* const slots = sv.data();
+    std::vector<ZhipSeq> seqs((size_t)nFrames * ZHIP_SEQ_CAP); std::vector<uint8_t> lits((size_t)nFrames * ZHIP_LIT_STRIDE);
+    std::vector<uint16_t> stBits((size_t)nFrames * ZHIP_SEQ_CAP * 3);
+    size_t const tabStride = maxLog > ZHIP_FRAME_LDS_HASHLOG ? (size_t)1 << maxLog : 0;
+    std::vector<uint32_t> tabs((size_t)nFrames * tabStride + 1);
+    std::vector<zhip::ZhipFrameState> states(nFrames ? nFrames : 1);
+    ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
+    zhip::ZhipFrameState* const stp = states.data();
+    simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(maxLog > ZHIP_FRAME_LDS_HASHLOG ? ZHIP_FRAME_LDS_HASHLOG : maxLog),
+                 [=] { zhip::k_frame_fast(src, frames, slots, nFrames, tb, tabStride, sq, lt, sb, out, outSize, stp, checks); }, osThreads);
+}
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }
 uint32_t emu_ent_shared(void) { return (uint32_t)sizeof(zhip::EntShared); }

@@ -1,0 +1,45 @@
+"""Multi-block frames on the host SIMT emulator: k_frame_fast against the oracle's
+zo_compress_frame — one frame holding the blocks ZSTD_compress emits (lib/compress/zstd_compress.c:4520-4640)."""
+import numpy as np
+import pytest
+from _libs import *
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return load_oracle(), load_emu()
+
+
+def _cases(lo):
+    rng = np.random.default_rng(5)
+    c = [("empty", np.zeros(0, np.uint8)), ("tiny", datagen(lo, 5, 50, 1)), ("small", datagen(lo, 5000, 50, 2)),
+         ("one_block", datagen(lo, 131072, 50, 3)), ("block_plus_1", datagen(lo, 131073, 50, 4)),
+         ("three_blocks", datagen(lo, 400000, 50, 5)), ("text", text_like(300000, 3)),
+         ("random", rng.integers(0, 256, size=300000, dtype=np.uint8)),              # raw blocks: repcodes / tables not confirmed
+         ("zeros", np.zeros(500000, np.uint8))]                                       # RLE blocks after the first
+    m = np.concatenate([datagen(lo, 150000, 50, 1), rng.integers(0, 256, size=140000, dtype=np.uint8), np.full(200000, 7, np.uint8), text_like(150000, 9)])
+    c.append(("mixed", m))
+    return c
+
+
+@pytest.mark.parametrize("level", [1, -1, -5])
+def test_frames_match_oracle(libs, level):
+    lo, le = libs
+    cases = _cases(lo)
+    got = emu_compress_frames(le, lo, [a for _, a in cases], level)
+    for (name, a), g in zip(cases, got):
+        assert g == oracle_frame(lo, a, level), f"{name} level {level}"
+
+
+def test_frames_table_in_hbm_and_checksum(libs):
+    """level 2 above 256 KB: hashLog 16 -> the table is in HBM; the frame checksum is XXH64 of the WHOLE input"""
+    lo, le = libs
+    a = datagen(lo, 600000, 50, 11)
+    got = emu_compress_frames(le, lo, [a], 2)[0]
+    assert got == oracle_frame(lo, a, 2)
+    ck = emu_compress_frames(le, lo, [a], 1, checksum=True)[0]
+    plain = oracle_frame(lo, a, 1)
+    assert ck[4] == plain[4] | 4 and ck[5:-4] == plain[5:]
+    lo.zo_xxh64.restype = C.c_uint64
+    lo.zo_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    assert int.from_bytes(ck[-4:], "little") == lo.zo_xxh64(a.ctypes.data_as(C.c_void_p), a.size, 0) & 0xFFFFFFFF

@@ -1,0 +1,110 @@
+"""-m gpu: multi-block frames.  zhip_compress_frames and the shim's single-frame mode against the
+committed digests of the REAL reference's single frame (tests/golden/frames_v1.json), the oracle's zo_compress_frame and —
+when oracle/_ref travelled — the reference itself.  Done-criterion of the round: ZSTD_compress2 of 1 MiB through the shim,
+byte-identical to the reference's frame at level 1."""
+import ctypes as C
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from _libs import load_oracle, load_ref, have_ref, frame_cases, oracle_frame, datagen, text_like, _buf, ROOT, ERR
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "frames_v1.json")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import zstd_amd
+    zstd_amd.lib()
+    return zstd_amd, load_oracle()
+
+
+def test_frames_equal_the_reference_digests(env):
+    z, lo = env
+    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["frames"]}
+    cases = list(frame_cases(lo))
+    ctx = z.Context(max_units=64)
+    seen = 0
+    for level in (1, 2, -1, -5):
+        todo = [(name, a) for name, a in cases if (name, level) in gold]
+        outs = ctx.compress_frames([a for _, a in todo], level)          # one batch: the frames run side by side
+        for (name, a), out in zip(todo, outs):
+            g = gold[(name, level)]
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level)
+            seen += 1
+    assert seen == len(gold)
+
+
+def test_frames_edge_sizes_and_checksum(env):
+    z, lo = env
+    ctx = z.Context(max_units=64)
+    bufs = [np.zeros(0, np.uint8), datagen(lo, 3, 50, 1), datagen(lo, 131072, 50, 2), datagen(lo, 131072 + 7, 50, 3),
+            datagen(lo, 2 * 131072, 30, 4), text_like(94208 + 131072, 5)]
+    for level in (1, -1):
+        outs = ctx.compress_frames(bufs, level)
+        for a, out in zip(bufs, outs):
+            assert out == oracle_frame(lo, a, level), (len(a), level)
+    ctx.set_checksum(True)
+    a = datagen(lo, 500000, 50, 9)
+    out = ctx.compress_frames([a], 1)[0]
+    plain = oracle_frame(lo, a, 1)
+    lo.zo_xxh64.restype = C.c_uint64
+    lo.zo_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    assert out[4] == plain[4] | 4 and out[5:-4] == plain[5:]
+    assert int.from_bytes(out[-4:], "little") == lo.zo_xxh64(_buf(a), a.size, 0) & 0xFFFFFFFF
+    assert z.DContext().decompress(out) == a.tobytes()
+
+
+def test_frames_decode_on_the_device_and_unsupported_strategy(env):
+    z, lo = env
+    ctx = z.Context(max_units=8)
+    a = datagen(lo, 1 << 20, 50, 21)
+    out = ctx.compress_frames([a], 1)[0]
+    assert z.DContext().decompress(out) == a.tobytes()                              # the device decoder reads multi-block frames too
+    with pytest.raises(z.ZhipError):
+        ctx.compress_frames([a], 3)                                      # dfast: not a frame-kernel strategy, no CPU fallback
+
+
+def test_shim_single_frame_mode_1mib_level1(env):
+    """ZSTD_compress2 of 1 MiB through the drop-in with ZHIP_c_singleFrame: the reference's single frame, byte for byte"""
+    z, lo = env
+    from zstd_amd import build as zb
+    S = C.CDLL(zb.SHIM)
+    S.ZSTD_createCCtx.restype = C.c_void_p
+    S.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    S.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    S.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    S.ZSTD_compress2.restype = C.c_size_t
+    S.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    S.ZSTD_compressBound.restype = C.c_size_t
+    S.ZSTD_compressBound.argtypes = [C.c_size_t]
+    S.ZSTD_isError.argtypes = [C.c_size_t]
+    lr = load_ref() if have_ref() else None
+    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD))["frames"]}
+    for name, a in (("dg_1m", datagen(lo, 1 << 20, 50, 6)), ("text_700k", text_like(700000, 3))):
+        c = S.ZSTD_createCCtx()
+        assert S.ZSTD_CCtx_setParameter(c, 100, 1) == 0
+        assert S.ZSTD_CCtx_setParameter(c, 100001, 1) == 0               # ZHIP_c_singleFrame
+        cap = S.ZSTD_compressBound(a.size)
+        dst = np.zeros(cap, dtype=np.uint8)
+        r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
+        assert not S.ZSTD_isError(r)
+        out = dst[:r].tobytes()
+        g = gold[(name, 1)]
+        assert r == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], name
+        assert out == oracle_frame(lo, a, 1)
+        if lr is not None:
+            lr.zref_compress_frame.restype = C.c_size_t
+            lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            want = np.zeros(cap + 1024, dtype=np.uint8)
+            k = lr.zref_compress_frame(1, _buf(a), a.size, _buf(want), len(want))
+            assert out == want[:k].tobytes()
+        # level 3 (dfast) keeps the frame-per-unit stream: still a valid zstd stream of the same content
+        assert S.ZSTD_CCtx_setParameter(c, 100, 3) == 0
+        r3 = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
+        assert not S.ZSTD_isError(r3) and z.DContext().decompress(dst[:r3].tobytes()) == a.tobytes()
+        S.ZSTD_freeCCtx(c)

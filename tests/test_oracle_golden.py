@@ -2,7 +2,7 @@
 Runs anywhere (no /root/reference, no oracle/_ref needed)."""
 import hashlib, json, os
 import numpy as np
-from _libs import load_oracle, corpus_cases, _buf, ERR
+from _libs import load_oracle, corpus_cases, frame_cases, oracle_frame, _buf, ERR
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
 
@@ -103,3 +103,24 @@ def test_oracle_reproduces_golden_dictionary_frames():
             frames += buf[:k].tobytes()
         assert hashlib.sha256(frames).hexdigest() == g["frames_sha256"], (g["dict"], g["level"])
         lo.zo_cdict_free(cd)
+
+
+GOLD_FRAMES = os.path.join(os.path.dirname(__file__), "golden", "frames_v1.json")
+
+
+def test_oracle_reproduces_golden_multiblock_frames():
+    """inputs above 128 KB as ONE frame (zo_compress_frame; zstd_compress.c:4520-4640): block split at 128 KB / 92 KB, shared
+    table and window, repcodes and Huffman table confirmed per compressed block, RLE and raw blocks"""
+    lo = load_oracle()
+    gold = {(g["case"], g["level"]): g for g in json.load(open(GOLD_FRAMES))["frames"]}
+    seen = 0
+    for name, a in frame_cases(lo):
+        for level in (1, 2, -1, -5):
+            g = gold.get((name, level))
+            if g is None:
+                continue
+            assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"], name
+            out = oracle_frame(lo, a, level)
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level)
+            seen += 1
+    assert seen == len(gold) >= 40

@@ -3,7 +3,7 @@
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, _buf, ERR
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, _buf, ERR
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -188,3 +188,25 @@ def test_rowhash_unit_bytes_match_reference_fresh_cctx(libs, level):
                 assert k != ERR and ora_unit(lo, a, level) == want[:k].tobytes(), (name, level)
     finally:
         lo.zo_set_row_matcher(0)
+
+
+def test_multiblock_frame_vs_reference(libs):
+    """zo_compress_frame against ZSTD_compress2 of the whole input on a fresh CCtx (the frame the shim's single-frame mode must equal)"""
+    lo, lr = libs
+    lr.zref_compress_frame.restype = C.c_size_t
+    lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(123)
+    for trial in range(12):
+        n = int(rng.integers(131073, 900000))
+        kind = trial % 4
+        a = (datagen(lo, n, int(rng.integers(10, 95)), trial) if kind == 0 else text_like(n, trial) if kind == 1 else
+             np.concatenate([datagen(lo, n // 2, 60, trial), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]) if kind == 2 else
+             np.repeat(rng.integers(0, 256, size=n // 4096 + 1, dtype=np.uint8), 4096)[:n].copy())
+        for level in (1, 2, -3):
+            cp = (C.c_uint * 7)()
+            assert lo.zo_get_cparams(level, n, cp) == 0
+            if cp[6] != 1:
+                continue
+            want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
+            k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
+            assert k != ERR and oracle_frame(lo, a, level) == want[:k].tobytes(), (trial, kind, n, level)

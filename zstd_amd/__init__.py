@@ -310,6 +310,31 @@ class Context:
         out = dst[:r].tobytes()
         return (out, sizes) if return_sizes else out
 
+    def compress_frames(self, buffers, level=1, cparams=None):
+        """each buffer -> ONE multi-block frame, byte-identical to the reference's ZSTD_compress of it (zhip_compress_frames;
+        strategy ZSTD_fast only).  Returns the list of frames (bytes)."""
+        L = lib()
+        L.zhip_frames_bound.restype = C.c_size_t
+        L.zhip_frames_bound.argtypes = [C.c_void_p, C.c_size_t]
+        L.zhip_compress_frames.restype = C.c_size_t
+        L.zhip_compress_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        arrs = [np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b for b in buffers]
+        offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([a.size for a in arrs])
+        src = np.concatenate(arrs + [np.zeros(1, dtype=np.uint8)])
+        cap = L.zhip_frames_bound(offs.ctypes.data_as(C.c_void_p), len(arrs))
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        sizes = np.zeros(len(arrs), dtype=np.uint64)
+        cp = (C.c_uint * 7)(*cparams) if cparams is not None else None
+        r = self._check(L.zhip_compress_frames(self._h, dst.ctypes.data_as(C.c_void_p), cap, src.ctypes.data_as(C.c_void_p),
+                                               offs.ctypes.data_as(C.c_void_p), len(arrs), level, cp, sizes.ctypes.data_as(C.c_void_p)),
+                        "zhip_compress_frames")
+        out, pos = [], 0
+        for z in sizes:
+            out.append(dst[pos: pos + int(z)].tobytes()); pos += int(z)
+        assert pos == r
+        return out
+
 
 # ---------------------------------------------------------------------------------------------------------------- decompression
 def find_frames(data):

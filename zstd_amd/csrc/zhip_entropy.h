@@ -80,7 +80,7 @@ struct EntShared {
     uint8_t  hufHdr[136];
     HufWork  huf;
     // scalars broadcast through LDS
-    uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream, litType /*2 compressed, 3 repeat*/;
+    uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream, litType /*2 compressed, 3 repeat*/, hufMaxSym /* of a new table */;
     uint32_t streamBits[4], streamBytes[4], streamOff[4];
     uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
     uint32_t sampleHist[2][256];
@@ -214,34 +214,19 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
     return rec;
 }
 
-// ================================================================== the unit encoder
-__device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
-                                    const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
-                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh,
-                                    const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID,
-                                    bool withChecksum, uint32_t checksum /* low 32 bits of XXH64(content), zstd_compress.c:5297 */)
+// ================================================================== the block encoder
+// Literals section + sequences section of one block (ZSTD_entropyCompressSeqStore, zstd_compress.c:3000-3050) into body[];
+// returns the compressed size, or 0 when the block has to be emitted uncompressed (same value in every thread).  n >= 7.
+// `de`: the previous block's / the dictionary's entropy state, or nullptr.  Afterwards sh->litMode / litType / code[] /
+// hufMaxSym describe the literals' Huffman table (a multi-block frame keeps it as the next block's previous table).
+__device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
+                                         const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
+                                         uint8_t* __restrict__ body, EntShared* sh, const ZhipDictEntropy* __restrict__ de)
 {
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t const n = u.srcLen;
-    uint32_t const nbSeq = (n < 7) ? 0 : pm.nbSeq;
-    uint32_t const fh = frame_header_size(n, dictID);
-    uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
+    uint32_t const nbSeq = pm.nbSeq;
     uint32_t const minGainBlock = (n >> 6) + 2;             // zstd_compress_internal.h:613
     ZPROF_DECL
-
-    // ---------------- trivial units: empty frame, or too small to attempt compression (zstd_compress.c:3216, :5270)
-    if (n < 7) {
-        if (t == 0) {
-            write_frame_header(out, n, dictID, withChecksum);
-            uint32_t const bh = 1u + (0u << 1) + (n << 3);
-            out[fh] = (uint8_t)bh; out[fh + 1] = (uint8_t)(bh >> 8); out[fh + 2] = (uint8_t)(bh >> 16);
-            for (uint32_t i = 0; i < n; i++) out[fh + 3 + i] = src[i];
-            uint32_t end = fh + 3 + n;
-            if (withChecksum) { for (int b = 0; b < 4; b++) out[end + b] = (uint8_t)(checksum >> (8 * b)); end += 4; }
-            *outSize = end;
-        }
-        return;
-    }
     uint16_t* const bLL = stBits; uint16_t* const bOF = stBits + seqCap; uint16_t* const bML = stBits + 2 * (size_t)seqCap;
 
     // ================ phase A (all threads): byte histogram of the literals; sequence codes + code histograms
@@ -345,7 +330,7 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
                         oldSize = tw_sum(oldSize); newSize = tw_sum(newSize);
                         if ((oldSize >> 3) <= h + (newSize >> 3) || h + 12 >= litSize) { mode = 2; useOld = true; }
                     }
-                    if (!useOld && h != 0 && h + 12 < litSize) { mode = 2; hdrSize = h; logOut = huffLog; }   // :1425
+                    if (!useOld && h != 0 && h + 12 < litSize) { mode = 2; hdrSize = h; logOut = huffLog; if (lane == 0) sh->hufMaxSym = maxSym; }   // :1425
                 }
             }
         }
@@ -635,6 +620,10 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             uint32_t const streamBytes = (streamBits >> 3) + 1;
             uint32_t const tblBytes = sh->ncountSize[0] + sh->ncountSize[1] + sh->ncountSize[2];
             uint8_t* const bs = seqDst + nbHdr + 1 + tblBytes;
+            // a block that cannot beat the uncompressed form is emitted raw (:3026): known before a bit is packed, so the
+            // bitstream is never written — and never runs past the block's output room
+            if (litSection + nbHdr + 1 + tblBytes + streamBytes >= n - minGainBlock) rawBlock = true;
+            else {
             // zero the bytes of the bitstream; lane 0 writes the table headers in front of it
             zero_bytes(bs, streamBytes);
             if (t == 0) {
@@ -678,20 +667,41 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
             for (int k = 0; k < 3; k++) if (sh->encType[k] == 2) lastCount = sh->ncountSize[k];
             if (lastCount && lastCount + streamBytes < 4) rawBlock = true;
             __syncthreads();
+            }
             ZPROF(6);
         }
     }
 
-    // ---------------- block + frame headers (zstd_compress.c:3026, :4582-4590)
     uint32_t const cSize = litSection + seqSection;
 #ifdef ZHIP_ENT_DEBUG
     if (t == 0) printf("ENT n=%u nbSeq=%u litSize=%u litMode=%u litSection=%u seqSection=%u enc=%u,%u,%u hufHdr=%u rawBlock=%d\n", n, nbSeq, litSize, sh->litMode, litSection, seqSection, sh->encType[0], sh->encType[1], sh->encType[2], sh->hufHdrSize, (int)rawBlock);
 #endif
-    if (cSize >= n - minGainBlock) rawBlock = true;
+    if (cSize >= n - minGainBlock) rawBlock = true;         // zstd_compress.c:3026
+    ZPROF(7);
+    ZPROF_FLUSH(16);
+    return rawBlock ? 0u : cSize;
+}
+
+// ================================================================== the unit encoder: one frame holding one block
+__device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
+                                    const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
+                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh,
+                                    const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID,
+                                    bool withChecksum, uint32_t checksum /* low 32 bits of XXH64(content), zstd_compress.c:5297 */)
+{
+    int const t = (int)threadIdx.x;
+    uint32_t const n = u.srcLen;
+    uint32_t const fh = frame_header_size(n, dictID);
+    uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
+    uint32_t cSize = 0;
+    // trivial units (empty, or too small to attempt compression: zstd_compress.c:3216, :5270) are emitted uncompressed
+    if (n >= 7) cSize = entropy_block(src, n, u, seqs, pm, lits, stBits, seqCap, body, sh, de);
+    bool const rawBlock = cSize == 0;
     if (rawBlock) {
         __syncthreads();                                        // thread 0's section-header bytes land before the copy overwrites them
         for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
     }
+    // block + frame headers (zstd_compress.c:4582-4590)
     if (t == 0) {
         write_frame_header(out, n, dictID, withChecksum);
         uint32_t const bh = rawBlock ? (1u + (0u << 1) + (n << 3)) : (1u + (2u << 1) + (cSize << 3));
@@ -700,8 +710,6 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
         if (withChecksum) { for (int b = 0; b < 4; b++) out[end + b] = (uint8_t)(checksum >> (8 * b)); end += 4; }   // zstd_compress.c:5297-5303
         *outSize = end;
     }
-    ZPROF(7);
-    ZPROF_FLUSH(16);
 }
 
 }  // namespace zhip

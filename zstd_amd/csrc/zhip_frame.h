@@ -1,0 +1,145 @@
+// zhip_frame.h — one standard frame with as many blocks as the reference emits for the same input
+// (ZSTD_compress_frameChunk, lib/compress/zstd_compress.c:4520-4640; strategy fast, no dictionary).
+//
+// What chains the blocks of a frame together, and therefore what this kernel carries from one block to the next:
+//   * the match finder's hash table and the window (a match may reach back 2^windowLog bytes into earlier blocks),
+//   * the repcode history and the literals' Huffman table — both only when the block was emitted compressed
+//     (ZSTD_blockState_confirmRepcodesAndEntropyTables, :3312-3320),
+//   * `savings`, which moves the block boundary from 128 KB to 92 KB (ZSTD_optimalBlockSize, :4494-4518).
+// The chain is strictly serial, so a frame is one 256-thread workgroup: wave 0 runs the ZSTD_fast parser of zhip_parse.h on
+// the block (table of 32-bit positions in LDS when 4 << hashLog fits, in HBM otherwise), then the four waves run the block
+// encoder of zhip_entropy.h with the previous block's Huffman table as the "repeat" candidate.  Independent frames of a
+// batch run side by side, one workgroup each.
+#pragma once
+#include "zhip_parse.h"
+#include "zhip_entropy.h"
+
+namespace zhip {
+
+#define ZHIP_FRAME_BLOCK_SPLIT   (92u * 1024u)     /* zstd_compress.c:4517 "blind" split of the strategies below lazy2 */
+#define ZHIP_FRAME_LDS_HASHLOG   14u               /* tables up to 64 KB live in LDS */
+
+struct FrameShared {
+    ZhipParse meta;            // the parser's result for the block in flight
+    uint32_t  flag;
+    uint32_t  pad[5];
+};
+
+// what one block hands to the next, per frame, in HBM
+struct ZhipFrameState { ZhipDictEntropy ent; };
+
+__host__ __device__ inline uint32_t frame_lds_bytes(uint32_t hashLog)
+{
+    uint32_t const base = (uint32_t)((sizeof(EntShared) + 15) & ~(size_t)15) + (uint32_t)sizeof(FrameShared);
+    return base + (hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (4u << hashLog) : 0u);
+}
+
+// ZSTD_writeFrameHeader (zstd_compress.c:4640-4690) with the content size known, no dictionary id
+__host__ __device__ inline uint32_t frame_header_bytes_multi(uint32_t n, uint32_t windowLog)
+{
+    bool const single = ((uint64_t)1 << windowLog) >= n;
+    uint32_t const fcs = (n >= 256) + (n >= 65536 + 256);
+    return 4 + 1 + (single ? 0 : 1) + (fcs == 0 ? (single ? 1 : 0) : (fcs == 1 ? 2 : 4));
+}
+__device__ inline uint32_t write_frame_header_multi(uint8_t* op, uint32_t n, uint32_t windowLog, bool checksum)
+{
+    bool const single = ((uint64_t)1 << windowLog) >= n;
+    uint32_t const fcs = (n >= 256) + (n >= 65536 + 256);
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
+    op[4] = (uint8_t)((checksum ? 4u : 0u) + ((uint32_t)single << 5) + (fcs << 6));
+    uint32_t pos = 5;
+    if (!single) op[pos++] = (uint8_t)((windowLog - 10) << 3);
+    if (fcs == 0) { if (single) op[pos++] = (uint8_t)n; }
+    else if (fcs == 1) { uint32_t const v = n - 256; op[pos++] = (uint8_t)v; op[pos++] = (uint8_t)(v >> 8); }
+    else { op[pos++] = (uint8_t)n; op[pos++] = (uint8_t)(n >> 8); op[pos++] = (uint8_t)(n >> 16); op[pos++] = (uint8_t)(n >> 24); }
+    return pos;
+}
+
+template <uint32_t MLS>
+__device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, ZhipSeq* seqs, uint8_t* lits,
+                                  uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
+                                  EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum)
+{
+    int const t = (int)threadIdx.x, wv = t >> 6;
+    uint32_t const n = u.srcLen;
+    uint32_t op = frame_header_bytes_multi(n, u.windowLog);
+    if (t == 0) write_frame_header_multi(out, n, u.windowLog, withChecksum);
+    if (n == 0) {                                                            // :5270 an empty frame is one empty raw block
+        if (t == 0) {
+            out[op] = 1; out[op + 1] = 0; out[op + 2] = 0; op += 3;
+            if (withChecksum) { for (int b = 0; b < 4; b++) out[op + b] = (uint8_t)(checksum >> (8 * b)); op += 4; }
+            *outSize = op;
+        }
+        return;
+    }
+    for (uint32_t i = (uint32_t)t; i < (1u << u.hashLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table (:2020)
+    if (t == 0) { st->ent.hufRepeat = 0; st->ent.hufMaxSym = 0; st->ent.fseRepeat[0] = 0; st->ent.fseRepeat[1] = 0; st->ent.fseRepeat[2] = 0; }
+    uint32_t rep1 = 1, rep2 = 4, rep3 = 8;
+    long long savings = 0;
+    uint32_t pos = 0;
+    uint32_t const maxDist = 1u << u.windowLog;
+    __syncthreads();
+    while (pos < n) {
+        uint32_t const remaining = n - pos;
+        uint32_t bLen = remaining < ZHIP_UNIT_MAX ? remaining : ZHIP_UNIT_MAX;                      // :4494-4518
+        if (remaining >= ZHIP_UNIT_MAX && savings >= 3) bLen = ZHIP_FRAME_BLOCK_SPLIT;
+        uint32_t const last = bLen == remaining ? 1u : 0u;
+        uint32_t const end = pos + bLen;
+        uint8_t* const body = out + op + 3;
+        uint32_t cSize = 0;
+        if (bLen >= 7) {                                                                         // :3216
+            if (wv == 0) {
+                // ZSTD_window_enforceMaxDist from the block start (:4555), then ZSTD_getLowestPrefixIndex(block end) (zstd_fast.c:205)
+                uint32_t const dictLimit = pos > maxDist ? pos - maxDist : 0;
+                uint32_t const prefixLow = (end - dictLimit > maxDist) ? end - maxDist : dictLimit;
+                uint32_t const ip0 = pos + (pos == prefixLow);
+                uint32_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;
+                parse_fast_block<MLS, WideTab>(src, pos, end, prefixLow, ip0 - windowLow, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta);
+            }
+            __syncthreads();
+            ZhipParse const pm = fs->meta;
+            cSize = entropy_block(src + pos, bLen, u, seqs, pm, lits, stBits, seqCap, body, sh, &st->ent);
+            if (pos != 0 && cSize < 25) {                                    // :4365-4376 an RLE block, never the first one
+                if (t == 0) fs->flag = 0;
+                __syncthreads();
+                uint8_t const b0 = src[pos];
+                bool diff = false;
+                for (uint32_t i = (uint32_t)t; i < bLen; i += ZHIP_ENT_THREADS) diff = diff || src[pos + i] != b0;
+                if (diff) fs->flag = 1;
+                __syncthreads();
+                if (fs->flag == 0) cSize = 1;
+            }
+            if (cSize > 1) {                                                 // :4379-4381 the block confirms repcodes and tables
+                rep1 = pm.rep[0]; rep2 = pm.rep[1]; rep3 = pm.rep[2];
+                if (sh->litMode == 2 && sh->litType == 2) {                  // a new Huffman table (zstd_compress_literals.c:223-226)
+                    st->ent.hufCode[t] = sh->code[t];
+                    if (t == 0) { st->ent.hufRepeat = 1; st->ent.hufMaxSym = sh->hufMaxSym; }
+                }
+            }
+        }
+        uint32_t total;
+        if (cSize == 0) {                                                    // :4592 ZSTD_noCompressBlock
+            __syncthreads();                                                 // the encoder's stray header bytes land first
+            for (uint32_t i = (uint32_t)t; i < bLen; i += ZHIP_ENT_THREADS) body[i] = src[pos + i];
+            if (t == 0) { uint32_t const bh = last + (0u << 1) + (bLen << 3); out[op] = (uint8_t)bh; out[op + 1] = (uint8_t)(bh >> 8); out[op + 2] = (uint8_t)(bh >> 16); }
+            total = 3 + bLen;
+        } else if (cSize == 1) {
+            __syncthreads();
+            if (t == 0) { uint32_t const bh = last + (1u << 1) + (bLen << 3); out[op] = (uint8_t)bh; out[op + 1] = (uint8_t)(bh >> 8); out[op + 2] = (uint8_t)(bh >> 16); body[0] = src[pos]; }
+            total = 4;
+        } else {
+            if (t == 0) { uint32_t const bh = last + (2u << 1) + (cSize << 3); out[op] = (uint8_t)bh; out[op + 1] = (uint8_t)(bh >> 8); out[op + 2] = (uint8_t)(bh >> 16); }
+            total = 3 + cSize;
+        }
+        op += total;
+        savings += (long long)bLen - (long long)total;
+        pos = end;
+        __syncthreads();                                                     // the block's bytes and the new state are in place
+    }
+    if (t == 0) {
+        if (withChecksum) { for (int b = 0; b < 4; b++) out[op + b] = (uint8_t)(checksum >> (8 * b)); op += 4; }   // :5297-5303
+        *outSize = op;
+    }
+}
+
+}  // namespace zhip

@@ -8,6 +8,7 @@
 #include "zhip_parse_dict.h"
 #include "zhip_parse_ext.h"
 #include "zhip_entropy.h"
+#include "zhip_frame.h"
 #include "zhip_decode.h"
 
 namespace zhip {
@@ -221,6 +222,40 @@ k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, c
     ZhipSlot const sl = slots[ui];
     entropy_unit(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
                  stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem, dictEntropy, dictID, checks != nullptr, checks ? checks[ui] : 0u);
+}
+
+// One workgroup per multi-block frame (zhip_frame.h).  frames[i].srcLen is the whole input of frame i (< 2^31); its slot gives
+// one block's worth of sequence / literal room (reused block after block) and the frame's output room.  Dynamic LDS =
+// frame_lds_bytes(largest hashLog); frames whose table does not fit LDS use tabs + i * tabStride words.
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS)
+k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
+             uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
+             uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
+             const uint32_t* __restrict__ checks)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const fi = blockIdx.x;
+    if (fi >= nFrames) return;
+    ZhipUnit const u = frames[fi];
+    ZhipSlot const sl = slots[fi];
+    EntShared* const sh = (EntShared*)smem;
+    size_t const shBytes = (sizeof(EntShared) + 15) & ~(size_t)15;
+    FrameShared* const fs = (FrameShared*)(smem + shBytes);
+    WideTab T;
+    T.w = u.hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (uint32_t*)(smem + shBytes + sizeof(FrameShared)) : tabs + (size_t)fi * tabStride;
+    const uint8_t* const p = src + u.srcOff;
+    ZhipSeq* const sq = seqs + sl.seqOff;
+    uint8_t* const lt = lits + sl.litOff;
+    uint16_t* const sb = stBits + 3 * sl.seqOff;
+    uint8_t* const o = out + sl.outOff;
+    bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[fi] : 0u;
+    switch (u.minMatch) {
+    case 5:  frame_fast<5>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
+    case 6:  frame_fast<6>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
+    case 7:  frame_fast<7>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
+    case 8:  frame_fast<8>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
+    default: frame_fast<4>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
+    }
 }
 
 // Frame checksum (ZSTD_c_checksumFlag): XXH64 of each unit's content, low 32 bits (zstd_compress.c:5297-5303).  XXH64 has four

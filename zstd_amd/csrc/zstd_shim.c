@@ -20,6 +20,7 @@ struct ZSTD_CCtx_s {
     int       checksum;              /* ZSTD_c_checksumFlag */
     int       rowMode;               /* ZSTD_c_useRowMatchFinder: 0 auto, 1 enable, 2 disable (lib/zstd.h ZSTD_paramSwitch_e) */
     unsigned  cp[7];                 /* ZSTD_c_windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; 0 = the level's */
+    int       singleFrame;           /* ZHIP_c_singleFrame / $ZHIP_SINGLE_FRAME: sources above 128 KB as ONE multi-block frame (zhip_compress_frames) */
     const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
 
@@ -28,7 +29,7 @@ static int shim_device(void) { const char* e = getenv("ZHIP_DEVICE"); return e ?
 ZSTD_CCtx* ZSTD_createCCtx(void)
 {
     ZSTD_CCtx* c = (ZSTD_CCtx*)calloc(1, sizeof(*c));
-    if (c) c->level = 3;                                          /* ZSTD_CLEVEL_DEFAULT, lib/zstd.h:129 */
+    if (c) { const char* e = getenv("ZHIP_SINGLE_FRAME"); c->level = 3; c->singleFrame = e && atoi(e) != 0; }      /* ZSTD_CLEVEL_DEFAULT, lib/zstd.h:129 */
     return c;
 }
 size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
@@ -67,6 +68,7 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     case ZSTD_c_checksumFlag:    c->checksum = value != 0; return 0;
     case ZSTD_c_dictIDFlag:      return 0;                        /* no dictionary can be attached: the flag has no effect */
     case ZSTD_c_nbWorkers:       return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
+    case ZHIP_c_singleFrame:     c->singleFrame = value != 0; return 0;
     default: return SHIM_ERR(E_parameter_unsupported);
     }
 }
@@ -126,6 +128,13 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
         return zhip_compress_multi(c->zm, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
     }
     {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
+    if (units > 1 && c->singleFrame && cap >= zhip_compressBound(n, SHIM_UNIT)) {
+        /* the reference's own output shape: one frame, many blocks.  Strategies the frame kernel does not run
+           (parameter_unsupported) fall through to the frame-per-128-KB stream below */
+        unsigned long long const offs[2] = { 0, n };
+        size_t const r = zhip_compress_frames(c->z, dst, cap, src, offs, 1, level, c->cp, NULL);
+        if (!zhip_isError(r) || r != SHIM_ERR(E_parameter_unsupported)) return r;
+    }
     /* zhip_compress wants room for its own bound; the reference only needs ZSTD_compressBound(n) for a guaranteed
        success and otherwise tries — give the device a private bounce buffer when the caller's is smaller */
     {   size_t const need = zhip_compressBound(n, SHIM_UNIT);
