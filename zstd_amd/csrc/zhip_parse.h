@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t lane_same_fwd(const uint8_t* src, uint32_t q
     return sh >= 8 ? 0 : same;
 }
 // Common-prefix length of src[a..) and src[b..) (b < a) — ZSTD_count (zstd_compress_internal.h:771), 512 B per round
-__device__ __forceinline__ uint32_t wave_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_t nm8)
+__device__ __attribute__((noinline)) uint32_t wave_count_fwd_far(const uint8_t* src, uint32_t a, uint32_t b, uint32_t nm8)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t total = 0;
@@ -139,7 +139,7 @@ __device__ __forceinline__ uint32_t wave_count_fwd(const uint8_t* src, uint32_t 
 }
 
 // Number of equal bytes walking backwards from src[ip-1] / src[m-1], at most `limit` (zstd_fast.c:387-391).
-__device__ __forceinline__ uint32_t wave_count_back(const uint8_t* src, uint32_t ip, uint32_t m, uint32_t limit)
+__device__ __attribute__((noinline)) uint32_t wave_count_back_far(const uint8_t* src, uint32_t ip, uint32_t m, uint32_t limit)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t total = 0;
@@ -151,6 +151,14 @@ __device__ __forceinline__ uint32_t wave_count_back(const uint8_t* src, uint32_t
         total += 64;
     }
 }
+
+// Both are out of line on purpose.  They are the rare continuation of an extension that left the 64 positions at hand; inlined
+// into the parser's event loop they cost it ~45 spilled SGPRs.  A called function returns in a VGPR, and the result is left
+// there: what derives from it (lengths, scan position, anchor) then lives in vector registers, which is what relieves the
+// scalar register file (measured on MI355X: text 66.8 -> 61.0 ms, Silesia-shaped 39.8 -> 34.7 ms per GiB-scale launch;
+// forcing the result back to an SGPR with readfirstlane brings the spills and the old times back).
+__device__ __forceinline__ uint32_t wave_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_t nm8) { return wave_count_fwd_far(src, a, b, nm8); }
+__device__ __forceinline__ uint32_t wave_count_back(const uint8_t* src, uint32_t ip, uint32_t m, uint32_t limit) { return wave_count_back_far(src, ip, m, limit); }
 
 // Backward (at most `lim` bytes before mpos / cand) and forward (from mpos+4 / cand+4) extension of a 4-byte match in
 // ONE round of loads: lanes 0..47 compare 8 bytes forward each, lanes 48..63 8 bytes backward each.
@@ -323,6 +331,21 @@ __device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint
         first = false;
         if ((int32_t)ip0 > ilimit) return false;
     }
+}
+
+// post_match for the window parser's rare case (a match that runs past the window), out of line for the same reason as the
+// wave_count_*_far pair: what it needs goes in and comes back by value
+struct PostState { uint32_t ip0, anchor, rep1, rep2, nbSeq, longPos, longType; };
+template <uint32_t MLS, typename TAB>
+__device__ __attribute__((noinline)) PostState post_match_far(const uint8_t* src, uint32_t nm8, uint32_t hshift, TAB T, ZhipSeq* seqs,
+                                                              PostState st, uint32_t cur0, bool first)
+{
+    FastOut o; o.seqs = seqs; o.lits = nullptr; o.nbSeq = st.nbSeq; o.longPos = st.longPos; o.longType = st.longType;
+    o.litPos = 0; o.pendV = 0; o.pendSh = 0; o.pendOff = 0; o.pendLen = 0;
+    FastBatch dummy;
+    post_match<MLS, false, TAB>(src, nm8, hshift, T, o, st.ip0, st.anchor, st.rep1, st.rep2, cur0, first, 0, 0, dummy);
+    st.nbSeq = o.nbSeq; st.longPos = o.longPos; st.longType = o.longType;
+    return st;
 }
 
 // ------------------------------------------------------------------ the dense-scan WINDOW: many events per gather
@@ -534,7 +557,11 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             nEv = out.nbSeq - nbSeq0;                                     // post_match stores its sequences itself
             ZW_TABLE_FLUSH();
             uint32_t ip0n = anchor;
-            if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false, TAB>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, B + cur0L, true, 0, 0, dummy); }
+            if (ip0n <= nm8) {
+                PostState ps; ps.ip0 = ip0n; ps.anchor = anchor; ps.rep1 = rep1; ps.rep2 = rep2; ps.nbSeq = out.nbSeq; ps.longPos = out.longPos; ps.longType = out.longType;
+                ps = post_match_far<MLS, TAB>(src, nm8, hshift, T, out.seqs, ps, B + cur0L, true);
+                ip0n = ps.ip0; anchor = ps.anchor; rep1 = ps.rep1; rep2 = ps.rep2; out.nbSeq = ps.nbSeq; out.longPos = ps.longPos; out.longType = ps.longType;
+            }
             i = ip0n - B;
             ZWPROF(out, 9);
             break;
@@ -556,7 +583,11 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
                 nEv = out.nbSeq - nbSeq0;
                 ZW_TABLE_FLUSH();
                 uint32_t ip0n = anchor;
-                if (ip0n <= nm8) { FastBatch dummy; post_match<MLS, false, TAB>(src, nm8, hshift, T, out, ip0n, anchor, rep1, rep2, 0, false, 0, 0, dummy); }
+                if (ip0n <= nm8) {
+                    PostState ps; ps.ip0 = ip0n; ps.anchor = anchor; ps.rep1 = rep1; ps.rep2 = rep2; ps.nbSeq = out.nbSeq; ps.longPos = out.longPos; ps.longType = out.longType;
+                    ps = post_match_far<MLS, TAB>(src, nm8, hshift, T, out.seqs, ps, 0, false);
+                    ip0n = ps.ip0; anchor = ps.anchor; rep1 = ps.rep1; rep2 = ps.rep2; out.nbSeq = ps.nbSeq; out.longPos = ps.longPos; out.longType = ps.longType;
+                }
                 i = ip0n - B;
                 break;
             }
