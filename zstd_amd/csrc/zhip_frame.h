@@ -55,7 +55,16 @@ __device__ inline uint32_t write_frame_header_multi(uint8_t* op, uint32_t n, uin
     return pos;
 }
 
+// the block parser as a called function: the frame kernel holds five instantiations of it next to the whole block encoder,
+// and inlined they left the scalar register file with ~1000 spilled values
 template <uint32_t MLS>
+__device__ __attribute__((noinline)) void parse_fast_block_far(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
+                                                               uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, WideTab T,
+                                                               ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    parse_fast_block<MLS, WideTab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
+}
+
 __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum)
@@ -94,7 +103,14 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
                 uint32_t const prefixLow = (end - dictLimit > maxDist) ? end - maxDist : dictLimit;
                 uint32_t const ip0 = pos + (pos == prefixLow);
                 uint32_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;
-                parse_fast_block<MLS, WideTab>(src, pos, end, prefixLow, ip0 - windowLow, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta);
+                uint32_t const maxRep = ip0 - windowLow;
+                switch (u.minMatch) {                                        // the hash width is a compile-time constant inside the parser
+                case 5:  parse_fast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 6:  parse_fast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 7:  parse_fast_block_far<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 8:  parse_fast_block_far<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                default: parse_fast_block_far<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                }
             }
             __syncthreads();
             ZhipParse const pm = fs->meta;

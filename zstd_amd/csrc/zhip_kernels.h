@@ -249,13 +249,7 @@ k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frame
     uint16_t* const sb = stBits + 3 * sl.seqOff;
     uint8_t* const o = out + sl.outOff;
     bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[fi] : 0u;
-    switch (u.minMatch) {
-    case 5:  frame_fast<5>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
-    case 6:  frame_fast<6>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
-    case 7:  frame_fast<7>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
-    case 8:  frame_fast<8>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
-    default: frame_fast<4>(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv); break;
-    }
+    frame_fast(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv);
 }
 
 // Frame checksum (ZSTD_c_checksumFlag): XXH64 of each unit's content, low 32 bits (zstd_compress.c:5297-5303).  XXH64 has four
