@@ -65,6 +65,12 @@ def test_two_ranks_ordered_gather_equals_single_process():
     assert same and sizes_ok and length > 0
 
 
+def test_two_ranks_empty_input_is_one_empty_frame():
+    """an empty source is one (empty) unit: exactly one rank compresses it, the stream equals the single-process one"""
+    same, sizes_ok, length = _run(2, 0)
+    assert same and sizes_ok and length > 0
+
+
 def test_unit_ranges_partition():
     from zstd_amd import shard
     for n_units in (0, 1, 2, 7, 8, 8192, 8193):

@@ -26,7 +26,9 @@ def compress_sharded(data, compress_fn, dist=None, level=1, unit_size=UNIT):
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     b0, b1 = byte_range(len(data), unit_size, world, rank)
-    if b1 > b0 or (world == 1):
+    n_units = max(1, -(-len(data) // unit_size))                 # an empty input is ONE (empty) unit = one empty frame
+    u0, u1 = unit_range(n_units, world, rank)
+    if u1 > u0:
         frames, sizes = compress_fn(data[b0:b1], level, unit_size)
     else:
         frames, sizes = b"", np.zeros(0, dtype=np.uint64)        # more ranks than units
