@@ -69,7 +69,6 @@ struct EntShared {
     int16_t  norm[3][56];
     FseCTable ct[3];              // LL, OF, ML
     uint8_t  symScratch[3][512];
-    alignas(8) uint16_t chainTile[3][256];   // LDS window of the code / state-record arrays while a chain walks it
     uint16_t cumul[3][64];
     uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
     uint32_t ncWords[3][16];      // their bit-level assembly area (fse_write_ncount_wave)
@@ -212,6 +211,117 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
     uint32_t const rec = (nbOut << 12) | (state & ((1u << nbOut) - 1));
     state = ct->state[(state >> nbOut) + dFind];
     return rec;
+}
+
+// ------------------------------------------------------------------ the FSE state chain of one table, by the whole wavefront
+// The chain is a recurrence over the sequences, last to first: record_i = the low nbBits of the state, state = next(state, code_i).
+// It is serial in principle, but an FSE state forgets its past — every step shifts nbBits of it out — so the chain is cut into 64
+// slices: lane L runs its slice after a short warm-up on the entries above it from an arbitrary state, and is then CHECKED against
+// the true state the lane above hands down.  Forgetting can be slow (a table with one dominant symbol emits ~0 bits per step: half
+// of a text unit's slices are still off after 24 entries), so a lane whose entering state was wrong redoes its slice from the right
+// one — but only until its new trajectory meets the old one (the state after every 8-entry chunk of the first run is kept in
+// `ckpt`), after which everything, the state handed down included, is as before.  Rounds repeat until no lane changes: none or a few
+// short ones in practice, as many full ones as lanes when nothing ever merges (= the serial chain).  Exact by construction.
+// Then every slice is run once more from its true entering state, this time writing the records over the codes.
+// Entries move 8 at a time (16-byte loads / stores per lane).
+#define ZHIP_FSE_WARM 3u          /* warm-up, in 8-entry chunks */
+__device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* arr, uint32_t c, uint32_t M, uint4 w, uint32_t& state, bool record)
+{   // entries [8c, 8c+8) ∩ [0, M), highest first; w = the 16 bytes at arr + 8c
+    uint32_t x[4] = { w.x, w.y, w.z, w.w };                                   // two 16-bit entries per word; all indices below are static
+    uint32_t const top = M - 8u * c < 8 ? M - 8u * c : 8;
+    if (top == 8) {
+        // a full chunk: the eight symbols' table parameters do not depend on the state, so they are fetched together and the
+        // serial part is ONE dependent LDS read (the next state) per step
+        uint32_t db[8]; int32_t df[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { uint32_t const sy = (x[q >> 1] >> ((q & 1) ? 16 : 0)) & 0xFFFFu; db[q] = ct->dBits[sy]; df[q] = ct->dFind[sy]; }
+#pragma unroll
+        for (int q = 7; q >= 0; q--) {
+            uint32_t const sh16 = (q & 1) ? 16u : 0u;
+            uint32_t const rec = fse_chain_step(ct, state, db[q], df[q]);
+            x[q >> 1] = (x[q >> 1] & ~(0xFFFFu << sh16)) | (rec << sh16);
+        }
+        if (record) { w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3]; __builtin_memcpy(arr + 8u * c, &w, 16); }
+        return;
+    }
+#pragma unroll
+    for (int q = 7; q >= 0; q--) if ((uint32_t)q < top) {
+        uint32_t const sh16 = (q & 1) ? 16u : 0u;
+        uint32_t const sy = (x[q >> 1] >> sh16) & 0xFFFFu;
+        uint32_t const rec = fse_chain_step(ct, state, ct->dBits[sy], ct->dFind[sy]);
+        x[q >> 1] = (x[q >> 1] & ~(0xFFFFu << sh16)) | (rec << sh16);
+    }
+    if (record) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) if ((uint32_t)q < top) arr[8u * c + q] = (uint16_t)(x[q >> 1] >> ((q & 1) ? 16 : 0));
+    }
+}
+// chunks hiC-1 down to loC through `state`, the next chunk's 16 bytes in flight while this one is walked.
+// mode 0: nothing kept; 1: the state after each chunk goes to ckpt; 2: it is compared with ckpt — equal = the trajectory met the
+// earlier one, stop and return true — and replaces it; 3: records are written over the codes
+enum { ZC_DRY = 0, ZC_KEEP = 1, ZC_MEET = 2, ZC_RECORD = 3 };
+__device__ __forceinline__ bool fse_chain_run(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t hiC, uint32_t loC, uint32_t& state,
+                                              int mode, uint16_t* ckpt, uint32_t lane)
+{
+    if (hiC <= loC) return false;
+    uint4 nxt; __builtin_memcpy(&nxt, arr + 8u * (hiC - 1), 16);
+    uint32_t t = 0;
+    for (uint32_t c = hiC; c > loC; c--, t++) {
+        uint4 const cur = nxt;
+        if (c - 1 > loC) __builtin_memcpy(&nxt, arr + 8u * (c - 2), 16);
+        fse_chain_chunk(ct, arr, c - 1, M, cur, state, mode == ZC_RECORD);
+        if (mode == ZC_KEEP) ckpt[t * 64 + lane] = (uint16_t)state;
+        else if (mode == ZC_MEET) {
+            if (ckpt[t * 64 + lane] == (uint16_t)state) return true;
+            ckpt[t * 64 + lane] = (uint16_t)state;
+        }
+    }
+    return false;
+}
+// room `ckpt` needs, in uint16 entries, for a chain of M entries
+__host__ __device__ inline uint32_t fse_chain_ckpt_entries(uint32_t M) { uint32_t const chunks = (M + 7) >> 3; return 64u * ((chunks + 63) >> 6); }
+// arr[0 .. M) codes -> records; returns the final state (after entry 0).  lastCode = the code of sequence M (it only seeds the state).
+// ckpt: fse_chain_ckpt_entries(M) uint16 of scratch in global memory, private to this wavefront; touched only when a lane owns two
+// or more chunks (M > 512), i.e. at most 0.19 bytes per source byte
+__device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt)
+{
+    uint32_t const lane = (uint32_t)(threadIdx.x & 63);
+    uint32_t const init = fse_init_state2(ct, lastCode);
+    if (M == 0) return init;
+    uint32_t const chunks = (M + 7) >> 3, cpl = (chunks + 63) >> 6;          // chunks per lane
+    uint32_t const used = (chunks + cpl - 1) / cpl;                          // lanes that own something; lane 0 owns the TOP slice
+    bool const mine = lane < used;
+    uint32_t const topC = mine ? chunks - lane * cpl : 0;                    // own chunks [botC, topC)
+    uint32_t const botC = topC > cpl ? topC - cpl : 0;
+    // pass 1, nothing written to arr: warm-up (one that reaches the very top starts from the true state), then the slice
+    uint32_t enter = init;
+    if (mine && lane) {
+        uint32_t w1 = topC + ZHIP_FSE_WARM;
+        if (w1 >= chunks) w1 = chunks; else enter = 1u << ct->tableLog;
+        fse_chain_run(ct, arr, M, w1, topC, enter, ZC_DRY, ckpt, lane);
+    }
+    uint32_t fin = enter;
+    bool const keep = cpl >= 2;                                               // one chunk per lane: nothing to meet (and a small record's output room is not borrowed)
+    fse_chain_run(ct, arr, M, topC, botC, fin, keep ? ZC_KEEP : ZC_DRY, ckpt, lane);
+    // hand-down rounds
+    for (;;) {
+        uint32_t const above = __shfl_up(fin, 1);
+        bool const bad = mine && lane && enter != above;
+#ifdef ZHIP_CHAIN_DEBUG
+        { unsigned long long const bb = __ballot(bad); if (lane == 0 && bb) printf("CHAIN M=%u tableLog=%u cpl=%u used=%u bad=%d lanes\n", M, ct->tableLog, cpl, used, (int)__builtin_popcountll(bb)); }
+#endif
+        if (!__ballot(bad)) break;
+        if (bad) {
+            enter = above;
+            uint32_t st = above;
+            if (!fse_chain_run(ct, arr, M, topC, botC, st, keep ? ZC_MEET : ZC_DRY, ckpt, lane)) fin = st;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                                          // all reads of pass 1 are done: records may replace codes
+    // pass 2: every slice again from its (now true) entering state, records written in place
+    uint32_t st = enter;
+    fse_chain_run(ct, arr, M, topC, botC, st, ZC_RECORD, ckpt, lane);
+    return (uint32_t)__builtin_amdgcn_readlane((int)fin, (int)(used - 1));
 }
 
 // ================================================================== the block encoder
@@ -425,58 +535,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         ZPROF_JOB_MARK(29);
         if (sh->encType[k] != 9) {
             // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
-            // becomes (nbBits << 12 | value).  The wavefront moves tiles of 256 entries between HBM and LDS (coalesced,
-            // the next tile's loads in flight during the walk); lane 0 walks the tile in LDS, so the serial path sees
-            // LDS latency only.
-            const FseCTable* ct = &sh->ct[k];
-            uint16_t* const tile = sh->chainTile[k];
-            uint32_t state = fse_init_state2(ct, lastCode);
-            uint32_t hi = nbSeq - 1;                               // entries [0, hi) remain, processed downwards
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-            {   uint32_t const lo0 = hi > 256 ? hi - 256 : 0, c = hi - lo0, e = 4u * (uint32_t)lane;
-                if (e + 0 < c) r0 = arr[lo0 + e + 0];
-                if (e + 1 < c) r1 = arr[lo0 + e + 1];
-                if (e + 2 < c) r2 = arr[lo0 + e + 2];
-                if (e + 3 < c) r3 = arr[lo0 + e + 3];
-            }
-            while (hi) {
-                uint32_t const lo_ = hi > 256 ? hi - 256 : 0, cnt = hi - lo_, e4 = 4u * (uint32_t)lane;
-                tile[e4 + 0] = (uint16_t)r0; tile[e4 + 1] = (uint16_t)r1; tile[e4 + 2] = (uint16_t)r2; tile[e4 + 3] = (uint16_t)r3;
-                __builtin_amdgcn_wave_barrier();
-                {   // next tile's codes: in flight while lane 0 walks this one
-                    uint32_t const nlo = lo_ > 256 ? lo_ - 256 : 0, c = lo_ - nlo;
-                    if (e4 + 0 < c) r0 = arr[nlo + e4 + 0];
-                    if (e4 + 1 < c) r1 = arr[nlo + e4 + 1];
-                    if (e4 + 2 < c) r2 = arr[nlo + e4 + 2];
-                    if (e4 + 3 < c) r3 = arr[nlo + e4 + 3];
-                }
-                if (lane == 0) {
-                    uint32_t e = cnt;
-                    while (e & 3) { e--; uint32_t const sy = tile[e]; tile[e] = (uint16_t)fse_chain_step(ct, state, ct->dBits[sy], ct->dFind[sy]); }
-                    while (e) {
-                        e -= 4;
-                        unsigned long long c4; __builtin_memcpy(&c4, tile + e, 8);
-                        uint32_t const y3 = (uint32_t)(c4 >> 48) & 0xFFFF, y2 = (uint32_t)(c4 >> 32) & 0xFFFF;
-                        uint32_t const y1 = (uint32_t)(c4 >> 16) & 0xFFFF, y0 = (uint32_t)c4 & 0xFFFF;
-                        uint32_t const b3 = ct->dBits[y3], b2 = ct->dBits[y2], b1 = ct->dBits[y1], b0 = ct->dBits[y0];
-                        int32_t const f3 = ct->dFind[y3], f2 = ct->dFind[y2], f1 = ct->dFind[y1], f0 = ct->dFind[y0];
-                        unsigned long long res = 0;
-                        res |= (unsigned long long)fse_chain_step(ct, state, b3, f3) << 48;
-                        res |= (unsigned long long)fse_chain_step(ct, state, b2, f2) << 32;
-                        res |= (unsigned long long)fse_chain_step(ct, state, b1, f1) << 16;
-                        res |= (unsigned long long)fse_chain_step(ct, state, b0, f0);
-                        __builtin_memcpy(tile + e, &res, 8);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (e4 + 0 < cnt) arr[lo_ + e4 + 0] = tile[e4 + 0];
-                if (e4 + 1 < cnt) arr[lo_ + e4 + 1] = tile[e4 + 1];
-                if (e4 + 2 < cnt) arr[lo_ + e4 + 2] = tile[e4 + 2];
-                if (e4 + 3 < cnt) arr[lo_ + e4 + 3] = tile[e4 + 3];
-                __builtin_amdgcn_wave_barrier();
-                hi = lo_;
-            }
-            if (lane == 0) sh->finalState[k] = state;
+            // becomes (nbBits << 12 | value)
+            // scratch for the slices' chunk states: the block's own output room, which nothing has written yet (3 x <= 8 KB of it)
+            uint16_t* const ckpt = (uint16_t*)(((uintptr_t)body + 15) & ~(uintptr_t)15) + (size_t)k * fse_chain_ckpt_entries(nbSeq - 1);
+            uint32_t const fin = fse_chain_wave(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt);
+            if (lane == 0) sh->finalState[k] = fin;
         }
         ZPROF_JOB_MARK(30);
     }
