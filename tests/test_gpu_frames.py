@@ -108,3 +108,44 @@ def test_shim_single_frame_mode_1mib_level1(env):
         r3 = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
         assert not S.ZSTD_isError(r3) and z.DContext().decompress(dst[:r3].tobytes()) == a.tobytes()
         S.ZSTD_freeCCtx(c)
+
+
+def test_frames_fuzz_against_oracle(env):
+    """random sizes / contents / levels in one batch per level: block splits at 128 KB / 92 KB, raw and RLE blocks in any order,
+    matches across block borders and beyond the window (level 1 above 512 KB), ragged last blocks"""
+    z, lo = env
+    rng = np.random.default_rng(20260923)
+    ctx = z.Context(max_units=64)
+
+    def piece(kind, n, seed):
+        if kind == 0:
+            return datagen(lo, n, int(rng.integers(5, 98)), seed)
+        if kind == 1:
+            return text_like(n, seed)
+        if kind == 2:
+            return rng.integers(0, 256, size=n, dtype=np.uint8)
+        if kind == 3:
+            return np.full(n, int(rng.integers(0, 256)), dtype=np.uint8)
+        return rng.integers(0, 3, size=n, dtype=np.uint8)
+
+    bufs = []
+    for t in range(40):
+        n = int(rng.integers(1, 1_600_000))
+        parts, left = [], n
+        while left > 0:
+            k = int(min(left, rng.integers(1, 400_000)))
+            parts.append(piece(int(rng.integers(0, 5)), k, t * 17 + len(parts)))
+            left -= k
+        a = np.concatenate(parts)
+        if t % 5 == 0 and n > 300_000:                       # a far repeat: same content 600 KB later (outside level 1's window of 512 KB when n allows)
+            m = min(n // 3, 200_000)
+            a[n - m:] = a[:m]
+        bufs.append(a)
+    for level in (1, -2):
+        outs = ctx.compress_frames(bufs, level)
+        for i, (a, out) in enumerate(zip(bufs, outs)):
+            cp = (C.c_uint * 7)()
+            assert lo.zo_get_cparams(level, len(a), cp) == 0
+            if cp[6] != 1:
+                continue
+            assert out == oracle_frame(lo, a, level), (i, len(a), level)
