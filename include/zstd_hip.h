@@ -78,8 +78,8 @@ size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dst
  * the blocks ZSTD_compress2 / ZSTD_compress emit for it on a fresh CCtx (lib/compress/zstd_compress.c:4520-4640 ZSTD_compress_frameChunk:
  * 128 KB blocks, 92 KB once the frame has saved 3 bytes; table, window, repcodes and Huffman table carried from block to block) —
  * byte-identical to the reference's single frame.  The block chain of a frame is serial: a frame is one workgroup, so the batch,
- * not the frame, is what fills the GPU (the per-unit calls above are the throughput path).  Implemented for strategy ZSTD_fast
- * (levels <= 2 by size class and the negative levels; other strategies -> parameter_unsupported), inputs below 2 GiB each,
+ * not the frame, is what fills the GPU (the per-unit calls above are the throughput path).  Implemented for the strategies ZSTD_fast
+ * and ZSTD_dfast (levels -N .. 3, and 2 / 4 where their size class is one of the two; lazy strategies -> parameter_unsupported), inputs below 2 GiB each,
  * nFrames <= the context's maxUnits.  dstCapacity >= zhip_frames_bound().  frameSizes (optional) receives each frame's size. */
 size_t       zhip_frames_bound(const unsigned long long* srcOffsets /* nFrames + 1 */, size_t nFrames);
 size_t       zhip_compress_frames(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,

@@ -26,8 +26,8 @@
  *                       `zstd -b<level> -B128K` chunking, but it is NOT the reference's single shared-window frame.
  *                       ZSTD_getFrameContentSize() of the stream reports the first unit only; use
  *                       ZSTD_findDecompressedSize() (lib/zstd.h:1492) for the total.
- *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and strategy ZSTD_fast (levels 1-2 by size
- *                       class, negative levels) the output IS the reference's single frame, byte for byte: one frame header,
+ *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and strategy ZSTD_fast or ZSTD_dfast (the default
+ *                       level 3, levels 1-2 and 4 by size class, negative levels) the output IS the reference's single frame, byte for byte: one frame header,
  *                       128 KB / 92 KB blocks sharing the window, the hash table, the repcodes and the Huffman table
  *                       (zstd_compress.c:4520-4640; zhip_compress_frames).  The block chain of one frame is serial — one
  *                       workgroup — so this is the fidelity mode, not the throughput mode; other strategies keep the

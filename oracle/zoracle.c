@@ -2349,6 +2349,102 @@ cleanup:
     return iend - anchor;
 }
 
+/* zstd_double_fast.c:105-323 for one block of a multi-block frame: the tables carry over from the previous blocks, matches may
+ * start anywhere in [prefixLow, position).  Table entries are pos+1 (0 = empty), positions relative to the frame start.
+ * Validity of a candidate, in the reference's own asymmetric terms: long / short match at ip: index >= prefixLowestIndex
+ * (ZSTD_selectAddr, :200, :214); long match at ip+1: index > prefixLowestIndex (:260); catch-up: match > prefixLowest (:207, :267). */
+static size_t zo_dfast_block(const zo_cparams* cp, const uint8_t* src /* frame start */, size_t bStart, size_t bLen, uint32_t* TL, uint32_t* TS,
+                             zo_store* st, uint32_t rep[3])
+{
+    unsigned const hL = cp->hashLog, hS = cp->chainLog, mls = cp->minMatch;
+    size_t const maxDist = (size_t)1 << cp->windowLog;
+    size_t const iend = bStart + bLen, ilimit = iend - 8;
+    size_t const dictLimit = bStart > maxDist ? bStart - maxDist : 0;
+    size_t const prefixLow = (iend - dictLimit > maxDist) ? iend - maxDist : dictLimit;
+    size_t anchor = bStart, ip = bStart, ip1, step, nextStep, curr = 0, mLength = 0;
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0, offset = 0;
+    ip += (ip == prefixLow);                                                     /* :157 */
+    {   size_t const windowLow = (ip - dictLimit > maxDist) ? ip - maxDist : dictLimit;
+        size_t const maxRep = ip - windowLow;
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
+    }
+#define ZO_GE(idx) ((idx) != 0 && (size_t)(idx) - 1 >= prefixLow)
+#define ZO_GT(idx) ((idx) != 0 && (size_t)(idx) - 1 > prefixLow)
+    for (;;) {
+        uint32_t hl0, hl1 = 0, idxl0, idxl1 = 0;
+        int kind = 0;
+        step = 1; nextStep = ip + 256; ip1 = ip + step;
+        if (ip1 > ilimit) break;
+        hl0 = zo_hash(src + ip, hL, 8); idxl0 = TL[hl0];
+        do {
+            uint32_t const hs0 = zo_hash(src + ip, hS, mls);
+            uint32_t const idxs0 = TS[hs0];
+            size_t matchs0;
+            curr = ip;
+            TL[hl0] = TS[hs0] = (uint32_t)ip + 1;
+            if (off1 > 0 && rd32(src + ip + 1 - off1) == rd32(src + ip + 1)) {
+                mLength = zo_count(src, ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+                ip++;
+                zo_store_seq(st, src, anchor, ip - anchor, 1, (uint32_t)mLength);
+                kind = 1; break;
+            }
+            hl1 = zo_hash(src + ip1, hL, 8);
+            if (ZO_GE(idxl0) && rd64(src + idxl0 - 1) == rd64(src + ip)) {
+                size_t m = idxl0 - 1;
+                mLength = zo_count(src, ip + 8, m + 8, iend) + 8;
+                offset = (uint32_t)(ip - m);
+                while (ip > anchor && m > prefixLow && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+                kind = 2; break;
+            }
+            idxl1 = TL[hl1];
+            if (ZO_GE(idxs0) && rd32(src + idxs0 - 1) == rd32(src + ip)) {
+                matchs0 = idxs0 - 1;
+                mLength = zo_count(src, ip + 4, matchs0 + 4, iend) + 4;
+                offset = (uint32_t)(ip - matchs0);
+                if (ZO_GT(idxl1) && rd64(src + idxl1 - 1) == rd64(src + ip1)) {
+                    size_t const m1 = idxl1 - 1;
+                    size_t const l1len = zo_count(src, ip1 + 8, m1 + 8, iend) + 8;
+                    if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (uint32_t)(ip - m1); matchs0 = m1; }
+                }
+                while (ip > anchor && matchs0 > prefixLow && src[ip - 1] == src[matchs0 - 1]) { ip--; matchs0--; mLength++; }
+                kind = 2; break;
+            }
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1;
+        } while (ip1 <= ilimit);
+        if (!kind) break;
+        if (kind == 2) {
+            off2 = off1; off1 = offset;
+            if (step < 4) TL[hl1] = (uint32_t)ip1 + 1;
+            zo_store_seq(st, src, anchor, ip - anchor, offset + 3, (uint32_t)mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            size_t const ins = curr + 2;
+            TL[zo_hash(src + ins, hL, 8)] = (uint32_t)ins + 1;
+            TL[zo_hash(src + ip - 2, hL, 8)] = (uint32_t)ip - 2 + 1;
+            TS[zo_hash(src + ins, hS, mls)] = (uint32_t)ins + 1;
+            TS[zo_hash(src + ip - 1, hS, mls)] = (uint32_t)ip - 1 + 1;
+            while (ip <= ilimit && off2 > 0 && rd32(src + ip) == rd32(src + ip - off2)) {
+                uint32_t const rLength = zo_count(src, ip + 4, ip + 4 - off2, iend) + 4;
+                uint32_t const t = off2; off2 = off1; off1 = t;
+                TS[zo_hash(src + ip, hS, mls)] = (uint32_t)ip + 1;
+                TL[zo_hash(src + ip, hL, 8)] = (uint32_t)ip + 1;
+                zo_store_seq(st, src, anchor, 0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+#undef ZO_GE
+#undef ZO_GT
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+    rep[0] = off1 ? off1 : saved1;
+    rep[1] = off2 ? off2 : saved2;
+    return iend - anchor;
+}
+
 size_t zo_frame_bound(size_t n) { return n + (n >> 8) + 64 + 3 * (n / 8192 + 2); }
 
 size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
@@ -2359,10 +2455,10 @@ size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t
     uint32_t rep[3] = {1, 4, 8};
     uint32_t* T; zo_seq* seqs; uint8_t* lits; uint8_t* body;
     zo_prev prev, next;
-    if (cp->strategy != 1 || cap < zo_frame_bound(n)) return ZO_ERROR;
+    if ((cp->strategy != 1 && cp->strategy != 2) || cap < zo_frame_bound(n)) return ZO_ERROR;
     op += write_frame_header(op, cp, n);
     if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
-    T = (uint32_t*)calloc((size_t)1 << cp->hashLog, sizeof(uint32_t));
+    T = (uint32_t*)calloc(((size_t)1 << cp->hashLog) + (cp->strategy == 2 ? (size_t)1 << cp->chainLog : 0), sizeof(uint32_t));   /* dfast: long table, then short table */
     seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 2));
     lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 8);
     body = (uint8_t*)malloc(ZO_BLOCK_MAX + 1024);
@@ -2377,7 +2473,8 @@ size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t
             zo_store st; uint32_t nrep[3] = { rep[0], rep[1], rep[2] };
             size_t lastLits;
             st.seqs = seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
-            lastLits = zo_fast_block(cp, src, pos, bLen, T, &st, nrep);
+            lastLits = cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, T, T + ((size_t)1 << cp->hashLog), &st, nrep)
+                                         : zo_fast_block(cp, src, pos, bLen, T, &st, nrep);
             memcpy(lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
             next = prev;
             {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);

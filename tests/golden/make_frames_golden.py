@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tests/golden/make_frames_golden.py — frames_v1.json: SHA-256 of the REAL reference's single multi-block frame
-(ZSTD_compress2 on a fresh CCtx, whole input in one call) for inputs above 128 KB at the ZSTD_fast levels.
+(ZSTD_compress2 on a fresh CCtx, whole input in one call) for inputs above 128 KB at the ZSTD_fast and ZSTD_dfast levels.
 Run here: python tests/golden/make_frames_golden.py"""
 import ctypes as C
 import hashlib
@@ -18,11 +18,11 @@ lr.zref_compress_frame.restype = C.c_size_t
 lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
 frames = []
 for name, a in frame_cases(lo):
-    for level in (1, 2, -1, -5):
+    for level in (1, 2, 3, 4, -1, -5):
         cp = (C.c_uint * 7)()
         assert lo.zo_get_cparams(level, len(a), cp) == 0
-        if cp[6] != 1:
-            continue                                   # strategy fast only
+        if cp[6] not in (1, 2):
+            continue                                   # strategies fast and dfast
         dst = np.zeros(len(a) + (len(a) >> 7) + 1024, dtype=np.uint8)
         r = lr.zref_compress_frame(level, _buf(a) if len(a) else None, len(a), _buf(dst), len(dst))
         assert r != ERR

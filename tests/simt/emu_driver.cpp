@@ -164,12 +164,16 @@ void emu_frame_fast(const uint8_t* src, const ZhipUnit* frames, uint32_t nFrames
     const ZhipSlot* const slots = sv.data();
     std::vector<ZhipSeq> seqs((size_t)nFrames * ZHIP_SEQ_CAP); std::vector<uint8_t> lits((size_t)nFrames * ZHIP_LIT_STRIDE);
     std::vector<uint16_t> stBits((size_t)nFrames * ZHIP_SEQ_CAP * 3);
-    size_t const tabStride = maxLog > ZHIP_FRAME_LDS_HASHLOG ? (size_t)1 << maxLog : 0;
+    size_t tabStride = 0; uint32_t ldsLog = 0;
+    for (uint32_t i = 0; i < nFrames; i++) {
+        if (zhip::frame_table_in_lds(frames[i].strategy, frames[i].hashLog)) { if (frames[i].hashLog > ldsLog) ldsLog = frames[i].hashLog; }
+        else { size_t const w = zhip::frame_table_words(frames[i].strategy, frames[i].hashLog, frames[i].chainLog); if (w > tabStride) tabStride = w; }
+    }
     std::vector<uint32_t> tabs((size_t)nFrames * tabStride + 1);
     std::vector<zhip::ZhipFrameState> states(nFrames ? nFrames : 1);
     ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
     zhip::ZhipFrameState* const stp = states.data();
-    simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(maxLog > ZHIP_FRAME_LDS_HASHLOG ? ZHIP_FRAME_LDS_HASHLOG : maxLog),
+    simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsLog),
                  [=] { zhip::k_frame_fast(src, frames, slots, nFrames, tb, tabStride, sq, lt, sb, out, outSize, stp, checks); }, osThreads);
 }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }

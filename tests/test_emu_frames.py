@@ -22,7 +22,7 @@ def _cases(lo):
     return c
 
 
-@pytest.mark.parametrize("level", [1, -1, -5])
+@pytest.mark.parametrize("level", [1, 3, -1, -5])
 def test_frames_match_oracle(libs, level):
     lo, le = libs
     cases = _cases(lo)

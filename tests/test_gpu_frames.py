@@ -29,7 +29,7 @@ def test_frames_equal_the_reference_digests(env):
     cases = list(frame_cases(lo))
     ctx = z.Context(max_units=64)
     seen = 0
-    for level in (1, 2, -1, -5):
+    for level in (1, 2, 3, 4, -1, -5):
         todo = [(name, a) for name, a in cases if (name, level) in gold]
         outs = ctx.compress_frames([a for _, a in todo], level)          # one batch: the frames run side by side
         for (name, a), out in zip(todo, outs):
@@ -44,7 +44,7 @@ def test_frames_edge_sizes_and_checksum(env):
     ctx = z.Context(max_units=64)
     bufs = [np.zeros(0, np.uint8), datagen(lo, 3, 50, 1), datagen(lo, 131072, 50, 2), datagen(lo, 131072 + 7, 50, 3),
             datagen(lo, 2 * 131072, 30, 4), text_like(94208 + 131072, 5)]
-    for level in (1, -1):
+    for level in (1, 3, -1):
         outs = ctx.compress_frames(bufs, level)
         for a, out in zip(bufs, outs):
             assert out == oracle_frame(lo, a, level), (len(a), level)
@@ -65,8 +65,10 @@ def test_frames_decode_on_the_device_and_unsupported_strategy(env):
     a = datagen(lo, 1 << 20, 50, 21)
     out = ctx.compress_frames([a], 1)[0]
     assert z.DContext().decompress(out) == a.tobytes()                              # the device decoder reads multi-block frames too
+    out3 = ctx.compress_frames([a], 3)[0]                                # level 3 (ZSTD_dfast, the default level) too
+    assert out3 == oracle_frame(lo, a, 3) and z.DContext().decompress(out3) == a.tobytes()
     with pytest.raises(z.ZhipError):
-        ctx.compress_frames([a], 3)                                      # dfast: not a frame-kernel strategy, no CPU fallback
+        ctx.compress_frames([a], 5)                                      # greedy: not a frame-kernel strategy, no CPU fallback
 
 
 def test_shim_single_frame_mode_1mib_level1(env):
@@ -103,10 +105,14 @@ def test_shim_single_frame_mode_1mib_level1(env):
             want = np.zeros(cap + 1024, dtype=np.uint8)
             k = lr.zref_compress_frame(1, _buf(a), a.size, _buf(want), len(want))
             assert out == want[:k].tobytes()
-        # level 3 (dfast) keeps the frame-per-unit stream: still a valid zstd stream of the same content
+        # level 3 (ZSTD_dfast, the default level): the reference's single frame too
         assert S.ZSTD_CCtx_setParameter(c, 100, 3) == 0
         r3 = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
-        assert not S.ZSTD_isError(r3) and z.DContext().decompress(dst[:r3].tobytes()) == a.tobytes()
+        assert not S.ZSTD_isError(r3) and dst[:r3].tobytes() == oracle_frame(lo, a, 3)
+        # level 5 (greedy) keeps the frame-per-unit stream: still a valid zstd stream of the same content
+        assert S.ZSTD_CCtx_setParameter(c, 100, 5) == 0
+        r5 = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
+        assert not S.ZSTD_isError(r5) and z.DContext().decompress(dst[:r5].tobytes()) == a.tobytes()
         S.ZSTD_freeCCtx(c)
 
 
@@ -141,11 +147,11 @@ def test_frames_fuzz_against_oracle(env):
             m = min(n // 3, 200_000)
             a[n - m:] = a[:m]
         bufs.append(a)
-    for level in (1, -2):
+    for level in (1, 3, -2):
         outs = ctx.compress_frames(bufs, level)
         for i, (a, out) in enumerate(zip(bufs, outs)):
             cp = (C.c_uint * 7)()
             assert lo.zo_get_cparams(level, len(a), cp) == 0
-            if cp[6] != 1:
+            if cp[6] not in (1, 2):
                 continue
             assert out == oracle_frame(lo, a, level), (i, len(a), level)

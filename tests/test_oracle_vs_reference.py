@@ -202,10 +202,10 @@ def test_multiblock_frame_vs_reference(libs):
         a = (datagen(lo, n, int(rng.integers(10, 95)), trial) if kind == 0 else text_like(n, trial) if kind == 1 else
              np.concatenate([datagen(lo, n // 2, 60, trial), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]) if kind == 2 else
              np.repeat(rng.integers(0, 256, size=n // 4096 + 1, dtype=np.uint8), 4096)[:n].copy())
-        for level in (1, 2, -3):
+        for level in (1, 2, 3, 4, -3):
             cp = (C.c_uint * 7)()
             assert lo.zo_get_cparams(level, n, cp) == 0
-            if cp[6] != 1:
+            if cp[6] not in (1, 2):
                 continue
             want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
             k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))

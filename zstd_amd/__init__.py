@@ -312,7 +312,7 @@ class Context:
 
     def compress_frames(self, buffers, level=1, cparams=None):
         """each buffer -> ONE multi-block frame, byte-identical to the reference's ZSTD_compress of it (zhip_compress_frames;
-        strategy ZSTD_fast only).  Returns the list of frames (bytes)."""
+        strategies ZSTD_fast and ZSTD_dfast: levels -N .. 3).  Returns the list of frames (bytes)."""
         L = lib()
         L.zhip_frames_bound.restype = C.c_size_t
         L.zhip_frames_bound.argtypes = [C.c_void_p, C.c_size_t]

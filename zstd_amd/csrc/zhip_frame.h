@@ -1,17 +1,19 @@
 // zhip_frame.h — one standard frame with as many blocks as the reference emits for the same input
-// (ZSTD_compress_frameChunk, lib/compress/zstd_compress.c:4520-4640; strategy fast, no dictionary).
+// (ZSTD_compress_frameChunk, lib/compress/zstd_compress.c:4520-4640; strategies ZSTD_fast and ZSTD_dfast, no dictionary).
 //
 // What chains the blocks of a frame together, and therefore what this kernel carries from one block to the next:
 //   * the match finder's hash table and the window (a match may reach back 2^windowLog bytes into earlier blocks),
 //   * the repcode history and the literals' Huffman table — both only when the block was emitted compressed
 //     (ZSTD_blockState_confirmRepcodesAndEntropyTables, :3312-3320),
 //   * `savings`, which moves the block boundary from 128 KB to 92 KB (ZSTD_optimalBlockSize, :4494-4518).
-// The chain is strictly serial, so a frame is one 256-thread workgroup: wave 0 runs the ZSTD_fast parser of zhip_parse.h on
-// the block (table of 32-bit positions in LDS when 4 << hashLog fits, in HBM otherwise), then the four waves run the block
+// The chain is strictly serial, so a frame is one 256-thread workgroup: wave 0 runs the ZSTD_fast parser of zhip_parse.h (table of
+// 32-bit positions in LDS when 4 << hashLog fits, in HBM otherwise) or the ZSTD_dfast parser of zhip_parse_dfast.h (two tables of
+// plain 32-bit positions in HBM) on the block, then the four waves run the block
 // encoder of zhip_entropy.h with the previous block's Huffman table as the "repeat" candidate.  Independent frames of a
 // batch run side by side, one workgroup each.
 #pragma once
 #include "zhip_parse.h"
+#include "zhip_parse_dfast.h"
 #include "zhip_entropy.h"
 
 namespace zhip {
@@ -23,6 +25,7 @@ struct FrameShared {
     ZhipParse meta;            // the parser's result for the block in flight
     uint32_t  flag;
     uint32_t  pad[5];
+    alignas(16) unsigned char dfScratch[2 * ZHIP_DF_SCRATCH];   // ZSTD_dfast: the parser's in-batch duplicate detectors
 };
 
 // what one block hands to the next, per frame, in HBM
@@ -31,8 +34,14 @@ struct ZhipFrameState { ZhipDictEntropy ent; };
 __host__ __device__ inline uint32_t frame_lds_bytes(uint32_t hashLog)
 {
     uint32_t const base = (uint32_t)((sizeof(EntShared) + 15) & ~(size_t)15) + (uint32_t)sizeof(FrameShared);
-    return base + (hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (4u << hashLog) : 0u);
+    return base + (hashLog && hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (4u << hashLog) : 0u);    // hashLog 0: no table in LDS
 }
+// words of table memory a frame needs: ZSTD_fast one table, ZSTD_dfast the long table followed by the short one
+__host__ __device__ inline size_t frame_table_words(uint32_t strategy, uint32_t hashLog, uint32_t chainLog)
+{
+    return ((size_t)1 << hashLog) + (strategy == ZHIP_STRAT_DFAST ? (size_t)1 << chainLog : 0);
+}
+__host__ __device__ inline bool frame_table_in_lds(uint32_t strategy, uint32_t hashLog) { return strategy == ZHIP_STRAT_FAST && hashLog <= ZHIP_FRAME_LDS_HASHLOG; }
 
 // ZSTD_writeFrameHeader (zstd_compress.c:4640-4690) with the content size known, no dictionary id
 __host__ __device__ inline uint32_t frame_header_bytes_multi(uint32_t n, uint32_t windowLog)
@@ -65,6 +74,14 @@ __device__ __attribute__((noinline)) void parse_fast_block_far(const uint8_t* sr
     parse_fast_block<MLS, WideTab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
 }
 
+template <uint32_t MLS>
+__device__ __attribute__((noinline)) void parse_dfast_block_far(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
+                                                                uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, unsigned char* scratch,
+                                                                uint32_t* tabL, uint32_t* tabS, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    parse_dfast_block<MLS, true>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, scratch, tabL, tabS, seqs, lits, meta);
+}
+
 __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum)
@@ -81,7 +98,7 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
         }
         return;
     }
-    for (uint32_t i = (uint32_t)t; i < (1u << u.hashLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table (:2020)
+    for (uint32_t i = (uint32_t)t; i < (uint32_t)frame_table_words(u.strategy, u.hashLog, u.chainLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table(s) (:2020)
     if (t == 0) { st->ent.hufRepeat = 0; st->ent.hufMaxSym = 0; st->ent.fseRepeat[0] = 0; st->ent.fseRepeat[1] = 0; st->ent.fseRepeat[2] = 0; }
     uint32_t rep1 = 1, rep2 = 4, rep3 = 8;
     long long savings = 0;
@@ -104,6 +121,16 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
                 uint32_t const ip0 = pos + (pos == prefixLow);
                 uint32_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;
                 uint32_t const maxRep = ip0 - windowLow;
+                if (u.strategy == ZHIP_STRAT_DFAST) {
+                    uint32_t* const tL = T.w; uint32_t* const tS = T.w + ((size_t)1 << u.hashLog);
+                    switch (u.minMatch) {
+                    case 5:  parse_dfast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 6:  parse_dfast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 7:  parse_dfast_block_far<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 8:  parse_dfast_block_far<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    default: parse_dfast_block_far<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    }
+                } else
                 switch (u.minMatch) {                                        // the hash width is a compile-time constant inside the parser
                 case 5:  parse_fast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
                 case 6:  parse_fast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;

@@ -242,7 +242,7 @@ k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frame
     size_t const shBytes = (sizeof(EntShared) + 15) & ~(size_t)15;
     FrameShared* const fs = (FrameShared*)(smem + shBytes);
     WideTab T;
-    T.w = u.hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (uint32_t*)(smem + shBytes + sizeof(FrameShared)) : tabs + (size_t)fi * tabStride;
+    T.w = frame_table_in_lds(u.strategy, u.hashLog) ? (uint32_t*)(smem + shBytes + sizeof(FrameShared)) : tabs + (size_t)fi * tabStride;
     const uint8_t* const p = src + u.srcOff;
     ZhipSeq* const sq = seqs + sl.seqOff;
     uint8_t* const lt = lits + sl.litOff;

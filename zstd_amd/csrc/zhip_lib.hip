@@ -549,24 +549,25 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
     if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
     if (nFrames > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu frames > context capacity %zu", nFrames, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
     const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
-    size_t bound = 0, outBytes = 0; uint32_t ldsLog = 0, bigLog = 0; unsigned long long totalSrc = 0;
+    size_t bound = 0, outBytes = 0, tabWords = 0; uint32_t ldsLog = 0; unsigned long long totalSrc = 0;
     for (size_t i = 0; i < nFrames; i++) {
         if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] >= (1ull << 31)) { snprintf(c->err, sizeof(c->err), "frame %zu: inputs of 2 GiB and more are not implemented on device", i); return ZERR(ZE_srcSize_wrong); }
         size_t const n = (size_t)(offs[i + 1] - offs[i]);
         zhip::CParams cp;
         if (!zhip::host_get_cparams(level, n, &cp, ov)) return ZERR(ZE_parameter_unsupported);
-        if (cp.strategy != ZHIP_STRAT_FAST) { snprintf(c->err, sizeof(c->err), "multi-block frames: strategy %u not implemented on device (ZSTD_fast only)", cp.strategy); return ZERR(ZE_parameter_unsupported); }
+        if (cp.strategy != ZHIP_STRAT_FAST && cp.strategy != ZHIP_STRAT_DFAST) { snprintf(c->err, sizeof(c->err), "multi-block frames: strategy %u not implemented on device (ZSTD_fast and ZSTD_dfast only)", cp.strategy); return ZERR(ZE_parameter_unsupported); }
         if (cp.windowLog < 17 && n > ((size_t)1 << cp.windowLog)) { snprintf(c->err, sizeof(c->err), "multi-block frames: windowLog %u below the block size is not implemented on device", cp.windowLog); return ZERR(ZE_parameter_unsupported); }
         ZhipUnit& u = c->hUnits[i];
         u.srcOff = offs[i]; u.srcLen = (uint32_t)n;
         u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
         u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-        u.litMode = cp.targetLength > 0 ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
+        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
         ZhipSlot& sl = c->hSlots[i];
         sl.seqOff = i * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = i * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = outBytes; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0;
         outBytes += (zhip::host_compress_bound(n) + 1024 + 15) & ~(size_t)15;      // the block in flight may overshoot before it is declared raw
         bound += zhip::host_compress_bound(n);
-        if (cp.hashLog <= ZHIP_FRAME_LDS_HASHLOG) { if (cp.hashLog > ldsLog) ldsLog = cp.hashLog; } else if (cp.hashLog > bigLog) bigLog = cp.hashLog;
+        if (zhip::frame_table_in_lds(cp.strategy, cp.hashLog)) { if (cp.hashLog > ldsLog) ldsLog = cp.hashLog; }
+        else { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
         totalSrc += n;
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
@@ -580,7 +581,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         if (hipMalloc((void**)&c->dFrameState, nFrames * sizeof(zhip::ZhipFrameState)) != hipSuccess) return ZERR(ZE_memory_allocation);
         c->frameStateCap = nFrames;
     }
-    size_t const tabStride = bigLog ? (size_t)1 << bigLog : 0;
+    size_t const tabStride = (tabWords + 3) & ~(size_t)3;
     if (tabStride && c->tabsCap < nFrames * tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
         if (hipMalloc((void**)&c->dTabs, nFrames * tabStride * sizeof(uint32_t)) != hipSuccess) return ZERR(ZE_memory_allocation);

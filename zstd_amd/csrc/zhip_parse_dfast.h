@@ -49,10 +49,16 @@ __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned
     return grp;
 }
 
-template <uint32_t MLS>
-__device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
-                                        uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS,
-                                        ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+// One block of ZSTD_dfast over src[b0, n) with the two tables as the previous blocks of the same frame left them (a unit: b0 = 0,
+// fresh tables).  WIDE: entries are plain 32-bit positions (a frame's positions exceed 17 bits) — no tag, every nonzero candidate
+// is fetched; else `position | tag << 17`.  Candidates must lie at or above prefixLow; the reference is asymmetric about the bound
+// itself: long / short match at ip: index >= lowest (ZSTD_selectAddr, zstd_double_fast.c:200, :214), the long match at ip+1:
+// index > lowest (:260), backward extension: match > lowest (:207, :267).
+template <uint32_t MLS, bool WIDE>
+__device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
+                                         uint32_t repIn1, uint32_t repIn2, uint32_t repIn3, const ZhipUnit& u, unsigned char* smem,
+                                         uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS,
+                                         ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const shL = 32 - u.hashLog, shS = 32 - u.chainLog;
@@ -60,23 +66,19 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
     lds_u8* const scrL = (lds_u8*)(uintptr_t)smem;
     lds_u8* const scrS = (lds_u8*)(uintptr_t)(smem + ZHIP_DF_SCRATCH);
+#define DF_POS(e)        (WIDE ? (e) : ((e) & ZHIP_DF_POS))
+#define DF_TAGOK(e, tg)  (WIDE ? true : (((e) >> 17) == (tg)))
+#define DF_ENTRY(p, tg)  (WIDE ? (p) : ((p) | ((tg) << 17)))
 
-    {   // fresh tables (zstd_compress.c:2020): the long and the short table are contiguous
-        uint32_t const words = (uint32_t)(dfast_table_bytes(u.hashLog, u.chainLog) >> 2);
-        uint4 const z = {0, 0, 0, 0};
-        for (uint32_t i = 4 * lane; i < words; i += 256) *(uint4*)(tabL + i) = z;      // tables are 16-byte aligned, sizes multiples of 16 words
-    }
-    __builtin_amdgcn_wave_barrier();
+    uint32_t anchor = b0, off1 = repIn1, off2 = repIn2, saved1 = 0, saved2 = 0;
+    // :158-164  a repcode that reaches below the window is set aside for the block
+    if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+    if (off1 > maxRep) { saved1 = off1; off1 = 0; }
 
-    uint32_t anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;
-    // :158-164  ip = 1, lowest index 0 -> maxRep = 1
-    if (off2 > 1) { saved2 = off2; off2 = 0; }
-    if (off1 > 1) { saved1 = off1; off1 = 0; }
-
-    if (n >= 10) {                          // shortest unit whose first iteration runs (ip1 = 2 <= n - 8)
+    if (n - b0 >= 9) {                      // shorter blocks never run an iteration (ip1 = ip + 1 <= n - 8); keeps n - 8 >= b0
     uint32_t const nm8 = n - 8;
     int32_t const ilimit = (int32_t)nm8;
-    uint32_t ip = 1;
+    uint32_t ip = b0 + (b0 == prefixLow);                                    // :157
     // Batch width.  Every searched lane costs two random table gathers (HBM/L2 sectors), and everything after the first
     // event of a batch is thrown away, so the batch is only as wide as events have recently been far apart: the running
     // mean distance (x16 fixed point) + 4 (best of the sweep in scripts/df_sweep.sh), doubled after a batch without an event.  Any width is exact.
@@ -107,7 +109,7 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
             uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short((uint32_t)bytes);
             uint32_t const eL = live ? tabL[hl] : 0, eS = live ? tabS[hs] : 0;
-            uint32_t const oldL = eL & ZHIP_DF_POS, oldS = eS & ZHIP_DF_POS;
+            uint32_t const oldL = DF_POS(eL), oldS = DF_POS(eS);
             uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
             if (live) { scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane; }
             __builtin_amdgcn_wave_barrier();
@@ -117,8 +119,8 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
 
             // candidate bytes are only fetched where the entry's tag says they can match (a random sector each)
             uint64_t cbL = ~bytes; uint32_t cbS = ~(uint32_t)bytes;
-            if (oldL != 0 && (eL >> 17) == tgL) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));     // table values are <= n-8 by construction
-            if (oldS != 0 && (eS >> 17) == tgS) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+            if (oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));     // table values are <= n-8 by construction
+            if (oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
             uint32_t candL = oldL, candS = oldS;
             unsigned long long grpL = 0, grpS = 0;
             if (loseL) {
@@ -135,8 +137,8 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd);
                 if (prev) { candS = dp; cbS = dlo; }
             }
-            bool const hitL = candL != 0 && cbL == bytes;                    // :203 MEM_read64 equal
-            bool const hitS = candS != 0 && cbS == (uint32_t)bytes;          // :218 MEM_read32 equal
+            bool const hitL = candL != 0 && candL >= prefixLow && cbL == bytes;                    // :203 MEM_read64 equal
+            bool const hitS = candS != 0 && candS >= prefixLow && cbS == (uint32_t)bytes;          // :218 MEM_read32 equal
             bool const hitR = off1 > 0 && rv == (uint32_t)(bytes >> 8);      // :190 repcode at ip+1
             unsigned long long const mL = __ballot(hitL), mR = __ballot(hitR) & searchMask, mS = __ballot(hitS) & searchMask;
             unsigned long long const mAny = (mL & searchMask) | mR | mS;
@@ -146,8 +148,8 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
             // :187 hashLong[hl0] = hashSmall[hs0] = curr for every position up to the event: last lane of a group wins
             {   bool const inC = (int)lane < Lcommit;
                 unsigned long long const cm = below_mask(Lcommit) & ~below_mask((int)lane + 1);
-                if (inC && (grpL & cm) == 0) tabL[hl] = p | (tgL << 17);
-                if (inC && (grpS & cm) == 0) tabS[hs] = p | (tgS << 17);
+                if (inC && (grpL & cm) == 0) tabL[hl] = DF_ENTRY(p, tgL);
+                if (inC && (grpS & cm) == 0) tabS[hs] = DF_ENTRY(p, tgS);
             }
             __builtin_amdgcn_wave_barrier();
             if (evKind) {
@@ -157,9 +159,9 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 candE = __builtin_amdgcn_readlane(evKind == 2 ? candL : candS, jE);
                 ip1 = __builtin_amdgcn_readlane(p, jE + 1);                  // lane jE+1 <= K is live
                 cand1 = __builtin_amdgcn_readlane(candL, jE + 1);
-                long1 = (mL >> (jE + 1)) & 1;                                // :253 long match at ip1 (8 bytes equal, valid index)
+                long1 = ((mL >> (jE + 1)) & 1) && cand1 > prefixLow;         // :260 long match at ip1 (8 bytes equal, index > lowest)
                 if (evKind != 1 && step < 4) {                               // :283-291 hashLong[hl1] = ip1
-                    if ((int)lane == jE + 1) tabL[hl] = p | (tgL << 17);
+                    if ((int)lane == jE + 1) tabL[hl] = DF_ENTRY(p, tgL);
                     __builtin_amdgcn_wave_barrier();
                 }
                 break;
@@ -189,7 +191,7 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 }
             }
             uint32_t const offset = mstart - match;
-            {   uint32_t const lim = (mstart - anchor) < match ? (mstart - anchor) : match;      // :207, :267 catch up
+            {   uint32_t const lim = (mstart - anchor) < match - prefixLow ? (mstart - anchor) : match - prefixLow;      // :207, :267 catch up
                 uint32_t const back = wave_count_back(src, mstart, match, lim);
                 mstart -= back; mLength += back;
             }
@@ -206,7 +208,7 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
                 uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
                 uint32_t const hL = vv >> shL, hS = hash_pos<MLS>(b, shS);
-                uint32_t const qL = q | (df_tag_long(vv) << 17), qS = q | (df_tag_short((uint32_t)b) << 17);
+                uint32_t const qL = DF_ENTRY(q, df_tag_long(vv)), qS = DF_ENTRY(q, df_tag_short((uint32_t)b));
                 if (lane == 0) { tabL[hL] = qL; tabS[hS] = qS; }
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 1) tabL[hL] = qL;
@@ -220,8 +222,8 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
                 {   uint32_t const t = off2; off2 = off1; off1 = t; }
                 if (lane == 0) {
                     uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
-                    tabS[hash_pos<MLS>(b, shS)] = ip | (df_tag_short((uint32_t)b) << 17);
-                    tabL[vv >> shL] = ip | (df_tag_long(vv) << 17);
+                    tabS[hash_pos<MLS>(b, shS)] = DF_ENTRY(ip, df_tag_short((uint32_t)b));
+                    tabL[vv >> shL] = DF_ENTRY(ip, df_tag_long(vv));
                 }
                 __builtin_amdgcn_wave_barrier();
                 store_seq(out, 0, 1, rLength);
@@ -232,17 +234,36 @@ __device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals
     lits_flush(out);
     } else {
-        for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];
-        out.litPos = n;
+        for (uint32_t i = lane; i < n - b0; i += 64) lits[i] = src[b0 + i];
+        out.litPos = n - b0;
     }
     // ---- _cleanup (:248-256)
     saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
     if (lane == 0) {
         meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
         meta->longPos = out.longPos; meta->longType = out.longType;
-        meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = 8;
+        meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = repIn3;
         meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
     }
+#undef DF_POS
+#undef DF_TAGOK
+#undef DF_ENTRY
+}
+
+// One unit = one block with fresh tables (tagged 17-bit entries)
+template <uint32_t MLS>
+__device__ inline void parse_dfast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem,
+                                        uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS,
+                                        ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    {   // fresh tables (zstd_compress.c:2020): the long and the short table are contiguous
+        uint32_t const words = (uint32_t)(dfast_table_bytes(u.hashLog, u.chainLog) >> 2);
+        uint4 const z = {0, 0, 0, 0};
+        for (uint32_t i = 4 * lane; i < words; i += 256) *(uint4*)(tabL + i) = z;      // tables are 16-byte aligned, sizes multiples of 16 words
+    }
+    __builtin_amdgcn_wave_barrier();
+    parse_dfast_block<MLS, false>(src, 0, n, 0, 1, 1, 4, 8, u, smem, tabL, tabS, seqs, lits, meta);   // lowest index 0, ip = 1 -> maxRep = 1
 }
 
 }  // namespace zhip
