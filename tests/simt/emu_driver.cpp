@@ -148,8 +148,11 @@ void emu_entropy_ck(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
                     const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, const uint32_t* checks, int osThreads)
 {
     std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
+    // both shapes of the encoder, as the host library launches them: 256 threads for the units above ZHIP_ENT_SMALL_MAX, one wavefront below
     simt::launch({nUnits, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, sizeof(zhip::EntShared),
-                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u, checks); }, osThreads);
+                 [=] { zhip::k_entropy(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u, checks, 1u); }, osThreads);
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, sizeof(zhip::EntSharedSmall),
+                 [=] { zhip::k_entropy_small(src, units, slots, nUnits, seqs, metas, lits, stBits, out, outSize, nullptr, 0u, checks); }, osThreads);
 }
 // multi-block frames: frames[i] describes one whole input; out holds outStride bytes per frame
 void emu_frame_fast(const uint8_t* src, const ZhipUnit* frames, uint32_t nFrames, uint8_t* out, uint64_t outStride, uint32_t* outSize,

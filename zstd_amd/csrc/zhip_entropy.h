@@ -86,6 +86,34 @@ struct EntShared {
     CodeTabs tabs;
 };
 
+// The same workspace for the one-wavefront form (NT = 64): one histogram instead of four, no cross-wave scan, no sampling
+// histograms (the sampling heuristic needs 40 KB of literals; units of this form are at most ZHIP_ENT_SMALL_MAX bytes), and the
+// Huffman builder's workspace shares its bytes with the sequence tables — the single wavefront is done with the literals job before
+// it starts the first table.  12.6 KB instead of 25.7 KB: twelve records resident per CU instead of six workgroups.
+#define ZHIP_ENT_SMALL_MAX 8192u
+struct EntSharedSmall {
+    uint32_t hist[1][256];
+    uint32_t code[256];
+    uint32_t scan[8];
+    uint32_t seqCount[3][64];
+    union {
+        HufWork huf;
+        struct { FseCTable ct[3]; int16_t norm[3][56]; uint8_t symScratch[3][512]; uint16_t cumul[3][64]; };
+    };
+    uint8_t  ncount[3][64];
+    uint32_t ncWords[3][16];
+    uint32_t ncountSize[3];
+    uint32_t encType[3];
+    uint32_t maxCode[3];
+    uint32_t finalState[3];
+    uint8_t  hufHdr[136];
+    uint32_t litSize, hufHdrSize, huffLog, litMode, singleStream, litType, hufMaxSym;
+    uint32_t streamBits[4], streamBytes[4], streamOff[4];
+    uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
+    uint32_t sampleHist[2][1];    // never touched (see above); keeps the shared code one text
+    CodeTabs tabs;
+};
+
 // ------------------------------------------------------------------ small block-wide helpers
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -93,29 +121,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     for (int d = 1; d < 64; d <<= 1) { uint32_t const o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
     return v;
 }
-// exclusive prefix sum over the 256 threads (thread order); *total gets the grand total. uses sh->scan
-__device__ inline uint32_t block_excl_scan(EntShared* sh, uint32_t v, uint32_t* total)
+// exclusive prefix sum over the NT threads of the workgroup (thread order); *total gets the grand total. uses sh->scan
+template <uint32_t NT, typename SH>
+__device__ inline uint32_t block_excl_scan(SH* sh, uint32_t v, uint32_t* total)
 {
     int const t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t const inc = wave_incl_scan(v);
+    if (NT == 64) { *total = __shfl(inc, 63); return inc - v; }
     if (lane == 63) sh->scan[w] = inc;
     __syncthreads();
-    uint32_t base = 0;
-    for (int i = 0; i < w; i++) base += sh->scan[i];
-    *total = sh->scan[0] + sh->scan[1] + sh->scan[2] + sh->scan[3];
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < (int)(NT / 64); i++) { if (i < w) base += sh->scan[i]; tot += sh->scan[i]; }
+    *total = tot;
     __syncthreads();
     return base + inc - v;
 }
 
 // zero exactly [p, p+nbytes) with all threads of the workgroup (neighbouring bytes belong to finished sections)
+template <uint32_t NT>
 __device__ inline void zero_bytes(uint8_t* p, uint32_t nbytes)
 {
     uint32_t const t = threadIdx.x;
     uint32_t head = (4u - (uint32_t)((uintptr_t)p & 3)) & 3u; if (head > nbytes) head = nbytes;
-    if (t < head) p[t] = 0;
+    if (t < head) p[t] = 0;                                              // head, tail < 4 <= NT
     uint32_t* const w = (uint32_t*)(p + head);
     uint32_t const words = (nbytes - head) >> 2;
-    for (uint32_t i = t; i < words; i += ZHIP_ENT_THREADS) w[i] = 0;
+    for (uint32_t i = t; i < words; i += NT) w[i] = 0;
     uint32_t const tail = nbytes - head - 4 * words;
     if (t < tail) p[head + 4 * words + t] = 0;
 }
@@ -278,24 +309,29 @@ __device__ __forceinline__ bool fse_chain_run(const FseCTable* ct, uint16_t* arr
     }
     return false;
 }
-// room `ckpt` needs, in uint16 entries, for a chain of M entries
-__host__ __device__ inline uint32_t fse_chain_ckpt_entries(uint32_t M) { uint32_t const chunks = (M + 7) >> 3; return 64u * ((chunks + 63) >> 6); }
-// arr[0 .. M) codes -> records; returns the final state (after entry 0).  lastCode = the code of sequence M (it only seeds the state).
-// ckpt: fse_chain_ckpt_entries(M) uint16 of scratch in global memory, private to this wavefront; touched only when a lane owns two
-// or more chunks (M > 512), i.e. at most 0.19 bytes per source byte
+// room `ckpt` needs, in uint16 entries, for a chain of M entries cut over G lanes
+__host__ __device__ inline uint32_t fse_chain_ckpt_entries(uint32_t M, uint32_t G = 64) { uint32_t const chunks = (M + 7) >> 3; return 64u * ((chunks + G - 1) / G); }
+// arr[0 .. M) codes -> records; returns (in every lane of the group) the final state (after entry 0).  lastCode = the code of
+// sequence M (it only seeds the state).  The wavefront is cut into groups of G lanes (G = 64: one chain by the whole wavefront;
+// G = 21: three chains — LL, OF, ML of one small block — side by side, lane 63 idle); ct / arr / lastCode are per GROUP (every
+// lane passes its group's), M is the same for all.  ckpt: fse_chain_ckpt_entries(M, G) uint16 of scratch in global memory, private
+// to this wavefront (all groups index it by t * 64 + lane); touched only when a lane owns two or more chunks (M > 8 G).
+template <uint32_t G>
 __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt)
 {
     uint32_t const lane = (uint32_t)(threadIdx.x & 63);
+    uint32_t const grp = lane / G, gl = lane - grp * G;                     // group, lane inside the group
+    bool const inGroup = G == 64 || grp < 64 / G;                           // G = 21: lane 63 belongs to no chain
     uint32_t const init = fse_init_state2(ct, lastCode);
     if (M == 0) return init;
-    uint32_t const chunks = (M + 7) >> 3, cpl = (chunks + 63) >> 6;          // chunks per lane
-    uint32_t const used = (chunks + cpl - 1) / cpl;                          // lanes that own something; lane 0 owns the TOP slice
-    bool const mine = lane < used;
-    uint32_t const topC = mine ? chunks - lane * cpl : 0;                    // own chunks [botC, topC)
+    uint32_t const chunks = (M + 7) >> 3, cpl = (chunks + G - 1) / G;       // chunks per lane
+    uint32_t const used = (chunks + cpl - 1) / cpl;                         // lanes of a group that own something; lane 0 of a group owns the TOP slice
+    bool const mine = inGroup && gl < used;
+    uint32_t const topC = mine ? chunks - gl * cpl : 0;                     // own chunks [botC, topC)
     uint32_t const botC = topC > cpl ? topC - cpl : 0;
     // pass 1, nothing written to arr: warm-up (one that reaches the very top starts from the true state), then the slice
     uint32_t enter = init;
-    if (mine && lane) {
+    if (mine && gl) {
         uint32_t w1 = topC + ZHIP_FSE_WARM;
         if (w1 >= chunks) w1 = chunks; else enter = 1u << ct->tableLog;
         fse_chain_run(ct, arr, M, w1, topC, enter, ZC_DRY, ckpt, lane);
@@ -306,7 +342,7 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
     // hand-down rounds
     for (;;) {
         uint32_t const above = __shfl_up(fin, 1);
-        bool const bad = mine && lane && enter != above;
+        bool const bad = mine && gl && enter != above;
 #ifdef ZHIP_CHAIN_DEBUG
         { unsigned long long const bb = __ballot(bad); if (lane == 0 && bb) printf("CHAIN M=%u tableLog=%u cpl=%u used=%u bad=%d lanes\n", M, ct->tableLog, cpl, used, (int)__builtin_popcountll(bb)); }
 #endif
@@ -321,7 +357,7 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
     // pass 2: every slice again from its (now true) entering state, records written in place
     uint32_t st = enter;
     fse_chain_run(ct, arr, M, topC, botC, st, ZC_RECORD, ckpt, lane);
-    return (uint32_t)__builtin_amdgcn_readlane((int)fin, (int)(used - 1));
+    return __shfl(fin, (int)(grp * G + used - 1));                            // the group's lowest slice holds the final state
 }
 
 // ================================================================== the block encoder
@@ -329,10 +365,16 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
 // returns the compressed size, or 0 when the block has to be emitted uncompressed (same value in every thread).  n >= 7.
 // `de`: the previous block's / the dictionary's entropy state, or nullptr.  Afterwards sh->litMode / litType / code[] /
 // hufMaxSym describe the literals' Huffman table (a multi-block frame keeps it as the next block's previous table).
+// NT threads per workgroup: 256 (four wavefronts: the literals job and the three sequence tables side by side, one Huffman stream
+// per wavefront) with SH = EntShared, or 64 (one wavefront does the jobs one after the other) with SH = EntSharedSmall — the form for
+// small records, where a 256-thread workgroup would mostly wait at its own barriers.
+template <uint32_t NT, typename SH>
 __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
                                          const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
-                                         uint8_t* __restrict__ body, EntShared* sh, const ZhipDictEntropy* __restrict__ de)
+                                         uint8_t* __restrict__ body, SH* sh, const ZhipDictEntropy* __restrict__ de)
 {
+    constexpr uint32_t NW = NT / 64;                         // wavefronts of the workgroup
+    constexpr uint32_t SPW = 4 / NW;                         // Huffman streams a wavefront takes care of
     int const t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t const nbSeq = pm.nbSeq;
     uint32_t const minGainBlock = (n >> 6) + 2;             // zstd_compress_internal.h:613
@@ -340,10 +382,10 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     uint16_t* const bLL = stBits; uint16_t* const bOF = stBits + seqCap; uint16_t* const bML = stBits + 2 * (size_t)seqCap;
 
     // ================ phase A (all threads): byte histogram of the literals; sequence codes + code histograms
-    for (int i = t; i < 4 * 256; i += ZHIP_ENT_THREADS) (&sh->hist[0][0])[i] = 0;
-    for (int i = t; i < 3 * 64; i += ZHIP_ENT_THREADS) (&sh->seqCount[0][0])[i] = 0;
+    for (int i = t; i < (int)(NW * 256); i += NT) (&sh->hist[0][0])[i] = 0;
+    for (int i = t; i < 3 * 64; i += NT) (&sh->seqCount[0][0])[i] = 0;
     if (t < 64) sh->tabs.llCode[t] = kLLcode[t];
-    if (t < 128) sh->tabs.mlCode[t] = kMLcode[t];
+    for (int i = t; i < 128; i += NT) sh->tabs.mlCode[i] = kMLcode[i];
     if (t < 36) sh->tabs.llBits[t] = kLLbits[t];
     if (t < 53) sh->tabs.mlBits[t] = kMLbits[t];
     const CodeTabs& TB = sh->tabs;
@@ -352,7 +394,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     // per step, coalesced; one histogram per wavefront to spread the LDS atomics
     uint32_t const litSize = pm.litSize;
     {   uint32_t* const myHist = sh->hist[wv];
-        uint32_t const strideB = 16u * ZHIP_ENT_THREADS;
+        uint32_t const strideB = 16u * NT;
         for (uint32_t i0 = 16u * (uint32_t)t; i0 < litSize; i0 += 4 * strideB) {      // 4 loads in flight per thread
             uint4 v[4];
             for (int q = 0; q < 4; q++) { uint32_t const i = i0 + (uint32_t)q * strideB; if (i < litSize) __builtin_memcpy(&v[q], lits + i, 16); }   // lits has >= 64 bytes of slack
@@ -367,7 +409,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     }
     ZPROF(9);
     // sequence codes (zstd_compress.c:2686-2712) -> stBits arrays (replaced by the FSE records in phase B) + histograms
-    for (uint32_t i = (uint32_t)t; i < nbSeq; i += ZHIP_ENT_THREADS) {
+    for (uint32_t i = (uint32_t)t; i < nbSeq; i += NT) {
         uint32_t ll, mlb, ob; seq_fields(seqs, pm, i, ll, mlb, ob);
         uint32_t const llc = ll_code(TB, ll), ofc = hb32(ob), mlc = ml_code(TB, mlb);
         bLL[i] = (uint16_t)llc; bOF[i] = (uint16_t)ofc; bML[i] = (uint16_t)mlc;
@@ -384,11 +426,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     bool const tryHuf0 = !(u.litMode) && litSize >= (hufRep0 == 2 ? 6u : 64u);        // :115-127 minLiteralsToCompress (strategy <= lazy2)
     bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);                      // zstd_compress.c:2918
     bool const sampling = tryHuf0 && suspect && litSize >= 40960;
-    if (sampling) for (int i = t; i < 512; i += ZHIP_ENT_THREADS) (&sh->sampleHist[0][0])[i] = 0;
+    if (sampling) for (int i = t; i < 512; i += NT) (&sh->sampleHist[0][0])[i] = 0;
     __syncthreads();                                        // lits[] complete, histograms complete
-    if (t < 256) sh->hist[0][t] += sh->hist[1][t] + sh->hist[2][t] + sh->hist[3][t];
+    if (NW > 1) for (int i = t; i < 256; i += NT) { uint32_t a = 0; for (uint32_t w = 1; w < NW; w++) a += sh->hist[w][i]; sh->hist[0][i] += a; }
     if (sampling) {
-        for (uint32_t i = (uint32_t)t; i < 4096; i += ZHIP_ENT_THREADS) {
+        for (uint32_t i = (uint32_t)t; i < 4096; i += NT) {
             atomicAdd(&sh->sampleHist[0][lits[i]], 1u);
             atomicAdd(&sh->sampleHist[1][lits[litSize - 4096 + i]], 1u);
         }
@@ -450,8 +492,9 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         if (de && mode == 2 && litType == 3) for (int s0 = lane; s0 < 256; s0 += 64) sh->code[s0] = de->hufCode[s0];
         ZPROF_JOB_MARK(31);
     }
-    if (wv >= 1 && nbSeq > 0) {
-        int const k = wv - 1;                                  // 0 LL, 1 OF, 2 ML
+    if (NW == 1) __builtin_amdgcn_wave_barrier();          // one wavefront: the literals job is done with its workspace before the tables reuse it
+    if ((NW == 1 || wv >= 1) && nbSeq > 0)
+    for (int k = (NW == 1 ? 0 : wv - 1); k < (NW == 1 ? 3 : wv); k++) {                                  // 0 LL, 1 OF, 2 ML
         uint16_t* const arr = stBits + (size_t)k * seqCap;
         uint32_t const lastCode = arr[nbSeq - 1];                  // for the "-1" rule (zstd_compress_sequences.c:271-274)
         ZPROF_JOB_BEGIN
@@ -533,15 +576,28 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             __builtin_amdgcn_wave_barrier();
         }
         ZPROF_JOB_MARK(29);
-        if (sh->encType[k] != 9) {
+        if (NW > 1 && sh->encType[k] != 9) {
             // the table's FSE state chain, last sequence -> first (zstd_compress_sequences.c:311-369): arr[i] (the code)
             // becomes (nbBits << 12 | value)
             // scratch for the slices' chunk states: the block's own output room, which nothing has written yet (3 x <= 8 KB of it)
             uint16_t* const ckpt = (uint16_t*)(((uintptr_t)body + 15) & ~(uintptr_t)15) + (size_t)k * fse_chain_ckpt_entries(nbSeq - 1);
-            uint32_t const fin = fse_chain_wave(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt);
+            uint32_t const fin = fse_chain_wave<64>(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt);
             if (lane == 0) sh->finalState[k] = fin;
         }
         ZPROF_JOB_MARK(30);
+    }
+    if (NW == 1 && nbSeq > 0) {
+        // one wavefront: the three chains side by side, 21 lanes each (a small block's chains are a handful of dependent round
+        // trips each — three in a row would be most of the kernel)
+        __builtin_amdgcn_wave_barrier();
+        bool const anyFail = (sh->encType[0] == 9) | (sh->encType[1] == 9) | (sh->encType[2] == 9);   // never for valid histograms; the block goes raw
+        if (!anyFail) {
+            uint32_t const g = (uint32_t)lane / 21u, k3 = g < 3 ? g : 2;
+            uint16_t* const arr3 = stBits + (size_t)k3 * seqCap;
+            uint16_t* const ckpt = (uint16_t*)(((uintptr_t)body + 15) & ~(uintptr_t)15);
+            uint32_t const fin = fse_chain_wave<21>(&sh->ct[k3], arr3, nbSeq - 1, arr3[nbSeq - 1], ckpt);
+            if (lane == 0 || lane == 21 || lane == 42) sh->finalState[k3] = fin;
+        }
     }
     __syncthreads();
     ZPROF(1);
@@ -554,24 +610,30 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         uint32_t const seg = single ? litSize : (litSize + 3) / 4;
         // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols, read 8 at a time
         // (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so an 8-byte read may run past the run).
-        uint32_t myBits = 0, segStart = 0, segLen = 0, runStart = 0, runLen = 0;
-        if ((uint32_t)wv < nStreams) {
-            segStart = (uint32_t)wv * seg;
-            segLen = single ? litSize : ((wv < 3) ? seg : litSize - 3 * seg);
-            uint32_t const rper = (segLen + 63) / 64;
-            runStart = (uint32_t)lane * rper; if (runStart > segLen) runStart = segLen;
-            runLen = (runStart + rper <= segLen) ? rper : segLen - runStart;
-            const uint8_t* p = lits + segStart + runStart;
-            for (uint32_t i = 0; i < runLen; i += 32) {
-                uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
-                uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
-                uint32_t const c = runLen - i;
-                for (uint32_t b = 0; b < 32; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
+        uint32_t segStart[SPW], runStart[SPW], runLen[SPW], incl[SPW], total[SPW];
+#pragma unroll
+        for (uint32_t q = 0; q < SPW; q++) {
+            uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
+            uint32_t myBits = 0;
+            segStart[q] = 0; runStart[q] = 0; runLen[q] = 0;
+            if (sI < nStreams) {
+                segStart[q] = sI * seg;
+                uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
+                uint32_t const rper = (segLen + 63) / 64;
+                runStart[q] = (uint32_t)lane * rper; if (runStart[q] > segLen) runStart[q] = segLen;
+                runLen[q] = (runStart[q] + rper <= segLen) ? rper : segLen - runStart[q];
+                const uint8_t* p = lits + segStart[q] + runStart[q];
+                for (uint32_t i = 0; i < runLen[q]; i += 32) {
+                    uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
+                    uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
+                    uint32_t const c = runLen[q] - i;
+                    for (uint32_t b = 0; b < 32; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
+                }
             }
+            incl[q] = wave_incl_scan(myBits);
+            total[q] = __shfl(incl[q], 63);
+            if (lane == 0 && sI < nStreams) { sh->streamBits[sI] = total[q]; sh->streamBytes[sI] = (total[q] >> 3) + 1; }
         }
-        uint32_t const incl = wave_incl_scan(myBits);
-        uint32_t const total = __shfl(incl, 63);
-        if (lane == 0 && (uint32_t)wv < nStreams) { sh->streamBits[wv] = total; sh->streamBytes[wv] = (total >> 3) + 1; }
         __syncthreads();
         if (t == 0) {
             uint32_t off = lhSize + sh->hufHdrSize + (single ? 0 : 6), tot = sh->hufHdrSize + (single ? 0 : 6);
@@ -591,7 +653,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         if (litMode == 2) {
             uint32_t const cLit = sh->litSectionSize - lhSize;
             // zero the stream bytes that will be OR-ed
-            zero_bytes(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
+            zero_bytes<NT>(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
             if (t == 0) {
                 // section header (zstd_compress_literals.c:209-232)
                 if (lhSize == 3) { uint32_t const lhc = sh->litType + ((uint32_t)(!single) << 2) + (litSize << 4) + (cLit << 14); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); }
@@ -604,14 +666,17 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             ZPROF(2);
             // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
             // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
-            if ((uint32_t)wv < nStreams) {
-                uint8_t* const sbase = litDst + sh->streamOff[wv];
+#pragma unroll
+            for (uint32_t q = 0; q < SPW; q++) {
+                uint32_t const sI = (uint32_t)wv + q * NW;
+                if (sI >= nStreams) continue;
+                uint8_t* const sbase = litDst + sh->streamOff[sI];
                 uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
                 uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
-                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total - incl));
-                const uint8_t* p = lits + segStart + runStart;
+                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total[q] - incl[q]));
+                const uint8_t* p = lits + segStart[q] + runStart[q];
                 // the run is consumed from its end, 32 bytes per round; the first round takes the odd part
-                uint32_t i = runLen;
+                uint32_t i = runLen[q];
                 while (i) {
                     uint32_t const c = (i & 31) ? (i & 31) : 32;
                     i -= c;
@@ -641,7 +706,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             if (litMode == 1) litDst[fl] = lits[0];
             sh->litSectionSize = (litMode == 1) ? fl + 1 : fl + litSize;
         }
-        if (litMode == 0) for (uint32_t i = (uint32_t)t; i < litSize; i += ZHIP_ENT_THREADS) litDst[fl + i] = lits[i];
+        if (litMode == 0) for (uint32_t i = (uint32_t)t; i < litSize; i += NT) litDst[fl + i] = lits[i];
         __syncthreads();
     }
     ZPROF(3);
@@ -663,7 +728,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         if (!rawBlock) {
             // per-sequence bit counts -> positions.  Stream order (LSB first): sequence nbSeq-1 first, then nbSeq-2 ...;
             // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra]
-            uint32_t const per2 = (nbSeq + ZHIP_ENT_THREADS - 1) / ZHIP_ENT_THREADS;
+            uint32_t const per2 = (nbSeq + NT - 1) / NT;
             uint32_t const a0 = (uint32_t)t * per2 < nbSeq ? (uint32_t)t * per2 : nbSeq;
             uint32_t const a1 = a0 + per2 < nbSeq ? a0 + per2 : nbSeq;
             uint32_t myBits = 0;
@@ -677,7 +742,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 }
             }
             uint32_t totalSeqBits;
-            uint32_t const before = block_excl_scan(sh, myBits, &totalSeqBits);      // bits of sequences with LOWER index
+            uint32_t const before = block_excl_scan<NT, SH>(sh, myBits, &totalSeqBits);      // bits of sequences with LOWER index
             uint32_t const tailBits = sh->ct[2].tableLog + sh->ct[1].tableLog + sh->ct[0].tableLog;
             uint32_t const streamBits = totalSeqBits + tailBits;                       // + 1 end mark
             uint32_t const streamBytes = (streamBits >> 3) + 1;
@@ -688,7 +753,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             if (litSection + nbHdr + 1 + tblBytes + streamBytes >= n - minGainBlock) rawBlock = true;
             else {
             // zero the bytes of the bitstream; lane 0 writes the table headers in front of it
-            zero_bytes(bs, streamBytes);
+            zero_bytes<NT>(bs, streamBytes);
             if (t == 0) {
                 uint8_t* op = seqDst + nbHdr;
                 *op++ = (uint8_t)((sh->encType[0] << 6) + (sh->encType[1] << 4) + (sh->encType[2] << 2));
@@ -746,9 +811,10 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
 }
 
 // ================================================================== the unit encoder: one frame holding one block
+template <uint32_t NT, typename SH>
 __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipSeq* __restrict__ seqs,
                                     const ZhipParse& pm, const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint32_t seqCap,
-                                    uint8_t* __restrict__ out, uint32_t* outSize, EntShared* sh,
+                                    uint8_t* __restrict__ out, uint32_t* outSize, SH* sh,
                                     const ZhipDictEntropy* __restrict__ de /* dictionary entropy state or nullptr */, uint32_t dictID,
                                     bool withChecksum, uint32_t checksum /* low 32 bits of XXH64(content), zstd_compress.c:5297 */)
 {
@@ -758,11 +824,11 @@ __device__ inline void entropy_unit(const uint8_t* __restrict__ src, const ZhipU
     uint8_t* const body = out + fh + 3;                     // block content starts after frame + block header
     uint32_t cSize = 0;
     // trivial units (empty, or too small to attempt compression: zstd_compress.c:3216, :5270) are emitted uncompressed
-    if (n >= 7) cSize = entropy_block(src, n, u, seqs, pm, lits, stBits, seqCap, body, sh, de);
+    if (n >= 7) cSize = entropy_block<NT, SH>(src, n, u, seqs, pm, lits, stBits, seqCap, body, sh, de);
     bool const rawBlock = cSize == 0;
     if (rawBlock) {
         __syncthreads();                                        // thread 0's section-header bytes land before the copy overwrites them
-        for (uint32_t i = (uint32_t)t; i < n; i += ZHIP_ENT_THREADS) body[i] = src[i];
+        for (uint32_t i = (uint32_t)t; i < n; i += NT) body[i] = src[i];
     }
     // block + frame headers (zstd_compress.c:4582-4590)
     if (t == 0) {

@@ -141,7 +141,7 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
             }
             __syncthreads();
             ZhipParse const pm = fs->meta;
-            cSize = entropy_block(src + pos, bLen, u, seqs, pm, lits, stBits, seqCap, body, sh, &st->ent);
+            cSize = entropy_block<ZHIP_ENT_THREADS, EntShared>(src + pos, bLen, u, seqs, pm, lits, stBits, seqCap, body, sh, &st->ent);
             if (pos != 0 && cSize < 25) {                                    // :4365-4376 an RLE block, never the first one
                 if (t == 0) fs->flag = 0;
                 __syncthreads();

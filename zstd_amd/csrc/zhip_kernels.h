@@ -206,22 +206,42 @@ k_parse_ext(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
     parse_ext_source(src + u.srcOff, u, cd, tabs + (size_t)i * tabStride, seqs + sl.seqOff, sl.seqCap, lits + sl.litOff, metas + ui);
 }
 
-// Stage 2: one 256-thread workgroup per unit: literals + sequences entropy coding and frame assembly into the unit's
-// output slot.  Dynamic LDS = sizeof(EntShared).
+// Stage 2: literals + sequences entropy coding and frame assembly into the unit's output slot.  Two shapes of the same code
+// (zhip_entropy.h): one 256-thread workgroup per unit (dynamic LDS = sizeof(EntShared)) and, for units of at most
+// ZHIP_ENT_SMALL_MAX bytes, one wavefront per unit (k_entropy_small, sizeof(EntSharedSmall)).  sizeClass: 0 = every unit,
+// 1 = only the units above ZHIP_ENT_SMALL_MAX (the small ones belong to the other launch).
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
 k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
           const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize,
-          const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID, const uint32_t* __restrict__ checks /* frame checksums or nullptr */)
+          const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID, const uint32_t* __restrict__ checks /* frame checksums or nullptr */,
+          uint32_t sizeClass)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
+    if (sizeClass == 1 && u.srcLen <= ZHIP_ENT_SMALL_MAX) return;
     ZhipParse const pm = metas[ui];
     ZhipSlot const sl = slots[ui];
-    entropy_unit(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
+    entropy_unit<ZHIP_ENT_THREADS, EntShared>(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
                  stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntShared*)smem, dictEntropy, dictID, checks != nullptr, checks ? checks[ui] : 0u);
+}
+__global__ void __launch_bounds__(64)
+k_entropy_small(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+                const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
+                const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize,
+                const ZhipDictEntropy* __restrict__ dictEntropy, uint32_t dictID, const uint32_t* __restrict__ checks)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    if (u.srcLen > ZHIP_ENT_SMALL_MAX) return;
+    ZhipParse const pm = metas[ui];
+    ZhipSlot const sl = slots[ui];
+    entropy_unit<64, EntSharedSmall>(src + u.srcOff, u, seqs + sl.seqOff, pm, lits + sl.litOff,
+                 stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + ui, (EntSharedSmall*)smem, dictEntropy, dictID, checks != nullptr, checks ? checks[ui] : 0u);
 }
 
 // One workgroup per multi-block frame (zhip_frame.h).  frames[i].srcLen is the whole input of frame i (< 2^31); its slot gives

@@ -381,8 +381,20 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
         if (!c->dChecks) HIPCHK(c, hipMalloc((void**)&c->dChecks, (c->maxUnits + 16) * sizeof(uint32_t)));
         hipLaunchKernelGGL(zhip::k_xxh64, dim3((unsigned)((nUnits + 15) / 16)), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dChecks);
     }
-    hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
-                       srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, c->checksum ? c->dChecks : (const uint32_t*)nullptr);
+    {   // units of at most ZHIP_ENT_SMALL_MAX bytes take the one-wavefront form of the encoder (small records: a 256-thread
+        // workgroup would mostly wait at its own barriers); $ZHIP_ENT_SMALL=0 keeps everything on the 256-thread form (A/B knob)
+        static int const useSmall = getenv("ZHIP_ENT_SMALL") ? atoi(getenv("ZHIP_ENT_SMALL")) : 1;
+        bool anySmall = false, anyLarge = false;
+        if (useSmall) for (size_t i = 0; i < nUnits && !(anySmall && anyLarge); i++) { if (c->hUnits[i].srcLen <= ZHIP_ENT_SMALL_MAX) anySmall = true; else anyLarge = true; }
+        else anyLarge = true;
+        const uint32_t* const ck = c->checksum ? c->dChecks : (const uint32_t*)nullptr;
+        if (anyLarge)
+            hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
+                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, ck, anySmall ? 1u : 0u);
+        if (anySmall)
+            hipLaunchKernelGGL(zhip::k_entropy_small, dim3((unsigned)nUnits), dim3(64), sizeof(zhip::EntSharedSmall), s,
+                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, ck);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
@@ -416,7 +428,7 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
                            c->dSeqs, c->dLits, c->dParse + u0);
         hipLaunchKernelGGL(zhip::k_entropy, dim3(nu), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), q,
                            srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dSeqs, c->dParse + u0, c->dLits,
-                           c->dStBits, c->dOut, c->dOutSize + u0, (const zhip::ZhipDictEntropy*)nullptr, 0u, (const uint32_t*)nullptr);
+                           c->dStBits, c->dOut, c->dOutSize + u0, (const zhip::ZhipDictEntropy*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->cev[i], q));
         HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
