@@ -61,10 +61,21 @@ __device__ __forceinline__ uint32_t ml_code(const CodeTabs& T, uint32_t mlBase) 
 
 // ------------------------------------------------------------------ LDS layout of the workgroup
 struct EntShared {
-    uint32_t hist[4][256];        // per-wavefront literal histograms, reduced into hist[0]
+    // The Huffman builder's workspace (8.6 KB, wave 0, phase B only) lies over what is dead or not yet alive while it runs: the three
+    // extra per-wavefront histograms (already reduced into hist[0], which the builder reads), the sampling histograms (read at the
+    // start of the literals job, before the builder) and the scan area (phase C).  18.5 KB instead of 25.7 KB: eight workgroups per CU.
+    union {
+        struct {
+            uint32_t hist[4][256];        // per-wavefront literal histograms, reduced into hist[0]
+            uint32_t sampleHist[2][256];
+            uint32_t scan[ZHIP_ENT_THREADS + 8];
+        };
+        struct {
+            uint32_t hist0_[256];         // = hist[0]
+            HufWork  huf;
+        };
+    };
     uint32_t code[256];           // huff0 code: value << 8 | nbBits
-    uint32_t scan[ZHIP_ENT_THREADS + 8];
-    uint32_t scan2[ZHIP_ENT_THREADS + 8];
     uint32_t seqCount[3][64];     // LL / OF / ML code histograms
     int16_t  norm[3][56];
     FseCTable ct[3];              // LL, OF, ML
@@ -77,19 +88,17 @@ struct EntShared {
     uint32_t maxCode[3];
     uint32_t finalState[3];
     uint8_t  hufHdr[136];
-    HufWork  huf;
     // scalars broadcast through LDS
     uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream, litType /*2 compressed, 3 repeat*/, hufMaxSym /* of a new table */;
     uint32_t streamBits[4], streamBytes[4], streamOff[4];
     uint32_t litSectionSize, seqSectionSize, seqBitsTotal, failRaw;
-    uint32_t sampleHist[2][256];
     CodeTabs tabs;
 };
 
 // The same workspace for the one-wavefront form (NT = 64): one histogram instead of four, no cross-wave scan, no sampling
 // histograms (the sampling heuristic needs 40 KB of literals; units of this form are at most ZHIP_ENT_SMALL_MAX bytes), and the
 // Huffman builder's workspace shares its bytes with the sequence tables — the single wavefront is done with the literals job before
-// it starts the first table.  12.6 KB instead of 25.7 KB: twelve records resident per CU instead of six workgroups.
+// it starts the first table.  12.6 KB: twelve records resident per CU.
 #define ZHIP_ENT_SMALL_MAX 8192u
 struct EntSharedSmall {
     uint32_t hist[1][256];
