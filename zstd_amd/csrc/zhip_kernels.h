@@ -44,22 +44,25 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
-    uint32_t const ui = blockIdx.x;
-    if (ui >= nUnits) return;
-    ZhipUnit const u = units[ui];
-    if (u.strategy != ZHIP_STRAT_DFAST) return;
-    const uint8_t* const p = src + u.srcOff;
-    ZhipSlot const sl = slots[ui];
-    ZhipSeq* const sq = seqs + sl.seqOff;
-    uint8_t* const lt = lits + sl.litOff;
-    uint32_t* const tL = tabs + (size_t)ui * tabStride;
-    uint32_t* const tS = tL + ((size_t)1 << u.hashLog);
-    switch (u.minMatch) {
-    case 5:  parse_dfast_unit<5>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
-    case 6:  parse_dfast_unit<6>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
-    case 7:  parse_dfast_unit<7>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
-    case 8:  parse_dfast_unit<8>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
-    default: parse_dfast_unit<4>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+    // persistent workgroups: workgroup w takes the units w, w + gridDim.x, ... and reuses ONE table pair (tabs + w * tabStride) for
+    // all of them, so the table memory in use is gridDim.x pairs, not nUnits pairs
+    for (uint32_t ui = blockIdx.x; ui < nUnits; ui += gridDim.x) {
+        ZhipUnit const u = units[ui];
+        if (u.strategy != ZHIP_STRAT_DFAST) continue;
+        const uint8_t* const p = src + u.srcOff;
+        ZhipSlot const sl = slots[ui];
+        ZhipSeq* const sq = seqs + sl.seqOff;
+        uint8_t* const lt = lits + sl.litOff;
+        uint32_t* const tL = tabs + (size_t)blockIdx.x * tabStride;
+        uint32_t* const tS = tL + ((size_t)1 << u.hashLog);
+        switch (u.minMatch) {
+        case 5:  parse_dfast_unit<5>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+        case 6:  parse_dfast_unit<6>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+        case 7:  parse_dfast_unit<7>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+        case 8:  parse_dfast_unit<8>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+        default: parse_dfast_unit<4>(p, u.srcLen, u, smem, tL, tS, sq, lt, metas + ui); break;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

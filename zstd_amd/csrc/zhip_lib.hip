@@ -333,8 +333,15 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // one launch per strategy family present; every kernel skips the units of the other families
     if (c->strategy & 2)
-        hipLaunchKernelGGL(zhip::k_parse_dfast, dim3((unsigned)nUnits), dim3(64), zhip::dfast_lds_bytes(), s,
+    {   // experiment knobs: $ZHIP_DF_SLOTS persistent workgroups (each reuses one table pair), $ZHIP_DF_LDS_PAD extra LDS bytes per workgroup (fewer resident)
+        static long const dfSlots = getenv("ZHIP_DF_SLOTS") ? atol(getenv("ZHIP_DF_SLOTS")) : 0;
+        static long const dfPad = getenv("ZHIP_DF_LDS_PAD") ? atol(getenv("ZHIP_DF_LDS_PAD")) : 0;
+        unsigned const grid = (dfSlots > 0 && (size_t)dfSlots < nUnits) ? (unsigned)dfSlots : (unsigned)nUnits;
+        size_t const ldsB = zhip::dfast_lds_bytes() + (dfPad > 0 ? (size_t)dfPad : 0);
+        if (ldsB > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dfast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+        hipLaunchKernelGGL(zhip::k_parse_dfast, dim3(grid), dim3(64), ldsB, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
+    }
     if (c->strategy & 1)
         hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
