@@ -521,6 +521,40 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
             "synchronous_single_stream": {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "path": "zhip_compress: pageable source, blocking H2D / kernels / D2H on one stream"}}
 
 
+def frames_leg(zstd_amd, local, host, level):
+    """inputs of 1 MiB, ONE multi-block frame each (the reference's own output shape), a batch of 256
+    through zhip_compress_frames.  The rate is over the frame kernel's duration (HIP events; the call itself goes through host
+    buffers); parity = SHA-256 of all frames against ZSTD_compress2 of each 1 MiB input by the real reference, full size."""
+    fsz, nf = 1 << 20, min(256, len(host) >> 20)
+    if nf == 0:
+        return None
+    bufs = [host[i * fsz:(i + 1) * fsz] for i in range(nf)]
+    ctx = zstd_amd.Context(local, max_units=nf)
+    best, outs = 1e9, None
+    for _ in range(3):
+        outs = ctx.compress_frames(bufs, level)
+        best = min(best, ctx.timing()["entropy_ms"])
+    ctx.close()
+    res = {"value": round(nf * fsz / best / 1e3, 1), "unit": "MB/s", "frames": nf, "frame_bytes": fsz, "level": level,
+           "kernel_ms": round(best, 3), "ratio": round(nf * fsz / sum(len(o) for o in outs), 4),
+           "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain); fidelity mode, never `value`"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if os.path.exists(exe):
+        tin, tout = f"/tmp/zhip_frames_in_{os.getpid()}.bin", f"/tmp/zhip_frames_out_{os.getpid()}.bin"
+        try:
+            host[: nf * fsz].tofile(tin)
+            info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(fsz), tin, tout, str(os.cpu_count() or 1)], timeout=600))
+            want = hashlib.sha256(open(tout, "rb").read()).hexdigest()
+            got = hashlib.sha256(b"".join(outs)).hexdigest()
+            res["parity"] = {"sha256_equals_reference_frames": bool(got == want and info["csize"] == sum(len(o) for o in outs)),
+                             "reference": f"oracle/_ref/zref_bench cfile = ZSTD_compress2 of every 1 MiB input (one multi-block frame each) on {info['threads']} host threads"}
+        finally:
+            for t in (tin, tout):
+                if os.path.exists(t):
+                    os.unlink(t)
+    return res
+
+
 def stub_main(args, rank, world):
     """ZHIP_BENCH_STUB=1: no GPU, no compression — exercises only the launch / barrier / max-over-ranks / one-line contract of the
     N-rank path with the gloo backend (tests/test_dist_gloo.py); the line says data = "stub" and must never be read as a measurement"""
@@ -610,6 +644,9 @@ def main():
     if default_line and rank == 0:
         # PCIe-inclusive figure of the same workload, then the metric's own data shape: Silesia-shaped mix at level 1
         out["end_to_end"] = end_to_end_leg(torch, zstd_amd, local, host, total, args.level)
+        fr = frames_leg(zstd_amd, local, host, args.level)
+        if fr is not None:
+            out["multi_block_frames"] = fr
     del src, host
     if default_line:
         torch.cuda.empty_cache()
