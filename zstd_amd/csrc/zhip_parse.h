@@ -354,8 +354,9 @@ __device__ __attribute__((noinline)) PostState post_match_far(const uint8_t* src
 // table gather (LDS) and one candidate gather (HBM/L2), and then resolves EVERY event among its lanes in the reference's
 // order with wave-uniform mask arithmetic:
 //   * M   — lanes whose table candidate matches 4 bytes (valid for the lanes whose hash no earlier lane of the window
-//           shares: their candidate cannot depend on what the window itself inserts; the first lane D that does share
-//           one is resolved exactly from its group's first lane a, the window ends before the second such lane);
+//           shares: their candidate cannot depend on what the window itself inserts; a lane that does share one is resolved
+//           exactly from its two closest earlier group members and the insert mask, the window ends before the first lane with
+//           three of them);
 //   * E1/E2 — per repcode offset, which lanes equal the byte (…b) / the 4 bytes (…q) that offset back: ONE coalesced
 //           load per offset.  Repcode probes (:268), the one-byte backward step of a repcode match (:271), forward and
 //           backward extension (:387-391, ZSTD_count) and the immediate-repcode loop (:410-420) are bit scans of these
@@ -434,39 +435,45 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
     unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
 
-    // NF: lanes that share their hash with an earlier lane (exact per group; after 6 groups everything from the first
-    // unresolved flagged lane on counts as sharing — a group's unflagged winner lies above its lowest flagged member)
+    // NF: lanes that share their hash with an earlier lane of the window.  What such a lane finds in the table depends on which of
+    // its group's earlier members have been inserted when it is looked up: the closest inserted one, else the table's old entry.
+    // Every lane keeps its two closest earlier members (p1, p2) and whether their bytes match its own (m1, m2); the event loop
+    // combines them with the insert mask.  The exact prefix Dw ends at the first lane with three or more earlier members (or, after
+    // 6 groups, at the first unresolved flagged lane) — word-salad text has a repeated hash in most windows, and stopping at the
+    // SECOND sharing lane (round-2 start) held its windows to 35 of 60 lanes on average.
     unsigned long long NF = 0;
+    uint32_t Dw = ZHIP_WIN_LANES;
+    uint32_t p1 = 0, p2 = 0, m1 = 0, m2 = 0, depth = 0;
     {   unsigned long long ML = __ballot(backId != lane);
+        unsigned long long myG = 0;
         int it = 0;
         while (ML) {
             uint32_t const j = ff1u(ML);
-            if (it == 6) { NF |= lanes_from(j); break; }
+            if (it == 6) { NF |= lanes_from(j); if (j < Dw) Dw = j; break; }
             uint32_t const hj = __builtin_amdgcn_readlane(h, (int)j);
             unsigned long long const G = __ballot(h == hj);
+            if (h == hj) myG = G;
             NF |= G & (G - 1);
             ML &= ~G; it++;
         }
-    }
-    // D: first sharing lane (resolved exactly below), Dn: the second one = end of the exact prefix
-    uint32_t D = 64, Dw = ZHIP_WIN_LANES, a = 64, MDa = 0;
-    if (NF) {
-        D = ff1u(NF);
-        unsigned long long const NF2 = NF & (NF - 1);
-        uint32_t const Dn = NF2 ? ff1u(NF2) : 64;
-        if (Dn < Dw) Dw = Dn;                                             // >= 2
-        if (D < Dw) {
-            uint32_t const hD = __builtin_amdgcn_readlane(h, (int)D);
-            a = ff1u(__ballot(h == hD));                                  // the group's first lane; == D only after the 6-group cut
-            if (a != D) { MDa = __builtin_amdgcn_readlane(cur32, (int)a) == __builtin_amdgcn_readlane(cur32, (int)D); NF &= ~(1ull << D); }
-            else a = 64;
+        if (NF) {
+            unsigned long long const prev = myG & lanes_below(lane);
+            depth = (uint32_t)__builtin_popcountll(prev);
+            p1 = prev ? 63u - (uint32_t)__clzll((long long)prev) : 0u;
+            unsigned long long const prev2 = prev & ~(1ull << p1);
+            p2 = prev2 ? 63u - (uint32_t)__clzll((long long)prev2) : 0u;
+            uint32_t const c1 = __shfl(cur32, (int)p1), c2 = __shfl(cur32, (int)p2);
+            m1 = (depth >= 1 && c1 == cur32) ? 1u : 0u;
+            m2 = (depth >= 2 && c2 == cur32) ? 1u : 0u;
+            unsigned long long const deep = __ballot(depth >= 3);
+            if (deep) { uint32_t const d3 = ff1u(deep); if (d3 < Dw) Dw = d3; }
         }
     }
     unsigned long long const M = __ballot(old != 0 && old >= prefixLow && cb == cur32) & lanes_below(Dw);
     ZWPROF(out, 1);
 
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
-    // one by one after the others, in position order, and end the window (the pair a/D shares a slot, D stays)
+    // one by one after the others, in position order (a later member of a hash group overwrites an earlier one)
     unsigned long long INS = 0, COV = 0;
     uint32_t evA = 0, evB = 0, nEv = ~0u;                                 // event registers: sequence t of this window in lane t
     uint32_t const nbSeq0 = out.nbSeq;
@@ -482,7 +489,6 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // the window's table writes: the lanes of INS outside NF together, then its NF lanes one by one
 #define ZW_TABLE_FLUSH() do {                                                                                    \
         unsigned long long late_ = INS & NF, CM = INS ^ late_;                                                    \
-        if (a < 64 && ((INS >> a) & (INS >> D) & 1)) CM &= ~(1ull << a);   /* same slot: the later position stays */ \
         if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put(T, h, P);                                            \
         __builtin_amdgcn_wave_barrier();                                                                          \
         while (late_) { if (lane == ff1u(late_)) tab_put(T, h, P); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
@@ -496,14 +502,19 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     for (;;) {
         int Kw = ((int)Dw - (int)i) >> 1;
         if (Kw > kLim) Kw = kLim;
-        if (Kw <= 0 || (INS & NF)) break;                                 // ZW_RESTART
+        if (Kw <= 0) break;                                               // ZW_RESTART
         uint32_t const hiLane = i + 2u * (uint32_t)Kw;                    // searched lanes i .. hiLane-1 (<= 60), probes up to hiLane
         unsigned long long const span = ZHIP_SBFM64(hiLane - i, i);
         unsigned long long Me = M;
-        uint32_t effA = 0;
-        if (a < 64) {
-            effA = (uint32_t)(a >= i) | (uint32_t)((INS >> a) & 1);       // a's insert precedes D's lookup
-            if (effA) Me = (Me & ~(1ull << D)) | ((unsigned long long)MDa << D);
+        uint32_t candSel = old;
+        if (NF) {
+            // a member of a hash group is inserted when the scan from i reaches it before the lane in question (every lane from i on
+            // is, as long as no event intervenes — and the first event is what is being looked for), or when INS already holds it
+            unsigned long long const insE = INS | lanes_from(i);
+            bool const in1 = depth >= 1 && ((insE >> p1) & 1), in2 = depth >= 2 && ((insE >> p2) & 1);
+            bool const hit = in1 ? (m1 != 0) : (in2 ? (m2 != 0) : (old != 0 && old >= prefixLow && cb == cur32));
+            candSel = in1 ? B + p1 : (in2 ? B + p2 : old);
+            Me = __ballot(hit) & lanes_below(Dw);
         }
         unsigned long long const MM = Me & span;
         unsigned long long const RP = E1q & ((i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull) & (span << 2);
@@ -519,8 +530,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         // the repcode probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326)
         uint32_t const isRep = ((jr - i - 2) >> 1) <= ((jm - i) >> 1) ? 1u : 0u;
         uint32_t const j = isRep ? jr : jm;
-        uint32_t c = __builtin_amdgcn_readlane(old, (int)j);
-        if (j == D && effA) c = B + a;
+        uint32_t const c = __builtin_amdgcn_readlane(candSel, (int)j);
         uint32_t const off = isRep ? rep1 : B + j - c;
         // lanes i .. j are inserted (hash0 = ip0); a repcode is found at ip2 = j, i.e. up to j-1 = ip1 (:283); a match
         // also inserts ip1 = j+1 (:296, :323 step <= 4)
