@@ -370,6 +370,9 @@ enum { ZW_CONT = 0, ZW_INC = 1, ZW_RESTART = 2 };
 #ifndef ZHIP_WIN_DENSE_ONLY
 #define ZHIP_WIN_DENSE_ONLY 0       /* 1: a scan leaves window mode after its first event-less window */
 #endif
+#ifndef ZHIP_WIN_GROUPS
+#define ZHIP_WIN_GROUPS 16           /* hash groups of a window resolved exactly; the exact prefix ends at the first lane of the next one */
+#endif
 #define ZHIP_WIN_LANES 60            /* events are taken from lanes below this (their +2/+4 neighbours stay inside the window) */
 
 #ifndef ZHIP_SBFM64                  /* s_bfm_b64: `width` (0..63) lanes from lane `offset` (0..63) on (the emulator brings its own) */
@@ -439,7 +442,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // its group's earlier members have been inserted when it is looked up: the closest inserted one, else the table's old entry.
     // Every lane keeps its two closest earlier members (p1, p2) and whether their bytes match its own (m1, m2); the event loop
     // combines them with the insert mask.  The exact prefix Dw ends at the first lane with three or more earlier members (or, after
-    // 6 groups, at the first unresolved flagged lane) — word-salad text has a repeated hash in most windows, and stopping at the
+    // ZHIP_WIN_GROUPS groups, at the first unresolved flagged lane) — word-salad text has a repeated hash in most windows, and stopping at the
     // SECOND sharing lane (round-2 start) held its windows to 35 of 60 lanes on average.
     unsigned long long NF = 0;
     uint32_t Dw = ZHIP_WIN_LANES;
@@ -449,7 +452,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         int it = 0;
         while (ML) {
             uint32_t const j = ff1u(ML);
-            if (it == 6) { NF |= lanes_from(j); if (j < Dw) Dw = j; break; }
+            if (it == ZHIP_WIN_GROUPS) { NF |= lanes_from(j); if (j < Dw) Dw = j; break; }
             uint32_t const hj = __builtin_amdgcn_readlane(h, (int)j);
             unsigned long long const G = __ballot(h == hj);
             if (h == hj) myG = G;
