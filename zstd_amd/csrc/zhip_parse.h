@@ -441,18 +441,18 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // NF: lanes that share their hash with an earlier lane of the window.  What such a lane finds in the table depends on which of
     // its group's earlier members have been inserted when it is looked up: the closest inserted one, else the table's old entry.
     // Every lane keeps its two closest earlier members (p1, p2) and whether their bytes match its own (m1, m2); the event loop
-    // combines them with the insert mask.  The exact prefix Dw ends at the first lane with three or more earlier members (or, after
-    // ZHIP_WIN_GROUPS groups, at the first unresolved flagged lane) — word-salad text has a repeated hash in most windows, and stopping at the
+    // combines them with the insert mask.  A lane with three or more earlier members (or, after ZHIP_WIN_GROUPS groups, any lane
+    // from the first unresolved flagged one on) cannot be resolved: the scan stops in front of it (DEEP) — word-salad text has a repeated hash in most windows, and stopping at the
     // SECOND sharing lane (round-2 start) held its windows to 35 of 60 lanes on average.
     unsigned long long NF = 0;
-    uint32_t Dw = ZHIP_WIN_LANES;
+    unsigned long long DEEP = lanes_from(ZHIP_WIN_LANES);      // lanes that cannot be searched from this window: >= 60, or beyond what the group data resolves
     uint32_t p1 = 0, p2 = 0, m1 = 0, m2 = 0, depth = 0;
     {   unsigned long long ML = __ballot(backId != lane);
         unsigned long long myG = 0;
         int it = 0;
         while (ML) {
             uint32_t const j = ff1u(ML);
-            if (it == ZHIP_WIN_GROUPS) { NF |= lanes_from(j); if (j < Dw) Dw = j; break; }
+            if (it == ZHIP_WIN_GROUPS) { NF |= lanes_from(j); DEEP |= lanes_from(j); break; }
             uint32_t const hj = __builtin_amdgcn_readlane(h, (int)j);
             unsigned long long const G = __ballot(h == hj);
             if (h == hj) myG = G;
@@ -468,11 +468,10 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             uint32_t const c1 = __shfl(cur32, (int)p1), c2 = __shfl(cur32, (int)p2);
             m1 = (depth >= 1 && c1 == cur32) ? 1u : 0u;
             m2 = (depth >= 2 && c2 == cur32) ? 1u : 0u;
-            unsigned long long const deep = __ballot(depth >= 3);
-            if (deep) { uint32_t const d3 = ff1u(deep); if (d3 < Dw) Dw = d3; }
+            DEEP |= __ballot(depth >= 3);
         }
     }
-    unsigned long long const M = __ballot(old != 0 && old >= prefixLow && cb == cur32) & lanes_below(Dw);
+    unsigned long long const M = __ballot(old != 0 && old >= prefixLow && cb == cur32);
     ZWPROF(out, 1);
 
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
@@ -503,6 +502,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     {   int32_t const d = (int32_t)(nextStep - B) - 4;
         kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
     for (;;) {
+        // a lane with three or more earlier group members only matters if the scan has to look it up: inside a match (a run of equal
+        // bytes is one hash group) it never is, so the bound is taken from the scan position on, every time
+        uint32_t const Dw = ff1u(DEEP & lanes_from(i));                   // DEEP holds lanes 60..63, i < 64 here
         int Kw = ((int)Dw - (int)i) >> 1;
         if (Kw > kLim) Kw = kLim;
         if (Kw <= 0) break;                                               // ZW_RESTART
@@ -517,7 +519,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             bool const in1 = depth >= 1 && ((insE >> p1) & 1), in2 = depth >= 2 && ((insE >> p2) & 1);
             bool const hit = in1 ? (m1 != 0) : (in2 ? (m2 != 0) : (old != 0 && old >= prefixLow && cb == cur32));
             candSel = in1 ? B + p1 : (in2 ? B + p2 : old);
-            Me = __ballot(hit) & lanes_below(Dw);
+            Me = __ballot(hit);
         }
         unsigned long long const MM = Me & span;
         unsigned long long const RP = E1q & ((i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull) & (span << 2);
