@@ -1,27 +1,27 @@
-// zhip_parse.h — gfx950 match finder for strategy ZSTD_fast, one wavefront per 128 KB unit.
+// zhip_parse.h — gfx950 match finder for strategy ZSTD_fast, one wavefront per 128 KB unit (or per block of a frame).
 //
 // WHAT it computes: exactly the sequences the reference's ZSTD_compressBlock_fast_noDict_generic
 // (lib/compress/zstd_fast.c:192-423) emits for a unit with no history (fresh table, rep = {1,4,8}).
 //
 // HOW (CDNA4 design, not a translation).  The reference walks positions one or two at a time because each lookup
-// sees the table writes of the positions before it.  Here one 64-lane wavefront owns the unit and evaluates a
-// *batch* of 32 reference iterations (64 search positions) at once:
-//   * the positions the reference would visit from the current point are a data-independent schedule (pairs
-//     A_k, A_k+1 with a gap that grows every 128 bytes, zstd_fast.c:232-347); lane 2k+b takes A_k+b, even lanes also
-//     carry the repcode probe of iteration k (at A_{k+1});
-//   * every lane hashes its position and gathers the table entry from LDS.  The table is wave-private LDS:
-//     16-bit entries + a 1-bit plane for bit 16 of the position = 17 KB for hashLog 13, so NINE units are resident
-//     per CU (LDS is allocated in 1280-byte granules on gfx950: 9 x 14 granules);
-//   * lanes of one batch that hash alike must see each other's inserts in lane order.  A 512-byte LDS scratch
-//     (write lane id / read back) finds the colliding lanes, ballots turn them into exact per-hash lane groups, and
-//     each lane takes the position of its closest earlier group member as its candidate — so ONE pass is exact;
-//   * ballots give the first event in the reference's own order (repcode at ip2, match at ip0, match at ip1);
-//     the lanes the reference would have inserted before that event write the table (last lane of a group only);
-//   * the unit is latency-bound (dependent global loads), so the code is organised around global round trips:
-//     per batch ONE (candidate bytes; the next batch's source bytes are loaded speculatively in its shadow), per
-//     match TWO: forward+backward extension in one wave-wide compare (48 x 8 B forward, 16 x 8 B backward), then one
-//     round that fetches the bytes for the two complementary inserts, the immediate-repcode probe+count and the
-//     next batch.
+// sees the table writes of the positions before it.  Here one 64-lane wavefront owns the unit; the table is wave-private LDS
+// (16-bit entries + a 1-bit plane for bit 16 of the position = 17 KB for hashLog 13, so NINE units are resident per CU: LDS
+// is allocated in 1280-byte granules on gfx950, 9 x 14 granules).  Two scan shapes share it:
+//   * the dense-scan WINDOW (window_batch, below): while the gap between searched pairs is 2 every position is searched, so
+//     lane l takes position B+l and ONE table gather + ONE candidate gather resolve every event among 60 positions — matches,
+//     repcodes, extensions, the immediate-repcode loop, inserts and literal stores — with mask arithmetic.  This is where
+//     dense-match data spends its time;
+//   * the schedule-shaped batch (parse_fast_block's second path, the round-1 design): for the stretches where the gap has
+//     grown (long literal runs), lane 2k+b takes the k-th pair of the reference's data-independent schedule (pairs A_k, A_k+1
+//     with a gap that grows every 128 bytes, zstd_fast.c:232-347), ballots give the first event in the reference's own order
+//     (repcode at ip2, match at ip0, match at ip1), extension in one wave-wide compare (48 x 8 B forward, 16 x 8 B backward),
+//     then one round that fetches the bytes of the two complementary inserts, the immediate-repcode probe + count and the next
+//     batch;
+//   * in both, lanes that hash alike must see each other's inserts in lane order: the slot itself is the detector (every lane
+//     leaves its lane id in its slot and reads it back), ballots turn the flagged lanes into exact per-hash groups.
+// The parser is written against a table policy (tab_get / tab_put / tab_mark / tab_peek / tab_unmark) and takes a block range,
+// the lowest valid match position and the incoming repcodes, so the same code parses the blocks of a multi-block frame on a
+// table of 32-bit positions (zhip_frame.h).
 // All control flow is wave-uniform (derived from ballots); LDS traffic is wave-private, so no s_barrier is needed.
 #pragma once
 #include <hip/hip_runtime.h>
