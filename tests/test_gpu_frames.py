@@ -155,3 +155,30 @@ def test_frames_fuzz_against_oracle(env):
             if cp[6] not in (1, 2):
                 continue
             assert out == oracle_frame(lo, a, level), (i, len(a), level)
+
+
+def test_frames_with_explicit_parameters(env):
+    """explicit windowLog / hashLog on a multi-block frame: a window smaller than the input (matches beyond it are refused, the
+    frame header carries a window descriptor), a table above the LDS bound (hashLog 15 -> HBM), a wider hash — against the
+    oracle's frame loop run with the same effective parameters (and the reference itself where oracle/_ref travelled)"""
+    z, lo = env
+    L = z.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    lo.zo_compress_frame_params.restype = C.c_size_t
+    lo.zo_compress_frame_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_frame_bound.restype = C.c_size_t
+    lo.zo_frame_bound.argtypes = [C.c_size_t]
+    ctx = z.Context(max_units=8)
+    a = datagen(lo, 900_000, 70, 33).copy()
+    a[600_000:700_000] = a[100_000:200_000]                    # a repeat 500 000 bytes back: inside a 2^19 window, outside a 2^17 one
+    for level, cp in ((1, [17, 0, 0, 0, 0, 0, 0]), (1, [18, 0, 15, 0, 4, 0, 0]), (3, [17, 15, 16, 0, 0, 0, 0]), (1, [0, 0, 13, 0, 6, 2, 0])):
+        eff = (C.c_uint * 7)()
+        req = (C.c_uint * 7)(*cp)
+        assert L.zhip_getCParams_explicit(level, a.size, req, eff) == 0
+        out = ctx.compress_frames([a], level, cparams=cp)[0]
+        cap = lo.zo_frame_bound(a.size)
+        want = np.zeros(cap, dtype=np.uint8)
+        r = lo.zo_compress_frame_params(_buf(want), cap, _buf(a), a.size, eff)
+        assert r != ERR and out == want[:r].tobytes(), (level, cp, list(eff))
+        assert z.DContext().decompress(out) == a.tobytes()

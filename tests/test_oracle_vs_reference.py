@@ -210,3 +210,37 @@ def test_multiblock_frame_vs_reference(libs):
             want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
             k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
             assert k != ERR and oracle_frame(lo, a, level) == want[:k].tobytes(), (trial, kind, n, level)
+
+
+def test_multiblock_frame_with_explicit_parameters_vs_reference(libs):
+    """the frame loop with explicit parameters (a window smaller than the input, other table sizes / hash widths, dfast) against
+    ZSTD_compress2 of the whole input on a CCtx with the same parameters set"""
+    lo, lr = libs
+    lr.zref_compress_chunks_level_params.restype = C.c_size_t
+    lr.zref_compress_chunks_level_params.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    import zstd_amd                                            # the product's host-side parameter logic (no GPU needed)
+    L = zstd_amd.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    lo.zo_compress_frame_params.restype = C.c_size_t
+    lo.zo_compress_frame_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_frame_bound.restype = C.c_size_t
+    lo.zo_frame_bound.argtypes = [C.c_size_t]
+    a = datagen(lo, 900_000, 70, 33).copy()
+    a[600_000:700_000] = a[100_000:200_000]
+    b = text_like(500_000, 8)
+    for src in (a, b):
+        n = src.size
+        for level, cp in ((1, [17, 0, 0, 0, 0, 0, 0]), (1, [18, 0, 15, 0, 4, 0, 0]), (3, [17, 15, 16, 0, 0, 0, 0]), (1, [0, 0, 13, 0, 6, 2, 0]), (2, [0, 0, 0, 0, 0, 0, 0])):
+            eff = (C.c_uint * 7)()
+            req = (C.c_uint * 7)(*cp)
+            assert L.zhip_getCParams_explicit(level, n, req, eff) == 0
+            if eff[6] not in (1, 2):
+                continue
+            cap = lo.zo_frame_bound(n)
+            got = np.zeros(cap, dtype=np.uint8)
+            r = lo.zo_compress_frame_params(_buf(got), cap, _buf(src), n, eff)
+            want = np.zeros(cap + 1024, dtype=np.uint8)
+            cpi = (C.c_int * 7)(*cp)
+            k = lr.zref_compress_chunks_level_params(level, cpi, 0, n, _buf(src), n, _buf(want), len(want))
+            assert r != ERR and k != ERR and got[:r].tobytes() == want[:k].tobytes(), (level, cp, list(eff))
