@@ -87,6 +87,19 @@ size_t       zhip_compress_frames(zhip_ctx* ctx, void* dst, size_t dstCapacity, 
 size_t       zhip_compress_frames_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* srcOffsets,
                                          size_t nFrames, int level, const unsigned cparams[7], uint32_t* frameSizesDev, void* stream);
 
+/* ---- the same inputs as the frames ZSTD_compress2 emits with ZSTD_c_nbWorkers >= 1 (lib/compress/zstdmt_compress.c; the bytes do not
+ * depend on the worker count): an input above 512 KB is cut into jobs of jobSize (0 = the reference's default 1 << max(20, windowLog+2);
+ * ZSTD_c_jobSize semantics: clamped to 512 KB .. 1 GiB, raised to the overlap), each job compressed with the last
+ * 1 << (windowLog - (9 - overlapLog)) bytes of its predecessor as prefix (overlapLog 0 = the strategy's default, 6 for fast/dfast;
+ * ZSTD_c_overlapLog 1..9) and its own tables; the concatenation is one standard frame.  Jobs are independent, so ONE large input
+ * fills the GPU: a workgroup per job.  Inputs of at most 512 KB come out as the plain frame above, as in the reference.  The context
+ * needs maxUnits >= the total number of jobs.  Same strategies and limits as zhip_compress_frames. */
+size_t       zhip_compress_frames_mt(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
+                                     size_t nFrames, int level, const unsigned cparams[7] /* or NULL */, size_t jobSize, int overlapLog, size_t* frameSizes);
+size_t       zhip_compress_frames_mt_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* srcOffsets,
+                                            size_t nFrames, int level, const unsigned cparams[7], size_t jobSize, int overlapLog,
+                                            uint32_t* frameSizesDev, void* stream);
+
 /* ---- host buffers over SEVERAL devices in one process: independent units shard across the GPUs of a node, one
  * HIP stream + pinned staging per lane ($ZHIP_MULTI_LANES lanes per device, default 4: some lanes' copies overlap another's kernels), no collective;
  * finished chunks are gathered on the host in source order (destination offset = exclusive prefix sum of the sizes before).

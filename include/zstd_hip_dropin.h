@@ -32,6 +32,11 @@
  *                       (zstd_compress.c:4520-4640; zhip_compress_frames).  The block chain of one frame is serial — one
  *                       workgroup — so this is the fidelity mode, not the throughput mode; other strategies keep the
  *                       frame-per-unit stream.
+ *                       With ZSTD_c_nbWorkers >= 1 (and ZSTD_c_jobSize / ZSTD_c_overlapLog) and a source above 512 KB the output is
+ *                       the reference's multi-threaded frame, byte for byte (lib/compress/zstdmt_compress.c: jobs of the job size,
+ *                       each with the overlap as prefix; the bytes do not depend on the worker count) — jobs are independent, a
+ *                       workgroup each, so this mode is both the reference's bytes and parallel inside one frame
+ *                       (zhip_compress_frames_mt).  Same strategies as ZHIP_c_singleFrame; others keep the frame-per-unit stream.
  */
 #ifndef ZSTD_HIP_DROPIN_H
 #define ZSTD_HIP_DROPIN_H
@@ -46,7 +51,7 @@ typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_rese
 /* ZSTD_cParameter values this shim understands (lib/zstd.h:331-507); all others -> parameter_unsupported */
 enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
        ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
-       ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400,
+       ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400, ZSTD_c_jobSize = 401, ZSTD_c_overlapLog = 402,
        ZSTD_c_useRowMatchFinder = 1011 /* = ZSTD_c_experimentalParam14: 0 auto, 1 enable, 2 disable */,
        ZHIP_c_singleFrame = 100001 /* not a reference parameter: 1 = sources above 128 KB as one multi-block frame (see above) */ };
 

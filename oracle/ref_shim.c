@@ -225,6 +225,27 @@ size_t zref_compress_frame(int level, const void* src, size_t n, void* dst, size
     return ZSTD_isError(r) ? (size_t)-1 : r;
 }
 
+/* ZSTD_compress2 with ZSTD_c_nbWorkers = 1 (zstdmt_compress.c): the input is cut into jobs of jobSize bytes (0 = the default,
+ * 1 << max(20, windowLog + 2)), every job after the first starts from a fresh context that has only loaded the last `overlap`
+ * bytes of the previous job as a prefix; the jobs' blocks are emitted back to back inside ONE frame.  overlapLog 0 = default. */
+size_t zref_compress_frame_mt(int level, const int cp[7], unsigned long long jobSize, int overlapLog, int checksumFlag,
+                              const void* src, size_t n, void* dst, size_t dstCap)
+{
+    static const ZSTD_cParameter ids[7] = { ZSTD_c_windowLog, ZSTD_c_chainLog, ZSTD_c_hashLog, ZSTD_c_searchLog, ZSTD_c_minMatch, ZSTD_c_targetLength, ZSTD_c_strategy };
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r; int i;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    if (cp) for (i = 0; i < 7; i++) if (cp[i]) ZSTD_CCtx_setParameter(c, ids[i], cp[i]);
+    if (ZSTD_isError(ZSTD_CCtx_setParameter(c, ZSTD_c_nbWorkers, 1))) { ZSTD_freeCCtx(c); return (size_t)-1; }
+    if (jobSize) ZSTD_CCtx_setParameter(c, ZSTD_c_jobSize, (int)jobSize);
+    if (overlapLog) ZSTD_CCtx_setParameter(c, ZSTD_c_overlapLog, overlapLog);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, checksumFlag);
+    r = ZSTD_compress2(c, dst, dstCap, src, n);
+    ZSTD_freeCCtx(c);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
 /* one frame with chosen frame parameters: contentSizeFlag (0 = the header does not state the size, what streaming without a
  * pledged size emits), checksumFlag, windowLog (0 = level default) — for the decoder tests */
 size_t zref_compress_frame_params(int level, int contentSizeFlag, int checksumFlag, int windowLog, const void* src, size_t n, void* dst, size_t dstCap)

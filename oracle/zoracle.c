@@ -2255,6 +2255,10 @@ size_t zo_frame_add_checksum(void* framev, size_t frameSize, const void* src, si
  * 92 KB split (:4494-4518), blocks sharing window, hash table, repcodes and the previous Huffman table
  * (ZSTD_blockState_confirmRepcodesAndEntropyTables :3549, only after a block that was emitted compressed :4379-4381).
  * Strategy ZSTD_fast (zstd_fast.c:192-423 with a prefix): positions are relative to the frame start; T[] holds pos+1. */
+/* lowest position of the window the block's context has seen: 0 for a frame compressed in one piece, the start of the overlap
+ * prefix for a job of the multi-threaded frame (zstdmt_compress.c) */
+static size_t g_zo_win_start = 0;
+
 static size_t zo_fast_block(const zo_cparams* cp, const uint8_t* src /* frame start */, size_t bStart, size_t bLen, uint32_t* T,
                             zo_store* st, uint32_t rep[3])
 {
@@ -2262,7 +2266,8 @@ static size_t zo_fast_block(const zo_cparams* cp, const uint8_t* src /* frame st
     size_t const stepSize = cp->targetLength + !cp->targetLength + 1;
     size_t const maxDist = (size_t)1 << cp->windowLog;
     size_t const iend = bStart + bLen, ilimit = iend - 8;
-    size_t const dictLimit = bStart > maxDist ? bStart - maxDist : 0;            /* ZSTD_window_enforceMaxDist (:1107) from the block START */
+    size_t const dl0 = bStart > maxDist ? bStart - maxDist : 0;                  /* ZSTD_window_enforceMaxDist (:1107) from the block START */
+    size_t const dictLimit = dl0 > g_zo_win_start ? dl0 : g_zo_win_start;
     size_t const prefixLow = (iend - dictLimit > maxDist) ? iend - maxDist : dictLimit;   /* ZSTD_getLowestPrefixIndex(endIndex) :1206 */
     size_t anchor = bStart, ip0 = bStart, ip1, ip2, ip3, cur0 = 0, step, nextStep, match0 = 0, mLength;
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, offBase;
@@ -2359,7 +2364,8 @@ static size_t zo_dfast_block(const zo_cparams* cp, const uint8_t* src /* frame s
     unsigned const hL = cp->hashLog, hS = cp->chainLog, mls = cp->minMatch;
     size_t const maxDist = (size_t)1 << cp->windowLog;
     size_t const iend = bStart + bLen, ilimit = iend - 8;
-    size_t const dictLimit = bStart > maxDist ? bStart - maxDist : 0;
+    size_t const dl0 = bStart > maxDist ? bStart - maxDist : 0;
+    size_t const dictLimit = dl0 > g_zo_win_start ? dl0 : g_zo_win_start;
     size_t const prefixLow = (iend - dictLimit > maxDist) ? iend - maxDist : dictLimit;
     size_t anchor = bStart, ip = bStart, ip1, step, nextStep, curr = 0, mLength = 0;
     uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0, offset = 0;
@@ -2447,64 +2453,176 @@ static size_t zo_dfast_block(const zo_cparams* cp, const uint8_t* src /* frame s
 
 size_t zo_frame_bound(size_t n) { return n + (n >> 8) + 64 + 3 * (n / 8192 + 2); }
 
+/* the state one compression context carries from block to block (ZSTD_CCtx: match state + blockState.prevCBlock) */
+typedef struct {
+    uint32_t* T;              /* fast: one table; dfast: long table followed by the short table */
+    zo_prev prev;             /* previous block's Huffman table */
+    uint32_t rep[3];
+    int isFirst;              /* zc->isFirstBlock */
+    long long savings;        /* consumedSrcSize - producedCSize of the context (zstd_compress.c:4538): what frame chunks inherit from one another */
+    zo_seq* seqs; uint8_t* lits; uint8_t* body;
+} zo_fctx;
+
+/* ZSTD_compress_frameChunk (zstd_compress.c:4527-4623) over src[pos, pos + len): `savings` starts from the context's running total; lastChunk = the
+ * call that ends the frame (its final block carries the last-block bit).  Returns the bytes written at op, ZO_ERROR on failure. */
+static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* src, size_t pos, size_t len, int lastChunk, uint8_t* op0)
+{
+    uint8_t* op = op0;
+    size_t const end = pos + len;
+    long long savings = f->savings;
+    while (pos < end) {
+        size_t const remaining = end - pos;
+        size_t bLen = remaining < ZO_BLOCK_MAX ? remaining : ZO_BLOCK_MAX;       /* :4494-4518 ZSTD_optimalBlockSize, strategies below lazy2 */
+        size_t cSize = 0; int last;
+        if (remaining >= ZO_BLOCK_MAX && savings >= 3) bLen = 92 * 1024;
+        last = lastChunk && bLen == remaining;
+        if (bLen >= 7) {                                                         /* :3216 */
+            zo_store st; uint32_t nrep[3] = { f->rep[0], f->rep[1], f->rep[2] };
+            size_t lastLits; zo_prev next;
+            st.seqs = f->seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = f->lits; st.litSize = 0; st.overflow = 0;
+            lastLits = cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
+                                         : zo_fast_block(cp, src, pos, bLen, f->T, &st, nrep);
+            memcpy(f->lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
+            next = f->prev;
+            {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);
+                size_t l, sq;
+                g_huf_next = &next;
+                l = zo_compress_literals_prev(f->body, ZO_BLOCK_MAX + 1024, f->lits, st.litSize, cp, suspect, &f->prev);
+                g_huf_next = NULL;
+                if (l >= 1 && (f->body[0] & 3) < 2) next = f->prev;              /* raw / RLE literals: the previous table stays (literals.c:186, :199) */
+                sq = zo_compress_sequences(f->body + l, ZO_BLOCK_MAX + 1024 - l, f->seqs, st.nb, cp);
+                if (sq == ZO_ERROR || st.overflow) return ZO_ERROR;
+                cSize = (sq == 0) ? 0 : l + sq;
+                if (cSize >= bLen - ((bLen >> 6) + 2)) cSize = 0;                /* :3026 */
+            }
+            if (!f->isFirst && cSize < 25) {                                     /* :4365-4376 an RLE block, never the context's first */
+                size_t i; int same = 1;
+                for (i = 1; i < bLen; i++) if (src[pos + i] != src[pos]) { same = 0; break; }
+                if (same) { cSize = 1; f->body[0] = src[pos]; }
+            }
+            if (cSize > 1) { f->rep[0] = nrep[0]; f->rep[1] = nrep[1]; f->rep[2] = nrep[2]; f->prev = next; }   /* :4379-4381 */
+        }
+        if (cSize == 0) { wr24(op, (uint32_t)(last + (0 << 1) + (bLen << 3))); memcpy(op + 3, src + pos, bLen); cSize = 3 + bLen; }
+        else if (cSize == 1) { wr24(op, (uint32_t)(last + (1 << 1) + (bLen << 3))); op[3] = f->body[0]; cSize = 4; }
+        else { wr24(op, (uint32_t)(last + (2 << 1) + (cSize << 3))); memcpy(op + 3, f->body, cSize); cSize += 3; }
+        op += cSize;
+        savings += (long long)bLen - (long long)cSize;
+        pos += bLen; f->isFirst = 0;
+    }
+    f->savings = savings;
+    return (size_t)(op - op0);
+}
+
+static int zo_fctx_init(zo_fctx* f, const zo_cparams* cp)
+{
+    memset(f, 0, sizeof(*f));
+    f->T = (uint32_t*)calloc(((size_t)1 << cp->hashLog) + (cp->strategy == 2 ? (size_t)1 << cp->chainLog : 0), sizeof(uint32_t));   /* dfast: long table, then short table */
+    f->seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 2));
+    f->lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 8);
+    f->body = (uint8_t*)malloc(ZO_BLOCK_MAX + 1024);
+    f->isFirst = 1;
+    return f->T && f->seqs && f->lits && f->body;
+}
+static void zo_fctx_free(zo_fctx* f) { free(f->T); free(f->seqs); free(f->lits); free(f->body); }
+
 size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
 {
     uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
     uint8_t* op = dst;
-    size_t pos = 0; long long savings = 0; int isFirst = 1;
-    uint32_t rep[3] = {1, 4, 8};
-    uint32_t* T; zo_seq* seqs; uint8_t* lits; uint8_t* body;
-    zo_prev prev, next;
+    zo_fctx f; size_t r;
     if ((cp->strategy != 1 && cp->strategy != 2) || cap < zo_frame_bound(n)) return ZO_ERROR;
     op += write_frame_header(op, cp, n);
     if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
-    T = (uint32_t*)calloc(((size_t)1 << cp->hashLog) + (cp->strategy == 2 ? (size_t)1 << cp->chainLog : 0), sizeof(uint32_t));   /* dfast: long table, then short table */
-    seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 2));
-    lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 8);
-    body = (uint8_t*)malloc(ZO_BLOCK_MAX + 1024);
-    memset(&prev, 0, sizeof(prev));
-    while (pos < n) {
-        size_t const remaining = n - pos;
-        size_t bLen = remaining < ZO_BLOCK_MAX ? remaining : ZO_BLOCK_MAX;       /* :4494-4518 ZSTD_optimalBlockSize, strategies below lazy2 */
-        size_t cSize = 0; int last;
-        if (remaining >= ZO_BLOCK_MAX && savings >= 3) bLen = 92 * 1024;
-        last = bLen == remaining;
-        if (bLen >= 7) {                                                         /* :3216 */
-            zo_store st; uint32_t nrep[3] = { rep[0], rep[1], rep[2] };
-            size_t lastLits;
-            st.seqs = seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
-            lastLits = cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, T, T + ((size_t)1 << cp->hashLog), &st, nrep)
-                                         : zo_fast_block(cp, src, pos, bLen, T, &st, nrep);
-            memcpy(lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
-            next = prev;
-            {   int const suspect = (st.nb == 0) || (st.litSize / st.nb >= 20);
-                size_t l, sq;
-                g_huf_next = &next;
-                l = zo_compress_literals_prev(body, ZO_BLOCK_MAX + 1024, lits, st.litSize, cp, suspect, &prev);
-                g_huf_next = NULL;
-                if (l >= 1 && (body[0] & 3) < 2) next = prev;                    /* raw / RLE literals: the previous table stays (literals.c:186, :199) */
-                sq = zo_compress_sequences(body + l, ZO_BLOCK_MAX + 1024 - l, seqs, st.nb, cp);
-                if (sq == ZO_ERROR || st.overflow) { free(T); free(seqs); free(lits); free(body); return ZO_ERROR; }
-                cSize = (sq == 0) ? 0 : l + sq;
-                if (cSize >= bLen - ((bLen >> 6) + 2)) cSize = 0;                /* :3026 */
-            }
-            if (!isFirst && cSize < 25) {                                        /* :4365-4376 an RLE block, never the first */
-                size_t i; int same = 1;
-                for (i = 1; i < bLen; i++) if (src[pos + i] != src[pos]) { same = 0; break; }
-                if (same) { cSize = 1; body[0] = src[pos]; }
-            }
-            if (cSize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2]; prev = next; }   /* :4379-4381 */
-        }
-        if (cSize == 0) { wr24(op, (uint32_t)(last + (0 << 1) + (bLen << 3))); memcpy(op + 3, src + pos, bLen); cSize = 3 + bLen; }
-        else if (cSize == 1) { wr24(op, (uint32_t)(last + (1 << 1) + (bLen << 3))); op[3] = body[0]; cSize = 4; }
-        else { wr24(op, (uint32_t)(last + (2 << 1) + (cSize << 3))); memcpy(op + 3, body, cSize); cSize += 3; }
-        op += cSize;
-        savings += (long long)bLen - (long long)cSize;
-        pos += bLen; isFirst = 0;
+    if (!zo_fctx_init(&f, cp)) { zo_fctx_free(&f); return ZO_ERROR; }
+    f.rep[0] = 1; f.rep[1] = 4; f.rep[2] = 8;
+    g_zo_win_start = 0;
+    r = zo_frame_chunk(&f, cp, src, 0, n, 1, op);                                /* ZSTD_compressEnd: the whole input is one chunk */
+    zo_fctx_free(&f);
+    return r == ZO_ERROR ? ZO_ERROR : (size_t)(op - dst) + r;
+}
+
+/* ---- ZSTD_c_nbWorkers >= 1: one frame cut into jobs (zstdmt_compress.c).  Job k > 0 starts from a FRESH context that has loaded
+ * the last `overlap` bytes of job k-1 as a raw-content prefix with ZSTD_dtlm_fast (every third position of the prefix goes into the
+ * table(s), zstd_fast.c:50-86 / zstd_double_fast.c:56-90), with invalid repcodes {0,0,0} (:741) and no previous entropy tables; it
+ * compresses its section in chunks of 512 KB, each one ZSTD_compressContinue call (:753-776; the block-split rule's `savings` is the
+ * context's consumed - produced, header bytes included); the last job ends
+ * the frame.  Inputs of at most 512 KB are compressed single-threaded (zstd_compress.c:6262). */
+static void zo_fill_prefix(const zo_cparams* cp, const uint8_t* src, size_t p0, size_t p1, uint32_t* T)
+{
+    size_t ip;
+    if (p1 - p0 <= 8) return;                                                    /* zstd_compress.c:4902 */
+    {   size_t const maxDict = (size_t)8 << ((cp->hashLog > cp->chainLog ? cp->hashLog : cp->chainLog) < 28 ? (cp->hashLog > cp->chainLog ? cp->hashLog : cp->chainLog) : 28);
+        if (p1 - p0 > maxDict) p0 = p1 - maxDict; }                              /* :4889-4896 */
+    for (ip = p0; ip + 3 < (p1 - 8) + 2; ip += 3) {
+        if (cp->strategy == 2) {
+            T[((size_t)1 << cp->hashLog) + zo_hash(src + ip, cp->chainLog, cp->minMatch)] = (uint32_t)ip + 1;     /* small table */
+            T[zo_hash(src + ip, cp->hashLog, 8)] = (uint32_t)ip + 1;                                                /* long table */
+        } else T[zo_hash(src + ip, cp->hashLog, cp->minMatch)] = (uint32_t)ip + 1;
     }
-    free(T); free(seqs); free(lits); free(body);
+}
+
+size_t zo_mt_job_size(const zo_cparams* cp, unsigned long long jobSize)
+{
+    unsigned long long sec = jobSize;
+    if (sec != 0 && sec < (512u << 10)) sec = 512u << 10;                        /* ZSTDMT_JOBSIZE_MIN */
+    if (sec > (1024ull << 20)) sec = 1024ull << 20;                              /* ZSTDMT_JOBSIZE_MAX (64-bit) */
+    if (sec == 0) { unsigned jl = cp->windowLog + 2; if (jl < 20) jl = 20; if (jl > 30) jl = 30; sec = 1ull << jl; }   /* :1168-1180 */
+    return (size_t)sec;
+}
+size_t zo_mt_overlap_size(const zo_cparams* cp, int overlapLog)
+{
+    int const dflt = cp->strategy == 9 ? 9 : (cp->strategy >= 7 ? 8 : (cp->strategy >= 5 ? 7 : 6));   /* ZSTDMT_overlapLog_default (:1182-1203) */
+    int const ov = overlapLog ? overlapLog : dflt;
+    int const rlog = 9 - ov;
+    int const ovLog = rlog >= 8 ? 0 : (int)cp->windowLog - rlog;
+    return ovLog <= 0 ? 0 : (size_t)1 << ovLog;
+}
+
+size_t zo_compress_frame_mt_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp,
+                                   unsigned long long jobSize, int overlapLog, int checksumFlag)
+{
+    uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
+    uint8_t* op = dst;
+    size_t pos = 0, prevLen = 0, section, overlap;
+    unsigned k = 0;
+    if ((cp->strategy != 1 && cp->strategy != 2) || cap < zo_frame_bound(n) + 4) return ZO_ERROR;
+    if (n <= (512u << 10)) {                                                     /* single-threaded below ZSTDMT_JOBSIZE_MIN */
+        size_t r = zo_compress_frame_params(dst, cap, src, n, cp);
+        if (r == ZO_ERROR) return r;
+        if (checksumFlag) { dst[4] |= 4; wr32(dst + r, (uint32_t)zo_xxh64(src, n, 0)); r += 4; }
+        return r;
+    }
+    section = zo_mt_job_size(cp, jobSize); overlap = zo_mt_overlap_size(cp, overlapLog);
+    if (section < overlap) section = overlap;                                    /* :1300 */
+    op += write_frame_header(op, cp, n);
+    if (checksumFlag) dst[4] |= 4;
+    while (pos < n) {
+        size_t const jLen = n - pos < section ? n - pos : section;
+        int const lastJob = pos + jLen == n;
+        size_t const preLen = k == 0 ? 0 : (prevLen < overlap ? prevLen : overlap);   /* :1404-1407 */
+        zo_fctx f; size_t c0;
+        if (!zo_fctx_init(&f, cp)) { zo_fctx_free(&f); return ZO_ERROR; }
+        if (k == 0) { f.rep[0] = 1; f.rep[1] = 4; f.rep[2] = 8; g_zo_win_start = 0; }
+        else {
+            uint8_t hdr[18];
+            f.rep[0] = f.rep[1] = f.rep[2] = 0; g_zo_win_start = pos - preLen; zo_fill_prefix(cp, src, pos - preLen, pos, f.T);
+            f.savings = -(long long)write_frame_header(hdr, cp, jLen);           /* the job's own (discarded) frame header counts as produced (:737-741, :4767) */
+        }
+        for (c0 = 0; c0 < jLen; c0 += (512u << 10)) {
+            size_t const cLen = jLen - c0 < (512u << 10) ? jLen - c0 : (512u << 10);
+            size_t const r = zo_frame_chunk(&f, cp, src, pos + c0, cLen, lastJob && c0 + cLen == jLen, op);
+            if (r == ZO_ERROR) { zo_fctx_free(&f); g_zo_win_start = 0; return ZO_ERROR; }
+            op += r;
+            if (k == 0 && c0 == 0) f.savings -= (long long)(op - r - dst);       /* the first job wrote the real header in its first call */
+        }
+        zo_fctx_free(&f);
+        prevLen = jLen; pos += jLen; k++;
+    }
+    g_zo_win_start = 0;
+    if (checksumFlag) { wr32(op, (uint32_t)zo_xxh64(src, n, 0)); op += 4; }
     return (size_t)(op - dst);
 }
+
 size_t zo_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level)
 {
     zo_cparams cp;

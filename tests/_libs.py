@@ -301,9 +301,9 @@ def emu_compress_frames(le, lo, bufs, level, checksum=False):
     chk = None
     if checksum:
         chk = np.zeros(nf + 16, dtype=np.uint32)
-        le.emu_xxh64.restype = None
-        le.emu_xxh64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
-        le.emu_xxh64(_buf(src), _buf(frames), nf, _buf(chk), 0)
+        le.emu_xxh64_wave.restype = None
+        le.emu_xxh64_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64_wave(_buf(src), _buf(frames), nf, _buf(chk), 0)
     le.emu_frame_fast.restype = None
     le.emu_frame_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
     le.emu_frame_fast(_buf(src), _buf(frames), nf, _buf(out), ostride, _buf(osz), _buf(chk) if checksum else None, 0)
@@ -326,3 +326,97 @@ def frame_cases(lo):
     b = datagen(lo, 262144 + 50, 50, 8).copy(); b[131072:262144] = b[:131072]      # a block that is one long match into the previous one
     yield "repeat_block", b
     yield "tail_6", datagen(lo, 131072 + 6, 50, 9)                    # last block below the 7-byte minimum
+
+
+JOB_DT = np.dtype([("start", "<u4"), ("prefixLen", "<u4"), ("flags", "<u4"), ("ownHeader", "<u4"), ("frameSize", "<u8"), ("frameIdx", "<u4"), ("pad0", "<u4")])
+
+
+def frame_header_bytes(n, window_log):
+    single = (1 << window_log) >= n
+    fcs = (n >= 256) + (n >= 65536 + 256)
+    return 4 + 1 + (0 if single else 1) + ((1 if single else 0) if fcs == 0 else (2 if fcs == 1 else 4))
+
+
+def make_jobs(lo, n, level, job_size=0, overlap_log=0):
+    """the job table of one frame compressed with ZSTD_c_nbWorkers >= 1 (zstdmt_compress.c: sections of the job size, each later one
+    with the overlap as prefix) -> (units, jobs); n must exceed 512 KB (below that the reference does not use jobs)"""
+    cp = (C.c_uint * 7)()
+    assert lo.zo_get_cparams(level, n, cp) == 0
+    lo.zo_mt_job_size.restype = C.c_size_t; lo.zo_mt_job_size.argtypes = [C.c_void_p, C.c_ulonglong]
+    lo.zo_mt_overlap_size.restype = C.c_size_t; lo.zo_mt_overlap_size.argtypes = [C.c_void_p, C.c_int]
+    sec, ov = lo.zo_mt_job_size(cp, job_size), lo.zo_mt_overlap_size(cp, overlap_log)
+    sec = max(sec, ov)
+    starts = list(range(0, n, sec))
+    units = np.zeros(len(starts), dtype=UNIT_DT); jobs = np.zeros(len(starts), dtype=JOB_DT)
+    prev = 0
+    for k, s in enumerate(starts):
+        ln = min(sec, n - s)
+        units[k] = (0, ln, cp[0], cp[1], cp[2], cp[4], cp[6], cp[3], 1 if (cp[6] == 1 and cp[5] > 0) else 0, 0, cp[5], 0, 0)
+        pre = 0 if k == 0 else min(prev, ov)
+        jobs[k] = (s, pre, (1 if k == 0 else 0) | (2 if s + ln == n else 0), frame_header_bytes(ln, cp[0]), n, 0, 0)
+        prev = ln
+    return units, jobs, cp
+
+
+def emu_compress_frame_jobs(le, lo, a, level, job_size=0, overlap_log=0, checksum=False):
+    """one frame as parallel jobs on the emulator; returns the frame bytes"""
+    n = len(a)
+    units, jobs, cp = make_jobs(lo, n, level, job_size, overlap_log)
+    assert le.emu_sizeof_job() == JOB_DT.itemsize
+    src = np.concatenate([a, np.zeros(16, dtype=np.uint8)])
+    nj = len(units)
+    ostride = (int(units["srcLen"].max()) + (int(units["srcLen"].max()) >> 8) + 2048 + 15) & ~15
+    out = np.full(nj * ostride, 0xEE, dtype=np.uint8); osz = np.zeros(nj, dtype=np.uint32)
+    chk = None
+    if checksum:
+        whole = np.zeros(1, dtype=UNIT_DT); whole[0] = units[0]; whole[0]["srcLen"] = n
+        chk = np.zeros(17, dtype=np.uint32)
+        le.emu_xxh64_wave.restype = None
+        le.emu_xxh64_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64_wave(_buf(src), _buf(whole), 1, _buf(chk), 0)
+    le.emu_frame_jobs.restype = None
+    le.emu_frame_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    le.emu_frame_jobs(_buf(src), _buf(units), _buf(jobs), nj, _buf(out), ostride, _buf(osz), _buf(chk) if checksum else None, 0)
+    return b"".join(out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nj))
+
+
+def oracle_frame_mt(lo, a, level, job_size=0, overlap_log=0, checksum=False):
+    lo.zo_compress_frame_mt_params.restype = C.c_size_t
+    lo.zo_compress_frame_mt_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int]
+    lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
+    cp = (C.c_uint * 7)()
+    assert lo.zo_get_cparams(level, len(a), cp) == 0
+    cap = lo.zo_frame_bound(len(a)) + 4
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = lo.zo_compress_frame_mt_params(_buf(dst), cap, _buf(a), len(a), cp, job_size, overlap_log, 1 if checksum else 0)
+    assert r != ERR
+    return dst[:r].tobytes()
+
+
+# (level, jobSize, overlapLog, checksum) of the ZSTD_c_nbWorkers tests; jobSize 0 / overlapLog 0 = the reference's defaults
+MT_MODES = [(1, 0, 0, 0), (1, 524288, 0, 1), (1, 700000, 9, 0), (1, 524288, 1, 0), (3, 0, 0, 0), (3, 1 << 20, 3, 1), (-1, 524288, 0, 0), (2, 600000, 8, 0)]
+
+
+def mt_frame_cases(lo):
+    """inputs above 512 KB for the job-pool frames (tests/golden/frames_mt_v1.json pins the reference's output for each)"""
+    rng = np.random.default_rng(99)
+    yield "dg_524289", datagen(lo, 524289, 50, 14)                    # one byte above ZSTDMT_JOBSIZE_MIN: two jobs, the second 1 byte
+    yield "dg_5m", datagen(lo, 5 << 20, 50, 15)
+    yield "dg_p80_2.3m", datagen(lo, 2_300_001, 80, 16)
+    yield "text_3m", text_like(3_000_000, 13)
+    yield "random_1.2m", rng.integers(0, 256, size=1_200_000, dtype=np.uint8)
+    yield "zeros_2m", np.zeros(2 << 20, np.uint8)                     # RLE blocks: the rule differs for a job's first block
+    yield "mixed_2.6m", np.concatenate([datagen(lo, 700000, 50, 1), rng.integers(0, 256, size=500000, dtype=np.uint8),
+                                        np.full(600000, 7, np.uint8), text_like(800000, 9)])
+    b = datagen(lo, 3 << 19, 50, 18).copy(); b[1 << 19: 2 << 19] = b[: 1 << 19]; b[2 << 19:] = b[: 1 << 19]    # sections that repeat earlier ones: the overlap matters
+    yield "repeat_sections", b
+
+
+def ref_frame_mt(lr, a, level, job_size=0, overlap_log=0, checksum=False, cp=None):
+    lr.zref_compress_frame_mt.restype = C.c_size_t
+    lr.zref_compress_frame_mt.argtypes = [C.c_int, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    dst = np.zeros(len(a) + (len(a) >> 7) + 1024, dtype=np.uint8)
+    cpi = (C.c_int * 7)(*cp) if cp is not None else None
+    r = lr.zref_compress_frame_mt(level, cpi, job_size, overlap_log, 1 if checksum else 0, _buf(a), len(a), _buf(dst), len(dst))
+    assert r != ERR
+    return dst[:r].tobytes()

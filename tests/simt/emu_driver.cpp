@@ -137,6 +137,12 @@ void emu_xxh64(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint3
     simt::launch({(nUnits + 15) / 16, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_xxh64(src, units, nUnits, checks); }, osThreads);
 }
 
+// the wave-per-unit variant for large units (frames)
+void emu_xxh64_wave(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* checks, int osThreads)
+{
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_XXH_WAVE_LDS, [=] { zhip::k_xxh64_wave(src, units, nUnits, checks); }, osThreads);
+}
+
 void emu_entropy_ck(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
                     const uint8_t* lits, uint16_t* stBits, uint8_t* out, uint32_t* outSize, const uint32_t* checks, int osThreads);
 void emu_entropy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, const ZhipSeq* seqs, const ZhipParse* metas,
@@ -177,8 +183,30 @@ void emu_frame_fast(const uint8_t* src, const ZhipUnit* frames, uint32_t nFrames
     ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
     zhip::ZhipFrameState* const stp = states.data();
     simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsLog),
-                 [=] { zhip::k_frame_fast(src, frames, slots, nFrames, tb, tabStride, sq, lt, sb, out, outSize, stp, checks); }, osThreads);
+                 [=] { zhip::k_frame_fast(src, frames, slots, nFrames, tb, tabStride, sq, lt, sb, out, outSize, stp, checks, (const zhip::ZhipJob*)nullptr); }, osThreads);
 }
+// one frame as jobs (ZSTD_c_nbWorkers semantics): units[i] / jobs[i] describe job i (units[i].srcOff = the frame start)
+void emu_frame_jobs(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJob* jobs, uint32_t nJobs, uint8_t* out, uint64_t outStride,
+                    uint32_t* outSize, const uint32_t* checks, int osThreads)
+{
+    std::vector<ZhipSlot> sv(nJobs ? nJobs : 1);
+    size_t tabStride = 0; uint32_t ldsLog = 0;
+    for (uint32_t i = 0; i < nJobs; i++) {
+        sv[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; sv[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; sv[i].outOff = (uint64_t)i * outStride; sv[i].seqCap = ZHIP_SEQ_CAP; sv[i].pad0 = 0;
+        if (zhip::frame_table_in_lds(units[i].strategy, units[i].hashLog)) { if (units[i].hashLog > ldsLog) ldsLog = units[i].hashLog; }
+        else { size_t const w = zhip::frame_table_words(units[i].strategy, units[i].hashLog, units[i].chainLog); if (w > tabStride) tabStride = w; }
+    }
+    const ZhipSlot* const slots = sv.data();
+    std::vector<ZhipSeq> seqs((size_t)nJobs * ZHIP_SEQ_CAP); std::vector<uint8_t> lits((size_t)nJobs * ZHIP_LIT_STRIDE);
+    std::vector<uint16_t> stBits((size_t)nJobs * ZHIP_SEQ_CAP * 3);
+    std::vector<uint32_t> tabs((size_t)nJobs * tabStride + 1);
+    std::vector<zhip::ZhipFrameState> states(nJobs ? nJobs : 1);
+    ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
+    zhip::ZhipFrameState* const stp = states.data();
+    simt::launch({nJobs, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsLog),
+                 [=] { zhip::k_frame_fast(src, units, slots, nJobs, tb, tabStride, sq, lt, sb, out, outSize, stp, checks, jobs); }, osThreads);
+}
+uint32_t emu_sizeof_job(void) { return (uint32_t)sizeof(zhip::ZhipJob); }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }
 uint32_t emu_ent_shared(void) { return (uint32_t)sizeof(zhip::EntShared); }

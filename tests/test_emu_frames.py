@@ -3,6 +3,7 @@ zo_compress_frame — one frame holding the blocks ZSTD_compress emits (lib/comp
 import numpy as np
 import pytest
 from _libs import *
+from _libs import UNIT_DT, _buf
 
 
 @pytest.fixture(scope="module")
@@ -43,3 +44,40 @@ def test_frames_table_in_hbm_and_checksum(libs):
     lo.zo_xxh64.restype = C.c_uint64
     lo.zo_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
     assert int.from_bytes(ck[-4:], "little") == lo.zo_xxh64(a.ctypes.data_as(C.c_void_p), a.size, 0) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("level,js,ov,ck", [(1, 524288, 0, True), (3, 524288, 9, False)])
+def test_job_pool_frames_match_oracle(libs, level, js, ov, ck):
+    """ZSTD_c_nbWorkers semantics: k_frame_fast with a job table (prefix fill, zero repcodes, chunked block rule, one checksum)
+    against zo_compress_frame_mt_params"""
+    lo, le = libs
+    rng = np.random.default_rng(8)
+    cases = [("dg_1.1m", datagen(lo, 1_100_000, 50, 1)),
+             ("mixed", np.concatenate([datagen(lo, 300000, 50, 3), rng.integers(0, 256, size=150000, dtype=np.uint8), np.zeros(300000, np.uint8), text_like(100000, 6)]))]
+    for name, a in cases:
+        assert emu_compress_frame_jobs(le, lo, a, level, js, ov, ck) == oracle_frame_mt(lo, a, level, js, ov, ck), (name, level, js, ov, ck)
+
+
+def test_wave_checksum_kernel_matches_xxh64(libs):
+    """k_xxh64_wave (one wavefront per large unit: staged pre-multiplied blocks + four accumulator chains) on sizes around its
+    4 KB block and 32-byte stripe borders, at unaligned starts"""
+    lo, le = libs
+    lo.zo_xxh64.restype = C.c_uint64
+    lo.zo_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    le.emu_xxh64_wave.restype = None
+    le.emu_xxh64_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+    sizes = [0, 1, 31, 32, 33, 4095, 4096, 4097, 8191, 8192, 8192 + 37, 12288 + 4, 100_003, 1_000_000]
+    rng = np.random.default_rng(12)
+    src = rng.integers(0, 256, size=sum(sizes) + 3 * len(sizes) + 64, dtype=np.uint8)
+    units = np.zeros(len(sizes), dtype=UNIT_DT)
+    pos = 0
+    for i, n in enumerate(sizes):
+        pos += 3                                                         # odd offsets: the loads are unaligned
+        units[i]["srcOff"] = pos; units[i]["srcLen"] = n
+        pos += n
+    chk = np.zeros(len(sizes) + 16, dtype=np.uint32)
+    le.emu_xxh64_wave(_buf(src), _buf(units), len(sizes), _buf(chk), 0)
+    for i, n in enumerate(sizes):
+        o = int(units[i]["srcOff"])
+        want = lo.zo_xxh64(src[o:].ctypes.data_as(C.c_void_p), n, 0) & 0xFFFFFFFF
+        assert int(chk[i]) == want, n

@@ -8,7 +8,8 @@ import json
 import os
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, frame_cases, oracle_frame, datagen, text_like, _buf, ROOT, ERR
+from _libs import (load_oracle, load_ref, have_ref, frame_cases, oracle_frame, mt_frame_cases, oracle_frame_mt, ref_frame_mt, MT_MODES,
+                   datagen, text_like, _buf, ROOT, ERR)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "frames_v1.json")
@@ -182,3 +183,89 @@ def test_frames_with_explicit_parameters(env):
         r = lo.zo_compress_frame_params(_buf(want), cap, _buf(a), a.size, eff)
         assert r != ERR and out == want[:r].tobytes(), (level, cp, list(eff))
         assert z.DContext().decompress(out) == a.tobytes()
+
+
+GOLD_MT = os.path.join(os.path.dirname(__file__), "golden", "frames_mt_v1.json")
+
+
+def test_job_pool_frames_equal_the_reference_digests(env):
+    """zhip_compress_frames_mt = ZSTD_compress2 with ZSTD_c_nbWorkers >= 1: every case of frames_mt_v1.json (digests of the REAL
+    reference), one batch per mode — jobs of all the frames run side by side"""
+    z, lo = env
+    gold = {(g["case"], g["level"], g["jobSize"], g["overlapLog"], g["checksum"]): g for g in json.load(open(GOLD_MT))["frames"]}
+    cases = list(mt_frame_cases(lo))
+    ctx = z.Context(max_units=64)
+    seen = 0
+    for level, js, ov, ck in MT_MODES:
+        ctx.set_checksum(bool(ck))
+        outs = ctx.compress_frames([a for _, a in cases], level, workers=1, job_size=js, overlap_log=ov)
+        for (name, a), out in zip(cases, outs):
+            g = gold[(name, level, js, ov, ck)]
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, js, ov, ck)
+            seen += 1
+    assert seen == len(gold)
+    ctx.set_checksum(False)
+    a = cases[1][1]
+    out = ctx.compress_frames([a], 1, workers=4)[0]                      # the worker count does not change the bytes
+    assert out == oracle_frame_mt(lo, a, 1) and z.DContext().decompress(out) == a.tobytes()
+
+
+def test_job_pool_frames_mixed_batch_and_small_inputs(env):
+    """inputs at or below 512 KB come out as the plain single-context frame (the reference drops the workers there); large and
+    small inputs share a batch; frame sizes are per input, not per job"""
+    z, lo = env
+    ctx = z.Context(max_units=64)
+    bufs = [np.zeros(0, np.uint8), datagen(lo, 100, 50, 1), datagen(lo, 524288, 50, 2), datagen(lo, 524289, 50, 3), text_like(1_500_000, 4),
+            datagen(lo, 300_000, 50, 5), datagen(lo, 2_500_000, 30, 6)]
+    for level in (1, 3):
+        outs = ctx.compress_frames(bufs, level, workers=2, job_size=524288)
+        for a, out in zip(bufs, outs):
+            want = oracle_frame(lo, a, level) if len(a) <= 524288 else oracle_frame_mt(lo, a, level, 524288, 0)
+            assert out == want, (len(a), level)
+    assert z.DContext().decompress(b"".join(outs)) == b"".join(a.tobytes() for a in bufs)
+    with pytest.raises(z.ZhipError):
+        ctx.compress_frames([bufs[-1]], 5, workers=1)                     # greedy: not a frame-kernel strategy, no CPU fallback
+    small = z.Context(max_units=2)
+    with pytest.raises(z.ZhipError):
+        small.compress_frames([bufs[-1]], 1, workers=1, job_size=524288)  # 5 jobs > the context's capacity
+
+
+def test_shim_nbworkers_mode(env):
+    """ZSTD_compress2 through the drop-in with ZSTD_c_nbWorkers / ZSTD_c_jobSize / ZSTD_c_overlapLog / ZSTD_c_checksumFlag: the
+    reference's multi-threaded frame, byte for byte"""
+    z, lo = env
+    from zstd_amd import build as zb
+    S = C.CDLL(zb.SHIM)
+    S.ZSTD_createCCtx.restype = C.c_void_p
+    S.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    S.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    S.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    S.ZSTD_compress2.restype = C.c_size_t
+    S.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    S.ZSTD_compressCCtx.restype = C.c_size_t
+    S.ZSTD_compressCCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    S.ZSTD_compressBound.restype = C.c_size_t
+    S.ZSTD_compressBound.argtypes = [C.c_size_t]
+    S.ZSTD_isError.argtypes = [C.c_size_t]
+    lr = load_ref() if have_ref() else None
+    a = datagen(lo, 3_000_000, 50, 41)
+    cap = S.ZSTD_compressBound(a.size)
+    dst = np.zeros(cap, dtype=np.uint8)
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 400, 257)) and S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 402, 10))   # out of bounds
+    for level, workers, js, ov, ck in ((1, 1, 0, 0, 0), (3, 8, 1 << 20, 4, 1), (-1, 2, 524288, 9, 0)):
+        for prm, v in ((100, level), (400, workers), (401, js), (402, ov), (201, ck)):
+            assert S.ZSTD_CCtx_setParameter(c, prm, v) == 0
+        r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), a.size)
+        assert not S.ZSTD_isError(r)
+        out = dst[:r].tobytes()
+        assert out == oracle_frame_mt(lo, a, level, js, ov, bool(ck)), (level, js, ov, ck)
+        if lr is not None:
+            assert out == ref_frame_mt(lr, a, level, js, ov, bool(ck)), (level, js, ov, ck)
+    # at or below 512 KB: the workers are dropped -> the frame-per-unit stream of the default mode; ZSTD_compressCCtx ignores the workers
+    b = a[:400_000]
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(b), b.size)
+    assert not S.ZSTD_isError(r) and z.DContext().decompress(dst[:r].tobytes()) == b.tobytes()
+    r = S.ZSTD_compressCCtx(c, _buf(dst), cap, _buf(a), a.size, 1)
+    assert not S.ZSTD_isError(r) and dst[:r].tobytes() != oracle_frame_mt(lo, a, 1) and z.DContext().decompress(dst[:r].tobytes()) == a.tobytes()
+    S.ZSTD_freeCCtx(c)

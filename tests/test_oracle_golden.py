@@ -2,7 +2,7 @@
 Runs anywhere (no /root/reference, no oracle/_ref needed)."""
 import hashlib, json, os
 import numpy as np
-from _libs import load_oracle, corpus_cases, frame_cases, oracle_frame, _buf, ERR
+from _libs import load_oracle, corpus_cases, frame_cases, oracle_frame, mt_frame_cases, oracle_frame_mt, MT_MODES, _buf, ERR
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
 
@@ -124,3 +124,23 @@ def test_oracle_reproduces_golden_multiblock_frames():
             assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level)
             seen += 1
     assert seen == len(gold) >= 60
+
+
+GOLD_FRAMES_MT = os.path.join(os.path.dirname(__file__), "golden", "frames_mt_v1.json")
+
+
+def test_oracle_reproduces_golden_job_pool_frames():
+    """ZSTD_c_nbWorkers = 1 (zo_compress_frame_mt_params; zstdmt_compress.c): jobs of the job size, each a fresh context that loaded
+    the overlap as prefix (every third position, repcodes zero), 512 KB chunks per compressContinue, `savings` counting the job's
+    own discarded frame header, one checksum of the whole input"""
+    lo = load_oracle()
+    gold = {(g["case"], g["level"], g["jobSize"], g["overlapLog"], g["checksum"]): g for g in json.load(open(GOLD_FRAMES_MT))["frames"]}
+    seen = 0
+    for name, a in mt_frame_cases(lo):
+        for level, js, ov, ck in MT_MODES:
+            g = gold[(name, level, js, ov, ck)]
+            assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"], name
+            out = oracle_frame_mt(lo, a, level, js, ov, bool(ck))
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, js, ov, ck)
+            seen += 1
+    assert seen == len(gold) == 64

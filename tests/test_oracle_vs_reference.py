@@ -3,7 +3,7 @@
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, _buf, ERR
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, oracle_frame_mt, ref_frame_mt, _buf, ERR
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -244,3 +244,21 @@ def test_multiblock_frame_with_explicit_parameters_vs_reference(libs):
             cpi = (C.c_int * 7)(*cp)
             k = lr.zref_compress_chunks_level_params(level, cpi, 0, n, _buf(src), n, _buf(want), len(want))
             assert r != ERR and k != ERR and got[:r].tobytes() == want[:k].tobytes(), (level, cp, list(eff))
+
+
+def test_job_pool_frame_vs_reference(libs):
+    """zo_compress_frame_mt_params against ZSTD_compress2 with ZSTD_c_nbWorkers = 1 on random sizes, job sizes and overlaps (the frame
+    the shim's nbWorkers mode must equal); at or below 512 KB the reference drops the workers"""
+    lo, lr = libs
+    rng = np.random.default_rng(321)
+    for trial in range(16):
+        n = int(rng.integers(400_000, 3_000_000))
+        kind = trial % 4
+        a = (datagen(lo, n, int(rng.integers(10, 95)), trial) if kind == 0 else text_like(n, trial) if kind == 1 else
+             np.concatenate([datagen(lo, n // 2, 60, trial), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]) if kind == 2 else
+             np.repeat(rng.integers(0, 256, size=n // 4096 + 1, dtype=np.uint8), 4096)[:n].copy())
+        for level in (1, 3, -3):
+            js = int(rng.choice([0, 1, 524288, 600_001, 1 << 20, 1 << 21]))
+            ov = int(rng.integers(0, 10))
+            ck = bool(rng.integers(0, 2))
+            assert oracle_frame_mt(lo, a, level, js, ov, ck) == ref_frame_mt(lr, a, level, js, ov, ck), (trial, kind, n, level, js, ov, ck)

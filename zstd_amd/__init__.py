@@ -310,9 +310,11 @@ class Context:
         out = dst[:r].tobytes()
         return (out, sizes) if return_sizes else out
 
-    def compress_frames(self, buffers, level=1, cparams=None):
+    def compress_frames(self, buffers, level=1, cparams=None, workers=0, job_size=0, overlap_log=0):
         """each buffer -> ONE multi-block frame, byte-identical to the reference's ZSTD_compress of it (zhip_compress_frames;
-        strategies ZSTD_fast and ZSTD_dfast: levels -N .. 3).  Returns the list of frames (bytes)."""
+        strategies ZSTD_fast and ZSTD_dfast: levels -N .. 3).  Returns the list of frames (bytes).
+        workers >= 1: the frames ZSTD_compress2 emits with ZSTD_c_nbWorkers >= 1 instead (zhip_compress_frames_mt: inputs above
+        512 KB are cut into independent jobs of job_size with overlap_log's prefix — one large input then fills the GPU)."""
         L = lib()
         L.zhip_frames_bound.restype = C.c_size_t
         L.zhip_frames_bound.argtypes = [C.c_void_p, C.c_size_t]
@@ -326,9 +328,17 @@ class Context:
         dst = np.empty(max(cap, 1), dtype=np.uint8)
         sizes = np.zeros(len(arrs), dtype=np.uint64)
         cp = (C.c_uint * 7)(*cparams) if cparams is not None else None
-        r = self._check(L.zhip_compress_frames(self._h, dst.ctypes.data_as(C.c_void_p), cap, src.ctypes.data_as(C.c_void_p),
-                                               offs.ctypes.data_as(C.c_void_p), len(arrs), level, cp, sizes.ctypes.data_as(C.c_void_p)),
-                        "zhip_compress_frames")
+        if workers:
+            L.zhip_compress_frames_mt.restype = C.c_size_t
+            L.zhip_compress_frames_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                                  C.c_size_t, C.c_int, C.c_void_p]
+            r = self._check(L.zhip_compress_frames_mt(self._h, dst.ctypes.data_as(C.c_void_p), cap, src.ctypes.data_as(C.c_void_p),
+                                                      offs.ctypes.data_as(C.c_void_p), len(arrs), level, cp, job_size, overlap_log,
+                                                      sizes.ctypes.data_as(C.c_void_p)), "zhip_compress_frames_mt")
+        else:
+            r = self._check(L.zhip_compress_frames(self._h, dst.ctypes.data_as(C.c_void_p), cap, src.ctypes.data_as(C.c_void_p),
+                                                   offs.ctypes.data_as(C.c_void_p), len(arrs), level, cp, sizes.ctypes.data_as(C.c_void_p)),
+                            "zhip_compress_frames")
         out, pos = [], 0
         for z in sizes:
             out.append(dst[pos: pos + int(z)].tobytes()); pos += int(z)

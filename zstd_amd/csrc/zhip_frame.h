@@ -31,6 +31,23 @@ struct FrameShared {
 // what one block hands to the next, per frame, in HBM
 struct ZhipFrameState { ZhipDictEntropy ent; };
 
+// One JOB of a frame compressed the way ZSTD_c_nbWorkers >= 1 compresses it (zstdmt_compress.c:683-790): a section of the input that
+// starts from a fresh context which has only loaded the `prefixLen` bytes in front of it (the overlap with the previous job) as a
+// raw-content prefix; jobs are independent of each other, so a frame's jobs run side by side, one workgroup each, and their blocks,
+// concatenated in job order, are the frame.  Positions are relative to the frame start.
+#define ZHIP_JOB_FIRST 1u          /* writes the frame header; repcodes start at {1,4,8} */
+#define ZHIP_JOB_LAST  2u          /* its final block carries the last-block bit; the frame checksum follows */
+#define ZHIP_JOB_CHUNK (512u * 1024u)   /* a job is compressed in chunks of 4 blocks, each its own frame-chunk call (:753) */
+struct ZhipJob {
+    uint32_t start;         // first byte of the section, from the frame start (the unit's srcLen is the section's length)
+    uint32_t prefixLen;     // bytes in front of it the job's window covers (0 for the first job)
+    uint32_t flags;
+    uint32_t ownHeader;     // bytes of the frame header a later job writes and discards — they count in its `savings` (:737, zstd_compress.c:4538)
+    uint64_t frameSize;     // content size of the whole frame (header)
+    uint32_t frameIdx;      // which frame of the batch the job belongs to (its checksum, its size)
+    uint32_t pad0;
+};
+
 __host__ __device__ inline uint32_t frame_lds_bytes(uint32_t hashLog)
 {
     uint32_t const base = (uint32_t)((sizeof(EntShared) + 15) & ~(size_t)15) + (uint32_t)sizeof(FrameShared);
@@ -82,14 +99,50 @@ __device__ __attribute__((noinline)) void parse_dfast_block_far(const uint8_t* s
     parse_dfast_block<MLS, true>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, scratch, tabL, tabS, seqs, lits, meta);
 }
 
+// ZSTD_fillHashTableForCCtx / ZSTD_fillDoubleHashTableForCCtx with ZSTD_dtlm_fast (zstd_fast.c:50-86, zstd_double_fast.c:56-90) over
+// the prefix [p0, p1): every third position, later positions win — an atomic max, so the order of the lanes does not matter
+__device__ inline void frame_fill_prefix(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, uint32_t p0, uint32_t p1)
+{
+    if (p1 - p0 <= 8) return;                                                // zstd_compress.c:4902
+    uint32_t const big = u.hashLog > u.chainLog ? u.hashLog : u.chainLog;
+    uint32_t const maxDict = 8u << (big < 28 ? big : 28);                    // :4889-4896
+    if (p1 - p0 > maxDict) p0 = p1 - maxDict;
+    uint32_t const stop = p1 - 8 + 2;                                        // ip + 3 < iend + 2
+    for (uint32_t ip = p0 + 3u * threadIdx.x; ip + 3 < stop; ip += 3u * ZHIP_ENT_THREADS) {
+        uint64_t const b = ld64(src + ip);
+        if (u.strategy == ZHIP_STRAT_DFAST) {
+            uint32_t const hl = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL) >> (32 - u.hashLog);
+            uint32_t hs;
+            switch (u.minMatch) { case 5: hs = hash_pos<5>(b, 32 - u.chainLog); break; case 6: hs = hash_pos<6>(b, 32 - u.chainLog); break;
+                                  case 7: hs = hash_pos<7>(b, 32 - u.chainLog); break; case 8: hs = hash_pos<8>(b, 32 - u.chainLog); break;
+                                  default: hs = hash_pos<4>(b, 32 - u.chainLog); break; }
+            atomicMax(&T.w[hl], ip);
+            atomicMax(&T.w[((size_t)1 << u.hashLog) + hs], ip);
+        } else {
+            uint32_t h;
+            switch (u.minMatch) { case 5: h = hash_pos<5>(b, 32 - u.hashLog); break; case 6: h = hash_pos<6>(b, 32 - u.hashLog); break;
+                                  case 7: h = hash_pos<7>(b, 32 - u.hashLog); break; case 8: h = hash_pos<8>(b, 32 - u.hashLog); break;
+                                  default: h = hash_pos<4>(b, 32 - u.hashLog); break; }
+            atomicMax(&T.w[h], ip);
+        }
+    }
+}
+
+// job == nullptr: the whole input src[0, u.srcLen) as ONE frame (ZSTD_compress2 without workers: one context, one frame chunk).
+// job != nullptr: one job of a frame (see ZhipJob); src is the frame start.
 __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
-                                  EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum)
+                                  EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum,
+                                  const ZhipJob* __restrict__ job)
 {
     int const t = (int)threadIdx.x, wv = t >> 6;
-    uint32_t const n = u.srcLen;
-    uint32_t op = frame_header_bytes_multi(n, u.windowLog);
-    if (t == 0) write_frame_header_multi(out, n, u.windowLog, withChecksum);
+    uint32_t const j0 = job ? job->start : 0u;                               // the section [j0, jEnd) of the frame
+    uint32_t const n = u.srcLen, jEnd = j0 + n;
+    bool const first = !job || (job->flags & ZHIP_JOB_FIRST), lastJob = !job || (job->flags & ZHIP_JOB_LAST);
+    uint32_t const winStart = job ? j0 - job->prefixLen : 0u;
+    uint32_t const frameSize = job ? (uint32_t)job->frameSize : n;
+    uint32_t op = first ? frame_header_bytes_multi(frameSize, u.windowLog) : 0u;
+    if (first && t == 0) write_frame_header_multi(out, frameSize, u.windowLog, withChecksum);
     if (n == 0) {                                                            // :5270 an empty frame is one empty raw block
         if (t == 0) {
             out[op] = 1; out[op + 1] = 0; out[op + 2] = 0; op += 3;
@@ -100,23 +153,28 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
     }
     for (uint32_t i = (uint32_t)t; i < (uint32_t)frame_table_words(u.strategy, u.hashLog, u.chainLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table(s) (:2020)
     if (t == 0) { st->ent.hufRepeat = 0; st->ent.hufMaxSym = 0; st->ent.fseRepeat[0] = 0; st->ent.fseRepeat[1] = 0; st->ent.fseRepeat[2] = 0; }
-    uint32_t rep1 = 1, rep2 = 4, rep3 = 8;
-    long long savings = 0;
-    uint32_t pos = 0;
+    __syncthreads();
+    if (job && job->prefixLen) { frame_fill_prefix(src, u, T, winStart, j0); __syncthreads(); }
+    uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u;     // later jobs: ZSTD_invalidateRepCodes (:741)
+    long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
+    uint32_t pos = j0;
     uint32_t const maxDist = 1u << u.windowLog;
     __syncthreads();
-    while (pos < n) {
-        uint32_t const remaining = n - pos;
+    while (pos < jEnd) {
+        // a job hands its section to the compressor in chunks of 512 KB (one ZSTD_compressContinue each): the block rule sees what
+        // is left of the CHUNK; without jobs the whole input is one chunk
+        uint32_t const chunkEnd = job ? (jEnd - pos > ZHIP_JOB_CHUNK - ((pos - j0) & (ZHIP_JOB_CHUNK - 1)) ? pos + ZHIP_JOB_CHUNK - ((pos - j0) & (ZHIP_JOB_CHUNK - 1)) : jEnd) : jEnd;
+        uint32_t const remaining = chunkEnd - pos;
         uint32_t bLen = remaining < ZHIP_UNIT_MAX ? remaining : ZHIP_UNIT_MAX;                      // :4494-4518
         if (remaining >= ZHIP_UNIT_MAX && savings >= 3) bLen = ZHIP_FRAME_BLOCK_SPLIT;
-        uint32_t const last = bLen == remaining ? 1u : 0u;
+        uint32_t const last = (lastJob && pos + bLen == jEnd) ? 1u : 0u;
         uint32_t const end = pos + bLen;
         uint8_t* const body = out + op + 3;
         uint32_t cSize = 0;
         if (bLen >= 7) {                                                                         // :3216
             if (wv == 0) {
                 // ZSTD_window_enforceMaxDist from the block start (:4555), then ZSTD_getLowestPrefixIndex(block end) (zstd_fast.c:205)
-                uint32_t const dictLimit = pos > maxDist ? pos - maxDist : 0;
+                uint32_t const dl0 = pos > maxDist ? pos - maxDist : 0, dictLimit = dl0 > winStart ? dl0 : winStart;
                 uint32_t const prefixLow = (end - dictLimit > maxDist) ? end - maxDist : dictLimit;
                 uint32_t const ip0 = pos + (pos == prefixLow);
                 uint32_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;
@@ -142,7 +200,7 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
             __syncthreads();
             ZhipParse const pm = fs->meta;
             cSize = entropy_block<ZHIP_ENT_THREADS, EntShared>(src + pos, bLen, u, seqs, pm, lits, stBits, seqCap, body, sh, &st->ent);
-            if (pos != 0 && cSize < 25) {                                    // :4365-4376 an RLE block, never the first one
+            if (pos != j0 && cSize < 25) {                                   // :4365-4376 an RLE block, never the context's first one
                 if (t == 0) fs->flag = 0;
                 __syncthreads();
                 uint8_t const b0 = src[pos];
@@ -176,11 +234,13 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
         }
         op += total;
         savings += (long long)bLen - (long long)total;
+        // the first job wrote the real frame header in its first call: from the second chunk on it counts as produced (zstd_compress.c:4767)
+        if (job && first && end == chunkEnd && end - j0 <= ZHIP_JOB_CHUNK) savings -= (long long)frame_header_bytes_multi(frameSize, u.windowLog);
         pos = end;
         __syncthreads();                                                     // the block's bytes and the new state are in place
     }
     if (t == 0) {
-        if (withChecksum) { for (int b = 0; b < 4; b++) out[op + b] = (uint8_t)(checksum >> (8 * b)); op += 4; }   // :5297-5303
+        if (withChecksum && lastJob) { for (int b = 0; b < 4; b++) out[op + b] = (uint8_t)(checksum >> (8 * b)); op += 4; }   // :5297-5303, zstdmt_compress.c:1516
         *outSize = op;
     }
 }

@@ -95,6 +95,27 @@ static inline bool host_check_overrides(const unsigned ov[7])
 }
 
 // ZSTD_COMPRESSBOUND, lib/zstd.h:235
+// ZSTD_c_nbWorkers >= 1: how the reference's job pool cuts one frame (lib/compress/zstdmt_compress.c).  The result does not depend on
+// the number of workers, only on the job size and the overlap.
+static const size_t MT_JOBSIZE_MIN = (size_t)512 << 10;                 // ZSTDMT_JOBSIZE_MIN (zstdmt_compress.h:36); at or below it: no jobs
+static inline size_t host_mt_job_size(const CParams& cp, unsigned long long jobSize)
+{
+    unsigned long long sec = jobSize;                                   // ZSTD_c_jobSize, clamped when set (zstdmt_compress.c:1250-1252)
+    if (sec != 0 && sec < MT_JOBSIZE_MIN) sec = MT_JOBSIZE_MIN;
+    if (sec > (1024ull << 20)) sec = 1024ull << 20;                     // ZSTDMT_JOBSIZE_MAX on 64-bit hosts
+    if (sec == 0) { unsigned jl = cp.windowLog + 2; if (jl < 20) jl = 20; if (jl > 30) jl = 30; sec = 1ull << jl; }   // ZSTDMT_computeTargetJobLog (:1168-1180), no LDM
+    return (size_t)sec;
+}
+static inline size_t host_mt_overlap_size(const CParams& cp, int overlapLog)
+{
+    // ZSTDMT_overlapLog_default (:1182-1203) by strategy, then ZSTDMT_computeOverlapSize (:1213-1233): 1 << (windowLog - (9 - overlapLog)), 0 at log 1
+    int const dflt = cp.strategy == 9 ? 9 : (cp.strategy >= 7 ? 8 : (cp.strategy >= 5 ? 7 : 6));
+    int const ov = overlapLog ? overlapLog : dflt;
+    int const rlog = 9 - ov;
+    int const ovLog = rlog >= 8 ? 0 : (int)cp.windowLog - rlog;
+    return ovLog <= 0 ? 0 : (size_t)1 << ovLog;
+}
+
 static inline size_t host_compress_bound(size_t n)
 {
     return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);

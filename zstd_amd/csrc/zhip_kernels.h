@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(ZHIP_ENT_THREADS)
 k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
              uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
              uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
-             const uint32_t* __restrict__ checks)
+             const uint32_t* __restrict__ checks, const ZhipJob* __restrict__ jobs /* nullptr: every unit is a whole frame; else unit i is one job of frame jobs[i].frameIdx */)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const fi = blockIdx.x;
@@ -271,8 +271,15 @@ k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frame
     uint8_t* const lt = lits + sl.litOff;
     uint16_t* const sb = stBits + 3 * sl.seqOff;
     uint8_t* const o = out + sl.outOff;
-    bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[fi] : 0u;
-    frame_fast(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv);
+    bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[fi].frameIdx : fi] : 0u;      // jobs: the checksum of the whole frame
+    frame_fast(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, jobs ? jobs + fi : (const ZhipJob*)nullptr);
+}
+
+// jobs -> frames: frameSizes[f] = sum of the compressed sizes of frame f's jobs (frameSizes zeroed by the caller)
+__global__ void k_frame_sizes(const uint32_t* __restrict__ outSize, const ZhipJob* __restrict__ jobs, uint32_t nJobs, uint32_t* __restrict__ frameSizes)
+{
+    uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nJobs) atomicAdd(frameSizes + jobs[i].frameIdx, outSize[i]);
 }
 
 // Frame checksum (ZSTD_c_checksumFlag): XXH64 of each unit's content, low 32 bits (zstd_compress.c:5297-5303).  XXH64 has four
@@ -316,6 +323,60 @@ k_xxh64(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uin
         uint32_t pos = stripes << 5;
         while (pos + 8 <= n) { uint64_t a; __builtin_memcpy(&a, p + pos, 8); h ^= xxh_round(0, a); h = xxh_rotl(h, 27) * P1 + P4; pos += 8; }
         if (pos + 4 <= n) { uint32_t a; __builtin_memcpy(&a, p + pos, 4); h ^= (uint64_t)a * P1; h = xxh_rotl(h, 23) * P2 + P3; pos += 4; }
+        while (pos < n) { h ^= (uint64_t)p[pos++] * P5; h = xxh_rotl(h, 11) * P1; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+        checks[ui] = (uint32_t)h;
+    }
+}
+
+// The same for LARGE units (whole frames of many blocks): one wavefront per unit.  The accumulator round
+// v = rotl(v + in * P2, 31) * P1 is serial in v, but in * P2 is not: all 64 lanes fetch 4 KB (coalesced) and pre-multiply it into
+// LDS while lanes 0..3 — one per accumulator — run the rotate-multiply chains over the block staged before.  The chain (about three
+// quarter-rate 32-bit multiplies per 32 input bytes) is what bounds one frame's checksum; frames of a batch hash side by side.
+#define ZHIP_XXH_WAVE_LDS (2u * 512u * 8u)
+__global__ void __launch_bounds__(64)
+k_xxh64_wave(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits, uint32_t* __restrict__ checks)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint64_t (*prod)[512] = (uint64_t (*)[512])smem;                    // two blocks of 128 stripes x 4 accumulators, pre-multiplied by P2
+    uint64_t const P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    uint32_t const lane = threadIdx.x & 63, j = lane & 3, ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    const uint8_t* const p = src + u.srcOff;
+    uint32_t const n = u.srcLen, stripes = n >> 5, blocks = stripes >> 7;
+    uint64_t v = j == 0 ? P1 + P2 : (j == 1 ? P2 : (j == 2 ? 0 : 0 - P1));
+    uint64_t a[8];
+    if (blocks) for (int k = 0; k < 8; k++) __builtin_memcpy(&a[k], p + 8u * ((uint32_t)k * 64u + lane), 8);
+    for (uint32_t b = 0; b < blocks; b++) {
+        uint64_t (&cur)[512] = prod[b & 1];
+        for (int k = 0; k < 8; k++) cur[(uint32_t)k * 64u + lane] = a[k] * P2;
+        if (b + 1 < blocks) for (int k = 0; k < 8; k++) __builtin_memcpy(&a[k], p + 4096u * (b + 1) + 8u * ((uint32_t)k * 64u + lane), 8);   // in flight during the chain
+        __syncthreads();
+        if (lane < 4) {
+            for (uint32_t s = 0; s < 128; s += 8) {
+                uint64_t m[8];
+                for (int q = 0; q < 8; q++) m[q] = cur[4u * (s + (uint32_t)q) + j];
+                for (int q = 0; q < 8; q++) v = xxh_rotl(v + m[q], 31) * P1;
+            }
+        }
+    }
+    for (uint32_t s = blocks << 7; s < stripes; s++) { uint64_t x; __builtin_memcpy(&x, p + 32u * s + 8u * j, 8); v = xxh_round(v, x); }
+    uint64_t vv[4];
+    for (int q = 0; q < 4; q++) {
+        uint32_t const lo = __shfl((uint32_t)v, q), hi = __shfl((uint32_t)(v >> 32), q);
+        vv[q] = ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) {
+        uint64_t h;
+        if (n >= 32) {
+            h = xxh_rotl(vv[0], 1) + xxh_rotl(vv[1], 7) + xxh_rotl(vv[2], 12) + xxh_rotl(vv[3], 18);
+            for (int q = 0; q < 4; q++) h = (h ^ xxh_round(0, vv[q])) * P1 + P4;
+        } else h = P5;
+        h += (uint64_t)n;
+        uint32_t pos = stripes << 5;
+        while (pos + 8 <= n) { uint64_t x; __builtin_memcpy(&x, p + pos, 8); h ^= xxh_round(0, x); h = xxh_rotl(h, 27) * P1 + P4; pos += 8; }
+        if (pos + 4 <= n) { uint32_t x; __builtin_memcpy(&x, p + pos, 4); h ^= (uint64_t)x * P1; h = xxh_rotl(h, 23) * P2 + P3; pos += 4; }
         while (pos < n) { h ^= (uint64_t)p[pos++] * P5; h = xxh_rotl(h, 11) * P1; }
         h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
         checks[ui] = (uint32_t)h;

@@ -48,6 +48,9 @@ struct zhip_ctx_s {
     uint64_t*  dOutOff;
     // multi-block frames (zhip_frame.h): output room and per-frame chain state, grown on demand
     uint8_t* dFrameOut; size_t frameOutCap; zhip::ZhipFrameState* dFrameState; size_t frameStateCap;
+    // ... as jobs (ZSTD_c_nbWorkers semantics): job table, whole-frame descriptors for the checksum, per-frame sizes
+    zhip::ZhipJob* dJobs; size_t jobsCap; ZhipUnit* dFrameUnits; uint32_t* dFrameSizes; size_t frameUnitsCap;
+    std::vector<zhip::ZhipJob> hJobs; std::vector<ZhipUnit> hFrameUnits; std::vector<uint32_t> hFrameSizes;
     // staging for the host-buffer API
     uint8_t* dSrcStage; size_t srcStageCap;
     uint8_t* dDstStage; size_t dstStageCap;
@@ -117,6 +120,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
+    (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse); (void)hipHostFree(c->hSlots);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->hcEv) (void)hipEventDestroy(e);
@@ -140,6 +144,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
+    c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
     for (int i = 0; i < ZHIP_MAX_CHUNKS; i++) { c->cs[i] = nullptr; c->cev[i] = nullptr; }
     memset(c->timing, 0, sizeof(c->timing));
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -562,13 +567,18 @@ static size_t compress_host_locked(zhip_ctx* c, void* dst, size_t dstCapacity, c
 // Each input becomes ONE standard frame holding the same blocks ZSTD_compress2 emits for it (zstd_compress.c:4520-4640): the
 // match finder's table, the window, the repcodes and the literals' Huffman table carry over from block to block.  The chain
 // is serial inside a frame (one workgroup per frame, zhip_frame.h); the frames of a batch run concurrently.
+// With mt (ZSTD_c_nbWorkers >= 1 semantics, zstdmt_compress.c): an input above 512 KB is cut into jobs of the job size; each job is
+// compressed by its own workgroup with the overlap in front of it as prefix, and the concatenation is the frame the reference's
+// worker pool emits (it does not depend on the number of workers).  A unit of the launch is then a job, not a frame.
+struct MtParams { bool on; unsigned long long jobSize; int overlapLog; };
 static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* offs,
-                                   size_t nFrames, int level, uint32_t* frameSizesDev, hipStream_t s)
+                                   size_t nFrames, int level, uint32_t* frameSizesDev, hipStream_t s, MtParams mt = MtParams{false, 0, 0})
 {
     if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
     if (nFrames > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu frames > context capacity %zu", nFrames, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
     const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
-    size_t bound = 0, outBytes = 0, tabWords = 0; uint32_t ldsLog = 0; unsigned long long totalSrc = 0;
+    size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsLog = 0; unsigned long long totalSrc = 0;
+    if (mt.on) { c->hJobs.clear(); c->hFrameUnits.resize(nFrames); }
     for (size_t i = 0; i < nFrames; i++) {
         if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] >= (1ull << 31)) { snprintf(c->err, sizeof(c->err), "frame %zu: inputs of 2 GiB and more are not implemented on device", i); return ZERR(ZE_srcSize_wrong); }
         size_t const n = (size_t)(offs[i + 1] - offs[i]);
@@ -576,14 +586,35 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         if (!zhip::host_get_cparams(level, n, &cp, ov)) return ZERR(ZE_parameter_unsupported);
         if (cp.strategy != ZHIP_STRAT_FAST && cp.strategy != ZHIP_STRAT_DFAST) { snprintf(c->err, sizeof(c->err), "multi-block frames: strategy %u not implemented on device (ZSTD_fast and ZSTD_dfast only)", cp.strategy); return ZERR(ZE_parameter_unsupported); }
         if (cp.windowLog < 17 && n > ((size_t)1 << cp.windowLog)) { snprintf(c->err, sizeof(c->err), "multi-block frames: windowLog %u below the block size is not implemented on device", cp.windowLog); return ZERR(ZE_parameter_unsupported); }
-        ZhipUnit& u = c->hUnits[i];
-        u.srcOff = offs[i]; u.srcLen = (uint32_t)n;
-        u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
-        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
-        ZhipSlot& sl = c->hSlots[i];
-        sl.seqOff = i * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = i * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = outBytes; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0;
-        outBytes += (zhip::host_compress_bound(n) + 1024 + 15) & ~(size_t)15;      // the block in flight may overshoot before it is declared raw
+        // the sections of this frame: one without workers or at most 512 KB (ZSTDMT_JOBSIZE_MIN: the reference then runs single-threaded)
+        size_t section = n ? n : 1, overlap = 0;
+        if (mt.on && n > zhip::MT_JOBSIZE_MIN) {
+            section = zhip::host_mt_job_size(cp, mt.jobSize); overlap = zhip::host_mt_overlap_size(cp, mt.overlapLog);
+            if (section < overlap) section = overlap;                                                   // zstdmt_compress.c:1300
+        }
+        size_t const nSec = n ? (n + section - 1) / section : 1;
+        if (nU + nSec > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu jobs > context capacity %zu", nU + nSec, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
+        size_t prevLen = 0;
+        for (size_t k = 0; k < nSec; k++, nU++) {
+            size_t const start = k * section, len = n - start < section ? n - start : section;
+            ZhipUnit& u = c->hUnits[nU];
+            u.srcOff = offs[i]; u.srcLen = (uint32_t)len;
+            u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
+            u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
+            u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
+            ZhipSlot& sl = c->hSlots[nU];
+            sl.seqOff = nU * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = nU * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = outBytes; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0;
+            outBytes += (zhip::host_compress_bound(len) + 1024 + 15) & ~(size_t)15;      // the block in flight may overshoot before it is declared raw
+            if (mt.on) {
+                zhip::ZhipJob j;
+                j.start = (uint32_t)start; j.prefixLen = (uint32_t)(k == 0 ? 0 : (prevLen < overlap ? prevLen : overlap));    // zstdmt_compress.c:1404-1407
+                j.flags = (k == 0 ? ZHIP_JOB_FIRST : 0u) | (k + 1 == nSec ? ZHIP_JOB_LAST : 0u);
+                j.ownHeader = zhip::frame_header_bytes_multi((uint32_t)len, cp.windowLog); j.frameSize = n; j.frameIdx = (uint32_t)i; j.pad0 = 0;
+                c->hJobs.push_back(j);
+            }
+            prevLen = len;
+        }
+        if (mt.on) { ZhipUnit& fu = c->hFrameUnits[i]; fu = c->hUnits[nU - 1]; fu.srcLen = (uint32_t)n; }
         bound += zhip::host_compress_bound(n);
         if (zhip::frame_table_in_lds(cp.strategy, cp.hashLog)) { if (cp.hashLog > ldsLog) ldsLog = cp.hashLog; }
         else { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
@@ -595,44 +626,64 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         if (hipMalloc((void**)&c->dFrameOut, outBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of frame output room", outBytes); return ZERR(ZE_memory_allocation); }
         c->frameOutCap = outBytes;
     }
-    if (c->frameStateCap < nFrames) {
+    if (c->frameStateCap < nU) {
         (void)hipFree(c->dFrameState); c->dFrameState = nullptr; c->frameStateCap = 0;
-        if (hipMalloc((void**)&c->dFrameState, nFrames * sizeof(zhip::ZhipFrameState)) != hipSuccess) return ZERR(ZE_memory_allocation);
-        c->frameStateCap = nFrames;
+        if (hipMalloc((void**)&c->dFrameState, nU * sizeof(zhip::ZhipFrameState)) != hipSuccess) return ZERR(ZE_memory_allocation);
+        c->frameStateCap = nU;
     }
     size_t const tabStride = (tabWords + 3) & ~(size_t)3;
-    if (tabStride && c->tabsCap < nFrames * tabStride) {
+    if (tabStride && c->tabsCap < nU * tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
-        if (hipMalloc((void**)&c->dTabs, nFrames * tabStride * sizeof(uint32_t)) != hipSuccess) return ZERR(ZE_memory_allocation);
-        c->tabsCap = nFrames * tabStride;
+        if (hipMalloc((void**)&c->dTabs, nU * tabStride * sizeof(uint32_t)) != hipSuccess) return ZERR(ZE_memory_allocation);
+        c->tabsCap = nU * tabStride;
+    }
+    if (mt.on) {
+        if (c->jobsCap < nU) {
+            (void)hipFree(c->dJobs); c->dJobs = nullptr; c->jobsCap = 0;
+            if (hipMalloc((void**)&c->dJobs, nU * sizeof(zhip::ZhipJob)) != hipSuccess) return ZERR(ZE_memory_allocation);
+            c->jobsCap = nU;
+        }
+        if (c->frameUnitsCap < nFrames) {
+            (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes); c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
+            if (hipMalloc((void**)&c->dFrameUnits, nFrames * sizeof(ZhipUnit)) != hipSuccess || hipMalloc((void**)&c->dFrameSizes, nFrames * sizeof(uint32_t)) != hipSuccess) return ZERR(ZE_memory_allocation);
+            c->frameUnitsCap = nFrames;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dJobs, c->hJobs.data(), nU * sizeof(zhip::ZhipJob), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->dFrameUnits, c->hFrameUnits.data(), nFrames * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     }
     size_t const lds = zhip::frame_lds_bytes(ldsLog);
     HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nFrames * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nFrames * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nU * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nU * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (c->checksum) {
+    if (c->checksum) {                                                                    // of whole frames, whatever the jobs
         if (!c->dChecks) HIPCHK(c, hipMalloc((void**)&c->dChecks, (c->maxUnits + 16) * sizeof(uint32_t)));
-        hipLaunchKernelGGL(zhip::k_xxh64, dim3((unsigned)((nFrames + 15) / 16)), dim3(64), 0, s, (const uint8_t*)srcDev, c->dUnits, (uint32_t)nFrames, c->dChecks);
+        hipLaunchKernelGGL(zhip::k_xxh64_wave, dim3((unsigned)nFrames), dim3(64), ZHIP_XXH_WAVE_LDS, s, (const uint8_t*)srcDev, mt.on ? c->dFrameUnits : c->dUnits, (uint32_t)nFrames, c->dChecks);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(zhip::k_frame_fast, dim3((unsigned)nFrames), dim3(ZHIP_ENT_THREADS), lds, s,
-                       (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nFrames, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
-                       c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(zhip::k_frame_fast, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), lds, s,
+                       (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nU, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
+                       c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nFrames, c->dOutOff);
-    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nFrames), dim3(256), 0, s, c->dFrameOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nFrames, (uint8_t*)dstDev);
+    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nU, c->dOutOff);
+    hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nU), dim3(256), 0, s, c->dFrameOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nU, (uint8_t*)dstDev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], s));
-    if (frameSizesDev) HIPCHK(c, hipMemcpyAsync(frameSizesDev, c->dOutSize, nFrames * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->hOutSize, c->dOutSize, nFrames * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (mt.on) {
+        HIPCHK(c, hipMemsetAsync(c->dFrameSizes, 0, nFrames * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(zhip::k_frame_sizes, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, s, c->dOutSize, c->dJobs, (uint32_t)nU, c->dFrameSizes);
+        if (frameSizesDev) HIPCHK(c, hipMemcpyAsync(frameSizesDev, c->dFrameSizes, nFrames * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    } else if (frameSizesDev) HIPCHK(c, hipMemcpyAsync(frameSizesDev, c->dOutSize, nFrames * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->hOutSize, c->dOutSize, nU * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     uint64_t total = 0;
-    for (size_t i = 0; i < nFrames; i++) total += c->hOutSize[i];
+    for (size_t i = 0; i < nU; i++) total += c->hOutSize[i];
+    c->hFrameSizes.assign(nFrames, 0);
+    for (size_t i = 0; i < nU; i++) c->hFrameSizes[mt.on ? c->hJobs[i].frameIdx : i] += c->hOutSize[i];
     read_timing(c);
-    c->stats[0] = nFrames; c->stats[1] = totalSrc; c->stats[2] = total; c->stats[3] = 0; c->stats[4] = 0;
-    c->nUnits = nFrames;
+    c->stats[0] = nU; c->stats[1] = totalSrc; c->stats[2] = total; c->stats[3] = 0; c->stats[4] = 0;
+    c->nUnits = nU;
     return (size_t)total;
 }
 
@@ -679,7 +730,50 @@ size_t zhip_compress_frames(zhip_ctx* c, void* dst, size_t dstCapacity, const vo
     size_t const total = frames_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, rel.data(), nFrames, level, nullptr, c->stream);
     if (zhip_isError(total)) return total;
     HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
-    if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hOutSize[i];
+    if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hFrameSizes[i];
+    return total;
+}
+
+// ZSTD_c_nbWorkers >= 1: the same inputs, each as the frame the reference's job pool produces
+size_t zhip_compress_frames_mt_device(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* srcOffsets,
+                                      size_t nFrames, int level, const unsigned cparams[7], size_t jobSize, int overlapLog, uint32_t* frameSizesDev, void* stream)
+{
+    if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
+    if (overlapLog < 0 || overlapLog > 9) return ZERR(ZE_parameter_outOfBound);        // ZSTDMT_OVERLAPLOG_MIN / MAX
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    OvrScope scope(c, cparams);
+    return frames_device_locked(c, dstDev, dstCapacity, srcDev, srcOffsets, nFrames, level, frameSizesDev, stream ? (hipStream_t)stream : c->stream, MtParams{true, jobSize, overlapLog});
+}
+
+size_t zhip_compress_frames_mt(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
+                               size_t nFrames, int level, const unsigned cparams[7], size_t jobSize, int overlapLog, size_t* frameSizes)
+{
+    if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
+    if (overlapLog < 0 || overlapLog > 9) return ZERR(ZE_parameter_outOfBound);
+    if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    OvrScope scope(c, cparams);
+    size_t const bound = zhip_frames_bound(srcOffsets, nFrames);
+    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    unsigned long long const lo = srcOffsets[0], hi = srcOffsets[nFrames];
+    size_t const srcSize = (size_t)(hi - lo);
+    if (c->srcStageCap < srcSize + 64) {
+        (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64;
+    }
+    if (c->dstStageCap < bound + 64) {
+        (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dDstStage, bound + 64)); c->dstStageCap = bound + 64;
+    }
+    if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, (const uint8_t*)src + lo, srcSize, hipMemcpyHostToDevice, c->stream));
+    std::vector<unsigned long long> rel(nFrames + 1);
+    for (size_t i = 0; i <= nFrames; i++) rel[i] = srcOffsets[i] - lo;
+    size_t const total = frames_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, rel.data(), nFrames, level, nullptr, c->stream, MtParams{true, jobSize, overlapLog});
+    if (zhip_isError(total)) return total;
+    HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
+    if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hFrameSizes[i];
     return total;
 }
 

@@ -21,6 +21,7 @@ struct ZSTD_CCtx_s {
     int       rowMode;               /* ZSTD_c_useRowMatchFinder: 0 auto, 1 enable, 2 disable (lib/zstd.h ZSTD_paramSwitch_e) */
     unsigned  cp[7];                 /* ZSTD_c_windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy; 0 = the level's */
     int       singleFrame;           /* ZHIP_c_singleFrame / $ZHIP_SINGLE_FRAME: sources above 128 KB as ONE multi-block frame (zhip_compress_frames) */
+    int       workers, jobSize, overlapLog;   /* ZSTD_c_nbWorkers / ZSTD_c_jobSize / ZSTD_c_overlapLog: sources above 512 KB as the frame the reference's job pool emits (zhip_compress_frames_mt) */
     const ZSTD_CDict* cdict;         /* ZSTD_CCtx_refCDict: sticky until reset / NULL (lib/zstd.h:1088-1102) */
 };
 
@@ -40,7 +41,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 {
     if (!c) return SHIM_ERR(E_GENERIC);
-    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; c->rowMode = 0; memset(c->cp, 0, sizeof(c->cp)); }
+    if (reset == ZSTD_reset_parameters || reset == ZSTD_reset_session_and_parameters) { c->level = 3; c->cdict = NULL; c->checksum = 0; c->rowMode = 0; c->workers = c->jobSize = c->overlapLog = 0; memset(c->cp, 0, sizeof(c->cp)); }
     return 0;
 }
 static size_t shim_set_cp(ZSTD_CCtx* c, int idx, int value, int lo, int hi)
@@ -67,7 +68,12 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     case ZSTD_c_contentSizeFlag: return value == 1 ? 0 : SHIM_ERR(E_parameter_unsupported);
     case ZSTD_c_checksumFlag:    c->checksum = value != 0; return 0;
     case ZSTD_c_dictIDFlag:      return 0;                        /* no dictionary can be attached: the flag has no effect */
-    case ZSTD_c_nbWorkers:       return value == 0 ? 0 : SHIM_ERR(E_parameter_unsupported);
+    /* multi-threaded mode (lib/zstd.h:452-491): the worker count does not change the reference's bytes, only that there are jobs; the
+       device runs a workgroup per job whatever the count.  Bounds: ZSTDMT_NBWORKERS_MAX 256, job size 0 or up to 1 GiB (clamped from
+       below to 512 KB at use, zstdmt_compress.c:1250), overlap log 0..9 */
+    case ZSTD_c_nbWorkers:       if (value < 0 || value > 256) return SHIM_ERR(E_parameter_outOfBound); c->workers = value; return 0;
+    case ZSTD_c_jobSize:         if (value < 0 || value > (1 << 30)) return SHIM_ERR(E_parameter_outOfBound); c->jobSize = value; return 0;
+    case ZSTD_c_overlapLog:      if (value < 0 || value > 9) return SHIM_ERR(E_parameter_outOfBound); c->overlapLog = value; return 0;
     case ZHIP_c_singleFrame:     c->singleFrame = value != 0; return 0;
     default: return SHIM_ERR(E_parameter_unsupported);
     }
@@ -128,6 +134,13 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
         return zhip_compress_multi(c->zm, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
     }
     {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
+    if (c->workers > 0 && n > (512u << 10) && cap >= zhip_compressBound(n, SHIM_UNIT)) {
+        /* ZSTD_c_nbWorkers >= 1: the frame of the reference's job pool, a workgroup per job.  At or below 512 KB the reference drops
+           the workers (zstd_compress.c:6215) and so does this; unsupported strategies fall through like below */
+        unsigned long long const offs[2] = { 0, n };
+        size_t const r = zhip_compress_frames_mt(c->z, dst, cap, src, offs, 1, level, c->cp, (size_t)c->jobSize, c->overlapLog, NULL);
+        if (!zhip_isError(r) || r != SHIM_ERR(E_parameter_unsupported)) return r;
+    }
     if (units > 1 && c->singleFrame && cap >= zhip_compressBound(n, SHIM_UNIT)) {
         /* the reference's own output shape: one frame, many blocks.  Strategies the frame kernel does not run
            (parameter_unsupported) fall through to the frame-per-128-KB stream below */
@@ -182,10 +195,10 @@ size_t ZSTD_compress_usingCDict(ZSTD_CCtx* c, void* dst, size_t cap, const void*
 }
 size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
 {   /* ignores the cctx's parameters (checksum flag included), like the reference (zstd_compress.c:5428) */
-    int const ck = c ? c->checksum : 0; size_t r; unsigned cp[7];
-    if (c) { c->checksum = 0; memcpy(cp, c->cp, sizeof(cp)); memset(c->cp, 0, sizeof(c->cp)); }
+    int const ck = c ? c->checksum : 0, wk = c ? c->workers : 0; size_t r; unsigned cp[7];
+    if (c) { c->checksum = 0; c->workers = 0; memcpy(cp, c->cp, sizeof(cp)); memset(c->cp, 0, sizeof(c->cp)); }
     r = shim_compress(c, dst, cap, src, n, level);
-    if (c) { c->checksum = ck; memcpy(c->cp, cp, sizeof(cp)); }
+    if (c) { c->checksum = ck; c->workers = wk; memcpy(c->cp, cp, sizeof(cp)); }
     return r;
 }
 size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level)
