@@ -555,6 +555,45 @@ def frames_leg(zstd_amd, local, host, level):
     return res
 
 
+def job_pool_leg(zstd_amd, local, host, level):
+    """the WHOLE workload as ONE frame the way ZSTD_compress2 emits it with ZSTD_c_nbWorkers >= 1 (jobs of the
+    default job size with the overlap as prefix; zhip_compress_frames_mt) — a workgroup per job, so one frame fills the GPU.  Rate
+    over the frame kernel's duration; parity = SHA-256 against the real reference's job pool on all host threads, which is also the
+    CPU figure beside it (`zstd -T0` on one big input)."""
+    n = min(len(host), (1 << 31) - (1 << 20))
+    if n <= (512 << 10):
+        return None
+    a = host[:n]
+    ctx = zstd_amd.Context(local, max_units=max(64, n // (512 << 10) + 1))
+    best, out = 1e9, None
+    for _ in range(3):
+        out = ctx.compress_frames([a], level, workers=1)[0]
+        best = min(best, ctx.timing()["entropy_ms"])
+    jobs = int(ctx.stats()["units"])
+    ctx.close()
+    res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
+           "ratio": round(n / len(out), 4),
+           "note": "k_frame_fast with a job table: one frame, jobs = independent workgroups (LDS: one per CU at level 1); never `value`"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if os.path.exists(exe):
+        tin, tout = f"/tmp/zhip_mt_in_{os.getpid()}.bin", f"/tmp/zhip_mt_out_{os.getpid()}.bin"
+        try:
+            a.tofile(tin)
+            thr = os.cpu_count() or 1
+            info = json.loads(subprocess.check_output([exe, "mtfile", str(level), str(min(thr, 256)), tin, tout, "0"], timeout=600))
+            want = hashlib.sha256(open(tout, "rb").read()).hexdigest()
+            res["parity"] = {"sha256_equals_reference_frame": bool(hashlib.sha256(out).hexdigest() == want and info["csize"] == len(out)),
+                             "reference": f"oracle/_ref/zref_bench mtfile = ZSTD_compress2 of the whole input, ZSTD_c_nbWorkers = {info['workers']}"}
+            res["cpu_reference"] = {"value": info["MBps"], "unit": "MB/s", "workers": info["workers"], "seconds": info["seconds"]}
+        except (subprocess.CalledProcessError, subprocess.TimeoutExpired) as e:
+            res["parity"] = {"error": str(e)}
+        finally:
+            for t in (tin, tout):
+                if os.path.exists(t):
+                    os.unlink(t)
+    return res
+
+
 def stub_main(args, rank, world):
     """ZHIP_BENCH_STUB=1: no GPU, no compression — exercises only the launch / barrier / max-over-ranks / one-line contract of the
     N-rank path with the gloo backend (tests/test_dist_gloo.py); the line says data = "stub" and must never be read as a measurement"""
@@ -647,6 +686,9 @@ def main():
         fr = frames_leg(zstd_amd, local, host, args.level)
         if fr is not None:
             out["multi_block_frames"] = fr
+        jp = job_pool_leg(zstd_amd, local, host, args.level)
+        if jp is not None:
+            out["job_pool_frame"] = jp
     del src, host
     if default_line:
         torch.cuda.empty_cache()

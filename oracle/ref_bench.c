@@ -11,6 +11,9 @@
  *   zref_bench file   <level> <chunkSize> <path> <seconds> <threads>   : same, input read from a file
  *   zref_bench cfile  <level> <chunkSize> <inPath> <outPath> <threads> : the file compressed ONCE, one frame per chunk, on
  *        `threads` cores, the frames written back to back to outPath (bench.py hashes that stream: full-size parity)
+ *   zref_bench mtfile <level> <workers> <inPath> <outPath> <jobSize>  : the WHOLE file as ONE frame by ZSTD_compress2 with
+ *        ZSTD_c_nbWorkers = workers (the reference's own job pool, lib/compress/zstdmt_compress.c; jobSize 0 = default), timed once
+ *        and written to outPath (bench.py's job_pool_frame leg hashes it; the bytes do not depend on the worker count)
  *   zref_bench dfile  <level> <chunkSize> <path> <seconds> <threads>   : DECODE speed (`zstd -b#` second figure,
  *        benchzstd.c:380-420): the file is compressed once into one frame per chunk, then ZSTD_decompressDCtx per frame on a
  *        reused DCtx is timed; threads split the frames.
@@ -266,8 +269,34 @@ static int cfile_main(char** argv)
     return 0;
 }
 
+/* mtfile: one frame through the reference's job pool */
+static int mtfile_main(char** argv)
+{
+    int const level = atoi(argv[2]), workers = atoi(argv[3]); int const jobSize = atoi(argv[6]);
+    size_t total; char* src = (char*)slurp(argv[4], &total);
+    size_t const bound = ZSTD_compressBound(total);
+    char* dst = (char*)malloc(bound ? bound : 1);
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r; FILE* o; double a, b;
+    if (!dst || !c) return 1;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, level);
+    if (ZSTD_isError(ZSTD_CCtx_setParameter(c, ZSTD_c_nbWorkers, workers))) { fprintf(stderr, "reference built without ZSTD_MULTITHREAD\n"); return 1; }
+    if (jobSize) ZSTD_CCtx_setParameter(c, ZSTD_c_jobSize, jobSize);
+    a = now_s(); r = ZSTD_compress2(c, dst, bound, src, total); b = now_s();
+    if (ZSTD_isError(r)) { fprintf(stderr, "%s\n", ZSTD_getErrorName(r)); return 1; }
+    o = fopen(argv[5], "wb");
+    if (!o) { perror(argv[5]); return 1; }
+    if (fwrite(dst, 1, r, o) != r) return 1;
+    fclose(o);
+    printf("{\"level\": %d, \"workers\": %d, \"jobSize\": %d, \"bytes\": %zu, \"csize\": %zu, \"seconds\": %.4f, \"MBps\": %.2f}\n",
+           level, workers, jobSize, total, r, b - a, (double)total / (b - a) / 1e6);
+    ZSTD_freeCCtx(c);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 7 && !strcmp(argv[1], "mtfile")) return mtfile_main(argv);
     if (argc >= 7 && !strcmp(argv[1], "cfile")) return cfile_main(argv);
     if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
     if (argc >= 8 && !strcmp(argv[1], "ddict")) return ddict_main(argv);
