@@ -12,7 +12,7 @@ import zstd_amd as z
 LEVEL = int(os.environ.get("LEVEL", "1"))
 SIZE = int(os.environ.get("SIZE", str(256 << 20)))
 ctx = z.Context(max_units=2048)
-for kind in ("datagen", "text"):
+for kind in os.environ.get("KINDS", "datagen,text").split(","):
     if kind == "datagen":
         a = z.datagen(SIZE, 50, 1)
     else:

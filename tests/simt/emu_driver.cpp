@@ -173,16 +173,17 @@ void emu_frame_fast(const uint8_t* src, const ZhipUnit* frames, uint32_t nFrames
     const ZhipSlot* const slots = sv.data();
     std::vector<ZhipSeq> seqs((size_t)nFrames * ZHIP_SEQ_CAP); std::vector<uint8_t> lits((size_t)nFrames * ZHIP_LIT_STRIDE);
     std::vector<uint16_t> stBits((size_t)nFrames * ZHIP_SEQ_CAP * 3);
-    size_t tabStride = 0; uint32_t ldsLog = 0;
+    size_t tabStride = 0; uint32_t ldsTab = 0;
     for (uint32_t i = 0; i < nFrames; i++) {
-        if (zhip::frame_table_in_lds(frames[i].strategy, frames[i].hashLog)) { if (frames[i].hashLog > ldsLog) ldsLog = frames[i].hashLog; }
+        uint32_t const mode = zhip::frame_table_mode(frames[i].strategy, frames[i].hashLog, frames[i].srcLen);
+        if (mode != zhip::ZHIP_FT_HBM) { uint32_t const b = zhip::frame_table_lds_bytes(mode, frames[i].hashLog); if (b > ldsTab) ldsTab = b; }
         else { size_t const w = zhip::frame_table_words(frames[i].strategy, frames[i].hashLog, frames[i].chainLog); if (w > tabStride) tabStride = w; }
     }
     std::vector<uint32_t> tabs((size_t)nFrames * tabStride + 1);
     std::vector<zhip::ZhipFrameState> states(nFrames ? nFrames : 1);
     ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
     zhip::ZhipFrameState* const stp = states.data();
-    simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsLog),
+    simt::launch({nFrames, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsTab),
                  [=] { zhip::k_frame_fast(src, frames, slots, nFrames, tb, tabStride, sq, lt, sb, out, outSize, stp, checks, (const zhip::ZhipJob*)nullptr); }, osThreads);
 }
 // one frame as jobs (ZSTD_c_nbWorkers semantics): units[i] / jobs[i] describe job i (units[i].srcOff = the frame start)
@@ -190,10 +191,11 @@ void emu_frame_jobs(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
                     uint32_t* outSize, const uint32_t* checks, int osThreads)
 {
     std::vector<ZhipSlot> sv(nJobs ? nJobs : 1);
-    size_t tabStride = 0; uint32_t ldsLog = 0;
+    size_t tabStride = 0; uint32_t ldsTab = 0;
     for (uint32_t i = 0; i < nJobs; i++) {
         sv[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; sv[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; sv[i].outOff = (uint64_t)i * outStride; sv[i].seqCap = ZHIP_SEQ_CAP; sv[i].pad0 = 0;
-        if (zhip::frame_table_in_lds(units[i].strategy, units[i].hashLog)) { if (units[i].hashLog > ldsLog) ldsLog = units[i].hashLog; }
+        uint32_t const mode = zhip::frame_table_mode(units[i].strategy, units[i].hashLog, (uint64_t)units[i].srcLen + jobs[i].prefixLen + 1u);
+        if (mode != zhip::ZHIP_FT_HBM) { uint32_t const b = zhip::frame_table_lds_bytes(mode, units[i].hashLog); if (b > ldsTab) ldsTab = b; }
         else { size_t const w = zhip::frame_table_words(units[i].strategy, units[i].hashLog, units[i].chainLog); if (w > tabStride) tabStride = w; }
     }
     const ZhipSlot* const slots = sv.data();
@@ -203,7 +205,7 @@ void emu_frame_jobs(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
     std::vector<zhip::ZhipFrameState> states(nJobs ? nJobs : 1);
     ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data(); uint32_t* const tb = tabs.data();
     zhip::ZhipFrameState* const stp = states.data();
-    simt::launch({nJobs, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsLog),
+    simt::launch({nJobs, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsTab),
                  [=] { zhip::k_frame_fast(src, units, slots, nJobs, tb, tabStride, sq, lt, sb, out, outSize, stp, checks, jobs); }, osThreads);
 }
 uint32_t emu_sizeof_job(void) { return (uint32_t)sizeof(zhip::ZhipJob); }

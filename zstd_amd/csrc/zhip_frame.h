@@ -48,17 +48,29 @@ struct ZhipJob {
     uint32_t pad0;
 };
 
-__host__ __device__ inline uint32_t frame_lds_bytes(uint32_t hashLog)
+// Where a frame's (or job's) hash table lives.  ZSTD_fast with hashLog <= 14: LDS — as 24-bit entries (Lds24Tab, 3 << hashLog bytes)
+// when every position of the walk, counted from the start of its window, stays below 2^24, else as 32-bit words (4 << hashLog);
+// larger tables and ZSTD_dfast's pair: HBM.  `span` = the bytes the workgroup walks over plus the prefix in front of them.
+enum { ZHIP_FT_HBM = 0, ZHIP_FT_LDS24 = 1, ZHIP_FT_LDS32 = 2 };
+__host__ __device__ inline uint32_t frame_table_mode(uint32_t strategy, uint32_t hashLog, uint64_t span)
+{
+    if (strategy != ZHIP_STRAT_FAST || hashLog > ZHIP_FRAME_LDS_HASHLOG) return ZHIP_FT_HBM;
+    return span < ((uint64_t)1 << 24) ? ZHIP_FT_LDS24 : ZHIP_FT_LDS32;
+}
+__host__ __device__ inline uint32_t frame_table_lds_bytes(uint32_t mode, uint32_t hashLog)
+{
+    return mode == ZHIP_FT_LDS24 ? (3u << hashLog) : (mode == ZHIP_FT_LDS32 ? (4u << hashLog) : 0u);
+}
+__host__ __device__ inline uint32_t frame_lds_bytes(uint32_t tableBytes /* largest frame_table_lds_bytes of the launch */)
 {
     uint32_t const base = (uint32_t)((sizeof(EntShared) + 15) & ~(size_t)15) + (uint32_t)sizeof(FrameShared);
-    return base + (hashLog && hashLog <= ZHIP_FRAME_LDS_HASHLOG ? (4u << hashLog) : 0u);    // hashLog 0: no table in LDS
+    return base + ((tableBytes + 15u) & ~15u);
 }
 // words of table memory a frame needs: ZSTD_fast one table, ZSTD_dfast the long table followed by the short one
 __host__ __device__ inline size_t frame_table_words(uint32_t strategy, uint32_t hashLog, uint32_t chainLog)
 {
     return ((size_t)1 << hashLog) + (strategy == ZHIP_STRAT_DFAST ? (size_t)1 << chainLog : 0);
 }
-__host__ __device__ inline bool frame_table_in_lds(uint32_t strategy, uint32_t hashLog) { return strategy == ZHIP_STRAT_FAST && hashLog <= ZHIP_FRAME_LDS_HASHLOG; }
 
 // ZSTD_writeFrameHeader (zstd_compress.c:4640-4690) with the content size known, no dictionary id
 __host__ __device__ inline uint32_t frame_header_bytes_multi(uint32_t n, uint32_t windowLog)
@@ -89,6 +101,14 @@ __device__ __attribute__((noinline)) void parse_fast_block_far(const uint8_t* sr
                                                                ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     parse_fast_block<MLS, WideTab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
+}
+
+template <uint32_t MLS>
+__device__ __attribute__((noinline)) void parse_fast_block_far24(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
+                                                                 uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, Lds24Tab T,
+                                                                 ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    parse_fast_block<MLS, Lds24Tab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
 }
 
 template <uint32_t MLS>
@@ -128,18 +148,66 @@ __device__ inline void frame_fill_prefix(const uint8_t* __restrict__ src, const 
     }
 }
 
+// the same fill for a 24-bit LDS table (ZSTD_fast only).  No 24-bit atomic exists, so the prefix is walked in pieces that do not cross
+// a multiple of 64 KB: inside a piece every writer has the same hi byte.  Phase one: every writer stores its entry — whatever earlier
+// pieces left in the slot is gone, as it would be in the serial loop.  Phase two: a 16-bit atomic max on lo[] (compare-and-swap on the
+// 32-bit word that holds the half) leaves the piece's largest position.  Two barriers per piece, a trip count that does not depend
+// on the data.  (A "store again until nobody lost" loop is NOT safe here: its exit test reads LDS, the compiler cannot see that it is
+// uniform, restructures the loop per lane — and the lane that resets the flag sits masked while its wave runs the next barrier.)
+__device__ inline void frame_fill_prefix24(const uint8_t* __restrict__ src, const ZhipUnit& u, const Lds24Tab& T, uint32_t* words /* lo[] as 32-bit words */,
+                                           uint32_t p0, uint32_t p1)
+{
+    if (p1 - p0 <= 8) return;
+    uint32_t const maxDict = 8u << (u.hashLog < 28 ? u.hashLog : 28);
+    if (p1 - p0 > maxDict) p0 = p1 - maxDict;
+    uint32_t const stop = p1 - 8 + 2;
+    for (uint32_t base = p0; base + 3 < stop; ) {
+        uint32_t const segEnd = (base | 0xFFFFu) + 1u;                                    // first position of the next 64 KB segment
+        uint32_t const ip = base + 3u * threadIdx.x;
+        bool const mine = ip + 3 < stop && ip < segEnd;
+        uint32_t h = 0;
+        if (mine) {
+            uint64_t const b = ld64(src + ip);
+            switch (u.minMatch) { case 5: h = hash_pos<5>(b, 32 - u.hashLog); break; case 6: h = hash_pos<6>(b, 32 - u.hashLog); break;
+                                  case 7: h = hash_pos<7>(b, 32 - u.hashLog); break; case 8: h = hash_pos<8>(b, 32 - u.hashLog); break;
+                                  default: h = hash_pos<4>(b, 32 - u.hashLog); break; }
+            tab_put(T, h, ip);
+        }
+        __syncthreads();
+        if (mine) {
+            uint32_t* const w = words + (h >> 1);
+            uint32_t const sh = (h & 1u) * 16u, lo16 = ip & 0xFFFFu;
+            uint32_t old = atomicOr(w, 0u);
+            while (((old >> sh) & 0xFFFFu) < lo16) {
+                uint32_t const got = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (lo16 << sh));
+                if (got == old) break;
+                old = got;
+            }
+        }
+        __syncthreads();
+        uint32_t const next = base + 3u * ZHIP_ENT_THREADS;
+        base = next < segEnd ? next : base + 3u * ((segEnd - base + 2u) / 3u);            // stay on the every-third grid across the border
+    }
+}
+
 // job == nullptr: the whole input src[0, u.srcLen) as ONE frame (ZSTD_compress2 without workers: one context, one frame chunk).
-// job != nullptr: one job of a frame (see ZhipJob); src is the frame start.
-__device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, ZhipSeq* seqs, uint8_t* lits,
+// job != nullptr: one job of a frame (see ZhipJob); src is the start of the job's WINDOW (its prefix) — one byte before it for a job
+// that is not the frame's first — and positions count from there.
+// use24: the table is T24 (LDS, 24-bit entries), else T.
+__device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, const Lds24Tab& T24, bool use24, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum,
                                   const ZhipJob* __restrict__ job)
 {
     int const t = (int)threadIdx.x, wv = t >> 6;
-    uint32_t const j0 = job ? job->start : 0u;                               // the section [j0, jEnd) of the frame
-    uint32_t const n = u.srcLen, jEnd = j0 + n;
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST), lastJob = !job || (job->flags & ZHIP_JOB_LAST);
-    uint32_t const winStart = job ? j0 - job->prefixLen : 0u;
+    // A table entry of 0 means "empty", and a frame never inserts its position 0 (zstd_fast.c:238).  A later job's prefix starts with
+    // a position the reference CAN match (its indices start at 2), so such a job counts from 1: src points one byte before its window.
+    // (Not when the window starts at the frame's byte 0 — jobSize <= overlap, second job — where no byte exists in front of it: there
+    // position 0 stays unstorable, which matters only if the prefix fill reaches it, i.e. 8 << hashLog >= 512 KB: see DESIGN.md §8.)
+    uint32_t const winStart = (first || job->start == job->prefixLen) ? 0u : 1u;
+    uint32_t const j0 = winStart + (job ? job->prefixLen : 0u);              // the section [j0, jEnd) behind the prefix [winStart, j0)
+    uint32_t const n = u.srcLen, jEnd = j0 + n;
     uint32_t const frameSize = job ? (uint32_t)job->frameSize : n;
     uint32_t op = first ? frame_header_bytes_multi(frameSize, u.windowLog) : 0u;
     if (first && t == 0) write_frame_header_multi(out, frameSize, u.windowLog, withChecksum);
@@ -151,10 +219,11 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
         }
         return;
     }
-    for (uint32_t i = (uint32_t)t; i < (uint32_t)frame_table_words(u.strategy, u.hashLog, u.chainLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table(s) (:2020)
+    if (use24) { lds_u32* const z = (lds_u32*)T24.lo; for (uint32_t i = (uint32_t)t; i < (3u << u.hashLog) >> 2; i += ZHIP_ENT_THREADS) z[i] = 0; }   // lo[] and hi[] are contiguous
+    else for (uint32_t i = (uint32_t)t; i < (uint32_t)frame_table_words(u.strategy, u.hashLog, u.chainLog); i += ZHIP_ENT_THREADS) T.w[i] = 0;     // fresh table(s) (:2020)
     if (t == 0) { st->ent.hufRepeat = 0; st->ent.hufMaxSym = 0; st->ent.fseRepeat[0] = 0; st->ent.fseRepeat[1] = 0; st->ent.fseRepeat[2] = 0; }
     __syncthreads();
-    if (job && job->prefixLen) { frame_fill_prefix(src, u, T, winStart, j0); __syncthreads(); }
+    if (job && job->prefixLen) { if (use24) frame_fill_prefix24(src, u, T24, T.w, winStart, j0); else frame_fill_prefix(src, u, T, winStart, j0); __syncthreads(); }
     uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u;     // later jobs: ZSTD_invalidateRepCodes (:741)
     long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
     uint32_t pos = j0;
@@ -188,7 +257,15 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
                     case 8:  parse_dfast_block_far<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
                     default: parse_dfast_block_far<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
                     }
-                } else
+                } else if (use24)
+                switch (u.minMatch) {
+                case 5:  parse_fast_block_far24<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 6:  parse_fast_block_far24<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 7:  parse_fast_block_far24<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 8:  parse_fast_block_far24<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                default: parse_fast_block_far24<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                }
+                else
                 switch (u.minMatch) {                                        // the hash width is a compile-time constant inside the parser
                 case 5:  parse_fast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
                 case 6:  parse_fast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;

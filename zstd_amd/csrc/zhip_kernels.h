@@ -249,8 +249,8 @@ k_entropy_small(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
 
 // One workgroup per multi-block frame (zhip_frame.h).  frames[i].srcLen is the whole input of frame i (< 2^31); its slot gives
 // one block's worth of sequence / literal room (reused block after block) and the frame's output room.  Dynamic LDS =
-// frame_lds_bytes(largest hashLog); frames whose table does not fit LDS use tabs + i * tabStride words.
-__global__ void __launch_bounds__(ZHIP_ENT_THREADS)
+// Dynamic LDS = frame_lds_bytes(largest frame_table_lds_bytes); frames whose table does not fit LDS use tabs + i * tabStride words.
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)      // two workgroups per CU (LDS: 2 x 75 KB): at most 256 registers per lane
 k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
              uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
              uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
@@ -264,15 +264,20 @@ k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frame
     EntShared* const sh = (EntShared*)smem;
     size_t const shBytes = (sizeof(EntShared) + 15) & ~(size_t)15;
     FrameShared* const fs = (FrameShared*)(smem + shBytes);
-    WideTab T;
-    T.w = frame_table_in_lds(u.strategy, u.hashLog) ? (uint32_t*)(smem + shBytes + sizeof(FrameShared)) : tabs + (size_t)fi * tabStride;
-    const uint8_t* const p = src + u.srcOff;
+    // a job's positions count from the start of its window (the prefix in front of its section), a frame's from the frame start
+    const ZhipJob* const job = jobs ? jobs + fi : (const ZhipJob*)nullptr;
+    uint32_t const mode = frame_table_mode(u.strategy, u.hashLog, (uint64_t)u.srcLen + (job ? job->prefixLen + 1u : 0u));
+    unsigned char* const ltab = smem + shBytes + sizeof(FrameShared);
+    WideTab T; Lds24Tab T24;
+    T.w = mode == ZHIP_FT_HBM ? tabs + (size_t)fi * tabStride : (uint32_t*)ltab;
+    T24.lo = (lds_u16*)(uintptr_t)ltab; T24.hi = (lds_u8*)(uintptr_t)(ltab + (2u << u.hashLog));
+    const uint8_t* const p = src + u.srcOff + (job ? (size_t)(job->start - job->prefixLen) : 0u) - ((job && !(job->flags & ZHIP_JOB_FIRST) && job->start != job->prefixLen) ? 1 : 0);
     ZhipSeq* const sq = seqs + sl.seqOff;
     uint8_t* const lt = lits + sl.litOff;
     uint16_t* const sb = stBits + 3 * sl.seqOff;
     uint8_t* const o = out + sl.outOff;
     bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[fi].frameIdx : fi] : 0u;      // jobs: the checksum of the whole frame
-    frame_fast(p, u, T, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, jobs ? jobs + fi : (const ZhipJob*)nullptr);
+    frame_fast(p, u, T, T24, mode == ZHIP_FT_LDS24, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, job);
 }
 
 // jobs -> frames: frameSizes[f] = sum of the compressed sizes of frame f's jobs (frameSizes zeroed by the caller)

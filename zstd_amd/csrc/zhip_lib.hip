@@ -577,7 +577,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
     if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
     if (nFrames > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu frames > context capacity %zu", nFrames, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
     const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
-    size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsLog = 0; unsigned long long totalSrc = 0;
+    size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsTab = 0; unsigned long long totalSrc = 0;
     if (mt.on) { c->hJobs.clear(); c->hFrameUnits.resize(nFrames); }
     for (size_t i = 0; i < nFrames; i++) {
         if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] >= (1ull << 31)) { snprintf(c->err, sizeof(c->err), "frame %zu: inputs of 2 GiB and more are not implemented on device", i); return ZERR(ZE_srcSize_wrong); }
@@ -616,8 +616,11 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         }
         if (mt.on) { ZhipUnit& fu = c->hFrameUnits[i]; fu = c->hUnits[nU - 1]; fu.srcLen = (uint32_t)n; }
         bound += zhip::host_compress_bound(n);
-        if (zhip::frame_table_in_lds(cp.strategy, cp.hashLog)) { if (cp.hashLog > ldsLog) ldsLog = cp.hashLog; }
-        else { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
+        {   // the longest walk of this frame: a section plus its prefix (the whole input without jobs)
+            uint32_t const mode = zhip::frame_table_mode(cp.strategy, cp.hashLog, (unsigned long long)(n < section ? n : section) + overlap + 1);
+            if (mode == zhip::ZHIP_FT_HBM) { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
+            else { uint32_t const b = zhip::frame_table_lds_bytes(mode, cp.hashLog); if (b > ldsTab) ldsTab = b; }
+        }
         totalSrc += n;
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
@@ -651,7 +654,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         HIPCHK(c, hipMemcpyAsync(c->dJobs, c->hJobs.data(), nU * sizeof(zhip::ZhipJob), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->dFrameUnits, c->hFrameUnits.data(), nFrames * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     }
-    size_t const lds = zhip::frame_lds_bytes(ldsLog);
+    size_t const lds = zhip::frame_lds_bytes(ldsTab);
     HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nU * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nU * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));

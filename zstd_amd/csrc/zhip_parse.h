@@ -110,6 +110,16 @@ __device__ __forceinline__ void tab_mark(const WideTab& T, uint32_t h, uint32_t 
 __device__ __forceinline__ uint32_t tab_peek(const WideTab& T, uint32_t h) { return T.w[h]; }
 __device__ __forceinline__ void tab_unmark(const WideTab& T, uint32_t h, uint32_t old) { T.w[h] = old; }
 
+// 24-bit positions in LDS for the blocks of a frame or job whose positions stay below 2^24: 16 low bits + one byte, 3 bytes per
+// entry instead of WideTab's 4 (48 KB at hashLog 14: two frame workgroups per CU instead of one) and LDS-typed pointers (ds_ instead of
+// flat_ instructions).  The marker of the duplicate detector only ever touches lo[], like FastTab's.
+struct Lds24Tab { lds_u16* lo; lds_u8* hi; };
+__device__ __forceinline__ void tab_put(const Lds24Tab& T, uint32_t h, uint32_t pos) { T.lo[h] = (uint16_t)pos; T.hi[h] = (uint8_t)(pos >> 16); }
+__device__ __forceinline__ uint32_t tab_get(const Lds24Tab& T, uint32_t h, bool) { return (uint32_t)T.lo[h] | ((uint32_t)T.hi[h] << 16); }
+__device__ __forceinline__ void tab_mark(const Lds24Tab& T, uint32_t h, uint32_t v) { T.lo[h] = (uint16_t)v; }
+__device__ __forceinline__ uint32_t tab_peek(const Lds24Tab& T, uint32_t h) { return T.lo[h]; }
+__device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
+
 // ------------------------------------------------------------------ wave-wide match extension
 // Every load below is clamped to [0, n-8] so that no lane ever reads outside the unit; `sh` bytes are then shifted out.
 // equal leading bytes (0..8) of the 8-byte windows at q and q-off, bounded by the end of the unit (nm8 = n - 8)
