@@ -18,9 +18,9 @@ for kind in os.environ.get("KINDS", "datagen,text").split(","):
     else:
         from _libs import text_like
         a = np.tile(text_like(16 << 20, 1), SIZE // (16 << 20))
-    for js in (0, 524288, 1 << 20, 4 << 20):
+    for js in [int(x) for x in os.environ.get("JOBS", "0,524288,1048576,4194304").split(",")]:
         for ck in (False, True):
-            if ck and js != 0:
+            if ck and (js != 0 or "JOBS" in os.environ):
                 continue
             ctx.set_checksum(ck)
             for rep in range(2):

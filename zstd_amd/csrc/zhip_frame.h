@@ -95,7 +95,7 @@ __device__ inline uint32_t write_frame_header_multi(uint8_t* op, uint32_t n, uin
 
 // the block parser as a called function: the frame kernel holds five instantiations of it next to the whole block encoder,
 // and inlined they left the scalar register file with ~1000 spilled values
-template <uint32_t MLS>
+template <uint32_t MLS, int OCC>
 __device__ __attribute__((noinline)) void parse_fast_block_far(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
                                                                uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, WideTab T,
                                                                ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
@@ -103,7 +103,7 @@ __device__ __attribute__((noinline)) void parse_fast_block_far(const uint8_t* sr
     parse_fast_block<MLS, WideTab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
 }
 
-template <uint32_t MLS>
+template <uint32_t MLS, int OCC>
 __device__ __attribute__((noinline)) void parse_fast_block_far24(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
                                                                  uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, Lds24Tab T,
                                                                  ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
@@ -111,7 +111,7 @@ __device__ __attribute__((noinline)) void parse_fast_block_far24(const uint8_t* 
     parse_fast_block<MLS, Lds24Tab>(src, b0, n, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, meta);
 }
 
-template <uint32_t MLS>
+template <uint32_t MLS, int OCC>
 __device__ __attribute__((noinline)) void parse_dfast_block_far(const uint8_t* src, uint32_t b0, uint32_t n, uint32_t prefixLow, uint32_t maxRep,
                                                                 uint32_t rep1, uint32_t rep2, uint32_t rep3, ZhipUnit u, unsigned char* scratch,
                                                                 uint32_t* tabL, uint32_t* tabS, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
@@ -194,6 +194,7 @@ __device__ inline void frame_fill_prefix24(const uint8_t* __restrict__ src, cons
 // job != nullptr: one job of a frame (see ZhipJob); src is the start of the job's WINDOW (its prefix) — one byte before it for a job
 // that is not the frame's first — and positions count from there.
 // use24: the table is T24 (LDS, 24-bit entries), else T.
+template <int OCC /* the kernel's waves per SIMD: its callees are instantiated per kernel so that each gets that kernel's register budget */>
 __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, const Lds24Tab& T24, bool use24, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum,
@@ -251,27 +252,27 @@ __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUni
                 if (u.strategy == ZHIP_STRAT_DFAST) {
                     uint32_t* const tL = T.w; uint32_t* const tS = T.w + ((size_t)1 << u.hashLog);
                     switch (u.minMatch) {
-                    case 5:  parse_dfast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
-                    case 6:  parse_dfast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
-                    case 7:  parse_dfast_block_far<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
-                    case 8:  parse_dfast_block_far<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
-                    default: parse_dfast_block_far<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 5:  parse_dfast_block_far<5, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 6:  parse_dfast_block_far<6, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 7:  parse_dfast_block_far<7, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    case 8:  parse_dfast_block_far<8, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
+                    default: parse_dfast_block_far<4, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, fs->dfScratch, tL, tS, seqs, lits, &fs->meta); break;
                     }
                 } else if (use24)
                 switch (u.minMatch) {
-                case 5:  parse_fast_block_far24<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
-                case 6:  parse_fast_block_far24<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
-                case 7:  parse_fast_block_far24<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
-                case 8:  parse_fast_block_far24<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
-                default: parse_fast_block_far24<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 5:  parse_fast_block_far24<5, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 6:  parse_fast_block_far24<6, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 7:  parse_fast_block_far24<7, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                case 8:  parse_fast_block_far24<8, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
+                default: parse_fast_block_far24<4, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T24, seqs, lits, &fs->meta); break;
                 }
                 else
                 switch (u.minMatch) {                                        // the hash width is a compile-time constant inside the parser
-                case 5:  parse_fast_block_far<5>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
-                case 6:  parse_fast_block_far<6>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
-                case 7:  parse_fast_block_far<7>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
-                case 8:  parse_fast_block_far<8>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
-                default: parse_fast_block_far<4>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 5:  parse_fast_block_far<5, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 6:  parse_fast_block_far<6, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 7:  parse_fast_block_far<7, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                case 8:  parse_fast_block_far<8, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
+                default: parse_fast_block_far<4, OCC>(src, pos, end, prefixLow, maxRep, rep1, rep2, rep3, u, T, seqs, lits, &fs->meta); break;
                 }
             }
             __syncthreads();

@@ -250,11 +250,11 @@ k_entropy_small(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
 // One workgroup per multi-block frame (zhip_frame.h).  frames[i].srcLen is the whole input of frame i (< 2^31); its slot gives
 // one block's worth of sequence / literal room (reused block after block) and the frame's output room.  Dynamic LDS =
 // Dynamic LDS = frame_lds_bytes(largest frame_table_lds_bytes); frames whose table does not fit LDS use tabs + i * tabStride words.
-__global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)      // two workgroups per CU (LDS: 2 x 75 KB): at most 256 registers per lane
-k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
+template <int OCC>
+__device__ __forceinline__ void frame_kernel_body(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
              uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
              uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
-             const uint32_t* __restrict__ checks, const ZhipJob* __restrict__ jobs /* nullptr: every unit is a whole frame; else unit i is one job of frame jobs[i].frameIdx */)
+             const uint32_t* __restrict__ checks, const ZhipJob* __restrict__ jobs)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const fi = blockIdx.x;
@@ -277,7 +277,26 @@ k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frame
     uint16_t* const sb = stBits + 3 * sl.seqOff;
     uint8_t* const o = out + sl.outOff;
     bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[fi].frameIdx : fi] : 0u;      // jobs: the checksum of the whole frame
-    frame_fast(p, u, T, T24, mode == ZHIP_FT_LDS24, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, job);
+    frame_fast<OCC>(p, u, T, T24, mode == ZHIP_FT_LDS24, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, job);
+}
+// launches with a table in LDS (ZSTD_fast, hashLog <= 14): two workgroups per CU (2 x 75 KB of LDS) -> 256 registers per lane
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)
+k_frame_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
+             uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
+             uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
+             const uint32_t* __restrict__ checks, const ZhipJob* __restrict__ jobs /* nullptr: every unit is a whole frame; else unit i is one job of frame jobs[i].frameIdx */)
+{
+    frame_kernel_body<2>(src, frames, slots, nFrames, tabs, tabStride, seqs, lits, stBits, out, outSize, states, checks, jobs);
+}
+// launches whose tables all live in HBM (ZSTD_dfast, larger ZSTD_fast tables): LDS is 27 KB per workgroup, so the register file
+// decides — four workgroups per CU at 128 registers per lane
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS, 4)
+k_frame_hbm(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ frames, const ZhipSlot* __restrict__ slots, uint32_t nFrames,
+            uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits,
+            uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states,
+            const uint32_t* __restrict__ checks, const ZhipJob* __restrict__ jobs)
+{
+    frame_kernel_body<4>(src, frames, slots, nFrames, tabs, tabStride, seqs, lits, stBits, out, outSize, states, checks, jobs);
 }
 
 // jobs -> frames: frameSizes[f] = sum of the compressed sizes of frame f's jobs (frameSizes zeroed by the caller)

@@ -655,7 +655,8 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         HIPCHK(c, hipMemcpyAsync(c->dFrameUnits, c->hFrameUnits.data(), nFrames * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     }
     size_t const lds = zhip::frame_lds_bytes(ldsTab);
-    HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    bool const hbmOnly = ldsTab == 0 && !getenv("ZHIP_FRAME_NO_HBM_KERNEL");           // no table in LDS: the variant compiled for four workgroups per CU
+    HIPCHK(c, hipFuncSetAttribute(hbmOnly ? (const void*)zhip::k_frame_hbm : (const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nU * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nU * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -664,9 +665,14 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         hipLaunchKernelGGL(zhip::k_xxh64_wave, dim3((unsigned)nFrames), dim3(64), ZHIP_XXH_WAVE_LDS, s, (const uint8_t*)srcDev, mt.on ? c->dFrameUnits : c->dUnits, (uint32_t)nFrames, c->dChecks);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(zhip::k_frame_fast, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), lds, s,
-                       (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nU, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
-                       c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr);
+    if (hbmOnly)
+        hipLaunchKernelGGL(zhip::k_frame_hbm, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), lds, s,
+                           (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nU, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
+                           c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr);
+    else
+        hipLaunchKernelGGL(zhip::k_frame_fast, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), lds, s,
+                           (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nU, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
+                           c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nU, c->dOutOff);
