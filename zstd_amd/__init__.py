@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzstd_hip.so")
+LIB_PATH = os.environ.get("ZHIP_LIB") or os.path.join(_HERE, "libzstd_hip.so")     # $ZHIP_LIB: another build of the same library (A/B timing)
 UNIT_SIZE_MAX = 131072
 _lib = None
 

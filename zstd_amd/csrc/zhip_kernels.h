@@ -11,6 +11,17 @@
 #include "zhip_frame.h"
 #include "zhip_decode.h"
 
+// register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
+#ifndef ZHIP_DFAST_OCC
+#define ZHIP_DFAST_OCC
+#endif
+#ifndef ZHIP_LAZY_OCC
+#define ZHIP_LAZY_OCC
+#endif
+#ifndef ZHIP_ENT_OCC
+#define ZHIP_ENT_OCC
+#endif
+
 namespace zhip {
 
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
@@ -38,7 +49,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 
 // Stage 1 for strategy dfast: one wavefront per unit, the unit's two hash tables live in HBM/L2 (tabs + ui * tabStride
 // words: long table, then short table).  Dynamic LDS = dfast_lds_bytes().
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) ZHIP_DFAST_OCC
 k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
               uint32_t* __restrict__ tabs, size_t tabStride,
               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
@@ -171,7 +182,7 @@ k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
     else for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = hc_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.chainLog);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) ZHIP_LAZY_OCC
 k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
@@ -213,7 +224,7 @@ k_parse_ext(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
 // (zhip_entropy.h): one 256-thread workgroup per unit (dynamic LDS = sizeof(EntShared)) and, for units of at most
 // ZHIP_ENT_SMALL_MAX bytes, one wavefront per unit (k_entropy_small, sizeof(EntSharedSmall)).  sizeClass: 0 = every unit,
 // 1 = only the units above ZHIP_ENT_SMALL_MAX (the small ones belong to the other launch).
-__global__ void __launch_bounds__(ZHIP_ENT_THREADS)
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS) ZHIP_ENT_OCC
 k_entropy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
           const ZhipSeq* __restrict__ seqs, const ZhipParse* __restrict__ metas,
           const uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits, uint8_t* __restrict__ out, uint32_t* __restrict__ outSize,
