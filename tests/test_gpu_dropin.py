@@ -124,7 +124,9 @@ def test_errors_use_the_reference_codes_and_nothing_falls_back_to_the_host(env):
         assert not S.ZSTD_isError(k1) and d1[:k1].tobytes() == d2[:k2].tobytes()
         k3 = S.ZSTD_compressCCtx(c, _buf(d1), cap, _buf(a), len(a), 3)          # ignores the flag, like the reference
         assert d1[:k3].tobytes() == expect_unit(lo, lr, a, 3)
-    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 400, 2))         # nbWorkers
+    assert S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 160, 1))         # ZSTD_c_enableLongDistanceMatching: not on the device
+    assert S.ZSTD_CCtx_setParameter(c, 400, 2) == 0 and S.ZSTD_isError(S.ZSTD_CCtx_setParameter(c, 400, 257))   # nbWorkers: accepted (job-pool frames), bounded
+    assert S.ZSTD_CCtx_setParameter(c, 400, 0) == 0
     assert S.ZSTD_CCtx_setParameter(c, 101, 0) == 0                    # windowLog 0 = default
     S.ZSTD_freeCCtx(c)
     r, dst = shim_compress2(S, a, 1, cap=64)                           # far too small
