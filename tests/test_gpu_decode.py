@@ -254,3 +254,12 @@ def test_seekable_random_access(env, checksum):
         bad = bytearray(blob); bad[len(blob) - 9 - 4] ^= 1      # the last frame's checksum in the table
         with pytest.raises(z.ZhipError, match="22"):
             dctx.seekable_read(bytes(bad), len(a) - 100, 100)
+
+
+def test_oversized_raw_and_rle_blocks_like_the_one_shot_reference(env):
+    """raw / RLE blocks above 128 KB: accepted, as ZSTD_decompress accepts them (tests/test_oracle_decode.py pins that to the reference)"""
+    z = env[0] if isinstance(env, tuple) else env
+    from test_oracle_decode import oversized_block_frames
+    d = z.DContext()
+    for frame, content in oversized_block_frames():
+        assert d.decompress(frame) == content, len(content)

@@ -184,3 +184,27 @@ def test_frames_without_content_size_small_windows_checksums(lo):
             zb = np.frombuffer(z, dtype=np.uint8)
             assert lo.zo_frame_info(_buf(zb), len(zb), C.byref(cs_), C.byref(ds_)) == 0 and cs_.value == len(z)
             assert ds_.value == (len(a) if cs else 2**64 - 1)
+
+
+def oversized_block_frames():
+    """hand-built frames whose raw / RLE blocks exceed the 128 KB block maximum: ZSTD_decompress (one-shot, zstd_decompress.c:1012-1024)
+    only checks them against the destination, unlike ZSTD_decompressContinue (:1313, :1365) — the one-shot behaviour is the contract"""
+    rng = np.random.default_rng(77)
+    out = []
+    for n, kind in ((200000, "raw"), (200000, "rle"), (131073, "raw"), (2000000, "rle")):
+        hdr = bytes([0x28, 0xB5, 0x2F, 0xFD, (2 << 6) | (1 << 5)]) + n.to_bytes(4, "little")          # single segment, 4-byte content size
+        if kind == "raw":
+            payload = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+            out.append((hdr + (1 | (0 << 1) | (n << 3)).to_bytes(3, "little") + payload, payload))
+        else:
+            out.append((hdr + (1 | (1 << 1) | (n << 3)).to_bytes(3, "little") + b"\x07", b"\x07" * n))
+    return out
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_oversized_raw_and_rle_blocks_like_the_one_shot_reference(lo):
+    lr = load_ref()
+    for frame, content in oversized_block_frames():
+        want = ref_decompress(lr, bytearray(frame), len(content) + 16)
+        got = oracle_decompress(lo, bytearray(frame), len(content) + 16)
+        assert want == content and got == content, len(content)
