@@ -573,7 +573,7 @@ def job_pool_leg(zstd_amd, local, host, level):
     ctx.close()
     res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
            "ratio": round(n / len(out), 4),
-           "note": "k_frame_fast with a job table: one frame, jobs = independent workgroups (LDS: one per CU at level 1); never `value`"}
+           "note": "k_frame_fast with a job table: one frame, jobs = independent workgroups, two per CU (48 KB 24-bit LDS table each); never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
         tin, tout = f"/tmp/zhip_mt_in_{os.getpid()}.bin", f"/tmp/zhip_mt_out_{os.getpid()}.bin"

@@ -6,11 +6,12 @@
 //   * the repcode history and the literals' Huffman table — both only when the block was emitted compressed
 //     (ZSTD_blockState_confirmRepcodesAndEntropyTables, :3312-3320),
 //   * `savings`, which moves the block boundary from 128 KB to 92 KB (ZSTD_optimalBlockSize, :4494-4518).
-// The chain is strictly serial, so a frame is one 256-thread workgroup: wave 0 runs the ZSTD_fast parser of zhip_parse.h (table of
-// 32-bit positions in LDS when 4 << hashLog fits, in HBM otherwise) or the ZSTD_dfast parser of zhip_parse_dfast.h (two tables of
-// plain 32-bit positions in HBM) on the block, then the four waves run the block
+// The chain is strictly serial, so a frame is one 256-thread workgroup: wave 0 runs the ZSTD_fast parser of zhip_parse.h (hashLog <= 14:
+// table in LDS, 24-bit entries when the positions fit — two workgroups per CU — else 32-bit; larger tables in HBM) or the ZSTD_dfast
+// parser of zhip_parse_dfast.h (two tables of plain 32-bit positions in HBM) on the block, then the four waves run the block
 // encoder of zhip_entropy.h with the previous block's Huffman table as the "repeat" candidate.  Independent frames of a
-// batch run side by side, one workgroup each.
+// batch run side by side, one workgroup each — and so do the JOBS of one frame when it is compressed the way the reference's
+// job pool compresses it (ZhipJob below).
 #pragma once
 #include "zhip_parse.h"
 #include "zhip_parse_dfast.h"
@@ -34,7 +35,8 @@ struct ZhipFrameState { ZhipDictEntropy ent; };
 // One JOB of a frame compressed the way ZSTD_c_nbWorkers >= 1 compresses it (zstdmt_compress.c:683-790): a section of the input that
 // starts from a fresh context which has only loaded the `prefixLen` bytes in front of it (the overlap with the previous job) as a
 // raw-content prefix; jobs are independent of each other, so a frame's jobs run side by side, one workgroup each, and their blocks,
-// concatenated in job order, are the frame.  Positions are relative to the frame start.
+// concatenated in job order, are the frame.  `start` is relative to the frame start; inside the kernel a job counts positions from
+// the start of its own window (see frame_fast), so that they fit the 24-bit LDS table whatever the frame's size.
 #define ZHIP_JOB_FIRST 1u          /* writes the frame header; repcodes start at {1,4,8} */
 #define ZHIP_JOB_LAST  2u          /* its final block carries the last-block bit; the frame checksum follows */
 #define ZHIP_JOB_CHUNK (512u * 1024u)   /* a job is compressed in chunks of 4 blocks, each its own frame-chunk call (:753) */
