@@ -81,3 +81,14 @@ def test_wave_checksum_kernel_matches_xxh64(libs):
         o = int(units[i]["srcOff"])
         want = lo.zo_xxh64(src[o:].ctypes.data_as(C.c_void_p), n, 0) & 0xFFFFFFFF
         assert int(chk[i]) == want, n
+
+
+@pytest.mark.parametrize("level,js,ov", [(2, 524288, 8), (3, 524288, 7)])
+def test_job_window_starting_at_the_frames_first_byte(libs, level, js, ov):
+    """jobSize <= overlap: the second job's prefix is everything before it, and the reference can match the frame's very first byte
+    from it (its indices start at 2).  On the device a job counts from 1 with src one byte before its window; here that byte does
+    not exist, and the parsers must not touch position 0 (tab_guard / non-empty candidates only).  HBM tables (hashLog >= 16)."""
+    lo, le = libs
+    a = datagen(lo, 700000, 20, 10).copy()
+    a[js: js + 64] = a[0: 64]
+    assert emu_compress_frame_jobs(le, lo, a, level, js, ov, False) == oracle_frame_mt(lo, a, level, js, ov, False)

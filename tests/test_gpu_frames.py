@@ -269,3 +269,16 @@ def test_shim_nbworkers_mode(env):
     r = S.ZSTD_compressCCtx(c, _buf(dst), cap, _buf(a), a.size, 1)
     assert not S.ZSTD_isError(r) and dst[:r].tobytes() != oracle_frame_mt(lo, a, 1) and z.DContext().decompress(dst[:r].tobytes()) == a.tobytes()
     S.ZSTD_freeCCtx(c)
+
+
+def test_job_window_starting_at_the_frames_first_byte(env):
+    """jobSize <= overlap: the second job's window starts at the frame's byte 0, which the reference can match from that job; the frame
+    is the FIRST thing in its device allocation here, so a stray read in front of it would fault"""
+    z, lo = env
+    ctx = z.Context(max_units=16)
+    for level, js, ov in ((2, 524288, 8), (3, 524288, 7), (1, 524288, 9)):
+        for seed in (10, 11):
+            a = datagen(lo, 700000, 20, seed).copy()
+            a[js: js + 64] = a[0: 64]
+            out = ctx.compress_frames([a], level, workers=1, job_size=js, overlap_log=ov)[0]
+            assert out == oracle_frame_mt(lo, a, level, js, ov), (level, seed)

@@ -192,6 +192,18 @@ __device__ inline void frame_fill_prefix24(const uint8_t* __restrict__ src, cons
     }
 }
 
+// Does a job count its positions from 1 (src one byte before its window)?  Not the frame's first job (a frame never inserts its
+// position 0, like the reference).  Every other job does — except in one corner: its window starts at the frame's byte 0 (jobSize <=
+// overlap, second job), where no byte exists in front of the window.  With the tables in HBM the parsers never touch position 0
+// (tab_guard; the ZSTD_dfast parser only reads candidates of non-empty entries), so the shift is still made; with a table in LDS
+// (hashLog <= 14) the job keeps counting from 0, which is exact there: the prefix fill covers the last 8 << hashLog <= 128 KB of a
+// prefix that is at least 512 KB long in this corner, so the frame's byte 0 is never inserted anyway.
+__host__ __device__ inline uint32_t frame_job_shift(const ZhipJob* job, uint32_t tableMode)
+{
+    if (!job || (job->flags & ZHIP_JOB_FIRST)) return 0u;
+    return (job->start == job->prefixLen && tableMode != ZHIP_FT_HBM) ? 0u : 1u;
+}
+
 // job == nullptr: the whole input src[0, u.srcLen) as ONE frame (ZSTD_compress2 without workers: one context, one frame chunk).
 // job != nullptr: one job of a frame (see ZhipJob); src is the start of the job's WINDOW (its prefix) — one byte before it for a job
 // that is not the frame's first — and positions count from there.
@@ -200,15 +212,13 @@ template <int OCC /* the kernel's waves per SIMD: its callees are instantiated p
 __device__ inline void frame_fast(const uint8_t* __restrict__ src, const ZhipUnit& u, const WideTab& T, const Lds24Tab& T24, bool use24, ZhipSeq* seqs, uint8_t* lits,
                                   uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, FrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum,
-                                  const ZhipJob* __restrict__ job)
+                                  const ZhipJob* __restrict__ job, uint32_t winStart /* 0, or 1 for a job whose src is one byte before its window */)
 {
     int const t = (int)threadIdx.x, wv = t >> 6;
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST), lastJob = !job || (job->flags & ZHIP_JOB_LAST);
     // A table entry of 0 means "empty", and a frame never inserts its position 0 (zstd_fast.c:238).  A later job's prefix starts with
-    // a position the reference CAN match (its indices start at 2), so such a job counts from 1: src points one byte before its window.
-    // (Not when the window starts at the frame's byte 0 — jobSize <= overlap, second job — where no byte exists in front of it: there
-    // position 0 stays unstorable, which matters only if the prefix fill reaches it, i.e. 8 << hashLog >= 512 KB: see DESIGN.md §8.)
-    uint32_t const winStart = (first || job->start == job->prefixLen) ? 0u : 1u;
+    // a position the reference CAN match (its indices start at 2), so such a job counts from winStart = 1: src points one byte before
+    // its window (the caller decides, see frame_job_shift).
     uint32_t const j0 = winStart + (job ? job->prefixLen : 0u);              // the section [j0, jEnd) behind the prefix [winStart, j0)
     uint32_t const n = u.srcLen, jEnd = j0 + n;
     uint32_t const frameSize = job ? (uint32_t)job->frameSize : n;

@@ -282,13 +282,14 @@ __device__ __forceinline__ void frame_kernel_body(const uint8_t* __restrict__ sr
     WideTab T; Lds24Tab T24;
     T.w = mode == ZHIP_FT_HBM ? tabs + (size_t)fi * tabStride : (uint32_t*)ltab;
     T24.lo = (lds_u16*)(uintptr_t)ltab; T24.hi = (lds_u8*)(uintptr_t)(ltab + (2u << u.hashLog));
-    const uint8_t* const p = src + u.srcOff + (job ? (size_t)(job->start - job->prefixLen) : 0u) - ((job && !(job->flags & ZHIP_JOB_FIRST) && job->start != job->prefixLen) ? 1 : 0);
+    uint32_t const shift = frame_job_shift(job, mode);
+    const uint8_t* const p = src + u.srcOff + (job ? (size_t)(job->start - job->prefixLen) : 0u) - shift;
     ZhipSeq* const sq = seqs + sl.seqOff;
     uint8_t* const lt = lits + sl.litOff;
     uint16_t* const sb = stBits + 3 * sl.seqOff;
     uint8_t* const o = out + sl.outOff;
     bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[fi].frameIdx : fi] : 0u;      // jobs: the checksum of the whole frame
-    frame_fast<OCC>(p, u, T, T24, mode == ZHIP_FT_LDS24, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, job);
+    frame_fast<OCC>(p, u, T, T24, mode == ZHIP_FT_LDS24, sq, lt, sb, sl.seqCap, o, outSize + fi, sh, fs, states + fi, ck, cv, job, shift);
 }
 // launches with a table in LDS (ZSTD_fast, hashLog <= 14): two workgroups per CU (2 x 75 KB of LDS) -> 256 registers per lane
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)

@@ -120,6 +120,13 @@ __device__ __forceinline__ void tab_mark(const Lds24Tab& T, uint32_t h, uint32_t
 __device__ __forceinline__ uint32_t tab_peek(const Lds24Tab& T, uint32_t h) { return T.lo[h]; }
 __device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
 
+// where the speculative read of a candidate's bytes goes when the entry is 0 (= empty; the loaded value is never used then).  The
+// unit tables read position 0 — the unit's first bytes, always there.  A job of a frame whose window starts at the frame's byte 0 counts
+// its positions from 1 with `src` one byte BEFORE the frame (zhip_frame.h): position 0 is not memory, so WideTab reads position 1.
+__device__ __forceinline__ uint32_t tab_guard(const FastTab&, uint32_t old) { return old; }
+__device__ __forceinline__ uint32_t tab_guard(const Lds24Tab&, uint32_t old) { return old; }
+__device__ __forceinline__ uint32_t tab_guard(const WideTab&, uint32_t old) { return old > 1u ? old : 1u; }
+
 // ------------------------------------------------------------------ wave-wide match extension
 // Every load below is clamped to [0, n-8] so that no lane ever reads outside the unit; `sh` bytes are then shifted out.
 // equal leading bytes (0..8) of the 8-byte windows at q and q-off, bounded by the end of the unit (nm8 = n - 8)
@@ -436,7 +443,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
     // lanes of one hash hold the same old value)
     uint32_t const old = tab_get(T, h, B > 65536);
-    uint32_t const cb = ld32(src + old);                                  // old == 0 reads the unit's first bytes: harmless; in flight
+    uint32_t const cb = ld32(src + tab_guard(T, old));                    // old == 0 reads the unit's first bytes: harmless; in flight
     __builtin_amdgcn_wave_barrier();                                      // during the duplicate detection below
     tab_mark(T, h, lane);
     __builtin_amdgcn_wave_barrier();
@@ -733,7 +740,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             if (g0 != step || nstep != step) batch_offsets(step, nstep, nposOff, nrposOff);
             FastBatch const nxt = batch_load(src, nm8, nip0, nposOff, nrposOff, rep1);
 
-            uint32_t cb = ld32(src + old);                                   // old == 0 reads the unit's first bytes: harmless
+            uint32_t cb = ld32(src + tab_guard(T, old));                     // old == 0 reads the unit's first bytes: harmless
             uint32_t cand = old;
             unsigned long long const dupMask = __ballot(back != lane) & liveMask;
             unsigned long long grp = 0;
