@@ -71,6 +71,18 @@ const char* ZSTD_getErrorName(size_t code);                                     
 ZSTD_CDict* ZSTD_createCDict(const void* dictBuffer, size_t dictSize, int compressionLevel);       /* :979 */
 size_t      ZSTD_freeCDict(ZSTD_CDict* CDict);                                                     /* :985 */
 size_t      ZSTD_CCtx_refCDict(ZSTD_CCtx* cctx, const ZSTD_CDict* cdict);                          /* :1102 */
+/* streaming entry point, one-shot form only (see zstd_shim.c): first call of the frame with ZSTD_e_end, all input present,
+ * output room >= ZSTD_compressBound(input) -> the bytes of ZSTD_compress2, returns 0; everything else -> parameter_unsupported */
+typedef struct ZSTD_inBuffer_s  { const void* src; size_t size; size_t pos; } ZSTD_inBuffer;       /* lib/zstd.h:681 */
+typedef struct ZSTD_outBuffer_s { void* dst; size_t size; size_t pos; } ZSTD_outBuffer;            /* :687 */
+typedef enum { ZSTD_e_continue = 0, ZSTD_e_flush = 1, ZSTD_e_end = 2 } ZSTD_EndDirective;          /* :763-774 */
+typedef ZSTD_CCtx ZSTD_CStream;                                                                    /* :756 */
+size_t        ZSTD_compressStream2(ZSTD_CCtx* cctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input, ZSTD_EndDirective endOp);   /* :803 */
+ZSTD_CStream* ZSTD_createCStream(void);                                                            /* :759 */
+size_t        ZSTD_freeCStream(ZSTD_CStream* zcs);                                                 /* :760 */
+size_t        ZSTD_initCStream(ZSTD_CStream* zcs, int compressionLevel);                           /* :842 */
+size_t        ZSTD_CStreamInSize(void);                                                            /* :822 */
+size_t        ZSTD_CStreamOutSize(void);                                                           /* :823 */
 size_t      ZSTD_compress_usingCDict(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_CDict* cdict);   /* :992 */
 /* decompression (served by k_decode; any RFC 8878 frame — this library's and the reference's) */
 typedef struct ZSTD_DCtx_s ZSTD_DCtx;                                                              /* :288 */

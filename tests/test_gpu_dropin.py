@@ -203,3 +203,33 @@ def test_c_program_against_the_shim(tmp_path):
     for n, level in ((5 << 20, 3), (100, 1), (131072, 5), (0, 1), (3_000_000, 1)):
         out = subprocess.run([exe, str(n), str(level)], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "roundtrip ok" in out.stdout, (n, level, out.stdout, out.stderr)
+
+
+def test_compressStream2_one_shot_equals_compress2(env):
+    """ZSTD_compressStream2(ZSTD_e_end) with all input and ZSTD_compressBound of room is ZSTD_compress2 in the reference
+    (zstd_compress.c:6069-6084) and here; the streaming state machine itself is not on the device: parameter_unsupported"""
+    S, lo, lr = env
+    class InB(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+    class OutB(C.Structure):
+        _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+    S.ZSTD_compressStream2.restype = C.c_size_t
+    S.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutB), C.POINTER(InB), C.c_int]
+    S.ZSTD_createCStream.restype = C.c_void_p
+    S.ZSTD_freeCStream.argtypes = [C.c_void_p]
+    S.ZSTD_initCStream.restype = C.c_size_t
+    S.ZSTD_initCStream.argtypes = [C.c_void_p, C.c_int]
+    a = datagen(lo, 100_000, 50, 3)
+    zcs = S.ZSTD_createCStream()
+    assert S.ZSTD_initCStream(zcs, 3) == 0
+    cap = S.ZSTD_compressBound(len(a))
+    dst = np.zeros(cap + 16, dtype=np.uint8)
+    o = OutB(dst.ctypes.data, cap + 16, 16); i = InB(a.ctypes.data, len(a), 0)
+    assert S.ZSTD_compressStream2(zcs, C.byref(o), C.byref(i), 2) == 0 and i.pos == len(a)
+    r, want = shim_compress2(S, a, 3)
+    assert o.pos - 16 == r and dst[16:o.pos].tobytes() == want[:r].tobytes()
+    i = InB(a.ctypes.data, len(a), 0); o = OutB(dst.ctypes.data, cap, 0)
+    assert S.ZSTD_isError(S.ZSTD_compressStream2(zcs, C.byref(o), C.byref(i), 0))          # ZSTD_e_continue: the state machine is the reference's
+    o = OutB(dst.ctypes.data, 100, 0)
+    assert S.ZSTD_isError(S.ZSTD_compressStream2(zcs, C.byref(o), C.byref(i), 2))          # too little room for the one-shot form
+    S.ZSTD_freeCStream(zcs)

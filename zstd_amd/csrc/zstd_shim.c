@@ -169,6 +169,33 @@ size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size
     return shim_compress(c, dst, cap, src, n, c ? c->level : 3);
 }
 
+/* ---- the streaming entry point, for the one case the reference itself handles as a single ZSTD_compress2-like pass
+ * (zstd_compress.c:6069-6084): the first call of a frame says ZSTD_e_end, all input is there and the output has room for
+ * ZSTD_compressBound of it.  Then the bytes are ZSTD_compress2's.  Anything that would need the streaming state machine
+ * (ZSTD_e_continue / ZSTD_e_flush with input, too little output room) returns parameter_unsupported: it stays with the reference. */
+size_t ZSTD_compressStream2(ZSTD_CCtx* c, ZSTD_outBuffer* out, ZSTD_inBuffer* in, ZSTD_EndDirective endOp)
+{
+    size_t n, room, r;
+    if (!c || !out || !in || out->pos > out->size || in->pos > in->size) return SHIM_ERR(E_GENERIC);
+    n = in->size - in->pos; room = out->size - out->pos;
+    if (endOp != ZSTD_e_end) return (n == 0 && endOp == ZSTD_e_flush) ? 0 : SHIM_ERR(E_parameter_unsupported);
+    if (room < ZSTD_compressBound(n)) return SHIM_ERR(E_parameter_unsupported);
+    r = ZSTD_compress2(c, (char*)out->dst + out->pos, room, (const char*)in->src + in->pos, n);
+    if (zhip_isError(r)) return r;
+    in->pos = in->size; out->pos += r;
+    return 0;                                                            /* frame completely written */
+}
+ZSTD_CStream* ZSTD_createCStream(void) { return ZSTD_createCCtx(); }     /* lib/zstd.h:756-760: a CStream is a CCtx */
+size_t ZSTD_freeCStream(ZSTD_CStream* zcs) { return ZSTD_freeCCtx(zcs); }
+size_t ZSTD_initCStream(ZSTD_CStream* zcs, int level)                    /* :842 = reset session + set level */
+{
+    if (!zcs) return SHIM_ERR(E_GENERIC);
+    zcs->cdict = NULL;
+    return ZSTD_CCtx_setParameter(zcs, ZSTD_c_compressionLevel, level);
+}
+size_t ZSTD_CStreamInSize(void) { return SHIM_UNIT; }                    /* :822-823 */
+size_t ZSTD_CStreamOutSize(void) { return ZSTD_compressBound(SHIM_UNIT); }
+
 /* ---- dictionaries (lib/zstd.h:979-995, :1102) */
 ZSTD_CDict* ZSTD_createCDict(const void* dict, size_t dictSize, int level)
 {
