@@ -522,10 +522,10 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
 
 
 def frames_leg(zstd_amd, local, host, level):
-    """inputs of 1 MiB, ONE multi-block frame each (the reference's own output shape), a batch of 256
-    through zhip_compress_frames.  The rate is over the frame kernel's duration (HIP events; the call itself goes through host
+    """inputs of 1 MiB, ONE multi-block frame each (the reference's own output shape), a batch of up to 1024
+    (two workgroups per CU: 512 run at once) through zhip_compress_frames.  The rate is over the frame kernel's duration (HIP events; the call itself goes through host
     buffers); parity = SHA-256 of all frames against ZSTD_compress2 of each 1 MiB input by the real reference, full size."""
-    fsz, nf = 1 << 20, min(256, len(host) >> 20)
+    fsz, nf = 1 << 20, min(1024, len(host) >> 20)
     if nf == 0:
         return None
     bufs = [host[i * fsz:(i + 1) * fsz] for i in range(nf)]
@@ -537,7 +537,7 @@ def frames_leg(zstd_amd, local, host, level):
     ctx.close()
     res = {"value": round(nf * fsz / best / 1e3, 1), "unit": "MB/s", "frames": nf, "frame_bytes": fsz, "level": level,
            "kernel_ms": round(best, 3), "ratio": round(nf * fsz / sum(len(o) for o in outs), 4),
-           "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain); fidelity mode, never `value`"}
+           "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain), two per CU; fidelity mode, never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
         tin, tout = f"/tmp/zhip_frames_in_{os.getpid()}.bin", f"/tmp/zhip_frames_out_{os.getpid()}.bin"
