@@ -337,11 +337,12 @@ def frame_header_bytes(n, window_log):
     return 4 + 1 + (0 if single else 1) + ((1 if single else 0) if fcs == 0 else (2 if fcs == 1 else 4))
 
 
-def make_jobs(lo, n, level, job_size=0, overlap_log=0):
+def make_jobs(lo, n, level, job_size=0, overlap_log=0, cp=None):
     """the job table of one frame compressed with ZSTD_c_nbWorkers >= 1 (zstdmt_compress.c: sections of the job size, each later one
     with the overlap as prefix) -> (units, jobs); n must exceed 512 KB (below that the reference does not use jobs)"""
-    cp = (C.c_uint * 7)()
-    assert lo.zo_get_cparams(level, n, cp) == 0
+    if cp is None:
+        cp = (C.c_uint * 7)()
+        assert lo.zo_get_cparams(level, n, cp) == 0
     lo.zo_mt_job_size.restype = C.c_size_t; lo.zo_mt_job_size.argtypes = [C.c_void_p, C.c_ulonglong]
     lo.zo_mt_overlap_size.restype = C.c_size_t; lo.zo_mt_overlap_size.argtypes = [C.c_void_p, C.c_int]
     sec, ov = lo.zo_mt_job_size(cp, job_size), lo.zo_mt_overlap_size(cp, overlap_log)
@@ -358,10 +359,10 @@ def make_jobs(lo, n, level, job_size=0, overlap_log=0):
     return units, jobs, cp
 
 
-def emu_compress_frame_jobs(le, lo, a, level, job_size=0, overlap_log=0, checksum=False):
-    """one frame as parallel jobs on the emulator; returns the frame bytes"""
+def emu_compress_frame_jobs(le, lo, a, level, job_size=0, overlap_log=0, checksum=False, cp=None):
+    """one frame as parallel jobs on the emulator; returns the frame bytes (cp: effective parameters instead of the level's)"""
     n = len(a)
-    units, jobs, cp = make_jobs(lo, n, level, job_size, overlap_log)
+    units, jobs, cp = make_jobs(lo, n, level, job_size, overlap_log, cp)
     assert le.emu_sizeof_job() == JOB_DT.itemsize
     src = np.concatenate([a, np.zeros(16, dtype=np.uint8)])
     nj = len(units)
@@ -380,12 +381,13 @@ def emu_compress_frame_jobs(le, lo, a, level, job_size=0, overlap_log=0, checksu
     return b"".join(out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nj))
 
 
-def oracle_frame_mt(lo, a, level, job_size=0, overlap_log=0, checksum=False):
+def oracle_frame_mt(lo, a, level, job_size=0, overlap_log=0, checksum=False, cp=None):
     lo.zo_compress_frame_mt_params.restype = C.c_size_t
     lo.zo_compress_frame_mt_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int]
     lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
-    cp = (C.c_uint * 7)()
-    assert lo.zo_get_cparams(level, len(a), cp) == 0
+    if cp is None:
+        cp = (C.c_uint * 7)()
+        assert lo.zo_get_cparams(level, len(a), cp) == 0
     cap = lo.zo_frame_bound(len(a)) + 4
     dst = np.zeros(cap, dtype=np.uint8)
     r = lo.zo_compress_frame_mt_params(_buf(dst), cap, _buf(a), len(a), cp, job_size, overlap_log, 1 if checksum else 0)

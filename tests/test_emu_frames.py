@@ -92,3 +92,12 @@ def test_job_window_starting_at_the_frames_first_byte(libs, level, js, ov):
     a = datagen(lo, 700000, 20, 10).copy()
     a[js: js + 64] = a[0: 64]
     assert emu_compress_frame_jobs(le, lo, a, level, js, ov, False) == oracle_frame_mt(lo, a, level, js, ov, False)
+
+
+def test_job_prefix_fill_counts_the_chain_log(libs):
+    """ZSTD_loadDictionaryContent keeps the last 8 << max(hashLog, chainLog) bytes of a prefix (zstd_compress.c:4889-4896) — the chain
+    log counts even for ZSTD_fast, which has no chain table (explicit parameters with chainLog > hashLog; found by the job fuzz)"""
+    lo, le = libs
+    a = text_like(650_000, 5)
+    eff = (C.c_uint * 7)(19, 15, 14, 1, 4, 2, 1)
+    assert emu_compress_frame_jobs(le, lo, a, -2, 524288, 9, False, cp=eff) == oracle_frame_mt(lo, a, -2, 524288, 9, False, cp=eff)

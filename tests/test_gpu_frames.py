@@ -282,3 +282,19 @@ def test_job_window_starting_at_the_frames_first_byte(env):
             a[js: js + 64] = a[0: 64]
             out = ctx.compress_frames([a], level, workers=1, job_size=js, overlap_log=ov)[0]
             assert out == oracle_frame_mt(lo, a, level, js, ov), (level, seed)
+
+
+def test_job_pool_frames_with_explicit_parameters(env):
+    """ZSTD_c_nbWorkers + explicit compression parameters (windows smaller than a job, table logs 12-17 = LDS 24-bit, LDS / HBM 32-bit
+    tables, both strategies) against the oracle, which tests/test_oracle_vs_reference.py pins to the reference on the same cases"""
+    z, lo = env
+    from test_oracle_vs_reference import mt_explicit_cases
+    ctx = z.Context(max_units=16)
+    seen = 0
+    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 14, 7):
+        ctx.set_checksum(ck)
+        out = ctx.compress_frames([a], level, cparams=req, workers=1, job_size=js, overlap_log=ov)[0]
+        assert out == oracle_frame_mt(lo, a, level, js, ov, ck, cp=eff), (len(a), level, req, js, ov, ck)
+        seen += 1
+    ctx.set_checksum(False)
+    assert seen >= 8

@@ -262,3 +262,35 @@ def test_job_pool_frame_vs_reference(libs):
             ov = int(rng.integers(0, 10))
             ck = bool(rng.integers(0, 2))
             assert oracle_frame_mt(lo, a, level, js, ov, ck) == ref_frame_mt(lr, a, level, js, ov, ck), (trial, kind, n, level, js, ov, ck)
+
+
+def mt_explicit_cases(lo, trials, seed):
+    """random inputs x explicit parameters x job sizes x overlaps for the job-pool frame (windows smaller than a job, table logs 12-17,
+    minMatch 4-7, both strategies): yields (input, level, requested[7], effective[7], jobSize, overlapLog, checksum)"""
+    import zstd_amd                                            # the product's host-side parameter logic (no GPU needed)
+    L = zstd_amd.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    for trial in range(trials):
+        n = int(rng.integers(530_000, 1_400_000))
+        kind = trial % 4
+        a = (datagen(lo, n, int(rng.integers(10, 95)), trial) if kind == 0 else text_like(n, trial) if kind == 1 else
+             np.concatenate([datagen(lo, n // 2, 60, trial), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]) if kind == 2 else
+             np.repeat(rng.integers(0, 256, size=n // 512 + 1, dtype=np.uint8), 512)[:n].copy())
+        level = int(rng.choice([1, 2, 3, -2]))
+        req = [int(rng.choice([0, 17, 18, 19, 20])), int(rng.choice([0, 12, 15, 16])), int(rng.choice([0, 12, 13, 14, 15, 16, 17])), 0,
+               int(rng.choice([0, 4, 5, 6, 7])), int(rng.choice([0, 0, 2, 8])), int(rng.choice([0, 1, 2]))]
+        eff = (C.c_uint * 7)()
+        if L.zhip_getCParams_explicit(level, n, (C.c_uint * 7)(*req), eff) != 0 or eff[6] not in (1, 2) or eff[0] < 17:
+            continue
+        yield a, level, req, eff, int(rng.choice([0, 524288, 600_001, 1 << 20])), int(rng.integers(0, 10)), bool(rng.integers(0, 2))
+
+
+def test_job_pool_frame_with_explicit_parameters_vs_reference(libs):
+    lo, lr = libs
+    seen = 0
+    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 14, 7):
+        assert oracle_frame_mt(lo, a, level, js, ov, ck, cp=eff) == ref_frame_mt(lr, a, level, js, ov, ck, cp=req), (len(a), level, req, js, ov, ck)
+        seen += 1
+    assert seen >= 8

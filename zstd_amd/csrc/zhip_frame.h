@@ -160,7 +160,8 @@ __device__ inline void frame_fill_prefix24(const uint8_t* __restrict__ src, cons
                                            uint32_t p0, uint32_t p1)
 {
     if (p1 - p0 <= 8) return;
-    uint32_t const maxDict = 8u << (u.hashLog < 28 ? u.hashLog : 28);
+    uint32_t const big = u.hashLog > u.chainLog ? u.hashLog : u.chainLog;        // the chain log counts even though ZSTD_fast has no chain (zstd_compress.c:4889-4896)
+    uint32_t const maxDict = 8u << (big < 28 ? big : 28);
     if (p1 - p0 > maxDict) p0 = p1 - maxDict;
     uint32_t const stop = p1 - 8 + 2;
     for (uint32_t base = p0; base + 3 < stop; ) {
@@ -193,15 +194,12 @@ __device__ inline void frame_fill_prefix24(const uint8_t* __restrict__ src, cons
 }
 
 // Does a job count its positions from 1 (src one byte before its window)?  Not the frame's first job (a frame never inserts its
-// position 0, like the reference).  Every other job does — except in one corner: its window starts at the frame's byte 0 (jobSize <=
-// overlap, second job), where no byte exists in front of the window.  With the tables in HBM the parsers never touch position 0
-// (tab_guard; the ZSTD_dfast parser only reads candidates of non-empty entries), so the shift is still made; with a table in LDS
-// (hashLog <= 14) the job keeps counting from 0, which is exact there: the prefix fill covers the last 8 << hashLog <= 128 KB of a
-// prefix that is at least 512 KB long in this corner, so the frame's byte 0 is never inserted anyway.
-__host__ __device__ inline uint32_t frame_job_shift(const ZhipJob* job, uint32_t tableMode)
+// position 0, like the reference); every other job does.  When its window starts at the frame's byte 0 (jobSize <= overlap, second
+// job) the byte in front of the window does not exist: the frame parsers never touch position 0 (tab_guard; the ZSTD_dfast parser
+// only reads the candidates of non-empty entries).
+__host__ __device__ inline uint32_t frame_job_shift(const ZhipJob* job, uint32_t /*tableMode*/)
 {
-    if (!job || (job->flags & ZHIP_JOB_FIRST)) return 0u;
-    return (job->start == job->prefixLen && tableMode != ZHIP_FT_HBM) ? 0u : 1u;
+    return (!job || (job->flags & ZHIP_JOB_FIRST)) ? 0u : 1u;
 }
 
 // job == nullptr: the whole input src[0, u.srcLen) as ONE frame (ZSTD_compress2 without workers: one context, one frame chunk).

@@ -122,9 +122,10 @@ __device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32
 
 // where the speculative read of a candidate's bytes goes when the entry is 0 (= empty; the loaded value is never used then).  The
 // unit tables read position 0 — the unit's first bytes, always there.  A job of a frame whose window starts at the frame's byte 0 counts
-// its positions from 1 with `src` one byte BEFORE the frame (zhip_frame.h): position 0 is not memory, so WideTab reads position 1.
+// its positions from 1 with `src` one byte BEFORE the frame (zhip_frame.h): position 0 is not memory, so the frame tables (WideTab,
+// Lds24Tab) read position 1.
 __device__ __forceinline__ uint32_t tab_guard(const FastTab&, uint32_t old) { return old; }
-__device__ __forceinline__ uint32_t tab_guard(const Lds24Tab&, uint32_t old) { return old; }
+__device__ __forceinline__ uint32_t tab_guard(const Lds24Tab&, uint32_t old) { return old > 1u ? old : 1u; }
 __device__ __forceinline__ uint32_t tab_guard(const WideTab&, uint32_t old) { return old > 1u ? old : 1u; }
 
 // ------------------------------------------------------------------ wave-wide match extension
