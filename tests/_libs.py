@@ -289,10 +289,16 @@ def oracle_frame(lo, a, level):
     return dst[:r].tobytes()
 
 
-def emu_compress_frames(le, lo, bufs, level, checksum=False):
-    """the frame kernel (one workgroup per multi-block frame) on the emulator; returns list of frame bytes"""
+def emu_compress_frames(le, lo, bufs, level, checksum=False, cparams=None):
+    """the frame kernel (one workgroup per multi-block frame) on the emulator; returns list of frame bytes
+    (cparams: effective parameters [windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy] for every frame)"""
     sizes = [len(b) for b in bufs]
     frames = make_units(lo, sizes, level)                  # parameters come from the whole input's size class
+    if cparams is not None:
+        cp = list(cparams)
+        for f in frames:
+            f["windowLog"], f["chainLog"], f["hashLog"], f["searchLog"], f["minMatch"], f["targetLength"], f["strategy"] = cp
+            f["litMode"] = 1 if (cp[6] == 1 and cp[5] > 0) else 0
     src = np.concatenate(list(bufs) + [np.zeros(16, dtype=np.uint8)])
     nf = len(bufs)
     ostride = (max(sizes) + (max(sizes) >> 8) + 2048 + 15) & ~15

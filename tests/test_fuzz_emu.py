@@ -145,3 +145,64 @@ def test_fuzz_decoder_on_the_emulator():
         got = emu_decode(le, frames, [len(w) for w in want], groups=5)
         for i, ((st, data, _), w) in enumerate(zip(got, want)):
             assert st == 0 and data == w, (rd, level, i, len(w), st)
+
+
+def _explicit(level, n, req):
+    """the product's host-side parameter logic (no GPU needed): requested -> effective parameters, None when not for the device"""
+    import ctypes as C
+    import zstd_amd
+    L = zstd_amd.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    eff = (C.c_uint * 7)()
+    if L.zhip_getCParams_explicit(level, n, (C.c_uint * 7)(*req), eff) != 0:
+        return None
+    return eff
+
+
+def test_fuzz_units_with_explicit_parameters():
+    """random explicit parameters (table logs 8-17, searchLog 1-6, minMatch 3-7, targetLength, every strategy up to lazy2, row matcher
+    on / off) on structured-random units: the kernels on the emulator against the oracle (the same sweep against the real reference:
+    500 trials clean when this test was written, /root/reference is not needed here)"""
+    import ctypes as C
+    import _libs
+    lo, le = load_oracle(), load_emu()
+    lo.zo_compress_unit_params.restype = C.c_size_t
+    lo.zo_compress_unit_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(77)
+    orig = _libs.make_units
+    seen = 0
+    try:
+        for t in range(60):
+            n = int(rng.integers(1, 30000)) if t % 6 else int(rng.integers(100000, 131073))
+            a = gen(rng, n)
+            level = int(rng.choice([1, 3, 5, 6, 7, -3]))
+            req = [int(rng.choice([0, 0, 12, 14, 15, 17, 18])), int(rng.choice([0, 0, 8, 12, 15, 16])), int(rng.choice([0, 0, 8, 11, 13, 15, 17])),
+                   int(rng.choice([0, 0, 1, 2, 4, 5, 6])), int(rng.choice([0, 0, 3, 4, 5, 6, 7])), int(rng.choice([0, 0, 1, 4, 16, 64])), int(rng.choice([0, 0, 1, 2, 3, 4, 5]))]
+            eff = _explicit(level, n, req)
+            if eff is None or not (1 <= eff[6] <= 5) or (1 << eff[0]) < n or (eff[6] == 1 and eff[2] > 15):
+                continue
+            no_row = int(rng.integers(0, 2))
+            row = 3 <= eff[6] <= 5 and eff[0] > 14 and not no_row
+            lo.zo_set_row_matcher(1 if row else 0)
+            cap = lo.zo_compress_bound(n) + 64
+            o = np.zeros(cap, dtype=np.uint8)
+            r = lo.zo_compress_unit_params(_buf(o), cap, _buf(a), n, eff)
+            assert r != ERR
+
+            def mk(lo_, sizes, level_, unit=131072, row=False, eff=eff, no_row=no_row):
+                units = orig(lo_, sizes, 1, unit, False)
+                for f in units:
+                    f["windowLog"], f["chainLog"], f["hashLog"], f["searchLog"], f["minMatch"], f["targetLength"], f["strategy"] = list(eff)
+                    f["litMode"] = 1 if (eff[6] == 1 and eff[5] > 0) else 0
+                    f["rowLog"] = min(6, max(4, eff[3])) if (3 <= eff[6] <= 5 and eff[0] > 14 and not no_row) else 0
+                return units
+            _libs.make_units = mk
+            got = emu_compress_units(le, lo, [a], 1)[0]
+            _libs.make_units = orig
+            assert got == o[:r].tobytes(), (t, n, level, req, list(eff), no_row)
+            seen += 1
+    finally:
+        _libs.make_units = orig
+        lo.zo_set_row_matcher(0)
+    assert seen >= 30
