@@ -111,6 +111,11 @@ void         zhip_multi_destroy(zhip_multi* m);
 int          zhip_multi_set_frame_checksum(zhip_multi* m, int enable);
 size_t       zhip_compress_multi(zhip_multi* m, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                  int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes);
+/* ONE input as the job-pool frame of zhip_compress_frames_mt (ZSTD_c_nbWorkers >= 1 semantics), its jobs spread over the lanes and
+ * devices of m: copies of one chunk of jobs overlap the kernels of another, and several GPUs share one frame.  One device only, frame
+ * checksum on, inputs up to 512 KB, or jobs larger than a lane's staging buffer: a single context's zhip_compress_frames_mt. */
+size_t       zhip_compress_frame_mt_multi(zhip_multi* m, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                          int level, const unsigned cparams[7] /* or NULL */, size_t jobSize, int overlapLog);
 const char*  zhip_multi_last_error(const zhip_multi* m);
 double       zhip_multi_last_seconds(const zhip_multi* m);      /* wall time of the most recent zhip_compress_multi call */
 

@@ -59,3 +59,33 @@ dst[:r].tofile({str(tmp_path / "out.bin")!r})
     env = dict(os.environ, ZHIP_DEVICES="0,0")
     subprocess.check_call([os.sys.executable, "-c", code], env=env)
     assert open(tmp_path / "out.bin", "rb").read() == want
+
+
+def test_job_pool_frame_over_lanes_equals_the_single_context_frame():
+    """zhip_compress_frame_mt_multi: ONE frame (ZSTD_c_nbWorkers semantics), chunks of consecutive jobs on different lanes / devices,
+    ordered gather — the bytes of zhip_compress_frames_mt on one context and of the oracle, whatever the chunking"""
+    import zstd_amd
+    from _libs import oracle_frame_mt, oracle_frame
+    lo = load_oracle()
+    os.environ["ZHIP_MULTI_FRAME_CHUNKED"] = "1"                                    # one GPU here: force the several-device path
+    a = np.concatenate([datagen(lo, 5_000_000, 50, 4), text_like(1_300_000, 9), np.zeros(700_000, np.uint8)])
+    for level, js, ov in ((1, 524288, 0), (3, 524288, 0), (1, 0, 9), (-1, 600_001, 3)):
+        want = oracle_frame_mt(lo, a, level, js, ov)
+        for devices, chunk in (([0], 0), ([0, 0], 8), ([0], 5)):                     # 64 MB lanes (one chunk), 1 MiB and 640 KB staging: one job per chunk
+            m = zstd_amd.MultiContext(devices, chunk_units=chunk)
+            for rep in range(2):
+                assert m.compress_frame_mt(a, level, job_size=js, overlap_log=ov) == want, (level, js, ov, devices, chunk, rep)
+            m.close()
+    m = zstd_amd.MultiContext([0, 0], chunk_units=16)
+    small = a[:400_000]
+    assert m.compress_frame_mt(small, 1) == oracle_frame(lo, small, 1)               # at or below 512 KB: the plain frame
+    m.set_checksum(True)
+    got = m.compress_frame_mt(a, 1, job_size=524288)                                 # checksum: one lane's zhip_compress_frames_mt
+    assert got == oracle_frame_mt(lo, a, 1, 524288, 0, True)
+    with pytest.raises(zstd_amd.ZhipError):
+        m.compress_frame_mt(a, 5)                                                    # greedy: no frame kernel, no CPU fallback
+    m.close()
+    del os.environ["ZHIP_MULTI_FRAME_CHUNKED"]
+    m = zstd_amd.MultiContext([0])                                                   # one device: the single-context path
+    assert m.compress_frame_mt(a, 1) == oracle_frame_mt(lo, a, 1)
+    m.close()

@@ -153,6 +153,26 @@ class MultiContext:
         dst = np.empty(compress_bound(data.nbytes, unit_size), dtype=np.uint8)
         return dst[: self.compress_into(dst, data, level, unit_size, cparams)].tobytes()
 
+    def compress_frame_mt_into(self, dst, data, level=1, cparams=None, job_size=0, overlap_log=0):
+        """ONE frame with the reference's ZSTD_c_nbWorkers >= 1 bytes, its jobs spread over the lanes (zhip_compress_frame_mt_multi)"""
+        L = lib()
+        L.zhip_compress_frame_mt_multi.restype = C.c_size_t
+        L.zhip_compress_frame_mt_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+        cp = (C.c_uint * 7)(*cparams) if cparams is not None else None
+        r = L.zhip_compress_frame_mt_multi(self._h, dst.ctypes.data_as(C.c_void_p), dst.nbytes, data.ctypes.data_as(C.c_void_p), data.nbytes, level, cp,
+                                           job_size, overlap_log)
+        if L.zhip_isError(r):
+            raise ZhipError(f"zhip_compress_frame_mt_multi: {L.zhip_getErrorName(r).decode()} ({L.zhip_multi_last_error(self._h).decode()})")
+        return int(r)
+
+    def compress_frame_mt(self, data, level=1, cparams=None, job_size=0, overlap_log=0):
+        data = np.ascontiguousarray(data)
+        dst = np.empty(compress_bound(data.nbytes, UNIT_SIZE_MAX) + 64, dtype=np.uint8)
+        return dst[: self.compress_frame_mt_into(dst, data, level, cparams, job_size, overlap_log)].tobytes()
+
+    def set_checksum(self, enable=True):
+        lib().zhip_multi_set_frame_checksum(self._h, 1 if enable else 0)
+
     def last_seconds(self):
         return float(lib().zhip_multi_last_seconds(self._h))
 

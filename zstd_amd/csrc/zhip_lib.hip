@@ -571,6 +571,8 @@ static size_t compress_host_locked(zhip_ctx* c, void* dst, size_t dstCapacity, c
 // compressed by its own workgroup with the overlap in front of it as prefix, and the concatenation is the frame the reference's
 // worker pool emits (it does not depend on the number of workers).  A unit of the launch is then a job, not a frame.
 struct MtParams { bool on; unsigned long long jobSize; int overlapLog; };
+static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, size_t nU, size_t nFrames, uint32_t ldsTab, size_t tabWords,
+                                size_t outBytes, unsigned long long totalSrc, bool withJobs, uint32_t* frameSizesDev, hipStream_t s);
 static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* offs,
                                    size_t nFrames, int level, uint32_t* frameSizesDev, hipStream_t s, MtParams mt = MtParams{false, 0, 0})
 {
@@ -624,6 +626,14 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         totalSrc += n;
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    return frames_run_locked(c, dstDev, srcDev, nU, nFrames, ldsTab, tabWords, outBytes, totalSrc, mt.on, frameSizesDev, s);
+}
+
+// the launch part: c->hUnits / c->hSlots (and c->hJobs / c->hFrameUnits with jobs) describe nU workgroups of nFrames frames
+static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, size_t nU, size_t nFrames, uint32_t ldsTab, size_t tabWords,
+                                size_t outBytes, unsigned long long totalSrc, bool withJobs, uint32_t* frameSizesDev, hipStream_t s)
+{
+    struct { bool on; } mt = { withJobs };
     if (c->frameOutCap < outBytes) {
         (void)hipFree(c->dFrameOut); c->dFrameOut = nullptr; c->frameOutCap = 0;
         if (hipMalloc((void**)&c->dFrameOut, outBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of frame output room", outBytes); return ZERR(ZE_memory_allocation); }
@@ -784,6 +794,42 @@ size_t zhip_compress_frames_mt(zhip_ctx* c, void* dst, size_t dstCapacity, const
     HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
     if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hFrameSizes[i];
     return total;
+}
+
+// One CHUNK of a job-pool frame on one context (zhip_compress_frame_mt_multi, zhip_multi.h): jobs[0..nJobs) in frame order, with
+// their ABSOLUTE starts and prefix lengths; srcDev holds the frame's bytes from absolute offset w0 on (w0 = the first job's window
+// start), so a unit's source offset is -w0 (mod 2^64: the kernel adds the absolute position back).  Packed output to dstDev.
+static size_t frame_jobs_chunk_device(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, unsigned long long w0,
+                                      const zhip::CParams& cp, const zhip::ZhipJob* jobs, const uint32_t* lens, size_t nJobs, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nJobs == 0 || nJobs > c->maxUnits) return ZERR(ZE_srcSize_wrong);
+    size_t outBytes = 0, tabWords = 0, bound = 0; uint32_t ldsTab = 0; unsigned long long total = 0;
+    c->hJobs.assign(jobs, jobs + nJobs); c->hFrameUnits.resize(1);
+    for (size_t i = 0; i < nJobs; i++) {
+        size_t const len = lens[i];
+        ZhipUnit& u = c->hUnits[i];
+        u.srcOff = 0ull - w0; u.srcLen = (uint32_t)len;
+        u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
+        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
+        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
+        ZhipSlot& sl = c->hSlots[i];
+        sl.seqOff = i * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = i * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = outBytes; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0;
+        outBytes += (zhip::host_compress_bound(len) + 1024 + 15) & ~(size_t)15;
+        bound += zhip::host_compress_bound(len);
+        c->hJobs[i].frameIdx = 0;
+        uint32_t const mode = zhip::frame_table_mode(cp.strategy, cp.hashLog, (unsigned long long)len + jobs[i].prefixLen + 1);
+        if (mode == zhip::ZHIP_FT_HBM) { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
+        else { uint32_t const b = zhip::frame_table_lds_bytes(mode, cp.hashLog); if (b > ldsTab) ldsTab = b; }
+        total += len;
+    }
+    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    c->hFrameUnits[0] = c->hUnits[0];
+    int const ck = c->checksum; c->checksum = 0;                          // a chunk does not see the whole frame: no checksum here
+    size_t const r = frames_run_locked(c, dstDev, srcDev, nJobs, 1, ldsTab, tabWords, outBytes, total, true, nullptr, s);
+    c->checksum = ck;
+    return r;
 }
 
 // ------------------------------------------------------------------ seekable container

@@ -131,6 +131,10 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
     if (level == 0) level = 3;
     if (units > 1 && shim_multi(c)) {            /* big sources: sharded over $ZHIP_DEVICES with overlapped copies; gathers straight into dst */
         zhip_multi_set_frame_checksum(c->zm, c->checksum);
+        if (c->workers > 0 && n > (512u << 10)) {    /* ZSTD_c_nbWorkers: one frame, its jobs spread over the lanes */
+            size_t const r = zhip_compress_frame_mt_multi(c->zm, dst, cap, src, n, level, c->cp, (size_t)c->jobSize, c->overlapLog);
+            if (!zhip_isError(r) || r != SHIM_ERR(E_parameter_unsupported)) return r;
+        }
         return zhip_compress_multi(c->zm, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
     }
     {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
