@@ -570,8 +570,23 @@ def job_pool_leg(zstd_amd, local, host, level):
         out = ctx.compress_frames([a], level, workers=1)[0]
         best = min(best, ctx.timing()["entropy_ms"])
     jobs = int(ctx.stats()["units"])
+    # the same call from pageable host memory, wall clock: blocking H2D + kernels + D2H (what the drop-in's ZSTD_c_nbWorkers mode does)
+    import ctypes as C
+    L = zstd_amd.lib()
+    L.zhip_compress_frames_mt.restype = C.c_size_t
+    L.zhip_compress_frames_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    offs = np.array([0, n], dtype=np.uint64)
+    d1 = np.empty(zstd_amd.compress_bound(n) + 64, dtype=np.uint8)
+    wall = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = L.zhip_compress_frames_mt(ctx._h, d1.ctypes.data_as(C.c_void_p), d1.nbytes, a.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), 1, level, None, 0, 0, None)
+        wall = min(wall, time.perf_counter() - t0)
+    same = bool(not L.zhip_isError(r) and d1[:r].tobytes() == out)
     ctx.close()
     res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
+           "end_to_end": {"value": round(n / wall / 1e6, 1), "unit": "MB/s", "same_bytes": same,
+                          "path": "zhip_compress_frames_mt from pageable host memory: blocking H2D, kernels, D2H on one context; PCIe-inclusive, never `value`"},
            "ratio": round(n / len(out), 4),
            "note": "k_frame_fast with a job table: one frame, jobs = independent workgroups, two per CU (48 KB 24-bit LDS table each); never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
