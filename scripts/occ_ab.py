@@ -15,7 +15,7 @@ for kind in ("datagen", "text"):
     a = z.datagen(N, 50, 1) if kind == "datagen" else np.tile(text_like(16 << 20, 1), N // (16 << 20))
     src = torch.from_numpy(a).cuda()
     dst = torch.empty(int(z.lib().zhip_compressBound(N, 131072)), dtype=torch.uint8, device="cuda")
-    for level in (1, 3, 5):
+    for level in [int(x) for x in os.environ.get("LEVELS", "1,3,5").split(",")]:
         best = None
         for rep in range(3):
             r = ctx.compress_device(dst.data_ptr(), dst.numel(), src.data_ptr(), N, level)
