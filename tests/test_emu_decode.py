@@ -39,9 +39,18 @@ def emu_decode(le, frames, caps, dictionary=None, groups=0):
                       _buf(res), groups, 0)
     assert e == 0
     out = []
+    lo = load_oracle()
+    lo.zo_xxh64.restype = C.c_uint64
+    lo.zo_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
     for i in range(len(frames)):
         o = int(fr["dstOff"][i])
-        out.append((int(res["status"][i]), dst[o:o + int(res["size"][i])].tobytes(), res[i]))
+        st, data = int(res["status"][i]), dst[o:o + int(res["size"][i])]
+        # the product verifies content checksums with two more kernels (k_xxh64 over the output + k_dec_verify); the same check here
+        if st == 0 and int(res["hasChecksum"][i]):
+            x = lo.zo_xxh64(data.ctypes.data_as(C.c_void_p) if len(data) else None, len(data), 0) & 0xFFFFFFFF
+            if x != int(res["checksum"][i]):
+                st, data = 0xC5, data[:0]
+        out.append((st, data.tobytes(), res[i]))
     assert (dst[do:] == 0xEE).all(), "wrote past the destination"
     return out
 
@@ -167,3 +176,43 @@ def test_frame_parameter_variants_on_the_emulator(libs):
     got = emu_decode(le, frames, [len(w) + 5 for w in want], groups=4)
     for (st, data, res), w in zip(got, want):
         assert st == 0 and data == w
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the real reference)")
+def test_corrupted_multi_block_frames(libs):
+    """mutants of multi-block frames (repeat modes, a frame without content size + checksum, a small window, RLE blocks): the device
+    rejects whatever the oracle rejects — the oracle is pinned to the reference on exactly this (tests/test_oracle_decode.py) — and
+    decodes alike otherwise; nothing is written past the destination"""
+    lo, le = libs
+    lr = load_ref()
+    from test_oracle_decode import ref_frame, ref_frame_params
+    rng = np.random.default_rng(5)
+    bases = [ref_frame(lr, text_like(300000, 2), 3), ref_frame(lr, datagen(lo, 400000, 50, 3), 1), ref_frame(lr, text_like(200000, 4), 19),
+             ref_frame_params(lr, datagen(lo, 300000, 70, 5), 5, 0, 1, 17), ref_frame_params(lr, text_like(150000, 6), 9, 0, 0, 12),
+             ref_frame(lr, np.zeros(300000, np.uint8), 3)]
+    cap = 420000
+    muts = []
+    for it in range(int(os.environ.get("ZHIP_EMU_MUTANTS_BIG", "96"))):
+        b = bytearray(bases[it % len(bases)])
+        k = rng.integers(0, 4)
+        if k == 0:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif k == 2:
+            del b[int(rng.integers(9, len(b))):]
+        else:
+            b[int(rng.integers(0, min(len(b), 64)))] = int(rng.integers(0, 256))          # the headers
+        muts.append(bytes(b))
+    nerr = nok = 0
+    for i in range(0, len(muts), 24):
+        chunk = muts[i:i + 24]
+        for m, (st, data, _) in zip(chunk, emu_decode(le, chunk, [cap] * len(chunk))):
+            w = oracle_decompress(lo, m, cap)
+            if w is None:
+                assert st != 0, m[:40].hex()
+                nerr += 1
+            else:
+                assert st == 0 and data == w, (st, m[:40].hex())
+                nok += 1
+    assert nerr > 20 and nok > 5
