@@ -291,10 +291,10 @@ def test_job_pool_frames_with_explicit_parameters(env):
     from test_oracle_vs_reference import mt_explicit_cases
     ctx = z.Context(max_units=16)
     seen = 0
-    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 14, 7):
+    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 40, 7):
         ctx.set_checksum(ck)
         out = ctx.compress_frames([a], level, cparams=req, workers=1, job_size=js, overlap_log=ov)[0]
         assert out == oracle_frame_mt(lo, a, level, js, ov, ck, cp=eff), (len(a), level, req, js, ov, ck)
         seen += 1
     ctx.set_checksum(False)
-    assert seen >= 8
+    assert seen >= 24

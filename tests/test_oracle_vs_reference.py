@@ -290,7 +290,7 @@ def mt_explicit_cases(lo, trials, seed):
 def test_job_pool_frame_with_explicit_parameters_vs_reference(libs):
     lo, lr = libs
     seen = 0
-    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 14, 7):
+    for a, level, req, eff, js, ov, ck in mt_explicit_cases(lo, 40, 7):
         assert oracle_frame_mt(lo, a, level, js, ov, ck, cp=eff) == ref_frame_mt(lr, a, level, js, ov, ck, cp=req), (len(a), level, req, js, ov, ck)
         seen += 1
-    assert seen >= 8
+    assert seen >= 24
