@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """scripts/gpu_fuzz_units.py <seed> <trials> — on the GPU box: structured-random data cut into units of random sizes, random explicit
-parameters (every strategy up to lazy2, row matcher on / off), through zhip_compress_params against the oracle unit by unit."""
+parameters (every strategy up to lazy2, row matcher on / off), through zhip_compress_params against the oracle unit by unit,
+and back through the device decoder."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,6 +21,7 @@ L.zhip_compress_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_
 seed, trials = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 ctx = z.Context(max_units=256)
+dctx = z.DContext()
 bad = cases = units = 0
 for t in range(trials):
     unit = int(rng.choice([131072, 65536, 20000, 4096, 100000]))
@@ -38,6 +40,9 @@ for t in range(trials):
     if L.zhip_isError(r):
         continue                                             # parameters the device does not run
     cases += 1
+    if dctx.decompress(dst[:r].tobytes()) != a.tobytes():    # the device decoder on the same frames
+        bad += 1
+        print("DECODE MISMATCH trial", t, level, req, flush=True)
     pos = 0
     for k in range(-(-n // unit)):
         u = a[k * unit: (k + 1) * unit]
