@@ -11,6 +11,11 @@
  * emits for that chunk, i.e. to `zstd -b<level> -B<unitSize>` (programs/benchzstd.c:336-345).  Concatenated
  * frames are a valid .zst stream (RFC 8878 §3.1; lib/decompress/zstd_decompress.c:1068 iterates frames).
  *
+ * Inputs above 128 KB have two more shapes, both byte-identical to the reference and both one standard frame per input (strategies
+ * ZSTD_fast / ZSTD_dfast): zhip_compress_frames = ZSTD_compress2 of the whole input (a serial block chain, one workgroup per frame),
+ * and zhip_compress_frames_mt = ZSTD_compress2 with ZSTD_c_nbWorkers >= 1 (the reference's job pool: independent jobs with an overlap
+ * prefix, one workgroup per job — the shape in which ONE large input fills the GPU).
+ *
  * Error convention = zstd's: size_t results are either a size or (size_t)-ZSTD_ErrorCode
  * (lib/common/error_private.h:55-60); test with zhip_isError().
  */
