@@ -213,7 +213,7 @@ def test_rowhash_parse_matches_oracle(libs):
     lo.zo_set_row_matcher.argtypes = [C.c_int]
     lo.zo_set_row_matcher(1)
     try:
-        for level in (5, 6, 7, 9, 10):
+        for level in (5, 7, 10):                                # greedy, lazy, lazy2 (6 and 9 are the same strategies with other table sizes: GPU suite)
             cases = list(corpus_cases(lo, sizes=(131072, 40000), seeds=(1,)))
             rng = np.random.default_rng(level)
             big = np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 190)[:131072].copy()       # matches of > 384 bytes: the skip rule
