@@ -723,8 +723,9 @@ size_t zhip_compress_frames_device(zhip_ctx* c, void* dstDev, size_t dstCapacity
     return frames_device_locked(c, dstDev, dstCapacity, srcDev, srcOffsets, nFrames, level, frameSizesDev, stream ? (hipStream_t)stream : c->stream);
 }
 
-size_t zhip_compress_frames(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
-                            size_t nFrames, int level, const unsigned cparams[7], size_t* frameSizes)
+// host buffers: stage the inputs on the device, run the frames (with or without jobs), copy the packed frames back
+static size_t frames_host(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
+                          size_t nFrames, int level, const unsigned cparams[7], size_t* frameSizes, MtParams mt)
 {
     if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
     if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
@@ -746,11 +747,17 @@ size_t zhip_compress_frames(zhip_ctx* c, void* dst, size_t dstCapacity, const vo
     if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, (const uint8_t*)src + lo, srcSize, hipMemcpyHostToDevice, c->stream));
     std::vector<unsigned long long> rel(nFrames + 1);
     for (size_t i = 0; i <= nFrames; i++) rel[i] = srcOffsets[i] - lo;
-    size_t const total = frames_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, rel.data(), nFrames, level, nullptr, c->stream);
+    size_t const total = frames_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, rel.data(), nFrames, level, nullptr, c->stream, mt);
     if (zhip_isError(total)) return total;
     HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
     if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hFrameSizes[i];
     return total;
+}
+
+size_t zhip_compress_frames(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
+                            size_t nFrames, int level, const unsigned cparams[7], size_t* frameSizes)
+{
+    return frames_host(c, dst, dstCapacity, src, srcOffsets, nFrames, level, cparams, frameSizes, MtParams{false, 0, 0});
 }
 
 // ZSTD_c_nbWorkers >= 1: the same inputs, each as the frame the reference's job pool produces
@@ -768,32 +775,8 @@ size_t zhip_compress_frames_mt_device(zhip_ctx* c, void* dstDev, size_t dstCapac
 size_t zhip_compress_frames_mt(zhip_ctx* c, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,
                                size_t nFrames, int level, const unsigned cparams[7], size_t jobSize, int overlapLog, size_t* frameSizes)
 {
-    if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
     if (overlapLog < 0 || overlapLog > 9) return ZERR(ZE_parameter_outOfBound);
-    if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
-    OvrScope scope(c, cparams);
-    size_t const bound = zhip_frames_bound(srcOffsets, nFrames);
-    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
-    unsigned long long const lo = srcOffsets[0], hi = srcOffsets[nFrames];
-    size_t const srcSize = (size_t)(hi - lo);
-    if (c->srcStageCap < srcSize + 64) {
-        (void)hipFree(c->dSrcStage); c->dSrcStage = nullptr; c->srcStageCap = 0;
-        HIPCHK(c, hipMalloc((void**)&c->dSrcStage, srcSize + 64)); c->srcStageCap = srcSize + 64;
-    }
-    if (c->dstStageCap < bound + 64) {
-        (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0;
-        HIPCHK(c, hipMalloc((void**)&c->dDstStage, bound + 64)); c->dstStageCap = bound + 64;
-    }
-    if (srcSize) HIPCHK(c, hipMemcpyAsync(c->dSrcStage, (const uint8_t*)src + lo, srcSize, hipMemcpyHostToDevice, c->stream));
-    std::vector<unsigned long long> rel(nFrames + 1);
-    for (size_t i = 0; i <= nFrames; i++) rel[i] = srcOffsets[i] - lo;
-    size_t const total = frames_device_locked(c, c->dDstStage, c->dstStageCap, c->dSrcStage, rel.data(), nFrames, level, nullptr, c->stream, MtParams{true, jobSize, overlapLog});
-    if (zhip_isError(total)) return total;
-    HIPCHK(c, hipMemcpy(dst, c->dDstStage, total, hipMemcpyDeviceToHost));
-    if (frameSizes) for (size_t i = 0; i < nFrames; i++) frameSizes[i] = c->hFrameSizes[i];
-    return total;
+    return frames_host(c, dst, dstCapacity, src, srcOffsets, nFrames, level, cparams, frameSizes, MtParams{true, jobSize, overlapLog});
 }
 
 // One CHUNK of a job-pool frame on one context (zhip_compress_frame_mt_multi, zhip_multi.h): jobs[0..nJobs) in frame order, with
