@@ -15,6 +15,7 @@
 /* ------------------------------------------------------------------ small helpers */
 static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static uint32_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 static unsigned hb32(uint32_t v) { return 31u - (unsigned)__builtin_clz(v); }          /* lib/common/bits.h:177 */
 static void wr16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static void wr24(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); }
@@ -554,6 +555,198 @@ static size_t zo_lazy(const zo_cparams* cp, const uint8_t* src, size_t n, zo_sto
     return n - anchor;
 }
 
+/* ---- the same parser for the blocks of a multi-block frame: the match state lives across blocks (zstd_lazy.c:1516-1779 with a
+ * prefix; positions are relative to the frame start, the reference's indices are position + 2).  S->low = window.lowLimit =
+ * window.dictLimit as a position: what ZSTD_window_enforceMaxDist (zstd_compress.c:4555, called with the block START) has left. */
+typedef struct { zo_hc hc; zo_row rw; int useRow; size_t low; unsigned windowLog; } zo_lz;
+
+static size_t zo_lz_low_limit(const zo_lz* S, size_t ip)                          /* ZSTD_getLowestMatchIndex, no dictionary (internal.h:1312) */
+{
+    size_t const maxDist = (size_t)1 << S->windowLog;
+    return (ip - S->low > maxDist) ? ip - maxDist : S->low;
+}
+static size_t zo_hc_best_w(zo_lz* S, const uint8_t* src, size_t bEnd, size_t ip, uint32_t* offBase)   /* :667-773 */
+{
+    zo_hc* const hc = &S->hc;
+    uint32_t const cmask = (1u << hc->clog) - 1;
+    size_t const chainSize = (size_t)1 << hc->clog;
+    size_t const lowLimit = zo_lz_low_limit(S, ip);
+    unsigned nbAttempts = 1u << hc->slog;
+    size_t ml = 4 - 1, idx = hc->nextToUpdate;
+    uint32_t m;
+    while (idx < ip) {                                                           /* :645-653 */
+        uint32_t const h = zo_hash(src + idx, hc->hlog, hc->mls);
+        hc->chain[idx & cmask] = hc->head[h];
+        hc->head[h] = (uint32_t)idx + 1;
+        idx++;
+        if (hc->lazySkipping) break;
+    }
+    hc->nextToUpdate = ip;
+    m = hc->head[zo_hash(src + ip, hc->hlog, hc->mls)];
+    for (; m != 0 && (size_t)(m - 1) >= lowLimit && nbAttempts > 0; nbAttempts--) {   /* :711 matchIndex >= lowLimit */
+        size_t const mp = m - 1;
+        size_t cur = 0;
+        if (rd32(src + mp + ml - 3) == rd32(src + ip + ml - 3)) cur = zo_count(src, ip, mp, bEnd);
+        if (cur > ml) {
+            ml = cur; *offBase = (uint32_t)(ip - mp) + 3;
+            if (ip + cur == bEnd) break;
+        }
+        if (ip + 2 > chainSize && mp + chainSize <= ip) break;                   /* :732 matchIndex <= minChain, indices = position + 2 */
+        m = hc->chain[mp & cmask];
+    }
+    return ml;
+}
+static size_t zo_row_best_w(zo_lz* S, const uint8_t* src, size_t bEnd, size_t ip, uint32_t* offBase)   /* :1141-1340 */
+{
+    zo_row* const r = &S->rw;
+    unsigned const rowEntries = 1u << r->rowLog, rowMask = rowEntries - 1;
+    unsigned const capped = r->slog < r->rowLog ? r->slog : r->rowLog;
+    size_t const lowLimit = zo_lz_low_limit(S, ip);
+    unsigned nbAttempts = 1u << capped, numMatches = 0, k;
+    uint32_t buf[64];
+    size_t ml = 4 - 1;
+    uint32_t h;
+    if (!r->lazySkipping) zo_row_update(r, src, ip);
+    else r->nextToUpdate = ip;
+    h = zo_hash_salted(src + ip, r->rowHashLog + 8, r->mls, r->salt);
+    {   size_t const rel = (size_t)(h >> 8) << r->rowLog;
+        uint8_t* const tagRow = r->tag + rel; uint32_t* const row = r->row + rel;
+        unsigned const head = tagRow[0] & rowMask;
+        for (k = 0; k < rowEntries && nbAttempts > 0; k++) {
+            unsigned const pos = (head + k) & rowMask;
+            if (tagRow[pos] != (uint8_t)h) continue;
+            if (pos == 0) continue;
+            if (row[pos] == 0 || (size_t)(row[pos] - 1) < lowLimit) break;       /* :1235 matchIndex < lowLimit */
+            buf[numMatches++] = row[pos] - 1;
+            nbAttempts--;
+        }
+        {   unsigned const pos = zo_row_next_index(tagRow, rowMask);
+            tagRow[pos] = (uint8_t)h;
+            row[pos] = (uint32_t)r->nextToUpdate + 1;
+            r->nextToUpdate++;
+        }
+    }
+    for (k = 0; k < numMatches; k++) {
+        size_t const mp = buf[k];
+        size_t cur = 0;
+        if (rd32(src + mp + ml - 3) == rd32(src + ip + ml - 3)) cur = zo_count(src, ip, mp, bEnd);
+        if (cur > ml) { ml = cur; *offBase = (uint32_t)(ip - mp) + 3; if (ip + cur == bEnd) break; }
+    }
+    return ml;
+}
+static int zo_lz_init(zo_lz* S, const zo_cparams* cp)
+{
+    memset(S, 0, sizeof(*S));
+    S->useRow = g_zo_row_matcher && cp->windowLog > 14; S->windowLog = cp->windowLog;
+    S->hc.hlog = cp->hashLog; S->hc.clog = cp->chainLog; S->hc.slog = cp->searchLog;
+    S->hc.mls = cp->minMatch < 4 ? 4 : (cp->minMatch > 6 ? 6 : cp->minMatch);
+    S->rw.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog);
+    S->rw.rowHashLog = cp->hashLog - S->rw.rowLog; S->rw.slog = cp->searchLog; S->rw.mls = S->hc.mls;
+    S->rw.salt = zo_fresh_hash_salt();
+    if (S->useRow) { S->rw.row = (uint32_t*)calloc((size_t)1 << cp->hashLog, sizeof(uint32_t)); S->rw.tag = (uint8_t*)calloc((size_t)1 << cp->hashLog, 1); return S->rw.row && S->rw.tag; }
+    S->hc.head = (uint32_t*)calloc((size_t)1 << S->hc.hlog, sizeof(uint32_t));
+    S->hc.chain = (uint32_t*)calloc((size_t)1 << S->hc.clog, sizeof(uint32_t));
+    return S->hc.head && S->hc.chain;
+}
+static void zo_lz_free(zo_lz* S) { free(S->hc.head); free(S->hc.chain); free(S->rw.row); free(S->rw.tag); }
+
+/* one block [bStart, bStart + bLen) of the frame; returns the trailing literals */
+static size_t zo_lazy_block(const zo_cparams* cp, const uint8_t* src, size_t bStart, size_t bLen, zo_lz* S, zo_store* st, uint32_t rep[3], unsigned depth)
+{
+    size_t const maxDist = (size_t)1 << cp->windowLog;
+    size_t const bEnd = bStart + bLen;
+    size_t const guard = S->useRow ? 16 : 8;                                     /* :1527 */
+    size_t ilimit, ip = bStart, anchor = bStart;
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
+    size_t* const ntu = S->useRow ? &S->rw.nextToUpdate : &S->hc.nextToUpdate;
+    /* zstd_compress.c:4555 ZSTD_window_enforceMaxDist(block start), then :3243-3249 "limited update after a very long match" */
+    if (bStart + 2 > maxDist && bStart > maxDist && bStart - maxDist > S->low) S->low = bStart - maxDist;
+    if (bStart > *ntu + 384) { size_t const d = bStart - *ntu - 384; *ntu = bStart - (d < 192 ? d : 192); }
+    S->hc.lazySkipping = S->rw.lazySkipping = 0;                                 /* :1567 */
+    if (bLen < guard) return bLen;
+    ilimit = bEnd - guard;
+#define ZO_BESTW(ipx, ob) (S->useRow ? zo_row_best_w(S, src, bEnd, (ipx), (ob)) : zo_hc_best_w(S, src, bEnd, (ipx), (ob)))
+    ip += (ip == S->low);                                                        /* :1552 dictAndPrefixLength == 0 */
+    {   size_t const windowLow = (ip - S->low > maxDist) ? ip - maxDist : S->low;   /* :1553-1559 ZSTD_getLowestPrefixIndex */
+        size_t const maxRep = ip - windowLow;
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
+    }
+    while (ip < ilimit) {
+        size_t matchLength = 0, start = ip + 1;
+        uint32_t offBase = 1;
+        int direct = 0;
+        if (off1 > 0 && rd32(src + ip + 1 - off1) == rd32(src + ip + 1)) {
+            matchLength = zo_count(src, ip + 1 + 4, ip + 1 + 4 - off1, bEnd) + 4;
+            if (depth == 0) direct = 1;
+        }
+        if (!direct) {
+            {   uint32_t found = 999999999;
+                size_t const ml2 = ZO_BESTW(ip, &found);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+            }
+            if (matchLength < 4) {
+                size_t const step = ((ip - anchor) >> 8) + 1;
+                ip += step;
+                S->hc.lazySkipping = S->rw.lazySkipping = step > 8;
+                continue;
+            }
+            if (depth >= 1)
+            while (ip < ilimit) {
+                ip++;
+                if (offBase && off1 > 0 && rd32(src + ip) == rd32(src + ip - off1)) {
+                    size_t const mlRep = zo_count(src, ip + 4, ip + 4 - off1, bEnd) + 4;
+                    int const gain2 = (int)(mlRep * 3);
+                    int const gain1 = (int)(matchLength * 3 - zo_gain_bits(offBase) + 1);
+                    if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                }
+                {   uint32_t cand = 999999999;
+                    size_t const ml2 = ZO_BESTW(ip, &cand);
+                    int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                    int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 4);
+                    if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                }
+                if (depth == 2 && ip < ilimit) {
+                    ip++;
+                    if (offBase && off1 > 0 && rd32(src + ip) == rd32(src + ip - off1)) {
+                        size_t const mlRep = zo_count(src, ip + 4, ip + 4 - off1, bEnd) + 4;
+                        int const gain2 = (int)(mlRep * 4);
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 1);
+                        if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                    {   uint32_t cand = 999999999;
+                        size_t const ml2 = ZO_BESTW(ip, &cand);
+                        int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 7);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3) {                                                   /* :1707-1714: match start > prefixLowest */
+                uint32_t const off = offBase - 3;
+                while (start > anchor && start - off > S->low && src[start - 1] == src[start - off - 1]) { start--; matchLength++; }
+                off2 = off1; off1 = off;
+            }
+        }
+        zo_store_seq(st, src, anchor, start - anchor, offBase, (uint32_t)matchLength);
+        anchor = ip = start + matchLength;
+        S->hc.lazySkipping = S->rw.lazySkipping = 0;
+        while (ip <= ilimit && off2 > 0 && rd32(src + ip) == rd32(src + ip - off2)) {
+            uint32_t const t = off2;
+            matchLength = zo_count(src, ip + 4, ip + 4 - off2, bEnd) + 4;
+            off2 = off1; off1 = t;
+            zo_store_seq(st, src, anchor, 0, 1, (uint32_t)matchLength);
+            ip += matchLength; anchor = ip;
+        }
+    }
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+    rep[0] = off1 ? off1 : saved1;
+    rep[1] = off2 ? off2 : saved2;
+#undef ZO_BESTW
+    return bEnd - anchor;
+}
+
 /* zstd_compress.c:3207-3369 ZSTD_buildSeqStore for a history-less block (+ :3365 trailing literals) */
 size_t zo_parse_block(const zo_cparams* cp, const uint8_t* src, size_t n,
                       zo_seq* seqs, size_t cap, uint8_t* lits, size_t* litSize, uint32_t repOut[3])
@@ -654,6 +847,7 @@ typedef struct {
     uint16_t state[512];            /* next-state table, sorted by symbol (fse_compress.c:170-173) */
     int32_t  dFind[64];             /* deltaFindState */
     uint32_t dBits[64];             /* deltaNbBits    */
+    unsigned maxSym;                /* FSE_CTable header: maxSymbolValue (what ZSTD_getFSEMaxSymbolValue reads) */
 } zo_fse;
 
 /* fse_compress.c:348-374 */
@@ -803,7 +997,7 @@ static void fse_build(zo_fse* ct, const short* norm, unsigned maxSym, unsigned t
     uint32_t const step = (tableSize >> 1) + (tableSize >> 3) + 3;               /* FSE_TABLESTEP */
     uint16_t cumul[66]; uint8_t sym[512];
     uint32_t high = tableSize - 1, u, pos = 0; unsigned s, total = 0;
-    ct->tableLog = tableLog;
+    ct->tableLog = tableLog; ct->maxSym = maxSym;
     cumul[0] = 0;
     for (u = 1; u <= maxSym + 1; u++) {
         if (norm[u-1] == -1) { cumul[u] = cumul[u-1] + 1; sym[high--] = (uint8_t)(u - 1); }
@@ -835,7 +1029,7 @@ static void fse_build(zo_fse* ct, const short* norm, unsigned maxSym, unsigned t
 }
 static void fse_build_rle(zo_fse* ct, unsigned symbol)                           /* fse_compress.c:528 */
 {
-    ct->tableLog = 0; ct->state[0] = 0; ct->state[1] = 0;
+    ct->tableLog = 0; ct->state[0] = 0; ct->state[1] = 0; ct->maxSym = symbol;
     ct->dBits[symbol] = 0; ct->dFind[symbol] = 0;
 }
 
@@ -1401,22 +1595,44 @@ static const unsigned kInvProbLog256[256] = {
 static unsigned fse_optimal_log(unsigned maxLog, size_t n, unsigned maxSym, unsigned minus);
 static size_t fse_write_ncount(uint8_t* out0, const short* norm, unsigned maxSym, unsigned tableLog);
 
-/* zstd_compress_sequences.c:157-235 with repeatMode none. returns set_* (0 basic,1 rle,2 compressed) */
-static int select_type(const unsigned* count, unsigned max, unsigned maxCount, size_t nbSeq, unsigned fseLog,
-                       const short* defNorm, unsigned defaultNormLog, int defaultAllowed, unsigned strategy, int repeatMode)
+/* zstd_compress_sequences.c:103-135 ZSTD_fseBitCost: cost in bits of coding `count` with a previous table, (size_t)-1 when it cannot */
+static size_t fse_bit_cost(const zo_fse* ct, const unsigned* count, unsigned max)
 {
-    if (maxCount == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+    size_t cost = 0; unsigned s;
+    unsigned const tableLog = ct->tableLog, badCost = (tableLog + 1) << 8;
+    if (ct->maxSym < max) return (size_t)-1;
+    for (s = 0; s <= max; s++) {
+        uint32_t const minNbBits = ct->dBits[s] >> 16, threshold = (minNbBits + 1) << 16;      /* lib/common/fse.h:494-509 FSE_bitCost */
+        uint32_t const tableSize = 1u << tableLog;
+        uint32_t const deltaFromThreshold = threshold - (ct->dBits[s] + tableSize);
+        uint32_t const normalized = (deltaFromThreshold << 8) >> tableLog;
+        uint32_t const bitCost = (minNbBits + 1) * 256 - normalized;
+        if (count[s] == 0) continue;
+        if (bitCost >= badCost) return (size_t)-1;
+        cost += (size_t)count[s] * bitCost;
+    }
+    return cost >> 8;
+}
+
+/* zstd_compress_sequences.c:157-235 ZSTD_selectEncodingType. *repeatMode (FSE_repeat: 0 none, 1 check, 2 valid) is the state of
+ * prevCT coming in and of the table this block leaves behind going out.  returns set_* (0 basic, 1 rle, 2 compressed, 3 repeat) */
+static int select_type(const unsigned* count, unsigned max, unsigned maxCount, size_t nbSeq, unsigned fseLog,
+                       const short* defNorm, unsigned defaultNormLog, int defaultAllowed, unsigned strategy,
+                       const zo_fse* prevCT, int* repeatMode)
+{
+    if (maxCount == nbSeq) { *repeatMode = 0; return (defaultAllowed && nbSeq <= 2) ? 0 : 1; }
     if (strategy < 4) {                                                          /* :179-204, strategy < ZSTD_lazy */
         if (defaultAllowed) {
             size_t const mult = 10 - strategy;
             size_t const dynMin = (((size_t)1 << defaultNormLog) * mult) >> 3;
-            if (repeatMode == 2 && nbSeq < 1000) return 3;                       /* :187-191 set_repeat with a VALID previous table */
-            if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) return 0;
+            if (*repeatMode == 2 && nbSeq < 1000) return 3;                      /* :187-191 set_repeat with a VALID previous table */
+            if (nbSeq < dynMin || maxCount < (nbSeq >> (defaultNormLog - 1))) { *repeatMode = 0; return 0; }
         }
+        *repeatMode = 1;
         return 2;
     }
-    {   /* :205-231: estimated costs in bits; the repeat cost is an error (= huge) without a previous table */
-        size_t basicCost = (size_t)-1, ncountCost, compressedCost;
+    {   /* :205-231: estimated costs in bits; an impossible choice costs "error" = more than anything */
+        size_t basicCost = (size_t)-1, repeatCost = (size_t)-1, ncountCost, compressedCost;
         unsigned s;
         if (defaultAllowed) {                                                    /* :141-155 ZSTD_crossEntropyCost */
             unsigned const shift = 8 - defaultNormLog;
@@ -1427,6 +1643,7 @@ static int select_type(const unsigned* count, unsigned max, unsigned maxCount, s
             }
             basicCost = cost >> 8;
         }
+        if (*repeatMode != 0 && prevCT) repeatCost = fse_bit_cost(prevCT, count, max);
         {   short norm[53]; uint8_t wksp[512];                                   /* :70-77 ZSTD_NCountCost */
             unsigned const tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
             if (zo_fse_normalize(norm, tableLog, count, nbSeq, max, nbSeq >= 2048) < 0) return -1;
@@ -1441,7 +1658,9 @@ static int select_type(const unsigned* count, unsigned max, unsigned maxCount, s
             }
             compressedCost = (ncountCost << 3) + (cost >> 8);
         }
-        if (basicCost <= compressedCost) return 0;                               /* :217-222 (repeatCost = error >= everything) */
+        if (basicCost <= repeatCost && basicCost <= compressedCost) { *repeatMode = 0; return 0; }   /* :217-222 */
+        if (repeatCost <= compressedCost) return 3;                              /* :223-227, the state of the table stays */
+        *repeatMode = 1;
         return 2;
     }
 }
@@ -1465,6 +1684,7 @@ static size_t build_ctable(uint8_t* dst, zo_fse* ct, unsigned fseLog, int type, 
 }
 
 /* zstd_compress.c:2934-2997 + :2756-2873 + zstd_compress_sequences.c:291-382 */
+static zo_prev* g_fse_next = NULL;   /* when set: receives the three FSE tables the sequences were coded with and their repeat states (multi-block frames) */
 size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp, const zo_prev* pv);
 size_t zo_compress_sequences(uint8_t* dst, size_t cap, const zo_seq* seqs, size_t nbSeq, const zo_cparams* cp)
 {
@@ -1476,6 +1696,7 @@ size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, 
     uint8_t *llc, *ofc, *mlc; size_t i, lastCount = 0;
     static zo_fse ctLL, ctOF, ctML;
     unsigned count[64], max; int tLL, tOF, tML;
+    int rLL = pv ? pv->llRepeat : 0, rOF = pv ? pv->ofRepeat : 0, rML = pv ? pv->mlRepeat : 0;
     (void)cap;
     if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
     else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
@@ -1490,7 +1711,7 @@ size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, 
     seqHead = op++;
     {   size_t h, mf;
         max = 35; mf = hist_small(count, &max, llc, nbSeq);
-        tLL = select_type(count, max, (unsigned)mf, nbSeq, 9, kLLnorm, 6, 1, cp->strategy, pv ? pv->llRepeat : 0);
+        tLL = select_type(count, max, (unsigned)mf, nbSeq, 9, kLLnorm, 6, 1, cp->strategy, pv ? &pv->ll : NULL, &rLL);
         if (tLL < 0) { free(llc); return ZO_ERROR; }
         if (tLL == 3) { ctLL = pv->ll; h = 0; } else
         h = build_ctable(op, &ctLL, 9, tLL, count, max, llc, nbSeq, kLLnorm, 6, 35);
@@ -1498,7 +1719,7 @@ size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, 
         if (tLL == 2) lastCount = h;
         op += h;
         max = 31; mf = hist_small(count, &max, ofc, nbSeq);
-        tOF = select_type(count, max, (unsigned)mf, nbSeq, 8, kOFnorm, 5, max <= 28, cp->strategy, pv ? pv->ofRepeat : 0);
+        tOF = select_type(count, max, (unsigned)mf, nbSeq, 8, kOFnorm, 5, max <= 28, cp->strategy, pv ? &pv->of : NULL, &rOF);
         if (tOF < 0) { free(llc); return ZO_ERROR; }
         if (tOF == 3) { ctOF = pv->of; h = 0; } else
         h = build_ctable(op, &ctOF, 8, tOF, count, max, ofc, nbSeq, kOFnorm, 5, 28);
@@ -1506,7 +1727,7 @@ size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, 
         if (tOF == 2) lastCount = h;
         op += h;
         max = 52; mf = hist_small(count, &max, mlc, nbSeq);
-        tML = select_type(count, max, (unsigned)mf, nbSeq, 9, kMLnorm, 6, 1, cp->strategy, pv ? pv->mlRepeat : 0);
+        tML = select_type(count, max, (unsigned)mf, nbSeq, 9, kMLnorm, 6, 1, cp->strategy, pv ? &pv->ml : NULL, &rML);
         if (tML < 0) { free(llc); return ZO_ERROR; }
         if (tML == 3) { ctML = pv->ml; h = 0; } else
         h = build_ctable(op, &ctML, 9, tML, count, max, mlc, nbSeq, kMLnorm, 6, 52);
@@ -1515,6 +1736,10 @@ size_t zo_compress_sequences_prev(uint8_t* dst, size_t cap, const zo_seq* seqs, 
         op += h;
     }
     *seqHead = (uint8_t)((tLL << 6) + (tOF << 4) + (tML << 2));
+    if (g_fse_next) {                                                            /* nextEntropy->fse: the tables this block used, and their states */
+        g_fse_next->ll = ctLL; g_fse_next->of = ctOF; g_fse_next->ml = ctML;
+        g_fse_next->llRepeat = rLL; g_fse_next->ofRepeat = rOF; g_fse_next->mlRepeat = rML;
+    }
     {   zo_bits b; uint32_t sML, sOF, sLL; size_t n = nbSeq - 1; uint8_t* end;     /* zstd_compress_sequences.c:291-382 */
         bw_init(&b, op);
         sML = fse_init2(&ctML, mlc[n]); sOF = fse_init2(&ctOF, ofc[n]); sLL = fse_init2(&ctLL, llc[n]);
@@ -2461,7 +2686,41 @@ typedef struct {
     int isFirst;              /* zc->isFirstBlock */
     long long savings;        /* consumedSrcSize - producedCSize of the context (zstd_compress.c:4538): what frame chunks inherit from one another */
     zo_seq* seqs; uint8_t* lits; uint8_t* body;
+    zo_lz lz;                 /* greedy / lazy / lazy2: hash chain or rows, nextToUpdate, window low */
 } zo_fctx;
+
+/* zstd_preSplit.c:139-181 ZSTD_splitBlock(split_lvl1) = ZSTD_splitBlock_byChunks with one 2-byte event out of five: what ZSTD_lazy2
+ * uses to place a block boundary inside the next 128 KB once the frame has saved 3 bytes (zstd_compress.c:4510-4511).  8 KB chunks;
+ * the fingerprint of what came before against the next chunk's; the first "too different" chunk starts the next block. */
+typedef struct { unsigned events[1024]; size_t nbEvents; } zo_fp;
+static void zo_fp_record(zo_fp* fp, const uint8_t* p, size_t n)                  /* :47-58, :79-83 */
+{
+    size_t const limit = n - 2 + 1; size_t i;
+    memset(fp, 0, sizeof(*fp));
+    for (i = 0; i < limit; i += 5) fp->events[(uint32_t)(rd16(p + i) * 0x9e3779b9u) >> (32 - 10)]++;
+    fp->nbEvents += limit / 5;
+}
+static size_t zo_split_block_lvl1(const uint8_t* p, size_t srcSize)
+{
+    static zo_fp past, cur;
+    int penalty = 3; size_t pos;
+    if (srcSize <= ZO_BLOCK_MAX) return srcSize;
+    zo_fp_record(&past, p, 8192);
+    for (pos = 8192; pos <= ZO_BLOCK_MAX - 8192; pos += 8192) {
+        uint64_t deviation = 0, threshold; size_t k;
+        zo_fp_record(&cur, p + pos, 8192);
+        for (k = 0; k < 1024; k++) {                                             /* :87-97 fpDistance */
+            int64_t const d = (int64_t)past.events[k] * (int64_t)cur.nbEvents - (int64_t)cur.events[k] * (int64_t)past.nbEvents;
+            deviation += (uint64_t)(d < 0 ? -d : d);
+        }
+        threshold = (uint64_t)past.nbEvents * (uint64_t)cur.nbEvents * (uint64_t)(14 + penalty) / 16;   /* :102-114 */
+        if (deviation >= threshold) return pos;
+        for (k = 0; k < 1024; k++) past.events[k] += cur.events[k];
+        past.nbEvents += cur.nbEvents;
+        if (penalty > 0) penalty--;
+    }
+    return ZO_BLOCK_MAX;
+}
 
 /* ZSTD_compress_frameChunk (zstd_compress.c:4527-4623) over src[pos, pos + len): `savings` starts from the context's running total; lastChunk = the
  * call that ends the frame (its final block carries the last-block bit).  Returns the bytes written at op, ZO_ERROR on failure. */
@@ -2474,13 +2733,14 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
         size_t const remaining = end - pos;
         size_t bLen = remaining < ZO_BLOCK_MAX ? remaining : ZO_BLOCK_MAX;       /* :4494-4518 ZSTD_optimalBlockSize, strategies below lazy2 */
         size_t cSize = 0; int last;
-        if (remaining >= ZO_BLOCK_MAX && savings >= 3) bLen = 92 * 1024;
+        if (remaining >= ZO_BLOCK_MAX && savings >= 3) bLen = cp->strategy >= 5 ? zo_split_block_lvl1(src + pos, remaining) : 92 * 1024;
         last = lastChunk && bLen == remaining;
         if (bLen >= 7) {                                                         /* :3216 */
             zo_store st; uint32_t nrep[3] = { f->rep[0], f->rep[1], f->rep[2] };
             size_t lastLits; zo_prev next;
             st.seqs = f->seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = f->lits; st.litSize = 0; st.overflow = 0;
-            lastLits = cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
+            lastLits = cp->strategy >= 3 ? zo_lazy_block(cp, src, pos, bLen, &f->lz, &st, nrep, cp->strategy - 3)
+                     : cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
                                          : zo_fast_block(cp, src, pos, bLen, f->T, &st, nrep);
             memcpy(f->lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
             next = f->prev;
@@ -2490,7 +2750,9 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
                 l = zo_compress_literals_prev(f->body, ZO_BLOCK_MAX + 1024, f->lits, st.litSize, cp, suspect, &f->prev);
                 g_huf_next = NULL;
                 if (l >= 1 && (f->body[0] & 3) < 2) next = f->prev;              /* raw / RLE literals: the previous table stays (literals.c:186, :199) */
-                sq = zo_compress_sequences(f->body + l, ZO_BLOCK_MAX + 1024 - l, f->seqs, st.nb, cp);
+                g_fse_next = &next;                                              /* the FSE tables and their repeat states carry over like the Huffman table */
+                sq = zo_compress_sequences_prev(f->body + l, ZO_BLOCK_MAX + 1024 - l, f->seqs, st.nb, cp, &f->prev);
+                g_fse_next = NULL;
                 if (sq == ZO_ERROR || st.overflow) return ZO_ERROR;
                 cSize = (sq == 0) ? 0 : l + sq;
                 if (cSize >= bLen - ((bLen >> 6) + 2)) cSize = 0;                /* :3026 */
@@ -2501,6 +2763,7 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
                 if (same) { cSize = 1; f->body[0] = src[pos]; }
             }
             if (cSize > 1) { f->rep[0] = nrep[0]; f->rep[1] = nrep[1]; f->rep[2] = nrep[2]; f->prev = next; }   /* :4379-4381 */
+            if (f->prev.ofRepeat == 2) f->prev.ofRepeat = 1;                     /* :3365-3367 offset codes of a dictionary are only trusted for the first block */
         }
         if (cSize == 0) { wr24(op, (uint32_t)(last + (0 << 1) + (bLen << 3))); memcpy(op + 3, src + pos, bLen); cSize = 3 + bLen; }
         else if (cSize == 1) { wr24(op, (uint32_t)(last + (1 << 1) + (bLen << 3))); op[3] = f->body[0]; cSize = 4; }
@@ -2516,6 +2779,8 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
 static int zo_fctx_init(zo_fctx* f, const zo_cparams* cp)
 {
     memset(f, 0, sizeof(*f));
+    if (cp->strategy >= 3) { if (!zo_lz_init(&f->lz, cp)) return 0; f->T = (uint32_t*)calloc(1, sizeof(uint32_t)); }
+    else
     f->T = (uint32_t*)calloc(((size_t)1 << cp->hashLog) + (cp->strategy == 2 ? (size_t)1 << cp->chainLog : 0), sizeof(uint32_t));   /* dfast: long table, then short table */
     f->seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 2));
     f->lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 8);
@@ -2523,14 +2788,14 @@ static int zo_fctx_init(zo_fctx* f, const zo_cparams* cp)
     f->isFirst = 1;
     return f->T && f->seqs && f->lits && f->body;
 }
-static void zo_fctx_free(zo_fctx* f) { free(f->T); free(f->seqs); free(f->lits); free(f->body); }
+static void zo_fctx_free(zo_fctx* f) { free(f->T); free(f->seqs); free(f->lits); free(f->body); zo_lz_free(&f->lz); }
 
 size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cparams* cp)
 {
     uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
     uint8_t* op = dst;
     zo_fctx f; size_t r;
-    if ((cp->strategy != 1 && cp->strategy != 2) || cap < zo_frame_bound(n)) return ZO_ERROR;
+    if (cp->strategy < 1 || cp->strategy > 5 || cap < zo_frame_bound(n)) return ZO_ERROR;   /* fast .. lazy2 */
     op += write_frame_header(op, cp, n);
     if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
     if (!zo_fctx_init(&f, cp)) { zo_fctx_free(&f); return ZO_ERROR; }

@@ -428,3 +428,35 @@ def ref_frame_mt(lr, a, level, job_size=0, overlap_log=0, checksum=False, cp=Non
     r = lr.zref_compress_frame_mt(level, cpi, job_size, overlap_log, 1 if checksum else 0, _buf(a), len(a), _buf(dst), len(dst))
     assert r != ERR
     return dst[:r].tobytes()
+
+
+def lazy_frame_cases(lo):
+    """inputs for the multi-block frames of the lazy strategies (tests/golden/frames_lazy_v1.json pins the reference's output)"""
+    rng = np.random.default_rng(55)
+    yield "dg_400000", datagen(lo, 400000, 50, 5)
+    yield "dg_p85_2.5m", datagen(lo, 2_500_000, 85, 7)               # beyond the chain table, long matches: the 384 / 192 nextToUpdate rule at block starts
+    yield "text_700k", text_like(700000, 3)
+    yield "random_300k", rng.integers(0, 256, size=300000, dtype=np.uint8)
+    yield "zeros_500k", np.zeros(500000, np.uint8)
+    yield "mixed_900k", np.concatenate([datagen(lo, 250000, 50, 1), rng.integers(0, 256, size=200000, dtype=np.uint8),
+                                        np.full(200000, 7, np.uint8), text_like(250000, 9)])     # the fingerprint splitter of lazy2 sees borders
+    yield "tail_10", datagen(lo, 131072 + 10, 50, 9)                 # a last block below the row matcher's 16-byte guard
+
+
+# (level, noRow) of the lazy-frame golden: greedy 5, lazy 6-7, lazy2 8-10; the row matcher (the reference's default) and the hash chain
+LAZY_FRAME_MODES = [(5, 0), (5, 1), (6, 0), (7, 1), (8, 0), (9, 1), (10, 0)]
+
+
+def oracle_frame_params(lo, a, cp, row):
+    lo.zo_compress_frame_params.restype = C.c_size_t
+    lo.zo_compress_frame_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
+    lo.zo_set_row_matcher(1 if row else 0)
+    try:
+        cap = lo.zo_frame_bound(len(a))
+        dst = np.zeros(cap, dtype=np.uint8)
+        r = lo.zo_compress_frame_params(_buf(dst), cap, _buf(a), len(a), cp)
+        assert r != ERR
+        return dst[:r].tobytes()
+    finally:
+        lo.zo_set_row_matcher(0)

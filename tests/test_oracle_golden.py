@@ -144,3 +144,27 @@ def test_oracle_reproduces_golden_job_pool_frames():
             assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, js, ov, ck)
             seen += 1
     assert seen == len(gold) == 64
+
+
+GOLD_FRAMES_LAZY = os.path.join(os.path.dirname(__file__), "golden", "frames_lazy_v1.json")
+
+
+def test_oracle_reproduces_golden_lazy_multiblock_frames():
+    """greedy / lazy / lazy2 across the blocks of one frame (zo_lazy_block: hash chain or rows, nextToUpdate and the window carried from
+    block to block, the 384 / 192 catch-up rule at block starts; FSE tables repeated by cost, zstd_compress_sequences.c:205-231; the
+    fingerprint block splitter of lazy2, zstd_preSplit.c) — the oracle side of the next frame kernel"""
+    from _libs import lazy_frame_cases, LAZY_FRAME_MODES, oracle_frame_params
+    import ctypes as C
+    lo = load_oracle()
+    gold = {(g["case"], g["level"], g["noRow"]): g for g in json.load(open(GOLD_FRAMES_LAZY))["frames"]}
+    seen = 0
+    for name, a in lazy_frame_cases(lo):
+        for level, no_row in LAZY_FRAME_MODES:
+            g = gold[(name, level, no_row)]
+            assert hashlib.sha256(a.tobytes()).hexdigest() == g["src_sha256"], name
+            cp = (C.c_uint * 7)()
+            assert lo.zo_get_cparams(level, len(a), cp) == 0
+            out = oracle_frame_params(lo, a, cp, row=not no_row)
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, no_row)
+            seen += 1
+    assert seen == len(gold) == 49

@@ -294,3 +294,37 @@ def test_job_pool_frame_with_explicit_parameters_vs_reference(libs):
         assert oracle_frame_mt(lo, a, level, js, ov, ck, cp=eff) == ref_frame_mt(lr, a, level, js, ov, ck, cp=req), (len(a), level, req, js, ov, ck)
         seen += 1
     assert seen >= 24
+
+
+def test_lazy_multiblock_frames_vs_reference(libs):
+    """zo_compress_frame_params at the greedy / lazy / lazy2 strategies against ZSTD_compress2 of the whole input: random sizes up to 2 MB,
+    random explicit parameters (windows below the input size, chain tables far smaller than the window, search depths, minMatch 3-6),
+    row matcher on and off"""
+    lo, lr = libs
+    from _libs import oracle_frame_params
+    import zstd_amd
+    L = zstd_amd.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    lr.zref_compress_chunks_level_params.restype = C.c_size_t
+    lr.zref_compress_chunks_level_params.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(77)
+    seen = 0
+    for t in range(24):
+        n = int(rng.integers(131073, 2_000_000))
+        kind = t % 4
+        a = (datagen(lo, n, int(rng.integers(10, 95)), t) if kind == 0 else text_like(n, t) if kind == 1 else
+             np.concatenate([datagen(lo, n // 2, 60, t), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]) if kind == 2 else
+             np.repeat(rng.integers(0, 256, size=n // 4096 + 1, dtype=np.uint8), 4096)[:n].copy())
+        level = int(rng.choice([5, 6, 7, 8, 10]))
+        req = [int(rng.choice([0, 17, 18, 19, 20])), int(rng.choice([0, 0, 10, 14, 16])), int(rng.choice([0, 0, 12, 15, 17])), int(rng.choice([0, 0, 1, 3, 5, 6])),
+               int(rng.choice([0, 0, 3, 4, 5, 6])), int(rng.choice([0, 0, 4, 32])), int(rng.choice([0, 3, 4, 5]))]
+        eff = (C.c_uint * 7)()
+        if L.zhip_getCParams_explicit(level, n, (C.c_uint * 7)(*req), eff) != 0 or eff[6] not in (3, 4, 5):
+            continue
+        no_row = int(rng.integers(0, 2))
+        want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
+        k = lr.zref_compress_chunks_level_params(level, (C.c_int * 7)(*req), no_row, n, _buf(a), n, _buf(want), len(want))
+        assert k != ERR and oracle_frame_params(lo, a, eff, row=not no_row) == want[:k].tobytes(), (t, n, level, req, list(eff), no_row)
+        seen += 1
+    assert seen >= 12
