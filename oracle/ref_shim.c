@@ -246,6 +246,26 @@ size_t zref_compress_frame_mt(int level, const int cp[7], unsigned long long job
     return ZSTD_isError(r) ? (size_t)-1 : r;
 }
 
+/* the same with the row matcher switched off (ZSTD_c_useRowMatchFinder = ZSTD_ps_disable): the lazy strategies' hash chain */
+size_t zref_compress_frame_mt_norow(int level, const int cp[7], unsigned long long jobSize, int overlapLog, int checksumFlag, int noRow,
+                                    const void* src, size_t n, void* dst, size_t dstCap)
+{
+    static const ZSTD_cParameter ids[7] = { ZSTD_c_windowLog, ZSTD_c_chainLog, ZSTD_c_hashLog, ZSTD_c_searchLog, ZSTD_c_minMatch, ZSTD_c_targetLength, ZSTD_c_strategy };
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r; int i;
+    if (!c) return (size_t)-1;
+    set_level(c, level);
+    if (cp) for (i = 0; i < 7; i++) if (cp[i]) ZSTD_CCtx_setParameter(c, ids[i], cp[i]);
+    if (noRow) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+    if (ZSTD_isError(ZSTD_CCtx_setParameter(c, ZSTD_c_nbWorkers, 1))) { ZSTD_freeCCtx(c); return (size_t)-1; }
+    if (jobSize) ZSTD_CCtx_setParameter(c, ZSTD_c_jobSize, (int)jobSize);
+    if (overlapLog) ZSTD_CCtx_setParameter(c, ZSTD_c_overlapLog, overlapLog);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, checksumFlag);
+    r = ZSTD_compress2(c, dst, dstCap, src, n);
+    ZSTD_freeCCtx(c);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
 /* one frame with chosen frame parameters: contentSizeFlag (0 = the header does not state the size, what streaming without a
  * pledged size emits), checksumFlag, windowLog (0 = level default) — for the decoder tests */
 size_t zref_compress_frame_params(int level, int contentSizeFlag, int checksumFlag, int windowLog, const void* src, size_t n, void* dst, size_t dstCap)

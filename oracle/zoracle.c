@@ -2826,6 +2826,25 @@ static void zo_fill_prefix(const zo_cparams* cp, const uint8_t* src, size_t p0, 
     }
 }
 
+/* the lazy strategies' part of ZSTD_loadDictionaryContent (zstd_compress.c:4878-4965) for a raw-content prefix [p0, p1): the window
+ * starts at p0; of a prefix longer than 8 << max(hashLog, chainLog) only the suffix is indexed; EVERY position up to p1 - 8 goes in
+ * (ZSTD_insertAndFindFirstIndex / ZSTD_row_update without its skip rule), then nextToUpdate = p1: the last 8 never do */
+static void zo_lz_load_prefix(zo_lz* S, const zo_cparams* cp, const uint8_t* src, size_t p0, size_t p1)
+{
+    size_t ip = p0, idx;
+    S->low = p0; S->hc.nextToUpdate = S->rw.nextToUpdate = p1;
+    {   unsigned const big = cp->hashLog > cp->chainLog ? cp->hashLog : cp->chainLog;
+        size_t const maxDict = (size_t)8 << (big < 28 ? big : 28);
+        if (p1 - p0 > maxDict) ip = p1 - maxDict; }
+    if (p1 - ip <= 8) return;
+    if (S->useRow) zo_row_insert_range(&S->rw, src, ip, p1 - 8);
+    else for (idx = ip; idx < p1 - 8; idx++) {
+        uint32_t const h = zo_hash(src + idx, S->hc.hlog, S->hc.mls);
+        S->hc.chain[idx & ((1u << S->hc.clog) - 1)] = S->hc.head[h];
+        S->hc.head[h] = (uint32_t)idx + 1;
+    }
+}
+
 size_t zo_mt_job_size(const zo_cparams* cp, unsigned long long jobSize)
 {
     unsigned long long sec = jobSize;
@@ -2850,7 +2869,7 @@ size_t zo_compress_frame_mt_params(void* dstv, size_t cap, const void* srcv, siz
     uint8_t* op = dst;
     size_t pos = 0, prevLen = 0, section, overlap;
     unsigned k = 0;
-    if ((cp->strategy != 1 && cp->strategy != 2) || cap < zo_frame_bound(n) + 4) return ZO_ERROR;
+    if (cp->strategy < 1 || cp->strategy > 5 || cap < zo_frame_bound(n) + 4) return ZO_ERROR;
     if (n <= (512u << 10)) {                                                     /* single-threaded below ZSTDMT_JOBSIZE_MIN */
         size_t r = zo_compress_frame_params(dst, cap, src, n, cp);
         if (r == ZO_ERROR) return r;
@@ -2870,7 +2889,9 @@ size_t zo_compress_frame_mt_params(void* dstv, size_t cap, const void* srcv, siz
         if (k == 0) { f.rep[0] = 1; f.rep[1] = 4; f.rep[2] = 8; g_zo_win_start = 0; }
         else {
             uint8_t hdr[18];
-            f.rep[0] = f.rep[1] = f.rep[2] = 0; g_zo_win_start = pos - preLen; zo_fill_prefix(cp, src, pos - preLen, pos, f.T);
+            f.rep[0] = f.rep[1] = f.rep[2] = 0; g_zo_win_start = pos - preLen;
+            if (cp->strategy >= 3) zo_lz_load_prefix(&f.lz, cp, src, pos - preLen, pos);
+            else zo_fill_prefix(cp, src, pos - preLen, pos, f.T);
             f.savings = -(long long)write_frame_header(hdr, cp, jLen);           /* the job's own (discarded) frame header counts as produced (:737-741, :4767) */
         }
         for (c0 = 0; c0 < jLen; c0 += (512u << 10)) {

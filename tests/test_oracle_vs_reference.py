@@ -328,3 +328,28 @@ def test_lazy_multiblock_frames_vs_reference(libs):
         assert k != ERR and oracle_frame_params(lo, a, eff, row=not no_row) == want[:k].tobytes(), (t, n, level, req, list(eff), no_row)
         seen += 1
     assert seen >= 12
+
+
+def test_job_pool_frame_lazy_strategies_vs_reference(libs):
+    """ZSTD_c_nbWorkers = 1 at the greedy / lazy / lazy2 levels: a later job's fresh context loads its prefix completely (every position
+    up to 8 before its end, zstd_compress.c:4920-4964) into the hash chain or the rows, overlapLog 7 by default for lazy2 — the oracle
+    against the reference, row matcher on and off (oracle-only so far: DESIGN.md §9 item 4)"""
+    lo, lr = libs
+    lr.zref_compress_frame_mt_norow.restype = C.c_size_t
+    lr.zref_compress_frame_mt_norow.argtypes = [C.c_int, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(17)
+    try:
+        for t in range(6):
+            n = int(rng.integers(600_000, 2_500_000))
+            kind = t % 3
+            a = (datagen(lo, n, int(rng.integers(10, 95)), t) if kind == 0 else text_like(n, t) if kind == 1 else
+                 np.concatenate([datagen(lo, n // 2, 60, t), rng.integers(0, 256, size=n - n // 2, dtype=np.uint8)]))
+            for level in (5, 7, 9):
+                no_row = int(rng.integers(0, 2))
+                js, ov, ck = int(rng.choice([0, 524288, 1 << 20])), int(rng.integers(0, 10)), bool(rng.integers(0, 2))
+                lo.zo_set_row_matcher(0 if no_row else 1)
+                want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
+                k = lr.zref_compress_frame_mt_norow(level, None, js, ov, 1 if ck else 0, no_row, _buf(a), n, _buf(want), len(want))
+                assert k != ERR and oracle_frame_mt(lo, a, level, js, ov, ck) == want[:k].tobytes(), (t, n, level, no_row, js, ov, ck)
+    finally:
+        lo.zo_set_row_matcher(0)
