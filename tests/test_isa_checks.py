@@ -1,0 +1,16 @@
+"""Static checks of the compiled gfx950 code (no GPU needed: hipcc cross-compiles)."""
+import os
+import subprocess
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_barrier_inside_an_exec_controlled_loop():
+    """a loop the compiler controls through EXEC (it could not prove the exit condition uniform) that contains s_barrier is only safe
+    while all lanes of a wavefront leave together — and the compiler may restructure it per lane: the one GPU-only hang of round 2
+     had exactly this shape and passed on the host emulator.  scripts/scan_divergent_barriers.py finds none."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "scan_divergent_barriers.py")], timeout=900).decode()
+    assert "EXEC-controlled loops containing s_barrier: 0" in out, out
