@@ -405,10 +405,18 @@ static void zo_row_insert_range(zo_row* r, const uint8_t* src, size_t from, size
         r->row[rel + pos] = (uint32_t)from + 1;
     }
 }
+/* analysis hook ("two-pass prediction"): log the ranges the 384-position rule leaves out; in PREDICT mode the rule is
+ * only logged, not applied — the parse a device pass would make from records that assume every position inserted */
+static int g_zo_row_predict = 0;
+static size_t g_zo_skiplog[2 * 4096]; static size_t g_zo_skiplog_n = 0;
+void zo_row_analysis(int predict) { g_zo_row_predict = predict; g_zo_skiplog_n = 0; }
+size_t zo_row_skiplog(size_t* out, size_t cap) { size_t i, n = g_zo_skiplog_n < cap ? g_zo_skiplog_n : cap; for (i = 0; i < 2 * n; i++) out[i] = g_zo_skiplog[i]; return g_zo_skiplog_n; }
 static void zo_row_update(zo_row* r, const uint8_t* src, size_t target)          /* :916-947 (useCache) */
 {
     size_t idx = r->nextToUpdate;
     if (target - idx > 384) {                                                    /* kSkipThreshold: only the first 96 and the last 32 */
+        if (g_zo_skiplog_n < 4096) { g_zo_skiplog[2 * g_zo_skiplog_n] = idx + 96; g_zo_skiplog[2 * g_zo_skiplog_n + 1] = target - 32; g_zo_skiplog_n++; }
+        if (g_zo_row_predict) { zo_row_insert_range(r, src, idx, target); r->nextToUpdate = target; return; }
         zo_row_insert_range(r, src, idx, idx + 96);
         idx = target - 32;
     }
