@@ -50,6 +50,28 @@ int main(int argc, char** argv)
     comp[cs / 2] ^= 0x10;                                     /* corrupt one bit: the decoder must refuse (checksum or structure) */
     ds = ZSTD_decompress(back, n, comp, cs);
     if (n > 64 && !ZSTD_isError(ds)) { fprintf(stderr, "corrupted stream was accepted\n"); return 1; }
+    if (n > ((size_t)1 << 20)) {
+        /* ZSTD_c_nbWorkers: the source as ONE standard frame (the bytes of the reference's job pool; a workgroup per job on the device),
+         * and the streaming entry point in its one-shot form, which must give the same bytes */
+        unsigned char* comp2 = (unsigned char*)malloc(bound);
+        ZSTD_inBuffer in; ZSTD_outBuffer out;
+        size_t r;
+        if (!comp2) return 2;
+        ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, 0);
+        if (ZSTD_isError(ZSTD_CCtx_setParameter(c, ZSTD_c_nbWorkers, 4))) { fprintf(stderr, "ZSTD_c_nbWorkers refused\n"); return 1; }
+        ZSTD_CCtx_setParameter(c, ZSTD_c_jobSize, 1 << 20);
+        cs = ZSTD_compress2(c, comp, bound, src, n);
+        if (ZSTD_isError(cs)) { fprintf(stderr, "compress2 with workers: %s\n", ZSTD_getErrorName(cs)); return 1; }
+        if (level >= 1 && level <= 3 && ZSTD_getFrameContentSize(comp, cs) != n) { fprintf(stderr, "not a single frame\n"); return 1; }
+        ds = ZSTD_decompress(back, n, comp, cs);
+        if (ZSTD_isError(ds) || ds != n || memcmp(src, back, n)) { fprintf(stderr, "round trip of the job-pool frame failed\n"); return 1; }
+        in.src = src; in.size = n; in.pos = 0; out.dst = comp2; out.size = bound; out.pos = 0;
+        r = ZSTD_compressStream2(c, &out, &in, ZSTD_e_end);
+        if (r != 0 || in.pos != n || out.pos != cs || memcmp(comp, comp2, cs)) { fprintf(stderr, "compressStream2(e_end) differs from compress2\n"); return 1; }
+        printf("job-pool frame: %zu -> %zu bytes\n", n, cs);
+        ZSTD_CCtx_setParameter(c, ZSTD_c_nbWorkers, 0);
+        free(comp2);
+    }
     {   /* dictionary round trip: ZSTD_createCDict / ZSTD_compress_usingCDict / ZSTD_createDDict / ZSTD_decompress_usingDDict */
         size_t const dn = n < 60000 ? n : 60000, rn = n < 3000 ? n : 3000;
         ZSTD_CDict* cd = ZSTD_createCDict(src, dn, 3);
