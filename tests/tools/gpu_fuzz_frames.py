@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""scripts/gpu_fuzz_frames.py <seed> <trials> — on the GPU box: random inputs x explicit parameters x job sizes x overlaps through
+"""tests/tools/gpu_fuzz_frames.py <seed> <trials> — on the GPU box: random inputs x explicit parameters x job sizes x overlaps through
 zhip_compress_frames / zhip_compress_frames_mt against the oracle (which the CPU tests pin to the reference on the same generator);
 real concurrency, which the host emulator cannot show."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
 import numpy as np

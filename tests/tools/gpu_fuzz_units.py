@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""scripts/gpu_fuzz_units.py <seed> <trials> — on the GPU box: structured-random data cut into units of random sizes, random explicit
+"""tests/tools/gpu_fuzz_units.py <seed> <trials> — on the GPU box: structured-random data cut into units of random sizes, random explicit
 parameters (every strategy up to lazy2, row matcher on / off), through zhip_compress_params against the oracle unit by unit,
 and back through the device decoder."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
 import numpy as np

@@ -1,7 +1,7 @@
 """first-contact probe on the GPU box: environment facts + parse-kernel timing (not the bench contract)."""
 import os, sys, time, json, subprocess
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 import zstd_amd
 from _libs import load_oracle, datagen

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scripts/repcode_scan_prototype.py — design check for the block-parallel decoder, CPU only.
+"""tests/tools/repcode_scan_prototype.py — design check for the block-parallel decoder, CPU only.
 
 A block's sequences can be decoded without knowing the repcode history it starts from if offsets that name a repcode stay SYMBOLIC:
 every history slot is either a constant (an offset introduced inside the block) or "incoming slot i minus d" (d > 0 only through the
@@ -12,7 +12,7 @@ import os
 import sys
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _libs import load_oracle, datagen, text_like, _buf
 
