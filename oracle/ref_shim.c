@@ -156,6 +156,37 @@ size_t zref_compress_records_cdict(int level, const void* dict, size_t dictSize,
     return pos;
 }
 
+/* the same with a FRESH CCtx per record (the row matcher's hash salt depends on what a context compressed before) and, optionally, the
+ * row matcher disabled for CDict and CCtx alike (ZSTD_createCDict_advanced2 with ZSTD_c_useRowMatchFinder = ZSTD_ps_disable) */
+size_t zref_compress_records_cdict_fresh(int level, int noRow, const void* dict, size_t dictSize, const void* src, const size_t* recSizes, size_t nRec,
+                                         void* dst, size_t dstCap, size_t* outSizes)
+{
+    ZSTD_CCtx_params* p = ZSTD_createCCtxParams();
+    ZSTD_CDict* cd;
+    size_t pos = 0, off = 0, k;
+    ZSTD_customMem const mem = { NULL, NULL, NULL };
+    if (!p) return (size_t)-1;
+    ZSTD_CCtxParams_init(p, level);
+    if (noRow) ZSTD_CCtxParams_setParameter(p, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+    cd = ZSTD_createCDict_advanced2(dict, dictSize, ZSTD_dlm_byCopy, ZSTD_dct_auto, p, mem);
+    ZSTD_freeCCtxParams(p);
+    if (!cd) return (size_t)-1;
+    for (k = 0; k < nRec; k++) {
+        ZSTD_CCtx* c = ZSTD_createCCtx();
+        size_t r;
+        if (!c) { ZSTD_freeCDict(cd); return (size_t)-1; }
+        if (noRow) ZSTD_CCtx_setParameter(c, ZSTD_c_useRowMatchFinder, ZSTD_ps_disable);
+        ZSTD_CCtx_refCDict(c, cd);
+        r = ZSTD_compress2(c, (char*)dst + pos, dstCap - pos, (const char*)src + off, recSizes[k]);
+        ZSTD_freeCCtx(c);
+        if (ZSTD_isError(r)) { ZSTD_freeCDict(cd); return (size_t)-1; }
+        if (outSizes) outSizes[k] = r;
+        pos += r; off += recSizes[k];
+    }
+    ZSTD_freeCDict(cd);
+    return pos;
+}
+
 /* decode one frame with a dictionary (validator) */
 size_t zref_decompress_dict(void* dst, size_t cap, const void* src, size_t n, const void* dict, size_t dictSize)
 {

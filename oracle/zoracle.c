@@ -67,6 +67,7 @@ static void zo_adjust_cparams(zo_cparams* cp, unsigned long long srcSize, unsign
 }
 
 /* zstd_compress.c:7098-7145 ZSTD_getCParamRowSize + ZSTD_getCParams_internal */
+static int g_zo_any_strategy = 0;   /* 1: do not refuse rows above lazy2 (a caller that only wants the row's windowLog) */
 static int zo_get_cparams_mode(int level, unsigned long long srcSize, unsigned long long dictSize, int mode, zo_cparams* out)
 {
     unsigned long long const rowDict = (mode == 1) ? 0 : dictSize;
@@ -83,7 +84,7 @@ static int zo_get_cparams_mode(int level, unsigned long long srcSize, unsigned l
         int const clamped = level < -131072 ? -131072 : level;
         cp.targetLength = (unsigned)(-clamped);
     }
-    if (cp.strategy > 5) return -1;                /* btlazy2 and up are outside this oracle */
+    if (cp.strategy > 5 && !g_zo_any_strategy) return -1;   /* btlazy2 and up are outside this oracle */
     zo_adjust_cparams(&cp, srcSize, dictSize, mode);
     *out = cp;
     return 0;
@@ -1787,6 +1788,9 @@ struct zo_cdict_s {
     int level;
     size_t fullSize;                       /* size of the dictionary buffer as given (cdict->dictContentSize) */
     int hasEntropy; zo_prev prev;          /* ZDICT-format dictionaries: the entropy tables the first block starts from */
+    /* greedy / lazy / lazy2 CDicts: the dictionary's own hash chain (head + chain, reference indices = byte + 2, 0 = empty) or rows (+ tags,
+     * unsalted: a CDict's hashSalt is 0, zstd_compress.c:2036-2040), filled by ZSTD_loadDictionaryContent (:4920-4964) */
+    uint32_t* lzHead; uint32_t* lzChain; uint32_t* lzRow; uint8_t* lzTag; int lzUseRow; unsigned lzRowLog;
 };
 
 static void zo_put_tagged(uint32_t* t, uint32_t hashAndTag, uint32_t index)     /* internal.h:1404 ZSTD_writeTaggedIndex */
@@ -1831,10 +1835,42 @@ static void zo_cdict_fill(zo_cdict* cd)
     }
 }
 
+/* the lazy strategies' CDict tables: every position of the (indexed suffix of the) dictionary up to 8 before its end goes into the hash
+ * chain (ZSTD_insertAndFindFirstIndex, zstd_lazy.c:632-662, hashed with the CDict's minMatch as it is) or into the rows (ZSTD_row_update
+ * without the skip rule and without salt, :950-958; minMatch capped at 6).  Row matcher when the CDict's windowLog > 14 (:237-253). */
+static void zo_cdict_fill_lazy(zo_cdict* cd)
+{
+    const uint8_t* const base = cd->content - 2;
+    size_t const endIdx = cd->len + 2;
+    size_t idx, first = 2;
+    cd->lzUseRow = g_zo_row_matcher && cd->cp.windowLog > 14;
+    cd->lzRowLog = cd->cp.searchLog < 4 ? 4 : (cd->cp.searchLog > 6 ? 6 : cd->cp.searchLog);
+    if (cd->lzUseRow) { cd->lzRow = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t)); cd->lzTag = (uint8_t*)calloc((size_t)1 << cd->cp.hashLog, 1); }
+    else { cd->lzHead = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t)); cd->lzChain = (uint32_t*)calloc((size_t)1 << cd->cp.chainLog, sizeof(uint32_t)); }
+    {   unsigned const m = cd->cp.hashLog > cd->cp.chainLog ? cd->cp.hashLog : cd->cp.chainLog;
+        size_t const maxDictSize = (size_t)8 << (m < 28 ? m : 28);
+        if (cd->len > maxDictSize) first = 2 + (cd->len - maxDictSize);
+    }
+    if (endIdx - first <= 8) return;
+    for (idx = first; idx < endIdx - 8; idx++) {
+        if (cd->lzUseRow) {
+            unsigned const rowMask = (1u << cd->lzRowLog) - 1, mls = cd->cp.minMatch > 6 ? 6 : cd->cp.minMatch;
+            uint32_t const h = zo_hash_salted(base + idx, cd->cp.hashLog - cd->lzRowLog + 8, mls, 0);
+            size_t const rel = (size_t)(h >> 8) << cd->lzRowLog;
+            unsigned const pos = zo_row_next_index(cd->lzTag + rel, rowMask);
+            cd->lzTag[rel + pos] = (uint8_t)h; cd->lzRow[rel + pos] = (uint32_t)idx;
+        } else {
+            uint32_t const h = zo_hash(base + idx, cd->cp.hashLog, cd->cp.minMatch);
+            cd->lzChain[idx & ((1u << cd->cp.chainLog) - 1)] = cd->lzHead[h];
+            cd->lzHead[h] = (uint32_t)idx;
+        }
+    }
+}
+
 void zo_cdict_free(zo_cdict* cd)
 {
     if (!cd) return;
-    free(cd->content ? cd->content - 16 : NULL); free(cd->tabL); free(cd->tabS); free(cd);
+    free(cd->content ? cd->content - 16 : NULL); free(cd->tabL); free(cd->tabS); free(cd->lzHead); free(cd->lzChain); free(cd->lzRow); free(cd->lzTag); free(cd);
 }
 
 /* ZSTD_createCDict (zstd_compress.c:5648): parameters for (level, unknown source, dictSize) in createCDict mode,
@@ -1844,7 +1880,7 @@ zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
     zo_cdict* cd = (zo_cdict*)calloc(1, sizeof(zo_cdict));
     uint8_t* buf;
     if (!cd) return NULL;
-    if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 2) { free(cd); return NULL; }
+    if (zo_get_cparams_mode(level, ZO_SRCSIZE_UNKNOWN, dictSize, 2, &cd->cp) < 0 || cd->cp.strategy > 5) { free(cd); return NULL; }
     cd->level = level == 0 ? 3 : level;
     cd->fullSize = dictSize;
     cd->dictID = 0; cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8; cd->hasEntropy = 0;
@@ -1877,6 +1913,7 @@ zo_cdict* zo_cdict_create(const void* dict, size_t dictSize, int level)
     buf = (uint8_t*)calloc(dictSize + 64, 1);
     cd->content = buf + 16; cd->len = dictSize;
     memcpy(cd->content, dict, dictSize);
+    if (cd->cp.strategy >= 3) { zo_cdict_fill_lazy(cd); return cd; }
     cd->tabL = (uint32_t*)calloc((size_t)1 << cd->cp.hashLog, sizeof(uint32_t));
     cd->tabS = (uint32_t*)calloc((size_t)1 << cd->cp.chainLog, sizeof(uint32_t));
     zo_cdict_fill(cd);
@@ -1900,6 +1937,231 @@ static size_t zo_count_ptr(const uint8_t* ip, const uint8_t* match, const uint8_
     size_t k = 0;
     while (ip + k < iEnd && ip[k] == match[k]) k++;
     return k;
+}
+
+/* ---- greedy / lazy / lazy2 with an ATTACHED dictionary (zstd_lazy.c:1516-1779, dictMode = ZSTD_dictMatchState; searches :667-773 and
+ * :1141-1340 with their dictMatchState tails).  Reference indices throughout: dictionary byte j = index j + 2, the working context starts
+ * at P = dictLen + 2 (dictIndexDelta = 0), source byte i = index P + i.  The working context's own tables are fresh per source. */
+typedef struct {
+    uint32_t* head; uint32_t* chain; uint32_t* row; uint8_t* tag;
+    unsigned hlog, clog, slog, mls, rowLog; int useRow; uint64_t salt;
+    uint32_t nextToUpdate; int lazySkipping;
+} zo_lzd;
+
+static void zo_lzd_row_insert(zo_lzd* w, const uint8_t* base, uint32_t from, uint32_t to)
+{
+    unsigned const rowMask = (1u << w->rowLog) - 1;
+    for (; from < to; from++) {
+        uint32_t const h = zo_hash_salted(base + from, w->hlog - w->rowLog + 8, w->mls, w->salt);
+        size_t const rel = (size_t)(h >> 8) << w->rowLog;
+        unsigned const pos = zo_row_next_index(w->tag + rel, rowMask);
+        w->tag[rel + pos] = (uint8_t)h; w->row[rel + pos] = from;
+    }
+}
+
+/* one ZSTD_searchMax call at ip (index curr): the working context's own candidates first, then the dictionary's, sharing the attempts */
+static size_t zo_lazy_dms_best(zo_lzd* w, const zo_cdict* cd, const uint8_t* src, size_t n, size_t ipPos, uint32_t* offBase)
+{
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P; const uint8_t* const dictBase = cd->content - 2;
+    const uint8_t* const ip = src + ipPos, * const iend = src + n, * const dictEnd = cd->content + cd->len;
+    uint32_t const curr = P + (uint32_t)ipPos, lowLimit = P;                      /* loadedDictEnd != 0: lowLimit = window.lowLimit = P */
+    size_t ml = 4 - 1;
+    if (!w->useRow) {
+        uint32_t const cmask = (1u << w->clog) - 1, chainSize = 1u << w->clog;
+        uint32_t const minChain = curr > chainSize ? curr - chainSize : 0;
+        unsigned nbAttempts = 1u << w->slog;
+        uint32_t idx = w->nextToUpdate, m;
+        while (idx < curr) {                                                     /* :645-653 */
+            uint32_t const h = zo_hash(base + idx, w->hlog, w->mls);
+            w->chain[idx & cmask] = w->head[h]; w->head[h] = idx; idx++;
+            if (w->lazySkipping) break;
+        }
+        w->nextToUpdate = curr;
+        m = w->head[zo_hash(ip, w->hlog, w->mls)];
+        for (; m >= lowLimit && nbAttempts > 0; nbAttempts--) {
+            const uint8_t* const match = base + m; size_t cur = 0;
+            if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = zo_count_ptr(ip, match, iend);
+            if (cur > ml) { ml = cur; *offBase = (curr - m) + 3; if (ip + cur == iend) break; }
+            if (m <= minChain) break;
+            m = w->chain[m & cmask];
+        }
+        {   uint32_t const dChainSize = 1u << cd->cp.chainLog, dmask = dChainSize - 1, dmsSize = P;      /* :742-770 */
+            uint32_t const dmsMinChain = dmsSize > dChainSize ? dmsSize - dChainSize : 0;
+            m = cd->lzHead[zo_hash(ip, cd->cp.hashLog, w->mls)];
+            for (; m >= 2 && nbAttempts > 0; nbAttempts--) {
+                const uint8_t* const match = dictBase + m; size_t cur = 0;
+                if (rd32(match) == rd32(ip)) cur = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, src) + 4;
+                if (cur > ml) { ml = cur; *offBase = (curr - m) + 3; if (ip + cur == iend) break; }
+                if (m <= dmsMinChain) break;
+                m = cd->lzChain[m & dmask];
+            }
+        }
+        return ml;
+    }
+    {   unsigned const rowEntries = 1u << w->rowLog, rowMask = rowEntries - 1;
+        unsigned const capped = w->slog < w->rowLog ? w->slog : w->rowLog;
+        unsigned nbAttempts = 1u << capped, numMatches = 0, k;
+        uint32_t buf[64]; uint32_t h;
+        uint32_t const dmsHash = zo_hash_salted(ip, cd->cp.hashLog - cd->lzRowLog + 8, w->mls, 0);   /* :1190-1196: the dictionary's rows, unsalted, the WORKING rowLog */
+        size_t const dRel = (size_t)(dmsHash >> 8) << w->rowLog;
+        if (!w->lazySkipping) {                                                  /* ZSTD_row_update_internal with its skip rule (:916-947) */
+            uint32_t idx = w->nextToUpdate;
+            if (curr - idx > 384) { zo_lzd_row_insert(w, base, idx, idx + 96); idx = curr - 32; }
+            zo_lzd_row_insert(w, base, idx, curr);
+        }
+        w->nextToUpdate = curr;
+        h = zo_hash_salted(ip, w->hlog - w->rowLog + 8, w->mls, w->salt);
+        {   size_t const rel = (size_t)(h >> 8) << w->rowLog;
+            uint8_t* const tagRow = w->tag + rel; uint32_t* const row = w->row + rel;
+            unsigned const head = tagRow[0] & rowMask;
+            for (k = 0; k < rowEntries && nbAttempts > 0; k++) {
+                unsigned const pos = (head + k) & rowMask;
+                if (tagRow[pos] != (uint8_t)h) continue;
+                if (pos == 0) continue;
+                if (row[pos] < lowLimit) break;
+                buf[numMatches++] = row[pos]; nbAttempts--;
+            }
+            {   unsigned const pos = zo_row_next_index(tagRow, rowMask);
+                tagRow[pos] = (uint8_t)h; row[pos] = w->nextToUpdate++; }
+        }
+        for (k = 0; k < numMatches; k++) {
+            const uint8_t* const match = base + buf[k]; size_t cur = 0;
+            if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = zo_count_ptr(ip, match, iend);
+            if (cur > ml) { ml = cur; *offBase = (curr - buf[k]) + 3; if (ip + cur == iend) break; }
+        }
+        {   const uint8_t* const tagRow = cd->lzTag + dRel; const uint32_t* const row = cd->lzRow + dRel;   /* :1296-1334 */
+            unsigned const head = tagRow[0] & rowMask;
+            numMatches = 0;
+            for (k = 0; k < rowEntries && nbAttempts > 0; k++) {
+                unsigned const pos = (head + k) & rowMask;
+                if (tagRow[pos] != (uint8_t)dmsHash) continue;
+                if (pos == 0) continue;
+                if (row[pos] < 2) break;
+                buf[numMatches++] = row[pos]; nbAttempts--;
+            }
+            for (k = 0; k < numMatches; k++) {
+                const uint8_t* const match = dictBase + buf[k]; size_t cur = 0;
+                if (rd32(match) == rd32(ip)) cur = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, src) + 4;
+                if (cur > ml) { ml = cur; *offBase = (curr - buf[k]) + 3; if (ip + cur == iend) break; }
+            }
+        }
+        return ml;
+    }
+}
+
+static size_t zo_lazy_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3], unsigned depth)
+{
+    zo_lzd w;
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P; const uint8_t* const dictBase = cd->content - 2;
+    const uint8_t* const iend = src + n, * const dictEnd = cd->content + cd->len;
+    size_t ilimit, ip = 0, anchor = 0;
+    uint32_t off1 = rep[0], off2 = rep[1];
+    memset(&w, 0, sizeof(w));
+    w.useRow = cd->lzUseRow;                                                     /* the CDict's choice overrides (zstd_compress.c:2322) */
+    w.hlog = cp->hashLog; w.clog = cp->chainLog; w.slog = cp->searchLog;
+    w.mls = cp->minMatch < 4 ? 4 : (cp->minMatch > 6 ? 6 : cp->minMatch);
+    w.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog);
+    w.salt = zo_fresh_hash_salt(); w.nextToUpdate = P;
+    if (n < (w.useRow ? 16u : 8u)) return n;
+    ilimit = n - (w.useRow ? 16 : 8);
+    if (w.useRow) { w.row = (uint32_t*)calloc((size_t)1 << w.hlog, sizeof(uint32_t)); w.tag = (uint8_t*)calloc((size_t)1 << w.hlog, 1); }
+    else { w.head = (uint32_t*)calloc((size_t)1 << w.hlog, sizeof(uint32_t)); w.chain = (uint32_t*)calloc((size_t)1 << w.clog, sizeof(uint32_t)); }
+#define ZO_REPPTR(idx_) ((idx_) < P ? dictBase + (idx_) : base + (idx_))
+#define ZO_REPEND(idx_) ((idx_) < P ? dictEnd : iend)
+#define ZO_REPOK(idx_)  ((uint32_t)((P - 1) - (idx_)) >= 3)                       /* ZSTD_index_overlap_check */
+    while (ip < ilimit) {
+        size_t matchLength = 0, start = ip + 1;
+        uint32_t offBase = 1;
+        int direct = 0;
+        {   uint32_t const repIndex = P + (uint32_t)ip + 1 - off1;               /* :1587-1599 */
+            const uint8_t* const repMatch = ZO_REPPTR(repIndex);
+            if (ZO_REPOK(repIndex) && rd32(repMatch) == rd32(src + ip + 1)) {
+                matchLength = zo_count_2seg(src + ip + 1 + 4, repMatch + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                if (depth == 0) direct = 1;
+            }
+        }
+        if (!direct) {
+            {   uint32_t found = 999999999;
+                size_t const ml2 = zo_lazy_dms_best(&w, cd, src, n, ip, &found);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+            }
+            if (matchLength < 4) {
+                size_t const step = ((ip - anchor) >> 8) + 1;
+                ip += step;
+                w.lazySkipping = step > 8;
+                continue;
+            }
+            if (depth >= 1)
+            while (ip < ilimit) {
+                ip++;
+                {   uint32_t const repIndex = P + (uint32_t)ip - off1;           /* :1640-1654 (no `offBase` guard in this branch) */
+                    const uint8_t* const repMatch = ZO_REPPTR(repIndex);
+                    if (ZO_REPOK(repIndex) && rd32(repMatch) == rd32(src + ip)) {
+                        size_t const mlRep = zo_count_2seg(src + ip + 4, repMatch + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                        int const gain2 = (int)(mlRep * 3);
+                        int const gain1 = (int)(matchLength * 3 - zo_gain_bits(offBase) + 1);
+                        if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                }
+                {   uint32_t cand = 999999999;
+                    size_t const ml2 = zo_lazy_dms_best(&w, cd, src, n, ip, &cand);
+                    int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                    int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 4);
+                    if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                }
+                if (depth == 2 && ip < ilimit) {
+                    ip++;
+                    {   uint32_t const repIndex = P + (uint32_t)ip - off1;
+                        const uint8_t* const repMatch = ZO_REPPTR(repIndex);
+                        if (ZO_REPOK(repIndex) && rd32(repMatch) == rd32(src + ip)) {
+                            size_t const mlRep = zo_count_2seg(src + ip + 4, repMatch + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                            int const gain2 = (int)(mlRep * 4);
+                            int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 1);
+                            if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                        }
+                    }
+                    {   uint32_t cand = 999999999;
+                        size_t const ml2 = zo_lazy_dms_best(&w, cd, src, n, ip, &cand);
+                        int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 7);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3) {                                                   /* :1716-1722 catch up over both segments */
+                uint32_t const matchIndex = P + (uint32_t)start - (offBase - 3);
+                const uint8_t* match = ZO_REPPTR(matchIndex);
+                const uint8_t* const mStart = matchIndex < P ? cd->content : src;
+                while (start > anchor && match > mStart && src[start - 1] == match[-1]) { start--; match--; matchLength++; }
+                off2 = off1; off1 = offBase - 3;
+            }
+        }
+        zo_store_seq(st, src, anchor, start - anchor, offBase, (uint32_t)matchLength);
+        anchor = ip = start + matchLength;
+        w.lazySkipping = 0;
+        while (ip <= ilimit) {                                                   /* :1741-1760 */
+            uint32_t const repIndex = P + (uint32_t)ip - off2;
+            const uint8_t* const repMatch = ZO_REPPTR(repIndex);
+            if (ZO_REPOK(repIndex) && rd32(repMatch) == rd32(src + ip)) {
+                uint32_t const t = off2;
+                matchLength = zo_count_2seg(src + ip + 4, repMatch + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                off2 = off1; off1 = t;
+                zo_store_seq(st, src, anchor, 0, 1, (uint32_t)matchLength);
+                ip += matchLength; anchor = ip;
+                continue;
+            }
+            break;
+        }
+    }
+#undef ZO_REPPTR
+#undef ZO_REPEND
+#undef ZO_REPOK
+    rep[0] = off1; rep[1] = off2;                                                /* no saved offsets in this mode (:1777-1783 with both zero) */
+    free(w.head); free(w.chain); free(w.row); free(w.tag);
+    return n - anchor;
 }
 
 /* zstd_double_fast.c:328-547 ZSTD_compressBlock_doubleFast_dictMatchState_generic */
@@ -2328,7 +2590,8 @@ int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
         *out = w;
         return 1;
     }
-    if (zo_get_cparams_mode(cd->level, n, cd->len, 1, &p) < 0) return -1;        /* :6289-6292 requested params, attach mode */
+    {   int r; g_zo_any_strategy = 1; r = zo_get_cparams_mode(cd->level, n, cd->len, 1, &p); g_zo_any_strategy = 0;   /* only its windowLog is used: any strategy's row will do */
+        if (r < 0) return -1; }                                                  /* :6289-6292 requested params, attach mode */
     w = cd->cp;                                                                  /* :2331-2335 */
     zo_adjust_cparams(&w, n, cd->len, 1);
     w.windowLog = p.windowLog;
@@ -2431,6 +2694,7 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
         st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
         if (n < 8) last = n;
         else if (mode == 1) last = cp.strategy == 1 ? zo_fast_ext(&cp, cd, src, n, &st, rep) : zo_dfast_ext(&cp, cd, src, n, &st, rep);
+        else if (cp.strategy >= 3) last = zo_lazy_dms(&cp, cd, src, n, &st, rep, cp.strategy - 3);
         else if (cp.strategy == 1) last = zo_fast_dms(&cp, cd, src, n, &st, rep);
         else last = zo_dfast_dms(&cp, cd, src, n, &st, rep);
         memcpy(lits + st.litSize, src + n - last, last);

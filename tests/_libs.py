@@ -2,6 +2,7 @@
 oracle/_ref/libzref_shim.so (the real reference, prebuilt from /root/reference by oracle/Makefile)."""
 import ctypes as C
 import os
+import sys
 import subprocess
 import numpy as np
 
@@ -458,5 +459,46 @@ def oracle_frame_params(lo, a, cp, row):
         r = lo.zo_compress_frame_params(_buf(dst), cap, _buf(a), len(a), cp)
         assert r != ERR
         return dst[:r].tobytes()
+    finally:
+        lo.zo_set_row_matcher(0)
+
+
+def lazy_dict_cases(lo):
+    """(name, dictionary bytes, records) for the lazy-strategy CDict oracle (tests/golden/dict_lazy_v1.json)"""
+    sys.path.insert(0, ROOT)
+    from zstd_amd import workloads as W
+    zd = np.fromfile(os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    flat, offs = W.github_like_records(40, seed=9)
+    yield "zdict_json", zd, [flat[int(offs[i]):int(offs[i + 1])].copy() for i in range(len(offs) - 1)]
+    rng = np.random.default_rng(31)
+    corpus = np.concatenate([text_like(150000, 3), datagen(lo, 150000, 50, 4)])
+    recs = []
+    for n in (0, 1, 7, 8, 15, 16, 17, 40, 300, 1200, 5000, 20000, 32768):
+        o = int(rng.integers(20000, len(corpus) - n))
+        r = corpus[o:o + n].copy()
+        if n > 20:
+            r[n // 2: n // 2 + 5] = rng.integers(0, 256, 5)
+        recs.append(r)
+    yield "raw_20k", corpus[:20000].copy(), recs
+
+
+def oracle_records_cdict(lo, d, recs, level, row):
+    """every record as its own frame with a CDict of `level` (attach mode), concatenated"""
+    lo.zo_cdict_create.restype = C.c_void_p; lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_cdict_free.argtypes = [C.c_void_p]
+    lo.zo_compress_unit_cdict.restype = C.c_size_t; lo.zo_compress_unit_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_compress_bound.restype = C.c_size_t; lo.zo_compress_bound.argtypes = [C.c_size_t]
+    lo.zo_set_row_matcher(1 if row else 0)
+    try:
+        cd = lo.zo_cdict_create(_buf(d), len(d), level)
+        assert cd
+        out = []
+        for r in recs:
+            o = np.zeros(lo.zo_compress_bound(len(r)) + 64, dtype=np.uint8)
+            k = lo.zo_compress_unit_cdict(_buf(o), len(o), _buf(r) if len(r) else None, len(r), cd)
+            assert k != ERR
+            out.append(o[:k].tobytes())
+        lo.zo_cdict_free(cd)
+        return out
     finally:
         lo.zo_set_row_matcher(0)

@@ -168,3 +168,21 @@ def test_oracle_reproduces_golden_lazy_multiblock_frames():
             assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, no_row)
             seen += 1
     assert seen == len(gold) == 49
+
+
+def test_oracle_reproduces_golden_lazy_cdict_records():
+    """records with a CDict whose parameter row is greedy / lazy / lazy2 (attach mode: ZSTD_compressBlock_*_dictMatchState, the working
+    context's own hash chain or rows first, then the dictionary's — zstd_lazy.c:742-770, :1296-1334 — two-segment repcodes and catch-up;
+    the dictionary's FSE tables repeated by cost): the oracle side of DESIGN.md §9 item 6"""
+    from _libs import lazy_dict_cases, oracle_records_cdict
+    lo = load_oracle()
+    gold = {(g["case"], g["level"], g["noRow"]): g for g in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dict_lazy_v1.json")))["streams"]}
+    seen = 0
+    for name, d, recs in lazy_dict_cases(lo):
+        for level in (5, 6, 8, 10):
+            for no_row in (0, 1):
+                g = gold[(name, level, no_row)]
+                out = b"".join(oracle_records_cdict(lo, d, recs, level, row=not no_row))
+                assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, no_row)
+                seen += 1
+    assert seen == len(gold) == 16
