@@ -2164,6 +2164,192 @@ static size_t zo_lazy_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_
     return n - anchor;
 }
 
+/* ---- greedy / lazy / lazy2 in the dictionary's COPY mode (sources above 32 KB: ZSTD_resetCCtx_byCopyingCDict, zstd_compress.c:2395-2470 —
+ * the CDict's hash chain / rows, tags and hash salt (0) are copied, the dictionary becomes the extDict segment; then
+ * ZSTD_compressBlock_lazy_extDict_generic, zstd_lazy.c:1937-2137, and the extDict branches of the two searches).  One set of tables:
+ * entries below P = dictLen + 2 point into the dictionary, the others into the source. */
+static size_t zo_lazy_ext_best(zo_lzd* w, const zo_cdict* cd, const uint8_t* src, size_t n, size_t ipPos, uint32_t* offBase)
+{
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P; const uint8_t* const dictBase = cd->content - 2;
+    const uint8_t* const ip = src + ipPos, * const iend = src + n, * const dictEnd = cd->content + cd->len;
+    uint32_t const curr = P + (uint32_t)ipPos, lowLimit = 2;                      /* loadedDictEnd != 0: the whole dictionary stays valid */
+    size_t ml = 4 - 1;
+    if (!w->useRow) {
+        uint32_t const cmask = (1u << w->clog) - 1, chainSize = 1u << w->clog;
+        uint32_t const minChain = curr > chainSize ? curr - chainSize : 0;
+        unsigned nbAttempts = 1u << w->slog;
+        uint32_t idx = w->nextToUpdate, m;
+        while (idx < curr) {
+            uint32_t const h = zo_hash(base + idx, w->hlog, w->mls);
+            w->chain[idx & cmask] = w->head[h]; w->head[h] = idx; idx++;
+            if (w->lazySkipping) break;
+        }
+        w->nextToUpdate = curr;
+        m = w->head[zo_hash(ip, w->hlog, w->mls)];
+        for (; m >= lowLimit && nbAttempts > 0; nbAttempts--) {
+            size_t cur = 0;
+            if (m >= P) { const uint8_t* const match = base + m; if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = zo_count_ptr(ip, match, iend); }
+            else { const uint8_t* const match = dictBase + m; if (rd32(match) == rd32(ip)) cur = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, src) + 4; }
+            if (cur > ml) { ml = cur; *offBase = (curr - m) + 3; if (ip + cur == iend) break; }
+            if (m <= minChain) break;
+            m = w->chain[m & cmask];
+        }
+        return ml;
+    }
+    {   unsigned const rowEntries = 1u << w->rowLog, rowMask = rowEntries - 1;
+        unsigned const capped = w->slog < w->rowLog ? w->slog : w->rowLog;
+        unsigned nbAttempts = 1u << capped, numMatches = 0, k;
+        uint32_t buf[64]; uint32_t h;
+        if (!w->lazySkipping) {
+            uint32_t idx = w->nextToUpdate;
+            if (curr - idx > 384) { zo_lzd_row_insert(w, base, idx, idx + 96); idx = curr - 32; }
+            zo_lzd_row_insert(w, base, idx, curr);
+        }
+        w->nextToUpdate = curr;
+        h = zo_hash_salted(ip, w->hlog - w->rowLog + 8, w->mls, w->salt);
+        {   size_t const rel = (size_t)(h >> 8) << w->rowLog;
+            uint8_t* const tagRow = w->tag + rel; uint32_t* const row = w->row + rel;
+            unsigned const head = tagRow[0] & rowMask;
+            for (k = 0; k < rowEntries && nbAttempts > 0; k++) {
+                unsigned const pos = (head + k) & rowMask;
+                if (tagRow[pos] != (uint8_t)h) continue;
+                if (pos == 0) continue;
+                if (row[pos] < lowLimit) break;
+                buf[numMatches++] = row[pos]; nbAttempts--;
+            }
+            {   unsigned const pos = zo_row_next_index(tagRow, rowMask);
+                tagRow[pos] = (uint8_t)h; row[pos] = w->nextToUpdate++; }
+        }
+        for (k = 0; k < numMatches; k++) {
+            uint32_t const m = buf[k]; size_t cur = 0;
+            if (m >= P) { const uint8_t* const match = base + m; if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = zo_count_ptr(ip, match, iend); }
+            else { const uint8_t* const match = dictBase + m; if (rd32(match) == rd32(ip)) cur = zo_count_2seg(ip + 4, match + 4, iend, dictEnd, src) + 4; }
+            if (cur > ml) { ml = cur; *offBase = (curr - m) + 3; if (ip + cur == iend) break; }
+        }
+        return ml;
+    }
+}
+
+static size_t zo_lazy_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3], unsigned depth)
+{
+    zo_lzd w;
+    uint32_t const P = (uint32_t)cd->len + 2;
+    const uint8_t* const base = src - P; const uint8_t* const dictBase = cd->content - 2;
+    const uint8_t* const iend = src + n, * const dictEnd = cd->content + cd->len;
+    size_t ilimit, ip = 0, anchor = 0;
+    uint32_t off1 = rep[0], off2 = rep[1];
+    memset(&w, 0, sizeof(w));
+    w.useRow = cd->lzUseRow;
+    w.hlog = cp->hashLog; w.clog = cp->chainLog; w.slog = cp->searchLog;
+    w.mls = cp->minMatch < 4 ? 4 : (cp->minMatch > 6 ? 6 : cp->minMatch);
+    w.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog);
+    w.salt = 0; w.nextToUpdate = P;                                             /* the CDict's salt and nextToUpdate come along (:2445, :2463) */
+    if (n < (w.useRow ? 16u : 8u)) return n;
+    ilimit = n - (w.useRow ? 16 : 8);
+    if (w.useRow) {
+        w.row = (uint32_t*)malloc(sizeof(uint32_t) << w.hlog); w.tag = (uint8_t*)malloc((size_t)1 << w.hlog);
+        memcpy(w.row, cd->lzRow, sizeof(uint32_t) << w.hlog); memcpy(w.tag, cd->lzTag, (size_t)1 << w.hlog);
+    } else {
+        w.head = (uint32_t*)malloc(sizeof(uint32_t) << w.hlog); w.chain = (uint32_t*)malloc(sizeof(uint32_t) << w.clog);
+        memcpy(w.head, cd->lzHead, sizeof(uint32_t) << w.hlog); memcpy(w.chain, cd->lzChain, sizeof(uint32_t) << w.clog);
+    }
+#define ZO_REPPTR(idx_) ((idx_) < P ? dictBase + (idx_) : base + (idx_))
+#define ZO_REPEND(idx_) ((idx_) < P ? dictEnd : iend)
+#define ZO_REPOK(idx_, off_, cur_) (((uint32_t)((P - 1) - (idx_)) >= 3) & ((off_) <= (cur_) - 2))   /* overlap check & offset <= curr - windowLow, windowLow = 2 */
+    ip += 1;                                                                     /* :1967 ip == prefixStart */
+    while (ip < ilimit) {
+        size_t matchLength = 0, start = ip + 1;
+        uint32_t offBase = 1;
+        uint32_t curr = P + (uint32_t)ip;
+        int direct = 0;
+        {   uint32_t const repIndex = curr + 1 - off1;
+            if (ZO_REPOK(repIndex, off1, curr + 1) && rd32(src + ip + 1) == rd32(ZO_REPPTR(repIndex))) {
+                matchLength = zo_count_2seg(src + ip + 1 + 4, ZO_REPPTR(repIndex) + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                if (depth == 0) direct = 1;
+            }
+        }
+        if (!direct) {
+            {   uint32_t found = 999999999;
+                size_t const ml2 = zo_lazy_ext_best(&w, cd, src, n, ip, &found);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+            }
+            if (matchLength < 4) {
+                size_t const step = (ip - anchor) >> 8;                          /* :2003-2013: the threshold is on the step WITHOUT its + 1 here */
+                ip += step + 1;
+                w.lazySkipping = step > 8;
+                continue;
+            }
+            if (depth >= 1)
+            while (ip < ilimit) {
+                ip++; curr++;
+                if (offBase) {
+                    uint32_t const repIndex = curr - off1;
+                    if (ZO_REPOK(repIndex, off1, curr) && rd32(src + ip) == rd32(ZO_REPPTR(repIndex))) {
+                        size_t const mlRep = zo_count_2seg(src + ip + 4, ZO_REPPTR(repIndex) + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                        int const gain2 = (int)(mlRep * 3);
+                        int const gain1 = (int)(matchLength * 3 - zo_gain_bits(offBase) + 1);
+                        if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                }
+                {   uint32_t cand = 999999999;
+                    size_t const ml2 = zo_lazy_ext_best(&w, cd, src, n, ip, &cand);
+                    int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                    int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 4);
+                    if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                }
+                if (depth == 2 && ip < ilimit) {
+                    ip++; curr++;
+                    if (offBase) {
+                        uint32_t const repIndex = curr - off1;
+                        if (ZO_REPOK(repIndex, off1, curr) && rd32(src + ip) == rd32(ZO_REPPTR(repIndex))) {
+                            size_t const mlRep = zo_count_2seg(src + ip + 4, ZO_REPPTR(repIndex) + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                            int const gain2 = (int)(mlRep * 4);
+                            int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 1);
+                            if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                        }
+                    }
+                    {   uint32_t cand = 999999999;
+                        size_t const ml2 = zo_lazy_ext_best(&w, cd, src, n, ip, &cand);
+                        int const gain2 = (int)(ml2 * 4 - zo_gain_bits(cand));
+                        int const gain1 = (int)(matchLength * 4 - zo_gain_bits(offBase) + 7);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offBase = cand; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3) {
+                uint32_t const matchIndex = P + (uint32_t)start - (offBase - 3);
+                const uint8_t* match = ZO_REPPTR(matchIndex);
+                const uint8_t* const mStart = matchIndex < P ? cd->content : src;      /* dictStart = dictBase + lowLimit */
+                while (start > anchor && match > mStart && src[start - 1] == match[-1]) { start--; match--; matchLength++; }
+                off2 = off1; off1 = offBase - 3;
+            }
+        }
+        zo_store_seq(st, src, anchor, start - anchor, offBase, (uint32_t)matchLength);
+        anchor = ip = start + matchLength;
+        w.lazySkipping = 0;
+        while (ip <= ilimit) {
+            uint32_t const repCurrent = P + (uint32_t)ip, repIndex = repCurrent - off2;
+            if (ZO_REPOK(repIndex, off2, repCurrent) && rd32(src + ip) == rd32(ZO_REPPTR(repIndex))) {
+                uint32_t const t = off2;
+                matchLength = zo_count_2seg(src + ip + 4, ZO_REPPTR(repIndex) + 4, iend, ZO_REPEND(repIndex), src) + 4;
+                off2 = off1; off1 = t;
+                zo_store_seq(st, src, anchor, 0, 1, (uint32_t)matchLength);
+                ip += matchLength; anchor = ip;
+                continue;
+            }
+            break;
+        }
+    }
+#undef ZO_REPPTR
+#undef ZO_REPEND
+#undef ZO_REPOK
+    rep[0] = off1; rep[1] = off2;
+    free(w.head); free(w.chain); free(w.row); free(w.tag);
+    return n - anchor;
+}
+
 /* zstd_double_fast.c:328-547 ZSTD_compressBlock_doubleFast_dictMatchState_generic */
 static size_t zo_dfast_dms(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
 {
@@ -2584,7 +2770,7 @@ int zo_cdict_params(const zo_cdict* cd, size_t n, zo_cparams* out)
         /* COPY mode (zstd_compress.c:2395-2419): the CDict's table parameters as they are, windowLog from the parameters
          * requested for (level, srcSize, dictSize) with the dictionary counted in (ZSTD_cpm_noAttachDict, :6289-6292).
          * Strategies fast and dfast are restated (ZSTD_compressBlock_{fast,doubleFast}_extDict). */
-        if (cd->cp.strategy > 2 || n > ZO_BLOCK_MAX) return -1;
+        if (cd->cp.strategy > 5 || n > ZO_BLOCK_MAX) return -1;
         if (zo_get_cparams_mode(cd->level, n, cd->fullSize, 0, &p) < 0) return -1;
         w = cd->cp; w.windowLog = p.windowLog;
         *out = w;
@@ -2693,7 +2879,8 @@ size_t zo_compress_unit_cdict(void* dstv, size_t cap, const void* srcv, size_t n
         rep[0] = cd->rep[0]; rep[1] = cd->rep[1]; rep[2] = cd->rep[2];
         st.seqs = seqs; st.nb = 0; st.cap = n / 3 + 2; st.lits = lits; st.litSize = 0; st.overflow = 0;
         if (n < 8) last = n;
-        else if (mode == 1) last = cp.strategy == 1 ? zo_fast_ext(&cp, cd, src, n, &st, rep) : zo_dfast_ext(&cp, cd, src, n, &st, rep);
+        else if (mode == 1) last = cp.strategy >= 3 ? zo_lazy_ext(&cp, cd, src, n, &st, rep, cp.strategy - 3)
+                                : cp.strategy == 1 ? zo_fast_ext(&cp, cd, src, n, &st, rep) : zo_dfast_ext(&cp, cd, src, n, &st, rep);
         else if (cp.strategy >= 3) last = zo_lazy_dms(&cp, cd, src, n, &st, rep, cp.strategy - 3);
         else if (cp.strategy == 1) last = zo_fast_dms(&cp, cd, src, n, &st, rep);
         else last = zo_dfast_dms(&cp, cd, src, n, &st, rep);

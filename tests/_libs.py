@@ -473,7 +473,7 @@ def lazy_dict_cases(lo):
     rng = np.random.default_rng(31)
     corpus = np.concatenate([text_like(150000, 3), datagen(lo, 150000, 50, 4)])
     recs = []
-    for n in (0, 1, 7, 8, 15, 16, 17, 40, 300, 1200, 5000, 20000, 32768):
+    for n in (0, 1, 7, 8, 15, 16, 17, 40, 300, 1200, 5000, 20000, 32768, 32769, 50000, 131072):     # above 32 KB: the copy mode
         o = int(rng.integers(20000, len(corpus) - n))
         r = corpus[o:o + n].copy()
         if n > 20:
