@@ -353,3 +353,33 @@ def test_job_pool_frame_lazy_strategies_vs_reference(libs):
                 assert k != ERR and oracle_frame_mt(lo, a, level, js, ov, ck) == want[:k].tobytes(), (t, n, level, no_row, js, ov, ck)
     finally:
         lo.zo_set_row_matcher(0)
+
+
+def test_lazy_cdict_records_vs_reference(libs):
+    """CDicts at the greedy / lazy / lazy2 levels: attach mode up to 32 KB, copy mode above, row matcher and hash chain, random raw
+    dictionaries and records — the oracle against ZSTD_createCDict_advanced2 + refCDict + compress2 on a fresh CCtx per record"""
+    lo, lr = libs
+    from _libs import oracle_records_cdict
+    lr.zref_compress_records_cdict_fresh.restype = C.c_size_t
+    lr.zref_compress_records_cdict_fresh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for t in range(3):
+        dsz = int(rng.choice([3000, 20000, 60000, 112640]))
+        corpus = text_like(400000, t) if t % 2 == 0 else np.concatenate([text_like(200000, t + 50), datagen(lo, 200000, 50, t)])
+        d = corpus[:dsz].copy()
+        recs = []
+        for k in range(8):
+            n = int(rng.choice([1, 8, 16, 40, 300, 1200, 5000, 20000, 32768, 32769, 70000]))
+            o = int(rng.integers(dsz, len(corpus) - n))
+            r = corpus[o:o + n].copy()
+            if k % 3 == 0 and n > 20:
+                r[n // 2: n // 2 + 5] = rng.integers(0, 256, 5)
+            recs.append(r)
+        src = np.concatenate(recs)
+        sizes = (C.c_size_t * len(recs))(*[len(r) for r in recs])
+        for level in (5, 7, 9):
+            no_row = int(rng.integers(0, 2))
+            cap = sum(len(r) + (len(r) >> 7) + 256 for r in recs)
+            dst = np.zeros(cap, dtype=np.uint8)
+            k = lr.zref_compress_records_cdict_fresh(level, no_row, _buf(d), len(d), _buf(src), sizes, len(recs), _buf(dst), cap, None)
+            assert k != ERR and b"".join(oracle_records_cdict(lo, d, recs, level, row=not no_row)) == dst[:k].tobytes(), (t, dsz, level, no_row)
