@@ -2571,22 +2571,24 @@ _cleanup:
 
 /* zstd_fast.c:709-960 ZSTD_compressBlock_fast_extDict_generic — strategy fast in COPY mode (same window layout as
  * zo_dfast_ext below: dictionary = indices 2 .. P-1, source = indices P ..). */
-static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+/* src = the start of the source (the prefix segment), the block is src[bStart, bStart + n); Tkeep = the context's table when the blocks
+ * of a frame share it (already a copy of the CDict's), NULL = one block with a fresh copy */
+static size_t zo_fast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* Tkeep, zo_store* st, uint32_t rep[3])
 {
     unsigned const hlog = cp->hashLog, mls = cp->minMatch;
     size_t const stepSize = cp->targetLength + !cp->targetLength + 1;
     size_t const sz = (size_t)1 << hlog;
-    uint32_t* const T = (uint32_t*)malloc(sz * sizeof(uint32_t));
+    uint32_t* const T = Tkeep ? Tkeep : (uint32_t*)malloc(sz * sizeof(uint32_t));
     uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
     const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
     const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
-    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* const istart = src + bStart, * const iend = istart + n, * const ilimit = iend - 8, * const prefixStart = src;
     const uint8_t* anchor = istart, * ip0 = istart, * ip1, * ip2, * ip3, * nextStep, * match0 = NULL, * matchEnd = NULL;
     uint32_t offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0, current0 = 0, idx, offcode = 0;
     uint32_t hash0, hash1;
     size_t step, mLength = 0, i;
 #define PTR(k) ((k) < P ? dictBase + (k) : base + (k))
-    for (i = 0; i < sz; i++) T[i] = cd->tabL[i] >> 8;                             /* :2379-2393 tags removed */
+    if (!Tkeep) for (i = 0; i < sz; i++) T[i] = cd->tabL[i] >> 8;                 /* :2379-2393 tags removed */
     {   uint32_t const maxRep = (uint32_t)(ip0 - base) - dictStartIndex;          /* :764-768 */
         if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
         if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
@@ -2633,7 +2635,7 @@ static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_
             while (((ip0 > anchor) & (match0 > low)) && ip0[-1] == match0[-1]) { ip0--; match0--; mLength++; }
         }
         mLength += zo_count_2seg(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);              /* _match :917-957 */
-        zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(ip0 - anchor), offcode, (uint32_t)mLength);
+        zo_store_seq(st, src, (size_t)(anchor - src), (size_t)(ip0 - anchor), offcode, (uint32_t)mLength);
         ip0 += mLength; anchor = ip0;
         if (ip1 < ip0) T[hash1] = (uint32_t)(ip1 - base);
         if (ip0 <= ilimit) {
@@ -2646,7 +2648,7 @@ static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_
                     const uint8_t* const repEnd2 = repIndex2 < P ? dictEnd : iend;
                     size_t const rl = zo_count_2seg(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
                     uint32_t const t = offset_2; offset_2 = offset_1; offset_1 = t;
-                    zo_store_seq(st, src, (size_t)(anchor - istart), 0, 1, (uint32_t)rl);
+                    zo_store_seq(st, src, (size_t)(anchor - src), 0, 1, (uint32_t)rl);
                     T[zo_hash(ip0, hlog, mls)] = (uint32_t)(ip0 - base);
                     ip0 += rl; anchor = ip0;
                     continue;
@@ -2659,30 +2661,36 @@ static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_
     offsetSaved2 = (offsetSaved1 != 0 && offset_1 != 0) ? offsetSaved1 : offsetSaved2;
     rep[0] = offset_1 ? offset_1 : offsetSaved1;
     rep[1] = offset_2 ? offset_2 : offsetSaved2;
-    free(T);
+    if (!Tkeep) free(T);
     return (size_t)(iend - anchor);
+}
+static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    return zo_fast_ext_block(cp, cd, src, 0, n, NULL, st, rep);
 }
 
 /* zstd_double_fast.c:551-759 ZSTD_compressBlock_doubleFast_extDict_generic — the COPY mode of a CDict (zstd_compress.c:2395-2470):
  * the working tables start as copies of the CDict's (tags removed, :2379-2393), the dictionary content is the window's
  * extDict segment (indices 2 .. P-1), the source the prefix (indices P ..); one table pair serves both segments. */
-#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - istart), (size_t)(litLen), (offBase), (uint32_t)(ml))
+#define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - src), (size_t)(litLen), (offBase), (uint32_t)(ml))
 #define PTR(idx) ((idx) < P ? dictBase + (idx) : base + (idx))
-static size_t zo_dfast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+static size_t zo_dfast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* TLkeep, uint32_t* TSkeep, zo_store* st, uint32_t rep[3])
 {
     unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
     size_t const szL = (size_t)1 << hBitsL, szS = (size_t)1 << hBitsS;
-    uint32_t* const hashLong = (uint32_t*)malloc(szL * sizeof(uint32_t));
-    uint32_t* const hashSmall = (uint32_t*)malloc(szS * sizeof(uint32_t));
+    uint32_t* const hashLong = TLkeep ? TLkeep : (uint32_t*)malloc(szL * sizeof(uint32_t));
+    uint32_t* const hashSmall = TLkeep ? TSkeep : (uint32_t*)malloc(szS * sizeof(uint32_t));
     uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
     const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
     const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
-    const uint8_t* const istart = src, * const iend = src + n, * const ilimit = iend - 8, * const prefixStart = src;
+    const uint8_t* const istart = src + bStart, * const iend = istart + n, * const ilimit = iend - 8, * const prefixStart = src;
     const uint8_t* ip = istart, * anchor = istart;
     uint32_t offset_1 = rep[0], offset_2 = rep[1];
     size_t i;
-    for (i = 0; i < szL; i++) hashLong[i] = cd->tabL[i] >> 8;
-    for (i = 0; i < szS; i++) hashSmall[i] = cd->tabS[i] >> 8;
+    if (!TLkeep) {
+        for (i = 0; i < szL; i++) hashLong[i] = cd->tabL[i] >> 8;
+        for (i = 0; i < szS; i++) hashSmall[i] = cd->tabS[i] >> 8;
+    }
     while (ip < ilimit) {
         uint32_t const hSmall = zo_hash(ip, hBitsS, mls), hLong = zo_hash(ip, hBitsL, 8);
         uint32_t const matchIndex = hashSmall[hSmall], matchLongIndex = hashLong[hLong];
@@ -2754,8 +2762,12 @@ static size_t zo_dfast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8
         }
     }
     rep[0] = offset_1; rep[1] = offset_2;
-    free(hashLong); free(hashSmall);
+    if (!TLkeep) { free(hashLong); free(hashSmall); }
     return (size_t)(iend - anchor);
+}
+static size_t zo_dfast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
+{
+    return zo_dfast_ext_block(cp, cd, src, 0, n, NULL, NULL, st, rep);
 }
 #undef PTR
 #undef SEQ
@@ -3146,6 +3158,7 @@ typedef struct {
     long long savings;        /* consumedSrcSize - producedCSize of the context (zstd_compress.c:4538): what frame chunks inherit from one another */
     zo_seq* seqs; uint8_t* lits; uint8_t* body;
     zo_lz lz;                 /* greedy / lazy / lazy2: hash chain or rows, nextToUpdate, window low */
+    const zo_cdict* cd;       /* a dictionary in copy mode: T starts as a copy of its tables, its content is the extDict segment of every block */
 } zo_fctx;
 
 /* zstd_preSplit.c:139-181 ZSTD_splitBlock(split_lvl1) = ZSTD_splitBlock_byChunks with one 2-byte event out of five: what ZSTD_lazy2
@@ -3198,7 +3211,9 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
             zo_store st; uint32_t nrep[3] = { f->rep[0], f->rep[1], f->rep[2] };
             size_t lastLits; zo_prev next;
             st.seqs = f->seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = f->lits; st.litSize = 0; st.overflow = 0;
-            lastLits = cp->strategy >= 3 ? zo_lazy_block(cp, src, pos, bLen, &f->lz, &st, nrep, cp->strategy - 3)
+            lastLits = f->cd ? (cp->strategy == 2 ? zo_dfast_ext_block(cp, f->cd, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
+                                                  : zo_fast_ext_block(cp, f->cd, src, pos, bLen, f->T, &st, nrep))
+                     : cp->strategy >= 3 ? zo_lazy_block(cp, src, pos, bLen, &f->lz, &st, nrep, cp->strategy - 3)
                      : cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
                                          : zo_fast_block(cp, src, pos, bLen, f->T, &st, nrep);
             memcpy(f->lits + st.litSize, src + pos + bLen - lastLits, lastLits); st.litSize += lastLits;
@@ -3261,6 +3276,34 @@ size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t
     f.rep[0] = 1; f.rep[1] = 4; f.rep[2] = 8;
     g_zo_win_start = 0;
     r = zo_frame_chunk(&f, cp, src, 0, n, 1, op);                                /* ZSTD_compressEnd: the whole input is one chunk */
+    zo_fctx_free(&f);
+    return r == ZO_ERROR ? ZO_ERROR : (size_t)(op - dst) + r;
+}
+
+/* ZSTD_compress2 with a CDict on a source above 128 KB, strategies ZSTD_fast and ZSTD_dfast: the COPY mode (the source is far above the
+ * attach cut-offs) carried through ZSTD_compress_frameChunk — the context's tables start as copies of the CDict's and live across blocks,
+ * every block runs the extDict parser with the dictionary as the other segment, the first block starts from the dictionary's repcodes
+ * and entropy tables.  Restated for sources no longer than the window (the parameters are chosen for source + dictionary, so that is every
+ * default case): then the dictionary stays valid for the whole frame (ZSTD_checkDictValidity, zstd_compress_internal.h:1140-1160). */
+size_t zo_compress_frame_cdict(void* dstv, size_t cap, const void* srcv, size_t n, const zo_cdict* cd)
+{
+    uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
+    uint8_t* op = dst;
+    zo_cparams cp, p; zo_fctx f; size_t r, i;
+    if (n <= ZO_BLOCK_MAX) return zo_compress_unit_cdict(dstv, cap, srcv, n, cd);
+    if (cd->cp.strategy > 2 || cap < zo_frame_bound(n)) return ZO_ERROR;
+    {   int rc; g_zo_any_strategy = 1; rc = zo_get_cparams_mode(cd->level, n, cd->fullSize, 0, &p); g_zo_any_strategy = 0; if (rc < 0) return ZO_ERROR; }
+    cp = cd->cp; cp.windowLog = p.windowLog;
+    if (cd->len == 0) return zo_compress_frame_params(dstv, cap, srcv, n, &cp);
+    if (n > ((size_t)1 << cp.windowLog)) return ZO_ERROR;
+    op += write_frame_header_dict(op, &cp, n, cd->dictID);
+    if (!zo_fctx_init(&f, &cp)) { zo_fctx_free(&f); return ZO_ERROR; }
+    for (i = 0; i < ((size_t)1 << cp.hashLog); i++) f.T[i] = cd->tabL[i] >> 8;                    /* zstd_compress.c:2379-2393 tags removed */
+    if (cp.strategy == 2) for (i = 0; i < ((size_t)1 << cp.chainLog); i++) f.T[((size_t)1 << cp.hashLog) + i] = cd->tabS[i] >> 8;
+    f.cd = cd;
+    f.rep[0] = cd->rep[0]; f.rep[1] = cd->rep[1]; f.rep[2] = cd->rep[2];
+    if (cd->hasEntropy) f.prev = cd->prev;
+    r = zo_frame_chunk(&f, &cp, src, 0, n, 1, op);
     zo_fctx_free(&f);
     return r == ZO_ERROR ? ZO_ERROR : (size_t)(op - dst) + r;
 }

@@ -98,6 +98,7 @@ size_t zo_frame_bound(size_t n);
 size_t zo_compress_frame(void* dst, size_t cap, const void* src, size_t n, int level);
 size_t zo_compress_frame_params(void* dst, size_t cap, const void* src, size_t n, const zo_cparams* cp);
 /* the frame ZSTD_compress2 emits with ZSTD_c_nbWorkers >= 1 (jobs sharing only an overlap prefix, zstdmt_compress.c); jobSize / overlapLog 0 = defaults */
+size_t zo_compress_frame_cdict(void* dst, size_t cap, const void* src, size_t n, const zo_cdict* cd);   /* refCDict + compress2 above 128 KB (copy mode, fast / dfast) */
 size_t zo_compress_frame_mt_params(void* dst, size_t cap, const void* src, size_t n, const zo_cparams* cp,
                                    unsigned long long jobSize, int overlapLog, int checksumFlag);
 size_t zo_mt_job_size(const zo_cparams* cp, unsigned long long jobSize);

@@ -4,6 +4,8 @@ import ctypes as C
 import numpy as np
 import pytest
 from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, oracle_frame_mt, ref_frame_mt, _buf, ERR
+from _libs import ROOT
+import os
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -383,3 +385,40 @@ def test_lazy_cdict_records_vs_reference(libs):
             dst = np.zeros(cap, dtype=np.uint8)
             k = lr.zref_compress_records_cdict_fresh(level, no_row, _buf(d), len(d), _buf(src), sizes, len(recs), _buf(dst), cap, None)
             assert k != ERR and b"".join(oracle_records_cdict(lo, d, recs, level, row=not no_row)) == dst[:k].tobytes(), (t, dsz, level, no_row)
+
+
+def test_cdict_on_sources_above_128k_vs_reference(libs):
+    """refCDict + ZSTD_compress2 on a source above 128 KB (strategies fast / dfast): copy mode carried through the frame's blocks — the
+    context's tables start as copies of the CDict's, every block runs the extDict parser, the first block starts from the dictionary's
+    repcodes and entropy tables.  Sources up to the window size (zo_compress_frame_cdict refuses the rest: the sliding window over an
+    extDict segment is not restated)"""
+    lo, lr = libs
+    lo.zo_cdict_create.restype = C.c_void_p; lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    lo.zo_cdict_free.argtypes = [C.c_void_p]
+    lo.zo_compress_frame_cdict.restype = C.c_size_t; lo.zo_compress_frame_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
+    lr.zref_compress_records_cdict_fresh.restype = C.c_size_t
+    lr.zref_compress_records_cdict_fresh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    zd = np.fromfile(os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    seen = 0
+    for t in range(6):
+        corpus = text_like(900000, t) if t % 2 == 0 else np.concatenate([text_like(400000, t + 50), datagen(lo, 500000, 50, t)])
+        d = zd if t % 3 == 2 else corpus[:int(rng.choice([3000, 20000, 112640]))].copy()
+        n = int(rng.integers(131073, 500000))
+        o = int(rng.integers(0, len(corpus) - n))
+        a = corpus[o:o + n].copy()
+        for level in (1, 3, -3):
+            cd = lo.zo_cdict_create(_buf(d), len(d), level)
+            assert cd
+            cap = lo.zo_frame_bound(n)
+            out = np.zeros(cap, dtype=np.uint8)
+            r = lo.zo_compress_frame_cdict(_buf(out), cap, _buf(a), n, cd)
+            lo.zo_cdict_free(cd)
+            if r == ERR:
+                continue                                   # greedy CDict rows of tiny dictionaries
+            want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
+            k = lr.zref_compress_records_cdict_fresh(level, 0, _buf(d), len(d), _buf(a), (C.c_size_t * 1)(n), 1, _buf(want), len(want), None)
+            assert k != ERR and out[:r].tobytes() == want[:k].tobytes(), (t, n, level, len(d))
+            seen += 1
+    assert seen >= 12
