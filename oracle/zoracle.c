@@ -2573,15 +2573,15 @@ _cleanup:
  * zo_dfast_ext below: dictionary = indices 2 .. P-1, source = indices P ..). */
 /* src = the start of the source (the prefix segment), the block is src[bStart, bStart + n); Tkeep = the context's table when the blocks
  * of a frame share it (already a copy of the CDict's), NULL = one block with a fresh copy */
-static size_t zo_fast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* Tkeep, zo_store* st, uint32_t rep[3])
+static size_t zo_fast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* Tkeep, uint32_t dictStartIndex /* window low, >= 2 */, zo_store* st, uint32_t rep[3])
 {
     unsigned const hlog = cp->hashLog, mls = cp->minMatch;
     size_t const stepSize = cp->targetLength + !cp->targetLength + 1;
     size_t const sz = (size_t)1 << hlog;
     uint32_t* const T = Tkeep ? Tkeep : (uint32_t*)malloc(sz * sizeof(uint32_t));
-    uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
+    uint32_t const P = (uint32_t)cd->len + 2;
     const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
-    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const dictStart = dictBase + dictStartIndex, * const dictEnd = cd->content + cd->len;
     const uint8_t* const istart = src + bStart, * const iend = istart + n, * const ilimit = iend - 8, * const prefixStart = src;
     const uint8_t* anchor = istart, * ip0 = istart, * ip1, * ip2, * ip3, * nextStep, * match0 = NULL, * matchEnd = NULL;
     uint32_t offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0, current0 = 0, idx, offcode = 0;
@@ -2666,7 +2666,7 @@ static size_t zo_fast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const 
 }
 static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
 {
-    return zo_fast_ext_block(cp, cd, src, 0, n, NULL, st, rep);
+    return zo_fast_ext_block(cp, cd, src, 0, n, NULL, 2, st, rep);
 }
 
 /* zstd_double_fast.c:551-759 ZSTD_compressBlock_doubleFast_extDict_generic — the COPY mode of a CDict (zstd_compress.c:2395-2470):
@@ -2674,15 +2674,15 @@ static size_t zo_fast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_
  * extDict segment (indices 2 .. P-1), the source the prefix (indices P ..); one table pair serves both segments. */
 #define SEQ(litLen, offBase, ml) zo_store_seq(st, src, (size_t)(anchor - src), (size_t)(litLen), (offBase), (uint32_t)(ml))
 #define PTR(idx) ((idx) < P ? dictBase + (idx) : base + (idx))
-static size_t zo_dfast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* TLkeep, uint32_t* TSkeep, zo_store* st, uint32_t rep[3])
+static size_t zo_dfast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t bStart, size_t n, uint32_t* TLkeep, uint32_t* TSkeep, uint32_t dictStartIndex, zo_store* st, uint32_t rep[3])
 {
     unsigned const hBitsL = cp->hashLog, hBitsS = cp->chainLog, mls = cp->minMatch;
     size_t const szL = (size_t)1 << hBitsL, szS = (size_t)1 << hBitsS;
     uint32_t* const hashLong = TLkeep ? TLkeep : (uint32_t*)malloc(szL * sizeof(uint32_t));
     uint32_t* const hashSmall = TLkeep ? TSkeep : (uint32_t*)malloc(szS * sizeof(uint32_t));
-    uint32_t const P = (uint32_t)cd->len + 2, dictStartIndex = 2;
+    uint32_t const P = (uint32_t)cd->len + 2;
     const uint8_t* const base = src - P, * const dictBase = cd->content - 2;
-    const uint8_t* const dictStart = cd->content, * const dictEnd = cd->content + cd->len;
+    const uint8_t* const dictStart = dictBase + dictStartIndex, * const dictEnd = cd->content + cd->len;
     const uint8_t* const istart = src + bStart, * const iend = istart + n, * const ilimit = iend - 8, * const prefixStart = src;
     const uint8_t* ip = istart, * anchor = istart;
     uint32_t offset_1 = rep[0], offset_2 = rep[1];
@@ -2767,7 +2767,7 @@ static size_t zo_dfast_ext_block(const zo_cparams* cp, const zo_cdict* cd, const
 }
 static size_t zo_dfast_ext(const zo_cparams* cp, const zo_cdict* cd, const uint8_t* src, size_t n, zo_store* st, uint32_t rep[3])
 {
-    return zo_dfast_ext_block(cp, cd, src, 0, n, NULL, NULL, st, rep);
+    return zo_dfast_ext_block(cp, cd, src, 0, n, NULL, NULL, 2, st, rep);
 }
 #undef PTR
 #undef SEQ
@@ -3159,6 +3159,8 @@ typedef struct {
     zo_seq* seqs; uint8_t* lits; uint8_t* body;
     zo_lz lz;                 /* greedy / lazy / lazy2: hash chain or rows, nextToUpdate, window low */
     const zo_cdict* cd;       /* a dictionary in copy mode: T starts as a copy of its tables, its content is the extDict segment of every block */
+    int dictValid;            /* ms->loadedDictEnd != 0: the whole dictionary is still inside the window */
+    uint32_t winLowIdx;       /* window.lowLimit as a reference index (dictionary byte j = j + 2, source byte i = dictLen + 2 + i) */
 } zo_fctx;
 
 /* zstd_preSplit.c:139-181 ZSTD_splitBlock(split_lvl1) = ZSTD_splitBlock_byChunks with one 2-byte event out of five: what ZSTD_lazy2
@@ -3194,6 +3196,14 @@ static size_t zo_split_block_lvl1(const uint8_t* p, size_t srcSize)
     return ZO_BLOCK_MAX;
 }
 
+/* ZSTD_getLowestMatchIndex at the block END for a context whose dictionary is an extDict segment (zstd_compress_internal.h:1312) */
+static uint32_t lowLimit_of(const zo_fctx* f, const zo_cparams* cp, size_t pos, size_t bLen)
+{
+    uint32_t const P = (uint32_t)f->cd->len + 2; size_t const maxDist = (size_t)1 << cp->windowLog;
+    size_t const endIndex = (size_t)P + pos + bLen;
+    return f->dictValid ? f->winLowIdx : (endIndex - f->winLowIdx > maxDist ? (uint32_t)(endIndex - maxDist) : f->winLowIdx);
+}
+
 /* ZSTD_compress_frameChunk (zstd_compress.c:4527-4623) over src[pos, pos + len): `savings` starts from the context's running total; lastChunk = the
  * call that ends the frame (its final block carries the last-block bit).  Returns the bytes written at op, ZO_ERROR on failure. */
 static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* src, size_t pos, size_t len, int lastChunk, uint8_t* op0)
@@ -3211,8 +3221,29 @@ static size_t zo_frame_chunk(zo_fctx* f, const zo_cparams* cp, const uint8_t* sr
             zo_store st; uint32_t nrep[3] = { f->rep[0], f->rep[1], f->rep[2] };
             size_t lastLits; zo_prev next;
             st.seqs = f->seqs; st.nb = 0; st.cap = ZO_BLOCK_MAX / 3 + 2; st.lits = f->lits; st.litSize = 0; st.overflow = 0;
-            lastLits = f->cd ? (cp->strategy == 2 ? zo_dfast_ext_block(cp, f->cd, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
-                                                  : zo_fast_ext_block(cp, f->cd, src, pos, bLen, f->T, &st, nrep))
+            if (f->cd) {
+                /* ZSTD_checkDictValidity (block end) and ZSTD_window_enforceMaxDist (block start), zstd_compress.c:4553-4556; then which
+                 * parser: the extDict one while part of the dictionary is inside the window — its own bound is taken at the block END
+                 * (zstd_fast.c:722-735 / zstd_double_fast.c:571-590) and it hands over to the plain parser when that bound passes the
+                 * dictionary; from then on the tables hold source positions only (entries of the dictionary are dropped) */
+                uint32_t const P = (uint32_t)f->cd->len + 2; size_t const maxDist = (size_t)1 << cp->windowLog;
+                uint32_t lowLimit;
+                if (f->dictValid && pos + bLen > maxDist) f->dictValid = 0;
+                if ((size_t)P + pos > maxDist + (f->dictValid ? P : 0)) {
+                    uint32_t const newLow = (uint32_t)(P + pos - maxDist);
+                    if (f->winLowIdx < newLow) f->winLowIdx = newLow;
+                    f->dictValid = 0;
+                }
+                {   size_t const endIndex = (size_t)P + pos + bLen;
+                    lowLimit = f->dictValid ? f->winLowIdx : (endIndex - f->winLowIdx > maxDist ? (uint32_t)(endIndex - maxDist) : f->winLowIdx); }
+                if (f->winLowIdx >= P || lowLimit >= P) {
+                    size_t i, words = ((size_t)1 << cp->hashLog) + (cp->strategy == 2 ? (size_t)1 << cp->chainLog : 0);
+                    for (i = 0; i < words; i++) f->T[i] = f->T[i] >= P ? f->T[i] - P + 1 : 0;      /* reference index -> position + 1, 0 = empty */
+                    f->cd = NULL;
+                }
+            }
+            lastLits = f->cd ? (cp->strategy == 2 ? zo_dfast_ext_block(cp, f->cd, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), lowLimit_of(f, cp, pos, bLen), &st, nrep)
+                                                  : zo_fast_ext_block(cp, f->cd, src, pos, bLen, f->T, lowLimit_of(f, cp, pos, bLen), &st, nrep))
                      : cp->strategy >= 3 ? zo_lazy_block(cp, src, pos, bLen, &f->lz, &st, nrep, cp->strategy - 3)
                      : cp->strategy == 2 ? zo_dfast_block(cp, src, pos, bLen, f->T, f->T + ((size_t)1 << cp->hashLog), &st, nrep)
                                          : zo_fast_block(cp, src, pos, bLen, f->T, &st, nrep);
@@ -3295,12 +3326,15 @@ size_t zo_compress_frame_cdict(void* dstv, size_t cap, const void* srcv, size_t 
     {   int rc; g_zo_any_strategy = 1; rc = zo_get_cparams_mode(cd->level, n, cd->fullSize, 0, &p); g_zo_any_strategy = 0; if (rc < 0) return ZO_ERROR; }
     cp = cd->cp; cp.windowLog = p.windowLog;
     if (cd->len == 0) return zo_compress_frame_params(dstv, cap, srcv, n, &cp);
-    if (n > ((size_t)1 << cp.windowLog)) return ZO_ERROR;
+    /* zstd_compress.c:5153-5165: the CDict's TABLES are only used for a source below 128 KB or below six times the dictionary content
+     * (a CDict made by ZSTD_createCDict; an "advanced" one always is, with default-level parameters requested).  Above that the reference
+     * reloads the dictionary content into the context with the context's own parameters (ZSTD_compress_insertDictionary): not restated */
+    if (n >= 6 * cd->fullSize) return ZO_ERROR;
     op += write_frame_header_dict(op, &cp, n, cd->dictID);
     if (!zo_fctx_init(&f, &cp)) { zo_fctx_free(&f); return ZO_ERROR; }
     for (i = 0; i < ((size_t)1 << cp.hashLog); i++) f.T[i] = cd->tabL[i] >> 8;                    /* zstd_compress.c:2379-2393 tags removed */
     if (cp.strategy == 2) for (i = 0; i < ((size_t)1 << cp.chainLog); i++) f.T[((size_t)1 << cp.hashLog) + i] = cd->tabS[i] >> 8;
-    f.cd = cd;
+    f.cd = cd; f.dictValid = 1; f.winLowIdx = 2;
     f.rep[0] = cd->rep[0]; f.rep[1] = cd->rep[1]; f.rep[2] = cd->rep[2];
     if (cd->hasEntropy) f.prev = cd->prev;
     r = zo_frame_chunk(&f, &cp, src, 0, n, 1, op);

@@ -388,24 +388,25 @@ def test_lazy_cdict_records_vs_reference(libs):
 
 
 def test_cdict_on_sources_above_128k_vs_reference(libs):
-    """refCDict + ZSTD_compress2 on a source above 128 KB (strategies fast / dfast): copy mode carried through the frame's blocks — the
-    context's tables start as copies of the CDict's, every block runs the extDict parser, the first block starts from the dictionary's
-    repcodes and entropy tables.  Sources up to the window size (zo_compress_frame_cdict refuses the rest: the sliding window over an
-    extDict segment is not restated)"""
+    """ZSTD_createCDict + refCDict + ZSTD_compress2 on a source above 128 KB (strategies fast / dfast): while the source is below six times
+    the dictionary (zstd_compress.c:5153-5190) the CDict's tables are copied and carried through the frame's blocks — every block runs the
+    extDict parser until the window has slid past the dictionary, then the plain one; the first block starts from the dictionary's
+    repcodes and entropy tables.  Larger sources make the reference reload the dictionary content with the context's own parameters:
+    zo_compress_frame_cdict refuses those (not restated)"""
     lo, lr = libs
     lo.zo_cdict_create.restype = C.c_void_p; lo.zo_cdict_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     lo.zo_cdict_free.argtypes = [C.c_void_p]
     lo.zo_compress_frame_cdict.restype = C.c_size_t; lo.zo_compress_frame_cdict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
-    lr.zref_compress_records_cdict_fresh.restype = C.c_size_t
-    lr.zref_compress_records_cdict_fresh.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lr.zref_compress_records_cdict.restype = C.c_size_t
+    lr.zref_compress_records_cdict.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     zd = np.fromfile(os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict"), dtype=np.uint8)
     rng = np.random.default_rng(9)
-    seen = 0
-    for t in range(6):
-        corpus = text_like(900000, t) if t % 2 == 0 else np.concatenate([text_like(400000, t + 50), datagen(lo, 500000, 50, t)])
-        d = zd if t % 3 == 2 else corpus[:int(rng.choice([3000, 20000, 112640]))].copy()
-        n = int(rng.integers(131073, 500000))
+    seen = slid = 0
+    for t in range(8):
+        corpus = text_like(1300000, t) if t % 2 == 0 else np.concatenate([text_like(600000, t + 50), datagen(lo, 700000, 50, t)])
+        d = zd if t % 3 == 2 else corpus[:int(rng.choice([60000, 112640, 200000]))].copy()
+        n = int(rng.integers(131073, min(6 * len(d), 1200000)))
         o = int(rng.integers(0, len(corpus) - n))
         a = corpus[o:o + n].copy()
         for level in (1, 3, -3):
@@ -415,10 +416,10 @@ def test_cdict_on_sources_above_128k_vs_reference(libs):
             out = np.zeros(cap, dtype=np.uint8)
             r = lo.zo_compress_frame_cdict(_buf(out), cap, _buf(a), n, cd)
             lo.zo_cdict_free(cd)
-            if r == ERR:
-                continue                                   # greedy CDict rows of tiny dictionaries
+            assert r != ERR
             want = np.zeros(n + (n >> 7) + 1024, dtype=np.uint8)
-            k = lr.zref_compress_records_cdict_fresh(level, 0, _buf(d), len(d), _buf(a), (C.c_size_t * 1)(n), 1, _buf(want), len(want), None)
+            k = lr.zref_compress_records_cdict(level, _buf(d), len(d), _buf(a), (C.c_size_t * 1)(n), 1, _buf(want), len(want), None)
             assert k != ERR and out[:r].tobytes() == want[:k].tobytes(), (t, n, level, len(d))
             seen += 1
-    assert seen >= 12
+            slid += (level != 3 and n > (1 << 19))                     # levels 1 and -3: a 512 KB window, the dictionary slides out
+    assert seen == 24 and slid >= 2
