@@ -3301,6 +3301,7 @@ size_t zo_compress_frame_params(void* dstv, size_t cap, const void* srcv, size_t
     uint8_t* op = dst;
     zo_fctx f; size_t r;
     if (cp->strategy < 1 || cp->strategy > 5 || cap < zo_frame_bound(n)) return ZO_ERROR;   /* fast .. lazy2 */
+    if (cp->windowLog < 17 && n > ((size_t)1 << cp->windowLog)) return ZO_ERROR;   /* the block size would follow the window (zstd_compress.c: blockSizeMax): not restated */
     op += write_frame_header(op, cp, n);
     if (n == 0) { wr24(op, 1); return (size_t)(op + 3 - dst); }
     if (!zo_fctx_init(&f, cp)) { zo_fctx_free(&f); return ZO_ERROR; }
@@ -3406,6 +3407,7 @@ size_t zo_compress_frame_mt_params(void* dstv, size_t cap, const void* srcv, siz
     size_t pos = 0, prevLen = 0, section, overlap;
     unsigned k = 0;
     if (cp->strategy < 1 || cp->strategy > 5 || cap < zo_frame_bound(n) + 4) return ZO_ERROR;
+    if (cp->windowLog < 17 && n > ((size_t)1 << cp->windowLog)) return ZO_ERROR;
     if (n <= (512u << 10)) {                                                     /* single-threaded below ZSTDMT_JOBSIZE_MIN */
         size_t r = zo_compress_frame_params(dst, cap, src, n, cp);
         if (r == ZO_ERROR) return r;

@@ -1,8 +1,8 @@
 """Oracle vs committed golden vectors (made by tests/golden/make_golden.py with the real reference).
 Runs anywhere (no /root/reference, no oracle/_ref needed)."""
-import hashlib, json, os
+import ctypes as C, hashlib, json, os
 import numpy as np
-from _libs import load_oracle, corpus_cases, frame_cases, oracle_frame, mt_frame_cases, oracle_frame_mt, MT_MODES, _buf, ERR
+from _libs import datagen, load_oracle, corpus_cases, frame_cases, oracle_frame, mt_frame_cases, oracle_frame_mt, MT_MODES, _buf, ERR
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "units_v1.json")
 
@@ -186,3 +186,25 @@ def test_oracle_reproduces_golden_lazy_cdict_records():
                 assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, no_row)
                 seen += 1
     assert seen == len(gold) == 16
+
+
+def test_oracle_refuses_frames_whose_window_is_below_the_block_size():
+    """with windowLog < 17 the reference's blocks follow the window (zstd_compress.c:4494-4501 blockSizeMax) and the window slides inside
+    the parser: neither the oracle nor the device restates that — both refuse (zhip_lib.hip: "windowLog below the block size"), found by
+    the emulator fuzz of the job-pool frames straying out of the domain"""
+    lo = load_oracle()
+    lo.zo_compress_frame_params.restype = C.c_size_t
+    lo.zo_compress_frame_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_compress_frame_mt_params.restype = C.c_size_t
+    lo.zo_compress_frame_mt_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int]
+    lo.zo_frame_bound.restype = C.c_size_t; lo.zo_frame_bound.argtypes = [C.c_size_t]
+    a = datagen(lo, 700000, 50, 3)
+    cap = lo.zo_frame_bound(len(a)) + 4
+    dst = np.zeros(cap, dtype=np.uint8)
+    for wl in (11, 16):
+        cp = (C.c_uint * 7)(wl, 10, 10, 1, 4, 0, 1)
+        assert lo.zo_compress_frame_params(_buf(dst), cap, _buf(a), len(a), cp) == ERR
+        assert lo.zo_compress_frame_mt_params(_buf(dst), cap, _buf(a), len(a), cp, 0, 0, 0) == ERR
+        assert lo.zo_compress_frame_params(_buf(dst), cap, _buf(a), 1 << wl, cp) != ERR       # a source that fits the window is one block at most
+    cp = (C.c_uint * 7)(17, 10, 10, 1, 4, 0, 1)
+    assert lo.zo_compress_frame_params(_buf(dst), cap, _buf(a), len(a), cp) != ERR
