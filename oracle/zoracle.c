@@ -2968,6 +2968,7 @@ static size_t zo_fast_block(const zo_cparams* cp, const uint8_t* src /* frame st
     size_t anchor = bStart, ip0 = bStart, ip1, ip2, ip3, cur0 = 0, step, nextStep, match0 = 0, mLength;
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, offBase;
     uint32_t h0, h1, cand;
+    if (iend < 8) return bLen;                                                   /* a 7-byte frame: ilimit lies before the source (the reference compares pointers), nothing is searched */
     ip0 += (ip0 == prefixLow);                                                   /* :238 */
     {   size_t const windowLow = (ip0 - dictLimit > maxDist) ? ip0 - maxDist : dictLimit;   /* :239-244 */
         size_t const maxRep = ip0 - windowLow;
@@ -3065,6 +3066,7 @@ static size_t zo_dfast_block(const zo_cparams* cp, const uint8_t* src /* frame s
     size_t const prefixLow = (iend - dictLimit > maxDist) ? iend - maxDist : dictLimit;
     size_t anchor = bStart, ip = bStart, ip1, step, nextStep, curr = 0, mLength = 0;
     uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0, offset = 0;
+    if (iend < 8) return bLen;                                                   /* a 7-byte frame, as in zo_fast_block */
     ip += (ip == prefixLow);                                                     /* :157 */
     {   size_t const windowLow = (ip - dictLimit > maxDist) ? ip - maxDist : dictLimit;
         size_t const maxRep = ip - windowLow;

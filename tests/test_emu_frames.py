@@ -32,6 +32,19 @@ def test_frames_match_oracle(libs, level):
         assert g == oracle_frame(lo, a, level), f"{name} level {level}"
 
 
+def test_tiny_frames_match_oracle(libs):
+    """frames of 1 .. 24 bytes in one batch (7 bytes is the size at which the parsers run with their search limit before the source:
+    the oracle once wrapped there, tests/test_oracle_vs_reference.py::test_tiny_frames_vs_reference pins it to the reference)"""
+    lo, le = libs
+    rng = np.random.default_rng(8)
+    bufs = [rng.integers(0, 256, size=n, dtype=np.uint8) for n in range(1, 25)] + [np.full(n, 66, np.uint8) for n in range(1, 25)]
+    for level, cp in ((1, None), (3, None), (1, [17, 13, 17, 1, 7, 16, 1]), (1, [18, 12, 12, 1, 5, 0, 2])):
+        got = emu_compress_frames(le, lo, bufs, level, cparams=cp)
+        for a, g in zip(bufs, got):
+            want = oracle_frame(lo, a, level) if cp is None else oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), False)
+            assert g == want, (len(a), level, cp)
+
+
 def test_frames_table_in_hbm_and_checksum(libs):
     """level 2 above 256 KB: hashLog 16 -> the table is in HBM; the frame checksum is XXH64 of the WHOLE input"""
     lo, le = libs

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, oracle_frame_mt, ref_frame_mt, _buf, ERR
-from _libs import ROOT
+from _libs import ROOT, oracle_frame_params
 import os
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
@@ -246,6 +246,35 @@ def test_multiblock_frame_with_explicit_parameters_vs_reference(libs):
             cpi = (C.c_int * 7)(*cp)
             k = lr.zref_compress_chunks_level_params(level, cpi, 0, n, _buf(src), n, _buf(want), len(want))
             assert r != ERR and k != ERR and got[:r].tobytes() == want[:k].tobytes(), (level, cp, list(eff))
+
+
+def test_tiny_frames_vs_reference(libs):
+    """frames of 0 .. 24 bytes: below 7 bytes the block is stored, at exactly 7 the fast / dfast parsers run with their search limit
+    (end - 8) BEFORE the source — the reference compares pointers there; the oracle's index arithmetic wrapped and read far out of the
+    buffer (found by tests/tools/emu_fuzz_frames.py, the kernel was right)"""
+    lo, lr = libs
+    lr.zref_compress_frame.restype = C.c_size_t
+    lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lr.zref_compress_chunks_level_params.restype = C.c_size_t
+    lr.zref_compress_chunks_level_params.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    import zstd_amd
+    L = zstd_amd.lib()
+    L.zhip_getCParams_explicit.restype = C.c_int
+    L.zhip_getCParams_explicit.argtypes = [C.c_int, C.c_ulonglong, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    want = np.zeros(4096, dtype=np.uint8)
+    for n in range(0, 25):
+        for kind in range(3):
+            a = (rng.integers(0, 256, size=n, dtype=np.uint8) if kind == 0 else np.full(n, 65, np.uint8) if kind == 1 else
+                 np.tile(rng.integers(0, 256, size=3, dtype=np.uint8), 9)[:n].copy())
+            for level in (1, 3, -5):
+                k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
+                assert k != ERR and oracle_frame(lo, a, level) == want[:k].tobytes(), (n, kind, level)
+            for level, cp in ((1, [17, 13, 17, 1, 7, 16, 1]), (3, [18, 12, 12, 1, 5, 0, 2]), (1, [17, 0, 0, 0, 3, 0, 1])):
+                eff = (C.c_uint * 7)()
+                assert L.zhip_getCParams_explicit(level, max(n, 1), (C.c_uint * 7)(*cp), eff) == 0
+                k = lr.zref_compress_chunks_level_params(level, (C.c_int * 7)(*cp), 0, max(n, 1), _buf(a), n, _buf(want), len(want))
+                assert k != ERR and oracle_frame_params(lo, a, eff, False) == want[:k].tobytes(), (n, kind, level, cp, list(eff))
 
 
 def test_job_pool_frame_vs_reference(libs):
