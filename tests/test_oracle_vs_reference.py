@@ -277,6 +277,29 @@ def test_tiny_frames_vs_reference(libs):
                 assert k != ERR and oracle_frame_params(lo, a, eff, False) == want[:k].tobytes(), (n, kind, level, cp, list(eff))
 
 
+def test_frame_sizes_around_the_parsers_limits_vs_reference(libs):
+    """every strategy up to lazy2 (levels 1 .. 10, the default matcher) on frames of 0 .. 40 bytes and on last blocks of 1 .. 33 bytes after
+    one or two full ones: the sizes at which a parser's search limit (end - 8, end - 16 with the row matcher) falls before the block"""
+    lo, lr = libs
+    lr.zref_compress_frame.restype = C.c_size_t
+    lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(5)
+    want = np.zeros(1 << 20, dtype=np.uint8)
+    seen = 0
+    for n in list(range(0, 41, 1)) + [131072 + k for k in (1, 6, 7, 8, 15, 16, 17, 33)] + [262144 + 7, 262144 + 16]:
+        kinds = range(3) if n < 64 else range(2, 3)
+        for kind in kinds:
+            a = (rng.integers(0, 256, size=n, dtype=np.uint8) if kind == 0 else np.full(n, 65, np.uint8) if kind == 1 else text_like(max(n, 1), n)[:n].copy())
+            for level in ((1, 3, 5, 6, 8, 10) if n < 64 else (3, 5, 8, 10)):
+                cp = (C.c_uint * 7)()
+                if lo.zo_get_cparams(level, max(n, 1), cp) != 0 or cp[6] > 5:      # a bt* row of the small-size tables: out of scope
+                    continue
+                k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
+                assert k != ERR and oracle_frame_params(lo, a, cp, cp[6] >= 3 and cp[0] > 14) == want[:k].tobytes(), (n, kind, level, list(cp))
+                seen += 1
+    assert seen >= 600
+
+
 def test_job_pool_frame_vs_reference(libs):
     """zo_compress_frame_mt_params against ZSTD_compress2 with ZSTD_c_nbWorkers = 1 on random sizes, job sizes and overlaps (the frame
     the shim's nbWorkers mode must equal); at or below 512 KB the reference drops the workers"""
