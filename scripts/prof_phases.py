@@ -30,7 +30,10 @@ def main():
     mib = int(os.environ.get("MIB", "1024"))
     level = int(os.environ.get("LEVEL", "1"))
     n = mib << 20
-    if os.environ.get("WORKLOAD", "datagen") == "text":
+    if os.environ.get("WORKLOAD", "datagen") == "silesia":
+        from zstd_amd import workloads as W
+        host = W.tile(W.silesia_like(lambda size, P, seed: zstd_amd.datagen(size, P, seed=seed, stream_mode=False), seed=0), n)
+    elif os.environ.get("WORKLOAD", "datagen") == "text":
         from zstd_amd import workloads as W
         import numpy as np
         base = W.text_corpus(64 << 20, seed=0)
@@ -58,6 +61,8 @@ def main():
     res = {"timing_ms": tm, "units": units,
            "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(10)},
            "parse_windows_per_unit": v[10] / units, "parse_window_events_per_unit": v[11] / units,
+           "fast_events_per_unit": v[12] / units, "window_reruns_per_unit": v[13] / units, "verify_rounds_per_unit": v[14] / units,
+           "trimmed_tails_per_unit": v[15] / units,
            "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)},
            "entropy_extra": [round(v[16 + i] / units) for i in range(8, 12)],
            "phaseB_jobs_ticks_per_unit": {"huf_build_codes": round(v[28] / units), "huf other (mode, write table)": round(v[31] / units),

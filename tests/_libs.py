@@ -180,9 +180,12 @@ def load_emu():
     srcs = [os.path.join(d, "emu_driver.cpp"), os.path.join(d, "simt_runtime.cpp"), os.path.join(d, "hip", "hip_runtime.h")]
     srcs += [os.path.join(ROOT, "zstd_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "zstd_amd", "csrc"))
              if f.endswith(".h")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    extra = os.environ.get("ZHIP_EMU_FLAGS", "").split()          # debugging: another build of the emulator library (e.g. -DZHIP_WIN_FAST=0)
+    if extra:
+        so = os.path.join(d, "libzhip_emu_dbg.so")
+    if extra or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-I" + d,
-                               "-I" + os.path.join(ROOT, "zstd_amd", "csrc"), srcs[0], srcs[1], "-o", so, "-lpthread"])
+                               "-I" + os.path.join(ROOT, "zstd_amd", "csrc"), srcs[0], srcs[1], "-o", so, "-lpthread"] + extra)
     lib = C.CDLL(so)
     assert lib.emu_sizeof_unit() == UNIT_DT.itemsize and lib.emu_sizeof_parse() == PARSE_DT.itemsize
     lib.emu_parse_fast.restype = None

@@ -61,10 +61,10 @@ struct ZhipParse {
 // expands all of this to nothing.
 #ifdef ZHIP_PROF
 namespace zhip { __device__ unsigned long long g_prof[32]; }
-#define ZPROF_DECL uint64_t zp_last_ = __builtin_amdgcn_s_memtime(); uint64_t zp_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define ZPROF_DECL uint64_t zp_last_ = __builtin_amdgcn_s_memtime(); uint64_t zp_acc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define ZPROF(i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); zp_acc_[i] += t_ - zp_last_; zp_last_ = t_; } while (0)
 #define ZPROF_COUNT(i, v) do { zp_acc_[i] += (uint64_t)(v); } while (0)
-#define ZPROF_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&zhip::g_prof[(base) + i_], (unsigned long long)zp_acc_[i_]); } while (0)
+#define ZPROF_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; i_++) atomicAdd(&zhip::g_prof[(base) + i_], (unsigned long long)zp_acc_[i_]); } while (0)
 #define ZPROF_JOB_BEGIN uint64_t zj_ = __builtin_amdgcn_s_memtime();
 #define ZPROF_JOB_MARK(slot) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd(&zhip::g_prof[slot], (unsigned long long)(t_ - zj_)); zj_ = t_; } while (0)
 #else

@@ -25,7 +25,14 @@
 namespace zhip {
 
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
-__global__ void __launch_bounds__(64)
+#ifndef ZHIP_FAST_OCC
+#if ZHIP_WIN_FAST
+#define ZHIP_FAST_OCC __attribute__((amdgpu_waves_per_eu(3)))      /* <= 170 VGPRs: the LDS table admits nine units per CU = three on one of the four SIMDs */
+#else
+#define ZHIP_FAST_OCC
+#endif
+#endif
+__global__ void __launch_bounds__(64) ZHIP_FAST_OCC
 k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
 {
