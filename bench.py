@@ -96,7 +96,7 @@ def cpu_decode_baseline(sample, seconds=6.0, level=1):
         allc = json.loads(subprocess.check_output([exe, "dfile", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
         return {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference",
                 "sample": f"first {len(sample) >> 20} MiB of the workload compressed at level {level} into {UNIT} B-unit frames, ZSTD_decompressDCtx per frame, best of "
-                          f"{one['runs']} runs (oracle/_ref/zref_bench dfile; the reference is built with ZSTD_DISABLE_ASM, its Huffman loops are the C ones)",
+                          f"{one['runs']} runs (oracle/_ref/zref_bench dfile, linked against the reference built WITH its x86-64 assembly Huffman loops)",
                 "all_cores": {"value": allc["MBps"], "cores": ncores}}
     finally:
         os.unlink(tmp)
@@ -131,12 +131,12 @@ def decode_measure(torch, zstd_amd, local, src, n, dst, sizes, steps, warmup, ba
     return dt, kms / steps, ok
 
 
-def parity_check(host, n, dev_out, total, sizes, level=1):
+def parity_check(host, n, dev_out, total, sizes, level=1, tile=None):
     """byte parity of the GPU stream.  With oracle/_ref present: the WHOLE workload is compressed once by the real reference on all
     host cores (zref_bench cfile) and the SHA-256 of that stream is compared with the SHA-256 of the whole GPU stream — full size.
     Always: the first 64 units byte for byte against the C restatement, and the structure of every frame (magic at the offset the
-    size table implies, sizes add up).  `host` may be shorter than n when the workload is tiled on the device (then the full-size
-    hash is taken over what the host holds: whole units only)."""
+    size table implies, sizes add up).  `host` may be shorter than n when the workload is tiled on the device: `tile` = (base corpus,
+    shift) then lets the reference build the very same tiling in memory (zref_bench ctile) — still the whole stream, full size."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import load_oracle, _buf, ERR
@@ -159,24 +159,36 @@ def parity_check(host, n, dev_out, total, sizes, level=1):
     res = {"bytes_identical_to_oracle_first_64_units": bool(same), "frames_well_formed": magic_ok and int(offs[-1]) == int(total)}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
-        full = min(len(host), n) // UNIT * UNIT if len(host) < n else min(len(host), n)
+        tiled = tile is not None and len(host) < n
+        full = n if tiled else (min(len(host), n) // UNIT * UNIT if len(host) < n else min(len(host), n))
         tin, tout = f"/tmp/zhip_parity_in_{os.getpid()}.bin", f"/tmp/zhip_parity_out_{os.getpid()}.bin"
         try:
-            host[:full].tofile(tin)
             # levels >= 5 (row-hash matcher): a new CCtx per unit — the salt of a reused CCtx depends on what it compressed before
             env = dict(os.environ, ZREF_FRESH_CCTX="1") if level >= 5 else dict(os.environ)
             env.pop("ZREF_NOROW", None)
-            info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(UNIT), tin, tout, str(os.cpu_count() or 1)], timeout=600, env=env))
+            nthr = str(os.cpu_count() or 1)
+            if tiled:
+                base, shift = tile
+                base.tofile(tin)
+                info = json.loads(subprocess.check_output([exe, "ctile", str(level), str(UNIT), tin, "0", str(shift), str(n), tout, nthr], timeout=900, env=env))
+            else:
+                host[:full].tofile(tin)
+                info = json.loads(subprocess.check_output([exe, "cfile", str(level), str(UNIT), tin, tout, nthr], timeout=600, env=env))
             h = hashlib.sha256()
             with open(tout, "rb") as f:
-                for blk in iter(lambda: f.read(1 << 24), b""):
+                for blk in iter(lambda: f.read(1 << 26), b""):
                     h.update(blk)
             nu = (full + UNIT - 1) // UNIT
             glen = int(offs[nu])
-            g = hashlib.sha256(dev_out[:glen].cpu().numpy().tobytes()).hexdigest()
+            gh = hashlib.sha256()
+            for a0 in range(0, glen, 1 << 28):                  # the GPU stream, hashed in 256 MiB pieces
+                gh.update(dev_out[a0: min(glen, a0 + (1 << 28))].cpu().numpy())
+            g = gh.hexdigest()
             res["full_size"] = {"sha256_equals_reference_stream": bool(g == h.hexdigest() and glen == info["csize"]), "source_bytes": int(full),
                                 "compressed_bytes": glen, "units": int(nu), "sha256": g,
-                                "reference": f"oracle/_ref/zref_bench cfile = ZSTD_compress2 per unit on {info['threads']} host threads, {info['seconds']} s"}
+                                "reference": f"oracle/_ref/zref_bench {'ctile (the same tiling built in memory)' if tiled else 'cfile'} = ZSTD_compress2 per unit on {info['threads']} host threads, {info['seconds']} s"}
+            if tiled and "MBps" in info:
+                res["full_size"]["reference_all_threads_MBps"] = info["MBps"]
         finally:
             for t in (tin, tout):
                 if os.path.exists(t):
@@ -184,13 +196,16 @@ def parity_check(host, n, dev_out, total, sizes, level=1):
     return res
 
 
-def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
-    """BASELINE configs[4] stand-in: many ~1.2 KB JSON records (GitHub-user shaped), each its own frame, compressed with a
-    dictionary attached (ZSTD_createCDict + refCDict + compress2 per record).  Dictionary = the committed ZDICT-trained fixture
-    (or, with --raw-dict, the first ~110 KB of records as raw content).  One step = every record once."""
+def records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, n_records, distinct, steps, warmup, want_cpu, want_decode):
+    """BASELINE configs[4] stand-in: `n_records` ~1.2 KB JSON records (GitHub-user shaped), `distinct` of them different (generated natively,
+    zstd_amd/workloads_src) and tiled, each its own frame, compressed with a dictionary attached (ZSTD_createCDict + refCDict + compress2
+    per record).  Dictionary = the committed ZDICT-trained fixture (or, with --raw-dict, the first ~110 KB of records as raw content).
+    One step = every record once.  Parity at FULL size: SHA-256 of the whole GPU stream against the real reference's stream of the
+    distinct records (zref_bench cdict) repeated once per copy; and the first 256 frames byte for byte against the C restatement."""
     from zstd_amd import workloads as W
     level = args.level if args.level != 1 else 3                       # configs[4] is level 3; --level 1 is the bench default
-    flat, offs = W.github_like_records(args.base_records, seed=rank)
+    distinct = max(1, min(distinct, n_records))
+    flat, offs = W.github_like_records_native(distinct, seed=rank)
     zpath = os.path.join(ROOT, "tests", "golden", "github_like_110k.zdict")
     if os.path.exists(zpath) and not args.raw_dict:
         dict_ = np.fromfile(zpath, dtype=np.uint8)                      # ZDICT_trainFromBuffer on 4 000 such records (tests/golden/make_dict.py)
@@ -200,7 +215,7 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
         dict_ = flat[: int(offs[ndict])].copy()
         ddesc = f"raw-content dictionary of {len(dict_)} B (the first records)"
     base_n, L = len(offs) - 1, int(offs[-1])
-    copies = max(1, (args.mib << 20) // L)
+    copies = max(1, n_records // base_n)
     n = L * copies
     all_offs = (np.arange(copies, dtype=np.uint64)[:, None] * np.uint64(L) + offs[None, :-1]).reshape(-1)
     all_offs = np.concatenate([all_offs, [np.uint64(n)]]).astype(np.uint64)
@@ -209,6 +224,7 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
     src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
     for c in range(copies):
         src[c * L:(c + 1) * L].copy_(bdev)
+    del bdev
     cap = int(zstd_amd.lib().zhip_records_bound(all_offs.ctypes.data_as(C.c_void_p), nrec))
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
     fsz = torch.zeros(nrec, dtype=torch.int32, device=dev)
@@ -222,22 +238,23 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         total = step()
     barrier()
     t0 = time.perf_counter()
     kp = ke = kt = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         total = step()
         tm = ctx.timing(); kp += tm["parse_ms"]; ke += tm["entropy_ms"]; kt += tm["total_ms"]
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        tt = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    out = None
     if rank == 0:
-        K = args.steps
+        K = steps
         sizes = fsz.cpu().numpy()
-        # parity: the first 256 frames byte for byte against the oracle's CDict restatement
+        # parity 1: the first 256 frames byte for byte against the oracle's CDict restatement
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _libs import load_oracle, _buf, ERR
         lo = load_oracle()
@@ -253,76 +270,130 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
             k = lo.zo_compress_unit_cdict(_buf(buf), len(buf), _buf(r), len(r), ocd)
             assert k != ERR
             want += buf[:k].tobytes()
-        parse_ms, ent_ms, tot_ms = kp / K, ke / K, kt / K
-        algo = n + int(total)
-        out = {"metric": f"compress_MBps_level{level}_records_with_dictionary", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
-               "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
-               "config": {"workload": f"{nrec} JSON records (GitHub-user shaped, mean {L // base_n} B; {base_n} distinct, tiled x{copies}), one frame per record, "
-                                      f"level {level}, {ddesc} attached (ZSTD_createCDict + refCDict + compress2 semantics), src+dst in HBM",
-                          "records_per_gpu": nrec, "parallelism": f"{world} x (one process per GPU, independent records, no collective)"},
-               "ratio": round(n / float(total), 4),
-               "roofline": {"bound": "hbm", "kernel": "k_parse_dict", "achieved": round(algo / (parse_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(algo / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(parse_ms, 3)},
-               "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "device_total_ms": round(tot_ms, 3),
-                            "host_ms_per_step": round(dt / K * 1e3 - tot_ms, 3)},
-               "parity": {"bytes_identical_to_oracle_first_256_records": gpu == want}}
-        if not args.no_cpu_baseline:
-            exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
-            if os.path.exists(exe):
-                dict_.tofile("/tmp/zb_d.bin"); flat.tofile("/tmp/zb_r.bin"); offs.tofile("/tmp/zb_o.bin")
-                one = json.loads(subprocess.check_output([exe, "dict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "6", "1"], timeout=120))
+        parity = {"bytes_identical_to_oracle_first_256_records": gpu == want}
+        # parity 2, full size: the whole GPU stream against the real reference's stream of the distinct records, once per copy
+        exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+        pid = os.getpid()
+        fd, fr, fo, fout = (f"/tmp/zb_{pid}_{x}.bin" for x in ("d", "r", "o", "out"))
+        have_ref = os.path.exists(exe)
+        if have_ref:
+            dict_.tofile(fd); flat.tofile(fr); offs.astype("<u8").tofile(fo)
+        try:
+            if have_ref:
+                nthr = os.cpu_count() or 1
+                info = json.loads(subprocess.check_output([exe, "cdict", str(level), fd, fr, fo, fout, str(nthr)], timeout=600))
+                ref_stream = np.fromfile(fout, dtype=np.uint8)
+                h = hashlib.sha256()
+                for _ in range(copies):
+                    h.update(ref_stream)
+                gh = hashlib.sha256()
+                glen = int(total)
+                for a0 in range(0, glen, 1 << 28):
+                    gh.update(dst[a0: min(glen, a0 + (1 << 28))].cpu().numpy())
+                parity["full_size"] = {"sha256_equals_reference_stream": bool(gh.hexdigest() == h.hexdigest() and glen == copies * int(info["csize"])),
+                                       "records": int(nrec), "distinct_records": int(base_n), "source_bytes": int(n), "compressed_bytes": glen, "sha256": gh.hexdigest(),
+                                       "reference": f"oracle/_ref/zref_bench cdict = ZSTD_createCDict + refCDict + ZSTD_compress2 of every distinct record on {info['threads']} host "
+                                                    f"threads ({info['seconds']} s), the stream hashed once per copy"}
+            parse_ms, ent_ms, tot_ms = kp / K, ke / K, kt / K
+            algo = n + int(total)
+            traffic, tsrc = traffic_lookup("records_zdict_level3", "k_parse_dict")
+            out = {"metric": f"compress_MBps_level{level}_records_with_dictionary", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
+                   "n_gpus": world, "steps": K, "warmup": warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+                   "config": {"workload": f"{nrec} JSON records (GitHub-user shaped, mean {L // base_n} B; {base_n} distinct = {L} B, tiled x{copies}), one frame per record, "
+                                          f"level {level}, {ddesc} attached (ZSTD_createCDict + refCDict + compress2 semantics), src+dst in HBM",
+                              "records_per_gpu": nrec, "parallelism": f"{world} x (one process per GPU, independent records, no collective)"},
+                   "ratio": round(n / float(total), 4),
+                   "roofline": {"bound": "hbm", "kernel": "k_parse_dict", "achieved": round(algo / (parse_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(algo / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                                "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(parse_ms, 3)},
+                   "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "device_total_ms": round(tot_ms, 3),
+                                "host_ms_per_step": round(dt / K * 1e3 - tot_ms, 3)},
+                   "parity": parity}
+            # the CPU figures use a bounded sample: the first 100 000 distinct records (about 120 MB)
+            ns = min(base_n, 100000)
+            if have_ref and (want_cpu or want_decode):
+                flat[: int(offs[ns])].tofile(fr); offs[: ns + 1].astype("<u8").tofile(fo)
+            if want_cpu and have_ref:
+                one = json.loads(subprocess.check_output([exe, "dict", str(level), fd, fr, fo, "5", "1"], timeout=120))
                 nc = os.cpu_count() or 1
-                allc = json.loads(subprocess.check_output([exe, "dict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "4", str(nc)], timeout=120))
+                allc = json.loads(subprocess.check_output([exe, "dict", str(level), fd, fr, fo, "3", str(nc)], timeout=120))
                 out["cpu_baseline"] = {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
-                                       "sample": f"the {base_n} distinct records, same dictionary, ZSTD_createCDict + refCDict + compress2 per record (oracle/_ref/zref_bench dict)",
+                                       "sample": f"the first {ns} distinct records, same dictionary, ZSTD_createCDict + refCDict + compress2 per record (oracle/_ref/zref_bench dict)",
                                        "all_cores": {"value": allc["MBps"], "cores": nc}}
-        if world == 1:                                          # the way back: every record frame decoded with the dictionary (ZSTD_decompress_usingDDict per record)
-            dd = zstd_amd.DDict(dict_, device=local)
-            dctx = zstd_amd.DContext(local)
-            csz = sizes.astype(np.uint64)
-            so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
-            rsz = np.diff(all_offs).astype(np.uint64)
-            back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
-            best = 1e9
-            for _ in range(3):
-                r, status, dsz = dctx.decompress_frames_device(back.data_ptr(), all_offs[:-1], rsz, dst.data_ptr(), so, csz, ddict=dd)
-                best = min(best, dctx.timing()["decode_ms"])
-            okd = bool(r == n and not status.any() and torch.equal(back[:n], src[:n]))
-            dcpu = None
-            if not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "zref_bench")):
-                exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
-                dict_.tofile("/tmp/zb_d.bin"); flat.tofile("/tmp/zb_r.bin"); offs.astype("<u8").tofile("/tmp/zb_o.bin")
-                try:
-                    one = json.loads(subprocess.check_output([exe, "ddict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "4", "1"], timeout=120))
-                    nc = os.cpu_count() or 1
-                    allc = json.loads(subprocess.check_output([exe, "ddict", str(level), "/tmp/zb_d.bin", "/tmp/zb_r.bin", "/tmp/zb_o.bin", "3", str(nc)], timeout=120))
-                    dcpu = {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference",
-                            "sample": f"the {base_n} distinct record frames, ZSTD_createDDict + ZSTD_decompress_usingDDict per record (oracle/_ref/zref_bench ddict)",
-                            "all_cores": {"value": allc["MBps"], "cores": nc}}
-                except Exception:
-                    dcpu = None
-            out["decode"] = {"metric": "decompress_MBps_records_with_dictionary", "value": round(n / best / 1e3, 1), "unit": "MB/s", "k_decode_ms": round(best, 3),
-                             "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
-                             "parity": {"decoded_equals_source_full_size": okd}}
-            if dcpu:
-                out["decode"]["cpu_baseline"] = dcpu
+            if want_decode and world == 1:                      # the way back: every record frame decoded with the dictionary (ZSTD_decompress_usingDDict per record)
+                dd = zstd_amd.DDict(dict_, device=local)
+                dctx = zstd_amd.DContext(local)
+                csz = sizes.astype(np.uint64)
+                so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
+                rsz = np.diff(all_offs).astype(np.uint64)
+                back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+                best = 1e9
+                for _ in range(2):
+                    r, status, dsz = dctx.decompress_frames_device(back.data_ptr(), all_offs[:-1], rsz, dst.data_ptr(), so, csz, ddict=dd)
+                    best = min(best, dctx.timing()["decode_ms"])
+                okd = bool(r == n and not status.any() and torch.equal(back[:n], src[:n]))
+                del back
+                dcpu = None
+                if want_cpu and have_ref:
+                    try:
+                        one = json.loads(subprocess.check_output([exe, "ddict", str(level), fd, fr, fo, "4", "1"], timeout=120))
+                        nc = os.cpu_count() or 1
+                        allc = json.loads(subprocess.check_output([exe, "ddict", str(level), fd, fr, fo, "3", str(nc)], timeout=120))
+                        dcpu = {"value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference",
+                                "sample": f"the first {ns} distinct record frames, ZSTD_createDDict + ZSTD_decompress_usingDDict per record (oracle/_ref/zref_bench ddict)",
+                                "all_cores": {"value": allc["MBps"], "cores": nc}}
+                    except Exception:
+                        dcpu = None
+                out["decode"] = {"metric": "decompress_MBps_records_with_dictionary", "value": round(n / best / 1e3, 1), "unit": "MB/s", "k_decode_ms": round(best, 3),
+                                 "roofline": {"bound": "hbm", "kernel": "k_decode", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
+                                 "parity": {"decoded_equals_source_full_size": okd}}
+                if dcpu:
+                    out["decode"]["cpu_baseline"] = dcpu
+        finally:
+            for t in (fd, fr, fo, fout):
+                if os.path.exists(t):
+                    os.unlink(t)
+    ctx.close()
+    del src, dst, fsz
+    return out
+
+
+def traffic_lookup(leg, kernel):
+    """HBM bytes per launch of `kernel` in bench leg `leg` from the committed PMC summary (profiles/latest_traffic.json) — measured
+    by rocprofv3 --pmc passes of that very configuration, not in this run; (None, None) when the file has no entry"""
+    tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    try:
+        tj = json.load(open(tpath))
+        e = tj.get("legs", {}).get(leg, {})
+        v = e.get(kernel + "_hbm_bytes_per_launch")
+        if v is None:
+            return None, None
+        return v, "profiles/latest_traffic.json <- " + str(e.get("source", tj.get("source", "")))
+    except Exception:
+        return None, None
+
+
+def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
+    nrec = args.records if args.records else max(args.base_records, ((args.mib << 20) // 1201))
+    out = records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, nrec, args.base_records, args.steps, args.warmup,
+                      want_cpu=not args.no_cpu_baseline, want_decode=True)
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
 
 def make_workload(torch, zstd_amd, dev, workload, rank, world, mib, copies, total_bytes):
-    """-> (host array for the CPU legs, device source tensor, n, description, scaling)"""
+    """-> (host array for the CPU legs, device source tensor, n, description, scaling, tile = (base corpus, shift) when the host array is only the base)"""
     scaling = "weak"
     if workload == "datagen":
         n = mib << 20
         host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)        # `datagen -g<n> -P50 -s<rank>`
         src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
         src[:n].copy_(torch.from_numpy(host))
-        return host, src, n, f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)", scaling
+        return host, src, n, f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)", scaling, None
     from zstd_amd import workloads as W
     if workload == "silesia":                                               # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in
         base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
@@ -348,14 +419,14 @@ def make_workload(torch, zstd_amd, dev, workload, rank, world, mib, copies, tota
         c += 1
     del bdev
     host = src[:n].cpu().numpy() if n <= (3 << 30) else base[: min(len(base), n)]     # the CPU legs see exactly what the device compresses
-    return host, src, n, wdesc, scaling
+    return host, src, n, wdesc, scaling, ((base, 9973) if n > (3 << 30) else None)
 
 
 def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload, level, steps, warmup, copies, total_bytes,
-                 want_decode, want_pipelined, want_cpu, cpu_seconds=8.0):
+                 want_decode, want_pipelined, want_cpu, cpu_seconds=8.0, leg=None):
     """one workload through the device pipeline: K timed steps bracketed by barrier + synchronize, max over ranks; rank 0 returns the
     JSON object (contract fields + roofline + pipeline + parity + cpu_baseline [+ decode, pipelined]), other ranks None"""
-    host, src, n, wdesc, scaling = make_workload(torch, zstd_amd, dev, workload, rank, world, args.mib, copies, total_bytes)
+    host, src, n, wdesc, scaling, tile = make_workload(torch, zstd_amd, dev, workload, rank, world, args.mib, copies, total_bytes)
     units = (n + UNIT - 1) // UNIT
     cap = zstd_amd.compress_bound(n, UNIT)
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
@@ -385,10 +456,10 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ct = torch.tensor([float(total)], dtype=torch.float64, device=dev)
+        ct = torch.tensor([float(total)], dtype=torch.float64)
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         total_all = float(ct.item())
     else:
@@ -400,7 +471,7 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
         dsteps = steps if args.mode == "decode" else max(2, min(steps, 4))
         ddt, dkms, dok = decode_measure(torch, zstd_amd, local, src, n, dst, sizes_all, dsteps, warmup if args.mode == "decode" else 1, barrier)
         if dist is not None:
-            tt = torch.tensor([ddt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([ddt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ddt = float(tt.item())
     out = None
@@ -424,6 +495,8 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
                 tsrc = "profiles/latest_traffic.json <- " + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (not measured in this run)"))
             except Exception:
                 traffic, tsrc = None, None
+        elif leg is not None:
+            traffic, tsrc = traffic_lookup(leg, {1: "k_parse_fast", 2: "k_parse_dfast"}.get(zstd_amd.get_cparams(level, UNIT)[6], "k_parse_lazy"))
         sname = {1: "ZSTD_fast", 2: "ZSTD_dfast", 3: "ZSTD_greedy (hash chain)", 4: "ZSTD_lazy (hash chain)", 5: "ZSTD_lazy2 (hash chain)"}[cp[6]]
         cpdesc = f"{sname} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} slog{cp[3]} mml{cp[4]}"
         kname = {1: "k_parse_fast", 2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
@@ -445,7 +518,7 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
         }
         if cp[6] >= 3:      # the match-finder stage is three kernels; the roofline figures above are for their sum
             out["roofline"]["kernels_ms"] = {k: round(v / K, 3) for k, v in hc.items()}
-        out["parity"] = parity_check(host, n, dst, total, sizes, level)
+        out["parity"] = parity_check(host, n, dst, total, sizes, level, tile) if not args.no_parity else {"skipped": "--no-parity (profiling run)"}
         if want_pipelined and os.environ.get("ZHIP_PIPELINE_CHUNKS") is None and units <= 16384:
             # optional stream pipelining of the same workload (a second context: the knob is read at creation)
             os.environ["ZHIP_PIPELINE_CHUNKS"] = "4"
@@ -651,12 +724,14 @@ def main():
     ap.add_argument("--workload", choices=["datagen", "silesia", "text", "records"], default="datagen",
                     help="datagen = BASELINE configs[1] (default); silesia / text / records = synthetic stand-ins for configs[2] / [3] / [4]")
     ap.add_argument("--raw-dict", action="store_true", help="records: use the first ~110 KB of records as a raw-content dictionary instead of the trained fixture")
-    ap.add_argument("--base-records", type=int, default=50000, help="records: distinct ~1.2 KB records generated on the host before tiling to --mib")
+    ap.add_argument("--base-records", type=int, default=1000000, help="records: DISTINCT ~1.2 KB records generated before tiling (1 M = 1.2 GB, beyond the 256 MB Infinity Cache)")
+    ap.add_argument("--records", type=int, default=0, help="records: total records per GPU (default: --mib worth; BASELINE configs[4] names 10 M)")
     ap.add_argument("--copies", type=int, default=1, help="silesia: number of copies of the 212 MB corpus (configs[2] uses 64)")
     ap.add_argument("--total-bytes", type=int, default=0, help="text: fixed total cut into one shard per GPU (configs[3]: 1000000000)")
     ap.add_argument("--mode", choices=["compress", "decode"], default="compress",
                     help="decode: the headline value is the DECODER's throughput on the frames the compressor just made (same workload, same units)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the parity legs (the printed line then says so and is not a measurement to quote)")
     ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
     ap.add_argument("--no-extra-legs", action="store_true", help="default line only: skip the Silesia-shaped level-1 leg and the end-to-end (PCIe-inclusive) figure")
     args = ap.parse_args()
@@ -683,7 +758,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # control plane only (barriers, the max-over-ranks time): gloo over 127.0.0.1 — the data path has no collective and needs no RCCL
+        dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: zstd_amd has no CPU path")
     torch.cuda.set_device(local)
@@ -706,11 +782,26 @@ def main():
             out["job_pool_frame"] = jp
     del src, host
     if default_line:
+        keys = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")
         torch.cuda.empty_cache()
-        sil, _ = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
-                              want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=6.0)
+        sil, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
+                                 want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=6.0, leg="silesia4_level1")
+        del keep
         if rank == 0:
-            out["silesia_shaped_level1"] = {k: sil[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline") if k in sil}
+            out["silesia_shaped_level1"] = {k: sil[k] for k in keys if k in sil}
+        # BASELINE configs[2] at its stated size: the Silesia-shaped mix x64 (about 13 GiB), level 3 (ZSTD_dfast), full-size digest against the reference
+        torch.cuda.empty_cache()
+        sil3, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 3, 3, 1, 64, 0,
+                                  want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=4.0, leg="silesia64_level3")
+        del keep
+        if rank == 0:
+            out["silesia64_level3"] = {k: sil3[k] for k in keys if k in sil3}
+        # BASELINE configs[4] at its stated size: 10 M records (1 M distinct = 1.2 GB) with the trained dictionary, level 3
+        torch.cuda.empty_cache()
+        rec = records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, 10_000_000, 1_000_000, 3, 1,
+                          want_cpu=not args.no_cpu_baseline, want_decode=False)
+        if rank == 0:
+            out["records_zdict_level3"] = {k: rec[k] for k in keys if k in rec}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

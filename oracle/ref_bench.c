@@ -19,6 +19,11 @@
  *        reused DCtx is timed; threads split the frames.
  *   zref_bench ddict  <level> <dictPath> <recordsPath> <offsetsPath> <seconds> <threads> : DECODE speed of the same record frames
  *        (ZSTD_createDDict + ZSTD_decompress_usingDDict per record)
+ *   zref_bench ctile  <level> <chunkSize> <basePath> <copies> <shift> <totalBytes> <outPath> <threads> : like cfile, but the input is
+ *        built here the way bench.py tiles a corpus on the device (copy c starts at offset c*shift mod len, wraps) — the 13 GiB of
+ *        BASELINE configs[2] never touch a file; the frames go to outPath
+ *   zref_bench cdict  <level> <dictPath> <recordsPath> <offsetsPath> <outPath> <threads> : the records compressed ONCE (one frame per record,
+ *        CDict attached), the frames written back to back to outPath (bench.py hashes that stream: full-size parity of the records leg)
  *   zref_bench stream <totalBytes> <P%> <seed>      : RDG_genStdout to stdout (what `datagen -g -P -s` emits)
  *   zref_bench dict   <level> <dictPath> <recordsPath> <offsetsPath(u64 LE, nRec+1)> <seconds> <threads>
  *        one frame per record with ZSTD_createCDict + ZSTD_CCtx_refCDict + ZSTD_compress2 (the `zstd -b# -D dict` /
@@ -294,8 +299,84 @@ static int mtfile_main(char** argv)
     return 0;
 }
 
+/* cdict: the records compressed once with T threads, frames written in record order */
+static int cdict_main(char** argv)
+{
+    int const level = atoi(argv[2]);
+    size_t dn, rn, on; int const T = atoi(argv[7]) > 0 ? atoi(argv[7]) : 1;
+    void* dict = slurp(argv[3], &dn); char* src = (char*)slurp(argv[4], &rn);
+    unsigned long long* offs = (unsigned long long*)slurp(argv[5], &on);
+    size_t const nRec = on / 8 - 1;
+    ZSTD_CDict* cd = ZSTD_createCDict(dict, dn, level);
+    size_t const cap = rn + rn / 128 + 128 * nRec + 1024;
+    char* dst = (char*)malloc(cap);
+    djob_t* jobs = (djob_t*)calloc((size_t)T, sizeof(djob_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    FILE* o; size_t csize = 0; int t; double const a = now_s();
+    if (!cd || !dst || !jobs || !th) return 1;
+    for (t = 0; t < T; t++) {
+        size_t const r0 = nRec * (size_t)t / (size_t)T, r1 = nRec * (size_t)(t + 1) / (size_t)T;
+        size_t const b0 = (size_t)offs[r0] + (size_t)offs[r0] / 128 + 128 * r0;
+        jobs[t].cd = cd; jobs[t].src = src; jobs[t].offs = offs; jobs[t].r0 = r0; jobs[t].r1 = r1;
+        jobs[t].dst = dst + b0; jobs[t].dstCap = cap - b0;
+        if (T == 1) dworker(&jobs[t]); else pthread_create(&th[t], NULL, dworker, &jobs[t]);
+    }
+    for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; }
+    o = fopen(argv[6], "wb");
+    if (!o) { perror(argv[6]); return 1; }
+    for (t = 0; t < T; t++) { if (fwrite(jobs[t].dst, 1, jobs[t].csize, o) != jobs[t].csize) return 1; csize += jobs[t].csize; }
+    fclose(o);
+    printf("{\"level\": %d, \"records\": %zu, \"bytes\": %zu, \"csize\": %zu, \"seconds\": %.3f, \"threads\": %d}\n", level, nRec, rn, csize, now_s() - a, T);
+    return 0;
+}
+
+/* ctile: cfile on a corpus tiled in memory (copy c starts at offset c*shift mod len and wraps around) */
+static int ctile_main(char** argv)
+{
+    int const level = atoi(argv[2]); size_t const chunk = strtoull(argv[3], 0, 10);
+    size_t const copies = strtoull(argv[5], 0, 10), shift = strtoull(argv[6], 0, 10), total = strtoull(argv[7], 0, 10);
+    int const T = atoi(argv[9]) > 0 ? atoi(argv[9]) : 1;
+    size_t L; char* base = (char*)slurp(argv[4], &L);
+    char* src = (char*)malloc(total + 16);
+    size_t const nChunks = (total + chunk - 1) / chunk, bound = ZSTD_compressBound(chunk);
+    char* dst = (char*)malloc(bound * (nChunks ? nChunks : 1));
+    job_t* jobs = (job_t*)calloc((size_t)T, sizeof(job_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    FILE* o; size_t csize = 0, pos = 0, c = 0; int t; double a;
+    if (!src || !dst || !jobs || !th || !L) return 1;
+    (void)copies;
+    while (pos < total) {
+        size_t const s0 = (c * shift) % L;
+        size_t take = L - s0 < total - pos ? L - s0 : total - pos;
+        memcpy(src + pos, base + s0, take); pos += take;
+        take = s0 < total - pos ? s0 : total - pos;
+        memcpy(src + pos, base, take); pos += take;
+        c++;
+    }
+    a = now_s();
+    for (t = 0; t < T; t++) {
+        size_t const k0 = nChunks * (size_t)t / (size_t)T, k1 = nChunks * (size_t)(t + 1) / (size_t)T;
+        size_t const b0 = k0 * chunk, b1 = (k1 * chunk < total) ? k1 * chunk : total;
+        jobs[t].level = level; jobs[t].chunk = chunk; jobs[t].src = src + b0; jobs[t].n = b1 - b0;
+        jobs[t].dst = dst + k0 * bound; jobs[t].dstCap = (k1 - k0) * bound;
+        if (T == 1) worker(&jobs[t]); else pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    for (t = 0; t < T; t++) { if (T > 1) pthread_join(th[t], NULL); if (jobs[t].err) return 1; }
+    {   double const secs = now_s() - a;
+        o = fopen(argv[8], "wb");
+        if (!o) { perror(argv[8]); return 1; }
+        for (t = 0; t < T; t++) { if (fwrite(jobs[t].dst, 1, jobs[t].csize, o) != jobs[t].csize) return 1; csize += jobs[t].csize; }
+        fclose(o);
+        printf("{\"level\": %d, \"chunk\": %zu, \"bytes\": %zu, \"csize\": %zu, \"seconds\": %.3f, \"MBps\": %.2f, \"threads\": %d}\n",
+               level, chunk, total, csize, secs, (double)total / secs / 1e6, T);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 10 && !strcmp(argv[1], "ctile")) return ctile_main(argv);
+    if (argc >= 8 && !strcmp(argv[1], "cdict")) return cdict_main(argv);
     if (argc >= 7 && !strcmp(argv[1], "mtfile")) return mtfile_main(argv);
     if (argc >= 7 && !strcmp(argv[1], "cfile")) return cfile_main(argv);
     if (argc >= 8 && !strcmp(argv[1], "dict")) return dict_main(argv);
