@@ -114,6 +114,7 @@ typedef struct zhip_multi_s zhip_multi;
 zhip_multi*  zhip_multi_create(const int* devices, int nDevices, size_t chunkUnits);
 void         zhip_multi_destroy(zhip_multi* m);
 int          zhip_multi_set_frame_checksum(zhip_multi* m, int enable);
+int          zhip_multi_set_row_matcher(zhip_multi* m, int mode);      /* zhip_set_row_matcher on every lane and on the wide context (modes as there) */
 size_t       zhip_compress_multi(zhip_multi* m, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                  int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes);
 /* ONE input as the job-pool frame of zhip_compress_frames_mt (ZSTD_c_nbWorkers >= 1 semantics), its jobs spread over the lanes and
@@ -146,9 +147,11 @@ size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* 
  * descriptor bit, exactly as lib/compress/zstd_compress.c:4637 / :5297-5303 write them.  Sticky until changed.  Returns 0. */
 int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
 /* = ZSTD_c_useRowMatchFinder (lib/zstd.h, experimental): which match finder the strategies greedy / lazy / lazy2 use.
- * 0 (default, ZSTD_ps_auto) and 1 (ZSTD_ps_enable): the reference's default — the row-hash matcher when windowLog > 14
- * (lib/compress/zstd_compress.c:237-253), with the hash salt of a FRESH CCtx (bytes = ZSTD_compress2 on a fresh CCtx per unit;
- * a reused reference CCtx mixes the previous frames' hashes into its salt, :1964-1975); 2 (ZSTD_ps_disable): the hash-chain matcher.
+ * 0 (default, ZSTD_ps_auto): the reference's default — the row-hash matcher when windowLog > 14 (lib/compress/zstd_compress.c:237-253),
+ * with the hash salt of a FRESH CCtx (bytes = ZSTD_compress2 on a fresh CCtx per unit; a reused reference CCtx mixes the previous
+ * frames' hashes into its salt, :1964-1975); 1 (ZSTD_ps_enable): the same, except that a unit the reference gives windowLog <= 14 is
+ * REFUSED (parameter_unsupported) — the reference would run its row matcher there too (:244), the device has none for such windows;
+ * 2 (ZSTD_ps_disable): the hash-chain matcher; -1: back to the mode the context was created with.
  * The environment variable ZHIP_ROW_MATCHER=disable sets 2 as a context's initial mode.  Returns 0, or 1 for another value. */
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 

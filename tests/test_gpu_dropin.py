@@ -233,3 +233,42 @@ def test_compressStream2_one_shot_equals_compress2(env):
     o = OutB(dst.ctypes.data, 100, 0)
     assert S.ZSTD_isError(S.ZSTD_compressStream2(zcs, C.byref(o), C.byref(i), 2))          # too little room for the one-shot form
     S.ZSTD_freeCStream(zcs)
+
+
+def test_row_matcher_parameter_is_not_sticky(env, monkeypatch):
+    """ZSTD_c_useRowMatchFinder = disable, compress, ZSTD_CCtx_reset(parameters), compress again — the second frame must be
+    the reference's DEFAULT (row-hash matcher) frame again, the first its hash-chain frame; level 5, one 128 KB unit each."""
+    S, lo, lr = env
+    if lr is None:
+        pytest.skip("needs oracle/_ref")
+    monkeypatch.delenv("ZHIP_ROW_MATCHER", raising=False)          # (conftest pins the hash chain for the older tests; the device context reads it at creation)
+    lr.zref_compress_chunks_norow.restype = C.c_size_t
+    lr.zref_compress_chunks_norow.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    a = datagen(lo, 131072, 50, 21)
+    cap = S.ZSTD_compressBound(len(a))
+    want_def = expect_unit(lo, lr, a, 5)
+    d2 = np.zeros(cap + 64, dtype=np.uint8)
+    r2 = lr.zref_compress_chunks_norow(5, 131072, _buf(a), len(a), _buf(d2), len(d2), None, 0)
+    assert r2 != ERR
+    want_hc = d2[:r2].tobytes()
+    assert want_def != want_hc                          # the two matchers really differ on this input
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_CCtx_setParameter(c, 100, 5) == 0
+    assert S.ZSTD_CCtx_setParameter(c, 1011, 2) == 0   # ZSTD_c_useRowMatchFinder = ZSTD_ps_disable
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), len(a))
+    assert not S.ZSTD_isError(r) and dst[:r].tobytes() == want_hc
+    assert S.ZSTD_CCtx_reset(c, 2) == 0                 # ZSTD_reset_parameters
+    assert S.ZSTD_CCtx_setParameter(c, 100, 5) == 0
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), len(a))
+    assert not S.ZSTD_isError(r) and dst[:r].tobytes() == want_def
+    assert S.ZSTD_CCtx_setParameter(c, 1011, 2) == 0
+    assert S.ZSTD_CCtx_setParameter(c, 1011, 0) == 0   # explicit ZSTD_ps_auto after disable
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), len(a))
+    assert not S.ZSTD_isError(r) and dst[:r].tobytes() == want_def
+    # ZSTD_ps_enable on a source the reference gives windowLog <= 14: refused, not compressed differently
+    small = a[:9000].copy()
+    assert S.ZSTD_CCtx_setParameter(c, 1011, 1) == 0
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(small), len(small))
+    assert S.ZSTD_isError(r)
+    S.ZSTD_freeCCtx(c)

@@ -59,7 +59,9 @@ struct zhip_ctx_s {
     // last call
     size_t nUnits; double timing[4]; unsigned long long stats[5];
     // sequence-producer cache
-    int rowMode;                         // greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14), 2 = hash chain (ZSTD_ps_disable)
+    int rowMode;                         // greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14), 1 = ZSTD_ps_enable (the same, and units
+                                         // with windowLog <= 14 are refused: the device has no row matcher for them), 2 = hash chain (ZSTD_ps_disable)
+    int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -141,7 +143,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
-    {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
+    {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -198,8 +200,11 @@ zhip_ctx* zhip_create_for_records(int device, size_t maxRecords, size_t maxTotal
 int zhip_set_row_matcher(zhip_ctx* c, int mode)
 {
     std::lock_guard<std::mutex> lk(c->mu);
-    if (mode != 0 && mode != 1 && mode != 2) return 1;
-    c->rowMode = mode == 2 ? 2 : 0;      // enable (1) = auto here: the device has no row matcher for windowLog <= 14 either way the reference resolves it
+    if (mode < -1 || mode > 2) return 1;
+    // -1: back to the context's own default ($ZHIP_ROW_MATCHER at creation); 0 = ZSTD_ps_auto: the reference's default; 1 = ZSTD_ps_enable: the reference then uses the row matcher whatever the window
+    // (ZSTD_resolveRowMatchFinderMode returns an explicit mode unchanged, zstd_compress.c:244) — units it would give windowLog <= 14 are
+    // refused when they are planned rather than compressed differently; 2 = ZSTD_ps_disable
+    c->rowMode = mode < 0 ? c->rowDefault : mode;
     return 0;
 }
 
@@ -289,6 +294,10 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.rowLog = 0; u.pad1 = 0;
         if (cp->strategy >= ZHIP_STRAT_GREEDY && cp->strategy <= ZHIP_STRAT_LAZY2 && c->rowMode != 2 && cp->windowLog > 14)
             u.rowLog = cp->searchLog < 4 ? 4 : (cp->searchLog > 6 ? 6 : cp->searchLog);       // :2042 BOUNDED(4, searchLog, 6)
+        else if (cp->strategy >= ZHIP_STRAT_GREEDY && cp->strategy <= ZHIP_STRAT_LAZY2 && c->rowMode == 1) {
+            snprintf(c->err, sizeof(c->err), "ZSTD_ps_enable with windowLog %u <= 14: the row matcher for such windows is not implemented on device", cp->windowLog);
+            *err = ZERR(ZE_parameter_unsupported); return 0;
+        }
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
@@ -596,6 +605,8 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         }
         size_t const nSec = n ? (n + section - 1) / section : 1;
         if (nU + nSec > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu jobs > context capacity %zu", nU + nSec, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
+        if ((nU + nSec) * (size_t)ZHIP_SEQ_CAP > c->seqArena || (nU + nSec) * (size_t)ZHIP_LIT_STRIDE > c->litArena) {      // a context made for small records has smaller arenas
+            snprintf(c->err, sizeof(c->err), "%zu jobs need full-size slots: this context's arenas are smaller (created for records?)", nU + nSec); return ZERR(ZE_srcSize_wrong); }
         size_t prevLen = 0;
         for (size_t k = 0; k < nSec; k++, nU++) {
             size_t const start = k * section, len = n - start < section ? n - start : section;
@@ -788,6 +799,7 @@ static size_t frame_jobs_chunk_device(zhip_ctx* c, void* dstDev, size_t dstCapac
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (nJobs == 0 || nJobs > c->maxUnits) return ZERR(ZE_srcSize_wrong);
+    if (nJobs * (size_t)ZHIP_SEQ_CAP > c->seqArena || nJobs * (size_t)ZHIP_LIT_STRIDE > c->litArena) return ZERR(ZE_srcSize_wrong);   // a records context: arenas too small for full-size slots
     size_t outBytes = 0, tabWords = 0, bound = 0; uint32_t ldsTab = 0; unsigned long long total = 0;
     c->hJobs.assign(jobs, jobs + nJobs); c->hFrameUnits.resize(1);
     for (size_t i = 0; i < nJobs; i++) {

@@ -26,6 +26,7 @@ struct zhip_multi_s {
     std::vector<zhip_multi_lane> lanes;
     size_t chunkUnits = 0;
     int checksum = 0;
+    int rowMode = -1;                                   // zhip_set_row_matcher mode as last set (-1 = every context's own default)
     std::mutex mu;                                     // one call at a time
     char err[256] = {0};
     double lastSeconds = 0;
@@ -73,6 +74,16 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
 
 void zhip_multi_destroy(zhip_multi* m) { if (m) multi_free(m); }
 int zhip_multi_set_frame_checksum(zhip_multi* m, int enable) { std::lock_guard<std::mutex> lk(m->mu); m->checksum = enable ? 1 : 0; return 0; }
+// ZSTD_c_useRowMatchFinder for every lane context (and the wide one, when it exists or is made later)
+int zhip_multi_set_row_matcher(zhip_multi* m, int mode)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (mode < -1 || mode > 2) return 1;
+    m->rowMode = mode;
+    for (auto& L : m->lanes) if (L.ctx) zhip_set_row_matcher(L.ctx, mode);
+    if (m->wide) zhip_set_row_matcher(m->wide, mode);
+    return 0;
+}
 const char* zhip_multi_last_error(const zhip_multi* m) { return m->err; }
 double zhip_multi_last_seconds(const zhip_multi* m) { return m->lastSeconds; }
 
@@ -182,6 +193,7 @@ size_t zhip_compress_frame_mt_multi(zhip_multi* m, void* dstv, size_t dstCapacit
             if (!m->wide) { m->wideUnits = 0; return ZERR(ZE_memory_allocation); }
         }
         zhip_set_frame_checksum(m->wide, m->checksum);
+        zhip_set_row_matcher(m->wide, m->rowMode);
         size_t const r = zhip_compress_frames_mt(m->wide, dstv, dstCapacity, srcv, offs, 1, level, cparams, jobSize, overlapLog, nullptr);
         if (zhip_isError(r)) snprintf(m->err, sizeof(m->err), "%s", zhip_last_error(m->wide));
         m->lastSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -89,7 +89,7 @@ static size_t shim_ensure(ZSTD_CCtx* c, size_t units)
         c->zUnits = want;
     }
     zhip_set_frame_checksum(c->z, c->checksum);
-    if (c->rowMode) zhip_set_row_matcher(c->z, c->rowMode);     /* 0 = keep the context's own default ($ZHIP_ROW_MATCHER) */
+    zhip_set_row_matcher(c->z, c->rowMode ? c->rowMode : -1);     /* always pushed: ZSTD_ps_auto (also after a parameter reset) = the device context's own default ($ZHIP_ROW_MATCHER, else the reference's) */
     return 0;
 }
 
@@ -127,10 +127,12 @@ static zhip_multi* shim_multi(ZSTD_CCtx* c)
 static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src, size_t n, int level)
 {
     size_t const units = n ? (n + SHIM_UNIT - 1) / SHIM_UNIT : 1;
+    size_t frameNeed = 0;
     if (!c) return SHIM_ERR(E_GENERIC);
     if (level == 0) level = 3;
     if (units > 1 && shim_multi(c)) {            /* big sources: sharded over $ZHIP_DEVICES with overlapped copies; gathers straight into dst */
         zhip_multi_set_frame_checksum(c->zm, c->checksum);
+        zhip_multi_set_row_matcher(c->zm, c->rowMode ? c->rowMode : -1);
         if (c->workers > 0 && n > (512u << 10)) {    /* ZSTD_c_nbWorkers: one frame, its jobs spread over the lanes */
             size_t const r = zhip_compress_frame_mt_multi(c->zm, dst, cap, src, n, level, c->cp, (size_t)c->jobSize, c->overlapLog);
             if (!zhip_isError(r) || r != SHIM_ERR(E_parameter_unsupported)) return r;
@@ -138,14 +140,17 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
         return zhip_compress_multi(c->zm, dst, cap, src, n, level, c->cp, SHIM_UNIT, NULL);
     }
     {   size_t const e = shim_ensure(c, units); if (zhip_isError(e)) return e; }
-    if (c->workers > 0 && n > (512u << 10) && cap >= zhip_compressBound(n, SHIM_UNIT)) {
+    {   unsigned long long const fo[2] = { 0, n };
+        frameNeed = zhip_frames_bound(fo, 1);           /* = ZSTD_COMPRESSBOUND(n): what a caller sizing dst with the reference's macro provides */
+    }
+    if (c->workers > 0 && n > (512u << 10) && cap >= frameNeed) {
         /* ZSTD_c_nbWorkers >= 1: the frame of the reference's job pool, a workgroup per job.  At or below 512 KB the reference drops
            the workers (zstd_compress.c:6215) and so does this; unsupported strategies fall through like below */
         unsigned long long const offs[2] = { 0, n };
         size_t const r = zhip_compress_frames_mt(c->z, dst, cap, src, offs, 1, level, c->cp, (size_t)c->jobSize, c->overlapLog, NULL);
         if (!zhip_isError(r) || r != SHIM_ERR(E_parameter_unsupported)) return r;
     }
-    if (units > 1 && c->singleFrame && cap >= zhip_compressBound(n, SHIM_UNIT)) {
+    if (units > 1 && c->singleFrame && cap >= frameNeed) {
         /* the reference's own output shape: one frame, many blocks.  Strategies the frame kernel does not run
            (parameter_unsupported) fall through to the frame-per-128-KB stream below */
         unsigned long long const offs[2] = { 0, n };

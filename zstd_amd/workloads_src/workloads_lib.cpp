@@ -35,7 +35,8 @@ extern "C" size_t zhip_wl_github_records(char* flat, size_t cap, unsigned long l
         if ((size_t)(p - flat) + 2048 > cap) return 0;
         offs[k] = (unsigned long long)(p - flat);
         char login[64]; { char* q = login; uint32_t const ns = 2 + r.below(3); for (uint32_t i = 0; i < ns; i++) q = put(q, kSyll[r.below(36)]);
-                          if (r.unit() < 0.4) q = putu(q, r.below(999)); *q = 0; }
+                          if (r.unit() < 0.4) { q = putu(q, r.below(999)); }
+                          *q = 0; }
         unsigned long long const uid = 1 + r.next() % 89999999ULL;
         char name[96]; bool const hasName = r.unit() >= 0.3;
         if (hasName) { char* q = name; q = put(q, login); name[0] = (char)(name[0] >= 'a' && name[0] <= 'z' ? name[0] - 32 : name[0]); *q++ = ' ';
