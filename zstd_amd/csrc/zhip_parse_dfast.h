@@ -49,6 +49,58 @@ __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned
     return grp;
 }
 
+
+// ONE round of loads for everything a dfast match needs (round 3; before: up to three dependent wave_count_* calls): lanes 0..31 compare
+// 8 bytes each FORWARD from the main candidate (256 B), lanes 32..47 forward from the long candidate of the next position (128 B,
+// zstd_double_fast.c:251-264), lanes 48..55 BACKWARD from the main pair, lanes 56..63 backward from the other pair (64 B each; which
+// pair wins is only known once both forward lengths are).  A run that fills its lanes goes on with the loops of zhip_parse.h.
+struct DfExt { uint32_t fwdM, fwdL, backM, backL; };
+__device__ __forceinline__ DfExt df_extend(const uint8_t* src, uint32_t nm8, uint32_t posM, uint32_t candM, bool useL, uint32_t posL, uint32_t candL,
+                                            bool useBack, uint32_t bposM, uint32_t bcandM, uint32_t limM, uint32_t bposL, uint32_t bcandL, uint32_t limL)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    bool const isF = lane < 48, isFL = lane >= 32 && lane < 48, isBL = lane >= 56;
+    uint32_t same;
+    if (isF) {
+        uint32_t const k = isFL ? lane - 32 : lane;
+        uint32_t const q = (isFL ? posL : posM) + 8u * k, off = isFL ? posL - candL : posM - candM;
+        same = (isFL && !useL) ? 0u : lane_same_fwd(src, q, off, nm8);
+    } else {
+        uint32_t const j8 = 8u * (isBL ? lane - 56 : lane - 48);
+        uint32_t const mp = isBL ? bposL : bposM, cd = isBL ? bcandL : bcandM, lim = isBL ? limL : limM;
+        bool const on = useBack && (!isBL || useL) && lim > j8;
+        uint32_t const rr = lim - j8, r = on ? (rr < 8 ? rr : 8) : 0;        // bytes of this lane's chunk: the r bytes that end at mp - j8
+        uint32_t const qb = r ? mp - j8 - r : mp;
+        uint64_t const x = r ? (ld64(src + qb) ^ ld64(src + (qb - (mp - cd)))) : 0;
+        uint64_t const y = x << (8 * ((8 - r) & 7));                          // byte r-1 (closest to mp) -> top byte
+        uint32_t const sm = y ? (uint32_t)__clzll((long long)y) >> 3 : r;
+        same = r ? sm : 0;
+    }
+    unsigned long long const stop = __ballot(same < 8);
+    DfExt e;
+    {   unsigned long long const m = stop & 0xFFFFFFFFull;
+        if (m) { int const f = first_lane(m); e.fwdM = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+        else e.fwdM = 256 + wave_count_fwd(src, posM + 256, candM + 256, nm8); }
+    e.fwdL = 0;
+    if (useL) {
+        unsigned long long const m = (stop >> 32) & 0xFFFFull;
+        if (m) { int const f = first_lane(m); e.fwdL = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f + 32); }
+        else e.fwdL = 128 + wave_count_fwd(src, posL + 128, candL + 128, nm8);
+    }
+    e.backM = e.backL = 0;
+    if (useBack) {
+        {   unsigned long long const m = (stop >> 48) & 0xFFull;
+            if (m) { int const f = first_lane(m); e.backM = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f + 48); }
+            else e.backM = 64 + wave_count_back(src, bposM - 64, bcandM - 64, limM - 64); }
+        if (useL) {
+            unsigned long long const m = stop >> 56;
+            if (m) { int const f = first_lane(m); e.backL = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f + 56); }
+            else e.backL = 64 + wave_count_back(src, bposL - 64, bcandL - 64, limL - 64);
+        }
+    }
+    return e;
+}
+
 // One block of ZSTD_dfast over src[b0, n) with the two tables as the previous blocks of the same frame left them (a unit: b0 = 0,
 // fresh tables).  WIDE: entries are plain 32-bit positions (a frame's positions exceed 17 bits) — no tag, every nonzero candidate
 // is fetched; else `position | tag << 17`.  Candidates must lie at or above prefixLow; the reference is asymmetric about the bound
@@ -84,6 +136,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     // mean distance (x16 fixed point) + 4 (best of the sweep in scripts/df_sweep.sh), doubled after a batch without an event.  Any width is exact.
     uint32_t const kMul = u.pad0 ? (uint32_t)(u.pad0 >> 4) : 8u, kAdd = u.pad0 ? (uint32_t)(u.pad0 & 15) : 4u;   // width = mean * kMul/8 + kAdd (measurement knob, any value is exact)
     uint32_t evAvg16 = 12u << 4, kCap = 32;
+    bool have = false; uint64_t nbytes = 0; uint32_t nrv = 0;                // the source bytes of the next batch, when the round behind a match fetched them
     for (;;) {                                                               // one turn per match (:167)
         uint32_t step = 1, nextStep = ip + 256;
         if ((int32_t)(ip + 1) > ilimit) break;                               // :172
@@ -103,8 +156,9 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
             bool const live = (int)lane <= K;
 
             uint32_t const pc = p < nm8 ? p : nm8;
-            uint64_t const bytes = ld64(src + pc);
-            uint32_t const rv = ld32(src + (pc + 1 - off1));                 // off1 <= pc always; off1 == 0 is masked below
+            uint64_t bytes; uint32_t rv;
+            if (have) { bytes = nbytes; rv = nrv; have = false; }            // loaded with the round behind the previous match (step is 1 there)
+            else { bytes = ld64(src + pc); rv = ld32(src + (pc + 1 - off1)); }   // off1 <= pc always; off1 == 0 is masked below
             uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
             uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
             uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short((uint32_t)bytes);
@@ -177,24 +231,25 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         uint32_t mstart = curr;
         if (evKind == 1) {                                                   // :190-195
             mstart = curr + 1;
-            mLength = 4 + wave_count_fwd(src, mstart + 4, mstart + 4 - off1, nm8);
+            DfExt const e = df_extend(src, nm8, mstart + 4, mstart + 4 - off1, false, 0, 0, false, 0, 0, 0, 0, 0, 0);
+            mLength = 4 + e.fwdM;
             offBase = 1;
         } else {
             uint32_t match = candE;
-            if (evKind == 2) {                                               // :203-209
-                mLength = 8 + wave_count_fwd(src, curr + 8, match + 8, nm8);
-            } else {                                                         // :248-264 _search_next_long
-                mLength = 4 + wave_count_fwd(src, curr + 4, match + 4, nm8);
-                if (long1) {
-                    uint32_t const l1len = 8 + wave_count_fwd(src, ip1 + 8, cand1 + 8, nm8);
-                    if (l1len > mLength) { mstart = ip1; mLength = l1len; match = cand1; }
-                }
+            uint32_t const k0 = evKind == 2 ? 8u : 4u;                       // :203-209 / :248-264 _search_next_long
+            bool const useL = evKind == 3 && long1;
+            // catch-up limits (:207, :267) of both pairs: literals available and distance of the candidate to the window's low end
+            uint32_t const limM = (curr - anchor) < candE - prefixLow ? (curr - anchor) : candE - prefixLow;
+            uint32_t const limL = useL ? ((ip1 - anchor) < cand1 - prefixLow ? (ip1 - anchor) : cand1 - prefixLow) : 0;
+            DfExt const e = df_extend(src, nm8, curr + k0, match + k0, useL, ip1 + 8, cand1 + 8, true, curr, candE, limM, ip1, cand1, limL);
+            mLength = k0 + e.fwdM;
+            uint32_t back = e.backM;
+            if (useL) {
+                uint32_t const l1len = 8 + e.fwdL;
+                if (l1len > mLength) { mstart = ip1; mLength = l1len; match = cand1; back = e.backL; }
             }
             uint32_t const offset = mstart - match;
-            {   uint32_t const lim = (mstart - anchor) < match - prefixLow ? (mstart - anchor) : match - prefixLow;      // :207, :267 catch up
-                uint32_t const back = wave_count_back(src, mstart, match, lim);
-                mstart -= back; mLength += back;
-            }
+            mstart -= back; mLength += back;
             off2 = off1; off1 = offset;
             offBase = offset + 3;
         }
@@ -202,32 +257,50 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         store_seq(out, mstart - anchor, offBase, mLength);
         ip = mstart + mLength; anchor = ip;
 
+        have = false;
         if ((int32_t)ip <= ilimit) {                                         // :300-320
-            {   // complementary inserts: long[curr+2], long[ip-2], short[curr+2], short[ip-1] — in this order
+            // ONE round of loads per pass (round 3; before: one for the inserts, one per repcode test, one for the next batch): lanes 0..2
+            // fetch the bytes of the complementary inserts (first pass only), every lane compares 8 bytes at ip + 8*lane with the bytes
+            // off2 back (the immediate repcode and its length), and the source bytes of the batch that starts at ip ride along
+            bool first = true;
+            for (;;) {
                 uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
-                uint64_t const b = ld64(src + (q < nm8 ? q : nm8));
-                uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
-                uint32_t const hL = vv >> shL, hS = hash_pos<MLS>(b, shS);
-                uint32_t const qL = DF_ENTRY(q, df_tag_long(vv)), qS = DF_ENTRY(q, df_tag_short((uint32_t)b));
-                if (lane == 0) { tabL[hL] = qL; tabS[hS] = qS; }
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 1) tabL[hL] = qL;
-                if (lane == 2) tabS[hS] = qS;
-                __builtin_amdgcn_wave_barrier();
-            }
-            while ((int32_t)ip <= ilimit && off2 > 0) {
-                uint64_t const b = ld64(src + ip);
-                if ((uint32_t)b != ld32(src + ip - off2)) break;
-                uint32_t const rLength = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
+                uint64_t b = 0;
+                if (first && lane < 3) b = ld64(src + (q < nm8 ? q : nm8));
+                uint32_t const fq = ip + 8u * lane;
+                uint32_t const same = off2 > 0 ? lane_same_fwd(src, fq, off2, nm8) : 0u;
+                uint64_t const ipb = ld64(src + ip);                         // (the bytes at ip: hashed when the repcode is taken)
+                uint32_t const pn = ip + lane, pnc = pn < nm8 ? pn : nm8;
+                nbytes = ld64(src + pnc); nrv = ld32(src + (pnc + 1 - off1));
+                if (first) {
+                    // complementary inserts: long[curr+2], long[ip-2], short[curr+2], short[ip-1] — in this order
+                    uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
+                    uint32_t const hL = vv >> shL, hS = hash_pos<MLS>(b, shS);
+                    uint32_t const qL = DF_ENTRY(q, df_tag_long(vv)), qS = DF_ENTRY(q, df_tag_short((uint32_t)b));
+                    if (lane == 0) { tabL[hL] = qL; tabS[hS] = qS; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 1) tabL[hL] = qL;
+                    if (lane == 2) tabS[hS] = qS;
+                    __builtin_amdgcn_wave_barrier();
+                    first = false;
+                }
+                unsigned long long const stop = __ballot(same < 8);
+                uint32_t rl = 0;
+                if (off2 > 0) {
+                    if (stop) { int const f = first_lane(stop); rl = 8u * (uint32_t)f + __builtin_amdgcn_readlane(same, f); }
+                    else rl = 512 + wave_count_fwd(src, ip + 512, ip + 512 - off2, nm8);
+                }
+                if (rl < 4) { have = true; break; }                          // no immediate repcode: the next batch's bytes are at hand
                 {   uint32_t const t = off2; off2 = off1; off1 = t; }
                 if (lane == 0) {
-                    uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
-                    tabS[hash_pos<MLS>(b, shS)] = DF_ENTRY(ip, df_tag_short((uint32_t)b));
+                    uint32_t const vv = mulhi64_top32(ipb, 0xCF1BBCDCB7A56463ULL);
+                    tabS[hash_pos<MLS>(ipb, shS)] = DF_ENTRY(ip, df_tag_short((uint32_t)ipb));
                     tabL[vv >> shL] = DF_ENTRY(ip, df_tag_long(vv));
                 }
                 __builtin_amdgcn_wave_barrier();
-                store_seq(out, 0, 1, rLength);
-                ip += rLength; anchor = ip;
+                store_seq(out, 0, 1, rl);
+                ip += rl; anchor = ip;
+                if ((int32_t)ip > ilimit) break;
             }
         }
     }
