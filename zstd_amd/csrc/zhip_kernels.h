@@ -13,7 +13,7 @@
 
 // register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
 #ifndef ZHIP_DFAST_OCC
-#define ZHIP_DFAST_OCC
+#define ZHIP_DFAST_OCC __attribute__((amdgpu_waves_per_eu(4)))   /* with the window (131 VGPRs as compiled): 4 waves per SIMD, A/B on 2 GiB: 3 / 4 / 5 / 6 -> text 195 / 169 / 188 / 252 ms */
 #endif
 #ifndef ZHIP_LAZY_OCC
 #define ZHIP_LAZY_OCC

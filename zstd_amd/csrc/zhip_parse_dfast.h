@@ -35,6 +35,10 @@ __host__ __device__ inline size_t dfast_table_bytes(uint32_t hashLog, uint32_t c
 __device__ __forceinline__ uint32_t df_tag_long(uint32_t v /* mulhi64_top32(bytes, prime8) */) { return v & 0x7FFFu; }   // the hash's spare low bits
 __device__ __forceinline__ uint32_t df_tag_short(uint32_t first4) { return (first4 * 2654435761U) >> 17; }
 
+#define DF_POS(e)        (WIDE ? (e) : ((e) & ZHIP_DF_POS))
+#define DF_TAGOK(e, tg)  (WIDE ? true : (((e) >> 17) == (tg)))
+#define DF_ENTRY(p, tg)  (WIDE ? (p) : ((p) | ((tg) << 17)))
+
 // exact groups of live lanes with equal key, given the lanes whose scratch slot was taken by another lane
 __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned long long losers, unsigned long long liveMask)
 {
@@ -49,6 +53,211 @@ __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned
     return grp;
 }
 
+
+// ------------------------------------------------------------------ the dense-scan WINDOW of ZSTD_dfast (round 3)
+// While the gap is 1 (the reference restarts at 1 after every match and keeps it for 256 bytes, zstd_double_fast.c:168-170, :232-236)
+// every position is searched, so lane l takes position B+l: ONE gather from each table and ONE candidate fetch per 64 positions, and
+// then EVERY event among them is resolved in the reference's order (per position: repcode at p+1, long match at p, short match at p
+// with the long candidate of p+1) by mask arithmetic on E masks — per offset, which lanes equal the byte / the 4 bytes that offset back,
+// one coalesced load per new offset — exactly like the ZSTD_fast window of zhip_parse.h.  The batch scheme below pays two HBM gathers
+// and a candidate fetch per EVENT; dense-match data has five events per 64 positions.
+// Lanes that hash alike (in either table) must see each other's inserts: the window ENDS in front of the first lane that shares a
+// hash with an earlier one (W), so inside it every table entry is the one the reference would read and the inserts — collected in two
+// masks, written once at the end — cannot collide.  A window that would end within its first lanes is not worth its gathers: the
+// scan then uses the batch scheme (ZW_BATCH).  A match whose post-match inserts or immediate-repcode test fall beyond W hands them to
+// the caller's round of loads (ZW_POST).
+enum { ZW_POST = 3, ZW_BATCH = 4 };
+#define ZHIP_DFW_NEED 80u            /* a window at B needs B + 80 <= n */
+#define ZHIP_DFW_LANES 56u           /* events are taken from lanes below this */
+#define ZHIP_DFW_MIN 12u             /* a window cut shorter than this by a hash collision is left to the batch scheme */
+#ifndef ZHIP_DF_WINDOWS
+#define ZHIP_DF_WINDOWS 1
+#endif
+
+// the second lowest lane among the lanes of `key` groups with two or more members (64: no group has two)
+__device__ __forceinline__ uint32_t first_repeat_lane(uint32_t key, unsigned long long losers)
+{
+    uint32_t w = 64;
+    while (losers) {
+        int const j = first_lane(losers);
+        uint32_t const kj = __builtin_amdgcn_readlane(key, j);
+        unsigned long long const G = __ballot(key == kj);
+        unsigned long long const rest = G & (G - 1);
+        if (rest) { uint32_t const second = ff1u(rest); if (second < w) w = second; }
+        losers &= ~G;
+    }
+    return w;
+}
+
+template <uint32_t MLS, bool WIDE>
+__device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t shL, uint32_t shS,
+                                            uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS, lds_u8* scrL, lds_u8* scrS, FastOut& out,
+                                            uint32_t& ip_, uint32_t& anchor_, uint32_t& off1_, uint32_t& off2_, uint32_t& nextStep_,
+                                            uint32_t prefixLow, uint32_t& curr_, bool& postFirst_)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    uint32_t const B = ip_, P = B + lane;
+    if (out.pendLen) lits_flush(out);
+    uint64_t const bytes = ld64(src + P);
+    uint32_t const cur32 = (uint32_t)bytes;
+    uint32_t const v1 = ld32(src + (P - off1_)), v2 = ld32(src + (P - off2_));       // an invalid repcode (0) reads the lane's own bytes
+    uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
+    uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
+    uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short(cur32);
+    uint32_t const eL = tabL[hl], eS = tabS[hs];
+    uint32_t const oldL = DF_POS(eL), oldS = DF_POS(eS);
+    uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
+    scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long const loseL = __ballot(scrL[sl] != (uint8_t)lane), loseS = __ballot(scrS[ss] != (uint8_t)lane);
+    __builtin_amdgcn_wave_barrier();
+    // candidate bytes only where the entry's tag says they can match
+    uint64_t cbL = ~bytes; uint32_t cbS = ~cur32;
+    if (oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
+    if (oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+    uint32_t W = 64;
+    if (loseL) { uint32_t const w = first_repeat_lane(hl, loseL); if (w < W) W = w; }
+    if (loseS) { uint32_t const w = first_repeat_lane(hs, loseS); if (w < W) W = w; }
+    if (W < ZHIP_DFW_MIN) return ZW_BATCH;
+    // events from lanes below this: an event at lane j reads the LONG candidate of lane j+1 (:251) and inserts lane j+1 (:283), both must
+    // lie below W; every other inserted lane is checked where it arises
+    uint32_t const hiBound = W - 1 < ZHIP_DFW_LANES ? W - 1 : ZHIP_DFW_LANES;
+    bool const hitL = oldL != 0 && oldL >= prefixLow && cbL == bytes;        // :203 (index >= lowest, ZSTD_selectAddr)
+    bool const hitS = oldS != 0 && oldS >= prefixLow && cbS == cur32;        // :218
+    unsigned long long const ML = __ballot(hitL), MS = __ballot(hitS), L1 = __ballot(hitL && oldL > prefixLow);   // :260 long match at ip+1: index > lowest
+    uint32_t const x1 = off1_ ? cur32 ^ v1 : 1u, x2 = off2_ ? cur32 ^ v2 : 1u;
+    unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
+    unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
+
+    uint32_t anchor = anchor_, off1 = off1_, off2 = off2_, nextStep = nextStep_;
+    uint32_t const nbSeq0 = out.nbSeq, anchorEntry = anchor_;
+    uint32_t evA = 0, evB = 0, nEv = ~0u;
+    unsigned long long INSL = 0, INSS = 0, COV = 0;
+    uint32_t backBefore = 0, sumLit = 0, i = 0;
+    bool fresh = false;
+    int status = ZW_CONT;
+#define DW_EMIT(ll, ob, ml) do { uint32_t const mb_ = (ml) - 3;                                                   \
+        if (((ll) | mb_) > 0xFFFF) {                                                                              \
+            if ((ll) > 0xFFFF) { out.longType = 1; out.longPos = out.nbSeq; }                                     \
+            if (mb_ > 0xFFFF) { out.longType = 2; out.longPos = out.nbSeq; } }                                    \
+        uint32_t const slot_ = out.nbSeq - nbSeq0;                                                                \
+        evA = ZHIP_WRITELANE((ob), slot_, evA); evB = ZHIP_WRITELANE(((ll) & 0xFFFFu) | (mb_ << 16), slot_, evB); \
+        out.nbSeq++; } while (0)
+    for (;;) {
+        // lanes searched with gap 1: those whose position + 1 stays below nextStep (:232); the entry scan may reach it inside the window
+        uint32_t const kLane = (int32_t)(nextStep - B) > 64 ? 64u : ((int32_t)(nextStep - B) < 0 ? 0u : nextStep - B);
+        uint32_t const hiS = kLane < hiBound ? kLane : hiBound;
+        if (i >= hiS) {
+            if (kLane <= hiBound && i >= kLane && !fresh) status = ZW_INC;    // (i == kLane: the position nextStep-1 was the last at gap 1)
+            else status = ZW_CONT;                                           // the scan (its nextStep rides along) goes on in the next window
+            break;
+        }
+        unsigned long long const span = ZHIP_SBFM64(hiS - i, i);
+        unsigned long long const R = (E1q >> 1) & span;                      // bit l: the repcode test of iteration l (position l+1, :190) hits
+        unsigned long long const any = R | ((ML | MS) & span);
+        if (any == 0) {
+            INSL |= span; INSS |= span;
+            i = hiS;
+            continue;                                                        // (the exit test above decides how the scan goes on)
+        }
+        uint32_t const j = ff1u(any);
+        int const kind = ((R >> j) & 1) ? 1 : (((ML >> j) & 1) ? 2 : 3);
+        {   unsigned long long const done = ZHIP_SBFM64(j + 1 - i, i);       // :187 both tables updated for every position up to the event's
+            INSL |= done; INSS |= done; }
+        uint32_t s, e, back = 0, offBase;
+        if (kind == 1) {
+            s = j + 1;
+            uint32_t const fl = fwd_run(src, nm8, B, E1b, s + 4, off1);
+            e = s + 4 + fl; offBase = 1;
+        } else {
+            uint32_t off, cand;
+            unsigned long long Wq, Wb;                                        // the masks of the match's offset
+            INSL |= 1ull << (j + 1);                                          // :283-291 hashLong[hl1] = ip1 (gap 1 < 4)
+            if (kind == 2) {
+                cand = __builtin_amdgcn_readlane(oldL, (int)j); off = B + j - cand;
+                uint32_t x = 1;
+                if (P >= off) x = cur32 ^ ld32(src + (P - off));
+                Wq = __ballot(x == 0); Wb = __ballot((x & 0xFFu) == 0);
+                s = j;
+                e = j + 8 + fwd_run(src, nm8, B, Wb, j + 8, off);
+            } else {
+                uint32_t const candS = __builtin_amdgcn_readlane(oldS, (int)j), offS = B + j - candS;
+                bool const long1 = (L1 >> (j + 1)) & 1;
+                uint32_t const cand1 = __builtin_amdgcn_readlane(oldL, (int)(j + 1)), offL = B + j + 1 - cand1;
+                uint32_t xs = 1, xl = 1;
+                if (P >= offS) xs = cur32 ^ ld32(src + (P - offS));
+                if (long1 && P >= offL) xl = cur32 ^ ld32(src + (P - offL));
+                unsigned long long const Sq = __ballot(xs == 0), Sb = __ballot((xs & 0xFFu) == 0);
+                unsigned long long const Lq = __ballot(xl == 0), Lb = __ballot((xl & 0xFFu) == 0);
+                uint32_t const mS = 4 + fwd_run(src, nm8, B, Sb, j + 4, offS);
+                uint32_t const mL = long1 ? 8 + fwd_run(src, nm8, B, Lb, j + 9, offL) : 0;
+                if (mL > mS) { s = j + 1; e = s + mL; off = offL; cand = cand1; Wq = Lq; Wb = Lb; }     // :251-264 the long match at ip+1 wins
+                else { s = j; e = s + mS; off = offS; cand = candS; Wq = Sq; Wb = Sb; }
+            }
+            // catch up (:207, :267): equal bytes in front of the match, as far as the literals and the window's low end allow
+            uint32_t const room = B + s - anchor;
+            uint32_t const limit = room < cand - prefixLow ? room : cand - prefixLow;
+            uint32_t run = 0;
+            if (s) { unsigned long long const t = ~Wb << (64 - s); run = t ? (uint32_t)__clzll((long long)t) : s; }
+            if (run == s && limit > run) run += wave_count_back(src, B, B - off, limit - run);
+            back = run < limit ? run : limit;
+            off2 = off1; E2q = E1q; E2b = E1b; off1 = off; E1q = Wq; E1b = Wb;
+            offBase = off + 3;
+        }
+        {   uint32_t const ll = B + s - anchor - back;
+            DW_EMIT(ll, offBase, e - s + back);
+            sumLit += ll; }
+        uint32_t sL = s - back;
+        if (back > s) { backBefore = back - s; sL = 0; }
+        anchor = B + e;
+        fresh = true; nextStep = B + e + 256;
+        if (e >= W || j + 2 >= W) {                                           // the inserts behind the match leave the collision-free lanes: by loads, in the caller
+            COV |= e < 64 ? ZHIP_SBFM64(e - sL, sL) : lanes_from(sL);
+            i = e; curr_ = B + j; postFirst_ = true; status = ZW_POST;
+            break;
+        }
+        COV |= ZHIP_SBFM64(e - sL, sL);
+        INSL |= (1ull << (j + 2)) | (1ull << (e - 2));                        // :305-310 complementary insertion
+        INSS |= (1ull << (j + 2)) | (1ull << (e - 1));
+        bool leave = false;
+        while (off2 > 0 && ((E2q >> e) & 1)) {                                // :313-327 immediate repcode
+            uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, e + 4, off2);
+            {   uint32_t const t = off2; off2 = off1; off1 = t; }
+            {   unsigned long long t = E2q; E2q = E1q; E1q = t; t = E2b; E2b = E1b; E1b = t; }
+            INSL |= 1ull << e; INSS |= 1ull << e;
+            DW_EMIT(0u, 1u, rl);
+            uint32_t const en = e + rl;
+            COV |= en < 64 ? ZHIP_SBFM64(rl, e) : lanes_from(e);
+            e = en; anchor = B + e; nextStep = B + e + 256;
+            if (e >= W) { leave = true; break; }                              // the next test reads beyond the lanes at hand: by loads
+        }
+        i = e;
+        if (leave) { curr_ = 0; postFirst_ = false; status = ZW_POST; break; }
+    }
+#undef DW_EMIT
+#ifdef ZHIP_DBG_PRINT
+    if (B + lane == 4191) printf("  lane %u: P=%u oldS=%u eS=%x tgS=%x oldL=%u cbS=%x cur32=%x hs=%u\n", lane, P, oldS, eS, tgS, oldL, cbS, cur32, hs);
+    if (lane == 0) printf("  dfwin B=%u W=%u hiBound=%u -> i=%u status=%d INSL=%llx INSS=%llx ML=%llx MS=%llx COV=%llx nbSeq=%u off=%u/%u nextStep=%u\n", B, W, hiBound, i, status, INSL, INSS, ML, MS, COV, out.nbSeq, off1, off2, nextStep);
+#endif
+    // the window's table writes (no two inserted lanes share a hash: they all lie below W)
+    if (__builtin_amdgcn_inverse_ballot_w64(INSL)) tabL[hl] = DF_ENTRY(P, tgL);
+    if (__builtin_amdgcn_inverse_ballot_w64(INSS)) tabS[hs] = DF_ENTRY(P, tgS);
+    __builtin_amdgcn_wave_barrier();
+    nEv = out.nbSeq - nbSeq0;
+    if (lane < nEv) {
+        ZhipSeq q; q.offBase = evA; q.litLength = (uint16_t)evB; q.mlBase = (uint16_t)(evB >> 16);
+        out.seqs[nbSeq0 + lane] = q;
+    }
+    {   unsigned long long const LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
+        if (__builtin_amdgcn_inverse_ballot_w64(LIT)) {
+            uint32_t const before = __builtin_amdgcn_mbcnt_hi((uint32_t)(COV >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)COV, 0));
+            out.lits[out.litPos + (B - anchorEntry) + lane - before - backBefore] = (uint8_t)bytes;
+        }
+    }
+    out.litPos += sumLit;
+    ip_ = B + i; anchor_ = anchor; off1_ = off1; off2_ = off2; nextStep_ = nextStep;
+    return status;
+}
 
 // ONE round of loads for everything a dfast match needs (round 3; before: up to three dependent wave_count_* calls): lanes 0..31 compare
 // 8 bytes each FORWARD from the main candidate (256 B), lanes 32..47 forward from the long candidate of the next position (128 B,
@@ -118,9 +327,6 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
     lds_u8* const scrL = (lds_u8*)(uintptr_t)smem;
     lds_u8* const scrS = (lds_u8*)(uintptr_t)(smem + ZHIP_DF_SCRATCH);
-#define DF_POS(e)        (WIDE ? (e) : ((e) & ZHIP_DF_POS))
-#define DF_TAGOK(e, tg)  (WIDE ? true : (((e) >> 17) == (tg)))
-#define DF_ENTRY(p, tg)  (WIDE ? (p) : ((p) | ((tg) << 17)))
 
     uint32_t anchor = b0, off1 = repIn1, off2 = repIn2, saved1 = 0, saved2 = 0;
     // :158-164  a repcode that reaches below the window is set aside for the block
@@ -131,6 +337,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     uint32_t const nm8 = n - 8;
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip = b0 + (b0 == prefixLow);                                    // :157
+    if (ip != b0 && lane == 0) lits[0] = src[b0];                            // that position is never searched: windows only store their own lanes' literals
     // Batch width.  Every searched lane costs two random table gathers (HBM/L2 sectors), and everything after the first
     // event of a batch is thrown away, so the batch is only as wide as events have recently been far apart: the running
     // mean distance (x16 fixed point) + 4 (best of the sweep in scripts/df_sweep.sh), doubled after a batch without an event.  Any width is exact.
@@ -142,6 +349,18 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         if ((int32_t)(ip + 1) > ilimit) break;                               // :172
         int evKind = 0;                      // 0 none (unit finished), 1 repcode, 2 long, 3 short
         uint32_t curr = 0, candE = 0, ip1 = 0, cand1 = 0; bool long1 = false;
+        int winDone = 0;                     // 2: a window emitted a match and the round of loads behind it is still due
+        bool postFirst = true;
+        // windows while the gap is 1 and the unit has room; a scan that meets a hash collision early goes on in batches
+        while (ZHIP_DF_WINDOWS && ip + ZHIP_DFW_NEED <= n) {
+            int const st = window_dfast<MLS, WIDE>(src, nm8, shL, shS, tabL, tabS, scrL, scrS, out, ip, anchor, off1, off2, nextStep, prefixLow, curr, postFirst);
+            have = false;
+            if (st == ZW_CONT) continue;
+            if (st == ZW_POST) { winDone = 2; break; }
+            if (st == ZW_INC) { step = 2; nextStep += 256; }
+            break;                                                           // ZW_INC / ZW_BATCH: the batch scheme takes over
+        }
+        if (winDone == 0) {
         for (;;) {
             // lanes 0..K-1 search p_j = ip + j*step; lane K is the helper for position p_K (= ip1 of lane K-1)
             uint32_t const p = ip + lane * step;
@@ -256,13 +475,14 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         lits_copy(out, src, nm8, anchor, mstart - anchor);
         store_seq(out, mstart - anchor, offBase, mLength);
         ip = mstart + mLength; anchor = ip;
+        }
 
         have = false;
         if ((int32_t)ip <= ilimit) {                                         // :300-320
             // ONE round of loads per pass (round 3; before: one for the inserts, one per repcode test, one for the next batch): lanes 0..2
             // fetch the bytes of the complementary inserts (first pass only), every lane compares 8 bytes at ip + 8*lane with the bytes
             // off2 back (the immediate repcode and its length), and the source bytes of the batch that starts at ip ride along
-            bool first = true;
+            bool first = postFirst;
             for (;;) {
                 uint32_t const q = lane == 0 ? curr + 2 : (lane == 1 ? ip - 2 : ip - 1);
                 uint64_t b = 0;
@@ -318,9 +538,6 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = repIn3;
         meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
     }
-#undef DF_POS
-#undef DF_TAGOK
-#undef DF_ENTRY
 }
 
 // One unit = one block with fresh tables (tagged 17-bit entries)
