@@ -93,15 +93,24 @@ def test_shim_honours_advanced_parameters_and_bounds():
     # ZSTD_compressCCtx ignores the advanced parameters (zstd_compress.c:5428): plain level 1
     r2 = S.ZSTD_compressCCtx(c, _buf(dst), cap, _buf(a), len(a), 1)
     assert not S.ZSTD_isError(r2) and hashlib.sha256(dst[:r2].tobytes()).hexdigest() == gold["shim|datagen33|1|plain"]
-    # what the device cannot run says so: binary-tree strategies, a window smaller than the unit, a table that does not fit LDS
-    for k, v in (("strategy", 7), ("windowLog", 12), ("hashLog", 18)):
+    # what the device cannot run says so: binary-tree strategies, a window smaller than the unit
+    for k, v in (("strategy", 7), ("windowLog", 12)):
         c2 = S.ZSTD_createCCtx(); S.ZSTD_CCtx_setParameter(c2, ZSTD_c["level"], 1); S.ZSTD_CCtx_setParameter(c2, ZSTD_c[k], v)
-        if k == "hashLog":
-            S.ZSTD_CCtx_setParameter(c2, ZSTD_c["windowLog"], 20)
         rr = S.ZSTD_compress2(c2, _buf(dst), cap, _buf(a), len(a))
-        if k == "hashLog":       # clipped to windowLog + 1 = 18 by the adjustment -> does not fit LDS
-            assert S.ZSTD_getErrorCode(rr) == 40, (k, v, S.ZSTD_getErrorCode(rr))
-        else:
-            assert S.ZSTD_getErrorCode(rr) == 40, (k, v, S.ZSTD_getErrorCode(rr))
+        assert S.ZSTD_getErrorCode(rr) == 40, (k, v, S.ZSTD_getErrorCode(rr))
+        S.ZSTD_freeCCtx(c2)
+    # a ZSTD_fast table above the unit kernel's LDS bound (hashLog 16 .. 18; round 2 refused it) goes through the frame kernel: the reference's bytes
+    lr = load_ref() if have_ref() else None
+    for hl in (16, 18):
+        c2 = S.ZSTD_createCCtx(); S.ZSTD_CCtx_setParameter(c2, ZSTD_c["level"], 1)
+        S.ZSTD_CCtx_setParameter(c2, ZSTD_c["windowLog"], 20); S.ZSTD_CCtx_setParameter(c2, ZSTD_c["hashLog"], hl)
+        for n in (len(a), 50000):
+            rr = S.ZSTD_compress2(c2, _buf(dst), cap, _buf(a), n)
+            assert not S.ZSTD_isError(rr), (hl, n, S.ZSTD_getErrorCode(rr))
+            if lr is not None:
+                want = np.zeros(cap + 1024, dtype=np.uint8)
+                arr = (C.c_int * 7)(20, 0, hl, 0, 0, 0, 0)
+                k = lr.zref_compress_chunks_level_params(1, arr, 0, UNIT, _buf(a), n, _buf(want), len(want))
+                assert k != ERR and k == rr and want[:k].tobytes() == dst[:rr].tobytes(), ("reference bytes", hl, n)
         S.ZSTD_freeCCtx(c2)
     S.ZSTD_freeCCtx(c)

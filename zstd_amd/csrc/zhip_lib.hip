@@ -61,6 +61,7 @@ struct zhip_ctx_s {
     // sequence-producer cache
     int rowMode;                         // greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14), 1 = ZSTD_ps_enable (the same, and units
                                          // with windowLog <= 14 are refused: the device has no row matcher for them), 2 = hash chain (ZSTD_ps_disable)
+    bool wideFast = false;               // build_units met a ZSTD_fast unit with hashLog > 15
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
@@ -304,7 +305,8 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
     }
-    if (mh > 15) { snprintf(c->err, sizeof(c->err), "hashLog %u does not fit LDS", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
+    if (mh > 15) {      // the unit kernel's LDS table ends at 2^15 entries: the caller sends such units through the frame kernel, whose table policy reaches HBM
+        c->wideFast = true; snprintf(c->err, sizeof(c->err), "hashLog %u does not fit the unit kernel's LDS table", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
     c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen; c->hcHashLog = hcHlog;
     {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
         static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 8192;
@@ -473,11 +475,25 @@ static void read_timing(zhip_ctx* c)
 }
 
 // device pipeline; returns total compressed size (after synchronising s)
+static size_t units_as_frames_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* offs,
+                                     size_t nFrames, int level, uint32_t* frameSizesDev, hipStream_t s);        // = frames_device_locked, below
 static size_t compress_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,
                                      int level, size_t unitSize, uint32_t* unitSizesDev, hipStream_t s)
 {
     size_t err = 0; uint32_t mh = 0;
+    c->wideFast = false;
     size_t const nUnits = build_units(c, srcSize, unitSize, level, &err, &mh);
+    if (!nUnits && c->wideFast) {
+        // explicit parameters with ZSTD_fast and hashLog > 15: every unit is a one-block frame for the frame kernel (k_frame_fast / k_frame_hbm:
+        // 24-bit LDS or 32-bit HBM table by size, zhip_frame.h) — the same bytes, the reference's ZSTD_compress2 of the unit
+        c->wideFast = false;
+        size_t const nU = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
+        if (nU > c->maxUnits) return ZERR(ZE_srcSize_wrong);
+        if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
+        std::vector<unsigned long long> offs(nU + 1);
+        for (size_t i = 0; i <= nU; i++) offs[i] = i * unitSize < srcSize ? (unsigned long long)(i * unitSize) : (unsigned long long)srcSize;
+        return units_as_frames_locked(c, dstDev, dstCapacity, srcDev, offs.data(), nU, level, unitSizesDev, s);
+    }
     if (!nUnits) return err;
     if (dstCapacity < zhip_compressBound(srcSize, unitSize)) return ZERR(ZE_dstSize_tooSmall);
     size_t r;
@@ -715,6 +731,12 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
     c->stats[0] = nU; c->stats[1] = totalSrc; c->stats[2] = total; c->stats[3] = 0; c->stats[4] = 0;
     c->nUnits = nU;
     return (size_t)total;
+}
+
+static size_t units_as_frames_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* offs,
+                                     size_t nFrames, int level, uint32_t* frameSizesDev, hipStream_t s)
+{
+    return frames_device_locked(c, dstDev, dstCapacity, srcDev, offs, nFrames, level, frameSizesDev, s);
 }
 
 size_t zhip_frames_bound(const unsigned long long* srcOffsets, size_t nFrames)
