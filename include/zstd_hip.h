@@ -72,8 +72,8 @@ size_t       zhip_compress_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacit
 
 /* ---- both with explicit compression parameters (see zhip_getCParams_explicit): = ZSTD_compress2 on a CCtx whose advanced
  * parameters were set (lib/compress/zstd_compress.c:710-768).  cparams may be NULL (= the plain calls above).  Not implemented on
- * the device -> parameter_unsupported: strategies above lazy2, ZSTD_fast with hashLog > 15 (the table must fit LDS), a windowLog
- * smaller than the unit it is applied to; values outside ZSTD_cParam_getBounds -> parameter_outOfBound. */
+ * the device -> parameter_unsupported: strategies above lazy2, a windowLog smaller than the unit it is applied to (ZSTD_fast with
+ * hashLog > 15 — beyond the unit kernel's LDS table — runs through the frame kernel's 24-bit LDS / HBM table, same bytes); values outside ZSTD_cParam_getBounds -> parameter_outOfBound. */
 size_t       zhip_compress_params(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                   int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes);
 size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dstCapacity, const void* srcDev, size_t srcSize,

@@ -17,8 +17,8 @@
  *                       The row matcher's hash is SALTED per CCtx reset (zstd_compress.c:1964-1975): the device uses the salt
  *                       of a fresh CCtx, so the bytes equal ZSTD_compress() / ZSTD_compress2 on a NEW CCtx; a reference CCtx
  *                       that already compressed something else has another salt and may pick other (equally valid) matches.
- *                       Not implemented on the device -> parameter_unsupported: strategies above lazy2, ZSTD_fast with
- *                       hashLog > 15 (the table lives in LDS), a windowLog smaller than the input, a dictionary whose CDict
+ *                       Not implemented on the device -> parameter_unsupported: strategies above lazy2,
+ *                       a windowLog smaller than the input, a dictionary whose CDict
  *                       row is a lazy strategy, dictionary + source above 128 KB.
  *   srcSize  > 128 KB : the source is cut into 128 KB units, each an independent frame (content size in every frame
  *                       header), emitted back to back.  That is a valid zstd stream (RFC 8878 3.1: frames may be
