@@ -89,3 +89,20 @@ def test_job_pool_frame_over_lanes_equals_the_single_context_frame():
     m = zstd_amd.MultiContext([0])                                                   # one device: the single-context path
     assert m.compress_frame_mt(a, 1) == oracle_frame_mt(lo, a, 1)
     m.close()
+
+
+def test_multi_create_rejects_devices_that_do_not_exist():
+    """two lanes on device ordinals the box does not have: the constructor fails cleanly (NULL -> ZhipError), nothing is left behind,
+    and a valid context still works afterwards"""
+    import torch
+    import zstd_amd
+    assert torch.cuda.is_available()
+    n = zstd_amd.lib().zhip_device_count()
+    with pytest.raises(zstd_amd.ZhipError):
+        zstd_amd.MultiContext([n + 3, n + 4])
+    with pytest.raises(zstd_amd.ZhipError):
+        zstd_amd.MultiContext([0, n + 1])
+    m = zstd_amd.MultiContext([0])
+    a = np.arange(300000, dtype=np.uint32).view(np.uint8)
+    assert len(m.compress(a, level=1)) > 0
+    m.close()

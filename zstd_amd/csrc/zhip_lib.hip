@@ -135,7 +135,10 @@ void zhip_destroy(zhip_ctx* c)
 static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_t litArena, size_t outArena)
 {
     if (maxUnits == 0) maxUnits = 1;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    {   int count = 0;                                  // (a failed hipSetDevice would leave a sticky error for the next launch check of another context)
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return nullptr; }
+    }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     zhip_ctx* c = new zhip_ctx_s();
     c->dUnits = nullptr; c->dSlots = nullptr; c->hSlots = nullptr; c->dSeqs = nullptr; c->dParse = nullptr; c->dLits = nullptr; c->dStBits = nullptr; c->dOut = nullptr;
     c->dOutSize = nullptr; c->dOutOff = nullptr; c->hUnits = nullptr; c->hOutSize = nullptr; c->hParse = nullptr;

@@ -50,6 +50,12 @@ extern "C" {
 zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnits)
 {
     if (!devices || nDevices <= 0) return nullptr;
+    {   // every ordinal must exist BEFORE anything is touched: a failed hipSetDevice leaves a sticky "invalid device ordinal" behind that
+        // the next, unrelated, launch check would report
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (int i = 0; i < nDevices; i++) if (devices[i] < 0 || devices[i] >= count) return nullptr;
+    }
     if (chunkUnits == 0) chunkUnits = 512;                                 // 64 MB of source per chunk
     size_t lanesPer = 4;
     if (const char* e = getenv("ZHIP_MULTI_LANES")) { long const v = atol(e); if (v >= 1 && v <= 16) lanesPer = (size_t)v; }
@@ -67,7 +73,7 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
         ok = ok && hipHostMalloc((void**)&L.pinSizes, chunkUnits * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
         ok = ok && hipMalloc((void**)&L.dIn, inCap) == hipSuccess && hipMalloc((void**)&L.dOut, outCap) == hipSuccess;
         ok = ok && hipMalloc((void**)&L.dSizes, chunkUnits * sizeof(uint32_t)) == hipSuccess;
-        if (!ok) { multi_free(m); return nullptr; }
+        if (!ok) { multi_free(m); (void)hipGetLastError(); return nullptr; }
     }
     return m;
 }
