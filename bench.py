@@ -510,7 +510,9 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
             "ratio": round(world * n / total_all, 4),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                         "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3)},
+                         "algorithmic_bytes_per_launch": parse_bytes, "avg_launch_ms": round(parse_ms, 3),
+                         # SURVEY.md 8(d) words the figure as S + C (the whole pipeline's bytes) — the same kernel priced that way, for comparison
+                         "frac_with_S_plus_C": round((n + int(total)) / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "gather_ms": round(gat_ms, 3),
                          "device_total_ms": round(tot_ms, 3), "algorithmic_bytes": n + int(total),
                          "achieved_GBps": round((n + int(total)) / (tot_ms * 1e-3) / 1e9, 2),
