@@ -164,3 +164,27 @@ def test_copy_mode_sources_match_oracle_bytes(env, kind, level, dsize):
     assert pos == len(got)
     dd = zstd_amd.DDict(dict_)
     assert zstd_amd.DContext(0).decompress(got, ddict=dd) == b"".join(r.tobytes() for r in recs)
+
+
+def test_many_records_use_the_tiled_prefix_sum(env):
+    """more than 65 536 records in one call: the packed stream's offsets come from the tiled prefix sum (k_offsets_tiles / _apply) —
+    it must equal the stream of the same records compressed in two calls of at most 65 536 (single-workgroup scan), and decode back"""
+    import os, sys
+    lo, zstd_amd, torch = env
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from zstd_amd import workloads as W
+    zd = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "github_like_110k.zdict"), dtype=np.uint8)
+    flat, offs = W.github_like_records_native(70000, seed=3)
+    recs = [flat[int(offs[i]):int(offs[i]) + 150 + (i % 200)] for i in range(70000)]        # short records, ragged lengths
+    tot = sum(len(r) for r in recs)
+    cd = zstd_amd.CDict(zd, level=3)
+    ctx = zstd_amd.Context(0, max_units=70000, records_total_bytes=tot)
+    whole, fs = ctx.compress_records(cd, recs, return_sizes=True)
+    a = ctx.compress_records(cd, recs[:40000])
+    b = ctx.compress_records(cd, recs[40000:])
+    assert whole == a + b
+    assert int(np.asarray(fs).sum()) == len(whole)
+    dd = zstd_amd.DDict(zd, device=0)
+    back = zstd_amd.DContext(0).decompress(whole, ddict=dd, capacity=tot)
+    assert back == b"".join(r.tobytes() for r in recs)
+    ctx.close()

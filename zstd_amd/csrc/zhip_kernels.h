@@ -465,6 +465,39 @@ k_offsets(const uint32_t* __restrict__ outSize, uint32_t nUnits, uint64_t* __res
     for (uint32_t i = a; i < b; i++) { offsets[i] = run; run += outSize[i]; }
 }
 
+// The same prefix sum for MANY units (the records workload: 10 M frames): tiles of ZHIP_SCAN_TILE sizes, one workgroup each.
+// k_offsets_tiles sums every tile, k_offsets (above) scans the tile sums, k_offsets_apply scans inside each tile from its base.
+#define ZHIP_SCAN_TILE 4096u
+__global__ void __launch_bounds__(256)
+k_offsets_tiles(const uint32_t* __restrict__ outSize, uint32_t nUnits, uint32_t* __restrict__ tileSums)
+{
+    __shared__ unsigned long long red[4];
+    uint32_t const t = threadIdx.x, base = blockIdx.x * ZHIP_SCAN_TILE;
+    unsigned long long s = 0;
+    for (uint32_t i = base + t; i < base + ZHIP_SCAN_TILE && i < nUnits; i += 256) s += outSize[i];
+    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) tileSums[blockIdx.x] = (uint32_t)(red[0] + red[1] + red[2] + red[3]);      // a tile of 4 096 frames of <= 128 KB + header fits 32 bits
+}
+__global__ void __launch_bounds__(256)
+k_offsets_apply(const uint32_t* __restrict__ outSize, uint32_t nUnits, const uint64_t* __restrict__ tileOffs, uint32_t nTiles, uint64_t* __restrict__ offsets)
+{
+    __shared__ unsigned long long part[256];
+    uint32_t const t = threadIdx.x, base = blockIdx.x * ZHIP_SCAN_TILE;
+    uint32_t const per = ZHIP_SCAN_TILE / 256;
+    uint32_t const a = base + t * per;
+    unsigned long long s = 0;
+    for (uint32_t i = a; i < a + per && i < nUnits; i++) s += outSize[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) { unsigned long long acc = tileOffs[blockIdx.x]; for (int i = 0; i < 256; i++) { unsigned long long const v = part[i]; part[i] = acc; acc += v; } }
+    __syncthreads();
+    unsigned long long run = part[t];
+    for (uint32_t i = a; i < a + per && i < nUnits; i++) { offsets[i] = run; run += outSize[i]; }
+    if (blockIdx.x == 0 && t == 0) offsets[nUnits] = tileOffs[nTiles];
+}
+
 // Decoder: persistent 128-thread workgroups, each takes frames from a queue (counter) until it is empty; per workgroup a
 // literal buffer and two hand-over buffers of sequence records in HBM/L2.  Dynamic LDS = sizeof(DecShared).
 #ifndef ZHIP_DEC_WAVES_PER_EU

@@ -61,6 +61,7 @@ struct zhip_ctx_s {
     // sequence-producer cache
     int rowMode;                         // greedy / lazy / lazy2: 0 auto = the reference's default (row-hash matcher when windowLog > 14), 1 = ZSTD_ps_enable (the same, and units
                                          // with windowLog <= 14 are refused: the device has no row matcher for them), 2 = hash chain (ZSTD_ps_disable)
+    uint32_t* dTileSums = nullptr; uint64_t* dTileOffs = nullptr; size_t scanCap = 0;    // tiles of the frame-size prefix sum (launch_offsets)
     bool wideFast = false;               // build_units met a ZSTD_fast unit with hashLog > 15
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
@@ -121,7 +122,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
-    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks);
+    (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse); (void)hipHostFree(c->hSlots);
@@ -338,6 +339,26 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     return nUnits;
 }
 
+// exclusive prefix sum of the frame sizes: one workgroup up to 64 K units, tiles above (10 M records: 37 ms -> well under one)
+static size_t launch_offsets(zhip_ctx* c, size_t nUnits, hipStream_t s)
+{
+    if (nUnits <= 65536) {
+        hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
+        return 0;
+    }
+    size_t const nTiles = (nUnits + ZHIP_SCAN_TILE - 1) / ZHIP_SCAN_TILE;
+    if (c->scanCap < nTiles) {
+        (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs); c->dTileSums = nullptr; c->dTileOffs = nullptr; c->scanCap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->dTileSums, nTiles * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->dTileOffs, (nTiles + 1) * sizeof(uint64_t)));
+        c->scanCap = nTiles;
+    }
+    hipLaunchKernelGGL(zhip::k_offsets_tiles, dim3((unsigned)nTiles), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dTileSums);
+    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dTileSums, (uint32_t)nTiles, c->dTileOffs);
+    hipLaunchKernelGGL(zhip::k_offsets_apply, dim3((unsigned)nTiles), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dTileOffs, (uint32_t)nTiles, c->dOutOff);
+    return 0;
+}
+
 static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
 {
     size_t smem = zhip::fast_lds_bytes(maxHashLog);
@@ -423,7 +444,7 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
+    {   size_t const e_ = launch_offsets(c, nUnits, s); if (zhip_isError(e_)) return e_; }
     hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -460,7 +481,7 @@ static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits
         HIPCHK(c, hipStreamWaitEvent(s, c->cev[i], 0));
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(zhip::k_offsets, dim3(1), dim3(256), 0, s, c->dOutSize, (uint32_t)nUnits, c->dOutOff);
+    {   size_t const e_ = launch_offsets(c, nUnits, s); if (zhip_isError(e_)) return e_; }
     hipLaunchKernelGGL(zhip::k_gather, dim3((unsigned)nUnits), dim3(256), 0, s, c->dOut, c->dSlots, c->dOutSize, c->dOutOff, (uint32_t)nUnits, dstDev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], s));
