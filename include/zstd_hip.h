@@ -154,6 +154,9 @@ int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
  * 2 (ZSTD_ps_disable): the hash-chain matcher; -1: back to the mode the context was created with.
  * The environment variable ZHIP_ROW_MATCHER=disable sets 2 as a context's initial mode.  Returns 0, or 1 for another value. */
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
+/* Batches of at least this many units run their ZSTD_fast / ZSTD_dfast units through the lane-per-unit match finder (one lane per
+ * unit, tables in HBM: throughput instead of latency; same bytes).  0 = never.  Environment: ZHIP_LANE_MIN_UNITS. */
+size_t       zhip_lane_min_units(void);
 
 /* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a
  * skippable frame holding the seek table — the natural on-disk form of frame-per-unit output; the reference's

@@ -7,6 +7,7 @@
 #include "zhip_parse_lazy.h"
 #include "zhip_parse_dict.h"
 #include "zhip_parse_ext.h"
+#include "zhip_parse_lane.h"
 #include "zhip_entropy.h"
 #include "zhip_frame.h"
 #include "zhip_decode.h"
@@ -40,7 +41,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
-    if (u.strategy != ZHIP_STRAT_FAST) return;          // another family's kernel handles it
+    if (u.strategy != ZHIP_STRAT_FAST || u.pad1 == ZHIP_UNIT_LANE) return;          // another family's kernel handles it
     const uint8_t* const p = src + u.srcOff;
     ZhipSlot const sl = slots[ui];
     ZhipSeq* const sq = seqs + sl.seqOff;
@@ -66,7 +67,7 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     // all of them, so the table memory in use is gridDim.x pairs, not nUnits pairs
     for (uint32_t ui = blockIdx.x; ui < nUnits; ui += gridDim.x) {
         ZhipUnit const u = units[ui];
-        if (u.strategy != ZHIP_STRAT_DFAST) continue;
+        if (u.strategy != ZHIP_STRAT_DFAST || u.pad1 == ZHIP_UNIT_LANE) continue;
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
@@ -82,6 +83,19 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Stage 1 for LARGE batches (zhip_parse_lane.h): one LANE per unit, tables (zeroed by the host's memset) at tabs + ui * tabStride words
+__global__ void __launch_bounds__(64)
+k_parse_lane(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+             uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    uint32_t const ui = blockIdx.x * 64u + threadIdx.x;
+    if (ui >= nUnits) return;
+    ZhipUnit const u = units[ui];
+    if (u.pad1 != ZHIP_UNIT_LANE) return;
+    ZhipSlot const sl = slots[ui];
+    parse_lane_unit(src + u.srcOff, u, tabs + (size_t)ui * tabStride, seqs + sl.seqOff, sl.seqCap, lits + sl.litOff, metas + ui);
 }
 
 // Stage 1 for records compressed with an attached dictionary (strategies fast and dfast), one wavefront per record.

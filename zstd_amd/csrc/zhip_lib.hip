@@ -271,6 +271,18 @@ size_t zhip_test_fse_tables(zhip_ctx* c, const unsigned* counts, const unsigned*
 
 // ------------------------------------------------------------------------------------------------ internals
 // fill ctx->hUnits for `srcSize` bytes cut into unitSize chunks; returns number of units or 0 with *err set
+// Batches of at least this many units take the lane-per-unit match finder for their ZSTD_fast / ZSTD_dfast units (zhip_parse_lane.h);
+// 0 = never.  $ZHIP_LANE_MIN_UNITS overrides the default (the measured cross-over).
+#ifndef ZHIP_LANE_MIN_UNITS_DEFAULT
+#define ZHIP_LANE_MIN_UNITS_DEFAULT 0
+#endif
+static size_t lane_min_units()
+{
+    static long const v = getenv("ZHIP_LANE_MIN_UNITS") ? atol(getenv("ZHIP_LANE_MIN_UNITS")) : (long)ZHIP_LANE_MIN_UNITS_DEFAULT;
+    return v > 0 ? (size_t)v : 0;
+}
+extern "C" size_t zhip_lane_min_units(void) { return lane_min_units(); }
+
 static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int level, size_t* err, uint32_t* maxHashLog)
 {
     if (unitSize == 0 || unitSize > ZHIP_UNIT_MAX) { *err = ZERR(ZE_parameter_outOfBound); return 0; }
@@ -278,6 +290,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
     uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
+    bool const laneOn = lane_min_units() != 0 && nUnits >= lane_min_units();
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -304,7 +317,12 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
             *err = ZERR(ZE_parameter_unsupported); return 0;
         }
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
-        if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
+        if (laneOn && (cp->strategy == ZHIP_STRAT_FAST || cp->strategy == ZHIP_STRAT_DFAST) && len >= 8) {
+            // a large batch: one lane per unit, its table(s) in HBM (family bit 8)
+            u.pad1 = ZHIP_UNIT_LANE; fam |= 8;
+            size_t const w = zhip::lane_table_words(cp->hashLog, cp->chainLog, cp->strategy); if (w > tabWords) tabWords = w;
+        }
+        else if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
         else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
@@ -318,7 +336,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         c->hcChunk = nUnits < chunk ? nUnits : chunk;
     }
     size_t const tabUnits = (fam & 4) ? c->hcChunk : nUnits;
-    if ((fam & 6) && c->tabsCap < tabUnits * c->tabStride) {
+    if ((fam & 14) && c->tabsCap < tabUnits * c->tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
         if (hipMalloc((void**)&c->dTabs, tabUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match-finder tables", tabUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
         c->tabsCap = tabUnits * c->tabStride;
@@ -328,7 +346,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
         c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
     }
-    if ((fam & 2) && (fam & 4)) {              // the dfast kernel indexes dTabs by the global unit id
+    if (((fam & 2) && (fam & 4)) || (fam & 8)) {   // the dfast and the lane kernels index dTabs by the global unit id
         if (c->tabsCap < nUnits * c->tabStride) {
             (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
             if (hipMalloc((void**)&c->dTabs, nUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { *err = ZERR(ZE_memory_allocation); return 0; }
@@ -372,6 +390,12 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // one launch per strategy family present; every kernel skips the units of the other families
+    if (c->strategy & 8) {
+        // lane-per-unit form: all tables zeroed by ONE memset (inside the timed match-finder stage), 64 units per wavefront
+        HIPCHK(c, hipMemsetAsync(c->dTabs, 0, nUnits * c->tabStride * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(zhip::k_parse_lane, dim3((unsigned)((nUnits + 63) / 64)), dim3(64), 0, s,
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
+    }
     if (c->strategy & 2)
     {   // experiment knobs: $ZHIP_DF_SLOTS persistent workgroups (each reuses one table pair), $ZHIP_DF_LDS_PAD extra LDS bytes per workgroup (fewer resident)
         static long const dfSlots = getenv("ZHIP_DF_SLOTS") ? atol(getenv("ZHIP_DF_SLOTS")) : 0;
