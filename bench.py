@@ -10,7 +10,7 @@ N > 1: one process per GPU — under torchrun, or started by bench.py itself whe
 GPU/stream; there is no data-path collective (units are independent) — torch.distributed only provides the
 barriers and the max-over-ranks time.  scaling = "weak".
 
-Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder k_parse_fast: algorithmic
+Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder stage k_parse_fast_q / k_parse_fast_g: algorithmic
 bytes = source read once + 8-byte sequence records + literals written once, divided by the kernel's average launch
 duration from HIP events recorded by the library on the stream it launches on), `pipeline` (all kernels, (S + C) bytes),
 `ratio`, `parity` (sha256 of the GPU stream == oracle stream on a bounded sample and a full-size structural property),
@@ -499,7 +499,10 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
             traffic, tsrc = traffic_lookup(leg, {1: "k_parse_fast", 2: "k_parse_dfast"}.get(zstd_amd.get_cparams(level, UNIT)[6], "k_parse_lazy"))
         sname = {1: "ZSTD_fast", 2: "ZSTD_dfast", 3: "ZSTD_greedy (hash chain)", 4: "ZSTD_lazy (hash chain)", 5: "ZSTD_lazy2 (hash chain)"}[cp[6]]
         cpdesc = f"{sname} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} slog{cp[3]} mml{cp[4]}"
-        kname = {1: "k_parse_fast", 2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
+        # ZSTD_fast runs as ONE stage of two kernels on one ticket queue (LDS-table wavefronts + global-table wavefronts beside them, zhip_lib.hip
+        # launch_parse); the stage's duration — cost estimate and sort of the dispatch order included — is what the events bracket
+        kname = {1: "k_parse_fast_q (+ k_parse_fast_g on the same queue; k_order_cost/k_order_sort inside the stage)" if os.environ.get("ZHIP_FAST_QUEUE", "1") != "0" else "k_parse_fast",
+                 2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
         out = {
             "metric": f"compress_MBps_level{level}_{'datagenP50' if workload == 'datagen' else workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": warmup, "ms_per_step": round(ms_step, 3),

@@ -243,7 +243,16 @@ def emu_parse_units(le, src, units, seqs, lits, metas):
         le.emu_parse_lane(_buf(src), _buf(units), nu, _buf(ltabs), stride, _buf(seqs), _buf(lits), _buf(metas), 0)
     if strat == 1:
         smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
-        le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
+        qmode = int(os.environ.get("ZHIP_EMU_QUEUE", "0"))
+        if qmode and nu:
+            # the queue form (k_order_cost + k_order_sort + k_parse_fast_q / k_parse_fast_g): LDS tables, global tables, or both on one queue
+            le.emu_parse_fast_queue.restype = None
+            le.emu_parse_fast_queue.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_void_p, C.c_int]
+            order = np.zeros(nu + 1, dtype=np.uint32)
+            le.emu_parse_fast_queue(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, qmode, _buf(order), 0)
+            assert sorted(order[:nu].tolist()) == list(range(nu)), "the dispatch order is not a permutation"
+        else:
+            le.emu_parse_fast(_buf(src), _buf(units), nu, _buf(seqs), _buf(lits), _buf(metas), smem, 0)
     elif strat >= 3:
         le.emu_hc_table_words.restype = C.c_uint64
         stride = (int(le.emu_hc_table_words(int(units["hashLog"].max()))) + 3) & ~3

@@ -27,6 +27,32 @@ void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
                  [=] { zhip::k_parse_fast(src, units, slots, nUnits, seqs, lits, metas); }, osThreads);
 }
 
+// the queue form of the same stage: dispatch order from k_order_cost + k_order_sort, then persistent workgroups on one ticket counter.
+// mode 1 = LDS tables (k_parse_fast_q), 2 = tables in global memory (k_parse_fast_g), 3 = both kernels, one after the other on one queue
+void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas,
+                          uint32_t smemBytes, int mode, uint32_t* orderOut, int osThreads)
+{
+    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
+    std::vector<uint32_t> cost(nUnits + 1), order(nUnits + 1), queue(16, 0);
+    uint32_t* const pc = cost.data(); uint32_t* const po = order.data(); uint32_t* const pq = queue.data();
+    simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_order_cost(src, units, nUnits, pc); }, osThreads);
+    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po); }, 1);
+    if (orderOut) for (uint32_t i = 0; i < nUnits; i++) orderOut[i] = po[i];
+    uint32_t maxH = 6; for (uint32_t i = 0; i < nUnits; i++) if (units[i].hashLog > maxH) maxH = units[i].hashLog;
+    uint32_t const gw = 1u << maxH, gridG = 3, gridQ = 2;
+    std::vector<uint32_t> gt((size_t)gridG * gw, 0xEEEEEEEEu); uint32_t* const pg = gt.data();
+    if (mode == 3) {
+        // the first kernel's workgroups leave after two units each, the second takes the rest (the queue is shared)
+        uint32_t const half = nUnits / 2;
+        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, half, seqs, lits, metas, po, pq); }, osThreads);
+        pq[0] = half;
+        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
+    } else if (mode == 2)
+        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
+    else
+        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, nUnits, seqs, lits, metas, po, pq); }, osThreads);
+}
+
 void emu_parse_dfast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride,
                      ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
 {

@@ -256,3 +256,17 @@ def test_lane_per_unit_form_on_the_emulator(libs, monkeypatch):
             cases += list(corpus_cases(lo, sizes=(n,), seeds=(level + 7,)))
         cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] in (1, 2)]
         check(le, lo, cases, level)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_queue_form_of_the_fast_stage_on_the_emulator(libs, monkeypatch, mode):
+    """k_order_cost + k_order_sort + the persistent queue kernels (mode 1: LDS tables, 2: tables in global memory with ballot hash
+    groups, 3: both kernels on one queue) give the oracle's sequences whatever order the units are taken in"""
+    lo, le = libs
+    monkeypatch.setenv("ZHIP_EMU_QUEUE", str(mode))
+    for level in (1, -3):
+        cases = []
+        for n in (0, 7, 12, 13, 100, 1000, 5000, 40000, 131072):
+            cases += list(corpus_cases(lo, sizes=(n,), seeds=(level + 11,)))
+        cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
+        check(le, lo, cases, level)

@@ -18,6 +18,18 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #define ZERR(c) ((size_t)-(long)(c))
 
 #define ZHIP_MAX_CHUNKS 8
+// The ZSTD_fast stage's launch form (A/B in profiles/r03_ab_queue_forms.log): persistent wavefronts on a ticket
+// queue, units dispatched by descending estimated cost, and three global-table wavefronts per CU beside the nine LDS-table ones (what the
+// 141 / 145 registers of the two kernels leave room for).  $ZHIP_FAST_QUEUE=0 restores one workgroup per unit in index order.
+#ifndef ZHIP_FAST_QUEUE_DEFAULT
+#define ZHIP_FAST_QUEUE_DEFAULT 1
+#endif
+#ifndef ZHIP_FAST_ORDER_DEFAULT
+#define ZHIP_FAST_ORDER_DEFAULT 1
+#endif
+#ifndef ZHIP_FAST_GWAVES_DEFAULT
+#define ZHIP_FAST_GWAVES_DEFAULT 3
+#endif
 struct zhip_ctx_s {
     int device;
     size_t maxUnits;
@@ -63,6 +75,11 @@ struct zhip_ctx_s {
                                          // with windowLog <= 14 are refused: the device has no row matcher for them), 2 = hash chain (ZSTD_ps_disable)
     uint32_t* dTileSums = nullptr; uint64_t* dTileOffs = nullptr; size_t scanCap = 0;    // tiles of the frame-size prefix sum (launch_offsets)
     bool wideFast = false;               // build_units met a ZSTD_fast unit with hashLog > 15
+    // ZSTD_fast queue form (launch_parse): ticket counter, dispatch order + cost classes, the co-kernel's tables in global memory, its stream
+    uint32_t* dQueue = nullptr; uint32_t* dOrder = nullptr; uint32_t* dCost = nullptr; uint32_t* dGTabs = nullptr; size_t gtabsCap = 0;
+    hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
+    int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
+    size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
@@ -125,6 +142,9 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
+    (void)hipFree(c->dQueue); (void)hipFree(c->dOrder); (void)hipFree(c->dCost); (void)hipFree(c->dGTabs);
+    if (c->coStream) (void)hipStreamDestroy(c->coStream);
+    for (int i = 0; i < 2; i++) if (c->coEv[i]) (void)hipEventDestroy(c->coEv[i]);
     (void)hipHostFree(c->hUnits); (void)hipHostFree(c->hOutSize); (void)hipHostFree(c->hParse); (void)hipHostFree(c->hSlots);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->hcEv) (void)hipEventDestroy(e);
@@ -180,6 +200,21 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     ok = ok && hipHostMalloc((void**)&c->hUnits, maxUnits * sizeof(ZhipUnit), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->hOutSize, (maxUnits + 1) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->hParse, maxUnits * sizeof(ZhipParse), hipHostMallocDefault) == hipSuccess;
+    {   // the queue form of the ZSTD_fast stage (launch_parse)
+        const char* e;
+        c->fastQueue = (e = getenv("ZHIP_FAST_QUEUE")) ? atoi(e) : ZHIP_FAST_QUEUE_DEFAULT;
+        c->fastOrder = (e = getenv("ZHIP_FAST_ORDER")) ? atoi(e) : ZHIP_FAST_ORDER_DEFAULT;
+        c->fastGWaves = (e = getenv("ZHIP_FAST_GWAVES")) ? atoi(e) : ZHIP_FAST_GWAVES_DEFAULT;
+        if (c->fastGWaves < 0) c->fastGWaves = 0;
+        if (c->fastGWaves > 16) c->fastGWaves = 16;
+        hipDeviceProp_t prop;
+        c->numCUs = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        ok = ok && hipMalloc((void**)&c->dQueue, 64) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->dOrder, maxUnits * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->dCost, maxUnits * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&c->coStream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->coEv[i], hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) { zhip_destroy(c); return nullptr; }
     return c;
 }
@@ -406,7 +441,47 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         hipLaunchKernelGGL(zhip::k_parse_dfast, dim3(grid), dim3(64), ldsB, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
     }
-    if (c->strategy & 1)
+    if ((c->strategy & 1) && c->fastQueue && nUnits > 1) {
+        // queue form: persistent wavefronts draw units from one ticket counter — the LDS-table kernel on this stream and, beside it on
+        // the same CUs, the global-table kernel on coStream (its wavefronts need no LDS); heaviest units first when an order is asked for
+        if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const uint32_t* order = nullptr;
+        if (c->fastOrder && nUnits > 2) {
+            if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
+            else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
+            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder);
+            order = c->dOrder;
+        }
+        HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));
+        if (c->fastOccSmem != smem) {                                         // resident LDS-form workgroups per CU for this table size (nine at hashLog 13)
+            int perCU_ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU_, (const void*)zhip::k_parse_fast_q, 64, smem) != hipSuccess || perCU_ < 1) { (void)hipGetLastError(); perCU_ = 1; }
+            c->fastOccSmem = smem; c->fastOccPerCU = perCU_;
+        }
+        int const perCU = c->fastOccPerCU;
+        size_t const gridQ = (size_t)perCU * (size_t)c->numCUs < nUnits ? (size_t)perCU * (size_t)c->numCUs : nUnits;
+        size_t gridG = (size_t)c->fastGWaves * (size_t)c->numCUs;
+        if (gridQ >= nUnits) gridG = 0;                                       // everything is resident on the LDS form already
+        else if (gridG > nUnits - gridQ) gridG = nUnits - gridQ;
+        uint32_t const gtabWords = 1u << maxHashLog;
+        if (gridG) {
+            if (c->gtabsCap < gridG * gtabWords) {
+                (void)hipFree(c->dGTabs); c->dGTabs = nullptr; c->gtabsCap = 0;
+                if (hipMalloc((void**)&c->dGTabs, gridG * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; }
+                else c->gtabsCap = gridG * gtabWords;
+            }
+        }
+        if (gridG) HIPCHK(c, hipEventRecord(c->coEv[0], s));
+        hipLaunchKernelGGL(zhip::k_parse_fast_q, dim3((unsigned)gridQ), dim3(64), smem, s,
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
+        if (gridG) {
+            HIPCHK(c, hipStreamWaitEvent(c->coStream, c->coEv[0], 0));
+            hipLaunchKernelGGL(zhip::k_parse_fast_g, dim3((unsigned)gridG), dim3(64), 0, c->coStream,
+                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
+            HIPCHK(c, hipEventRecord(c->coEv[1], c->coStream));
+            HIPCHK(c, hipStreamWaitEvent(s, c->coEv[1], 0));
+        }
+    } else if (c->strategy & 1)
         hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     if (c->strategy & 4) {

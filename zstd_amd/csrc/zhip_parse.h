@@ -120,6 +120,30 @@ __device__ __forceinline__ void tab_mark(const Lds24Tab& T, uint32_t h, uint32_t
 __device__ __forceinline__ uint32_t tab_peek(const Lds24Tab& T, uint32_t h) { return T.lo[h]; }
 __device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
 
+// the unit table with 32-bit positions in GLOBAL memory (L2 / Infinity Cache), for the wavefronts that run beside the LDS-table ones on a
+// CU whose LDS is full (k_parse_fast_g): no LDS at all, so the slot cannot double as the duplicate detector (three dependent global
+// round trips) — lanes that hash alike are found with one ballot per hash bit instead (wave_hash_group; TabTraits<>::ballotGroups)
+struct GlobTab { uint32_t* w; };
+__device__ __forceinline__ void tab_put(const GlobTab& T, uint32_t h, uint32_t pos) { T.w[h] = pos; }
+__device__ __forceinline__ uint32_t tab_get(const GlobTab& T, uint32_t h, bool) { return T.w[h]; }
+__device__ __forceinline__ void tab_mark(const GlobTab&, uint32_t, uint32_t) { }
+__device__ __forceinline__ uint32_t tab_peek(const GlobTab&, uint32_t) { return 0; }
+__device__ __forceinline__ void tab_unmark(const GlobTab&, uint32_t, uint32_t) { }
+template <typename TAB> struct TabTraits { static constexpr bool ballotGroups = false; };
+template <> struct TabTraits<GlobTab> { static constexpr bool ballotGroups = true; };
+// per lane: the lanes of the wavefront whose `bits`-bit value equals this lane's (itself included) — one ballot per bit
+__device__ __forceinline__ unsigned long long wave_hash_group(uint32_t h, uint32_t bits)
+{
+    uint32_t glo = ~0u, ghi = ~0u;
+    for (uint32_t b = 0; b < bits; b++) {
+        bool const bit = (h >> b) & 1u;
+        unsigned long long const S = __ballot(bit);
+        uint32_t const flip = bit ? 0u : ~0u;
+        glo &= (uint32_t)S ^ flip; ghi &= (uint32_t)(S >> 32) ^ flip;
+    }
+    return (unsigned long long)glo | ((unsigned long long)ghi << 32);
+}
+
 // where the speculative read of a candidate's bytes goes when the entry is 0 (= empty; the loaded value is never used then).  The
 // unit tables read position 0 — the unit's first bytes, always there.  A job of a frame whose window starts at the frame's byte 0 counts
 // its positions from 1 with `src` one byte BEFORE the frame (zhip_frame.h): position 0 is not memory, so the frame tables (WideTab,
@@ -127,6 +151,7 @@ __device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32
 __device__ __forceinline__ uint32_t tab_guard(const FastTab&, uint32_t old) { return old; }
 __device__ __forceinline__ uint32_t tab_guard(const Lds24Tab&, uint32_t old) { return old > 1u ? old : 1u; }
 __device__ __forceinline__ uint32_t tab_guard(const WideTab&, uint32_t old) { return old > 1u ? old : 1u; }
+__device__ __forceinline__ uint32_t tab_guard(const GlobTab&, uint32_t old) { return old; }
 
 // ------------------------------------------------------------------ wave-wide match extension
 // Every load below is clamped to [0, n-8] so that no lane ever reads outside the unit; `sh` bytes are then shifted out.
@@ -511,13 +536,16 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     } else {
         cb = ld32(src + tab_guard(T, old));                               // old == 0 reads the unit's first bytes: harmless
     }
-    __builtin_amdgcn_wave_barrier();
-    tab_mark(T, h, lane);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t const backId = tab_peek(T, h);
-    __builtin_amdgcn_wave_barrier();
-    tab_unmark(T, h, old);
-    __builtin_amdgcn_wave_barrier();
+    uint32_t backId = lane;
+    if constexpr (!TabTraits<TAB>::ballotGroups) {
+        __builtin_amdgcn_wave_barrier();
+        tab_mark(T, h, lane);
+        __builtin_amdgcn_wave_barrier();
+        backId = tab_peek(T, h);
+        __builtin_amdgcn_wave_barrier();
+        tab_unmark(T, h, old);
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // NF: lanes that share their hash with an earlier lane of the window.  What such a lane finds in the table depends on which of
     // its group's earlier members have been inserted when it is looked up: the closest inserted one, else the table's old entry.
@@ -528,8 +556,12 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     unsigned long long NF = 0;
     unsigned long long DEEP = lanes_from(ZHIP_WIN_LANES);      // lanes that cannot be searched from this window: >= 60, or beyond what the group data resolves
     uint32_t p1 = 0, p2 = 0, m1 = 0, m2 = 0, depth = 0;
-    {   unsigned long long ML = __ballot(backId != lane);
-        unsigned long long myG = 0;
+    {   unsigned long long myG = 0;
+        if constexpr (TabTraits<TAB>::ballotGroups) {
+            myG = wave_hash_group(h, 32u - hshift);                       // every group exactly, whatever their number
+            NF = __ballot((myG & lanes_below(lane)) != 0);
+        } else {
+        unsigned long long ML = __ballot(backId != lane);
         int it = 0;
         while (ML) {
             uint32_t const j = ff1u(ML);
@@ -539,6 +571,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             if (h == hj) myG = G;
             NF |= G & (G - 1);
             ML &= ~G; it++;
+        }
         }
         if (NF) {
             unsigned long long const prev = myG & lanes_below(lane);
@@ -1008,10 +1041,13 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             uint32_t const cur32 = (uint32_t)cur.bytes;
             uint32_t const h = hash_pos<MLS>(cur.bytes, hshift);
             uint32_t const old = tab_get(T, h, ip0 > 65536);
-            __builtin_amdgcn_wave_barrier();
-            if (live) tab_mark(T, h, lane);
-            __builtin_amdgcn_wave_barrier();
-            uint32_t const back = tab_peek(T, h);
+            uint32_t back = lane;
+            if constexpr (!TabTraits<TAB>::ballotGroups) {
+                __builtin_amdgcn_wave_barrier();
+                if (live) tab_mark(T, h, lane);
+                __builtin_amdgcn_wave_barrier();
+                back = tab_peek(T, h);
+            }
 
             // speculative loads for the next batch (used if this one has no event)
             uint32_t const nip0 = ip0 + g0 + (uint32_t)(K - 1) * step;
@@ -1022,10 +1058,15 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
 
             uint32_t cb = ld32(src + tab_guard(T, old));                     // old == 0 reads the unit's first bytes: harmless
             uint32_t cand = old;
-            unsigned long long const dupMask = __ballot(back != lane) & liveMask;
-            unsigned long long grp = 0;
+            unsigned long long dupMask, grp = 0;
+            if constexpr (TabTraits<TAB>::ballotGroups) {
+                grp = wave_hash_group(h, 32u - hshift) & liveMask;
+                dupMask = __ballot(live && (grp & (grp - 1)) != 0);
+                if (!live || !(grp & (grp - 1))) grp = 0;                    // (lanes outside a group carry no group, like the loop below leaves them)
+            } else dupMask = __ballot(back != lane) & liveMask;
             if (dupMask) {
                 // exact groups of live lanes with equal hash; a lane's candidate is its closest earlier group member
+                if constexpr (!TabTraits<TAB>::ballotGroups) {
                 unsigned long long ML = dupMask;
                 while (ML) {
                     int const j = first_lane(ML);
@@ -1033,6 +1074,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
                     unsigned long long const G = __ballot(h == hj) & liveMask;
                     if (h == hj) grp = G;
                     ML &= ~G;
+                }
                 }
                 unsigned long long const prevMask = grp & below_mask((int)lane);
                 uint32_t const pd = prevMask ? 63u - (uint32_t)__clzll((long long)prevMask) : lane;
@@ -1134,7 +1176,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
 
 // One unit = one block with a fresh table.  smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
 template <uint32_t MLS>
-__device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
+__device__ __forceinline__ void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
                                        unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
@@ -1149,6 +1191,20 @@ __device__ inline void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t
     }
     __builtin_amdgcn_wave_barrier();
     parse_fast_block<MLS, FastTab>(src, 0, n, 0, 1, 1, 4, 8, u, T, seqs, lits, meta);   // lowest index 0, ip0 = 1 -> maxRep = 1
+}
+
+// The same unit on a table in global memory (`gtab`: 1 << hashLog words owned by this wavefront, reused from unit to unit)
+template <uint32_t MLS>
+__device__ __forceinline__ void parse_fast_unit_g(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
+                                         uint32_t* gtab, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+{
+    uint32_t const lane = (uint32_t)lane_id();
+    GlobTab T; T.w = gtab;
+    {   uint32_t const words = 1u << u.hashLog;                               // fresh table (hashLog >= 6: at least one word per lane)
+        for (uint32_t i = lane * 4; i < words; i += 256) { gtab[i] = 0; gtab[i + 1] = 0; gtab[i + 2] = 0; gtab[i + 3] = 0; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    parse_fast_block<MLS, GlobTab>(src, 0, n, 0, 1, 1, 4, 8, u, T, seqs, lits, meta);
 }
 
 }  // namespace zhip
