@@ -121,8 +121,19 @@ int emu_parse_dict(const uint8_t* src, const uint64_t* offsets, uint32_t nRec, c
     dv.strategy = cd.cp.strategy; dv.tabL = cd.tabL.data(); dv.tabS = cd.tabS.data(); dv.rep[0] = cd.rep[0]; dv.rep[1] = cd.rep[1]; dv.rep[2] = cd.rep[2]; dv.dictID = cd.dictID;
     std::vector<ZhipSlot> const sv = fixed_slots(nRec); const ZhipSlot* const slots = sv.data();
     const ZhipUnit* units = unitsOut;
+    int const qmode = getenv("ZHIP_EMU_DICT_QUEUE") ? atoi(getenv("ZHIP_EMU_DICT_QUEUE")) : 0;   // 1: k_parse_dict_q, 2: k_parse_dict_g (tables in global memory)
+    uint32_t const ldsB = cd.cp.strategy == 1 ? zhip::dict_fast_lds_bytes(mh) : zhip::dict_lds_bytes(mh, mc);
+    if (extIdx.size() < nRec && qmode) {
+        std::vector<uint32_t> queue(16, 0); uint32_t* const pq = queue.data();
+        uint32_t const grid = 3, gtabBytes = ((2u << mh) + (2u << mc) + 255u) & ~255u;
+        std::vector<unsigned char> gt((size_t)grid * gtabBytes, 0xEE); unsigned char* const pg = gt.data();
+        if (qmode == 2)
+            simt::launch({grid, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_dict_g(src, units, slots, nRec, dv, seqs, lits, metas, pq, pg, gtabBytes); }, osThreads);
+        else
+            simt::launch({grid, 1, 1}, {64, 1, 1}, ldsB, [=] { zhip::k_parse_dict_q(src, units, slots, nRec, dv, seqs, lits, metas, pq); }, osThreads);
+    } else
     if (extIdx.size() < nRec)
-        simt::launch({nRec, 1, 1}, {64, 1, 1}, cd.cp.strategy == 1 ? zhip::dict_fast_lds_bytes(mh) : zhip::dict_lds_bytes(mh, mc),
+        simt::launch({nRec, 1, 1}, {64, 1, 1}, ldsB,
                      [=] { zhip::k_parse_dict(src, units, slots, nRec, dv, seqs, lits, metas); }, osThreads);
     if (!extIdx.empty()) {                                     // copy mode (sources above the attach cut-off), like the host library launches it
         uint32_t const nExt = (uint32_t)extIdx.size();

@@ -125,6 +125,17 @@ def test_hashchain_parse_skip_regions_then_matches(libs, level):
 
 def test_dict_records_parse_like_the_oracle(libs):
     """k_parse_dict (dfast with an attached dictionary) on the emulator vs the oracle's dictMatchState restatement"""
+    _dict_records_check(libs)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_dict_records_queue_forms_on_the_emulator(libs, monkeypatch, mode):
+    """the records stage as a ticket queue: k_parse_dict_q (tables in LDS) and k_parse_dict_g (tables in global memory, ballot hash groups)"""
+    monkeypatch.setenv("ZHIP_EMU_DICT_QUEUE", str(mode))
+    _dict_records_check(libs, cases=(("text", 3), ("datagen", 3), ("text", 1), ("text", -3)))
+
+
+def _dict_records_check(libs, cases=(("text", 3), ("datagen", 3), ("text", 4), ("text", 1), ("datagen", 1), ("text", 2), ("text", -3))):
     lo, le = libs
     from _libs import datagen, text_like
     lo.zo_cdict_create.restype = C.c_void_p
@@ -135,7 +146,7 @@ def test_dict_records_parse_like_the_oracle(libs):
     le.emu_parse_dict.restype = C.c_int
     le.emu_parse_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
     rng = np.random.default_rng(5)
-    for kind, level in (("text", 3), ("datagen", 3), ("text", 4), ("text", 1), ("datagen", 1), ("text", 2), ("text", -3)):
+    for kind, level in cases:
         corpus = text_like(200000, 3) if kind == "text" else datagen(lo, 200000, 60, 3)
         dict_ = corpus[:110000 if level in (3, 1) else 60000].copy()
         recs = []

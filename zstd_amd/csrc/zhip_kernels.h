@@ -238,6 +238,32 @@ k_parse_lane(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 
 // Stage 1 for records compressed with an attached dictionary (strategies fast and dfast), one wavefront per record.
 // Dynamic LDS = max(dict_lds_bytes(hashLog, chainLog), dict_fast_lds_bytes(hashLog)) over the records.
+template <bool GLOB>
+__device__ __forceinline__ void parse_dict_record(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t ui,
+                                                  const ZhipCDictDev& cd, unsigned char* tabmem, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+{
+    ZhipUnit const u = units[ui];
+    if (u.pad0 == ZHIP_UNIT_COPYMODE) return;             // above the attach cut-off: k_parse_ext's
+    const uint8_t* const p = src + u.srcOff;
+    ZhipSlot const sl = slots[ui];
+    if (u.strategy == ZHIP_STRAT_FAST) {
+        switch (u.minMatch) {
+        case 5:  parse_fast_dms_unit<5, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        case 6:  parse_fast_dms_unit<6, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        case 7: case 8: parse_fast_dms_unit<7, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        default: parse_fast_dms_unit<4, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+        }
+        return;
+    }
+    if (u.strategy != ZHIP_STRAT_DFAST) return;
+    switch (u.minMatch) {
+    case 5:  parse_dfast_dms_unit<5, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 6:  parse_dfast_dms_unit<6, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 7:  parse_dfast_dms_unit<7, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    case 8:  parse_dfast_dms_unit<8, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    default: parse_dfast_dms_unit<4, GLOB>(p, u.srcLen, u, cd, tabmem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    }
+}
 __global__ void __launch_bounds__(64)
 k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
@@ -245,26 +271,46 @@ k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
-    ZhipUnit const u = units[ui];
-    if (u.pad0 == ZHIP_UNIT_COPYMODE) return;             // above the attach cut-off: k_parse_ext's
-    const uint8_t* const p = src + u.srcOff;
-    ZhipSlot const sl = slots[ui];
-    if (u.strategy == ZHIP_STRAT_FAST) {
-        switch (u.minMatch) {
-        case 5:  parse_fast_dms_unit<5>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-        case 6:  parse_fast_dms_unit<6>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-        case 7: case 8: parse_fast_dms_unit<7>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-        default: parse_fast_dms_unit<4>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+    parse_dict_record<false>(src, units, slots, ui, cd, smem, seqs, lits, metas);
+}
+// The same stage as a ticket queue (ZHIP_DICT_TICKET records per ticket: ten million records on one counter): persistent wavefronts
+// with the record's tables in LDS (k_parse_dict_q, as many as the LDS admits) and, beside them on the same CUs, persistent wavefronts with
+// the tables in a per-wavefront region of global memory (k_parse_dict_g: `gtabs + blockIdx.x * gtabBytes`) — the stage is a chain of
+// dependent round trips per match, so what it lacks is wavefronts in flight, and 62 registers admit three times what the LDS does.
+#define ZHIP_DICT_TICKET 8u
+__global__ void __launch_bounds__(64)
+k_parse_dict_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+               ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, uint32_t* __restrict__ queue)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    for (;;) {
+        uint32_t t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, ZHIP_DICT_TICKET);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= nUnits) return;
+        uint32_t const tEnd = t + ZHIP_DICT_TICKET < nUnits ? t + ZHIP_DICT_TICKET : nUnits;
+        for (uint32_t ui = t; ui < tEnd; ui++) {
+            parse_dict_record<false>(src, units, slots, ui, cd, smem, seqs, lits, metas);
+            __builtin_amdgcn_wave_barrier();
         }
-        return;
     }
-    if (u.strategy != ZHIP_STRAT_DFAST) return;
-    switch (u.minMatch) {
-    case 5:  parse_dfast_dms_unit<5>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-    case 6:  parse_dfast_dms_unit<6>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-    case 7:  parse_dfast_dms_unit<7>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-    case 8:  parse_dfast_dms_unit<8>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
-    default: parse_dfast_dms_unit<4>(p, u.srcLen, u, cd, smem, seqs + sl.seqOff, lits + sl.litOff, metas + ui); break;
+}
+__global__ void __launch_bounds__(64)
+k_parse_dict_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+               ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, uint32_t* __restrict__ queue,
+               unsigned char* __restrict__ gtabs, uint32_t gtabBytes)
+{
+    unsigned char* const gtab = gtabs + (size_t)blockIdx.x * gtabBytes;
+    for (;;) {
+        uint32_t t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, ZHIP_DICT_TICKET);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= nUnits) return;
+        uint32_t const tEnd = t + ZHIP_DICT_TICKET < nUnits ? t + ZHIP_DICT_TICKET : nUnits;
+        for (uint32_t ui = t; ui < tEnd; ui++) {
+            parse_dict_record<true>(src, units, slots, ui, cd, gtab, seqs, lits, metas);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 

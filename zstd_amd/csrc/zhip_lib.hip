@@ -27,6 +27,9 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #ifndef ZHIP_FAST_ORDER_DEFAULT
 #define ZHIP_FAST_ORDER_DEFAULT 1
 #endif
+#ifndef ZHIP_DICT_GWAVES_DEFAULT
+#define ZHIP_DICT_GWAVES_DEFAULT 16
+#endif
 #ifndef ZHIP_FAST_GWAVES_DEFAULT
 #define ZHIP_FAST_GWAVES_DEFAULT 3
 #endif
@@ -80,6 +83,7 @@ struct zhip_ctx_s {
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
     int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
+    int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
@@ -206,6 +210,8 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
         c->fastOrder = (e = getenv("ZHIP_FAST_ORDER")) ? atoi(e) : ZHIP_FAST_ORDER_DEFAULT;
         c->fastGWaves = (e = getenv("ZHIP_FAST_GWAVES")) ? atoi(e) : ZHIP_FAST_GWAVES_DEFAULT;
         if (c->fastGWaves < 0) c->fastGWaves = 0;
+        c->dictQueue = (e = getenv("ZHIP_DICT_QUEUE")) ? atoi(e) : 1;
+        c->dictGWaves = (e = getenv("ZHIP_DICT_GWAVES")) ? atoi(e) : ZHIP_DICT_GWAVES_DEFAULT;
         if (c->fastGWaves > 16) c->fastGWaves = 16;
         hipDeviceProp_t prop;
         c->numCUs = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -1109,9 +1115,38 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nRec * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
         if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         HIPCHK(c, hipEventRecord(c->ev[0], s));
-        if (extIdx.size() < nRec)
+        if (extIdx.size() < nRec) {
+            // queue form (like the ZSTD_fast stage's): LDS-table wavefronts on this stream, global-table wavefronts beside them on coStream
+            int perCU = 0;
+            if (c->dictQueue && nRec > 1 &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)zhip::k_parse_dict_q, 64, smem) == hipSuccess && perCU >= 1 &&
+                (size_t)perCU * (size_t)c->numCUs * ZHIP_DICT_TICKET < nRec) {
+                size_t const gridQ = (size_t)perCU * (size_t)c->numCUs;
+                int gw = c->dictGWaves; if (gw > 32 - perCU) gw = 32 - perCU; if (gw < 0) gw = 0;
+                size_t gridG = (size_t)gw * (size_t)c->numCUs;
+                size_t const gtabFast = (fam & 1) ? (size_t)(2u << mhFast) : 0, gtabDfast = (fam & 2) ? (size_t)(2u << mhL) + (size_t)(2u << mhS) : 0;
+                size_t const gtabBytes = ((gtabFast > gtabDfast ? gtabFast : gtabDfast) + 255) & ~(size_t)255;
+                if (gridG && c->gtabsCap * sizeof(uint32_t) < gridG * gtabBytes) {
+                    (void)hipFree(c->dGTabs); c->dGTabs = nullptr; c->gtabsCap = 0;
+                    if (hipMalloc((void**)&c->dGTabs, gridG * gtabBytes) != hipSuccess) { (void)hipGetLastError(); gridG = 0; }
+                    else c->gtabsCap = gridG * gtabBytes / sizeof(uint32_t);
+                }
+                HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));
+                if (gridG) HIPCHK(c, hipEventRecord(c->coEv[0], s));
+                hipLaunchKernelGGL(zhip::k_parse_dict_q, dim3((unsigned)gridQ), dim3(64), smem, s,
+                                   (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse, c->dQueue);
+                if (gridG) {
+                    HIPCHK(c, hipStreamWaitEvent(c->coStream, c->coEv[0], 0));
+                    hipLaunchKernelGGL(zhip::k_parse_dict_g, dim3((unsigned)gridG), dim3(64), 0, c->coStream,
+                                       (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse, c->dQueue,
+                                       (unsigned char*)c->dGTabs, (uint32_t)gtabBytes);
+                    HIPCHK(c, hipEventRecord(c->coEv[1], c->coStream));
+                    HIPCHK(c, hipStreamWaitEvent(s, c->coEv[1], 0));
+                }
+            } else
             hipLaunchKernelGGL(zhip::k_parse_dict, dim3((unsigned)nRec), dim3(64), smem, s,
                                (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nRec, dv, c->dSeqs, c->dLits, c->dParse);
+        }
         HIPCHK(c, hipGetLastError());
         if (!extIdx.empty()) {                                  // copy mode: private table copies + one lane per source
             size_t const nExt = extIdx.size();

@@ -126,7 +126,31 @@ __device__ inline void wave_extend_dict(const uint8_t* src, uint32_t n, uint32_t
     if (dPos + fwd == dictLen && ipPos + fwd < n) fwd += wave_count_cross(src + ipPos + fwd, n - ipPos - fwd, src, n);
 }
 
-template <uint32_t MLS>
+// Where a record's own tables live: LDS (16-bit entries, the few KB a record needs: about ten records per CU at the 14 KB the ~1.5 KB
+// records of a github-users-like batch ask for) or, for the wavefronts that run BESIDE those on a CU whose LDS is full
+// (k_parse_dict_g, 62 registers leave room for three times as many), a per-wavefront region of global memory.  The global form has no
+// LDS scratch either: lanes that hash alike are found with one ballot per hash bit (wave_hash_group).
+template <bool GLOB> struct DictTabPtr { typedef lds_u16* type; };
+template <> struct DictTabPtr<true> { typedef uint16_t* type; };
+// exact groups (masks of live lanes with equal key; 0 for a lane alone with its key) + whether any exists
+template <bool GLOB>
+__device__ __forceinline__ unsigned long long dict_groups(uint32_t key, uint32_t bits, bool live, unsigned long long liveMask, lds_u8* scr)
+{
+    if constexpr (GLOB) {
+        unsigned long long g = wave_hash_group(key, bits) & liveMask;
+        if (!live || !(g & (g - 1))) g = 0;
+        return __ballot(g != 0) ? g : 0ull;
+    } else {
+        uint32_t const sl = key & (ZHIP_DF_SCRATCH - 1);
+        if (live) scr[sl] = (uint8_t)lane_id();
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long const lose = __ballot(live && scr[sl] != (uint8_t)lane_id());
+        __builtin_amdgcn_wave_barrier();
+        return lose ? lane_groups(key, lose, liveMask) : 0ull;
+    }
+}
+
+template <uint32_t MLS, bool GLOB = false>
 __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipCDictDev& cd,
                                             unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
@@ -137,12 +161,19 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
     const uint8_t* const dict = cd.content;
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
-    lds_u16* const tabL = (lds_u16*)(uintptr_t)smem;                                     // position + 1, 0 = empty
-    lds_u16* const tabS = (lds_u16*)(uintptr_t)(smem + (2u << u.hashLog));
-    lds_u8* const scrL = (lds_u8*)(uintptr_t)(smem + (2u << u.hashLog) + (2u << u.chainLog));
-    lds_u8* const scrS = scrL + ZHIP_DF_SCRATCH;
-    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = ((2u << u.hashLog) + (2u << u.chainLog)) >> 2;
+    typedef typename DictTabPtr<GLOB>::type TabP;
+    TabP tabL, tabS; lds_u8* scrL = nullptr; lds_u8* scrS = nullptr;                      // entries: position + 1, 0 = empty
+    uint32_t const words = ((2u << u.hashLog) + (2u << u.chainLog)) >> 2;
+    if constexpr (GLOB) {
+        tabL = (uint16_t*)smem; tabS = (uint16_t*)(smem + (2u << u.hashLog));
+        uint32_t* const z = (uint32_t*)smem;
+        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+    } else {
+        tabL = (lds_u16*)(uintptr_t)smem;
+        tabS = (lds_u16*)(uintptr_t)(smem + (2u << u.hashLog));
+        scrL = (lds_u8*)(uintptr_t)(smem + (2u << u.hashLog) + (2u << u.chainLog));
+        scrS = scrL + ZHIP_DF_SCRATCH;
+        lds_u32* const z = (lds_u32*)(uintptr_t)smem;
         for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
@@ -185,27 +216,20 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
             uint32_t const oldL = live ? (uint32_t)tabL[hl] : 0, oldS = live ? (uint32_t)tabS[hs] : 0;
             uint32_t const dEL = live ? cd.tabL[dHTL >> 8] : 0, dES = live ? cd.tabS[dHTS >> 8] : 0;
             uint32_t const rv = pre ? nbRv : ld32(rep_ptr(pc + 1, off1));
-            uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
-            if (live) { scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane; }
-            __builtin_amdgcn_wave_barrier();
-            unsigned long long const loseL = __ballot(live && scrL[sl] != (uint8_t)lane);
-            unsigned long long const loseS = __ballot(live && scrS[ss] != (uint8_t)lane);
-            __builtin_amdgcn_wave_barrier();
-
             // record-side candidates (position + 1), with the inserts of earlier lanes of this batch
             uint32_t candL = oldL, candS = oldS;
             uint64_t cbL = oldL ? ld64(src + (oldL - 1)) : ~bytes;
             uint32_t cbS = oldS >= 2 ? ld32(src + (oldS - 1)) : ~(uint32_t)bytes;
-            unsigned long long grpL = 0, grpS = 0;
-            if (loseL) {
-                grpL = lane_groups(hl, loseL, liveMask);
+            unsigned long long const grpL = dict_groups<GLOB>(hl, u.hashLog, live, liveMask, scrL);
+            unsigned long long const grpS = dict_groups<GLOB>(hs, u.chainLog, live, liveMask, scrS);
+            unsigned long long const loseL = grpL, loseS = grpS;                 // (a lane's own group: nonzero = it has company)
+            if (__ballot(loseL != 0)) {
                 unsigned long long const prev = grpL & below_mask((int)lane);
                 uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
                 uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd), dhi = __shfl((uint32_t)(bytes >> 32), (int)pd);
                 if (prev) { candL = dp + 1; cbL = ((uint64_t)dhi << 32) | dlo; }
             }
-            if (loseS) {
-                grpS = lane_groups(hs, loseS, liveMask);
+            if (__ballot(loseS != 0)) {
                 unsigned long long const prev = grpS & below_mask((int)lane);
                 uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
                 uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd);
@@ -392,7 +416,7 @@ __device__ inline void parse_dfast_dms_unit(const uint8_t* __restrict__ src, uin
 // noDict dfast loop (step grows every 256 bytes without a match, :618-625), so the batching is the one of zhip_parse_dfast.h.
 __host__ __device__ inline uint32_t dict_fast_lds_bytes(uint32_t hashLog) { return (2u << hashLog) + ZHIP_DF_SCRATCH; }
 
-template <uint32_t MLS>
+template <uint32_t MLS, bool GLOB = false>
 __device__ inline void parse_fast_dms_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const ZhipCDictDev& cd,
                                            unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
@@ -403,10 +427,17 @@ __device__ inline void parse_fast_dms_unit(const uint8_t* __restrict__ src, uint
     const uint8_t* const dict = cd.content;
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
-    lds_u16* const tab = (lds_u16*)(uintptr_t)smem;                                      // position + 1, 0 = empty
-    lds_u8* const scr = (lds_u8*)(uintptr_t)(smem + (2u << u.hashLog));
-    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = (2u << u.hashLog) >> 2;
+    typedef typename DictTabPtr<GLOB>::type TabP;
+    TabP tab; lds_u8* scr = nullptr;                                                      // entries: position + 1, 0 = empty
+    uint32_t const words = (2u << u.hashLog) >> 2;
+    if constexpr (GLOB) {
+        tab = (uint16_t*)smem;
+        uint32_t* const z = (uint32_t*)smem;
+        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
+    } else {
+        tab = (lds_u16*)(uintptr_t)smem;
+        scr = (lds_u8*)(uintptr_t)(smem + (2u << u.hashLog));
+        lds_u32* const z = (lds_u32*)(uintptr_t)smem;
         for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
@@ -441,16 +472,10 @@ __device__ inline void parse_fast_dms_unit(const uint8_t* __restrict__ src, uint
             uint32_t const old = live ? (uint32_t)tab[h] : 0;
             uint32_t const dE = live ? cd.tabL[dHT >> 8] : 0;
             uint32_t const rv = ld32(rep_ptr(pc + 1, off1));
-            uint32_t const ss = h & (ZHIP_DF_SCRATCH - 1);
-            if (live) scr[ss] = (uint8_t)lane;
-            __builtin_amdgcn_wave_barrier();
-            unsigned long long const lose = __ballot(live && scr[ss] != (uint8_t)lane);
-            __builtin_amdgcn_wave_barrier();
             uint32_t cand = old;
             uint32_t cb = old ? ld32(src + (old - 1)) : ~(uint32_t)bytes;
-            unsigned long long grp = 0;
-            if (lose) {
-                grp = lane_groups(h, lose, liveMask);
+            unsigned long long const grp = dict_groups<GLOB>(h, u.hashLog, live, liveMask, scr);
+            if (__ballot(grp != 0)) {
                 unsigned long long const prev = grp & below_mask((int)lane);
                 uint32_t const pd = prev ? 63u - (uint32_t)__clzll((long long)prev) : lane;
                 uint32_t const dp = __shfl(p, (int)pd), dlo = __shfl((uint32_t)bytes, (int)pd);
