@@ -525,3 +525,57 @@ def oracle_records_cdict(lo, d, recs, level, row):
         return out
     finally:
         lo.zo_set_row_matcher(0)
+
+
+def row_log_of(cp, row):
+    """ZSTD_resolveRowMatchFinderMode + rowLog (zstd_compress.c:237-253, :2042): 0 = the hash chain"""
+    if not row or cp[0] <= 14 or not 3 <= cp[6] <= 5:
+        return 0
+    return min(max(cp[3], 4), 6)
+
+
+def emu_compress_frames_lazy(le, lo, bufs, cps, row, checksum=False, threads=0):
+    """k_lz_links + k_lz_search + k_frame_lazy on the emulator: one multi-block frame per input with the lazy strategies;
+    cps[i] = effective parameters of frame i [windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy]"""
+    sizes = [len(b) for b in bufs]
+    nf = len(bufs)
+    units = np.zeros(nf, dtype=UNIT_DT)
+    off = 0
+    for i, (n, cp) in enumerate(zip(sizes, cps)):
+        units[i] = (off, n, cp[0], cp[1], cp[2], cp[4], cp[6], cp[3], 0, 0, cp[5], row_log_of(cp, row), 0)
+        off += n
+    src = np.concatenate(list(bufs) + [np.zeros(16, dtype=np.uint8)])
+    ostride = (max(sizes) + (max(sizes) >> 8) + 2048 + 15) & ~15
+    out = np.full(nf * ostride, 0xEE, dtype=np.uint8); osz = np.zeros(nf, dtype=np.uint32)
+    chk = None
+    if checksum:
+        chk = np.zeros(nf + 16, dtype=np.uint32)
+        le.emu_xxh64_wave.restype = None
+        le.emu_xxh64_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64_wave(_buf(src), _buf(units), nf, _buf(chk), 0)
+    le.emu_frame_lazy.restype = None
+    le.emu_frame_lazy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    le.emu_frame_lazy(_buf(src), _buf(units), None, nf, _buf(out), ostride, _buf(osz), _buf(chk) if checksum else None, threads)
+    return [out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nf)]
+
+
+def emu_compress_frame_jobs_lazy(le, lo, a, cp, row, job_size=0, overlap_log=0, checksum=False, threads=0):
+    """one frame of a lazy strategy as parallel jobs (ZSTD_c_nbWorkers semantics) on the emulator; returns the frame bytes"""
+    n = len(a)
+    units, jobs, cp = make_jobs(lo, n, 0, job_size, overlap_log, cp)
+    units["rowLog"] = row_log_of(cp, row)
+    src = np.concatenate([a, np.zeros(16, dtype=np.uint8)])
+    nj = len(units)
+    ostride = (int(units["srcLen"].max()) + (int(units["srcLen"].max()) >> 8) + 2048 + 15) & ~15
+    out = np.full(nj * ostride, 0xEE, dtype=np.uint8); osz = np.zeros(nj, dtype=np.uint32)
+    chk = None
+    if checksum:
+        whole = np.zeros(1, dtype=UNIT_DT); whole[0] = units[0]; whole[0]["srcLen"] = n
+        chk = np.zeros(17, dtype=np.uint32)
+        le.emu_xxh64_wave.restype = None
+        le.emu_xxh64_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        le.emu_xxh64_wave(_buf(src), _buf(whole), 1, _buf(chk), 0)
+    le.emu_frame_lazy.restype = None
+    le.emu_frame_lazy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    le.emu_frame_lazy(_buf(src), _buf(units), _buf(jobs), nj, _buf(out), ostride, _buf(osz), _buf(chk) if checksum else None, threads)
+    return b"".join(out[i * ostride: i * ostride + int(osz[i])].tobytes() for i in range(nj))

@@ -255,6 +255,37 @@ void emu_frame_jobs(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
     simt::launch({nJobs, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lds_bytes(ldsTab),
                  [=] { zhip::k_frame_fast(src, units, slots, nJobs, tb, tabStride, sq, lt, sb, out, outSize, stp, checks, jobs); }, osThreads);
 }
+// multi-block frames / jobs of the lazy strategies (zhip_frame_lazy.h): units[i] (+ jobs[i], or jobs == nullptr for whole frames);
+// the three launches of the host library, in order
+void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJob* jobs, uint32_t nW, uint8_t* out, uint64_t outStride,
+                    uint32_t* outSize, const uint32_t* checks, int osThreads)
+{
+    std::vector<ZhipSlot> sv(nW ? nW : 1);
+    std::vector<zhip::ZhipLzSlot> lv(nW ? nW : 1);
+    uint64_t posTotal = 0, headTotal = 0; uint32_t longest = 1;
+    for (uint32_t i = 0; i < nW; i++) {
+        sv[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; sv[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; sv[i].outOff = (uint64_t)i * outStride; sv[i].seqCap = ZHIP_SEQ_CAP; sv[i].pad0 = 0;
+        zhip::lz_fill_slot(lv[i], units[i], jobs ? jobs[i].prefixLen : 0u, posTotal, headTotal);
+        if (units[i].srcLen > longest) longest = units[i].srcLen;
+    }
+    const ZhipSlot* const slots = sv.data(); const zhip::ZhipLzSlot* const lz = lv.data();
+    std::vector<ZhipSeq> seqs((size_t)nW * ZHIP_SEQ_CAP); std::vector<uint8_t> lits((size_t)nW * ZHIP_LIT_STRIDE);
+    std::vector<uint16_t> stBits((size_t)nW * ZHIP_SEQ_CAP * 3);
+    std::vector<uint32_t> prev(posTotal + 16, 0xDDDDDDDDu), heads(headTotal + 16, 0xDDDDDDDDu);
+    std::vector<uint8_t> tags(posTotal + 16, 0xDD);
+    std::vector<zhip::LzRec> best(posTotal + 16);
+    memset(best.data(), 0xDD, best.size() * sizeof(zhip::LzRec));
+    std::vector<zhip::ZhipFrameState> states(nW ? nW : 1);
+    ZhipSeq* const sq = seqs.data(); uint8_t* const lt = lits.data(); uint16_t* const sb = stBits.data();
+    uint32_t* const pv = prev.data(); uint32_t* const hd = heads.data(); uint8_t* const tg = tags.data(); zhip::LzRec* const bs = best.data();
+    zhip::ZhipFrameState* const stp = states.data();
+    simt::launch({nW, 1, 1}, {ZHIP_LZ_LINK_THREADS, 1, 1}, sizeof(zhip::LzLinkShared),
+                 [=] { zhip::k_lz_links(src, units, jobs, lz, nW, pv, tg, hd); }, osThreads);
+    simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0,
+                 [=] { zhip::k_lz_search(src, units, jobs, lz, nW, pv, tg, bs); }, osThreads);
+    simt::launch({nW, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lazy_lds_bytes(),
+                 [=] { zhip::k_frame_lazy(src, units, slots, jobs, lz, nW, pv, tg, bs, hd, sq, lt, sb, out, outSize, stp, checks); }, osThreads);
+}
 uint32_t emu_sizeof_job(void) { return (uint32_t)sizeof(zhip::ZhipJob); }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }

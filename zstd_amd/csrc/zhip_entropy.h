@@ -369,6 +369,27 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
     return __shfl(fin, (int)(grp * G + used - 1));                            // the group's lowest slice holds the final state
 }
 
+// ZSTD_fseBitCost (zstd_compress_sequences.c:103-135) with FSE_bitCost (lib/common/fse.h:494-509): the cost in bits of coding the
+// histogram (lane = symbol, myCnt = its count, max = the largest symbol present) with a previous table; ~0 when a symbol that occurs
+// has no cell in it (its transform is the zero-probability one: the "bad" cost).  Wave-wide, the same value in every lane.
+__device__ inline uint64_t fse_bit_cost_wave(const FseCTable* __restrict__ ct, uint32_t myCnt, uint32_t max)
+{
+    uint32_t const lane = tw_lane();
+    uint32_t const tableLog = ct->tableLog, badCost = (tableLog + 1) << 8;
+    uint32_t cost = 0; bool bad = false;
+    if (lane <= max && lane < 56 && myCnt != 0) {
+        uint32_t const dBits = ct->dBits[lane];
+        uint32_t const minNbBits = dBits >> 16, threshold = (minNbBits + 1) << 16;
+        uint32_t const deltaFromThreshold = threshold - (dBits + (1u << tableLog));
+        uint32_t const normalized = (deltaFromThreshold << 8) >> tableLog;
+        uint32_t const bitCost = (minNbBits + 1) * 256 - normalized;
+        bad = bitCost >= badCost;
+        cost = myCnt * bitCost;
+    }
+    if (__ballot(bad)) return ~0ull;
+    return (uint64_t)(tw_sum(cost) >> 8);
+}
+
 // ================================================================== the block encoder
 // Literals section + sequences section of one block (ZSTD_entropyCompressSeqStore, zstd_compress.c:3000-3050) into body[];
 // returns the compressed size, or 0 when the block has to be emitted uncompressed (same value in every thread).  n >= 7.
@@ -551,7 +572,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 }
                 uint32_t const ecost = tw_sum(mineE);
                 uint64_t const compressedCost = ((uint64_t)ncountCost << 3) + (ecost >> 8);
-                type = basicCost <= compressedCost ? 0 : 2;                            // :217-222
+                // :212 the previous block's table (multi-block frames of the lazy strategies, zhip_frame_lazy.h): ZSTD_fseBitCost
+                uint64_t const repeatCost = (de && de->fseRepeat[k] != 0) ? fse_bit_cost_wave(&de->ct[k], myCnt, max) : ~0ull;
+                if (basicCost <= repeatCost && basicCost <= compressedCost) type = 0;  // :217-222
+                else if (repeatCost <= compressedCost) type = 3;                       // :223-227 set_repeat, the table's state stays
+                else type = 2;
             }
             if (type == 3) {           // zstd_compress_sequences.c:264-266: the previous table as it is, no header bytes
                                        // (copied below by the whole wavefront)

@@ -10,6 +10,7 @@
 #include "zhip_parse_lane.h"
 #include "zhip_entropy.h"
 #include "zhip_frame.h"
+#include "zhip_frame_lazy.h"
 #include "zhip_decode.h"
 
 // register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
@@ -521,6 +522,69 @@ __global__ void k_frame_sizes(const uint32_t* __restrict__ outSize, const ZhipJo
 {
     uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nJobs) atomicAdd(frameSizes + jobs[i].frameIdx, outSize[i]);
+}
+
+// Multi-block frames / jobs of the strategies greedy, lazy, lazy2 (zhip_frame_lazy.h), three launches over the same workgroup-units:
+// lz[i] says where unit i's links / tags / records / head table live; jobs as in k_frame_fast (nullptr: whole frames).
+// the start of unit i's window in the source
+__device__ __forceinline__ const uint8_t* lz_window(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipJob* __restrict__ jobs, uint32_t i)
+{
+    return src + u.srcOff + (jobs ? (size_t)(jobs[i].start - jobs[i].prefixLen) : (size_t)0);
+}
+// k_lz_links: dynamic LDS = sizeof(LzLinkShared)
+__global__ void __launch_bounds__(ZHIP_LZ_LINK_THREADS)
+k_lz_links(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t nW,
+           uint32_t* __restrict__ prev, uint8_t* __restrict__ tags, uint32_t* __restrict__ heads)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const wi = blockIdx.x;
+    if (wi >= nW) return;
+    ZhipUnit const u = units[wi];
+    ZhipLzSlot const L = lz[wi];
+    const uint8_t* const p = lz_window(src, u, jobs, wi);
+    LzLinkShared* const sh = (LzLinkShared*)smem;
+    switch (lz_mls(u)) {
+    case 5:  lz_links_t<5>(p, u, L, sh, prev + L.posOff, tags + L.posOff, heads + L.headOff); break;
+    case 6:  lz_links_t<6>(p, u, L, sh, prev + L.posOff, tags + L.posOff, heads + L.headOff); break;
+    default: lz_links_t<4>(p, u, L, sh, prev + L.posOff, tags + L.posOff, heads + L.headOff); break;
+    }
+}
+// k_lz_search: grid (ceil(longest section / 256), nW); one thread per position of the unit's section
+__global__ void __launch_bounds__(256)
+k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t nW,
+            const uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, LzRec* __restrict__ best)
+{
+    uint32_t const wi = blockIdx.y;
+    if (wi >= nW) return;
+    ZhipUnit const u = units[wi];
+    ZhipLzSlot const L = lz[wi];
+    uint32_t const j0 = jobs ? jobs[wi].prefixLen : 0u;
+    uint32_t const p = j0 + blockIdx.x * 256u + threadIdx.x;
+    if (L.span < 9 || p > L.span - 8) return;
+    const uint8_t* const w = lz_window(src, u, jobs, wi);
+    uint32_t const maxDist = 1u << u.windowLog, lowLimit = p > maxDist ? p - maxDist : 0u;
+    best[L.posOff + p] = u.rowLog ? lz_search_rh(w, L.span, p, prev + L.posOff, tags + L.posOff, u.searchLog, u.rowLog, lowLimit)
+                                  : lz_search_hc(w, L.span, p, prev + L.posOff, u.searchLog, u.chainLog, lowLimit);
+}
+// k_frame_lazy: dynamic LDS = frame_lazy_lds_bytes()
+__global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)
+k_frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, const ZhipJob* __restrict__ jobs,
+             const ZhipLzSlot* __restrict__ lz, uint32_t nW, uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, const LzRec* __restrict__ best,
+             uint32_t* __restrict__ heads, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
+             uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states, const uint32_t* __restrict__ checks)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const wi = blockIdx.x;
+    if (wi >= nW) return;
+    ZhipUnit const u = units[wi];
+    ZhipSlot const sl = slots[wi];
+    ZhipLzSlot const L = lz[wi];
+    EntShared* const sh = (EntShared*)smem;
+    LzFrameShared* const fs = (LzFrameShared*)(smem + ((sizeof(EntShared) + 15) & ~(size_t)15));
+    const ZhipJob* const job = jobs ? jobs + wi : (const ZhipJob*)nullptr;
+    bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[wi].frameIdx : wi] : 0u;
+    frame_lazy(lz_window(src, u, jobs, wi), u, L, prev + L.posOff, tags + L.posOff, best + L.posOff, heads + L.headOff,
+               seqs + sl.seqOff, lits + sl.litOff, stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + wi, sh, fs, states + wi, ck, cv, job);
 }
 
 // Frame checksum (ZSTD_c_checksumFlag): XXH64 of each unit's content, low 32 bits (zstd_compress.c:5297-5303).  XXH64 has four
