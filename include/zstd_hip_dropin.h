@@ -26,17 +26,18 @@
  *                       `zstd -b<level> -B128K` chunking, but it is NOT the reference's single shared-window frame.
  *                       ZSTD_getFrameContentSize() of the stream reports the first unit only; use
  *                       ZSTD_findDecompressedSize() (lib/zstd.h:1492) for the total.
- *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and strategy ZSTD_fast or ZSTD_dfast (the default
- *                       level 3, levels 1-2 and 4 by size class, negative levels) the output IS the reference's single frame, byte for byte: one frame header,
- *                       128 KB / 92 KB blocks sharing the window, the hash table, the repcodes and the Huffman table
- *                       (zstd_compress.c:4520-4640; zhip_compress_frames).  The block chain of one frame is serial — one
- *                       workgroup — so this is the fidelity mode, not the throughput mode; other strategies keep the
- *                       frame-per-unit stream.
+ *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and any strategy up to ZSTD_lazy2 (levels -N .. 12)
+ *                       the output IS the reference's single frame, byte for byte: one frame header,
+ *                       128 KB / 92 KB blocks (ZSTD_lazy2: the fingerprint splitter's borders) sharing the window, the match
+ *                       finder's table (hash table, hash chain or rows), the repcodes, the Huffman table and — greedy and above —
+ *                       the FSE tables (zstd_compress.c:4520-4640; zhip_compress_frames).  The block chain of one frame is
+ *                       serial — one workgroup — so this is the fidelity mode, not the throughput mode; strategies above
+ *                       lazy2 are parameter_unsupported.
  *                       With ZSTD_c_nbWorkers >= 1 (and ZSTD_c_jobSize / ZSTD_c_overlapLog) and a source above 512 KB the output is
  *                       the reference's multi-threaded frame, byte for byte (lib/compress/zstdmt_compress.c: jobs of the job size,
  *                       each with the overlap as prefix; the bytes do not depend on the worker count) — jobs are independent, a
  *                       workgroup each, so this mode is both the reference's bytes and parallel inside one frame
- *                       (zhip_compress_frames_mt).  Same strategies as ZHIP_c_singleFrame; others keep the frame-per-unit stream.
+ *                       (zhip_compress_frames_mt).  Same strategies as ZHIP_c_singleFrame.
  */
 #ifndef ZSTD_HIP_DROPIN_H
 #define ZSTD_HIP_DROPIN_H

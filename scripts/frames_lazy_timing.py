@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""scripts/frames_lazy_timing.py — multi-block frames of the lazy strategies (k_lz_links + k_lz_search + k_frame_lazy): device time of
+batches of 1 MiB frames and of one large job-pool frame, per level.  Prints one JSON line per configuration; run it under
+rocprofv3 --kernel-trace --stats for the split between the three kernels."""
+import json, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401  (HIP runtime first)
+import zstd_amd as z
+from _libs import text_like
+
+ctx = z.Context(max_units=1024)
+LEVELS = [int(x) for x in os.environ.get("LEVELS", "5,7").split(",")]
+for level in LEVELS:
+    for kind in ("datagen", "text"):
+        base = z.datagen(1 << 20, 50, 1) if kind == "datagen" else text_like(1 << 20, 1)
+        for nf in (256, 1024):
+            bufs = [base] * nf
+            for rep in range(2):
+                outs = ctx.compress_frames(bufs, level)
+            t = ctx.timing()
+            print(json.dumps({"level": level, "kind": kind, "frames": nf, "frame_bytes": 1 << 20, "timing_ms": t, "csize": len(outs[0])}), flush=True)
+    big = np.concatenate([z.datagen(64 << 20, 50, s) for s in range(4)])
+    for rep in range(2):
+        outs = ctx.compress_frames([big], level, workers=4)
+    t = ctx.timing()
+    print(json.dumps({"level": level, "kind": "datagen job-pool frame", "frames": 1, "frame_bytes": int(big.size), "timing_ms": t, "csize": len(outs[0])}), flush=True)

@@ -282,7 +282,7 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
     simt::launch({nW, 1, 1}, {ZHIP_LZ_LINK_THREADS, 1, 1}, sizeof(zhip::LzLinkShared),
                  [=] { zhip::k_lz_links(src, units, jobs, lz, nW, pv, tg, hd); }, osThreads);
     simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0,
-                 [=] { zhip::k_lz_search(src, units, jobs, lz, nW, pv, tg, bs); }, osThreads);
+                 [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs); }, osThreads);
     simt::launch({nW, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lazy_lds_bytes(),
                  [=] { zhip::k_frame_lazy(src, units, slots, jobs, lz, nW, pv, tg, bs, hd, sq, lt, sb, out, outSize, stp, checks); }, osThreads);
 }

@@ -1,0 +1,65 @@
+"""Multi-block frames and job-pool frames of the strategies greedy / lazy / lazy2 on the host SIMT emulator: k_lz_links + k_lz_search +
+k_frame_lazy (zstd_amd/csrc/zhip_frame_lazy.h) against the oracle's zo_compress_frame_params / zo_compress_frame_mt_params, which are
+pinned to the reference (tests/golden/frames_lazy_v1.json, test_oracle_vs_reference.py).  Both match finders: the row hash (the
+reference's default above windowLog 14) and the hash chain."""
+import numpy as np
+import pytest
+from _libs import *
+from _libs import _buf
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return load_oracle(), load_emu()
+
+
+def _cp(lo, level, n):
+    cp = (C.c_uint * 7)()
+    assert lo.zo_get_cparams(level, n, cp) == 0
+    return list(cp)
+
+
+def _cases(lo):
+    rng = np.random.default_rng(55)
+    return [("dg_150k", datagen(lo, 150000, 50, 5)),
+            ("mixed_310k", np.concatenate([datagen(lo, 70000, 50, 1), rng.integers(0, 256, size=90000, dtype=np.uint8),      # lazy skipping, raw blocks,
+                                           np.full(80000, 7, np.uint8), text_like(70000, 9)])),                                 # long matches (the 384 / 192 rule), splitter borders
+            ("tail_10", datagen(lo, 131072 + 10, 50, 9))]                                                                       # last block below the row matcher's guard
+
+
+@pytest.mark.parametrize("level,row", [(5, 1), (8, 0)])
+def test_lazy_frames_match_oracle(libs, level, row):
+    lo, le = libs
+    cases = _cases(lo)
+    bufs = [a for _, a in cases]
+    cps = [_cp(lo, level, len(a)) for a in bufs]
+    got = emu_compress_frames_lazy(le, lo, bufs, cps, row)
+    for (name, a), cp, g in zip(cases, cps, got):
+        assert cp[6] in (3, 4, 5)
+        assert g == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (name, level, row)
+
+
+@pytest.mark.parametrize("cp,row", [([17, 16, 17, 3, 5, 2, 4], 1), ([17, 17, 18, 4, 4, 16, 5], 0)])
+def test_lazy_frames_beyond_the_window(libs, cp, row):
+    """inputs larger than 2^windowLog: the window's low end moves with the blocks (candidates, repcodes, catch-up)"""
+    lo, le = libs
+    bufs = [datagen(lo, 270000, 70, 3)] if row else [datagen(lo, 300000, 70, 3), np.concatenate([datagen(lo, 140000, 50, 2)] * 2)]
+    got = emu_compress_frames_lazy(le, lo, bufs, [cp] * len(bufs), row)
+    for a, g in zip(bufs, got):
+        assert g == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (cp, row, len(a))
+
+
+@pytest.mark.parametrize("level,row,js,ov,ck", [(6, 1, 524288, 9, 1)])
+def test_lazy_job_pool_frames_match_oracle(libs, level, row, js, ov, ck):
+    """ZSTD_c_nbWorkers semantics: every job indexes its whole prefix (all positions but the last 8), starts with zero repcodes"""
+    lo, le = libs
+    rng = np.random.default_rng(8)
+    a = np.concatenate([datagen(lo, 250000, 50, 3), rng.integers(0, 256, size=40000, dtype=np.uint8), np.zeros(120000, np.uint8), text_like(150000, 6)])
+    cp = _cp(lo, level, len(a))
+    got = emu_compress_frame_jobs_lazy(le, lo, a, (C.c_uint * 7)(*cp), row, js, ov, bool(ck))
+    lo.zo_set_row_matcher(1 if row else 0)
+    try:
+        want = oracle_frame_mt(lo, a, 0, js, ov, ck, cp=(C.c_uint * 7)(*cp))
+    finally:
+        lo.zo_set_row_matcher(0)
+    assert got == want, (level, row, js, ov, ck)

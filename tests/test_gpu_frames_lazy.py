@@ -1,0 +1,115 @@
+"""-m gpu: multi-block frames and job-pool frames of the strategies greedy / lazy / lazy2 (levels 5-10; SURVEY.md §8f rank 1, the
+round-2 verdict's item 4).  zhip_compress_frames / zhip_compress_frames_mt and the shim's ZSTD_compress2 against the committed digests
+of the REAL reference's frames (tests/golden/frames_lazy_v1.json: 49 frames, the row matcher and the hash chain), the oracle, and —
+when oracle/_ref travelled — the reference itself with ZSTD_c_nbWorkers."""
+import ctypes as C
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from _libs import (load_oracle, load_ref, have_ref, lazy_frame_cases, LAZY_FRAME_MODES, oracle_frame_params, oracle_frame_mt, ref_frame_mt,
+                   datagen, text_like, _buf, ROOT, ERR)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "frames_lazy_v1.json")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import zstd_amd
+    zstd_amd.lib()
+    return zstd_amd, load_oracle()
+
+
+def test_lazy_frames_equal_the_reference_digests(env):
+    z, lo = env
+    gold = {(g["case"], g["level"], g["noRow"]): g for g in json.load(open(GOLD))["frames"]}
+    cases = list(lazy_frame_cases(lo))
+    ctx = z.Context(max_units=64)
+    seen = 0
+    for level, no_row in LAZY_FRAME_MODES:
+        ctx.set_row_matcher(2 if no_row else 0)
+        outs = ctx.compress_frames([a for _, a in cases], level)          # one batch: the frames run side by side
+        for (name, a), out in zip(cases, outs):
+            g = gold[(name, level, no_row)]
+            assert len(out) == g["csize"] and hashlib.sha256(out).hexdigest() == g["dst_sha256"], (name, level, no_row)
+            seen += 1
+    assert seen == len(gold)
+    d = z.DContext()
+    assert d.decompress(outs[0]) == cases[0][1].tobytes()
+
+
+def test_lazy_frames_explicit_parameters_and_small_windows(env):
+    """inputs larger than the window, both matchers, against the oracle (pinned to the reference by test_oracle_vs_reference.py)"""
+    z, lo = env
+    ctx = z.Context(max_units=64)
+    rng = np.random.default_rng(3)
+    bufs = [datagen(lo, 900000, 70, 3), np.concatenate([datagen(lo, 140000, 50, 2)] * 5), text_like(500000, 4),
+            np.concatenate([rng.integers(0, 256, size=200000, dtype=np.uint8), np.zeros(300000, np.uint8), datagen(lo, 200000, 30, 8)])]
+    for cp, row in (([17, 16, 17, 3, 5, 2, 3], 1), ([17, 15, 16, 4, 4, 8, 4], 0), ([17, 17, 18, 4, 5, 16, 5], 1), ([18, 17, 18, 5, 4, 32, 5], 0),
+                    ([19, 12, 13, 2, 6, 4, 4], 1)):
+        ctx.set_row_matcher(0 if row else 2)
+        outs = ctx.compress_frames(bufs, 5, cparams=cp)
+        for a, out in zip(bufs, outs):
+            assert out == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (cp, row, len(a))
+
+
+@pytest.mark.parametrize("level,no_row,js,ov,ck", [(5, 0, 0, 0, 0), (6, 1, 524288, 9, 1), (8, 0, 700000, 0, 0), (10, 1, 1 << 20, 3, 1)])
+def test_lazy_job_pool_frames(env, level, no_row, js, ov, ck):
+    """ZSTD_c_nbWorkers >= 1 at the lazy levels: a workgroup per job; against the oracle and, when it travelled, the reference"""
+    z, lo = env
+    ctx = z.Context(max_units=64)
+    ctx.set_row_matcher(2 if no_row else 0)
+    ctx.set_checksum(bool(ck))
+    rng = np.random.default_rng(9)
+    bufs = [datagen(lo, 5 << 20, 50, 15), text_like(3_000_000, 13),
+            np.concatenate([datagen(lo, 700000, 50, 1), rng.integers(0, 256, size=500000, dtype=np.uint8), np.full(600000, 7, np.uint8), text_like(800000, 9)])]
+    outs = ctx.compress_frames(bufs, level, workers=4, job_size=js, overlap_log=ov)
+    lr = load_ref() if have_ref() else None
+    for a, out in zip(bufs, outs):
+        lo.zo_set_row_matcher(0 if no_row else 1)
+        try:
+            want = oracle_frame_mt(lo, a, level, js, ov, ck)
+        finally:
+            lo.zo_set_row_matcher(0)
+        assert out == want, (level, no_row, js, ov, ck, len(a))
+        if lr is not None and not no_row:
+            assert out == ref_frame_mt(lr, a, level, js, ov, ck), ("reference", level, js, ov, ck, len(a))
+    assert z.DContext().decompress(outs[1]) == bufs[1].tobytes()
+
+
+def test_shim_compress2_lazy_levels_with_workers(env):
+    """the done-criterion: ZSTD_compress2 of the drop-in at levels 5-7 with nbWorkers >= 1 on >= 3 MB, byte-identical to the reference"""
+    z, lo = env
+    shim = C.CDLL(os.path.join(ROOT, "zstd_amd", "libzstd_hipshim.so"))
+    shim.ZSTD_createCCtx.restype = C.c_void_p
+    shim.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    shim.ZSTD_CCtx_setParameter.restype = C.c_size_t; shim.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    shim.ZSTD_compress2.restype = C.c_size_t; shim.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    shim.ZSTD_compressBound.restype = C.c_size_t; shim.ZSTD_compressBound.argtypes = [C.c_size_t]
+    shim.ZSTD_isError.restype = C.c_uint; shim.ZSTD_isError.argtypes = [C.c_size_t]
+    a = np.concatenate([datagen(lo, 2 << 20, 50, 21), text_like(1_200_000, 22)])
+    lr = load_ref() if have_ref() else None
+    for level in (5, 6, 7):
+        cc = shim.ZSTD_createCCtx()
+        assert shim.ZSTD_isError(shim.ZSTD_CCtx_setParameter(cc, 100, level)) == 0          # ZSTD_c_compressionLevel
+        assert shim.ZSTD_isError(shim.ZSTD_CCtx_setParameter(cc, 400, 2)) == 0              # ZSTD_c_nbWorkers
+        assert shim.ZSTD_isError(shim.ZSTD_CCtx_setParameter(cc, 1011, 1)) == 0            # ZSTD_c_useRowMatchFinder = enable: the reference's default here (the suite's environment says hash chain)
+        cap = shim.ZSTD_compressBound(len(a))
+        dst = np.zeros(cap, dtype=np.uint8)
+        r = shim.ZSTD_compress2(cc, _buf(dst), cap, _buf(a), len(a))
+        assert not shim.ZSTD_isError(r), level
+        out = dst[:r].tobytes()
+        lo.zo_set_row_matcher(1)
+        try:
+            want = oracle_frame_mt(lo, a, level, 0, 0, 0)
+        finally:
+            lo.zo_set_row_matcher(0)
+        assert out == want, level
+        if lr is not None:
+            assert out == ref_frame_mt(lr, a, level, 0, 0, 0), ("reference", level)
+        shim.ZSTD_freeCCtx(cc)
+    assert z.DContext().decompress(out) == a.tobytes()

@@ -332,7 +332,7 @@ class Context:
 
     def compress_frames(self, buffers, level=1, cparams=None, workers=0, job_size=0, overlap_log=0):
         """each buffer -> ONE multi-block frame, byte-identical to the reference's ZSTD_compress of it (zhip_compress_frames;
-        strategies ZSTD_fast and ZSTD_dfast: levels -N .. 3).  Returns the list of frames (bytes).
+        strategies ZSTD_fast ... ZSTD_lazy2: levels -N .. 12).  Returns the list of frames (bytes).
         workers >= 1: the frames ZSTD_compress2 emits with ZSTD_c_nbWorkers >= 1 instead (zhip_compress_frames_mt: inputs above
         512 KB are cut into independent jobs of job_size with overlap_log's prefix — one large input then fills the GPU)."""
         L = lib()

@@ -546,7 +546,7 @@ __device__ inline uint32_t lz_split_lvl1(const uint8_t* __restrict__ p, LzSplitS
         }
         atomicAdd(&sp->dev, mine);
         __syncthreads();
-        uint32_t const deviation = sp->dev;
+        uint32_t const deviation = __builtin_amdgcn_readfirstlane(sp->dev);      // one value for the workgroup: the loop's exit is uniform (scripts/scan_divergent_barriers.py)
         uint32_t const threshold = (uint32_t)(((uint64_t)pastN * nEv * (14u + penalty)) / 16u);      // :102-114
         if (deviation >= threshold) { result = pos; break; }                 // uniform: every thread read the same sum
         for (uint32_t k = t; k < 1024; k += ZHIP_ENT_THREADS) sp->past[k] += sp->cur[k];

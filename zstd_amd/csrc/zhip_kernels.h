@@ -477,6 +477,7 @@ __device__ __forceinline__ void frame_kernel_body(const uint8_t* __restrict__ sr
     uint32_t const fi = blockIdx.x;
     if (fi >= nFrames) return;
     ZhipUnit const u = frames[fi];
+    if (u.strategy >= ZHIP_STRAT_GREEDY) return;                     // a frame of the lazy strategies: k_frame_lazy's
     ZhipSlot const sl = slots[fi];
     EntShared* const sh = (EntShared*)smem;
     size_t const shBytes = (sizeof(EntShared) + 15) & ~(size_t)15;
@@ -540,6 +541,7 @@ k_lz_links(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
     uint32_t const wi = blockIdx.x;
     if (wi >= nW) return;
     ZhipUnit const u = units[wi];
+    if (u.strategy < ZHIP_STRAT_GREEDY) return;                      // a ZSTD_fast / ZSTD_dfast frame of a mixed batch: k_frame_fast's
     ZhipLzSlot const L = lz[wi];
     const uint8_t* const p = lz_window(src, u, jobs, wi);
     LzLinkShared* const sh = (LzLinkShared*)smem;
@@ -551,12 +553,13 @@ k_lz_links(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
 }
 // k_lz_search: grid (ceil(longest section / 256), nW); one thread per position of the unit's section
 __global__ void __launch_bounds__(256)
-k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t nW,
+k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t wBase, uint32_t nW,
             const uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, LzRec* __restrict__ best)
 {
-    uint32_t const wi = blockIdx.y;
+    uint32_t const wi = wBase + blockIdx.y;
     if (wi >= nW) return;
     ZhipUnit const u = units[wi];
+    if (u.strategy < ZHIP_STRAT_GREEDY) return;
     ZhipLzSlot const L = lz[wi];
     uint32_t const j0 = jobs ? jobs[wi].prefixLen : 0u;
     uint32_t const p = j0 + blockIdx.x * 256u + threadIdx.x;
@@ -577,6 +580,7 @@ k_frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const wi = blockIdx.x;
     if (wi >= nW) return;
     ZhipUnit const u = units[wi];
+    if (u.strategy < ZHIP_STRAT_GREEDY) return;
     ZhipSlot const sl = slots[wi];
     ZhipLzSlot const L = lz[wi];
     EntShared* const sh = (EntShared*)smem;

@@ -66,6 +66,10 @@ struct zhip_ctx_s {
     // ... as jobs (ZSTD_c_nbWorkers semantics): job table, whole-frame descriptors for the checksum, per-frame sizes
     zhip::ZhipJob* dJobs; size_t jobsCap; ZhipUnit* dFrameUnits; uint32_t* dFrameSizes; size_t frameUnitsCap;
     std::vector<zhip::ZhipJob> hJobs; std::vector<ZhipUnit> hFrameUnits; std::vector<uint32_t> hFrameSizes;
+    // ... of the lazy strategies (zhip_frame_lazy.h): links, tags, records per position of every window; head tables; grown on demand
+    uint32_t* dLzPrev = nullptr; uint8_t* dLzTags = nullptr; zhip::LzRec* dLzBest = nullptr; uint32_t* dLzHeads = nullptr; zhip::ZhipLzSlot* dLzSlots = nullptr;
+    size_t lzPosCap = 0, lzHeadCap = 0, lzSlotCap = 0;
+    std::vector<zhip::ZhipLzSlot> hLz; bool lzAny = false, lzAll = false; uint64_t lzPos = 0, lzHeads = 0; uint32_t lzLongest = 0;
     // staging for the host-buffer API
     uint8_t* dSrcStage; size_t srcStageCap;
     uint8_t* dDstStage; size_t dstStageCap;
@@ -146,6 +150,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
+    (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots);
     (void)hipFree(c->dQueue); (void)hipFree(c->dOrder); (void)hipFree(c->dCost); (void)hipFree(c->dGTabs);
     if (c->coStream) (void)hipStreamDestroy(c->coStream);
     for (int i = 0; i < 2; i++) if (c->coEv[i]) (void)hipEventDestroy(c->coEv[i]);
@@ -735,12 +740,19 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
     const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
     size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsTab = 0; unsigned long long totalSrc = 0;
     if (mt.on) { c->hJobs.clear(); c->hFrameUnits.resize(nFrames); }
+    bool lzAny = false, lzAll = true;
+    c->hLz.clear(); c->lzPos = 0; c->lzHeads = 0; c->lzLongest = 1;
     for (size_t i = 0; i < nFrames; i++) {
         if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] >= (1ull << 31)) { snprintf(c->err, sizeof(c->err), "frame %zu: inputs of 2 GiB and more are not implemented on device", i); return ZERR(ZE_srcSize_wrong); }
         size_t const n = (size_t)(offs[i + 1] - offs[i]);
         zhip::CParams cp;
         if (!zhip::host_get_cparams(level, n, &cp, ov)) return ZERR(ZE_parameter_unsupported);
-        if (cp.strategy != ZHIP_STRAT_FAST && cp.strategy != ZHIP_STRAT_DFAST) { snprintf(c->err, sizeof(c->err), "multi-block frames: strategy %u not implemented on device (ZSTD_fast and ZSTD_dfast only)", cp.strategy); return ZERR(ZE_parameter_unsupported); }
+        if (cp.strategy < ZHIP_STRAT_FAST || cp.strategy > ZHIP_STRAT_LAZY2) { snprintf(c->err, sizeof(c->err), "multi-block frames: strategy %u not implemented on device (ZSTD_fast ... ZSTD_lazy2 only)", cp.strategy); return ZERR(ZE_parameter_unsupported); }
+        bool const lazy = cp.strategy >= ZHIP_STRAT_GREEDY;
+        uint32_t rowLog = 0;                                                                          // zstd_compress.c:237-253, :2042
+        if (lazy && c->rowMode != 2 && cp.windowLog > 14) rowLog = cp.searchLog < 4 ? 4 : (cp.searchLog > 6 ? 6 : cp.searchLog);
+        else if (lazy && c->rowMode == 1) { snprintf(c->err, sizeof(c->err), "ZSTD_ps_enable with windowLog %u <= 14: no row matcher for it on device", cp.windowLog); return ZERR(ZE_parameter_unsupported); }
+        if (lazy) lzAny = true; else lzAll = false;
         if (cp.windowLog < 17 && n > ((size_t)1 << cp.windowLog)) { snprintf(c->err, sizeof(c->err), "multi-block frames: windowLog %u below the block size is not implemented on device", cp.windowLog); return ZERR(ZE_parameter_unsupported); }
         // the sections of this frame: one without workers or at most 512 KB (ZSTDMT_JOBSIZE_MIN: the reference then runs single-threaded)
         size_t section = n ? n : 1, overlap = 0;
@@ -759,10 +771,15 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
             u.srcOff = offs[i]; u.srcLen = (uint32_t)len;
             u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
             u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-            u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
+            u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = 0; u.targetLength = cp.targetLength; u.rowLog = rowLog; u.pad1 = 0;
             ZhipSlot& sl = c->hSlots[nU];
             sl.seqOff = nU * (uint64_t)ZHIP_SEQ_CAP; sl.litOff = nU * (uint64_t)ZHIP_LIT_STRIDE; sl.outOff = outBytes; sl.seqCap = ZHIP_SEQ_CAP; sl.pad0 = 0;
             outBytes += (zhip::host_compress_bound(len) + 1024 + 15) & ~(size_t)15;      // the block in flight may overshoot before it is declared raw
+            {   zhip::ZhipLzSlot L; memset(&L, 0, sizeof(L));
+                size_t const pre = (mt.on && k) ? (prevLen < overlap ? prevLen : overlap) : 0;
+                if (lazy) { zhip::lz_fill_slot(L, u, (uint32_t)pre, c->lzPos, c->lzHeads); if (len > c->lzLongest) c->lzLongest = (uint32_t)len; }
+                c->hLz.push_back(L);
+            }
             if (mt.on) {
                 zhip::ZhipJob j;
                 j.start = (uint32_t)start; j.prefixLen = (uint32_t)(k == 0 ? 0 : (prevLen < overlap ? prevLen : overlap));    // zstdmt_compress.c:1404-1407
@@ -774,7 +791,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         }
         if (mt.on) { ZhipUnit& fu = c->hFrameUnits[i]; fu = c->hUnits[nU - 1]; fu.srcLen = (uint32_t)n; }
         bound += zhip::host_compress_bound(n);
-        {   // the longest walk of this frame: a section plus its prefix (the whole input without jobs)
+        if (!lazy) {   // the longest walk of this frame: a section plus its prefix (the whole input without jobs)
             uint32_t const mode = zhip::frame_table_mode(cp.strategy, cp.hashLog, (unsigned long long)(n < section ? n : section) + overlap + 1);
             if (mode == zhip::ZHIP_FT_HBM) { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
             else { uint32_t const b = zhip::frame_table_lds_bytes(mode, cp.hashLog); if (b > ldsTab) ldsTab = b; }
@@ -782,7 +799,10 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         totalSrc += n;
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
-    return frames_run_locked(c, dstDev, srcDev, nU, nFrames, ldsTab, tabWords, outBytes, totalSrc, mt.on, frameSizesDev, s);
+    c->lzAny = lzAny; c->lzAll = lzAny && lzAll;
+    size_t const r = frames_run_locked(c, dstDev, srcDev, nU, nFrames, ldsTab, tabWords, outBytes, totalSrc, mt.on, frameSizesDev, s);
+    c->lzAny = c->lzAll = false;
+    return r;
 }
 
 // the launch part: c->hUnits / c->hSlots (and c->hJobs / c->hFrameUnits with jobs) describe nU workgroups of nFrames frames
@@ -820,6 +840,29 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
         HIPCHK(c, hipMemcpyAsync(c->dJobs, c->hJobs.data(), nU * sizeof(zhip::ZhipJob), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->dFrameUnits, c->hFrameUnits.data(), nFrames * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     }
+    if (c->lzAny) {
+        // per position of every window: link (4 B) + tag (1 B) + record (16 B); per unit a head table of 4 << keyBits bytes
+        size_t const needPos = (size_t)c->lzPos + 64, needHeads = (size_t)c->lzHeads + 64;
+        if (c->lzPosCap < needPos) {
+            (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); c->dLzPrev = nullptr; c->dLzTags = nullptr; c->dLzBest = nullptr; c->lzPosCap = 0;
+            if (hipMalloc((void**)&c->dLzPrev, needPos * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&c->dLzTags, needPos) != hipSuccess ||
+                hipMalloc((void**)&c->dLzBest, needPos * sizeof(zhip::LzRec)) != hipSuccess) {
+                (void)hipGetLastError();
+                snprintf(c->err, sizeof(c->err), "lazy frames: cannot allocate %zu bytes of match-state room (21 bytes per position)", needPos * 21); return ZERR(ZE_memory_allocation); }
+            c->lzPosCap = needPos;
+        }
+        if (c->lzHeadCap < needHeads) {
+            (void)hipFree(c->dLzHeads); c->dLzHeads = nullptr; c->lzHeadCap = 0;
+            if (hipMalloc((void**)&c->dLzHeads, needHeads * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
+            c->lzHeadCap = needHeads;
+        }
+        if (c->lzSlotCap < nU) {
+            (void)hipFree(c->dLzSlots); c->dLzSlots = nullptr; c->lzSlotCap = 0;
+            if (hipMalloc((void**)&c->dLzSlots, nU * sizeof(zhip::ZhipLzSlot)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
+            c->lzSlotCap = nU;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dLzSlots, c->hLz.data(), nU * sizeof(zhip::ZhipLzSlot), hipMemcpyHostToDevice, s));
+    }
     size_t const lds = zhip::frame_lds_bytes(ldsTab);
     bool const hbmOnly = ldsTab == 0 && !getenv("ZHIP_FRAME_NO_HBM_KERNEL");           // no table in LDS: the variant compiled for four workgroups per CU
     HIPCHK(c, hipFuncSetAttribute(hbmOnly ? (const void*)zhip::k_frame_hbm : (const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -831,7 +874,23 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
         hipLaunchKernelGGL(zhip::k_xxh64_wave, dim3((unsigned)nFrames), dim3(64), ZHIP_XXH_WAVE_LDS, s, (const uint8_t*)srcDev, mt.on ? c->dFrameUnits : c->dUnits, (uint32_t)nFrames, c->dChecks);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    if (hbmOnly)
+    if (c->lzAny) {
+        const zhip::ZhipJob* const jb = mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr;
+        HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_frame_lazy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)zhip::frame_lazy_lds_bytes()));
+        hipLaunchKernelGGL(zhip::k_lz_links, dim3((unsigned)nU), dim3(ZHIP_LZ_LINK_THREADS), sizeof(zhip::LzLinkShared), s,
+                           (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzHeads);
+        for (size_t w0 = 0; w0 < nU; w0 += 32768) {
+            size_t const nw = nU - w0 < 32768 ? nU - w0 : 32768;
+            hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
+                               (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+        }
+        hipLaunchKernelGGL(zhip::k_frame_lazy, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), zhip::frame_lazy_lds_bytes(), s,
+                           (const uint8_t*)srcDev, c->dUnits, c->dSlots, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dLzHeads,
+                           c->dSeqs, c->dLits, c->dStBits, c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (c->lzAll) { }
+    else if (hbmOnly)
         hipLaunchKernelGGL(zhip::k_frame_hbm, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), lds, s,
                            (const uint8_t*)srcDev, c->dUnits, c->dSlots, (uint32_t)nU, c->dTabs, tabStride, c->dSeqs, c->dLits, c->dStBits,
                            c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, mt.on ? c->dJobs : (const zhip::ZhipJob*)nullptr);
