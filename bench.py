@@ -662,10 +662,23 @@ def job_pool_leg(zstd_amd, local, host, level):
         wall = min(wall, time.perf_counter() - t0)
     same = bool(not L.zhip_isError(r) and d1[:r].tobytes() == out)
     ctx.close()
+    # the way back: that ONE frame through the decoder — block-parallel (zhip_decode_big.h), where one workgroup walked it at 0.26 GB/s
+    dec = None
+    try:
+        d = zstd_amd.DContext(local)
+        back, dms = None, 1e9
+        for _ in range(2):
+            back = d.decompress(out, capacity=n)
+            dms = min(dms, d.timing()["decode_ms"])
+        dec = {"value": round(n / dms / 1e3, 1), "unit": "MB/s", "decode_ms": round(dms, 3), "equals_source": bool(back == a.tobytes()), **d.last_bigframe(),
+               "path": "zhip_decompress of the frame above: k_bf_walk / prep / deps / entropy (a workgroup per block) / scan / build / jump rounds / copy; device time between the first and the last launch, host round trips of the jump loop included"}
+        d.close()
+    except Exception as e:                                       # noqa: BLE001
+        dec = {"error": str(e)}
     res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
            "end_to_end": {"value": round(n / wall / 1e6, 1), "unit": "MB/s", "same_bytes": same,
                           "path": "zhip_compress_frames_mt from pageable host memory: blocking H2D, kernels, D2H on one context; PCIe-inclusive, never `value`"},
-           "ratio": round(n / len(out), 4),
+           "ratio": round(n / len(out), 4), "decode": dec,
            "note": "k_frame_fast with a job table: one frame, jobs = independent workgroups, two per CU (48 KB 24-bit LDS table each); never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):

@@ -234,6 +234,12 @@ size_t       zhip_decompress(zhip_dctx* dctx, const zhip_ddict* ddict, void* dst
 size_t       zhip_seekable_read(zhip_dctx* dctx, void* dst, size_t len, const void* src, size_t srcSize, unsigned long long offset);
 /* HIP-event durations (ms) of the most recent call: t[0] = k_decode, t[1] = checksum verification (0 when no frame has one) */
 void         zhip_dctx_last_timing(const zhip_dctx* dctx, double t[2]);
+/* One LARGE frame is decoded block-parallel (zstd_amd/csrc/zhip_decode_big.h: symbolic repeat offsets + a scan, pointer jumping over a
+ * copy map) instead of by one workgroup: frames without a dictionary whose header states at least minContent bytes of content
+ * (default 8 MiB, $ZHIP_BIGFRAME_MIN; 0 = never).  Same bytes, same errors: whatever that path declines goes through the per-frame decoder.
+ * zhip_dctx_last_bigframe: [0] frames of the last call decoded block-parallel, [1] frames that fell back, [2] pointer-jumping rounds, [3] blocks. */
+void         zhip_dctx_set_bigframe_min(zhip_dctx* dctx, unsigned long long minContent);
+void         zhip_dctx_last_bigframe(const zhip_dctx* dctx, unsigned out[4]);
 
 /* ---- measurement: HIP-event durations (ms) of the kernels of the most recent call on this ctx
  * t[0] = match finder, t[1] = entropy + frame assembly, t[2] = output compaction, t[3] = whole device pipeline */

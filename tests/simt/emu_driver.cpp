@@ -8,6 +8,7 @@
 
 #include <vector>
 #include <stdlib.h>
+#include <stdio.h>
 // full-size slots (fixed strides), what the host library fills for 128 KB units
 static std::vector<ZhipSlot> fixed_slots(uint32_t nUnits)
 {
@@ -172,6 +173,54 @@ int emu_decode(const uint8_t* src, const ZhipDFrame* frames, uint32_t nFrames, u
     uint8_t* const lp = lit.data(); ZhipDSeq* const rp = recs.data(); const uint64_t* const dt = defTabs;
     simt::launch({nGroups, 1, 1}, {ZHIP_DEC_THREADS, 1, 1}, sizeof(zhip::DecShared),
                  [=] { zhip::k_decode(src, frames, nFrames, dst, lp, rp, cp, dv, dt, results); }, osThreads);
+    return 0;
+}
+// ONE frame through the block-parallel decoder (zhip_decode_big.h), the launches of the host library in order.
+// returns 0 and *outSize, or the path's status (the caller would then fall back to k_decode); rounds (optional) = jump rounds made
+uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint32_t dstCap, uint32_t* outSize, uint32_t* checksumOut, uint32_t* rounds, int osThreads)
+{
+    zhip::BfHeader const H = zhip::bf_parse_header(src, srcLen);
+    if (!H.ok || H.fcs > dstCap) return ZHIP_DE_UNSUPPORTED;
+    uint32_t const capBlocks = (uint32_t)(H.fcs / 1024 + 1024);
+    std::vector<ZhipBfBlock> blocks(capBlocks);
+    ZhipBfInfo info; memset(&info, 0, sizeof(info));
+    ZhipBfBlock* const bp = blocks.data(); ZhipBfInfo* const ip = &info;
+    uint64_t defTabs[160]; zhip::host_dec_default_tables(defTabs); const uint64_t* const dt = defTabs;
+    uint32_t const hdrSize = H.hdrSize, blockMax = H.blockMax, hasCk = H.hasChecksum;
+    bool const tr = getenv("ZHIP_EMU_TRACE") != nullptr;
+#define BFTR(x) do { if (tr) fprintf(stderr, "bf: %s\n", x); } while (0)
+    BFTR("walk");
+    simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_walk(src, srcLen, hdrSize, blockMax, hasCk, bp, capBlocks, ip); }, 1);
+    if (info.status) return info.status;
+    uint32_t const nB = info.nBlocks;
+    BFTR("prep");
+    simt::launch({(nB + 255) / 256, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_prep(src, blockMax, bp, ip); }, osThreads);
+    BFTR("deps");
+    simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_deps(bp, ip); }, 1);
+    if (info.status) return info.status;
+    if (info.totalRecs > (uint64_t)H.fcs + nB) return ZHIP_DE_UNSUPPORTED;
+    std::vector<uint8_t> lit(info.totalLit + 64, 0xEE); std::vector<ZhipDSeq> recs(info.totalRecs + 1);
+    uint8_t* const lp = lit.data(); ZhipDSeq* const rp = recs.data();
+    BFTR("entropy");
+    simt::launch({nB, 1, 1}, {ZHIP_BF_THREADS, 1, 1}, sizeof(zhip::DecShared), [=] { zhip::k_bf_entropy(src, blockMax, bp, ip, lp, rp, dt); }, osThreads);
+    BFTR("scan");
+    simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_scan(bp, ip, dstCap); }, 1);
+    if (info.status) return info.status;
+    if (info.totalOut != H.fcs) return ZHIP_DE_CORRUPT;
+    uint32_t const n = (uint32_t)info.totalOut;
+    std::vector<uint32_t> map((size_t)n + 8, 0xDDDDDDDDu); uint32_t* const mp = map.data();
+    BFTR("build");
+    simt::launch({nB, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_build(src, bp, ip, lp, rp, dst, mp); }, osThreads);
+    if (info.status) return info.status;
+    uint32_t r = 0;
+    if (n) for (; r < 64; r++) {
+        info.changed = 0;
+        simt::launch({(n + 1023) / 1024, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_jump(mp, n, ip); }, osThreads);
+        if (!info.changed) break;
+    }
+    if (rounds) *rounds = r;
+    if (n) simt::launch({(n + 1023) / 1024, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_copy(mp, dst, n); }, osThreads);
+    *outSize = n; if (checksumOut) *checksumOut = info.checksum;
     return 0;
 }
 uint32_t emu_sizeof_dframe(void) { return sizeof(ZhipDFrame); }

@@ -79,6 +79,8 @@ def lib():
                                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
             ("zhip_decompress", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
             ("zhip_dctx_last_timing", None, [C.c_void_p, C.c_void_p]),
+            ("zhip_dctx_set_bigframe_min", None, [C.c_void_p, C.c_ulonglong]),
+            ("zhip_dctx_last_bigframe", None, [C.c_void_p, C.c_void_p]),
             ("zhip_seekable_read", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_ulonglong]),
         ]:
             if hasattr(L, name):
@@ -432,6 +434,15 @@ class DContext:
         t = (C.c_double * 2)()
         lib().zhip_dctx_last_timing(self._h, t)
         return {"decode_ms": t[0], "verify_ms": t[1]}
+
+    def set_bigframe_min(self, min_content):
+        """frames stating at least this much content are decoded block-parallel (zhip_decode_big.h); 0 = never"""
+        lib().zhip_dctx_set_bigframe_min(self._h, int(min_content))
+
+    def last_bigframe(self):
+        t = (C.c_uint * 4)()
+        lib().zhip_dctx_last_bigframe(self._h, t)
+        return {"block_parallel": t[0], "fell_back": t[1], "jump_rounds": t[2], "blocks": t[3]}
 
     def _err(self, r, what):
         L = lib()

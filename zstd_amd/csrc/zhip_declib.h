@@ -21,6 +21,12 @@ struct zhip_dctx_s {
     ZhipDFrame* dFrames; ZhipDResult* dResults; ZhipUnit* dUnits; uint32_t* dChecks; size_t framesCap;
     ZhipDFrame* hFrames; ZhipDResult* hResults; ZhipUnit* hUnits;
     uint8_t* dSrcStage; size_t srcStageCap; uint8_t* dDstStage; size_t dstStageCap;
+    // one large frame, block-parallel (zhip_decode_big.h): block table, literal / record arenas, the copy map; grown on demand
+    ZhipBfBlock* dBfBlocks = nullptr; ZhipBfInfo* dBfInfo = nullptr; uint8_t* dBfLit = nullptr; ZhipDSeq* dBfRecs = nullptr; uint32_t* dBfMap = nullptr;
+    size_t bfBlocksCap = 0, bfLitCap = 0, bfRecsCap = 0, bfMapCap = 0;
+    hipEvent_t bfEv[2] = { nullptr, nullptr };
+    unsigned long long bigMin = 8ull << 20;        // frames stating at least this much content take the block-parallel path ($ZHIP_BIGFRAME_MIN, 0 = never)
+    unsigned bfLast[4] = { 0, 0, 0, 0 };           // last call: frames decoded block-parallel, frames that fell back, jump rounds, blocks
     double timing[2];
     std::mutex mu;
     char err[256];
@@ -73,6 +79,8 @@ void zhip_free_dctx(zhip_dctx* c)
     (void)hipFree(c->dLit); (void)hipFree(c->dRecs); (void)hipFree(c->dCounter); (void)hipFree(c->dDefTabs);
     (void)hipFree(c->dFrames); (void)hipFree(c->dResults); (void)hipFree(c->dUnits); (void)hipFree(c->dChecks);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage);
+    (void)hipFree(c->dBfBlocks); (void)hipFree(c->dBfInfo); (void)hipFree(c->dBfLit); (void)hipFree(c->dBfRecs); (void)hipFree(c->dBfMap);
+    for (int i = 0; i < 2; i++) if (c->bfEv[i]) (void)hipEventDestroy(c->bfEv[i]);
     (void)hipHostFree(c->hFrames); (void)hipHostFree(c->hResults); (void)hipHostFree(c->hUnits);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -103,9 +111,15 @@ zhip_dctx* zhip_create_dctx(int device)
     ok = ok && hipMalloc((void**)&c->dCounter, 64) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dDefTabs, 160 * sizeof(uint64_t)) == hipSuccess;
     if (ok) { uint64_t t[160]; zhip::host_dec_default_tables(t); ok = hipMemcpy(c->dDefTabs, t, sizeof(t), hipMemcpyHostToDevice) == hipSuccess; }
+    {   const char* e = getenv("ZHIP_BIGFRAME_MIN"); if (e && *e) c->bigMin = strtoull(e, nullptr, 10); }
     if (!ok) { zhip_free_dctx(c); return nullptr; }
     return c;
 }
+
+// block-parallel path: minimum stated content size (0 = never), and what the last call did with it:
+// out[0] frames decoded block-parallel, [1] frames that fell back to k_decode, [2] pointer-jumping rounds, [3] blocks
+void zhip_dctx_set_bigframe_min(zhip_dctx* c, unsigned long long minContent) { if (c) c->bigMin = minContent; }
+void zhip_dctx_last_bigframe(const zhip_dctx* c, unsigned out[4]) { for (int i = 0; i < 4; i++) out[i] = c ? c->bfLast[i] : 0; }
 
 const char* zhip_dctx_last_error(const zhip_dctx* c) { return c ? c->err : "null context"; }
 void zhip_dctx_last_timing(const zhip_dctx* c, double t[2]) { t[0] = c->timing[0]; t[1] = c->timing[1]; }
@@ -168,6 +182,61 @@ static size_t ensure_frames(zhip_dctx* c, size_t n)
     return 0;
 }
 
+// One frame through the block-parallel decoder (zhip_decode_big.h).  true: res is its result (status 0).  false: not a frame for this
+// path, or the path met anything it does not handle — the caller leaves the frame to k_decode, which reports the reference's codes.
+template <typename T> static bool bf_grow(T*& p, size_t& cap, size_t need)
+{
+    if (cap >= need) return true;
+    (void)hipFree(p); p = nullptr; cap = 0;
+    if (hipMalloc((void**)&p, need * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    cap = need; return true;
+}
+static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, const uint8_t* srcDev, hipStream_t s, ZhipDResult* res, float* msOut)
+{
+    uint8_t hdr[32]; memset(hdr, 0, sizeof(hdr));
+    size_t const hn = f.srcLen < sizeof(hdr) ? f.srcLen : sizeof(hdr);
+    if (hipMemcpyAsync(hdr, srcDev + f.srcOff, hn, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+    zhip::BfHeader const H = zhip::bf_parse_header(hdr, f.srcLen);
+    if (!H.ok || H.fcs < c->bigMin || H.fcs > f.dstCap || H.fcs >= 0xFFFFFF00ull) return false;
+    const uint8_t* const src = srcDev + f.srcOff; uint8_t* const out = dstDev + f.dstOff;
+    size_t const capBlocks = (size_t)(H.fcs / 1024 + 1024);
+    if (!c->dBfInfo && hipMalloc((void**)&c->dBfInfo, sizeof(ZhipBfInfo)) != hipSuccess) return false;
+    if (!bf_grow(c->dBfBlocks, c->bfBlocksCap, capBlocks)) return false;
+    for (int i = 0; i < 2; i++) if (!c->bfEv[i] && hipEventCreate(&c->bfEv[i]) != hipSuccess) return false;
+    ZhipBfInfo info;
+    auto readInfo = [&]() { return hipMemcpyAsync(&info, c->dBfInfo, sizeof(info), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess; };
+    (void)hipEventRecord(c->bfEv[0], s);
+    hipLaunchKernelGGL(zhip::k_bf_walk, dim3(1), dim3(64), 0, s, src, f.srcLen, H.hdrSize, H.blockMax, H.hasChecksum, c->dBfBlocks, (uint32_t)capBlocks, c->dBfInfo);
+    hipLaunchKernelGGL(zhip::k_bf_prep, dim3((unsigned)((capBlocks + 255) / 256)), dim3(256), 0, s, src, H.blockMax, c->dBfBlocks, c->dBfInfo);
+    hipLaunchKernelGGL(zhip::k_bf_deps, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo);
+    if (hipGetLastError() != hipSuccess || !readInfo() || info.status) return false;
+    uint32_t const nB = info.nBlocks;
+    if (info.totalRecs > H.fcs + nB) return false;                     // more sequences than bytes: not a frame worth 16 bytes per record
+    if (!bf_grow(c->dBfLit, c->bfLitCap, (size_t)info.totalLit + 64) || !bf_grow(c->dBfRecs, c->bfRecsCap, (size_t)info.totalRecs + 1) ||
+        !bf_grow(c->dBfMap, c->bfMapCap, (size_t)H.fcs + 8)) return false;
+    hipLaunchKernelGGL(zhip::k_bf_entropy, dim3(nB), dim3(ZHIP_BF_THREADS), sizeof(zhip::DecShared), s, src, H.blockMax, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, c->dDefTabs);
+    hipLaunchKernelGGL(zhip::k_bf_scan, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo, f.dstCap);
+    hipLaunchKernelGGL(zhip::k_bf_build, dim3(nB), dim3(256), 0, s, src, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, out, c->dBfMap);
+    if (hipGetLastError() != hipSuccess || !readInfo() || info.status || info.totalOut != H.fcs) return false;
+    uint32_t const n = (uint32_t)H.fcs, grid = (n + 1023) / 1024;
+    unsigned rounds = 0;
+    for (; n && rounds < 64; rounds++) {
+        if (hipMemsetAsync(&c->dBfInfo->changed, 0, 4, s) != hipSuccess) return false;
+        hipLaunchKernelGGL(zhip::k_bf_jump, dim3(grid), dim3(256), 0, s, c->dBfMap, n, c->dBfInfo);
+        uint32_t changed = 1;
+        if (hipMemcpyAsync(&changed, &c->dBfInfo->changed, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+        if (!changed) break;
+    }
+    if (rounds == 64) return false;
+    if (n) hipLaunchKernelGGL(zhip::k_bf_copy, dim3(grid), dim3(256), 0, s, c->dBfMap, out, n);
+    (void)hipEventRecord(c->bfEv[1], s);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+    float ms = 0; if (hipEventElapsedTime(&ms, c->bfEv[0], c->bfEv[1]) == hipSuccess) *msOut += ms;
+    res->status = 0; res->size = n; res->hasChecksum = H.hasChecksum; res->checksum = info.checksum;
+    c->bfLast[0]++; c->bfLast[2] += rounds; c->bfLast[3] += nB;
+    return true;
+}
+
 // frames already described in c->hFrames[0..n); returns total decoded bytes or the first frame error
 static size_t decode_locked(zhip_dctx* c, const zhip_ddict* dd, uint8_t* dstDev, const uint8_t* srcDev, size_t n, unsigned* statusOut,
                             unsigned long long* sizesOut, hipStream_t s)
@@ -177,16 +246,38 @@ static size_t decode_locked(zhip_dctx* c, const zhip_ddict* dd, uint8_t* dstDev,
     if (n > 0xFFFFFFFFull) return DERR(72);
     ZhipDDictDev dv; memset(&dv, 0, sizeof(dv));
     if (dd) dv = dd->dev;
-    DCHK(c, hipMemcpyAsync(c->dFrames, c->hFrames, n * sizeof(ZhipDFrame), hipMemcpyHostToDevice, s));
-    DCHK(c, hipMemsetAsync(c->dCounter, 0, 4, s));
-    uint32_t const grid = n < c->grid ? (uint32_t)n : c->grid;
-    DCHK(c, hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(zhip::k_decode, dim3(grid), dim3(ZHIP_DEC_THREADS), sizeof(zhip::DecShared), s,
-                       srcDev, c->dFrames, (uint32_t)n, dstDev, c->dLit, c->dRecs, c->dCounter, dv, c->dDefTabs, c->dResults);
-    DCHK(c, hipGetLastError());
-    DCHK(c, hipEventRecord(c->ev[1], s));
-    DCHK(c, hipMemcpyAsync(c->hResults, c->dResults, n * sizeof(ZhipDResult), hipMemcpyDeviceToHost, s));
-    DCHK(c, hipStreamSynchronize(s));
+    // large frames first, one at a time over the whole GPU (zhip_decode_big.h); the others — and every frame that path declines — as a batch
+    std::vector<ZhipDFrame> all; std::vector<ZhipDResult> bigRes; std::vector<size_t> rest;
+    float bigMs = 0;
+    c->bfLast[0] = c->bfLast[1] = c->bfLast[2] = c->bfLast[3] = 0;
+    if (!dd && c->bigMin) {
+        for (size_t i = 0; i < n; i++) {
+            if (c->hFrames[i].dstCap < c->bigMin) continue;
+            ZhipDResult r; memset(&r, 0, sizeof(r));
+            if (!bigframe_decode(c, c->hFrames[i], dstDev, srcDev, s, &r, &bigMs)) { c->bfLast[1]++; continue; }
+            if (all.empty()) { all.assign(c->hFrames, c->hFrames + n); bigRes.resize(n); for (size_t k = 0; k < n; k++) bigRes[k].status = 0xFFFFFFFFu; }
+            bigRes[i] = r;
+        }
+    }
+    size_t m = n;
+    if (!all.empty()) { m = 0; for (size_t i = 0; i < n; i++) if (bigRes[i].status == 0xFFFFFFFFu) { rest.push_back(i); c->hFrames[m++] = all[i]; } }
+    if (m) {
+        DCHK(c, hipMemcpyAsync(c->dFrames, c->hFrames, m * sizeof(ZhipDFrame), hipMemcpyHostToDevice, s));
+        DCHK(c, hipMemsetAsync(c->dCounter, 0, 4, s));
+        uint32_t const grid = m < c->grid ? (uint32_t)m : c->grid;
+        DCHK(c, hipEventRecord(c->ev[0], s));
+        hipLaunchKernelGGL(zhip::k_decode, dim3(grid), dim3(ZHIP_DEC_THREADS), sizeof(zhip::DecShared), s,
+                           srcDev, c->dFrames, (uint32_t)m, dstDev, c->dLit, c->dRecs, c->dCounter, dv, c->dDefTabs, c->dResults);
+        DCHK(c, hipGetLastError());
+        DCHK(c, hipEventRecord(c->ev[1], s));
+        DCHK(c, hipMemcpyAsync(c->hResults, c->dResults, m * sizeof(ZhipDResult), hipMemcpyDeviceToHost, s));
+        DCHK(c, hipStreamSynchronize(s));
+    }
+    if (!all.empty()) {                                         // back to the caller's order
+        for (size_t k = m; k-- > 0; ) bigRes[rest[k]] = c->hResults[k];
+        for (size_t i = 0; i < n; i++) { c->hFrames[i] = all[i]; c->hResults[i] = bigRes[i]; }
+        if (n) DCHK(c, hipMemcpyAsync(c->dResults, c->hResults, n * sizeof(ZhipDResult), hipMemcpyHostToDevice, s));      // k_dec_verify works on the device copy
+    }
     bool anyCheck = false;
     for (size_t i = 0; i < n; i++) if (c->hResults[i].hasChecksum) { anyCheck = true; break; }
     c->timing[1] = 0;
@@ -194,6 +285,10 @@ static size_t decode_locked(zhip_dctx* c, const zhip_ddict* dd, uint8_t* dstDev,
         for (size_t i = 0; i < n; i++) { ZhipUnit u; memset(&u, 0, sizeof(u)); u.srcOff = c->hFrames[i].dstOff; u.srcLen = c->hResults[i].hasChecksum ? c->hResults[i].size : 0; c->hUnits[i] = u; }
         DCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, n * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
         DCHK(c, hipEventRecord(c->ev[2], s));
+        bool large = false;                                     // XXH64 is a serial chain per frame: a large one gets a whole wavefront (k_xxh64_wave), small ones share one
+        for (size_t i = 0; i < n; i++) if (c->hUnits[i].srcLen >= (1u << 20)) { large = true; break; }
+        if (large) hipLaunchKernelGGL(zhip::k_xxh64_wave, dim3((uint32_t)n), dim3(64), ZHIP_XXH_WAVE_LDS, s, (const uint8_t*)dstDev, c->dUnits, (uint32_t)n, c->dChecks);
+        else
         hipLaunchKernelGGL(zhip::k_xxh64, dim3((uint32_t)((n + 15) / 16)), dim3(64), 0, s, (const uint8_t*)dstDev, c->dUnits, (uint32_t)n, c->dChecks);
         hipLaunchKernelGGL(zhip::k_dec_verify, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, c->dResults, c->dChecks, (uint32_t)n);
         DCHK(c, hipGetLastError());
@@ -202,7 +297,7 @@ static size_t decode_locked(zhip_dctx* c, const zhip_ddict* dd, uint8_t* dstDev,
         DCHK(c, hipStreamSynchronize(s));
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->timing[1] = ms;
     }
-    {   float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->timing[0] = ms; }
+    {   float ms = 0; if (m && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->timing[0] = ms; else c->timing[0] = 0; c->timing[0] += bigMs; }
     uint64_t total = 0; size_t firstErr = 0;
     for (size_t i = 0; i < n; i++) {
         if (statusOut) statusOut[i] = c->hResults[i].status;

@@ -839,8 +839,10 @@ __device__ inline uint32_t dec_seq_setup(DecShared* S, const uint8_t* seq, uint3
 //   pass 2, one lane per sequence: value bits, literal / match lengths, raw offset codes; then the repeat-offset history is
 //     resolved in order (a short wave-uniform loop), positions come from two wave prefix sums, every record is validated
 //     (ZSTD_execSequence's checks :1025-1054) and stored.
+// deferOff (the block-parallel decoder of zhip_decode_big.h): positions are block-relative and the offset history may be symbolic —
+// offsets are validated later, when the block's place in the frame and its incoming history are known.
 __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, int buf, uint32_t nbSeq, uint32_t litSize,
-                                     uint32_t dstCap, uint32_t dictLen)
+                                     uint32_t dstCap, uint32_t dictLen, bool deferOff = false)
 {
     uint32_t const lane = (uint32_t)lane_id();
     const lds_u32* const TL = (const lds_u32*)(uintptr_t)dec_tab(S, 0);     // entries as two dwords: [next | nbAdd << 16 | nb << 24], [base]
@@ -958,7 +960,7 @@ __device__ inline void dec_seq_chunk(DecShared* S, SeqDec& D, ZhipDSeq* recs, in
         if (on) {
             if (ll > litSize || litPos > litSize - ll) e = ZHIP_DE_CORRUPT;
             else if (outPos64 + ll + ml > dstCap) e = ZHIP_DE_DST_SMALL;
-            else if ((uint64_t)offv > outPos64 + ll + dictLen) e = ZHIP_DE_CORRUPT;
+            else if (!deferOff && (uint64_t)offv > outPos64 + ll + dictLen) e = ZHIP_DE_CORRUPT;
         }
         unsigned long long const bads = __ballot(e != 0);
         if (bads) { err = __builtin_amdgcn_readlane(e, first_lane(bads)); break; }

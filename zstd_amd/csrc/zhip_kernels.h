@@ -12,6 +12,7 @@
 #include "zhip_frame.h"
 #include "zhip_frame_lazy.h"
 #include "zhip_decode.h"
+#include "zhip_decode_big.h"
 
 // register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
 #ifndef ZHIP_DFAST_OCC
@@ -789,6 +790,46 @@ k_decode(const uint8_t* __restrict__ src, const ZhipDFrame* __restrict__ frames,
         decode_frame(S, src + fr.srcOff, fr.srcLen, dst + fr.dstOff, fr.dstCap, litBuf, recBuf, dict.content ? &dict : nullptr, defTabs, results + f);
     }
 }
+
+// ONE large frame, block-parallel (zhip_decode_big.h): src = the frame, out = its content; the launches in order
+__global__ void __launch_bounds__(64)
+k_bf_walk(const uint8_t* __restrict__ src, uint32_t srcLen, uint32_t hdrSize, uint32_t blockMax, uint32_t hasChecksum,
+          ZhipBfBlock* __restrict__ blocks, uint32_t capBlocks, ZhipBfInfo* __restrict__ info)
+{
+    bf_walk(src, srcLen, hdrSize, blockMax, hasChecksum, blocks, capBlocks, info);
+}
+__global__ void __launch_bounds__(256)
+k_bf_prep(const uint8_t* __restrict__ src, uint32_t blockMax, ZhipBfBlock* __restrict__ blocks, const ZhipBfInfo* __restrict__ info)
+{
+    uint32_t const bi = blockIdx.x * 256 + threadIdx.x;
+    if (bi < info->nBlocks) bf_prep(src, blockMax, blocks, bi);
+}
+__global__ void __launch_bounds__(64)
+k_bf_deps(ZhipBfBlock* __restrict__ blocks, ZhipBfInfo* __restrict__ info) { bf_deps(blocks, info); }
+// dynamic LDS = sizeof(DecShared); grid = number of blocks
+__global__ void __launch_bounds__(ZHIP_BF_THREADS)
+k_bf_entropy(const uint8_t* __restrict__ src, uint32_t blockMax, ZhipBfBlock* __restrict__ blocks, const ZhipBfInfo* __restrict__ info,
+             uint8_t* __restrict__ litArena, ZhipDSeq* __restrict__ recArena, const uint64_t* __restrict__ defTabs)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    if (blockIdx.x < info->nBlocks) bf_entropy_block((DecShared*)smem, src, blockMax, blocks, blockIdx.x, litArena, recArena, defTabs);
+}
+__global__ void __launch_bounds__(64)
+k_bf_scan(ZhipBfBlock* __restrict__ blocks, ZhipBfInfo* __restrict__ info, uint32_t dstCap)
+{
+    __shared__ uint32_t sh[64 * 3];
+    bf_scan(blocks, info, dstCap, sh);
+}
+__global__ void __launch_bounds__(256)
+k_bf_build(const uint8_t* __restrict__ src, const ZhipBfBlock* __restrict__ blocks, ZhipBfInfo* __restrict__ info, const uint8_t* __restrict__ litArena,
+           const ZhipDSeq* __restrict__ recArena, uint8_t* __restrict__ out, uint32_t* __restrict__ map)
+{
+    if (blockIdx.x < info->nBlocks && info->status == 0) bf_build_block(src, blocks, blockIdx.x, litArena, recArena, out, map, info);
+}
+__global__ void __launch_bounds__(256)
+k_bf_jump(uint32_t* __restrict__ map, uint32_t n, ZhipBfInfo* __restrict__ info) { bf_jump(map, n, &info->changed); }
+__global__ void __launch_bounds__(256)
+k_bf_copy(const uint32_t* __restrict__ map, uint8_t* __restrict__ out, uint32_t n) { bf_copy(map, out, n); }
 
 // content checksums: checks[] = XXH64 low words of the decoded frames (k_xxh64 over the destination)
 __global__ void __launch_bounds__(256)
