@@ -48,10 +48,15 @@ def test_big_frames_of_every_strategy_and_shape(env):
     ctx = z.Context(max_units=64)
     d = z.DContext()
     d.set_bigframe_min(1 << 20)
-    for level in (1, 3, 5, 8, -1):
-        ctx.set_row_matcher(0)
-        frame = ctx.compress_frames([mixed], level)[0]           # one multi-block frame: treeless literals, repeated FSE tables (5, 8), RLE / raw blocks
+    for level in (1, 3, -1):
+        frame = ctx.compress_frames([mixed], level)[0]           # one multi-block frame: treeless literals, RLE / raw blocks, long periodic matches
         assert d.decompress(frame) == mixed.tobytes(), level
+        assert d.last_bigframe()["block_parallel"] == 1, (level, d.last_bigframe())
+    light = np.concatenate([text_like(2 << 20, 4), datagen(lo, 256 << 10, 50, 6)])      # the lazy strategies repeat FSE tables by cost (their frame kernel is slow on long matches: kept small)
+    for level, row in ((5, 0), (8, 2)):
+        ctx.set_row_matcher(row)
+        frame = ctx.compress_frames([light], level)[0]
+        assert d.decompress(frame) == light.tobytes(), level
         assert d.last_bigframe()["block_parallel"] == 1, (level, d.last_bigframe())
     # several frames in one call, large and small mixed: the large ones block-parallel, the others as a batch, results in order
     small = [datagen(lo, n, 50, n) for n in (0, 5, 70000, 300000)]
