@@ -15,13 +15,16 @@ LEVELS = [int(x) for x in os.environ.get("LEVELS", "5,7").split(",")]
 for level in LEVELS:
     for kind in ("datagen", "text"):
         base = z.datagen(1 << 20, 50, 1) if kind == "datagen" else text_like(1 << 20, 1)
-        for nf in (256, 1024):
+        for nf in [int(x) for x in os.environ.get("NFRAMES", "256,1024").split(",")]:
             bufs = [base] * nf
             for rep in range(2):
                 outs = ctx.compress_frames(bufs, level)
             t = ctx.timing()
             print(json.dumps({"level": level, "kind": kind, "frames": nf, "frame_bytes": 1 << 20, "timing_ms": t, "csize": len(outs[0])}), flush=True)
-    big = np.concatenate([z.datagen(64 << 20, 50, s) for s in range(4)])
+    JP = int(os.environ.get("JOBPOOL_MIB", "256"))
+    if JP <= 0:
+        continue
+    big = np.concatenate([z.datagen(JP << 18, 50, s) for s in range(4)])
     for rep in range(2):
         outs = ctx.compress_frames([big], level, workers=4)
     t = ctx.timing()

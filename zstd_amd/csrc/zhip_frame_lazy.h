@@ -37,6 +37,8 @@ namespace zhip {
 
 #define ZHIP_LZ_LINK_THREADS 1024
 #define ZHIP_LZ_NONE 0xFFFFFFFFu
+#define ZHIP_LZ_PRED  0x40000000u             /* prev[] flag: the predicting parse expects this position to stay un-inserted (windows below 2^30 positions) */
+#define ZHIP_LZ_LINK(w) ((w) & 0x3FFFFFFFu)
 
 // one per workgroup-unit, filled by the host
 struct ZhipLzSlot {
@@ -170,12 +172,13 @@ __device__ inline LzRec lz_search_hc(const uint8_t* __restrict__ src, uint32_t e
     uint32_t const nm8 = end - 8, chainSize = 1u << chainLog;
     uint32_t attempts = 1u << searchLog;
     uint32_t ml = 3, off = 0, minCand = ZHIP_LZ_NONE, nCap = 0, capA = 0, capB = 0;
-    uint32_t m = prev[p];
+    uint32_t m = ZHIP_LZ_LINK(prev[p]);
     while (m != 0 && attempts) {
         uint32_t const mp = m - 1;
         if (mp < lowLimit) break;                                                  // :711 matchIndex >= lowLimit
-        uint32_t const nx = prev[mp];
-        minCand = mp;
+        uint32_t const wl = prev[mp], nx = ZHIP_LZ_LINK(wl);
+        minCand = mp;                                                              // the lowest position VISITED
+        if (wl & ZHIP_LZ_PRED) { m = nx; continue; }                               // the predicting parse left it out: not in the chain
         if (p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
             uint32_t cur = 0;
             for (;;) {
@@ -203,13 +206,15 @@ __device__ inline LzRec lz_search_rh(const uint8_t* __restrict__ src, uint32_t e
     uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
     uint32_t ml = 3, off = 0, minCand = ZHIP_LZ_NONE, nCap = 0, capA = 0, capB = 0;
     uint32_t const myTag = tags[p];
-    uint32_t m = prev[p];
+    uint32_t m = ZHIP_LZ_LINK(prev[p]);
     bool done = false;
     while (m != 0 && attempts && room) {
         uint32_t const mp = m - 1;
         if (mp < lowLimit) break;                                                  // :1235 (every older entry is below it too)
-        uint32_t const w = prev[mp], tg = tags[mp];
-        minCand = mp; room--;
+        uint32_t const wl = prev[mp], w = ZHIP_LZ_LINK(wl); uint32_t const tg = tags[mp];
+        minCand = mp;                                                              // the lowest position VISITED
+        if (wl & ZHIP_LZ_PRED) { m = w; continue; }                                // the predicting parse left it out: it takes no slot of the row
+        room--;
         if (tg == myTag) {
             attempts--;
             if (!done && p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
@@ -236,8 +241,11 @@ __device__ inline LzRec lz_search_rh(const uint8_t* __restrict__ src, uint32_t e
 struct LzState {
     uint32_t ntu;           // ms->nextToUpdate (hash chain: the last searched position; rows: one past it)
     uint32_t skipping;      // ms->lazySkipping
-    uint32_t gapEnd;        // highest position flagged as never inserted, 0 = none
-    uint32_t* dirty;        // one bit per key: a position with that key was flagged
+    uint32_t gapEnd;        // highest position decided otherwise than predicted, 0 = none
+    uint32_t* dirty;        // one bit per key: a position with that key was decided otherwise than predicted
+    uint32_t predict;       // 1: the PREDICTING parse (zhip_parse_lazy.h: rh_reconcile) — positions it would leave out get ZHIP_LZ_PRED, nothing is flagged or stored
+    uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
+    uint32_t nPred;         // predicting parse: positions marked so far
 };
 __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
 {
@@ -246,19 +254,49 @@ __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
     o.minCand = __builtin_amdgcn_readlane(r.minCand, l); o.mode = __builtin_amdgcn_readlane(r.mode, l);
     return o;
 }
-// flag the never-inserted positions [f0, f1) (all below the window's end - 8)
+// exact parse: the positions [st.scanned, upTo) were inserted — those the predicting parse expected to be left out are mismatches
+__device__ inline void lz_reconcile(const uint8_t* __restrict__ src, const ZhipUnit& u, const uint32_t* prev, LzState& st, uint32_t upTo)
+{
+    if (st.predict || upTo <= st.scanned) return;
+    bool any = false;
+    for (uint32_t q0 = st.scanned; q0 < upTo; q0 += 64) {
+        uint32_t const q = q0 + (uint32_t)lane_id();
+        uint32_t const w = q < upTo ? prev[q] : 0;
+        bool const mism = (w & ZHIP_LZ_PRED) && !(w & ZHIP_HC_SKIPPED);
+        if (mism) { uint32_t tag; uint32_t const k = lz_key(ld64(src + q), u, tag); atomicOr(&st.dirty[k >> 5], 1u << (k & 31)); }
+        if (__ballot(mism)) any = true;
+    }
+    if (any) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; }
+    st.scanned = upTo;
+}
+// the never-inserted positions [f0, f1) (all below the window's end - 8): flagged; the keys of those that were not predicted are marked
 __device__ inline void lz_flag_range(const uint8_t* __restrict__ src, const ZhipUnit& u, uint32_t* prev, LzState& st, uint32_t f0, uint32_t f1)
 {
     if (f1 <= f0) return;
-    for (uint32_t q = f0 + (uint32_t)lane_id(); q < f1; q += 64) {
-        prev[q] |= ZHIP_HC_SKIPPED;
-        uint32_t tag;
-        uint32_t const k = lz_key(ld64(src + q), u, tag);
-        atomicOr(&st.dirty[k >> 5], 1u << (k & 31));
+    if (st.predict) {
+        for (uint32_t q = f0 + (uint32_t)lane_id(); q < f1; q += 64) prev[q] |= ZHIP_LZ_PRED;
+        st.nPred += f1 - f0;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    lz_reconcile(src, u, prev, st, f0);
+    bool any = false;
+    for (uint32_t q0 = f0; q0 < f1; q0 += 64) {
+        uint32_t const q = q0 + (uint32_t)lane_id();
+        bool mism = false;
+        if (q < f1) {
+            uint32_t const w = prev[q];
+            prev[q] = w | ZHIP_HC_SKIPPED;
+            mism = !(w & ZHIP_LZ_PRED);
+            if (mism) { uint32_t tag; uint32_t const k = lz_key(ld64(src + q), u, tag); atomicOr(&st.dirty[k >> 5], 1u << (k & 31)); }
+        }
+        if (__ballot(mism)) any = true;
     }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    if (f1 - 1 > st.gapEnd) st.gapEnd = f1 - 1;
+    if (any && f1 - 1 > st.gapEnd) st.gapEnd = f1 - 1;
+    if (f1 > st.scanned) st.scanned = f1;
 }
 __device__ __forceinline__ bool lz_dirty(const uint8_t* __restrict__ src, const ZhipUnit& u, const LzState& st, uint32_t x)
 {
@@ -273,19 +311,19 @@ __device__ inline void lz_live_hc(const uint8_t* __restrict__ src, uint32_t bEnd
     uint32_t const nm8 = bEnd - 8, chainSize = 1u << chainLog;
     uint32_t attempts = 1u << searchLog;
     uint32_t ml = 3, off = 0;
-    uint32_t m = uni(prev[x]) & ~ZHIP_HC_SKIPPED;
+    uint32_t m = ZHIP_LZ_LINK(uni(prev[x]));
     while (m != 0) {
         uint32_t const mp = m - 1;
         if (mp < lowLimit) break;
         uint32_t const w = uni(prev[mp]);
-        if (w & ZHIP_HC_SKIPPED) { m = w & ~ZHIP_HC_SKIPPED; continue; }
+        if (w & ZHIP_HC_SKIPPED) { m = ZHIP_LZ_LINK(w); continue; }
         if (uni(ld32(src + mp + ml - 3)) == uni(ld32(src + x + ml - 3))) {
             uint32_t const cur = (wave_count_fwd(src, x, mp, nm8));
             if (cur > ml) { ml = cur; off = x - mp; if (x + cur == bEnd) break; }
         }
         if (--attempts == 0) break;
         if (x >= chainSize && mp <= x - chainSize) break;
-        m = w;
+        m = ZHIP_LZ_LINK(w);
     }
     mlOut = ml; offOut = off;
 }
@@ -296,13 +334,13 @@ __device__ inline void lz_live_rh(const uint8_t* __restrict__ src, uint32_t bEnd
     uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
     uint32_t ml = 3, off = 0;
     uint32_t const myTag = uni((uint32_t)tags[x]);
-    uint32_t m = uni(prev[x]) & ~ZHIP_HC_SKIPPED;
+    uint32_t m = ZHIP_LZ_LINK(uni(prev[x]));
     bool done = false;
     while (m != 0 && attempts && room) {
         uint32_t const mp = m - 1;
         if (mp < lowLimit) break;
         uint32_t const w = uni(prev[mp]);
-        m = w & ~ZHIP_HC_SKIPPED;
+        m = ZHIP_LZ_LINK(w);
         if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
         room--;
         if (uni((uint32_t)tags[mp]) != myTag) continue;
@@ -335,6 +373,7 @@ __device__ inline void lz_search(const LzBlock& B, const ZhipUnit& u, LzState& s
         if (st.skipping && st.ntu + 1 < x) lz_flag_range(B.src, u, B.prev, st, st.ntu + 1, x);      // :651 only nextToUpdate itself is inserted
         st.ntu = x;
     }
+    lz_reconcile(B.src, u, B.prev, st, x);               // everything below x is decided now: was it what the predicting parse expected?
     uint32_t off;
     bool live = rec.mode == 3 || x + ZHIP_HC_CAP > B.bEnd;
     if (!live && st.gapEnd != 0 && rec.minCand != ZHIP_LZ_NONE && rec.minCand <= st.gapEnd) live = lz_dirty(B.src, u, st, x);
@@ -396,6 +435,10 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
                 if (valid) recj = B.best[xj];
                 uint32_t const cur4 = ld32(src + xc + 1), rv = ld32(src + (xc + 1 - off1));
                 repj = valid && off1 > 0 && rv == cur4;                      // :1600 repcode at ip+1
+                if (!st.predict) {                                           // the batch's positions (and what lies between them) are inserted by its searches
+                    uint32_t const Kv = (uint32_t)__popcll(__ballot(valid));
+                    if (Kv) lz_reconcile(src, u, B.prev, st, ip + (Kv - 1) * step);
+                }
                 bool stale = valid && (xj + ZHIP_HC_CAP > bEnd);
                 if (!stale && valid && st.gapEnd != 0 && recj.minCand != ZHIP_LZ_NONE && recj.minCand <= st.gapEnd) stale = lz_dirty(src, u, st, xc);
                 bool const needLive = valid && (recj.mode == 3 || stale);
@@ -488,21 +531,25 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
                     off2 = off1; off1 = off;
                 }
             }
+            if (!st.predict) {
             lits_copy(out, src, nm8, anchor, start - anchor);                // :1727-1731
             store_seq(out, start - anchor, offBase, matchLength);
+            }
             anchor = ip = start + matchLength;
             st.skipping = 0;                                                 // :1732-1738
             while (ip <= ilimit && off2 > 0) {                               // :1763-1773
                 if (uni(ld32(src + ip)) != uni(ld32(src + (ip - off2)))) break;
                 uint32_t const rl = 4 + (wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8));
                 {   uint32_t const t = off2; off2 = off1; off1 = t; }
-                store_seq(out, 0, 1, rl);
+                if (!st.predict) store_seq(out, 0, 1, rl);
                 ip += rl; anchor = ip;
             }
         }
+        if (!st.predict) {
         lits_copy(out, src, nm8, anchor, bEnd - anchor);                    // trailing literals (zstd_compress.c:3365)
         lits_flush(out);
-    } else {
+        }
+    } else if (!st.predict) {
         for (uint32_t i = lane; i < bLen; i += 64) lits[i] = src[bStart + i];
         out.litPos = bLen;
     }
@@ -583,6 +630,33 @@ __device__ inline void lz_keep_fse_table(ZhipDictEntropy* ent, const EntShared* 
     if (t > maxSym && t < 56) ent->ct[k].dBits[t] = ((tl + 1) << 16) - (1u << tl);
 }
 
+// The PREDICTING parse of a window (one wavefront; see rh_reconcile in zhip_parse_lazy.h): the block loop with fixed 128 KB blocks (the real
+// borders depend on the compressed sizes; a border a few KB off only costs a few mispredictions), every block taken as confirmed, nothing
+// stored.  Data without long matches leaves almost nothing un-inserted: when the first block marked less than 1 position in 64, the rest
+// of the window is not parsed twice.
+__device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const ZhipUnit& u, uint32_t* prev, const uint8_t* tags, const LzRec* best,
+                                          ZhipParse* meta /* LDS */, const ZhipJob* __restrict__ job)
+{
+    bool const first = !job || (job->flags & ZHIP_JOB_FIRST);
+    uint32_t const j0 = job ? job->prefixLen : 0u, jEnd = j0 + u.srcLen, maxDist = 1u << u.windowLog;
+    if (jEnd >= (1u << 30)) return;                            // bit 30 of a link is the mark
+    uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u, low = 0;
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0;
+    for (uint32_t pos = j0; pos < jEnd; ) {
+        uint32_t const bLen = jEnd - pos < ZHIP_UNIT_MAX ? jEnd - pos : ZHIP_UNIT_MAX;
+        if (bLen >= 7) {
+            if (pos > maxDist && pos - maxDist > low) low = pos - maxDist;
+            LzBlock B; B.src = src; B.bStart = pos; B.bEnd = pos + bLen; B.low = low; B.maxDist = maxDist; B.prev = prev; B.tags = tags; B.best = best;
+            parse_lazy_block(B, u, ls, rep1, rep2, rep3, nullptr, nullptr, meta);
+            __builtin_amdgcn_wave_barrier();
+            rep1 = meta->rep[0]; rep2 = meta->rep[1]; rep3 = meta->rep[2];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pos == j0 && ls.nPred * 64u < bLen) return;
+        pos += bLen;
+    }
+}
+
 // job == nullptr: the whole input src[0, u.srcLen) as one frame; else one job of a frame, src = the start of the job's window
 __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipLzSlot& L, uint32_t* prev, const uint8_t* tags, const LzRec* best,
                                   uint32_t* dirty, ZhipSeq* seqs, uint8_t* lits, uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
@@ -611,7 +685,7 @@ __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUni
     long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
     uint32_t pos = j0, low = 0;
     uint32_t const maxDist = 1u << u.windowLog;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty;             // a job: nextToUpdate = the prefix's end
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0;      // a job: nextToUpdate = the prefix's end
     __threadfence_block();
     __syncthreads();
     while (pos < jEnd) {

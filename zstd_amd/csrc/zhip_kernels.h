@@ -365,11 +365,13 @@ k_hc_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
 // k_hc_search with the unit staged in LDS: one 1024-thread workgroup per unit, dynamic LDS = longest unit + 16.
 __global__ void __launch_bounds__(ZHIP_HC_SEARCH_LDS_THREADS)
 k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
-                const uint32_t* __restrict__ tabs, size_t tabStride, uint64_t* __restrict__ best)
+                const uint32_t* __restrict__ tabs, size_t tabStride, uint64_t* __restrict__ best,
+                const ZhipParse* __restrict__ metas /* not nullptr: only the units whose TRY parse gave up (ZHIP_PARSE_REDO) */)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const ui = blockIdx.x, t = threadIdx.x;
     if (ui >= nUnits) return;
+    if (metas && metas[ui].status != ZHIP_PARSE_REDO) return;
     ZhipUnit const u = units[ui];
     uint32_t const n = u.srcLen;
     if (u.strategy < ZHIP_STRAT_GREEDY || n < 10) return;
@@ -392,16 +394,20 @@ k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
 __global__ void __launch_bounds__(64) ZHIP_LAZY_OCC
 k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
              uint32_t* __restrict__ tabs, size_t tabStride, const uint64_t* __restrict__ best,
-             ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+             ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
+             uint32_t mode /* 0: the parse.  The row matcher's two-pass prediction (zhip_parse_lazy.h: rh_reconcile): 2 = TRY — the parse, given up (status
+                              ZHIP_PARSE_REDO) once `budget` searches had to be redone live; then, for those units only, 1 = the predicting parse, and 3 = the parse again */,
+             uint32_t budget)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)                // ZHIP_RH_DIRTY_BYTES: the row matcher's dirty-row bits
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
+    if ((mode == 1 || mode == 3) && metas[ui].status != ZHIP_PARSE_REDO) return;
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
     parse_lazy_unit(src + u.srcOff, u.srcLen, u, smem, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
-                    seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui);
+                    seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui, mode == 1, mode == 2 ? budget : 0u);
 }
 
 // Copy mode of a dictionary (sources above the attach cut-off): k_ext_init gives every such source a private copy of the
@@ -569,6 +575,19 @@ k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
     uint32_t const maxDist = 1u << u.windowLog, lowLimit = p > maxDist ? p - maxDist : 0u;
     best[L.posOff + p] = u.rowLog ? lz_search_rh(w, L.span, p, prev + L.posOff, tags + L.posOff, u.searchLog, u.rowLog, lowLimit)
                                   : lz_search_hc(w, L.span, p, prev + L.posOff, u.searchLog, u.chainLog, lowLimit);
+}
+// k_lz_predict: one wavefront per unit, dynamic LDS = sizeof(ZhipParse): the predicting parse (frame_lazy_predict); k_lz_search runs again after it
+__global__ void __launch_bounds__(64)
+k_lz_predict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t nW,
+             uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, const LzRec* __restrict__ best)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
+    uint32_t const wi = blockIdx.x;
+    if (wi >= nW) return;
+    ZhipUnit const u = units[wi];
+    if (u.strategy < ZHIP_STRAT_GREEDY || u.srcLen == 0) return;
+    ZhipLzSlot const L = lz[wi];
+    frame_lazy_predict(lz_window(src, u, jobs, wi), u, prev + L.posOff, tags + L.posOff, best + L.posOff, (ZhipParse*)smem, jobs ? jobs + wi : (const ZhipJob*)nullptr);
 }
 // k_frame_lazy: dynamic LDS = frame_lazy_lds_bytes()
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)

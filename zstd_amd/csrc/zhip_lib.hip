@@ -514,13 +514,33 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 else {
                     if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_search_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
-                                       srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
+                                       srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)nullptr);
                 }
             }
             HIPCHK(c, hipEventRecord(he[2], s));
-            hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                               srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
-                               c->dSeqs, c->dLits, c->dParse + u0);
+            {   // row matcher: the two-pass prediction of the positions the 384-position rule leaves out (zhip_parse_lazy.h: rh_reconcile).  The
+                // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
+                // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
+                // long matches never leaves the first launch ($ZHIP_RH_PREDICT=0: one pass, $ZHIP_RH_BUDGET: the budget)
+                static int const predictOn = getenv("ZHIP_RH_PREDICT") ? atoi(getenv("ZHIP_RH_PREDICT")) : 1;
+                static int const budget = getenv("ZHIP_RH_BUDGET") ? atoi(getenv("ZHIP_RH_BUDGET")) : 256;
+                bool anyRow = false;
+                for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
+                if (predictOn && anyRow && budget > 0) {
+                    size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
+                    hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 2u, (uint32_t)budget);
+                    hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 1u, 0u);
+                    hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
+                                       srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)(c->dParse + u0));
+                    hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 3u, 0u);
+                } else
+                hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
+                                   srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
+                                   c->dSeqs, c->dLits, c->dParse + u0, 0u, 0u);
+            }
             HIPCHK(c, hipEventRecord(he[3], s));
         }
     } else c->hcEvUsed = 0;
@@ -883,6 +903,18 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
             size_t const nw = nU - w0 < 32768 ? nU - w0 : 32768;
             hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
                                (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+        }
+        {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=0: one pass)
+            static int const predictOn = getenv("ZHIP_LZ_PREDICT") ? atoi(getenv("ZHIP_LZ_PREDICT")) : 1;
+            if (predictOn) {
+                hipLaunchKernelGGL(zhip::k_lz_predict, dim3((unsigned)nU), dim3(64), sizeof(ZhipParse), s,
+                                   (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+                for (size_t w0 = 0; w0 < nU; w0 += 32768) {
+                    size_t const nw = nU - w0 < 32768 ? nU - w0 : 32768;
+                    hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
+                                       (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+                }
+            }
         }
         hipLaunchKernelGGL(zhip::k_frame_lazy, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), zhip::frame_lazy_lds_bytes(), s,
                            (const uint8_t*)srcDev, c->dUnits, c->dSlots, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dLzHeads,

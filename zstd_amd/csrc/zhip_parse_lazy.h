@@ -40,6 +40,7 @@ namespace zhip {
 #endif
 #define ZHIP_HC_NONE     0x1FFFFu            /* "no candidate" in the minCand field */
 #define ZHIP_HC_SKIPPED  0x80000000u         /* prev[] flag: position was never inserted (lazy skipping) */
+#define ZHIP_HC_PRED     0x40000000u         /* prev[] flag, row matcher: a first parse in predict mode expects this position to be skipped (two-pass prediction, see rh_reconcile) */
 #define ZHIP_HC_SEARCH_THREADS 256
 #define ZHIP_HC_SEARCH_LDS_THREADS 1024
 
@@ -352,7 +353,9 @@ __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
     while (m != 0 && attempts && room) {
         uint32_t const mp = m - 1;
         uint32_t const w = prev[mp];
-        minCand = mp; room--;
+        minCand = mp;                                                       // the lowest position VISITED (predicted-skipped ones included)
+        if (w & ZHIP_HC_PRED) { m = w & ZHIP_RH_LINK_MASK; continue; }      // the predicting parse skipped it: it takes no slot of the row
+        room--;
         if (((w >> 18) & 0xFFu) == myTag) {
             attempts--;
             if (!done && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
@@ -378,29 +381,91 @@ struct HcState {
     uint32_t ntu;           // ms->nextToUpdate (zstd_compress_internal.h:232)
     uint32_t skipping;      // ms->lazySkipping (:253)
     uint32_t gapEnd;        // highest position flagged ZHIP_HC_SKIPPED so far, 0 = none (position 0 is always inserted)
-    lds_u32* dirty;         // row matcher: one bit per row, set when a position of that row was flagged (2^(hashLog - rowLog) bits of LDS)
+    lds_u32* dirty;         // row matcher: one bit per row, set when a position of that row was decided otherwise than predicted (2^(hashLog - rowLog) bits of LDS)
+    uint32_t predict;       // 1: the PREDICTING parse — positions it would skip get ZHIP_HC_PRED, nothing is flagged, nothing is stored
+    uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
+    uint32_t nLive;         // searches redone live (statistics: ZhipParse.pad0)
+    uint32_t budget;        // TRY parse: give up (the unit is parsed again with the prediction) once this many searches went live; 0 = never
+    uint32_t abort;
 };
+#define ZHIP_PARSE_REDO 0x5245444Fu          /* ZhipParse.status of a unit whose TRY parse gave up */
 #define ZHIP_RH_DIRTY_BYTES 2048u      /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
 
-// row matcher: mark the rows of the never-inserted positions [f0, f1): only searches in such a row can differ from their record
+// Two-pass prediction (row matcher).  A record is computed before the parse knows which positions it will leave un-inserted; on
+// long-match data the 384-position rule skips the inside of every long match, nearly every row then holds such a position and every
+// search would have to be redone live.  So the parse runs twice: first in PREDICT mode — rule logged (ZHIP_HC_PRED), not applied, no live
+// searches, nothing stored —, then k_hc_search_lds again, stepping over the predicted positions, then the exact parse, which only
+// distrusts a record when a position of its row at or above the record's lowest visited one was DECIDED OTHERWISE than predicted
+// (flagged but not predicted: found when it is flagged; predicted but inserted: found by rh_reconcile as the parse passes it).
+// Without the first pass every flagged position is such a mismatch: the one-pass behaviour.
+template <uint32_t MLS>
+__device__ inline void rh_reconcile_t(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
+{
+    uint32_t const nm8 = n - 8, hBits = (uint32_t)u.hashLog - u.rowLog + 8;
+    uint64_t const salt = rh_fresh_salt();
+    bool any = false;
+    for (uint32_t q0 = st.scanned; q0 < upTo; q0 += 64) {
+        uint32_t const q = q0 + (uint32_t)lane_id();
+        uint32_t const w = q < upTo ? prev[q] : 0;
+        bool const mism = (w & ZHIP_HC_PRED) && !(w & ZHIP_HC_SKIPPED);       // predicted skipped, but it was inserted
+        if (mism) {
+            uint32_t const qc = q < nm8 ? q : nm8;
+            uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + qc) : ld64(src + qc);
+            uint32_t const row = hash_pos_salted<MLS>(bytes, hBits, salt) >> 8;
+            __hip_atomic_fetch_or(&st.dirty[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (__ballot(mism)) any = true;
+    }
+    if (any) { __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; }
+    st.scanned = upTo;
+}
+__device__ inline void rh_reconcile(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
+{
+    if (st.predict || upTo <= st.scanned) return;
+    uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
+    if (mls == 4) rh_reconcile_t<4>(src, n, u, prev, st, upTo);
+    else if (mls == 5) rh_reconcile_t<5>(src, n, u, prev, st, upTo);
+    else rh_reconcile_t<6>(src, n, u, prev, st, upTo);
+}
+// row matcher: the never-inserted positions [f0, f1) — flagged; the rows of those that were not predicted are marked: only searches in
+// such a row can differ from their record
 template <uint32_t MLS>
 __device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t f0, uint32_t f1)
 {
     uint32_t const nm8 = n - 8, hBits = (uint32_t)u.hashLog - u.rowLog + 8;
     uint64_t const salt = rh_fresh_salt();
-    for (uint32_t q = f0 + (uint32_t)lane_id(); q < f1; q += 64) {
-        prev[q] |= ZHIP_HC_SKIPPED;
-        uint32_t const qc = q < nm8 ? q : nm8;
-        uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + qc) : ld64(src + qc);
-        uint32_t const row = hash_pos_salted<MLS>(bytes, hBits, salt) >> 8;
-        __hip_atomic_fetch_or(&st.dirty[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (st.predict) {
+        for (uint32_t q = f0 + (uint32_t)lane_id(); q < f1; q += 64) prev[q] |= ZHIP_HC_PRED;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    bool any = false;
+    for (uint32_t q0 = f0; q0 < f1; q0 += 64) {
+        uint32_t const q = q0 + (uint32_t)lane_id();
+        bool mism = false;
+        if (q < f1) {
+            uint32_t const w = prev[q];
+            prev[q] = w | ZHIP_HC_SKIPPED;
+            mism = !(w & ZHIP_HC_PRED);
+            if (mism) {
+                uint32_t const qc = q < nm8 ? q : nm8;
+                uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + qc) : ld64(src + qc);
+                uint32_t const row = hash_pos_salted<MLS>(bytes, hBits, salt) >> 8;
+                __hip_atomic_fetch_or(&st.dirty[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        if (__ballot(mism)) any = true;
     }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    st.gapEnd = f1 - 1;
+    if (any && f1 - 1 > st.gapEnd) st.gapEnd = f1 - 1;
+    if (f1 > st.scanned) st.scanned = f1;
 }
 __device__ inline void rh_flag_range(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t f0, uint32_t f1)
 {
+    if (f1 <= f0) return;
+    rh_reconcile(src, n, u, prev, st, f0);                 // what lies between the last decided position and this range was inserted
     uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
     if (mls == 4) rh_flag_range_t<4>(src, n, u, prev, st, f0, f1);
     else if (mls == 5) rh_flag_range_t<5>(src, n, u, prev, st, f0, f1);
@@ -528,6 +593,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
         if (!st.skipping) rh_gap_rule(src, n, u, prev, st, x);
         else if (st.ntu < x) rh_flag_range(src, n, u, prev, st, st.ntu, x);
         st.ntu = x + 1;                                   // the searched position is inserted by the search itself (:1251-1255)
+        rh_reconcile(src, n, u, prev, st, x);             // everything below x is decided now: was it what the first pass predicted?
     } else {
     if (st.skipping && st.ntu + 1 < x) {                  // :651 only nextToUpdate itself is inserted; the rest never will be
         for (uint32_t q = st.ntu + 1 + (uint32_t)lane_id(); q < x; q += 64) prev[q] |= ZHIP_HC_SKIPPED;
@@ -542,6 +608,8 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     bool live = mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd);
     if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x);      // a record only depends on its own row
     if (live) {
+        st.nLive++;
+        if (st.budget && st.nLive > st.budget) st.abort = 1;
         if (u.rowLog) rh_search_live(src, n, x, prev, u.searchLog, u.rowLog, ml, off);
         else hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
     }
@@ -558,9 +626,11 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     offBase = off + 3;
 }
 
+// predict: the first of the row matcher's two parses (see rh_reconcile) — same walk, but the positions the 384-position rule or lazy
+// skipping would leave out are only MARKED in prev[] (ZHIP_HC_PRED); no sequences, literals or meta are written
 __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem /* ZHIP_RH_DIRTY_BYTES */,
                                        uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
-                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
+                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0)
 {
     uint32_t const lane = (uint32_t)lane_id();
     {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
@@ -577,10 +647,11 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     if (off1 > 1) { saved1 = off1; off1 = 0; }
 
     uint32_t const rowBias = u.rowLog ? 1u : 0u;          // the row matcher's nextToUpdate sits one past the last searched position
+    uint32_t nLiveOut = 0;
     if (n >= (u.rowLog ? 18u : 10u)) {
     uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
-    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem;
+    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
@@ -590,7 +661,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         pfCur4 = ld32(src + xc + 1); pfRv = ld32(src + (xc + 1 - o1));
         pfIp = at; pfOff1 = o1;
     };
-    while (ip < ilimit) {                                                    // :1581
+    while (ip < ilimit && !st.abort) {                                       // :1581
         uint32_t const step = ((ip - anchor) >> 8) + 1;                      // :1614 kSearchStrength = 8
         // ---- the next position where something happens (repcode hit at x+1, or a search that needs a closer look)
         uint32_t x, K = 0, ip0 = ip;
@@ -606,6 +677,10 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             if (pfIp == ip && pfOff1 == off1 && step == 1) { recj = pfRec; cur4 = pfCur4; rv = pfRv; }   // loaded while the last sequence was finished
             else { recj = valid ? best[xj] : 0; cur4 = ld32(src + xc + 1); rv = ld32(src + (xc + 1 - off1)); }
             repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
+            if (u.rowLog && !predict) {                                       // the batch's positions (and what lies between them) are inserted by its searches
+                uint32_t const Kv = (uint32_t)__popcll(__ballot(valid));
+                if (Kv) rh_reconcile(src, n, u, prev, st, ip + (Kv - 1) * step);
+            }
             uint32_t const minCand = hc_rec_min(recj);
             bool stale = st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd;
             if (u.rowLog && st.gapEnd != 0) {
@@ -707,21 +782,27 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
                 off2 = off1; off1 = off;
             }
         }
+        if (!predict) {
         lits_copy(out, src, nm8, anchor, start - anchor);                    // :1727-1731
         store_seq(out, start - anchor, offBase, matchLength);
+        }
         anchor = ip = start + matchLength;
         st.skipping = 0;                                                     // :1732-1738
         while (ip <= ilimit && off2 > 0) {                                   // :1763-1773
             if (uni(ld32(src + ip)) != uni(ld32(src + (ip - off2)))) break;
             uint32_t const rl = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
             {   uint32_t const t = off2; off2 = off1; off1 = t; }
-            store_seq(out, 0, 1, rl);
+            if (!predict) store_seq(out, 0, 1, rl);
             ip += rl; anchor = ip;
         }
     }
+    if (predict) return;
+    if (st.abort) { if (lane == 0) meta->status = ZHIP_PARSE_REDO; return; }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
     lits_flush(out);
+    nLiveOut = st.nLive;
     } else {
+        if (predict) return;
         for (uint32_t i = lane; i < n; i += 64) lits[i] = src[i];
         out.litPos = n;
     }
@@ -731,7 +812,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
         meta->longPos = out.longPos; meta->longType = out.longType;
         meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = 8;
-        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
+        meta->status = 0; meta->litSize = out.litPos; meta->pad0 = nLiveOut;      // pad0: searches redone live (statistics only)
     }
 }
 
