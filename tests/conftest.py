@@ -28,3 +28,13 @@ def _oracle_hash_chain_mode_by_default():
     except Exception:
         pass
     yield
+
+
+def pytest_collection_modifyitems(config, items):
+    """a GPU test that does not come back is a failed run, not a stalled one: pytest-timeout (thread method: works while the test sits in a
+    HIP call) ends the process after 4 minutes; the whole -m gpu suite takes about one"""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") is not None and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(240, method="thread"))

@@ -89,12 +89,12 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     else
         simt::launch({nUnits, 1, 1}, {ZHIP_HC_SEARCH_LDS_THREADS, 1, 1}, ((maxLen + 15) & ~15u) + 32,
                      [=] { zhip::k_hc_search_lds(src, units, nUnits, tabs, tabStride, best, (const ZhipParse*)nullptr); }, osThreads);
-    // the row matcher's two-pass prediction, as the host library launches it ($ZHIP_RH_PREDICT=0: one pass; $ZHIP_RH_BUDGET: live searches a TRY parse may make)
+    // the row matcher's two-pass prediction, as the host library launches it ($ZHIP_RH_PREDICT=1 turns it on, as in the library; $ZHIP_RH_BUDGET: live searches a TRY parse may make)
     bool anyRow = false; for (uint32_t i = 0; i < nUnits; i++) anyRow = anyRow || units[i].rowLog != 0;
     const char* const pe = getenv("ZHIP_RH_PREDICT"); const char* const be = getenv("ZHIP_RH_BUDGET");
     uint32_t const budget = be ? (uint32_t)atoi(be) : 256u;
     const ZhipParse* const cm = metas;
-    if (anyRow && !(pe && atoi(pe) == 0)) {
+    if (anyRow && pe && atoi(pe) != 0) {
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
                      [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 2u, budget); }, osThreads);
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
@@ -347,8 +347,8 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
                  [=] { zhip::k_lz_links(src, units, jobs, lz, nW, pv, tg, hd); }, osThreads);
     simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0,
                  [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs); }, osThreads);
-    {   const char* const pe = getenv("ZHIP_LZ_PREDICT");        // the two-pass prediction, as the host library launches it ($ZHIP_LZ_PREDICT=0: one pass)
-        if (!(pe && atoi(pe) == 0)) {
+    {   const char* const pe = getenv("ZHIP_LZ_PREDICT");        // the two-pass prediction, as the host library launches it ($ZHIP_LZ_PREDICT=1 turns it on, as in the library)
+        if (pe && atoi(pe) != 0) {
             simt::launch({nW, 1, 1}, {64, 1, 1}, sizeof(ZhipParse), [=] { zhip::k_lz_predict(src, units, jobs, lz, nW, pv, tg, bs); }, osThreads);
             simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0, [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs); }, osThreads);
         }

@@ -63,3 +63,17 @@ def test_lazy_job_pool_frames_match_oracle(libs, level, row, js, ov, ck):
     finally:
         lo.zo_set_row_matcher(0)
     assert got == want, (level, row, js, ov, ck)
+
+
+def test_lazy_frames_with_the_two_pass_prediction(libs, monkeypatch):
+    """$ZHIP_LZ_PREDICT=1: k_lz_predict marks what the parse will leave un-inserted, k_lz_search runs again without those positions, the exact
+    parse only distrusts records where prediction and truth differ — same frames"""
+    lo, le = libs
+    monkeypatch.setenv("ZHIP_LZ_PREDICT", "1")
+    cases = _cases(lo)
+    bufs = [a for _, a in cases]
+    for level, row in ((5, 1), (9, 0)):
+        cps = [_cp(lo, level, len(a)) for a in bufs]
+        got = emu_compress_frames_lazy(le, lo, bufs, cps, row)
+        for (name, a), cp, g in zip(cases, cps, got):
+            assert g == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (name, level, row)

@@ -3,7 +3,7 @@ CPU only: this checks the wave-parallel algorithm, not the GPU build."""
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_)
+from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_, datagen, text_like)
 
 
 @pytest.fixture(scope="module")
@@ -281,3 +281,45 @@ def test_queue_form_of_the_fast_stage_on_the_emulator(libs, monkeypatch, mode):
             cases += list(corpus_cases(lo, sizes=(n,), seeds=(level + 11,)))
         cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] == 1]
         check(le, lo, cases, level)
+
+
+def test_rowhash_two_pass_prediction(libs, monkeypatch):
+    """$ZHIP_RH_PREDICT=1: the parse is tried, units that had to redo more than a budget of searches live are parsed again after a predicting
+    parse marked the positions the 384-position rule / lazy skipping will leave out and the records were recomputed without them
+    (zhip_parse_lazy.h: rh_reconcile).  Same sequences as the oracle; far fewer live searches on long-match data."""
+    lo, le = libs
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(1)
+    try:
+        rng = np.random.default_rng(3)
+        big = np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 190)[:131072].copy()
+        big[rng.integers(0, 131072, 40)] ^= 0xFF
+        a = datagen(lo, 2 * 131072 + 5, 35, 2)
+        bufs = [datagen(lo, 131072, 50, 1), a[:131072], a[131072:262144], a[262144:], big, text_like(60000, 2)]       # incl. a 5-byte unit
+        for level in (5, 8):
+            live = {}
+            for mode in ("0", "1"):
+                monkeypatch.setenv("ZHIP_RH_PREDICT", mode)
+                units = make_units(lo, [len(b) for b in bufs], level, row=True)
+                src = np.concatenate(bufs + [np.zeros(16, dtype=np.uint8)])
+                cap = le.emu_seq_cap()
+                seqs = np.zeros(len(bufs) * cap, dtype=SEQ_DT); metas = np.zeros(len(bufs), dtype=PARSE_DT)
+                lstride = le.emu_lit_stride()
+                lits = np.full(len(bufs) * lstride, 0xEE, dtype=np.uint8)
+                emu_parse_units(le, src, units, seqs, lits, metas)
+                for i, b in enumerate(bufs):
+                    oseqs, litSize, rep, olits = oracle_parse(lo, b, level, want_lits=True)
+                    m = metas[i]
+                    assert int(m["status"]) == 0
+                    s = seqs[i * cap: i * cap + int(m["nbSeq"])]
+                    ll = s["litLength"].astype(np.uint32); ml = s["mlBase"].astype(np.uint32) + 3
+                    if m["longType"] == 1: ll[m["longPos"]] += 0x10000
+                    if m["longType"] == 2: ml[m["longPos"]] += 0x10000
+                    got = np.stack([ll, ml, s["offBase"]], axis=1) if len(s) else np.zeros((0, 3), np.uint32)
+                    assert len(got) == len(oseqs) and (got == oseqs).all(), (level, mode, i)
+                    assert int(m["litSize"]) == litSize and np.array_equal(lits[i * lstride: i * lstride + litSize], olits), (level, mode, i)
+                live[mode] = metas["pad0"].astype(np.int64)
+            assert live["1"][0] * 3 < live["0"][0], (level, live)          # datagen P50: most searches were live, now few are
+            assert live["1"].sum() < live["0"].sum()
+    finally:
+        lo.zo_set_row_matcher(0)

@@ -521,8 +521,8 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             {   // row matcher: the two-pass prediction of the positions the 384-position rule leaves out (zhip_parse_lazy.h: rh_reconcile).  The
                 // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
                 // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
-                // long matches never leaves the first launch ($ZHIP_RH_PREDICT=0: one pass, $ZHIP_RH_BUDGET: the budget)
-                static int const predictOn = getenv("ZHIP_RH_PREDICT") ? atoi(getenv("ZHIP_RH_PREDICT")) : 1;
+                // long matches never leaves the first launch ($ZHIP_RH_PREDICT=1 turns it on, $ZHIP_RH_BUDGET: the budget)
+                static int const predictOn = getenv("ZHIP_RH_PREDICT") ? atoi(getenv("ZHIP_RH_PREDICT")) : 0;      // opt-in: exact (emulator, GPU parity tests), its speed not measured yet
                 static int const budget = getenv("ZHIP_RH_BUDGET") ? atoi(getenv("ZHIP_RH_BUDGET")) : 256;
                 bool anyRow = false;
                 for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
@@ -904,8 +904,8 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
             hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
                                (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
         }
-        {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=0: one pass)
-            static int const predictOn = getenv("ZHIP_LZ_PREDICT") ? atoi(getenv("ZHIP_LZ_PREDICT")) : 1;
+        {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=1 turns it on)
+            static int const predictOn = getenv("ZHIP_LZ_PREDICT") ? atoi(getenv("ZHIP_LZ_PREDICT")) : 0;      // opt-in, like $ZHIP_RH_PREDICT
             if (predictOn) {
                 hipLaunchKernelGGL(zhip::k_lz_predict, dim3((unsigned)nU), dim3(64), sizeof(ZhipParse), s,
                                    (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
