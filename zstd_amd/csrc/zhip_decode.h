@@ -348,7 +348,8 @@ __device__ inline uint32_t dec_fse_weights(DecShared* S, const uint8_t* src, uin
 
 // tree description -> decoding table in LDS (HUF_readStats + HUF_readDTableX1_wksp); whole wave 0, control on lane 0.
 // returns bytes consumed, 0 = error
-__device__ inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint32_t size)
+// (always inlined: since the block-parallel decoder of zhip_decode_big.h calls it too the compiler would otherwise make it a real function — a different k_decode)
+__device__ __attribute__((always_inline)) inline uint32_t dec_huf_table(DecShared* S, const uint8_t* src, uint32_t size)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t ok = 0, consumed = 0, nbSym = 0, tableLog = 0;
@@ -506,7 +507,7 @@ __device__ __forceinline__ uint32_t huf_run2(BitsAt& b, const lds_u32* T2, uint3
     }
     return cnt;
 }
-__device__ inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
+__device__ __attribute__((always_inline)) inline uint32_t dec_huf_streams_par(DecShared* S, const uint8_t* src, uint32_t size, uint32_t litSize, bool single, uint8_t* lit)
 {
     uint32_t const lane = (uint32_t)lane_id(), grp = lane >> 4, j = lane & 15;
     uint32_t const tl = S->hufLog, sh = 64 - tl;
