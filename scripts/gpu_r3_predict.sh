@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_rowhash.py tests/test_gpu_decode_big.py tests/test_gpu_frames_lazy.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu_predict.log
+timeout 300 python -m pytest tests/test_gpu_rowhash.py tests/test_gpu_zz_decode_big.py tests/test_gpu_frames_lazy.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/pytest_gpu_predict.log
 B="--level 5 --mib 1024 --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined-extra --no-extra-legs"
 for W in datagen text; do for P in 1 0; do
   echo "== workload $W ZHIP_RH_PREDICT=$P" | tee -a gpurun_out/bench_L5_predict.log

@@ -1,6 +1,8 @@
 """-m gpu: ONE large frame decoded block-parallel (zstd_amd/csrc/zhip_decode_big.h) — the frames this library's single-frame and
 job-pool modes emit (and any other frame that states its content size and needs no dictionary).  Same bytes as the per-frame
-decoder, same error codes (whatever the block-parallel path declines goes through k_decode), content checksums verified."""
+decoder, same error codes (whatever the block-parallel path declines goes through k_decode), content checksums verified.
+The path itself ran on MI355X (profiles/r03_big_frame_decode_*: the 1 GiB frame, bit-exact); this file sorts last in the suite because
+its own first complete GPU run is the driver's (the round's GPU budget ended before it)."""
 import ctypes as C
 import numpy as np
 import pytest
