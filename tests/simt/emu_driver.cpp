@@ -219,7 +219,8 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     BFTR("entropy");
     simt::launch({nB, 1, 1}, {ZHIP_BF_THREADS, 1, 1}, sizeof(zhip::DecShared), [=] { zhip::k_bf_entropy(src, blockMax, bp, ip, lp, rp, dt); }, osThreads);
     BFTR("scan");
-    simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_scan(bp, ip, dstCap); }, 1);
+    uint32_t const fcs32 = (uint32_t)H.fcs;
+    simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_scan(bp, ip, fcs32); }, 1);
     if (info.status) return info.status;
     if (info.totalOut != H.fcs) return ZHIP_DE_CORRUPT;
     uint32_t const n = (uint32_t)info.totalOut;

@@ -215,7 +215,7 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     if (!bf_grow(c->dBfLit, c->bfLitCap, (size_t)info.totalLit + 64) || !bf_grow(c->dBfRecs, c->bfRecsCap, (size_t)info.totalRecs + 1) ||
         !bf_grow(c->dBfMap, c->bfMapCap, (size_t)H.fcs + 8)) return false;
     hipLaunchKernelGGL(zhip::k_bf_entropy, dim3(nB), dim3(ZHIP_BF_THREADS), sizeof(zhip::DecShared), s, src, H.blockMax, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, c->dDefTabs);
-    hipLaunchKernelGGL(zhip::k_bf_scan, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo, f.dstCap);
+    hipLaunchKernelGGL(zhip::k_bf_scan, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo, (uint32_t)H.fcs);       // the map has one entry per byte of the STATED content: a frame that regenerates more never reaches k_bf_build
     hipLaunchKernelGGL(zhip::k_bf_build, dim3(nB), dim3(256), 0, s, src, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, out, c->dBfMap);
     if (hipGetLastError() != hipSuccess || !readInfo() || info.status || info.totalOut != H.fcs) return false;
     uint32_t const n = (uint32_t)H.fcs, grid = (n + 1023) / 1024;
