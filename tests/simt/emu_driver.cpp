@@ -214,8 +214,11 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_deps(bp, ip); }, 1);
     if (info.status) return info.status;
     if (info.totalRecs > (uint64_t)H.fcs + nB) return ZHIP_DE_UNSUPPORTED;
-    std::vector<uint8_t> lit(info.totalLit + 64, 0xEE); std::vector<ZhipDSeq> recs(info.totalRecs + 1);
-    uint8_t* const lp = lit.data(); ZhipDSeq* const rp = recs.data();
+    // arenas with 256 canary bytes on both sides: a kernel that writes outside what the host sized is reported (0xBAD)
+    size_t const CAN = 256;
+    std::vector<uint8_t> litV(info.totalLit + 64 + 2 * CAN, 0xA5); std::vector<uint8_t> recV((info.totalRecs + 1) * sizeof(ZhipDSeq) + 2 * CAN, 0xA5);
+    uint8_t* const lp = litV.data() + CAN; ZhipDSeq* const rp = (ZhipDSeq*)(recV.data() + CAN);
+    auto canaries_ok = [&](const std::vector<uint8_t>& v) { for (size_t i = 0; i < CAN; i++) if (v[i] != 0xA5 || v[v.size() - 1 - i] != 0xA5) return false; return true; };
     BFTR("entropy");
     simt::launch({nB, 1, 1}, {ZHIP_BF_THREADS, 1, 1}, sizeof(zhip::DecShared), [=] { zhip::k_bf_entropy(src, blockMax, bp, ip, lp, rp, dt); }, osThreads);
     BFTR("scan");
@@ -224,9 +227,11 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     if (info.status) return info.status;
     if (info.totalOut != H.fcs) return ZHIP_DE_CORRUPT;
     uint32_t const n = (uint32_t)info.totalOut;
-    std::vector<uint32_t> map((size_t)n + 8, 0xDDDDDDDDu); uint32_t* const mp = map.data();
+    if (!canaries_ok(litV) || !canaries_ok(recV)) return 0xBAD;
+    std::vector<uint8_t> mapV(((size_t)n + 8) * 4 + 2 * CAN, 0xA5); uint32_t* const mp = (uint32_t*)(mapV.data() + CAN);
     BFTR("build");
     simt::launch({nB, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_build(src, bp, ip, lp, rp, dst, mp); }, osThreads);
+    if (!canaries_ok(mapV)) return 0xBAD;
     if (info.status) return info.status;
     uint32_t r = 0;
     if (n) for (; r < 64; r++) {
@@ -236,6 +241,7 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     }
     if (rounds) *rounds = r;
     if (n) simt::launch({(n + 1023) / 1024, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_copy(mp, dst, n); }, osThreads);
+    if (!canaries_ok(litV) || !canaries_ok(recV) || !canaries_ok(mapV)) return 0xBAD;
     *outSize = n; if (checksumOut) *checksumOut = info.checksum;
     return 0;
 }
