@@ -36,6 +36,17 @@ def test_job_pool_frame_is_decoded_block_parallel(env):
         assert info["block_parallel"] == 1 and info["fell_back"] == 0 and info["blocks"] >= (96 << 20) // (128 << 10), info
         d.set_bigframe_min(0)                                    # the same frame through one workgroup: same bytes
         assert d.decompress(frame[:]) == out and d.last_bigframe()["block_parallel"] == 0
+    # device-resident frame (zhip_decompress_frames_device): the block headers are walked on the device (k_bf_walk) instead of on the host
+    import torch
+    d = z.DContext()
+    blob = np.frombuffer(frame + b"\x00" * 64, dtype=np.uint8)
+    srcT = torch.from_numpy(blob.copy()).cuda()
+    outT = torch.zeros(len(a) + 64, dtype=torch.uint8, device="cuda")
+    r, status, dsz = d.decompress_frames_device(outT.data_ptr(), np.array([0], np.uint64), np.array([len(a)], np.uint64), srcT.data_ptr(),
+                                                np.array([0], np.uint64), np.array([len(frame)], np.uint64))
+    assert status[0] == 0 and int(dsz[0]) == len(a) and d.last_bigframe()["block_parallel"] == 1
+    assert outT[:len(a)].cpu().numpy().tobytes() == a.tobytes()
+    del srcT, outT
     ctx.set_checksum(True)
     frame = bytearray(ctx.compress_frames([a[:20 << 20]], 1, workers=2)[0])
     frame[-1] ^= 0x55                                            # a wrong content checksum is still found

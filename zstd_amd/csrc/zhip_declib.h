@@ -27,6 +27,8 @@ struct zhip_dctx_s {
     hipEvent_t bfEv[2] = { nullptr, nullptr };
     unsigned long long bigMin = 8ull << 20;        // frames stating at least this much content take the block-parallel path ($ZHIP_BIGFRAME_MIN, 0 = never)
     unsigned bfLast[4] = { 0, 0, 0, 0 };           // last call: frames decoded block-parallel, frames that fell back, jump rounds, blocks
+    const uint8_t* bfHostSrc = nullptr;            // set by zhip_decompress for the duration of a call: the frames also lie in host memory at this address (same offsets as in the staged copy)
+    std::vector<ZhipBfBlock> bfHostBlocks;
     double timing[2];
     std::mutex mu;
     char err[256];
@@ -195,7 +197,9 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
 {
     uint8_t hdr[32]; memset(hdr, 0, sizeof(hdr));
     size_t const hn = f.srcLen < sizeof(hdr) ? f.srcLen : sizeof(hdr);
-    if (hipMemcpyAsync(hdr, srcDev + f.srcOff, hn, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+    const uint8_t* const hostFrame = c->bfHostSrc ? c->bfHostSrc + f.srcOff : nullptr;
+    if (hostFrame) memcpy(hdr, hostFrame, hn);
+    else if (hipMemcpyAsync(hdr, srcDev + f.srcOff, hn, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
     zhip::BfHeader const H = zhip::bf_parse_header(hdr, f.srcLen);
     if (!H.ok || H.fcs < c->bigMin || H.fcs > f.dstCap || H.fcs >= 0xFFFFFF00ull) return false;
     const uint8_t* const src = srcDev + f.srcOff; uint8_t* const out = dstDev + f.dstOff;
@@ -203,9 +207,16 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     if (!c->dBfInfo && hipMalloc((void**)&c->dBfInfo, sizeof(ZhipBfInfo)) != hipSuccess) return false;
     if (!bf_grow(c->dBfBlocks, c->bfBlocksCap, capBlocks)) return false;
     for (int i = 0; i < 2; i++) if (!c->bfEv[i] && hipEventCreate(&c->bfEv[i]) != hipSuccess) return false;
-    ZhipBfInfo info;
+    ZhipBfInfo info; memset(&info, 0, sizeof(info));
     auto readInfo = [&]() { return hipMemcpyAsync(&info, c->dBfInfo, sizeof(info), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess; };
     (void)hipEventRecord(c->bfEv[0], s);
+    if (hostFrame) {                                                   // the caller's bytes are in host memory: walk the block headers here (microseconds) and upload the table
+        c->bfHostBlocks.resize(capBlocks);
+        zhip::bf_walk_core(hostFrame, f.srcLen, H.hdrSize, H.blockMax, H.hasChecksum, c->bfHostBlocks.data(), (uint32_t)capBlocks, &info);
+        if (info.status) return false;
+        if (hipMemcpyAsync(c->dBfBlocks, c->bfHostBlocks.data(), (size_t)info.nBlocks * sizeof(ZhipBfBlock), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(c->dBfInfo, &info, sizeof(info), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+    } else
     hipLaunchKernelGGL(zhip::k_bf_walk, dim3(1), dim3(64), 0, s, src, f.srcLen, H.hdrSize, H.blockMax, H.hasChecksum, c->dBfBlocks, (uint32_t)capBlocks, c->dBfInfo);
     hipLaunchKernelGGL(zhip::k_bf_prep, dim3((unsigned)((capBlocks + 255) / 256)), dim3(256), 0, s, src, H.blockMax, c->dBfBlocks, c->dBfInfo);
     hipLaunchKernelGGL(zhip::k_bf_deps, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo);
@@ -418,7 +429,9 @@ size_t zhip_decompress(zhip_dctx* c, const zhip_ddict* dd, void* dst, size_t dst
         }
         if (exact && total > dstCapacity) return DERR(70);
         if (c->dstStageCap < total + 64) { (void)hipFree(c->dDstStage); c->dDstStage = nullptr; c->dstStageCap = 0; DCHK(c, hipMalloc((void**)&c->dDstStage, total + 64)); c->dstStageCap = total + 64; }
+        c->bfHostSrc = (const uint8_t*)src;                         // the staged copy holds the same bytes at the same offsets
         size_t const r = decode_locked(c, dd, c->dDstStage, c->dSrcStage, g, nullptr, nullptr, c->stream);
+        c->bfHostSrc = nullptr;
         if (zhip_isError(r)) return r;
         if (r > dstCapacity - pos) return DERR(70);
         if (exact) { if (r) DCHK(c, hipMemcpy((uint8_t*)dst + pos, c->dDstStage, r, hipMemcpyDeviceToHost)); pos += r; }
