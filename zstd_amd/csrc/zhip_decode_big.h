@@ -357,19 +357,19 @@ __device__ inline void bf_scan(ZhipBfBlock* __restrict__ blocks, ZhipBfInfo* __r
         unsigned long long const bad2 = __ballot(on && st == ZHIP_DE_DST_SMALL);
         if (bad2 && !status) status = ZHIP_DE_DST_SMALL;
         out += __builtin_amdgcn_readlane(inc, 63);
-        sh[3 * lane] = ro[0]; sh[3 * lane + 1] = ro[1]; sh[3 * lane + 2] = ro[2];
-        __builtin_amdgcn_wave_barrier();
+        (void)sh;
         uint32_t const cnt = nB - b0 < 64 ? nB - b0 : 64;
-        // the composition is a serial walk over values that sit in LDS; every lane runs it on the same addresses
+        // the composition is a serial walk over values that sit in the lanes' registers (block j's outgoing history is read with a
+        // readlane: no memory round trip inside the chain); every lane runs it, lane j keeps what block j starts from
         uint32_t myIn[3] = { 0, 0, 0 };
         for (uint32_t j = 0; j < cnt; j++) {
             if (j == lane) { myIn[0] = R[0]; myIn[1] = R[1]; myIn[2] = R[2]; }
-            uint32_t const n0 = bf_resolve(sh[3 * j], R), n1 = bf_resolve(sh[3 * j + 1], R), n2 = bf_resolve(sh[3 * j + 2], R);
+            uint32_t const o0 = __builtin_amdgcn_readlane(ro[0], (int)j), o1 = __builtin_amdgcn_readlane(ro[1], (int)j), o2 = __builtin_amdgcn_readlane(ro[2], (int)j);
+            uint32_t const n0 = bf_resolve(o0, R), n1 = bf_resolve(o1, R), n2 = bf_resolve(o2, R);
             if ((n0 == 0 || n1 == 0 || n2 == 0) && !status) status = ZHIP_DE_CORRUPT;
             R[0] = n0; R[1] = n1; R[2] = n2;
         }
         if (on) { blocks[bi].repIn[0] = myIn[0]; blocks[bi].repIn[1] = myIn[1]; blocks[bi].repIn[2] = myIn[2]; }
-        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) { info->status = status; info->totalOut = out; }
 }
@@ -432,6 +432,17 @@ __device__ inline void bf_jump(uint32_t* __restrict__ map, uint32_t n, uint32_t*
     uint32_t const j4[4] = { v.x, v.y, v.z, v.w };
     uint32_t jj4[4];
     for (uint32_t e = 0; e < 4; e++) jj4[e] = (i0 + e < n && j4[e] != i0 + e) ? map[j4[e]] : j4[e];       // four gathers in flight
+    // up to three more hops for the entries that are still on their way (a pass then multiplies a chain's reach by up to five instead of two:
+    // every pass reads the whole map once, so passes are what costs once most entries have arrived)
+    bool act[4];
+    for (uint32_t e = 0; e < 4; e++) act[e] = jj4[e] != j4[e];
+    for (int hop = 0; hop < 3; hop++) {
+        bool moved = false;
+        uint32_t t4[4];
+        for (uint32_t e = 0; e < 4; e++) t4[e] = act[e] ? map[jj4[e]] : jj4[e];
+        for (uint32_t e = 0; e < 4; e++) { act[e] = act[e] && t4[e] != jj4[e]; if (act[e]) { jj4[e] = t4[e]; moved = true; } }
+        if (!moved) break;
+    }
     bool any = false;
     for (uint32_t e = 0; e < 4; e++) if (jj4[e] != j4[e]) { map[i0 + e] = jj4[e]; any = true; }
     if (any) *changed = 1;
