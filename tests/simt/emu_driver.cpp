@@ -192,6 +192,8 @@ int emu_decode(const uint8_t* src, const ZhipDFrame* frames, uint32_t nFrames, u
 }
 // ONE frame through the block-parallel decoder (zhip_decode_big.h), the launches of the host library in order.
 // returns 0 and *outSize, or the path's status (the caller would then fall back to k_decode); rounds (optional) = jump rounds made
+static uint32_t* g_bf_map_out = nullptr;      // analysis hook (tests/tools/jump_rounds.py): receives the copy map as k_bf_build leaves it
+void emu_decode_big_want_map(uint32_t* mapOut) { g_bf_map_out = mapOut; }
 uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint32_t dstCap, uint32_t* outSize, uint32_t* checksumOut, uint32_t* rounds, int osThreads)
 {
     zhip::BfHeader const H = zhip::bf_parse_header(src, srcLen);
@@ -233,6 +235,7 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     simt::launch({nB, 1, 1}, {256, 1, 1}, 0, [=] { zhip::k_bf_build(src, bp, ip, lp, rp, dst, mp); }, osThreads);
     if (!canaries_ok(mapV)) return 0xBAD;
     if (info.status) return info.status;
+    if (g_bf_map_out) memcpy(g_bf_map_out, mp, (size_t)n * 4);
     uint32_t r = 0;
     if (n) for (; r < 64; r++) {
         info.changed = 0;
