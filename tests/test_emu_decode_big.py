@@ -92,3 +92,22 @@ def test_damaged_frames_never_decode_to_something_else(libs):
             assert want is not None and out == want, trial
             same += 1
     assert declined > 0
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (the reference built by oracle/Makefile)")
+def test_frames_of_the_reference_at_every_strategy(libs):
+    """the REAL reference's frames — levels -3 .. 22: every strategy up to btultra2, its block splitter's variable blocks, its table modes —
+    through the block-parallel decoder"""
+    lo, le = libs
+    lr = load_ref()
+    lr.zref_compress_frame.restype = C.c_size_t
+    lr.zref_compress_frame.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(2)
+    a = np.concatenate([datagen(lo, 200000, 70, 1), rng.integers(0, 256, size=100000, dtype=np.uint8), np.zeros(150000, np.uint8), text_like(200000, 9),
+                        np.tile(rng.integers(0, 256, size=333, dtype=np.uint8), 500)])
+    for level in (-3, 1, 3, 6, 9, 13, 16, 19, 22):
+        d = np.zeros(len(a) + (len(a) >> 7) + 1024, dtype=np.uint8)
+        k = lr.zref_compress_frame(level, _buf(a), len(a), _buf(d), len(d))
+        assert k != ERR
+        st, out, _ = big(le, d[:k].tobytes(), len(a))
+        assert st == 0 and out == a.tobytes(), level
