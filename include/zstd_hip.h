@@ -235,7 +235,7 @@ size_t       zhip_seekable_read(zhip_dctx* dctx, void* dst, size_t len, const vo
 /* HIP-event durations (ms) of the most recent call: t[0] = k_decode, t[1] = checksum verification (0 when no frame has one) */
 void         zhip_dctx_last_timing(const zhip_dctx* dctx, double t[2]);
 /* One LARGE frame is decoded block-parallel (zstd_amd/csrc/zhip_decode_big.h: symbolic repeat offsets + a scan, pointer jumping over a
- * copy map) instead of by one workgroup: frames without a dictionary whose header states at least minContent bytes of content
+ * copy map) instead of by one workgroup: frames without a dictionary that hold at least minContent bytes of content (stated in the header, or bounded by the destination slot)
  * (default 8 MiB, $ZHIP_BIGFRAME_MIN; 0 = never).  Same bytes, same errors: whatever that path declines goes through the per-frame decoder.
  * zhip_dctx_last_bigframe: [0] frames of the last call decoded block-parallel, [1] frames that fell back, [2] pointer-jumping rounds, [3] blocks. */
 void         zhip_dctx_set_bigframe_min(zhip_dctx* dctx, unsigned long long minContent);

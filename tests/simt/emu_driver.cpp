@@ -197,8 +197,10 @@ void emu_decode_big_want_map(uint32_t* mapOut) { g_bf_map_out = mapOut; }
 uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint32_t dstCap, uint32_t* outSize, uint32_t* checksumOut, uint32_t* rounds, int osThreads)
 {
     zhip::BfHeader const H = zhip::bf_parse_header(src, srcLen);
-    if (!H.ok || H.fcs > dstCap) return ZHIP_DE_UNSUPPORTED;
-    uint32_t const capBlocks = (uint32_t)(H.fcs / 1024 + 1024);
+    if (!H.ok) return ZHIP_DE_UNSUPPORTED;
+    uint64_t const limit = H.known ? H.fcs : (uint64_t)dstCap;          // as bigframe_decode (zhip_declib.h)
+    if (limit > dstCap) return ZHIP_DE_UNSUPPORTED;
+    uint32_t const capBlocks = (uint32_t)(limit / 1024 + 1024);
     std::vector<ZhipBfBlock> blocks(capBlocks);
     ZhipBfInfo info; memset(&info, 0, sizeof(info));
     ZhipBfBlock* const bp = blocks.data(); ZhipBfInfo* const ip = &info;
@@ -215,7 +217,7 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     BFTR("deps");
     simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_deps(bp, ip); }, 1);
     if (info.status) return info.status;
-    if (info.totalRecs > (uint64_t)H.fcs + nB) return ZHIP_DE_UNSUPPORTED;
+    if (info.totalRecs > limit + nB) return ZHIP_DE_UNSUPPORTED;
     // arenas with 256 canary bytes on both sides: a kernel that writes outside what the host sized is reported (0xBAD)
     size_t const CAN = 256;
     std::vector<uint8_t> litV(info.totalLit + 64 + 2 * CAN, 0xA5); std::vector<uint8_t> recV((info.totalRecs + 1) * sizeof(ZhipDSeq) + 2 * CAN, 0xA5);
@@ -224,10 +226,10 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     BFTR("entropy");
     simt::launch({nB, 1, 1}, {ZHIP_BF_THREADS, 1, 1}, sizeof(zhip::DecShared), [=] { zhip::k_bf_entropy(src, blockMax, bp, ip, lp, rp, dt); }, osThreads);
     BFTR("scan");
-    uint32_t const fcs32 = (uint32_t)H.fcs;
+    uint32_t const fcs32 = (uint32_t)limit;
     simt::launch({1, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_bf_scan(bp, ip, fcs32); }, 1);
     if (info.status) return info.status;
-    if (info.totalOut != H.fcs) return ZHIP_DE_CORRUPT;
+    if (H.known && info.totalOut != H.fcs) return ZHIP_DE_CORRUPT;
     uint32_t const n = (uint32_t)info.totalOut;
     if (!canaries_ok(litV) || !canaries_ok(recV)) return 0xBAD;
     std::vector<uint8_t> mapV(((size_t)n + 8) * 4 + 2 * CAN, 0xA5); uint32_t* const mp = (uint32_t*)(mapV.data() + CAN);

@@ -111,3 +111,27 @@ def test_frames_of_the_reference_at_every_strategy(libs):
         assert k != ERR
         st, out, _ = big(le, d[:k].tobytes(), len(a))
         assert st == 0 and out == a.tobytes(), level
+
+
+def _strip_content_size(frame):
+    """the same frame as a streaming compressor without a pledged size writes it: no content size in the header, a window descriptor instead"""
+    f = bytes(frame)
+    fhd = f[4]
+    single, fcs_code = (fhd >> 5) & 1, fhd >> 6
+    fcs_b = (1 if single else 0) if fcs_code == 0 else (1 << fcs_code)
+    pos = 5 + (0 if single else 1)
+    v = int.from_bytes(f[pos: pos + fcs_b], "little") + (256 if fcs_code == 1 else 0)
+    wd = f[5] if not single else (max(10, int(v - 1).bit_length() if v > 1 else 10) - 10) << 3
+    return f[:4] + bytes([fhd & 0x04, wd]) + f[pos + fcs_b:]
+
+
+def test_frames_that_do_not_state_their_content_size(libs):
+    lo, le = libs
+    rng = np.random.default_rng(9)
+    a = np.concatenate([datagen(lo, 300000, 50, 2), text_like(150000, 3), rng.integers(0, 256, size=50000, dtype=np.uint8)])
+    for level in (1, 3):
+        f = _strip_content_size(oracle_frame(lo, a, level))
+        assert oracle_decompress(lo, f, len(a) + 1000) == a.tobytes()          # still a valid frame
+        st, out, _ = big(le, f, len(a) + 1000)                                  # the destination slot is a bound, not the size
+        assert st == 0 and out == a.tobytes(), level
+        assert big(le, f, len(a) - 1)[0] != 0                                   # too small a slot is declined

@@ -201,9 +201,12 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     if (hostFrame) memcpy(hdr, hostFrame, hn);
     else if (hipMemcpyAsync(hdr, srcDev + f.srcOff, hn, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
     zhip::BfHeader const H = zhip::bf_parse_header(hdr, f.srcLen);
-    if (!H.ok || H.fcs < c->bigMin || H.fcs > f.dstCap || H.fcs >= 0xFFFFFF00ull) return false;
+    if (!H.ok) return false;
+    // the room the content may take: its stated size, or — a frame that does not state it — the destination slot (then the compressed size has to look large too)
+    uint64_t const limit = H.known ? H.fcs : (uint64_t)f.dstCap;
+    if (limit < c->bigMin || limit > f.dstCap || limit >= 0xFFFFFF00ull || (!H.known && (uint64_t)f.srcLen * 64 < c->bigMin)) return false;
     const uint8_t* const src = srcDev + f.srcOff; uint8_t* const out = dstDev + f.dstOff;
-    size_t const capBlocks = (size_t)(H.fcs / 1024 + 1024);
+    size_t const capBlocks = (size_t)(limit / 1024 + 1024);
     if (!c->dBfInfo && hipMalloc((void**)&c->dBfInfo, sizeof(ZhipBfInfo)) != hipSuccess) return false;
     if (!bf_grow(c->dBfBlocks, c->bfBlocksCap, capBlocks)) return false;
     for (int i = 0; i < 2; i++) if (!c->bfEv[i] && hipEventCreate(&c->bfEv[i]) != hipSuccess) return false;
@@ -222,14 +225,19 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     hipLaunchKernelGGL(zhip::k_bf_deps, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo);
     if (hipGetLastError() != hipSuccess || !readInfo() || info.status) return false;
     uint32_t const nB = info.nBlocks;
-    if (info.totalRecs > H.fcs + nB) return false;                     // more sequences than bytes: not a frame worth 16 bytes per record
-    if (!bf_grow(c->dBfLit, c->bfLitCap, (size_t)info.totalLit + 64) || !bf_grow(c->dBfRecs, c->bfRecsCap, (size_t)info.totalRecs + 1) ||
-        !bf_grow(c->dBfMap, c->bfMapCap, (size_t)H.fcs + 8)) return false;
+    if (info.totalRecs > limit + nB) return false;                     // more sequences than bytes: not a frame worth 16 bytes per record
+    if (!bf_grow(c->dBfLit, c->bfLitCap, (size_t)info.totalLit + 64) || !bf_grow(c->dBfRecs, c->bfRecsCap, (size_t)info.totalRecs + 1)) return false;
     hipLaunchKernelGGL(zhip::k_bf_entropy, dim3(nB), dim3(ZHIP_BF_THREADS), sizeof(zhip::DecShared), s, src, H.blockMax, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, c->dDefTabs);
-    hipLaunchKernelGGL(zhip::k_bf_scan, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo, (uint32_t)H.fcs);       // the map has one entry per byte of the STATED content: a frame that regenerates more never reaches k_bf_build
+    hipLaunchKernelGGL(zhip::k_bf_scan, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo, (uint32_t)limit);       // the map has one entry per byte of the content: a frame that regenerates more than `limit` never reaches k_bf_build
+    uint64_t content = H.fcs;
+    if (!H.known) {                                                    // the blocks' sizes say how much content there is
+        if (hipGetLastError() != hipSuccess || !readInfo() || info.status) return false;
+        content = info.totalOut;
+    }
+    if (!bf_grow(c->dBfMap, c->bfMapCap, (size_t)content + 8)) return false;
     hipLaunchKernelGGL(zhip::k_bf_build, dim3(nB), dim3(256), 0, s, src, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, out, c->dBfMap);
-    if (hipGetLastError() != hipSuccess || !readInfo() || info.status || info.totalOut != H.fcs) return false;
-    uint32_t const n = (uint32_t)H.fcs, grid = (n + 1023) / 1024;
+    if (hipGetLastError() != hipSuccess || !readInfo() || info.status || info.totalOut != content) return false;
+    uint32_t const n = (uint32_t)content, grid = (n + 1023) / 1024;
     unsigned rounds = 0;
     for (; n && rounds < 64; rounds++) {
         if (hipMemsetAsync(&c->dBfInfo->changed, 0, 4, s) != hipSuccess) return false;

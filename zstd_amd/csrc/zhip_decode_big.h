@@ -1,6 +1,6 @@
 // zhip_decode_big.h — ONE large frame decoded by the whole GPU (the other side of the single-frame / job-pool frames of zhip_frame.h).
 //
-// WHAT it computes: the content of one RFC 8878 frame without a dictionary whose header states the content size — what
+// WHAT it computes: the content of one RFC 8878 frame without a dictionary (its header may or may not state the content size) — what
 // ZSTD_decompressFrame (lib/decompress/zstd_decompress.c:951-1064) regenerates — but block-parallel.  k_decode (zhip_decode.h) walks a
 // frame's blocks one after the other in one workgroup (0.26 GB/s on a 1 GiB frame); here the blocks are independent work until the very
 // last step.  Anything this path does not like (an error of any kind, a frame shape outside its limits) makes the caller fall back to
@@ -52,15 +52,15 @@ struct ZhipBfInfo {               // one per frame
 namespace zhip {
 
 // host: the frame header fields this path needs (zstd_decompress.c:438-545); ok = a frame it may take: no dictionary, content size stated
-struct BfHeader { uint32_t hdrSize, blockMax, hasChecksum; uint64_t fcs; bool ok; };
+struct BfHeader { uint32_t hdrSize, blockMax, hasChecksum; uint64_t fcs; bool known /* the header states the content size */; bool ok; };
 inline BfHeader bf_parse_header(const uint8_t* p, size_t n)
 {
-    BfHeader h; h.hdrSize = 0; h.blockMax = ZHIP_UNIT_MAX; h.hasChecksum = 0; h.fcs = 0; h.ok = false;
+    BfHeader h; h.hdrSize = 0; h.blockMax = ZHIP_UNIT_MAX; h.hasChecksum = 0; h.fcs = 0; h.known = false; h.ok = false;
     if (n < 8 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return h;
     uint32_t const fhd = p[4], didCode = fhd & 3, fcsCode = fhd >> 6, single = (fhd >> 5) & 1;
     if ((fhd & 8) || didCode) return h;
     uint32_t const fcsB = fcsCode == 0 ? (single ? 1u : 0u) : (1u << fcsCode);
-    if (!fcsB) return h;
+    h.known = fcsB != 0;                                        // a frame of a streaming compressor may not state its size: then the blocks' sizes say it (k_bf_scan)
     h.hdrSize = 5 + (single ? 0u : 1u) + fcsB;
     if (n < h.hdrSize + 3) return h;
     uint32_t pos = 5; uint64_t window = 0;
