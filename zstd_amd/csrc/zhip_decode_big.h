@@ -8,7 +8,7 @@
 //
 // HOW.  What chains the blocks of a frame together in the reference, and what replaces each chain here:
 //   * where a block starts (3-byte headers, zstd_decompress.c:1000-1040)            -> k_bf_walk: one lane follows the headers (3 bytes per
-//     128 KB); everything else about a block (literals header, number of sequences, table modes) is read block-parallel by k_bf_prep;
+//     128 KB) — or the host does, when the frame lies in host memory (bf_walk_core is the same function on both sides); everything else about a block (literals header, number of sequences, table modes) is read block-parallel by k_bf_prep;
 //   * treeless literals / repeat-mode FSE tables (zstd_decompress_block.c:134, :625-660: "the previous block's table")
 //                                                                                   -> k_bf_deps: a wave-wide scan names, per block and
 //     table, the block whose description DEFINES it; k_bf_entropy rebuilds the table from that block's bytes (a description is a few
@@ -22,8 +22,8 @@
 //   * the bytes themselves (ZSTD_execSequence :1001-1095: a match copies what earlier sequences produced, across block borders)
 //                                                                                   -> pointer jumping.  k_bf_build writes every LITERAL to its
 //     final place and, for every byte a match produces, the position it copies from (map[i] = i - offset; map[i] = i for literals).
-//     k_bf_jump replaces map[i] by map[map[i]] until nothing changes — O(log(longest copy chain)) rounds of gathers over the whole
-//     frame, every byte of every block at once — and k_bf_copy reads each byte from the literal its chain ends in.  Memory traffic (this
+//     k_bf_jump replaces map[i] by map[map[i]] (and up to three hops more for entries still on their way) until nothing changes —
+//     O(log(longest copy chain)) passes of gathers over the whole frame, every byte of every block at once — and k_bf_copy reads each byte from the literal its chain ends in.  Memory traffic (this
 //     machine has 8 TB/s of it) instead of a dependency chain through 8 192 blocks (which nothing hides).
 // Algorithmic bytes per frame: compressed in + content out; the map costs 4 bytes per content byte per round on top.
 #pragma once

@@ -29,6 +29,9 @@
 //                in a dirty-key bitmap; a record within ZHIP_HC_CAP bytes of its block's end was measured against the window's
 //                end, not the block's), then the four wavefronts encode the block (zhip_entropy.h) against the previous block's
 //                Huffman and FSE tables.
+//   k_lz_predict (opt-in, $ZHIP_LZ_PREDICT=1) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
+//                it would leave un-inserted, k_lz_search runs again stepping over them, and the exact parse distrusts a record only where
+//                prediction and truth differ — exact on the emulator, not timed on the GPU yet.
 #pragma once
 #include "zhip_parse_lazy.h"
 #include "zhip_frame.h"
