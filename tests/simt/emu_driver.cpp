@@ -200,7 +200,7 @@ uint32_t emu_decode_big(const uint8_t* src, uint32_t srcLen, uint8_t* dst, uint3
     if (!H.ok) return ZHIP_DE_UNSUPPORTED;
     uint64_t const limit = H.known ? H.fcs : (uint64_t)dstCap;          // as bigframe_decode (zhip_declib.h)
     if (limit > dstCap) return ZHIP_DE_UNSUPPORTED;
-    uint32_t const capBlocks = (uint32_t)(limit / 1024 + 1024);
+    uint32_t const capBlocks = (uint32_t)(limit / 4096 + 4096);
     std::vector<ZhipBfBlock> blocks(capBlocks);
     ZhipBfInfo info; memset(&info, 0, sizeof(info));
     ZhipBfBlock* const bp = blocks.data(); ZhipBfInfo* const ip = &info;

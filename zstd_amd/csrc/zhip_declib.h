@@ -206,7 +206,7 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     uint64_t const limit = H.known ? H.fcs : (uint64_t)f.dstCap;
     if (limit < c->bigMin || limit > f.dstCap || limit >= 0xFFFFFF00ull || (!H.known && (uint64_t)f.srcLen * 64 < c->bigMin)) return false;
     const uint8_t* const src = srcDev + f.srcOff; uint8_t* const out = dstDev + f.dstOff;
-    size_t const capBlocks = (size_t)(limit / 1024 + 1024);
+    size_t const capBlocks = (size_t)(limit / 4096 + 4096);                 // a frame whose blocks regenerate less than 4 KB on average is left to k_decode
     if (!c->dBfInfo && hipMalloc((void**)&c->dBfInfo, sizeof(ZhipBfInfo)) != hipSuccess) return false;
     if (!bf_grow(c->dBfBlocks, c->bfBlocksCap, capBlocks)) return false;
     for (int i = 0; i < 2; i++) if (!c->bfEv[i] && hipEventCreate(&c->bfEv[i]) != hipSuccess) return false;
