@@ -42,3 +42,17 @@ for i, l in enumerate(lines):
         found += 1
         print(f"{fn(i):24s} loop of {i - t:6d} instructions lines, {nb:2d} s_barrier inside")
 print("EXEC-controlled loops containing s_barrier:", found, "(each must exit all lanes of a wavefront together)")
+
+# second check (round 3): k_decode must stay ONE piece of code.  When the block-parallel decoder became a second caller of dec_huf_table /
+# dec_huf_streams_par the compiler stopped inlining them; every GPU step that then used k_decode did not come back ("the last GPU call").
+body = []
+inside = False
+for l in lines:
+    if re.match(r"^_ZN4zhip8k_decodeE\w+:", l):
+        inside = True
+    elif inside and l.startswith(".Lfunc_end"):
+        break
+    if inside:
+        body.append(l)
+calls = sum(1 for l in body if "s_swappc_b64" in l)
+print("k_decode function calls:", calls, "(must be 0: its callees are always_inline)")

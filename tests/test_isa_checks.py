@@ -14,3 +14,4 @@ def test_no_barrier_inside_an_exec_controlled_loop():
      had exactly this shape and passed on the host emulator.  scripts/scan_divergent_barriers.py finds none."""
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "scan_divergent_barriers.py")], timeout=900).decode()
     assert "EXEC-controlled loops containing s_barrier: 0" in out, out
+    assert "k_decode function calls: 0" in out, out          # the decoder kernel is one piece of code (see the script)
