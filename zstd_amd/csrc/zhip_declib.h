@@ -225,6 +225,7 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     hipLaunchKernelGGL(zhip::k_bf_deps, dim3(1), dim3(64), 0, s, c->dBfBlocks, c->dBfInfo);
     if (hipGetLastError() != hipSuccess || !readInfo() || info.status) return false;
     uint32_t const nB = info.nBlocks;
+    if (nB == 0) return false;
     if (info.totalRecs > limit + nB) return false;                     // more sequences than bytes: not a frame worth 16 bytes per record
     if (!bf_grow(c->dBfLit, c->bfLitCap, (size_t)info.totalLit + 64) || !bf_grow(c->dBfRecs, c->bfRecsCap, (size_t)info.totalRecs + 1)) return false;
     hipLaunchKernelGGL(zhip::k_bf_entropy, dim3(nB), dim3(ZHIP_BF_THREADS), sizeof(zhip::DecShared), s, src, H.blockMax, c->dBfBlocks, c->dBfInfo, c->dBfLit, c->dBfRecs, c->dDefTabs);
