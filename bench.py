@@ -700,6 +700,50 @@ def job_pool_leg(zstd_amd, local, host, level):
     return res
 
 
+def prediction_leg(zstd_amd, local, host):
+    """The row matcher's two-pass prediction, measured where it matters: level 5 (greedy, the reference's default row-hash matcher) on the
+    headline's long-match data, the same call with the prediction off (the default) and on.  Device time of the whole call; the two outputs must be the same bytes
+    and the first units are checked against the oracle.  Never `value`."""
+    n = min(len(host), 256 << 20) // UNIT * UNIT
+    if n < 16 * UNIT:
+        return None
+    a = host[:n]
+    res = {"level": 5, "source_bytes": int(n), "units": int(n // UNIT),
+           "note": "zhip_compress at level 5 (ZSTD_greedy, row-hash matcher), 128 KB units; `off` = one parse, every search behind a skipped position redone live; `on` = zhip_set_prediction(units=1): tried, predicted, parsed again; device ms of the call (parse + entropy + gather), best of 2; never `value`"}
+    try:
+        ctx = zstd_amd.Context(local, max_units=n // UNIT + 1)
+        ctx.set_row_matcher(0)
+        outs = {}
+        for mode in (0, 1):
+            ctx.set_prediction(units=mode)
+            best, hc, out = 1e9, None, None
+            for _ in range(2):
+                out = ctx.compress(a, level=5)
+                t = ctx.timing()
+                if t["total_ms"] < best:
+                    best, hc = t["total_ms"], ctx.hc_timing()
+            outs[mode] = out
+            res["on" if mode else "off"] = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "device_ms": round(best, 3), "match_finder_ms": {k: round(v, 3) for k, v in hc.items()}}
+        ctx.close()
+        res["same_bytes"] = bool(outs[0] == outs[1])
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _libs import load_oracle, _buf, ERR
+        lo = load_oracle()
+        lo.zo_set_row_matcher.argtypes = [C.c_int]
+        lo.zo_set_row_matcher(1)
+        try:
+            nsamp = 8
+            cap = lo.zo_compress_bound(UNIT) * nsamp
+            dst = np.empty(cap, dtype=np.uint8)
+            r = lo.zo_compress_chunks(5, UNIT, _buf(a[: nsamp * UNIT]), nsamp * UNIT, _buf(dst), cap, None, 0)
+            res["bytes_identical_to_oracle_first_8_units"] = bool(r != ERR and outs[1][: int(r)] == dst[: int(r)].tobytes())
+        finally:
+            lo.zo_set_row_matcher(0)
+    except Exception as e:                                       # noqa: BLE001
+        res["error"] = str(e)
+    return res
+
+
 def stub_main(args, rank, world):
     """ZHIP_BENCH_STUB=1: no GPU, no compression — exercises only the launch / barrier / max-over-ranks / one-line contract of the
     N-rank path with the gloo backend (tests/test_dist_gloo.py); the line says data = "stub" and must never be read as a measurement"""
@@ -798,6 +842,9 @@ def main():
         jp = job_pool_leg(zstd_amd, local, host, args.level)
         if jp is not None:
             out["job_pool_frame"] = jp
+        pl = prediction_leg(zstd_amd, local, host)
+        if pl is not None:
+            out["level5_row_prediction"] = pl
     del src, host
     if default_line:
         keys = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")

@@ -314,6 +314,14 @@ class Context:
         if L.zhip_set_row_matcher(self._h, int(mode)) != 0:
             raise ZhipError("zhip_set_row_matcher: bad mode")
 
+    def set_prediction(self, units=None, frames=None):
+        """the row matcher's two-pass prediction for units / for multi-block frames (same bytes either way; off by default)"""
+        L = lib()
+        L.zhip_set_prediction.restype = C.c_int
+        L.zhip_set_prediction.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if L.zhip_set_prediction(self._h, -1 if units is None else int(bool(units)), -1 if frames is None else int(bool(frames))) != 0:
+            raise ZhipError("zhip_set_prediction: bad value")
+
     def compress_device(self, dst_ptr, dst_cap, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, sizes_ptr=None, stream=None):
         return self._check(lib().zhip_compress_device(self._h, dst_ptr, dst_cap, src_ptr, src_size, level, unit_size,
                                                       sizes_ptr, stream), "zhip_compress_device")

@@ -89,6 +89,7 @@ struct zhip_ctx_s {
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
+    int rhPredict = 0, lzPredict = 0;    // the row matcher's two-pass prediction for units / for frames (zhip_set_prediction; at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT, default off)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -178,6 +179,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
+    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 0; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -256,6 +258,17 @@ int zhip_set_row_matcher(zhip_ctx* c, int mode)
     // (ZSTD_resolveRowMatchFinderMode returns an explicit mode unchanged, zstd_compress.c:244) — units it would give windowLog <= 14 are
     // refused when they are planned rather than compressed differently; 2 = ZSTD_ps_disable
     c->rowMode = mode < 0 ? c->rowDefault : mode;
+    return 0;
+}
+
+// the row matcher's two-pass prediction (zhip_parse_lazy.h: rh_reconcile; zhip_frame_lazy.h: frame_lazy_predict): 1 on, 0 off, -1 unchanged.
+// Same bytes either way — it only changes how many searches the exact parse has to redo live.
+int zhip_set_prediction(zhip_ctx* c, int units, int frames)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (units < -1 || units > 1 || frames < -1 || frames > 1) return 1;
+    if (units >= 0) c->rhPredict = units;
+    if (frames >= 0) c->lzPredict = frames;
     return 0;
 }
 
@@ -522,7 +535,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
                 // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
                 // long matches never leaves the first launch ($ZHIP_RH_PREDICT=1 turns it on, $ZHIP_RH_BUDGET: the budget)
-                static int const predictOn = getenv("ZHIP_RH_PREDICT") ? atoi(getenv("ZHIP_RH_PREDICT")) : 0;      // opt-in: exact (emulator, GPU parity tests), its speed not measured yet
+                int const predictOn = c->rhPredict;          // opt-in (zhip_set_prediction / $ZHIP_RH_PREDICT): exact (emulator, GPU parity tests), its speed not measured yet
                 static int const budget = getenv("ZHIP_RH_BUDGET") ? atoi(getenv("ZHIP_RH_BUDGET")) : 256;
                 bool anyRow = false;
                 for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
@@ -905,7 +918,7 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
                                (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
         }
         {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=1 turns it on)
-            static int const predictOn = getenv("ZHIP_LZ_PREDICT") ? atoi(getenv("ZHIP_LZ_PREDICT")) : 0;      // opt-in, like $ZHIP_RH_PREDICT
+            int const predictOn = c->lzPredict;              // opt-in, like the units' (zhip_set_prediction / $ZHIP_LZ_PREDICT)
             if (predictOn) {
                 hipLaunchKernelGGL(zhip::k_lz_predict, dim3((unsigned)nU), dim3(64), sizeof(ZhipParse), s,
                                    (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
