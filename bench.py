@@ -379,6 +379,16 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
     nrec = args.records if args.records else max(args.base_records, ((args.mib << 20) // 1201))
     out = records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, nrec, args.base_records, args.steps, args.warmup,
                       want_cpu=not args.no_cpu_baseline, want_decode=True)
+    if default_line and rank == 0:
+        # last, and in a child with a deadline: the row matcher's two-pass prediction at level 5, off against on (an opt-in whose first timing is this leg)
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--prediction-leg"], capture_output=True, timeout=180, text=True)
+            line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            out["level5_row_prediction"] = json.loads(line[-1]) if line else {"error": f"no result (rc {cp.returncode})", "stderr_tail": cp.stderr[-300:]}
+        except subprocess.TimeoutExpired:
+            out["level5_row_prediction"] = {"error": "did not finish within 180 s"}
+        except Exception as e:                                   # noqa: BLE001
+            out["level5_row_prediction"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -795,6 +805,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the parity legs (the printed line then says so and is not a measurement to quote)")
     ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
+    ap.add_argument("--prediction-leg", action="store_true", help="internal: run only the level-5 prediction on/off leg on a fresh 256 MiB of the headline workload and print its JSON (the default line starts it as a child with a timeout)")
     ap.add_argument("--no-extra-legs", action="store_true", help="default line only: skip the Silesia-shaped level-1 leg and the end-to-end (PCIe-inclusive) figure")
     args = ap.parse_args()
 
@@ -827,6 +838,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.prediction_leg:                                      # child of the default line: its own process, so that it can be given a deadline
+        host = zstd_amd.datagen(256 << 20, 50, 0)
+        print(json.dumps(prediction_leg(zstd_amd, local, np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host)))
+        return
     if args.workload == "records":
         return records_main(args, torch, zstd_amd, dev, local, rank, world, dist)
     out, (host, src, n, total) = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
@@ -842,9 +857,6 @@ def main():
         jp = job_pool_leg(zstd_amd, local, host, args.level)
         if jp is not None:
             out["job_pool_frame"] = jp
-        pl = prediction_leg(zstd_amd, local, host)
-        if pl is not None:
-            out["level5_row_prediction"] = pl
     del src, host
     if default_line:
         keys = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")
