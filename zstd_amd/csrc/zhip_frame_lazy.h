@@ -248,6 +248,7 @@ struct LzState {
     uint32_t* dirty;        // one bit per key: a position with that key was decided otherwise than predicted
     uint32_t predict;       // 1: the PREDICTING parse (zhip_parse_lazy.h: rh_reconcile) — positions it would leave out get ZHIP_LZ_PRED, nothing is flagged or stored
     uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
+    uint32_t havePred;      // exact parse: k_lz_predict ran before it (otherwise nothing is marked and there is nothing to compare)
     uint32_t nPred;         // predicting parse: positions marked so far
 };
 __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
@@ -260,7 +261,7 @@ __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
 // exact parse: the positions [st.scanned, upTo) were inserted — those the predicting parse expected to be left out are mismatches
 __device__ inline void lz_reconcile(const uint8_t* __restrict__ src, const ZhipUnit& u, const uint32_t* prev, LzState& st, uint32_t upTo)
 {
-    if (st.predict || upTo <= st.scanned) return;
+    if (st.predict || !st.havePred || upTo <= st.scanned) return;
     bool any = false;
     for (uint32_t q0 = st.scanned; q0 < upTo; q0 += 64) {
         uint32_t const q = q0 + (uint32_t)lane_id();
@@ -438,7 +439,7 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
                 if (valid) recj = B.best[xj];
                 uint32_t const cur4 = ld32(src + xc + 1), rv = ld32(src + (xc + 1 - off1));
                 repj = valid && off1 > 0 && rv == cur4;                      // :1600 repcode at ip+1
-                if (!st.predict) {                                           // the batch's positions (and what lies between them) are inserted by its searches
+                if (!st.predict && st.havePred) {                            // the batch's positions (and what lies between them) are inserted by its searches
                     uint32_t const Kv = (uint32_t)__popcll(__ballot(valid));
                     if (Kv) lz_reconcile(src, u, B.prev, st, ip + (Kv - 1) * step);
                 }
@@ -644,7 +645,7 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
     uint32_t const j0 = job ? job->prefixLen : 0u, jEnd = j0 + u.srcLen, maxDist = 1u << u.windowLog;
     if (jEnd >= (1u << 30)) return;                            // bit 30 of a link is the mark
     uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u, low = 0;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0;
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {
         uint32_t const bLen = jEnd - pos < ZHIP_UNIT_MAX ? jEnd - pos : ZHIP_UNIT_MAX;
         if (bLen >= 7) {
@@ -663,7 +664,7 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
 // job == nullptr: the whole input src[0, u.srcLen) as one frame; else one job of a frame, src = the start of the job's window
 __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipLzSlot& L, uint32_t* prev, const uint8_t* tags, const LzRec* best,
                                   uint32_t* dirty, ZhipSeq* seqs, uint8_t* lits, uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
-                                  EntShared* sh, LzFrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum, const ZhipJob* __restrict__ job)
+                                  EntShared* sh, LzFrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum, const ZhipJob* __restrict__ job, bool havePred)
 {
     int const t = (int)threadIdx.x, wv = t >> 6;
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST), lastJob = !job || (job->flags & ZHIP_JOB_LAST);
@@ -688,7 +689,7 @@ __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUni
     long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
     uint32_t pos = j0, low = 0;
     uint32_t const maxDist = 1u << u.windowLog;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0;      // a job: nextToUpdate = the prefix's end
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = havePred ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
     __threadfence_block();
     __syncthreads();
     while (pos < jEnd) {

@@ -931,7 +931,7 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
         }
         hipLaunchKernelGGL(zhip::k_frame_lazy, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), zhip::frame_lazy_lds_bytes(), s,
                            (const uint8_t*)srcDev, c->dUnits, c->dSlots, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dLzHeads,
-                           c->dSeqs, c->dLits, c->dStBits, c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr);
+                           c->dSeqs, c->dLits, c->dStBits, c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, (uint32_t)(c->lzPredict != 0));
         HIPCHK(c, hipGetLastError());
     }
     if (c->lzAll) { }

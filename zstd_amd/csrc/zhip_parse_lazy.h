@@ -384,6 +384,7 @@ struct HcState {
     lds_u32* dirty;         // row matcher: one bit per row, set when a position of that row was decided otherwise than predicted (2^(hashLog - rowLog) bits of LDS)
     uint32_t predict;       // 1: the PREDICTING parse — positions it would skip get ZHIP_HC_PRED, nothing is flagged, nothing is stored
     uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
+    uint32_t havePred;      // exact parse: a predicting parse ran before it (otherwise nothing is marked and there is nothing to compare)
     uint32_t nLive;         // searches redone live (statistics: ZhipParse.pad0)
     uint32_t budget;        // TRY parse: give up (the unit is parsed again with the prediction) once this many searches went live; 0 = never
     uint32_t abort;
@@ -421,7 +422,7 @@ __device__ inline void rh_reconcile_t(const uint8_t* __restrict__ src, uint32_t 
 }
 __device__ inline void rh_reconcile(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
 {
-    if (st.predict || upTo <= st.scanned) return;
+    if (st.predict || !st.havePred || upTo <= st.scanned) return;
     uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
     if (mls == 4) rh_reconcile_t<4>(src, n, u, prev, st, upTo);
     else if (mls == 5) rh_reconcile_t<5>(src, n, u, prev, st, upTo);
@@ -630,7 +631,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
 // skipping would leave out are only MARKED in prev[] (ZHIP_HC_PRED); no sequences, literals or meta are written
 __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem /* ZHIP_RH_DIRTY_BYTES */,
                                        uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
-                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0)
+                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0, bool havePred = false)
 {
     uint32_t const lane = (uint32_t)lane_id();
     {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
@@ -651,7 +652,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     if (n >= (u.rowLog ? 18u : 10u)) {
     uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
-    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0;
+    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0; st.havePred = havePred ? 1u : 0u;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
@@ -677,7 +678,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             if (pfIp == ip && pfOff1 == off1 && step == 1) { recj = pfRec; cur4 = pfCur4; rv = pfRv; }   // loaded while the last sequence was finished
             else { recj = valid ? best[xj] : 0; cur4 = ld32(src + xc + 1); rv = ld32(src + (xc + 1 - off1)); }
             repj = valid && off1 > 0 && rv == cur4;                          // :1600 repcode at ip+1
-            if (u.rowLog && !predict) {                                       // the batch's positions (and what lies between them) are inserted by its searches
+            if (u.rowLog && havePred) {                                       // the batch's positions (and what lies between them) are inserted by its searches
                 uint32_t const Kv = (uint32_t)__popcll(__ballot(valid));
                 if (Kv) rh_reconcile(src, n, u, prev, st, ip + (Kv - 1) * step);
             }
