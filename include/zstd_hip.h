@@ -85,7 +85,7 @@ size_t       zhip_compress_params_device(zhip_ctx* ctx, void* dstDev, size_t dst
  * byte-identical to the reference's single frame.  The block chain of a frame is serial: a frame is one workgroup, so the batch,
  * not the frame, is what fills the GPU (the per-unit calls above are the throughput path).  Implemented for the strategies ZSTD_fast
  * ... ZSTD_lazy2 (levels -N .. 12 of every size class; greedy / lazy / lazy2 with the row-hash matcher or the hash chain as zhip_set_row_matcher says:
- * zhip_frame_lazy.h carries chain / rows, nextToUpdate, the FSE tables repeated by cost and lazy2's block splitter across the blocks), inputs below 2 GiB each,
+ * zhip_frame_lazy.h carries chain / rows, nextToUpdate, the FSE tables repeated by cost and lazy2's block splitter across the blocks; a window — input, or job + overlap — below 1 GiB), inputs below 2 GiB each,
  * nFrames <= the context's maxUnits.  dstCapacity >= zhip_frames_bound().  frameSizes (optional) receives each frame's size. */
 size_t       zhip_frames_bound(const unsigned long long* srcOffsets /* nFrames + 1 */, size_t nFrames);
 size_t       zhip_compress_frames(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, const unsigned long long* srcOffsets,

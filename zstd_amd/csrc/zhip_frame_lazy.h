@@ -643,7 +643,6 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
 {
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST);
     uint32_t const j0 = job ? job->prefixLen : 0u, jEnd = j0 + u.srcLen, maxDist = 1u << u.windowLog;
-    if (jEnd >= (1u << 30)) return;                            // bit 30 of a link is the mark
     uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u, low = 0;
     LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {

@@ -810,6 +810,8 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
             outBytes += (zhip::host_compress_bound(len) + 1024 + 15) & ~(size_t)15;      // the block in flight may overshoot before it is declared raw
             {   zhip::ZhipLzSlot L; memset(&L, 0, sizeof(L));
                 size_t const pre = (mt.on && k) ? (prevLen < overlap ? prevLen : overlap) : 0;
+                if (lazy && pre + len >= ((size_t)1 << 30)) {             // a link is 30 bits + two flags (zhip_frame_lazy.h: ZHIP_LZ_LINK)
+                    snprintf(c->err, sizeof(c->err), "frame %zu: a window of 1 GiB and more with a lazy strategy is not implemented on device (use ZSTD_c_nbWorkers: jobs)", i); return ZERR(ZE_srcSize_wrong); }
                 if (lazy) { zhip::lz_fill_slot(L, u, (uint32_t)pre, c->lzPos, c->lzHeads); if (len > c->lzLongest) c->lzLongest = (uint32_t)len; }
                 c->hLz.push_back(L);
             }
