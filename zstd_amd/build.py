@@ -1,12 +1,19 @@
-"""Builds zstd_amd/libzstd_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and the tests."""
+"""Builds zstd_amd/libzstd_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and the tests.
+
+One object per translation unit — zhip_lib.hip (host side: the C ABI, launches) and one zhip_k_<family>.hip per kernel family — compiled in
+parallel and linked into one shared library.  Each family is its own code object, so a change in one cannot move another's code."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libzstd_hip.so")
 SHIM = os.path.join(HERE, "libzstd_hipshim.so")      # ZSTD_*-named drop-in (plain C) on top of LIB
 WORKLOADS = os.path.join(HERE, "libzhip_workloads.so")   # bench / test input generators (host C++, NOT part of the product library)
+UNITS = ["zhip_lib", "zhip_k_parse", "zhip_k_lazy", "zhip_k_entropy", "zhip_k_frames", "zhip_k_decode"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
 def _stale(target, deps):
@@ -22,13 +29,26 @@ def sources():
     return deps
 
 
+def hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def compile_unit(name, extra=(), verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, name + ".o")
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=False):
     """compile every HIP source for gfx950 into one shared library; returns its path"""
     if force or _stale(LIB, sources()):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-Wno-unused-result",
-               os.path.join(CSRC, "zhip_lib.hip"), "-o", LIB]
+        with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 2)) as ex:
+            objs = list(ex.map(lambda u: compile_unit(u, verbose=verbose), UNITS))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -55,6 +55,15 @@ struct ZhipParse {
     uint32_t pad0;
 };
 
+// ------------------------------------------------------------------ wave-uniform control flow (kernels that use workgroup barriers)
+// A value every lane of a wavefront holds alike but the compiler cannot prove so (anything loaded from LDS or memory) makes each branch on it
+// an EXEC-masked one, and an EXEC-masked loop around s_barrier is at the mercy of how the compiler orders the "divergent" paths (the
+// round-2 and round-3 GPU-only stalls).  ZHIP_UNIFORM moves such a value into a scalar register: the branch becomes
+// s_cbranch_scc for the whole wavefront.  ZHIP_CONVERGE is a convergent no-op: code on either side of it is not merged or threaded across.
+// tests/test_isa_checks.py holds the compiled kernels to it (no EXEC-conditional branch may span an s_barrier).
+#define ZHIP_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+#define ZHIP_CONVERGE() __builtin_amdgcn_wave_barrier()
+
 // ------------------------------------------------------------------ optional phase profiling (scripts/prof_phases.py)
 // Compiled only into the measurement variant of the library (-DZHIP_PROF, zstd_amd/libzstd_hip_prof.so): thread 0 of
 // each workgroup accumulates s_memtime deltas per phase and adds them to g_prof at the end.  The product build

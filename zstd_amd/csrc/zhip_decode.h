@@ -1138,32 +1138,43 @@ __device__ inline void dec_exec_chunk(const ZhipDSeq* recs, uint32_t cnt, uint8_
 
 // ------------------------------------------------------------------ one frame, whole workgroup
 __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t srcLen, uint8_t* out, uint32_t dstCap,
-                                    uint8_t* litBuf, ZhipDSeq* recBuf, const ZhipDDictDev* dict /* nullptr: none */, const uint64_t* defTabs, ZhipDResult* res)
+                                    uint8_t* litBuf, ZhipDSeq* recBuf, const ZhipDDictDev& dictArg /* the kernel argument itself: its fields stay scalar */, bool hasDict, const uint64_t* defTabs, ZhipDResult* res)
 {
-    uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // Control flow around the workgroup barriers is wave-uniform BY CONSTRUCTION (ZHIP_UNIFORM = v_readfirstlane): the wave index, every
+    // status / count read back from LDS and hence every loop condition live in scalar registers and branch with s_cbranch_scc.  Left as
+    // per-lane values (the compiler cannot prove an LDS load uniform) the loops became EXEC-masked, and in round 3 the compiler merged the
+    // `tid == 0` epilogue of one frame with the `tid == 0` queue pop of the next into a lane-0-only path scheduled AFTER the other 127 lanes'
+    // loop — they met the next barrier without it, read the stale queue slot and decoded frame 0 for ever.  ZHIP_CONVERGE()
+    // (a convergent no-op) between two leader-only regions keeps the compiler from threading one into the other.
+    uint32_t const tid = threadIdx.x, wave = ZHIP_UNIFORM(tid >> 6), lane = tid & 63;
     DPROF_BEGIN
     DecHeader const H = dec_frame_header(src, srcLen);
+    const ZhipDDictDev* const dict = hasDict ? &dictArg : nullptr;
+    bool const dictEnt = hasDict && dictArg.hasEntropy;        // wave-uniform (kernel argument)
     uint32_t const dictLen = dict ? dict->len : 0;
     const uint8_t* const dictEnd = dict ? dict->content + dict->len : nullptr;
     if (tid == 0) {
         uint32_t err = H.err;
         if (!err && H.dictID && (!dict || dict->dictID != H.dictID)) err = ZHIP_DE_DICT_WRONG;
         S->status = err; S->hufValid = 0; S->fseValid = 0; S->rep[0] = 1; S->rep[1] = 4; S->rep[2] = 8;
-        if (dict && dict->hasEntropy) { S->hufValid = 1; S->fseValid = 1; S->hufLog = dict->hufLog; for (int k = 0; k < 3; k++) { S->log[k] = dict->log[k]; S->rep[k] = dict->rep[k]; } }
+        if (dictEnt) { S->hufValid = 1; S->fseValid = 1; S->hufLog = dict->hufLog; for (int k = 0; k < 3; k++) { S->log[k] = dict->log[k]; S->rep[k] = dict->rep[k]; } }
     }
-    if (dict && dict->hasEntropy) {                            // the dictionary's tables, unless the previous frame left them untouched
-        bool const needHuf = !S->dictHufIn, needFse = !S->dictFseIn;
+    ZHIP_CONVERGE();
+    if (dictEnt) {                                              // the dictionary's tables, unless the previous frame left them untouched
+        bool const needHuf = !ZHIP_UNIFORM(S->dictHufIn), needFse = !ZHIP_UNIFORM(S->dictFseIn);
         __syncthreads();
         if (needHuf) {
             if (dict->hufLog <= 11) { for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) ((uint32_t*)S->huf)[i] = dict->huf2[i]; }
             else for (uint32_t i = tid; i < (1u << dict->hufLog); i += ZHIP_DEC_THREADS) S->huf[i] = dict->huf[i];
         }
         if (needFse) for (uint32_t i = tid; i < 1280; i += ZHIP_DEC_THREADS) S->fseAll[i] = dict->fse[i];
+        ZHIP_CONVERGE();
         if (tid == 0) { S->dictHufIn = 1; S->dictFseIn = 1; }
+        ZHIP_CONVERGE();
     }
     __syncthreads();
     DPROF(wave ? 16 : 0);                                       // frame setup
-    uint32_t status = S->status;
+    uint32_t status = ZHIP_UNIFORM(S->status);
     __syncthreads();                                            // everybody has read the status before anybody may raise it again (a wave that
                                                                 // ran ahead and flagged an error must not split the workgroup's control flow)
     uint32_t ip = H.size, op = 0;
@@ -1171,7 +1182,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
     bool last = false;
     while (!status && !last) {
         if (srcLen - ip < 3) { status = ZHIP_DE_SRC_WRONG; break; }
-        uint32_t const bh = src[ip] | (src[ip + 1] << 8) | (src[ip + 2] << 16);
+        uint32_t const bh = ZHIP_UNIFORM(src[ip] | (src[ip + 1] << 8) | (src[ip + 2] << 16));
         uint32_t const type = (bh >> 1) & 3, bsize = bh >> 3;
         last = bh & 1;
         ip += 3;
@@ -1214,24 +1225,24 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
         }
         __syncthreads();
         DPROF(wave ? 19 : 2);                                   // waiting for the other wave
-        status = S->status;
+        status = ZHIP_UNIFORM(S->status);
         __syncthreads();                                        // (same rule: read, then barrier, then the next writer)
         if (status) break;
-        uint32_t const nbSeq = S->nbSeq, litSize = S->litSize;
-        LitSrc L; L.mode = S->litMode; L.byte = S->litByte; L.p = L.mode == 1 ? blk + S->litSrcOff : litBuf;
+        uint32_t const nbSeq = ZHIP_UNIFORM(S->nbSeq), litSize = ZHIP_UNIFORM(S->litSize);
+        LitSrc L; L.mode = ZHIP_UNIFORM(S->litMode); L.byte = ZHIP_UNIFORM(S->litByte); L.p = L.mode == 1 ? blk + ZHIP_UNIFORM(S->litSrcOff) : litBuf;
         uint32_t const nChunks = (nbSeq + ZHIP_DEC_CHUNK - 1) / ZHIP_DEC_CHUNK;
         for (uint32_t c = 0; c < nChunks && !status; c++) {
-            if (wave == 0) dec_exec_chunk(recBuf + (size_t)(c & 1) * (ZHIP_DEC_CHUNK + 1), S->cnt[c & 1], out, L, dictEnd);
+            if (wave == 0) dec_exec_chunk(recBuf + (size_t)(c & 1) * (ZHIP_DEC_CHUNK + 1), ZHIP_UNIFORM(S->cnt[c & 1]), out, L, dictEnd);
             else if (c + 1 < nChunks) dec_seq_chunk(S, D, recBuf + (size_t)((c + 1) & 1) * (ZHIP_DEC_CHUNK + 1), (int)((c + 1) & 1), nbSeq, litSize, dstCap, dictLen);
             DPROF(wave ? 20 : 3);                               // executing / decoding a chunk
             __syncthreads();
             DPROF(wave ? 21 : 4);
-            status = S->status;
+            status = ZHIP_UNIFORM(S->status);
             __syncthreads();
         }
         if (status) break;
         {   // last literals (zstd_decompress_block.c:1681-1690)
-            uint32_t const endOut = nbSeq ? S->endOut : op, endLit = nbSeq ? S->endLit : 0;
+            uint32_t const endOut = nbSeq ? ZHIP_UNIFORM(S->endOut) : op, endLit = nbSeq ? ZHIP_UNIFORM(S->endLit) : 0;
             uint32_t const rest = litSize - endLit;
             if (rest > dstCap - endOut) { status = ZHIP_DE_DST_SMALL; break; }
             if (wave == 0) { if (L.mode == 2) wave_fill(out + endOut, L.byte, rest); else wave_copy(out + endOut, L.p + endLit, rest); __threadfence_block(); }
@@ -1247,6 +1258,7 @@ __device__ inline void decode_frame(DecShared* S, const uint8_t* src, uint32_t s
     if (!status && H.checksum) { if (srcLen - ip < 4) status = ZHIP_DE_CHECKSUM; else ck = ld32(src + ip); }
     __syncthreads();
     if (tid == 0) { res->status = status; res->size = status ? 0 : op; res->hasChecksum = !status && H.checksum; res->checksum = ck; }
+    ZHIP_CONVERGE();                                            // the caller's next leader-only region (the queue pop) stays a region of its own
     DPROF(wave ? 23 : 6);
 }
 #endif  // ZHIP_DECODE_HOST_ONLY

@@ -217,9 +217,9 @@ __device__ inline uint32_t bf_walk_tables(DecShared* S, const uint8_t* seq, uint
 __device__ inline void bf_entropy_block(DecShared* S, const uint8_t* __restrict__ src, uint32_t blockMax, ZhipBfBlock* __restrict__ blocks, uint32_t bi,
                                         uint8_t* __restrict__ litArena, ZhipDSeq* __restrict__ recArena, const uint64_t* __restrict__ defTabs)
 {
-    uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t const tid = threadIdx.x, wave = ZHIP_UNIFORM(tid >> 6), lane = tid & 63;       // scalar branches around the barriers (zhip_common.h, ZHIP_UNIFORM)
     ZhipBfBlock const b = blocks[bi];
-    if (b.type != 2) {                                          // raw / RLE: nothing to decode, the history passes through
+    if (ZHIP_UNIFORM(b.type) != 2) {                                          // raw / RLE: nothing to decode, the history passes through
         if (tid == 0) { blocks[bi].repOut[0] = ZHIP_BF_SYM | ZHIP_BF_SYM_ZERO; blocks[bi].repOut[1] = ZHIP_BF_SYM | (1u << 29) | ZHIP_BF_SYM_ZERO; blocks[bi].repOut[2] = ZHIP_BF_SYM | (2u << 29) | ZHIP_BF_SYM_ZERO; }
         return;
     }
@@ -228,6 +228,7 @@ __device__ inline void bf_entropy_block(DecShared* S, const uint8_t* __restrict_
     ZhipDSeq* const recs = recArena + b.recOff;
     if (tid == 0) { S->status = 0; S->hufValid = 0; S->fseValid = 1; S->nbSeq = b.nbSeq; S->endOut = 0; S->endLit = 0; S->dictHufIn = 0; S->dictFseIn = 0;
                     S->rep[0] = ZHIP_BF_SYM | ZHIP_BF_SYM_ZERO; S->rep[1] = ZHIP_BF_SYM | (1u << 29) | ZHIP_BF_SYM_ZERO; S->rep[2] = ZHIP_BF_SYM | (2u << 29) | ZHIP_BF_SYM_ZERO; }
+    ZHIP_CONVERGE();
     __syncthreads();
     LitHeader const lh = dec_lit_header(blk, b.csize, blockMax);
     if (wave == 0) {

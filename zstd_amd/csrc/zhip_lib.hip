@@ -8,7 +8,24 @@
 #include <chrono>
 #include "../../include/zstd_hip.h"
 #include "zhip_common.h"
+// the kernels are compiled family by family (zhip_k_*.hip -> their own code objects); this translation unit only launches them:
+// the family headers for their structures / LDS sizes / constants, then one prototype per kernel
+#ifdef ZHIP_UNITY
 #include "zhip_kernels.h"
+#else
+#include "zhip_parse.h"
+#include "zhip_parse_dfast.h"
+#include "zhip_parse_lazy.h"
+#include "zhip_parse_dict.h"
+#include "zhip_parse_ext.h"
+#include "zhip_parse_lane.h"
+#include "zhip_entropy.h"
+#include "zhip_frame.h"
+#include "zhip_frame_lazy.h"
+#include "zhip_decode.h"
+#include "zhip_decode_big.h"
+#include "zhip_kernel_decls.h"
+#endif
 #include "zhip_host.h"
 #include "zhip_cdict_host.h"
 
