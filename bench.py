@@ -379,18 +379,8 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
     nrec = args.records if args.records else max(args.base_records, ((args.mib << 20) // 1201))
     out = records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, nrec, args.base_records, args.steps, args.warmup,
                       want_cpu=not args.no_cpu_baseline, want_decode=True)
-    if default_line and rank == 0:
-        # last, and in a child with a deadline: the row matcher's two-pass prediction at level 5, off against on (an opt-in whose first timing is this leg)
-        try:
-            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--prediction-leg"], capture_output=True, timeout=180, text=True)
-            line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
-            out["level5_row_prediction"] = json.loads(line[-1]) if line else {"error": f"no result (rc {cp.returncode})", "stderr_tail": cp.stderr[-300:]}
-        except subprocess.TimeoutExpired:
-            out["level5_row_prediction"] = {"error": "did not finish within 180 s"}
-        except Exception as e:                                   # noqa: BLE001
-            out["level5_row_prediction"] = {"error": str(e)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
@@ -805,7 +795,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the parity legs (the printed line then says so and is not a measurement to quote)")
     ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the extra 4-chunk pipelined measurement (profiling runs: keeps the per-kernel averages clean)")
-    ap.add_argument("--prediction-leg", action="store_true", help="internal: run only the level-5 prediction on/off leg on a fresh 256 MiB of the headline workload and print its JSON (the default line starts it as a child with a timeout)")
+    ap.add_argument("--leg", default="", help="internal: run ONE extra leg of the default line (see LEGS) and print its JSON — the default line starts these as child processes with deadlines")
+    ap.add_argument("--budget", type=float, default=600.0, help="default line: wall-clock seconds after which no further extra leg is started (each leg also has its own deadline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="default line only: skip the Silesia-shaped level-1 leg and the end-to-end (PCIe-inclusive) figure")
     args = ap.parse_args()
 
@@ -838,52 +829,99 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.prediction_leg:                                      # child of the default line: its own process, so that it can be given a deadline
-        host = zstd_amd.datagen(256 << 20, 50, 0)
-        print(json.dumps(prediction_leg(zstd_amd, local, np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host)))
+    if args.leg:                                                 # child of the default line: one extra leg in its own process (so that it can be given a deadline)
+        print(json.dumps(run_leg(args, torch, zstd_amd, dev, local)), flush=True)
         return
     if args.workload == "records":
         return records_main(args, torch, zstd_amd, dev, local, rank, world, dist)
-    out, (host, src, n, total) = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
-                                       args.copies, args.total_bytes, want_decode=(args.mode == "decode" or world == 1),
-                                       want_pipelined=(world == 1 and not args.no_pipelined_extra), want_cpu=not args.no_cpu_baseline)
     default_line = (args.workload == "datagen" and args.level == 1 and args.mode == "compress" and world == 1 and not args.no_extra_legs)
-    if default_line and rank == 0:
-        # PCIe-inclusive figure of the same workload, then the metric's own data shape: Silesia-shaped mix at level 1
-        out["end_to_end"] = end_to_end_leg(torch, zstd_amd, local, host, total, args.level)
-        fr = frames_leg(zstd_amd, local, host, args.level)
-        if fr is not None:
-            out["multi_block_frames"] = fr
-        jp = job_pool_leg(zstd_amd, local, host, args.level)
-        if jp is not None:
-            out["job_pool_frame"] = jp
-    del src, host
-    if default_line:
-        keys = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")
-        torch.cuda.empty_cache()
-        sil, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
-                                 want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=6.0, leg="silesia4_level1")
-        del keep
-        if rank == 0:
-            out["silesia_shaped_level1"] = {k: sil[k] for k in keys if k in sil}
-        # BASELINE configs[2] at its stated size: the Silesia-shaped mix x64 (about 13 GiB), level 3 (ZSTD_dfast), full-size digest against the reference
-        torch.cuda.empty_cache()
-        sil3, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, "silesia", 3, 3, 1, 64, 0,
-                                  want_decode=False, want_pipelined=False, want_cpu=not args.no_cpu_baseline, cpu_seconds=4.0, leg="silesia64_level3")
-        del keep
-        if rank == 0:
-            out["silesia64_level3"] = {k: sil3[k] for k in keys if k in sil3}
-        # BASELINE configs[4] at its stated size: 10 M records (1 M distinct = 1.2 GB) with the trained dictionary, level 3
-        torch.cuda.empty_cache()
-        rec = records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, 10_000_000, 1_000_000, 3, 1,
-                          want_cpu=not args.no_cpu_baseline, want_decode=False)
-        if rank == 0:
-            out["records_zdict_level3"] = {k: rec[k] for k in keys if k in rec}
+    t_start = time.time()
+    out, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
+                             args.copies, args.total_bytes, want_decode=(args.mode == "decode" or (world == 1 and not default_line)),
+                             want_pipelined=(world == 1 and not args.no_pipelined_extra and not default_line), want_cpu=not args.no_cpu_baseline)
+    del keep
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)                      # the headline (metric, value, roofline, cpu_baseline, parity) is out before anything else runs
+    if default_line and rank == 0:
+        # Everything below is extra: each leg is a child process with its own deadline, and the line is printed again (augmented) after every
+        # leg — the LAST line is the complete one, and a leg that stalls or dies leaves {"error": ...} instead of taking the line with it.
+        torch.cuda.empty_cache()
+        for name, deadline in LEGS:
+            left = args.budget - (time.time() - t_start)
+            if left < 20:
+                out[name] = {"skipped": f"the run's time budget (--budget {args.budget} s) was used up"}
+                continue
+            out[name] = child_leg(name, min(deadline, left), args)
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# the default line's extra legs: (key in the JSON line, deadline in seconds)
+LEGS = [("decode", 90), ("pipelined", 60), ("end_to_end", 90), ("multi_block_frames", 90), ("job_pool_frame", 120), ("silesia_shaped_level1", 120),
+        ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_row_prediction", 150)]
+LEG_KEYS = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")
+
+
+def child_leg(name, deadline, args):
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", str(args.steps), "--warmup", str(args.warmup), "--mib", str(args.mib)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_parity:
+        cmd.append("--no-parity")
+    t0 = time.time()
+    try:
+        cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=deadline, text=True)
+        line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        res = json.loads(line[-1]) if line else {"error": f"no result (rc {cp.returncode})", "stderr_tail": cp.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        res = {"error": f"did not finish within {int(deadline)} s (child killed)"}
+    except Exception as e:                                       # noqa: BLE001
+        res = {"error": str(e)}
+    if isinstance(res, dict):
+        res["leg_wall_s"] = round(time.time() - t0, 1)
+    return res
+
+
+def run_leg(args, torch, zstd_amd, dev, local):
+    """one extra leg, in the child: builds its own workload (same generator, same seed as the headline) and returns the leg's JSON object"""
+    name = args.leg
+    nocpu = args.no_cpu_baseline
+    if name == "level5_row_prediction":
+        host = zstd_amd.datagen(256 << 20, 50, 0)
+        return prediction_leg(zstd_amd, local, np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host)
+    if name == "silesia_shaped_level1":                          # the metric's own data shape: Silesia-shaped mix x4 at level 1
+        sil, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
+                              want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="silesia4_level1")
+        return {k: sil[k] for k in LEG_KEYS if k in sil}
+    if name == "silesia64_level3":                               # BASELINE configs[2] at its stated size: the mix x64 (about 13 GiB), level 3 (ZSTD_dfast)
+        sil3, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 3, 3, 1, 64, 0,
+                               want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=4.0, leg="silesia64_level3")
+        return {k: sil3[k] for k in LEG_KEYS if k in sil3}
+    if name == "records_zdict_level3":                           # BASELINE configs[4] at its stated size: 10 M records (1 M distinct), trained dictionary, level 3
+        rec = records_leg(args, torch, zstd_amd, dev, local, 0, 1, None, 10_000_000, 1_000_000, 3, 1, want_cpu=not nocpu, want_decode=False)
+        return {k: rec[k] for k in LEG_KEYS if k in rec}
+    # the legs on the headline's own workload: a short pass of the device path first (its frames / its total are what they work on)
+    args.no_parity = True
+    short, (host, src, n, total) = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "datagen", args.level, 3, 1, 1, 0,
+                                                 want_decode=(name == "decode"), want_pipelined=(name == "pipelined"), want_cpu=False)
+    if name == "decode":
+        dec = short["decode"]
+        if not nocpu:
+            dec["cpu_baseline"] = cpu_decode_baseline(host[: 256 << 20] if len(host) >= (256 << 20) else host, level=args.level)
+        return dec
+    if name == "pipelined":
+        return short.get("pipelined", {"error": "not measured"})
+    del src
+    torch.cuda.empty_cache()
+    if name == "end_to_end":
+        return end_to_end_leg(torch, zstd_amd, local, host, total, args.level)
+    if name == "multi_block_frames":
+        return frames_leg(zstd_amd, local, host, args.level) or {"skipped": "workload below 1 MiB"}
+    if name == "job_pool_frame":
+        return job_pool_leg(zstd_amd, local, host, args.level) or {"skipped": "workload below 512 KB"}
+    return {"error": "unknown leg " + name}
 
 
 if __name__ == "__main__":

@@ -154,7 +154,7 @@ def barrier_rule(body):
     for b, (lab, ins) in enumerate(blocks):
         if inn[b] is not None:
             transfer(inn[b], ins, report, lab)
-    return report + sorted(mismatch.items())
+    return report, sorted(mismatch.items())
 
 
 def stream_hash(body):
@@ -178,14 +178,24 @@ def lint(units=UNITS):
                       "scratch": int(desc.get("private_segment_fixed_size", 0)), "lds": int(desc.get("group_segment_fixed_size", 0)),
                       "barriers": sum(1 for l in body if re.match(r"\s*s_barrier", l)),
                       "calls": sum(1 for l in body if "s_swappc_b64" in l),
-                      "masked_barriers": [f"{lab}: {','.join(st)}" for lab, st in barrier_rule(body)],
                       "hash": stream_hash(body)}
+            must, notes = barrier_rule(body)
+            res[k]["masked_barriers"] = [f"{lab}: {'+'.join(st)}" for lab, st in must]     # narrowed on EVERY path into the barrier
+            res[k]["path_notes"] = [f"{lab}: {st[0]}" for lab, st in notes]                 # paths arrive with different masks (the tracking is coarse: informational)
     return res
+
+
+PINS = os.path.join(ROOT, "tests", "golden", "isa_pins.json")
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     res = lint(args or UNITS)
+    if "--pin" in sys.argv:                             # after a green `pytest -m gpu` on a real MI355X: these instruction streams are the tested ones
+        pins = {k: r["hash"] for k, r in sorted(res.items()) if r["barriers"]}
+        json.dump({"note": "instruction-stream hashes of the kernels that use workgroup barriers, as they last passed pytest -m gpu on MI355X "
+                           "(scripts/isa_lint.py --pin; ROCm 7.2.0 hipcc -O3)", "kernels": pins}, open(PINS, "w"), indent=1)
+        print("pinned", len(pins), "kernels ->", PINS)
     if "--json" in sys.argv:
         print(json.dumps(res, indent=1, sort_keys=True))
     else:
@@ -195,7 +205,9 @@ if __name__ == "__main__":
             print(f"{k:20s} {r['unit'][7:]:8s} vgpr {r['vgpr']:3d} sgpr {r['sgpr']:3d} scratch {r['scratch']:4d} barriers {r['barriers']:2d} calls {r['calls']} hash {r['hash']}"
                   + (f"  MASKED BARRIERS: {len(r['masked_barriers'])}" if r["masked_barriers"] else ""))
             for mb in r["masked_barriers"][:6]:
-                print("      ", mb)
+                print("       masked:", mb)
+            for mb in r["path_notes"][:4]:
+                print("       note:  ", mb)
             bad += len(r["masked_barriers"])
-        print("s_barrier reached under a narrowed EXEC:", bad)
+        print("s_barrier under a narrowed EXEC on every path:", bad)
         print("k_decode function calls:", res.get("k_decode", {}).get("calls", "n/a"))

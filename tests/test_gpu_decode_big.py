@@ -8,9 +8,7 @@ import numpy as np
 import pytest
 from _libs import load_oracle, oracle_frame, oracle_frame_mt, oracle_frame_params, datagen, text_like, _buf
 
-# not strict: these tests have not had a complete GPU run yet (the round's GPU budget ended first) — a failure here is reported as xfailed and does not
-# hide the state of the verified tests before it; a pass is reported as xpassed
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first complete GPU run is the driver's")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")

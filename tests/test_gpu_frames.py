@@ -69,7 +69,7 @@ def test_frames_decode_on_the_device_and_unsupported_strategy(env):
     out3 = ctx.compress_frames([a], 3)[0]                                # level 3 (ZSTD_dfast, the default level) too
     assert out3 == oracle_frame(lo, a, 3) and z.DContext().decompress(out3) == a.tobytes()
     with pytest.raises(z.ZhipError):
-        ctx.compress_frames([a], 5)                                      # greedy: not a frame-kernel strategy, no CPU fallback
+        ctx.compress_frames([a], 13)                                     # btlazy2: not a device strategy, and there is no CPU fallback (levels 5..12 are tests/test_gpu_frames_lazy.py's)
 
 
 def test_shim_single_frame_mode_1mib_level1(env):
@@ -224,7 +224,7 @@ def test_job_pool_frames_mixed_batch_and_small_inputs(env):
             assert out == want, (len(a), level)
     assert z.DContext().decompress(b"".join(outs)) == b"".join(a.tobytes() for a in bufs)
     with pytest.raises(z.ZhipError):
-        ctx.compress_frames([bufs[-1]], 5, workers=1)                     # greedy: not a frame-kernel strategy, no CPU fallback
+        ctx.compress_frames([bufs[-1]], 13, workers=1)                    # btlazy2: not a device strategy, no CPU fallback
     small = z.Context(max_units=2)
     with pytest.raises(z.ZhipError):
         small.compress_frames([bufs[-1]], 1, workers=1, job_size=524288)  # 5 jobs > the context's capacity

@@ -83,7 +83,7 @@ def test_job_pool_frame_over_lanes_equals_the_single_context_frame():
     got = m.compress_frame_mt(a, 1, job_size=524288)                                 # checksum: one lane's zhip_compress_frames_mt
     assert got == oracle_frame_mt(lo, a, 1, 524288, 0, True)
     with pytest.raises(zstd_amd.ZhipError):
-        m.compress_frame_mt(a, 5)                                                    # greedy: no frame kernel, no CPU fallback
+        m.compress_frame_mt(a, 13)                                                   # btlazy2: not a device strategy, no CPU fallback
     m.close()
     del os.environ["ZHIP_MULTI_FRAME_CHUNKED"]
     m = zstd_amd.MultiContext([0])                                                   # one device: the single-context path

@@ -10,8 +10,7 @@ import numpy as np
 import pytest
 from _libs import (load_oracle, corpus_cases, lazy_frame_cases, LAZY_FRAME_MODES, oracle_frame_mt, datagen, text_like, _buf, ROOT, ERR)
 
-# not strict: see tests/test_gpu_zz_decode_big.py
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first complete GPU run is the driver's")]
+pytestmark = pytest.mark.gpu
 UNIT = 131072
 
 
