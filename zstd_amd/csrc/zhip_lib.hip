@@ -49,6 +49,9 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #endif
 #ifndef ZHIP_FAST_GWAVES_DEFAULT
 #define ZHIP_FAST_GWAVES_DEFAULT 3
+#ifndef ZHIP_FAST_DENSE_CUT_DEFAULT
+#define ZHIP_FAST_DENSE_CUT_DEFAULT 4500u       /* datagen P50: ~2 000 sequences per 128 KB unit, Silesia-shaped ~6 000, word-salad text ~11 000 (A/B: profiles/r04_ab_dense_form.log) */
+#endif
 #endif
 struct zhip_ctx_s {
     int device;
@@ -103,10 +106,12 @@ struct zhip_ctx_s {
     uint32_t* dQueue = nullptr; uint32_t* dOrder = nullptr; uint32_t* dCost = nullptr; uint32_t* dGTabs = nullptr; size_t gtabsCap = 0;
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
     int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
+    uint32_t fastDenseCut = ZHIP_FAST_DENSE_CUT_DEFAULT; // mean estimated sequences per unit from which a batch runs the 4-waves-per-SIMD form ($ZHIP_FAST_DENSE: 0 never, 1 always, n >= 2 the cut)
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
-    int rhPredict = 0, lzPredict = 0;    // the row matcher's two-pass prediction for units / for frames (zhip_set_prediction; at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT, default off)
+    int rhPredict = 1, lzPredict = 0;    // the row matcher's two-pass prediction for units (on: only units whose first parse went over the live-search budget are parsed again — datagen level 5
+                                         // 1.44 -> 1.98 GB/s, text unchanged) / for frames (off: 1 MiB datagen frames x3.4, text frames -33 %; profiles/r04_L5_predict.log); zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -196,7 +201,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
-    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 0; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
+    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 1; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -237,6 +242,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
         c->dictQueue = (e = getenv("ZHIP_DICT_QUEUE")) ? atoi(e) : 1;
         c->dictGWaves = (e = getenv("ZHIP_DICT_GWAVES")) ? atoi(e) : ZHIP_DICT_GWAVES_DEFAULT;
         if (c->fastGWaves > 16) c->fastGWaves = 16;
+        if ((e = getenv("ZHIP_FAST_DENSE"))) { long const v = atol(e); c->fastDenseCut = v <= 0 ? 0xFFFFFFFFu : (v == 1 ? 0u : (uint32_t)v); }
         hipDeviceProp_t prop;
         c->numCUs = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         ok = ok && hipMalloc((void**)&c->dQueue, 64) == hipSuccess;
@@ -487,13 +493,13 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         // the same CUs, the global-table kernel on coStream (its wavefronts need no LDS); heaviest units first when an order is asked for
         if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const uint32_t* order = nullptr;
+        HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));                      // ticket counter; [ZHIP_QF_DENSE]: which register budget runs (k_order_sort decides, 0 without an order)
         if (c->fastOrder && nUnits > 2) {
             if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
             else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
-            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder);
+            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder, c->dQueue, c->fastDenseCut);
             order = c->dOrder;
         }
-        HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));
         if (c->fastOccSmem != smem) {                                         // resident LDS-form workgroups per CU for this table size (nine at hashLog 13)
             int perCU_ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU_, (const void*)zhip::k_parse_fast_q, 64, smem) != hipSuccess || perCU_ < 1) { (void)hipGetLastError(); perCU_ = 1; }
@@ -504,21 +510,36 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         size_t gridG = (size_t)c->fastGWaves * (size_t)c->numCUs;
         if (gridQ >= nUnits) gridG = 0;                                       // everything is resident on the LDS form already
         else if (gridG > nUnits - gridQ) gridG = nUnits - gridQ;
+        // the dense form (<= 128 VGPRs: sixteen wavefronts per CU) has room for 16 - perCU global-table wavefronts beside the LDS-table ones
+        bool const denseForm = order != nullptr && c->fastDenseCut != 0xFFFFFFFFu && gridG != 0;
+        size_t gridG4 = 0;
+        if (denseForm) { int g4 = 16 - perCU; if (g4 < c->fastGWaves) g4 = c->fastGWaves;
+            {   static int const g4env = getenv("ZHIP_FAST_GWAVES_DENSE") ? atoi(getenv("ZHIP_FAST_GWAVES_DENSE")) : 0; if (g4env > 0) g4 = g4env; }   /* measurement knob */
+            gridG4 = (size_t)g4 * (size_t)c->numCUs; if (gridG4 > nUnits - gridQ) gridG4 = nUnits - gridQ; }
+        size_t const gridGmax = gridG4 > gridG ? gridG4 : gridG;
         uint32_t const gtabWords = 1u << maxHashLog;
         if (gridG) {
-            if (c->gtabsCap < gridG * gtabWords) {
+            if (c->gtabsCap < gridGmax * gtabWords) {
                 (void)hipFree(c->dGTabs); c->dGTabs = nullptr; c->gtabsCap = 0;
-                if (hipMalloc((void**)&c->dGTabs, gridG * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; }
-                else c->gtabsCap = gridG * gtabWords;
+                if (hipMalloc((void**)&c->dGTabs, gridGmax * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; gridG4 = 0; }
+                else c->gtabsCap = gridGmax * gtabWords;
             }
         }
         if (gridG) HIPCHK(c, hipEventRecord(c->coEv[0], s));
         hipLaunchKernelGGL(zhip::k_parse_fast_q, dim3((unsigned)gridQ), dim3(64), smem, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
+        if (denseForm && gridG4) {
+            if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(zhip::k_parse_fast_q4, dim3((unsigned)gridQ), dim3(64), smem, s,
+                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
+        }
         if (gridG) {
             HIPCHK(c, hipStreamWaitEvent(c->coStream, c->coEv[0], 0));
             hipLaunchKernelGGL(zhip::k_parse_fast_g, dim3((unsigned)gridG), dim3(64), 0, c->coStream,
                                srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
+            if (denseForm && gridG4)
+                hipLaunchKernelGGL(zhip::k_parse_fast_g4, dim3((unsigned)gridG4), dim3(64), 0, c->coStream,
+                                   srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
             HIPCHK(c, hipEventRecord(c->coEv[1], c->coStream));
             HIPCHK(c, hipStreamWaitEvent(s, c->coEv[1], 0));
         }
@@ -552,7 +573,7 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
                 // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
                 // long matches never leaves the first launch ($ZHIP_RH_PREDICT=1 turns it on, $ZHIP_RH_BUDGET: the budget)
-                int const predictOn = c->rhPredict;          // opt-in (zhip_set_prediction / $ZHIP_RH_PREDICT): exact (emulator, GPU parity tests), its speed not measured yet
+                int const predictOn = c->rhPredict;          // default on (zhip_set_prediction / $ZHIP_RH_PREDICT): exact (emulator, GPU parity tests), measured in round 4
                 static int const budget = getenv("ZHIP_RH_BUDGET") ? atoi(getenv("ZHIP_RH_BUDGET")) : 256;
                 bool anyRow = false;
                 for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
