@@ -157,12 +157,9 @@ int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 /* The row matcher's two-pass prediction: a first parse marks the positions the 384-position rule and lazy skipping will leave
  * un-inserted, the per-position records are recomputed without them, and the exact parse redoes a search live only where prediction and truth differ.
- * Same bytes with it on or off; off by default (also $ZHIP_RH_PREDICT=1 for units, $ZHIP_LZ_PREDICT=1 for multi-block / job-pool frames at creation).
+ * Same bytes with it on or off; units: on by default, frames: off by default (at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT = 0 | 1).
  * units / frames: 1 on, 0 off, -1 unchanged.  returns 0, or 1 for a bad value. */
 int          zhip_set_prediction(zhip_ctx* ctx, int units, int frames);
-/* Batches of at least this many units run their ZSTD_fast / ZSTD_dfast units through the lane-per-unit match finder (one lane per
- * unit, tables in HBM: throughput instead of latency; same bytes).  0 = never.  Environment: ZHIP_LANE_MIN_UNITS. */
-size_t       zhip_lane_min_units(void);
 
 /* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a
  * skippable frame holding the seek table — the natural on-disk form of frame-per-unit output; the reference's

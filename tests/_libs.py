@@ -230,17 +230,6 @@ def emu_parse_units(le, src, units, seqs, lits, metas):
     nu = len(units)
     strat = int(units["strategy"][0]) if nu else 1
     assert (units["strategy"] == strat).all() or ((units["strategy"] >= 3) & (units["strategy"] <= 5)).all()
-    if os.environ.get("ZHIP_EMU_LANE") == "1" and strat in (1, 2) and nu:
-        # the lane-per-unit form (zhip_parse_lane.h) for every unit it takes (>= 8 bytes); the wave-per-unit kernel below skips those
-        units = units.copy()
-        units["pad1"][units["srcLen"] >= 8] = 1
-        le.emu_lane_table_words.restype = C.c_uint64
-        stride = max(int(le.emu_lane_table_words(int(h), int(c), strat)) for h, c in zip(units["hashLog"], units["chainLog"]))
-        stride = (stride + 3) & ~3
-        ltabs = np.zeros(nu * stride + 4, dtype=np.uint32)
-        le.emu_parse_lane.restype = None
-        le.emu_parse_lane.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        le.emu_parse_lane(_buf(src), _buf(units), nu, _buf(ltabs), stride, _buf(seqs), _buf(lits), _buf(metas), 0)
     if strat == 1:
         smem = le.emu_fast_lds_bytes(int(units["hashLog"].max()))
         qmode = int(os.environ.get("ZHIP_EMU_QUEUE", "0"))

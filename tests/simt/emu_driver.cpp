@@ -68,19 +68,10 @@ void emu_parse_dfast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits,
 {
     std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, zhip::dfast_lds_bytes(),
-                 [=] { zhip::k_parse_dfast(src, units, slots, nUnits, tabs, tabStride, seqs, lits, metas); }, osThreads);
+                 [=] { zhip::k_parse_dfast(src, units, slots, nUnits, tabs, tabStride, seqs, lits, metas, nullptr); }, osThreads);
 }
 uint64_t emu_dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return zhip::dfast_table_bytes(hashLog, chainLog); }
 
-// lane-per-unit form (zhip_parse_lane.h): units flagged pad1 = ZHIP_UNIT_LANE, tables zeroed by the caller
-void emu_parse_lane(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride,
-                    ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas, int osThreads)
-{
-    std::vector<ZhipSlot> const sv = fixed_slots(nUnits); const ZhipSlot* const slots = sv.data();
-    simt::launch({(nUnits + 63) / 64, 1, 1}, {64, 1, 1}, 0,
-                 [=] { zhip::k_parse_lane(src, units, slots, nUnits, tabs, tabStride, seqs, lits, metas); }, osThreads);
-}
-uint64_t emu_lane_table_words(uint32_t hashLog, uint32_t chainLog, uint32_t strategy) { return zhip::lane_table_words(hashLog, chainLog, strategy); }
 
 // hash-chain strategies (greedy / lazy / lazy2): the three launches of zhip_parse_lazy.h
 void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, uint32_t* tabs, size_t tabStride, uint64_t* best,

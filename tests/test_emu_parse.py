@@ -257,18 +257,6 @@ def test_rowhash_parse_matches_oracle(libs):
         lo.zo_set_row_matcher(0)
 
 
-def test_lane_per_unit_form_on_the_emulator(libs, monkeypatch):
-    """zhip_parse_lane.h (one lane per unit, tables in global memory) against the oracle: ZSTD_fast and ZSTD_dfast, small and ragged units"""
-    lo, le = libs
-    monkeypatch.setenv("ZHIP_EMU_LANE", "1")
-    for level in (1, 3, -5):
-        cases = []
-        for n in (0, 7, 8, 9, 12, 13, 100, 1000, 5000, 40000, 131072):
-            cases += list(corpus_cases(lo, sizes=(n,), seeds=(level + 7,)))
-        cases = [c for c in cases if make_units(lo, [len(c[1])], level)["strategy"][0] in (1, 2)]
-        check(le, lo, cases, level)
-
-
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_queue_form_of_the_fast_stage_on_the_emulator(libs, monkeypatch, mode):
     """k_order_cost + k_order_sort + the persistent queue kernels (mode 1: LDS tables, 2: tables in global memory with ballot hash

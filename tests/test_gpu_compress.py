@@ -235,30 +235,3 @@ def test_dst_too_small_and_unsupported_level_are_errors(env):
     assert L.zhip_isError(r) and b"too small" in L.zhip_getErrorName(r)
     with pytest.raises(zstd_amd.ZhipError):
         ctx.compress(a, level=19)
-
-
-def test_lane_per_unit_form_is_byte_identical(tmp_path):
-    """the lane-per-unit match finders (zhip_parse_lane.h, $ZHIP_LANE_MIN_UNITS — off by default: slower than the wave-per-unit kernels on
-    the bench's data shapes) produce the oracle's frames too: levels 1 and 3, ragged tail, in a process of their own
-    (the threshold is read once per process)"""
-    import os, subprocess, sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import torch, zstd_amd
-from _libs import load_oracle, _buf, ERR, datagen, text_like
-lo = load_oracle()
-assert zstd_amd.lib().zhip_lane_min_units() == 1
-a = np.concatenate([datagen(lo, 5 * 131072, 50, 3), text_like(3 * 131072 + 777, 5), datagen(lo, 70000, 85, 9)])
-ctx = zstd_amd.Context(0, max_units=64)
-for level in (1, 3, -3):
-    got = ctx.compress(a, level=level)
-    cap = lo.zo_compress_bound(131072) * 12
-    dst = np.zeros(cap, dtype=np.uint8)
-    r = lo.zo_compress_chunks(level, 131072, _buf(a), len(a), _buf(dst), cap, None, 0)
-    assert r != ERR and got == dst[:r].tobytes(), level
-print("lane ok")
-''' % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, ZHIP_LANE_MIN_UNITS="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "lane ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

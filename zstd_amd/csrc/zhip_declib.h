@@ -204,7 +204,8 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     if (!H.ok) return false;
     // the room the content may take: its stated size, or — a frame that does not state it — the destination slot (then the compressed size has to look large too)
     uint64_t const limit = H.known ? H.fcs : (uint64_t)f.dstCap;
-    if (limit < c->bigMin || limit > f.dstCap || limit >= 0xFFFFFF00ull || (!H.known && (uint64_t)f.srcLen * 64 < c->bigMin)) return false;
+    // (offsets of 2^31 and more would collide with the symbolic-history marker ZHIP_BF_SYM of the deferred offsets: content below 2 GiB keeps every real offset under it)
+    if (limit < c->bigMin || limit > f.dstCap || limit >= 0x80000000ull || (!H.known && (uint64_t)f.srcLen * 64 < c->bigMin)) return false;
     const uint8_t* const src = srcDev + f.srcOff; uint8_t* const out = dstDev + f.dstOff;
     size_t const capBlocks = (size_t)(limit / 4096 + 4096);                 // a frame whose blocks regenerate less than 4 KB on average is left to k_decode
     if (!c->dBfInfo && hipMalloc((void**)&c->dBfInfo, sizeof(ZhipBfInfo)) != hipSuccess) return false;
@@ -254,6 +255,12 @@ static bool bigframe_decode(zhip_dctx* c, const ZhipDFrame& f, uint8_t* dstDev, 
     float ms = 0; if (hipEventElapsedTime(&ms, c->bfEv[0], c->bfEv[1]) == hipSuccess) *msOut += ms;
     res->status = 0; res->size = n; res->hasChecksum = H.hasChecksum; res->checksum = info.checksum;
     c->bfLast[0]++; c->bfLast[2] += rounds; c->bfLast[3] += nB;
+    // the arenas of a very large frame (the map alone is 4 bytes per content byte) do not stay with the context
+    if (c->bfMapCap > ((size_t)1 << 30) + 4096) {              // content above 1 GiB: more than 4 GiB of map
+        (void)hipFree(c->dBfMap); c->dBfMap = nullptr; c->bfMapCap = 0;
+        (void)hipFree(c->dBfRecs); c->dBfRecs = nullptr; c->bfRecsCap = 0;
+        (void)hipFree(c->dBfLit); c->dBfLit = nullptr; c->bfLitCap = 0;
+    }
     return true;
 }
 

@@ -9,7 +9,6 @@
 #include "zhip_parse_dfast.h"
 #include "zhip_parse_dict.h"
 #include "zhip_parse_ext.h"
-#include "zhip_parse_lane.h"
 
 // register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
 #ifndef ZHIP_DFAST_OCC
@@ -37,7 +36,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     uint32_t const ui = blockIdx.x;
     if (ui >= nUnits) return;
     ZhipUnit const u = units[ui];
-    if (u.strategy != ZHIP_STRAT_FAST || u.pad1 == ZHIP_UNIT_LANE) return;          // another family's kernel handles it
+    if (u.strategy != ZHIP_STRAT_FAST) return;          // another family's kernel handles it
     const uint8_t* const p = src + u.srcOff;
     ZhipSlot const sl = slots[ui];
     ZhipSeq* const sq = seqs + sl.seqOff;
@@ -86,7 +85,7 @@ __device__ __forceinline__ void parse_fast_q_body(const uint8_t* __restrict__ sr
         if (t >= nUnits) return;
         uint32_t const ui = order ? order[t] : t;
         ZhipUnit const u = units[ui];
-        if (u.strategy != ZHIP_STRAT_FAST || u.pad1 == ZHIP_UNIT_LANE) continue;
+        if (u.strategy != ZHIP_STRAT_FAST) continue;
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
@@ -111,7 +110,7 @@ __device__ __forceinline__ void parse_fast_g_body(const uint8_t* __restrict__ sr
         if (t >= nUnits) return;
         uint32_t const ui = order ? order[t] : t;
         ZhipUnit const u = units[ui];
-        if (u.strategy != ZHIP_STRAT_FAST || u.pad1 == ZHIP_UNIT_LANE) continue;
+        if (u.strategy != ZHIP_STRAT_FAST) continue;
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
@@ -242,14 +241,15 @@ __global__ void k_order_cost_stale(const ZhipParse* __restrict__ metas, uint32_t
 __global__ void __launch_bounds__(64) ZHIP_DFAST_OCC
 k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
               uint32_t* __restrict__ tabs, size_t tabStride,
-              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
+              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, uint32_t* __restrict__ queue)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
-    // persistent workgroups: workgroup w takes the units w, w + gridDim.x, ... and reuses ONE table pair (tabs + w * tabStride) for
-    // all of them, so the table memory in use is gridDim.x pairs, not nUnits pairs
-    for (uint32_t ui = blockIdx.x; ui < nUnits; ui += gridDim.x) {
+    // persistent workgroups on a ticket counter (queue; nullptr: workgroup w takes the units w, w + gridDim.x, ...): every workgroup reuses ONE
+    // table pair (tabs + w * tabStride) for all its units, so the table memory in use is gridDim.x pairs — what is resident — not nUnits pairs
+    // (Silesia-shaped x64: 1.5 GB of tables instead of 40 GB)
+    for (uint32_t ui = queue ? queue_take(queue) : blockIdx.x; ui < nUnits; ui = queue ? queue_take(queue) : ui + gridDim.x) {
         ZhipUnit const u = units[ui];
-        if (u.strategy != ZHIP_STRAT_DFAST || u.pad1 == ZHIP_UNIT_LANE) continue;
+        if (u.strategy != ZHIP_STRAT_DFAST) continue;
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
@@ -267,18 +267,6 @@ k_parse_dfast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ unit
     }
 }
 
-// Stage 1 for LARGE batches (zhip_parse_lane.h): one LANE per unit, tables (zeroed by the host's memset) at tabs + ui * tabStride words
-__global__ void __launch_bounds__(64)
-k_parse_lane(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-             uint32_t* __restrict__ tabs, size_t tabStride, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas)
-{
-    uint32_t const ui = blockIdx.x * 64u + threadIdx.x;
-    if (ui >= nUnits) return;
-    ZhipUnit const u = units[ui];
-    if (u.pad1 != ZHIP_UNIT_LANE) return;
-    ZhipSlot const sl = slots[ui];
-    parse_lane_unit(src + u.srcOff, u, tabs + (size_t)ui * tabStride, seqs + sl.seqOff, sl.seqCap, lits + sl.litOff, metas + ui);
-}
 
 // Stage 1 for records compressed with an attached dictionary (strategies fast and dfast), one wavefront per record.
 // Dynamic LDS = max(dict_lds_bytes(hashLog, chainLog), dict_fast_lds_bytes(hashLog)) over the records.

@@ -18,7 +18,6 @@
 #include "zhip_parse_lazy.h"
 #include "zhip_parse_dict.h"
 #include "zhip_parse_ext.h"
-#include "zhip_parse_lane.h"
 #include "zhip_entropy.h"
 #include "zhip_frame.h"
 #include "zhip_frame_lazy.h"
@@ -106,6 +105,7 @@ struct zhip_ctx_s {
     uint32_t* dQueue = nullptr; uint32_t* dOrder = nullptr; uint32_t* dCost = nullptr; uint32_t* dGTabs = nullptr; size_t gtabsCap = 0;
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
     int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
+    int dfOccPerCU = 0;                                  // resident k_parse_dfast workgroups per CU (asked once)
     uint32_t fastDenseCut = ZHIP_FAST_DENSE_CUT_DEFAULT; // mean estimated sequences per unit from which a batch runs the 4-waves-per-SIMD form ($ZHIP_FAST_DENSE: 0 never, 1 always, n >= 2 the cut)
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
@@ -169,6 +169,7 @@ void zhip_destroy(zhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->coStream) (void)hipStreamSynchronize(c->coStream);      // the global-table co-kernels use dGTabs / dQueue / dOrder (a call that returned early on an error may have left one running)
     (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
@@ -353,17 +354,6 @@ size_t zhip_test_fse_tables(zhip_ctx* c, const unsigned* counts, const unsigned*
 
 // ------------------------------------------------------------------------------------------------ internals
 // fill ctx->hUnits for `srcSize` bytes cut into unitSize chunks; returns number of units or 0 with *err set
-// Batches of at least this many units take the lane-per-unit match finder for their ZSTD_fast / ZSTD_dfast units (zhip_parse_lane.h);
-// 0 = never.  $ZHIP_LANE_MIN_UNITS overrides the default (the measured cross-over).
-#ifndef ZHIP_LANE_MIN_UNITS_DEFAULT
-#define ZHIP_LANE_MIN_UNITS_DEFAULT 0
-#endif
-static size_t lane_min_units()
-{
-    static long const v = getenv("ZHIP_LANE_MIN_UNITS") ? atol(getenv("ZHIP_LANE_MIN_UNITS")) : (long)ZHIP_LANE_MIN_UNITS_DEFAULT;
-    return v > 0 ? (size_t)v : 0;
-}
-extern "C" size_t zhip_lane_min_units(void) { return lane_min_units(); }
 
 static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int level, size_t* err, uint32_t* maxHashLog)
 {
@@ -372,7 +362,6 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
     uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
-    bool const laneOn = lane_min_units() != 0 && nUnits >= lane_min_units();
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -399,12 +388,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
             *err = ZERR(ZE_parameter_unsupported); return 0;
         }
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
-        if (laneOn && (cp->strategy == ZHIP_STRAT_FAST || cp->strategy == ZHIP_STRAT_DFAST) && len >= 8) {
-            // a large batch: one lane per unit, its table(s) in HBM (family bit 8)
-            u.pad1 = ZHIP_UNIT_LANE; fam |= 8;
-            size_t const w = zhip::lane_table_words(cp->hashLog, cp->chainLog, cp->strategy); if (w > tabWords) tabWords = w;
-        }
-        else if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
+        if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
         else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
@@ -417,7 +401,9 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         size_t const chunk = envChunk > 0 ? (size_t)envChunk : 8192;
         c->hcChunk = nUnits < chunk ? nUnits : chunk;
     }
-    size_t const tabUnits = (fam & 4) ? c->hcChunk : nUnits;
+    // dfast: one table pair per RESIDENT workgroup (k_parse_dfast's workgroups are persistent and reuse theirs: at most 32 wavefronts per CU), not per unit
+    size_t const dfPairs = nUnits < (size_t)32 * (size_t)c->numCUs ? nUnits : (size_t)32 * (size_t)c->numCUs;
+    size_t const tabUnits = (fam & 4) ? c->hcChunk : dfPairs;
     if ((fam & 14) && c->tabsCap < tabUnits * c->tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
         if (hipMalloc((void**)&c->dTabs, tabUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match-finder tables", tabUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
@@ -428,11 +414,11 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
         c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
     }
-    if (((fam & 2) && (fam & 4)) || (fam & 8)) {   // the dfast and the lane kernels index dTabs by the global unit id
-        if (c->tabsCap < nUnits * c->tabStride) {
+    if ((fam & 2) && (fam & 4)) {                  // a mixed batch: room for the dfast workgroups' pairs as well
+        if (c->tabsCap < dfPairs * c->tabStride) {
             (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
-            if (hipMalloc((void**)&c->dTabs, nUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { *err = ZERR(ZE_memory_allocation); return 0; }
-            c->tabsCap = nUnits * c->tabStride;
+            if (hipMalloc((void**)&c->dTabs, dfPairs * c->tabStride * sizeof(uint32_t)) != hipSuccess) { *err = ZERR(ZE_memory_allocation); return 0; }
+            c->tabsCap = dfPairs * c->tabStride;
         }
     }
     *maxHashLog = mh;
@@ -462,31 +448,32 @@ static size_t launch_offsets(zhip_ctx* c, size_t nUnits, hipStream_t s)
 static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
 {
     size_t smem = zhip::fast_lds_bytes(maxHashLog);
-    {   // measurement knob (scripts/): extra LDS bytes per unit lower the number of resident units per CU
-        static long const pad = getenv("ZHIP_PARSE_LDS_PAD") ? atol(getenv("ZHIP_PARSE_LDS_PAD")) : 0;
-        if (pad > 0) smem += (size_t)pad;
-    }
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nUnits * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     if (smem > 64 * 1024 && (c->strategy & 1))
         HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // one launch per strategy family present; every kernel skips the units of the other families
-    if (c->strategy & 8) {
-        // lane-per-unit form: all tables zeroed by ONE memset (inside the timed match-finder stage), 64 units per wavefront
-        HIPCHK(c, hipMemsetAsync(c->dTabs, 0, nUnits * c->tabStride * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(zhip::k_parse_lane, dim3((unsigned)((nUnits + 63) / 64)), dim3(64), 0, s,
-                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
-    }
     if (c->strategy & 2)
-    {   // experiment knobs: $ZHIP_DF_SLOTS persistent workgroups (each reuses one table pair), $ZHIP_DF_LDS_PAD extra LDS bytes per workgroup (fewer resident)
-        static long const dfSlots = getenv("ZHIP_DF_SLOTS") ? atol(getenv("ZHIP_DF_SLOTS")) : 0;
-        static long const dfPad = getenv("ZHIP_DF_LDS_PAD") ? atol(getenv("ZHIP_DF_LDS_PAD")) : 0;
-        unsigned const grid = (dfSlots > 0 && (size_t)dfSlots < nUnits) ? (unsigned)dfSlots : (unsigned)nUnits;
-        size_t const ldsB = zhip::dfast_lds_bytes() + (dfPad > 0 ? (size_t)dfPad : 0);
+    {
+        size_t const ldsB = zhip::dfast_lds_bytes();
         if (ldsB > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_dfast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+        // persistent workgroups — as many as are resident — drawing units from a ticket counter: one table pair per RESIDENT wavefront
+        // (A/B against one workgroup and one table pair per unit, profiles/r04_ab_dfast_persistent.log: the same time — the kernel is latency-bound either way —
+        // with 1.5 GB of tables instead of 40 GB on Silesia-shaped x64)
+        unsigned grid = (unsigned)nUnits; uint32_t* dfQueue = nullptr;
+        if (nUnits > 1) {
+            if (!c->dfOccPerCU) {
+                int perCU_ = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU_, (const void*)zhip::k_parse_dfast, 64, ldsB) != hipSuccess || perCU_ < 1) { (void)hipGetLastError(); perCU_ = 16; }
+                c->dfOccPerCU = perCU_;
+            }
+            size_t resident = (size_t)c->dfOccPerCU * (size_t)c->numCUs;
+            if (c->tabStride && resident > c->tabsCap / c->tabStride) resident = c->tabsCap / c->tabStride;       // never more workgroups than table pairs
+            if (resident < nUnits) { grid = (unsigned)resident; dfQueue = c->dQueue + 4; HIPCHK(c, hipMemsetAsync(dfQueue, 0, 4, s)); }
+        }
         hipLaunchKernelGGL(zhip::k_parse_dfast, dim3(grid), dim3(64), ldsB, s,
-                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse);
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dTabs, c->tabStride, c->dSeqs, c->dLits, c->dParse, dfQueue);
     }
     if ((c->strategy & 1) && c->fastQueue && nUnits > 1) {
         // queue form: persistent wavefronts draw units from one ticket counter — the LDS-table kernel on this stream and, beside it on
