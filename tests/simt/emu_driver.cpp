@@ -30,9 +30,6 @@ void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
 
 // the queue form of the same stage: dispatch order from k_order_cost + k_order_sort, then persistent workgroups on one ticket counter.
 // mode 1 = LDS tables (k_parse_fast_q), 2 = tables in global memory (k_parse_fast_g), 3 = both kernels, one after the other on one queue
-#ifndef ZHIP_EMU_DENSE_CUT
-#define ZHIP_EMU_DENSE_CUT 4500u        /* the product's default cut (zhip_lib.hip): the test inputs fall on both sides of it */
-#endif
 void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas,
                           uint32_t smemBytes, int mode, uint32_t* orderOut, int osThreads)
 {
@@ -40,7 +37,7 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
     std::vector<uint32_t> cost(nUnits + 1), order(nUnits + 1), queue(16, 0);
     uint32_t* const pc = cost.data(); uint32_t* const po = order.data(); uint32_t* const pq = queue.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_order_cost(src, units, nUnits, pc); }, osThreads);
-    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po, pq, ZHIP_EMU_DENSE_CUT); }, 1);    // leaves the dense / sparse decision in pq[ZHIP_QF_DENSE]
+    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po); }, 1);
     if (orderOut) for (uint32_t i = 0; i < nUnits; i++) orderOut[i] = po[i];
     uint32_t maxH = 6; for (uint32_t i = 0; i < nUnits; i++) if (units[i].hashLog > maxH) maxH = units[i].hashLog;
     uint32_t const gw = 1u << maxH, gridG = 3, gridQ = 2;
@@ -48,18 +45,13 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
     if (mode == 3) {
         // the first kernel's workgroups leave after two units each, the second takes the rest (the queue is shared)
         uint32_t const half = nUnits / 2;
-        // (both register-budget forms of each kernel are launched, as the product does: the one whose turn it is not returns at once)
         simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, half, seqs, lits, metas, po, pq); }, osThreads);
-        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q4(src, units, slots, half, seqs, lits, metas, po, pq); }, osThreads);
         pq[0] = half;
         simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
-        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g4(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
     } else if (mode == 2) {
         simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
-        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g4(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
     } else {
         simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, nUnits, seqs, lits, metas, po, pq); }, osThreads);
-        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q4(src, units, slots, nUnits, seqs, lits, metas, po, pq); }, osThreads);
     }
 }
 

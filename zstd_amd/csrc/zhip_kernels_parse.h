@@ -63,19 +63,8 @@ __device__ __forceinline__ uint32_t queue_take(uint32_t* queue)
 #ifndef ZHIP_FASTG_OCC
 #define ZHIP_FASTG_OCC
 #endif
-// Two register budgets of the same two kernels (round 4).  k_order_sort leaves the batch's mean estimated cost (expected sequences per unit) as a flag
-// beside the ticket counter: SPARSE batches (long literal runs: dependent round trips dominate, spill code in the long-literal path is what hurts)
-// run the 3-waves-per-SIMD form — nine LDS-table wavefronts + three global-table wavefronts per CU; DENSE batches (text, Silesia-shaped: the event loop's
-// instruction issue dominates) run the 4-waves-per-SIMD form — <= 128 VGPRs, nine + SEVEN wavefronts per CU.  All four kernels are launched, the two
-// whose turn it is not return at once (the decision stays on the device: no host round trip inside the stage).  Same code, same bytes.
-#define ZHIP_QF_DENSE 8              /* queue[8]: 1 = dense batch */
-#ifndef ZHIP_DENSE_Q_EU
-#define ZHIP_DENSE_Q_EU 4            /* waves per SIMD the dense forms are compiled for (A/B: profiles/r04_ab_dense_form.log) */
-#endif
-#ifndef ZHIP_DENSE_G_EU
-#define ZHIP_DENSE_G_EU 4
-#endif
-__device__ __forceinline__ void parse_fast_q_body(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+__global__ void __launch_bounds__(64) ZHIP_FAST_OCC
+k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
                ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
                const uint32_t* __restrict__ order, uint32_t* __restrict__ queue)
 {
@@ -100,7 +89,8 @@ __device__ __forceinline__ void parse_fast_q_body(const uint8_t* __restrict__ sr
         __builtin_amdgcn_wave_barrier();
     }
 }
-__device__ __forceinline__ void parse_fast_g_body(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+__global__ void __launch_bounds__(64) ZHIP_FASTG_OCC
+k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
                ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
                const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
 {
@@ -127,53 +117,19 @@ __device__ __forceinline__ void parse_fast_g_body(const uint8_t* __restrict__ sr
 }
 
 
-__global__ void __launch_bounds__(64) ZHIP_FAST_OCC
-k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, const uint32_t* __restrict__ order, uint32_t* __restrict__ queue)
-{
-    if (__builtin_amdgcn_readfirstlane(queue[ZHIP_QF_DENSE]) != 0) return;
-    parse_fast_q_body(src, units, slots, nUnits, seqs, lits, metas, order, queue);
-}
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZHIP_DENSE_Q_EU)))
-k_parse_fast_q4(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, const uint32_t* __restrict__ order, uint32_t* __restrict__ queue)
-{
-    if (__builtin_amdgcn_readfirstlane(queue[ZHIP_QF_DENSE]) == 0) return;
-    parse_fast_q_body(src, units, slots, nUnits, seqs, lits, metas, order, queue);
-}
-__global__ void __launch_bounds__(64) ZHIP_FASTG_OCC
-k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
-{
-    if (__builtin_amdgcn_readfirstlane(queue[ZHIP_QF_DENSE]) != 0) return;
-    parse_fast_g_body(src, units, slots, nUnits, seqs, lits, metas, order, queue, gtabs, gtabWords);
-}
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZHIP_DENSE_G_EU)))
-k_parse_fast_g4(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
-{
-    if (__builtin_amdgcn_readfirstlane(queue[ZHIP_QF_DENSE]) == 0) return;
-    parse_fast_g_body(src, units, slots, nUnits, seqs, lits, metas, order, queue, gtabs, gtabWords);
-}
-
 // Dispatch order for the queue kernels: units sorted by descending cost (a counting sort over 2 048 cost classes, one workgroup).
 // cost: mode 2 = the sequence count the previous call left in metas[] (measurement only: the upper bound an estimator can reach),
 // mode 1 = k_order_cost's estimate.
 __global__ void __launch_bounds__(1024)
-k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t denseCut)
+k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t part[1024];
-    __shared__ unsigned long long sum;
     uint32_t const tid = threadIdx.x;
     hist[tid] = 0; hist[tid + 1024] = 0;
-    if (tid == 0) sum = 0;
     __syncthreads();
-    unsigned long long mine = 0;
-    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const b = cost[i] >> 4; mine += cost[i]; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
-    atomicAdd(&sum, mine);
+    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const b = cost[i] >> 4; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
     __syncthreads();
-    if (tid == 0) queue[ZHIP_QF_DENSE] = (sum / (nUnits ? nUnits : 1u) >= (unsigned long long)denseCut) ? 1u : 0u;      // mean expected sequences per unit (k_parse_fast_q / _q4)
     // exclusive prefix over the classes (class 0 = the most expensive): two classes per thread, then a scan of the pair sums
     uint32_t const a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
     part[tid] = a0 + a1;

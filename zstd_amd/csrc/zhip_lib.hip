@@ -48,9 +48,6 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #endif
 #ifndef ZHIP_FAST_GWAVES_DEFAULT
 #define ZHIP_FAST_GWAVES_DEFAULT 3
-#ifndef ZHIP_FAST_DENSE_CUT_DEFAULT
-#define ZHIP_FAST_DENSE_CUT_DEFAULT 4500u       /* datagen P50: ~2 000 sequences per 128 KB unit, Silesia-shaped ~6 000, word-salad text ~11 000 (A/B: profiles/r04_ab_dense_form.log) */
-#endif
 #endif
 struct zhip_ctx_s {
     int device;
@@ -106,7 +103,6 @@ struct zhip_ctx_s {
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
     int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
     int dfOccPerCU = 0;                                  // resident k_parse_dfast workgroups per CU (asked once)
-    uint32_t fastDenseCut = ZHIP_FAST_DENSE_CUT_DEFAULT; // mean estimated sequences per unit from which a batch runs the 4-waves-per-SIMD form ($ZHIP_FAST_DENSE: 0 never, 1 always, n >= 2 the cut)
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
@@ -243,7 +239,6 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
         c->dictQueue = (e = getenv("ZHIP_DICT_QUEUE")) ? atoi(e) : 1;
         c->dictGWaves = (e = getenv("ZHIP_DICT_GWAVES")) ? atoi(e) : ZHIP_DICT_GWAVES_DEFAULT;
         if (c->fastGWaves > 16) c->fastGWaves = 16;
-        if ((e = getenv("ZHIP_FAST_DENSE"))) { long const v = atol(e); c->fastDenseCut = v <= 0 ? 0xFFFFFFFFu : (v == 1 ? 0u : (uint32_t)v); }
         hipDeviceProp_t prop;
         c->numCUs = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         ok = ok && hipMalloc((void**)&c->dQueue, 64) == hipSuccess;
@@ -479,14 +474,6 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         // queue form: persistent wavefronts draw units from one ticket counter — the LDS-table kernel on this stream and, beside it on
         // the same CUs, the global-table kernel on coStream (its wavefronts need no LDS); heaviest units first when an order is asked for
         if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const uint32_t* order = nullptr;
-        HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));                      // ticket counter; [ZHIP_QF_DENSE]: which register budget runs (k_order_sort decides, 0 without an order)
-        if (c->fastOrder && nUnits > 2) {
-            if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
-            else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
-            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder, c->dQueue, c->fastDenseCut);
-            order = c->dOrder;
-        }
         if (c->fastOccSmem != smem) {                                         // resident LDS-form workgroups per CU for this table size (nine at hashLog 13)
             int perCU_ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU_, (const void*)zhip::k_parse_fast_q, 64, smem) != hipSuccess || perCU_ < 1) { (void)hipGetLastError(); perCU_ = 1; }
@@ -497,36 +484,30 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         size_t gridG = (size_t)c->fastGWaves * (size_t)c->numCUs;
         if (gridQ >= nUnits) gridG = 0;                                       // everything is resident on the LDS form already
         else if (gridG > nUnits - gridQ) gridG = nUnits - gridQ;
-        // the dense form (<= 128 VGPRs: sixteen wavefronts per CU) has room for 16 - perCU global-table wavefronts beside the LDS-table ones
-        bool const denseForm = order != nullptr && c->fastDenseCut != 0xFFFFFFFFu && gridG != 0;
-        size_t gridG4 = 0;
-        if (denseForm) { int g4 = 16 - perCU; if (g4 < c->fastGWaves) g4 = c->fastGWaves;
-            {   static int const g4env = getenv("ZHIP_FAST_GWAVES_DENSE") ? atoi(getenv("ZHIP_FAST_GWAVES_DENSE")) : 0; if (g4env > 0) g4 = g4env; }   /* measurement knob */
-            gridG4 = (size_t)g4 * (size_t)c->numCUs; if (gridG4 > nUnits - gridQ) gridG4 = nUnits - gridQ; }
-        size_t const gridGmax = gridG4 > gridG ? gridG4 : gridG;
+        bool const wantOrder = c->fastOrder && nUnits > 2;
+        const uint32_t* order = nullptr;
+        HIPCHK(c, hipMemsetAsync(c->dQueue, 0, 64, s));                      // the ticket counter
+        if (wantOrder) {
+            if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
+            else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
+            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder);
+            order = c->dOrder;
+        }
         uint32_t const gtabWords = 1u << maxHashLog;
         if (gridG) {
-            if (c->gtabsCap < gridGmax * gtabWords) {
+            if (c->gtabsCap < gridG * gtabWords) {
                 (void)hipFree(c->dGTabs); c->dGTabs = nullptr; c->gtabsCap = 0;
-                if (hipMalloc((void**)&c->dGTabs, gridGmax * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; gridG4 = 0; }
-                else c->gtabsCap = gridGmax * gtabWords;
+                if (hipMalloc((void**)&c->dGTabs, gridG * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; }
+                else c->gtabsCap = gridG * gtabWords;
             }
         }
         if (gridG) HIPCHK(c, hipEventRecord(c->coEv[0], s));
         hipLaunchKernelGGL(zhip::k_parse_fast_q, dim3((unsigned)gridQ), dim3(64), smem, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
-        if (denseForm && gridG4) {
-            if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(zhip::k_parse_fast_q4, dim3((unsigned)gridQ), dim3(64), smem, s,
-                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
-        }
         if (gridG) {
             HIPCHK(c, hipStreamWaitEvent(c->coStream, c->coEv[0], 0));
             hipLaunchKernelGGL(zhip::k_parse_fast_g, dim3((unsigned)gridG), dim3(64), 0, c->coStream,
                                srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
-            if (denseForm && gridG4)
-                hipLaunchKernelGGL(zhip::k_parse_fast_g4, dim3((unsigned)gridG4), dim3(64), 0, c->coStream,
-                                   srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
             HIPCHK(c, hipEventRecord(c->coEv[1], c->coStream));
             HIPCHK(c, hipStreamWaitEvent(s, c->coEv[1], 0));
         }
