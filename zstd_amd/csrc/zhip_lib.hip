@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
+#include <thread>
 #include <chrono>
 #include "../../include/zstd_hip.h"
 #include "zhip_common.h"
@@ -1173,32 +1174,60 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
 {
     if (nRec == 0) return 0;
     if (nRec > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu records > context capacity %zu", nRec, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
-    if (dstCapacity < zhip_records_bound(recOffsets, nRec)) return ZERR(ZE_dstSize_tooSmall);
+    // The per-record descriptors (parameters by size class, slots in the arenas) are filled by several host threads for large batches — 10 M records are
+    // 640 MB of descriptors: each thread takes a contiguous range with offsets relative to its start, the ranges' totals are prefix-summed, a second
+    // sweep adds the bases.  The destination bound of the call is summed in the same sweep.
     uint64_t seqOff = 0, litOff = 0, outOff = 0;
     uint32_t mhL = 6, mhS = 6, mhFast = 0; int fam = 0;
     bool const attached = cd->h.len != 0;                // dictionaries below 8 bytes are not attached, their parameters still apply
     std::vector<uint32_t> extIdx;                        // sources above the attach cut-off: the reference copies the dictionary (zstd_compress.c:2289-2315)
-    for (size_t i = 0; i < nRec; i++) {
-        size_t const n = (size_t)(recOffsets[i + 1] - recOffsets[i]);
-        zhip::CParams cp;
-        bool const copyParams = zhip::host_cdict_is_copy_mode(cd->h, n);     // the parameter rule also applies to an ignored (< 8 byte) dictionary
-        bool const copyMode = attached && copyParams;
-        if (n > ZHIP_UNIT_MAX || !(copyParams ? zhip::host_cdict_copy_params(cd->h, n, &cp) : zhip::host_cdict_unit_params(cd->h, n, &cp))) {
-            snprintf(c->err, sizeof(c->err), "record %zu (%zu bytes): no parameter row (sources above 128 KB are not single-block frames)", i, n);
+    struct Part { uint64_t seq = 0, lit = 0, out = 0, bound = 0; uint32_t mhL = 6, mhS = 6, mhFast = 0; int fam = 0; size_t bad = (size_t)-1; std::vector<uint32_t> ext; };
+    unsigned nThreads = 1;
+    if (nRec >= 262144) { unsigned const hw = std::thread::hardware_concurrency(); nThreads = hw >= 16 ? 16 : (hw ? hw : 1); }
+    std::vector<Part> parts(nThreads);
+    auto fill = [&](unsigned t) {
+        Part& P = parts[t];
+        size_t const a = nRec * t / nThreads, b = nRec * (t + 1) / nThreads;
+        for (size_t i = a; i < b; i++) {
+            size_t const n = (size_t)(recOffsets[i + 1] - recOffsets[i]);
+            zhip::CParams cp;
+            bool const copyParams = zhip::host_cdict_is_copy_mode(cd->h, n);     // the parameter rule also applies to an ignored (< 8 byte) dictionary
+            bool const copyMode = attached && copyParams;
+            if (n > ZHIP_UNIT_MAX || !(copyParams ? zhip::host_cdict_copy_params(cd->h, n, &cp) : zhip::host_cdict_unit_params(cd->h, n, &cp))) { P.bad = i; return; }
+            ZhipUnit& u = c->hUnits[i];
+            u.srcOff = recOffsets[i]; u.srcLen = (uint32_t)n;
+            u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
+            u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
+            u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
+            ZhipSlot& sl = c->hSlots[i];
+            sl.seqOff = P.seq; sl.litOff = P.lit; sl.outOff = P.out; sl.seqCap = (uint32_t)rec_seq_cap(n); sl.pad0 = 0;
+            P.seq += rec_seq_cap(n); P.lit += rec_lit_bytes(n); P.out += rec_out_bytes(n); P.bound += zhip::host_compress_bound(n);
+            if (copyMode) { P.ext.push_back((uint32_t)i); continue; }            // its tables are the CDict's geometry, in HBM
+            if (cp.strategy == ZHIP_STRAT_FAST) { P.fam |= 1; if (cp.hashLog > P.mhFast) P.mhFast = cp.hashLog; }
+            else { P.fam |= 2; if (cp.hashLog > P.mhL) P.mhL = cp.hashLog; if (cp.chainLog > P.mhS) P.mhS = cp.chainLog; }
+        }
+    };
+    auto rebase = [&](unsigned t, uint64_t bs, uint64_t bl, uint64_t bo) {
+        size_t const a = nRec * t / nThreads, b = nRec * (t + 1) / nThreads;
+        for (size_t i = a; i < b; i++) { ZhipSlot& sl = c->hSlots[i]; sl.seqOff += bs; sl.litOff += bl; sl.outOff += bo; }
+    };
+    if (nThreads == 1) fill(0);
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < nThreads; t++) th.emplace_back(fill, t); for (auto& x : th) x.join(); }
+    uint64_t bound = 0;
+    std::vector<uint64_t> bs(nThreads), bl(nThreads), bo(nThreads);
+    for (unsigned t = 0; t < nThreads; t++) {
+        Part const& P = parts[t];
+        if (P.bad != (size_t)-1) {
+            snprintf(c->err, sizeof(c->err), "record %zu (%zu bytes): no parameter row (sources above 128 KB are not single-block frames)", P.bad, (size_t)(recOffsets[P.bad + 1] - recOffsets[P.bad]));
             return ZERR(ZE_parameter_unsupported);
         }
-        ZhipUnit& u = c->hUnits[i];
-        u.srcOff = recOffsets[i]; u.srcLen = (uint32_t)n;
-        u.windowLog = (uint8_t)cp.windowLog; u.chainLog = (uint8_t)cp.chainLog; u.hashLog = (uint8_t)cp.hashLog;
-        u.minMatch = (uint8_t)cp.minMatch; u.strategy = (uint8_t)cp.strategy; u.searchLog = (uint8_t)cp.searchLog;
-        u.litMode = (cp.strategy == ZHIP_STRAT_FAST && cp.targetLength > 0) ? 1 : 0; u.pad0 = copyMode ? ZHIP_UNIT_COPYMODE : 0; u.targetLength = cp.targetLength; u.rowLog = 0; u.pad1 = 0;
-        ZhipSlot& sl = c->hSlots[i];
-        sl.seqOff = seqOff; sl.litOff = litOff; sl.outOff = outOff; sl.seqCap = (uint32_t)rec_seq_cap(n); sl.pad0 = 0;
-        seqOff += rec_seq_cap(n); litOff += rec_lit_bytes(n); outOff += rec_out_bytes(n);
-        if (copyMode) { extIdx.push_back((uint32_t)i); continue; }          // its tables are the CDict's geometry, in HBM
-        if (cp.strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp.hashLog > mhFast) mhFast = cp.hashLog; }
-        else { fam |= 2; if (cp.hashLog > mhL) mhL = cp.hashLog; if (cp.chainLog > mhS) mhS = cp.chainLog; }
+        bs[t] = seqOff; bl[t] = litOff; bo[t] = outOff;
+        seqOff += P.seq; litOff += P.lit; outOff += P.out; bound += P.bound;
+        fam |= P.fam; if (P.mhL > mhL) mhL = P.mhL; if (P.mhS > mhS) mhS = P.mhS; if (P.mhFast > mhFast) mhFast = P.mhFast;
+        extIdx.insert(extIdx.end(), P.ext.begin(), P.ext.end());
     }
+    if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
+    if (nThreads > 1) { std::vector<std::thread> th; for (unsigned t = 1; t < nThreads; t++) th.emplace_back(rebase, t, bs[t], bl[t], bo[t]); for (auto& x : th) x.join(); }
     if (seqOff > c->seqArena || litOff > c->litArena || outOff > c->outArena) {
         snprintf(c->err, sizeof(c->err), "records need %llu sequence slots / %llu literal bytes / %llu output bytes: context too small (zhip_create_for_records)",
                  (unsigned long long)seqOff, (unsigned long long)litOff, (unsigned long long)outOff);
