@@ -11,12 +11,16 @@ GPU/stream; there is no data-path collective (units are independent) — torch.d
 barriers and the max-over-ranks time.  scaling = "weak".
 
 Besides the contract fields the JSON line carries `roofline` (dominant kernel = the match finder stage k_parse_fast_q / k_parse_fast_g: algorithmic
-bytes = source read once + 8-byte sequence records + literals written once, divided by the kernel's average launch
-duration from HIP events recorded by the library on the stream it launches on), `pipeline` (all kernels, (S + C) bytes),
-`ratio`, `parity` (sha256 of the GPU stream == oracle stream on a bounded sample and a full-size structural property),
-`cpu_baseline` (the REAL reference timed on this box's host cores) and `pipelined` (an extra, shorter measurement with
-the library's optional 4-chunk stream pipelining, in which a chunk's entropy stage overlaps the match finder of the next
-chunks; per-kernel durations are not separable there, so the headline numbers come from the sequential launches).
+bytes = source read once + 8-byte sequence records + literals written once, divided by the stage's average
+duration from HIP events recorded by the library on the stream it launches on — the two kernels run side by side on two streams and share one
+ticket queue, so the STAGE is what the events bracket), `pipeline` (all kernels, (S + C) bytes),
+`ratio`, `parity` (sha256 of the GPU stream == the real reference's stream at full size, and the first units against the C restatement),
+`cpu_baseline` (the REAL reference timed on this box's host cores).
+
+The line is printed as soon as the headline leg is done.  Every further leg (decode, pipelined, end_to_end, multi_block_frames, job_pool_frame,
+silesia_shaped_level1, silesia64_level3 = BASELINE configs[2], records_zdict_level3 = configs[4], level5_row_prediction) then runs as a CHILD process
+under its own deadline, and the augmented line is printed again after each: the LAST line of stdout is the complete one, and a leg that stalls or
+dies leaves {"error": ...} under its key instead of taking the line with it (round 3 lost every number of the round to one stalled leg).
 """
 import argparse
 import ctypes as C
@@ -304,7 +308,7 @@ def records_leg(args, torch, zstd_amd, dev, local, rank, world, dist, n_records,
                                           f"level {level}, {ddesc} attached (ZSTD_createCDict + refCDict + compress2 semantics), src+dst in HBM",
                               "records_per_gpu": nrec, "parallelism": f"{world} x (one process per GPU, independent records, no collective)"},
                    "ratio": round(n / float(total), 4),
-                   "roofline": {"bound": "hbm", "kernel": "k_parse_dict", "achieved": round(algo / (parse_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "roofline": {"bound": "hbm", "kernel": "k_parse_dict_q (+ k_parse_dict_g on the same ticket queue)", "achieved": round(algo / (parse_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(algo / (parse_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                                 "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(parse_ms, 3)},
                    "pipeline": {"parse_ms": round(parse_ms, 3), "entropy_ms": round(ent_ms, 3), "device_total_ms": round(tot_ms, 3),
