@@ -367,7 +367,7 @@ uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }
 uint32_t emu_ent_shared(void) { return (uint32_t)sizeof(zhip::EntShared); }
 
-uint32_t emu_fast_lds_bytes(uint32_t hlog) { return zhip::fast_lds_bytes(hlog); }
+uint32_t emu_fast_lds_bytes(uint32_t hlog) { return zhip::fast_tag_lds_bytes(hlog); }
 uint32_t emu_seq_cap(void) { return ZHIP_SEQ_CAP; }
 uint32_t emu_sizeof_unit(void) { return sizeof(ZhipUnit); }
 uint32_t emu_sizeof_parse(void) { return sizeof(ZhipParse); }

@@ -48,7 +48,7 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #define ZHIP_DICT_GWAVES_DEFAULT 16
 #endif
 #ifndef ZHIP_FAST_GWAVES_DEFAULT
-#define ZHIP_FAST_GWAVES_DEFAULT 3
+#define ZHIP_FAST_GWAVES_DEFAULT 4
 #endif
 struct zhip_ctx_s {
     int device;
@@ -443,7 +443,7 @@ static size_t launch_offsets(zhip_ctx* c, size_t nUnits, hipStream_t s)
 
 static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, hipStream_t s)
 {
-    size_t smem = zhip::fast_lds_bytes(maxHashLog);
+    size_t smem = zhip::fast_tag_lds_bytes(maxHashLog);
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nUnits * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nUnits * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
     if (smem > 64 * 1024 && (c->strategy & 1))
@@ -605,7 +605,7 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
 // the stages of different chunks overlap, so timing[] reports the match finder + entropy time as one figure.
 static size_t launch_pipelined(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, uint32_t maxHashLog, uint8_t* dstDev, hipStream_t s)
 {
-    size_t const smem = zhip::fast_lds_bytes(maxHashLog);
+    size_t const smem = zhip::fast_tag_lds_bytes(maxHashLog);
     static bool attrSet = false;
     if (!attrSet) { (void)hipFuncSetAttribute((const void*)zhip::k_entropy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(zhip::EntShared)); attrSet = true; }
     if (smem > 64 * 1024)

@@ -101,6 +101,40 @@ __device__ __forceinline__ void tab_mark(const FastTab& T, uint32_t h, uint32_t 
 __device__ __forceinline__ uint32_t tab_peek(const FastTab& T, uint32_t h) { return T.lo[h]; }
 __device__ __forceinline__ void tab_unmark(const FastTab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
 
+// ---- TAGS (round 4).  A window fetches the 4 bytes at every lane's table candidate — 64 random lines for 64 positions of source, of which
+// about one is a match: the stage's HBM traffic was 10-20x its algorithmic bytes and each such gather costs four coalesced loads' time.
+// A tag is a second hash of exactly the 4 bytes the parser compares at a candidate (MEM_read32(match) == MEM_read32(ip), zstd_fast.c:289):
+// different tags PROVE the compare fails, so the candidate's bytes are only fetched by the lanes whose tag agrees.  The unit table in LDS
+// has room for 2 bits per entry (a third bit plane pair; 8 units per CU instead of 9), the table in global memory carries 15 bits above
+// the 17-bit position.  Every insert writes the tag of the bytes at the inserted position; tables without room (frames) report "maybe".
+#ifndef ZHIP_FAST_TAGS
+#define ZHIP_FAST_TAGS 1             /* 0: no tags, the tables as they were (A/B builds) */
+#endif
+__device__ __forceinline__ uint32_t fast_tag15(uint32_t b4) { return (b4 * 0x9E3779B1u) >> 17; }
+struct FastTagTab { lds_u16* lo; lds_u32* hi; lds_u32* tg; };
+__host__ __device__ inline uint32_t fast_tg_bytes(uint32_t hlog) { uint32_t const b = (1u << hlog) >> 2; return ZHIP_FAST_TAGS ? (b < 4 ? 4 : b) : 0u; }
+__host__ __device__ inline uint32_t fast_tag_lds_bytes(uint32_t hlog) { return fast_lds_bytes(hlog) + fast_tg_bytes(hlog); }
+__device__ __forceinline__ void tab_put_t(const FastTagTab& T, uint32_t h, uint32_t pos, uint32_t tag)
+{
+    T.lo[h] = (uint16_t)pos;
+    if (pos >> 16) __hip_atomic_fetch_or(&T.hi[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (ZHIP_FAST_TAGS) {
+        uint32_t const sh = 2u * (h & 15u);
+        __hip_atomic_fetch_and(&T.tg[h >> 4], ~(3u << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_or(&T.tg[h >> 4], (tag >> 13) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+__device__ __forceinline__ uint32_t tab_get_t(const FastTagTab& T, uint32_t h, bool high, uint32_t tag, bool& maybe)
+{
+    uint32_t v = T.lo[h];
+    if (high) v |= ((T.hi[h >> 5] >> (h & 31)) & 1u) << 16;
+    maybe = !ZHIP_FAST_TAGS || ((T.tg[h >> 4] >> (2u * (h & 15u))) & 3u) == (tag >> 13);
+    return v;
+}
+__device__ __forceinline__ void tab_mark(const FastTagTab& T, uint32_t h, uint32_t v) { T.lo[h] = (uint16_t)v; }
+__device__ __forceinline__ uint32_t tab_peek(const FastTagTab& T, uint32_t h) { return T.lo[h]; }
+__device__ __forceinline__ void tab_unmark(const FastTagTab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
+
 // the same table with full 32-bit positions, for blocks that share one table across a multi-block frame (positions are relative
 // to the frame start and exceed 2^17); a flat pointer: LDS when 4 << hashLog bytes fit, else global memory
 struct WideTab { uint32_t* w; };
@@ -109,6 +143,8 @@ __device__ __forceinline__ uint32_t tab_get(const WideTab& T, uint32_t h, bool) 
 __device__ __forceinline__ void tab_mark(const WideTab& T, uint32_t h, uint32_t v) { T.w[h] = v; }
 __device__ __forceinline__ uint32_t tab_peek(const WideTab& T, uint32_t h) { return T.w[h]; }
 __device__ __forceinline__ void tab_unmark(const WideTab& T, uint32_t h, uint32_t old) { T.w[h] = old; }
+__device__ __forceinline__ void tab_put_t(const WideTab& T, uint32_t h, uint32_t pos, uint32_t) { T.w[h] = pos; }
+__device__ __forceinline__ uint32_t tab_get_t(const WideTab& T, uint32_t h, bool, uint32_t, bool& maybe) { maybe = true; return T.w[h]; }
 
 // 24-bit positions in LDS for the blocks of a frame or job whose positions stay below 2^24: 16 low bits + one byte, 3 bytes per
 // entry instead of WideTab's 4 (48 KB at hashLog 14: two frame workgroups per CU instead of one) and LDS-typed pointers (ds_ instead of
@@ -119,6 +155,8 @@ __device__ __forceinline__ uint32_t tab_get(const Lds24Tab& T, uint32_t h, bool)
 __device__ __forceinline__ void tab_mark(const Lds24Tab& T, uint32_t h, uint32_t v) { T.lo[h] = (uint16_t)v; }
 __device__ __forceinline__ uint32_t tab_peek(const Lds24Tab& T, uint32_t h) { return T.lo[h]; }
 __device__ __forceinline__ void tab_unmark(const Lds24Tab& T, uint32_t h, uint32_t old) { T.lo[h] = (uint16_t)old; }
+__device__ __forceinline__ void tab_put_t(const Lds24Tab& T, uint32_t h, uint32_t pos, uint32_t) { tab_put(T, h, pos); }
+__device__ __forceinline__ uint32_t tab_get_t(const Lds24Tab& T, uint32_t h, bool high, uint32_t, bool& maybe) { maybe = true; return tab_get(T, h, high); }
 
 // the unit table with 32-bit positions in GLOBAL memory (L2 / Infinity Cache), for the wavefronts that run beside the LDS-table ones on a
 // CU whose LDS is full (k_parse_fast_g): no LDS at all, so the slot cannot double as the duplicate detector (three dependent global
@@ -129,6 +167,13 @@ __device__ __forceinline__ uint32_t tab_get(const GlobTab& T, uint32_t h, bool) 
 __device__ __forceinline__ void tab_mark(const GlobTab&, uint32_t, uint32_t) { }
 __device__ __forceinline__ uint32_t tab_peek(const GlobTab&, uint32_t) { return 0; }
 __device__ __forceinline__ void tab_unmark(const GlobTab&, uint32_t, uint32_t) { }
+__device__ __forceinline__ void tab_put_t(const GlobTab& T, uint32_t h, uint32_t pos, uint32_t tag) { T.w[h] = ZHIP_FAST_TAGS ? (pos | (tag << 17)) : pos; }      // positions are < 2^17 here (units)
+__device__ __forceinline__ uint32_t tab_get_t(const GlobTab& T, uint32_t h, bool, uint32_t tag, bool& maybe)
+{
+    uint32_t const e = T.w[h];
+    maybe = !ZHIP_FAST_TAGS || (e >> 17) == tag;
+    return ZHIP_FAST_TAGS ? (e & 0x1FFFFu) : e;
+}
 template <typename TAB> struct TabTraits { static constexpr bool ballotGroups = false; };
 template <> struct TabTraits<GlobTab> { static constexpr bool ballotGroups = true; };
 // per lane: the lanes of the wavefront whose `bits`-bit value equals this lane's (itself included) — one ballot per bit
@@ -149,6 +194,7 @@ __device__ __forceinline__ unsigned long long wave_hash_group(uint32_t h, uint32
 // its positions from 1 with `src` one byte BEFORE the frame (zhip_frame.h): position 0 is not memory, so the frame tables (WideTab,
 // Lds24Tab) read position 1.
 __device__ __forceinline__ uint32_t tab_guard(const FastTab&, uint32_t old) { return old; }
+__device__ __forceinline__ uint32_t tab_guard(const FastTagTab&, uint32_t old) { return old; }
 __device__ __forceinline__ uint32_t tab_guard(const Lds24Tab&, uint32_t old) { return old > 1u ? old : 1u; }
 __device__ __forceinline__ uint32_t tab_guard(const WideTab&, uint32_t old) { return old > 1u ? old : 1u; }
 __device__ __forceinline__ uint32_t tab_guard(const GlobTab&, uint32_t old) { return old; }
@@ -350,9 +396,9 @@ __device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint
         if (NEXT) nxt = batch_load(src, nm8, ip0, startPosOff, startRposOff, rep1);
         uint32_t const hh = hash_pos<MLS>(a, hshift);
         if (first) {
-            if (lane == 62) tab_put(T, hh, cur0 + 2);
+            if (lane == 62) tab_put_t(T, hh, cur0 + 2, fast_tag15((uint32_t)a));
             __builtin_amdgcn_wave_barrier();
-            if (lane == 63) tab_put(T, hh, ip0 - 2);
+            if (lane == 63) tab_put_t(T, hh, ip0 - 2, fast_tag15((uint32_t)a));
             __builtin_amdgcn_wave_barrier();
         }
         uint32_t rLength = 0;
@@ -366,7 +412,7 @@ __device__ __forceinline__ bool post_match(const uint8_t* __restrict__ src, uint
         }
         if (rLength < 4) { cur = nxt; return NEXT; }                     // :411 MEM_read32(ip0) != MEM_read32(ip0 - rep2)
         {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }
-        if (lane == 0) tab_put(T, hh, ip0);                              // lane 0 hashed the bytes at ip0
+        if (lane == 0) tab_put_t(T, hh, ip0, fast_tag15((uint32_t)a));   // lane 0 hashed the bytes at ip0
         __builtin_amdgcn_wave_barrier();
         ip0 += rLength;
         store_seq(out, 0, 1, rLength);
@@ -517,7 +563,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
 
     // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
     // lanes of one hash hold the same old value)
-    uint32_t const old = tab_get(T, h, B > 65536);
+    uint32_t const myTag = fast_tag15(cur32);
+    bool tagMaybe;
+    uint32_t const old = tab_get_t(T, h, B > 65536, myTag, tagMaybe);
     // candidates below position 8 cannot be read 4 bytes back (rare: only the first entries of a unit): such a window goes the exact way
     if (ext && __ballot(old != 0 && old < 8u)) ext = false;
     uint32_t cb, info = 0;                                                // info: bits 0-4 forward bytes, 5-7 backward bytes, 8 = the lane's candidate is the table's
@@ -534,7 +582,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             t = same_lo(o2 ^ c.z); f = t + (t == 4u ? f : 0u); }
         info = f | (back << 5) | 0x100u;
     } else {
-        cb = ld32(src + tab_guard(T, old));                               // old == 0 reads the unit's first bytes: harmless
+        // only the lanes whose tag agrees fetch their candidate's bytes (an empty slot or a different tag cannot match: zhip_parse.h, TAGS)
+        cb = ~cur32;
+        if (old != 0 && tagMaybe) cb = ld32(src + tab_guard(T, old));
     }
     uint32_t backId = lane;
     if constexpr (!TabTraits<TAB>::ballotGroups) {
@@ -615,9 +665,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // the window's table writes: the lanes of INS outside NF together, then its NF lanes one by one
 #define ZW_TABLE_FLUSH() do {                                                                                    \
         unsigned long long late_ = INS & NF, CM = INS ^ late_;                                                    \
-        if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put(T, h, P);                                            \
+        if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put_t(T, h, P, myTag);                                   \
         __builtin_amdgcn_wave_barrier();                                                                          \
-        while (late_) { if (lane == ff1u(late_)) tab_put(T, h, P); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
+        while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
         INS = 0; } while (0)
 
     // pass 0 chains events where it can; if a deferred repcode check fails, pass 1 runs the window again the exact way
@@ -1040,7 +1090,9 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             // Each live lane rewrites its slot below (new position, or the old value), so nothing leaks.
             uint32_t const cur32 = (uint32_t)cur.bytes;
             uint32_t const h = hash_pos<MLS>(cur.bytes, hshift);
-            uint32_t const old = tab_get(T, h, ip0 > 65536);
+            uint32_t const myTag = fast_tag15(cur32);
+            bool tagMaybe;
+            uint32_t const old = tab_get_t(T, h, ip0 > 65536, myTag, tagMaybe);
             uint32_t back = lane;
             if constexpr (!TabTraits<TAB>::ballotGroups) {
                 __builtin_amdgcn_wave_barrier();
@@ -1056,7 +1108,8 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             if (g0 != step || nstep != step) batch_offsets(step, nstep, nposOff, nrposOff);
             FastBatch const nxt = batch_load(src, nm8, nip0, nposOff, nrposOff, rep1);
 
-            uint32_t cb = ld32(src + tab_guard(T, old));                     // old == 0 reads the unit's first bytes: harmless
+            uint32_t cb = ~cur32;                                            // an empty slot or a different tag cannot match: no fetch
+            if (old != 0 && tagMaybe) cb = ld32(src + tab_guard(T, old));
             uint32_t cand = old;
             unsigned long long dupMask, grp = 0;
             if constexpr (TabTraits<TAB>::ballotGroups) {
@@ -1099,7 +1152,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
                 unsigned long long const later = inside & ~below_mask((int)lane + 1);
                 we = live && (inC ? later == 0 : inside == 0);
             }
-            if (we) { if (inC) tab_put(T, h, pos); else tab_unmark(T, h, old); }
+            if (we) { if (inC) tab_put_t(T, h, pos, myTag); else tab_unmark(T, h, old); }
             __builtin_amdgcn_wave_barrier();
             ZPROF(6);
 
@@ -1109,8 +1162,8 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
                 cur0 = mpos;
                 if ((jm & 1) && step <= 4) {                                 // :318-324 hashTable[hash1] = ip1 (= A_{k+1})
                     // A_{k+1} is lane jm+1's position (its hash is at hand); for jm == 63 it opens the next batch
-                    if (jm < 63) { if ((int)lane == jm + 1) tab_put(T, h, pos); }
-                    else if (lane == 0) tab_put(T, hash_pos<MLS>(nxt.bytes, hshift), nip0);
+                    if (jm < 63) { if ((int)lane == jm + 1) tab_put_t(T, h, pos, myTag); }
+                    else if (lane == 0) tab_put_t(T, hash_pos<MLS>(nxt.bytes, hshift), nip0, fast_tag15((uint32_t)nxt.bytes));
                     __builtin_amdgcn_wave_barrier();
                 }
                 break;
@@ -1174,23 +1227,24 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     }
 }
 
-// One unit = one block with a fresh table.  smem: fast_lds_bytes(hashLog) bytes of wave-private LDS
+// One unit = one block with a fresh table.  smem: fast_tag_lds_bytes(hashLog) bytes of wave-private LDS
 template <uint32_t MLS>
 __device__ __forceinline__ void parse_fast_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u,
                                        unsigned char* smem, ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const hlog = u.hashLog;
-    FastTab T;
+    FastTagTab T;
     T.lo = (lds_u16*)(uintptr_t)smem;
     T.hi = (lds_u32*)(uintptr_t)(smem + (2u << hlog));
-    {   // fresh table (zstd_compress.c:2020): lo[] and hi[] are contiguous
+    T.tg = (lds_u32*)(uintptr_t)(smem + fast_lds_bytes(hlog));
+    {   // fresh table (zstd_compress.c:2020): lo[], hi[] and the tag plane are contiguous
         lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = fast_lds_bytes(hlog) >> 2;
+        uint32_t const words = fast_tag_lds_bytes(hlog) >> 2;
         for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    parse_fast_block<MLS, FastTab>(src, 0, n, 0, 1, 1, 4, 8, u, T, seqs, lits, meta);   // lowest index 0, ip0 = 1 -> maxRep = 1
+    parse_fast_block<MLS, FastTagTab>(src, 0, n, 0, 1, 1, 4, 8, u, T, seqs, lits, meta);   // lowest index 0, ip0 = 1 -> maxRep = 1
 }
 
 // The same unit on a table in global memory (`gtab`: 1 << hashLog words owned by this wavefront, reused from unit to unit)
