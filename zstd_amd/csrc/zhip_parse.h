@@ -582,9 +582,12 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             t = same_lo(o2 ^ c.z); f = t + (t == 4u ? f : 0u); }
         info = f | (back << 5) | 0x100u;
     } else {
-        // only the lanes whose tag agrees fetch their candidate's bytes (an empty slot or a different tag cannot match: zhip_parse.h, TAGS)
-        cb = ~cur32;
-        if (old != 0 && tagMaybe) cb = ld32(src + tab_guard(T, old));
+        // only the lanes whose tag agrees fetch their candidate's bytes (an empty slot or a different tag cannot match: zhip_parse.h, TAGS); the
+        // others all read the unit's first bytes — one line, one request — so that the load stays unconditional: a load inside a branch is
+        // waited for inside the branch (round 3), and this one has the duplicate detection below to hide behind
+        bool const fetch = old != 0 && tagMaybe;
+        cb = ld32(src + tab_guard(T, fetch ? old : 0u));
+        if (!fetch) cb = ~cur32;
     }
     uint32_t backId = lane;
     if constexpr (!TabTraits<TAB>::ballotGroups) {
@@ -1108,8 +1111,9 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             if (g0 != step || nstep != step) batch_offsets(step, nstep, nposOff, nrposOff);
             FastBatch const nxt = batch_load(src, nm8, nip0, nposOff, nrposOff, rep1);
 
-            uint32_t cb = ~cur32;                                            // an empty slot or a different tag cannot match: no fetch
-            if (old != 0 && tagMaybe) cb = ld32(src + tab_guard(T, old));
+            bool const fetch = old != 0 && tagMaybe;                        // an empty slot or a different tag cannot match: those lanes share one harmless line
+            uint32_t cb = ld32(src + tab_guard(T, fetch ? old : 0u));
+            if (!fetch) cb = ~cur32;
             uint32_t cand = old;
             unsigned long long dupMask, grp = 0;
             if constexpr (TabTraits<TAB>::ballotGroups) {
