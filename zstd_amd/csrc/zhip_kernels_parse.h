@@ -26,7 +26,7 @@ namespace zhip {
 
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
 #ifndef ZHIP_FAST_OCC
-#define ZHIP_FAST_OCC __attribute__((amdgpu_waves_per_eu(3)))      /* <= 170 VGPRs: the LDS table admits nine units per CU = three on one of the four SIMDs (left alone the compiler has chosen anything from 141 to 248) */
+#define ZHIP_FAST_OCC __attribute__((amdgpu_waves_per_eu(3)))      /* <= 170 VGPRs: the LDS table admits eight units per CU (nine before the tag plane) = at most three on one of the four SIMDs (left alone the compiler has chosen anything from 141 to 248) */
 #endif
 __global__ void __launch_bounds__(64) ZHIP_FAST_OCC
 k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
@@ -51,7 +51,7 @@ k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 }
 
 // Stage 1, queue form: persistent wavefronts take units from a ticket counter, in the order `order[]` gives (heaviest first, k_order_*;
-// nullptr = as they come).  Two kernels share ONE queue: k_parse_fast_q keeps its table in LDS (nine wavefronts fill a CU's LDS),
+// nullptr = as they come).  Two kernels share ONE queue: k_parse_fast_q keeps its table in LDS (eight wavefronts fill a CU's LDS),
 // k_parse_fast_g keeps it in global memory and needs no LDS at all, so its wavefronts run BESIDE the nine on the same CU and hide the
 // latency those cannot.  Whoever is free takes the next unit: the split between the two adjusts itself.
 __device__ __forceinline__ uint32_t queue_take(uint32_t* queue)

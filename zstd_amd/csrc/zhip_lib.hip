@@ -36,7 +36,7 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 
 #define ZHIP_MAX_CHUNKS 8
 // The ZSTD_fast stage's launch form (A/B in profiles/r03_ab_queue_forms.log): persistent wavefronts on a ticket
-// queue, units dispatched by descending estimated cost, and three global-table wavefronts per CU beside the nine LDS-table ones (what the
+// queue, units dispatched by descending estimated cost, and four global-table wavefronts per CU beside the eight LDS-table ones (what the
 // 141 / 145 registers of the two kernels leave room for).  $ZHIP_FAST_QUEUE=0 restores one workgroup per unit in index order.
 #ifndef ZHIP_FAST_QUEUE_DEFAULT
 #define ZHIP_FAST_QUEUE_DEFAULT 1
