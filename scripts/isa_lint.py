@@ -23,8 +23,10 @@ PAIR = r"(s\[\d+:\d+\]|vcc|-1|0)"
 
 def compile_asm(unit):
     out = os.path.join(tempfile.gettempdir(), f"isa_lint_{unit}.s")
+    sys.path.insert(0, ROOT)
+    from zstd_amd.build import UNIT_FLAGS                         # the unit's own code generation options: the lint reads the code the library ships
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           "-Wno-unused-function", "-Wno-unused-result", os.path.join(CSRC, unit + ".hip"), "-o", out], stderr=subprocess.DEVNULL)
+                           "-Wno-unused-function", "-Wno-unused-result"] + UNIT_FLAGS.get(unit, []) + [os.path.join(CSRC, unit + ".hip"), "-o", out], stderr=subprocess.DEVNULL)
     return out
 
 

@@ -14,6 +14,10 @@ SHIM = os.path.join(HERE, "libzstd_hipshim.so")      # ZSTD_*-named drop-in (pla
 WORKLOADS = os.path.join(HERE, "libzhip_workloads.so")   # bench / test input generators (host C++, NOT part of the product library)
 UNITS = ["zhip_lib", "zhip_k_parse", "zhip_k_lazy", "zhip_k_entropy", "zhip_k_frames", "zhip_k_decode"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# per-unit code generation options, each an A/B on MI355X (profiles/r04_ab_sched_strategies.log, r04_ab_maxilp.log): the machine scheduler's max-ILP strategy
+# shortens the match finders' dependent chains (ZSTD_fast stage: datagen -3 %, text -2 %, Silesia-shaped -8 %; frame kernels -3 %; decoder -1.5 %); the entropy
+# stage and ZSTD_dfast (bound by table-line latency) do not move, the lazy unit kernels were not measured and keep the default
+UNIT_FLAGS = {u: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] for u in ("zhip_k_parse", "zhip_k_frames", "zhip_k_decode")}
 
 
 def _stale(target, deps):
@@ -36,7 +40,7 @@ def hipcc():
 def compile_unit(name, extra=(), verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     obj = os.path.join(OBJ, name + ".o")
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj]
+    cmd = [hipcc()] + FLAGS + UNIT_FLAGS.get(name, []) + list(extra) + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
