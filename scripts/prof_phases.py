@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "zstd_amd", "libzstd_hip_prof.so")
 
 def build():
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZHIP_PROF",
-           "-Wno-unused-result", os.path.join(ROOT, "zstd_amd", "csrc", "zhip_lib.hip"), "-o", LIB]
+           "-Wno-unused-result", os.path.join(ROOT, "zstd_amd", "csrc", "zhip_unity.hip"), "-o", LIB]      # one translation unit: the phase counters are one __device__ array
     subprocess.check_call(cmd)
 
 

@@ -761,22 +761,20 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         if (tblFail) rawBlock = true;          // cannot happen for valid histograms; keep the frame valid regardless
         if (!rawBlock) {
             // per-sequence bit counts -> positions.  Stream order (LSB first): sequence nbSeq-1 first, then nbSeq-2 ...;
-            // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra]
-            uint32_t const per2 = (nbSeq + NT - 1) / NT;
-            uint32_t const a0 = (uint32_t)t * per2 < nbSeq ? (uint32_t)t * per2 : nbSeq;
-            uint32_t const a1 = a0 + per2 < nbSeq ? a0 + per2 : nbSeq;
+            // inside a sequence: [OF state][ML state][LL state] (not for the first-coded one) [LL extra][ML extra][OF extra].
+            // Round 4: COALESCED.  Thread t takes the sequences t, t + NT, ... (one line per wavefront and array instead of 64); the old form gave
+            // every thread a run of consecutive sequences, i.e. 64 lines per load instruction, and was 45 % of the stage on dense-match data.
+            uint32_t const nbSeqU = ZHIP_UNIFORM(nbSeq);                 // the tile loop below holds barriers: its trip count is scalar
             uint32_t myBits = 0;
-            for (uint32_t i = a0; i < a1; i += 4) {                     // four sequences' loads in flight at a time
-                ZhipSeq sq[4]; uint32_t nb[4];
-                for (uint32_t q = 0; q < 4; q++) if (i + q < a1) { sq[q] = seqs[i + q]; nb[q] = (uint32_t)(bLL[i + q] >> 12) + (bOF[i + q] >> 12) + (bML[i + q] >> 12); }
-                for (uint32_t q = 0; q < 4; q++) if (i + q < a1) {
-                    uint32_t ll, mlb, ob; seq_unpack(sq[q], pm, i + q, ll, mlb, ob);
-                    myBits += TB.llBits[ll_code(TB, ll)] + TB.mlBits[ml_code(TB, mlb)] + hb32(ob);
-                    if (i + q + 1 < nbSeq) myBits += nb[q];
-                }
+            for (uint32_t i = (uint32_t)t; i < nbSeqU; i += NT) {
+                ZhipSeq const sq1 = seqs[i];
+                uint32_t const nb1 = (uint32_t)(bLL[i] >> 12) + (bOF[i] >> 12) + (bML[i] >> 12);
+                uint32_t ll, mlb, ob; seq_unpack(sq1, pm, i, ll, mlb, ob);
+                myBits += TB.llBits[ll_code(TB, ll)] + TB.mlBits[ml_code(TB, mlb)] + hb32(ob);
+                if (i + 1 < nbSeqU) myBits += nb1;
             }
             uint32_t totalSeqBits;
-            uint32_t const before = block_excl_scan<NT, SH>(sh, myBits, &totalSeqBits);      // bits of sequences with LOWER index
+            (void)block_excl_scan<NT, SH>(sh, myBits, &totalSeqBits);
             uint32_t const tailBits = sh->ct[2].tableLog + sh->ct[1].tableLog + sh->ct[0].tableLog;
             uint32_t const streamBits = totalSeqBits + tailBits;                       // + 1 end mark
             uint32_t const streamBytes = (streamBits >> 3) + 1;
@@ -796,24 +794,53 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             __syncthreads();
             {   uint32_t* const w32 = (uint32_t*)((uintptr_t)bs & ~(uintptr_t)3);
                 uint64_t const bit0 = 8ull * ((uintptr_t)bs & 3);
-                // sequences a0..a1-1 of this thread occupy bits [total - before - myBits, total - before)
-                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(totalSeqBits - before - myBits));
-                for (uint32_t top = a1; top > a0; ) {                     // downwards, four sequences' loads in flight
-                    uint32_t const c = top - a0 < 4 ? top - a0 : 4;
-                    top -= c;
-                    ZhipSeq sq[4]; uint32_t x[4], y[4], z[4];
-                    for (uint32_t q = 0; q < 4; q++) if (q < c) { sq[q] = seqs[top + q]; x[q] = bOF[top + q]; y[q] = bML[top + q]; z[q] = bLL[top + q]; }
-                    for (int q = 3; q >= 0; q--) if ((uint32_t)q < c) {
-                        uint32_t const i = top + (uint32_t)q;
-                        uint32_t ll, mlb, ob; seq_unpack(sq[q], pm, i, ll, mlb, ob);
-                        uint32_t const llc = ll_code(TB, ll), mlc = ml_code(TB, mlb), ofc = hb32(ob);
-                        if (i + 1 < nbSeq) { pk.add(x[q] & 0xFFF, x[q] >> 12); pk.add(y[q] & 0xFFF, y[q] >> 12); pk.add(z[q] & 0xFFF, z[q] >> 12); }
-                        { uint32_t const lb = TB.llBits[llc], mb = TB.mlBits[mlc];
-                          pk.add(ll & ((1u << lb) - 1), lb); pk.add(mlb & ((1u << mb) - 1), mb); }
-                        pk.add(ob & (uint32_t)((1ull << ofc) - 1), ofc);
+                // Tiles of NT consecutive sequences, from the top of the block down (the highest sequence comes first in the stream).  Inside a tile
+                // sequence i starts where the higher ones of the tile end: a prefix sum over the tile; its bits are OR-ed into an LDS image of the
+                // tile's stretch of the stream (aligned like the stream's words), which then goes out with whole-word stores — the first and the last
+                // word of a tile are shared with its neighbours and go through atomicOr.  The image lives in the literal histograms (dead by now).
+                uint32_t* const tile = &sh->hist[0][0];
+                uint32_t const nTiles = (nbSeqU + NT - 1) / NT;
+                uint32_t run = 0;                                           // bits placed so far (those of all higher tiles)
+                for (uint32_t k = nTiles; k-- > 0; ) {
+                    uint32_t const i = k * NT + (uint32_t)t;
+                    bool const on = i < nbSeqU;
+                    uint32_t x = 0, y = 0, z = 0, ll = 0, mlb = 0, ob = 1, lb = 0, mb = 0, ofc = 0, nb = 0;
+                    if (on) {
+                        ZhipSeq const sq1 = seqs[i]; x = bOF[i]; y = bML[i]; z = bLL[i];
+                        seq_unpack(sq1, pm, i, ll, mlb, ob);
+                        lb = TB.llBits[ll_code(TB, ll)]; mb = TB.mlBits[ml_code(TB, mlb)]; ofc = hb32(ob);
+                        if (i + 1 >= nbSeqU) { x = 0; y = 0; z = 0; }      // the first-coded sequence carries no state bits
+                        nb = (x >> 12) + (y >> 12) + (z >> 12) + lb + mb + ofc;
                     }
+                    uint32_t tileBits;
+                    uint32_t const lower = block_excl_scan<NT, SH>(sh, nb, &tileBits);        // bits of the tile's sequences BELOW mine
+                    uint32_t const sh0 = (uint32_t)((bit0 + run) & 31);
+                    uint32_t const words = (sh0 + tileBits + 31) >> 5;
+                    for (uint32_t w = (uint32_t)t; w < words; w += NT) tile[w] = 0;
+                    __syncthreads();
+                    if (nb) {
+                        // my bits start behind those of the tile's higher sequences: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+                        uint32_t pos = sh0 + (tileBits - lower - nb);
+                        uint32_t* wp = tile + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
+                        auto put = [&](uint32_t v, uint32_t n) {
+                            acc |= (uint64_t)v << have; have += n;
+                            if (have >= 32) { __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wp++; acc >>= 32; have -= 32; }
+                        };
+                        put(x & 0xFFF, x >> 12); put(y & 0xFFF, y >> 12); put(z & 0xFFF, z >> 12);
+                        put(ll & ((1u << lb) - 1), lb); put(mlb & ((1u << mb) - 1), mb);
+                        put(ob & (uint32_t)((1ull << ofc) - 1), ofc);
+                        if (have) __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __syncthreads();
+                    {   uint32_t* const g = w32 + ((bit0 + run) >> 5);
+                        for (uint32_t w = (uint32_t)t; w < words; w += NT) {
+                            uint32_t const v = tile[w];
+                            if (v) { if (w == 0 || w + 1 == words) atomicOr(g + w, v); else g[w] = v; }
+                        }
+                    }
+                    run += tileBits;
+                    __syncthreads();                                        // the image is free again
                 }
-                pk.finish();
                 if (t == 0) {     // final states ML, OF, LL then the end mark (zstd_compress_sequences.c:371-381)
                     RunPacker tl; tl.init(w32, bit0 + totalSeqBits);
                     tl.add(sh->finalState[2] & ((1u << sh->ct[2].tableLog) - 1), sh->ct[2].tableLog);
