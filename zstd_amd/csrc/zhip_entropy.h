@@ -642,31 +642,64 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         // stream geometry (huf_compress.c:1168-1215): 4 segments of (litSize+3)/4, or one stream
         uint32_t const nStreams = single ? 1 : 4;
         uint32_t const seg = single ? litSize : (litSize + 3) / 4;
-        // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols, read 8 at a time
-        // (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so an 8-byte read may run past the run).
-        uint32_t segStart[SPW], runStart[SPW], runLen[SPW], incl[SPW], total[SPW];
+        // Two forms of the literal pack, the same bits: small units (one wavefront per unit, NT == 64: records of a kilobyte) walk a stream in chunks of
+        // 64 x 16 symbols, lane l taking the 16 bytes at chunk + 16 l — coalesced (records leg: entropy 108 -> 96 ms per 10 M records); full-size units keep
+        // one contiguous run of the stream per lane, whose lines stay in L1 from round to round (the chunked form was 10 % slower there: A/B in
+        // profiles/r04_entropy_tiles2.log)
+        constexpr bool chunked = NT == 64;
+        uint32_t segStart[SPW], segLenA[SPW], total[SPW], runStart[SPW], runLen[SPW], incl[SPW];
+        if constexpr (chunked) {
+            // pass 1: wavefront `wv` sizes stream `wv`.  Round 4: COALESCED — the wavefront walks the stream in chunks of 64 x 16 symbols, lane l takes
+            // the 16 bytes at chunk + 16 l (one 1 KB stretch per load instruction; a lane used to own one contiguous run of the stream, i.e. 64 lines per
+            // load).  (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so a 16-byte read may run past the stream.)
 #pragma unroll
-        for (uint32_t q = 0; q < SPW; q++) {
-            uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
-            uint32_t myBits = 0;
-            segStart[q] = 0; runStart[q] = 0; runLen[q] = 0;
-            if (sI < nStreams) {
-                segStart[q] = sI * seg;
-                uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
-                uint32_t const rper = (segLen + 63) / 64;
-                runStart[q] = (uint32_t)lane * rper; if (runStart[q] > segLen) runStart[q] = segLen;
-                runLen[q] = (runStart[q] + rper <= segLen) ? rper : segLen - runStart[q];
-                const uint8_t* p = lits + segStart[q] + runStart[q];
-                for (uint32_t i = 0; i < runLen[q]; i += 32) {
-                    uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
-                    uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
-                    uint32_t const c = runLen[q] - i;
-                    for (uint32_t b = 0; b < 32; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
+            for (uint32_t q = 0; q < SPW; q++) {
+                uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
+                uint32_t myBits = 0;
+                segStart[q] = 0; segLenA[q] = 0;
+                if (sI < nStreams) {
+                    segStart[q] = sI * seg;
+                    uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
+                    segLenA[q] = segLen;
+                    const uint8_t* const p = lits + segStart[q];
+                    for (uint32_t c0 = 16u * (uint32_t)lane; c0 < segLen; c0 += 1024u) {
+                        uint4 va; __builtin_memcpy(&va, p + c0, 16);
+                        uint32_t const w[4] = { va.x, va.y, va.z, va.w };
+                        uint32_t const c = segLen - c0;
+#pragma unroll
+                        for (uint32_t b = 0; b < 16; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
+                    }
                 }
+                uint32_t const inclAll = wave_incl_scan(myBits);
+                total[q] = __shfl(inclAll, 63);
+                if (lane == 0 && sI < nStreams) { sh->streamBits[sI] = total[q]; sh->streamBytes[sI] = (total[q] >> 3) + 1; }
             }
-            incl[q] = wave_incl_scan(myBits);
-            total[q] = __shfl(incl[q], 63);
-            if (lane == 0 && sI < nStreams) { sh->streamBits[sI] = total[q]; sh->streamBytes[sI] = (total[q] >> 3) + 1; }
+        } else {
+            // pass 1: wavefront `wv` sizes stream `wv`.  lane owns a contiguous run of symbols, read 8 at a time
+            // (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so an 8-byte read may run past the run).
+#pragma unroll
+            for (uint32_t q = 0; q < SPW; q++) {
+                uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
+                uint32_t myBits = 0;
+                segStart[q] = 0; runStart[q] = 0; runLen[q] = 0;
+                if (sI < nStreams) {
+                    segStart[q] = sI * seg;
+                    uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
+                    uint32_t const rper = (segLen + 63) / 64;
+                    runStart[q] = (uint32_t)lane * rper; if (runStart[q] > segLen) runStart[q] = segLen;
+                    runLen[q] = (runStart[q] + rper <= segLen) ? rper : segLen - runStart[q];
+                    const uint8_t* p = lits + segStart[q] + runStart[q];
+                    for (uint32_t i = 0; i < runLen[q]; i += 32) {
+                        uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
+                        uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
+                        uint32_t const c = runLen[q] - i;
+                        for (uint32_t b = 0; b < 32; b++) if (b < c) myBits += sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] & 0xFF;
+                    }
+                }
+                incl[q] = wave_incl_scan(myBits);
+                total[q] = __shfl(incl[q], 63);
+                if (lane == 0 && sI < nStreams) { sh->streamBits[sI] = total[q]; sh->streamBytes[sI] = (total[q] >> 3) + 1; }
+            }
         }
         __syncthreads();
         if (t == 0) {
@@ -700,31 +733,74 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             ZPROF(2);
             // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
             // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
+            if constexpr (chunked) {
 #pragma unroll
-            for (uint32_t q = 0; q < SPW; q++) {
-                uint32_t const sI = (uint32_t)wv + q * NW;
-                if (sI >= nStreams) continue;
-                uint8_t* const sbase = litDst + sh->streamOff[sI];
-                uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
-                uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
-                RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total[q] - incl[q]));
-                const uint8_t* p = lits + segStart[q] + runStart[q];
-                // the run is consumed from its end, 32 bytes per round; the first round takes the odd part
-                uint32_t i = runLen[q];
-                while (i) {
-                    uint32_t const c = (i & 31) ? (i & 31) : 32;
-                    i -= c;
-                    uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
-                    uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
-                    for (int b = 31; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per packer step
-                        uint32_t const c1 = (uint32_t)b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0;
-                        uint32_t const c0 = (uint32_t)(b - 1) < c ? sh->code[(w[(b - 1) >> 2] >> (8 * ((b - 1) & 3))) & 0xFF] : 0;
-                        uint32_t const n1 = c1 & 0xFF;
-                        pk.add((c1 >> 8) | ((c0 >> 8) << n1), n1 + (c0 & 0xFF));
+                for (uint32_t q = 0; q < SPW; q++) {
+                    uint32_t const sI = (uint32_t)wv + q * NW;
+                    if (sI >= nStreams) continue;
+                    uint8_t* const sbase = litDst + sh->streamOff[sI];
+                    uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
+                    uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
+                    // chunks from the stream's end to its start; inside a chunk the higher lanes' symbols come first: a lane's 16 symbols start at
+                    // (bits of all later chunks) + (bits of the chunk's higher lanes) = run + chunk total - inclusive prefix
+                    const uint8_t* const p = lits + segStart[q];
+                    uint32_t const segLen = segLenA[q];
+                    uint32_t const nChunks = (segLen + 1023u) >> 10;           // wave-uniform (stream geometry)
+                    uint32_t run = 0;
+                    for (uint32_t ch = nChunks; ch-- > 0; ) {
+                        uint32_t const c0 = (ch << 10) + 16u * (uint32_t)lane;
+                        uint32_t const c = c0 < segLen ? (segLen - c0 < 16u ? segLen - c0 : 16u) : 0u;
+                        uint32_t cd[16]; uint32_t myBits = 0;
+                        if (c) {
+                            uint4 va; __builtin_memcpy(&va, p + c0, 16);
+                            uint32_t const w[4] = { va.x, va.y, va.z, va.w };
+#pragma unroll
+                            for (uint32_t b = 0; b < 16; b++) { cd[b] = b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0u; myBits += cd[b] & 0xFF; }
+                        }
+                        uint32_t const incl = wave_incl_scan(myBits);
+                        uint32_t const chunkBits = __shfl(incl, 63);
+                        if (c) {
+                            RunPacker pk; pk.init(w32, bit0 + (uint64_t)(run + chunkBits - incl));
+#pragma unroll
+                            for (int b = 15; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per packer step, last -> first
+                                uint32_t const c1 = cd[b], c0v = cd[b - 1];
+                                uint32_t const n1 = c1 & 0xFF;
+                                pk.add((c1 >> 8) | ((c0v >> 8) << n1), n1 + (c0v & 0xFF));
+                            }
+                            if (ch == 0 && lane == 0) pk.add(1, 1);             // the stream's FIRST symbols come last: the end mark follows them
+                            pk.finish();
+                        }
+                        run += chunkBits;
                     }
+                    if (segLen == 0 && lane == 0) { RunPacker e; e.init(w32, bit0); e.add(1, 1); e.finish(); }      // an empty stream is its end mark
                 }
-                if (lane == 0) pk.add(1, 1);              // lane 0 holds the FIRST symbols = the end of the stream: end mark
-                pk.finish();
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < SPW; q++) {
+                    uint32_t const sI = (uint32_t)wv + q * NW;
+                    if (sI >= nStreams) continue;
+                    uint8_t* const sbase = litDst + sh->streamOff[sI];
+                    uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
+                    uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
+                    RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total[q] - incl[q]));
+                    const uint8_t* p = lits + segStart[q] + runStart[q];
+                    // the run is consumed from its end, 32 bytes per round; the first round takes the odd part
+                    uint32_t i = runLen[q];
+                    while (i) {
+                        uint32_t const c = (i & 31) ? (i & 31) : 32;
+                        i -= c;
+                        uint4 va, vb; __builtin_memcpy(&va, p + i, 16); __builtin_memcpy(&vb, p + i + 16, 16);
+                        uint32_t const w[8] = { va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w };
+                        for (int b = 31; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per packer step
+                            uint32_t const c1 = (uint32_t)b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0;
+                            uint32_t const c0 = (uint32_t)(b - 1) < c ? sh->code[(w[(b - 1) >> 2] >> (8 * ((b - 1) & 3))) & 0xFF] : 0;
+                            uint32_t const n1 = c1 & 0xFF;
+                            pk.add((c1 >> 8) | ((c0 >> 8) << n1), n1 + (c0 & 0xFF));
+                        }
+                    }
+                    if (lane == 0) pk.add(1, 1);              // lane 0 holds the FIRST symbols = the end of the stream: end mark
+                    pk.finish();
+                }
             }
             __syncthreads();
         }
