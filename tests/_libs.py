@@ -260,12 +260,12 @@ def emu_parse_units(le, src, units, seqs, lits, metas):
         le.emu_parse_dfast(_buf(src), _buf(units), nu, _buf(tabs), stride, _buf(seqs), _buf(lits), _buf(metas), 0)
 
 
-def emu_compress_units(le, lo, bufs, level, checksum=False):
+def emu_compress_units(le, lo, bufs, level, checksum=False, row=False):
     """run stage 1 + stage 2 of the product kernels on the emulator; returns list of frame bytes"""
     le.emu_entropy.restype = None
     le.emu_entropy.argtypes = [C.c_void_p] * 2 + [C.c_uint] + [C.c_void_p] * 6 + [C.c_int]
     sizes = [len(b) for b in bufs]
-    units = make_units(lo, sizes, level)
+    units = make_units(lo, sizes, level, row=row)
     src = np.concatenate(list(bufs) + [np.zeros(16, dtype=np.uint8)])
     cap = le.emu_seq_cap()
     nu = len(bufs)

@@ -2,6 +2,9 @@
 // Runs the product's kernels (zstd_amd/csrc/zhip_kernels.h, unmodified) on the host SIMT emulator so that the
 // wave-level logic can be checked against the oracle without a GPU.  Built by tests/_libs.py with g++.
 #include <hip/hip_runtime.h>
+#ifdef ZHIP_LZ_STATS
+namespace zhip { unsigned long long zhip_lz_stats[8]; }
+#endif
 #include "zhip_kernels.h"
 #include "zhip_cdict_host.h"
 #include "zhip_ddict_host.h"
@@ -86,18 +89,24 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     const char* const pe = getenv("ZHIP_RH_PREDICT"); const char* const be = getenv("ZHIP_RH_BUDGET");
     uint32_t const budget = be ? (uint32_t)atoi(be) : 256u;
     const ZhipParse* const cm = metas;
+    size_t ringStride = 0;                                       // the live rows (as in the library: on unless $ZHIP_LZ_RING=0)
+    {   const char* const re = getenv("ZHIP_LZ_RING");
+        if (!(re && atoi(re) == 0)) for (uint32_t i = 0; i < nUnits; i++) { size_t const w = zhip::rh_ring_words(units[i].hashLog, units[i].rowLog); if (w > ringStride) ringStride = w; }
+    }
+    std::vector<uint32_t> ringv(ringStride * nUnits + 1, 0xDDDDDDDDu);
+    uint32_t* const rings = ringv.data();
     if (anyRow && pe && atoi(pe) != 0) {
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 2u, budget); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 2u, budget, rings, ringStride); }, osThreads);
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 1u, 0u); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 1u, 0u, rings, ringStride); }, osThreads);
         simt::launch({nUnits, 1, 1}, {ZHIP_HC_SEARCH_LDS_THREADS, 1, 1}, ((maxLen + 15) & ~15u) + 32,
                      [=] { zhip::k_hc_search_lds(src, units, nUnits, tabs, tabStride, best, cm); }, osThreads);
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 3u, 0u); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 3u, 0u, rings, ringStride); }, osThreads);
     } else
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                 [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 0u, 0u); }, osThreads);
+                 [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 0u, 0u, rings, ringStride); }, osThreads);
 }
 uint64_t emu_hc_table_words(uint32_t hashLog) { return zhip::hc_table_words(hashLog); }
 
@@ -330,10 +339,10 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
 {
     std::vector<ZhipSlot> sv(nW ? nW : 1);
     std::vector<zhip::ZhipLzSlot> lv(nW ? nW : 1);
-    uint64_t posTotal = 0, headTotal = 0; uint32_t longest = 1;
+    uint64_t posTotal = 0, headTotal = 0, ringTotal = 0; uint32_t longest = 1;
     for (uint32_t i = 0; i < nW; i++) {
         sv[i].seqOff = (uint64_t)i * ZHIP_SEQ_CAP; sv[i].litOff = (uint64_t)i * ZHIP_LIT_STRIDE; sv[i].outOff = (uint64_t)i * outStride; sv[i].seqCap = ZHIP_SEQ_CAP; sv[i].pad0 = 0;
-        zhip::lz_fill_slot(lv[i], units[i], jobs ? jobs[i].prefixLen : 0u, posTotal, headTotal);
+        zhip::lz_fill_slot(lv[i], units[i], jobs ? jobs[i].prefixLen : 0u, posTotal, headTotal, ringTotal);
         if (units[i].srcLen > longest) longest = units[i].srcLen;
     }
     const ZhipSlot* const slots = sv.data(); const zhip::ZhipLzSlot* const lz = lv.data();
@@ -341,6 +350,9 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
     std::vector<uint16_t> stBits((size_t)nW * ZHIP_SEQ_CAP * 3);
     std::vector<uint32_t> prev(posTotal + 16, 0xDDDDDDDDu), heads(headTotal + 16, 0xDDDDDDDDu);
     std::vector<uint8_t> tags(posTotal + 16, 0xDD);
+    const char* const re = getenv("ZHIP_LZ_RING");               // the live rows (as in the library: on unless $ZHIP_LZ_RING=0)
+    std::vector<uint8_t> rings((re && atoi(re) == 0) ? 0 : ringTotal + 256, 0xDD);
+    uint8_t* const rg = rings.empty() ? (uint8_t*)nullptr : rings.data();
     std::vector<zhip::LzRec> best(posTotal + 16);
     memset(best.data(), 0xDD, best.size() * sizeof(zhip::LzRec));
     std::vector<zhip::ZhipFrameState> states(nW ? nW : 1);
@@ -360,8 +372,11 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
         }
     }
     simt::launch({nW, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lazy_lds_bytes(),
-                 [=] { zhip::k_frame_lazy(src, units, slots, jobs, lz, nW, pv, tg, bs, hd, sq, lt, sb, out, outSize, stp, checks, havePred); }, osThreads);
+                 [=] { zhip::k_frame_lazy(src, units, slots, jobs, lz, nW, pv, tg, bs, hd, rg, sq, lt, sb, out, outSize, stp, checks, havePred); }, osThreads);
 }
+#ifdef ZHIP_LZ_STATS
+void emu_lz_stats(unsigned long long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = zhip::zhip_lz_stats[i]; if (reset) zhip::zhip_lz_stats[i] = 0; } }
+#endif
 uint32_t emu_sizeof_job(void) { return (uint32_t)sizeof(zhip::ZhipJob); }
 uint32_t emu_out_stride(void) { return ZHIP_OUT_STRIDE; }
 uint32_t emu_lit_stride(void) { return ZHIP_LIT_STRIDE; }

@@ -171,6 +171,35 @@ def test_device_buffers_full_size(env):
     print(f"decode {n >> 20} MiB: {t['decode_ms']:.2f} ms = {n / t['decode_ms'] / 1e6:.1f} GB/s")
 
 
+def test_many_small_frames_every_workgroup_takes_several(env):
+    """the decode kernel's frame queue: far more frames than resident workgroups, of mixed kinds (compressed / raw / rle / empty-ish
+    tails) and sizes, so every workgroup goes round its take-a-frame loop many times and the frames finish out of order.  (Round 3's
+    stall sat in exactly this loop: the leader's queue take and the workgroup barrier after it — DESIGN.md 4.6c.)"""
+    z, lo, dctx, torch = env
+    rng = np.random.default_rng(11)
+    unit = 1024
+    n = 12_000 * unit - 333
+    parts = [text_like(n // 3, 7), datagen(lo, n // 3, 40, 9), np.zeros(40_000, np.uint8), rng.integers(0, 256, 60_000, dtype=np.uint8)]
+    src = np.concatenate(parts + [text_like(n - sum(len(p) for p in parts), 8)])
+    assert len(src) == n
+    ctx = z.Context(0, max_units=n // unit + 1)
+    for level in (1, 3):
+        frames, sizes = ctx.compress(src, level=level, unit_size=unit, return_sizes=True)
+        assert len(sizes) == n // unit + 1
+        assert dctx.decompress(frames, capacity=n) == src.tobytes(), level
+    # the same frames, device to device, in a shuffled order of destinations
+    csz = np.asarray(sizes, dtype=np.uint64)
+    so = np.concatenate([[0], np.cumsum(csz)[:-1]]).astype(np.uint64)
+    dlen = np.full(len(csz), unit, np.uint64); dlen[-1] = n - unit * (len(csz) - 1)
+    do = np.arange(len(csz), dtype=np.uint64) * unit
+    perm = rng.permutation(len(csz))
+    comp = torch.from_numpy(np.frombuffer(frames, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    r, status, dsz = dctx.decompress_frames_device(out.data_ptr(), do[perm], dlen[perm], comp.data_ptr(), so[perm], csz[perm])
+    assert r == n and not status.any() and (dsz == dlen[perm]).all()
+    assert torch.equal(out.cpu(), torch.from_numpy(src))
+
+
 def test_shim_decompress(env):
     z, lo, _, _ = env
     shim = C.CDLL(os.path.join(os.path.dirname(z.LIB_PATH), "libzstd_hipshim.so"))

@@ -79,3 +79,27 @@ def test_lazy_job_pool_frames(env, level, no_row, js, ov, ck):
         if lr is not None and not no_row:
             assert out == ref_frame_mt(lr, a, level, js, ov, ck), ("reference", level, js, ov, ck, len(a))
     assert z.DContext().decompress(outs[1]) == bufs[1].tobytes()
+
+
+def test_live_rows_switch_gives_the_same_bytes(env, monkeypatch):
+    """the row matcher's live rows (LzRing, on by default) against the walk through the links they replace ($ZHIP_LZ_RING=0, also what a context
+    falls back to when the rows' arena cannot be allocated): same bytes, and the oracle's, on long-match data — frames and a job-pool frame"""
+    z, lo = env
+    bufs = [datagen(lo, 1 << 20, 50, 5), datagen(lo, 700000, 80, 6), text_like(400000, 3)]
+    whole = np.concatenate(bufs)
+    outs = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("ZHIP_LZ_RING", ring)
+        ctx = z.Context(max_units=64)                       # the switch is read when the context is created
+        ctx.set_row_matcher(0)
+        outs[ring] = (ctx.compress_frames(bufs, 5), ctx.compress_frames([whole], 7, workers=2, job_size=1 << 20), ctx.compress_frames(bufs[:2], 5, cparams=[20, 16, 17, 6, 5, 2, 5]))
+        ctx.close()
+    assert outs["1"] == outs["0"]
+    lo.zo_set_row_matcher(1)
+    try:
+        assert outs["1"][1][0] == oracle_frame_mt(lo, whole, 7, 1 << 20, 0, 0)
+        cp = (C.c_uint * 7)(); assert lo.zo_get_cparams(5, len(bufs[0]), cp) == 0
+    finally:
+        lo.zo_set_row_matcher(0)
+    assert outs["1"][0][0] == oracle_frame_params(lo, bufs[0], cp, 1)
+    assert outs["1"][2][1] == oracle_frame_params(lo, bufs[1], (C.c_uint * 7)(20, 16, 17, 6, 5, 2, 5), 1)          # rowLog 6: 63 entries per row

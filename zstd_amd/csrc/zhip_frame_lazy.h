@@ -29,6 +29,11 @@
 //                in a dirty-key bitmap; a record within ZHIP_HC_CAP bytes of its block's end was measured against the window's
 //                end, not the block's), then the four wavefronts encode the block (zhip_entropy.h) against the previous block's
 //                Huffman and FSE tables.
+//                Row matcher: those live searches read the rows AS THE REFERENCE KEEPS THEM — per row the 2^rowLog - 1 most recently
+//                inserted positions + tags (LzRing), brought up to date by the parser, 64 positions per step, only once a position was
+//                left out (data without long matches never pays for it).  A live search is then two round trips (row, candidates' bytes)
+//                whatever the number of left-out positions; the walk through prev[] steps over every one of them — on long-match data
+//                some 250 dependent loads per search in an 8 MiB window (round 3 / 4: 0.004 GB/s on one job-pool frame).
 //   k_lz_predict (opt-in, $ZHIP_LZ_PREDICT=1) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
 //                it would leave un-inserted, k_lz_search runs again stepping over them, and the exact parse distrusts a record only where
 //                prediction and truth differ — exact on the emulator, not timed on the GPU yet.
@@ -50,6 +55,7 @@ struct ZhipLzSlot {
     uint32_t span;          // positions of the window: prefix + section
     uint32_t linkStart;     // first position that is ever inserted (a prefix longer than 8 << max(hashLog, chainLog) is only indexed at its end)
     uint32_t holeStart, holeEnd;   // positions of the prefix the reference never inserts (its last 8: zstd_compress.c:4920-4964), empty for a frame
+    uint64_t ringOff;       // row matcher: byte offset of W's live rows (lz_ring_bytes) in the ring arena
 };
 
 struct LzRec { uint32_t a, b, minCand, mode; };
@@ -58,12 +64,14 @@ struct LzRec { uint32_t a, b, minCand, mode; };
 // ZSTD_loadDictionaryContent (zstd_compress.c:4878-4965) for a job's raw-content prefix: of a prefix longer than
 // 8 << max(hashLog, chainLog) only the suffix is indexed, every position up to its end - 8 goes in, the last 8 never do
 __host__ __device__ inline uint32_t lz_key_bits(const ZhipUnit& u);
-__host__ inline void lz_fill_slot(ZhipLzSlot& L, const ZhipUnit& u, uint32_t prefixLen, uint64_t& posCursor, uint64_t& headCursor)
+__host__ __device__ inline uint64_t lz_ring_bytes(const ZhipUnit& u);
+__host__ inline void lz_fill_slot(ZhipLzSlot& L, const ZhipUnit& u, uint32_t prefixLen, uint64_t& posCursor, uint64_t& headCursor, uint64_t& ringCursor)
 {
     uint32_t const span = prefixLen + u.srcLen;
     L.span = span; L.linkStart = 0; L.holeStart = 0; L.holeEnd = 0;
     L.posOff = posCursor; posCursor += ((uint64_t)span + 16 + 15) & ~(uint64_t)15;
     L.headOff = headCursor; headCursor += (uint64_t)1 << lz_key_bits(u);
+    L.ringOff = ringCursor; ringCursor += lz_ring_bytes(u);
     if (prefixLen) {
         uint32_t const big = u.hashLog > u.chainLog ? u.hashLog : u.chainLog;
         uint64_t const maxDict = (uint64_t)8 << (big < 28 ? big : 28);
@@ -75,6 +83,13 @@ __host__ inline void lz_fill_slot(ZhipLzSlot& L, const ZhipUnit& u, uint32_t pre
       // see hc_pack in zhip_parse_lazy.h; positions and offsets need more than 17 bits here
 
 __host__ __device__ inline uint32_t lz_key_bits(const ZhipUnit& u) { return u.rowLog ? (uint32_t)u.hashLog - u.rowLog : (uint32_t)u.hashLog; }
+// the live rows of one W: a count of inserts per row (4 B), then 2^rowLog position slots (4 B) and tag slots (1 B) per row
+__host__ __device__ inline uint64_t lz_ring_bytes(const ZhipUnit& u)
+{
+    if (!u.rowLog) return 0;
+    uint64_t const rows = (uint64_t)1 << lz_key_bits(u);
+    return ((rows * 4 + (rows << u.rowLog) * 5) + 255) & ~(uint64_t)255;
+}
 __host__ __device__ inline uint32_t lz_mls(const ZhipUnit& u) { return u.minMatch < 4 ? 4u : (u.minMatch > 6 ? 6u : (uint32_t)u.minMatch); }   // zstd_lazy.c:1531
 
 // key of the 8 bytes at a position: the chain's hash, or the row index (tag = the salted hash's low 8 bits)
@@ -241,6 +256,7 @@ __device__ inline LzRec lz_search_rh(const uint8_t* __restrict__ src, uint32_t e
 }
 
 // ------------------------------------------------------------------ the parser of one block
+struct LzRing { uint32_t* cnt; uint32_t* pos; uint8_t* tag; };      // cnt[row] = inserts so far; insert i of a row sits in slot i mod (2^rowLog - 1) of pos / tag[row << rowLog | slot]
 struct LzState {
     uint32_t ntu;           // ms->nextToUpdate (hash chain: the last searched position; rows: one past it)
     uint32_t skipping;      // ms->lazySkipping
@@ -250,6 +266,11 @@ struct LzState {
     uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
     uint32_t havePred;      // exact parse: k_lz_predict ran before it (otherwise nothing is marked and there is nothing to compare)
     uint32_t nPred;         // predicting parse: positions marked so far
+    LzRing ring;            // row matcher, exact parse: the live rows (cnt == nullptr: none — live searches walk prev[])
+    uint32_t ins;           // every position below this that was inserted is in the live rows
+    uint32_t nFlagged;      // exact parse: positions left out so far (0: prev[] is the truth and nothing needs the live rows)
+    uint32_t epoch;         // exact parse: grows whenever a key is marked dirty (what a batch of records looked up about its staleness is then out of date)
+    uint32_t holeStart, holeEnd;   // a job's never-inserted prefix positions (ZhipLzSlot)
 };
 __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
 {
@@ -270,7 +291,7 @@ __device__ inline void lz_reconcile(const uint8_t* __restrict__ src, const ZhipU
         if (mism) { uint32_t tag; uint32_t const k = lz_key(ld64(src + q), u, tag); atomicOr(&st.dirty[k >> 5], 1u << (k & 31)); }
         if (__ballot(mism)) any = true;
     }
-    if (any) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; }
+    if (any) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; st.epoch++; }
     st.scanned = upTo;
 }
 // the never-inserted positions [f0, f1) (all below the window's end - 8): flagged; the keys of those that were not predicted are marked
@@ -285,6 +306,7 @@ __device__ inline void lz_flag_range(const uint8_t* __restrict__ src, const Zhip
         return;
     }
     lz_reconcile(src, u, prev, st, f0);
+    st.nFlagged += f1 - f0;
     bool any = false;
     for (uint32_t q0 = f0; q0 < f1; q0 += 64) {
         uint32_t const q = q0 + (uint32_t)lane_id();
@@ -300,6 +322,7 @@ __device__ inline void lz_flag_range(const uint8_t* __restrict__ src, const Zhip
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     if (any && f1 - 1 > st.gapEnd) st.gapEnd = f1 - 1;
+    if (any) st.epoch++;
     if (f1 > st.scanned) st.scanned = f1;
 }
 __device__ __forceinline__ bool lz_dirty(const uint8_t* __restrict__ src, const ZhipUnit& u, const LzState& st, uint32_t x)
@@ -345,6 +368,7 @@ __device__ inline void lz_live_rh(const uint8_t* __restrict__ src, uint32_t bEnd
         if (mp < lowLimit) break;
         uint32_t const w = uni(prev[mp]);
         m = ZHIP_LZ_LINK(w);
+        LZ_STAT(3, 1);
         if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
         room--;
         if (uni((uint32_t)tags[mp]) != myTag) continue;
@@ -354,6 +378,118 @@ __device__ inline void lz_live_rh(const uint8_t* __restrict__ src, uint32_t bEnd
             if (cur > ml) { ml = cur; off = x - mp; if (x + cur == bEnd) done = true; }
         }
     }
+    mlOut = ml; offOut = off;
+}
+
+// ------------------------------------------------------------------ the live rows (row matcher, exact parse)
+// What ZSTD_row_update (zstd_lazy.c:916-947) has put into the rows when the search at `upTo` starts: every position of [st.ins, upTo) that
+// was not left out (flagged in prev[]; a job's hole), in order, 64 at a time.  A row keeps its 2^rowLog - 1 latest inserts (ZSTD_row_nextIndex
+// :784-795 cycles through the slots 1 .. rowMask; slot 0 of the reference's tag row is the head), so insert i of a row goes to slot
+// i mod (2^rowLog - 1): lanes of one row are ranked with ballots, the first reads the row's count, the last writes it back.
+__device__ inline void lz_ring_catchup(const uint8_t* __restrict__ src, const ZhipUnit& u, const uint32_t* prev, LzState& st, uint32_t upTo)
+{
+    if (upTo <= st.ins) return;
+    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, keyBits = lz_key_bits(u);
+    uint32_t qcN = st.ins + lane < upTo ? st.ins + lane : upTo - 1;
+    uint32_t wN = prev[qcN]; uint64_t bN = ld64(src + qcN);                     // the next step's loads are in flight while this step's count makes its round trip
+    for (uint32_t q0 = st.ins; q0 < upTo; q0 += 64) {
+        uint32_t const q = q0 + lane, w = wN; uint64_t const bytes = bN;
+        if (q0 + 64 < upTo) { qcN = q + 64 < upTo ? q + 64 : upTo - 1; wN = prev[qcN]; bN = ld64(src + qcN); }
+        bool const in = q < upTo && !(w & ZHIP_HC_SKIPPED) && !(q >= st.holeStart && q < st.holeEnd);
+        unsigned long long const inM = __ballot(in);
+        LZ_STAT(4, 1);
+        if (!inM) { LZ_STAT(5, 1); continue; }
+        uint32_t tag; uint32_t const k = lz_key(bytes, u, tag);
+        unsigned long long const same = wave_hash_group(k, keyBits) & inM;           // the step's inserted positions of my row
+        uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
+        uint32_t c = (in && rank == 0) ? st.ring.cnt[k] : 0u;
+        c = __shfl(c, same ? first_lane(same) : 0);
+        if (in) {
+            if (rank + 1 == total) st.ring.cnt[k] = c + total;
+            if (rank + usable >= total) {                                        // of more than a row's worth in one step only the latest stay
+                size_t const at = ((size_t)k << rowLog) + (c + rank) % usable;
+                st.ring.pos[at] = q; st.ring.tag[at] = (uint8_t)tag;
+            }
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+    st.ins = upTo;
+}
+// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340) at x from the live rows: the row's entries most recent first (ZSTD_row_getMatchMask rotates by the
+// head), those at or above lowLimit with x's tag, at most 2^min(searchLog, rowLog) of them; the longest wins, the earlier of equals (:1287
+// `currentMl > ml`), a match that reaches the block's end ends the search.  Lane r holds the r-th most recent entry; every candidate lane
+// measures its own match up to ZHIP_HC_CAP bytes, longer ones are measured wave-wide.  All results uniform.
+// The last (<= 63) positions that are still to be inserted travel with the search — three dependent round trips in all: (1) their link words
+// and bytes + x's bytes, (2) the counts of their rows + the count and every slot of x's row, as it was BEFORE them, (3) the candidates'
+// bytes.  Those of them that fall into x's own row are its most recent entries: they go in front of what the slots held.
+__device__ inline void lz_live_ring(const uint8_t* __restrict__ src, uint32_t bEnd, uint32_t x, const ZhipUnit& u, const uint32_t* prev, LzState& st, uint32_t lowLimit,
+                                    uint32_t& mlOut, uint32_t& offOut)
+{
+    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, nm8 = bEnd - 8, keyBits = lz_key_bits(u);
+    uint32_t const capped = u.searchLog < rowLog ? u.searchLog : rowLog, attempts = 1u << capped;
+    LzRing const R = st.ring;
+    if (x - st.ins > 63) lz_ring_catchup(src, u, prev, st, x - 63);
+    uint32_t const ins0 = st.ins, nPend = x - ins0;                             // lanes below nPend: a position to insert; the others (lane 63 always) look at x
+    uint32_t const q = lane < nPend ? ins0 + lane : x;
+    uint32_t const w = prev[q];
+    uint32_t tagq; uint32_t const kq = lz_key(ld64(src + q), u, tagq);
+    bool const in = lane < nPend && !(w & ZHIP_HC_SKIPPED) && !(q >= st.holeStart && q < st.holeEnd);
+    uint32_t const kx = (uint32_t)__builtin_amdgcn_readlane(kq, 63), tag = (uint32_t)__builtin_amdgcn_readlane(tagq, 63);
+    unsigned long long const inM = __ballot(in);
+    unsigned long long const same = wave_hash_group(kq, keyBits) & inM;
+    uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
+    // round trip 2
+    uint32_t cIns = (in && rank == 0) ? R.cnt[kq] : 0u;
+    size_t const at = ((size_t)kx << rowLog) + (lane < usable ? lane : 0u);
+    uint32_t const cw = R.cnt[kx], sp = R.pos[at], stg = R.tag[at];
+    uint32_t const c = uni(cw), nOld = c < usable ? c : usable;
+    cIns = __shfl(cIns, same ? first_lane(same) : 0);
+    __threadfence_block();                                                      // the row of x HAS been read (the loads are complete): now the inserts may land in it
+    __builtin_amdgcn_wave_barrier();
+    if (in) {
+        if (rank + 1 == total) R.cnt[kq] = cIns + total;
+        if (rank + usable >= total) {
+            size_t const ia = ((size_t)kq << rowLog) + (cIns + rank) % usable;
+            R.pos[ia] = q; R.tag[ia] = (uint8_t)tagq;
+        }
+    }
+    st.ins = x;
+    // the candidates, most recent first: x's row among the pending positions (the higher the later), then the slots
+    unsigned long long P = __ballot(in && kq == kx);
+    uint32_t const nP = (uint32_t)__popcll(P);
+    uint32_t const rr = lane - nP;
+    bool have = lane >= nP && rr < nOld && lane < usable;
+    uint32_t const from = have ? (c - 1u - rr) % usable : 0u;                   // the r-th most recent insert of the row is its number c - 1 - r
+    uint32_t mp = __shfl(sp, (int)from), tg = __shfl(stg, (int)from);
+    for (uint32_t i = 0; P != 0 && i < usable; i++) {
+        int const l = 63 - __clzll((long long)P);
+        P &= ~(1ull << l);
+        uint32_t const tl = (uint32_t)__builtin_amdgcn_readlane(tagq, l);
+        if (lane == i) { mp = ins0 + (uint32_t)l; tg = tl; have = true; }
+    }
+    bool cand = have && mp >= lowLimit && tg == tag;
+    unsigned long long const cm = __ballot(cand);
+    cand = cand && (uint32_t)__popcll(cm & below_mask((int)lane)) < attempts;
+    uint32_t cur = 0;
+    if (cand) {
+        for (;;) {
+            uint32_t const sameB = lane_same_fwd(src, x + cur, x - mp, nm8);
+            cur += sameB;
+            if (sameB < 8 || cur >= ZHIP_HC_CAP) break;
+        }
+    }
+    unsigned long long rest = __ballot(cand);
+    uint32_t ml = 3, off = 0;
+    while (rest) {
+        int const l = first_lane(rest);
+        rest &= rest - 1;
+        uint32_t len = (uint32_t)__builtin_amdgcn_readlane(cur, l);
+        uint32_t const mpl = (uint32_t)__builtin_amdgcn_readlane(mp, l);
+        if (len >= ZHIP_HC_CAP) len = uni(wave_count_fwd(src, x, mpl, nm8));
+        if (len > ml) { ml = len; off = x - mpl; if (x + len == bEnd) break; }
+    }
+    __threadfence_block();
     mlOut = ml; offOut = off;
 }
 
@@ -379,11 +515,16 @@ __device__ inline void lz_search(const LzBlock& B, const ZhipUnit& u, LzState& s
     }
     lz_reconcile(B.src, u, B.prev, st, x);               // everything below x is decided now: was it what the predicting parse expected?
     uint32_t off;
+    if (!st.predict) LZ_STAT(0, 1);
     bool live = rec.mode == 3 || x + ZHIP_HC_CAP > B.bEnd;
     if (!live && st.gapEnd != 0 && rec.minCand != ZHIP_LZ_NONE && rec.minCand <= st.gapEnd) live = lz_dirty(B.src, u, st, x);
     if (live) {
         uint32_t const lowLimit = lz_low_limit(B, x);
-        if (u.rowLog) lz_live_rh(B.src, B.bEnd, x, B.prev, B.tags, u.searchLog, u.rowLog, lowLimit, ml, off);
+        if (u.rowLog && st.ring.cnt && st.nFlagged && !st.predict) {
+            LZ_STAT(1, 1);
+            lz_live_ring(B.src, B.bEnd, x, u, B.prev, st, lowLimit, ml, off);
+        }
+        else if (u.rowLog) { if (!st.predict) LZ_STAT(2, 1); lz_live_rh(B.src, B.bEnd, x, B.prev, B.tags, u.searchLog, u.rowLog, lowLimit, ml, off); }
         else lz_live_hc(B.src, B.bEnd, x, B.prev, u.searchLog, u.chainLog, lowLimit, ml, off);
     }
     else if (rec.mode == 0) { ml = rec.b; off = rec.a; }
@@ -431,6 +572,7 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
             LzRec recj; recj.a = 0; recj.b = 0; recj.minCand = ZHIP_LZ_NONE; recj.mode = 0;
             bool repj = false;
             bool repHit; LzRec rec;
+            unsigned long long ev = 0;
             if (step <= 8) {
                 if (u.rowLog) lz_gap_rule(B, u, st, ip);                     // the batch's first search (not lazy-skipping) meets the gap since nextToUpdate
                 uint32_t const xj = ip + lane * step;
@@ -448,23 +590,58 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
                 bool const needLive = valid && (recj.mode == 3 || stale);
                 bool const found = valid && (recj.mode != 0 || recj.b >= 4);
                 K = (uint32_t)__popcll(__ballot(valid));
-                unsigned long long const ev = __ballot(repj || needLive || found);
+                ev = __ballot(repj || needLive || found);
                 if (!ev) {                                                   // K failed searches (:1613-1624), lazySkipping = 0
                     st.ntu = ip + (K - 1) * step + rowBias; st.skipping = 0;
                     ip = ip + K * step;
                     continue;
                 }
-                int const e = first_lane(ev);
-                x = ip + (uint32_t)e * step;
-                if (e > 0) { st.ntu = x - step + rowBias; st.skipping = 0; }
-                repHit = (__ballot(repj) >> e) & 1;
-                rec = lz_rec_lane(recj, e);
-            } else {
-                x = ip;
-                LzRec const r0 = B.best[x];
-                rec = lz_rec_lane(r0, 0);
-                repHit = off1 > 0 && uni(ld32(src + x + 1)) == uni(ld32(src + (x + 1 - off1)));
             }
+            uint32_t const epoch1 = st.epoch;                               // what the batch found out about its records' staleness holds while this does not move
+            uint32_t matchLength = 0, start = 0, offBase = 1;
+            bool direct = false, failed = false;
+            // the events of the batch in order: a search that fails (no match, no repcode) moves on to the batch's next event without
+            // loading the batch again — on long-match data without the prediction nearly every search is such a live search that fails
+            for (;;) {
+                int e = 0;
+                if (step <= 8) {
+                    e = first_lane(ev);
+                    x = ip0 + (uint32_t)e * step;
+                    if (e > 0) { st.ntu = x - step + rowBias; st.skipping = 0; }
+                    repHit = (__ballot(repj) >> e) & 1;
+                    rec = lz_rec_lane(recj, e);
+                } else {
+                    x = ip;
+                    LzRec const r0 = B.best[x];
+                    rec = lz_rec_lane(r0, 0);
+                    repHit = off1 > 0 && uni(ld32(src + x + 1)) == uni(ld32(src + (x + 1 - off1)));
+                }
+                matchLength = 0; start = x + 1; offBase = 1; direct = false;
+                if (repHit) {                                                // :1600-1604
+                    matchLength = 4 + (wave_count_fwd(src, x + 5, x + 5 - off1, nm8));
+                    if (depth == 0) direct = true;
+                }
+                ip = x;
+                if (direct) break;
+                {   uint32_t ml2, ob2;                                       // :1607-1611
+                    lz_search(B, u, st, x, rec, ml2, ob2);
+                    if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
+                }
+                if (matchLength >= 4) break;
+                failed = true;                                               // :1613-1625
+                if (step <= 8 && st.epoch == epoch1) {
+                    ev &= ~below_mask(e + 1);
+                    if (ev) { failed = false; continue; }
+                    st.ntu = ip0 + (K - 1) * step + rowBias; st.skipping = 0;   // the batch's remaining searches fail from their records
+                    ip = ip0 + K * step;
+                    break;
+                }
+                uint32_t const stp = ((x - anchor) >> 8) + 1;
+                ip = x + stp;
+                st.skipping = stp > 8;                                       // kLazySkippingStep = 8
+                break;
+            }
+            if (failed) continue;
             bool const window = step == 1;
             auto rec_at = [&](uint32_t q) -> LzRec {
                 if (window && q - ip0 < K) return lz_rec_lane(recj, (int)(q - ip0));
@@ -475,25 +652,7 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
                 if (window && q - 1 - ip0 < K) return (__ballot(repj) >> (q - 1 - ip0)) & 1;
                 return uni(ld32(src + q)) == uni(ld32(src + (q - off1)));
             };
-
-            uint32_t matchLength = 0, start = x + 1, offBase = 1;
-            bool direct = false;
-            if (repHit) {                                                    // :1600-1604
-                matchLength = 4 + (wave_count_fwd(src, x + 5, x + 5 - off1, nm8));
-                if (depth == 0) direct = true;
-            }
-            ip = x;
             if (!direct) {
-                {   uint32_t ml2, ob2;                                       // :1607-1611
-                    lz_search(B, u, st, x, rec, ml2, ob2);
-                    if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
-                }
-                if (matchLength < 4) {                                       // :1613-1625
-                    uint32_t const stp = ((x - anchor) >> 8) + 1;
-                    ip = x + stp;
-                    st.skipping = stp > 8;                                   // kLazySkippingStep = 8
-                    continue;
-                }
                 if (depth >= 1) {
                     while (ip < ilimit) {                                    // :1628-1700
                         ip++;
@@ -645,6 +804,7 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
     uint32_t const j0 = job ? job->prefixLen : 0u, jEnd = j0 + u.srcLen, maxDist = 1u << u.windowLog;
     uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u, low = 0;
     LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
+    ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = 0; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = 0; ls.holeEnd = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {
         uint32_t const bLen = jEnd - pos < ZHIP_UNIT_MAX ? jEnd - pos : ZHIP_UNIT_MAX;
         if (bLen >= 7) {
@@ -662,7 +822,7 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
 
 // job == nullptr: the whole input src[0, u.srcLen) as one frame; else one job of a frame, src = the start of the job's window
 __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit& u, const ZhipLzSlot& L, uint32_t* prev, const uint8_t* tags, const LzRec* best,
-                                  uint32_t* dirty, ZhipSeq* seqs, uint8_t* lits, uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
+                                  uint32_t* dirty, uint8_t* ring /* lz_ring_bytes(u), or nullptr */, ZhipSeq* seqs, uint8_t* lits, uint16_t* stBits, uint32_t seqCap, uint8_t* __restrict__ out, uint32_t* outSize,
                                   EntShared* sh, LzFrameShared* fs, ZhipFrameState* st, bool withChecksum, uint32_t checksum, const ZhipJob* __restrict__ job, bool havePred)
 {
     int const t = (int)threadIdx.x, wv = t >> 6;
@@ -689,6 +849,12 @@ __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUni
     uint32_t pos = j0, low = 0;
     uint32_t const maxDist = 1u << u.windowLog;
     LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = havePred ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
+    ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = L.linkStart; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = L.holeStart; ls.holeEnd = L.holeEnd;
+    if (ring && u.rowLog) {                                                  // fresh rows: every count 0 (the slots are only read below a count)
+        uint32_t const rows = 1u << lz_key_bits(u);
+        ls.ring.cnt = (uint32_t*)ring; ls.ring.pos = ls.ring.cnt + rows; ls.ring.tag = (uint8_t*)(ls.ring.pos + ((size_t)rows << u.rowLog));
+        for (uint32_t i = (uint32_t)t; i < rows; i += ZHIP_ENT_THREADS) ls.ring.cnt[i] = 0;
+    }
     __threadfence_block();
     __syncthreads();
     while (pos < jEnd) {

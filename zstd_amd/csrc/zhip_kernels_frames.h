@@ -136,7 +136,7 @@ k_lz_predict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)
 k_frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, const ZhipJob* __restrict__ jobs,
              const ZhipLzSlot* __restrict__ lz, uint32_t nW, uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, const LzRec* __restrict__ best,
-             uint32_t* __restrict__ heads, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
+             uint32_t* __restrict__ heads, uint8_t* __restrict__ rings /* the live rows' arena, or nullptr */, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, uint16_t* __restrict__ stBits,
              uint8_t* __restrict__ out, uint32_t* __restrict__ outSize, ZhipFrameState* __restrict__ states, const uint32_t* __restrict__ checks,
              uint32_t havePred /* k_lz_predict ran before: compare what the parse decides with what it marked */)
 {
@@ -151,7 +151,7 @@ k_frame_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     LzFrameShared* const fs = (LzFrameShared*)(smem + ((sizeof(EntShared) + 15) & ~(size_t)15));
     const ZhipJob* const job = jobs ? jobs + wi : (const ZhipJob*)nullptr;
     bool const ck = checks != nullptr; uint32_t const cv = ck ? checks[jobs ? jobs[wi].frameIdx : wi] : 0u;
-    frame_lazy(lz_window(src, u, jobs, wi), u, L, prev + L.posOff, tags + L.posOff, best + L.posOff, heads + L.headOff,
+    frame_lazy(lz_window(src, u, jobs, wi), u, L, prev + L.posOff, tags + L.posOff, best + L.posOff, heads + L.headOff, rings ? rings + L.ringOff : (uint8_t*)nullptr,
                seqs + sl.seqOff, lits + sl.litOff, stBits + 3 * sl.seqOff, sl.seqCap, out + sl.outOff, outSize + wi, sh, fs, states + wi, ck, cv, job, havePred != 0);
 }
 

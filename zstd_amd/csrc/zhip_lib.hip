@@ -85,7 +85,9 @@ struct zhip_ctx_s {
     std::vector<zhip::ZhipJob> hJobs; std::vector<ZhipUnit> hFrameUnits; std::vector<uint32_t> hFrameSizes;
     // ... of the lazy strategies (zhip_frame_lazy.h): links, tags, records per position of every window; head tables; grown on demand
     uint32_t* dLzPrev = nullptr; uint8_t* dLzTags = nullptr; zhip::LzRec* dLzBest = nullptr; uint32_t* dLzHeads = nullptr; zhip::ZhipLzSlot* dLzSlots = nullptr;
-    size_t lzPosCap = 0, lzHeadCap = 0, lzSlotCap = 0;
+    size_t lzPosCap = 0, lzHeadCap = 0, lzSlotCap = 0, lzRingCap = 0;
+    uint32_t* dRhRing = nullptr; size_t rhRingCap = 0, rhRingStride = 0;    // the same for units (zhip_parse_lazy.h: rh_live_ring), one set of rows per unit of a chunk
+    uint8_t* dLzRing = nullptr; uint64_t lzRing = 0; int lzRingOn = 1;      // the row matcher's live rows (zhip_frame_lazy.h: LzRing); $ZHIP_LZ_RING=0: live searches walk the links
     std::vector<zhip::ZhipLzSlot> hLz; bool lzAny = false, lzAll = false; uint64_t lzPos = 0, lzHeads = 0; uint32_t lzLongest = 0;
     // staging for the host-buffer API
     uint8_t* dSrcStage; size_t srcStageCap;
@@ -171,7 +173,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
-    (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots);
+    (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots); (void)hipFree(c->dLzRing); (void)hipFree(c->dRhRing);
     (void)hipFree(c->dQueue); (void)hipFree(c->dOrder); (void)hipFree(c->dCost); (void)hipFree(c->dGTabs);
     if (c->coStream) (void)hipStreamDestroy(c->coStream);
     for (int i = 0; i < 2; i++) if (c->coEv[i]) (void)hipEventDestroy(c->coEv[i]);
@@ -199,7 +201,8 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
-    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 1; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
+    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 1; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0;
+        e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -357,7 +360,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
-    uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
+    uint32_t mh = 0; size_t tabWords = 0, ringWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -386,7 +389,8 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
-        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
+        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog;
+            size_t const rw = zhip::rh_ring_words(cp->hashLog, u.rowLog); if (rw > ringWords) ringWords = rw; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
     }
     if (mh > 15) {      // the unit kernel's LDS table ends at 2^15 entries: the caller sends such units through the frame kernel, whose table policy reaches HBM
@@ -409,6 +413,15 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         (void)hipFree(c->dBest); c->dBest = nullptr; c->bestCap = 0;
         if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
         c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
+    }
+    c->rhRingStride = 0;
+    if ((fam & 4) && ringWords && c->lzRingOn) {     // the row matcher's live rows (zhip_parse_lazy.h: rh_live_ring), one set per unit of a chunk; without room for them the parser walks the links
+        size_t const need = c->hcChunk * ringWords;
+        if (c->rhRingCap < need) {
+            (void)hipFree(c->dRhRing); c->dRhRing = nullptr; c->rhRingCap = 0;
+            if (hipMalloc((void**)&c->dRhRing, need * sizeof(uint32_t)) == hipSuccess) c->rhRingCap = need; else (void)hipGetLastError();
+        }
+        if (c->rhRingCap >= need) c->rhRingStride = ringWords;
     }
     if ((fam & 2) && (fam & 4)) {                  // a mixed batch: room for the dfast workgroups' pairs as well
         if (c->tabsCap < dfPairs * c->tabStride) {
@@ -549,17 +562,17 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 if (predictOn && anyRow && budget > 0) {
                     size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 2u, (uint32_t)budget);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 2u, (uint32_t)budget, c->dRhRing, c->rhRingStride);
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 1u, 0u);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 1u, 0u, c->dRhRing, c->rhRingStride);
                     hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
                                        srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)(c->dParse + u0));
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 3u, 0u);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 3u, 0u, c->dRhRing, c->rhRingStride);
                 } else
                 hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
                                    srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
-                                   c->dSeqs, c->dLits, c->dParse + u0, 0u, 0u);
+                                   c->dSeqs, c->dLits, c->dParse + u0, 0u, 0u, c->dRhRing, c->rhRingStride);
             }
             HIPCHK(c, hipEventRecord(he[3], s));
         }
@@ -781,7 +794,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
     size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsTab = 0; unsigned long long totalSrc = 0;
     if (mt.on) { c->hJobs.clear(); c->hFrameUnits.resize(nFrames); }
     bool lzAny = false, lzAll = true;
-    c->hLz.clear(); c->lzPos = 0; c->lzHeads = 0; c->lzLongest = 1;
+    c->hLz.clear(); c->lzPos = 0; c->lzHeads = 0; c->lzRing = 0; c->lzLongest = 1;
     for (size_t i = 0; i < nFrames; i++) {
         if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] >= (1ull << 31)) { snprintf(c->err, sizeof(c->err), "frame %zu: inputs of 2 GiB and more are not implemented on device", i); return ZERR(ZE_srcSize_wrong); }
         size_t const n = (size_t)(offs[i + 1] - offs[i]);
@@ -819,7 +832,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
                 size_t const pre = (mt.on && k) ? (prevLen < overlap ? prevLen : overlap) : 0;
                 if (lazy && pre + len >= ((size_t)1 << 30)) {             // a link is 30 bits + two flags (zhip_frame_lazy.h: ZHIP_LZ_LINK)
                     snprintf(c->err, sizeof(c->err), "frame %zu: a window of 1 GiB and more with a lazy strategy is not implemented on device (use ZSTD_c_nbWorkers: jobs)", i); return ZERR(ZE_srcSize_wrong); }
-                if (lazy) { zhip::lz_fill_slot(L, u, (uint32_t)pre, c->lzPos, c->lzHeads); if (len > c->lzLongest) c->lzLongest = (uint32_t)len; }
+                if (lazy) { zhip::lz_fill_slot(L, u, (uint32_t)pre, c->lzPos, c->lzHeads, c->lzRing); if (len > c->lzLongest) c->lzLongest = (uint32_t)len; }
                 c->hLz.push_back(L);
             }
             if (mt.on) {
@@ -898,6 +911,11 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
             if (hipMalloc((void**)&c->dLzHeads, needHeads * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
             c->lzHeadCap = needHeads;
         }
+        if (c->lzRingOn && c->lzRing && c->lzRingCap < (size_t)c->lzRing + 256) {
+            (void)hipFree(c->dLzRing); c->dLzRing = nullptr; c->lzRingCap = 0;
+            if (hipMalloc((void**)&c->dLzRing, (size_t)c->lzRing + 256) == hipSuccess) c->lzRingCap = (size_t)c->lzRing + 256;
+            else (void)hipGetLastError();                         // no room for the live rows: the parser walks the links instead (same bytes, slower on long matches)
+        }
         if (c->lzSlotCap < nU) {
             (void)hipFree(c->dLzSlots); c->dLzSlots = nullptr; c->lzSlotCap = 0;
             if (hipMalloc((void**)&c->dLzSlots, nU * sizeof(zhip::ZhipLzSlot)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
@@ -940,7 +958,7 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
         }
         hipLaunchKernelGGL(zhip::k_frame_lazy, dim3((unsigned)nU), dim3(ZHIP_ENT_THREADS), zhip::frame_lazy_lds_bytes(), s,
                            (const uint8_t*)srcDev, c->dUnits, c->dSlots, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dLzHeads,
-                           c->dSeqs, c->dLits, c->dStBits, c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, (uint32_t)(c->lzPredict != 0));
+                           (c->lzRingOn && c->lzRingCap >= (size_t)c->lzRing + 256) ? c->dLzRing : (uint8_t*)nullptr, c->dSeqs, c->dLits, c->dStBits, c->dFrameOut, c->dOutSize, c->dFrameState, c->checksum ? c->dChecks : (const uint32_t*)nullptr, (uint32_t)(c->lzPredict != 0));
         HIPCHK(c, hipGetLastError());
     }
     if (c->lzAll) { }

@@ -36,6 +36,12 @@
 namespace zhip {
 
 #ifndef ZHIP_HC_CAP
+#ifdef ZHIP_LZ_STATS        /* emulator builds of tests/tools only: how the searches of the exact parse were served (units: zhip_parse_lazy.h, frames: zhip_frame_lazy.h) */
+extern unsigned long long zhip_lz_stats[8];   /* 0 searches, 1 live from the rows, 2 live by walking links, 3 links followed, 4 catch-up steps, 5 of them without an insert */
+#define LZ_STAT(i, n) do { if (lane_id() == 0) zhip_lz_stats[i] += (n); } while (0)
+#else
+#define LZ_STAT(i, n) do { } while (0)
+#endif
 #define ZHIP_HC_CAP 32u
 #endif
 #define ZHIP_HC_NONE     0x1FFFFu            /* "no candidate" in the minCand field */
@@ -388,7 +394,15 @@ struct HcState {
     uint32_t nLive;         // searches redone live (statistics: ZhipParse.pad0)
     uint32_t budget;        // TRY parse: give up (the unit is parsed again with the prediction) once this many searches went live; 0 = never
     uint32_t abort;
+    uint32_t* ringCnt;      // row matcher, exact parse: the live rows (RhRing below; nullptr: none — live searches walk prev[])
+    uint32_t* ringEnt;
+    uint32_t ins;           // every position below this that was inserted is in the live rows
+    uint32_t nFlagged;      // positions left out so far (0: prev[] is the truth, nothing needs the live rows)
+    uint32_t epoch;         // grows whenever a row is marked dirty (what a batch of records looked up about its staleness is then out of date)
+    uint32_t ringReady;     // the counts have been zeroed (done at the first use: data without long matches never touches the rows)
 };
+// the live rows of one unit: rows counts of inserts (4 B each), then 2^rowLog slots per row: position | tag << 17
+__host__ __device__ inline size_t rh_ring_words(uint32_t hashLog, uint32_t rowLog) { return rowLog ? ((size_t)1 << (hashLog - rowLog)) + ((size_t)1 << hashLog) : 0; }
 #define ZHIP_PARSE_REDO 0x5245444Fu          /* ZhipParse.status of a unit whose TRY parse gave up */
 #define ZHIP_RH_DIRTY_BYTES 2048u      /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
 
@@ -417,7 +431,7 @@ __device__ inline void rh_reconcile_t(const uint8_t* __restrict__ src, uint32_t 
         }
         if (__ballot(mism)) any = true;
     }
-    if (any) { __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; }
+    if (any) { __builtin_amdgcn_wave_barrier(); if (upTo - 1 > st.gapEnd) st.gapEnd = upTo - 1; st.epoch++; }
     st.scanned = upTo;
 }
 __device__ inline void rh_reconcile(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
@@ -441,6 +455,7 @@ __device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t
         __builtin_amdgcn_wave_barrier();
         return;
     }
+    st.nFlagged += f1 - f0;
     bool any = false;
     for (uint32_t q0 = f0; q0 < f1; q0 += 64) {
         uint32_t const q = q0 + (uint32_t)lane_id();
@@ -461,6 +476,7 @@ __device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     if (any && f1 - 1 > st.gapEnd) st.gapEnd = f1 - 1;
+    if (any) st.epoch++;
     if (f1 > st.scanned) st.scanned = f1;
 }
 __device__ inline void rh_flag_range(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t f0, uint32_t f1)
@@ -564,6 +580,7 @@ __device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t 
         uint32_t const mp = m - 1;
         uint32_t const w = uni(prev[mp]);
         m = w & ZHIP_RH_LINK_MASK;
+        LZ_STAT(3, 1);
         if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
         room--;
         if (((w >> 18) & 0xFFu) != myTag) continue;
@@ -573,6 +590,121 @@ __device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t 
             if (cur > ml) { ml = cur; off = x - mp; if (x + cur == n) done = true; }
         }
     }
+    mlOut = ml; offOut = off;
+}
+
+// ------------------------------------------------------------------ the live rows (row matcher, exact parse) — the unit form of zhip_frame_lazy.h's LzRing
+// row and tag of position q (q <= n - 8)
+__device__ __forceinline__ uint32_t rh_key(const uint8_t* __restrict__ src, uint32_t q, const ZhipUnit& u, uint32_t& tag)
+{
+    uint32_t const hBits = (uint32_t)u.hashLog - u.rowLog + 8, mls = u.minMatch < 4 ? 4u : (u.minMatch > 6 ? 6u : (uint32_t)u.minMatch);
+    uint64_t const salt = rh_fresh_salt();
+    uint64_t const bytes = mls == 4 ? (uint64_t)ld32(src + q) : ld64(src + q);
+    uint32_t const h = mls == 4 ? hash_pos_salted<4>(bytes, hBits, salt) : (mls == 5 ? hash_pos_salted<5>(bytes, hBits, salt) : hash_pos_salted<6>(bytes, hBits, salt));
+    tag = h & 0xFFu;
+    return h >> 8;
+}
+// What ZSTD_row_update (zstd_lazy.c:916-947) has put into the rows when the search at `upTo` starts: every position of [st.ins, upTo) that was not
+// left out (flagged in prev[]), in order, 64 per step.  A row keeps its 2^rowLog - 1 latest inserts (ZSTD_row_nextIndex :784-795 cycles through
+// the slots 1 .. rowMask), so insert i of a row goes to slot i mod (2^rowLog - 1); the lanes of one row are ranked with ballots, the first
+// reads the row's count, the last writes it back.  The next step's loads are in flight while the counts make their round trip.
+__device__ inline void rh_ring_catchup(const uint8_t* __restrict__ src, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
+{
+    if (upTo <= st.ins) return;
+    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, keyBits = (uint32_t)u.hashLog - rowLog;
+    uint32_t qcN = st.ins + lane < upTo ? st.ins + lane : upTo - 1;
+    uint32_t wN = prev[qcN], tN, kN = rh_key(src, qcN, u, tN);
+    for (uint32_t q0 = st.ins; q0 < upTo; q0 += 64) {
+        uint32_t const q = q0 + lane, w = wN, k = kN, tag = tN;
+        if (q0 + 64 < upTo) { qcN = q + 64 < upTo ? q + 64 : upTo - 1; wN = prev[qcN]; kN = rh_key(src, qcN, u, tN); }
+        bool const in = q < upTo && !(w & ZHIP_HC_SKIPPED);
+        unsigned long long const inM = __ballot(in);
+        LZ_STAT(4, 1);
+        if (!inM) { LZ_STAT(5, 1); continue; }
+        unsigned long long const same = wave_hash_group(k, keyBits) & inM;
+        uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
+        uint32_t c = (in && rank == 0) ? st.ringCnt[k] : 0u;
+        c = __shfl(c, same ? first_lane(same) : 0);
+        if (in) {
+            if (rank + 1 == total) st.ringCnt[k] = c + total;
+            if (rank + usable >= total) st.ringEnt[((size_t)k << rowLog) + (c + rank) % usable] = q | (tag << 17);
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+    st.ins = upTo;
+}
+// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340) at x from the live rows — see lz_live_ring (zhip_frame_lazy.h) for the scheme: three dependent round
+// trips (the last <= 63 pending positions' link words and bytes + x's bytes; their rows' counts + the count and slots of x's row as it was before
+// them; the candidates' bytes) instead of a walk of up to 2^rowLog - 1 links plus every left-out position between them.  All results uniform.
+__device__ inline void rh_live_ring(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const ZhipUnit& u, const uint32_t* prev, HcState& st,
+                                    uint32_t& mlOut, uint32_t& offOut)
+{
+    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, nm8 = n - 8, keyBits = (uint32_t)u.hashLog - rowLog;
+    uint32_t const capped = u.searchLog < rowLog ? u.searchLog : rowLog, attempts = 1u << capped;
+    if (!st.ringReady) {
+        for (uint32_t i = lane; i < (1u << keyBits); i += 64) st.ringCnt[i] = 0;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        st.ringReady = 1;
+    }
+    if (x - st.ins > 63) rh_ring_catchup(src, u, prev, st, x - 63);
+    uint32_t const ins0 = st.ins, nPend = x - ins0;                             // lanes below nPend: a position to insert; the others (lane 63 always) look at x
+    uint32_t const q = lane < nPend ? ins0 + lane : x;
+    uint32_t const w = prev[q];
+    uint32_t tagq; uint32_t const kq = rh_key(src, q, u, tagq);
+    bool const in = lane < nPend && !(w & ZHIP_HC_SKIPPED);
+    uint32_t const kx = (uint32_t)__builtin_amdgcn_readlane(kq, 63), tag = (uint32_t)__builtin_amdgcn_readlane(tagq, 63);
+    unsigned long long const inM = __ballot(in);
+    unsigned long long const same = wave_hash_group(kq, keyBits) & inM;
+    uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
+    uint32_t cIns = (in && rank == 0) ? st.ringCnt[kq] : 0u;
+    uint32_t const cw = st.ringCnt[kx], se = st.ringEnt[((size_t)kx << rowLog) + (lane < usable ? lane : 0u)];
+    uint32_t const c = uni(cw), nOld = c < usable ? c : usable;
+    cIns = __shfl(cIns, same ? first_lane(same) : 0);
+    __threadfence_block();                                                      // the row of x HAS been read: now the inserts may land in it
+    __builtin_amdgcn_wave_barrier();
+    if (in) {
+        if (rank + 1 == total) st.ringCnt[kq] = cIns + total;
+        if (rank + usable >= total) st.ringEnt[((size_t)kq << rowLog) + (cIns + rank) % usable] = q | (tagq << 17);
+    }
+    st.ins = x;
+    // the candidates, most recent first: x's row among the pending positions (the higher the later), then the slots
+    unsigned long long P = __ballot(in && kq == kx);
+    uint32_t const nP = (uint32_t)__popcll(P);
+    uint32_t const rr = lane - nP;
+    bool have = lane >= nP && rr < nOld && lane < usable;
+    uint32_t const from = have ? (c - 1u - rr) % usable : 0u;                   // the r-th most recent insert of the row is its number c - 1 - r
+    uint32_t const e = __shfl(se, (int)from);
+    uint32_t mp = e & 0x1FFFFu, tg = e >> 17;
+    for (uint32_t i = 0; P != 0 && i < usable; i++) {
+        int const l = 63 - __clzll((long long)P);
+        P &= ~(1ull << l);
+        uint32_t const tl = (uint32_t)__builtin_amdgcn_readlane(tagq, l);
+        if (lane == i) { mp = ins0 + (uint32_t)l; tg = tl; have = true; }
+    }
+    bool cand = have && tg == tag;
+    unsigned long long const cm = __ballot(cand);
+    cand = cand && (uint32_t)__popcll(cm & below_mask((int)lane)) < attempts;
+    uint32_t cur = 0;
+    if (cand) {
+        for (;;) {
+            uint32_t const sameB = lane_same_fwd(src, x + cur, x - mp, nm8);
+            cur += sameB;
+            if (sameB < 8 || cur >= ZHIP_HC_CAP) break;
+        }
+    }
+    unsigned long long rest = __ballot(cand);
+    uint32_t ml = 3, off = 0;
+    while (rest) {
+        int const l = first_lane(rest);
+        rest &= rest - 1;
+        uint32_t len = (uint32_t)__builtin_amdgcn_readlane(cur, l);
+        uint32_t const mpl = (uint32_t)__builtin_amdgcn_readlane(mp, l);
+        if (len >= ZHIP_HC_CAP) len = uni(wave_count_fwd(src, x, mpl, nm8));
+        if (len > ml) { ml = len; off = x - mpl; if (x + len == n) break; }
+    }
+    __threadfence_block();
     mlOut = ml; offOut = off;
 }
 
@@ -600,18 +732,20 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
         for (uint32_t q = st.ntu + 1 + (uint32_t)lane_id(); q < x; q += 64) prev[q] |= ZHIP_HC_SKIPPED;
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
-        st.gapEnd = x - 1;
+        st.gapEnd = x - 1; st.epoch++;
     }
     st.ntu = x;
     }
     uint32_t off;
+    if (!st.predict) LZ_STAT(0, 1);
     uint32_t const minCand = hc_rec_min(rec), mode = hc_rec_mode(rec);
     bool live = mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd);
     if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x);      // a record only depends on its own row
     if (live) {
         st.nLive++;
         if (st.budget && st.nLive > st.budget) st.abort = 1;
-        if (u.rowLog) rh_search_live(src, n, x, prev, u.searchLog, u.rowLog, ml, off);
+        if (u.rowLog && st.ringCnt && st.nFlagged && !st.predict) { LZ_STAT(1, 1); rh_live_ring(src, n, x, u, prev, st, ml, off); }
+        else if (u.rowLog) { if (!st.predict) LZ_STAT(2, 1); rh_search_live(src, n, x, prev, u.searchLog, u.rowLog, ml, off); }
         else hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
     }
     else if (mode == 0) { ml = hc_rec_b(rec); off = hc_rec_a(rec); }
@@ -631,7 +765,8 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
 // skipping would leave out are only MARKED in prev[] (ZHIP_HC_PRED); no sequences, literals or meta are written
 __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem /* ZHIP_RH_DIRTY_BYTES */,
                                        uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
-                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0, bool havePred = false)
+                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0, bool havePred = false,
+                                       uint32_t* ring = nullptr /* rh_ring_words(hashLog, rowLog) words for the live rows, or none */)
 {
     uint32_t const lane = (uint32_t)lane_id();
     {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
@@ -653,6 +788,8 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
     HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0; st.havePred = havePred ? 1u : 0u;
+    st.ringCnt = (ring && u.rowLog) ? ring : (uint32_t*)nullptr; st.ringEnt = st.ringCnt ? ring + ((size_t)1 << ((uint32_t)u.hashLog - u.rowLog)) : (uint32_t*)nullptr;
+    st.ins = 0; st.nFlagged = 0; st.ringReady = 0; st.epoch = 0;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
@@ -668,6 +805,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         uint32_t x, K = 0, ip0 = ip;
         uint64_t recj = 0; bool repj = false;
         bool repHit; uint64_t rec;
+        unsigned long long ev = 0;
         if (step <= 8) {
             if (u.rowLog) rh_gap_rule(src, n, u, prev, st, ip);       // the batch's first search (at ip, not lazy-skipping) meets the gap since nextToUpdate
             // lanes take the positions the reference visits next while nothing is found: ip, ip+step, ... (same step)
@@ -694,23 +832,58 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             bool const needLive = valid && (hc_rec_mode(recj) == 3 || stale);
             bool const found = valid && (hc_rec_mode(recj) != 0 || hc_rec_b(recj) >= 4);
             K = (uint32_t)__popcll(__ballot(valid));
-            unsigned long long const ev = __ballot(repj || needLive || found);
+            ev = __ballot(repj || needLive || found);
             if (!ev) {                                                       // K failed searches (:1613-1624), lazySkipping = 0
                 st.ntu = ip + (K - 1) * step + rowBias; st.skipping = 0;
                 ip = ip + K * step;
                 continue;
             }
-            int const e = first_lane(ev);
-            x = ip + (uint32_t)e * step;
-            if (e > 0) { st.ntu = x - step + rowBias; st.skipping = 0; }
-            repHit = (__ballot(repj) >> e) & 1;
-            rec = readlane64(recj, e);
-        } else {
-            x = ip;
-            rec = best[x];
-            rec = readlane64(rec, 0);
-            repHit = off1 > 0 && uni(ld32(src + x + 1)) == uni(ld32(src + (x + 1 - off1)));
         }
+        uint32_t const epoch1 = st.epoch;                                    // what the batch found out about its records' staleness holds while this does not move
+        uint32_t matchLength = 0, start = 0, offBase = 1;
+        bool direct = false, failed = false;
+        // the events of the batch in order: a search that fails (no match, no repcode) moves on to the batch's next event without loading
+        // the batch again — on long-match data without the prediction nearly every search is such a live search that fails
+        for (;;) {
+            int e = 0;
+            if (step <= 8) {
+                e = first_lane(ev);
+                x = ip0 + (uint32_t)e * step;
+                if (e > 0) { st.ntu = x - step + rowBias; st.skipping = 0; }
+                repHit = (__ballot(repj) >> e) & 1;
+                rec = readlane64(recj, e);
+            } else {
+                x = ip;
+                rec = best[x];
+                rec = readlane64(rec, 0);
+                repHit = off1 > 0 && uni(ld32(src + x + 1)) == uni(ld32(src + (x + 1 - off1)));
+            }
+            matchLength = 0; start = x + 1; offBase = 1; direct = false;
+            if (repHit) {                                                    // :1600-1604
+                matchLength = 4 + wave_count_fwd(src, x + 5, x + 5 - off1, nm8);
+                if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1); }
+            }
+            ip = x;
+            if (direct) break;
+            {   uint32_t ml2, ob2;                                           // :1607-1611
+                hc_search(src, n, u, prev, st, x, rec, ml2, ob2);
+                if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
+            }
+            if (matchLength >= 4) break;
+            failed = true;                                                   // :1613-1625
+            if (step <= 8 && st.epoch == epoch1 && !st.abort) {
+                ev &= ~below_mask(e + 1);
+                if (ev) { failed = false; continue; }
+                st.ntu = ip0 + (K - 1) * step + rowBias; st.skipping = 0;       // the batch's remaining searches fail from their records
+                ip = ip0 + K * step;
+                break;
+            }
+            uint32_t const stp = ((x - anchor) >> 8) + 1;
+            ip = x + stp;
+            st.skipping = stp > 8;                                           // kLazySkippingStep = 8
+            break;
+        }
+        if (failed) continue;
         // records / repcode probes of the positions after x, from the batch registers when they are there
         bool const window = step == 1;
         auto rec_at = [&](uint32_t q) -> uint64_t {
@@ -722,25 +895,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             if (window && q - 1 - ip0 < K) return (__ballot(repj) >> (q - 1 - ip0)) & 1;
             return uni(ld32(src + q)) == uni(ld32(src + (q - off1)));
         };
-
-        uint32_t matchLength = 0, start = x + 1, offBase = 1;
-        bool direct = false;
-        if (repHit) {                                                        // :1600-1604
-            matchLength = 4 + wave_count_fwd(src, x + 5, x + 5 - off1, nm8);
-            if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1); }
-        }
-        ip = x;
         if (!direct) {
-            {   uint32_t ml2, ob2;                                           // :1607-1611
-                hc_search(src, n, u, prev, st, x, rec, ml2, ob2);
-                if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
-            }
-            if (matchLength < 4) {                                           // :1613-1625
-                uint32_t const stp = ((x - anchor) >> 8) + 1;
-                ip = x + stp;
-                st.skipping = stp > 8;                                       // kLazySkippingStep = 8
-                continue;
-            }
             if (depth >= 1) {
                 while (ip < ilimit) {                                        // :1628-1700
                     ip++;
