@@ -708,7 +708,7 @@ def prediction_leg(zstd_amd, local, host):
     """The row matcher's two-pass prediction, measured where it matters: level 5 (greedy, the reference's default row-hash matcher) on the
     headline's long-match data, the same call with the prediction off (the default) and on.  Device time of the whole call; the two outputs must be the same bytes
     and the first units are checked against the oracle.  Never `value`."""
-    n = min(len(host), 256 << 20) // UNIT * UNIT
+    n = len(host) // UNIT * UNIT
     if n < 16 * UNIT:
         return None
     a = host[:n]
@@ -893,7 +893,7 @@ def run_leg(args, torch, zstd_amd, dev, local):
     name = args.leg
     nocpu = args.no_cpu_baseline
     if name == "level5_row_prediction":
-        host = zstd_amd.datagen(256 << 20, 50, 0)
+        host = zstd_amd.datagen(int(os.environ.get("ZHIP_L5_LEG_MIB", "256")) << 20, 50, 0)
         return prediction_leg(zstd_amd, local, np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host)
     if name == "silesia_shaped_level1":                          # the metric's own data shape: Silesia-shaped mix x4 at level 1
         sil, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,

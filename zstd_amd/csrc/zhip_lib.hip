@@ -109,8 +109,9 @@ struct zhip_ctx_s {
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
-    int rhPredict = 1, lzPredict = 0;    // the row matcher's two-pass prediction for units (on: only units whose first parse went over the live-search budget are parsed again — datagen level 5
-                                         // 1.44 -> 1.98 GB/s, text unchanged) / for frames (off: 1 MiB datagen frames x3.4, text frames -33 %; profiles/r04_L5_predict.log); zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT
+    int rhPredict = 0, lzPredict = 0;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT).  Units: off with the live rows (datagen level 5,
+                                         // 256 MiB: 2.57 GB/s against 2.27 with it; without the rows 1.53 / 2.00 — then it defaults to on), text the same either way.  Frames: opt-in (1 MiB datagen frames
+                                         // 681 -> 366 ms, text frames 168 -> 224 ms; profiles/r04_live_rows.log)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -201,8 +202,9 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
-    {   const char* e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : 1; e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0;
-        e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1; }
+    {   const char* e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1;
+        e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : (c->lzRingOn ? 0 : 1);        // with the live rows one parse is faster than try + predict + parse (profiles/r04_live_rows.log)
+        e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;

@@ -523,49 +523,6 @@ __device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t 
     mlOut = ml; offOut = off;
 }
 
-// (measured, datagen P50 level 5, 8192 units resident: refreshing whole batches costs 616 ms per GiB against 324 ms for one
-// wave-wide live search per stale search — 64 lanes x ~20 random sectors per batch is HBM traffic without any locality; the
-// real fix is to run the search kernel again with the flags of a first parse applied — see DESIGN.md)
-#ifndef ZHIP_RH_BATCH_REFRESH
-#define ZHIP_RH_BATCH_REFRESH 0
-#endif
-// the same search redone by ONE LANE for its own position with the never-inserted positions (flagged in prev[]) left out of the
-// rows: the parser refreshes the stale records of a whole batch with it, 64 positions at a time (a stale record per search would
-// otherwise mean a serial walk of dependent loads per search — gaps of more than 384 positions are common in long-match data)
-__device__ inline uint64_t rh_search_lane(const uint8_t* __restrict__ src, uint32_t n, uint32_t p, const uint32_t* __restrict__ prev,
-                                          uint32_t searchLog, uint32_t rowLog)
-{
-    uint32_t const nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
-    uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
-    uint32_t ml = 3, off = 0, nCap = 0, capA = 0, capB = 0;
-    uint32_t const w0 = prev[p], myTag = (w0 >> 18) & 0xFFu;
-    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
-    bool done = false;
-    while (m != 0 && attempts && room) {
-        uint32_t const mp = m - 1;
-        uint32_t const w = prev[mp];
-        m = w & ZHIP_RH_LINK_MASK;
-        if (w & ZHIP_HC_SKIPPED) continue;
-        room--;
-        if (((w >> 18) & 0xFFu) != myTag) continue;
-        attempts--;
-        if (!done && p + ml < n && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
-            uint32_t cur = 0;
-            for (;;) {
-                uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
-                cur += same;
-                if (same < 8 || cur >= ZHIP_HC_CAP) break;
-            }
-            if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
-            else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) done = true; }
-        }
-    }
-    // minCand = NONE: this record already accounts for every flag raised so far
-    if (nCap == 0) return hc_pack(off, ml, 0, ZHIP_HC_NONE);
-    if (nCap <= 2) return hc_pack(capA, capB, nCap, ZHIP_HC_NONE);
-    return hc_pack(0, 0, 3, ZHIP_HC_NONE);
-}
-
 // the row search the reference would run at x with the positions flagged in prev[] missing from the rows (all values uniform)
 __device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
                                       uint32_t searchLog, uint32_t rowLog, uint32_t& mlOut, uint32_t& offOut)
@@ -603,6 +560,15 @@ __device__ __forceinline__ uint32_t rh_key(const uint8_t* __restrict__ src, uint
     uint32_t const h = mls == 4 ? hash_pos_salted<4>(bytes, hBits, salt) : (mls == 5 ? hash_pos_salted<5>(bytes, hBits, salt) : hash_pos_salted<6>(bytes, hBits, salt));
     tag = h & 0xFFu;
     return h >> 8;
+}
+// fresh rows at the first use: every count 0 (the slots are only read below a count)
+__device__ inline void rh_ring_ready(const ZhipUnit& u, HcState& st)
+{
+    if (st.ringReady) return;
+    for (uint32_t i = (uint32_t)lane_id(); i < (1u << ((uint32_t)u.hashLog - u.rowLog)); i += 64) st.ringCnt[i] = 0;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    st.ringReady = 1;
 }
 // What ZSTD_row_update (zstd_lazy.c:916-947) has put into the rows when the search at `upTo` starts: every position of [st.ins, upTo) that was not
 // left out (flagged in prev[]), in order, 64 per step.  A row keeps its 2^rowLog - 1 latest inserts (ZSTD_row_nextIndex :784-795 cycles through
@@ -642,12 +608,7 @@ __device__ inline void rh_live_ring(const uint8_t* __restrict__ src, uint32_t n,
 {
     uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, nm8 = n - 8, keyBits = (uint32_t)u.hashLog - rowLog;
     uint32_t const capped = u.searchLog < rowLog ? u.searchLog : rowLog, attempts = 1u << capped;
-    if (!st.ringReady) {
-        for (uint32_t i = lane; i < (1u << keyBits); i += 64) st.ringCnt[i] = 0;
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        st.ringReady = 1;
-    }
+    rh_ring_ready(u, st);
     if (x - st.ins > 63) rh_ring_catchup(src, u, prev, st, x - 63);
     uint32_t const ins0 = st.ins, nPend = x - ins0;                             // lanes below nPend: a position to insert; the others (lane 63 always) look at x
     uint32_t const q = lane < nPend ? ins0 + lane : x;
@@ -824,10 +785,6 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             bool stale = st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd;
             if (u.rowLog && st.gapEnd != 0) {
                 stale = valid && stale && rh_row_dirty(src, n, u, st, xc);      // per lane: a record only depends on its own row
-#if ZHIP_RH_BATCH_REFRESH
-                if (stale) recj = rh_search_lane(src, n, xj, prev, u.searchLog, u.rowLog);     // refreshed in place, all stale lanes at once
-                stale = false;
-#endif
             }
             bool const needLive = valid && (hc_rec_mode(recj) == 3 || stale);
             bool const found = valid && (hc_rec_mode(recj) != 0 || hc_rec_b(recj) >= 4);
