@@ -713,10 +713,17 @@ def prediction_leg(zstd_amd, local, host):
         return None
     a = host[:n]
     res = {"level": 5, "source_bytes": int(n), "units": int(n // UNIT),
-           "note": "zhip_compress at level 5 (ZSTD_greedy, row-hash matcher), 128 KB units; `off` = one parse, every search behind a skipped position redone live; `on` = zhip_set_prediction(units=1): tried, predicted, parsed again; device ms of the call (parse + entropy + gather), best of 2; never `value`"}
+           "note": "zhip_compress at level 5 (ZSTD_greedy, row-hash matcher), 128 KB units; `off` (the default) = one parse, every search behind a left-out position redone live from the row matcher's live rows (DESIGN.md 4.2b); `on` = zhip_set_prediction(units=1): tried, predicted, parsed again; device ms of the call (parse + entropy + gather), best of 2; `first_256MiB_off` = the same call on the first 2 048 units only (half of the 4 096 resident wavefronts: the size this leg was quoted on before); never `value`"}
     try:
         ctx = zstd_amd.Context(local, max_units=n // UNIT + 1)
         ctx.set_row_matcher(0)
+        if n > (256 << 20):
+            ctx.set_prediction(units=0)
+            best = 1e9
+            for _ in range(2):
+                ctx.compress(a[: 256 << 20], level=5)
+                best = min(best, ctx.timing()["total_ms"])
+            res["first_256MiB_off"] = {"value": round((256 << 20) / best / 1e3, 1), "unit": "MB/s", "device_ms": round(best, 3)}
         outs = {}
         for mode in (0, 1):
             ctx.set_prediction(units=mode)
@@ -893,7 +900,7 @@ def run_leg(args, torch, zstd_amd, dev, local):
     name = args.leg
     nocpu = args.no_cpu_baseline
     if name == "level5_row_prediction":
-        host = zstd_amd.datagen(int(os.environ.get("ZHIP_L5_LEG_MIB", "256")) << 20, 50, 0)
+        host = zstd_amd.datagen(int(os.environ.get("ZHIP_L5_LEG_MIB", "1024")) << 20, 50, 0)
         return prediction_leg(zstd_amd, local, np.frombuffer(host, dtype=np.uint8) if not isinstance(host, np.ndarray) else host)
     if name == "silesia_shaped_level1":                          # the metric's own data shape: Silesia-shaped mix x4 at level 1
         sil, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
