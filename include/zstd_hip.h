@@ -157,9 +157,10 @@ int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 /* The row matcher's two-pass prediction: a first parse marks the positions the 384-position rule and lazy skipping will leave
  * un-inserted, the per-position records are recomputed without them, and the exact parse redoes a search live only where prediction and truth differ.
- * Same bytes with it on or off; off by default for units and for frames (at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT = 0 | 1) — the live searches
- * read the row matcher's rows as the reference keeps them ("live rows"; $ZHIP_LZ_RING=0 at creation: walk the links instead, and the
- * units' prediction then defaults to on).
+ * Same bytes with it on or off (at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT = 0 | 1).  Units: off by default — the live searches read the row
+ * matcher's rows as the reference keeps them ("live rows"), and one parse is then the fastest form ($ZHIP_LZ_RING=0 at creation: walk
+ * the links instead; the units' prediction then defaults to on).  Frames: on by default, behind a probe — a window whose first 32 KB leave nothing
+ * un-inserted is parsed once.
  * units / frames: 1 on, 0 off, -1 unchanged.  returns 0, or 1 for a bad value. */
 int          zhip_set_prediction(zhip_ctx* ctx, int units, int frames);
 

@@ -362,13 +362,13 @@ void emu_frame_lazy(const uint8_t* src, const ZhipUnit* units, const zhip::ZhipJ
     simt::launch({nW, 1, 1}, {ZHIP_LZ_LINK_THREADS, 1, 1}, sizeof(zhip::LzLinkShared),
                  [=] { zhip::k_lz_links(src, units, jobs, lz, nW, pv, tg, hd); }, osThreads);
     simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0,
-                 [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs); }, osThreads);
+                 [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs, (const zhip::ZhipFrameState*)nullptr); }, osThreads);
     uint32_t havePred = 0;
-    {   const char* const pe = getenv("ZHIP_LZ_PREDICT");        // the two-pass prediction, as the host library launches it ($ZHIP_LZ_PREDICT=1 turns it on, as in the library)
-        if (pe && atoi(pe) != 0) {
+    {   const char* const pe = getenv("ZHIP_LZ_PREDICT");        // the two-pass prediction, as the host library launches it (on unless $ZHIP_LZ_PREDICT=0, as in the library)
+        if (!(pe && atoi(pe) == 0)) {
             havePred = 1;
-            simt::launch({nW, 1, 1}, {64, 1, 1}, sizeof(ZhipParse), [=] { zhip::k_lz_predict(src, units, jobs, lz, nW, pv, tg, bs); }, osThreads);
-            simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0, [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs); }, osThreads);
+            simt::launch({nW, 1, 1}, {64, 1, 1}, sizeof(ZhipParse), [=] { zhip::k_lz_predict(src, units, jobs, lz, nW, pv, tg, bs, stp); }, osThreads);
+            simt::launch({(longest + 255) / 256, nW, 1}, {256, 1, 1}, 0, [=] { zhip::k_lz_search(src, units, jobs, lz, 0u, nW, pv, tg, bs, (const zhip::ZhipFrameState*)stp); }, osThreads);
         }
     }
     simt::launch({nW, 1, 1}, {ZHIP_ENT_THREADS, 1, 1}, zhip::frame_lazy_lds_bytes(),

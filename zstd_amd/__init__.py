@@ -315,7 +315,7 @@ class Context:
             raise ZhipError("zhip_set_row_matcher: bad mode")
 
     def set_prediction(self, units=None, frames=None):
-        """the row matcher's two-pass prediction for units / for multi-block frames (same bytes either way; off by default — DESIGN.md 4.2b "the live rows")"""
+        """the row matcher's two-pass prediction for units / for multi-block frames (same bytes either way; units: off by default, frames: on behind a 32 KB probe — DESIGN.md 4.2b "the live rows", 4.7c)"""
         L = lib()
         L.zhip_set_prediction.restype = C.c_int
         L.zhip_set_prediction.argtypes = [C.c_void_p, C.c_int, C.c_int]

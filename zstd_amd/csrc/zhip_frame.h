@@ -30,7 +30,7 @@ struct FrameShared {
 };
 
 // what one block hands to the next, per frame, in HBM
-struct ZhipFrameState { ZhipDictEntropy ent; };
+struct ZhipFrameState { ZhipDictEntropy ent; uint32_t predicted; uint32_t pad[3]; };     // predicted: k_lz_predict marked this window (zhip_frame_lazy.h)
 
 // One JOB of a frame compressed the way ZSTD_c_nbWorkers >= 1 compresses it (zstdmt_compress.c:683-790): a section of the input that
 // starts from a fresh context which has only loaded the `prefixLen` bytes in front of it (the overlap with the previous job) as a

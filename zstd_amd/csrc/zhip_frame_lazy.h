@@ -34,9 +34,9 @@
 //                left out (data without long matches never pays for it).  A live search is then two round trips (row, candidates' bytes)
 //                whatever the number of left-out positions; the walk through prev[] steps over every one of them — on long-match data
 //                some 250 dependent loads per search in an 8 MiB window (round 3 / 4: 0.004 GB/s on one job-pool frame).
-//   k_lz_predict (opt-in, $ZHIP_LZ_PREDICT=1) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
+//   k_lz_predict (on by default, $ZHIP_LZ_PREDICT=0 turns it off) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
 //                it would leave un-inserted, k_lz_search runs again stepping over them, and the exact parse distrusts a record only where
-//                prediction and truth differ — exact on the emulator, not timed on the GPU yet.
+//                prediction and truth differ.  Its first 32 KB are a probe: a window that leaves (almost) nothing out there is parsed once.
 #pragma once
 #include "zhip_parse_lazy.h"
 #include "zhip_frame.h"
@@ -793,11 +793,11 @@ __device__ inline void lz_keep_fse_table(ZhipDictEntropy* ent, const EntShared* 
     if (t > maxSym && t < 56) ent->ct[k].dBits[t] = ((tl + 1) << 16) - (1u << tl);
 }
 
-// The PREDICTING parse of a window (one wavefront; see rh_reconcile in zhip_parse_lazy.h): the block loop with fixed 128 KB blocks (the real
-// borders depend on the compressed sizes; a border a few KB off only costs a few mispredictions), every block taken as confirmed, nothing
-// stored.  Data without long matches leaves almost nothing un-inserted: when the first block marked less than 1 position in 64, the rest
-// of the window is not parsed twice.
-__device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const ZhipUnit& u, uint32_t* prev, const uint8_t* tags, const LzRec* best,
+// The PREDICTING parse of a window (one wavefront; see rh_reconcile in zhip_parse_lazy.h): the block loop with fixed block sizes (the real borders depend on
+// the compressed sizes; a border a few KB off only costs a few mispredictions), every block taken as confirmed, nothing stored.  Data without long matches
+// leaves almost nothing un-inserted: the first 32 KB are a probe — when they marked less than 1 position in 64 the marks are taken back and the window is
+// parsed once, as if there were no prediction (returns false: the exact parse then has nothing to compare with).
+__device__ inline bool frame_lazy_predict(const uint8_t* __restrict__ src, const ZhipUnit& u, uint32_t* prev, const uint8_t* tags, const LzRec* best,
                                           ZhipParse* meta /* LDS */, const ZhipJob* __restrict__ job)
 {
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST);
@@ -806,7 +806,8 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
     LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
     ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = 0; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = 0; ls.holeEnd = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {
-        uint32_t const bLen = jEnd - pos < ZHIP_UNIT_MAX ? jEnd - pos : ZHIP_UNIT_MAX;
+        uint32_t const most = pos == j0 ? 32768u : ZHIP_UNIT_MAX;
+        uint32_t const bLen = jEnd - pos < most ? jEnd - pos : most;
         if (bLen >= 7) {
             if (pos > maxDist && pos - maxDist > low) low = pos - maxDist;
             LzBlock B; B.src = src; B.bStart = pos; B.bEnd = pos + bLen; B.low = low; B.maxDist = maxDist; B.prev = prev; B.tags = tags; B.best = best;
@@ -815,9 +816,16 @@ __device__ inline void frame_lazy_predict(const uint8_t* __restrict__ src, const
             rep1 = meta->rep[0]; rep2 = meta->rep[1]; rep3 = meta->rep[2];
             __builtin_amdgcn_wave_barrier();
         }
-        if (pos == j0 && ls.nPred * 64u < bLen) return;
+        if (pos == j0 && ls.nPred * 64u < bLen) {
+            if (ls.nPred) {
+                for (uint32_t q = pos + (uint32_t)lane_id(); q < pos + bLen; q += 64) { uint32_t const w = prev[q]; if (w & ZHIP_LZ_PRED) prev[q] = w & ~ZHIP_LZ_PRED; }
+                __threadfence_block();
+            }
+            return false;
+        }
         pos += bLen;
     }
+    return true;
 }
 
 // job == nullptr: the whole input src[0, u.srcLen) as one frame; else one job of a frame, src = the start of the job's window
@@ -848,7 +856,7 @@ __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUni
     long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
     uint32_t pos = j0, low = 0;
     uint32_t const maxDist = 1u << u.windowLog;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = havePred ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = (havePred && st->predicted) ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
     ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = L.linkStart; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = L.holeStart; ls.holeEnd = L.holeEnd;
     if (ring && u.rowLog) {                                                  // fresh rows: every count 0 (the slots are only read below a count)
         uint32_t const rows = 1u << lz_key_bits(u);

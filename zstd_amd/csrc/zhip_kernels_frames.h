@@ -104,10 +104,12 @@ k_lz_links(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, 
 // k_lz_search: grid (ceil(longest section / 256), nW); one thread per position of the unit's section
 __global__ void __launch_bounds__(256)
 k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t wBase, uint32_t nW,
-            const uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, LzRec* __restrict__ best)
+            const uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, LzRec* __restrict__ best,
+            const ZhipFrameState* __restrict__ states /* the pass after k_lz_predict: only the windows it marked; nullptr: all */)
 {
     uint32_t const wi = wBase + blockIdx.y;
     if (wi >= nW) return;
+    if (states && !states[wi].predicted) return;
     ZhipUnit const u = units[wi];
     if (u.strategy < ZHIP_STRAT_GREEDY) return;
     ZhipLzSlot const L = lz[wi];
@@ -122,15 +124,18 @@ k_lz_search(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units,
 // k_lz_predict: one wavefront per unit, dynamic LDS = sizeof(ZhipParse): the predicting parse (frame_lazy_predict); k_lz_search runs again after it
 __global__ void __launch_bounds__(64)
 k_lz_predict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipJob* __restrict__ jobs, const ZhipLzSlot* __restrict__ lz, uint32_t nW,
-             uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, const LzRec* __restrict__ best)
+             uint32_t* __restrict__ prev, const uint8_t* __restrict__ tags, const LzRec* __restrict__ best, ZhipFrameState* __restrict__ states)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)
     uint32_t const wi = blockIdx.x;
     if (wi >= nW) return;
     ZhipUnit const u = units[wi];
-    if (u.strategy < ZHIP_STRAT_GREEDY || u.srcLen == 0) return;
-    ZhipLzSlot const L = lz[wi];
-    frame_lazy_predict(lz_window(src, u, jobs, wi), u, prev + L.posOff, tags + L.posOff, best + L.posOff, (ZhipParse*)smem, jobs ? jobs + wi : (const ZhipJob*)nullptr);
+    bool marked = false;
+    if (u.strategy >= ZHIP_STRAT_GREEDY && u.srcLen != 0) {
+        ZhipLzSlot const L = lz[wi];
+        marked = frame_lazy_predict(lz_window(src, u, jobs, wi), u, prev + L.posOff, tags + L.posOff, best + L.posOff, (ZhipParse*)smem, jobs ? jobs + wi : (const ZhipJob*)nullptr);
+    }
+    if (threadIdx.x == 0) states[wi].predicted = marked ? 1u : 0u;           // k_frame_lazy compares its decisions with the marks only where there are any
 }
 // k_frame_lazy: dynamic LDS = frame_lazy_lds_bytes()
 __global__ void __launch_bounds__(ZHIP_ENT_THREADS, 2)

@@ -109,7 +109,7 @@ struct zhip_ctx_s {
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
-    int rhPredict = 0, lzPredict = 0;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT).  Units: off with the live rows (datagen level 5,
+    int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT).  Units: off with the live rows (datagen level 5,
                                          // 256 MiB: 2.57 GB/s against 2.27 with it; without the rows 1.53 / 2.00 — then it defaults to on), text the same either way.  Frames: opt-in (1 MiB datagen frames
                                          // 681 -> 366 ms, text frames 168 -> 224 ms; profiles/r04_live_rows.log)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
@@ -204,7 +204,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
     {   const char* e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1;
         e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : (c->lzRingOn ? 0 : 1);        // with the live rows one parse is faster than try + predict + parse (profiles/r04_live_rows.log)
-        e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 0; }
+        e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 1; }                                 // frames: on, behind its 32 KB probe (k_lz_predict)
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -944,17 +944,17 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
         for (size_t w0 = 0; w0 < nU; w0 += 32768) {
             size_t const nw = nU - w0 < 32768 ? nU - w0 : 32768;
             hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
-                               (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+                               (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, (const zhip::ZhipFrameState*)nullptr);
         }
         {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=1 turns it on)
-            int const predictOn = c->lzPredict;              // opt-in, like the units' (zhip_set_prediction / $ZHIP_LZ_PREDICT)
+            int const predictOn = c->lzPredict;              // on by default (zhip_set_prediction / $ZHIP_LZ_PREDICT): a window whose first 32 KB leave nothing out is parsed once
             if (predictOn) {
                 hipLaunchKernelGGL(zhip::k_lz_predict, dim3((unsigned)nU), dim3(64), sizeof(ZhipParse), s,
-                                   (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+                                   (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dFrameState);
                 for (size_t w0 = 0; w0 < nU; w0 += 32768) {
                     size_t const nw = nU - w0 < 32768 ? nU - w0 : 32768;
                     hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
-                                       (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest);
+                                       (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, (const zhip::ZhipFrameState*)c->dFrameState);
                 }
             }
         }
