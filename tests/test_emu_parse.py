@@ -3,7 +3,7 @@ CPU only: this checks the wave-parallel algorithm, not the GPU build."""
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, _buf, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_, datagen, text_like)
+from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, emu_compress_units, _buf, ERR, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_, datagen, text_like)
 
 
 @pytest.fixture(scope="module")
@@ -311,3 +311,25 @@ def test_rowhash_two_pass_prediction(libs, monkeypatch):
             assert live["1"].sum() < live["0"].sum()
     finally:
         lo.zo_set_row_matcher(0)
+
+
+def test_rowhash_units_without_the_live_rows(libs, monkeypatch):
+    """$ZHIP_LZ_RING=0: the row matcher's live searches walk the links (the form before the live rows, and the fallback without their arena) — with and
+    without the units' two-pass prediction: the same sequences as with the rows, i.e. the oracle's frames"""
+    lo, le = libs
+    bufs = [datagen(lo, 131072, 50, 4), datagen(lo, 100000, 80, 5), text_like(60000, 2)]
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    lo.zo_set_row_matcher(1)
+    try:
+        want = []
+        for b in bufs:
+            dst = np.zeros(lo.zo_compress_bound(len(b)) + 64, dtype=np.uint8)
+            r = lo.zo_compress_unit(_buf(dst), len(dst), _buf(b), len(b), 5)
+            assert r != ERR
+            want.append(dst[:r].tobytes())
+    finally:
+        lo.zo_set_row_matcher(0)
+    for ring, predict in (("0", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("ZHIP_LZ_RING", ring)
+        monkeypatch.setenv("ZHIP_RH_PREDICT", predict)
+        assert emu_compress_units(le, lo, bufs, 5, row=True) == want, (ring, predict)
