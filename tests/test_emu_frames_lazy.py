@@ -79,7 +79,7 @@ def test_lazy_frames_with_the_two_pass_prediction(libs, monkeypatch):
             assert g == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (name, level, row)
 
 
-@pytest.mark.parametrize("ring,predict", [("0", "0"), ("0", "1"), ("1", "0")])
+@pytest.mark.parametrize("ring,predict", [("0", "0"), ("1", "0")])            # ("0", "1"): tests/test_gpu_frames_lazy.py::test_live_rows_switch_gives_the_same_bytes
 def test_lazy_frames_without_the_live_rows_and_without_the_prediction(libs, monkeypatch, ring, predict):
     """the other forms of the exact parse (the suite's default is live rows + probed prediction): live searches that walk the links ($ZHIP_LZ_RING=0 —
     also what a context falls back to when the rows' arena cannot be allocated), with and without the two-pass prediction; and one parse from the
@@ -87,7 +87,7 @@ def test_lazy_frames_without_the_live_rows_and_without_the_prediction(libs, monk
     lo, le = libs
     monkeypatch.setenv("ZHIP_LZ_RING", ring)
     monkeypatch.setenv("ZHIP_LZ_PREDICT", predict)
-    bufs = [datagen(lo, 300000, 50, 11), text_like(200000, 3), np.concatenate([text_like(140000, 5), datagen(lo, 160000, 80, 6)])]
+    bufs = [datagen(lo, 160000, 50, 11), text_like(135000, 3), np.concatenate([text_like(70000, 5), datagen(lo, 100000, 80, 6)])]
     cps = [_cp(lo, 5, len(a)) for a in bufs]
     got = emu_compress_frames_lazy(le, lo, bufs, cps, 1)
     for a, cp, g in zip(bufs, cps, got):
