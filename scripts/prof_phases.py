@@ -56,8 +56,19 @@ def main():
     names_p = ["init", "window front (loads, hash, table + candidate gather, groups)", "window event search", "window match (E load, extension)",
                "window emit + inserts + repcode loop", "window end (table, sequences, literals)", "schedule-shaped batch", "its event (extension, post-match)", "tail",
                "window long match (post-match by loads)"]
+    names_d = ["init (table zeroing)", "window: source + repcode bytes", "window: table gather (2 x 64 entries)", "window: scratch + candidate bytes (tag hits)",
+               "window: cut W + hit masks", "window: event loop (E loads, extension, emits)", "window: end (table writes, sequences, literals)",
+               "batch scheme until its event", "its match (df_extend) + emit", "post-match round(s) (inserts, immediate repcode, next bytes)"]
     names_e = ["gather+hist", "huf table build", "huf sizing+hdr", "huf pack", "seq hist+tables", "fse state chains",
                "seq bit pack", "headers"]
+    if level in (3, 4):
+        tot = sum(v[:10]) or 1
+        print(json.dumps({"timing_ms": tm, "units": units,
+                          "dfast_ticks_per_unit": {names_d[i]: [round(v[i] / units), round(100.0 * v[i] / tot, 1)] for i in range(10)},
+                          "event_loop_E_load_wait_ticks_per_unit (part of the event loop, not in the shares above)": round(v[15] / units),
+                          "windows_per_unit": v[10] / units, "window_events_per_unit": v[11] / units, "batch_iterations_per_unit": v[12] / units,
+                          "window_post_exits_per_unit": v[13] / units, "windows_cut_short_per_unit": v[14] / units}, indent=1))
+        return
     res = {"timing_ms": tm, "units": units,
            "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(10)},
            "parse_windows_per_unit": v[10] / units, "parse_window_events_per_unit": v[11] / units,

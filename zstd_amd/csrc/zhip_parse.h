@@ -301,7 +301,9 @@ struct FastOut {
 #ifdef ZHIP_PROF
 #define ZWPROF(o, i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); (o).zp[i] += t_ - *(o).zlast; *(o).zlast = t_; } while (0)
 #define ZWPROF_COUNT(o, i, v) do { (o).zp[i] += (uint64_t)(v); } while (0)
+#define ZWPROF_SYNC(o, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ZWPROF(o, i); } while (0)   /* charges the outstanding loads to phase i */
 #else
+#define ZWPROF_SYNC(o, i) do { } while (0)
 #define ZWPROF(o, i) do { } while (0)
 #define ZWPROF_COUNT(o, i, v) do { } while (0)
 #endif

@@ -66,7 +66,7 @@ __device__ __forceinline__ unsigned long long lane_groups(uint32_t key, unsigned
 // masks, written once at the end — cannot collide.  A window that would end within its first lanes is not worth its gathers: the
 // scan then uses the batch scheme (ZW_BATCH).  A match whose post-match inserts or immediate-repcode test fall beyond W hands them to
 // the caller's round of loads (ZW_POST).
-enum { ZW_POST = 3, ZW_BATCH = 4 };
+enum { ZW_POST = 3, ZW_BATCH = 4, ZW_CARRY = 5 };
 #define ZHIP_DFW_NEED 80u            /* a window at B needs B + 80 <= n */
 #define ZHIP_DFW_LANES 56u           /* events are taken from lanes below this */
 #define ZHIP_DFW_MIN 12u             /* a window cut shorter than this by a hash collision is left to the batch scheme */
@@ -89,41 +89,77 @@ __device__ __forceinline__ uint32_t first_repeat_lane(uint32_t key, unsigned lon
     return w;
 }
 
+// Round 5.  The phase counters of round 4's window (profiles/r05_dfast_phases_before.log, Silesia-shaped mix, 35 000 cycles per window) put 17 %
+// into the caller's round of loads behind a match that leaves the window (43 % of the windows ended that way), 13 % into waiting for the
+// window's own source bytes behind the previous window's 128 scattered table stores (loads and stores retire in order), 10 % into the
+// candidate fetch.  Two changes came of it, both exact and kept because they take loads off the chain:
+//   * CARRY: a match that leaves the collision-free lanes hands its end to the NEXT window, which starts two positions in front of it — the
+//     complementary inserts long[ip-2], short[ip-1] (zstd_double_fast.c:303-309) are lanes 0 and 1 of an ordinary window, the immediate-repcode
+//     test (:313) is bit 2 of its E2 mask; the insert of curr+2 is a lane of the window that found the match, stored after the others.  An
+//     immediate-repcode match that leaves the lanes carries the same way without the two inserts (carry 2).  No round of loads;
+//   * the next window's source bytes are loaded BEFORE this window's table stores are issued (DfPre), unconditionally (a load inside a branch
+//     is waited for inside the branch).
+// Measured (profiles/r05_ab_dfast_carry_preload.log, 2 GiB per shape, the four on/off combinations): the stage's time does not move
+// (Silesia-shaped 136.4-137.9 ms, text 166.0-169.6, datagen 121.0-121.2) — shortening a wavefront's chain buys nothing because the stage
+// is bound by the RATE OF RANDOM MEMORY REQUESTS, not by their latency: profiles/r05_L3_silesia10_sq_tcc.txt has 5.1 G read + 1.0 G
+// write requests at the L2's memory side per 136 ms = 45 G/s, which is what this machine's DRAM activates sustain; a wavefront that waits
+// less only queues sooner.  Taking a tag match as a hit and letting the match's own E load confirm it (no candidate fetch: fewer
+// requests) lost as well — the candidate fetch is also the prefetch that makes the E loads of the event loop hit (event loop 29.5 -> 48 M
+// cycles per unit, profiles/r05_dfast_phases_tagtrust.log).  What would move the stage is fewer table requests per searched position:
+// a window gathers 2 x 64 entries and the reference searches about a quarter of those positions on dense-match data.
+struct DfPre { uint64_t bytes; uint32_t v1, v2, B; };       // B = ~0: nothing preloaded
+
 template <uint32_t MLS, bool WIDE>
-__device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t shL, uint32_t shS,
+__device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uint32_t n, uint32_t nm8, uint32_t shL, uint32_t shS,
                                             uint32_t* __restrict__ tabL, uint32_t* __restrict__ tabS, lds_u8* scrL, lds_u8* scrS, FastOut& out,
                                             uint32_t& ip_, uint32_t& anchor_, uint32_t& off1_, uint32_t& off2_, uint32_t& nextStep_,
-                                            uint32_t prefixLow, uint32_t& curr_, bool& postFirst_)
+                                            uint32_t prefixLow, uint32_t& curr_, bool& postFirst_, uint32_t& carry_, DfPre& pre)
 {
     uint32_t const lane = (uint32_t)lane_id();
-    uint32_t const B = ip_, P = B + lane;
+    uint32_t const carryIn = carry_;                                     // 1: lanes 0, 1 are ip-2, ip-1 of the previous window's last match; 2: the immediate-repcode test at lane 0 is due
+    uint32_t const B = ip_ - (carryIn == 1 ? 2u : 0u), P = B + lane;
     if (out.pendLen) lits_flush(out);
-    uint64_t const bytes = ld64(src + P);
+    uint64_t bytes; uint32_t v1, v2;
+    if (pre.B == B) { bytes = pre.bytes; v1 = pre.v1; v2 = pre.v2; }
+    else {
+        bytes = ld64(src + P);
+        v1 = ld32(src + (P - off1_)); v2 = ld32(src + (P - off2_));       // an invalid repcode (0) reads the lane's own bytes
+    }
+    pre.B = ~0u;
+    ZWPROF_SYNC(out, 1);
     uint32_t const cur32 = (uint32_t)bytes;
-    uint32_t const v1 = ld32(src + (P - off1_)), v2 = ld32(src + (P - off2_));       // an invalid repcode (0) reads the lane's own bytes
     uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
     uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
     uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short(cur32);
     uint32_t const eL = tabL[hl], eS = tabS[hs];
+    ZWPROF_SYNC(out, 2);
     uint32_t const oldL = DF_POS(eL), oldS = DF_POS(eS);
     uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
     scrL[sl] = (uint8_t)lane; scrS[ss] = (uint8_t)lane;
     __builtin_amdgcn_wave_barrier();
     unsigned long long const loseL = __ballot(scrL[sl] != (uint8_t)lane), loseS = __ballot(scrS[ss] != (uint8_t)lane);
     __builtin_amdgcn_wave_barrier();
-    // candidate bytes only where the entry's tag says they can match
+    // candidate bytes only where the entry's tag says they can match.  The fetch also brings the candidates' lines close: the E loads of
+    // the event loop hit them (taking the tag's word and confirming by the E load alone was measured: the loads then miss one after the
+    // other, event loop 29.5 -> 48 M cycles per unit, profiles/r05_dfast_phases_tagtrust.log)
     uint64_t cbL = ~bytes; uint32_t cbS = ~cur32;
     if (oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
     if (oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+    bool const hitL = oldL != 0 && oldL >= prefixLow && cbL == bytes;        // :203 (index >= lowest, ZSTD_selectAddr)
+    bool const hitS = oldS != 0 && oldS >= prefixLow && cbS == cur32;        // :218
+    ZWPROF_SYNC(out, 3);
+    ZWPROF_COUNT(out, 10, 1);
     uint32_t W = 64;
     if (loseL) { uint32_t const w = first_repeat_lane(hl, loseL); if (w < W) W = w; }
     if (loseS) { uint32_t const w = first_repeat_lane(hs, loseS); if (w < W) W = w; }
-    if (W < ZHIP_DFW_MIN) return ZW_BATCH;
+#ifdef ZHIP_DBG_PRINT
+    if (W < ZHIP_DFW_MIN && lane == 0) printf("  dfwin B=%u carryIn=%u W=%u -> ZW_BATCH\n", B, carryIn, W);
+#endif
+    if (W < ZHIP_DFW_MIN) { ZWPROF_COUNT(out, 14, 1); ZWPROF(out, 4); return ZW_BATCH; }     // (carry_ stays: the caller settles it by loads)
+    carry_ = 0;
     // events from lanes below this: an event at lane j reads the LONG candidate of lane j+1 (:251) and inserts lane j+1 (:283), both must
     // lie below W; every other inserted lane is checked where it arises
     uint32_t const hiBound = W - 1 < ZHIP_DFW_LANES ? W - 1 : ZHIP_DFW_LANES;
-    bool const hitL = oldL != 0 && oldL >= prefixLow && cbL == bytes;        // :203 (index >= lowest, ZSTD_selectAddr)
-    bool const hitS = oldS != 0 && oldS >= prefixLow && cbS == cur32;        // :218
     unsigned long long const ML = __ballot(hitL), MS = __ballot(hitS), L1 = __ballot(hitL && oldL > prefixLow);   // :260 long match at ip+1: index > lowest
     uint32_t const x1 = off1_ ? cur32 ^ v1 : 1u, x2 = off2_ ? cur32 ^ v2 : 1u;
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
@@ -133,9 +169,10 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     uint32_t const nbSeq0 = out.nbSeq, anchorEntry = anchor_;
     uint32_t evA = 0, evB = 0, nEv = ~0u;
     unsigned long long INSL = 0, INSS = 0, COV = 0;
-    uint32_t backBefore = 0, sumLit = 0, i = 0;
+    uint32_t backBefore = 0, sumLit = 0, i = 0, lateLane = 64;
     bool fresh = false;
     int status = ZW_CONT;
+    ZWPROF(out, 4);
 #define DW_EMIT(ll, ob, ml) do { uint32_t const mb_ = (ml) - 3;                                                   \
         if (((ll) | mb_) > 0xFFFF) {                                                                              \
             if ((ll) > 0xFFFF) { out.longType = 1; out.longPos = out.nbSeq; }                                     \
@@ -143,6 +180,32 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         uint32_t const slot_ = out.nbSeq - nbSeq0;                                                                \
         evA = ZHIP_WRITELANE((ob), slot_, evA); evB = ZHIP_WRITELANE(((ll) & 0xFFFFu) | (mb_ << 16), slot_, evB); \
         out.nbSeq++; } while (0)
+    // :313-327 the immediate-repcode loop from lane e_ on; leave_: it went on beyond the collision-free lanes
+#define DW_IMMEDIATE(e_, leave_) do {                                                                             \
+        while (off2 > 0 && (((e_) < 64 ? E2q >> (e_) : 0ull) & 1)) {                                              \
+            uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, (e_) + 4, off2);                                    \
+            {   uint32_t const t = off2; off2 = off1; off1 = t; }                                                 \
+            {   unsigned long long t = E2q; E2q = E1q; E1q = t; t = E2b; E2b = E1b; E1b = t; }                    \
+            INSL |= 1ull << (e_); INSS |= 1ull << (e_);                                                           \
+            DW_EMIT(0u, 1u, rl);                                                                                  \
+            uint32_t const en = (e_) + rl;                                                                        \
+            COV |= en < 64 ? ZHIP_SBFM64(rl, (e_)) : lanes_from(e_);                                              \
+            (e_) = en; anchor = B + (e_); nextStep = B + (e_) + 256; fresh = true;                               \
+            if ((e_) >= W) { (leave_) = true; break; }                    /* the next test reads beyond the lanes at hand */ \
+        } } while (0)
+    // a scan that leaves the collision-free lanes behind a match: the next window takes it over when there is room for one, else the caller's loads
+#define DW_LEAVE(e_, kind_, currLane_) do {                                                                       \
+        i = (e_);                                                                                                 \
+        if (B + (e_) - ((kind_) == 1 ? 2u : 0u) + ZHIP_DFW_NEED <= n) { carry_ = (kind_); status = ZW_CARRY; } \
+        else { status = ZW_POST; postFirst_ = (kind_) == 1; curr_ = (kind_) == 1 ? B + (currLane_) : 0u; } } while (0)
+    if (carryIn) {
+        uint32_t e = 0;
+        if (carryIn == 1) { INSL |= 1ull; INSS |= 2ull; e = 2; }         // :305-309 long[ip-2], short[ip-1]
+        bool leave = false;
+        DW_IMMEDIATE(e, leave);
+        i = e;
+        if (leave) { DW_LEAVE(e, 2u, 0u); goto dw_done; }
+    }
     for (;;) {
         // lanes searched with gap 1: those whose position + 1 stays below nextStep (:232); the entry scan may reach it inside the window
         uint32_t const kLane = (int32_t)(nextStep - B) > 64 ? 64u : ((int32_t)(nextStep - B) < 0 ? 0u : nextStep - B);
@@ -172,12 +235,13 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         } else {
             uint32_t off, cand;
             unsigned long long Wq, Wb;                                        // the masks of the match's offset
-            INSL |= 1ull << (j + 1);                                          // :283-291 hashLong[hl1] = ip1 (gap 1 < 4)
             if (kind == 2) {
                 cand = __builtin_amdgcn_readlane(oldL, (int)j); off = B + j - cand;
                 uint32_t x = 1;
+                ZWPROF(out, 5);
                 if (P >= off) x = cur32 ^ ld32(src + (P - off));
                 Wq = __ballot(x == 0); Wb = __ballot((x & 0xFFu) == 0);
+                ZWPROF_SYNC(out, 15);
                 s = j;
                 e = j + 8 + fwd_run(src, nm8, B, Wb, j + 8, off);
             } else {
@@ -185,15 +249,18 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
                 bool const long1 = (L1 >> (j + 1)) & 1;
                 uint32_t const cand1 = __builtin_amdgcn_readlane(oldL, (int)(j + 1)), offL = B + j + 1 - cand1;
                 uint32_t xs = 1, xl = 1;
+                ZWPROF(out, 5);
                 if (P >= offS) xs = cur32 ^ ld32(src + (P - offS));
                 if (long1 && P >= offL) xl = cur32 ^ ld32(src + (P - offL));
                 unsigned long long const Sq = __ballot(xs == 0), Sb = __ballot((xs & 0xFFu) == 0);
                 unsigned long long const Lq = __ballot(xl == 0), Lb = __ballot((xl & 0xFFu) == 0);
+                ZWPROF_SYNC(out, 15);
                 uint32_t const mS = 4 + fwd_run(src, nm8, B, Sb, j + 4, offS);
                 uint32_t const mL = long1 ? 8 + fwd_run(src, nm8, B, Lb, j + 9, offL) : 0;
                 if (mL > mS) { s = j + 1; e = s + mL; off = offL; cand = cand1; Wq = Lq; Wb = Lb; }     // :251-264 the long match at ip+1 wins
                 else { s = j; e = s + mS; off = offS; cand = candS; Wq = Sq; Wb = Sb; }
             }
+            INSL |= 1ull << (j + 1);                                          // :283-291 hashLong[hl1] = ip1 (gap 1 < 4)
             // catch up (:207, :267): equal bytes in front of the match, as far as the literals and the window's low end allow
             uint32_t const room = B + s - anchor;
             uint32_t const limit = room < cand - prefixLow ? room : cand - prefixLow;
@@ -211,44 +278,58 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         if (back > s) { backBefore = back - s; sL = 0; }
         anchor = B + e;
         fresh = true; nextStep = B + e + 256;
-        if (e >= W || j + 2 >= W) {                                           // the inserts behind the match leave the collision-free lanes: by loads, in the caller
+        if (e >= W || j + 2 >= W) {                                           // the scan leaves the collision-free lanes behind this match
             COV |= e < 64 ? ZHIP_SBFM64(e - sL, sL) : lanes_from(sL);
-            i = e; curr_ = B + j; postFirst_ = true; status = ZW_POST;
+            DW_LEAVE(e, 1u, j);
+            if (status == ZW_CARRY) {                                         // :303-307 curr+2 is a lane of this window (j <= 55); beyond W it is stored after the others
+                if (j + 2 < W) { INSL |= 1ull << (j + 2); INSS |= 1ull << (j + 2); }
+                else lateLane = j + 2;
+            }
             break;
         }
         COV |= ZHIP_SBFM64(e - sL, sL);
         INSL |= (1ull << (j + 2)) | (1ull << (e - 2));                        // :305-310 complementary insertion
         INSS |= (1ull << (j + 2)) | (1ull << (e - 1));
         bool leave = false;
-        while (off2 > 0 && ((E2q >> e) & 1)) {                                // :313-327 immediate repcode
-            uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, e + 4, off2);
-            {   uint32_t const t = off2; off2 = off1; off1 = t; }
-            {   unsigned long long t = E2q; E2q = E1q; E1q = t; t = E2b; E2b = E1b; E1b = t; }
-            INSL |= 1ull << e; INSS |= 1ull << e;
-            DW_EMIT(0u, 1u, rl);
-            uint32_t const en = e + rl;
-            COV |= en < 64 ? ZHIP_SBFM64(rl, e) : lanes_from(e);
-            e = en; anchor = B + e; nextStep = B + e + 256;
-            if (e >= W) { leave = true; break; }                              // the next test reads beyond the lanes at hand: by loads
-        }
+        DW_IMMEDIATE(e, leave);
         i = e;
-        if (leave) { curr_ = 0; postFirst_ = false; status = ZW_POST; break; }
+        if (leave) { DW_LEAVE(e, 2u, 0u); break; }
     }
+dw_done:
 #undef DW_EMIT
+#undef DW_IMMEDIATE
+#undef DW_LEAVE
 #ifdef ZHIP_DBG_PRINT
-    if (B + lane == 4191) printf("  lane %u: P=%u oldS=%u eS=%x tgS=%x oldL=%u cbS=%x cur32=%x hs=%u\n", lane, P, oldS, eS, tgS, oldL, cbS, cur32, hs);
-    if (lane == 0) printf("  dfwin B=%u W=%u hiBound=%u -> i=%u status=%d INSL=%llx INSS=%llx ML=%llx MS=%llx COV=%llx nbSeq=%u off=%u/%u nextStep=%u\n", B, W, hiBound, i, status, INSL, INSS, ML, MS, COV, out.nbSeq, off1, off2, nextStep);
+    if (lane == 0) printf("  dfwin B=%u carryIn=%u W=%u hiBound=%u -> i=%u status=%d carry=%u INSL=%llx INSS=%llx ML=%llx MS=%llx COV=%llx nbSeq=%u off=%u/%u nextStep=%u late=%u\n", B, carryIn, W, hiBound, i, status, carry_, INSL, INSS, ML, MS, COV, out.nbSeq, off1, off2, nextStep, lateLane);
 #endif
+    ZWPROF_SYNC(out, 5);
+    ZWPROF_COUNT(out, 11, out.nbSeq - nbSeq0);
+    if (status == ZW_POST) ZWPROF_COUNT(out, 13, 1);
+    // the next window's source bytes, requested before this window's stores (loads and stores retire in order: behind the 128 scattered table
+    // stores they would wait for every one of them)
+    {   uint32_t const nB = B + i - (carry_ == 1 ? 2u : 0u);
+        bool const nxt = (status == ZW_CONT || status == ZW_CARRY) && nB + ZHIP_DFW_NEED <= n;
+        // unconditional on purpose (a load inside a branch is waited for inside the branch): without a next window the lanes read their own bytes again
+        uint32_t const q = (nxt ? nB : B) + lane;
+        pre.bytes = ld64(src + q);
+        pre.v1 = ld32(src + (q - (nxt ? off1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? off2 : 0u)));
+        pre.B = nxt ? nB : ~0u;
+    }
     // the window's table writes (no two inserted lanes share a hash: they all lie below W)
     if (__builtin_amdgcn_inverse_ballot_w64(INSL)) tabL[hl] = DF_ENTRY(P, tgL);
     if (__builtin_amdgcn_inverse_ballot_w64(INSS)) tabS[hs] = DF_ENTRY(P, tgS);
     __builtin_amdgcn_wave_barrier();
+    if (lateLane < 64) {                                                     // curr+2 of a carried match: the highest position this window inserts, so it is stored last
+        if (lane == lateLane) { tabL[hl] = DF_ENTRY(P, tgL); tabS[hs] = DF_ENTRY(P, tgS); }
+        __builtin_amdgcn_wave_barrier();
+    }
     nEv = out.nbSeq - nbSeq0;
     if (lane < nEv) {
         ZhipSeq q; q.offBase = evA; q.litLength = (uint16_t)evB; q.mlBase = (uint16_t)(evB >> 16);
         out.seqs[nbSeq0 + lane] = q;
     }
-    {   unsigned long long const LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
+    {   unsigned long long LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
+        if (carryIn == 1) LIT &= ~3ull;                                      // lanes 0, 1 lie in front of the anchor
         if (__builtin_amdgcn_inverse_ballot_w64(LIT)) {
             uint32_t const before = __builtin_amdgcn_mbcnt_hi((uint32_t)(COV >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)COV, 0));
             out.lits[out.litPos + (B - anchorEntry) + lane - before - backBefore] = (uint8_t)bytes;
@@ -256,6 +337,7 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     }
     out.litPos += sumLit;
     ip_ = B + i; anchor_ = anchor; off1_ = off1; off2_ = off2; nextStep_ = nextStep;
+    ZWPROF(out, 6);
     return status;
 }
 
@@ -325,6 +407,11 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     uint32_t const shL = 32 - u.hashLog, shS = 32 - u.chainLog;
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
+    ZPROF_DECL
+#ifdef ZHIP_PROF
+    out.zp = zp_acc_; out.zlast = &zp_last_;
+#endif
+    ZPROF(0);
     lds_u8* const scrL = (lds_u8*)(uintptr_t)smem;
     lds_u8* const scrS = (lds_u8*)(uintptr_t)(smem + ZHIP_DF_SCRATCH);
 
@@ -344,19 +431,26 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     uint32_t const kMul = u.pad0 ? (uint32_t)(u.pad0 >> 4) : 8u, kAdd = u.pad0 ? (uint32_t)(u.pad0 & 15) : 4u;   // width = mean * kMul/8 + kAdd (measurement knob, any value is exact)
     uint32_t evAvg16 = 12u << 4, kCap = 32;
     bool have = false; uint64_t nbytes = 0; uint32_t nrv = 0;                // the source bytes of the next batch, when the round behind a match fetched them
+    uint32_t carry = 0;                                                      // a window handed the end of its last match to the next one (window_dfast)
+    DfPre pre; pre.bytes = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;            // the next window's source bytes, loaded by the window before
     for (;;) {                                                               // one turn per match (:167)
         uint32_t step = 1, nextStep = ip + 256;
         if ((int32_t)(ip + 1) > ilimit) break;                               // :172
         int evKind = 0;                      // 0 none (unit finished), 1 repcode, 2 long, 3 short
         uint32_t curr = 0, candE = 0, ip1 = 0, cand1 = 0; bool long1 = false;
         int winDone = 0;                     // 2: a window emitted a match and the round of loads behind it is still due
-        bool postFirst = true;
+        bool postFirst = true, skipCurr2 = false;
         // windows while the gap is 1 and the unit has room; a scan that meets a hash collision early goes on in batches
-        while (ZHIP_DF_WINDOWS && ip + ZHIP_DFW_NEED <= n) {
-            int const st = window_dfast<MLS, WIDE>(src, nm8, shL, shS, tabL, tabS, scrL, scrS, out, ip, anchor, off1, off2, nextStep, prefixLow, curr, postFirst);
+        while (ZHIP_DF_WINDOWS && ip - (carry == 1 ? 2u : 0u) + ZHIP_DFW_NEED <= n) {
+            int const st = window_dfast<MLS, WIDE>(src, n, nm8, shL, shS, tabL, tabS, scrL, scrS, out, ip, anchor, off1, off2, nextStep, prefixLow, curr, postFirst, carry, pre);
             have = false;
-            if (st == ZW_CONT) continue;
+            if (st == ZW_CONT || st == ZW_CARRY) continue;                   // (a carrying window has checked that the next one has room)
+            pre.B = ~0u;
             if (st == ZW_POST) { winDone = 2; break; }
+            if (st == ZW_BATCH && carry) {                                   // a hash collision in the first lanes of a carried window: what was carried goes by loads
+                winDone = 2; postFirst = carry == 1; skipCurr2 = true; curr = 0; carry = 0;
+                break;
+            }
             if (st == ZW_INC) { step = 2; nextStep += 256; }
             break;                                                           // ZW_INC / ZW_BATCH: the batch scheme takes over
         }
@@ -425,6 +519,9 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
                 if (inC && (grpS & cm) == 0) tabS[hs] = DF_ENTRY(p, tgS);
             }
             __builtin_amdgcn_wave_barrier();
+#ifdef ZHIP_DBG_PRINT
+            if (lane == 0) printf("  dfbatch ip=%u step=%u K=%d jE=%d kind=%d mL=%llx mS=%llx mR=%llx\n", ip, step, K, jE, evKind, mL, mS, mR);
+#endif
             if (evKind) {
                 evAvg16 = (3 * evAvg16 + (((uint32_t)jE + 1) << 4)) >> 2;
                 kCap = ((evAvg16 * kMul) >> 7) + kAdd; if (kCap > 63) kCap = 63; if (kCap < 2) kCap = 2;
@@ -439,11 +536,13 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
                 }
                 break;
             }
+            ZWPROF_COUNT(out, 12, 1);
             ip = ip + (uint32_t)K * step;                                    // :236-237
             kCap = kCap * 2 > 63 ? 63 : kCap * 2;
             if (lastEnd) break;
             if (lastInc) { step++; nextStep += 256; }
         }
+        ZWPROF_SYNC(out, 7);
         if (evKind == 0) break;
 
         uint32_t mLength, offBase;
@@ -472,9 +571,13 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
             off2 = off1; off1 = offset;
             offBase = offset + 3;
         }
+#ifdef ZHIP_DBG_PRINT
+        if (lane == 0) printf("  dfmatch curr=%u kind=%d mstart=%u len=%u offBase=%u\n", curr, evKind, mstart, mLength, offBase);
+#endif
         lits_copy(out, src, nm8, anchor, mstart - anchor);
         store_seq(out, mstart - anchor, offBase, mLength);
         ip = mstart + mLength; anchor = ip;
+        ZWPROF_SYNC(out, 8);
         }
 
         have = false;
@@ -497,7 +600,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
                     uint32_t const vv = mulhi64_top32(b, 0xCF1BBCDCB7A56463ULL);
                     uint32_t const hL = vv >> shL, hS = hash_pos<MLS>(b, shS);
                     uint32_t const qL = DF_ENTRY(q, df_tag_long(vv)), qS = DF_ENTRY(q, df_tag_short((uint32_t)b));
-                    if (lane == 0) { tabL[hL] = qL; tabS[hS] = qS; }
+                    if (lane == 0 && !skipCurr2) { tabL[hL] = qL; tabS[hS] = qS; }   // (a carrying window has stored curr+2 itself)
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 1) tabL[hL] = qL;
                     if (lane == 2) tabS[hS] = qS;
@@ -523,6 +626,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
                 if ((int32_t)ip > ilimit) break;
             }
         }
+        ZWPROF_SYNC(out, 9);
     }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals
     lits_flush(out);
@@ -538,6 +642,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
         meta->rep[0] = off1 ? off1 : saved1; meta->rep[1] = off2 ? off2 : saved2; meta->rep[2] = repIn3;
         meta->status = 0; meta->litSize = out.litPos; meta->pad0 = 0;
     }
+    ZPROF_FLUSH(0);
 }
 
 // One unit = one block with fresh tables (tagged 17-bit entries)
