@@ -508,59 +508,38 @@ __device__ __forceinline__ uint32_t low_bit(uint32_t lo, uint32_t hi) { return l
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t pull(uint32_t v, uint32_t srcLane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), (int)v); }
 
-// EVENT CHAINS (round 3).  A window's cost used to be per EVENT and serial: a dependent load for the E masks of every new offset
-// (they carry the extension of the match AND the repcode probes that follow it) and ~250 wave-uniform instructions — which this
-// machine runs at 5-10 cycles each (a wavefront issues one instruction per ~4 cycles, a value that goes from a vector compare into a
-// scalar instruction waits ~20: scripts/ubench/issue.hip).  Dense-match data has five events per window.  Now:
-//   * every lane fetches 24 bytes around its own table candidate with the candidate gather itself (the same sectors) and resolves its
-//     own would-be match in the lane: backward up to 4 bytes, forward up to 16 (`info`);
-//   * the first event of a window is still found the exact way (its repcode probes use the masks the front loaded).  If it is a plain
-//     match a short scalar CHASE follows the chain of events it starts — next candidate lane at or after the end of the previous
-//     match, one v_readlane per hop — ASSUMING that no repcode check in between hits;
-//   * everything else about the events of the chain — match start, lengths, sequences, covered lanes, inserted lanes — is computed
-//     for ALL of them at once, each event in its own lane (four ds_bpermute in two rounds, no loop);
-//   * the assumption is checked afterwards: the lanes where the reference would have probed a repcode (zstd_fast.c:268) or checked
-//     the immediate repcode (:410), each with the offset valid at that point, are compared in ONE masked gather.  A hit is rare
-//     (repcodes are 1-3 % of the sequences); the window is then run again from its entry state the exact way — nothing of it has left
-//     the registers by then except sequence records that the exact pass overwrites;
-//   * a match that runs past lane 63 but whose end its lane knows needs no loads either: the next window starts two positions in
-//     front of that end (CARRY), so that the complementary insert of end-2 (:408) and the immediate-repcode check at the end are lanes
-//     0 and 2 of an ordinary window.
-#ifndef ZHIP_WIN_FAST
-#define ZHIP_WIN_FAST 0              /* 0: every event the exact way.  1: event chains — byte-identical, measured slower so far */
+// CARRY.  A match that runs past lane 63 hands its end to the NEXT window, which starts two positions in front of it: the complementary
+// insert of end-2 (zstd_fast.c:408) is lane 0 of an ordinary window, the immediate-repcode test (:410) bit 2 of its E2 mask; the insert of
+// cur0+2 (:407) is a lane of the window that found the match.  An immediate-repcode match that runs past lane 63 carries the same way
+// without the insert (carry 2: the test is due at lane 0).  Only where the next scan cannot be a window does the rest of :403-420 go by
+// loads (post_match_far).  (Round 3's event chains — every lane resolving its own would-be match from 24 candidate bytes, the chain's
+// repcode probes checked afterwards — were byte-identical and measured slower; the carry is what is left of them.)
+#ifndef ZHIP_FAST_PRELOAD
+#define ZHIP_FAST_PRELOAD 1          /* measurement switch: 0 = every window loads its own source bytes */
 #endif
-#ifndef ZHIP_FAST_TAIL
-#define ZHIP_FAST_TAIL 16u           /* a chain of one event: an unverified tail shorter than this is left to the next window instead of being verified by a load */
+struct FastPre { uint64_t c8; uint32_t v1, v2, B; };        // the next window's source bytes (B = ~0: none)
+#ifndef ZHIP_FAST_CARRY
+#define ZHIP_FAST_CARRY 1            /* measurement switch: 0 = never carry (every leaving match goes by loads), 1 = plain matches only, 2 = immediate repcodes too */
 #endif
-#define ZHIP_FAST_FWD 16u            /* forward bytes (beyond the 4 compared) a lane resolves on its own; this many = "or more" */
-#define ZHIP_WIN_EXT_NEED 84u        /* a window that resolves matches in the lanes reads up to 20 bytes beyond its last position */
-
 template <uint32_t MLS, typename TAB>
-__device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uint32_t nm8, uint32_t hshift, const TAB& T, FastOut& out,
+__device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uint32_t n, uint32_t nm8, uint32_t hshift, const TAB& T, FastOut& out,
                                             uint32_t& ip0_, uint32_t& anchor_, uint32_t& rep1_, uint32_t& rep2_, uint32_t& nextStep,
-                                            uint32_t prefixLow /* lowest valid match position (0 for a unit) */, uint32_t& carry_)
+                                            uint32_t prefixLow /* lowest valid match position (0 for a unit) */, uint32_t& carry_, FastPre& pre)
 {
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const B = ip0_;
     uint32_t const P = B + lane;
-    uint32_t const carryIn = carry_;                                      // the previous window's last match ended at B+2: lanes 0, 1 belong to it
+    uint32_t const carryIn = carry_;                                      // 1: the previous window's last match ended at B+2 (lanes 0, 1 belong to it); 2: it ended at B, the immediate-repcode test is due
     carry_ = 0;
-    if (carryIn) nextStep += 2;                                           // the scan starts at B+2
+    if (carryIn == 1) nextStep += 2;                                      // the scan starts at B+2
     if (out.pendLen) lits_flush(out);                                     // an earlier run's deferred store (and its spill) goes first
-    // the lanes' own bytes: P-4 .. P+19 when the window may resolve matches in the lanes (ext), else P .. P+7
-    bool ext = ZHIP_WIN_FAST && B >= 8u && B + ZHIP_WIN_EXT_NEED <= nm8 + 8u;
-    uint32_t o0 = 0, cur32, o2, o3 = 0, o4 = 0, o5 = 0;
-    if (ext) {
-        Quad const a = ld128(src + (P - 4)); uint64_t const b = ld64(src + (P + 12));
-        o0 = a.x; cur32 = a.y; o2 = a.z; o3 = a.w; o4 = (uint32_t)b; o5 = (uint32_t)(b >> 32);
-    } else {
-        uint64_t const c8 = ld64(src + P);
-        cur32 = (uint32_t)c8; o2 = (uint32_t)(c8 >> 32);
-    }
-    uint64_t const cur8 = (uint64_t)cur32 | ((uint64_t)o2 << 32);
-    // the bytes the two repcodes point at: loaded unconditionally (an invalid repcode, 0, reads the lane's own bytes) so that all the
-    // loads of the front are in flight together — a load inside a branch is waited for inside the branch
-    uint32_t const v1 = ld32(src + (P - rep1_)), v2 = ld32(src + (P - rep2_));       // a repcode offset never exceeds the position it is used at
+    // the lanes' own bytes and the bytes the two repcodes point at (an invalid repcode, 0, reads the lane's own bytes): the window before this
+    // one has usually requested them already (FastPre), else all three loads are in flight together
+    uint64_t cur8; uint32_t v1, v2;
+    if (ZHIP_FAST_PRELOAD && pre.B == B) { cur8 = pre.c8; v1 = pre.v1; v2 = pre.v2; }
+    else { cur8 = ld64(src + P); v1 = ld32(src + (P - rep1_)); v2 = ld32(src + (P - rep2_)); }     // a repcode offset never exceeds the position it is used at
+    pre.B = ~0u;
+    uint32_t const cur32 = (uint32_t)cur8;
     uint32_t const h = hash_pos<MLS>(cur8, hshift);
 
     // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
@@ -568,29 +547,12 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     uint32_t const myTag = fast_tag15(cur32);
     bool tagMaybe;
     uint32_t const old = tab_get_t(T, h, B > 65536, myTag, tagMaybe);
-    // candidates below position 8 cannot be read 4 bytes back (rare: only the first entries of a unit): such a window goes the exact way
-    if (ext && __ballot(old != 0 && old < 8u)) ext = false;
-    uint32_t cb, info = 0;                                                // info: bits 0-4 forward bytes, 5-7 backward bytes, 8 = the lane's candidate is the table's
-    if (ext) {
-        uint32_t const cbase = old ? old - 4 : 4u;                        // old == 0 reads harmless bytes; in flight during the duplicate detection below
-        Quad const c = ld128(src + cbase); uint64_t const d = ld64(src + cbase + 16);
-        cb = c.y;
-        uint32_t const xb = o0 ^ c.x;
-        uint32_t const back = xb ? (uint32_t)__clz((int)xb) >> 3 : 4u;
-        uint32_t f = same_lo(o5 ^ (uint32_t)(d >> 32));
-        {   uint32_t t;
-            t = same_lo(o4 ^ (uint32_t)d); f = t + (t == 4u ? f : 0u);
-            t = same_lo(o3 ^ c.w); f = t + (t == 4u ? f : 0u);
-            t = same_lo(o2 ^ c.z); f = t + (t == 4u ? f : 0u); }
-        info = f | (back << 5) | 0x100u;
-    } else {
-        // only the lanes whose tag agrees fetch their candidate's bytes (an empty slot or a different tag cannot match: zhip_parse.h, TAGS); the
-        // others all read the unit's first bytes — one line, one request — so that the load stays unconditional: a load inside a branch is
-        // waited for inside the branch (round 3), and this one has the duplicate detection below to hide behind
-        bool const fetch = old != 0 && tagMaybe;
-        cb = ld32(src + tab_guard(T, fetch ? old : 0u));
-        if (!fetch) cb = ~cur32;
-    }
+    // only the lanes whose tag agrees fetch their candidate's bytes (an empty slot or a different tag cannot match: zhip_parse.h, TAGS); the
+    // others all read the unit's first bytes — one line, one request — so that the load stays unconditional: a load inside a branch is
+    // waited for inside the branch (round 3), and this one has the duplicate detection below to hide behind
+    bool const fetch = old != 0 && tagMaybe;
+    uint32_t cb = ld32(src + tab_guard(T, fetch ? old : 0u));
+    if (!fetch) cb = ~cur32;
     uint32_t backId = lane;
     if constexpr (!TabTraits<TAB>::ballotGroups) {
         __builtin_amdgcn_wave_barrier();
@@ -643,23 +605,14 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     bool const hitOld = old != 0 && old >= prefixLow && cb == cur32;
     unsigned long long const M = __ballot(hitOld);
     uint32_t const x1 = rep1_ ? cur32 ^ v1 : 1u, x2 = rep2_ ? cur32 ^ v2 : 1u;
-    uint32_t const offv = P - old;                                        // the offset of a match with the table's candidate
-    uint32_t const lanesLo = lane < 32 ? (1u << lane) - 1u : ~0u, lanesHi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;   // the lanes below this one
     ZWPROF(out, 1);
 
-    uint32_t const nbSeq0 = out.nbSeq, longPos0 = out.longPos, longType0 = out.longType;
+    uint32_t const nbSeq0 = out.nbSeq;
     uint32_t const anchorEntry = anchor_;
-    uint32_t const nextStep0 = nextStep;
-    // a match that crosses lane 63 may hand its end to the next window only if that one is a window too
-#ifdef ZHIP_DBG_NOCARRY
-    uint32_t const carryMaxE = 64u;
-#else
-    uint32_t const carryMaxE = (B + 64u + ZHIP_FAST_FWD + 4u + ZHIP_WIN_NEED <= nm8 + 8u + 2u) ? 64u + ZHIP_FAST_FWD + 4u : 64u;   // e < this bound
-#endif
-    uint32_t evA = 0, evB = 0, nEv;                                       // event registers: sequence t of this window in lane t
-    unsigned long long INS, COV, DIRECT;                                  // DIRECT: sequence slots of this window already stored by a chain
-    uint32_t anchor, rep1, rep2, backBefore, sumLit, i;
-    int status;
+    uint32_t evA = 0, evB = 0, nEv = ~0u;                                 // event registers: sequence t of this window in lane t
+    unsigned long long INS = 0, COV = 0;
+    uint32_t anchor = anchor_, rep1 = rep1_, rep2 = rep2_, backBefore = 0, sumLit = 0, i = 0;
+    int status = ZW_RESTART;
 #define ZW_EMIT(ll, ob, ml) do { uint32_t const mb_ = (ml) - 3;                                                   \
         if (((ll) | mb_) > 0xFFFF) {                                                                              \
             if ((ll) > 0xFFFF) { out.longType = 1; out.longPos = out.nbSeq; }                                     \
@@ -674,34 +627,12 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         __builtin_amdgcn_wave_barrier();                                                                          \
         while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
         INS = 0; } while (0)
-
-    // pass 0 chains events where it can; if a deferred repcode check fails, pass 1 runs the window again the exact way
-    for (uint32_t pass = 0; ; pass++) {
-    bool const fastOn = ext && pass == 0;
-    bool failed = false;
-    anchor = anchor_; rep1 = rep1_; rep2 = rep2_; nextStep = nextStep0;
-    out.nbSeq = nbSeq0; out.longPos = longPos0; out.longType = longType0;
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
     unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
-    bool e1ok = true, e2ok = true;                                       // E1* / E2* hold the masks of rep1 / rep2
-    unsigned long long V = 0;                                            // lanes whose deferred repcode check is pending ...
-    uint32_t vOff = 0;                                                   // ... and the offset each is compared at
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
     // one by one after the others, in position order (a later member of a hash group overwrites an earlier one)
-    INS = 0; COV = 0; DIRECT = 0; nEv = ~0u; backBefore = 0; sumLit = 0; i = 0;
-    status = ZW_RESTART;
     int kLim;                                                             // iterations before the gap grows (:342-346), entry scan only
-    // exact masks for both repcodes + the verdict on every deferred check, in one round of loads; false: a deferred check failed
-#define ZW_RESOLVE() do {                                                                                        \
-        uint32_t xv_ = 1, xa_ = 1, xb_ = 1;                                                                       \
-        if (__builtin_amdgcn_inverse_ballot_w64(V)) xv_ = cur32 ^ ld32(src + (P - vOff));                          \
-        if (!e1ok && rep1 && P >= rep1) xa_ = cur32 ^ ld32(src + (P - rep1));                                      \
-        if (!e2ok && rep2 && P >= rep2) xb_ = cur32 ^ ld32(src + (P - rep2));                                      \
-        if (__ballot(xv_ == 0) & V) failed = true;                                                                 \
-        if (!e1ok) { E1q = __ballot(xa_ == 0); E1b = __ballot((xa_ & 0xFFu) == 0); e1ok = true; }                  \
-        if (!e2ok) { E2q = __ballot(xb_ == 0); E2b = __ballot((xb_ & 0xFFu) == 0); e2ok = true; }                  \
-        V = 0; } while (0)
-    // :410-420 at lane e_ with exact masks; leaves e_ at the end of the last immediate repcode
+    // :410-420 at lane e_; leaves e_ at the end of the last immediate repcode
 #define ZW_IMMEDIATE(e_) do {                                                                                    \
         uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, (e_) + 4, rep2);                                         \
         {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }                                                      \
@@ -711,28 +642,32 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t const en = (e_) + rl;                                                                             \
         COV |= en < 64 ? (lanes_from(e_) & lanes_below(en)) : lanes_from(e_);                                      \
         (e_) = en; anchor = B + (e_); } while ((e_) < 64 && ((E2q >> (e_)) & 1))
-    // the repcode loop went on beyond the window: continue it by loads (the table must be up to date for its inserts)
-#define ZW_POST_FAR(cur0_, first_) do {                                                                          \
-        nEv = out.nbSeq - nbSeq0;                                                                                  \
-        ZW_TABLE_FLUSH();                                                                                          \
-        uint32_t ip0n = anchor;                                                                                    \
-        if (ip0n <= nm8) {                                                                                         \
-            PostState ps; ps.ip0 = ip0n; ps.anchor = anchor; ps.rep1 = rep1; ps.rep2 = rep2; ps.nbSeq = out.nbSeq; ps.longPos = out.longPos; ps.longType = out.longType; \
-            ps = post_match_far<MLS, TAB>(src, nm8, hshift, T, out.seqs, ps, (cur0_), (first_));                  \
-            ip0n = ps.ip0; anchor = ps.anchor; rep1 = ps.rep1; rep2 = ps.rep2; out.nbSeq = ps.nbSeq; out.longPos = ps.longPos; out.longType = ps.longType; \
-        }                                                                                                          \
-        i = ip0n - B; } while (0)
+    // the scan left the window behind a match that ended at lane e_ (>= 64; anchor = B + e_): the next window takes it over (kind_ 1: it
+    // starts at the end - 2 and inserts that position, 2: at the end of an immediate repcode), or — no room for a window — :403-420 go by loads
+#define ZW_LEAVE(e_, kind_, cur0_) do {                                                                          \
+        if (ZHIP_FAST_CARRY >= (kind_) && B + (e_) - ((kind_) == 1 ? 2u : 0u) + ZHIP_WIN_NEED <= n) {              \
+            i = (e_) - ((kind_) == 1 ? 2u : 0u); carry_ = (kind_);                                                 \
+        } else {                                                                                                   \
+            nEv = out.nbSeq - nbSeq0;                                                                              \
+            ZW_TABLE_FLUSH();                                                                                      \
+            uint32_t ip0n = anchor;                                                                                \
+            if (ip0n <= nm8) {                                                                                     \
+                PostState ps; ps.ip0 = ip0n; ps.anchor = anchor; ps.rep1 = rep1; ps.rep2 = rep2; ps.nbSeq = out.nbSeq; ps.longPos = out.longPos; ps.longType = out.longType; \
+                ps = post_match_far<MLS, TAB>(src, nm8, hshift, T, out.seqs, ps, (cur0_), (kind_) == 1);           \
+                ip0n = ps.ip0; anchor = ps.anchor; rep1 = ps.rep1; rep2 = ps.rep2; out.nbSeq = ps.nbSeq; out.longPos = ps.longPos; out.longType = ps.longType; \
+            }                                                                                                      \
+            i = ip0n - B; } } while (0)
     {   int32_t const d = (int32_t)(nextStep - B) - 4;
         kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
     if (carryIn) {
-        // lanes 0 and 1 are the last two bytes of the previous window's last match: its second complementary insert (:408) is lane 0,
-        // its immediate-repcode check (:410) is lane 2 — with exact masks, the front loaded them for the repcodes that match left
-        INS = 1ull; i = 2;                                           // (lanes 0, 1 are not literals: masked out at the end, they lie in front of the anchor)
-        if (rep2 && ((E2q >> 2) & 1)) {
-            uint32_t e = 2;
+        // carry 1: lanes 0 and 1 are the last two bytes of the previous window's last match: its second complementary insert (:408) is lane 0,
+        // its immediate-repcode test (:410) is lane 2; carry 2: the test is lane 0.  The front loaded exact masks for the repcodes that match left
+        if (carryIn == 1) { INS = 1ull; i = 2; }                     // (lanes 0, 1 are not literals: masked out at the end, they lie in front of the anchor)
+        if (rep2 && ((E2q >> i) & 1)) {
+            uint32_t e = i;
             ZW_IMMEDIATE(e);
             i = e; nextStep = B + e + 128;
-            if (e >= 64) { ZW_POST_FAR(0, false); goto window_done; }
+            if (e >= 64) { ZW_LEAVE(e, 2u, 0u); goto window_done; }
         }
         {   int32_t const d = (int32_t)(nextStep - (B + i)) - 4;           // a fresh scan: 64 iterations before the gap grows
             kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
@@ -748,7 +683,6 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         unsigned long long const span = ZHIP_SBFM64(hiLane - i, i);
         unsigned long long Me = M;
         uint32_t candSel = old;
-        uint32_t infoSel = info;
         if (NF) {
             // a member of a hash group is inserted when the scan from i reaches it before the lane in question (every lane from i on
             // is, as long as no event intervenes — and the first event is what is being looked for), or when INS already holds it
@@ -756,30 +690,13 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             bool const in1 = depth >= 1 && ((insE >> p1) & 1), in2 = depth >= 2 && ((insE >> p2) & 1);
             bool const hit = in1 ? (m1 != 0) : (in2 ? (m2 != 0) : hitOld);
             candSel = in1 ? B + p1 : (in2 ? B + p2 : old);
-            if (in1 || in2) infoSel = 0;                                  // a candidate inside the window: not resolved in the lane
             Me = __ballot(hit);
         }
         unsigned long long const MM = Me & span;
         unsigned long long const parity = (i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
-        // the repcode probes of this scan: exact when E1* is (after a chain it is not: the events that follow get exact masks first)
-        unsigned long long const RP = e1ok ? (E1q & parity & (span << 2)) : 0ull;
+        unsigned long long const RP = E1q & parity & (span << 2);         // the repcode probes of this scan
         uint32_t const jm = ff1u(MM), jr = ff1u(RP);
-        if (!e1ok && rep1 && (int32_t)jm >= 0) {
-            // an event after a chain: settle the chain's deferred checks and this scan's own probes, get exact masks, look again
-            unsigned long long const VM = parity & ZHIP_SBFM64(((jm - i) & ~1u) + 1u, i + 2);
-            if (__builtin_amdgcn_inverse_ballot_w64(VM)) vOff = rep1;
-            V |= VM;
-            ZWPROF_COUNT(out, 14, 1);
-            ZW_RESOLVE();
-            if (failed) break;
-            // all probes up to the match were just verified negative: the match at jm stands (isRep below is 0: jr is empty)
-        }
         if ((int32_t)(jm & jr) < 0) {                                     // neither
-            if (!e1ok && rep1) {                                          // the tail of a chain: its probes join the deferred checks
-                unsigned long long const VM = parity & (span << 2);
-                if (__builtin_amdgcn_inverse_ballot_w64(VM)) vOff = rep1;
-                V |= VM;
-            }
             INS |= span;
             i = hiLane;
             status = (Kw == kLim) ? ZW_INC : ZW_CONT;
@@ -793,143 +710,6 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t const c = __builtin_amdgcn_readlane(candSel, (int)j);
         uint32_t const room = B + j - anchor;
         uint32_t const limit = isRep ? 1u : (room < c - prefixLow ? room : c - prefixLow);        // :271 / :387 (match0 > prefixStart)
-        if (fastOn && !isRep && e1ok && room <= 0xFFFFu) {
-            uint32_t const inf0 = __builtin_amdgcn_readlane(infoSel, (int)j);
-            uint32_t const fl0 = inf0 & 31u, braw0 = (inf0 >> 5) & 7u;
-            uint32_t const e0 = j + 4 + fl0;
-            bool const immHit = rep1 != 0 && e0 < 64u && ((E1q >> e0) & 1);       // the immediate repcode after this match would hit (rep2 = today's rep1)
-            if ((inf0 & 0x100u) && fl0 < ZHIP_FAST_FWD && (braw0 < 4u || limit <= 4u) && e0 < carryMaxE && !immHit) {
-                // ================= a CHAIN of events starts at lane j =================
-                // ---- the chase: J collects the event lanes, s is the scan position behind the last one
-                unsigned long long J = 1ull << j;
-                uint32_t s = e0, jLast = j, hiT = 0;
-                int mode = 0;                                             // how the chain ends: 0 at s (nothing searchable / an event for the exact code), 1 = scan ran out (tail to hiT), 2 = crossing
-                unsigned long long insSoFar = INS | ZHIP_SBFM64(j + 3 - i, i) | (1ull << ((e0 - 2) & 63));   // what the NF lanes ahead need to know
-                for (;;) {
-                    if (s >= 64u) { mode = 2; break; }
-#ifdef ZHIP_DBG_CHAIN1
-                    break;
-#endif
-                    uint32_t const Dc = ff1u(DEEP & lanes_from(s));
-                    int const Kc = ((int)Dc - (int)s) >> 1;
-                    if (Kc <= 0) break;
-                    uint32_t const hiC = s + 2u * (uint32_t)Kc;
-                    unsigned long long const spanC = ZHIP_SBFM64(hiC - s, s);
-                    unsigned long long MeC = M;
-                    uint32_t infoC = info;
-                    if (NF & spanC) {
-                        unsigned long long const insE = insSoFar | lanes_from(s);
-                        bool const in1 = depth >= 1 && ((insE >> p1) & 1), in2 = depth >= 2 && ((insE >> p2) & 1);
-                        bool const hit = in1 ? (m1 != 0) : (in2 ? (m2 != 0) : hitOld);
-                        if (in1 || in2) infoC = 0;
-                        MeC = __ballot(hit);
-                    }
-                    uint32_t const jn = ff1u(MeC & spanC);
-                    if ((int32_t)jn < 0) { mode = 1; hiT = hiC; break; }
-                    uint32_t const infn = __builtin_amdgcn_readlane(infoC, (int)jn);
-                    uint32_t const fln = infn & 31u, en = jn + 4 + fln;
-                    if (!((infn & 0x100u) && fln < ZHIP_FAST_FWD && (((infn >> 5) & 7u) < 4u || jn - s <= 4u) && en < carryMaxE)) break;
-                    J |= 1ull << jn;
-                    insSoFar |= ZHIP_SBFM64(jn + 3 - s, s) | (1ull << ((en - 2) & 63));
-                    jLast = jn; s = en;
-                }
-                bool trim = false;
-                if (mode == 1 && J == (1ull << j) && hiT - s < ZHIP_FAST_TAIL) { mode = 0; trim = true; ZWPROF_COUNT(out, 15, 1); }   // one event, short tail: leave the tail to the next window
-                // ---- every event of the chain in its own lane (straight-line code: flags are 0/1 words, no branches)
-                uint32_t const Jlo = (uint32_t)J, Jhi = (uint32_t)(J >> 32);
-                uint32_t const selfLo = lane < 32 ? 1u << lane : 0u, selfHi = lane < 32 ? 0u : 1u << (lane - 32);
-                uint32_t const isEv = ((Jlo & selfLo) | (Jhi & selfHi)) ? 1u : 0u;
-                uint32_t const bLo = Jlo & lanesLo, bHi = Jhi & lanesHi;             // events below this lane
-                uint32_t const hasP = (bLo | bHi) ? 1u : 0u;
-                uint32_t const jp = hasP ? top_bit(bLo, bHi) : 0u;
-                uint32_t const rank = (uint32_t)__popc(bLo) + (uint32_t)__popc(bHi);
-                uint32_t const flL = info & 31u, brawL = (info >> 5) & 7u;
-                uint32_t const endL = lane + 4 + flL;                                // where my match would end
-                uint32_t const endP = pull(endL, jp), offP = pull(offv, jp);         // round 1: the event before this lane
-                int32_t const aPrev = hasP ? (int32_t)endP : (int32_t)(anchor - B);  // where the literals in front of my match start
-                uint32_t const sPrev = hasP ? endP : i;                              // where the scan that found me started
-                uint32_t const roomL = (uint32_t)((int32_t)lane - aPrev);
-                uint32_t const limL = umin32(roomL, old - prefixLow);
-                uint32_t const backL = umin32(brawL, limL);
-                int32_t const startL = (int32_t)lane - (int32_t)backL;
-                if (isEv) {
-                    ZhipSeq q; q.offBase = offv + 3; q.litLength = (uint16_t)(roomL - backL); q.mlBase = (uint16_t)(1 + backL + flL);
-                    out.seqs[out.nbSeq + rank] = q;
-                }
-                // round 2: the start of the next event (its backward extension takes literals away), and what the event before me
-                // knew about ITS predecessor (offset | parity of its scan start << 31) for the deferred checks that use that offset
-                uint32_t const aLo = Jlo & ~lanesLo & ~selfLo, aHi = Jhi & ~lanesHi & ~selfHi;
-                uint32_t const hasN = (aLo | aHi) ? 1u : 0u;
-                uint32_t const jn2 = hasN ? low_bit(aLo, aHi) : 0u;
-                int32_t const startN = (int32_t)pull((uint32_t)startL, jn2);
-                uint32_t const kn = (hasP ? offP : 0u) | (sPrev << 31);              // (first event of the chain: no deferred check uses it)
-                uint32_t const knP = pull(kn, jp);
-                uint32_t const offPP = knP & 0x7FFFFFFFu;                            // the offset of the event before my predecessor
-                // owner of this lane = the last event at or below it
-                uint32_t const hasW = isEv | hasP;
-                uint32_t const wL = isEv ? lane : jp, endW = isEv ? endL : endP;
-                uint32_t const inSpan = hasW & (lane < endW ? 1u : 0u);
-                uint32_t const cov = inSpan | (hasN & ((int32_t)lane >= startN ? 1u : 0u));
-                uint32_t const tail1 = mode == 1 ? 1u : 0u;
-                uint32_t const lastX = (mode == 2 && wL == jLast) ? 1u : 0u;          // my owner is a crossing match: the next window inserts its end - 2
-                uint32_t const insIn = (lane <= wL + 2 ? 1u : 0u) | ((lane + 2 == endW ? 1u : 0u) & (lastX ^ 1u));
-                uint32_t const insOut = (lane >= (hasW ? endW : i) ? 1u : 0u) & (hasN | (tail1 & (lane < hiT ? 1u : 0u)));
-                uint32_t const ins = inSpan ? insIn : insOut;
-                // deferred checks.  Probes of the scan behind event w (= jp for a lane that is no event): lanes endW+2, +4 .. up to the lane of
-                // the next event (which, an event lane itself, takes the same rule), and up to hiT behind the last event; offset = w's.
-                // Probe inside the span of event w, by the scan that FOUND w: lane w+2 or w+1 (parity of that scan's start), offset = the
-                // event before w's; not for the chain's first event (exact).  Immediate check where event w ended: offset = the event
-                // before w's; not for the chain's first event either (checked above).
-                uint32_t const pFirst = jp == j ? 1u : 0u;                           // my predecessor is the chain's first event
-                uint32_t const even = ((lane - endP) & 1u) ^ 1u;                     // same parity as the scan that started where my predecessor ended
-                uint32_t const behind = hasP & (lane >= endP + 2 ? 1u : 0u) & even & (isEv | hasN | (tail1 & (lane <= hiT ? 1u : 0u)));
-                uint32_t const atEnd = hasP & (lane == endP ? 1u : 0u) & (pFirst ^ 1u);
-                uint32_t const inside = (isEv ^ 1u) & hasP & (lane < endP ? 1u : 0u) & (pFirst ^ 1u) & (lane == jp + 2 - ((jp - (knP >> 31)) & 1u) ? 1u : 0u);
-                uint32_t const role = behind | atEnd | inside;
-                uint32_t const myOff = behind ? offP : offPP;
-                unsigned long long const VMc = __ballot(role && myOff != 0);
-                vOff = role ? myOff : vOff;
-                V |= VMc;
-                // ---- back to the wave-uniform state
-                uint32_t const cnt = (uint32_t)__builtin_popcountll(J);
-                unsigned long long const covM = __ballot(cov), insM = __ballot(ins);
-                int32_t const start0 = (int32_t)__builtin_amdgcn_readlane((uint32_t)startL, (int)j);
-                int32_t const startZ = (int32_t)__builtin_amdgcn_readlane((uint32_t)startL, (int)jLast);
-                uint32_t const endZ = __builtin_amdgcn_readlane(endL, (int)jLast);
-                uint32_t const offZ = __builtin_amdgcn_readlane(offv, (int)jLast);
-                uint32_t const offY = cnt >= 2 ? __builtin_amdgcn_readlane(offP, (int)jLast) : rep1;
-                uint32_t const bb = start0 < 0 ? (uint32_t)(-start0) : 0u;
-                if (bb) backBefore = bb;
-                // literals the chain's sequences carry = everything between the entry anchor and the last match's start that no match covers
-                {   uint32_t const upto = startZ > 0 ? (uint32_t)startZ : 0u;
-                    unsigned long long below = upto < 64 ? lanes_below(upto) : ~0ull;
-                    if ((int32_t)(anchorEntry - B) > 0) below &= lanes_from(anchorEntry - B);             // a carried window: lanes 0, 1 lie in front of the anchor
-                    uint32_t const covered = (uint32_t)__builtin_popcountll((COV | covM) & below) + (startZ >= 0 ? backBefore : 0u);   // (bytes a match took back in front of lane 0)
-                    uint32_t const total = (uint32_t)(startZ - (int32_t)(anchorEntry - B));       // bytes from the entry anchor to the last match's start
-                    sumLit = total - covered; }
-                DIRECT |= ZHIP_SBFM64(cnt, out.nbSeq - nbSeq0);
-                out.nbSeq += cnt;
-                COV |= covM; INS |= insM;
-                rep2 = offY; rep1 = offZ; e1ok = false; e2ok = (cnt == 1);
-                if (cnt == 1) { E2q = E1q; E2b = E1b; }
-                anchor = B + endZ;
-                ZWPROF_COUNT(out, 12, cnt);
-#ifdef ZHIP_DBG_PRINT
-                if (lane == 0) printf("chain B=%u i=%u J=%llx mode=%d trim=%d s=%u jLast=%u endZ=%u startZ=%d off=%u/%u V=%llx INS=%llx COV=%llx nbSeq=%u sumLit=%u\n", B, i, J, mode, (int)trim, s, jLast, endZ, startZ, offZ, offY, V, INS, COV, out.nbSeq, sumLit);
-#endif
-                if (mode == 2) {                                          // the last match crossed lane 63: the next window starts at its end - 2
-                    i = endZ - 2; carry_ = 1;
-                    break;
-                }
-                kLim = 64; nextStep = B + endZ + 128;                     // _start: a fresh scan behind the last match
-                if (mode == 1) { i = hiT; status = ZW_CONT; break; }
-                i = endZ;
-                if (trim) break;                                          // ZW_RESTART at the end of the match
-                ZWPROF(out, 4);
-                continue;
-            }
-        }
-        // ---- exact event
         uint32_t const off = isRep ? rep1 : B + j - c;
         // lanes i .. j are inserted (hash0 = ip0); a repcode is found at ip2 = j, i.e. up to j-1 = ip1 (:283); a match
         // also inserts ip1 = j+1 (:296, :323 step <= 4)
@@ -959,9 +739,10 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t e = j + 4 + fl;
         anchor = B + e;
         uint32_t const cur0L = j - 2 * isRep;
-        if (e >= 64) {                                                    // ran past the window: :403-420 by loads
+        if (e >= 64) {                                                    // ran past the window
             COV |= lanes_from(sL);
-            ZW_POST_FAR(B + cur0L, true);
+            ZW_LEAVE(e, 1u, B + cur0L);
+            if (carry_) INS |= 1ull << (cur0L + 2);                       // :407 is a lane of this window (cur0L <= 59); :408 and :410 are the next window's lanes 0 and 2
             ZWPROF(out, 9);
             break;
         }
@@ -969,45 +750,41 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         INS |= (1ull << (cur0L + 2)) | (1ull << (e - 2));                 // :407-408 (ip0 <= ilimit inside a window)
         if (rep2 && ((E2q >> e) & 1)) {                                   // :410-420
             ZW_IMMEDIATE(e);
-            if (e >= 64) { ZW_POST_FAR(0, false); break; }
+            if (e >= 64) { ZW_LEAVE(e, 2u, 0u); break; }
         }
         i = e;
         kLim = 64; nextStep = B + e + 128;                                // _start: a fresh scan inside the window
         ZWPROF(out, 4);
     }
 window_done:
-    // deferred checks still open at the end of the scan (nothing of the window has been written yet but sequence records)
-    if (!failed && V) {
-        ZWPROF_COUNT(out, 14, 1);
-        uint32_t xv = 1;
-        if (__builtin_amdgcn_inverse_ballot_w64(V)) xv = cur32 ^ ld32(src + (P - vOff));
-        if (__ballot(xv == 0) & V) failed = true;
-        V = 0;
-    }
-#undef ZW_RESOLVE
 #undef ZW_IMMEDIATE
-#undef ZW_POST_FAR
-    if (!failed) break;
-    carry_ = 0;
-    ZWPROF_COUNT(out, 13, 1);
-    }
+#undef ZW_LEAVE
     ZWPROF(out, 2);
 #undef ZW_EMIT
 #ifdef ZHIP_DBG_PRINT
-    if (lane == 0) printf("  window B=%u carry=%u ext=%d -> i=%u status=%d INS=%llx NF=%llx COV=%llx nbSeq=%u rep=%u/%u anchor=%u carryOut=%u\n", B, carryIn, (int)ext, i, status, INS, NF, COV, out.nbSeq, rep1, rep2, anchor, carry_);
+    if (lane == 0) printf("  window B=%u carry=%u -> i=%u status=%d INS=%llx NF=%llx COV=%llx nbSeq=%u rep=%u/%u anchor=%u carryOut=%u\n", B, carryIn, i, status, INS, NF, COV, out.nbSeq, rep1, rep2, anchor, carry_);
 #endif
+    if (ZHIP_FAST_PRELOAD) {
+        // the next window's source bytes, requested before this window's stores; unconditional (a load inside a branch is waited for inside
+        // the branch): without a next window the lanes read their own bytes again
+        bool const nxt = status != ZW_INC && B + i + ZHIP_WIN_NEED <= n;
+        uint32_t const q = (nxt ? B + i : B) + lane;
+        pre.c8 = ld64(src + q);
+        pre.v1 = ld32(src + (q - (nxt ? rep1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? rep2 : 0u)));
+        pre.B = nxt ? B + i : ~0u;
+    }
     ZW_TABLE_FLUSH();
 #undef ZW_TABLE_FLUSH
-    // its sequences (those of a chain are in place already)
+    // its sequences
     if (nEv == ~0u) nEv = out.nbSeq - nbSeq0;
-    if (lane < nEv && !((DIRECT >> lane) & 1)) {
+    if (lane < nEv) {
         ZhipSeq q; q.offBase = evA; q.litLength = (uint16_t)evB; q.mlBase = (uint16_t)(evB >> 16);
         out.seqs[nbSeq0 + lane] = q;
     }
     {   // its literals: the lanes behind the new scan position that no match covers (the tail after the last match is
         // tentative: a later backward extension may take it back, its bytes are then simply overwritten)
         unsigned long long LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
-        if (carryIn) LIT &= ~3ull;
+        if (carryIn == 1) LIT &= ~3ull;
         if (__builtin_amdgcn_inverse_ballot_w64(LIT)) {
             uint32_t const before = __builtin_amdgcn_mbcnt_hi((uint32_t)(COV >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)COV, 0));
             out.lits[out.litPos + (B - anchorEntry) + lane - before - backBefore] = (uint8_t)cur8;
@@ -1052,6 +829,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
     uint32_t carry = 0;                     // a window handed the end of its last match to the next one (see window_batch)
+    FastPre pre; pre.c8 = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;
     bool have = false;                      // `cur` already holds the bytes of the batch that starts at ip0
     FastBatch cur; cur.bytes = 0; cur.rcur = 0; cur.rv = 0;
     for (;;) {                                                               // one turn per `_start`
@@ -1066,7 +844,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
         dense = true;                            // schedule-shaped batches (cheaper per position when events are far apart)
         for (;;) {
             if (dense && stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
-                int const st = window_batch<MLS, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep, prefixLow, carry);
+                int const st = window_batch<MLS, TAB>(src, n, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep, prefixLow, carry, pre);
                 have = false;
                 ZPROF_COUNT(10, 1);
                 if (st == ZW_RESTART) { evKind = 3; break; }
@@ -1075,7 +853,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
                 continue;
             }
             if (!have) cur = batch_load(src, nm8, ip0, posOff, rposOff, rep1);
-            have = false;
+            have = false; pre.B = ~0u;
             // iterations this batch covers: iteration k+1 runs iff A_{k+2}+1 < ilimit (:347); the gap grows after the
             // iteration whose A_{k+2} reaches nextStep (:342-346) — a batch ends there
             uint32_t const pos = ip0 + posOff, rpos = ip0 + rposOff;
