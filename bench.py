@@ -618,8 +618,11 @@ def frames_leg(zstd_amd, local, host, level):
         outs = ctx.compress_frames(bufs, level)
         best = min(best, ctx.timing()["entropy_ms"])
     ctx.close()
+    algo = nf * fsz + sum(len(o) for o in outs)
     res = {"value": round(nf * fsz / best / 1e3, 1), "unit": "MB/s", "frames": nf, "frame_bytes": fsz, "level": level,
            "kernel_ms": round(best, 3), "ratio": round(nf * fsz / sum(len(o) for o in outs), 4),
+           "roofline": {"bound": "hbm", "kernel": "k_frame_fast", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(best, 3)},
            "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain), two per CU; fidelity mode, never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
@@ -681,6 +684,8 @@ def job_pool_leg(zstd_amd, local, host, level):
     except Exception as e:                                       # noqa: BLE001
         dec = {"error": str(e)}
     res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
+           "roofline": {"bound": "hbm", "kernel": "k_frame_fast (job table)", "achieved": round((n + len(out)) / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((n + len(out)) / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(n + len(out)), "avg_launch_ms": round(best, 3)},
            "end_to_end": {"value": round(n / wall / 1e6, 1), "unit": "MB/s", "same_bytes": same,
                           "path": "zhip_compress_frames_mt from pageable host memory: blocking H2D, kernels, D2H on one context; PCIe-inclusive, never `value`"},
            "ratio": round(n / len(out), 4), "decode": dec,
@@ -753,6 +758,232 @@ def prediction_leg(zstd_amd, local, host):
             lo.zo_set_row_matcher(0)
     except Exception as e:                                       # noqa: BLE001
         res["error"] = str(e)
+    return res
+
+
+def plugin_leg(zstd_amd, local, host, level):
+    """Boundary B1 at the headline's size: zhip_prepare_sequences parses every 128 KB block of the workload on the device in ONE batch, then the REAL
+    reference (oracle/_ref/libzstd_ref.so) compresses the same buffer with zhip_sequence_producer registered (ZSTD_registerSequenceProducer,
+    lib/zstd.h:2866; contrib/externalSequenceProducer/main.c:38-49 shape) — its own entropy stage on N host threads, one CCtx and one shard of whole
+    blocks each (a CCtx with a producer cannot use nbWorkers, lib/compress/zstd_compress.c:7180).  Reported: MB/s of prepare + compress, the device
+    part's roofline at S + 16 * nbSeq, round trip through the reference's decoder, and sequence-level equality of every block with
+    ZSTD_generateSequences of the reference on that block (full size).  Never `value`."""
+    zpath = os.path.join(ROOT, "oracle", "_ref", "libzstd_ref.so")
+    if not os.path.exists(zpath):
+        return {"skipped": "oracle/_ref/libzstd_ref.so absent (built from /root/reference by oracle/Makefile)"}
+    import threading
+    Z = C.CDLL(zpath)
+    Z.ZSTD_createCCtx.restype = C.c_void_p
+    Z.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    Z.ZSTD_CCtx_setParameter.restype = C.c_size_t; Z.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    Z.ZSTD_registerSequenceProducer.restype = None; Z.ZSTD_registerSequenceProducer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    Z.ZSTD_compress2.restype = C.c_size_t; Z.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    Z.ZSTD_decompress.restype = C.c_size_t; Z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    Z.ZSTD_isError.restype = C.c_uint; Z.ZSTD_isError.argtypes = [C.c_size_t]
+    Z.ZSTD_compressBound.restype = C.c_size_t; Z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    BLK = 65536            # ZSTD_c_maxBlockSize below 128 KB: the reference then asks for exactly these blocks (at 128 KB it splits some at 92 KB, zstd_compress.c:4494-4518)
+    n = len(host) // BLK * BLK
+    a = np.ascontiguousarray(host[:n])
+    units = n // BLK
+    nthr = max(1, min(64, os.cpu_count() or 1, units))
+    per = (units + nthr - 1) // nthr * BLK                              # whole blocks per shard: every callback's block is one prepared block
+    shards = [(o, min(per, n - o)) for o in range(0, n, per)]
+    L = zstd_amd.lib()
+    ctx = zstd_amd.Context(local, max_units=units)
+    fn = C.cast(L.zhip_sequence_producer, C.c_void_p)
+    base = a.ctypes.data
+    dsts = [np.empty(int(Z.ZSTD_compressBound(ln)), dtype=np.uint8) for _, ln in shards]
+    sizes = [0] * len(shards)
+
+    def work(i):
+        o, ln = shards[i]
+        cctx = Z.ZSTD_createCCtx()
+        Z.ZSTD_CCtx_setParameter(cctx, 100, level)                      # ZSTD_c_compressionLevel
+        Z.ZSTD_CCtx_setParameter(cctx, 1015, BLK)                       # ZSTD_c_maxBlockSize: the blocks the producer is asked for are the prepared ones
+        Z.ZSTD_CCtx_setParameter(cctx, 1009, 1)                         # ZSTD_c_validateSequences
+        Z.ZSTD_registerSequenceProducer(cctx, ctx._h, fn)
+        sizes[i] = Z.ZSTD_compress2(cctx, dsts[i].ctypes.data, dsts[i].nbytes, base + o, ln)
+        Z.ZSTD_freeCCtx(cctx)
+
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = L.zhip_prepare_sequences(ctx._h, C.c_void_p(base), n, BLK, level)
+        t1 = time.perf_counter()
+        if L.zhip_isError(r):
+            ctx.close()
+            return {"error": "zhip_prepare_sequences failed"}
+        dev_ms = ctx.timing()["parse_ms"]
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(shards))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        t2 = time.perf_counter()
+        cur = {"prepare_s": t1 - t0, "compress_s": t2 - t1, "device_parse_ms": dev_ms}
+        if best is None or cur["prepare_s"] + cur["compress_s"] < best["prepare_s"] + best["compress_s"]:
+            best = cur
+    if any(Z.ZSTD_isError(x) for x in sizes):
+        ctx.close()
+        return {"error": "ZSTD_compress2 with the producer registered failed"}
+    st = ctx.stats()
+    csize = int(sum(sizes))
+    # round trip through the reference's decoder, every shard
+    ok_rt = True
+    back = np.empty(per, dtype=np.uint8)
+    for (o, ln), d, k in zip(shards, dsts, sizes):
+        got = Z.ZSTD_decompress(back.ctypes.data, ln, d.ctypes.data, k)
+        ok_rt = ok_rt and got == ln and bool(np.array_equal(back[:ln], a[o:o + ln]))
+    # sequence-level equality, full size: the device's (litLength, matchLength, offset) of every block against ZSTD_generateSequences of the
+    # reference on that block alone (a dedicated CCtx per call: oracle/ref_shim.c zref_sequences), compared as one SHA-256 over all blocks
+    seq_eq = None
+    shim = os.path.join(ROOT, "oracle", "_ref", "libzref_shim.so")
+    if os.path.exists(shim):
+        try:
+            R = C.CDLL(shim)
+            R.zref_sequences.restype = C.c_size_t
+            R.zref_sequences.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            hg, hr = hashlib.sha256(), hashlib.sha256()
+            cap = BLK // 3 + 16
+            ref_blocks = [None] * units
+
+            def refwork(lo_, hi_):
+                buf = np.zeros((cap, 4), dtype=np.uint32)
+                for u in range(lo_, hi_):
+                    k = R.zref_sequences(level, base + u * BLK, BLK, buf.ctypes.data, cap)
+                    ref_blocks[u] = buf[:k, :3].copy()
+            tw = max(1, min(64, os.cpu_count() or 1))
+            th = [threading.Thread(target=refwork, args=(units * t // tw, units * (t + 1) // tw)) for t in range(tw)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for u in range(units):
+                g = ctx.get_sequences(u, cap=cap)
+                hg.update(np.ascontiguousarray(g[:, :3]).tobytes()); hr.update(np.ascontiguousarray(ref_blocks[u]).tobytes())
+            seq_eq = hg.hexdigest() == hr.hexdigest()
+        except Exception as e:                                       # noqa: BLE001
+            seq_eq = "not checked: " + str(e)
+    ctx.close()
+    tot_s = best["prepare_s"] + best["compress_s"]
+    algo = n + 16 * int(st["sequences"])
+    return {"value": round(n / tot_s / 1e6, 1), "unit": "MB/s", "level": level, "source_bytes": int(n), "blocks": int(units), "block_bytes": BLK, "host_threads": len(shards),
+            "ratio": round(n / csize, 4), "prepare_MBps": round(n / best["prepare_s"] / 1e6, 1), "reference_entropy_stage_MBps": round(n / best["compress_s"] / 1e6, 1),
+            "prepare_ms": round(best["prepare_s"] * 1e3, 2), "compress_ms": round(best["compress_s"] * 1e3, 2),
+            "roofline": {"bound": "hbm", "kernel": "match finder stage of zhip_prepare_sequences (k_parse_fast_q/_g)", "achieved": round(algo / (best["device_parse_ms"] * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (best["device_parse_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(best["device_parse_ms"], 3)},
+            "parity": {"roundtrip_through_reference_decoder": bool(ok_rt), "sequences_equal_ZSTD_generateSequences_full_size": seq_eq},
+            "path": "zhip_prepare_sequences (pageable H2D, match finder, one packed D2H of the sequences, host fingerprints) + ZSTD_compress2 of the real reference with "
+                    "zhip_sequence_producer registered, one CCtx per shard of whole blocks on that many host threads; PCIe-inclusive, never `value`"}
+
+
+def strong_text_leg(args, torch, zstd_amd, dev, local, rank, world, dist):
+    """BASELINE configs[3] as north_star words it: a FIXED total (10^9 B of text, --total-bytes) cut into one shard of whole 128 KB units per rank,
+    every rank compresses its shard on its own GPU and copies its frames straight to its offset of ONE host buffer (a shared-memory segment: the
+    host-side gather is the D2H itself, the offsets come from an all_gather of the shard sizes) — no data-path collective.  One step = compress +
+    size exchange + gather, max over ranks.  Parity per rank: SHA-256 of its stream against the real reference's stream of its shard; rank 0 also
+    reports the SHA-256 of the gathered stream (tests/test_gpu_multi.py compares it with a single-process run).  Returns the object on rank 0."""
+    from multiprocessing import shared_memory
+    from zstd_amd import workloads as W
+    total = int(args.total_bytes) if args.total_bytes else 1_000_000_000
+    units_total = (total + UNIT - 1) // UNIT
+    per = (units_total + world - 1) // world * UNIT
+    lo, hi = min(total, rank * per), min(total, (rank + 1) * per)
+    n = hi - lo
+    host = W.tile(W.text_corpus(64 << 20, seed=0), total)[lo:hi].copy()     # the same buffer on every rank, each keeps its own shard
+    src = torch.empty(max(n, 1) + 64, dtype=torch.uint8, device=dev)
+    if n:
+        src[:n].copy_(torch.from_numpy(host))
+    units = max(1, (n + UNIT - 1) // UNIT)
+    cap = zstd_amd.compress_bound(max(n, 1), UNIT)
+    dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    ctx = zstd_amd.Context(local, max_units=units)
+    name = f"zhip_gather_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}"
+    bound_total = zstd_amd.compress_bound(total, UNIT) + 64 * world
+    shm = None
+    if rank == 0:
+        try:
+            old = shared_memory.SharedMemory(name=name); old.close(); old.unlink()
+        except FileNotFoundError:
+            pass
+        shm = shared_memory.SharedMemory(name=name, create=True, size=bound_total)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        shm = shared_memory.SharedMemory(name=name)
+    gathered = torch.frombuffer(shm.buf, dtype=torch.uint8)
+
+    def step():
+        c = int(ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, 1, UNIT)) if n else 0
+        sz = torch.tensor([c], dtype=torch.int64)
+        if dist is not None:
+            allsz = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allsz, sz)
+            sizes = [int(t.item()) for t in allsz]
+        else:
+            sizes = [c]
+        off = sum(sizes[:rank])
+        if c:
+            gathered[off:off + c].copy_(dst[:c])                          # D2H into the shared host buffer = this rank's part of the gather
+        return sizes
+
+    K, Wm = max(2, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(Wm):
+        sizes = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        sizes = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # per-rank parity against the real reference (its threads shared out over the ranks)
+    mine = gathered[sum(sizes[:rank]): sum(sizes[:rank + 1])].numpy()
+    ok = None
+    exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
+    if os.path.exists(exe) and n and not args.no_parity:
+        tin, tout = f"/tmp/zhip_strong_in_{os.getpid()}.bin", f"/tmp/zhip_strong_out_{os.getpid()}.bin"
+        try:
+            host.tofile(tin)
+            info = json.loads(subprocess.check_output([exe, "cfile", "1", str(UNIT), tin, tout, str(max(1, (os.cpu_count() or 1) // world))], timeout=600))
+            want = hashlib.sha256(open(tout, "rb").read()).hexdigest()
+            ok = bool(hashlib.sha256(mine.tobytes()).hexdigest() == want and info["csize"] == len(mine))
+        finally:
+            for t in (tin, tout):
+                if os.path.exists(t):
+                    os.unlink(t)
+    oks = [ok]
+    if dist is not None:
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+    res = None
+    if rank == 0:
+        ctot = sum(sizes)
+        res = {"metric": "compress_MBps_level1_text_frame_per_shard", "value": round(total / (dt / K) / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": K,
+               "ms_per_step": round(dt / K * 1e3, 3), "scaling": "strong", "ratio": round(total / max(1, ctot), 4),
+               "config": {"workload": f"Zipf word-salad text (zstd_amd/workloads.py text_corpus, 64 MiB generated, tiled to {total} B; enwik9 stand-in), level 1, "
+                                      f"{world} shard(s) of whole {UNIT} B units = independent frames, one shard per GPU", "shard_bytes": int(per)},
+               "gather": "every rank's D2H lands at its offset of ONE shared host buffer (offsets from an all_gather of the shard sizes); timed inside the step",
+               "parity": {"per_rank_sha256_equals_reference": oks, "full_size": {"sha256_equals_reference_stream": (all(bool(x) for x in oks) if all(x is not None for x in oks) else None)},
+                          "gathered_stream_sha256": hashlib.sha256(gathered[:ctot].numpy().tobytes()).hexdigest(), "gathered_bytes": int(ctot)}}
+    if dist is not None:
+        dist.barrier()
+    del gathered, mine
+    ctx.close()
+    try:
+        shm.close()
+        if rank == 0:
+            shm.unlink()
+    except Exception:                                             # noqa: BLE001
+        pass
     return res
 
 
@@ -838,21 +1069,28 @@ def main():
         dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: zstd_amd has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    local_dev = local % torch.cuda.device_count()                # more ranks than visible GPUs: they share them (tests/test_gpu_multi.py runs two ranks on one device)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     if args.leg:                                                 # child of the default line: one extra leg in its own process (so that it can be given a deadline)
-        print(json.dumps(run_leg(args, torch, zstd_amd, dev, local)), flush=True)
+        print(json.dumps(run_leg(args, torch, zstd_amd, dev, local_dev)), flush=True)
         return
     if args.workload == "records":
-        return records_main(args, torch, zstd_amd, dev, local, rank, world, dist)
+        return records_main(args, torch, zstd_amd, dev, local_dev, rank, world, dist)
     default_line = (args.workload == "datagen" and args.level == 1 and args.mode == "compress" and world == 1 and not args.no_extra_legs)
     t_start = time.time()
-    out, keep = compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
+    out, keep = compress_leg(args, torch, zstd_amd, dev, local_dev, rank, world, dist, args.workload, args.level, args.steps, args.warmup,
                              args.copies, args.total_bytes, want_decode=(args.mode == "decode" or (world == 1 and not default_line)),
                              want_pipelined=(world == 1 and not args.no_pipelined_extra and not default_line), want_cpu=not args.no_cpu_baseline)
     del keep
+    if world > 1 and args.workload == "datagen" and not args.no_extra_legs:
+        # BASELINE configs[3] beside the weak-scaling line: 10^9 B of text cut into one shard of whole units per rank, host gather timed
+        ts = strong_text_leg(args, torch, zstd_amd, dev, local_dev, rank, world, dist)
+        if rank == 0:
+            out["text_strong_scaling"] = ts
     if rank == 0:
+        out["digest"] = make_digest(out)
         print(json.dumps(out), flush=True)                      # the headline (metric, value, roofline, cpu_baseline, parity) is out before anything else runs
     if default_line and rank == 0:
         # Everything below is extra: each leg is a child process with its own deadline, and the line is printed again (augmented) after every
@@ -861,9 +1099,13 @@ def main():
         for name, deadline in LEGS:
             left = args.budget - (time.time() - t_start)
             if left < 20:
+                out.pop("digest", None)
                 out[name] = {"skipped": f"the run's time budget (--budget {args.budget} s) was used up"}
+                out["digest"] = make_digest(out)
                 continue
+            out.pop("digest", None)
             out[name] = child_leg(name, min(deadline, left), args)
+            out["digest"] = make_digest(out)                    # always the last key: the tail of the line alone says what every leg did
             print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -871,8 +1113,50 @@ def main():
 
 
 # the default line's extra legs: (key in the JSON line, deadline in seconds)
-LEGS = [("decode", 90), ("pipelined", 60), ("end_to_end", 90), ("multi_block_frames", 90), ("job_pool_frame", 120), ("silesia_shaped_level1", 120),
-        ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_row_prediction", 150)]
+LEGS = [("decode", 90), ("pipelined", 60), ("end_to_end", 90), ("plugin_B1", 120), ("multi_block_frames", 90), ("job_pool_frame", 120), ("silesia_shaped_level1", 120),
+        ("text_level1", 150), ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_units", 180)]
+# short names of the legs in the line's closing `digest`
+DIGEST_NAMES = {"decode": "dec_L1", "pipelined": "pipe4", "end_to_end": "e2e_host", "plugin_B1": "plugin_B1", "multi_block_frames": "frames_1MiB",
+                "job_pool_frame": "job_pool_1GiB", "silesia_shaped_level1": "silesia4_L1", "text_level1": "text1e9_L1", "silesia64_level3": "silesia64_L3",
+                "records_zdict_level3": "records10M_L3", "level5_units": "datagen_L5"}
+
+
+def make_digest(out):
+    """every leg in one compact object, appended as the LAST key of the line: [MB/s, frac = (S + C) / dominant-kernel time / 8 TB/s, full-size parity
+    against the real reference (sha256 of the stream; the decoder: decoded == source; plugin: sequences == ZSTD_generateSequences), the reference on
+    ALL host cores in MB/s where the leg timed it]"""
+    def ent(o):
+        if not isinstance(o, dict):
+            return None
+        if "value" not in o:
+            return [None, None, o.get("error") or o.get("skipped") or "no value"]
+        par = o.get("parity", {}) if isinstance(o.get("parity"), dict) else {}
+        ok = None
+        for path in (("full_size", "sha256_equals_reference_stream"), ("sha256_equals_reference_frames",), ("sha256_equals_reference_frame",),
+                     ("decoded_equals_source_full_size",), ("sequences_equal_ZSTD_generateSequences_full_size",)):
+            cur = par
+            for k in path:
+                cur = cur.get(k) if isinstance(cur, dict) else None
+            if cur is not None:
+                ok = cur
+                break
+        if ok is None and "same_bytes_as_device_path" in o:
+            ok = o["same_bytes_as_device_path"]
+        if ok is None and "same_bytes" in o:
+            ok = o["same_bytes"]
+        host = None
+        cb = o.get("cpu_baseline") or o.get("cpu_reference")
+        if isinstance(cb, dict):
+            host = (cb.get("all_cores") or {}).get("value") if "all_cores" in cb else cb.get("value")
+        r = o.get("roofline") if isinstance(o.get("roofline"), dict) else {}
+        return [o["value"], r.get("frac"), ok, host]
+    d = {"fields": "[MB/s, frac_S_plus_C_of_8TB/s, parity_vs_reference_full_size, reference_all_host_cores_MB/s]", "datagen_L1": ent(out)}
+    for name, _ in LEGS:
+        if name in out:
+            d[DIGEST_NAMES.get(name, name)] = ent(out[name])
+    if isinstance(out.get("text_strong_scaling"), dict):
+        d["text1e9_strong"] = ent(out["text_strong_scaling"])
+    return d
 LEG_KEYS = ("metric", "value", "unit", "steps", "ms_per_step", "ratio", "config", "roofline", "pipeline", "parity", "cpu_baseline")
 
 
@@ -907,6 +1191,16 @@ def run_leg(args, torch, zstd_amd, dev, local):
         sil, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 1, max(3, min(args.steps, 20)), 2, 4, 0,
                               want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="silesia4_level1")
         return {k: sil[k] for k in LEG_KEYS if k in sil}
+    if name == "text_level1":                                    # BASELINE configs[3] on one GPU: 10^9 B of text as ONE shard, level 1
+        tx, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "text", 1, max(3, min(args.steps, 10)), 2, 1, 1000000000,
+                             want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="text_level1")
+        return {k: tx[k] for k in LEG_KEYS if k in tx}
+    if name == "level5_units":                                   # the lazy family's sample row: level 5 (ZSTD_greedy, the reference's default row-hash matcher) on the headline's data
+        host5 = int(os.environ.get("ZHIP_L5_LEG_MIB", "1024"))
+        a5 = argparse.Namespace(**vars(args)); a5.mib = host5
+        l5, _ = compress_leg(a5, torch, zstd_amd, dev, local, 0, 1, None, "datagen", 5, 3, 1, 1, 0,
+                             want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="datagen_level5")
+        return {k: l5[k] for k in LEG_KEYS if k in l5}
     if name == "silesia64_level3":                               # BASELINE configs[2] at its stated size: the mix x64 (about 13 GiB), level 3 (ZSTD_dfast)
         sil3, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 3, 3, 1, 64, 0,
                                want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=4.0, leg="silesia64_level3")
@@ -929,6 +1223,8 @@ def run_leg(args, torch, zstd_amd, dev, local):
     torch.cuda.empty_cache()
     if name == "end_to_end":
         return end_to_end_leg(torch, zstd_amd, local, host, total, args.level)
+    if name == "plugin_B1":
+        return plugin_leg(zstd_amd, local, host, args.level)
     if name == "multi_block_frames":
         return frames_leg(zstd_amd, local, host, args.level) or {"skipped": "workload below 1 MiB"}
     if name == "job_pool_frame":

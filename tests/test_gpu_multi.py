@@ -106,3 +106,35 @@ def test_multi_create_rejects_devices_that_do_not_exist():
     a = np.arange(300000, dtype=np.uint32).view(np.uint8)
     assert len(m.compress(a, level=1)) > 0
     m.close()
+
+
+def test_two_ranks_on_one_device_through_bench_py():
+    """The N > 1 path with the REAL per-rank compressor: `bench.py --gpus 2` starts two ranks (torch.distributed.run, gloo control plane) that share
+    device 0, each compresses its own datagen shard (the weak-scaling line) and its shard of ONE text buffer (the frame-per-shard form of BASELINE
+    configs[3]) and copies its frames to its offset of one shared host buffer.  The gathered stream must be the stream a single process makes of
+    the whole buffer, and every rank's stream the real reference's."""
+    import hashlib
+    import json
+    import sys
+    import zstd_amd
+    from zstd_amd import workloads as W
+    total = 24 * UNIT + 12345
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mib", "8", "--no-cpu-baseline",
+                         "--total-bytes", str(total)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert cp.returncode == 0 and lines, cp.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["parity"]["bytes_identical_to_oracle_first_64_units"] and out["parity"]["frames_well_formed"]
+    if "full_size" in out["parity"]:
+        assert out["parity"]["full_size"]["sha256_equals_reference_stream"]
+    ts = out["text_strong_scaling"]
+    assert ts["n_gpus"] == 2 and ts["scaling"] == "strong"
+    assert list(out.keys())[-1] == "digest" and "text1e9_strong" in out["digest"]
+    a = W.tile(W.text_corpus(64 << 20, seed=0), total)
+    single = zstd_amd.Context(0, max_units=32).compress(a, level=1)
+    assert ts["parity"]["gathered_bytes"] == len(single)
+    assert ts["parity"]["gathered_stream_sha256"] == hashlib.sha256(single).hexdigest()
+    assert all(x in (True, None) for x in ts["parity"]["per_rank_sha256_equals_reference"])

@@ -158,6 +158,20 @@ k_xxh64_wave(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     }
 }
 
+// Plugin boundary (zhip_prepare_sequences): the blocks' sequence records, each in its own slot of the sequence arena, packed back to back
+// (offs[] = exclusive prefix sum of metas[].nbSeq) so that ONE copy brings them to the host
+__global__ void __launch_bounds__(256)
+k_seq_compact(const ZhipSeq* __restrict__ seqs, const ZhipSlot* __restrict__ slots, const ZhipParse* __restrict__ metas,
+              const uint64_t* __restrict__ offs, uint32_t nUnits, ZhipSeq* __restrict__ dst)
+{
+    uint32_t const ui = blockIdx.x;
+    if (ui >= nUnits) return;
+    const ZhipSeq* s = seqs + slots[ui].seqOff;
+    ZhipSeq* d = dst + offs[ui];
+    uint32_t const ns = metas[ui].nbSeq;
+    for (uint32_t i = threadIdx.x; i < ns; i += 256) d[i] = s[i];
+}
+
 // Stage 3: pack the per-unit slots into one contiguous stream.  offsets[] = exclusive prefix sum of outSize[].
 __global__ void __launch_bounds__(256)
 k_gather(const uint8_t* __restrict__ outArena, const ZhipSlot* __restrict__ slots, const uint32_t* __restrict__ outSize,

@@ -116,6 +116,9 @@ struct zhip_ctx_s {
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
     std::vector<ZhipSeq> cacheSeqs; std::vector<ZhipParse> cacheParse; std::vector<ZhipUnit> cacheUnits;
+    std::vector<uint64_t> cacheSeqOff;   // where each prepared block's records start in cacheSeqs
+    ZhipSeq* dSeqPack; size_t seqPackCap; uint64_t* dSeqPackOff; size_t seqPackOffCap;   // device side of the packed copy (k_seq_compact)
+    std::mutex cacheMu;                  // guards the prepared-block cache alone: producer callbacks of many host threads only share this one
     std::mutex mu;
     char err[256];
 };
@@ -172,6 +175,7 @@ void zhip_destroy(zhip_ctx* c)
     if (c->coStream) (void)hipStreamSynchronize(c->coStream);      // the global-table co-kernels use dGTabs / dQueue / dOrder (a call that returned early on an error may have left one running)
     (void)hipFree(c->dUnits); (void)hipFree(c->dSlots); (void)hipFree(c->dSeqs); (void)hipFree(c->dParse); (void)hipFree(c->dLits); (void)hipFree(c->dStBits);
     (void)hipFree(c->dOut); (void)hipFree(c->dOutSize); (void)hipFree(c->dOutOff); (void)hipFree(c->dTabs); (void)hipFree(c->dBest); (void)hipFree(c->dChecks); (void)hipFree(c->dTileSums); (void)hipFree(c->dTileOffs);
+    (void)hipFree(c->dSeqPack); (void)hipFree(c->dSeqPackOff);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
     (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots); (void)hipFree(c->dLzRing); (void)hipFree(c->dRhRing);
@@ -200,6 +204,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->seqArena = seqArena; c->litArena = litArena; c->outArena = outArena;
     c->device = device; c->maxUnits = maxUnits; c->err[0] = 0; c->nUnits = 0;
     c->cacheSrc = nullptr; c->cacheSize = 0; c->cacheBlock = 0; c->cacheLevel = 0;
+    c->dSeqPack = nullptr; c->seqPackCap = 0; c->dSeqPackOff = nullptr; c->seqPackOffCap = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
     {   const char* e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1;
@@ -1477,6 +1482,14 @@ static void block_fingerprint(const uint8_t* p, size_t n, uint64_t out[2])
 }
 
 // parse `srcSize` host bytes cut into blockSize blocks (each without history); results copied to the host cache
+// fingerprints of the blocks [lo, hi) of a prepared buffer
+static void fingerprint_range(const uint8_t* src, const ZhipUnit* units, size_t lo, size_t hi, uint64_t* out)
+{
+    for (size_t i = lo; i < hi; i++) block_fingerprint(src + units[i].srcOff, units[i].srcLen, out + 2 * i);
+}
+
+// Parse every block of the buffer in one launch and bring the sequences to the host: H2D, match finder, ONE packed copy back
+// (k_seq_compact), while host threads fingerprint the blocks.  The cache is replaced under cacheMu at the very end.
 static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
 {
     if (blockSize == 0 || blockSize > ZHIP_UNIT_MAX) blockSize = ZHIP_UNIT_MAX;
@@ -1491,23 +1504,49 @@ static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_
     size_t const r = launch_parse(c, c->dSrcStage, nUnits, mh, c->stream);
     if (zhip_isError(r)) return r;
     HIPCHK(c, hipMemcpyAsync(c->hParse, c->dParse, nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->cacheParse.assign(c->hParse, c->hParse + nUnits);
-    c->cacheUnits.assign(c->hUnits, c->hUnits + nUnits);
-    size_t totalSeq = 0;
-    for (size_t i = 0; i < nUnits; i++) totalSeq += c->hParse[i].nbSeq;
-    c->cacheSeqs.resize(totalSeq ? totalSeq : 1);
-    size_t pos = 0;
-    for (size_t i = 0; i < nUnits; i++) {
-        uint32_t const ns = c->hParse[i].nbSeq;
-        if (ns) HIPCHK(c, hipMemcpyAsync(c->cacheSeqs.data() + pos, c->dSeqs + c->hSlots[i].seqOff, ns * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
-        pos += ns;
+    // the content fingerprints (what lets a later callback trust the cache) while the device works: up to 16 host threads for large buffers
+    std::vector<uint64_t> hashes(2 * nUnits);
+    std::vector<std::thread> workers;
+    size_t nThr = srcSize >= ((size_t)32 << 20) ? 16 : 1;
+    if (nThr > nUnits) nThr = nUnits;
+    if (nThr > 1) {
+        try {
+            for (size_t t = 1; t < nThr; t++)
+                workers.emplace_back(fingerprint_range, (const uint8_t*)src, (const ZhipUnit*)c->hUnits, nUnits * t / nThr, nUnits * (t + 1) / nThr, hashes.data());
+        } catch (...) { for (auto& w : workers) w.join(); workers.clear(); nThr = 1; }      // no threads to be had: this one does it all
     }
+    fingerprint_range((const uint8_t*)src, c->hUnits, 0, nThr > 1 ? nUnits / nThr : nUnits, hashes.data());
+    for (auto& w : workers) w.join();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->cacheHash.resize(2 * nUnits);
-    for (size_t i = 0; i < nUnits; i++)
-        block_fingerprint((const uint8_t*)src + c->hUnits[i].srcOff, c->hUnits[i].srcLen, &c->cacheHash[2 * i]);
-    c->cacheSrc = src; c->cacheSize = srcSize; c->cacheBlock = blockSize; c->cacheLevel = level;
+    {   float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);           // the match finder's own duration (zhip_last_timing: parse_ms)
+        c->timing[0] = ms; c->timing[1] = c->timing[2] = 0; c->timing[3] = ms; }
+    c->stats[0] = nUnits; c->stats[1] = srcSize; c->stats[2] = 0; c->stats[3] = 0; c->stats[4] = 0;
+    std::vector<uint64_t> seqOff(nUnits + 1);
+    size_t totalSeq = 0;
+    for (size_t i = 0; i < nUnits; i++) { seqOff[i] = totalSeq; totalSeq += c->hParse[i].nbSeq; }
+    seqOff[nUnits] = totalSeq;
+    std::vector<ZhipSeq> seqs(totalSeq ? totalSeq : 1);
+    if (totalSeq) {
+        if (c->seqPackCap < totalSeq) {
+            (void)hipFree(c->dSeqPack); c->dSeqPack = nullptr; c->seqPackCap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->dSeqPack, totalSeq * sizeof(ZhipSeq))); c->seqPackCap = totalSeq;
+        }
+        if (c->seqPackOffCap < nUnits) {
+            (void)hipFree(c->dSeqPackOff); c->dSeqPackOff = nullptr; c->seqPackOffCap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->dSeqPackOff, nUnits * sizeof(uint64_t))); c->seqPackOffCap = nUnits;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dSeqPackOff, seqOff.data(), nUnits * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(zhip::k_seq_compact, dim3((unsigned)nUnits), dim3(256), 0, c->stream, c->dSeqs, c->dSlots, c->dParse, c->dSeqPackOff, (uint32_t)nUnits, c->dSeqPack);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(seqs.data(), c->dSeqPack, totalSeq * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    {   std::lock_guard<std::mutex> lk(c->cacheMu);
+        c->cacheParse.assign(c->hParse, c->hParse + nUnits);
+        c->cacheUnits.assign(c->hUnits, c->hUnits + nUnits);
+        c->cacheSeqs.swap(seqs); c->cacheSeqOff.swap(seqOff); c->cacheHash.swap(hashes);
+        c->cacheSrc = src; c->cacheSize = srcSize; c->cacheBlock = blockSize; c->cacheLevel = level;
+    }
     c->nUnits = nUnits;
     return nUnits;
 }
@@ -1530,27 +1569,39 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
     zhip_ctx* c = (zhip_ctx*)state;
     (void)windowSize;
     if (!c || dict != nullptr || dictSize != 0 || srcSize > ZHIP_UNIT_MAX || srcSize == 0) return ZHIP_SEQUENCE_PRODUCER_ERROR;
+    const uint8_t* p = (const uint8_t*)src;
+    // a prepared block: served from the cache without touching the device or the context's own lock, so the callbacks of many CCtx on many
+    // host threads (one zhip_prepare_sequences, N x ZSTD_compress2) only meet in cacheMu for the copy.  The same address range is not
+    // enough: the bytes must be the ones that were parsed (fingerprint taken before the lock)
+    uint64_t fp[2]; block_fingerprint(p, srcSize, fp);
+    {   std::lock_guard<std::mutex> lk(c->cacheMu);
+        const uint8_t* base = (const uint8_t*)c->cacheSrc;
+        bool hit = base && c->cacheLevel == compressionLevel && p >= base && p + srcSize <= base + c->cacheSize
+                   && ((size_t)(p - base) % c->cacheBlock) == 0;
+        size_t const idx = hit ? (size_t)(p - base) / c->cacheBlock : 0;
+        if (hit && c->cacheUnits[idx].srcLen != srcSize) hit = false;
+        if (hit && (fp[0] != c->cacheHash[2 * idx] || fp[1] != c->cacheHash[2 * idx + 1])) hit = false;
+        if (hit) {
+            size_t const r = seqs_to_public(c->cacheSeqs.data() + c->cacheSeqOff[idx], c->cacheParse[idx], outSeqs, outSeqsCapacity);
+            return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
+        }
+    }
+    // not prepared: one launch for this block (latency-bound path).  It leaves no cache of its own behind and keeps the one a
+    // zhip_prepare_sequences call installed: blocks of other sizes (the reference splits some 128 KB blocks at 92 KB,
+    // lib/compress/zstd_compress.c:4494-4518) must not cost the prepared blocks their parse
     std::lock_guard<std::mutex> lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return ZHIP_SEQUENCE_PRODUCER_ERROR;
-    const uint8_t* p = (const uint8_t*)src; const uint8_t* base = (const uint8_t*)c->cacheSrc;
-    bool hit = base && c->cacheLevel == compressionLevel && p >= base && p + srcSize <= base + c->cacheSize
-               && ((size_t)(p - base) % c->cacheBlock) == 0;
-    size_t idx = hit ? (size_t)(p - base) / c->cacheBlock : 0;
-    if (hit && c->cacheUnits[idx].srcLen != srcSize) hit = false;
-    if (hit) {                                   // same address range is not enough: the bytes must be the ones that were parsed
-        uint64_t fp[2]; block_fingerprint(p, srcSize, fp);
-        if (fp[0] != c->cacheHash[2 * idx] || fp[1] != c->cacheHash[2 * idx + 1]) hit = false;
-    }
-    bool const oneShot = !hit;
-    if (!hit) {                                  // not prepared: one launch for this block (latency-bound path)
-        size_t const r = prepare_locked(c, src, srcSize, srcSize, compressionLevel);
-        if (zhip_isError(r)) return ZHIP_SEQUENCE_PRODUCER_ERROR;
-        idx = 0;
-    }
-    size_t pos = 0;
-    for (size_t i = 0; i < idx; i++) pos += c->cacheParse[i].nbSeq;
-    size_t const r = seqs_to_public(c->cacheSeqs.data() + pos, c->cacheParse[idx], outSeqs, outSeqsCapacity);
-    if (oneShot) c->cacheSrc = nullptr;          // the unprepared path never leaves a cache behind
+    std::vector<uint64_t> kHash, kOff; std::vector<ZhipSeq> kSeqs; std::vector<ZhipParse> kParse; std::vector<ZhipUnit> kUnits;
+    const void* kSrc; size_t kSize, kBlock; int kLevel;
+    {   std::lock_guard<std::mutex> lk2(c->cacheMu);
+        kHash.swap(c->cacheHash); kOff.swap(c->cacheSeqOff); kSeqs.swap(c->cacheSeqs); kParse.swap(c->cacheParse); kUnits.swap(c->cacheUnits);
+        kSrc = c->cacheSrc; kSize = c->cacheSize; kBlock = c->cacheBlock; kLevel = c->cacheLevel; c->cacheSrc = nullptr; }
+    size_t const rp = prepare_locked(c, src, srcSize, srcSize, compressionLevel);
+    std::lock_guard<std::mutex> lk2(c->cacheMu);
+    size_t r = rp;
+    if (!zhip_isError(rp)) r = seqs_to_public(c->cacheSeqs.data(), c->cacheParse[0], outSeqs, outSeqsCapacity);
+    c->cacheHash.swap(kHash); c->cacheSeqOff.swap(kOff); c->cacheSeqs.swap(kSeqs); c->cacheParse.swap(kParse); c->cacheUnits.swap(kUnits);
+    c->cacheSrc = kSrc; c->cacheSize = kSize; c->cacheBlock = kBlock; c->cacheLevel = kLevel;
     return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
 }
 
