@@ -125,6 +125,10 @@ size_t       zhip_compress_frame_mt_multi(zhip_multi* m, void* dst, size_t dstCa
                                           int level, const unsigned cparams[7] /* or NULL */, size_t jobSize, int overlapLog);
 const char*  zhip_multi_last_error(const zhip_multi* m);
 double       zhip_multi_last_seconds(const zhip_multi* m);      /* wall time of the most recent zhip_compress_multi call */
+/* where the most recent zhip_compress_multi call spent its time, seconds summed over all chunks and lanes (lanes overlap: the sum exceeds the
+ * wall time): [0] host copy into pinned staging, [1] H2D, [2] kernels, [3] D2H (HIP events on the lane's stream), [4] waiting for earlier
+ * chunks' sizes (the ordered gather), [5] host copy of the frames to their final place; [6] = number of chunks */
+void         zhip_multi_last_stages(const zhip_multi* m, double out[7]);
 
 /* ---- block-level plugin (B1) = ZSTD_sequenceProducer_F, lib/zstd.h:2838; contrib/externalSequenceProducer.
  * zhip_sequence_producer has exactly that signature; pass the zhip_ctx as sequenceProducerState:

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""scripts/e2e_sweep.py — GPU box, measurement helper: host-buffer path (zhip_compress_multi on one device) over lanes x chunk size; 1 GiB datagen, level 1"""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+n = 1 << 30
+res = []
+for lanes in (2, 3, 4):
+    for cu in (768, 1024, 2048):
+        os.environ["ZHIP_MULTI_LANES"] = str(lanes)
+        import zstd_amd
+        host = zstd_amd.datagen(n, 50, seed=0, stream_mode=True)
+        m = zstd_amd.MultiContext([0], chunk_units=cu)
+        dst = np.empty(zstd_amd.compress_bound(n), dtype=np.uint8)
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter(); k = m.compress_into(dst, host, level=1); best = min(best, time.perf_counter() - t0)
+        st = m.last_stages()
+        m.close()
+        print(json.dumps({"lanes": lanes, "chunk_units": cu, "GBps": round(n / best / 1e9, 2), "csize": int(k), "stages_last_call": st}), flush=True)

@@ -134,6 +134,8 @@ class MultiContext:
         L.zhip_multi_last_error.argtypes = [C.c_void_p]
         L.zhip_multi_last_seconds.restype = C.c_double
         L.zhip_multi_last_seconds.argtypes = [C.c_void_p]
+        L.zhip_multi_last_stages.restype = None
+        L.zhip_multi_last_stages.argtypes = [C.c_void_p, C.c_void_p]
         L.zhip_multi_set_frame_checksum.argtypes = [C.c_void_p, C.c_int]
         arr = (C.c_int * len(devices))(*devices)
         self._h = L.zhip_multi_create(arr, len(devices), chunk_units)
@@ -177,6 +179,13 @@ class MultiContext:
 
     def last_seconds(self):
         return float(lib().zhip_multi_last_seconds(self._h))
+
+    def last_stages(self):
+        """seconds summed over chunks and lanes of the most recent compress call, per stage (zhip_multi_last_stages)"""
+        out = (C.c_double * 7)()
+        lib().zhip_multi_last_stages(self._h, out)
+        keys = ("host_copy_in_s", "h2d_s", "kernels_s", "d2h_s", "ordered_gather_wait_s", "host_copy_out_s", "chunks")
+        return {k: (int(out[i]) if k == "chunks" else round(out[i], 5)) for i, k in enumerate(keys)}
 
     def close(self):
         if self._h:

@@ -1,10 +1,11 @@
 // zhip_multi.h — in-process multi-device compression of HOST buffers (north_star: "independent blocks/frames shard
 // across the GPUs of one node on separate HIP streams with a host-side gather — no RCCL collectives").  Host C++ only.
 //
-// The source is cut into chunks of `chunkUnits` units; chunk k belongs to lane (k mod nLanes), nLanes = ZHIP_MULTI_LANES (default 4)
-// per device, each lane a host thread with its own zhip_ctx + HIP stream + pinned staging, so that on every device some lanes'
-// host memcpy and H2D / D2H copies overlap another lane's kernels (multi-buffering; measured on one MI355X with a 1 GiB source:
-// 2 lanes 12.8 GB/s, 4 lanes 26.9 GB/s — the pageable-to-pinned memcpy of one host thread is the slowest stage), and devices
+// The source is cut into chunks of `chunkUnits` units; chunk k belongs to lane (k mod nLanes), nLanes = ZHIP_MULTI_LANES (default 2)
+// per device.  A lane is one zhip_ctx + HIP stream and three host threads with two pinned slots between them in each direction: a feeder
+// copies the next chunk from the caller's pageable buffer into staging while the device thread runs H2D -> kernels -> D2H of the current
+// one and a gatherer copies finished frames to their final place (round 4: one thread per lane did all of it in turn, 22 GB/s; now
+// 29 GB/s on one MI355X with a 1 GiB source — the per-lane chain H2D + kernels + D2H of a 128 MB chunk, 7.3 ms, is what is left), and devices
 // run independently.  No exchange step exists:
 // units are independent.  Results are variable-length, so a finished chunk publishes its size, and is copied to its final
 // place as soon as every earlier chunk (in source order) has published: the destination offset of chunk k is the exclusive
@@ -17,10 +18,11 @@
 struct zhip_multi_lane {
     int device = 0;
     zhip_ctx* ctx = nullptr;
-    uint8_t *pinIn = nullptr, *pinOut = nullptr;       // hipHostMalloc
-    uint32_t* pinSizes = nullptr;
+    uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[2] = {nullptr, nullptr};       // hipHostMalloc; two slots each: the copy into / out of staging of one chunk runs beside the device work of another
+    uint32_t* pinSizes[2] = {nullptr, nullptr};
     uint8_t *dIn = nullptr, *dOut = nullptr; uint32_t* dSizes = nullptr;
     size_t inCap = 0, outCap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // stage marks of the chunk in flight: before H2D, after H2D, after the kernels, after D2H
 };
 struct zhip_multi_s {
     std::vector<zhip_multi_lane> lanes;
@@ -30,6 +32,7 @@ struct zhip_multi_s {
     std::mutex mu;                                     // one call at a time
     char err[256] = {0};
     double lastSeconds = 0;
+    double stages[7] = {0, 0, 0, 0, 0, 0, 0};          // zhip_multi_last_stages
     zhip_ctx* wide = nullptr; size_t wideUnits = 0;    // job-pool frames that go to ONE context (checksum, jobs larger than a staging buffer): sized on demand
 };
 
@@ -39,7 +42,8 @@ static void multi_free(zhip_multi_s* m)
     for (auto& L : m->lanes) {
         (void)hipSetDevice(L.device);
         if (L.ctx) zhip_destroy(L.ctx);
-        (void)hipHostFree(L.pinIn); (void)hipHostFree(L.pinOut); (void)hipHostFree(L.pinSizes);
+        for (auto& e : L.ev) if (e) (void)hipEventDestroy(e);
+        for (int b = 0; b < 2; b++) { (void)hipHostFree(L.pinIn[b]); (void)hipHostFree(L.pinOut[b]); (void)hipHostFree(L.pinSizes[b]); }
         (void)hipFree(L.dIn); (void)hipFree(L.dOut); (void)hipFree(L.dSizes);
     }
     delete m;
@@ -56,8 +60,11 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
         if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         for (int i = 0; i < nDevices; i++) if (devices[i] < 0 || devices[i] >= count) return nullptr;
     }
-    if (chunkUnits == 0) chunkUnits = 512;                                 // 64 MB of source per chunk
-    size_t lanesPer = 4;
+    // 128 MB of source per chunk on two lanes per device (profiles/r05_e2e_stages.log, 1 GiB, level 1, one MI355X): a chunk's kernels have a
+    // floor of about 3.3 ms (one unit is a serial walk), so small chunks waste the device (512 units: 3.3 ms, 1024: 3.75 ms) and more than two
+    // chunks' kernels at once only queue behind each other (per-chunk kernel time 3.3 / 6.4 / 11.2 ms at 2 / 4 / 8 lanes)
+    if (chunkUnits == 0) chunkUnits = 1024;
+    size_t lanesPer = 2;
     if (const char* e = getenv("ZHIP_MULTI_LANES")) { long const v = atol(e); if (v >= 1 && v <= 16) lanesPer = (size_t)v; }
     zhip_multi_s* m = new zhip_multi_s();
     m->chunkUnits = chunkUnits;
@@ -68,11 +75,14 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
         L.device = devices[i / lanesPer]; L.inCap = inCap; L.outCap = outCap;
         bool ok = hipSetDevice(L.device) == hipSuccess;
         ok = ok && (L.ctx = zhip_create(L.device, chunkUnits)) != nullptr;
-        ok = ok && hipHostMalloc((void**)&L.pinIn, inCap, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&L.pinOut, outCap, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&L.pinSizes, chunkUnits * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+        for (int b = 0; b < 2; b++) {
+            ok = ok && hipHostMalloc((void**)&L.pinIn[b], inCap, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&L.pinOut[b], outCap, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&L.pinSizes[b], chunkUnits * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+        }
         ok = ok && hipMalloc((void**)&L.dIn, inCap) == hipSuccess && hipMalloc((void**)&L.dOut, outCap) == hipSuccess;
         ok = ok && hipMalloc((void**)&L.dSizes, chunkUnits * sizeof(uint32_t)) == hipSuccess;
+        for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         if (!ok) { multi_free(m); (void)hipGetLastError(); return nullptr; }
     }
     return m;
@@ -92,6 +102,7 @@ int zhip_multi_set_row_matcher(zhip_multi* m, int mode)
 }
 const char* zhip_multi_last_error(const zhip_multi* m) { return m->err; }
 double zhip_multi_last_seconds(const zhip_multi* m) { return m->lastSeconds; }
+void zhip_multi_last_stages(const zhip_multi* m, double out[7]) { for (int i = 0; i < 7; i++) out[i] = m->stages[i]; }
 
 size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const void* srcv, size_t srcSize,
                            int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes)
@@ -111,40 +122,105 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
     size_t firstErr = 0;
     std::mutex gm; std::condition_variable gcv;
     m->err[0] = 0;
+    for (auto& v : m->stages) v = 0;
 
+    // A lane is three host threads around one HIP stream, two pinned slots between them in each direction:
+    //   feeder  : copies chunk i+1 of the lane from the caller's (pageable) buffer into a free input slot while chunk i is on the device;
+    //   device  : H2D -> kernels -> D2H of one chunk at a time on the lane's stream;
+    //   gatherer: waits until every earlier chunk (in source order) has published its size, then copies the frames to their final place.
+    // (Round 4 ran the three in one thread per lane: 10.4 ms per 64 MB chunk of which 4 ms were the device's — profiles/r05_e2e_stages.log.)
     auto lane_fn = [&](size_t li) {
         zhip_multi_lane& L = m->lanes[li];
-        if (hipSetDevice(L.device) != hipSuccess) { std::lock_guard<std::mutex> g(gm); if (!firstErr) firstErr = ZERR(ZE_GENERIC); gcv.notify_all(); return; }
-        zhip_set_frame_checksum(L.ctx, m->checksum);
-        for (size_t k = li; k < nChunks; k += nLanes) {
-            {   std::lock_guard<std::mutex> g(gm); if (firstErr) return; }
-            size_t const b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
-            if (len) memcpy(L.pinIn, src + b0, len);
-            size_t r = 0;
-            hipStream_t const s = L.ctx->stream;
-            if (len && hipMemcpyAsync(L.dIn, L.pinIn, len, hipMemcpyHostToDevice, s) != hipSuccess) r = ZERR(ZE_GENERIC);
-            if (!r) r = zhip_compress_params_device(L.ctx, L.dOut, L.outCap, L.dIn, len, level, cparams, unitSize, L.dSizes, (void*)s);
-            size_t const nu = len ? (len + unitSize - 1) / unitSize : 1;
-            if (!zhip_isError(r)) {
-                bool ok = hipMemcpyAsync(L.pinOut, L.dOut, r, hipMemcpyDeviceToHost, s) == hipSuccess;
-                ok = ok && hipMemcpyAsync(L.pinSizes, L.dSizes, nu * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
-                ok = ok && hipStreamSynchronize(s) == hipSuccess;
-                if (!ok) r = ZERR(ZE_GENERIC);
+        std::vector<size_t> mine;
+        for (size_t k = li; k < nChunks; k += nLanes) mine.push_back(k);
+        std::mutex lm; std::condition_variable lcv;
+        int inState[2] = {0, 0};            // 0 free, 1 filled
+        int outState[2] = {0, 0};           // 0 free, 1 holds a finished chunk
+        size_t outBytes[2] = {0, 0};
+        bool stop = false;
+        auto fail = [&](size_t code, size_t k) {
+            {   std::lock_guard<std::mutex> g(gm);
+                if (!firstErr) { firstErr = code; snprintf(m->err, sizeof(m->err), "chunk %zu on device %d: %s", k, L.device, zhip_last_error(L.ctx)); }
+                gcv.notify_all(); }
+            {   std::lock_guard<std::mutex> g(lm); stop = true; }
+            lcv.notify_all();
+        };
+        auto failed = [&] { std::lock_guard<std::mutex> g(gm); return firstErr != 0; };
+        double tIn = 0, tWait = 0, tOut = 0, tH2D = 0, tK = 0, tD2H = 0;
+        std::thread feeder([&] {
+            for (size_t i = 0; i < mine.size(); i++) {
+                int const b = (int)(i & 1);
+                {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return inState[b] == 0 || stop; }); if (stop) return; }
+                size_t const k = mine[i], b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                auto const t0 = std::chrono::steady_clock::now();
+                if (len) memcpy(L.pinIn[b], src + b0, len);
+                tIn += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                {   std::lock_guard<std::mutex> g(lm); inState[b] = 1; }
+                lcv.notify_all();
             }
-            size_t myOff = 0;
-            {   std::unique_lock<std::mutex> g(gm);
-                if (zhip_isError(r)) { if (!firstErr) { firstErr = r; snprintf(m->err, sizeof(m->err), "chunk %zu on device %d: %s", k, L.device, zhip_last_error(L.ctx)); } gcv.notify_all(); return; }
-                size[k] = r; known[k] = 1;
-                while (placed < nChunks && known[placed]) { off[placed + 1] = off[placed] + size[placed]; placed++; }
-                gcv.notify_all();
-                gcv.wait(g, [&] { return placed > k || firstErr; });
-                if (firstErr) return;
-                myOff = off[k];
-                if (myOff + r > dstCapacity) { firstErr = ZERR(ZE_dstSize_tooSmall); gcv.notify_all(); return; }
+        });
+        std::thread gatherer([&] {
+            for (size_t i = 0; i < mine.size(); i++) {
+                int const b = (int)(i & 1);
+                size_t const k = mine[i];
+                {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return outState[b] == 1 || stop; }); if (stop) return; }
+                size_t const r = outBytes[b];
+                size_t const b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                size_t const nu = len ? (len + unitSize - 1) / unitSize : 1;
+                auto const t0 = std::chrono::steady_clock::now();
+                size_t myOff = 0;
+                {   std::unique_lock<std::mutex> g(gm);
+                    size[k] = r; known[k] = 1;
+                    while (placed < nChunks && known[placed]) { off[placed + 1] = off[placed] + size[placed]; placed++; }
+                    gcv.notify_all();
+                    gcv.wait(g, [&] { return placed > k || firstErr; });
+                    if (firstErr) { g.unlock(); { std::lock_guard<std::mutex> g2(lm); stop = true; } lcv.notify_all(); return; }
+                    myOff = off[k];
+                }
+                if (myOff + r > dstCapacity) { fail(ZERR(ZE_dstSize_tooSmall), k); return; }
+                auto const t1 = std::chrono::steady_clock::now();
+                memcpy(dst + myOff, L.pinOut[b], r);
+                if (unitSizes) { size_t const u0 = k * m->chunkUnits; for (size_t j = 0; j < nu; j++) unitSizes[u0 + j] = L.pinSizes[b][j]; }
+                auto const t2 = std::chrono::steady_clock::now();
+                tWait += std::chrono::duration<double>(t1 - t0).count(); tOut += std::chrono::duration<double>(t2 - t1).count();
+                {   std::lock_guard<std::mutex> g(lm); outState[b] = 0; }
+                lcv.notify_all();
             }
-            memcpy(dst + myOff, L.pinOut, r);
-            if (unitSizes) { size_t const u0 = k * m->chunkUnits; for (size_t i = 0; i < nu; i++) unitSizes[u0 + i] = L.pinSizes[i]; }
+        });
+        if (hipSetDevice(L.device) != hipSuccess) fail(ZERR(ZE_GENERIC), mine.empty() ? 0 : mine[0]);
+        else {
+            zhip_set_frame_checksum(L.ctx, m->checksum);
+            for (size_t i = 0; i < mine.size(); i++) {
+                int const b = (int)(i & 1);
+                size_t const k = mine[i], b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                if (failed()) { { std::lock_guard<std::mutex> g(lm); stop = true; } lcv.notify_all(); break; }
+                {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return (inState[b] == 1 && outState[b] == 0) || stop; }); if (stop) break; }
+                size_t r = 0;
+                hipStream_t const s = L.ctx->stream;
+                (void)hipEventRecord(L.ev[0], s);
+                if (len && hipMemcpyAsync(L.dIn, L.pinIn[b], len, hipMemcpyHostToDevice, s) != hipSuccess) r = ZERR(ZE_GENERIC);
+                (void)hipEventRecord(L.ev[1], s);
+                if (!r) r = zhip_compress_params_device(L.ctx, L.dOut, L.outCap, L.dIn, len, level, cparams, unitSize, L.dSizes, (void*)s);
+                size_t const nu = len ? (len + unitSize - 1) / unitSize : 1;
+                if (!zhip_isError(r)) {
+                    bool ok = hipEventRecord(L.ev[2], s) == hipSuccess;
+                    ok = ok && hipMemcpyAsync(L.pinOut[b], L.dOut, r, hipMemcpyDeviceToHost, s) == hipSuccess;
+                    ok = ok && hipMemcpyAsync(L.pinSizes[b], L.dSizes, nu * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+                    ok = ok && hipEventRecord(L.ev[3], s) == hipSuccess;
+                    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+                    if (!ok) r = ZERR(ZE_GENERIC);
+                }
+                if (zhip_isError(r)) { fail(r, k); break; }
+                {   float a = 0, bb = 0, c2 = 0;
+                    (void)hipEventElapsedTime(&a, L.ev[0], L.ev[1]); (void)hipEventElapsedTime(&bb, L.ev[1], L.ev[2]); (void)hipEventElapsedTime(&c2, L.ev[2], L.ev[3]);
+                    tH2D += a * 1e-3; tK += bb * 1e-3; tD2H += c2 * 1e-3; }
+                {   std::lock_guard<std::mutex> g(lm); inState[b] = 0; outState[b] = 1; outBytes[b] = r; }
+                lcv.notify_all();
+            }
         }
+        feeder.join(); gatherer.join();
+        {   std::lock_guard<std::mutex> g(gm);
+            m->stages[0] += tIn; m->stages[1] += tH2D; m->stages[2] += tK; m->stages[3] += tD2H; m->stages[4] += tWait; m->stages[5] += tOut; m->stages[6] += (double)mine.size(); }
     };
     std::vector<std::thread> th;
     size_t const use = nChunks < nLanes ? nChunks : nLanes;
@@ -233,13 +309,13 @@ size_t zhip_compress_frame_mt_multi(zhip_multi* m, void* dstv, size_t dstCapacit
             size_t const w0 = (size_t)jobs[0].start - jobs[0].prefixLen;
             size_t const end = (size_t)jobs.back().start + lens.back(), bytes = end - w0;
             // one byte of headroom in front: a job whose window starts at the chunk's first byte reads its position 1 = that byte
-            memcpy(L.pinIn + 16, src + w0, bytes);
+            memcpy(L.pinIn[0] + 16, src + w0, bytes);
             size_t r = 0;
             hipStream_t const s = L.ctx->stream;
-            if (hipMemcpyAsync(L.dIn + 16, L.pinIn + 16, bytes, hipMemcpyHostToDevice, s) != hipSuccess) r = ZERR(ZE_GENERIC);
+            if (hipMemcpyAsync(L.dIn + 16, L.pinIn[0] + 16, bytes, hipMemcpyHostToDevice, s) != hipSuccess) r = ZERR(ZE_GENERIC);
             if (!r) r = frame_jobs_chunk_device(L.ctx, L.dOut, L.outCap, L.dIn + 16, w0, cp, jobs.data(), lens.data(), jobs.size(), s);
             if (!zhip_isError(r)) {
-                bool ok = hipMemcpyAsync(L.pinOut, L.dOut, r, hipMemcpyDeviceToHost, s) == hipSuccess;
+                bool ok = hipMemcpyAsync(L.pinOut[0], L.dOut, r, hipMemcpyDeviceToHost, s) == hipSuccess;
                 ok = ok && hipStreamSynchronize(s) == hipSuccess;
                 if (!ok) r = ZERR(ZE_GENERIC);
             }
@@ -254,7 +330,7 @@ size_t zhip_compress_frame_mt_multi(zhip_multi* m, void* dstv, size_t dstCapacit
                 myOff = off[k];
                 if (myOff + r > dstCapacity) { firstErr = ZERR(ZE_dstSize_tooSmall); gcv.notify_all(); return; }
             }
-            memcpy(dst + myOff, L.pinOut, r);
+            memcpy(dst + myOff, L.pinOut[0], r);
         }
     };
     std::vector<std::thread> th;
