@@ -505,7 +505,7 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
         cpdesc = f"{sname} wlog{cp[0]} clog{cp[1]} hlog{cp[2]} slog{cp[3]} mml{cp[4]}"
         # ZSTD_fast runs as ONE stage of two kernels on one ticket queue (LDS-table wavefronts + global-table wavefronts beside them, zhip_lib.hip
         # launch_parse); the stage's duration — cost estimate and sort of the dispatch order included — is what the events bracket
-        kname = {1: "k_parse_fast_q (+ k_parse_fast_g on the same queue; k_order_cost/k_order_sort inside the stage)" if os.environ.get("ZHIP_FAST_QUEUE", "1") != "0" else "k_parse_fast",
+        kname = {1: "k_parse_fast_q (+ k_parse_fast_g on the same queue; k_order_cost/k_order_sort inside the stage)",
                  2: "k_parse_dfast"}.get(cp[6], "k_hc_chain+k_hc_search+k_parse_lazy")
         out = {
             "metric": f"compress_MBps_level{level}_{'datagenP50' if workload == 'datagen' else workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",

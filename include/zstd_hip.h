@@ -167,6 +167,9 @@ int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
  * un-inserted is parsed once.
  * units / frames: 1 on, 0 off, -1 unchanged.  returns 0, or 1 for a bad value. */
 int          zhip_set_prediction(zhip_ctx* ctx, int units, int frames);
+/* the live rows themselves: 1 on (default), 0 = live searches walk the links (what a context without the rows' arena does); the units' prediction
+ * follows the switch (off with the rows, on without).  Same bytes either way.  returns 0. */
+int          zhip_set_live_rows(zhip_ctx* ctx, int on);
 
 /* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a
  * skippable frame holding the seek table — the natural on-disk form of frame-per-unit output; the reference's

@@ -81,16 +81,16 @@ def test_lazy_job_pool_frames(env, level, no_row, js, ov, ck):
     assert z.DContext().decompress(outs[1]) == bufs[1].tobytes()
 
 
-def test_live_rows_switch_gives_the_same_bytes(env, monkeypatch):
-    """the row matcher's live rows (LzRing, on by default) against the walk through the links they replace ($ZHIP_LZ_RING=0, also what a context
+def test_live_rows_switch_gives_the_same_bytes(env):
+    """the row matcher's live rows (LzRing, on by default) against the walk through the links they replace (zhip_set_live_rows(0), also what a context
     falls back to when the rows' arena cannot be allocated): same bytes, and the oracle's, on long-match data — frames and a job-pool frame"""
     z, lo = env
     bufs = [datagen(lo, 1 << 20, 50, 5), datagen(lo, 700000, 80, 6), text_like(400000, 3)]
     whole = np.concatenate(bufs)
     outs = {}
     for ring in ("1", "0"):
-        monkeypatch.setenv("ZHIP_LZ_RING", ring)
-        ctx = z.Context(max_units=64)                       # the switch is read when the context is created
+        ctx = z.Context(max_units=64)
+        ctx.set_live_rows(ring == "1")
         ctx.set_row_matcher(0)
         outs[ring] = (ctx.compress_frames(bufs, 5), ctx.compress_frames([whole], 7, workers=2, job_size=1 << 20), ctx.compress_frames(bufs[:2], 5, cparams=[20, 16, 17, 6, 5, 2, 5]))
         ctx.close()

@@ -331,6 +331,13 @@ class Context:
         if L.zhip_set_prediction(self._h, -1 if units is None else int(bool(units)), -1 if frames is None else int(bool(frames))) != 0:
             raise ZhipError("zhip_set_prediction: bad value")
 
+    def set_live_rows(self, on=True):
+        """the row matcher's live rows: on (default) / off = live searches walk the links, the units' prediction then on (zhip_set_live_rows); same bytes"""
+        L = lib()
+        L.zhip_set_live_rows.restype = C.c_int
+        L.zhip_set_live_rows.argtypes = [C.c_void_p, C.c_int]
+        L.zhip_set_live_rows(self._h, int(bool(on)))
+
     def compress_device(self, dst_ptr, dst_cap, src_ptr, src_size, level=1, unit_size=UNIT_SIZE_MAX, sizes_ptr=None, stream=None):
         return self._check(lib().zhip_compress_device(self._h, dst_ptr, dst_cap, src_ptr, src_size, level, unit_size,
                                                       sizes_ptr, stream), "zhip_compress_device")

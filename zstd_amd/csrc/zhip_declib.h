@@ -25,7 +25,7 @@ struct zhip_dctx_s {
     ZhipBfBlock* dBfBlocks = nullptr; ZhipBfInfo* dBfInfo = nullptr; uint8_t* dBfLit = nullptr; ZhipDSeq* dBfRecs = nullptr; uint32_t* dBfMap = nullptr;
     size_t bfBlocksCap = 0, bfLitCap = 0, bfRecsCap = 0, bfMapCap = 0;
     hipEvent_t bfEv[2] = { nullptr, nullptr };
-    unsigned long long bigMin = 8ull << 20;        // frames stating at least this much content take the block-parallel path ($ZHIP_BIGFRAME_MIN, 0 = never)
+    unsigned long long bigMin = 8ull << 20;        // frames stating at least this much content take the block-parallel path (zhip_dctx_set_bigframe_min, 0 = never)
     unsigned bfLast[4] = { 0, 0, 0, 0 };           // last call: frames decoded block-parallel, frames that fell back, jump rounds, blocks
     const uint8_t* bfHostSrc = nullptr;            // set by zhip_decompress for the duration of a call: the frames also lie in host memory at this address (same offsets as in the staged copy)
     std::vector<ZhipBfBlock> bfHostBlocks;
@@ -101,10 +101,9 @@ zhip_dctx* zhip_create_dctx(int device)
     hipDeviceProp_t prop;
     bool ok = hipGetDeviceProperties(&prop, device) == hipSuccess;
     c->nCU = ok ? prop.multiProcessorCount : 256;
-    // resident workgroups per CU: what registers and LDS (sizeof(DecShared) of 160 KB) allow; ZHIP_DEC_WG_PER_CU lowers it (measurement knob)
+    // resident workgroups per CU: what registers and LDS (sizeof(DecShared) of 160 KB) allow
     int perCU = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zhip::k_decode, ZHIP_DEC_THREADS, sizeof(zhip::DecShared)) != hipSuccess || perCU < 1) perCU = 4;
-    {   const char* e = getenv("ZHIP_DEC_WG_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }
     c->grid = (uint32_t)(c->nCU * perCU);
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -113,7 +112,6 @@ zhip_dctx* zhip_create_dctx(int device)
     ok = ok && hipMalloc((void**)&c->dCounter, 64) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->dDefTabs, 160 * sizeof(uint64_t)) == hipSuccess;
     if (ok) { uint64_t t[160]; zhip::host_dec_default_tables(t); ok = hipMemcpy(c->dDefTabs, t, sizeof(t), hipMemcpyHostToDevice) == hipSuccess; }
-    {   const char* e = getenv("ZHIP_BIGFRAME_MIN"); if (e && *e) c->bigMin = strtoull(e, nullptr, 10); }
     if (!ok) { zhip_free_dctx(c); return nullptr; }
     return c;
 }

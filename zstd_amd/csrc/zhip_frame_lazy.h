@@ -806,7 +806,8 @@ __device__ inline bool frame_lazy_predict(const uint8_t* __restrict__ src, const
     LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
     ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = 0; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = 0; ls.holeEnd = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {
-        uint32_t const most = pos == j0 ? 32768u : ZHIP_UNIT_MAX;
+        // the 32 KB probe, then the rest of the first 128 KB block, then whole blocks: the predicted block borders stay on the exact parse's j0 + k * 128 KB
+        uint32_t const most = pos == j0 ? 32768u : (pos == j0 + 32768u ? ZHIP_UNIT_MAX - 32768u : ZHIP_UNIT_MAX);
         uint32_t const bLen = jEnd - pos < most ? jEnd - pos : most;
         if (bLen >= 7) {
             if (pos > maxDist && pos - maxDist > low) low = pos - maxDist;

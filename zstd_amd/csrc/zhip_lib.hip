@@ -109,9 +109,9 @@ struct zhip_ctx_s {
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
-    int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction, $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT).  Units: off with the live rows (datagen level 5,
-                                         // 256 MiB: 2.57 GB/s against 2.27 with it; without the rows 1.53 / 2.00 — then it defaults to on), text the same either way.  Frames: opt-in (1 MiB datagen frames
-                                         // 681 -> 366 ms, text frames 168 -> 224 ms; profiles/r04_live_rows.log)
+    int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction).  Units: OFF with the live rows (datagen level 5, 256 MiB: 2.57 GB/s
+                                         // against 2.27 with it; without the rows 1.53 / 2.00 — zhip_set_live_rows(0) turns it on).  Frames: ON, behind a 32 KB probe per window (1 MiB datagen
+                                         // frames 681 -> 366 ms; text frames 168 -> 171 ms with the probe, 224 without; profiles/r04_live_rows.log, r04_predict_probe.log)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -207,9 +207,7 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     c->dSeqPack = nullptr; c->seqPackCap = 0; c->dSeqPackOff = nullptr; c->seqPackOffCap = 0;
     memset(c->ovr, 0, sizeof(c->ovr)); c->haveOvr = false;
     {   const char* e = getenv("ZHIP_ROW_MATCHER"); c->rowMode = c->rowDefault = (e && (!strcmp(e, "disable") || !strcmp(e, "0"))) ? 2 : 0; }
-    {   const char* e = getenv("ZHIP_LZ_RING"); c->lzRingOn = e ? atoi(e) != 0 : 1;
-        e = getenv("ZHIP_RH_PREDICT"); c->rhPredict = e ? atoi(e) != 0 : (c->lzRingOn ? 0 : 1);        // with the live rows one parse is faster than try + predict + parse (profiles/r04_live_rows.log)
-        e = getenv("ZHIP_LZ_PREDICT"); c->lzPredict = e ? atoi(e) != 0 : 1; }                                 // frames: on, behind its 32 KB probe (k_lz_predict)
+    c->lzRingOn = 1; c->rhPredict = 0; c->lzPredict = 1;      // live rows on; prediction: units off (one parse is faster with the rows, profiles/r04_live_rows.log), frames on behind the 32 KB probe (zhip_set_live_rows / zhip_set_prediction)
     c->dSrcStage = nullptr; c->srcStageCap = 0; c->dDstStage = nullptr; c->dstStageCap = 0;
     c->dFrameOut = nullptr; c->frameOutCap = 0; c->dFrameState = nullptr; c->frameStateCap = 0;
     c->dJobs = nullptr; c->jobsCap = 0; c->dFrameUnits = nullptr; c->dFrameSizes = nullptr; c->frameUnitsCap = 0;
@@ -242,14 +240,8 @@ static zhip_ctx* create_impl(int device, size_t maxUnits, size_t seqArena, size_
     ok = ok && hipHostMalloc((void**)&c->hOutSize, (maxUnits + 1) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->hParse, maxUnits * sizeof(ZhipParse), hipHostMallocDefault) == hipSuccess;
     {   // the queue form of the ZSTD_fast stage (launch_parse)
-        const char* e;
-        c->fastQueue = (e = getenv("ZHIP_FAST_QUEUE")) ? atoi(e) : ZHIP_FAST_QUEUE_DEFAULT;
-        c->fastOrder = (e = getenv("ZHIP_FAST_ORDER")) ? atoi(e) : ZHIP_FAST_ORDER_DEFAULT;
-        c->fastGWaves = (e = getenv("ZHIP_FAST_GWAVES")) ? atoi(e) : ZHIP_FAST_GWAVES_DEFAULT;
-        if (c->fastGWaves < 0) c->fastGWaves = 0;
-        c->dictQueue = (e = getenv("ZHIP_DICT_QUEUE")) ? atoi(e) : 1;
-        c->dictGWaves = (e = getenv("ZHIP_DICT_GWAVES")) ? atoi(e) : ZHIP_DICT_GWAVES_DEFAULT;
-        if (c->fastGWaves > 16) c->fastGWaves = 16;
+        c->fastQueue = ZHIP_FAST_QUEUE_DEFAULT; c->fastOrder = ZHIP_FAST_ORDER_DEFAULT; c->fastGWaves = ZHIP_FAST_GWAVES_DEFAULT;
+        c->dictQueue = 1; c->dictGWaves = ZHIP_DICT_GWAVES_DEFAULT;
         hipDeviceProp_t prop;
         c->numCUs = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         ok = ok && hipMalloc((void**)&c->dQueue, 64) == hipSuccess;
@@ -299,6 +291,16 @@ int zhip_set_prediction(zhip_ctx* c, int units, int frames)
     if (units < -1 || units > 1 || frames < -1 || frames > 1) return 1;
     if (units >= 0) c->rhPredict = units;
     if (frames >= 0) c->lzPredict = frames;
+    return 0;
+}
+
+// the row matcher's live rows (LzRing): 1 on (default), 0 = live searches walk the links instead — the form a context also falls back to when the
+// rows' arena cannot be allocated; the units' prediction follows (off with the rows, on without).  Same bytes either way.
+int zhip_set_live_rows(zhip_ctx* c, int on)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->lzRingOn = on ? 1 : 0;
+    c->rhPredict = on ? 0 : 1;
     return 0;
 }
 
@@ -383,7 +385,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         u.windowLog = (uint8_t)cp->windowLog; u.chainLog = (uint8_t)cp->chainLog; u.hashLog = (uint8_t)cp->hashLog;
         u.minMatch = (uint8_t)cp->minMatch; u.strategy = (uint8_t)cp->strategy; u.searchLog = (uint8_t)cp->searchLog;
         u.litMode = (cp->strategy == ZHIP_STRAT_FAST && cp->targetLength > 0) ? 1 : 0;
-        {   static int const knob = getenv("ZHIP_DF_WIDTH") ? atoi(getenv("ZHIP_DF_WIDTH")) : 0; u.pad0 = (uint8_t)knob; }   // dfast batch-width knob (scripts/)
+        u.pad0 = 0;
         u.targetLength = cp->targetLength;
         // ZSTD_resolveRowMatchFinderMode (zstd_compress.c:237-253): greedy / lazy / lazy2 use the row-hash matcher when windowLog > 14
         u.rowLog = 0; u.pad1 = 0;
@@ -404,8 +406,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         c->wideFast = true; snprintf(c->err, sizeof(c->err), "hashLog %u does not fit the unit kernel's LDS table", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
     c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen; c->hcHashLog = hcHlog;
     {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
-        static long const envChunk = getenv("ZHIP_HC_CHUNK_UNITS") ? atol(getenv("ZHIP_HC_CHUNK_UNITS")) : 8192;
-        size_t const chunk = envChunk > 0 ? (size_t)envChunk : 8192;
+        size_t const chunk = 8192;
         c->hcChunk = nUnits < chunk ? nUnits : chunk;
     }
     // dfast: one table pair per RESIDENT workgroup (k_parse_dfast's workgroups are persistent and reuse theirs: at most 32 wavefronts per CU), not per unit
@@ -546,24 +547,18 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::hc_chain_lds_bytes(c->hcHashLog), s,
                                srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
             HIPCHK(c, hipEventRecord(he[1], s));
-            {   static int const useGlobal = getenv("ZHIP_HC_SEARCH_GLOBAL") ? atoi(getenv("ZHIP_HC_SEARCH_GLOBAL")) : 0;   // measurement knob: the L2-resident variant
-                size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
-                if (useGlobal)
-                    hipLaunchKernelGGL(zhip::k_hc_search, dim3(((nu + 7) / 8) * 8 * bpu), dim3(ZHIP_HC_SEARCH_THREADS), 0, s,
-                                       srcDev, c->dUnits + u0, nu, bpu, c->dTabs, c->tabStride, c->dBest);
-                else {
-                    if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_search_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
-                                       srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)nullptr);
-                }
+            {   size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
+                if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_search_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
+                                   srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)nullptr);
             }
             HIPCHK(c, hipEventRecord(he[2], s));
             {   // row matcher: the two-pass prediction of the positions the 384-position rule leaves out (zhip_parse_lazy.h: rh_reconcile).  The
                 // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
                 // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
-                // long matches never leaves the first launch ($ZHIP_RH_PREDICT=1 turns it on, $ZHIP_RH_BUDGET: the budget)
-                int const predictOn = c->rhPredict;          // default on (zhip_set_prediction / $ZHIP_RH_PREDICT): exact (emulator, GPU parity tests), measured in round 4
-                static int const budget = getenv("ZHIP_RH_BUDGET") ? atoi(getenv("ZHIP_RH_BUDGET")) : 256;
+                // long matches never leaves the first launch (zhip_set_prediction(units = 1) turns it on; the budget is 256 live searches)
+                int const predictOn = c->rhPredict;          // default off for units with the live rows (zhip_set_prediction): exact either way (emulator, GPU parity tests), measured in round 4
+                int const budget = 256;
                 bool anyRow = false;
                 for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
                 if (predictOn && anyRow && budget > 0) {
@@ -599,8 +594,8 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
         hipLaunchKernelGGL(zhip::k_xxh64, dim3((unsigned)((nUnits + 15) / 16)), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dChecks);
     }
     {   // units of at most ZHIP_ENT_SMALL_MAX bytes take the one-wavefront form of the encoder (small records: a 256-thread
-        // workgroup would mostly wait at its own barriers); $ZHIP_ENT_SMALL=0 keeps everything on the 256-thread form (A/B knob)
-        static int const useSmall = getenv("ZHIP_ENT_SMALL") ? atoi(getenv("ZHIP_ENT_SMALL")) : 1;
+        // workgroup would mostly wait at its own barriers)
+        int const useSmall = 1;
         bool anySmall = false, anyLarge = false;
         if (useSmall) for (size_t i = 0; i < nUnits && !(anySmall && anyLarge); i++) { if (c->hUnits[i].srcLen <= ZHIP_ENT_SMALL_MAX) anySmall = true; else anyLarge = true; }
         else anyLarge = true;
@@ -918,20 +913,25 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
             if (hipMalloc((void**)&c->dLzHeads, needHeads * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
             c->lzHeadCap = needHeads;
         }
+        if (c->lzSlotCap < nU) {
+            (void)hipFree(c->dLzSlots); c->dLzSlots = nullptr; c->lzSlotCap = 0;
+            if (hipMalloc((void**)&c->dLzSlots, nU * sizeof(zhip::ZhipLzSlot)) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(c->dLzRing); c->dLzRing = nullptr; c->lzRingCap = 0;                 // the optional arena makes room for the mandatory one
+                if (hipMalloc((void**)&c->dLzSlots, nU * sizeof(zhip::ZhipLzSlot)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
+            }
+            c->lzSlotCap = nU;
+        }
+        // the OPTIONAL arena last: the live rows must never take the room a mandatory buffer of this call needs
         if (c->lzRingOn && c->lzRing && c->lzRingCap < (size_t)c->lzRing + 256) {
             (void)hipFree(c->dLzRing); c->dLzRing = nullptr; c->lzRingCap = 0;
             if (hipMalloc((void**)&c->dLzRing, (size_t)c->lzRing + 256) == hipSuccess) c->lzRingCap = (size_t)c->lzRing + 256;
             else (void)hipGetLastError();                         // no room for the live rows: the parser walks the links instead (same bytes, slower on long matches)
         }
-        if (c->lzSlotCap < nU) {
-            (void)hipFree(c->dLzSlots); c->dLzSlots = nullptr; c->lzSlotCap = 0;
-            if (hipMalloc((void**)&c->dLzSlots, nU * sizeof(zhip::ZhipLzSlot)) != hipSuccess) { (void)hipGetLastError(); return ZERR(ZE_memory_allocation); }
-            c->lzSlotCap = nU;
-        }
         HIPCHK(c, hipMemcpyAsync(c->dLzSlots, c->hLz.data(), nU * sizeof(zhip::ZhipLzSlot), hipMemcpyHostToDevice, s));
     }
     size_t const lds = zhip::frame_lds_bytes(ldsTab);
-    bool const hbmOnly = ldsTab == 0 && !getenv("ZHIP_FRAME_NO_HBM_KERNEL");           // no table in LDS: the variant compiled for four workgroups per CU
+    bool const hbmOnly = ldsTab == 0;                                                  // no table in LDS: the variant compiled for four workgroups per CU
     HIPCHK(c, hipFuncSetAttribute(hbmOnly ? (const void*)zhip::k_frame_hbm : (const void*)zhip::k_frame_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipMemcpyAsync(c->dUnits, c->hUnits, nU * sizeof(ZhipUnit), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->dSlots, c->hSlots, nU * sizeof(ZhipSlot), hipMemcpyHostToDevice, s));
@@ -1236,8 +1236,18 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         size_t const a = nRec * t / nThreads, b = nRec * (t + 1) / nThreads;
         for (size_t i = a; i < b; i++) { ZhipSlot& sl = c->hSlots[i]; sl.seqOff += bs; sl.litOff += bl; sl.outOff += bo; }
     };
-    if (nThreads == 1) fill(0);
-    else { std::vector<std::thread> th; for (unsigned t = 0; t < nThreads; t++) th.emplace_back(fill, t); for (auto& x : th) x.join(); }
+    // run f(t) for t in [first, nThreads): on threads where they can be had (thread creation may throw — rlimit, a container's pid cap — and nothing
+    // may unwind through the C ABI), the rest on this one
+    auto run_parts = [&](auto f, unsigned first) {
+        std::vector<std::thread> th;
+        unsigned t = first;
+        if (nThreads - first > 1) {
+            try { for (; t + 1 < nThreads; t++) th.emplace_back(f, t); } catch (...) { }
+        }
+        for (; t < nThreads; t++) f(t);
+        for (auto& x : th) x.join();
+    };
+    run_parts(fill, 0);
     uint64_t bound = 0;
     std::vector<uint64_t> bs(nThreads), bl(nThreads), bo(nThreads);
     for (unsigned t = 0; t < nThreads; t++) {
@@ -1252,7 +1262,7 @@ static size_t compress_records_locked(zhip_ctx* c, const zhip_cdict* cd, void* d
         extIdx.insert(extIdx.end(), P.ext.begin(), P.ext.end());
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
-    if (nThreads > 1) { std::vector<std::thread> th; for (unsigned t = 1; t < nThreads; t++) th.emplace_back(rebase, t, bs[t], bl[t], bo[t]); for (auto& x : th) x.join(); }
+    if (nThreads > 1) run_parts([&](unsigned t) { rebase(t, bs[t], bl[t], bo[t]); }, 1);
     if (seqOff > c->seqArena || litOff > c->litArena || outOff > c->outArena) {
         snprintf(c->err, sizeof(c->err), "records need %llu sequence slots / %llu literal bytes / %llu output bytes: context too small (zhip_create_for_records)",
                  (unsigned long long)seqOff, (unsigned long long)litOff, (unsigned long long)outOff);
