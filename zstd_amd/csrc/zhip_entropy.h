@@ -194,6 +194,36 @@ struct RunPacker {
     __device__ __forceinline__ void finish() { if (nb) atomicOr(wp, (uint32_t)acc); nb = 0; acc = 0; }
 };
 
+// The same with the interior words collected four at a time and stored as 16 bytes (round 5).  A lane of the full-size huff0 packer owns a
+// run of ~190 symbols = ~48 output words of its own: stored one by one, every store instruction of the wavefront touched 64 different
+// lines four bytes at a time, the lines left L2 between two visits, and WRITE_SIZE of the stage was 7 x the frames it wrote
+// (profiles/r04_L1_datagen_sq_tcc.txt).
+struct RunPacker4 {
+    uint32_t* wp; uint64_t acc; uint32_t nb; bool first;
+    uint32_t b0, b1, b2, b3, nbuf;
+    __device__ __forceinline__ void init(uint32_t* base, uint64_t startBit) { wp = base + (startBit >> 5); nb = (uint32_t)startBit & 31; acc = 0; first = true; nbuf = 0; b0 = b1 = b2 = b3 = 0; }
+    __device__ __forceinline__ void add(uint32_t v, uint32_t n)
+    {
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) {
+            uint32_t const w = (uint32_t)acc;
+            acc >>= 32; nb -= 32;
+            if (first) { atomicOr(wp, w); first = false; wp++; return; }
+            if (nbuf == 0) b0 = w; else if (nbuf == 1) b1 = w; else if (nbuf == 2) b2 = w; else b3 = w;
+            if (++nbuf == 4) { uint4 const q = { b0, b1, b2, b3 }; __builtin_memcpy(wp, &q, 16); wp += 4; nbuf = 0; }
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nbuf >= 1) wp[0] = b0;
+        if (nbuf >= 2) wp[1] = b1;
+        if (nbuf >= 3) wp[2] = b2;
+        wp += nbuf; nbuf = 0;
+        if (nb) atomicOr(wp, (uint32_t)acc);
+        nb = 0; acc = 0;
+    }
+};
+
 // ------------------------------------------------------------------ sequence field access
 __device__ __forceinline__ void seq_fields(const ZhipSeq* seqs, const ZhipParse& m, uint32_t i, uint32_t& ll, uint32_t& mlBase, uint32_t& offBase)
 {
@@ -782,7 +812,15 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                     uint8_t* const sbase = litDst + sh->streamOff[sI];
                     uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
                     uint64_t const bit0 = 8ull * ((uintptr_t)sbase & 3);
-                    RunPacker pk; pk.init(w32, bit0 + (uint64_t)(total[q] - incl[q]));
+#ifndef ZHIP_HUF_PACK4
+#define ZHIP_HUF_PACK4 1
+#endif
+#if ZHIP_HUF_PACK4
+                    RunPacker4 pk;
+#else
+                    RunPacker pk;
+#endif
+                    pk.init(w32, bit0 + (uint64_t)(total[q] - incl[q]));
                     const uint8_t* p = lits + segStart[q] + runStart[q];
                     // the run is consumed from its end, 32 bytes per round; the first round takes the odd part
                     uint32_t i = runLen[q];
