@@ -107,7 +107,20 @@ __device__ __forceinline__ uint32_t first_repeat_lane(uint32_t key, unsigned lon
 // requests) lost as well — the candidate fetch is also the prefetch that makes the E loads of the event loop hit (event loop 29.5 -> 48 M
 // cycles per unit, profiles/r05_dfast_phases_tagtrust.log).  What would move the stage is fewer table requests per searched position:
 // a window gathers 2 x 64 entries and the reference searches about a quarter of those positions on dense-match data.
-struct DfPre { uint64_t bytes; uint32_t v1, v2, B; };       // B = ~0: nothing preloaded
+// What one window hands to the next (B = ~0 / tB = ~0: nothing): the next window's source bytes (requested before the stores), and — round 5 —
+// the table entries of the lanes this window gathered but did not reach.  Consecutive windows overlap (on text a window advances 29 of its 64
+// positions: hash collisions cut it short) and the stage is bound by the NUMBER of random requests (profiles/README_r05.md): every gather
+// misses the L2, the re-gather of the overlapping lanes included.  An entry read by the window at tB is still the table's entry when the next
+// window starts iff no lane the window INSERTED shares its hash; the inserted lanes leave a mark in the scratch slots (the detector the window's
+// front uses), a lane whose two slots carry no mark hands its entries and hit flags over (bit 2 of `hit`; the compares do not change: same
+// position, same entry), the others — and slot aliases of inserted lanes — are gathered again.
+struct DfPre { uint64_t bytes; uint32_t v1, v2, B; uint32_t eL, eS, hit, tB; };
+#ifndef ZHIP_DF_PRELOAD
+#define ZHIP_DF_PRELOAD 1            /* measurement switch: 0 = every window loads its own source bytes */
+#endif
+#ifndef ZHIP_DF_TABCARRY
+#define ZHIP_DF_TABCARRY 1           /* measurement switch: 0 = every window gathers all of its lanes */
+#endif
 
 template <uint32_t MLS, bool WIDE>
 __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uint32_t n, uint32_t nm8, uint32_t shL, uint32_t shS,
@@ -120,7 +133,7 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     uint32_t const B = ip_ - (carryIn == 1 ? 2u : 0u), P = B + lane;
     if (out.pendLen) lits_flush(out);
     uint64_t bytes; uint32_t v1, v2;
-    if (pre.B == B) { bytes = pre.bytes; v1 = pre.v1; v2 = pre.v2; }
+    if (ZHIP_DF_PRELOAD && pre.B == B) { bytes = pre.bytes; v1 = pre.v1; v2 = pre.v2; }
     else {
         bytes = ld64(src + P);
         v1 = ld32(src + (P - off1_)); v2 = ld32(src + (P - off2_));       // an invalid repcode (0) reads the lane's own bytes
@@ -131,7 +144,19 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     uint32_t const vL = mulhi64_top32(bytes, 0xCF1BBCDCB7A56463ULL);
     uint32_t const hl = vL >> shL, hs = hash_pos<MLS>(bytes, shS);
     uint32_t const tgL = df_tag_long(vL), tgS = df_tag_short(cur32);
-    uint32_t const eL = tabL[hl], eS = tabS[hs];
+    // the lanes the window before already gathered (see DfPre) take their entries from its registers; they all read entry 0 — one line, one request
+    bool haveT = false; uint32_t eLc = 0, eSc = 0, hitc = 0;
+    if (ZHIP_DF_TABCARRY) {
+        uint32_t const shift = B - pre.tB, ol = lane + shift;              // the lane's index in the window at tB
+        eLc = pull(pre.eL, ol & 63u); eSc = pull(pre.eS, ol & 63u); hitc = pull(pre.hit, ol & 63u);
+        haveT = pre.tB != ~0u && shift < 64u && ol < 64u && (hitc & 4u) != 0;
+    }
+#ifdef ZHIP_DBG_PRINT
+    { unsigned long long hv = __ballot(haveT); if (lane == 0) printf("  dftab B=%u carried=%d\n", B, (int)__builtin_popcountll(hv)); }
+#endif
+    pre.tB = ~0u;
+    uint32_t const tL = tabL[haveT ? 0u : hl], tS = tabS[haveT ? 0u : hs];
+    uint32_t const eL = haveT ? eLc : tL, eS = haveT ? eSc : tS;
     ZWPROF_SYNC(out, 2);
     uint32_t const oldL = DF_POS(eL), oldS = DF_POS(eS);
     uint32_t const sl = hl & (ZHIP_DF_SCRATCH - 1), ss = hs & (ZHIP_DF_SCRATCH - 1);
@@ -143,10 +168,10 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     // the event loop hit them (taking the tag's word and confirming by the E load alone was measured: the loads then miss one after the
     // other, event loop 29.5 -> 48 M cycles per unit, profiles/r05_dfast_phases_tagtrust.log)
     uint64_t cbL = ~bytes; uint32_t cbS = ~cur32;
-    if (oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
-    if (oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
-    bool const hitL = oldL != 0 && oldL >= prefixLow && cbL == bytes;        // :203 (index >= lowest, ZSTD_selectAddr)
-    bool const hitS = oldS != 0 && oldS >= prefixLow && cbS == cur32;        // :218
+    if (!haveT && oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
+    if (!haveT && oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+    bool const hitL = haveT ? (hitc & 1u) != 0 : (oldL != 0 && oldL >= prefixLow && cbL == bytes);        // :203 (index >= lowest, ZSTD_selectAddr)
+    bool const hitS = haveT ? (hitc & 2u) != 0 : (oldS != 0 && oldS >= prefixLow && cbS == cur32);        // :218
     ZWPROF_SYNC(out, 3);
     ZWPROF_COUNT(out, 10, 1);
     uint32_t W = 64;
@@ -311,9 +336,22 @@ dw_done:
         bool const nxt = (status == ZW_CONT || status == ZW_CARRY) && nB + ZHIP_DFW_NEED <= n;
         // unconditional on purpose (a load inside a branch is waited for inside the branch): without a next window the lanes read their own bytes again
         uint32_t const q = (nxt ? nB : B) + lane;
-        pre.bytes = ld64(src + q);
-        pre.v1 = ld32(src + (q - (nxt ? off1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? off2 : 0u)));
-        pre.B = nxt ? nB : ~0u;
+        if (ZHIP_DF_PRELOAD) {
+            pre.bytes = ld64(src + q);
+            pre.v1 = ld32(src + (q - (nxt ? off1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? off2 : 0u)));
+            pre.B = nxt ? nB : ~0u;
+        }
+        if (ZHIP_DF_TABCARRY && nxt && nB < B + 64u) {
+            // which of the lanes the next window shares with this one still hold the table's entries: those no inserted lane shares a slot with
+            unsigned long long const insAnyL = INSL | (lateLane < 64 ? 1ull << lateLane : 0ull), insAnyS = INSS | (lateLane < 64 ? 1ull << lateLane : 0ull);
+            if (__builtin_amdgcn_inverse_ballot_w64(insAnyL)) scrL[sl] = 0x80;
+            if (__builtin_amdgcn_inverse_ballot_w64(insAnyS)) scrS[ss] = 0x80;
+            __builtin_amdgcn_wave_barrier();
+            bool const clean = scrL[sl] != 0x80 && scrS[ss] != 0x80;
+            __builtin_amdgcn_wave_barrier();
+            pre.eL = eL; pre.eS = eS; pre.hit = (hitL ? 1u : 0u) | (hitS ? 2u : 0u) | (clean ? 4u : 0u);
+            pre.tB = B;
+        }
     }
     // the window's table writes (no two inserted lanes share a hash: they all lie below W)
     if (__builtin_amdgcn_inverse_ballot_w64(INSL)) tabL[hl] = DF_ENTRY(P, tgL);
@@ -432,7 +470,8 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
     uint32_t evAvg16 = 12u << 4, kCap = 32;
     bool have = false; uint64_t nbytes = 0; uint32_t nrv = 0;                // the source bytes of the next batch, when the round behind a match fetched them
     uint32_t carry = 0;                                                      // a window handed the end of its last match to the next one (window_dfast)
-    DfPre pre; pre.bytes = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;            // the next window's source bytes, loaded by the window before
+    DfPre pre; pre.bytes = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;            // what one window hands to the next: source bytes, table entries (DfPre)
+    pre.eL = 0; pre.eS = 0; pre.hit = 0; pre.tB = ~0u;
     for (;;) {                                                               // one turn per match (:167)
         uint32_t step = 1, nextStep = ip + 256;
         if ((int32_t)(ip + 1) > ilimit) break;                               // :172
@@ -445,7 +484,7 @@ __device__ inline void parse_dfast_block(const uint8_t* __restrict__ src, uint32
             int const st = window_dfast<MLS, WIDE>(src, n, nm8, shL, shS, tabL, tabS, scrL, scrS, out, ip, anchor, off1, off2, nextStep, prefixLow, curr, postFirst, carry, pre);
             have = false;
             if (st == ZW_CONT || st == ZW_CARRY) continue;                   // (a carrying window has checked that the next one has room)
-            pre.B = ~0u;
+            pre.B = ~0u; pre.tB = ~0u;
             if (st == ZW_POST) { winDone = 2; break; }
             if (st == ZW_BATCH && carry) {                                   // a hash collision in the first lanes of a carried window: what was carried goes by loads
                 winDone = 2; postFirst = carry == 1; skipCurr2 = true; curr = 0; carry = 0;
