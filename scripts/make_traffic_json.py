@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """scripts/make_traffic_json.py — writes profiles/latest_traffic.json (what bench.py's `roofline.traffic` quotes) from the round's committed counter
-summaries: profiles/r04_L1_datagen_sq_tcc.txt (scripts/pmc_sq.sh) and profiles/r04_pmc_legs_<leg>.txt (scripts/pmc_legs.sh).  FETCH_SIZE / WRITE_SIZE are KiB
+summaries: profiles/r05_L1_datagen_sq_tcc.txt (scripts/pmc_sq.sh) and profiles/r05_pmc_legs_<leg>.txt (scripts/pmc_legs.sh).  FETCH_SIZE / WRITE_SIZE are KiB
 per dispatch.  Note for the queue stages: rocprofv3 serialises kernels while it collects counters, so the LDS-table kernel (k_parse_fast_q, k_parse_dict_q)
 takes every unit of the batch and its global-table co-kernel finds the queue empty — the figures are the STAGE's traffic with all units on the LDS form."""
 import json, os, re, sys
@@ -24,8 +24,8 @@ def hbm(c):      # FETCH_SIZE x2 = the guide's gfx950 correction (calibrated on 
     return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
 
 
-head = counters(os.path.join(P, "r04_L1_datagen_sq_tcc.txt"))
-out = {"source": "profiles/r04_L1_datagen_sq_tcc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only; scripts/pmc_sq.sh r04_L1_datagen 1 1024: "
+head = counters(os.path.join(P, "r05_L1_datagen_sq_tcc.txt"))
+out = {"source": "profiles/r05_L1_datagen_sq_tcc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only; scripts/pmc_sq.sh r05_L1_datagen 1 1024: "
                  "bench.py --level 1 --mib 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined-extra --no-extra-legs); counter passes serialise kernels: k_parse_fast_q takes all "
                  "8 192 units, the figure is the whole ZSTD_fast stage on the LDS form",
        "units": "counter values are KiB per dispatch, averaged over the dispatches of the run",
@@ -38,12 +38,13 @@ out["k_parse_fast_hbm_bytes_per_launch"], out["k_parse_fast_hbm_bytes_per_launch
 out["k_decode_hbm_bytes_per_launch"] = hbm(head["k_decode"])[0]
 out["legs"] = {}
 for leg, kern, key in (("silesia4_level1", "k_parse_fast_q", "k_parse_fast"), ("silesia64_level3", "k_parse_dfast", "k_parse_dfast"), ("records_zdict_level3", "k_parse_dict_q", "k_parse_dict")):
-    c = counters(os.path.join(P, f"r04_pmc_legs_{leg}.txt"))[kern]
+    c = counters(os.path.join(P, f"r05_pmc_legs_{leg}.txt"))[kern]
     a, b = hbm(c)
     out["legs"][leg] = {f"{key}_FETCH_SIZE_KiB_raw": c["FETCH_SIZE"], f"{key}_WRITE_SIZE_KiB_raw": c["WRITE_SIZE"], f"{key}_hbm_bytes_per_launch": a,
                         f"{key}_hbm_bytes_per_launch_uncorrected": b, "kernel_counted": kern,
-                        "source": f"profiles/r04_pmc_legs_{leg}.txt (scripts/pmc_legs.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only, of bench.py with "
-                                  f"this leg's workload flags, round 4; FETCH_SIZE x2 = the guide's gfx950 correction, WRITE_SIZE as counted)"}
+                        "source": f"profiles/r05_pmc_legs_{leg}.txt (scripts/pmc_legs.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only, of bench.py with "
+                                  f"this leg's workload flags, round 5; FETCH_SIZE x2 = the guide's gfx950 correction, WRITE_SIZE as counted; counter passes serialise kernels, so for the queue stages "
+                                  f"(k_parse_fast_q/_g, k_parse_dict_q/_g) the LDS-table kernel takes every unit and the figure is the stage with all units on that form — not the mix the timed run executes)"}
 json.dump(out, open(os.path.join(P, "latest_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "bytes_per_launch" in k}, indent=1))
 print(json.dumps({l: {k: v for k, v in d.items() if "bytes_per_launch" in k} for l, d in out["legs"].items()}, indent=1))
