@@ -161,8 +161,8 @@ int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 /* The row matcher's two-pass prediction: a first parse marks the positions the 384-position rule and lazy skipping will leave
  * un-inserted, the per-position records are recomputed without them, and the exact parse redoes a search live only where prediction and truth differ.
- * Same bytes with it on or off (at creation: $ZHIP_RH_PREDICT / $ZHIP_LZ_PREDICT = 0 | 1).  Units: off by default — the live searches read the row
- * matcher's rows as the reference keeps them ("live rows"), and one parse is then the fastest form ($ZHIP_LZ_RING=0 at creation: walk
+ * Same bytes with it on or off (this call sets it).  Units: off by default — the live searches read the row
+ * matcher's rows as the reference keeps them ("live rows"), and one parse is then the fastest form (zhip_set_live_rows(ctx, 0): walk
  * the links instead; the units' prediction then defaults to on).  Frames: on by default, behind a probe — a window whose first 32 KB leave nothing
  * un-inserted is parsed once.
  * units / frames: 1 on, 0 off, -1 unchanged.  returns 0, or 1 for a bad value. */
@@ -248,7 +248,7 @@ size_t       zhip_seekable_read(zhip_dctx* dctx, void* dst, size_t len, const vo
 void         zhip_dctx_last_timing(const zhip_dctx* dctx, double t[2]);
 /* One LARGE frame is decoded block-parallel (zstd_amd/csrc/zhip_decode_big.h: symbolic repeat offsets + a scan, pointer jumping over a
  * copy map) instead of by one workgroup: frames without a dictionary that hold at least minContent bytes of content (stated in the header, or bounded by the destination slot)
- * (default 8 MiB, $ZHIP_BIGFRAME_MIN; 0 = never).  Same bytes, same errors: whatever that path declines goes through the per-frame decoder.
+ * (default 8 MiB; 0 = never).  Same bytes, same errors: whatever that path declines goes through the per-frame decoder.
  * zhip_dctx_last_bigframe: [0] frames of the last call decoded block-parallel, [1] frames that fell back, [2] pointer-jumping rounds, [3] blocks. */
 void         zhip_dctx_set_bigframe_min(zhip_dctx* dctx, unsigned long long minContent);
 void         zhip_dctx_last_bigframe(const zhip_dctx* dctx, unsigned out[4]);

@@ -34,7 +34,7 @@
 //                left out (data without long matches never pays for it).  A live search is then two round trips (row, candidates' bytes)
 //                whatever the number of left-out positions; the walk through prev[] steps over every one of them — on long-match data
 //                some 250 dependent loads per search in an 8 MiB window (round 3 / 4: 0.004 GB/s on one job-pool frame).
-//   k_lz_predict (on by default, $ZHIP_LZ_PREDICT=0 turns it off) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
+//   k_lz_predict (on by default, zhip_set_prediction(frames = 0) turns it off) the two-pass prediction of zhip_parse_lazy.h (rh_reconcile) for a window: a first parse marks the positions
 //                it would leave un-inserted, k_lz_search runs again stepping over them, and the exact parse distrusts a record only where
 //                prediction and truth differ.  Its first 32 KB are a probe: a window that leaves (almost) nothing out there is parsed once.
 #pragma once

@@ -87,7 +87,7 @@ struct zhip_ctx_s {
     uint32_t* dLzPrev = nullptr; uint8_t* dLzTags = nullptr; zhip::LzRec* dLzBest = nullptr; uint32_t* dLzHeads = nullptr; zhip::ZhipLzSlot* dLzSlots = nullptr;
     size_t lzPosCap = 0, lzHeadCap = 0, lzSlotCap = 0, lzRingCap = 0;
     uint32_t* dRhRing = nullptr; size_t rhRingCap = 0, rhRingStride = 0;    // the same for units (zhip_parse_lazy.h: rh_live_ring), one set of rows per unit of a chunk
-    uint8_t* dLzRing = nullptr; uint64_t lzRing = 0; int lzRingOn = 1;      // the row matcher's live rows (zhip_frame_lazy.h: LzRing); $ZHIP_LZ_RING=0: live searches walk the links
+    uint8_t* dLzRing = nullptr; uint64_t lzRing = 0; int lzRingOn = 1;      // the row matcher's live rows (zhip_frame_lazy.h: LzRing); zhip_set_live_rows(0): live searches walk the links
     std::vector<zhip::ZhipLzSlot> hLz; bool lzAny = false, lzAll = false; uint64_t lzPos = 0, lzHeads = 0; uint32_t lzLongest = 0;
     // staging for the host-buffer API
     uint8_t* dSrcStage; size_t srcStageCap;
@@ -104,10 +104,10 @@ struct zhip_ctx_s {
     // ZSTD_fast queue form (launch_parse): ticket counter, dispatch order + cost classes, the co-kernel's tables in global memory, its stream
     uint32_t* dQueue = nullptr; uint32_t* dOrder = nullptr; uint32_t* dCost = nullptr; uint32_t* dGTabs = nullptr; size_t gtabsCap = 0;
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
-    int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // $ZHIP_FAST_QUEUE / $ZHIP_FAST_ORDER / $ZHIP_FAST_GWAVES
+    int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // the ZSTD_fast stage: queue form, heaviest-first order, global-table wavefronts per CU (constants, A/B in profiles/r05_ab_fast_occupancy.log)
     int dfOccPerCU = 0;                                  // resident k_parse_dfast workgroups per CU (asked once)
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
-    int dictQueue = 1, dictGWaves = 0;                   // $ZHIP_DICT_QUEUE / $ZHIP_DICT_GWAVES: the records stage's queue form, global-table wavefronts per CU
+    int dictQueue = 1, dictGWaves = 0;                   // the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
     int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction).  Units: OFF with the live rows (datagen level 5, 256 MiB: 2.57 GB/s
                                          // against 2.27 with it; without the rows 1.53 / 2.00 — zhip_set_live_rows(0) turns it on).  Frames: ON, behind a 32 KB probe per window (1 MiB datagen
@@ -951,8 +951,8 @@ static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, s
             hipLaunchKernelGGL(zhip::k_lz_search, dim3((c->lzLongest + 255) / 256, (unsigned)nw), dim3(256), 0, s,
                                (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)w0, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, (const zhip::ZhipFrameState*)nullptr);
         }
-        {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict; $ZHIP_LZ_PREDICT=1 turns it on)
-            int const predictOn = c->lzPredict;              // on by default (zhip_set_prediction / $ZHIP_LZ_PREDICT): a window whose first 32 KB leave nothing out is parsed once
+        {   // the two-pass prediction of the positions the parse leaves un-inserted (zhip_frame_lazy.h: frame_lazy_predict)
+            int const predictOn = c->lzPredict;              // on by default (zhip_set_prediction): a window whose first 32 KB leave nothing out is parsed once
             if (predictOn) {
                 hipLaunchKernelGGL(zhip::k_lz_predict, dim3((unsigned)nU), dim3(64), sizeof(ZhipParse), s,
                                    (const uint8_t*)srcDev, c->dUnits, jb, c->dLzSlots, (uint32_t)nU, c->dLzPrev, c->dLzTags, c->dLzBest, c->dFrameState);
