@@ -40,6 +40,18 @@ def _oracle_hash_chain_mode_by_default():
 # test and then reports every test of the file from the child's XML, so counts, -x and -k behave as usual.
 CHILD = os.environ.get("ZHIP_GPU_CHILD") == "1"
 _file_results = {}
+_selected = {}            # file -> node ids of the GPU tests the parent selected there (-k, a node id, --deselect): the child runs exactly those
+
+
+def pytest_collection_modifyitems(session, config, items):
+    if CHILD:
+        return
+    _selected.clear()
+
+
+def _key_of_nodeid(nodeid):
+    """`tests/test_x.py::TestC::test_a[p]` -> `TestC::test_a[p]` (what the child's junit record is keyed by below)"""
+    return "::".join(nodeid.split("::")[1:])
 
 
 def _run_file(item):
@@ -50,7 +62,8 @@ def _run_file(item):
         deadline = int(m.args[0])
     xml = tempfile.NamedTemporaryFile(prefix="zhip_gpu_", suffix=".xml", delete=False).name
     env = dict(os.environ, ZHIP_GPU_CHILD="1")
-    cmd = [sys.executable, "-m", "pytest", path, "-m", "gpu", "-q", "-p", "no:cacheprovider", "--junitxml=" + xml, "-o", "junit_family=xunit1"]
+    targets = _selected.get(path) or [path]
+    cmd = [sys.executable, "-m", "pytest"] + targets + ["-m", "gpu", "-q", "-p", "no:cacheprovider", "--junitxml=" + xml, "-o", "junit_family=xunit1"]
     t0 = time.time()
     timed_out, tail = False, ""
     try:
@@ -62,7 +75,11 @@ def _run_file(item):
     res = {}
     try:
         for tc in ET.parse(xml).getroot().iter("testcase"):
-            name = tc.get("name")
+            # classname = dotted module path (+ .Class): the key is Class::name, so equal test names in two classes of one file do not collide
+            cparts = (tc.get("classname") or "").split(".")
+            mod = os.path.splitext(os.path.basename(path))[0]
+            cls = cparts[cparts.index(mod) + 1:] if mod in cparts else []
+            name = "::".join(cls + [tc.get("name")])
             bad = [c for c in tc if c.tag in ("failure", "error")]
             skip = [c for c in tc if c.tag == "skipped"]
             if bad:
@@ -90,7 +107,7 @@ def pytest_runtest_protocol(item, nextitem):
     if path not in _file_results:
         _file_results[path] = _run_file(item)
     res, why = _file_results[path]
-    outcome, text = res.get(item.name, ("failed", why))
+    outcome, text = res.get(_key_of_nodeid(item.nodeid), ("failed", why))
     from _pytest.reports import TestReport
     item.ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
     for when in ("setup", "call", "teardown"):
@@ -112,7 +129,12 @@ def pytest_runtest_protocol(item, nextitem):
 
 
 def pytest_collection_finish(session):
-    """the -m gpu parent loads the product library (no GPU call) so that the run's own process shows the in-tree .so it tests"""
+    """the parent remembers which GPU tests of each file were selected; it also loads the product library (no GPU call) so that the run's own
+    process shows the in-tree .so it tests"""
+    if not CHILD:
+        for it in session.items:
+            if it.get_closest_marker("gpu") is not None:
+                _selected.setdefault(str(it.fspath), []).append(it.nodeid)
     if not CHILD and any(it.get_closest_marker("gpu") is not None for it in session.items):
         try:
             import zstd_amd

@@ -140,3 +140,52 @@ def test_plugin_reused_buffer_with_new_content_is_reparsed(env):
         Z.ZSTD_freeCCtx(cctx)
         assert not Z.ZSTD_isError(r2)
         roundtrip(Z, buf, r2, dst2)
+
+
+def test_plugin_many_cctx_on_host_threads_share_one_prepared_context(env):
+    """ONE zhip_prepare_sequences, then N reference CCtx on N host threads — each with the producer registered and the SAME zhip context as its
+    state — compress shards of whole blocks: prepared blocks are served from the cache without the context lock (the bench's plugin_B1 leg).  Every
+    shard must round-trip and equal what one thread alone makes of it; a block the cache does not hold (another size) must not cost the others
+    their parse."""
+    import threading
+    Z, zstd_amd, ctx, lo = env
+    blk, nthr = 65536, 4
+    a = np.concatenate([datagen(lo, 24 * blk, 50, 21), text_like(8 * blk, 4)])
+    per = len(a) // nthr // blk * blk
+    shards = [(i * per, per) for i in range(nthr)]
+    L = zstd_amd.lib()
+    fn = C.cast(L.zhip_sequence_producer, C.c_void_p)
+    big = zstd_amd.Context(0, max_units=len(a) // blk + 2)
+
+    def one(o, ln, out, idx):
+        cctx = Z.ZSTD_createCCtx()
+        Z.ZSTD_CCtx_setParameter(cctx, ZSTD_c_compressionLevel, 1)
+        Z.ZSTD_CCtx_setParameter(cctx, ZSTD_c_maxBlockSize, blk)
+        Z.ZSTD_CCtx_setParameter(cctx, ZSTD_c_validateSequences, 1)
+        Z.ZSTD_registerSequenceProducer(cctx, big._h, fn)
+        cap = Z.ZSTD_compressBound(ln)
+        dst = np.zeros(cap, dtype=np.uint8)
+        r = Z.ZSTD_compress2(cctx, _buf(dst), cap, a.ctypes.data + o, ln)
+        Z.ZSTD_freeCCtx(cctx)
+        out[idx] = (r, dst)
+
+    assert not L.zhip_isError(L.zhip_prepare_sequences(big._h, _buf(a), len(a), blk, 1))
+    par = [None] * nthr
+    th = [threading.Thread(target=one, args=(o, ln, par, i)) for i, (o, ln) in enumerate(shards)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    # an unprepared block of another size in between (served by its own launch) ...
+    odd = datagen(lo, 50000, 50, 33)
+    r_odd, d_odd = compress_with_plugin(Z, zstd_amd, big, odd, 1, max_block=50000, prepare=False)
+    assert not Z.ZSTD_isError(r_odd)
+    roundtrip(Z, odd, r_odd, d_odd)
+    # ... must leave the prepared cache in place: the same shards again, one thread, same bytes
+    seq = [None] * nthr
+    for i, (o, ln) in enumerate(shards):
+        one(o, ln, seq, i)
+    for (o, ln), (r, dst), (r2, dst2) in zip(shards, par, seq):
+        assert not Z.ZSTD_isError(r) and r == r2 and dst[:r].tobytes() == dst2[:r2].tobytes()
+        roundtrip(Z, a[o:o + ln], r, dst)
+    big.close()
