@@ -21,8 +21,11 @@ struct zhip_multi_lane {
     uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[2] = {nullptr, nullptr};       // hipHostMalloc; two slots each: the copy into / out of staging of one chunk runs beside the device work of another
     uint32_t* pinSizes[2] = {nullptr, nullptr};
     uint8_t *dIn = nullptr, *dOut = nullptr; uint32_t* dSizes = nullptr;
+    uint8_t* dIn2[2] = {nullptr, nullptr};                     // zhip_compress_multi: two device input buffers (dIn2[0] == dIn), so that the H2D of chunk i+1 runs under the kernels of chunk i
+    hipStream_t copyStream = nullptr;                          // the lane's H2D copies (the kernels and the D2H are on ctx->stream)
+    hipEvent_t evIn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per input slot: before / after its H2D on copyStream
     size_t inCap = 0, outCap = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // stage marks of the chunk in flight: before H2D, after H2D, after the kernels, after D2H
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // stage marks of the chunk in flight: (unused), start of the kernels, after the kernels, after D2H
 };
 struct zhip_multi_s {
     std::vector<zhip_multi_lane> lanes;
@@ -43,6 +46,9 @@ static void multi_free(zhip_multi_s* m)
         (void)hipSetDevice(L.device);
         if (L.ctx) zhip_destroy(L.ctx);
         for (auto& e : L.ev) if (e) (void)hipEventDestroy(e);
+        for (auto& ee : L.evIn) for (auto& e : ee) if (e) (void)hipEventDestroy(e);
+        if (L.copyStream) (void)hipStreamDestroy(L.copyStream);
+        (void)hipFree(L.dIn2[1]);
         for (int b = 0; b < 2; b++) { (void)hipHostFree(L.pinIn[b]); (void)hipHostFree(L.pinOut[b]); (void)hipHostFree(L.pinSizes[b]); }
         (void)hipFree(L.dIn); (void)hipFree(L.dOut); (void)hipFree(L.dSizes);
     }
@@ -83,6 +89,10 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
         ok = ok && hipMalloc((void**)&L.dIn, inCap) == hipSuccess && hipMalloc((void**)&L.dOut, outCap) == hipSuccess;
         ok = ok && hipMalloc((void**)&L.dSizes, chunkUnits * sizeof(uint32_t)) == hipSuccess;
         for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        for (auto& ee : L.evIn) for (auto& e : ee) ok = ok && hipEventCreate(&e) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&L.copyStream, hipStreamNonBlocking) == hipSuccess;
+        L.dIn2[0] = L.dIn;
+        ok = ok && hipMalloc((void**)&L.dIn2[1], inCap) == hipSuccess;
         if (!ok) { multi_free(m); (void)hipGetLastError(); return nullptr; }
     }
     return m;
@@ -112,9 +122,27 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
     if (cparams && !zhip::host_check_overrides(cparams)) return ZERR(ZE_parameter_outOfBound);
     auto const t0 = std::chrono::steady_clock::now();
     uint8_t* const dst = (uint8_t*)dstv; const uint8_t* const src = (const uint8_t*)srcv;
-    size_t const chunkBytes = m->chunkUnits * unitSize;
-    size_t const nChunks = srcSize ? (srcSize + chunkBytes - 1) / chunkBytes : 1;
     size_t const nLanes = m->lanes.size();
+    // The chunk plan.  Full chunks of chunkUnits units, with a RAMP at both ends when the source is long enough: the first chunk of every lane
+    // is a quarter chunk (the device starts after 32 MB have been copied into staging instead of 128), and so is the last one (what runs after the
+    // last byte has crossed PCIe — kernels, D2H, copy-out of one chunk — is a quarter as long).  cu0[k] = first unit of chunk k.
+    size_t const nUnitsAll = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
+    std::vector<size_t> cu0;
+    {   size_t const full = m->chunkUnits, small = full >= 8 ? full / 4 : full;
+        bool const ramp = small < full && nUnitsAll >= 2 * nLanes * full;
+        size_t u = 0, k = 0;
+        size_t const tailStart = ramp ? nUnitsAll - nLanes * small : nUnitsAll;
+        while (u < nUnitsAll) {
+            cu0.push_back(u);
+            size_t take = (ramp && (k < nLanes || u >= tailStart)) ? small : full;
+            if (ramp && u < tailStart && u + take > tailStart) take = tailStart - u;     // the last full-size chunk ends where the tail ramp starts
+            u += take; k++;
+        }
+        cu0.push_back(nUnitsAll);
+    }
+    size_t const nChunks = cu0.size() - 1;
+    auto chunk_b0 = [&](size_t k) { return cu0[k] * unitSize; };
+    auto chunk_len = [&](size_t k) { size_t const a = cu0[k] * unitSize, b = cu0[k + 1] * unitSize; return (b < srcSize ? b : srcSize) - (a < srcSize ? a : srcSize); };
     // ordered gather state
     std::vector<size_t> size(nChunks, 0), off(nChunks + 1, 0);
     std::vector<char> known(nChunks, 0);
@@ -124,9 +152,10 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
     m->err[0] = 0;
     for (auto& v : m->stages) v = 0;
 
-    // A lane is three host threads around one HIP stream, two pinned slots between them in each direction:
-    //   feeder  : copies chunk i+1 of the lane from the caller's (pageable) buffer into a free input slot while chunk i is on the device;
-    //   device  : H2D -> kernels -> D2H of one chunk at a time on the lane's stream;
+    // A lane is three host threads around two HIP streams, two pinned slots between them in each direction:
+    //   feeder  : copies chunk i+1 of the lane from the caller's (pageable) buffer into a free input slot and issues its H2D on the lane's copy
+    //             stream (its own device buffer), while chunk i is in its kernels;
+    //   device  : kernels -> D2H of one chunk at a time on the lane's stream, behind the event of the chunk's H2D;
     //   gatherer: waits until every earlier chunk (in source order) has published its size, then copies the frames to their final place.
     // (Round 4 ran the three in one thread per lane: 10.4 ms per 64 MB chunk of which 4 ms were the device's — profiles/r05_e2e_stages.log.)
     auto lane_fn = [&](size_t li) {
@@ -151,10 +180,15 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
             for (size_t i = 0; i < mine.size(); i++) {
                 int const b = (int)(i & 1);
                 {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return inState[b] == 0 || stop; }); if (stop) return; }
-                size_t const k = mine[i], b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                size_t const k = mine[i], b0 = chunk_b0(k), len = chunk_len(k);
                 auto const t0 = std::chrono::steady_clock::now();
                 if (len) memcpy(L.pinIn[b], src + b0, len);
                 tIn += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                bool ok = i != 0 || hipSetDevice(L.device) == hipSuccess;
+                ok = ok && hipEventRecord(L.evIn[b][0], L.copyStream) == hipSuccess;
+                if (ok && len) ok = hipMemcpyAsync(L.dIn2[b], L.pinIn[b], len, hipMemcpyHostToDevice, L.copyStream) == hipSuccess;
+                ok = ok && hipEventRecord(L.evIn[b][1], L.copyStream) == hipSuccess;
+                if (!ok) { fail(ZERR(ZE_GENERIC), k); return; }
                 {   std::lock_guard<std::mutex> g(lm); inState[b] = 1; }
                 lcv.notify_all();
             }
@@ -165,7 +199,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 size_t const k = mine[i];
                 {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return outState[b] == 1 || stop; }); if (stop) return; }
                 size_t const r = outBytes[b];
-                size_t const b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                size_t const len = chunk_len(k);
                 size_t const nu = len ? (len + unitSize - 1) / unitSize : 1;
                 auto const t0 = std::chrono::steady_clock::now();
                 size_t myOff = 0;
@@ -180,7 +214,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 if (myOff + r > dstCapacity) { fail(ZERR(ZE_dstSize_tooSmall), k); return; }
                 auto const t1 = std::chrono::steady_clock::now();
                 memcpy(dst + myOff, L.pinOut[b], r);
-                if (unitSizes) { size_t const u0 = k * m->chunkUnits; for (size_t j = 0; j < nu; j++) unitSizes[u0 + j] = L.pinSizes[b][j]; }
+                if (unitSizes) { size_t const u0 = cu0[k]; for (size_t j = 0; j < nu; j++) unitSizes[u0 + j] = L.pinSizes[b][j]; }
                 auto const t2 = std::chrono::steady_clock::now();
                 tWait += std::chrono::duration<double>(t1 - t0).count(); tOut += std::chrono::duration<double>(t2 - t1).count();
                 {   std::lock_guard<std::mutex> g(lm); outState[b] = 0; }
@@ -192,17 +226,18 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
             zhip_set_frame_checksum(L.ctx, m->checksum);
             for (size_t i = 0; i < mine.size(); i++) {
                 int const b = (int)(i & 1);
-                size_t const k = mine[i], b0 = k * chunkBytes, len = srcSize - b0 < chunkBytes ? srcSize - b0 : chunkBytes;
+                size_t const k = mine[i], len = chunk_len(k);
                 if (failed()) { { std::lock_guard<std::mutex> g(lm); stop = true; } lcv.notify_all(); break; }
                 {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return (inState[b] == 1 && outState[b] == 0) || stop; }); if (stop) break; }
                 size_t r = 0;
                 hipStream_t const s = L.ctx->stream;
-                (void)hipEventRecord(L.ev[0], s);
-                if (len && hipMemcpyAsync(L.dIn, L.pinIn[b], len, hipMemcpyHostToDevice, s) != hipSuccess) r = ZERR(ZE_GENERIC);
+                if (hipStreamWaitEvent(s, L.evIn[b][1], 0) != hipSuccess) r = ZERR(ZE_GENERIC);       // the chunk's H2D (issued by the feeder on the copy stream)
                 (void)hipEventRecord(L.ev[1], s);
-                if (!r) r = zhip_compress_params_device(L.ctx, L.dOut, L.outCap, L.dIn, len, level, cparams, unitSize, L.dSizes, (void*)s);
+                if (!r) r = zhip_compress_params_device(L.ctx, L.dOut, L.outCap, L.dIn2[b], len, level, cparams, unitSize, L.dSizes, (void*)s);
                 size_t const nu = len ? (len + unitSize - 1) / unitSize : 1;
                 if (!zhip_isError(r)) {
+                    // (the D2H stays on the kernels' stream: on its own stream, under the next chunk's kernels, the call got slower — 30.0 -> 24.6 GB/s,
+                    // per-chunk kernel time 3.7 -> 6.2 ms, profiles/r05_e2e_stages.log)
                     bool ok = hipEventRecord(L.ev[2], s) == hipSuccess;
                     ok = ok && hipMemcpyAsync(L.pinOut[b], L.dOut, r, hipMemcpyDeviceToHost, s) == hipSuccess;
                     ok = ok && hipMemcpyAsync(L.pinSizes[b], L.dSizes, nu * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
@@ -212,7 +247,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 }
                 if (zhip_isError(r)) { fail(r, k); break; }
                 {   float a = 0, bb = 0, c2 = 0;
-                    (void)hipEventElapsedTime(&a, L.ev[0], L.ev[1]); (void)hipEventElapsedTime(&bb, L.ev[1], L.ev[2]); (void)hipEventElapsedTime(&c2, L.ev[2], L.ev[3]);
+                    (void)hipEventElapsedTime(&a, L.evIn[b][0], L.evIn[b][1]); (void)hipEventElapsedTime(&bb, L.ev[1], L.ev[2]); (void)hipEventElapsedTime(&c2, L.ev[2], L.ev[3]);
                     tH2D += a * 1e-3; tK += bb * 1e-3; tD2H += c2 * 1e-3; }
                 {   std::lock_guard<std::mutex> g(lm); inState[b] = 0; outState[b] = 1; outBytes[b] = r; }
                 lcv.notify_all();
