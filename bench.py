@@ -601,8 +601,9 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
     return {"value": round(len(host) / bestm / 1e6, 1), "unit": "MB/s", "best_of": 4, "source_bytes": int(len(host)),
             "same_bytes_as_device_path": same,
             "stages_of_last_call": stages,
-            "path": "zhip_compress_multi on this one device: two lanes (stream + feeder / device / gatherer threads + two pinned slots each way), 128 MB chunks: memcpy -> H2D -> kernels -> "
-                    "D2H -> ordered host gather into the caller's buffer; stage seconds are summed over chunks and lanes (they overlap); PCIe- and host-memcpy-inclusive, never `value`",
+            "path": "zhip_compress_multi on this one device: two lanes (kernel stream + copy stream, feeder / device / gatherer threads, two pinned slots each way), 128 MB chunks with quarter "
+                    "chunks at both ends: memcpy -> H2D (under the previous chunk's kernels) -> kernels -> D2H -> ordered host gather into the caller's buffer; stage seconds are summed "
+                    "over chunks and lanes (they overlap); PCIe- and host-memcpy-inclusive, never `value`",
             "synchronous_single_stream": {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "path": "zhip_compress: pageable source, blocking H2D / kernels / D2H on one stream"}}
 
 
