@@ -61,6 +61,14 @@ def main():
                "batch scheme until its event", "its match (df_extend) + emit", "post-match round(s) (inserts, immediate repcode, next bytes)"]
     names_e = ["gather+hist", "huf table build", "huf sizing+hdr", "huf pack", "seq hist+tables", "fse state chains",
                "seq bit pack", "headers"]
+    if level >= 5:
+        names_l = ["init", "batch front (records + repcode bytes, event detect)", "event pick + repcode extension", "search: LIVE (rows catch-up + ring search)",
+                   "search: from the record", "lazy steps + catch-up + prefetch", "emit (literals, sequence)", "immediate-repcode loop"]
+        tot = sum(v[:8]) or 1
+        print(json.dumps({"timing_ms": tm, "hc_ms": ctx.hc_timing(), "units": units,
+                          "lazy_ticks_per_unit": {names_l[i]: [round(v[i] / units), round(100.0 * v[i] / tot, 1)] for i in range(8)},
+                          "batches_per_unit": v[10] / units, "sequences_per_unit": v[11] / units, "live_searches_per_unit": v[12] / units, "failed_searches_per_unit": v[13] / units}, indent=1))
+        return
     if level in (3, 4):
         tot = sum(v[:10]) or 1
         print(json.dumps({"timing_ms": tm, "units": units,

@@ -82,11 +82,19 @@ __device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r
 //      equal hash are put in order with the slot-as-detector trick of zhip_parse.h.
 // (The version that re-scanned the unit once per slice spent most of its instructions on those scans: 25 ms per GiB.)
 #define ZHIP_HC_SLICE_LOG 14u
+#ifndef ZHIP_RH_SEEN_BITS
+#define ZHIP_RH_SEEN_BITS 16u        /* the row matcher's tag filter, bits per row (rh_chain_unit; 16: two rows share a word; 32 costs the link builder a resident wavefront per CU: 49 KB of LDS instead of 33) */
+#endif
 __host__ __device__ inline uint32_t hc_chain_lds_bytes(uint32_t hashLog)
 {
     uint32_t const e = 1u << (hashLog < ZHIP_HC_SLICE_LOG ? hashLog : ZHIP_HC_SLICE_LOG);
     uint32_t const plane = (e >> 3) < 4 ? 4 : (e >> 3);
-    return 2u * e + plane + 64u * 4u;                     // lo16[e], bit plane, slice counters / cursors
+    uint32_t const hc = 2u * e + plane + 64u * 4u;        // lo16[e], bit plane, slice counters / cursors
+    // the row matcher's link builder (rh_chain_unit) shares the allocation: head table of 2^(hashLog - rowLog) rows (rowLog >= 4) + one 32-bit
+    // tag filter per row
+    uint32_t const rl = hashLog > 9 ? hashLog - 4 : 5;
+    uint32_t const rh = (2u << rl) + ((1u << rl) >> 3) + (ZHIP_RH_SEEN_BITS / 8u << rl) + 64u;
+    return hc > rh ? hc : rh;
 }
 
 template <uint32_t MLS>
@@ -281,6 +289,12 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
 // search walks at most 2^rowLog - 1 links.  The salt is the one a fresh CCtx has on its first frame.
 //   prev[p] = (1 + previous position of p's row) | tag(p) << 18   (| ZHIP_HC_SKIPPED once the parser knows p was never inserted)
 #define ZHIP_RH_LINK_MASK 0x3FFFFu
+// (round 5) prev[p] bit 26, copied into bit 53 of p's record: some EARLIER position of p's row may carry p's tag (a 32-bit filter per row over the
+// tags' low five bits, kept by the link builder over ALL earlier positions of the row).  Clear = no position the row ever saw has p's tag, so
+// ZSTD_RowFindBestMatch at p finds no candidate whatever subset of them the parse inserted: such a search never needs to be redone live — on
+// long-match data most live searches were of this kind and failed (profiles/r05_l5_phases_before.log: 17 000 live searches per unit, 12 300 failed).
+#define ZHIP_RH_TAGSEEN  0x04000000u
+#define ZHIP_REC_TAGSEEN (1ull << 53)
 __host__ __device__ inline uint64_t rh_bitmix(uint64_t val, uint64_t len)            // zstd_compress.c:1964-1970
 {
     val ^= ((val >> 49) | (val << 15)) ^ ((val >> 24) | (val << 40));
@@ -310,8 +324,9 @@ __device__ inline void rh_chain_unit(const uint8_t* __restrict__ src, uint32_t n
     FastTab T;
     T.lo = (lds_u16*)(uintptr_t)smem;
     T.hi = (lds_u32*)(uintptr_t)(smem + (2u << rowHashLog));
+    lds_u32* const seenBits = (lds_u32*)(uintptr_t)(smem + ((fast_lds_bytes(rowHashLog) + 63u) & ~63u));      // one word per row: which tags (mod 32) the row has seen
     {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = fast_lds_bytes(rowHashLog) >> 2;
+        uint32_t const words = (((fast_lds_bytes(rowHashLog) + 63u) & ~63u) >> 2) + ((ZHIP_RH_SEEN_BITS / 8u << rowHashLog) >> 2);
         for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
@@ -323,7 +338,11 @@ __device__ inline void rh_chain_unit(const uint8_t* __restrict__ src, uint32_t n
         uint32_t const h = hash_pos_salted<MLS>(bytes, hBits, salt), row = h >> 8, tag = h & 0xFFu;
         uint32_t old = T.lo[row];
         if (p0 + 64 > 65535u) old |= ((T.hi[row >> 5] >> (row & 31)) & 1u) << 16;
+        // the row's tags BEFORE this step: bit (tag mod SEEN_BITS) of the row's field
+        uint32_t const sIdx = ZHIP_RH_SEEN_BITS == 32u ? row : row >> 1, sBit = ZHIP_RH_SEEN_BITS == 32u ? (tag & 31u) : ((tag & 15u) + 16u * (row & 1u));
+        uint32_t const seenWord = seenBits[sIdx];
         __builtin_amdgcn_wave_barrier();
+        if (live) __hip_atomic_fetch_or(&seenBits[sIdx], 1u << sBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (live) T.lo[row] = (uint16_t)lane;
         __builtin_amdgcn_wave_barrier();
         unsigned long long const liveMask = __ballot(live);
@@ -339,7 +358,9 @@ __device__ inline void rh_chain_unit(const uint8_t* __restrict__ src, uint32_t n
         }
         __builtin_amdgcn_wave_barrier();
         if (live) {
-            prev[p] = link | (tag << 18);
+            // a lane that shares its row with an earlier lane of this step counts as "seen" (their tags are not compared: rare, and only costs a live search)
+            bool const seen = ((seenWord >> sBit) & 1u) != 0 || (grp & laneBelow) != 0;
+            prev[p] = link | (tag << 18) | (seen ? ZHIP_RH_TAGSEEN : 0u);
             if ((grp & ~below_mask((int)lane + 1)) == 0) tab_put(T, row, p + 1);     // the last lane of a row group leaves the head
         }
         __builtin_amdgcn_wave_barrier();
@@ -377,9 +398,10 @@ __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
         }
         m = w & ZHIP_RH_LINK_MASK;
     }
-    if (nCap == 0) return hc_pack(off, ml, 0, minCand);
-    if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand);
-    return hc_pack(0, 0, 3, minCand);
+    uint64_t const seen = (w0 & ZHIP_RH_TAGSEEN) ? ZHIP_REC_TAGSEEN : 0ull;
+    if (nCap == 0) return hc_pack(off, ml, 0, minCand) | seen;
+    if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand) | seen;
+    return hc_pack(0, 0, 3, minCand) | seen;
 }
 
 // ------------------------------------------------------------------ kernel C: the parser, one wavefront per unit
@@ -701,6 +723,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     if (!st.predict) LZ_STAT(0, 1);
     uint32_t const minCand = hc_rec_min(rec), mode = hc_rec_mode(rec);
     bool live = mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd);
+    if (live && u.rowLog && !(rec & ZHIP_REC_TAGSEEN)) live = false;                // no position of x's row ever carried x's tag: the record's "nothing" stands
     if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x);      // a record only depends on its own row
     if (live) {
         st.nLive++;
@@ -737,6 +760,11 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const depth = (uint32_t)u.strategy - 3;      // greedy 0, lazy 1, lazy2 2
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
+    ZPROF_DECL
+#ifdef ZHIP_PROF
+    out.zp = zp_acc_; out.zlast = &zp_last_;
+#endif
+    ZPROF(0);
 
     uint32_t anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;
     // zstd_lazy.c:1552-1559  ip = 1, lowest index 0 -> maxRep = 1
@@ -786,10 +814,14 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             if (u.rowLog && st.gapEnd != 0) {
                 stale = valid && stale && rh_row_dirty(src, n, u, st, xc);      // per lane: a record only depends on its own row
             }
-            bool const needLive = valid && (hc_rec_mode(recj) == 3 || stale);
+            // a search whose row never saw its tag finds nothing whatever the rows hold: never live (row matcher; the hash-chain records do not carry the bit)
+            bool const tagSeen = !u.rowLog || (recj & ZHIP_REC_TAGSEEN) != 0;
+            bool const needLive = valid && tagSeen && (hc_rec_mode(recj) == 3 || stale);
             bool const found = valid && (hc_rec_mode(recj) != 0 || hc_rec_b(recj) >= 4);
             K = (uint32_t)__popcll(__ballot(valid));
             ev = __ballot(repj || needLive || found);
+            ZWPROF_SYNC(out, 1);
+            ZWPROF_COUNT(out, 10, 1);
             if (!ev) {                                                       // K failed searches (:1613-1624), lazySkipping = 0
                 st.ntu = ip + (K - 1) * step + rowBias; st.skipping = 0;
                 ip = ip + K * step;
@@ -821,12 +853,16 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
                 if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1); }
             }
             ip = x;
+            ZWPROF_SYNC(out, 2);
             if (direct) break;
             {   uint32_t ml2, ob2;                                           // :1607-1611
+                uint32_t const live0 = st.nLive;
                 hc_search(src, n, u, prev, st, x, rec, ml2, ob2);
+                if (st.nLive != live0) { ZWPROF_SYNC(out, 3); ZWPROF_COUNT(out, 12, 1); } else ZWPROF_SYNC(out, 4);
                 if (ml2 > matchLength) { matchLength = ml2; start = x; offBase = ob2; }
             }
             if (matchLength >= 4) break;
+            ZWPROF_COUNT(out, 13, 1);
             failed = true;                                                   // :1613-1625
             if (step <= 8 && st.epoch == epoch1 && !st.abort) {
                 ev &= ~below_mask(e + 1);
@@ -895,10 +931,13 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
                 off2 = off1; off1 = off;
             }
         }
+        ZWPROF_SYNC(out, 5);
         if (!predict) {
         lits_copy(out, src, nm8, anchor, start - anchor);                    // :1727-1731
         store_seq(out, start - anchor, offBase, matchLength);
         }
+        ZWPROF_COUNT(out, 11, 1);
+        ZWPROF(out, 6);
         anchor = ip = start + matchLength;
         st.skipping = 0;                                                     // :1732-1738
         while (ip <= ilimit && off2 > 0) {                                   // :1763-1773
@@ -908,7 +947,9 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             if (!predict) store_seq(out, 0, 1, rl);
             ip += rl; anchor = ip;
         }
+        ZWPROF_SYNC(out, 7);
     }
+    ZPROF_FLUSH(0);
     if (predict) return;
     if (st.abort) { if (lane == 0) meta->status = ZHIP_PARSE_REDO; return; }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
