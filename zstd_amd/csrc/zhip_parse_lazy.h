@@ -376,6 +376,7 @@ __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
     uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE, nCap = 0, capA = 0, capB = 0;
     uint32_t const w0 = prev[p], myTag = (w0 >> 18) & 0xFFu;
     uint32_t m = w0 & ZHIP_RH_LINK_MASK;
+    if (!(w0 & ZHIP_RH_TAGSEEN)) m = 0;                                     // the row never saw this tag: no candidate whatever is inserted, nothing to walk
     bool done = false;
     while (m != 0 && attempts && room) {
         uint32_t const mp = m - 1;
