@@ -295,6 +295,7 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
 // long-match data most live searches were of this kind and failed (profiles/r05_l5_phases_before.log: 17 000 live searches per unit, 12 300 failed).
 #define ZHIP_RH_TAGSEEN  0x04000000u
 #define ZHIP_REC_TAGSEEN (1ull << 53)
+#define ZHIP_REC_WHOLE (1ull << 54)      /* row matcher: the record's walk saw every earlier position of its row (see rh_search_pos_lds) */
 __host__ __device__ inline uint64_t rh_bitmix(uint64_t val, uint64_t len)            // zstd_compress.c:1964-1970
 {
     val ^= ((val >> 49) | (val << 15)) ^ ((val >> 24) | (val << 40));
@@ -399,7 +400,9 @@ __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
         }
         m = w & ZHIP_RH_LINK_MASK;
     }
-    uint64_t const seen = (w0 & ZHIP_RH_TAGSEEN) ? ZHIP_REC_TAGSEEN : 0ull;
+    // WHOLE: the walk reached the end of the row's links with room left — the row never held 2^rowLog - 1 positions, so whatever is left out of
+    // it the candidates of this search are the inserted positions of its own tag: only a left-out position of the same row AND tag changes it
+    uint64_t const seen = ((w0 & ZHIP_RH_TAGSEEN) ? ZHIP_REC_TAGSEEN : 0ull) | ((m == 0 && room) ? ZHIP_REC_WHOLE : 0ull);
     if (nCap == 0) return hc_pack(off, ml, 0, minCand) | seen;
     if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand) | seen;
     return hc_pack(0, 0, 3, minCand) | seen;
@@ -427,7 +430,11 @@ struct HcState {
 // the live rows of one unit: rows counts of inserts (4 B each), then 2^rowLog slots per row: position | tag << 17
 __host__ __device__ inline size_t rh_ring_words(uint32_t hashLog, uint32_t rowLog) { return rowLog ? ((size_t)1 << (hashLog - rowLog)) + ((size_t)1 << hashLog) : 0; }
 #define ZHIP_PARSE_REDO 0x5245444Fu          /* ZhipParse.status of a unit whose TRY parse gave up */
-#define ZHIP_RH_DIRTY_BYTES 2048u      /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
+#define ZHIP_RH_ROWBITS_BYTES 2048u    /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
+#define ZHIP_RH_FINE_LOG 16u           /* then one bit per (row, leading tag bits): the top 16 bits of the row-and-tag hash */
+#define ZHIP_RH_DIRTY_BYTES (ZHIP_RH_ROWBITS_BYTES + (1u << ZHIP_RH_FINE_LOG) / 8u)
+// bit index of a row-and-tag hash of hBits bits in the fine map
+__device__ __forceinline__ uint32_t rh_fine_key(uint32_t h, uint32_t hBits) { return hBits > ZHIP_RH_FINE_LOG ? h >> (hBits - ZHIP_RH_FINE_LOG) : h; }
 
 // Two-pass prediction (row matcher).  A record is computed before the parse knows which positions it will leave un-inserted; on
 // long-match data the 384-position rule skips the inside of every long match, nearly every row then holds such a position and every
@@ -490,8 +497,9 @@ __device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t
             if (mism) {
                 uint32_t const qc = q < nm8 ? q : nm8;
                 uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + qc) : ld64(src + qc);
-                uint32_t const row = hash_pos_salted<MLS>(bytes, hBits, salt) >> 8;
+                uint32_t const h = hash_pos_salted<MLS>(bytes, hBits, salt), row = h >> 8, fk = rh_fine_key(h, hBits);
                 __hip_atomic_fetch_or(&st.dirty[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(&st.dirty[ZHIP_RH_ROWBITS_BYTES / 4 + (fk >> 5)], 1u << (fk & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         if (__ballot(mism)) any = true;
@@ -512,7 +520,9 @@ __device__ inline void rh_flag_range(const uint8_t* __restrict__ src, uint32_t n
     else rh_flag_range_t<6>(src, n, u, prev, st, f0, f1);
 }
 // is the row of position x dirty?  (uniform x: every lane computes the same)
-__device__ inline bool rh_row_dirty(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const HcState& st, uint32_t x)
+// `rec`: the record of x — one whose walk saw the whole row (ZHIP_REC_WHOLE) is only out of date when a position of its row AND tag was left out; that
+// holds while every left-out position was expected in (no predicting parse: with one, a predicted position that IS inserted adds to the rows)
+__device__ inline bool rh_row_dirty(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, const HcState& st, uint32_t x, uint64_t rec)
 {
     uint32_t const nm8 = n - 8, hBits = (uint32_t)u.hashLog - u.rowLog + 8, xc = x < nm8 ? x : nm8;
     uint32_t const mls = u.minMatch < 4 ? 4 : (u.minMatch > 6 ? 6 : u.minMatch);
@@ -520,6 +530,10 @@ __device__ inline bool rh_row_dirty(const uint8_t* __restrict__ src, uint32_t n,
     uint64_t const bytes = mls == 4 ? (uint64_t)ld32(src + xc) : ld64(src + xc);
     uint32_t const h = mls == 4 ? hash_pos_salted<4>(bytes, hBits, salt) : (mls == 5 ? hash_pos_salted<5>(bytes, hBits, salt) : hash_pos_salted<6>(bytes, hBits, salt));
     uint32_t const row = h >> 8;
+    if ((rec & ZHIP_REC_WHOLE) && !st.havePred) {
+        uint32_t const fk = rh_fine_key(h, hBits);
+        return (st.dirty[ZHIP_RH_ROWBITS_BYTES / 4 + (fk >> 5)] >> (fk & 31)) & 1u;
+    }
     return (st.dirty[row >> 5] >> (row & 31)) & 1u;
 }
 
@@ -725,7 +739,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     uint32_t const minCand = hc_rec_min(rec), mode = hc_rec_mode(rec);
     bool live = mode == 3 || (st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd);
     if (live && u.rowLog && !(rec & ZHIP_REC_TAGSEEN)) live = false;                // no position of x's row ever carried x's tag: the record's "nothing" stands
-    if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x);      // a record only depends on its own row
+    if (live && mode != 3 && u.rowLog) live = rh_row_dirty(src, n, u, st, x, rec);      // a record only depends on its own row
     if (live) {
         st.nLive++;
         if (st.budget && st.nLive > st.budget) st.abort = 1;
@@ -813,7 +827,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             uint32_t const minCand = hc_rec_min(recj);
             bool stale = st.gapEnd != 0 && minCand != ZHIP_HC_NONE && minCand <= st.gapEnd;
             if (u.rowLog && st.gapEnd != 0) {
-                stale = valid && stale && rh_row_dirty(src, n, u, st, xc);      // per lane: a record only depends on its own row
+                stale = valid && stale && rh_row_dirty(src, n, u, st, xc, recj);      // per lane: a record only depends on its own row
             }
             // a search whose row never saw its tag finds nothing whatever the rows hold: never live (row matcher; the hash-chain records do not carry the bit)
             bool const tagSeen = !u.rowLog || (recj & ZHIP_REC_TAGSEEN) != 0;
