@@ -22,7 +22,7 @@
 namespace zhip {
 
 // Stage 1 for strategies greedy / lazy / lazy2 (hash chain), three launches — see zhip_parse_lazy.h.
-// tabs + ui * tabStride words: prev[ZHIP_UNIT_MAX]; best + ui * ZHIP_UNIT_MAX records.
+// tabs + ui * tabStride words: prev[ZHIP_UNIT_MAX] (row matcher: + its row lists, hc_table_words); best + ui * ZHIP_UNIT_MAX records.
 // k_hc_chain: dynamic LDS = hc_chain_lds_bytes(max hashLog).
 __global__ void __launch_bounds__(64)
 k_hc_chain(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, uint32_t nUnits,
@@ -92,7 +92,7 @@ k_hc_search_lds(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ un
     __syncthreads();
     const uint32_t* const prev = tabs + (size_t)ui * tabStride;
     uint64_t* const b = best + (size_t)ui * ZHIP_UNIT_MAX;
-    if (u.rowLog) { for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = rh_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.rowLog); }
+    if (u.rowLog) { for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = rh_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.rowLog, metas != nullptr); }
     else for (uint32_t p = t; p <= n - 8; p += ZHIP_HC_SEARCH_LDS_THREADS) b[p] = hc_search_pos_lds(lsrc, n, p, prev, u.searchLog, u.chainLog);
 }
 

@@ -50,8 +50,10 @@ extern unsigned long long zhip_lz_stats[8];   /* 0 searches, 1 live from the row
 #define ZHIP_HC_SEARCH_THREADS 256
 #define ZHIP_HC_SEARCH_LDS_THREADS 1024
 
-// per-unit table memory in 32-bit words: prev[ZHIP_UNIT_MAX] (the chain links; the hash heads only ever live in LDS)
-__host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { (void)hashLog; return ZHIP_UNIT_MAX; }
+// per-unit table memory in 32-bit words: prev[ZHIP_UNIT_MAX] (the chain links; the hash heads only ever live in LDS), and for the row matcher its
+// row lists (rh_chain_unit): 16 words that are only ever read, then one entry per position
+#define ZHIP_RH_LIST_OFF (ZHIP_UNIT_MAX + 16u)
+__host__ __device__ inline size_t hc_table_words(uint32_t hashLog) { (void)hashLog; return (size_t)ZHIP_RH_LIST_OFF + ZHIP_UNIT_MAX; }
 
 // best[] record (64 bits): A (17) | B << 17 (17) | mode << 34 (2) | lowest candidate examined << 36 (17)
 //   mode 0 exact     : A = offset, B = match length (3 = nothing found)
@@ -85,6 +87,13 @@ __device__ __forceinline__ uint32_t hc_rec_min(uint64_t r) { return (uint32_t)(r
 #ifndef ZHIP_RH_SEEN_BITS
 #define ZHIP_RH_SEEN_BITS 16u        /* the row matcher's tag filter, bits per row (rh_chain_unit; 16: two rows share a word; 32 costs the link builder a resident wavefront per CU: 49 KB of LDS instead of 33) */
 #endif
+#define ZHIP_RH_STAGE_BYTES (2048u + 256u)      /* rh_chain_unit: the source bytes of 32 steps */
+// rh_chain_unit's LDS for 2^rl rows: 16-bit cursors | tag filters (together the 32-bit counters of its first pass) | the cursors' 17th bits | staged source bytes
+__host__ __device__ inline uint32_t rh_chain_lds_need(uint32_t rl)
+{
+    uint32_t const a = (2u << rl) + (ZHIP_RH_SEEN_BITS / 8u << rl), cnt = 4u << rl, plane = ((1u << rl) >> 3) < 4 ? 4u : ((1u << rl) >> 3);
+    return (a > cnt ? a : cnt) + plane + ZHIP_RH_STAGE_BYTES + 64u;
+}
 __host__ __device__ inline uint32_t hc_chain_lds_bytes(uint32_t hashLog)
 {
     uint32_t const e = 1u << (hashLog < ZHIP_HC_SLICE_LOG ? hashLog : ZHIP_HC_SLICE_LOG);
@@ -93,7 +102,7 @@ __host__ __device__ inline uint32_t hc_chain_lds_bytes(uint32_t hashLog)
     // the row matcher's link builder (rh_chain_unit) shares the allocation: head table of 2^(hashLog - rowLog) rows (rowLog >= 4) + one 32-bit
     // tag filter per row
     uint32_t const rl = hashLog > 9 ? hashLog - 4 : 5;
-    uint32_t const rh = (2u << rl) + ((1u << rl) >> 3) + (ZHIP_RH_SEEN_BITS / 8u << rl) + 64u;
+    uint32_t const rh = rh_chain_lds_need(rl);
     return hc > rh ? hc : rh;
 }
 
@@ -287,8 +296,15 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
 // is a chain link (prev[], built like the hash-chain links but keyed by the row index — 2^(hashLog - rowLog) <= 2^13 heads, so
 // the head table is the 17-bit LDS table of zhip_parse.h and needs no slicing), the tag rides in the link word, and the
 // search walks at most 2^rowLog - 1 links.  The salt is the one a fresh CCtx has on its first frame.
-//   prev[p] = (1 + previous position of p's row) | tag(p) << 18   (| ZHIP_HC_SKIPPED once the parser knows p was never inserted)
-#define ZHIP_RH_LINK_MASK 0x3FFFFu
+// (round 5) The links became LISTS: a walk down 15 links is 15 dependent loads from 15 cache lines, and k_hc_search_lds was bound by exactly
+// those requests (two walks per thread in flight made it slower, profiles/r05_ab_l5_rowlists.log).  The builder now sorts the unit's positions by
+// row — count, prefix sum, then in position order every position takes the next index of its row — into rowList[] (behind prev[], ZHIP_RH_LIST_OFF),
+// so the row's earlier positions lie right below a position's own index, most recent first going down: 64 contiguous bytes for a whole row.
+//   prev[p]     = index of p in rowList | ZHIP_RH_FIRST (p opens its row) | tag(p) << 18 | ZHIP_RH_TAGSEEN   (| ZHIP_HC_SKIPPED / ZHIP_HC_PRED from the parser)
+//   rowList[i]  = position | tag << 17 | ZHIP_RL_FIRST (the row's first position: a walk ends behind it)
+#define ZHIP_RH_IDX_MASK 0x1FFFFu
+#define ZHIP_RH_FIRST    0x20000u
+#define ZHIP_RL_FIRST    0x02000000u
 // (round 5) prev[p] bit 26, copied into bit 53 of p's record: some EARLIER position of p's row may carry p's tag (a 32-bit filter per row over the
 // tags' low five bits, kept by the link builder over ALL earlier positions of the row).  Clear = no position the row ever saw has p's tag, so
 // ZSTD_RowFindBestMatch at p finds no candidate whatever subset of them the parse inserted: such a search never needs to be redone live — on
@@ -313,96 +329,182 @@ __device__ __forceinline__ uint32_t hash_pos_salted(uint64_t bytes, uint32_t hBi
     uint32_t const top = MLS == 5 ? mulhi64_top32(bytes, 889523592379ULL << 24) : mulhi64_top32(bytes, 227718039650203ULL << 16);
     return (top ^ (uint32_t)(salt >> 32)) >> (32 - hBits);
 }
-__host__ __device__ inline uint32_t rh_chain_lds_bytes(uint32_t rowHashLog) { return fast_lds_bytes(rowHashLog < 5 ? 5 : rowHashLog); }
+typedef ZHIP_LDS uint16_t __attribute__((may_alias)) lds_u16_alias;
+typedef ZHIP_LDS uint32_t __attribute__((may_alias)) lds_u32_alias;
 
 template <uint32_t MLS>
 __device__ inline void rh_chain_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem, uint32_t* __restrict__ prev)
 {
     if (n < 10) return;
     uint32_t const lane = (uint32_t)lane_id();
-    uint32_t const nm8 = n - 8, rowHashLog = (uint32_t)u.hashLog - u.rowLog, hBits = rowHashLog + 8;
+    uint32_t const nm8 = n - 8, rowHashLog = (uint32_t)u.hashLog - u.rowLog, hBits = rowHashLog + 8, rows = 1u << rowHashLog;
     uint64_t const salt = rh_fresh_salt();
-    FastTab T;
-    T.lo = (lds_u16*)(uintptr_t)smem;
-    T.hi = (lds_u32*)(uintptr_t)(smem + (2u << rowHashLog));
-    lds_u32* const seenBits = (lds_u32*)(uintptr_t)(smem + ((fast_lds_bytes(rowHashLog) + 63u) & ~63u));      // one word per row: which tags (mod 32) the row has seen
-    {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
-        uint32_t const words = (((fast_lds_bytes(rowHashLog) + 63u) & ~63u) >> 2) + ((ZHIP_RH_SEEN_BITS / 8u << rowHashLog) >> 2);
-        for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
-    }
+    uint32_t* const rowList = prev + ZHIP_RH_LIST_OFF;
+    // LDS (rh_chain_lds_need): first the rows' 32-bit counts; then, in their place, 16-bit cursors (the next index of each row) and the tag filters; the
+    // cursors' 17th bits lie behind both
+    uint32_t const body = (2u << rowHashLog) + (ZHIP_RH_SEEN_BITS / 8u << rowHashLog) > (4u << rowHashLog) ? (2u << rowHashLog) + (ZHIP_RH_SEEN_BITS / 8u << rowHashLog) : (4u << rowHashLog);
+    lds_u32_alias* const cnt = (lds_u32_alias*)(uintptr_t)smem;
+    lds_u16_alias* const curLo = (lds_u16_alias*)(uintptr_t)smem;
+    lds_u32_alias* const seenBits = (lds_u32_alias*)(uintptr_t)(smem + (2u << rowHashLog));      // per row: which tags (mod ZHIP_RH_SEEN_BITS) it has seen
+    lds_u32_alias* const curHi = (lds_u32_alias*)(uintptr_t)(smem + body);
+    uint32_t const hiWords = rows < 32 ? 1u : rows >> 5;
+    for (uint32_t i = lane; i < (body >> 2) + hiWords; i += 64) cnt[i] = 0;
+    __threadfence_block();
     __builtin_amdgcn_wave_barrier();
+    // ---- 1. how many positions each row gets (order does not matter: four steps' loads in flight together)
+    for (uint32_t p0 = 0; p0 <= nm8; p0 += 256) {
+        uint64_t b[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { uint32_t const p = p0 + 64 * k + lane, pc = p <= nm8 ? p : nm8; b[k] = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc); }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            uint32_t const p = p0 + 64 * k + lane;
+            if (p <= nm8) __hip_atomic_fetch_add(&cnt[hash_pos_salted<MLS>(b[k], hBits, salt) >> 8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    // ---- 2. every row's first index: prefix sums, 64 rows per step; the 16-bit cursor of row r overwrites the count of row r / 2 (read already)
+    {   uint32_t base = 0;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 64) {
+            uint32_t const r = r0 + lane, c = r < rows ? cnt[r] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t const t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            uint32_t const start = base + incl - c;
+            base += __shfl(incl, 63);
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            if (r < rows) curLo[r] = (uint16_t)start;
+            unsigned long long const hiM = __ballot(r < rows && (start >> 16) != 0);
+            if (lane == 0) { curHi[r0 >> 5] = (uint32_t)hiM; if (r0 + 32 < rows) curHi[(r0 >> 5) + 1] = (uint32_t)(hiM >> 32); }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (uint32_t i = lane; i < ((ZHIP_RH_SEEN_BITS / 8u << rowHashLog) >> 2); i += 64) seenBits[i] = 0;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- 3. positions in order, 64 per step: each takes its row's next index
     unsigned long long const laneBelow = below_mask((int)lane);
-    for (uint32_t p0 = 0; p0 <= nm8; p0 += 64) {                              // positions in order, 64 per step; heads hold position + 1
+    // The source bytes come through LDS, 2048 positions per fetch: a wavefront's loads and stores retire in order, so a load issued after the
+    // row-list stores (scattered 4-byte writes) waits for them — with one load per step the loop ran at the pace of those stores (24 ms per GiB
+    // instead of 10, profiles/r05_ab_l5_rowlists.log); now one wait per 32 steps, for loads issued 32 steps earlier.
+    lds_u32_alias* const stage = (lds_u32_alias*)(uintptr_t)(smem + body + (hiWords << 2));        // ZHIP_RH_STAGE_BYTES
+    auto step = [&](uint32_t p0, uint64_t bytes) {
         uint32_t const p = p0 + lane; bool const live = p <= nm8;
-        uint32_t const pc = live ? p : nm8;
-        uint64_t const bytes = MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc);
         uint32_t const h = hash_pos_salted<MLS>(bytes, hBits, salt), row = h >> 8, tag = h & 0xFFu;
-        uint32_t old = T.lo[row];
-        if (p0 + 64 > 65535u) old |= ((T.hi[row >> 5] >> (row & 31)) & 1u) << 16;
+        uint32_t const cur = (uint32_t)curLo[row] | (((curHi[row >> 5] >> (row & 31)) & 1u) << 16);
         // the row's tags BEFORE this step: bit (tag mod SEEN_BITS) of the row's field
-        uint32_t const sIdx = ZHIP_RH_SEEN_BITS == 32u ? row : row >> 1, sBit = ZHIP_RH_SEEN_BITS == 32u ? (tag & 31u) : ((tag & 15u) + 16u * (row & 1u));
+        uint32_t const sIdx = ZHIP_RH_SEEN_BITS == 32u ? row : row >> 1, sSh = ZHIP_RH_SEEN_BITS == 32u ? 0u : 16u * (row & 1u);
+        uint32_t const sBit = (ZHIP_RH_SEEN_BITS == 32u ? (tag & 31u) : (tag & 15u)) + sSh;
         uint32_t const seenWord = seenBits[sIdx];
         __builtin_amdgcn_wave_barrier();
         if (live) __hip_atomic_fetch_or(&seenBits[sIdx], 1u << sBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (live) T.lo[row] = (uint16_t)lane;
+        if (live) curLo[row] = (uint16_t)lane;                                 // the slot as duplicate detector
         __builtin_amdgcn_wave_barrier();
         unsigned long long const liveMask = __ballot(live);
-        unsigned long long const lose = __ballot(live && T.lo[row] != (uint16_t)lane);
-        uint32_t link = old;
+        unsigned long long const lose = __ballot(live && curLo[row] != (uint16_t)lane);
         unsigned long long grp = 0;
-        if (lose) {
-            grp = lane_groups(row, lose, liveMask);
-            unsigned long long const before = grp & laneBelow;
-            uint32_t const pd = before ? 63u - (uint32_t)__clzll((long long)before) : lane;
-            uint32_t const dp = __shfl(p, (int)pd);
-            if (before) link = dp + 1;
-        }
+        if (lose) grp = lane_groups(row, lose, liveMask);
         __builtin_amdgcn_wave_barrier();
         if (live) {
+            uint32_t const rank = (uint32_t)__popcll(grp & laneBelow), total = grp ? (uint32_t)__popcll(grp) : 1u;
+            uint32_t const field = ZHIP_RH_SEEN_BITS == 32u ? seenWord : ((seenWord >> sSh) & 0xFFFFu);
+            bool const first = rank == 0 && field == 0;                        // every earlier position of the row left a bit in its field
             // a lane that shares its row with an earlier lane of this step counts as "seen" (their tags are not compared: rare, and only costs a live search)
-            bool const seen = ((seenWord >> sBit) & 1u) != 0 || (grp & laneBelow) != 0;
-            prev[p] = link | (tag << 18) | (seen ? ZHIP_RH_TAGSEEN : 0u);
-            if ((grp & ~below_mask((int)lane + 1)) == 0) tab_put(T, row, p + 1);     // the last lane of a row group leaves the head
+            bool const seen = ((seenWord >> sBit) & 1u) != 0 || rank != 0;
+            uint32_t const idx = cur + rank;
+            rowList[idx] = p | (tag << 17) | (first ? ZHIP_RL_FIRST : 0u);
+            prev[p] = idx | (first ? ZHIP_RH_FIRST : 0u) | (tag << 18) | (seen ? ZHIP_RH_TAGSEEN : 0u);
+            if (rank + 1 == total) {                                           // the last lane of a row group leaves the cursor
+                uint32_t const nx = cur + total;
+                curLo[row] = (uint16_t)nx;
+                if (nx >> 16) __hip_atomic_fetch_or(&curHi[row >> 5], 1u << (row & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // two loops, so that the staged one holds no load whose wait would fall into every step
+    uint32_t c0 = 0;
+    if (2048 + 256 <= n) {
+        Quad nA, nB; uint32_t nC;
+        auto fetch = [&](uint32_t base) {                                     // bytes [base, base + 2048 + 256) lie inside the unit
+            nA = ld128(src + base + 32 * lane); nB = ld128(src + base + 32 * lane + 16); nC = ld32(src + base + 2048 + 4 * lane);
+        };
+        fetch(0);
+        for (; c0 + 2048 + 256 <= n; c0 += 2048) {
+            __builtin_amdgcn_wave_barrier();
+            stage[8 * lane] = nA.x; stage[8 * lane + 1] = nA.y; stage[8 * lane + 2] = nA.z; stage[8 * lane + 3] = nA.w;
+            stage[8 * lane + 4] = nB.x; stage[8 * lane + 5] = nB.y; stage[8 * lane + 6] = nB.z; stage[8 * lane + 7] = nB.w;
+            stage[512 + lane] = nC;
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            fetch(c0 + 2048 + 2048 + 256 <= n ? c0 + 2048 : c0);              // the next fetch (unconditional: a load inside a branch is waited for there)
+            for (uint32_t k = 0; k < 2048; k += 64) {
+                uint32_t const o = k + lane, sh = (o & 3u) * 8u;
+                uint32_t const w0 = stage[o >> 2], w1 = stage[(o >> 2) + 1], w2 = stage[(o >> 2) + 2];
+                uint64_t const w01 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+                uint64_t const b8 = sh ? (w01 >> sh) | ((uint64_t)w2 << (64u - sh)) : w01;
+                step(c0 + k, MLS <= 4 ? (uint64_t)(uint32_t)b8 : b8);
+            }
+        }
+    }
+    for (uint32_t p0 = c0; p0 <= nm8; p0 += 64) {                             // the unit's last positions: one load per step
+        uint32_t const p = p0 + lane, pc = p <= nm8 ? p : nm8;
+        step(p0, MLS <= 4 ? (uint64_t)ld32(src + pc) : ld64(src + pc));
     }
 }
 
-// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340, noDict) at p with every earlier position inserted; the unit staged in LDS
+// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340, noDict) at p with every earlier position inserted; the unit staged in LDS.  The row's earlier
+// positions are the entries below p's own in rowList, 16 per fetch (four loads in flight); `havePred`: the predicting parse has marked positions
+// in prev[] (k_hc_search_lds's second run) — they take no slot of the row
 __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uint32_t p, const uint32_t* __restrict__ prev,
-                                             uint32_t searchLog, uint32_t rowLog)
+                                             uint32_t searchLog, uint32_t rowLog, bool havePred)
 {
+    const uint32_t* const rowList = prev + ZHIP_RH_LIST_OFF;
     uint32_t const capped = searchLog < rowLog ? searchLog : rowLog;
     uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;             // a row holds 2^rowLog - 1 positions (slot 0 is its head byte)
     uint32_t ml = 3, off = 0, minCand = ZHIP_HC_NONE, nCap = 0, capA = 0, capB = 0;
     uint32_t const w0 = prev[p], myTag = (w0 >> 18) & 0xFFu;
-    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
-    if (!(w0 & ZHIP_RH_TAGSEEN)) m = 0;                                     // the row never saw this tag: no candidate whatever is inserted, nothing to walk
-    bool done = false;
-    while (m != 0 && attempts && room) {
-        uint32_t const mp = m - 1;
-        uint32_t const w = prev[mp];
+    // nothing to walk: p opens its row, or the row never saw p's tag (no candidate whatever is inserted)
+    bool on = !(w0 & ZHIP_RH_FIRST) && (w0 & ZHIP_RH_TAGSEEN);
+    bool ended = !on, done = false;                                          // ended: the walk passed the row's first position
+    uint32_t j = w0 & ZHIP_RH_IDX_MASK;
+    auto visit = [&](uint32_t e) {
+        uint32_t const mp = e & 0x1FFFFu;
         minCand = mp;                                                       // the lowest position VISITED (predicted-skipped ones included)
-        if (w & ZHIP_HC_PRED) { m = w & ZHIP_RH_LINK_MASK; continue; }      // the predicting parse skipped it: it takes no slot of the row
-        room--;
-        if (((w >> 18) & 0xFFu) == myTag) {
-            attempts--;
-            if (!done && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
-                uint32_t cur = 0;
-                for (;;) {
-                    uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
-                    cur += same;
-                    if (same < 8 || cur >= ZHIP_HC_CAP) break;
+        bool const pred = havePred && (prev[mp] & ZHIP_HC_PRED) != 0;       // the predicting parse skipped it: it takes no slot of the row
+        if (!pred) {
+            room--;
+            if (((e >> 17) & 0xFFu) == myTag) {
+                attempts--;
+                if (!done && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+                    uint32_t cur = 0;
+                    for (;;) {
+                        uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
+                        cur += same;
+                        if (same < 8 || cur >= ZHIP_HC_CAP) break;
+                    }
+                    if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
+                    else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) done = true; }      // :1281 best possible: evaluation stops, the row was read anyway
                 }
-                if (cur >= ZHIP_HC_CAP) { if (nCap == 0) capA = mp; else if (nCap == 1) capB = mp; nCap++; if (ml < ZHIP_HC_CAP) ml = ZHIP_HC_CAP; }
-                else if (cur > ml) { ml = cur; off = p - mp; if (p + cur == n) done = true; }      // :1281 best possible: evaluation stops, the row was read anyway
             }
         }
-        m = w & ZHIP_RH_LINK_MASK;
+        if (e & ZHIP_RL_FIRST) { ended = true; on = false; }
+        else if (!attempts || !room) on = false;
+    };
+    while (on) {
+        Quad const q0 = ld128((const uint8_t*)(rowList + j) - 16), q1 = ld128((const uint8_t*)(rowList + j) - 32),
+                   q2 = ld128((const uint8_t*)(rowList + j) - 48), q3 = ld128((const uint8_t*)(rowList + j) - 64);
+        uint32_t const E[16] = { q0.w, q0.z, q0.y, q0.x, q1.w, q1.z, q1.y, q1.x, q2.w, q2.z, q2.y, q2.x, q3.w, q3.z, q3.y, q3.x };
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) if (on) visit(E[i]);
+        j -= 16;
     }
-    // WHOLE: the walk reached the end of the row's links with room left — the row never held 2^rowLog - 1 positions, so whatever is left out of
+    // WHOLE: the walk passed the row's first position with room left — the row never held 2^rowLog - 1 positions, so whatever is left out of
     // it the candidates of this search are the inserted positions of its own tag: only a left-out position of the same row AND tag changes it
-    uint64_t const seen = ((w0 & ZHIP_RH_TAGSEEN) ? ZHIP_REC_TAGSEEN : 0ull) | ((m == 0 && room) ? ZHIP_REC_WHOLE : 0ull);
+    uint64_t const seen = ((w0 & ZHIP_RH_TAGSEEN) ? ZHIP_REC_TAGSEEN : 0ull) | ((ended && room) ? ZHIP_REC_WHOLE : 0ull);
     if (nCap == 0) return hc_pack(off, ml, 0, minCand) | seen;
     if (nCap <= 2) return hc_pack(capA, capB, nCap, minCand) | seen;
     return hc_pack(0, 0, 3, minCand) | seen;
@@ -564,20 +666,21 @@ __device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t 
 __device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
                                       uint32_t searchLog, uint32_t rowLog, uint32_t& mlOut, uint32_t& offOut)
 {
+    const uint32_t* const rowList = prev + ZHIP_RH_LIST_OFF;
     uint32_t const nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
     uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
     uint32_t ml = 3, off = 0;
     uint32_t const w0 = uni(prev[x]), myTag = (w0 >> 18) & 0xFFu;
-    uint32_t m = w0 & ZHIP_RH_LINK_MASK;
-    bool done = false;
-    while (m != 0 && attempts && room) {
-        uint32_t const mp = m - 1;
+    uint32_t j = w0 & ZHIP_RH_IDX_MASK;
+    bool more = !(w0 & ZHIP_RH_FIRST), done = false;
+    while (more && attempts && room) {
+        uint32_t const e = uni(rowList[--j]), mp = e & 0x1FFFFu;
         uint32_t const w = uni(prev[mp]);
-        m = w & ZHIP_RH_LINK_MASK;
+        more = !(e & ZHIP_RL_FIRST);
         LZ_STAT(3, 1);
         if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
         room--;
-        if (((w >> 18) & 0xFFu) != myTag) continue;
+        if (((e >> 17) & 0xFFu) != myTag) continue;
         attempts--;
         if (!done && uni(ld32(src + mp + ml - 3)) == uni(ld32(src + x + ml - 3))) {
             uint32_t const cur = wave_count_fwd(src, x, mp, nm8);
