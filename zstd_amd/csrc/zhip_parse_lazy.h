@@ -900,11 +900,17 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
-    auto prefetch = [&](uint32_t at, uint32_t o1) {
+    // with it, the first immediate-repcode test behind that sequence (:1763): the sequence's end and the offset it is tested with are known too, so its
+    // two loads travel with the catch-up's instead of making a round trip of their own after it
+    uint32_t irAt = 0xFFFFFFFFu, irOff = 0, irCur = 0, irRep = 0;
+    auto prefetch = [&](uint32_t at, uint32_t o1, uint32_t o2) {
         uint32_t const xj = at + lane, xc = xj < nm8 ? xj : nm8;
         pfRec = xj < ilimit ? best[xj] : 0;
         pfCur4 = ld32(src + xc + 1); pfRv = ld32(src + (xc + 1 - o1));
         pfIp = at; pfOff1 = o1;
+        uint32_t const o2c = o2 <= at ? o2 : 0u;
+        irCur = ld32(src + at); irRep = ld32(src + (at - o2c));
+        irAt = at; irOff = o2;
     };
     while (ip < ilimit && !st.abort) {                                       // :1581
         uint32_t const step = ((ip - anchor) >> 8) + 1;                      // :1614 kSearchStrength = 8
@@ -968,7 +974,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
             matchLength = 0; start = x + 1; offBase = 1; direct = false;
             if (repHit) {                                                    // :1600-1604
                 matchLength = 4 + wave_count_fwd(src, x + 5, x + 5 - off1, nm8);
-                if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1); }
+                if (depth == 0) { direct = true; if (start + matchLength < ilimit) prefetch(start + matchLength, off1, off2); }
             }
             ip = x;
             ZWPROF_SYNC(out, 2);
@@ -1040,7 +1046,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
                     break;
                 }
             }
-            if (start + matchLength < ilimit) prefetch(start + matchLength, offBase > 3 ? offBase - 3 : off1);
+            if (start + matchLength < ilimit) prefetch(start + matchLength, offBase > 3 ? offBase - 3 : off1, offBase > 3 ? off1 : off2);
             if (offBase > 3) {                                               // :1707-1714 catch up
                 uint32_t const off = offBase - 3, match = start - off;
                 uint32_t const lim = (start - anchor) < match ? (start - anchor) : match;
@@ -1059,7 +1065,11 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
         anchor = ip = start + matchLength;
         st.skipping = 0;                                                     // :1732-1738
         while (ip <= ilimit && off2 > 0) {                                   // :1763-1773
-            if (uni(ld32(src + ip)) != uni(ld32(src + (ip - off2)))) break;
+            uint32_t cur4, rep4;
+            if (irAt == ip && irOff == off2) { cur4 = irCur; rep4 = irRep; }     // requested before the catch-up
+            else { cur4 = ld32(src + ip); rep4 = ld32(src + (ip - off2)); }
+            irAt = 0xFFFFFFFFu;
+            if (uni(cur4) != uni(rep4)) break;
             uint32_t const rl = 4 + wave_count_fwd(src, ip + 4, ip + 4 - off2, nm8);
             {   uint32_t const t = off2; off2 = off1; off1 = t; }
             if (!predict) store_seq(out, 0, 1, rl);
