@@ -114,6 +114,9 @@ const char* zhip_multi_last_error(const zhip_multi* m) { return m->err; }
 double zhip_multi_last_seconds(const zhip_multi* m) { return m->lastSeconds; }
 void zhip_multi_last_stages(const zhip_multi* m, double out[7]) { for (int i = 0; i < 7; i++) out[i] = m->stages[i]; }
 
+#ifndef ZHIP_MULTI_COPY_THREADS
+#define ZHIP_MULTI_COPY_THREADS 4
+#endif
 size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const void* srcv, size_t srcSize,
                            int level, const unsigned cparams[7], size_t unitSize, size_t* unitSizes)
 {
@@ -158,6 +161,18 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
     //   device  : kernels -> D2H of one chunk at a time on the lane's stream, behind the event of the chunk's H2D;
     //   gatherer: waits until every earlier chunk (in source order) has published its size, then copies the frames to their final place.
     // (Round 4 ran the three in one thread per lane: 10.4 ms per 64 MB chunk of which 4 ms were the device's — profiles/r05_e2e_stages.log.)
+    // a staging copy of more than a few MB is split over ZHIP_MULTI_COPY_THREADS host threads (one thread moves ~26 GB/s of pageable memory on this
+    // box: 4.6 ms per 128 MB chunk, as long as the chunk's kernels)
+    auto par_copy = [](uint8_t* d, const uint8_t* s_, size_t len) {
+        size_t const parts = len >= ((size_t)8 << 20) ? ZHIP_MULTI_COPY_THREADS : 1;
+        if (parts <= 1) { if (len) memcpy(d, s_, len); return; }
+        size_t const per = ((len / parts) + 4095) & ~(size_t)4095;
+        std::vector<std::thread> hs;
+        try { for (size_t i = 1; i < parts; i++) { size_t const a = i * per; if (a < len) hs.emplace_back([=] { memcpy(d + a, s_ + a, (a + per < len ? a + per : len) - a); }); } }
+        catch (...) { for (auto& h : hs) h.join(); memcpy(d, s_, len); return; }        // no thread to be had: one copy of everything (idempotent)
+        memcpy(d, s_, per < len ? per : len);
+        for (auto& h : hs) h.join();
+    };
     auto lane_fn = [&](size_t li) {
         zhip_multi_lane& L = m->lanes[li];
         std::vector<size_t> mine;
@@ -182,7 +197,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return inState[b] == 0 || stop; }); if (stop) return; }
                 size_t const k = mine[i], b0 = chunk_b0(k), len = chunk_len(k);
                 auto const t0 = std::chrono::steady_clock::now();
-                if (len) memcpy(L.pinIn[b], src + b0, len);
+                par_copy(L.pinIn[b], src + b0, len);
                 tIn += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 bool ok = i != 0 || hipSetDevice(L.device) == hipSuccess;
                 ok = ok && hipEventRecord(L.evIn[b][0], L.copyStream) == hipSuccess;
@@ -213,7 +228,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 }
                 if (myOff + r > dstCapacity) { fail(ZERR(ZE_dstSize_tooSmall), k); return; }
                 auto const t1 = std::chrono::steady_clock::now();
-                memcpy(dst + myOff, L.pinOut[b], r);
+                par_copy(dst + myOff, L.pinOut[b], r);
                 if (unitSizes) { size_t const u0 = cu0[k]; for (size_t j = 0; j < nu; j++) unitSizes[u0 + j] = L.pinSizes[b][j]; }
                 auto const t2 = std::chrono::steady_clock::now();
                 tWait += std::chrono::duration<double>(t1 - t0).count(); tOut += std::chrono::duration<double>(t2 - t1).count();
