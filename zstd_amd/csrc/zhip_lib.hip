@@ -406,7 +406,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         c->wideFast = true; snprintf(c->err, sizeof(c->err), "hashLog %u does not fit the unit kernel's LDS table", mh); *err = ZERR(ZE_parameter_unsupported); return 0; }
     c->strategy = fam ? fam : 1; c->tabStride = (tabWords + 3) & ~(size_t)3; c->hcMaxLen = hcMaxLen; c->hcHashLog = hcHlog;
     {   // hash chain: dTabs / dBest hold one chunk of units at a time (1 MB + 1 MB per 128 KB unit)
-        size_t const chunk = 8192;
+        size_t const chunk = 8192;                     // level 5, 1 GiB: 8192 units per chunk 185 ms, 4096: 192 ms, 2048: 263 ms (profiles/r05_ab_l5_rowlists.log) — 21 GB of tables, records and live rows at 8192
         c->hcChunk = nUnits < chunk ? nUnits : chunk;
     }
     // dfast: one table pair per RESIDENT workgroup (k_parse_dfast's workgroups are persistent and reuse theirs: at most 32 wavefronts per CU), not per unit
