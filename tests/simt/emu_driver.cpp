@@ -40,8 +40,7 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
     std::vector<uint32_t> cost(nUnits + 1), order(nUnits + 1), queue(16, 0);
     uint32_t* const pc = cost.data(); uint32_t* const po = order.data(); uint32_t* const pq = queue.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_order_cost(src, units, nUnits, pc); }, osThreads);
-    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po, pq + 8); }, 1);
-    pq[8] = 0;                                            // the 12-wavefront pair of queue kernels (the 16-wavefront pair is the same code under a register cap)
+    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po); }, 1);
     if (orderOut) for (uint32_t i = 0; i < nUnits; i++) orderOut[i] = po[i];
     uint32_t maxH = 6; for (uint32_t i = 0; i < nUnits; i++) if (units[i].hashLog > maxH) maxH = units[i].hashLog;
     uint32_t const gw = 1u << maxH, gridG = 3, gridQ = 2;
@@ -49,13 +48,13 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
     if (mode == 3) {
         // the first kernel's workgroups leave after two units each, the second takes the rest (the queue is shared)
         uint32_t const half = nUnits / 2;
-        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, half, seqs, lits, metas, po, pq, pq + 8); }, osThreads);
+        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, half, seqs, lits, metas, po, pq); }, osThreads);
         pq[0] = half;
-        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw, pq + 8); }, osThreads);
+        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
     } else if (mode == 2) {
-        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw, pq + 8); }, osThreads);
+        simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
     } else {
-        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, nUnits, seqs, lits, metas, po, pq, pq + 8); }, osThreads);
+        simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, nUnits, seqs, lits, metas, po, pq); }, osThreads);
     }
 }
 

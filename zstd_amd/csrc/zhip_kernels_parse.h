@@ -63,11 +63,12 @@ __device__ __forceinline__ uint32_t queue_take(uint32_t* queue)
 #ifndef ZHIP_FASTG_OCC
 #define ZHIP_FASTG_OCC
 #endif
-// the bodies of the two queue kernels (each exists twice, see below)
-__device__ __forceinline__ void fast_q_loop(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-                                            ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-                                            const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, unsigned char* smem)
+__global__ void __launch_bounds__(64) ZHIP_FAST_OCC
+k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
+               const uint32_t* __restrict__ order, uint32_t* __restrict__ queue)
 {
+    HIP_DYNAMIC_SHARED(unsigned char, smem)
     for (;;) {
         uint32_t const t = queue_take(queue);
         if (t >= nUnits) return;
@@ -88,9 +89,10 @@ __device__ __forceinline__ void fast_q_loop(const uint8_t* __restrict__ src, con
         __builtin_amdgcn_wave_barrier();
     }
 }
-__device__ __forceinline__ void fast_g_loop(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-                                            ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-                                            const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
+__global__ void __launch_bounds__(64) ZHIP_FASTG_OCC
+k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
+               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
+               const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
 {
     uint32_t* const gtab = gtabs + (size_t)blockIdx.x * gtabWords;
     for (;;) {
@@ -113,74 +115,21 @@ __device__ __forceinline__ void fast_g_loop(const uint8_t* __restrict__ src, con
         __builtin_amdgcn_wave_barrier();
     }
 }
-// Each queue kernel is compiled twice: for 3 wavefronts per SIMD (~155 VGPRs, no spills; 8 LDS-table + 4 global-table wavefronts per CU) and for 4
-// (128 VGPRs, ~30 scratch accesses per window outside its event loop; 8 + 8).  Sixteen wavefronts win on dense-match data (Silesia-shaped -7 %, text
-// -4 %) and lose where most positions are looked up and nothing is found (datagen +15 %: eight 32 KB global tables per CU fall out of the L2) —
-// profiles/r05_ab_fast_occupancy.log.  Both pairs are launched; `sel` (k_order_sort: the call's mean estimated sequences per unit against
-// ZHIP_FAST_DENSE_COST) tells which one works, the other's workgroups return at once.
-__global__ void __launch_bounds__(64) ZHIP_FAST_OCC
-k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-               const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, const uint32_t* __restrict__ sel)
-{
-    HIP_DYNAMIC_SHARED(unsigned char, smem)
-    if (sel && *sel != 0u) return;
-    fast_q_loop(src, units, slots, nUnits, seqs, lits, metas, order, queue, smem);
-}
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_parse_fast_q4(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-                ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-                const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, const uint32_t* __restrict__ sel)
-{
-    HIP_DYNAMIC_SHARED(unsigned char, smem)
-    if (*sel != 1u) return;
-    fast_q_loop(src, units, slots, nUnits, seqs, lits, metas, order, queue, smem);
-}
-__global__ void __launch_bounds__(64) ZHIP_FASTG_OCC
-k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-               ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-               const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords, const uint32_t* __restrict__ sel)
-{
-    if (sel && *sel != 0u) return;
-    fast_g_loop(src, units, slots, nUnits, seqs, lits, metas, order, queue, gtabs, gtabWords);
-}
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_parse_fast_g4(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
-                ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
-                const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords, const uint32_t* __restrict__ sel)
-{
-    if (*sel != 1u) return;
-    fast_g_loop(src, units, slots, nUnits, seqs, lits, metas, order, queue, gtabs, gtabWords);
-}
 
 
 // Dispatch order for the queue kernels: units sorted by descending cost (a counting sort over 2 048 cost classes, one workgroup).
 // cost: mode 2 = the sequence count the previous call left in metas[] (measurement only: the upper bound an estimator can reach),
 // mode 1 = k_order_cost's estimate.
-#ifndef ZHIP_FAST_DENSE_COST
-#define ZHIP_FAST_DENSE_COST 4500u           /* mean estimated sequences per unit from which the 16-wavefront pair of queue kernels takes the call (datagen 2 864: +27 % there; Silesia-shaped 6 596: -4.3 %; text 10 710: +-0) */
-#endif
 __global__ void __launch_bounds__(1024)
-k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order, uint32_t* __restrict__ sel /* queue kernel pair of this call: 0 = 12 wavefronts per CU, 1 = 16 */)
+k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t part[1024];
-    __shared__ unsigned long long total;
     uint32_t const tid = threadIdx.x;
     hist[tid] = 0; hist[tid + 1024] = 0;
-    if (tid == 0) total = 0;
     __syncthreads();
-    unsigned long long mySum = 0;
-    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const b = cost[i] >> 4; mySum += cost[i]; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
-    atomicAdd(&total, mySum);
+    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const b = cost[i] >> 4; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t const mean = nUnits ? (uint32_t)(total / nUnits) : 0u;
-#ifdef ZHIP_DBG_COST
-        printf("k_order_sort: %u units, mean cost %u\n", nUnits, mean);
-#endif
-        *sel = mean >= ZHIP_FAST_DENSE_COST ? 1u : 0u;
-    }
     // exclusive prefix over the classes (class 0 = the most expensive): two classes per thread, then a scan of the pair sums
     uint32_t const a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
     part[tid] = a0 + a1;

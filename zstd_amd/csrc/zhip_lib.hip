@@ -512,38 +512,24 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         if (wantOrder) {
             if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
             else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
-            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder, c->dQueue + 8);
+            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder);
             order = c->dOrder;
         }
-        // with an order there is a density estimate, and the call goes to one of the two kernel pairs (zhip_kernels_parse.h); the 16-wavefront pair
-        // runs eight global-table wavefronts per CU
-        const uint32_t* const sel = wantOrder ? c->dQueue + 8 : (const uint32_t*)nullptr;
-        size_t gridG4 = 0;
-        if (sel && gridG) { gridG4 = (size_t)8 * (size_t)c->numCUs; if (gridG4 > nUnits - gridQ) gridG4 = nUnits - gridQ; }
-        size_t const gridGmax = gridG4 > gridG ? gridG4 : gridG;
         uint32_t const gtabWords = 1u << maxHashLog;
         if (gridG) {
-            if (c->gtabsCap < gridGmax * gtabWords) {
+            if (c->gtabsCap < gridG * gtabWords) {
                 (void)hipFree(c->dGTabs); c->dGTabs = nullptr; c->gtabsCap = 0;
-                if (hipMalloc((void**)&c->dGTabs, gridGmax * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; gridG4 = 0; }
-                else c->gtabsCap = gridGmax * gtabWords;
+                if (hipMalloc((void**)&c->dGTabs, gridG * gtabWords * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); gridG = 0; }
+                else c->gtabsCap = gridG * gtabWords;
             }
         }
         if (gridG) HIPCHK(c, hipEventRecord(c->coEv[0], s));
         hipLaunchKernelGGL(zhip::k_parse_fast_q, dim3((unsigned)gridQ), dim3(64), smem, s,
-                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, sel);
-        if (sel) {
-            if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_parse_fast_q4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(zhip::k_parse_fast_q4, dim3((unsigned)gridQ), dim3(64), smem, s,
-                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, sel);
-        }
+                           srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue);
         if (gridG) {
             HIPCHK(c, hipStreamWaitEvent(c->coStream, c->coEv[0], 0));
             hipLaunchKernelGGL(zhip::k_parse_fast_g, dim3((unsigned)gridG), dim3(64), 0, c->coStream,
-                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords, sel);
-            if (sel && gridG4)
-                hipLaunchKernelGGL(zhip::k_parse_fast_g4, dim3((unsigned)gridG4), dim3(64), 0, c->coStream,
-                                   srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords, sel);
+                               srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse, order, c->dQueue, c->dGTabs, gtabWords);
             HIPCHK(c, hipEventRecord(c->coEv[1], c->coStream));
             HIPCHK(c, hipStreamWaitEvent(s, c->coEv[1], 0));
         }
