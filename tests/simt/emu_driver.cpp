@@ -89,24 +89,18 @@ void emu_parse_lazy(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
     const char* const pe = getenv("ZHIP_RH_PREDICT"); const char* const be = getenv("ZHIP_RH_BUDGET");
     uint32_t const budget = be ? (uint32_t)atoi(be) : 256u;
     const ZhipParse* const cm = metas;
-    size_t ringStride = 0;                                       // the live rows (as in the library: on unless $ZHIP_LZ_RING=0)
-    {   const char* const re = getenv("ZHIP_LZ_RING");
-        if (!(re && atoi(re) == 0)) for (uint32_t i = 0; i < nUnits; i++) { size_t const w = zhip::rh_ring_words(units[i].hashLog, units[i].rowLog); if (w > ringStride) ringStride = w; }
-    }
-    std::vector<uint32_t> ringv(ringStride * nUnits + 1, 0xDDDDDDDDu);
-    uint32_t* const rings = ringv.data();
     if (anyRow && pe && atoi(pe) != 0) {
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 2u, budget, rings, ringStride); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 2u, budget); }, osThreads);
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 1u, 0u, rings, ringStride); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 1u, 0u); }, osThreads);
         simt::launch({nUnits, 1, 1}, {ZHIP_HC_SEARCH_LDS_THREADS, 1, 1}, ((maxLen + 15) & ~15u) + 32,
                      [=] { zhip::k_hc_search_lds(src, units, nUnits, tabs, tabStride, best, cm); }, osThreads);
         simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 3u, 0u, rings, ringStride); }, osThreads);
+                     [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 3u, 0u); }, osThreads);
     } else
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, ZHIP_RH_DIRTY_BYTES,
-                 [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 0u, 0u, rings, ringStride); }, osThreads);
+                 [=] { zhip::k_parse_lazy(src, units, slots, nUnits, tabs, tabStride, best, seqs, lits, metas, 0u, 0u); }, osThreads);
 }
 uint64_t emu_hc_table_words(uint32_t hashLog) { return zhip::hc_table_words(hashLog); }
 

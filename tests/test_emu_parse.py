@@ -313,9 +313,9 @@ def test_rowhash_two_pass_prediction(libs, monkeypatch):
         lo.zo_set_row_matcher(0)
 
 
-def test_rowhash_units_without_the_live_rows(libs, monkeypatch):
-    """$ZHIP_LZ_RING=0: the row matcher's live searches walk the links (the form before the live rows, and the fallback without their arena) — with and
-    without the units' two-pass prediction: the same sequences as with the rows, i.e. the oracle's frames"""
+def test_rowhash_units_with_and_without_the_two_pass_prediction(libs, monkeypatch):
+    """the unit kernels' live searches read the row lists (rh_live_lists; no live rows are kept for units since round 5) — with and without the units'
+    two-pass prediction ($ZHIP_RH_PREDICT, the emulator driver's switch for what zhip_set_prediction does): the oracle's frames either way"""
     lo, le = libs
     bufs = [datagen(lo, 131072, 50, 4), datagen(lo, 100000, 80, 5), text_like(60000, 2)]
     lo.zo_set_row_matcher.argtypes = [C.c_int]
@@ -329,7 +329,6 @@ def test_rowhash_units_without_the_live_rows(libs, monkeypatch):
             want.append(dst[:r].tobytes())
     finally:
         lo.zo_set_row_matcher(0)
-    for ring, predict in (("0", "0"), ("0", "1"), ("1", "1")):
-        monkeypatch.setenv("ZHIP_LZ_RING", ring)
+    for predict in ("0", "1"):
         monkeypatch.setenv("ZHIP_RH_PREDICT", predict)
-        assert emu_compress_units(le, lo, bufs, 5, row=True) == want, (ring, predict)
+        assert emu_compress_units(le, lo, bufs, 5, row=True) == want, predict

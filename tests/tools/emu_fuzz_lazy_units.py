@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tests/tools/emu_fuzz_lazy_units.py <seed> <seconds> — no GPU: 128 KB-class units of the strategies greedy / lazy / lazy2 with the ROW matcher on the host SIMT
 emulator against the oracle, weighted towards long-match data (where positions are left out and searches go live): random effective parameters (hashLog 10-17,
-searchLog 1-6 = rows of 16 / 32 / 64 entries, minMatch 3-7), the live rows on / off ($ZHIP_LZ_RING), the units' two-pass prediction on / off ($ZHIP_RH_PREDICT).
+searchLog 1-6 = rows of 16 / 32 / 64 entries, minMatch 3-7), the units' two-pass prediction on / off ($ZHIP_RH_PREDICT).
 Prints BAD lines and saves the input under /tmp; `done <seed> <cases> bad <n>` at the end."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,8 +41,8 @@ try:
         n = int(rng.choice([rng.integers(20000, 131072), 131072]))
         a = np.ascontiguousarray(mk(n))
         eff = [17, int(rng.integers(8, 18)), int(rng.integers(10, 18)), int(rng.integers(1, 7)), int(rng.integers(3, 8)), int(rng.choice([0, 2, 8, 16])), int(rng.choice([3, 4, 5]))]
-        ring, pred = int(rng.integers(0, 2)), int(rng.integers(0, 2))
-        os.environ["ZHIP_LZ_RING"] = str(ring); os.environ["ZHIP_RH_PREDICT"] = str(pred)
+        ring, pred = 0, int(rng.integers(0, 2))
+        os.environ["ZHIP_RH_PREDICT"] = str(pred)
         lo.zo_set_row_matcher(1)
         cap = lo.zo_compress_bound(n) + 64
         o = np.zeros(cap, dtype=np.uint8)

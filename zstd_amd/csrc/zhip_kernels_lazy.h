@@ -102,7 +102,7 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
              ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas,
              uint32_t mode /* 0: the parse.  The row matcher's two-pass prediction (zhip_parse_lazy.h: rh_reconcile): 2 = TRY — the parse, given up (status
                               ZHIP_PARSE_REDO) once `budget` searches had to be redone live; then, for those units only, 1 = the predicting parse, and 3 = the parse again */,
-             uint32_t budget, uint32_t* __restrict__ rings, size_t ringStride /* words per unit for the row matcher's live rows (zhip_parse_lazy.h: rh_ring_words); 0 = none */)
+             uint32_t budget)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem)                // ZHIP_RH_DIRTY_BYTES: the row matcher's dirty-row bits
     uint32_t const ui = blockIdx.x;
@@ -112,8 +112,7 @@ k_parse_lazy(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
     if ((mode == 1 || mode == 3) && metas[ui].status != ZHIP_PARSE_REDO) return;
     uint32_t* const prev = tabs + (size_t)ui * tabStride;
     parse_lazy_unit(src + u.srcOff, u.srcLen, u, smem, prev, best + (size_t)ui * ZHIP_UNIT_MAX,
-                    seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui, mode == 1, mode == 2 ? budget : 0u, mode == 3,
-                    ringStride ? rings + (size_t)ui * ringStride : (uint32_t*)nullptr);
+                    seqs + slots[ui].seqOff, lits + slots[ui].litOff, metas + ui, mode == 1, mode == 2 ? budget : 0u, mode == 3);
 }
 
 }  // namespace zhip

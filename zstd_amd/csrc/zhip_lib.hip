@@ -86,7 +86,6 @@ struct zhip_ctx_s {
     // ... of the lazy strategies (zhip_frame_lazy.h): links, tags, records per position of every window; head tables; grown on demand
     uint32_t* dLzPrev = nullptr; uint8_t* dLzTags = nullptr; zhip::LzRec* dLzBest = nullptr; uint32_t* dLzHeads = nullptr; zhip::ZhipLzSlot* dLzSlots = nullptr;
     size_t lzPosCap = 0, lzHeadCap = 0, lzSlotCap = 0, lzRingCap = 0;
-    uint32_t* dRhRing = nullptr; size_t rhRingCap = 0, rhRingStride = 0;    // the same for units (zhip_parse_lazy.h: rh_live_ring), one set of rows per unit of a chunk
     uint8_t* dLzRing = nullptr; uint64_t lzRing = 0; int lzRingOn = 1;      // the row matcher's live rows (zhip_frame_lazy.h: LzRing); zhip_set_live_rows(0): live searches walk the links
     std::vector<zhip::ZhipLzSlot> hLz; bool lzAny = false, lzAll = false; uint64_t lzPos = 0, lzHeads = 0; uint32_t lzLongest = 0;
     // staging for the host-buffer API
@@ -109,9 +108,9 @@ struct zhip_ctx_s {
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
     int dictQueue = 1, dictGWaves = 0;                   // the records stage's queue form, global-table wavefronts per CU
     int rowDefault;                      // what mode 0 restores: the context's $ZHIP_ROW_MATCHER default, captured at creation
-    int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction).  Units: OFF with the live rows (datagen level 5, 256 MiB: 2.57 GB/s
-                                         // against 2.27 with it; without the rows 1.53 / 2.00 — zhip_set_live_rows(0) turns it on).  Frames: ON, behind a 32 KB probe per window (1 MiB datagen
-                                         // frames 681 -> 366 ms; text frames 168 -> 171 ms with the probe, 224 without; profiles/r04_live_rows.log, r04_predict_probe.log)
+    int rhPredict = 0, lzPredict = 1;    // the row matcher's two-pass prediction, units / frames (zhip_set_prediction).  Units: OFF — a live search reads the row's list (rh_live_lists),
+                                         // one parse is faster.  Frames: ON, behind a 32 KB probe per window (1 MiB datagen frames 681 -> 366 ms; text frames 168 -> 171 ms with the
+                                         // probe, 224 without; profiles/r04_live_rows.log, r04_predict_probe.log)
     unsigned ovr[7]; bool haveOvr;       // explicit compression parameters of the call in progress (zhip_compress_params*), 0 = level's own
     const void* cacheSrc; size_t cacheSize, cacheBlock; int cacheLevel;
     std::vector<uint64_t> cacheHash;     // two 64-bit content hashes per prepared block: a hit must also match the bytes
@@ -178,7 +177,7 @@ void zhip_destroy(zhip_ctx* c)
     (void)hipFree(c->dSeqPack); (void)hipFree(c->dSeqPackOff);
     (void)hipFree(c->dSrcStage); (void)hipFree(c->dDstStage); (void)hipFree(c->dFrameOut); (void)hipFree(c->dFrameState);
     (void)hipFree(c->dJobs); (void)hipFree(c->dFrameUnits); (void)hipFree(c->dFrameSizes);
-    (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots); (void)hipFree(c->dLzRing); (void)hipFree(c->dRhRing);
+    (void)hipFree(c->dLzPrev); (void)hipFree(c->dLzTags); (void)hipFree(c->dLzBest); (void)hipFree(c->dLzHeads); (void)hipFree(c->dLzSlots); (void)hipFree(c->dLzRing);
     (void)hipFree(c->dQueue); (void)hipFree(c->dOrder); (void)hipFree(c->dCost); (void)hipFree(c->dGTabs);
     if (c->coStream) (void)hipStreamDestroy(c->coStream);
     for (int i = 0; i < 2; i++) if (c->coEv[i]) (void)hipEventDestroy(c->coEv[i]);
@@ -294,13 +293,13 @@ int zhip_set_prediction(zhip_ctx* c, int units, int frames)
     return 0;
 }
 
-// the row matcher's live rows (LzRing): 1 on (default), 0 = live searches walk the links instead — the form a context also falls back to when the
-// rows' arena cannot be allocated; the units' prediction follows (off with the rows, on without).  Same bytes either way.
+// the row matcher's live rows of the FRAME kernels (LzRing, zhip_frame_lazy.h): 1 on (default), 0 = their live searches walk the links instead — the form a
+// context also falls back to when the rows' arena cannot be allocated.  Same bytes either way.  (The unit kernels keep no rows since round 5: a live
+// search there reads the row's list, zhip_parse_lazy.h: rh_live_lists.)
 int zhip_set_live_rows(zhip_ctx* c, int on)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     c->lzRingOn = on ? 1 : 0;
-    c->rhPredict = on ? 0 : 1;
     return 0;
 }
 
@@ -369,7 +368,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     size_t const nUnits = srcSize ? (srcSize + unitSize - 1) / unitSize : 1;
     if (nUnits > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu units > context capacity %zu", nUnits, c->maxUnits); *err = ZERR(ZE_srcSize_wrong); return 0; }
     zhip::CParams full, tail; bool haveFull = false;
-    uint32_t mh = 0; size_t tabWords = 0, ringWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
+    uint32_t mh = 0; size_t tabWords = 0; int fam = 0; uint32_t hcMaxLen = 0, hcHlog = 6;
     for (size_t i = 0; i < nUnits; i++) {
         size_t const off = i * unitSize;
         size_t const len = srcSize - off < unitSize ? srcSize - off : unitSize;
@@ -398,8 +397,7 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         // a call may mix families (a ragged tail takes the row of its own size class, e.g. level 4: dfast + greedy tail)
         if (cp->strategy == ZHIP_STRAT_FAST) { fam |= 1; if (cp->hashLog > mh) mh = cp->hashLog; }
         else if (cp->strategy == ZHIP_STRAT_DFAST) { fam |= 2; size_t const w = zhip::dfast_table_bytes(cp->hashLog, cp->chainLog) >> 2; if (w > tabWords) tabWords = w; }
-        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog;
-            size_t const rw = zhip::rh_ring_words(cp->hashLog, u.rowLog); if (rw > ringWords) ringWords = rw; }
+        else if (cp->strategy <= ZHIP_STRAT_LAZY2) { fam |= 4; size_t const w = zhip::hc_table_words(cp->hashLog); if (w > tabWords) tabWords = w; if (len > hcMaxLen) hcMaxLen = (uint32_t)len; if (cp->hashLog > hcHlog) hcHlog = cp->hashLog; }
         else { snprintf(c->err, sizeof(c->err), "strategy %u not implemented on device", cp->strategy); *err = ZERR(ZE_parameter_unsupported); return 0; }
     }
     if (mh > 15) {      // the unit kernel's LDS table ends at 2^15 entries: the caller sends such units through the frame kernel, whose table policy reaches HBM
@@ -421,15 +419,6 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
         (void)hipFree(c->dBest); c->dBest = nullptr; c->bestCap = 0;
         if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
         c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
-    }
-    c->rhRingStride = 0;
-    if ((fam & 4) && ringWords && c->lzRingOn) {     // the row matcher's live rows (zhip_parse_lazy.h: rh_live_ring), one set per unit of a chunk; without room for them the parser walks the links
-        size_t const need = c->hcChunk * ringWords;
-        if (c->rhRingCap < need) {
-            (void)hipFree(c->dRhRing); c->dRhRing = nullptr; c->rhRingCap = 0;
-            if (hipMalloc((void**)&c->dRhRing, need * sizeof(uint32_t)) == hipSuccess) c->rhRingCap = need; else (void)hipGetLastError();
-        }
-        if (c->rhRingCap >= need) c->rhRingStride = ringWords;
     }
     if ((fam & 2) && (fam & 4)) {                  // a mixed batch: room for the dfast workgroups' pairs as well
         if (c->tabsCap < dfPairs * c->tabStride) {
@@ -557,24 +546,24 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
                 // parse is TRIED first; a unit whose parse had to redo more than the budget of searches live gives up, and only those
                 // units get the predicting parse, their records again without the predicted positions, and the parse again.  Data without
                 // long matches never leaves the first launch (zhip_set_prediction(units = 1) turns it on; the budget is 256 live searches)
-                int const predictOn = c->rhPredict;          // default off for units with the live rows (zhip_set_prediction): exact either way (emulator, GPU parity tests), measured in round 4
+                int const predictOn = c->rhPredict;          // default off for units (zhip_set_prediction): exact either way (emulator, GPU parity tests), DESIGN.md 4.2b
                 int const budget = 256;
                 bool anyRow = false;
                 for (uint32_t i = 0; i < nu && !anyRow; i++) anyRow = c->hUnits[u0 + i].rowLog != 0;
                 if (predictOn && anyRow && budget > 0) {
                     size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 2u, (uint32_t)budget, c->dRhRing, c->rhRingStride);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 2u, (uint32_t)budget);
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 1u, 0u, c->dRhRing, c->rhRingStride);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 1u, 0u);
                     hipLaunchKernelGGL(zhip::k_hc_search_lds, dim3(nu), dim3(ZHIP_HC_SEARCH_LDS_THREADS), lds, s,
                                        srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest, (const ZhipParse*)(c->dParse + u0));
                     hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
-                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 3u, 0u, c->dRhRing, c->rhRingStride);
+                                       srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest, c->dSeqs, c->dLits, c->dParse + u0, 3u, 0u);
                 } else
                 hipLaunchKernelGGL(zhip::k_parse_lazy, dim3(nu), dim3(64), ZHIP_RH_DIRTY_BYTES, s,
                                    srcDev, c->dUnits + u0, c->dSlots + u0, nu, c->dTabs, c->tabStride, c->dBest,
-                                   c->dSeqs, c->dLits, c->dParse + u0, 0u, 0u, c->dRhRing, c->rhRingStride);
+                                   c->dSeqs, c->dLits, c->dParse + u0, 0u, 0u);
             }
             HIPCHK(c, hipEventRecord(he[3], s));
         }

@@ -522,15 +522,8 @@ struct HcState {
     uint32_t nLive;         // searches redone live (statistics: ZhipParse.pad0)
     uint32_t budget;        // TRY parse: give up (the unit is parsed again with the prediction) once this many searches went live; 0 = never
     uint32_t abort;
-    uint32_t* ringCnt;      // row matcher, exact parse: the live rows (RhRing below; nullptr: none — live searches walk prev[])
-    uint32_t* ringEnt;
-    uint32_t ins;           // every position below this that was inserted is in the live rows
-    uint32_t nFlagged;      // positions left out so far (0: prev[] is the truth, nothing needs the live rows)
     uint32_t epoch;         // grows whenever a row is marked dirty (what a batch of records looked up about its staleness is then out of date)
-    uint32_t ringReady;     // the counts have been zeroed (done at the first use: data without long matches never touches the rows)
 };
-// the live rows of one unit: rows counts of inserts (4 B each), then 2^rowLog slots per row: position | tag << 17
-__host__ __device__ inline size_t rh_ring_words(uint32_t hashLog, uint32_t rowLog) { return rowLog ? ((size_t)1 << (hashLog - rowLog)) + ((size_t)1 << hashLog) : 0; }
 #define ZHIP_PARSE_REDO 0x5245444Fu          /* ZhipParse.status of a unit whose TRY parse gave up */
 #define ZHIP_RH_ROWBITS_BYTES 2048u    /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
 #define ZHIP_RH_FINE_LOG 16u           /* then one bit per (row, leading tag bits): the top 16 bits of the row-and-tag hash */
@@ -587,7 +580,6 @@ __device__ inline void rh_flag_range_t(const uint8_t* __restrict__ src, uint32_t
         __builtin_amdgcn_wave_barrier();
         return;
     }
-    st.nFlagged += f1 - f0;
     bool any = false;
     for (uint32_t q0 = f0; q0 < f1; q0 += 64) {
         uint32_t const q = q0 + (uint32_t)lane_id();
@@ -662,150 +654,59 @@ __device__ inline void hc_search_live(const uint8_t* __restrict__ src, uint32_t 
     mlOut = ml; offOut = off;
 }
 
-// the row search the reference would run at x with the positions flagged in prev[] missing from the rows (all values uniform)
-__device__ inline void rh_search_live(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
-                                      uint32_t searchLog, uint32_t rowLog, uint32_t& mlOut, uint32_t& offOut)
+// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340) at x with the positions flagged in prev[] missing from the rows, from the row LISTS: x's row as the
+// reference holds it is the 2^rowLog - 1 most recent positions below x in the row's list that were not left out.  Lane l looks at the l-th entry
+// below x's own (one coalesced load), fetches that position's flag word (one gather), ballots rank the inserted ones, and the candidates — own tag,
+// within the row's capacity, at most 2^min(searchLog, rowLog) — are compared at once.  No state is kept between searches (the live rows of round 4
+// had to be fed every position the parse passed: 65 GB of scattered stores per GiB, profiles/r05_L5_datagen_sq_tcc.txt).  All results uniform.
+__device__ inline void rh_live_lists(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const uint32_t* prev,
+                                     uint32_t searchLog, uint32_t rowLog, uint32_t& mlOut, uint32_t& offOut)
 {
     const uint32_t* const rowList = prev + ZHIP_RH_LIST_OFF;
-    uint32_t const nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
+    uint32_t const lane = (uint32_t)lane_id(), nm8 = n - 8, capped = searchLog < rowLog ? searchLog : rowLog;
     uint32_t attempts = 1u << capped, room = (1u << rowLog) - 1;
     uint32_t ml = 3, off = 0;
     uint32_t const w0 = uni(prev[x]), myTag = (w0 >> 18) & 0xFFu;
-    uint32_t j = w0 & ZHIP_RH_IDX_MASK;
+    uint32_t j = w0 & ZHIP_RH_IDX_MASK;                                       // the entries below j are the row's earlier positions, most recent first going down
     bool more = !(w0 & ZHIP_RH_FIRST), done = false;
-    while (more && attempts && room) {
-        uint32_t const e = uni(rowList[--j]), mp = e & 0x1FFFFu;
-        uint32_t const w = uni(prev[mp]);
-        more = !(e & ZHIP_RL_FIRST);
+    unsigned long long const lower = below_mask((int)lane);
+    while (more && attempts && room && !done) {
+        bool const inList = lane < j;
+        uint32_t const e = rowList[inList ? j - 1u - lane : 0u];
+        unsigned long long const firstM = __ballot(inList && (e & ZHIP_RL_FIRST) != 0);
+        uint32_t const nRow = firstM ? (uint32_t)first_lane(firstM) + 1u : 64u;      // entries of x's row in this window (its first position ends it)
+        bool const inRow = lane < nRow && inList;
+        uint32_t const mp = e & 0x1FFFFu;
+        uint32_t const w = prev[inRow ? mp : x];
         LZ_STAT(3, 1);
-        if (w & ZHIP_HC_SKIPPED) continue;                                   // never inserted: it takes no slot of the row
-        room--;
-        if (((e >> 17) & 0xFFu) != myTag) continue;
-        attempts--;
-        if (!done && uni(ld32(src + mp + ml - 3)) == uni(ld32(src + x + ml - 3))) {
-            uint32_t const cur = wave_count_fwd(src, x, mp, nm8);
-            if (cur > ml) { ml = cur; off = x - mp; if (x + cur == n) done = true; }
+        bool const ins = inRow && !(w & ZHIP_HC_SKIPPED);                     // never inserted: it takes no slot of the row
+        unsigned long long const insM = __ballot(ins);
+        bool cand = ins && (uint32_t)__popcll(insM & lower) < room && ((e >> 17) & 0xFFu) == myTag;
+        unsigned long long const tagM = __ballot(cand);
+        cand = cand && (uint32_t)__popcll(tagM & lower) < attempts;
+        uint32_t cur = 0;
+        if (cand) {
+            for (;;) {
+                uint32_t const sameB = lane_same_fwd(src, x + cur, x - mp, nm8);
+                cur += sameB;
+                if (sameB < 8 || cur >= ZHIP_HC_CAP) break;
+            }
         }
-    }
-    mlOut = ml; offOut = off;
-}
-
-// ------------------------------------------------------------------ the live rows (row matcher, exact parse) — the unit form of zhip_frame_lazy.h's LzRing
-// row and tag of position q (q <= n - 8)
-__device__ __forceinline__ uint32_t rh_key(const uint8_t* __restrict__ src, uint32_t q, const ZhipUnit& u, uint32_t& tag)
-{
-    uint32_t const hBits = (uint32_t)u.hashLog - u.rowLog + 8, mls = u.minMatch < 4 ? 4u : (u.minMatch > 6 ? 6u : (uint32_t)u.minMatch);
-    uint64_t const salt = rh_fresh_salt();
-    uint64_t const bytes = mls == 4 ? (uint64_t)ld32(src + q) : ld64(src + q);
-    uint32_t const h = mls == 4 ? hash_pos_salted<4>(bytes, hBits, salt) : (mls == 5 ? hash_pos_salted<5>(bytes, hBits, salt) : hash_pos_salted<6>(bytes, hBits, salt));
-    tag = h & 0xFFu;
-    return h >> 8;
-}
-// fresh rows at the first use: every count 0 (the slots are only read below a count)
-__device__ inline void rh_ring_ready(const ZhipUnit& u, HcState& st)
-{
-    if (st.ringReady) return;
-    for (uint32_t i = (uint32_t)lane_id(); i < (1u << ((uint32_t)u.hashLog - u.rowLog)); i += 64) st.ringCnt[i] = 0;
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    st.ringReady = 1;
-}
-// What ZSTD_row_update (zstd_lazy.c:916-947) has put into the rows when the search at `upTo` starts: every position of [st.ins, upTo) that was not
-// left out (flagged in prev[]), in order, 64 per step.  A row keeps its 2^rowLog - 1 latest inserts (ZSTD_row_nextIndex :784-795 cycles through
-// the slots 1 .. rowMask), so insert i of a row goes to slot i mod (2^rowLog - 1); the lanes of one row are ranked with ballots, the first
-// reads the row's count, the last writes it back.  The next step's loads are in flight while the counts make their round trip.
-__device__ inline void rh_ring_catchup(const uint8_t* __restrict__ src, const ZhipUnit& u, const uint32_t* prev, HcState& st, uint32_t upTo)
-{
-    if (upTo <= st.ins) return;
-    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, keyBits = (uint32_t)u.hashLog - rowLog;
-    uint32_t qcN = st.ins + lane < upTo ? st.ins + lane : upTo - 1;
-    uint32_t wN = prev[qcN], tN, kN = rh_key(src, qcN, u, tN);
-    for (uint32_t q0 = st.ins; q0 < upTo; q0 += 64) {
-        uint32_t const q = q0 + lane, w = wN, k = kN, tag = tN;
-        if (q0 + 64 < upTo) { qcN = q + 64 < upTo ? q + 64 : upTo - 1; wN = prev[qcN]; kN = rh_key(src, qcN, u, tN); }
-        bool const in = q < upTo && !(w & ZHIP_HC_SKIPPED);
-        unsigned long long const inM = __ballot(in);
-        LZ_STAT(4, 1);
-        if (!inM) { LZ_STAT(5, 1); continue; }
-        unsigned long long const same = wave_hash_group(k, keyBits) & inM;
-        uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
-        uint32_t c = (in && rank == 0) ? st.ringCnt[k] : 0u;
-        c = __shfl(c, same ? first_lane(same) : 0);
-        if (in) {
-            if (rank + 1 == total) st.ringCnt[k] = c + total;
-            if (rank + usable >= total) st.ringEnt[((size_t)k << rowLog) + (c + rank) % usable] = q | (tag << 17);
+        unsigned long long rest = __ballot(cand);
+        while (rest) {
+            int const l = first_lane(rest);
+            rest &= rest - 1;
+            uint32_t len = (uint32_t)__builtin_amdgcn_readlane(cur, l);
+            uint32_t const mpl = (uint32_t)__builtin_amdgcn_readlane(mp, l);
+            if (len >= ZHIP_HC_CAP) len = uni(wave_count_fwd(src, x, mpl, nm8));
+            if (len > ml) { ml = len; off = x - mpl; if (x + len == n) { done = true; break; } }
         }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
+        uint32_t const nIns = (uint32_t)__popcll(insM), nTag = (uint32_t)__popcll(tagM);
+        room -= nIns < room ? nIns : room;
+        attempts -= nTag < attempts ? nTag : attempts;
+        more = firstM == 0;
+        j -= 64;
     }
-    st.ins = upTo;
-}
-// ZSTD_RowFindBestMatch (zstd_lazy.c:1141-1340) at x from the live rows — see lz_live_ring (zhip_frame_lazy.h) for the scheme: three dependent round
-// trips (the last <= 63 pending positions' link words and bytes + x's bytes; their rows' counts + the count and slots of x's row as it was before
-// them; the candidates' bytes) instead of a walk of up to 2^rowLog - 1 links plus every left-out position between them.  All results uniform.
-__device__ inline void rh_live_ring(const uint8_t* __restrict__ src, uint32_t n, uint32_t x, const ZhipUnit& u, const uint32_t* prev, HcState& st,
-                                    uint32_t& mlOut, uint32_t& offOut)
-{
-    uint32_t const lane = (uint32_t)lane_id(), rowLog = u.rowLog, usable = (1u << rowLog) - 1u, nm8 = n - 8, keyBits = (uint32_t)u.hashLog - rowLog;
-    uint32_t const capped = u.searchLog < rowLog ? u.searchLog : rowLog, attempts = 1u << capped;
-    rh_ring_ready(u, st);
-    if (x - st.ins > 63) rh_ring_catchup(src, u, prev, st, x - 63);
-    uint32_t const ins0 = st.ins, nPend = x - ins0;                             // lanes below nPend: a position to insert; the others (lane 63 always) look at x
-    uint32_t const q = lane < nPend ? ins0 + lane : x;
-    uint32_t const w = prev[q];
-    uint32_t tagq; uint32_t const kq = rh_key(src, q, u, tagq);
-    bool const in = lane < nPend && !(w & ZHIP_HC_SKIPPED);
-    uint32_t const kx = (uint32_t)__builtin_amdgcn_readlane(kq, 63), tag = (uint32_t)__builtin_amdgcn_readlane(tagq, 63);
-    unsigned long long const inM = __ballot(in);
-    unsigned long long const same = wave_hash_group(kq, keyBits) & inM;
-    uint32_t const rank = (uint32_t)__popcll(same & below_mask((int)lane)), total = (uint32_t)__popcll(same);
-    uint32_t cIns = (in && rank == 0) ? st.ringCnt[kq] : 0u;
-    uint32_t const cw = st.ringCnt[kx], se = st.ringEnt[((size_t)kx << rowLog) + (lane < usable ? lane : 0u)];
-    uint32_t const c = uni(cw), nOld = c < usable ? c : usable;
-    cIns = __shfl(cIns, same ? first_lane(same) : 0);
-    __threadfence_block();                                                      // the row of x HAS been read: now the inserts may land in it
-    __builtin_amdgcn_wave_barrier();
-    if (in) {
-        if (rank + 1 == total) st.ringCnt[kq] = cIns + total;
-        if (rank + usable >= total) st.ringEnt[((size_t)kq << rowLog) + (cIns + rank) % usable] = q | (tagq << 17);
-    }
-    st.ins = x;
-    // the candidates, most recent first: x's row among the pending positions (the higher the later), then the slots
-    unsigned long long P = __ballot(in && kq == kx);
-    uint32_t const nP = (uint32_t)__popcll(P);
-    uint32_t const rr = lane - nP;
-    bool have = lane >= nP && rr < nOld && lane < usable;
-    uint32_t const from = have ? (c - 1u - rr) % usable : 0u;                   // the r-th most recent insert of the row is its number c - 1 - r
-    uint32_t const e = __shfl(se, (int)from);
-    uint32_t mp = e & 0x1FFFFu, tg = e >> 17;
-    for (uint32_t i = 0; P != 0 && i < usable; i++) {
-        int const l = 63 - __clzll((long long)P);
-        P &= ~(1ull << l);
-        uint32_t const tl = (uint32_t)__builtin_amdgcn_readlane(tagq, l);
-        if (lane == i) { mp = ins0 + (uint32_t)l; tg = tl; have = true; }
-    }
-    bool cand = have && tg == tag;
-    unsigned long long const cm = __ballot(cand);
-    cand = cand && (uint32_t)__popcll(cm & below_mask((int)lane)) < attempts;
-    uint32_t cur = 0;
-    if (cand) {
-        for (;;) {
-            uint32_t const sameB = lane_same_fwd(src, x + cur, x - mp, nm8);
-            cur += sameB;
-            if (sameB < 8 || cur >= ZHIP_HC_CAP) break;
-        }
-    }
-    unsigned long long rest = __ballot(cand);
-    uint32_t ml = 3, off = 0;
-    while (rest) {
-        int const l = first_lane(rest);
-        rest &= rest - 1;
-        uint32_t len = (uint32_t)__builtin_amdgcn_readlane(cur, l);
-        uint32_t const mpl = (uint32_t)__builtin_amdgcn_readlane(mp, l);
-        if (len >= ZHIP_HC_CAP) len = uni(wave_count_fwd(src, x, mpl, nm8));
-        if (len > ml) { ml = len; off = x - mpl; if (x + len == n) break; }
-    }
-    __threadfence_block();
     mlOut = ml; offOut = off;
 }
 
@@ -846,8 +747,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
     if (live) {
         st.nLive++;
         if (st.budget && st.nLive > st.budget) st.abort = 1;
-        if (u.rowLog && st.ringCnt && st.nFlagged && !st.predict) { LZ_STAT(1, 1); rh_live_ring(src, n, x, u, prev, st, ml, off); }
-        else if (u.rowLog) { if (!st.predict) LZ_STAT(2, 1); rh_search_live(src, n, x, prev, u.searchLog, u.rowLog, ml, off); }
+        if (u.rowLog) { if (!st.predict) LZ_STAT(2, 1); rh_live_lists(src, n, x, prev, u.searchLog, u.rowLog, ml, off); }
         else hc_search_live(src, n, x, prev, u.searchLog, u.chainLog, ml, off);
     }
     else if (mode == 0) { ml = hc_rec_b(rec); off = hc_rec_a(rec); }
@@ -867,8 +767,7 @@ __device__ inline void hc_search(const uint8_t* __restrict__ src, uint32_t n, co
 // skipping would leave out are only MARKED in prev[] (ZHIP_HC_PRED); no sequences, literals or meta are written
 __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, unsigned char* smem /* ZHIP_RH_DIRTY_BYTES */,
                                        uint32_t* __restrict__ prev, const uint64_t* __restrict__ best,
-                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0, bool havePred = false,
-                                       uint32_t* ring = nullptr /* rh_ring_words(hashLog, rowLog) words for the live rows, or none */)
+                                       ZhipSeq* seqs, uint8_t* lits, ZhipParse* meta, bool predict = false, uint32_t tryBudget = 0, bool havePred = false)
 {
     uint32_t const lane = (uint32_t)lane_id();
     {   lds_u32* const z = (lds_u32*)(uintptr_t)smem;
@@ -895,8 +794,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
     HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0; st.havePred = havePred ? 1u : 0u;
-    st.ringCnt = (ring && u.rowLog) ? ring : (uint32_t*)nullptr; st.ringEnt = st.ringCnt ? ring + ((size_t)1 << ((uint32_t)u.hashLog - u.rowLog)) : (uint32_t*)nullptr;
-    st.ins = 0; st.nFlagged = 0; st.ringReady = 0; st.epoch = 0;
+    st.epoch = 0;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
     uint32_t pfIp = 0xFFFFFFFFu, pfOff1 = 0, pfCur4 = 0, pfRv = 0; uint64_t pfRec = 0;
