@@ -161,14 +161,12 @@ int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
 int          zhip_set_row_matcher(zhip_ctx* ctx, int mode);
 /* The row matcher's two-pass prediction: a first parse marks the positions the 384-position rule and lazy skipping will leave
  * un-inserted, the per-position records are recomputed without them, and the exact parse redoes a search live only where prediction and truth differ.
- * Same bytes with it on or off (this call sets it).  Units: off by default — the live searches read the row
- * matcher's rows as the reference keeps them ("live rows"), and one parse is then the fastest form (zhip_set_live_rows(ctx, 0): walk
- * the links instead; the units' prediction then defaults to on).  Frames: on by default, behind a probe — a window whose first 32 KB leave nothing
- * un-inserted is parsed once.
+ * Same bytes with it on or off (this call sets it).  Units: off by default — a live search there reads the row's list of positions
+ * and one parse is the fastest form.  Frames: on by default, behind a probe — a window whose first 32 KB leave nothing un-inserted is parsed once.
  * units / frames: 1 on, 0 off, -1 unchanged.  returns 0, or 1 for a bad value. */
 int          zhip_set_prediction(zhip_ctx* ctx, int units, int frames);
-/* the live rows themselves: 1 on (default), 0 = live searches walk the links (what a context without the rows' arena does); the units' prediction
- * follows the switch (off with the rows, on without).  Same bytes either way.  returns 0. */
+/* the FRAME kernels' live rows (the row matcher's rows as the reference keeps them): 1 on (default), 0 = their live searches walk the
+ * links (what a context without the rows' arena does).  Same bytes either way; the unit kernels keep no rows.  returns 0. */
 int          zhip_set_live_rows(zhip_ctx* ctx, int on);
 
 /* ---- seekable container (contrib/seekable_format/zstd_seekable_compression_format.md): independent frames followed by a

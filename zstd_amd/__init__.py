@@ -332,7 +332,7 @@ class Context:
             raise ZhipError("zhip_set_prediction: bad value")
 
     def set_live_rows(self, on=True):
-        """the row matcher's live rows: on (default) / off = live searches walk the links, the units' prediction then on (zhip_set_live_rows); same bytes"""
+        """the frame kernels' live rows: on (default) / off = their live searches walk the links (zhip_set_live_rows); same bytes; the unit kernels keep no rows"""
         L = lib()
         L.zhip_set_live_rows.restype = C.c_int
         L.zhip_set_live_rows.argtypes = [C.c_void_p, C.c_int]
