@@ -62,7 +62,7 @@ def main():
     names_e = ["gather+hist", "huf table build", "huf sizing+hdr", "huf pack", "seq hist+tables", "fse state chains",
                "seq bit pack", "headers"]
     if level >= 5:
-        names_l = ["init", "batch front (records + repcode bytes, event detect)", "event pick + repcode extension", "search: LIVE (rows catch-up + ring search)",
+        names_l = ["init", "batch front (records + repcode bytes, event detect)", "event pick + repcode extension", "search: LIVE (gap rule + list search)",
                    "search: from the record", "lazy steps + catch-up + prefetch", "emit (literals, sequence)", "immediate-repcode loop"]
         tot = sum(v[:8]) or 1
         print(json.dumps({"timing_ms": tm, "hc_ms": ctx.hc_timing(), "units": units,
