@@ -526,7 +526,10 @@ struct HcState {
 };
 #define ZHIP_PARSE_REDO 0x5245444Fu          /* ZhipParse.status of a unit whose TRY parse gave up */
 #define ZHIP_RH_ROWBITS_BYTES 2048u    /* rows <= 2^14 (hashLog <= 18, rowLog >= 4) */
-#define ZHIP_RH_FINE_LOG 16u           /* then one bit per (row, leading tag bits): the top 16 bits of the row-and-tag hash */
+#ifndef ZHIP_RH_FINE_LOG
+#define ZHIP_RH_FINE_LOG 16u           /* then one bit per (row, leading tag bits): the top 16 bits of the row-and-tag hash.  15 bits (6 KB of LDS per wavefront) and five wavefronts
+                                          per SIMD instead of four: datagen +1 %, text -3 % (profiles/r05_ab_final.log) — after the row lists the parse no longer follows occupancy */
+#endif
 #define ZHIP_RH_DIRTY_BYTES (ZHIP_RH_ROWBITS_BYTES + (1u << ZHIP_RH_FINE_LOG) / 8u)
 // bit index of a row-and-tag hash of hBits bits in the fine map
 __device__ __forceinline__ uint32_t rh_fine_key(uint32_t h, uint32_t hBits) { return hBits > ZHIP_RH_FINE_LOG ? h >> (hBits - ZHIP_RH_FINE_LOG) : h; }
