@@ -46,11 +46,11 @@ for leg, kern, key in (("silesia4_level1", "k_parse_fast_q", "k_parse_fast"), ("
                                   f"this leg's workload flags, round 5; FETCH_SIZE x2 = the guide's gfx950 correction, WRITE_SIZE as counted; counter passes serialise kernels, so for the queue stages "
                                   f"(k_parse_fast_q/_g, k_parse_dict_q/_g) the LDS-table kernel takes every unit and the figure is the stage with all units on that form — not the mix the timed run executes)"}
 # level 5: the match-finder stage is three kernels (link / list builder, record search, parse); the leg's figure is their sum
-c5 = counters(os.path.join(P, "r05_L5_datagen_sq_tcc.txt"))
+c5 = counters(os.path.join(P, "r05_L5_datagen_final_sq_tcc.txt"))
 a5 = sum(hbm(c5[k])[0] for k in ("k_hc_chain", "k_hc_search_lds", "k_parse_lazy")); b5 = sum(hbm(c5[k])[1] for k in ("k_hc_chain", "k_hc_search_lds", "k_parse_lazy"))
 out["legs"]["datagen_level5"] = {"k_parse_lazy_hbm_bytes_per_launch": a5, "k_parse_lazy_hbm_bytes_per_launch_uncorrected": b5, "kernel_counted": "k_hc_chain + k_hc_search_lds + k_parse_lazy",
                                "per_kernel_KiB_raw": {k: {"FETCH_SIZE": c5[k]["FETCH_SIZE"], "WRITE_SIZE": c5[k]["WRITE_SIZE"]} for k in ("k_hc_chain", "k_hc_search_lds", "k_parse_lazy")},
-                               "source": "profiles/r05_L5_datagen_sq_tcc.txt (scripts/pmc_sq.sh r05_L5_datagen 5 1024: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only, of "
+                               "source": "profiles/r05_L5_datagen_final_sq_tcc.txt (scripts/pmc_sq.sh r05_L5_final 5 1024, the kernels as shipped at the end of round 5: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --kernel-trace only, of "
                                          "bench.py --level 5 --mib 1024; FETCH_SIZE x2 = the guide's gfx950 correction, WRITE_SIZE as counted; sum of the stage's three kernels)"}
 json.dump(out, open(os.path.join(P, "latest_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "bytes_per_launch" in k}, indent=1))
