@@ -129,6 +129,16 @@ def datagen(lib_o, n, P, seed=0, lit=0.0):
     return a[:n]
 
 
+def lorem(lr, n, seed=0):
+    """what `zstd -b#` compresses when it is given no file: LOREM_genBuffer(buffer, n, seed) (programs/lorem.h:20, programs/benchzstd.c:1014), made by the
+    reference's own generator as oracle/_ref/libzstd_ref.so holds it (lr = load_ref(): the shim resolves the symbol through its dependency)"""
+    lr.LOREM_genBuffer.restype = None
+    lr.LOREM_genBuffer.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    a = np.zeros(max(n, 1), dtype=np.uint8)
+    lr.LOREM_genBuffer(_buf(a), n, seed)
+    return a[:n]
+
+
 def text_like(n, seed):
     """word-salad text (a lorem-ish stand-in that needs no reference code)."""
     rng = np.random.default_rng(seed)

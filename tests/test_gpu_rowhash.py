@@ -7,7 +7,7 @@ import json
 import os
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, _buf, ERR, ROOT
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, lorem, _buf, ERR, ROOT
 
 pytestmark = pytest.mark.gpu
 UNIT = 131072
@@ -73,6 +73,27 @@ def test_rowhash_batch_matches_oracle_and_reference(env):
         ctx.set_row_matcher(0)
     finally:
         lo.zo_set_row_matcher(0)
+
+
+def test_lorem_ipsum_units_equal_the_reference(env):
+    """the input of `zstd -b#` without a file — LOREM_genBuffer(.., seed 0), programs/benchzstd.c:1014, made by the reference's own generator — in 128 KB units:
+    the device's frames are the reference's (fresh CCtx per unit) at the default level of every match-finder family"""
+    zstd_amd, ctx, lo = env
+    if not have_ref():
+        pytest.skip("oracle/_ref (the reference build) did not travel")
+    lr = load_ref()
+    a = lorem(lr, 9 * UNIT + 4321, 0)
+    assert bytes(a[:27]) == b"Lorem ipsum dolor sit amet,"
+    for level in (1, 3, 5, 7, 8):
+        got = ctx.compress(a, level=level)
+        ref = b""
+        for off in range(0, len(a), UNIT):
+            u = np.ascontiguousarray(a[off: off + UNIT])
+            d = np.zeros(len(u) + 1024, dtype=np.uint8)
+            k = lr.zref_compress_frame(level, _buf(u), len(u), _buf(d), len(d))
+            assert k != ERR
+            ref += d[:k].tobytes()
+        assert got == ref, level
 
 
 def test_rowhash_frames_decode_on_the_device(env):

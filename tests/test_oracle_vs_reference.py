@@ -3,7 +3,7 @@
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, oracle_frame, oracle_frame_mt, ref_frame_mt, _buf, ERR
+from _libs import load_oracle, load_ref, have_ref, corpus_cases, datagen, text_like, lorem, oracle_frame, oracle_frame_mt, ref_frame_mt, _buf, ERR
 from _libs import ROOT, oracle_frame_params
 import os
 
@@ -188,6 +188,25 @@ def test_rowhash_unit_bytes_match_reference_fresh_cctx(libs, level):
                 want = np.zeros(n + 1024, dtype=np.uint8)
                 k = lr.zref_compress_frame(level, _buf(a), n, _buf(want), len(want))
                 assert k != ERR and ora_unit(lo, a, level) == want[:k].tobytes(), (name, level)
+    finally:
+        lo.zo_set_row_matcher(0)
+
+
+def test_lorem_ipsum_units_vs_reference(libs):
+    """`zstd -b#` without a file benches LOREM_genBuffer(.., seed 0) (programs/benchzstd.c:1014): the oracle equals the reference on that text too, at the
+    default level of every match-finder family (fast, dfast, greedy / lazy / lazy2 with the row matcher, fresh CCtx per unit)"""
+    lo, lr = libs
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    a = lorem(lr, 3 * 131072 + 4321, 0)
+    assert bytes(a[:27]) == b"Lorem ipsum dolor sit amet,"
+    lo.zo_set_row_matcher(1)
+    try:
+        for level in (1, 3, 5, 7, 8):
+            for off in range(0, len(a), 131072):
+                u = np.ascontiguousarray(a[off: off + 131072])
+                want = np.zeros(len(u) + 1024, dtype=np.uint8)
+                k = lr.zref_compress_frame(level, _buf(u), len(u), _buf(want), len(want))
+                assert k != ERR and ora_unit(lo, u, level) == want[:k].tobytes(), (level, off)
     finally:
         lo.zo_set_row_matcher(0)
 
