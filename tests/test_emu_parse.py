@@ -3,7 +3,7 @@ CPU only: this checks the wave-parallel algorithm, not the GPU build."""
 import ctypes as C
 import numpy as np
 import pytest
-from _libs import (load_oracle, load_emu, corpus_cases, make_units, oracle_parse, emu_parse_units, emu_compress_units, _buf, ERR, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_, datagen, text_like)
+from _libs import (load_oracle, load_emu, load_ref, have_ref, lorem, corpus_cases, make_units, oracle_parse, emu_parse_units, emu_compress_units, _buf, ERR, SEQ_DT, PARSE_DT, UNIT_DT as UNIT_DT_, datagen, text_like)
 
 
 @pytest.fixture(scope="module")
@@ -332,3 +332,25 @@ def test_rowhash_units_with_and_without_the_two_pass_prediction(libs, monkeypatc
     for predict in ("0", "1"):
         monkeypatch.setenv("ZHIP_RH_PREDICT", predict)
         assert emu_compress_units(le, lo, bufs, 5, row=True) == want, predict
+
+
+def test_lorem_ipsum_units_on_the_emulator(libs):
+    """the product's two stages on the emulator, fed what `zstd -b#` benches without a file (LOREM_genBuffer(.., seed 0), programs/benchzstd.c:1014, made by the
+    reference's own generator): frames equal the reference's, every match-finder family (row matcher for greedy / lazy / lazy2, fresh CCtx per unit)"""
+    if not have_ref():
+        pytest.skip("needs oracle/_ref (the reference build)")
+    lo, le = libs
+    lr = load_ref()
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    a = lorem(lr, 131072 + 70000 + 4321, 0)
+    bufs = [np.ascontiguousarray(a[:131072]), np.ascontiguousarray(a[131072:201072]), np.ascontiguousarray(a[201072:])]
+    try:
+        for level in (1, 3, 5, 7, 8):
+            lo.zo_set_row_matcher(1 if level >= 5 else 0)
+            frames = emu_compress_units(le, lo, bufs, level, row=level >= 5)
+            for u, f in zip(bufs, frames):
+                d = np.zeros(len(u) + 1024, dtype=np.uint8)
+                k = lr.zref_compress_frame(level, _buf(u), len(u), _buf(d), len(d))
+                assert k != ERR and bytes(f) == d[:k].tobytes(), (level, len(u))
+    finally:
+        lo.zo_set_row_matcher(0)
