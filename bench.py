@@ -577,17 +577,9 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
 
 
 def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
-    """SURVEY.md §8(d) second timing: host buffers in, host bytes out (H2D + kernels + D2H + gather) through zhip_compress —
-    PCIe-inclusive, never `value`"""
+    """SURVEY.md §8(d) second timing: host buffers in, host bytes out (H2D + kernels + D2H + gather) through zhip_compress_multi /
+    zhip_compress — PCIe-inclusive, never `value`.  The multi-lane path is measured FIRST, before this process has created any other context."""
     units = (len(host) + UNIT - 1) // UNIT
-    ctx = zstd_amd.Context(local, max_units=units)
-    best = 1e9
-    got = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        got = ctx.compress(host, level=level)
-        best = min(best, time.perf_counter() - t0)
-    ctx.close()
     m = zstd_amd.MultiContext([local])
     dst = np.empty(zstd_amd.compress_bound(len(host)), dtype=np.uint8)
     bestm, k = 1e9, 0
@@ -595,8 +587,8 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
         t0 = time.perf_counter()
         k = m.compress_into(dst, host, level=level)
         bestm = min(bestm, time.perf_counter() - t0)
-    same = bool(k == int(total_expected) and dst[:k].tobytes() == got)
     stages = m.last_stages()
+    multi_stream = dst[:k].tobytes()
     # the same call on four times the source (the buffer tiled: units are independent, so the output is the 1x output four times): what is left of
     # the ramp — first chunk in, last chunk's kernels and copy-out, about 8 ms — weighs a quarter as much
     big = None
@@ -608,18 +600,29 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
             t0 = time.perf_counter()
             k4 = m.compress_into(dst4, host4, level=level)
             b4 = min(b4, time.perf_counter() - t0)
-        same4 = bool(k4 == 4 * k and all(dst4[i * k:(i + 1) * k].tobytes() == got for i in range(4)))
+        same4 = bool(k4 == 4 * k and all(dst4[i * k:(i + 1) * k].tobytes() == multi_stream for i in range(4)))
         big = {"value": round(len(host4) / b4 / 1e6, 1), "unit": "MB/s", "source_bytes": int(len(host4)), "best_of": 3, "same_bytes_as_device_path": same4,
                "stages_of_last_call": m.last_stages()}
         del host4, dst4
     m.close()
+    ctx = zstd_amd.Context(local, max_units=units)
+    best = 1e9
+    got = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        got = ctx.compress(host, level=level)
+        best = min(best, time.perf_counter() - t0)
+    ctx.close()
+    same = bool((total_expected is None or k == int(total_expected)) and multi_stream == got)       # `got` = the single context's stream of the same source
+    if big is not None:
+        big["same_bytes_as_device_path"] = bool(big["same_bytes_as_device_path"] and same)
     return {"value": round(len(host) / bestm / 1e6, 1), "unit": "MB/s", "best_of": 4, "source_bytes": int(len(host)),
             "same_bytes_as_device_path": same,
             "stages_of_last_call": stages,
             "four_times_the_source": big,
             "path": "zhip_compress_multi on this one device: two lanes (kernel stream + copy stream, feeder / device / gatherer threads, two pinned slots each way; staging copies split over 4 host threads), 128 MB chunks with quarter "
                     "chunks at both ends: memcpy -> H2D (under the previous chunk's kernels) -> kernels -> D2H -> ordered host gather into the caller's buffer; stage seconds are summed "
-                    "over chunks and lanes (they overlap); PCIe- and host-memcpy-inclusive, never `value`",
+                    "over chunks and lanes (they overlap); PCIe- and host-memcpy-inclusive, never `value`; the leg's process holds the library only (no torch tensors, no other context before the measurement)",
             "synchronous_single_stream": {"value": round(len(host) / best / 1e6, 1), "unit": "MB/s", "path": "zhip_compress: pageable source, blocking H2D / kernels / D2H on one stream"}}
 
 
@@ -1076,6 +1079,14 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} (launch N ranks for --gpus N, or omit the launcher)")
     if os.environ.get("ZHIP_BENCH_STUB") == "1":
         return stub_main(args, rank, world)
+
+    if args.leg == "end_to_end" and world == 1:
+        # the host-buffer leg runs as a host application would: its process holds the library and nothing else — no torch tensors, no other context's
+        # arenas (in a process that had run the device path before it, the same call measured 29 instead of 36 GB/s: profiles/r05_e2e_stages.log)
+        import zstd_amd
+        host = zstd_amd.datagen(args.mib << 20, 50, seed=rank, stream_mode=True)      # the headline's workload (make_workload)
+        print(json.dumps(end_to_end_leg(None, zstd_amd, local, host, None, args.level)), flush=True)
+        return
 
     import torch
     import zstd_amd
