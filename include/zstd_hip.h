@@ -107,9 +107,9 @@ size_t       zhip_compress_frames_mt_device(zhip_ctx* ctx, void* dstDev, size_t 
                                             uint32_t* frameSizesDev, void* stream);
 
 /* ---- host buffers over SEVERAL devices in one process: independent units shard across the GPUs of a node, one
- * HIP stream + pinned staging per lane ($ZHIP_MULTI_LANES lanes per device, default 4: some lanes' copies overlap another's kernels), no collective;
+ * kernel stream + copy stream + pinned staging per lane ($ZHIP_MULTI_LANES lanes per device, default 2: one lane's copies overlap the other's kernels), no collective;
  * finished chunks are gathered on the host in source order (destination offset = exclusive prefix sum of the sizes before).
- * devices[] may name the same device more than once (more lanes on it).  chunkUnits = units per chunk (0 = 512 = 64 MB).
+ * devices[] may name the same device more than once (more lanes on it).  chunkUnits = units per chunk (0 = 1024 = 128 MB, with quarter chunks at both ends of a call).
  * The stream written to dst is byte-identical to zhip_compress's.  cparams may be NULL. */
 typedef struct zhip_multi_s zhip_multi;
 zhip_multi*  zhip_multi_create(const int* devices, int nDevices, size_t chunkUnits);
