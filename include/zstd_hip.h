@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ZHIP_UNIT_SIZE_MAX 131072          /* lib/zstd.h:141 ZSTD_BLOCKSIZE_MAX */
+#define ZHIP_UNIT_SIZE_MAX 131072          /* lib/zstd.h:143 ZSTD_BLOCKSIZE_MAX */
 #define ZHIP_SEQUENCE_PRODUCER_ERROR ((size_t)(-1))   /* lib/zstd.h:2836 ZSTD_SEQUENCE_PRODUCER_ERROR */
 
 typedef struct zhip_ctx_s zhip_ctx;
@@ -48,7 +48,7 @@ unsigned     zhip_isError(size_t code);
 const char*  zhip_getErrorName(size_t code);
 size_t       zhip_compressBound(size_t srcSize, size_t unitSize);   /* sum of ZSTD_compressBound over the units */
 
-/* ---- parameters = ZSTD_getCParams (lib/zstd.h:1756; lib/compress/zstd_compress.c:7150) for the supported rows
+/* ---- parameters = ZSTD_getCParams (lib/zstd.h:1877; lib/compress/zstd_compress.c:7150) for the supported rows
  * out[7] = windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy. returns 0, or -1 if the
  * level/size maps to a strategy this library does not implement (greedy and above). */
 int          zhip_getCParams(int level, unsigned long long srcSize, unsigned out[7]);
@@ -132,7 +132,7 @@ void         zhip_multi_last_stages(const zhip_multi* m, double out[7]);
 
 /* ---- block-level plugin (B1) = ZSTD_sequenceProducer_F, lib/zstd.h:2838; contrib/externalSequenceProducer.
  * zhip_sequence_producer has exactly that signature; pass the zhip_ctx as sequenceProducerState:
- *      ZSTD_registerSequenceProducer(cctx, zhip_ctx, zhip_sequence_producer);        lib/zstd.h:2866
+ *      ZSTD_registerSequenceProducer(cctx, zhip_ctx, zhip_sequence_producer);        lib/zstd.h:2866-2871
  * One kernel launch per callback is latency-bound, so zhip_prepare_sequences() parses every block of a buffer in
  * one launch beforehand; the callback then serves blocks of that buffer from the cache and launches only for
  * blocks it has not seen.  Failures map to ZHIP_SEQUENCE_PRODUCER_ERROR so that
@@ -143,11 +143,11 @@ size_t       zhip_sequence_producer(void* sequenceProducerState, zhip_Sequence* 
 size_t       zhip_prepare_sequences(zhip_ctx* ctx, const void* src, size_t srcSize, size_t blockSize, int level);
 
 /* Stage-1 only, device-resident: parse every unit, keep the result in ctx; fetch one unit's sequences in the
- * ZSTD_generateSequences format (lib/zstd.h:1612; block delimiter {0,lastLits,0,0} appended). */
+ * ZSTD_generateSequences format (lib/zstd.h:1593-1597; block delimiter {0,lastLits,0,0} appended). */
 size_t       zhip_parse_device(zhip_ctx* ctx, const void* srcDev, size_t srcSize, int level, size_t unitSize, void* stream);
 size_t       zhip_get_sequences(zhip_ctx* ctx, size_t unitIndex, zhip_Sequence* out, size_t capacity);
 
-/* ---- ZSTD_c_checksumFlag (lib/zstd.h:449; what the zstd CLI turns on by default, programs/fileio.c:287): when enabled every
+/* ---- ZSTD_c_checksumFlag (lib/zstd.h:444; what the zstd CLI turns on by default, programs/fileio.c:287): when enabled every
  * frame this context emits carries the 32-bit content checksum (low half of XXH64, computed on the device: k_xxh64) and the
  * descriptor bit, exactly as lib/compress/zstd_compress.c:4637 / :5297-5303 write them.  Sticky until changed.  Returns 0. */
 int          zhip_set_frame_checksum(zhip_ctx* ctx, int enable);
@@ -181,8 +181,8 @@ size_t       zhip_write_seek_table(void* dst, size_t dstCapacity, const unsigned
 size_t       zhip_compress_seekable(zhip_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, size_t unitSize);
 
 /* ---- dictionary compression of many small records (BASELINE configs[4]): what
- *      cdict = ZSTD_createCDict(dict, dictSize, level);                      lib/zstd.h:1006
- *      ZSTD_CCtx_refCDict(cctx, cdict); ZSTD_compress2(cctx, ..record..)     lib/zstd.h:1180, :603    per record
+ *      cdict = ZSTD_createCDict(dict, dictSize, level);                      lib/zstd.h:979
+ *      ZSTD_CCtx_refCDict(cctx, cdict); ZSTD_compress2(cctx, ..record..)     lib/zstd.h:1102, :603    per record
  * produces — one frame per record, byte-identical.  Records up to the reference's attach cut-off (8 KB for strategy fast,
  * 16 KB for dfast: lib/compress/zstd_compress.c:2289-2315) take its ATTACH mode (zstd_fast.c:483-678,
  * zstd_double_fast.c:328-547); larger ones, up to 128 KB, its COPY mode: private copies of the CDict's tables and the
@@ -209,19 +209,19 @@ size_t       zhip_compress_records(zhip_ctx* ctx, const zhip_cdict* cdict, void*
                                    const void* src, const unsigned long long* recOffsets, size_t nRec, size_t* frameSizes);
 
 /* ---- decompression: the step on the other side of the path, batch form of
- *      ZSTD_decompress (lib/zstd.h:205) / ZSTD_decompressDCtx (:299) / ZSTD_decompress_usingDDict (:1046).
+ *      ZSTD_decompress (lib/zstd.h:168) / ZSTD_decompressDCtx (:294) / ZSTD_decompress_usingDDict (:1013).
  * Any RFC 8878 frame is accepted (what this library emits and what the reference emits: several blocks per frame, repeat /
  * treeless modes, checksums, dictionaries); frames are independent work items, one workgroup each.  Per-frame failures
  * carry zstd's error codes (corruption_detected 20, checksum_wrong 22, dictionary_wrong 32, dstSize_tooSmall 70, ...). */
-typedef struct zhip_dctx_s  zhip_dctx;                      /* device state the way ZSTD_DCtx owns it, lib/zstd.h:288 */
-typedef struct zhip_ddict_s zhip_ddict;                     /* = ZSTD_DDict, lib/zstd.h:1035: content + entropy tables in decoding form */
+typedef struct zhip_dctx_s  zhip_dctx;                      /* device state the way ZSTD_DCtx owns it, lib/zstd.h:285 */
+typedef struct zhip_ddict_s zhip_ddict;                     /* = ZSTD_DDict, lib/zstd.h:998: content + entropy tables in decoding form */
 zhip_dctx*   zhip_create_dctx(int device);
 void         zhip_free_dctx(zhip_dctx* dctx);
 const char*  zhip_dctx_last_error(const zhip_dctx* dctx);
 zhip_ddict*  zhip_create_ddict(int device, const void* dict, size_t dictSize);   /* raw-content or ZDICT format (zstd_decompress.c:1476-1500) */
 void         zhip_free_ddict(zhip_ddict* ddict);
-unsigned     zhip_ddict_id(const zhip_ddict* ddict);        /* = ZSTD_getDictID_fromDDict, lib/zstd.h:1100 */
-/* frame walker over a HOST buffer of concatenated frames = ZSTD_findFrameCompressedSize (lib/zstd.h:254) +
+unsigned     zhip_ddict_id(const zhip_ddict* ddict);        /* = ZSTD_getDictID_fromDDict, lib/zstd.h:1039 */
+/* frame walker over a HOST buffer of concatenated frames = ZSTD_findFrameCompressedSize (lib/zstd.h:214) +
  * ZSTD_getFrameContentSize (:215) + ZSTD_decompressBound's per-frame term (:1520); skippable frames are stepped over.
  * Arrays are optional, filled for the first maxFrames frames; contentSizes[i] = ~0ull when the header does not state it.
  * returns the number of frames, or an error (srcSize_wrong when the buffer does not end on a frame boundary). */

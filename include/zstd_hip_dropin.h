@@ -25,7 +25,7 @@
  *                       concatenated; ZSTD_decompress decodes it, lib/decompress/zstd_decompress.c:1068) and equals
  *                       `zstd -b<level> -B128K` chunking, but it is NOT the reference's single shared-window frame.
  *                       ZSTD_getFrameContentSize() of the stream reports the first unit only; use
- *                       ZSTD_findDecompressedSize() (lib/zstd.h:1492) for the total.
+ *                       ZSTD_findDecompressedSize() (lib/zstd.h:1458) for the total.
  *                       With ZHIP_c_singleFrame = 1 (or $ZHIP_SINGLE_FRAME=1) and any strategy up to ZSTD_lazy2 (levels -N .. 12)
  *                       the output IS the reference's single frame, byte for byte: one frame header,
  *                       128 KB / 92 KB blocks (ZSTD_lazy2: the fingerprint splitter's borders) sharing the window, the match
@@ -47,9 +47,9 @@ extern "C" {
 #endif
 
 typedef struct ZSTD_CCtx_s ZSTD_CCtx;                                   /* lib/zstd.h:262 */
-typedef struct ZSTD_CDict_s ZSTD_CDict;                                 /* lib/zstd.h:998 */
-typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_reset_session_and_parameters = 3 } ZSTD_ResetDirective;   /* :569 */
-/* ZSTD_cParameter values this shim understands (lib/zstd.h:331-507); all others -> parameter_unsupported */
+typedef struct ZSTD_CDict_s ZSTD_CDict;                                 /* lib/zstd.h:965 */
+typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_reset_session_and_parameters = 3 } ZSTD_ResetDirective;   /* :569-573 */
+/* ZSTD_cParameter values this shim understands (lib/zstd.h:331-522); all others -> parameter_unsupported */
 enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
        ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
        ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400, ZSTD_c_jobSize = 401, ZSTD_c_overlapLog = 402,
@@ -58,14 +58,14 @@ enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 1
 
 ZSTD_CCtx*  ZSTD_createCCtx(void);                                                                 /* lib/zstd.h:263 */
 size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                                        /* :264 */
-size_t      ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);                         /* :534 */
-size_t      ZSTD_CCtx_reset(ZSTD_CCtx* cctx, ZSTD_ResetDirective reset);                           /* :590 */
+size_t      ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);                         /* :550 */
+size_t      ZSTD_CCtx_reset(ZSTD_CCtx* cctx, ZSTD_ResetDirective reset);                           /* :589 */
 size_t      ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* :603 */
 size_t      ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* :274 */
-size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* :160 */
+size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* :155 */
 size_t      ZSTD_compressBound(size_t srcSize);                                                    /* :236 (here: the bound of the frame-per-unit stream, >= the reference's) */
-unsigned    ZSTD_isError(size_t code);                                                             /* :243 */
-const char* ZSTD_getErrorName(size_t code);                                                        /* :244 */
+unsigned    ZSTD_isError(size_t code);                                                             /* :242 */
+const char* ZSTD_getErrorName(size_t code);                                                        /* :243 */
 /* dictionaries: raw-content and ZDICT-format, CDict levels whose row is fast/dfast, sources up to 128 KB (attach mode below
  * the reference's cut-off of 8 KB fast / 16 KB dfast, copy mode above it) — byte-identical to the reference; anything else ->
  * NULL / parameter_unsupported */
@@ -86,27 +86,27 @@ size_t        ZSTD_CStreamInSize(void);                                         
 size_t        ZSTD_CStreamOutSize(void);                                                           /* :823 */
 size_t      ZSTD_compress_usingCDict(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_CDict* cdict);   /* :992 */
 /* decompression (served by k_decode; any RFC 8878 frame — this library's and the reference's) */
-typedef struct ZSTD_DCtx_s ZSTD_DCtx;                                                              /* :288 */
-typedef struct ZSTD_DDict_s ZSTD_DDict;                                                            /* :1035 */
-#define ZSTD_CONTENTSIZE_UNKNOWN 0xFFFFFFFFFFFFFFFFULL                                                       /* :211 */
-#define ZSTD_CONTENTSIZE_ERROR   0xFFFFFFFFFFFFFFFEULL                                                       /* :212 */
-size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);   /* :205 every frame of src */
-ZSTD_DCtx*  ZSTD_createDCtx(void);                                                                 /* :289 */
-size_t      ZSTD_freeDCtx(ZSTD_DCtx* dctx);                                                        /* :290 */
-size_t      ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* :299 */
-ZSTD_DDict* ZSTD_createDDict(const void* dictBuffer, size_t dictSize);                             /* :1037 */
-size_t      ZSTD_freeDDict(ZSTD_DDict* ddict);                                                     /* :1042 */
-size_t      ZSTD_decompress_usingDDict(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_DDict* ddict);   /* :1046 */
-unsigned    ZSTD_getDictID_fromDDict(const ZSTD_DDict* ddict);                                     /* :1100 */
-unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);                      /* :215 first frame only */
-unsigned long long ZSTD_findDecompressedSize(const void* src, size_t srcSize);                     /* :1492 all frames */
-size_t      ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);                         /* :254 */
-unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);                          /* :1520 upper bound of all frames' content */
-unsigned    ZSTD_isFrame(const void* buffer, size_t size);                                         /* :1466 zstd or skippable frame magic */
-unsigned    ZSTD_getDictID_fromFrame(const void* src, size_t srcSize);                             /* :1112 0 = not stated */
-int         ZSTD_minCLevel(void);                                                                  /* :245 */
-int         ZSTD_maxCLevel(void);                                                                  /* :246 (highest level the device core implements) */
-int         ZSTD_defaultCLevel(void);                                                              /* :247 */
+typedef struct ZSTD_DCtx_s ZSTD_DCtx;                                                              /* :285 */
+typedef struct ZSTD_DDict_s ZSTD_DDict;                                                            /* :998 */
+#define ZSTD_CONTENTSIZE_UNKNOWN 0xFFFFFFFFFFFFFFFFULL                                                       /* :194 */
+#define ZSTD_CONTENTSIZE_ERROR   0xFFFFFFFFFFFFFFFEULL                                                       /* :195 */
+size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);   /* :168 every frame of src */
+ZSTD_DCtx*  ZSTD_createDCtx(void);                                                                 /* :286 */
+size_t      ZSTD_freeDCtx(ZSTD_DCtx* dctx);                                                        /* :287 */
+size_t      ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* :294 */
+ZSTD_DDict* ZSTD_createDDict(const void* dictBuffer, size_t dictSize);                             /* :1003 */
+size_t      ZSTD_freeDDict(ZSTD_DDict* ddict);                                                     /* :1008 */
+size_t      ZSTD_decompress_usingDDict(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const ZSTD_DDict* ddict);   /* :1013 */
+unsigned    ZSTD_getDictID_fromDDict(const ZSTD_DDict* ddict);                                     /* :1039 */
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);                      /* :196 first frame only */
+unsigned long long ZSTD_findDecompressedSize(const void* src, size_t srcSize);                     /* :1458 all frames */
+size_t      ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);                         /* :214 */
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);                          /* :1473 upper bound of all frames' content */
+unsigned    ZSTD_isFrame(const void* buffer, size_t size);                                         /* :2361 zstd or skippable frame magic */
+unsigned    ZSTD_getDictID_fromFrame(const void* src, size_t srcSize);                             /* :1051 0 = not stated */
+int         ZSTD_minCLevel(void);                                                                  /* :244 */
+int         ZSTD_maxCLevel(void);                                                                  /* :245 (highest level the device core implements) */
+int         ZSTD_defaultCLevel(void);                                                              /* :246 */
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,26 @@ def test_dropin_shim_exports_every_declared_symbol(zlib_):
     assert L.ZSTD_defaultCLevel() == 3
 
 
+def test_dropin_header_cites_the_reference_lines_it_stands_in_for():
+    """include/zstd_hip_dropin.h declares the reference's prototypes again and names, per function, the line of lib/zstd.h it stands in for: the line
+    cited holds that function's declaration (checked where the reference is on disk)"""
+    import re
+    ref_h = "/root/reference/lib/zstd.h"
+    if not os.path.exists(ref_h):
+        pytest.skip("reference sources not on this box")
+    ref = open(ref_h).read().split("\n")
+    seen = 0
+    for l in open(os.path.join(ROOT, "include", "zstd_hip_dropin.h")).read().split("\n"):
+        m = re.match(r"\s*[\w\s\*]+?\b(ZSTD_\w+)\s*\(.*\);\s*/\*\s*(?:lib/zstd\.h)?:(\d+)", l)
+        if not m:
+            continue
+        name, cited = m.group(1), int(m.group(2))
+        around = " ".join(ref[cited - 1: cited + 1])                 # the return type may sit on the line before the name
+        assert re.search(r"\b" + name + r"\s*\(", around), (name, cited, ref[cited - 1])
+        seen += 1
+    assert seen >= 35
+
+
 def test_no_oracle_or_reference_in_the_product_binary(zlib_):
     from zstd_amd import build as zb
     for lib in (zlib_.LIB_PATH, zb.SHIM):

@@ -124,7 +124,7 @@ void zhip_dctx_last_bigframe(const zhip_dctx* c, unsigned out[4]) { for (int i =
 const char* zhip_dctx_last_error(const zhip_dctx* c) { return c ? c->err : "null context"; }
 void zhip_dctx_last_timing(const zhip_dctx* c, double t[2]) { t[0] = c->timing[0]; t[1] = c->timing[1]; }
 
-// = ZSTD_findFrameCompressedSize (lib/zstd.h:254): the frame (or skippable frame) at the start of src, which may hold more
+// = ZSTD_findFrameCompressedSize (lib/zstd.h:214): the frame (or skippable frame) at the start of src, which may hold more
 size_t zhip_frame_compressed_size(const void* srcv, size_t srcSize)
 {
     const uint8_t* const src = (const uint8_t*)srcv;
@@ -134,7 +134,7 @@ size_t zhip_frame_compressed_size(const void* srcv, size_t srcSize)
     return e ? DERR(e) : cs;
 }
 
-// = ZSTD_findFrameCompressedSize + ZSTD_getFrameContentSize over concatenated frames (lib/zstd.h:254, :215), skippable
+// = ZSTD_findFrameCompressedSize + ZSTD_getFrameContentSize over concatenated frames (lib/zstd.h:214, :196), skippable
 // frames (magic 0x184D2A5?) are stepped over like ZSTD_decompress does (zstd_decompress.c:1100-1110).
 size_t zhip_find_frames(const void* srcv, size_t srcSize, unsigned long long* srcOffsets, unsigned long long* srcSizes,
                         unsigned long long* contentSizes, unsigned long long* contentBounds, size_t maxFrames)
@@ -409,7 +409,7 @@ size_t zhip_seekable_read(zhip_dctx* c, void* dst, size_t len, const void* srcv,
     return len;
 }
 
-// = ZSTD_decompress / ZSTD_decompress_usingDDict (lib/zstd.h:205, :1046) for host buffers: every frame of src, contents back to back in dst
+// = ZSTD_decompress / ZSTD_decompress_usingDDict (lib/zstd.h:168, :1013) for host buffers: every frame of src, contents back to back in dst
 size_t zhip_decompress(zhip_dctx* c, const zhip_ddict* dd, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     std::lock_guard<std::mutex> lk(c->mu);

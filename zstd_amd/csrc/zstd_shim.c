@@ -247,7 +247,7 @@ size_t ZSTD_compress(void* dst, size_t cap, const void* src, size_t n, int level
     return r;
 }
 
-/* ---- decompression (lib/zstd.h:205-299, :1035-1046): host buffers through zhip_decompress */
+/* ---- decompression (lib/zstd.h:168-294, :998-1013): host buffers through zhip_decompress */
 struct ZSTD_DCtx_s { zhip_dctx* z; };
 struct ZSTD_DDict_s { zhip_ddict* d; };
 ZSTD_DCtx* ZSTD_createDCtx(void) { return (ZSTD_DCtx*)calloc(1, sizeof(ZSTD_DCtx)); }
@@ -337,7 +337,7 @@ unsigned ZSTD_getDictID_fromFrame(const void* src, size_t n)
 size_t ZSTD_compressBound(size_t n) { return zhip_compressBound(n, SHIM_UNIT); }
 unsigned ZSTD_isError(size_t code) { return zhip_isError(code); }
 const char* ZSTD_getErrorName(size_t code) { return zhip_getErrorName(code); }
-int ZSTD_minCLevel(void) { return -131072; }                      /* -ZSTD_TARGETLENGTH_MAX, lib/zstd.h:1269 */
+int ZSTD_minCLevel(void) { return -131072; }                      /* -ZSTD_TARGETLENGTH_MAX, lib/zstd.h:1249 */
 int ZSTD_maxCLevel(void) { return 10; }                           /* fast, dfast and the hash-chain greedy/lazy/lazy2 rows of units <= 128 KB; levels >= 5 reproduce the
                                                                       reference with ZSTD_c_useRowMatchFinder = ZSTD_ps_disable; small units at 9-10 (btlazy2) -> parameter_unsupported */
 int ZSTD_defaultCLevel(void) { return 3; }
