@@ -50,6 +50,7 @@ def main():
     for it in range(3):
         ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, 131072)
         L.zhip_prof_read(out, 1)
+        if it < 2 and level < 3: L.zhip_wph_read((C.c_ulonglong * 64)(), 1)
     v = list(out)
     units = n // 131072
     tm = ctx.timing()
@@ -77,11 +78,18 @@ def main():
                           "windows_per_unit": v[10] / units, "window_events_per_unit": v[11] / units, "batch_iterations_per_unit": v[12] / units,
                           "window_post_exits_per_unit": v[13] / units, "windows_cut_short_per_unit": v[14] / units}, indent=1))
         return
-    res = {"timing_ms": tm, "units": units,
-           "parse_ticks_per_unit": {names_p[i]: round(v[i] / units) for i in range(10)},
-           "parse_windows_per_unit": v[10] / units, "parse_window_events_per_unit": v[11] / units,
-           "fast_events_per_unit": v[12] / units, "window_reruns_per_unit": v[13] / units, "verify_rounds_per_unit": v[14] / units,
-           "trimmed_tails_per_unit": v[15] / units,
+    w = (C.c_ulonglong * 64)()
+    L.zhip_wph_read(w, 1)
+    w = list(w)
+    wn = {0: "F_SRC", 1: "F_TAB", 2: "F_DUP", 3: "F_GRP", 4: "F_MASK", 5: "SEARCH", 6: "M_ELOAD", 7: "M_RUNS", 8: "M_EMIT", 9: "LEAVE", 10: "E_PRE", 11: "E_TAB", 12: "E_OUT",
+          13: "B_SCAN", 14: "B_MATCH", 15: "B_POST", 16: "TAIL", 17: "INIT", 18: "LOOP", 19: "CARRY", 20: "IMM", 21: "GRP_IT", 22: "GRP_NF", 23: "LATE", 24: "LEAVE_FAR"}
+    wtot = sum(w[:32]) or 1
+    res = {"timing_ms": tm, "units": units, "unit_bytes": n // units,
+           # ZSTD_fast window phases (zhip_parse.h WPH_*): id -> [ticks per unit, visits per unit]; scripts/isa_phase_table.py --hits reads this
+           "phases": {str(i): [w[i] / units, w[32 + i] / units] for i in range(32) if w[32 + i]},
+           "phase_share_percent": {wn.get(i, str(i)): round(100.0 * w[i] / wtot, 1) for i in range(32) if w[32 + i]},
+           "ticks_per_visit": {wn.get(i, str(i)): round(w[i] / w[32 + i]) for i in range(32) if w[32 + i]},
+           "parse_ticks_per_unit": wtot / units,
            "entropy_ticks_per_unit": {names_e[i]: round(v[16 + i] / units) for i in range(8)},
            "entropy_extra": [round(v[16 + i] / units) for i in range(8, 12)],
            "phaseB_jobs_ticks_per_unit": {"huf_build_codes": round(v[28] / units), "huf other (mode, write table)": round(v[31] / units),

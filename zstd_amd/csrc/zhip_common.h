@@ -69,7 +69,7 @@ struct ZhipParse {
 // each workgroup accumulates s_memtime deltas per phase and adds them to g_prof at the end.  The product build
 // expands all of this to nothing.
 #ifdef ZHIP_PROF
-namespace zhip { __device__ unsigned long long g_prof[32]; }
+namespace zhip { __device__ unsigned long long g_prof[32]; __device__ unsigned long long g_wph[64]; }   /* g_wph: ZSTD_fast window phases, [0,32) ticks, [32,64) visits */
 #define ZPROF_DECL uint64_t zp_last_ = __builtin_amdgcn_s_memtime(); uint64_t zp_acc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define ZPROF(i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); zp_acc_[i] += t_ - zp_last_; zp_last_ = t_; } while (0)
 #define ZPROF_COUNT(i, v) do { zp_acc_[i] += (uint64_t)(v); } while (0)

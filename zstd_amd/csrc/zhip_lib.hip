@@ -1460,6 +1460,13 @@ extern "C" void zhip_prof_read(unsigned long long out[32], int reset)
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zhip::g_prof), 32 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[32]; memset(z, 0, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(zhip::g_prof), z, sizeof(z)); }
 }
+// the ZSTD_fast window's phases (zhip_parse.h, WPH_*): [0,32) ticks, [32,64) visits
+extern "C" void zhip_wph_read(unsigned long long out[64], int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zhip::g_wph), 64 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[64]; memset(z, 0, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(zhip::g_wph), z, sizeof(z)); }
+}
 #endif
 
 // ------------------------------------------------------------------ block-level plugin (B1)

@@ -295,17 +295,50 @@ struct FastOut {
     uint32_t pendSh;        // per lane: bits to shift pendV right by (loads are clamped to the unit)
     uint32_t pendOff, pendLen;
 #ifdef ZHIP_PROF
-    uint64_t* zp; uint64_t* zlast;   // the caller's phase accumulators (measurement build only)
+    uint64_t* zp; uint32_t* ws; uint32_t* wh; uint64_t* zlast;   // the caller's phase accumulators (measurement build only; ws / wh: the ZSTD_fast window's)
 #endif
 };
+// WINDOW PHASES (measurement build only, -DZHIP_PROF; scripts/isa_phase_table.py + scripts/prof_phases.py).  ZWPH(o, id) closes phase `id`: the
+// s_memtime ticks since the previous marker and one visit go to the phase's slots, and a "; ZWPH id" comment lands in the assembly, from which
+// the table script counts the instructions of every phase (basic blocks inherit the phase their predecessors end in).  Nothing is waited for at
+// a marker: a stall is charged to the phase whose instruction stalls.  The product build expands all of it to nothing.
+enum { WPH_F_SRC = 0,      // window: pending literal store, source + repcode bytes (preloaded or loaded), hash, tag
+       WPH_F_TAB = 1,      // table gather (LDS: position, bit 16, tag), candidate address
+       WPH_F_DUP = 2,      // candidate load issued; duplicate detection in the slots (mark / peek / unmark)
+       WPH_F_GRP = 3,      // hash groups of the flagged lanes (readlane / ballot loop), p1 / p2 / m1 / m2
+       WPH_F_MASK = 4,     // candidate bytes arrive: M, E1 / E2 masks (four ballots)
+       WPH_SEARCH = 5,     // event loop: one search of the span (cut, NF selection, first match / first probe)
+       WPH_M_ELOAD = 6,    // a match: inserts, E load of a new offset + its two ballots
+       WPH_M_RUNS = 7,     // backward + forward runs from the masks (incl. the out-of-line continuation past the window)
+       WPH_M_EMIT = 8,     // emit, coverage, complementary inserts, immediate-repcode loop, next scan set up
+       WPH_LEAVE = 9,      // a match left the window: carry, or :403-420 by loads
+       WPH_E_PRE = 10,     // window end: the next window's source bytes requested
+       WPH_E_TAB = 11,     // table writes (together, then the NF lanes one by one)
+       WPH_E_OUT = 12,     // sequences + literals stored
+       WPH_B_SCAN = 13,    // schedule-shaped batch up to its event decision
+       WPH_B_MATCH = 14,   // its match: wave_extend, literals, sequence
+       WPH_B_POST = 15,    // post_match (inserts, immediate repcode, next batch's bytes)
+       WPH_TAIL = 16, WPH_INIT = 17, WPH_LOOP = 18, /* between windows: the scan loop of parse_fast_block */
+       WPH_CARRY = 19,     // a carried match's lanes 0..2: insert, immediate-repcode test (carry windows only)
+       WPH_IMM = 20,       // one immediate-repcode loop (:410-420 from the masks)
+       WPH_GRP_IT = 21,    // one hash group resolved (readlane + ballot)
+       WPH_GRP_NF = 22,    // a window with groups: p1 / p2 / m1 / m2 of every lane
+       WPH_LATE = 23,      // one late (NF) insert
+       WPH_LEAVE_FAR = 24  /* :403-420 by loads (post_match_far) */ };
 #ifdef ZHIP_PROF
-#define ZWPROF(o, i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); (o).zp[i] += t_ - *(o).zlast; *(o).zlast = t_; } while (0)
+#define ZWPROF(o, i) do { uint64_t const t_ = __builtin_amdgcn_s_memtime(); (o).zp[i] += t_ - *(o).zlast; *(o).zlast = t_; } while (0)      /* the lazy parser's coarse timers (zhip_parse_lazy.h) */
 #define ZWPROF_COUNT(o, i, v) do { (o).zp[i] += (uint64_t)(v); } while (0)
 #define ZWPROF_SYNC(o, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ZWPROF(o, i); } while (0)   /* charges the outstanding loads to phase i */
+#define ZWPH(o, i) do { asm volatile("; ZWPH %0" :: "n"(i)); uint64_t const t_ = __builtin_amdgcn_s_memtime(); (o).ws[i] += (uint32_t)(t_ - *(o).zlast); (o).wh[i]++; *(o).zlast = t_; } while (0)
 #else
 #define ZWPROF_SYNC(o, i) do { } while (0)
 #define ZWPROF(o, i) do { } while (0)
 #define ZWPROF_COUNT(o, i, v) do { } while (0)
+#ifdef ZHIP_WPH_MARK                 /* the table script's build: the markers alone, on the product's code */
+#define ZWPH(o, i) asm volatile("; ZWPH %0" :: "n"(i))
+#else
+#define ZWPH(o, i) do { } while (0)
+#endif
 #endif
 
 __device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
@@ -517,7 +550,13 @@ __device__ __forceinline__ uint32_t pull(uint32_t v, uint32_t srcLane) { return 
 #ifndef ZHIP_FAST_PRELOAD
 #define ZHIP_FAST_PRELOAD 1          /* measurement switch: 0 = every window loads its own source bytes */
 #endif
-struct FastPre { uint64_t c8; uint32_t v1, v2, B; };        // the next window's source bytes (B = ~0: none)
+struct FastPre { uint64_t c8; uint32_t v1, v2, B; uint64_t c8b; };        // the next window's source bytes (B = ~0: none); c8b: the 64 positions behind them (candidate prefetch)
+#ifndef ZHIP_FAST_CANDPF
+#define ZHIP_FAST_CANDPF 0           /* 1: every window also looks up the 64 positions BEHIND its own and touches their candidates' lines (a hint, never waited for) */
+#endif
+#ifndef ZHIP_FAST_PREFETCH
+#define ZHIP_FAST_PREFETCH 0         /* bytes in front of the window's base at which the source stream prefetch starts (0 = none) */
+#endif
 #ifndef ZHIP_FAST_CARRY
 #define ZHIP_FAST_CARRY 1            /* measurement switch: 0 = never carry (every leaving match goes by loads), 1 = plain matches only, 2 = immediate repcodes too */
 #endif
@@ -536,11 +575,23 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // the lanes' own bytes and the bytes the two repcodes point at (an invalid repcode, 0, reads the lane's own bytes): the window before this
     // one has usually requested them already (FastPre), else all three loads are in flight together
     uint64_t cur8; uint32_t v1, v2;
-    if (ZHIP_FAST_PRELOAD && pre.B == B) { cur8 = pre.c8; v1 = pre.v1; v2 = pre.v2; }
-    else { cur8 = ld64(src + P); v1 = ld32(src + (P - rep1_)); v2 = ld32(src + (P - rep2_)); }     // a repcode offset never exceeds the position it is used at
+    uint64_t c8b = 0;
+    if (ZHIP_FAST_PRELOAD && pre.B == B) { cur8 = pre.c8; v1 = pre.v1; v2 = pre.v2; c8b = pre.c8b; }
+    else { cur8 = ld64(src + P); v1 = ld32(src + (P - rep1_)); v2 = ld32(src + (P - rep2_));      // a repcode offset never exceeds the position it is used at
+           if (ZHIP_FAST_CANDPF) c8b = ld64(src + (P + 64 < nm8 ? P + 64 : nm8)); }
     pre.B = ~0u;
+#if ZHIP_FAST_PREFETCH
+    // SOURCE STREAM PREFETCH.  Where the next window starts is only known when this one's events are resolved, so its source bytes are requested
+    // at the very end (FastPre) and the wavefront then sits through that load's whole latency (the LOOP phase of profiles/r06_phases_*: 12-16 % of
+    // the stage).  The bytes are the unit's sequential stream, though: every lane touches 8 bytes further ahead now — 512 bytes = four or five lines,
+    // one request each — and the window's own work hides the HBM latency; the load at the end then finds its lines in the L2.  The value is
+    // only "used" (an empty asm) at the window's end, when it has long arrived: nothing waits for it.
+    uint32_t const pfAt = B + ZHIP_FAST_PREFETCH + 8u * lane;
+    uint32_t const pfv = ld32(src + (pfAt < nm8 ? pfAt : nm8));
+#endif
     uint32_t const cur32 = (uint32_t)cur8;
     uint32_t const h = hash_pos<MLS>(cur8, hshift);
+    ZWPH(out, WPH_F_SRC);
 
     // table gather; the slot doubles as the duplicate detector (lane id written, read back, old value restored — the
     // lanes of one hash hold the same old value)
@@ -551,8 +602,17 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // others all read the unit's first bytes — one line, one request — so that the load stays unconditional: a load inside a branch is
     // waited for inside the branch (round 3), and this one has the duplicate detection below to hide behind
     bool const fetch = old != 0 && tagMaybe;
+    ZWPH(out, WPH_F_TAB);
     uint32_t cb = ld32(src + tab_guard(T, fetch ? old : 0u));
     if (!fetch) cb = ~cur32;
+#if ZHIP_FAST_CANDPF
+    // CANDIDATE PREFETCH.  A window waits for its candidates' bytes — 64 random lines of the unit's past, HBM latency — before it can tell its first event.  The lookups of
+    // the NEXT window are made now as well, with the table as it stands (what this window inserts may change a few entries: it is a hint, exactness is not at stake),
+    // and their candidates' lines requested; nobody waits for them (the value is "used" by an empty asm at the window's end): the next window's gather finds them in the L2.
+    uint32_t pfc;
+    {   bool m2; uint32_t const o2 = tab_get_t(T, hash_pos<MLS>(c8b, hshift), B > 65536 - 64, fast_tag15((uint32_t)c8b), m2);
+        pfc = ld32(src + tab_guard(T, (o2 != 0 && m2) ? o2 : 0u)); }
+#endif
     uint32_t backId = lane;
     if constexpr (!TabTraits<TAB>::ballotGroups) {
         __builtin_amdgcn_wave_barrier();
@@ -563,6 +623,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         tab_unmark(T, h, old);
         __builtin_amdgcn_wave_barrier();
     }
+    ZWPH(out, WPH_F_DUP);
 
     // NF: lanes that share their hash with an earlier lane of the window.  What such a lane finds in the table depends on which of
     // its group's earlier members have been inserted when it is looked up: the closest inserted one, else the table's old entry.
@@ -588,6 +649,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             if (h == hj) myG = G;
             NF |= G & (G - 1);
             ML &= ~G; it++;
+            ZWPH(out, WPH_GRP_IT);
         }
         }
         if (NF) {
@@ -600,12 +662,13 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             m1 = (depth >= 1 && c1 == cur32) ? 1u : 0u;
             m2 = (depth >= 2 && c2 == cur32) ? 1u : 0u;
             DEEP |= __ballot(depth >= 3);
+            ZWPH(out, WPH_GRP_NF);
         }
     }
+    ZWPH(out, WPH_F_GRP);
     bool const hitOld = old != 0 && old >= prefixLow && cb == cur32;
     unsigned long long const M = __ballot(hitOld);
     uint32_t const x1 = rep1_ ? cur32 ^ v1 : 1u, x2 = rep2_ ? cur32 ^ v2 : 1u;
-    ZWPROF(out, 1);
 
     uint32_t const nbSeq0 = out.nbSeq;
     uint32_t const anchorEntry = anchor_;
@@ -625,10 +688,11 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         unsigned long long late_ = INS & NF, CM = INS ^ late_;                                                    \
         if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put_t(T, h, P, myTag);                                   \
         __builtin_amdgcn_wave_barrier();                                                                          \
-        while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); } \
+        while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); ZWPH(out, WPH_LATE); } \
         INS = 0; } while (0)
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
     unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
+    ZWPH(out, WPH_F_MASK);
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
     // one by one after the others, in position order (a later member of a hash group overwrites an earlier one)
     int kLim;                                                             // iterations before the gap grows (:342-346), entry scan only
@@ -641,7 +705,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         ZW_EMIT(0u, 1u, rl);                                                                                       \
         uint32_t const en = (e_) + rl;                                                                             \
         COV |= en < 64 ? (lanes_from(e_) & lanes_below(en)) : lanes_from(e_);                                      \
-        (e_) = en; anchor = B + (e_); } while ((e_) < 64 && ((E2q >> (e_)) & 1))
+        (e_) = en; anchor = B + (e_); ZWPH(out, WPH_IMM); } while ((e_) < 64 && ((E2q >> (e_)) & 1))
     // the scan left the window behind a match that ended at lane e_ (>= 64; anchor = B + e_): the next window takes it over (kind_ 1: it
     // starts at the end - 2 and inserts that position, 2: at the end of an immediate repcode), or — no room for a window — :403-420 go by loads
 #define ZW_LEAVE(e_, kind_, cur0_) do {                                                                          \
@@ -656,7 +720,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
                 ps = post_match_far<MLS, TAB>(src, nm8, hshift, T, out.seqs, ps, (cur0_), (kind_) == 1);           \
                 ip0n = ps.ip0; anchor = ps.anchor; rep1 = ps.rep1; rep2 = ps.rep2; out.nbSeq = ps.nbSeq; out.longPos = ps.longPos; out.longType = ps.longType; \
             }                                                                                                      \
-            i = ip0n - B; } } while (0)
+            i = ip0n - B; ZWPH(out, WPH_LEAVE_FAR); } } while (0)
     {   int32_t const d = (int32_t)(nextStep - B) - 4;
         kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
     if (carryIn) {
@@ -671,6 +735,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         }
         {   int32_t const d = (int32_t)(nextStep - (B + i)) - 4;           // a fresh scan: 64 iterations before the gap grows
             kLim = (d <= 0 ? 0 : (d + 1) >> 1) + 1; }
+        ZWPH(out, WPH_CARRY);
     }
     for (;;) {
         // a lane with three or more earlier group members only matters if the scan has to look it up: inside a match (a run of equal
@@ -702,8 +767,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             status = (Kw == kLim) ? ZW_INC : ZW_CONT;
             break;
         }
-        ZWPROF(out, 2);
-        ZWPROF_COUNT(out, 11, 1);
+        ZWPH(out, WPH_SEARCH);
         // the repcode probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326)
         uint32_t const isRep = ((jr - i - 2) >> 1) <= ((jm - i) >> 1) ? 1u : 0u;
         uint32_t const j = isRep ? jr : jm;
@@ -721,6 +785,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             if (P >= off) x = cur32 ^ ld32(src + (P - off));
             E1q = __ballot(x == 0); E1b = __ballot((x & 0xFFu) == 0);
         }
+        ZWPH(out, WPH_M_ELOAD);
         uint32_t run = 0;
         if (j) {
             unsigned long long const t = ~E1b << (64 - j);
@@ -730,7 +795,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t const back = run < limit ? run : limit;
         uint32_t const fl = fwd_run(src, nm8, B, E1b, j + 4, off);
         uint32_t const mLength = 4 + back + fl;
-        ZWPROF(out, 3);
+        ZWPH(out, WPH_M_RUNS);
         uint32_t const ll = room - back;
         ZW_EMIT(ll, isRep ? 1u : off + 3, mLength);
         sumLit += ll;
@@ -743,7 +808,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             COV |= lanes_from(sL);
             ZW_LEAVE(e, 1u, B + cur0L);
             if (carry_) INS |= 1ull << (cur0L + 2);                       // :407 is a lane of this window (cur0L <= 59); :408 and :410 are the next window's lanes 0 and 2
-            ZWPROF(out, 9);
+            ZWPH(out, WPH_LEAVE);
             break;
         }
         COV |= ZHIP_SBFM64(e - sL, sL);
@@ -754,15 +819,21 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         }
         i = e;
         kLim = 64; nextStep = B + e + 128;                                // _start: a fresh scan inside the window
-        ZWPROF(out, 4);
+        ZWPH(out, WPH_M_EMIT);
     }
 window_done:
 #undef ZW_IMMEDIATE
 #undef ZW_LEAVE
-    ZWPROF(out, 2);
+    ZWPH(out, WPH_SEARCH);
 #undef ZW_EMIT
 #ifdef ZHIP_DBG_PRINT
     if (lane == 0) printf("  window B=%u carry=%u -> i=%u status=%d INS=%llx NF=%llx COV=%llx nbSeq=%u rep=%u/%u anchor=%u carryOut=%u\n", B, carryIn, i, status, INS, NF, COV, out.nbSeq, rep1, rep2, anchor, carry_);
+#endif
+#if ZHIP_FAST_PREFETCH
+    asm volatile("" :: "v"(pfv));
+#endif
+#if ZHIP_FAST_CANDPF
+    asm volatile("" :: "v"(pfc));
 #endif
     if (ZHIP_FAST_PRELOAD) {
         // the next window's source bytes, requested before this window's stores; unconditional (a load inside a branch is waited for inside
@@ -771,9 +842,12 @@ window_done:
         uint32_t const q = (nxt ? B + i : B) + lane;
         pre.c8 = ld64(src + q);
         pre.v1 = ld32(src + (q - (nxt ? rep1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? rep2 : 0u)));
+        if (ZHIP_FAST_CANDPF) pre.c8b = ld64(src + (q + 64 < nm8 ? q + 64 : nm8));
         pre.B = nxt ? B + i : ~0u;
     }
+    ZWPH(out, WPH_E_PRE);
     ZW_TABLE_FLUSH();
+    ZWPH(out, WPH_E_TAB);
 #undef ZW_TABLE_FLUSH
     // its sequences
     if (nEv == ~0u) nEv = out.nbSeq - nbSeq0;
@@ -792,7 +866,7 @@ window_done:
     }
     out.litPos += sumLit;
     ip0_ = B + i; anchor_ = anchor; rep1_ = rep1; rep2_ = rep2;
-    ZWPROF(out, 5);
+    ZWPH(out, WPH_E_OUT);
     return status;
 }
 
@@ -809,11 +883,12 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     uint32_t const stepSize = u.targetLength + !u.targetLength + 1;         // zstd_fast.c:200
     FastOut out; out.seqs = seqs; out.lits = lits; out.nbSeq = 0; out.longPos = 0; out.longType = 0;
     out.litPos = 0; out.pendV = 0; out.pendSh = 0; out.pendOff = 0; out.pendLen = 0;
-    ZPROF_DECL
 #ifdef ZHIP_PROF
-    out.zp = zp_acc_; out.zlast = &zp_last_;
+    uint32_t ws_acc_[32], wh_acc_[32]; uint64_t zp_last_ = __builtin_amdgcn_s_memtime();
+    for (int i_ = 0; i_ < 32; i_++) { ws_acc_[i_] = 0; wh_acc_[i_] = 0; }
+    out.ws = ws_acc_; out.wh = wh_acc_; out.zlast = &zp_last_;
 #endif
-    ZPROF(0);
+    ZWPH(out, WPH_INIT);
 
     uint32_t anchor = b0, rep1 = repIn1, rep2 = repIn2, saved1 = 0, saved2 = 0;
     // :238-244  a repcode that reaches below the window is set aside for the block
@@ -829,7 +904,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
     uint32_t carry = 0;                     // a window handed the end of its last match to the next one (see window_batch)
-    FastPre pre; pre.c8 = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;
+    FastPre pre; pre.c8 = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u; pre.c8b = 0;
     bool have = false;                      // `cur` already holds the bytes of the batch that starts at ip0
     FastBatch cur; cur.bytes = 0; cur.rcur = 0; cur.rv = 0;
     for (;;) {                                                               // one turn per `_start`
@@ -844,9 +919,9 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
         dense = true;                            // schedule-shaped batches (cheaper per position when events are far apart)
         for (;;) {
             if (dense && stepSize == 2 && step == 2 && g0 == 2 && ip0 + ZHIP_WIN_NEED <= n) {
+                ZWPH(out, WPH_LOOP);
                 int const st = window_batch<MLS, TAB>(src, n, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep, prefixLow, carry, pre);
                 have = false;
-                ZPROF_COUNT(10, 1);
                 if (st == ZW_RESTART) { evKind = 3; break; }
                 if (st == ZW_INC) { step = 3; nextStep += 128; batch_offsets(g0, step, posOff, rposOff); }
                 if (ZHIP_WIN_DENSE_ONLY) dense = false;
@@ -938,7 +1013,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             }
             if (we) { if (inC) tab_put_t(T, h, pos, myTag); else tab_unmark(T, h, old); }
             __builtin_amdgcn_wave_barrier();
-            ZPROF(6);
+            ZWPH(out, WPH_B_SCAN);
 
             if (evKind == 1) {
                 mpos = __builtin_amdgcn_readlane(pos, jm);
@@ -979,7 +1054,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             lim = 1;                                                         // :271 mLength = ip0[-1] == match0[-1]
         }
         uint32_t backLen, fwdLen;
-        ZPROF(6);
+        ZWPH(out, WPH_B_SCAN);
         wave_extend(src, nm8, mpos, cand0, lim, backLen, fwdLen);
         ip0 = mpos - backLen;
         {   uint32_t const mLength = 4 + backLen + fwdLen;
@@ -987,11 +1062,12 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
             store_seq(out, ip0 - anchor, offBase, mLength);
             ip0 += mLength; anchor = ip0;
         }
+        ZWPH(out, WPH_B_MATCH);
         // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along
         have = false;
         if ((int32_t)ip0 <= ilimit)
             have = post_match<MLS, true, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, startPosOff, startRposOff, cur);
-        ZPROF(7);
+        ZWPH(out, WPH_B_POST);
     }
     lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
     lits_flush(out);
@@ -1000,8 +1076,10 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
         out.litPos = n - b0;
     }
     // ---- _cleanup (:368-375)
-    ZPROF(8);
-    ZPROF_FLUSH(0);
+    ZWPH(out, WPH_TAIL);
+#ifdef ZHIP_PROF
+    if (threadIdx.x == 0) for (int i_ = 0; i_ < 32; i_++) { atomicAdd(&zhip::g_wph[i_], (unsigned long long)ws_acc_[i_]); atomicAdd(&zhip::g_wph[32 + i_], (unsigned long long)wh_acc_[i_]); }
+#endif
     saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
     if (lane == 0) {
         meta->nbSeq = out.nbSeq; meta->lastLits = n - anchor;
