@@ -557,6 +557,9 @@ struct FastPre { uint64_t c8; uint32_t v1, v2, B; uint64_t c8b; };        // the
 #ifndef ZHIP_FAST_PREFETCH
 #define ZHIP_FAST_PREFETCH 0         /* bytes in front of the window's base at which the source stream prefetch starts (0 = none) */
 #endif
+#ifndef ZHIP_FAST_WINNERS
+#define ZHIP_FAST_WINNERS 1          /* 0: every inserted lane that shares its hash with an earlier one is written on its own, in position order (round 5) */
+#endif
 #ifndef ZHIP_FAST_CARRY
 #define ZHIP_FAST_CARRY 1            /* measurement switch: 0 = never carry (every leaving match goes by loads), 1 = plain matches only, 2 = immediate repcodes too */
 #endif
@@ -634,7 +637,8 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     unsigned long long NF = 0;
     unsigned long long DEEP = lanes_from(ZHIP_WIN_LANES);      // lanes that cannot be searched from this window: >= 60, or beyond what the group data resolves
     uint32_t p1 = 0, p2 = 0, m1 = 0, m2 = 0, depth = 0;
-    {   unsigned long long myG = 0;
+    unsigned long long myG = 0;                                // the lanes of this lane's hash group (0: none, or a group the loop below did not get to)
+    {
         if constexpr (TabTraits<TAB>::ballotGroups) {
             myG = wave_hash_group(h, 32u - hshift);                       // every group exactly, whatever their number
             NF = __ballot((myG & lanes_below(lane)) != 0);
@@ -683,9 +687,17 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t const slot_ = out.nbSeq - nbSeq0;                                                                \
         evA = ZHIP_WRITELANE((ob), slot_, evA); evB = ZHIP_WRITELANE(((ll) & 0xFFFFu) | (mb_ << 16), slot_, evB); \
         out.nbSeq++; } while (0)
-    // the window's table writes: the lanes of INS outside NF together, then its NF lanes one by one
+    // the window's table writes.  Lanes of one hash share a slot and the reference leaves the LAST inserted one there: every lane that knows its group (myG) checks that no
+    // higher member is inserted too, and all such winners write together.  Only inserted lanes of a group the front did not resolve (beyond ZHIP_WIN_GROUPS) go one by one,
+    // in position order, behind the others (round 5 wrote every inserted NF lane that way: 5 200 serial writes per unit of text, profiles/r06_isa_phase_table_fast_text.txt)
 #define ZW_TABLE_FLUSH() do {                                                                                    \
         unsigned long long late_ = INS & NF, CM = INS ^ late_;                                                    \
+        if (ZHIP_FAST_WINNERS && late_) {                                                                         \
+            unsigned long long const known_ = __ballot(myG != 0);                                                 \
+            unsigned long long const win_ = __ballot((myG & INS & (lanes_from(lane) << 1)) == 0);                 \
+            late_ &= ~known_;                                         /* inserted lanes of unresolved groups */   \
+            CM = INS & win_ & ~late_;                                                                             \
+        }                                                                                                         \
         if (__builtin_amdgcn_inverse_ballot_w64(CM)) tab_put_t(T, h, P, myTag);                                   \
         __builtin_amdgcn_wave_barrier();                                                                          \
         while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); ZWPH(out, WPH_LATE); } \
