@@ -389,9 +389,39 @@ def records_main(args, torch, zstd_amd, dev, local, rank, world, dist):
         dist.barrier(); dist.destroy_process_group()
 
 
+def real_corpus(env_name):
+    """the REAL corpus when the box has one: $ZHIP_SILESIA (the Silesia corpus as one file, e.g. silesia.tar — tests/regression/data.c:33-52 names its
+    members) / $ZHIP_ENWIK9 give a file path; None when unset.  No box of this project ever had either: the hooks exist so that the first one that does
+    yields the metric's real number (round-5 verdict, item 6 ii); tests/test_bench_corpus_hooks.py exercises them with a small file."""
+    path = os.environ.get(env_name)
+    if not path:
+        return None
+    if not os.path.isfile(path) or os.path.getsize(path) < 4096:
+        raise SystemExit(f"bench.py: ${env_name}={path} is not a readable file of at least 4 KB")
+    return np.fromfile(path, dtype=np.uint8)
+
+
+def lorem_corpus(n, seed=0):
+    """LOREM_genBuffer(buffer, n, seed) — what `zstd -b#` compresses when it is given no file (programs/benchzstd.c:1014, programs/lorem.h:20; SURVEY 8(d) names it as
+    the text stand-in) — made by the reference's own generator in oracle/_ref/libzstd_ref.so.  Generation only: the bytes are input data, nothing of the reference runs
+    in the timed path."""
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle", "_ref", "libzstd_ref.so")
+    if not os.path.exists(path):
+        raise SystemExit("bench.py: the lorem workload needs oracle/_ref/libzstd_ref.so (make -C oracle ref, where /root/reference exists)")
+    lr = C.CDLL(path)
+    lr.LOREM_genBuffer.restype = None
+    lr.LOREM_genBuffer.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    a = np.zeros(n, dtype=np.uint8)
+    lr.LOREM_genBuffer(a.ctypes.data_as(C.c_void_p), n, seed)
+    return a
+
+
 def make_workload(torch, zstd_amd, dev, workload, rank, world, mib, copies, total_bytes):
-    """-> (host array for the CPU legs, device source tensor, n, description, scaling, tile = (base corpus, shift) when the host array is only the base)"""
+    """-> (host array for the CPU legs, device source tensor, n, description, scaling, tile = (base corpus, shift) when the host array is only the base).
+    make_workload.data_kind says what the bytes are: "synthetic", or "real" when $ZHIP_SILESIA / $ZHIP_ENWIK9 supplied the corpus."""
     scaling = "weak"
+    make_workload.data_kind = "synthetic"
     if workload == "datagen":
         n = mib << 20
         host = zstd_amd.datagen(n, 50, seed=rank, stream_mode=True)        # `datagen -g<n> -P50 -s<rank>`
@@ -399,18 +429,34 @@ def make_workload(torch, zstd_amd, dev, workload, rank, world, mib, copies, tota
         src[:n].copy_(torch.from_numpy(host))
         return host, src, n, f"datagen -g{n} -P50 -s<rank> (programs/datagen.c stream mode)", scaling, None
     from zstd_amd import workloads as W
-    if workload == "silesia":                                               # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in
-        base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
+    if workload == "silesia":                                               # configs[0]/[2]: Silesia is not on disk -> Silesia-shaped stand-in, unless $ZHIP_SILESIA names the corpus
+        base = real_corpus("ZHIP_SILESIA")
+        if base is not None:
+            make_workload.data_kind = "real"
+            wdesc = f"the Silesia corpus ($ZHIP_SILESIA = {os.environ['ZHIP_SILESIA']}, {len(base)} B) x{copies} copies"
+        else:
+            base = W.silesia_like(lambda m, P, seed: zstd_amd.datagen(m, P, seed=seed, stream_mode=False), seed=rank)
+            wdesc = f"Silesia-shaped synthetic mix ({len(base)} B: text / structured / tables / runs / incompressible, zstd_amd/workloads.py) x{copies} copies"
         n = len(base) * copies
-        wdesc = f"Silesia-shaped synthetic mix ({len(base)} B: text / structured / tables / runs / incompressible, zstd_amd/workloads.py) x{copies} copies"
-    else:                                                                   # configs[3]: enwik9 is not on disk -> Zipf word-salad text
-        base = W.text_corpus(64 << 20, seed=rank)
+    else:                                                                   # configs[3]: enwik9 is not on disk -> Zipf word-salad text (or LOREM_genBuffer), unless $ZHIP_ENWIK9 names it
+        real = real_corpus("ZHIP_ENWIK9") if workload == "text" else None
+        if real is not None:
+            base = real; make_workload.data_kind = "real"
+        elif workload == "lorem":
+            base = lorem_corpus(64 << 20, seed=rank)
+        else:
+            base = W.text_corpus(64 << 20, seed=rank)
         if total_bytes:
             n = total_bytes // world                                        # frame-per-shard: a fixed total cut into one shard per GPU
             scaling = "strong"
         else:
             n = mib << 20
-        wdesc = f"Zipf word-salad text (64 MiB generated, tiled to {n} B per GPU, zstd_amd/workloads.py), enwik9 stand-in"
+        if real is not None:
+            wdesc = f"enwik9 ($ZHIP_ENWIK9 = {os.environ['ZHIP_ENWIK9']}, {len(base)} B; {n} B per GPU, tiled if shorter)"
+        elif workload == "lorem":
+            wdesc = f"LOREM_genBuffer text (programs/lorem.h:20 — what `zstd -b#` compresses without a file; 64 MiB from the reference's generator, tiled to {n} B per GPU)"
+        else:
+            wdesc = f"Zipf word-salad text (64 MiB generated, tiled to {n} B per GPU, zstd_amd/workloads.py), enwik9 stand-in"
     bdev = torch.from_numpy(base).to(dev)
     src = torch.empty(n + 64, dtype=torch.uint8, device=dev)
     pos, c, L = 0, 0, len(base)
@@ -510,7 +556,7 @@ def compress_leg(args, torch, zstd_amd, dev, local, rank, world, dist, workload,
         out = {
             "metric": f"compress_MBps_level{level}_{'datagenP50' if workload == 'datagen' else workload}_128KB_units", "value": round(world * n / dt * K / 1e6, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8/u32 integer", "data": getattr(make_workload, "data_kind", "synthetic"),
             "config": {"workload": f"{wdesc}, level {level} ({cpdesc}), "
                                    f"{UNIT} B independent units = one frame each, src+dst resident in HBM", "units_per_gpu": units,
                        "parallelism": f"{world} x (one process per GPU, independent units, no collective)"},
@@ -913,7 +959,7 @@ def strong_text_leg(args, torch, zstd_amd, dev, local, rank, world, dist):
     per = (units_total + world - 1) // world * UNIT
     lo, hi = min(total, rank * per), min(total, (rank + 1) * per)
     n = hi - lo
-    host = W.tile(W.text_corpus(64 << 20, seed=0), total)[lo:hi].copy()     # the same buffer on every rank, each keeps its own shard
+    host = W.tile_range(W.text_corpus(64 << 20, seed=0), lo, hi)            # the same buffer on every rank; each makes only its own shard of it
     src = torch.empty(max(n, 1) + 64, dtype=torch.uint8, device=dev)
     if n:
         src[:n].copy_(torch.from_numpy(host))
@@ -1048,7 +1094,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mib", type=int, default=1024, help="source MiB per GPU (default = the 1 GiB of configs[1])")
     ap.add_argument("--level", type=int, default=1)
-    ap.add_argument("--workload", choices=["datagen", "silesia", "text", "records"], default="datagen",
+    ap.add_argument("--workload", choices=["datagen", "silesia", "text", "lorem", "records"], default="datagen",
                     help="datagen = BASELINE configs[1] (default); silesia / text / records = synthetic stand-ins for configs[2] / [3] / [4]")
     ap.add_argument("--raw-dict", action="store_true", help="records: use the first ~110 KB of records as a raw-content dictionary instead of the trained fixture")
     ap.add_argument("--base-records", type=int, default=1000000, help="records: DISTINCT ~1.2 KB records generated before tiling (1 M = 1.2 GB, beyond the 256 MB Infinity Cache)")
@@ -1144,10 +1190,10 @@ def main():
 
 # the default line's extra legs: (key in the JSON line, deadline in seconds)
 LEGS = [("decode", 90), ("pipelined", 60), ("end_to_end", 90), ("plugin_B1", 120), ("multi_block_frames", 90), ("job_pool_frame", 120), ("silesia_shaped_level1", 120),
-        ("text_level1", 150), ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_units", 180)]
+        ("text_level1", 150), ("lorem_level1", 120), ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_units", 180)]
 # short names of the legs in the line's closing `digest`
 DIGEST_NAMES = {"decode": "dec_L1", "pipelined": "pipe4", "end_to_end": "e2e_host", "plugin_B1": "plugin_B1", "multi_block_frames": "frames_1MiB",
-                "job_pool_frame": "job_pool_1GiB", "silesia_shaped_level1": "silesia4_L1", "text_level1": "text1e9_L1", "silesia64_level3": "silesia64_L3",
+                "job_pool_frame": "job_pool_1GiB", "silesia_shaped_level1": "silesia4_L1", "text_level1": "text1e9_L1", "lorem_level1": "lorem1GiB_L1", "silesia64_level3": "silesia64_L3",
                 "records_zdict_level3": "records10M_L3", "level5_units": "datagen_L5"}
 
 
@@ -1225,6 +1271,11 @@ def run_leg(args, torch, zstd_amd, dev, local):
         tx, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "text", 1, max(3, min(args.steps, 10)), 2, 1, 1000000000,
                              want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="text_level1")
         return {k: tx[k] for k in LEG_KEYS if k in tx}
+    if name == "lorem_level1":                                   # SURVEY 8(d)'s text stand-in by name: LOREM_genBuffer, 1 GiB, level 1 (beside the word salad of text_level1)
+        a6 = argparse.Namespace(**vars(args)); a6.mib = 1024
+        lm, _ = compress_leg(a6, torch, zstd_amd, dev, local, 0, 1, None, "lorem", 1, max(3, min(args.steps, 10)), 2, 1, 0,
+                             want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="lorem_level1")
+        return {k: lm[k] for k in LEG_KEYS if k in lm}
     if name == "level5_units":                                   # the lazy family's sample row: level 5 (ZSTD_greedy, the reference's default row-hash matcher) on the headline's data
         host5 = int(os.environ.get("ZHIP_L5_LEG_MIB", "1024"))
         a5 = argparse.Namespace(**vars(args)); a5.mib = host5

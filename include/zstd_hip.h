@@ -50,7 +50,8 @@ size_t       zhip_compressBound(size_t srcSize, size_t unitSize);   /* sum of ZS
 
 /* ---- parameters = ZSTD_getCParams (lib/zstd.h:1877; lib/compress/zstd_compress.c:7150) for the supported rows
  * out[7] = windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy. returns 0, or -1 if the
- * level/size maps to a strategy this library does not implement (greedy and above). */
+ * level/size maps to a strategy this library does not implement (the binary-tree strategies btlazy2 .. btultra2, levels 13 and up;
+ * fast, dfast, greedy, lazy and lazy2 are implemented). */
 int          zhip_getCParams(int level, unsigned long long srcSize, unsigned out[7]);
 /* the same with explicitly set parameters = what a CCtx holds after ZSTD_CCtx_setParameter(ZSTD_c_windowLog / chainLog / hashLog /
  * searchLog / minMatch / targetLength / strategy) (lib/compress/zstd_compress.c:710-768): cparams[7] in ZSTD_compressionParameters

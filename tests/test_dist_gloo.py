@@ -100,3 +100,29 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     env["WORLD_SIZE"] = "1"; env["RANK"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "disagrees" in (r.stderr + r.stdout)
+
+
+def test_eight_ranks_ordered_gather_equals_single_process():
+    """the first 8-GPU lease must not fail on plumbing (round-5 verdict, item 7): eight ranks, unit ranges, ordered host gather — with fewer units than ranks in
+    one case (ranks with an empty range)"""
+    same, sizes_ok, length = _run(8, 131072 * 19 + 4321)
+    assert same and sizes_ok and length > 0
+    same, sizes_ok, length = _run(8, 131072 * 3 + 5)
+    assert same and sizes_ok and length > 0
+
+
+def test_bench_eight_ranks_the_way_the_driver_launches_them():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` (the contract's launch line)
+    in the stub context: ONE JSON line from rank 0, n_gpus = 8"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ZHIP_BENCH_STUB"] = "1"
+    port = 29500 + (os.getpid() % 2000) + 7
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["data"] == "stub"

@@ -177,7 +177,7 @@ def test_fuzz_units_with_explicit_parameters():
             n = int(rng.integers(1, 30000)) if t % 6 else int(rng.integers(100000, 131073))
             a = gen(rng, n)
             level = int(rng.choice([1, 3, 5, 6, 7, -3]))
-            req = [int(rng.choice([0, 0, 12, 14, 15, 17, 18])), int(rng.choice([0, 0, 8, 12, 15, 16])), int(rng.choice([0, 0, 8, 11, 13, 15, 17])),
+            req = [int(rng.choice([0, 0, 12, 14, 15, 17, 18])), int(rng.choice([0, 0, 8, 12, 15, 16])), int(rng.choice([0, 0, 8, 11, 13, 15, 17, 18])),
                    int(rng.choice([0, 0, 1, 2, 4, 5, 6])), int(rng.choice([0, 0, 3, 4, 5, 6, 7])), int(rng.choice([0, 0, 1, 4, 16, 64])), int(rng.choice([0, 0, 1, 2, 3, 4, 5]))]
             eff = _explicit(level, n, req)
             if eff is None or not (1 <= eff[6] <= 5) or (1 << eff[0]) < n or (eff[6] == 1 and eff[2] > 15):
@@ -206,3 +206,45 @@ def test_fuzz_units_with_explicit_parameters():
         _libs.make_units = orig
         lo.zo_set_row_matcher(0)
     assert seen >= 30
+
+
+def test_lazy_units_at_hashlog_18_on_the_emulator():
+    """hashLog 18 (windowLog + 1 of a 128 KB unit) splits the hash-chain builder's table into SIXTEEN LDS slices; until round 6 its slice counters held eight and the
+    case was never run (the fuzzers stopped at 17).  Hash chain and row matcher, greedy / lazy / lazy2, against the oracle."""
+    import ctypes as C
+    import _libs
+    lo, le = load_oracle(), load_emu()
+    lo.zo_compress_unit_params.restype = C.c_size_t
+    lo.zo_compress_unit_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(1818)
+    orig = _libs.make_units
+    ran = 0
+    try:
+        for strat, no_row, n in ((3, 1, 131072), (4, 0, 131072), (5, 1, 100003), (3, 0, 70000)):
+            a = gen(rng, n)
+            req = [18, 16, 18, 4, 5, 16, strat]
+            eff = _explicit(5, n, req)
+            assert eff is not None and eff[2] == 18, list(eff)
+            row = eff[0] > 14 and not no_row
+            lo.zo_set_row_matcher(1 if row else 0)
+            cap = lo.zo_compress_bound(n) + 64
+            o = np.zeros(cap, dtype=np.uint8)
+            r = lo.zo_compress_unit_params(_buf(o), cap, _buf(a), n, eff)
+            assert r != ERR
+
+            def mk(lo_, sizes, level_, unit=131072, row=False, eff=eff, no_row=no_row):
+                units = orig(lo_, sizes, 1, unit, False)
+                for f in units:
+                    f["windowLog"], f["chainLog"], f["hashLog"], f["searchLog"], f["minMatch"], f["targetLength"], f["strategy"] = list(eff)
+                    f["litMode"] = 0
+                    f["rowLog"] = min(6, max(4, eff[3])) if (eff[0] > 14 and not no_row) else 0
+                return units
+            _libs.make_units = mk
+            got = emu_compress_units(le, lo, [a], 1)[0]
+            _libs.make_units = orig
+            assert got == o[:r].tobytes(), (strat, no_row, n, list(eff))
+            ran += 1
+    finally:
+        _libs.make_units = orig
+        lo.zo_set_row_matcher(0)
+    assert ran == 4

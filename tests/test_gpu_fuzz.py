@@ -71,7 +71,7 @@ def test_fuzz_explicit_parameters_slice():
             n = int(rng.integers(unit, 8 * unit))
             a = gen(rng, n) if t % 3 else np.concatenate([gen(rng, n // 2), datagen(lo, n - n // 2, int(rng.integers(5, 95)), t)])
             level = int(rng.choice([1, 3, 5, 6, 7, -3]))
-            req = [int(rng.choice([0, 0, 17, 18])), int(rng.choice([0, 0, 8, 12, 15, 16])), int(rng.choice([0, 0, 8, 11, 13, 15, 17])),
+            req = [int(rng.choice([0, 0, 17, 18])), int(rng.choice([0, 0, 8, 12, 15, 16])), int(rng.choice([0, 0, 8, 11, 13, 15, 17, 18])),
                    int(rng.choice([0, 0, 1, 2, 4, 5, 6])), int(rng.choice([0, 0, 3, 4, 5, 6, 7])), int(rng.choice([0, 0, 1, 4, 16, 64])), int(rng.choice([0, 0, 1, 2, 3, 4, 5]))]
             no_row = int(rng.integers(0, 2))
             ctx.set_row_matcher(2 if no_row else 0)
@@ -97,6 +97,58 @@ def test_fuzz_explicit_parameters_slice():
         lo.zo_set_row_matcher(0)
         ctx.close(); dctx.close()
     assert cases >= 10 and units >= 100
+
+
+def test_lazy_units_at_hashlog_18_the_chain_builder_asks_for_more_than_64_KB_of_lds():
+    """hashLog 18 is the largest the reference's adjustment leaves a 128 KB unit (windowLog + 1, zstd_compress.c:1466): the row matcher's builder then needs 69 952 bytes
+    of LDS (hc_chain_lds_bytes), more than a launch gets without hipFuncAttributeMaxDynamicSharedMemorySize (round-5 advisor finding: the attribute was missing and
+    no test reached the case).  Greedy / lazy / lazy2 with explicit parameters, row matcher on and off, unit by unit against the oracle."""
+    import ctypes as C
+    import torch
+    import zstd_amd as z
+    from _libs import datagen
+    from test_fuzz_emu import _explicit
+    assert torch.cuda.is_available()
+    lo = load_oracle()
+    lo.zo_compress_unit_params.restype = C.c_size_t
+    lo.zo_compress_unit_params.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lo.zo_set_row_matcher.argtypes = [C.c_int]
+    L = z.lib()
+    L.zhip_compress_params.restype = C.c_size_t
+    L.zhip_compress_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(18)
+    unit = 131072
+    n = 3 * unit + 7777
+    a = np.concatenate([gen(rng, n // 2), datagen(lo, n - n // 2, 40, 3)])
+    ctx = z.Context(max_units=8)
+    dctx = z.DContext()
+    ran = 0
+    try:
+        for strat in (3, 4, 5):
+            for no_row in (0, 1):
+                req = [18, 16, 18, 4, 5, 16, strat]
+                ctx.set_row_matcher(2 if no_row else 0)
+                cap = z.compress_bound(n, unit)
+                dst = np.empty(cap, dtype=np.uint8); sizes = np.zeros(n // unit + 2, dtype=np.uint64)
+                r = L.zhip_compress_params(ctx._h, dst.ctypes.data_as(C.c_void_p), cap, a.ctypes.data_as(C.c_void_p), n, 5, (C.c_uint * 7)(*req), unit, sizes.ctypes.data_as(C.c_void_p))
+                assert not L.zhip_isError(r), (strat, no_row, z.lib().zhip_getErrorName(r))
+                assert dctx.decompress(dst[:r].tobytes()) == a.tobytes()
+                pos = 0
+                for k in range(-(-n // unit)):
+                    u = a[k * unit: (k + 1) * unit]
+                    eff = _explicit(5, len(u), req)
+                    if len(u) == unit:
+                        assert eff[2] == 18, list(eff)                     # the case this test exists for
+                    lo.zo_set_row_matcher(1 if (3 <= eff[6] <= 5 and eff[0] > 14 and not no_row) else 0)
+                    o = np.zeros(lo.zo_compress_bound(len(u)) + 64, dtype=np.uint8)
+                    rr = lo.zo_compress_unit_params(_buf(o), len(o), _buf(u), len(u), eff)
+                    got = dst[pos: pos + int(sizes[k])].tobytes(); pos += int(sizes[k])
+                    assert rr != ERR and got == o[:rr].tobytes(), ("unit", strat, no_row, k, list(eff))
+                    ran += 1
+    finally:
+        lo.zo_set_row_matcher(0)
+        ctx.close(); dctx.close()
+    assert ran == 24
 
 
 def test_fuzz_frames_and_job_frames_slice():

@@ -138,3 +138,51 @@ def test_two_ranks_on_one_device_through_bench_py():
     assert ts["parity"]["gathered_bytes"] == len(single)
     assert ts["parity"]["gathered_stream_sha256"] == hashlib.sha256(single).hexdigest()
     assert all(x in (True, None) for x in ts["parity"]["per_rank_sha256_equals_reference"])
+
+
+def test_eight_ranks_on_one_device_through_bench_py():
+    """The first 8-GPU lease must not fail on plumbing (round-5 verdict, item 7): `bench.py --gpus 8` with eight real ranks sharing device 0 on a small --mib —
+    one JSON line, n_gpus 8, the weak-scaling parity of rank 0, the frame-per-shard text leg with eight shards gathered into ONE stream that equals a single
+    process's, every rank's stream the real reference's."""
+    import hashlib
+    import json
+    import sys
+    import zstd_amd
+    from zstd_amd import workloads as W
+    total = 41 * UNIT + 777                                       # 42 units over 8 ranks: six per rank, the last rank's range is short (and ragged)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--mib", "4", "--no-cpu-baseline",
+                         "--total-bytes", str(total)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert cp.returncode == 0 and lines, cp.stderr[-3000:]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["units_per_gpu"] == 32
+    assert out["parity"]["bytes_identical_to_oracle_first_64_units"] and out["parity"]["frames_well_formed"]
+    ts = out["text_strong_scaling"]
+    assert ts["n_gpus"] == 8 and ts["scaling"] == "strong"
+    assert list(out.keys())[-1] == "digest" and "text1e9_strong" in out["digest"]
+    a = W.tile(W.text_corpus(64 << 20, seed=0), total)
+    single = zstd_amd.Context(0, max_units=64).compress(a, level=1)
+    assert ts["parity"]["gathered_bytes"] == len(single)
+    assert ts["parity"]["gathered_stream_sha256"] == hashlib.sha256(single).hexdigest()
+    assert len(ts["parity"]["per_rank_sha256_equals_reference"]) == 8
+    assert all(x in (True, None) for x in ts["parity"]["per_rank_sha256_equals_reference"])
+
+
+def test_multi_context_with_eight_devices_entries_on_one_gpu():
+    """zhip_compress_multi with devices = {0,0,0,0,0,0,0,0}: eight "devices" (sixteen lanes) on the one GPU of the box — the lane / ordered-gather machinery at the
+    width an 8-GPU node gives it; the stream equals a single context's and the oracle's"""
+    import zstd_amd
+    lo = load_oracle()
+    a = np.concatenate([datagen(lo, 40 * UNIT + 999, 50, 11), text_like(9 * UNIT + 17, 5)])
+    want = zstd_amd.Context(0, max_units=64).compress(a, level=1)
+    m = zstd_amd.MultiContext([0] * 8, chunk_units=2)              # 256 KB chunks: 25 chunks over 16 lanes
+    for rep in range(2):
+        assert m.compress(a, level=1) == want, rep
+    assert m.compress(a, level=3) == zstd_amd.Context(0, max_units=64).compress(a, level=3)
+    m.close()
+    m = zstd_amd.MultiContext([0] * 8)                             # default chunking: one or two chunks, most lanes idle
+    assert m.compress(a, level=1) == want
+    m.close()

@@ -409,16 +409,34 @@ static size_t build_units(zhip_ctx* c, size_t srcSize, size_t unitSize, int leve
     }
     // dfast: one table pair per RESIDENT workgroup (k_parse_dfast's workgroups are persistent and reuse theirs: at most 32 wavefronts per CU), not per unit
     size_t const dfPairs = nUnits < (size_t)32 * (size_t)c->numCUs ? nUnits : (size_t)32 * (size_t)c->numCUs;
-    size_t const tabUnits = (fam & 4) ? c->hcChunk : dfPairs;
-    if ((fam & 14) && c->tabsCap < tabUnits * c->tabStride) {
+    if (fam & 4) {
+        // hash chain / row matcher: links + lists and the match records of one CHUNK of units.  When the device cannot give a chunk's worth (8 192 units of
+        // 128 KB: 8 GB + 8 GB) the chunk is halved until it fits — the launch loop takes any chunk size (round-5 advisor finding: a failed hipMalloc used to
+        // end the call with no smaller retry).  Buffers that are already large enough are kept.
+        for (;;) {
+            bool ok = true;
+            if (c->tabsCap < c->hcChunk * c->tabStride) {
+                (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
+                if (hipMalloc((void**)&c->dTabs, c->hcChunk * c->tabStride * sizeof(uint32_t)) == hipSuccess) c->tabsCap = c->hcChunk * c->tabStride;
+                else { (void)hipGetLastError(); ok = false; }
+            }
+            if (ok && c->bestCap < c->hcChunk * (size_t)ZHIP_UNIT_MAX) {
+                (void)hipFree(c->dBest); c->dBest = nullptr; c->bestCap = 0;
+                if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) == hipSuccess) c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
+                else { (void)hipGetLastError(); ok = false; }
+            }
+            if (ok) break;
+            if (c->hcChunk <= 1) {
+                snprintf(c->err, sizeof(c->err), "cannot allocate the match finder's tables and records for even one unit (%zu + %zu bytes)",
+                         c->tabStride * sizeof(uint32_t), (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t));
+                *err = ZERR(ZE_memory_allocation); return 0;
+            }
+            c->hcChunk = (c->hcChunk + 1) / 2;
+        }
+    } else if ((fam & 2) && c->tabsCap < dfPairs * c->tabStride) {
         (void)hipFree(c->dTabs); c->dTabs = nullptr; c->tabsCap = 0;
-        if (hipMalloc((void**)&c->dTabs, tabUnits * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match-finder tables", tabUnits * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
-        c->tabsCap = tabUnits * c->tabStride;
-    }
-    if ((fam & 4) && c->bestCap < c->hcChunk * (size_t)ZHIP_UNIT_MAX) {
-        (void)hipFree(c->dBest); c->dBest = nullptr; c->bestCap = 0;
-        if (hipMalloc((void**)&c->dBest, c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match records", c->hcChunk * (size_t)ZHIP_UNIT_MAX * sizeof(uint64_t)); *err = ZERR(ZE_memory_allocation); return 0; }
-        c->bestCap = c->hcChunk * (size_t)ZHIP_UNIT_MAX;
+        if (hipMalloc((void**)&c->dTabs, dfPairs * c->tabStride * sizeof(uint32_t)) != hipSuccess) { snprintf(c->err, sizeof(c->err), "cannot allocate %zu bytes of match-finder tables", dfPairs * c->tabStride * sizeof(uint32_t)); *err = ZERR(ZE_memory_allocation); return 0; }
+        c->tabsCap = dfPairs * c->tabStride;
     }
     if ((fam & 2) && (fam & 4)) {                  // a mixed batch: room for the dfast workgroups' pairs as well
         if (c->tabsCap < dfPairs * c->tabStride) {
@@ -533,8 +551,14 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             while (c->hcEv.size() < c->hcEvUsed + 4) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->hcEv.push_back(e); }
             hipEvent_t* const he = &c->hcEv[c->hcEvUsed]; c->hcEvUsed += 4;
             HIPCHK(c, hipEventRecord(he[0], s));
-            hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), zhip::hc_chain_lds_bytes(c->hcHashLog), s,
-                               srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
+            {   // the builder's LDS covers the row counters, tag filters and the 2 304-byte stage as well (rh_chain_lds_need): 69 952 bytes at an effective hashLog of 18
+                // (a cparams override on units above 64 KB) — past the 64 KB a launch may ask for without the attribute
+                size_t const ldsC = zhip::hc_chain_lds_bytes(c->hcHashLog);
+                if (ldsC > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));
+                hipLaunchKernelGGL(zhip::k_hc_chain, dim3(nu), dim3(64), ldsC, s,
+                                   srcDev, c->dUnits + u0, nu, c->dTabs, c->tabStride, c->dBest);
+                HIPCHK(c, hipGetLastError());
+            }
             HIPCHK(c, hipEventRecord(he[1], s));
             {   size_t const lds = (((size_t)c->hcMaxLen + 15) & ~(size_t)15) + 32;
                 if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)zhip::k_hc_search_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1495,8 +1519,11 @@ static void fingerprint_range(const uint8_t* src, const ZhipUnit* units, size_t 
 }
 
 // Parse every block of the buffer in one launch and bring the sequences to the host: H2D, match finder, ONE packed copy back
-// (k_seq_compact), while host threads fingerprint the blocks.  The cache is replaced under cacheMu at the very end.
-static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level)
+// (k_seq_compact), while host threads fingerprint the blocks.  With `local` == nullptr the prepared cache is replaced under cacheMu at the very
+// end (zhip_prepare_sequences); with `local` the result goes there and the shared cache is never touched (the producer's one-shot parse of an
+// unprepared block: callbacks of other threads keep finding their prepared blocks while it runs — round-5 advisor finding).
+struct PreparedLocal { std::vector<ZhipSeq> seqs; std::vector<ZhipParse> parse; };
+static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_t blockSize, int level, PreparedLocal* local = nullptr)
 {
     if (blockSize == 0 || blockSize > ZHIP_UNIT_MAX) blockSize = ZHIP_UNIT_MAX;
     size_t err = 0; uint32_t mh = 0;
@@ -1511,17 +1538,18 @@ static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_
     if (zhip_isError(r)) return r;
     HIPCHK(c, hipMemcpyAsync(c->hParse, c->dParse, nUnits * sizeof(ZhipParse), hipMemcpyDeviceToHost, c->stream));
     // the content fingerprints (what lets a later callback trust the cache) while the device works: up to 16 host threads for large buffers
-    std::vector<uint64_t> hashes(2 * nUnits);
+    std::vector<uint64_t> hashes(local ? 0 : 2 * nUnits);
     std::vector<std::thread> workers;
     size_t nThr = srcSize >= ((size_t)32 << 20) ? 16 : 1;
     if (nThr > nUnits) nThr = nUnits;
+    if (local) nThr = 0;                                                           // a one-shot parse is never looked up by content
     if (nThr > 1) {
         try {
             for (size_t t = 1; t < nThr; t++)
                 workers.emplace_back(fingerprint_range, (const uint8_t*)src, (const ZhipUnit*)c->hUnits, nUnits * t / nThr, nUnits * (t + 1) / nThr, hashes.data());
         } catch (...) { for (auto& w : workers) w.join(); workers.clear(); nThr = 1; }      // no threads to be had: this one does it all
     }
-    fingerprint_range((const uint8_t*)src, c->hUnits, 0, nThr > 1 ? nUnits / nThr : nUnits, hashes.data());
+    if (!local) fingerprint_range((const uint8_t*)src, c->hUnits, 0, nThr > 1 ? nUnits / nThr : nUnits, hashes.data());
     for (auto& w : workers) w.join();
     HIPCHK(c, hipStreamSynchronize(c->stream));
     {   float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);           // the match finder's own duration (zhip_last_timing: parse_ms)
@@ -1547,6 +1575,7 @@ static size_t prepare_locked(zhip_ctx* c, const void* src, size_t srcSize, size_
         HIPCHK(c, hipMemcpyAsync(seqs.data(), c->dSeqPack, totalSeq * sizeof(ZhipSeq), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    if (local) { local->seqs.swap(seqs); local->parse.assign(c->hParse, c->hParse + nUnits); c->nUnits = nUnits; return nUnits; }
     {   std::lock_guard<std::mutex> lk(c->cacheMu);
         c->cacheParse.assign(c->hParse, c->hParse + nUnits);
         c->cacheUnits.assign(c->hUnits, c->hUnits + nUnits);
@@ -1592,22 +1621,15 @@ size_t zhip_sequence_producer(void* state, zhip_Sequence* outSeqs, size_t outSeq
             return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
         }
     }
-    // not prepared: one launch for this block (latency-bound path).  It leaves no cache of its own behind and keeps the one a
-    // zhip_prepare_sequences call installed: blocks of other sizes (the reference splits some 128 KB blocks at 92 KB,
+    // not prepared: one launch for this block (latency-bound path).  Its result stays local: the cache a zhip_prepare_sequences call
+    // installed is neither replaced nor hidden while this runs: blocks of other sizes (the reference splits some 128 KB blocks at 92 KB,
     // lib/compress/zstd_compress.c:4494-4518) must not cost the prepared blocks their parse
     std::lock_guard<std::mutex> lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return ZHIP_SEQUENCE_PRODUCER_ERROR;
-    std::vector<uint64_t> kHash, kOff; std::vector<ZhipSeq> kSeqs; std::vector<ZhipParse> kParse; std::vector<ZhipUnit> kUnits;
-    const void* kSrc; size_t kSize, kBlock; int kLevel;
-    {   std::lock_guard<std::mutex> lk2(c->cacheMu);
-        kHash.swap(c->cacheHash); kOff.swap(c->cacheSeqOff); kSeqs.swap(c->cacheSeqs); kParse.swap(c->cacheParse); kUnits.swap(c->cacheUnits);
-        kSrc = c->cacheSrc; kSize = c->cacheSize; kBlock = c->cacheBlock; kLevel = c->cacheLevel; c->cacheSrc = nullptr; }
-    size_t const rp = prepare_locked(c, src, srcSize, srcSize, compressionLevel);
-    std::lock_guard<std::mutex> lk2(c->cacheMu);
+    PreparedLocal one;
+    size_t const rp = prepare_locked(c, src, srcSize, srcSize, compressionLevel, &one);
     size_t r = rp;
-    if (!zhip_isError(rp)) r = seqs_to_public(c->cacheSeqs.data(), c->cacheParse[0], outSeqs, outSeqsCapacity);
-    c->cacheHash.swap(kHash); c->cacheSeqOff.swap(kOff); c->cacheSeqs.swap(kSeqs); c->cacheParse.swap(kParse); c->cacheUnits.swap(kUnits);
-    c->cacheSrc = kSrc; c->cacheSize = kSize; c->cacheBlock = kBlock; c->cacheLevel = kLevel;
+    if (!zhip_isError(rp)) r = seqs_to_public(one.seqs.data(), one.parse[0], outSeqs, outSeqsCapacity);
     return zhip_isError(r) ? ZHIP_SEQUENCE_PRODUCER_ERROR : r;
 }
 

@@ -182,16 +182,17 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
         int outState[2] = {0, 0};           // 0 free, 1 holds a finished chunk
         size_t outBytes[2] = {0, 0};
         bool stop = false;
-        auto fail = [&](size_t code, size_t k) {
+        // (the context's own message is only read by the lane's DEVICE thread, the one that may be writing it; the feeder and the gatherer name their stage)
+        auto fail = [&](size_t code, size_t k, const char* stage = nullptr) {
             {   std::lock_guard<std::mutex> g(gm);
-                if (!firstErr) { firstErr = code; snprintf(m->err, sizeof(m->err), "chunk %zu on device %d: %s", k, L.device, zhip_last_error(L.ctx)); }
+                if (!firstErr) { firstErr = code; snprintf(m->err, sizeof(m->err), "chunk %zu on device %d: %s", k, L.device, stage ? stage : zhip_last_error(L.ctx)); }
                 gcv.notify_all(); }
             {   std::lock_guard<std::mutex> g(lm); stop = true; }
             lcv.notify_all();
         };
         auto failed = [&] { std::lock_guard<std::mutex> g(gm); return firstErr != 0; };
         double tIn = 0, tWait = 0, tOut = 0, tH2D = 0, tK = 0, tD2H = 0;
-        std::thread feeder([&] {
+        auto feeder_fn = [&] {
             for (size_t i = 0; i < mine.size(); i++) {
                 int const b = (int)(i & 1);
                 {   std::unique_lock<std::mutex> g(lm); lcv.wait(g, [&] { return inState[b] == 0 || stop; }); if (stop) return; }
@@ -203,12 +204,12 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 ok = ok && hipEventRecord(L.evIn[b][0], L.copyStream) == hipSuccess;
                 if (ok && len) ok = hipMemcpyAsync(L.dIn2[b], L.pinIn[b], len, hipMemcpyHostToDevice, L.copyStream) == hipSuccess;
                 ok = ok && hipEventRecord(L.evIn[b][1], L.copyStream) == hipSuccess;
-                if (!ok) { fail(ZERR(ZE_GENERIC), k); return; }
+                if (!ok) { fail(ZERR(ZE_GENERIC), k, "the host-to-device copy could not be issued"); return; }
                 {   std::lock_guard<std::mutex> g(lm); inState[b] = 1; }
                 lcv.notify_all();
             }
-        });
-        std::thread gatherer([&] {
+        };
+        auto gatherer_fn = [&] {
             for (size_t i = 0; i < mine.size(); i++) {
                 int const b = (int)(i & 1);
                 size_t const k = mine[i];
@@ -226,7 +227,7 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                     if (firstErr) { g.unlock(); { std::lock_guard<std::mutex> g2(lm); stop = true; } lcv.notify_all(); return; }
                     myOff = off[k];
                 }
-                if (myOff + r > dstCapacity) { fail(ZERR(ZE_dstSize_tooSmall), k); return; }
+                if (myOff + r > dstCapacity) { fail(ZERR(ZE_dstSize_tooSmall), k, "the destination buffer is too small for the frames"); return; }
                 auto const t1 = std::chrono::steady_clock::now();
                 par_copy(dst + myOff, L.pinOut[b], r);
                 if (unitSizes) { size_t const u0 = cu0[k]; for (size_t j = 0; j < nu; j++) unitSizes[u0 + j] = L.pinSizes[b][j]; }
@@ -235,8 +236,18 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
                 {   std::lock_guard<std::mutex> g(lm); outState[b] = 0; }
                 lcv.notify_all();
             }
-        });
-        if (hipSetDevice(L.device) != hipSuccess) fail(ZERR(ZE_GENERIC), mine.empty() ? 0 : mine[0]);
+        };
+        // a thread that cannot be had must not take the process down from inside a C call (std::system_error out of a std::thread constructor on a lane
+        // thread is std::terminate): the call fails with memory_allocation instead and whatever started is joined (round-5 advisor finding)
+        std::thread feeder, gatherer;
+        try { feeder = std::thread(feeder_fn); gatherer = std::thread(gatherer_fn); }
+        catch (...) {
+            fail(ZERR(ZE_memory_allocation), mine.empty() ? 0 : mine[0], "no host thread for the lane's feeder / gatherer");
+            if (feeder.joinable()) feeder.join();
+            if (gatherer.joinable()) gatherer.join();
+            return;
+        }
+        if (hipSetDevice(L.device) != hipSuccess) fail(ZERR(ZE_GENERIC), mine.empty() ? 0 : mine[0], "hipSetDevice failed");
         else {
             zhip_set_frame_checksum(L.ctx, m->checksum);
             for (size_t i = 0; i < mine.size(); i++) {
@@ -274,7 +285,15 @@ size_t zhip_compress_multi(zhip_multi* m, void* dstv, size_t dstCapacity, const 
     };
     std::vector<std::thread> th;
     size_t const use = nChunks < nLanes ? nChunks : nLanes;
-    for (size_t li = 1; li < use; li++) th.emplace_back(lane_fn, li);
+    for (size_t li = 1; li < use; li++) {
+        try { th.emplace_back(lane_fn, li); }
+        catch (...) {                                    // no thread for this lane: the call fails (the lanes that did start see firstErr at their next chunk and stop)
+            {   std::lock_guard<std::mutex> g(gm);
+                if (!firstErr) { firstErr = ZERR(ZE_memory_allocation); snprintf(m->err, sizeof(m->err), "no host thread for lane %zu", li); } }
+            gcv.notify_all();
+            break;
+        }
+    }
     lane_fn(0);
     for (auto& t : th) t.join();
     m->lastSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -385,7 +404,15 @@ size_t zhip_compress_frame_mt_multi(zhip_multi* m, void* dstv, size_t dstCapacit
     };
     std::vector<std::thread> th;
     size_t const use = nChunks < nLanes ? nChunks : nLanes;
-    for (size_t li = 1; li < use; li++) th.emplace_back(lane_fn, li);
+    for (size_t li = 1; li < use; li++) {
+        try { th.emplace_back(lane_fn, li); }
+        catch (...) {                                    // no thread for this lane: the call fails (the lanes that did start see firstErr at their next chunk and stop)
+            {   std::lock_guard<std::mutex> g(gm);
+                if (!firstErr) { firstErr = ZERR(ZE_memory_allocation); snprintf(m->err, sizeof(m->err), "no host thread for lane %zu", li); } }
+            gcv.notify_all();
+            break;
+        }
+    }
     lane_fn(0);
     for (auto& t : th) t.join();
     m->lastSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -73,6 +73,9 @@ enum { ZW_POST = 3, ZW_BATCH = 4, ZW_CARRY = 5 };
 #ifndef ZHIP_DF_WINDOWS
 #define ZHIP_DF_WINDOWS 1
 #endif
+#ifndef ZHIP_DFW_GATHER
+#define ZHIP_DFW_GATHER 64u          /* lanes of a window that look their table entries up (the others count as beyond the cut W) */
+#endif
 
 // the second lowest lane among the lanes of `key` groups with two or more members (64: no group has two)
 __device__ __forceinline__ uint32_t first_repeat_lane(uint32_t key, unsigned long long losers)
@@ -151,11 +154,12 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         eLc = pull(pre.eL, ol & 63u); eSc = pull(pre.eS, ol & 63u); hitc = pull(pre.hit, ol & 63u);
         haveT = pre.tB != ~0u && shift < 64u && ol < 64u && (hitc & 4u) != 0;
     }
+    bool const gath = ZHIP_DFW_GATHER >= 64u || lane < ZHIP_DFW_GATHER;     // a lane beyond the gather width reads entry 0 (one line for all of them) and nothing is taken from it
 #ifdef ZHIP_DBG_PRINT
     { unsigned long long hv = __ballot(haveT); if (lane == 0) printf("  dftab B=%u carried=%d\n", B, (int)__builtin_popcountll(hv)); }
 #endif
     pre.tB = ~0u;
-    uint32_t const tL = tabL[haveT ? 0u : hl], tS = tabS[haveT ? 0u : hs];
+    uint32_t const tL = tabL[(haveT || !gath) ? 0u : hl], tS = tabS[(haveT || !gath) ? 0u : hs];
     uint32_t const eL = haveT ? eLc : tL, eS = haveT ? eSc : tS;
     ZWPROF_SYNC(out, 2);
     uint32_t const oldL = DF_POS(eL), oldS = DF_POS(eS);
@@ -168,13 +172,13 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     // the event loop hit them (taking the tag's word and confirming by the E load alone was measured: the loads then miss one after the
     // other, event loop 29.5 -> 48 M cycles per unit, profiles/r05_dfast_phases_tagtrust.log)
     uint64_t cbL = ~bytes; uint32_t cbS = ~cur32;
-    if (!haveT && oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
-    if (!haveT && oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
+    if (!haveT && gath && oldL != 0 && DF_TAGOK(eL, tgL)) cbL = ld64(src + (oldL < nm8 ? oldL : nm8));
+    if (!haveT && gath && oldS != 0 && DF_TAGOK(eS, tgS)) cbS = ld32(src + (oldS < nm8 ? oldS : nm8));
     bool const hitL = haveT ? (hitc & 1u) != 0 : (oldL != 0 && oldL >= prefixLow && cbL == bytes);        // :203 (index >= lowest, ZSTD_selectAddr)
     bool const hitS = haveT ? (hitc & 2u) != 0 : (oldS != 0 && oldS >= prefixLow && cbS == cur32);        // :218
     ZWPROF_SYNC(out, 3);
     ZWPROF_COUNT(out, 10, 1);
-    uint32_t W = 64;
+    uint32_t W = ZHIP_DFW_GATHER < 64u ? ZHIP_DFW_GATHER : 64u;
     if (loseL) { uint32_t const w = first_repeat_lane(hl, loseL); if (w < W) W = w; }
     if (loseS) { uint32_t const w = first_repeat_lane(hs, loseS); if (w < W) W = w; }
 #ifdef ZHIP_DBG_PRINT
@@ -349,7 +353,7 @@ dw_done:
             __builtin_amdgcn_wave_barrier();
             bool const clean = scrL[sl] != 0x80 && scrS[ss] != 0x80;
             __builtin_amdgcn_wave_barrier();
-            pre.eL = eL; pre.eS = eS; pre.hit = (hitL ? 1u : 0u) | (hitS ? 2u : 0u) | (clean ? 4u : 0u);
+            pre.eL = eL; pre.eS = eS; pre.hit = (hitL ? 1u : 0u) | (hitS ? 2u : 0u) | ((clean && (haveT || gath)) ? 4u : 0u);
             pre.tB = B;
         }
     }

@@ -114,15 +114,15 @@ __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n
     uint32_t const lane = (uint32_t)lane_id();
     uint32_t const nm8 = n - 8, sh = 32 - u.hashLog;
     uint32_t const sliceLog = u.hashLog < ZHIP_HC_SLICE_LOG ? u.hashLog : ZHIP_HC_SLICE_LOG;
-    uint32_t const E = 1u << sliceLog, passes = 1u << (u.hashLog - sliceLog);         // passes <= 8 (hashLog <= 17)
+    uint32_t const E = 1u << sliceLog, passes = 1u << (u.hashLog - sliceLog);         // passes <= 16: hashLog <= 18 = windowLog + 1 of a 128 KB unit (ZSTD_adjustCParams_internal, zstd_compress.c:1466)
     uint32_t const planeBytes = (E >> 3) < 4 ? 4 : (E >> 3);
     lds_u16* const lo = (lds_u16*)(uintptr_t)smem;
     lds_u32* const hi = (lds_u32*)(uintptr_t)(smem + 2u * E);
-    lds_u32* const ctr = (lds_u32*)(uintptr_t)(smem + 2u * E + planeBytes);            // [0..7] counts, [8..15] start offsets, [16..23] cursors
+    lds_u32* const ctr = (lds_u32*)(uintptr_t)(smem + 2u * E + planeBytes);            // [0..15] counts, [16..31] start offsets, [32..47] cursors (round 6: eight slices until then — hashLog 18 overran them)
     unsigned long long const laneBelow = below_mask((int)lane);
 
     // ---- 1. bucket the positions 0 .. n-8 by hash slice (the lazy look-ahead searches up to n-8, :1628)
-    if (lane < 24) ctr[lane] = 0;
+    if (lane < 48) ctr[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {                   // scan one: slice sizes
         uint64_t bv[8];
@@ -138,7 +138,7 @@ __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < 8; k++) { ctr[8 + k] = acc; ctr[16 + k] = acc; acc += ctr[k]; } }
+    if (lane == 0) { uint32_t acc = 0; for (uint32_t k = 0; k < 16; k++) { ctr[16 + k] = acc; ctr[32 + k] = acc; acc += ctr[k]; } }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t base0 = 0; base0 <= nm8; base0 += 512) {                   // scan two: entries = position | slice index << 17
         uint64_t bv[8];
@@ -152,16 +152,16 @@ __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n
             uint32_t const p = base0 + 64u * (uint32_t)j + lane;
             bool const live = p <= nm8;
             uint32_t const h = hash_pos<MLS>(bv[j], sh), sl = h >> sliceLog;
-            // lanes of this batch in the same slice, from three ballots over the slice id's bits
-            unsigned long long const b0 = __ballot(sl & 1), b1 = __ballot(sl & 2), b2 = __ballot(sl & 4);
+            // lanes of this batch in the same slice, from four ballots over the slice id's bits
+            unsigned long long const b0 = __ballot(sl & 1), b1 = __ballot(sl & 2), b2 = __ballot(sl & 4), b3 = __ballot(sl & 8);
             unsigned long long same = __ballot(live);
-            same &= (sl & 1) ? b0 : ~b0; same &= (sl & 2) ? b1 : ~b1; same &= (sl & 4) ? b2 : ~b2;
+            same &= (sl & 1) ? b0 : ~b0; same &= (sl & 2) ? b1 : ~b1; same &= (sl & 4) ? b2 : ~b2; same &= (sl & 8) ? b3 : ~b3;
             uint32_t const rank = (uint32_t)__popcll(same & laneBelow);
-            uint32_t const cur = ctr[16 + sl];
+            uint32_t const cur = ctr[32 + sl];
             __builtin_amdgcn_wave_barrier();
             if (live) {
                 queue[cur + rank] = p | ((h & (E - 1)) << 17);
-                if ((same & ~below_mask((int)lane + 1)) == 0) ctr[16 + sl] = cur + rank + 1;     // the slice's last lane moves its cursor
+                if ((same & ~below_mask((int)lane + 1)) == 0) ctr[32 + sl] = cur + rank + 1;     // the slice's last lane moves its cursor
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -176,7 +176,7 @@ __device__ inline void hc_chain_unit(const uint8_t* __restrict__ src, uint32_t n
             for (uint32_t i = lane; i < words; i += 64) z[i] = 0;
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t const q0 = ctr[8 + pass], q1 = q0 + ctr[pass];
+        uint32_t const q0 = ctr[16 + pass], q1 = q0 + ctr[pass];
         for (uint32_t qb = q0; qb < q1; qb += 64) {
             uint32_t const cnt = q1 - qb < 64 ? q1 - qb : 64;
             bool const live = lane < cnt;
