@@ -103,6 +103,7 @@ struct zhip_ctx_s {
     // ZSTD_fast queue form (launch_parse): ticket counter, dispatch order + cost classes, the co-kernel's tables in global memory, its stream
     uint32_t* dQueue = nullptr; uint32_t* dOrder = nullptr; uint32_t* dCost = nullptr; uint32_t* dGTabs = nullptr; size_t gtabsCap = 0;
     hipStream_t coStream = nullptr; hipEvent_t coEv[2] = {nullptr, nullptr}; int numCUs = 0;
+    int slotShare = 1;                   // the contexts that share this device's wavefront slots (a lane of zhip_compress_multi: the lanes of its device); launch_parse sizes its grids for 1 / slotShare of them
     int fastQueue = 0, fastOrder = 0, fastGWaves = 0;    // the ZSTD_fast stage: queue form, heaviest-first order, global-table wavefronts per CU (constants, A/B in profiles/r05_ab_fast_occupancy.log)
     int dfOccPerCU = 0;                                  // resident k_parse_dfast workgroups per CU (asked once)
     size_t fastOccSmem = ~(size_t)0; int fastOccPerCU = 1;
@@ -509,8 +510,12 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
             c->fastOccSmem = smem; c->fastOccPerCU = perCU_;
         }
         int const perCU = c->fastOccPerCU;
-        size_t const gridQ = (size_t)perCU * (size_t)c->numCUs < nUnits ? (size_t)perCU * (size_t)c->numCUs : nUnits;
-        size_t gridG = (size_t)c->fastGWaves * (size_t)c->numCUs;
+        // a lane of the host-buffer path shares the device with the other lanes' chunks: each takes its share of BOTH kinds of slots, so that a chunk larger than
+        // its share of the LDS slots spills to the global-table form instead of queueing behind the other lane's wavefronts (slotShare = 1: the whole device)
+        size_t const share = c->slotShare > 1 ? (size_t)c->slotShare : 1;
+        size_t const slotsQ = ((size_t)perCU * (size_t)c->numCUs + share - 1) / share;
+        size_t const gridQ = slotsQ < nUnits ? slotsQ : nUnits;
+        size_t gridG = ((size_t)c->fastGWaves * (size_t)c->numCUs + share - 1) / share;
         if (gridQ >= nUnits) gridG = 0;                                       // everything is resident on the LDS form already
         else if (gridG > nUnits - gridQ) gridG = nUnits - gridQ;
         bool const wantOrder = c->fastOrder && nUnits > 2;

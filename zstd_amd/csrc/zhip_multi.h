@@ -81,6 +81,9 @@ zhip_multi* zhip_multi_create(const int* devices, int nDevices, size_t chunkUnit
         L.device = devices[i / lanesPer]; L.inCap = inCap; L.outCap = outCap;
         bool ok = hipSetDevice(L.device) == hipSuccess;
         ok = ok && (L.ctx = zhip_create(L.device, chunkUnits)) != nullptr;
+#ifdef ZHIP_MULTI_SLOT_SHARE
+        if (ok) L.ctx->slotShare = (int)lanesPer;
+#endif
         for (int b = 0; b < 2; b++) {
             ok = ok && hipHostMalloc((void**)&L.pinIn[b], inCap, hipHostMallocDefault) == hipSuccess;
             ok = ok && hipHostMalloc((void**)&L.pinOut[b], outCap, hipHostMallocDefault) == hipSuccess;

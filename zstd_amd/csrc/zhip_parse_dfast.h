@@ -73,6 +73,9 @@ enum { ZW_POST = 3, ZW_BATCH = 4, ZW_CARRY = 5 };
 #ifndef ZHIP_DF_WINDOWS
 #define ZHIP_DF_WINDOWS 1
 #endif
+#ifndef ZHIP_DF_DYNCUT
+#define ZHIP_DF_DYNCUT 1             /* 0: round 5's window, cut once in front of the first lane that shares a hash with an earlier one */
+#endif
 #ifndef ZHIP_DFW_GATHER
 #define ZHIP_DFW_GATHER 64u          /* lanes of a window that look their table entries up (the others count as beyond the cut W) */
 #endif
@@ -178,6 +181,23 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     bool const hitS = haveT ? (hitc & 2u) != 0 : (oldS != 0 && oldS >= prefixLow && cbS == cur32);        // :218
     ZWPROF_SYNC(out, 3);
     ZWPROF_COUNT(out, 10, 1);
+#if ZHIP_DF_DYNCUT
+    // THE CUT FROM THE SCAN POSITION ON (round 6; DESIGN 9.2 of round 5).  A lane's table entries are the ones the reference reads unless an EARLIER lane of the same hash
+    // (in either table) is inserted before the scan gets to it — it is, when INSL / INSS hold it already or when it lies at or behind the scan position i (every lane from i
+    // on is inserted as the scan passes it, until the next event: and the next event is what is being looked for).  A member INSIDE a match is neither: the scan jumps over it.
+    // Round 5 cut the window once, in front of the first lane that shares a hash with ANY earlier lane, and left windows cut before their 12th lane to the batch scheme: 575 of
+    // a unit's 3 150 scan steps on the Silesia-shaped mix, 22 % of the stage — most of them runs and long matches, where the colliding lanes lie inside the match lane 0 finds.
+    // prevL / prevS: the earlier lanes of this lane's exact hash groups (the scratch slots only flag candidates: aliases of different hashes fall out in lane_groups).
+    unsigned long long gL = 0, gS = 0;
+    if (loseL) gL = lane_groups(hl, loseL, ~0ull);
+    if (loseS) gS = lane_groups(hs, loseS, ~0ull);
+    unsigned long long const prevL = gL & lanes_below(lane), prevS = gS & lanes_below(lane);
+    bool const anyGroups = __ballot((prevL | prevS) != 0) != 0;
+    uint32_t W = ZHIP_DFW_GATHER < 64u ? ZHIP_DFW_GATHER : 64u;                  // first lane from i on that the window cannot look up (recomputed when the scan gets there: it only moves up)
+    uint32_t const Wmax = W;
+#define DW_CUT(i_) (anyGroups ? umin32(Wmax, ff1u(__ballot(((prevL & (INSL | lanes_from(i_))) | (prevS & (INSS | lanes_from(i_)))) != 0) & lanes_from(i_))) : Wmax)
+    carry_ = 0;
+#else
     uint32_t W = ZHIP_DFW_GATHER < 64u ? ZHIP_DFW_GATHER : 64u;
     if (loseL) { uint32_t const w = first_repeat_lane(hl, loseL); if (w < W) W = w; }
     if (loseS) { uint32_t const w = first_repeat_lane(hs, loseS); if (w < W) W = w; }
@@ -189,6 +209,7 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
     // events from lanes below this: an event at lane j reads the LONG candidate of lane j+1 (:251) and inserts lane j+1 (:283), both must
     // lie below W; every other inserted lane is checked where it arises
     uint32_t const hiBound = W - 1 < ZHIP_DFW_LANES ? W - 1 : ZHIP_DFW_LANES;
+#endif
     unsigned long long const ML = __ballot(hitL), MS = __ballot(hitS), L1 = __ballot(hitL && oldL > prefixLow);   // :260 long match at ip+1: index > lowest
     uint32_t const x1 = off1_ ? cur32 ^ v1 : 1u, x2 = off2_ ? cur32 ^ v2 : 1u;
     unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
@@ -220,7 +241,7 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
             uint32_t const en = (e_) + rl;                                                                        \
             COV |= en < 64 ? ZHIP_SBFM64(rl, (e_)) : lanes_from(e_);                                              \
             (e_) = en; anchor = B + (e_); nextStep = B + (e_) + 256; fresh = true;                               \
-            if ((e_) >= W) { (leave_) = true; break; }                    /* the next test reads beyond the lanes at hand */ \
+            if ((e_) >= (ZHIP_DF_DYNCUT ? 64u : W)) { (leave_) = true; break; }     /* the next test reads beyond the lanes at hand */ \
         } } while (0)
     // a scan that leaves the collision-free lanes behind a match: the next window takes it over when there is room for one, else the caller's loads
 #define DW_LEAVE(e_, kind_, currLane_) do {                                                                       \
@@ -235,9 +256,38 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         i = e;
         if (leave) { DW_LEAVE(e, 2u, 0u); goto dw_done; }
     }
+#if ZHIP_DF_DYNCUT
+    W = DW_CUT(i);
+#endif
     for (;;) {
         // lanes searched with gap 1: those whose position + 1 stays below nextStep (:232); the entry scan may reach it inside the window
         uint32_t const kLane = (int32_t)(nextStep - B) > 64 ? 64u : ((int32_t)(nextStep - B) < 0 ? 0u : nextStep - B);
+#if ZHIP_DF_DYNCUT
+        if (i + 1 >= W && W < Wmax) W = DW_CUT(i);                           // the scan has reached the cut: where is it from here?
+        // lanes i .. hiS-1 take any event (an event at lane j reads the LONG candidate of lane j+1, :251, and inserts lane j+1, :283: j+1 < W); lane W-1 itself takes a
+        // repcode or a long match (neither looks at lane W's entries; what they insert beyond W is put in order by the winners' write at the end) but not a short one
+        uint32_t const limitLane = kLane < ZHIP_DFW_LANES ? kLane : ZHIP_DFW_LANES;
+        uint32_t const hiS = limitLane < W - 1 ? limitLane : W - 1;
+        bool const lastOK = W - 1 < limitLane && i <= W - 1;                // lane W-1 is within the gap and the lanes events are taken from
+        if (i >= hiS && !lastOK) {
+            if (i >= kLane && kLane <= ZHIP_DFW_LANES && !fresh) status = ZW_INC;    // (i == kLane: the position nextStep-1 was the last at gap 1)
+            else status = ZW_CONT;                                           // the scan (its nextStep rides along) goes on in the next window
+            break;
+        }
+        unsigned long long const span = i < hiS ? ZHIP_SBFM64(hiS - i, i) : 0ull;
+        unsigned long long const R = (E1q >> 1) & span;                      // bit l: the repcode test of iteration l (position l+1, :190) hits
+        unsigned long long any = R | ((ML | MS) & span);
+        if (any == 0) {
+            INSL |= span; INSS |= span;
+            i = hiS;
+            if (!lastOK) continue;                                           // (the exit test above decides how the scan goes on)
+            // lane W-1 (= i now): its own entries are good; a short match there would read lane W's long candidate
+            unsigned long long const bitW = 1ull << i;
+            if ((((E1q >> 1) | ML) & bitW) != 0) any = bitW;
+            else if (MS & bitW) { status = ZW_BATCH; ZWPROF_COUNT(out, 14, 1); break; }      // the batch scheme takes this one event (its lanes see each other's inserts)
+            else { INSL |= bitW; INSS |= bitW; i++; continue; }             // no event: searched and inserted like any lane; the scan now stands in front of W
+        }
+#else
         uint32_t const hiS = kLane < hiBound ? kLane : hiBound;
         if (i >= hiS) {
             if (kLane <= hiBound && i >= kLane && !fresh) status = ZW_INC;    // (i == kLane: the position nextStep-1 was the last at gap 1)
@@ -252,8 +302,9 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
             i = hiS;
             continue;                                                        // (the exit test above decides how the scan goes on)
         }
+#endif
         uint32_t const j = ff1u(any);
-        int const kind = ((R >> j) & 1) ? 1 : (((ML >> j) & 1) ? 2 : 3);
+        int const kind = (((ZHIP_DF_DYNCUT ? (E1q >> 1) : R) >> j) & 1) ? 1 : (((ML >> j) & 1) ? 2 : 3);
         {   unsigned long long const done = ZHIP_SBFM64(j + 1 - i, i);       // :187 both tables updated for every position up to the event's
             INSL |= done; INSS |= done; }
         uint32_t s, e, back = 0, offBase;
@@ -307,11 +358,11 @@ __device__ __forceinline__ int window_dfast(const uint8_t* __restrict__ src, uin
         if (back > s) { backBefore = back - s; sL = 0; }
         anchor = B + e;
         fresh = true; nextStep = B + e + 256;
-        if (e >= W || j + 2 >= W) {                                           // the scan leaves the collision-free lanes behind this match
+        if (ZHIP_DF_DYNCUT ? e >= 64 : (e >= W || j + 2 >= W)) {              // the scan leaves the window (round 5: the collision-free lanes) behind this match
             COV |= e < 64 ? ZHIP_SBFM64(e - sL, sL) : lanes_from(sL);
             DW_LEAVE(e, 1u, j);
             if (status == ZW_CARRY) {                                         // :303-307 curr+2 is a lane of this window (j <= 55); beyond W it is stored after the others
-                if (j + 2 < W) { INSL |= 1ull << (j + 2); INSS |= 1ull << (j + 2); }
+                if (ZHIP_DF_DYNCUT || j + 2 < W) { INSL |= 1ull << (j + 2); INSS |= 1ull << (j + 2); }
                 else lateLane = j + 2;
             }
             break;
@@ -329,7 +380,7 @@ dw_done:
 #undef DW_IMMEDIATE
 #undef DW_LEAVE
 #ifdef ZHIP_DBG_PRINT
-    if (lane == 0) printf("  dfwin B=%u carryIn=%u W=%u hiBound=%u -> i=%u status=%d carry=%u INSL=%llx INSS=%llx ML=%llx MS=%llx COV=%llx nbSeq=%u off=%u/%u nextStep=%u late=%u\n", B, carryIn, W, hiBound, i, status, carry_, INSL, INSS, ML, MS, COV, out.nbSeq, off1, off2, nextStep, lateLane);
+    if (lane == 0) printf("  dfwin B=%u carryIn=%u W=%u hiBound=%u -> i=%u status=%d carry=%u INSL=%llx INSS=%llx ML=%llx MS=%llx COV=%llx nbSeq=%u off=%u/%u nextStep=%u late=%u\n", B, carryIn, W, (uint32_t)(ZHIP_DF_DYNCUT ? 0u : 1u), i, status, carry_, INSL, INSS, ML, MS, COV, out.nbSeq, off1, off2, nextStep, lateLane);
 #endif
     ZWPROF_SYNC(out, 5);
     ZWPROF_COUNT(out, 11, out.nbSeq - nbSeq0);
@@ -357,9 +408,16 @@ dw_done:
             pre.tB = B;
         }
     }
+#if ZHIP_DF_DYNCUT
+    // the window's table writes: of the inserted lanes of one hash the HIGHEST writes (the reference's inserts of a window follow each other in position order), all at once
+    if (((INSL >> lane) & 1) && (gL & INSL & (lanes_from(lane) << 1)) == 0) tabL[hl] = DF_ENTRY(P, tgL);
+    if (((INSS >> lane) & 1) && (gS & INSS & (lanes_from(lane) << 1)) == 0) tabS[hs] = DF_ENTRY(P, tgS);
+#undef DW_CUT
+#else
     // the window's table writes (no two inserted lanes share a hash: they all lie below W)
     if (__builtin_amdgcn_inverse_ballot_w64(INSL)) tabL[hl] = DF_ENTRY(P, tgL);
     if (__builtin_amdgcn_inverse_ballot_w64(INSS)) tabS[hs] = DF_ENTRY(P, tgS);
+#endif
     __builtin_amdgcn_wave_barrier();
     if (lateLane < 64) {                                                     // curr+2 of a carried match: the highest position this window inserts, so it is stored last
         if (lane == lateLane) { tabL[hl] = DF_ENTRY(P, tgL); tabS[hs] = DF_ENTRY(P, tgS); }
