@@ -550,13 +550,7 @@ __device__ __forceinline__ uint32_t pull(uint32_t v, uint32_t srcLane) { return 
 #ifndef ZHIP_FAST_PRELOAD
 #define ZHIP_FAST_PRELOAD 1          /* measurement switch: 0 = every window loads its own source bytes */
 #endif
-struct FastPre { uint64_t c8; uint32_t v1, v2, B; uint64_t c8b; };        // the next window's source bytes (B = ~0: none); c8b: the 64 positions behind them (candidate prefetch)
-#ifndef ZHIP_FAST_CANDPF
-#define ZHIP_FAST_CANDPF 0           /* 1: every window also looks up the 64 positions BEHIND its own and touches their candidates' lines (a hint, never waited for) */
-#endif
-#ifndef ZHIP_FAST_PREFETCH
-#define ZHIP_FAST_PREFETCH 0         /* bytes in front of the window's base at which the source stream prefetch starts (0 = none) */
-#endif
+struct FastPre { uint64_t c8; uint32_t v1, v2, B; };        // the next window's source bytes (B = ~0: none)
 #ifndef ZHIP_FAST_WINNERS
 #define ZHIP_FAST_WINNERS 1          /* 0: every inserted lane that shares its hash with an earlier one is written on its own, in position order (round 5) */
 #endif
@@ -578,20 +572,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // the lanes' own bytes and the bytes the two repcodes point at (an invalid repcode, 0, reads the lane's own bytes): the window before this
     // one has usually requested them already (FastPre), else all three loads are in flight together
     uint64_t cur8; uint32_t v1, v2;
-    uint64_t c8b = 0;
-    if (ZHIP_FAST_PRELOAD && pre.B == B) { cur8 = pre.c8; v1 = pre.v1; v2 = pre.v2; c8b = pre.c8b; }
-    else { cur8 = ld64(src + P); v1 = ld32(src + (P - rep1_)); v2 = ld32(src + (P - rep2_));      // a repcode offset never exceeds the position it is used at
-           if (ZHIP_FAST_CANDPF) c8b = ld64(src + (P + 64 < nm8 ? P + 64 : nm8)); }
+    if (ZHIP_FAST_PRELOAD && pre.B == B) { cur8 = pre.c8; v1 = pre.v1; v2 = pre.v2; }
+    else { cur8 = ld64(src + P); v1 = ld32(src + (P - rep1_)); v2 = ld32(src + (P - rep2_)); }     // a repcode offset never exceeds the position it is used at
     pre.B = ~0u;
-#if ZHIP_FAST_PREFETCH
-    // SOURCE STREAM PREFETCH.  Where the next window starts is only known when this one's events are resolved, so its source bytes are requested
-    // at the very end (FastPre) and the wavefront then sits through that load's whole latency (the LOOP phase of profiles/r06_phases_*: 12-16 % of
-    // the stage).  The bytes are the unit's sequential stream, though: every lane touches 8 bytes further ahead now — 512 bytes = four or five lines,
-    // one request each — and the window's own work hides the HBM latency; the load at the end then finds its lines in the L2.  The value is
-    // only "used" (an empty asm) at the window's end, when it has long arrived: nothing waits for it.
-    uint32_t const pfAt = B + ZHIP_FAST_PREFETCH + 8u * lane;
-    uint32_t const pfv = ld32(src + (pfAt < nm8 ? pfAt : nm8));
-#endif
     uint32_t const cur32 = (uint32_t)cur8;
     uint32_t const h = hash_pos<MLS>(cur8, hshift);
     ZWPH(out, WPH_F_SRC);
@@ -608,14 +591,6 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     ZWPH(out, WPH_F_TAB);
     uint32_t cb = ld32(src + tab_guard(T, fetch ? old : 0u));
     if (!fetch) cb = ~cur32;
-#if ZHIP_FAST_CANDPF
-    // CANDIDATE PREFETCH.  A window waits for its candidates' bytes — 64 random lines of the unit's past, HBM latency — before it can tell its first event.  The lookups of
-    // the NEXT window are made now as well, with the table as it stands (what this window inserts may change a few entries: it is a hint, exactness is not at stake),
-    // and their candidates' lines requested; nobody waits for them (the value is "used" by an empty asm at the window's end): the next window's gather finds them in the L2.
-    uint32_t pfc;
-    {   bool m2; uint32_t const o2 = tab_get_t(T, hash_pos<MLS>(c8b, hshift), B > 65536 - 64, fast_tag15((uint32_t)c8b), m2);
-        pfc = ld32(src + tab_guard(T, (o2 != 0 && m2) ? o2 : 0u)); }
-#endif
     uint32_t backId = lane;
     if constexpr (!TabTraits<TAB>::ballotGroups) {
         __builtin_amdgcn_wave_barrier();
@@ -841,12 +816,6 @@ window_done:
 #ifdef ZHIP_DBG_PRINT
     if (lane == 0) printf("  window B=%u carry=%u -> i=%u status=%d INS=%llx NF=%llx COV=%llx nbSeq=%u rep=%u/%u anchor=%u carryOut=%u\n", B, carryIn, i, status, INS, NF, COV, out.nbSeq, rep1, rep2, anchor, carry_);
 #endif
-#if ZHIP_FAST_PREFETCH
-    asm volatile("" :: "v"(pfv));
-#endif
-#if ZHIP_FAST_CANDPF
-    asm volatile("" :: "v"(pfc));
-#endif
     if (ZHIP_FAST_PRELOAD) {
         // the next window's source bytes, requested before this window's stores; unconditional (a load inside a branch is waited for inside
         // the branch): without a next window the lanes read their own bytes again
@@ -854,7 +823,6 @@ window_done:
         uint32_t const q = (nxt ? B + i : B) + lane;
         pre.c8 = ld64(src + q);
         pre.v1 = ld32(src + (q - (nxt ? rep1 : 0u))); pre.v2 = ld32(src + (q - (nxt ? rep2 : 0u)));
-        if (ZHIP_FAST_CANDPF) pre.c8b = ld64(src + (q + 64 < nm8 ? q + 64 : nm8));
         pre.B = nxt ? B + i : ~0u;
     }
     ZWPH(out, WPH_E_PRE);
@@ -916,7 +884,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
     uint32_t carry = 0;                     // a window handed the end of its last match to the next one (see window_batch)
-    FastPre pre; pre.c8 = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u; pre.c8b = 0;
+    FastPre pre; pre.c8 = 0; pre.v1 = 0; pre.v2 = 0; pre.B = ~0u;
     bool have = false;                      // `cur` already holds the bytes of the batch that starts at ip0
     FastBatch cur; cur.bytes = 0; cur.rcur = 0; cur.rv = 0;
     for (;;) {                                                               // one turn per `_start`

@@ -23,7 +23,9 @@
 
 namespace zhip {
 
+#ifndef ZHIP_DF_SCRATCH
 #define ZHIP_DF_SCRATCH 1024u                       /* entries per scratch array */
+#endif
 __host__ __device__ inline uint32_t dfast_lds_bytes() { return 2u * ZHIP_DF_SCRATCH; }
 // bytes of table memory one unit needs (long + short, 32-bit entries)
 __host__ __device__ inline size_t dfast_table_bytes(uint32_t hashLog, uint32_t chainLog) { return ((size_t)4 << hashLog) + ((size_t)4 << chainLog); }
