@@ -690,7 +690,9 @@ def frames_leg(zstd_amd, local, host, level):
     res = {"value": round(nf * fsz / best / 1e3, 1), "unit": "MB/s", "frames": nf, "frame_bytes": fsz, "level": level,
            "kernel_ms": round(best, 3), "ratio": round(nf * fsz / sum(len(o) for o in outs), 4),
            "roofline": {"bound": "hbm", "kernel": "k_frame_fast", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(best, 3)},
+                        "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_lookup("multi_block_frames", "k_frame_fast")[0] if (nf, fsz) == (1024, 1 << 20) else None,
+                        "traffic_source": traffic_lookup("multi_block_frames", "k_frame_fast")[1] if (nf, fsz) == (1024, 1 << 20) else None,
+                        "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(best, 3)},
            "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain), two per CU; fidelity mode, never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
@@ -753,7 +755,9 @@ def job_pool_leg(zstd_amd, local, host, level):
         dec = {"error": str(e)}
     res = {"value": round(n / best / 1e3, 1), "unit": "MB/s", "frame_bytes": int(n), "jobs": jobs, "level": level, "kernel_ms": round(best, 3),
            "roofline": {"bound": "hbm", "kernel": "k_frame_fast (job table)", "achieved": round((n + len(out)) / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round((n + len(out)) / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(n + len(out)), "avg_launch_ms": round(best, 3)},
+                        "frac": round((n + len(out)) / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_lookup("job_pool_frame", "k_frame_fast")[0] if n == (1 << 30) else None,
+                        "traffic_source": traffic_lookup("job_pool_frame", "k_frame_fast")[1] if n == (1 << 30) else None,
+                        "algorithmic_bytes_per_launch": int(n + len(out)), "avg_launch_ms": round(best, 3)},
            "end_to_end": {"value": round(n / wall / 1e6, 1), "unit": "MB/s", "same_bytes": same,
                           "path": "zhip_compress_frames_mt from pageable host memory: blocking H2D, kernels, D2H on one context; PCIe-inclusive, never `value`"},
            "ratio": round(n / len(out), 4), "decode": dec,
@@ -939,7 +943,8 @@ def plugin_leg(zstd_amd, local, host, level):
             "ratio": round(n / csize, 4), "prepare_MBps": round(n / best["prepare_s"] / 1e6, 1), "reference_entropy_stage_MBps": round(n / best["compress_s"] / 1e6, 1),
             "prepare_ms": round(best["prepare_s"] * 1e3, 2), "compress_ms": round(best["compress_s"] * 1e3, 2),
             "roofline": {"bound": "hbm", "kernel": "match finder stage of zhip_prepare_sequences (k_parse_fast_q/_g)", "achieved": round(algo / (best["device_parse_ms"] * 1e-3) / 1e9, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (best["device_parse_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (best["device_parse_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": traffic_lookup("plugin_B1", "k_parse_fast")[0] if n == (1 << 30) else None, "traffic_source": traffic_lookup("plugin_B1", "k_parse_fast")[1] if n == (1 << 30) else None,
                          "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(best["device_parse_ms"], 3)},
             "parity": {"roundtrip_through_reference_decoder": bool(ok_rt), "sequences_equal_ZSTD_generateSequences_full_size": seq_eq},
             "path": "zhip_prepare_sequences (pageable H2D, match finder, one packed D2H of the sequences, host fingerprints) + ZSTD_compress2 of the real reference with "

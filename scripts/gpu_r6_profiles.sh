@@ -39,7 +39,7 @@ for leg in $LEGS; do
     datagen_L5)   run datagen_L5 $B --level 5 --mib 1024 ;;
     frames_1MiB)  run frames_1MiB $L multi_block_frames ;;
     job_pool_1GiB) run job_pool_1GiB $L job_pool_frame ;;
-    plugin_B1)    run plugin_B1 $L plugin_B1 ;;
+    plugin_B1)    run plugin_B1 python $ROOT/scripts/plugin_prepare_only.py 1024 ;;     # the leg's device part (rocprofv3 crashes under the leg's 64 reference threads)
     decode_L1)    run decode_L1 $B --level 1 --mib 1024 --mode decode ;;
   esac
 done
