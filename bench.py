@@ -48,7 +48,9 @@ def cpu_baseline(sample, seconds=8.0, level=1):
         try:
             one = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds), "1"], timeout=120))
             ncores = os.cpu_count() or 1
-            allc = json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(seconds / 2), str(ncores)], timeout=120))
+            # the all-core figure moved 2.7-9.1 GB/s between runs at level 5 (round-5 verdict): three separate processes (thread placement is decided at start), the best counts
+            allr = [json.loads(subprocess.check_output([exe, "file", str(level), str(UNIT), tmp, str(max(1.0, seconds / 4)), str(ncores)], timeout=120)) for _ in range(3)]
+            allc = max(allr, key=lambda r: r["MBps"])
             extra = {}
             if level >= 5:      # both matchers exist on the device; `value` is the reference default (row hash), the extra figure its hash-chain mode
                 env = dict(os.environ, ZREF_NOROW="1")
@@ -59,7 +61,7 @@ def cpu_baseline(sample, seconds=8.0, level=1):
             return {**extra, "value": one["MBps"], "unit": "MB/s", "cores": 1, "kind": "reference", "ratio": one["ratio"],
                     "sample": f"first {len(sample) >> 20} MiB of the workload, level {level}, {UNIT} B units, best of {one['runs']} runs "
                               f"(oracle/_ref/zref_bench = ZSTD_compress2 per unit, programs/benchzstd.c semantics)",
-                    "all_cores": {"value": allc["MBps"], "cores": ncores}}
+                    "all_cores": {"value": allc["MBps"], "cores": ncores, "best_of_processes": [r["MBps"] for r in allr]}}
         finally:
             os.unlink(tmp)
     # reference build absent: time our C restatement instead (slower than the real thing; say so)
