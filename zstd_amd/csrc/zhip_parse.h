@@ -554,6 +554,9 @@ struct FastPre { uint64_t c8; uint32_t v1, v2, B; };        // the next window's
 #ifndef ZHIP_FAST_WINNERS
 #define ZHIP_FAST_WINNERS 1          /* 0: every inserted lane that shares its hash with an earlier one is written on its own, in position order (round 5) */
 #endif
+#ifndef ZHIP_FAST_ONE_FF1
+#define ZHIP_FAST_ONE_FF1 1          /* 0: round 5's search (first match and first probe found separately, then ordered) */
+#endif
 #ifndef ZHIP_FAST_CARRY
 #define ZHIP_FAST_CARRY 1            /* measurement switch: 0 = never carry (every leaving match goes by loads), 1 = plain matches only, 2 = immediate repcodes too */
 #endif
@@ -733,6 +736,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         if (Kw <= 0) break;                                               // ZW_RESTART
         uint32_t const hiLane = i + 2u * (uint32_t)Kw;                    // searched lanes i .. hiLane-1 (<= 60), probes up to hiLane
         unsigned long long const span = ZHIP_SBFM64(hiLane - i, i);
+        unsigned long long const parity = (i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
         unsigned long long Me = M;
         uint32_t candSel = old;
         if (NF) {
@@ -745,7 +749,24 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             Me = __ballot(hit);
         }
         unsigned long long const MM = Me & span;
-        unsigned long long const parity = (i & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+#if ZHIP_FAST_ONE_FF1
+        // the repcode probes of this scan, each moved to the FIRST lane of its iteration (the probe at ip2 = l + 2 belongs to the iteration whose ip0 is lane l): one bit scan
+        // then finds the first event in the reference's order — the probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326), so at its
+        // iteration's first lane it wins the tie, and the iteration's second lane carries no probe bit.  (Resolving the hash-group state lazily, for the first candidate only,
+        // was measured on top of this and lost 3-6 %: profiles/r06_ab_fast_one_bit_scan_and_lazy_groups.log)
+        unsigned long long const RPs = ((E1q & parity) >> 2) & span;
+        unsigned long long const anyEv = MM | RPs;
+        if (anyEv == 0) {                                                 // neither
+            INS |= span;
+            i = hiLane;
+            status = (Kw == kLim) ? ZW_INC : ZW_CONT;
+            break;
+        }
+        ZWPH(out, WPH_SEARCH);
+        uint32_t const jp = ff1u(anyEv);
+        uint32_t const isRep = (uint32_t)((RPs >> jp) & 1);
+        uint32_t const j = jp + 2u * isRep;
+#else
         unsigned long long const RP = E1q & parity & (span << 2);         // the repcode probes of this scan
         uint32_t const jm = ff1u(MM), jr = ff1u(RP);
         if ((int32_t)(jm & jr) < 0) {                                     // neither
@@ -758,6 +779,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         // the repcode probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326)
         uint32_t const isRep = ((jr - i - 2) >> 1) <= ((jm - i) >> 1) ? 1u : 0u;
         uint32_t const j = isRep ? jr : jm;
+#endif
         uint32_t const c = __builtin_amdgcn_readlane(candSel, (int)j);
         uint32_t const room = B + j - anchor;
         uint32_t const limit = isRep ? 1u : (room < c - prefixLow ? room : c - prefixLow);        // :271 / :387 (match0 > prefixStart)
