@@ -2,7 +2,9 @@
 #pragma once
 #include <stdint.h>
 
-#define ZHIP_COST_SAMPLE 4096u
+#ifndef ZHIP_COST_SAMPLE
+#define ZHIP_COST_SAMPLE 1024u      /* bytes per sample of k_order_cost (four samples per unit); 4096 until round 6: the estimate orders the queue as well from a quarter of the bytes (profiles/r06_ab_fast_cost_sample.log) */
+#endif
 #define ZHIP_DICT_TICKET 8u
 #define ZHIP_XXH_WAVE_LDS (2u * 512u * 8u)
 #define ZHIP_SCAN_TILE 4096u
