@@ -653,6 +653,19 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
                "stages_of_last_call": m.last_stages()}
         del host4, dst4
     m.close()
+    # the drop-in itself: ZSTD_compress2 through libzstd_hipshim.so on the same source (what programs/benchzstd.c:344 calls).  From 256 MiB on the shim routes the call through
+    # the lanes above (round 6; the plain single-stream call before); must be within 10 % of the multi-lane figure and the same bytes
+    shim = None
+    try:
+        if len(host) % (1 << 20) == 0:
+            o = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "shim_compress2_timing.py"), str(len(host) >> 20), str(level), str(local)], timeout=120, stderr=subprocess.DEVNULL)
+            sj = json.loads([l for l in o.decode().splitlines() if l.startswith("{")][-1])
+            shim = {"value": sj["value"], "unit": "MB/s", "best_of": sj["best_of"],
+                    "same_bytes_as_multi_lane_call": bool(sj["bytes"] == k and sj["sha256"] == hashlib.sha256(multi_stream).hexdigest()),
+                    "path": "a process of its own (scripts/shim_compress2_timing.py): ZSTD_createCCtx + ZSTD_CCtx_setParameter(ZSTD_c_compressionLevel) + ZSTD_compress2 of libzstd_hipshim.so "
+                            "(include/zstd_hip_dropin.h) on the whole source; from 256 MiB on the shim runs the call on the lanes of zhip_compress_multi"}
+    except Exception as e:                                       # noqa: BLE001
+        shim = {"error": str(e)}
     ctx = zstd_amd.Context(local, max_units=units)
     best = 1e9
     got = None
@@ -668,6 +681,7 @@ def end_to_end_leg(torch, zstd_amd, local, host, total_expected, level):
             "same_bytes_as_device_path": same,
             "stages_of_last_call": stages,
             "four_times_the_source": big,
+            "dropin_ZSTD_compress2": shim,
             "path": "zhip_compress_multi on this one device: two lanes (kernel stream + copy stream, feeder / device / gatherer threads, two pinned slots each way; staging copies split over 4 host threads), 128 MB chunks with quarter "
                     "chunks at both ends: memcpy -> H2D (under the previous chunk's kernels) -> kernels -> D2H -> ordered host gather into the caller's buffer; stage seconds are summed "
                     "over chunks and lanes (they overlap); PCIe- and host-memcpy-inclusive, never `value`; the leg's process holds the library only (no torch tensors, no other context before the measurement)",
@@ -1237,6 +1251,9 @@ def make_digest(out):
     for name, _ in LEGS:
         if name in out:
             d[DIGEST_NAMES.get(name, name)] = ent(out[name])
+            sh = out[name].get("dropin_ZSTD_compress2") if isinstance(out[name], dict) else None
+            if name == "end_to_end" and isinstance(sh, dict) and "value" in sh:      # the drop-in's ZSTD_compress2 on the same source, a process of its own
+                d["shim_compress2"] = [sh["value"], None, sh.get("same_bytes_as_multi_lane_call"), None]
     if isinstance(out.get("text_strong_scaling"), dict):
         d["text1e9_strong"] = ent(out["text_strong_scaling"])
     return d

@@ -272,3 +272,29 @@ def test_row_matcher_parameter_is_not_sticky(env, monkeypatch):
     r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(small), len(small))
     assert S.ZSTD_isError(r)
     S.ZSTD_freeCCtx(c)
+
+
+def test_a_source_of_256_MiB_takes_the_lanes_and_keeps_its_bytes(env):
+    """From 256 MiB on (SHIM_LANES_MIN) ZSTD_compress2 through the shim runs on the lanes of zhip_compress_multi on the CCtx's one device (overlapped staging copies,
+    PCIe transfers and kernels) instead of the plain one-stream call: the stream must be the one a single context makes, with a destination sized by ZSTD_compressBound
+    alone, and a small source compressed by the SAME CCtx afterwards (plain path again) must still equal the reference's frame."""
+    import hashlib
+    import zstd_amd
+    S, lo, lr = env
+    n = (256 << 20) + 3 * 131072 + 777
+    a = zstd_amd.datagen(n, 50, seed=5, stream_mode=True)
+    c = S.ZSTD_createCCtx()
+    assert S.ZSTD_CCtx_setParameter(c, 100, 1) == 0
+    cap = S.ZSTD_compressBound(n)
+    dst = np.zeros(cap, dtype=np.uint8)
+    r = S.ZSTD_compress2(c, _buf(dst), cap, _buf(a), n)
+    assert not S.ZSTD_isError(r), S.ZSTD_getErrorName(r)
+    ctx = zstd_amd.Context(0, max_units=n // 131072 + 2)
+    want = ctx.compress(a, level=1)
+    ctx.close()
+    assert r == len(want) and hashlib.sha256(dst[:r].tobytes()).digest() == hashlib.sha256(want).digest()
+    small = datagen(lo, 100000, 40, 3)
+    d2 = np.zeros(S.ZSTD_compressBound(len(small)), dtype=np.uint8)
+    r2 = S.ZSTD_compress2(c, _buf(d2), len(d2), _buf(small), len(small))
+    assert not S.ZSTD_isError(r2) and d2[:r2].tobytes() == expect_unit(lo, lr, small, 1)
+    S.ZSTD_freeCCtx(c)

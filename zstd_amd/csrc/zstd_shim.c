@@ -113,13 +113,18 @@ static size_t shim_compress_cdict(ZSTD_CCtx* c, const ZSTD_CDict* cd, void* dst,
     }
 }
 
-/* $ZHIP_DEVICES: comma-separated device ordinals -> the multi-device host path (created on first use) */
-static zhip_multi* shim_multi(ZSTD_CCtx* c)
+/* $ZHIP_DEVICES: comma-separated device ordinals -> the multi-device host path (created on first use).  Without it, a source of SHIM_LANES_MIN bytes or more that is to
+ * become the frame-per-128-KB stream takes the same path on the CCtx's ONE device: its lanes overlap the staging copies, the PCIe transfers and the kernels of
+ * consecutive 128 MB chunks, where the plain call does them one after the other on one stream (1 GiB of datagen at level 1: 35 vs 8 GB/s, bench.py `end_to_end`).  The
+ * bytes are the same either way (units are independent).  Smaller sources stay on the plain call: the lanes' pinned staging is 1 GB. */
+#define SHIM_LANES_MIN ((size_t)256 << 20)
+static zhip_multi* shim_multi(ZSTD_CCtx* c, size_t srcSize)
 {
     const char* e = getenv("ZHIP_DEVICES");
     int dev[64]; int n = 0;
-    if (c->zm || !e || !*e) return c->zm;
-    while (*e && n < 64) { dev[n++] = atoi(e); while (*e && *e != ',') e++; if (*e == ',') e++; }
+    if (c->zm) return c->zm;
+    if (e && *e) { while (*e && n < 64) { dev[n++] = atoi(e); while (*e && *e != ',') e++; if (*e == ',') e++; } }
+    else if (srcSize >= SHIM_LANES_MIN && !c->singleFrame && c->workers == 0) dev[n++] = shim_device();
     if (n) c->zm = zhip_multi_create(dev, n, 0);
     return c->zm;
 }
@@ -130,7 +135,8 @@ static size_t shim_compress(ZSTD_CCtx* c, void* dst, size_t cap, const void* src
     size_t frameNeed = 0;
     if (!c) return SHIM_ERR(E_GENERIC);
     if (level == 0) level = 3;
-    if (units > 1 && shim_multi(c)) {            /* big sources: sharded over $ZHIP_DEVICES with overlapped copies; gathers straight into dst */
+    if (units > 1 && (getenv("ZHIP_DEVICES") ? 1 : (n >= SHIM_LANES_MIN && !c->singleFrame && c->workers == 0)) && shim_multi(c, n)) {
+        /* big sources: sharded over $ZHIP_DEVICES — or, from SHIM_LANES_MIN bytes on, over the lanes of the CCtx's one device — with overlapped copies; gathers straight into dst */
         zhip_multi_set_frame_checksum(c->zm, c->checksum);
         zhip_multi_set_row_matcher(c->zm, c->rowMode ? c->rowMode : -1);
         if (c->workers > 0 && n > (512u << 10)) {    /* ZSTD_c_nbWorkers: one frame, its jobs spread over the lanes */
