@@ -40,7 +40,7 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
     std::vector<uint32_t> cost(nUnits + 1), order(nUnits + 1), queue(16, 0);
     uint32_t* const pc = cost.data(); uint32_t* const po = order.data(); uint32_t* const pq = queue.data();
     simt::launch({nUnits, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_order_cost(src, units, nUnits, pc); }, osThreads);
-    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po); }, 1);
+    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(pc, nUnits, po, nullptr, 0, 0); }, 1);
     if (orderOut) for (uint32_t i = 0; i < nUnits; i++) orderOut[i] = po[i];
     uint32_t maxH = 6; for (uint32_t i = 0; i < nUnits; i++) if (units[i].hashLog > maxH) maxH = units[i].hashLog;
     uint32_t const gw = 1u << maxH, gridG = 3, gridQ = 2;

@@ -26,7 +26,9 @@ namespace zhip {
 
 // Stage 1: one wavefront (= one 64-thread workgroup) per unit.  Dynamic LDS = fast_lds_bytes(hashLog).
 #ifndef ZHIP_FAST_OCC
-#define ZHIP_FAST_OCC __attribute__((amdgpu_waves_per_eu(3)))      /* <= 170 VGPRs: the LDS table admits eight units per CU (nine before the tag plane) = at most three on one of the four SIMDs (left alone the compiler has chosen anything from 141 to 248) */
+#define ZHIP_FAST_OCC __attribute__((amdgpu_waves_per_eu(4)))      /* 128 VGPRs (round 6: the window's state was cut to fit them — repcode state as two XOR words instead of four masks, the sequences stored as they are found,
+                                                                      no deferred literal chunk, the schedule's lane offsets recomputed — 130-135 without the cap, 48 bytes of scratch with it): four wavefronts per SIMD = sixteen per CU,
+                                                                      eight on LDS tables and up to eight on global ones.  Round 5's 152 registers held three. */
 #endif
 __global__ void __launch_bounds__(64) ZHIP_FAST_OCC
 k_parse_fast(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
@@ -61,7 +63,7 @@ __device__ __forceinline__ uint32_t queue_take(uint32_t* queue)
     return __builtin_amdgcn_readfirstlane(t);
 }
 #ifndef ZHIP_FASTG_OCC
-#define ZHIP_FASTG_OCC
+#define ZHIP_FASTG_OCC __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 __global__ void __launch_bounds__(64) ZHIP_FAST_OCC
 k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
@@ -95,6 +97,8 @@ k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ uni
                const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t* __restrict__ gtabs, uint32_t gtabWords)
 {
     uint32_t* const gtab = gtabs + (size_t)blockIdx.x * gtabWords;
+    {   uint32_t const lim = __builtin_amdgcn_readfirstlane(queue[1]);       // k_order_sort's decision: the workgroups from `lim` on stay out (0: no limit)
+        if (lim && blockIdx.x >= lim) return; }
     for (;;) {
         uint32_t const t = queue_take(queue);
         if (t >= nUnits) return;
@@ -120,16 +124,25 @@ k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ uni
 // Dispatch order for the queue kernels: units sorted by descending cost (a counting sort over 2 048 cost classes, one workgroup).
 // cost: mode 2 = the sequence count the previous call left in metas[] (measurement only: the upper bound an estimator can reach),
 // mode 1 = k_order_cost's estimate.
+// It also decides how many global-table wavefronts join the queue (round 6): `gLimit` (the queue's second word, read by k_parse_fast_g; 0 = all that
+// were launched) is set to `gSparse` when the batch's mean estimated cost is below `denseCost` — a batch with few sequences per unit spends its time in
+// table gathers, and more than six global tables per CU then miss the L2 (datagen: +8 % with eight), a dense one spends it in the event loop and takes
+// all eight (Silesia-shaped -5 %, text -4 % against six; profiles/r06_ab_fast_128_registers.log).  nullptr: no decision.
 __global__ void __launch_bounds__(1024)
-k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order)
+k_order_sort(const uint32_t* __restrict__ cost, uint32_t nUnits, uint32_t* __restrict__ order, uint32_t* __restrict__ gLimit, uint32_t gSparse, uint32_t denseCost)
 {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t part[1024];
+    __shared__ unsigned long long costSum;
     uint32_t const tid = threadIdx.x;
     hist[tid] = 0; hist[tid + 1024] = 0;
+    if (tid == 0) costSum = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const b = cost[i] >> 4; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
+    unsigned long long mine = 0;
+    for (uint32_t i = tid; i < nUnits; i += 1024) { uint32_t const cst = cost[i], b = cst >> 4; mine += cst; atomicAdd(&hist[2047u - (b < 2047u ? b : 2047u)], 1u); }
+    if (gLimit) atomicAdd(&costSum, mine);
     __syncthreads();
+    if (gLimit && tid == 0 && costSum < (unsigned long long)denseCost * nUnits) *gLimit = gSparse;
     // exclusive prefix over the classes (class 0 = the most expensive): two classes per thread, then a scan of the pair sums
     uint32_t const a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
     part[tid] = a0 + a1;

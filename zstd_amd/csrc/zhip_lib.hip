@@ -48,7 +48,13 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #define ZHIP_DICT_GWAVES_DEFAULT 16
 #endif
 #ifndef ZHIP_FAST_GWAVES_DEFAULT
-#define ZHIP_FAST_GWAVES_DEFAULT 4
+#define ZHIP_FAST_GWAVES_DEFAULT 8      /* round 6: both kernels fit 128 registers = 16 wavefronts per CU, eight of them on the LDS tables */
+#endif
+#ifndef ZHIP_FAST_GWAVES_SPARSE
+#define ZHIP_FAST_GWAVES_SPARSE 6       /* the global-table wavefronts per CU a batch of few sequences per unit gets (k_order_sort decides on the device) */
+#endif
+#ifndef ZHIP_FAST_DENSE_COST
+#define ZHIP_FAST_DENSE_COST 4000u      /* mean k_order_cost estimate (sequences + bytes / 128) from which a batch counts as dense: datagen -P50 ~ 1 900, Silesia-shaped ~ 6 500, text ~ 11 900 */
 #endif
 struct zhip_ctx_s {
     int device;
@@ -524,7 +530,11 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         if (wantOrder) {
             if (c->fastOrder == 2) hipLaunchKernelGGL(zhip::k_order_cost_stale, dim3((unsigned)((nUnits + 255) / 256)), dim3(256), 0, s, c->dParse, (uint32_t)nUnits, c->dCost);
             else hipLaunchKernelGGL(zhip::k_order_cost, dim3((unsigned)nUnits), dim3(64), 0, s, srcDev, c->dUnits, (uint32_t)nUnits, c->dCost);
-            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder);
+            // (the sort also sets the queue's second word: how many of the global-table workgroups take part, by the batch's mean cost)
+            size_t const gSparse = ((size_t)ZHIP_FAST_GWAVES_SPARSE * (size_t)c->numCUs + share - 1) / share;
+            bool const decide = c->fastOrder == 1 && c->fastGWaves > ZHIP_FAST_GWAVES_SPARSE && gridG > gSparse;
+            hipLaunchKernelGGL(zhip::k_order_sort, dim3(1), dim3(1024), 0, s, c->dCost, (uint32_t)nUnits, c->dOrder,
+                               decide ? c->dQueue + 1 : (uint32_t*)nullptr, (uint32_t)gSparse, ZHIP_FAST_DENSE_COST);
             order = c->dOrder;
         }
         uint32_t const gtabWords = 1u << maxHashLog;

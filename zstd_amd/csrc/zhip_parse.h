@@ -371,6 +371,19 @@ __device__ __forceinline__ void lits_copy(FastOut& o, const uint8_t* src, uint32
     o.litPos += len;
 }
 
+// the same copy without the deferred first chunk: the ZSTD_fast parser (round 6) gives up that trick — three vector registers held through every window for the sake of the
+// schedule-shaped batches' events — to fit 128 registers (a fourth wavefront per SIMD).  Like the reference's wildcopy the last 8-byte chunk of a run may spill up to 7 bytes past it.
+__device__ __forceinline__ void lits_copy_now(FastOut& o, const uint8_t* src, uint32_t nm8, uint32_t from, uint32_t len)
+{
+    uint32_t const lane8 = 8u * (uint32_t)lane_id();
+    for (uint32_t off = 0; off < len; off += 512) {
+        uint32_t const q = from + off + lane8, qc = q < nm8 ? q : nm8, sh = q - qc;
+        if (off + lane8 < len) st64(o.lits + o.litPos + off + lane8, ld64(src + qc) >> (8 * (sh & 7)));
+    }
+    o.litPos += len;
+    __builtin_amdgcn_wave_barrier();        // later runs overwrite this run's spill: keep the stores in program order
+}
+
 __device__ __forceinline__ void store_seq(FastOut& o, uint32_t litLength, uint32_t offBase, uint32_t matchLength)
 {   // zstd_compress_internal.h:671-728 minus the literal copy (literals are gathered by the entropy kernel)
     uint32_t const mlBase = matchLength - 3;
@@ -571,7 +584,6 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     uint32_t const carryIn = carry_;                                      // 1: the previous window's last match ended at B+2 (lanes 0, 1 belong to it); 2: it ended at B, the immediate-repcode test is due
     carry_ = 0;
     if (carryIn == 1) nextStep += 2;                                      // the scan starts at B+2
-    if (out.pendLen) lits_flush(out);                                     // an earlier run's deferred store (and its spill) goes first
     // the lanes' own bytes and the bytes the two repcodes point at (an invalid repcode, 0, reads the lane's own bytes): the window before this
     // one has usually requested them already (FastPre), else all three loads are in flight together
     uint64_t cur8; uint32_t v1, v2;
@@ -614,7 +626,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     // SECOND sharing lane (round-2 start) held its windows to 35 of 60 lanes on average.
     unsigned long long NF = 0;
     unsigned long long DEEP = lanes_from(ZHIP_WIN_LANES);      // lanes that cannot be searched from this window: >= 60, or beyond what the group data resolves
-    uint32_t p1 = 0, p2 = 0, m1 = 0, m2 = 0, depth = 0;
+    uint32_t grp = 0;                                          // this lane's two closest earlier group members and what they say: p1 | p2 << 6 | m1 << 12 | m2 << 13 | (depth >= 1) << 14 | (depth >= 2) << 15 (one register, held through the event loop)
     unsigned long long myG = 0;                                // the lanes of this lane's hash group (0: none, or a group the loop below did not get to)
     {
         if constexpr (TabTraits<TAB>::ballotGroups) {
@@ -636,13 +648,14 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         }
         if (NF) {
             unsigned long long const prev = myG & lanes_below(lane);
-            depth = (uint32_t)__builtin_popcountll(prev);
-            p1 = prev ? 63u - (uint32_t)__clzll((long long)prev) : 0u;
+            uint32_t const depth = (uint32_t)__builtin_popcountll(prev);
+            uint32_t const p1 = prev ? 63u - (uint32_t)__clzll((long long)prev) : 0u;
             unsigned long long const prev2 = prev & ~(1ull << p1);
-            p2 = prev2 ? 63u - (uint32_t)__clzll((long long)prev2) : 0u;
+            uint32_t const p2 = prev2 ? 63u - (uint32_t)__clzll((long long)prev2) : 0u;
             uint32_t const c1 = __shfl(cur32, (int)p1), c2 = __shfl(cur32, (int)p2);
-            m1 = (depth >= 1 && c1 == cur32) ? 1u : 0u;
-            m2 = (depth >= 2 && c2 == cur32) ? 1u : 0u;
+            uint32_t const m1 = (depth >= 1 && c1 == cur32) ? 1u : 0u;
+            uint32_t const m2 = (depth >= 2 && c2 == cur32) ? 1u : 0u;
+            grp = p1 | (p2 << 6) | (m1 << 12) | (m2 << 13) | ((depth >= 1 ? 1u : 0u) << 14) | ((depth >= 2 ? 1u : 0u) << 15);
             DEEP |= __ballot(depth >= 3);
             ZWPH(out, WPH_GRP_NF);
         }
@@ -650,11 +663,14 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
     ZWPH(out, WPH_F_GRP);
     bool const hitOld = old != 0 && old >= prefixLow && cb == cur32;
     unsigned long long const M = __ballot(hitOld);
-    uint32_t const x1 = rep1_ ? cur32 ^ v1 : 1u, x2 = rep2_ ? cur32 ^ v2 : 1u;
+    // x1 / x2: the lane's 4 bytes XOR the 4 bytes rep1 / rep2 back (1: no such repcode).  They ARE the state the event loop carries for the two repcode offsets — one
+    // vector register each; the masks of round 5 (which lanes equal the byte / the 4 bytes that offset back: four 64-bit masks = eight registers in this loop, whose control
+    // flow is lane-divergent for the compiler, plus four register-pair copies at every offset change) are one v_cmp away wherever they are used (ZW_Eq / ZW_Eb)
+    uint32_t x1 = rep1_ ? cur32 ^ v1 : 1u, x2 = rep2_ ? cur32 ^ v2 : 1u;
+#define ZW_Eq(x_) __ballot((x_) == 0)
+#define ZW_Eb(x_) __ballot(((x_) & 0xFFu) == 0)
 
-    uint32_t const nbSeq0 = out.nbSeq;
     uint32_t const anchorEntry = anchor_;
-    uint32_t evA = 0, evB = 0, nEv = ~0u;                                 // event registers: sequence t of this window in lane t
     unsigned long long INS = 0, COV = 0;
     uint32_t anchor = anchor_, rep1 = rep1_, rep2 = rep2_, backBefore = 0, sumLit = 0, i = 0;
     int status = ZW_RESTART;
@@ -662,8 +678,8 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         if (((ll) | mb_) > 0xFFFF) {                                                                              \
             if ((ll) > 0xFFFF) { out.longType = 1; out.longPos = out.nbSeq; }                                     \
             if (mb_ > 0xFFFF) { out.longType = 2; out.longPos = out.nbSeq; } }                                    \
-        uint32_t const slot_ = out.nbSeq - nbSeq0;                                                                \
-        evA = ZHIP_WRITELANE((ob), slot_, evA); evB = ZHIP_WRITELANE(((ll) & 0xFFFFu) | (mb_ << 16), slot_, evB); \
+        /* stored as it is found (round 5 collected a window's sequences in two registers, lane t = sequence t, and stored them at its end: two registers held through the loop) */ \
+        if (lane == 0) { ZhipSeq q_; q_.offBase = (ob); q_.litLength = (uint16_t)(ll); q_.mlBase = (uint16_t)mb_; out.seqs[out.nbSeq] = q_; }                                  \
         out.nbSeq++; } while (0)
     // the window's table writes.  Lanes of one hash share a slot and the reference leaves the LAST inserted one there: every lane that knows its group (myG) checks that no
     // higher member is inserted too, and all such winners write together.  Only inserted lanes of a group the front did not resolve (beyond ZHIP_WIN_GROUPS) go one by one,
@@ -680,29 +696,26 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         __builtin_amdgcn_wave_barrier();                                                                          \
         while (late_) { if (lane == ff1u(late_)) tab_put_t(T, h, P, myTag); late_ &= late_ - 1; __builtin_amdgcn_wave_barrier(); ZWPH(out, WPH_LATE); } \
         INS = 0; } while (0)
-    unsigned long long E1q = __ballot(x1 == 0), E1b = __ballot((x1 & 0xFFu) == 0);
-    unsigned long long E2q = __ballot(x2 == 0), E2b = __ballot((x2 & 0xFFu) == 0);
     ZWPH(out, WPH_F_MASK);
     // inserts: INS collects the inserted lanes; the lanes of NF among them (only single inserts can be) are written
     // one by one after the others, in position order (a later member of a hash group overwrites an earlier one)
     int kLim;                                                             // iterations before the gap grows (:342-346), entry scan only
     // :410-420 at lane e_; leaves e_ at the end of the last immediate repcode
 #define ZW_IMMEDIATE(e_) do {                                                                                    \
-        uint32_t const rl = 4 + fwd_run(src, nm8, B, E2b, (e_) + 4, rep2);                                         \
+        uint32_t const rl = 4 + fwd_run(src, nm8, B, ZW_Eb(x2), (e_) + 4, rep2);                                   \
         {   uint32_t const t = rep2; rep2 = rep1; rep1 = t; }                                                      \
-        {   unsigned long long t = E2q; E2q = E1q; E1q = t; t = E2b; E2b = E1b; E1b = t; }                         \
+        {   uint32_t const t = x2; x2 = x1; x1 = t; }                                                              \
         INS |= 1ull << (e_);                                                                                       \
         ZW_EMIT(0u, 1u, rl);                                                                                       \
         uint32_t const en = (e_) + rl;                                                                             \
         COV |= en < 64 ? (lanes_from(e_) & lanes_below(en)) : lanes_from(e_);                                      \
-        (e_) = en; anchor = B + (e_); ZWPH(out, WPH_IMM); } while ((e_) < 64 && ((E2q >> (e_)) & 1))
+        (e_) = en; anchor = B + (e_); ZWPH(out, WPH_IMM); } while ((e_) < 64 && ((ZW_Eq(x2) >> (e_)) & 1))
     // the scan left the window behind a match that ended at lane e_ (>= 64; anchor = B + e_): the next window takes it over (kind_ 1: it
     // starts at the end - 2 and inserts that position, 2: at the end of an immediate repcode), or — no room for a window — :403-420 go by loads
 #define ZW_LEAVE(e_, kind_, cur0_) do {                                                                          \
         if (ZHIP_FAST_CARRY >= (kind_) && B + (e_) - ((kind_) == 1 ? 2u : 0u) + ZHIP_WIN_NEED <= n) {              \
             i = (e_) - ((kind_) == 1 ? 2u : 0u); carry_ = (kind_);                                                 \
         } else {                                                                                                   \
-            nEv = out.nbSeq - nbSeq0;                                                                              \
             ZW_TABLE_FLUSH();                                                                                      \
             uint32_t ip0n = anchor;                                                                                \
             if (ip0n <= nm8) {                                                                                     \
@@ -717,7 +730,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         // carry 1: lanes 0 and 1 are the last two bytes of the previous window's last match: its second complementary insert (:408) is lane 0,
         // its immediate-repcode test (:410) is lane 2; carry 2: the test is lane 0.  The front loaded exact masks for the repcodes that match left
         if (carryIn == 1) { INS = 1ull; i = 2; }                     // (lanes 0, 1 are not literals: masked out at the end, they lie in front of the anchor)
-        if (rep2 && ((E2q >> i) & 1)) {
+        if (rep2 && ((ZW_Eq(x2) >> i) & 1)) {
             uint32_t e = i;
             ZW_IMMEDIATE(e);
             i = e; nextStep = B + e + 128;
@@ -743,8 +756,9 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
             // a member of a hash group is inserted when the scan from i reaches it before the lane in question (every lane from i on
             // is, as long as no event intervenes — and the first event is what is being looked for), or when INS already holds it
             unsigned long long const insE = INS | lanes_from(i);
-            bool const in1 = depth >= 1 && ((insE >> p1) & 1), in2 = depth >= 2 && ((insE >> p2) & 1);
-            bool const hit = in1 ? (m1 != 0) : (in2 ? (m2 != 0) : hitOld);
+            uint32_t const p1 = grp & 63u, p2 = (grp >> 6) & 63u;
+            bool const in1 = ((grp >> 14) & 1) && ((insE >> p1) & 1), in2 = ((grp >> 15) & 1) && ((insE >> p2) & 1);
+            bool const hit = in1 ? ((grp >> 12) & 1) != 0 : (in2 ? ((grp >> 13) & 1) != 0 : hitOld);
             candSel = in1 ? B + p1 : (in2 ? B + p2 : old);
             Me = __ballot(hit);
         }
@@ -754,7 +768,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         // then finds the first event in the reference's order — the probe of an iteration comes before its two matches (:268-290, then :292-299 / :317-326), so at its
         // iteration's first lane it wins the tie, and the iteration's second lane carries no probe bit.  (Resolving the hash-group state lazily, for the first candidate only,
         // was measured on top of this and lost 3-6 %: profiles/r06_ab_fast_one_bit_scan_and_lazy_groups.log)
-        unsigned long long const RPs = ((E1q & parity) >> 2) & span;
+        unsigned long long const RPs = ((ZW_Eq(x1) & parity) >> 2) & span;
         unsigned long long const anyEv = MM | RPs;
         if (anyEv == 0) {                                                 // neither
             INS |= span;
@@ -767,7 +781,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         uint32_t const isRep = (uint32_t)((RPs >> jp) & 1);
         uint32_t const j = jp + 2u * isRep;
 #else
-        unsigned long long const RP = E1q & parity & (span << 2);         // the repcode probes of this scan
+        unsigned long long const RP = ZW_Eq(x1) & parity & (span << 2);   // the repcode probes of this scan
         uint32_t const jm = ff1u(MM), jr = ff1u(RP);
         if ((int32_t)(jm & jr) < 0) {                                     // neither
             INS |= span;
@@ -789,11 +803,11 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         INS |= ZHIP_SBFM64(j + 1 - isRep - i, i);
         if (!isRep) {
             INS |= 1ull << (j + 1);
-            rep2 = rep1; E2q = E1q; E2b = E1b; rep1 = off;
-            uint32_t x = 1;
-            if (P >= off) x = cur32 ^ ld32(src + (P - off));
-            E1q = __ballot(x == 0); E1b = __ballot((x & 0xFFu) == 0);
+            rep2 = rep1; x2 = x1; rep1 = off;
+            x1 = 1;
+            if (P >= off) x1 = cur32 ^ ld32(src + (P - off));
         }
+        unsigned long long const E1b = ZW_Eb(x1);
         ZWPH(out, WPH_M_ELOAD);
         uint32_t run = 0;
         if (j) {
@@ -822,7 +836,7 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
         }
         COV |= ZHIP_SBFM64(e - sL, sL);
         INS |= (1ull << (cur0L + 2)) | (1ull << (e - 2));                 // :407-408 (ip0 <= ilimit inside a window)
-        if (rep2 && ((E2q >> e) & 1)) {                                   // :410-420
+        if (rep2 && ((ZW_Eq(x2) >> e) & 1)) {                             // :410-420
             ZW_IMMEDIATE(e);
             if (e >= 64) { ZW_LEAVE(e, 2u, 0u); break; }
         }
@@ -833,6 +847,8 @@ __device__ __forceinline__ int window_batch(const uint8_t* __restrict__ src, uin
 window_done:
 #undef ZW_IMMEDIATE
 #undef ZW_LEAVE
+#undef ZW_Eq
+#undef ZW_Eb
     ZWPH(out, WPH_SEARCH);
 #undef ZW_EMIT
 #ifdef ZHIP_DBG_PRINT
@@ -851,12 +867,6 @@ window_done:
     ZW_TABLE_FLUSH();
     ZWPH(out, WPH_E_TAB);
 #undef ZW_TABLE_FLUSH
-    // its sequences
-    if (nEv == ~0u) nEv = out.nbSeq - nbSeq0;
-    if (lane < nEv) {
-        ZhipSeq q; q.offBase = evA; q.litLength = (uint16_t)evB; q.mlBase = (uint16_t)(evB >> 16);
-        out.seqs[nbSeq0 + lane] = q;
-    }
     {   // its literals: the lanes behind the new scan position that no match covers (the tail after the last match is
         // tentative: a later backward extension may take it back, its bytes are then simply overwritten)
         unsigned long long LIT = i < 64 ? (~COV & lanes_below(i)) : ~COV;
@@ -902,7 +912,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     int32_t const ilimit = (int32_t)nm8;
     uint32_t ip0 = b0 + (b0 == prefixLow);                                   // :238 ip0 += (ip0 == prefixStart)
     if (ip0 != b0 && lane == 0) lits[0] = src[b0];                           // that position is never searched: windows only store their own lanes
-    uint32_t startPosOff, startRposOff; batch_offsets(stepSize, stepSize, startPosOff, startRposOff);
+    // (the schedule's lane offsets are recomputed where a batch needs them — six instructions — instead of riding through every window in two registers)
     unsigned long long const evenLanes = 0x5555555555555555ull;
 
     uint32_t carry = 0;                     // a window handed the end of its last match to the next one (see window_batch)
@@ -912,7 +922,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
     for (;;) {                                                               // one turn per `_start`
         uint32_t step = stepSize, g0 = stepSize, nextStep = ip0 + 128;
         if ((int32_t)(ip0 + g0 + 1) >= ilimit) break;                        // :257
-        uint32_t posOff = startPosOff, rposOff = startRposOff;
+        uint32_t posOff = 0, rposOff = 0; bool haveOffs = false;
 
         // ---- scan until an event or the end of the unit: windows while the gap is 2, schedule-shaped batches otherwise
         int evKind = 0;                      // 0 none (unit finished), 1 match, 2 repcode, 3 the window handled its events
@@ -925,10 +935,11 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
                 int const st = window_batch<MLS, TAB>(src, n, nm8, hshift, T, out, ip0, anchor, rep1, rep2, nextStep, prefixLow, carry, pre);
                 have = false;
                 if (st == ZW_RESTART) { evKind = 3; break; }
-                if (st == ZW_INC) { step = 3; nextStep += 128; batch_offsets(g0, step, posOff, rposOff); }
+                if (st == ZW_INC) { step = 3; nextStep += 128; batch_offsets(g0, step, posOff, rposOff); haveOffs = true; }
                 if (ZHIP_WIN_DENSE_ONLY) dense = false;
                 continue;
             }
+            if (!haveOffs) { batch_offsets(g0, step, posOff, rposOff); haveOffs = true; }
             if (!have) cur = batch_load(src, nm8, ip0, posOff, rposOff, rep1);
             have = false; pre.B = ~0u;
             // iterations this batch covers: iteration k+1 runs iff A_{k+2}+1 < ilimit (:347); the gap grows after the
@@ -1060,7 +1071,7 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
         wave_extend(src, nm8, mpos, cand0, lim, backLen, fwdLen);
         ip0 = mpos - backLen;
         {   uint32_t const mLength = 4 + backLen + fwdLen;
-            lits_copy(out, src, nm8, anchor, ip0 - anchor);
+            lits_copy_now(out, src, nm8, anchor, ip0 - anchor);
             store_seq(out, ip0 - anchor, offBase, mLength);
             ip0 += mLength; anchor = ip0;
         }
@@ -1068,11 +1079,17 @@ __device__ inline void parse_fast_block(const uint8_t* __restrict__ src, uint32_
         // ---- :403-420 complementary inserts + immediate repcode; the next batch's bytes ride along
         have = false;
         if ((int32_t)ip0 <= ilimit)
-            have = post_match<MLS, true, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, startPosOff, startRposOff, cur);
+        {   // the next batch's bytes ride along with the post-match round only when a batch can follow: behind a match the gap is stepSize again, and with stepSize 2 a WINDOW
+            // takes over (it loads its own bytes), so `cur` is not kept alive through the windows for nothing
+            if (stepSize == 2) have = post_match<MLS, false, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, 0, 0, cur);
+            else {
+                uint32_t sp, sr; batch_offsets(stepSize, stepSize, sp, sr);
+                have = post_match<MLS, true, TAB>(src, nm8, hshift, T, out, ip0, anchor, rep1, rep2, cur0, true, sp, sr, cur);
+            }
+        }
         ZWPH(out, WPH_B_POST);
     }
-    lits_copy(out, src, nm8, anchor, n - anchor);                           // trailing literals (zstd_compress.c:3365)
-    lits_flush(out);
+    lits_copy_now(out, src, nm8, anchor, n - anchor);                       // trailing literals (zstd_compress.c:3365)
     } else {
         for (uint32_t i = lane; i < n - b0; i += 64) lits[i] = src[b0 + i]; // tiny block: everything is a literal
         out.litPos = n - b0;
