@@ -22,10 +22,16 @@ gen = {
     "datagen": lambda: zstd_amd.datagen(n, 50, seed=0, stream_mode=True),
     "text": lambda: W.tile(W.text_corpus(64 << 20, seed=0), n),
     "silesia": lambda: W.tile(W.silesia_like(lambda size, P, seed: zstd_amd.datagen(size, P, seed=seed, stream_mode=False), seed=0), n),
+    # the bench's own leg (bench.py --workload silesia --copies 4): 4 copies of the mix, 6 468 units — not a whole number of rounds of the resident wavefronts
+    "silesia4": lambda: np.tile(W.silesia_like(lambda size, P, seed: zstd_amd.datagen(size, P, seed=seed, stream_mode=False), seed=0), 4),
+    "text1e9": lambda: W.tile(W.text_corpus(64 << 20, seed=0), 1000000000),
 }
+nmax = n
 for name in shapes:
+    n = nmax
     host = np.ascontiguousarray(gen[name]())
-    src = torch.empty(n + 64, dtype=torch.uint8, device=dev); src[:n].copy_(torch.from_numpy(host))
+    n = min(len(host), nmax)                                    # (the generators read `n`: every shape starts from the asked size)
+    src = torch.empty(n + 64, dtype=torch.uint8, device=dev); src[:n].copy_(torch.from_numpy(host[:n]))
     best = None
     for _ in range(4):
         r = ctx.compress_device(dst.data_ptr(), cap, src.data_ptr(), n, level, 131072)

@@ -62,6 +62,20 @@ __device__ __forceinline__ uint32_t queue_take(uint32_t* queue)
     if ((threadIdx.x & 63) == 0) t = atomicAdd(queue, 1u);
     return __builtin_amdgcn_readfirstlane(t);
 }
+// Issue priority by rank (round 6).  With the heaviest units first, a batch that is only one or two rounds of the resident wavefronts deep takes as long as its
+// heaviest unit takes on a CU it shares with fifteen others (Silesia-shaped x4: 6 468 units on 4 096 slots — the 128-register parser gained nothing there although
+// 8 192 units of the same mix gained 18 %).  The first tickets therefore run at a higher s_setprio: about one wavefront per SIMD at 3, one more at 2, two more at 1.
+#ifndef ZHIP_FAST_PRIO
+#define ZHIP_FAST_PRIO 1
+#endif
+__device__ __forceinline__ void queue_prio(uint32_t t, bool ranked)
+{
+    if (!ZHIP_FAST_PRIO) return;
+    if (!ranked || t >= 4096u) __builtin_amdgcn_s_setprio(0);
+    else if (t < 1024u) __builtin_amdgcn_s_setprio(3);
+    else if (t < 2048u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+}
 #ifndef ZHIP_FASTG_OCC
 #define ZHIP_FASTG_OCC __attribute__((amdgpu_waves_per_eu(4)))
 #endif
@@ -77,6 +91,7 @@ k_parse_fast_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ uni
         uint32_t const ui = order ? order[t] : t;
         ZhipUnit const u = units[ui];
         if (u.strategy != ZHIP_STRAT_FAST) continue;
+        queue_prio(t, order != nullptr);
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
@@ -105,6 +120,7 @@ k_parse_fast_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ uni
         uint32_t const ui = order ? order[t] : t;
         ZhipUnit const u = units[ui];
         if (u.strategy != ZHIP_STRAT_FAST) continue;
+        queue_prio(t, order != nullptr);
         const uint8_t* const p = src + u.srcOff;
         ZhipSlot const sl = slots[ui];
         ZhipSeq* const sq = seqs + sl.seqOff;
