@@ -15,7 +15,7 @@
 #define ZHIP_LAZY_OCC
 #endif
 #ifndef ZHIP_ENT_OCC
-#define ZHIP_ENT_OCC __attribute__((amdgpu_waves_per_eu(8)))     /* 64 VGPRs: the eight workgroups per CU the 18.5 KB of LDS admit (74 registers held six); A/B profiles/r06_ab_entropy_occupancy.log: datagen 2.07 -> 2.00 ms, text 3.28 -> 3.11, Silesia-shaped 3.04 -> 2.96 per GiB */
+#define ZHIP_ENT_OCC
 #endif
 
 namespace zhip {
