@@ -20,7 +20,9 @@
 namespace zhip {
 
 #define ZHIP_FRAME_BLOCK_SPLIT   (92u * 1024u)     /* zstd_compress.c:4517 "blind" split of the strategies below lazy2 */
+#ifndef ZHIP_FRAME_LDS_HASHLOG
 #define ZHIP_FRAME_LDS_HASHLOG   14u               /* tables up to 64 KB live in LDS */
+#endif
 
 struct FrameShared {
     ZhipParse meta;            // the parser's result for the block in flight

@@ -34,7 +34,8 @@ __device__ __forceinline__ void frame_kernel_body(const uint8_t* __restrict__ sr
     FrameShared* const fs = (FrameShared*)(smem + shBytes);
     // a job's positions count from the start of its window (the prefix in front of its section), a frame's from the frame start
     const ZhipJob* const job = jobs ? jobs + fi : (const ZhipJob*)nullptr;
-    uint32_t const mode = frame_table_mode(u.strategy, u.hashLog, (uint64_t)u.srcLen + (job ? job->prefixLen + 1u : 0u));
+    // (the four-per-CU variant keeps every table in HBM, also the ones that would fit LDS: the host launches it for batches of more workgroups than the LDS form holds at once)
+    uint32_t const mode = OCC == 4 ? (uint32_t)ZHIP_FT_HBM : frame_table_mode(u.strategy, u.hashLog, (uint64_t)u.srcLen + (job ? job->prefixLen + 1u : 0u));
     unsigned char* const ltab = smem + shBytes + sizeof(FrameShared);
     WideTab T; Lds24Tab T24;
     T.w = mode == ZHIP_FT_HBM ? tabs + (size_t)fi * tabStride : (uint32_t*)ltab;

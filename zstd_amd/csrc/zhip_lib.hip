@@ -813,6 +813,16 @@ static size_t compress_host_locked(zhip_ctx* c, void* dst, size_t dstCapacity, c
 // compressed by its own workgroup with the overlap in front of it as prefix, and the concatenation is the frame the reference's
 // worker pool emits (it does not depend on the number of workers).  A unit of the launch is then a job, not a frame.
 struct MtParams { bool on; unsigned long long jobSize; int overlapLog; };
+// ZSTD_fast frames whose table fits LDS run two workgroups per CU (k_frame_fast); a batch of more workgroups than that holds at once goes to the all-HBM form instead — four per
+// CU, each parser somewhat slower on its table in L2 / HBM, half as many rounds (round 6, profiles/r06_ab_frames_hbm_tables.log: 1 024 frames of 1 MiB, datagen 45.5 -> 39.9 ms,
+// text 191.7 -> 121.4 ms; 256 frames: 20.5 vs 26.2 ms the other way).  tabWordsAll = the largest table of the batch's ZSTD_fast / ZSTD_dfast workgroups.
+static void frames_prefer_hbm(const zhip_ctx* c, size_t nU, uint32_t& ldsTab, size_t& tabWords, size_t tabWordsAll)
+{
+    if (!ldsTab || nU <= (size_t)2 * (size_t)c->numCUs) return;
+    if (nU * tabWordsAll * sizeof(uint32_t) > ((size_t)2 << 30)) return;          // (tables are per workgroup, not per resident workgroup, in the frame kernels)
+    ldsTab = 0;
+    if (tabWordsAll > tabWords) tabWords = tabWordsAll;
+}
 static size_t frames_run_locked(zhip_ctx* c, void* dstDev, const void* srcDev, size_t nU, size_t nFrames, uint32_t ldsTab, size_t tabWords,
                                 size_t outBytes, unsigned long long totalSrc, bool withJobs, uint32_t* frameSizesDev, hipStream_t s);
 static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity, const void* srcDev, const unsigned long long* offs,
@@ -821,7 +831,7 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
     if (nFrames == 0) return ZERR(ZE_srcSize_wrong);
     if (nFrames > c->maxUnits) { snprintf(c->err, sizeof(c->err), "%zu frames > context capacity %zu", nFrames, c->maxUnits); return ZERR(ZE_srcSize_wrong); }
     const unsigned* const ov = c->haveOvr ? c->ovr : nullptr;
-    size_t bound = 0, outBytes = 0, tabWords = 0, nU = 0; uint32_t ldsTab = 0; unsigned long long totalSrc = 0;
+    size_t bound = 0, outBytes = 0, tabWords = 0, tabWordsAll = 0, nU = 0; uint32_t ldsTab = 0; unsigned long long totalSrc = 0;
     if (mt.on) { c->hJobs.clear(); c->hFrameUnits.resize(nFrames); }
     bool lzAny = false, lzAll = true;
     c->hLz.clear(); c->lzPos = 0; c->lzHeads = 0; c->lzRing = 0; c->lzLongest = 1;
@@ -878,13 +888,16 @@ static size_t frames_device_locked(zhip_ctx* c, void* dstDev, size_t dstCapacity
         bound += zhip::host_compress_bound(n);
         if (!lazy) {   // the longest walk of this frame: a section plus its prefix (the whole input without jobs)
             uint32_t const mode = zhip::frame_table_mode(cp.strategy, cp.hashLog, (unsigned long long)(n < section ? n : section) + overlap + 1);
-            if (mode == zhip::ZHIP_FT_HBM) { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
+            size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog);
+            if (w > tabWordsAll) tabWordsAll = w;
+            if (mode == zhip::ZHIP_FT_HBM) { if (w > tabWords) tabWords = w; }
             else { uint32_t const b = zhip::frame_table_lds_bytes(mode, cp.hashLog); if (b > ldsTab) ldsTab = b; }
         }
         totalSrc += n;
     }
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
     c->lzAny = lzAny; c->lzAll = lzAny && lzAll;
+    frames_prefer_hbm(c, nU, ldsTab, tabWords, tabWordsAll);
     size_t const r = frames_run_locked(c, dstDev, srcDev, nU, nFrames, ldsTab, tabWords, outBytes, totalSrc, mt.on, frameSizesDev, s);
     c->lzAny = c->lzAll = false;
     return r;
@@ -1117,7 +1130,7 @@ static size_t frame_jobs_chunk_device(zhip_ctx* c, void* dstDev, size_t dstCapac
     HIPCHK(c, hipSetDevice(c->device));
     if (nJobs == 0 || nJobs > c->maxUnits) return ZERR(ZE_srcSize_wrong);
     if (nJobs * (size_t)ZHIP_SEQ_CAP > c->seqArena || nJobs * (size_t)ZHIP_LIT_STRIDE > c->litArena) return ZERR(ZE_srcSize_wrong);   // a records context: arenas too small for full-size slots
-    size_t outBytes = 0, tabWords = 0, bound = 0; uint32_t ldsTab = 0; unsigned long long total = 0;
+    size_t outBytes = 0, tabWords = 0, tabWordsAll = 0, bound = 0; uint32_t ldsTab = 0; unsigned long long total = 0;
     c->hJobs.assign(jobs, jobs + nJobs); c->hFrameUnits.resize(1);
     for (size_t i = 0; i < nJobs; i++) {
         size_t const len = lens[i];
@@ -1132,10 +1145,13 @@ static size_t frame_jobs_chunk_device(zhip_ctx* c, void* dstDev, size_t dstCapac
         bound += zhip::host_compress_bound(len);
         c->hJobs[i].frameIdx = 0;
         uint32_t const mode = zhip::frame_table_mode(cp.strategy, cp.hashLog, (unsigned long long)len + jobs[i].prefixLen + 1);
-        if (mode == zhip::ZHIP_FT_HBM) { size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog); if (w > tabWords) tabWords = w; }
+        size_t const w = zhip::frame_table_words(cp.strategy, cp.hashLog, cp.chainLog);
+        if (w > tabWordsAll) tabWordsAll = w;
+        if (mode == zhip::ZHIP_FT_HBM) { if (w > tabWords) tabWords = w; }
         else { uint32_t const b = zhip::frame_table_lds_bytes(mode, cp.hashLog); if (b > ldsTab) ldsTab = b; }
         total += len;
     }
+    frames_prefer_hbm(c, nJobs, ldsTab, tabWords, tabWordsAll);
     if (dstCapacity < bound) return ZERR(ZE_dstSize_tooSmall);
     c->hFrameUnits[0] = c->hUnits[0];
     int const ck = c->checksum; c->checksum = 0;                          // a chunk does not see the whole frame: no checksum here
