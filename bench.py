@@ -705,11 +705,11 @@ def frames_leg(zstd_amd, local, host, level):
     algo = nf * fsz + sum(len(o) for o in outs)
     res = {"value": round(nf * fsz / best / 1e3, 1), "unit": "MB/s", "frames": nf, "frame_bytes": fsz, "level": level,
            "kernel_ms": round(best, 3), "ratio": round(nf * fsz / sum(len(o) for o in outs), 4),
-           "roofline": {"bound": "hbm", "kernel": "k_frame_fast", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_lookup("multi_block_frames", "k_frame_fast")[0] if (nf, fsz) == (1024, 1 << 20) else None,
-                        "traffic_source": traffic_lookup("multi_block_frames", "k_frame_fast")[1] if (nf, fsz) == (1024, 1 << 20) else None,
+           "roofline": {"bound": "hbm", "kernel": "k_frame_hbm" if nf > 512 else "k_frame_fast", "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_lookup("multi_block_frames", "k_frame_hbm")[0] if (nf, fsz) == (1024, 1 << 20) else None,
+                        "traffic_source": traffic_lookup("multi_block_frames", "k_frame_hbm")[1] if (nf, fsz) == (1024, 1 << 20) else None,
                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(best, 3)},
-           "note": "k_frame_fast: one workgroup per frame (blocks of a frame are a serial chain), two per CU; fidelity mode, never `value`"}
+           "note": "one workgroup per frame (blocks of a frame are a serial chain): k_frame_fast (table in LDS, two per CU) up to 2 x CUs frames, k_frame_hbm (tables in HBM, four per CU) beyond — round 6; fidelity mode, never `value`"}
     exe = os.path.join(ROOT, "oracle", "_ref", "zref_bench")
     if os.path.exists(exe):
         tin, tout = f"/tmp/zhip_frames_in_{os.getpid()}.bin", f"/tmp/zhip_frames_out_{os.getpid()}.bin"

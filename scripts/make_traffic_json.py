@@ -62,7 +62,7 @@ leg("lorem_level1", "lorem_L1", ["k_parse_fast_q"], "k_parse_fast", "bench.py --
 leg("silesia64_level3", "silesia64_L3", ["k_parse_dfast"], "k_parse_dfast", "bench.py --workload silesia --copies 64 --level 3 (BASELINE configs[2])")
 leg("records_zdict_level3", "records_L3", ["k_parse_dict_q"], "k_parse_dict", "bench.py --workload records --records 10000000 --base-records 1000000 --level 3 (BASELINE configs[4])")
 leg("datagen_level5", "datagen_L5", ["k_hc_chain", "k_hc_search_lds", "k_parse_lazy"], "k_parse_lazy", "bench.py --level 5 --mib 1024 (sum of the stage's three kernels)")
-leg("multi_block_frames", "frames_1MiB", ["k_frame_fast"], "k_frame_fast", "bench.py --leg multi_block_frames (1 024 frames of 1 MiB)")
+leg("multi_block_frames", "frames_1MiB", ["k_frame_hbm"], "k_frame_hbm", "bench.py --leg multi_block_frames (1 024 frames of 1 MiB: more workgroups than the LDS-table form holds, so the all-HBM form runs)")
 leg("job_pool_frame", "job_pool_1GiB", ["k_frame_fast"], "k_frame_fast", "bench.py --leg job_pool_frame (one 1 GiB frame, job table)")
 leg("plugin_B1", "plugin_B1", ["k_parse_fast_q"], "k_parse_fast", "scripts/plugin_prepare_only.py 1024 (the leg's device part: zhip_prepare_sequences on 16 384 blocks of 64 KB; rocprofv3 crashes under the leg's 64 reference threads)")
 json.dump(out, open(os.path.join(P, "latest_traffic.json"), "w"), indent=1)
