@@ -33,6 +33,14 @@ void emu_parse_fast(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, 
 
 // the queue form of the same stage: dispatch order from k_order_cost + k_order_sort, then persistent workgroups on one ticket counter.
 // mode 1 = LDS tables (k_parse_fast_q), 2 = tables in global memory (k_parse_fast_g), 3 = both kernels, one after the other on one queue
+// k_order_sort's second job: the number of global-table workgroups a batch of these costs gets (0 = all that were launched)
+uint32_t emu_order_sort_limit(const uint32_t* cost, uint32_t nUnits, uint32_t gSparse, uint32_t denseCost)
+{
+    std::vector<uint32_t> order(nUnits + 1); uint32_t lim = 0;
+    uint32_t* const po = order.data(); uint32_t* const pl = &lim;
+    simt::launch({1, 1, 1}, {1024, 1, 1}, 0, [=] { zhip::k_order_sort(cost, nUnits, po, pl, gSparse, denseCost); }, 1);
+    return lim;
+}
 void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nUnits, ZhipSeq* seqs, uint8_t* lits, ZhipParse* metas,
                           uint32_t smemBytes, int mode, uint32_t* orderOut, int osThreads)
 {
@@ -51,7 +59,8 @@ void emu_parse_fast_queue(const uint8_t* src, const ZhipUnit* units, uint32_t nU
         simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, half, seqs, lits, metas, po, pq); }, osThreads);
         pq[0] = half;
         simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
-    } else if (mode == 2) {
+    } else if (mode == 2 || mode == 4) {
+        if (mode == 4) pq[1] = 1;              // k_order_sort's decision: one global-table workgroup takes part, the other two leave at once
         simt::launch({gridG, 1, 1}, {64, 1, 1}, 0, [=] { zhip::k_parse_fast_g(src, units, slots, nUnits, seqs, lits, metas, po, pq, pg, gw); }, osThreads);
     } else {
         simt::launch({gridQ, 1, 1}, {64, 1, 1}, smemBytes, [=] { zhip::k_parse_fast_q(src, units, slots, nUnits, seqs, lits, metas, po, pq); }, osThreads);

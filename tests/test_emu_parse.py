@@ -257,10 +257,25 @@ def test_rowhash_parse_matches_oracle(libs):
         lo.zo_set_row_matcher(0)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_order_sort_decides_the_global_table_wavefronts_by_mean_cost(libs):
+    """k_order_sort also writes how many global-table workgroups join the queue (round 6): a batch whose mean estimated cost is below the
+    threshold gets `gSparse`, a dense one keeps all that were launched (the word stays 0)"""
+    lo, le = libs
+    le.emu_order_sort_limit.restype = C.c_uint
+    le.emu_order_sort_limit.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint]
+    sparse = np.full(3000, 1900, dtype=np.uint32); dense = np.full(3000, 6500, dtype=np.uint32)
+    mixed = np.concatenate([np.full(1500, 1000, dtype=np.uint32), np.full(1500, 9000, dtype=np.uint32)])       # mean 5 000
+    assert le.emu_order_sort_limit(_buf(sparse), 3000, 1536, 4000) == 1536
+    assert le.emu_order_sort_limit(_buf(dense), 3000, 1536, 4000) == 0
+    assert le.emu_order_sort_limit(_buf(mixed), 3000, 1536, 4000) == 0
+    assert le.emu_order_sort_limit(_buf(mixed), 3000, 1536, 5001) == 1536
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_queue_form_of_the_fast_stage_on_the_emulator(libs, monkeypatch, mode):
     """k_order_cost + k_order_sort + the persistent queue kernels (mode 1: LDS tables, 2: tables in global memory with ballot hash
-    groups, 3: both kernels on one queue) give the oracle's sequences whatever order the units are taken in"""
+    groups, 3: both kernels on one queue, 4: as 2 with all but one global-table workgroup told to stay out) give the oracle's
+    sequences whatever order the units are taken in"""
     lo, le = libs
     monkeypatch.setenv("ZHIP_EMU_QUEUE", str(mode))
     for level in (1, -3):

@@ -60,6 +60,24 @@ def test_frames_edge_sizes_and_checksum(env):
     assert z.DContext().decompress(out) == a.tobytes()
 
 
+def test_large_batch_of_frames_takes_the_hbm_table_form(env):
+    """more workgroups than the LDS-table form holds at once (2 per CU) run on k_frame_hbm with every table in HBM (round 6): the same bytes as the
+    oracle's frames, and as the same frames compressed a few at a time (the LDS form)"""
+    z, lo = env
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    nf = 2 * ncu + 40
+    base = [datagen(lo, 131072 + 4096 * k, 40 + 5 * k, 70 + k) for k in range(4)] + [text_like(200000, 3), datagen(lo, 300, 50, 4), np.zeros(0, np.uint8)]
+    bufs = [base[i % len(base)] for i in range(nf)]
+    big = z.Context(max_units=nf)
+    outs = big.compress_frames(bufs, 1)
+    want = [oracle_frame(lo, a, 1) for a in base]
+    for i, out in enumerate(outs):
+        assert out == want[i % len(base)], i
+    few = z.Context(max_units=16).compress_frames(base, 1)                # 7 workgroups: tables in LDS
+    assert few == want
+
+
 def test_frames_decode_on_the_device_and_unsupported_strategy(env):
     z, lo = env
     ctx = z.Context(max_units=8)
