@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 ctx = zstd_amd.Context(0, max_units=n // 131072 + 1)
 if os.environ.get("ROW") is not None:
     ctx.set_row_matcher(int(os.environ["ROW"]))
+if os.environ.get("PREDICT") is not None:                       # the row matcher's two-pass prediction for units (off by default)
+    ctx.set_prediction(units=int(os.environ["PREDICT"]))
 cap = zstd_amd.compress_bound(n, 131072)
 dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
 gen = {

@@ -231,6 +231,9 @@ def test_rowhash_parse_matches_oracle(libs):
             big[rng.integers(0, 131072, 40)] ^= 0xFF
             cases.append(("period700", big))
             cases.append(("incompressible_then_text", np.concatenate([rng.integers(0, 256, 60000, dtype=np.uint8), cases[3][1][:71072]])))   # lazy skipping
+            # every byte 24 times: each sequence a repcode (greedy takes it without a search, so nextToUpdate never moves and every batch start meets the whole gap
+            # behind it: the 384-position rule flagged the unit's past again per batch until round 6 — 70 s here, 4.4 s per unit on the GPU)
+            cases.append(("runs_of_24", np.repeat(rng.integers(0, 256, 131072 // 24 + 1, dtype=np.uint8), 24)[:131072]))
             bufs = [c[1] for c in cases]
             units = make_units(lo, [len(b) for b in bufs], level, row=True)
             assert (units["rowLog"] > 0).all()

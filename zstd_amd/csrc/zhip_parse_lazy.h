@@ -515,6 +515,7 @@ struct HcState {
     uint32_t ntu;           // ms->nextToUpdate (zstd_compress_internal.h:232)
     uint32_t skipping;      // ms->lazySkipping (:253)
     uint32_t gapEnd;        // highest position flagged ZHIP_HC_SKIPPED so far, 0 = none (position 0 is always inserted)
+    uint32_t gapFlagged;    // row matcher: where the 384-position rule's flagging of the gap behind nextToUpdate has got to (rh_gap_rule)
     lds_u32* dirty;         // row matcher: one bit per row, set when a position of that row was decided otherwise than predicted (2^(hashLog - rowLog) bits of LDS)
     uint32_t predict;       // 1: the PREDICTING parse — positions it would skip get ZHIP_HC_PRED, nothing is flagged, nothing is stored
     uint32_t scanned;       // exact parse: every position below this has been compared with its prediction
@@ -717,7 +718,14 @@ __device__ inline void rh_live_lists(const uint8_t* __restrict__ src, uint32_t n
 // nextToUpdate only the first 96 and the last 32 are inserted — the rest is flagged as never inserted
 __device__ inline void rh_gap_rule(const uint8_t* __restrict__ src, uint32_t n, const ZhipUnit& u, uint32_t* prev, HcState& st, uint32_t x)
 {
-    if (x > st.ntu && x - st.ntu > 384) rh_flag_range(src, n, u, prev, st, st.ntu + 96, x - 32);
+    if (x > st.ntu && x - st.ntu > 384) {
+        // (a batch start is taken for a search at its first position; when the batch's first event is a repcode taken without a search — greedy — nextToUpdate stays where it
+        // was and the NEXT batch start meets the same gap, longer: only what lies behind the part already flagged is new.  Without this a unit of short runs — every
+        // sequence a repcode, no search ever — flagged its whole past again at every batch: 4.4 s per unit, profiles/r06_l5_runs_of_24.log)
+        uint32_t f0 = st.ntu + 96;
+        if (st.gapFlagged > f0) f0 = st.gapFlagged;
+        if (x - 32 > f0) { rh_flag_range(src, n, u, prev, st, f0, x - 32); st.gapFlagged = x - 32; }
+    }
 }
 
 // one ZSTD_HcFindBestMatch / ZSTD_RowFindBestMatch call of the reference at x: insertion bookkeeping + the (pre)computed result
@@ -796,7 +804,7 @@ __device__ inline void parse_lazy_unit(const uint8_t* __restrict__ src, uint32_t
     if (n >= (u.rowLog ? 18u : 10u)) {
     uint32_t const nm8 = n - 8, ilimit = u.rowLog ? n - 16 : n - 8;          // :1527 the row matcher stops ZSTD_ROW_HASH_CACHE_SIZE earlier
     uint32_t ip = 1;
-    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0; st.havePred = havePred ? 1u : 0u;
+    HcState st; st.ntu = 0; st.skipping = 0; st.gapEnd = 0; st.gapFlagged = 0; st.dirty = (lds_u32*)(uintptr_t)smem; st.predict = predict ? 1u : 0u; st.scanned = 0; st.nLive = 0; st.budget = u.rowLog ? tryBudget : 0u; st.abort = 0; st.havePred = havePred ? 1u : 0u;
     st.epoch = 0;
     // the batch that will start right after the current sequence (known as soon as its end is: catch-up moves the start,
     // not the end), fetched while the sequence is finished; used if the immediate-repcode loop does not move on
