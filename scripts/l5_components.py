@@ -22,7 +22,19 @@ members = {
     "random": lambda: rng.integers(0, 256, size=n, dtype=np.uint8),
     "runs_of_24": lambda: np.repeat(rng.integers(0, 256, size=n // 24 + 1, dtype=np.uint8), 24)[:n],
     "datagen_P50": lambda: dg(50, 6),
+    # shapes outside the mix, each a known hard case of some match finder (EXTRA=1)
+    "zeros": lambda: np.zeros(n, dtype=np.uint8),
+    "period_2": lambda: np.tile(np.array([65, 66], dtype=np.uint8), n // 2),
+    "period_7": lambda: np.tile(np.arange(7, dtype=np.uint8) + 48, n // 7 + 1)[:n],
+    "runs_of_1000": lambda: np.repeat(rng.integers(0, 256, size=n // 1000 + 1, dtype=np.uint8), 1000)[:n],
+    "two_symbols": lambda: rng.integers(0, 2, size=n, dtype=np.uint8) + 48,
+    "one_line_x": lambda: np.tile(np.frombuffer(b"the quick brown fox jumps over the lazy dog and keeps on running through the field until dusk\n", dtype=np.uint8), n // 94 + 1)[:n],
+    "le_u32_counter": lambda: np.arange(n // 4, dtype=np.uint32).view(np.uint8)[:n],
+    "datagen_P98": lambda: dg(98, 8),
 }
+if os.environ.get("EXTRA") != "1":
+    for k in ("zeros", "period_2", "period_7", "runs_of_1000", "two_symbols", "one_line_x", "le_u32_counter", "datagen_P98"):
+        members.pop(k)
 dev = torch.device("cuda", 0)
 ctx = zstd_amd.Context(0, max_units=n // 131072 + 1)
 if os.environ.get("PREDICT") is not None:

@@ -57,6 +57,28 @@ def test_lazy_frames_explicit_parameters_and_small_windows(env):
             assert out == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (cp, row, len(a))
 
 
+def test_frames_of_short_runs_at_greedy(env):
+    """every byte 24 times: each sequence is a repcode that greedy takes without a search, so nextToUpdate never moves — the 384-position rule used to flag the whole
+    gap behind it again at every batch start (9 s per MiB of such a frame until round 6).  The oracle's frame, and a time bound far above what it takes now"""
+    import time
+    z, lo = env
+    ctx = z.Context(max_units=8)
+    rng = np.random.default_rng(24)
+    a = np.repeat(rng.integers(0, 256, size=(1 << 20) // 24 + 1, dtype=np.uint8), 24)[: 1 << 20]
+    b = np.repeat(rng.integers(0, 256, size=300000 // 1000 + 1, dtype=np.uint8), 1000)[:300000]
+    ctx.compress_frames([a[:70000]], 5)                                  # (the first call of a process loads the code object and sizes the arenas)
+    for level, row in ((5, 1), (6, 1), (5, 0)):
+        ctx.set_row_matcher(0 if row else 2)                             # (the suite's default is the hash chain: tests/conftest.py)
+        cp = (C.c_uint * 7)(); assert lo.zo_get_cparams(level, len(a), cp) == 0
+        t0 = time.time()
+        outs = ctx.compress_frames([a, b], level)
+        dt = time.time() - t0
+        assert outs[0] == oracle_frame_params(lo, a, cp, row), (level, row)
+        cpb = (C.c_uint * 7)(); assert lo.zo_get_cparams(level, len(b), cpb) == 0
+        assert outs[1] == oracle_frame_params(lo, b, cpb, row), (level, row)
+        assert dt < 3.0, (level, row, dt)
+
+
 @pytest.mark.parametrize("level,no_row,js,ov,ck", [(5, 0, 0, 0, 0), (6, 1, 524288, 9, 1), (8, 0, 700000, 0, 0), (10, 1, 1 << 20, 3, 1)])
 def test_lazy_job_pool_frames(env, level, no_row, js, ov, ck):
     """ZSTD_c_nbWorkers >= 1 at the lazy levels: a workgroup per job; against the oracle and, when it travelled, the reference"""

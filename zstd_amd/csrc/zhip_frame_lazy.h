@@ -271,6 +271,7 @@ struct LzState {
     uint32_t nFlagged;      // exact parse: positions left out so far (0: prev[] is the truth and nothing needs the live rows)
     uint32_t epoch;         // exact parse: grows whenever a key is marked dirty (what a batch of records looked up about its staleness is then out of date)
     uint32_t holeStart, holeEnd;   // a job's never-inserted prefix positions (ZhipLzSlot)
+    uint32_t gapFlagged;    // row matcher: where the 384-position rule's flagging of the gap behind nextToUpdate has got to (lz_gap_rule)
 };
 __device__ __forceinline__ LzRec lz_rec_lane(const LzRec& r, int l)
 {
@@ -500,7 +501,13 @@ struct LzBlock {           // what is constant over one block
 __device__ __forceinline__ uint32_t lz_low_limit(const LzBlock& B, uint32_t x) { return (x - B.low > B.maxDist) ? x - B.maxDist : B.low; }   // internal.h:1312
 __device__ __forceinline__ void lz_gap_rule(const LzBlock& B, const ZhipUnit& u, LzState& st, uint32_t x)      // zstd_lazy.c:916-947
 {
-    if (x > st.ntu && x - st.ntu > 384) lz_flag_range(B.src, u, B.prev, st, st.ntu + 96, x - 32);
+    if (x > st.ntu && x - st.ntu > 384) {
+        // (as rh_gap_rule, zhip_parse_lazy.h: a batch start whose first event is a repcode taken without a search leaves nextToUpdate where it was — the next batch start meets
+        // the same gap, longer, and only flags what lies behind the part already flagged; a frame of short runs took 9 s per MiB at level 5 before)
+        uint32_t f0 = st.ntu + 96;
+        if (st.gapFlagged > f0) f0 = st.gapFlagged;
+        if (x - 32 > f0) { lz_flag_range(B.src, u, B.prev, st, f0, x - 32); st.gapFlagged = x - 32; }
+    }
 }
 // one ZSTD_HcFindBestMatch / ZSTD_RowFindBestMatch call of the reference at x: insertion bookkeeping + the (pre)computed result
 __device__ inline void lz_search(const LzBlock& B, const ZhipUnit& u, LzState& st, uint32_t x, const LzRec& rec, uint32_t& ml, uint32_t& offBase)
@@ -803,7 +810,7 @@ __device__ inline bool frame_lazy_predict(const uint8_t* __restrict__ src, const
     bool const first = !job || (job->flags & ZHIP_JOB_FIRST);
     uint32_t const j0 = job ? job->prefixLen : 0u, jEnd = j0 + u.srcLen, maxDist = 1u << u.windowLog;
     uint32_t rep1 = first ? 1u : 0u, rep2 = first ? 4u : 0u, rep3 = first ? 8u : 0u, low = 0;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.gapFlagged = 0; ls.dirty = nullptr; ls.predict = 1; ls.scanned = j0; ls.nPred = 0; ls.havePred = 0;
     ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = 0; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = 0; ls.holeEnd = 0;
     for (uint32_t pos = j0; pos < jEnd; ) {
         // the 32 KB probe, then the rest of the first 128 KB block, then whole blocks: the predicted block borders stay on the exact parse's j0 + k * 128 KB
@@ -857,7 +864,7 @@ __device__ inline void frame_lazy(const uint8_t* __restrict__ src, const ZhipUni
     long long savings = (job && !first) ? -(long long)job->ownHeader : 0;
     uint32_t pos = j0, low = 0;
     uint32_t const maxDist = 1u << u.windowLog;
-    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = (havePred && st->predicted) ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
+    LzState ls; ls.ntu = j0; ls.skipping = 0; ls.gapEnd = 0; ls.gapFlagged = 0; ls.dirty = dirty; ls.predict = 0; ls.scanned = j0; ls.nPred = 0; ls.havePred = (havePred && st->predicted) ? 1u : 0u;      // a job: nextToUpdate = the prefix's end
     ls.ring.cnt = nullptr; ls.ring.pos = nullptr; ls.ring.tag = nullptr; ls.ins = L.linkStart; ls.nFlagged = 0; ls.epoch = 0; ls.holeStart = L.holeStart; ls.holeEnd = L.holeEnd;
     if (ring && u.rowLog) {                                                  // fresh rows: every count 0 (the slots are only read below a count)
         uint32_t const rows = 1u << lz_key_bits(u);
