@@ -197,7 +197,7 @@ __device__ inline LzRec lz_search_hc(const uint8_t* __restrict__ src, uint32_t e
         uint32_t const wl = prev[mp], nx = ZHIP_LZ_LINK(wl);
         minCand = mp;                                                              // the lowest position VISITED
         if (wl & ZHIP_LZ_PRED) { m = nx; continue; }                               // the predicting parse left it out: not in the chain
-        if (p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
+        if (nCap < 3 && p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {      // (three capped candidates: the record says "live" whatever follows)
             uint32_t cur = 0;
             for (;;) {
                 uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
@@ -235,7 +235,7 @@ __device__ inline LzRec lz_search_rh(const uint8_t* __restrict__ src, uint32_t e
         room--;
         if (tg == myTag) {
             attempts--;
-            if (!done && p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
+            if (!done && nCap < 3 && p + ml < end && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {
                 uint32_t cur = 0;
                 for (;;) {
                     uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);

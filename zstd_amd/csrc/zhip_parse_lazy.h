@@ -226,7 +226,7 @@ __device__ inline uint64_t hc_search_pos(const uint8_t* __restrict__ src, uint32
         uint32_t const mp = m - 1;
         uint32_t const nx = prev[mp];                                           // independent of the compare below
         minCand = mp;
-        if (p + ml < n && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {   // :714 quick reject at the current best length (a longer match needs byte ml)
+        if (nCap < 3 && p + ml < n && ld32(src + mp + ml - 3) == ld32(src + p + ml - 3)) {   // :714 quick reject at the current best length (a longer match needs byte ml); with three capped candidates the record says "live" whatever follows
             uint32_t cur = 0;
             for (;;) {
                 uint32_t const same = lane_same_fwd(src, p + cur, p - mp, nm8);
@@ -270,7 +270,7 @@ __device__ inline uint64_t hc_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
         uint32_t const mp = m - 1;
         uint32_t const nx = prev[mp];
         minCand = mp;
-        if (p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+        if (nCap < 3 && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {      // (three capped candidates: the record says "live" whatever follows — round 6: runs at level 10 spent 70 ms per 64 MiB here)
             uint32_t cur = 0;
             for (;;) {
                 uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
@@ -479,7 +479,7 @@ __device__ inline uint64_t rh_search_pos_lds(const lds_u8* lsrc, uint32_t n, uin
             room--;
             if (((e >> 17) & 0xFFu) == myTag) {
                 attempts--;
-                if (!done && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {
+                if (!done && nCap < 3 && p + ml < n && lds_ld32(lsrc + mp + ml - 3) == lds_ld32(lsrc + p + ml - 3)) {      // (three capped candidates: "live" whatever follows; the walk goes on for minCand / WHOLE)
                     uint32_t cur = 0;
                     for (;;) {
                         uint32_t const same = (p + cur < n) ? lds_same_fwd(lsrc, p + cur, p - mp, n) : 0;
