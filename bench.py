@@ -1211,11 +1211,11 @@ def main():
 
 # the default line's extra legs: (key in the JSON line, deadline in seconds)
 LEGS = [("decode", 90), ("pipelined", 60), ("end_to_end", 90), ("plugin_B1", 120), ("multi_block_frames", 90), ("job_pool_frame", 120), ("silesia_shaped_level1", 120),
-        ("text_level1", 150), ("lorem_level1", 120), ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_units", 180)]
+        ("text_level1", 150), ("lorem_level1", 120), ("silesia64_level3", 200), ("records_zdict_level3", 200), ("level5_units", 180), ("silesia_shaped_level5", 150)]
 # short names of the legs in the line's closing `digest`
 DIGEST_NAMES = {"decode": "dec_L1", "pipelined": "pipe4", "end_to_end": "e2e_host", "plugin_B1": "plugin_B1", "multi_block_frames": "frames_1MiB",
                 "job_pool_frame": "job_pool_1GiB", "silesia_shaped_level1": "silesia4_L1", "text_level1": "text1e9_L1", "lorem_level1": "lorem1GiB_L1", "silesia64_level3": "silesia64_L3",
-                "records_zdict_level3": "records10M_L3", "level5_units": "datagen_L5"}
+                "records_zdict_level3": "records10M_L3", "level5_units": "datagen_L5", "silesia_shaped_level5": "silesia4_L5"}
 
 
 def make_digest(out):
@@ -1306,6 +1306,10 @@ def run_leg(args, torch, zstd_amd, dev, local):
         l5, _ = compress_leg(a5, torch, zstd_amd, dev, local, 0, 1, None, "datagen", 5, 3, 1, 1, 0,
                              want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="datagen_level5")
         return {k: l5[k] for k in LEG_KEYS if k in l5}
+    if name == "silesia_shaped_level5":                          # the metric's data shape at the lazy family's level (round 6: its member of short runs took 4.4 s per unit until the 384-position rule stopped flagging a gap twice)
+        s5, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 5, 3, 1, 4, 0,
+                             want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=6.0, leg="silesia4_level5")
+        return {k: s5[k] for k in LEG_KEYS if k in s5}
     if name == "silesia64_level3":                               # BASELINE configs[2] at its stated size: the mix x64 (about 13 GiB), level 3 (ZSTD_dfast)
         sil3, _ = compress_leg(args, torch, zstd_amd, dev, local, 0, 1, None, "silesia", 3, 3, 1, 64, 0,
                                want_decode=False, want_pipelined=False, want_cpu=not nocpu, cpu_seconds=4.0, leg="silesia64_level3")
