@@ -39,6 +39,24 @@ def test_lazy_frames_match_oracle(libs, level, row):
         assert g == oracle_frame_params(lo, a, (C.c_uint * 7)(*cp), row), (name, level, row)
 
 
+def test_greedy_frame_of_runs_across_block_borders(libs):
+    """runs of 24 with a byte flipped every 1 021: greedy takes repcode after repcode without a search, nextToUpdate lags, the batch starts flag the gap behind it
+    (384-position rule) for a search that never comes — and at the next BLOCK start the reference moves nextToUpdate up (zstd_compress.c:3243) and later inserts what lies
+    behind it.  The device used to keep those positions flagged (a parity bug older than round 6; found by tests/tools/gpu_fuzz_shapes.py seed 7002)."""
+    lo, le = libs
+    rng = np.random.default_rng(7002)
+    n = 400000
+    a = np.repeat(rng.integers(0, 256, size=n // 24 + 1, dtype=np.uint8), 24)[:n].copy()
+    a[::1021] ^= 1
+    b = np.repeat(rng.integers(0, 256, size=300000 // 96 + 1, dtype=np.uint8), 96)[:300000].copy()
+    b[::389] ^= 1
+    for row in (1, 0):
+        cps = [_cp(lo, 5, len(x)) for x in (a, b)]
+        got = emu_compress_frames_lazy(le, lo, [a, b], cps, row)
+        for x, cp, g in zip((a, b), cps, got):
+            assert g == oracle_frame_params(lo, x, (C.c_uint * 7)(*cp), row), (len(x), row)
+
+
 @pytest.mark.parametrize("cp,row", [([17, 16, 17, 3, 5, 2, 4], 1), ([17, 17, 18, 4, 4, 16, 5], 0)])
 def test_lazy_frames_beyond_the_window(libs, cp, row):
     """inputs larger than 2^windowLog: the window's low end moves with the blocks (candidates, repcodes, catch-up)"""

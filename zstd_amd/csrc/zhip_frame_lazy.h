@@ -561,9 +561,27 @@ __device__ inline void parse_lazy_block(const LzBlock& B, const ZhipUnit& u, LzS
     // zstd_compress.c:3243-3249 limited update after a very long match; zstd_lazy.c:1567
     if (bStart > st.ntu + 384) {
         uint32_t const d = bStart - st.ntu - 384, nn = bStart - (d < 192 ? d : 192);
+        if (u.rowLog && st.gapFlagged > nn) {
+            // lz_gap_rule flags at a batch START, for the search the batch opens with — but greedy takes a repcode without one, and when no search came before the block
+            // ended, what was flagged behind the new nextToUpdate is inserted after all (the reference's next search starts at nn): taken back, their keys marked like any
+            // position decided otherwise than expected.  (Round 6: found by tests/tools/gpu_fuzz_shapes.py — runs of 24 with a byte flipped every 97, level 5, 400 KB.)
+            uint32_t const g1 = st.gapFlagged;
+            for (uint32_t q0 = nn; q0 < g1; q0 += 64) {
+                uint32_t const q = q0 + (uint32_t)lane_id();
+                if (q < g1) {
+                    if (st.predict) B.prev[q] &= ~ZHIP_LZ_PRED;
+                    else { B.prev[q] &= ~ZHIP_HC_SKIPPED; uint32_t tag; uint32_t const k = lz_key(ld64(src + q), u, tag); atomicOr(&st.dirty[k >> 5], 1u << (k & 31)); }
+                }
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            if (st.predict) st.nPred -= g1 - nn;
+            else { if (g1 - 1 > st.gapEnd) st.gapEnd = g1 - 1; st.epoch++; }
+        }
         lz_flag_range(src, u, B.prev, st, st.ntu, nn);
         st.ntu = nn;
     }
+    st.gapFlagged = 0;
     st.skipping = 0;
     if (bLen > guard) {
         uint32_t const nm8 = bEnd - 8, ilimit = bEnd - guard;
