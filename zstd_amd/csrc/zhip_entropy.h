@@ -677,8 +677,18 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         // one contiguous run of the stream per lane, whose lines stay in L1 from round to round (the chunked form was 10 % slower there: A/B in
         // profiles/r04_entropy_tiles2.log)
         constexpr bool chunked = NT == 64;
+        // Round 6: full-size units pack through LDS (ZHIP_HUF_STAGE).  A wavefront walks its stream in chunks of 64 x 16 symbols (one coalesced kilobyte per load),
+        // the lanes OR their codes into the wavefront's own LDS image of the chunk's stretch of the stream, and the image leaves with whole-word stores, 256
+        // contiguous bytes per instruction; the chunk's last partial word stays behind as the next image's first.  Every byte of a stream is stored exactly once
+        // and only by its own wavefront (the stream's first and last words go out byte by byte where they are shared), so the zeroing pass, its barrier and the
+        // global atomics are gone.  The per-lane form it replaces touched 64 lines per store instruction, 16 bytes of each (WRITE_SIZE 4.7 x the frames).
+#ifndef ZHIP_HUF_STAGE
+#define ZHIP_HUF_STAGE 1
+#endif
+        constexpr bool staged = (NT == 256) && (ZHIP_HUF_STAGE != 0);
+        constexpr bool sizeChunked = chunked || (staged && ZHIP_HUF_STAGE == 2);
         uint32_t segStart[SPW], segLenA[SPW], total[SPW], runStart[SPW], runLen[SPW], incl[SPW];
-        if constexpr (chunked) {
+        if constexpr (sizeChunked) {
             // pass 1: wavefront `wv` sizes stream `wv`.  Round 4: COALESCED — the wavefront walks the stream in chunks of 64 x 16 symbols, lane l takes
             // the 16 bytes at chunk + 16 l (one 1 KB stretch per load instruction; a lane used to own one contiguous run of the stream, i.e. 64 lines per
             // load).  (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so a 16-byte read may run past the stream.)
@@ -711,10 +721,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             for (uint32_t q = 0; q < SPW; q++) {
                 uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
                 uint32_t myBits = 0;
-                segStart[q] = 0; runStart[q] = 0; runLen[q] = 0;
+                segStart[q] = 0; runStart[q] = 0; runLen[q] = 0; segLenA[q] = 0;
                 if (sI < nStreams) {
                     segStart[q] = sI * seg;
                     uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
+                    segLenA[q] = segLen;
                     uint32_t const rper = (segLen + 63) / 64;
                     runStart[q] = (uint32_t)lane * rper; if (runStart[q] > segLen) runStart[q] = segLen;
                     runLen[q] = (runStart[q] + rper <= segLen) ? rper : segLen - runStart[q];
@@ -749,8 +760,8 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         litMode = sh->litMode;
         if (litMode == 2) {
             uint32_t const cLit = sh->litSectionSize - lhSize;
-            // zero the stream bytes that will be OR-ed
-            zero_bytes<NT>(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
+            // zero the stream bytes that will be OR-ed (the staged packer stores every byte of a stream itself: no zeroing, no shared words)
+            if constexpr (!staged) zero_bytes<NT>(litDst + sh->streamOff[0], sh->litSectionSize - sh->streamOff[0]);
             if (t == 0) {
                 // section header (zstd_compress_literals.c:209-232)
                 if (lhSize == 3) { uint32_t const lhc = sh->litType + ((uint32_t)(!single) << 2) + (litSize << 4) + (cLit << 14); litDst[0] = (uint8_t)lhc; litDst[1] = (uint8_t)(lhc >> 8); litDst[2] = (uint8_t)(lhc >> 16); }
@@ -759,11 +770,78 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 for (uint32_t i = 0; i < sh->hufHdrSize; i++) litDst[lhSize + i] = sh->hufHdr[i];
                 if (!single) for (int k = 0; k < 3; k++) { uint8_t* jt = litDst + lhSize + sh->hufHdrSize + 2 * k; jt[0] = (uint8_t)sh->streamBytes[k]; jt[1] = (uint8_t)(sh->streamBytes[k] >> 8); }
             }
-            __syncthreads();      // zeroing + header byte stores are complete before any atomicOr touches a shared word
+            if constexpr (!staged) __syncthreads();      // zeroing + header byte stores are complete before any atomicOr touches a shared word
             ZPROF(2);
             // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
             // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
-            if constexpr (chunked) {
+            if constexpr (staged) {
+                uint32_t const sI = (uint32_t)wv;                                  // SPW == 1: wavefront = stream
+                if (sI < nStreams) {
+                    uint8_t* const sbase = litDst + sh->streamOff[sI];
+                    uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
+                    uint8_t* const w8 = (uint8_t*)w32;
+                    uint32_t const firstB = (uint32_t)((uintptr_t)sbase & 3);      // the stream's bytes are [firstB, endB) counted from w32
+                    uint32_t const endB = firstB + sh->streamBytes[sI];
+                    uint32_t* const img = &sh->hist[0][0] + 384u * (uint32_t)wv;   // 1 536 bytes per wavefront: hist[] + sampleHist[], dead since phase B (31 + 1 024 x 11 bits at most)
+                    const uint8_t* const p = lits + segStart[0];
+                    uint32_t const segLen = segLenA[0];
+                    uint32_t const nChunks = (segLen + 1023u) >> 10;               // wave-uniform (stream geometry)
+                    for (uint32_t w = (uint32_t)lane; w < 384u; w += 64u) img[w] = 0;
+                    __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t carry = 8u * firstB;                                   // bits of image word 0 in front of this chunk's
+                    uint32_t wordBase = 0;                                          // image word 0 is w32[wordBase]
+                    auto flush = [&](uint32_t words) {                              // image words [0, words) -> the frame; words shared with a neighbour section go byte by byte
+                        for (uint32_t w = (uint32_t)lane; w < words; w += 64u) {
+                            uint32_t const v = img[w], g = wordBase + w, b0 = 4u * g;
+                            if (b0 >= firstB && b0 + 4u <= endB) w32[g] = v;
+                            else for (uint32_t k = 0; k < 4; k++) if (b0 + k >= firstB && b0 + k < endB) w8[b0 + k] = (uint8_t)(v >> (8 * k));
+                        }
+                    };
+                    for (uint32_t ch = nChunks; ch-- > 0; ) {
+                        // chunks from the stream's end to its start; inside a chunk the higher lanes' symbols come first
+                        uint32_t const c0 = (ch << 10) + 16u * (uint32_t)lane;
+                        uint32_t const c = c0 < segLen ? (segLen - c0 < 16u ? segLen - c0 : 16u) : 0u;
+                        uint32_t cd[16]; uint32_t myBits = 0;
+                        if (c) {
+                            uint4 va; __builtin_memcpy(&va, p + c0, 16);
+                            uint32_t const w[4] = { va.x, va.y, va.z, va.w };
+#pragma unroll
+                            for (uint32_t b = 0; b < 16; b++) { cd[b] = b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0u; myBits += cd[b] & 0xFF; }
+                        }
+                        uint32_t const inclC = wave_incl_scan(myBits);
+                        uint32_t const chunkBits = __shfl(inclC, 63);
+                        if (c) {
+                            uint32_t const pos = carry + chunkBits - inclC;
+                            uint32_t* wp = img + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
+#pragma unroll
+                            for (int b = 15; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per step, last -> first
+                                uint32_t const c1 = cd[b], c0v = cd[b - 1];
+                                uint32_t const n1 = c1 & 0xFF;
+                                acc |= (uint64_t)((c1 >> 8) | ((c0v >> 8) << n1)) << have; have += n1 + (c0v & 0xFF);
+                                if (have >= 32) { __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); wp++; acc >>= 32; have -= 32; }
+                            }
+                            if (have) __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                        __threadfence_block();
+                        __builtin_amdgcn_wave_barrier();
+                        uint32_t const tot = carry + chunkBits, full = tot >> 5;
+                        flush(full);
+                        uint32_t const cw = img[full];                              // the partial word: first of the next image
+                        __threadfence_block();
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t w = (uint32_t)lane; w <= full; w += 64u) img[w] = w ? 0u : cw;
+                        __threadfence_block();
+                        __builtin_amdgcn_wave_barrier();
+                        carry = tot & 31; wordBase += full;
+                    }
+                    // the stream's FIRST symbols came last: the end mark follows them; what is left is at most one word
+                    if (lane == 0) img[0] |= 1u << carry;
+                    __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                    flush(1);
+                }
+            } else if constexpr (chunked) {
 #pragma unroll
                 for (uint32_t q = 0; q < SPW; q++) {
                     uint32_t const sI = (uint32_t)wv + q * NW;
@@ -898,6 +976,79 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             // bitstream is never written — and never runs past the block's output room
             if (litSection + nbHdr + 1 + tblBytes + streamBytes >= n - minGainBlock) rawBlock = true;
             else {
+#ifndef ZHIP_SEQ_STAGE
+#define ZHIP_SEQ_STAGE 1
+#endif
+#if ZHIP_SEQ_STAGE
+            // Round 6: every byte of the bitstream is stored once.  Tiles of NT consecutive sequences, from the top of the block down (the highest sequence comes
+            // first in the stream); a tile's bits are OR-ed into an LDS image of its stretch of the stream and leave with whole-word stores; the tile's last partial
+            // word stays behind as the next image's first (round 5 zeroed the stream in global memory and joined the tiles with atomicOr).  The stream's first word
+            // (shared with the table headers) and its last go out byte by byte.  The next tile's four loads per thread are in flight while this one is packed.
+            if (t == 0) {
+                uint8_t* op = seqDst + nbHdr;
+                *op++ = (uint8_t)((sh->encType[0] << 6) + (sh->encType[1] << 4) + (sh->encType[2] << 2));
+                for (int k = 0; k < 3; k++) for (uint32_t i = 0; i < sh->ncountSize[k]; i++) *op++ = sh->ncount[k][i];
+            }
+            {   uint32_t* const w32 = (uint32_t*)((uintptr_t)bs & ~(uintptr_t)3);
+                uint8_t* const w8 = (uint8_t*)w32;
+                uint32_t const firstB = (uint32_t)((uintptr_t)bs & 3), endB = firstB + streamBytes;      // the stream's bytes are [firstB, endB) counted from w32
+                uint32_t* const tile = &sh->hist[0][0];                     // the literal histograms (dead by now): 1 536 words with sampleHist[] behind them
+                uint32_t const nTiles = (nbSeqU + NT - 1) / NT;
+                uint32_t carry = 8u * firstB, wordBase = 0, cw = 0;         // bits of image word 0 in front of the tile's; image word 0 = w32[wordBase]; its value
+                ZhipSeq sqN = {}; uint32_t xN = 0, yN = 0, zN = 0;
+                {   uint32_t const i = (nTiles - 1) * NT + (uint32_t)t;
+                    if (i < nbSeqU) { sqN = seqs[i]; xN = bOF[i]; yN = bML[i]; zN = bLL[i]; }
+                }
+                for (uint32_t k = nTiles; k-- > 0; ) {
+                    uint32_t const i = k * NT + (uint32_t)t;
+                    bool const on = i < nbSeqU;
+                    ZhipSeq const sq1 = sqN;
+                    uint32_t x = xN, y = yN, z = zN, ll = 0, mlb = 0, ob = 1, lb = 0, mb = 0, ofc = 0, nb = 0;
+                    if (k > 0) { uint32_t const j = i - NT; sqN = seqs[j]; xN = bOF[j]; yN = bML[j]; zN = bLL[j]; }      // every lower tile is full
+                    if (on) {
+                        seq_unpack(sq1, pm, i, ll, mlb, ob);
+                        lb = TB.llBits[ll_code(TB, ll)]; mb = TB.mlBits[ml_code(TB, mlb)]; ofc = hb32(ob);
+                        if (i + 1 >= nbSeqU) { x = 0; y = 0; z = 0; }      // the first-coded sequence carries no state bits
+                        nb = (x >> 12) + (y >> 12) + (z >> 12) + lb + mb + ofc;
+                    }
+                    uint32_t tileBits;
+                    uint32_t const lower = block_excl_scan<NT, SH>(sh, nb, &tileBits);        // bits of the tile's sequences BELOW mine (its barriers also end the last flush)
+                    uint32_t const tot = carry + tileBits, full = tot >> 5, words = (tot + 31) >> 5;
+                    for (uint32_t w = (uint32_t)t; w < words; w += NT) tile[w] = w ? 0u : cw;
+                    __syncthreads();
+                    if (nb) {
+                        // my bits start behind those of the tile's higher sequences: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+                        uint32_t pos = carry + (tileBits - lower - nb);
+                        uint32_t* wp = tile + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
+                        auto put = [&](uint32_t v, uint32_t n) {
+                            acc |= (uint64_t)v << have; have += n;
+                            if (have >= 32) { __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wp++; acc >>= 32; have -= 32; }
+                        };
+                        put(x & 0xFFF, x >> 12); put(y & 0xFFF, y >> 12); put(z & 0xFFF, z >> 12);
+                        put(ll & ((1u << lb) - 1), lb); put(mlb & ((1u << mb) - 1), mb);
+                        put(ob & (uint32_t)((1ull << ofc) - 1), ofc);
+                        if (have) __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    __syncthreads();
+                    for (uint32_t w = (uint32_t)t; w < full; w += NT) {
+                        uint32_t const v = tile[w], g = wordBase + w, b0 = 4u * g;
+                        if (b0 >= firstB && b0 + 4u <= endB) w32[g] = v;
+                        else for (uint32_t q = 0; q < 4; q++) if (b0 + q >= firstB && b0 + q < endB) w8[b0 + q] = (uint8_t)(v >> (8 * q));
+                    }
+                    cw = (tot & 31) ? tile[full] : 0u;
+                    carry = tot & 31; wordBase += full;
+                }
+                if (t == 0) {     // final states ML, OF, LL then the end mark (zstd_compress_sequences.c:371-381): at most 27 bits behind the carried ones
+                    uint64_t acc = cw; uint32_t have = carry;
+                    acc |= (uint64_t)(sh->finalState[2] & ((1u << sh->ct[2].tableLog) - 1)) << have; have += sh->ct[2].tableLog;
+                    acc |= (uint64_t)(sh->finalState[1] & ((1u << sh->ct[1].tableLog) - 1)) << have; have += sh->ct[1].tableLog;
+                    acc |= (uint64_t)(sh->finalState[0] & ((1u << sh->ct[0].tableLog) - 1)) << have; have += sh->ct[0].tableLog;
+                    acc |= 1ull << have;
+                    uint32_t const b0 = 4u * wordBase;
+                    for (uint32_t q = 0; q < 8; q++) if (b0 + q >= firstB && b0 + q < endB) w8[b0 + q] = (uint8_t)(acc >> (8 * q));
+                }
+            }
+#else
             // zero the bytes of the bitstream; lane 0 writes the table headers in front of it
             zero_bytes<NT>(bs, streamBytes);
             if (t == 0) {
@@ -964,6 +1115,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                     tl.finish();
                 }
             }
+#endif
             seqSection = nbHdr + 1 + tblBytes + streamBytes;
             // zstd_compress.c:2987: last FSE header + bitstream < 4 bytes -> emit the block uncompressed
             uint32_t lastCount = 0;
