@@ -61,19 +61,17 @@ __device__ __forceinline__ uint32_t ml_code(const CodeTabs& T, uint32_t mlBase) 
 
 // ------------------------------------------------------------------ LDS layout of the workgroup
 struct EntShared {
-    // The Huffman builder's workspace (8.6 KB, wave 0, phase B only) lies over what is dead or not yet alive while it runs: the three
-    // extra per-wavefront histograms (already reduced into hist[0], which the builder reads), the sampling histograms (read at the
-    // start of the literals job, before the builder) and the scan area (phase C).  18.5 KB instead of 25.7 KB: eight workgroups per CU.
+    // The Huffman builder's workspace (8.6 KB, wave 0, phase B only) lies over what is dead or not yet alive while it runs: the sampling
+    // histograms (read at the start of the literals job, before the builder) and the scan area (phase C).  The four per-wavefront literal
+    // histograms stay alive through phase B (round 6): wavefront w counts the bytes of Huffman stream w, so the streams' sizes are
+    // sum(count x code length) — no sizing pass over the literals.  21.5 KB: seven workgroups per CU (its registers allow six).
+    uint32_t hist[4][256];        // per-wavefront = per-stream literal histograms; hist[0] becomes the block's (sum of the four)
     union {
         struct {
-            uint32_t hist[4][256];        // per-wavefront literal histograms, reduced into hist[0]
-            uint32_t sampleHist[2][256];
+            uint32_t sampleHist[2][256];      // directly behind hist[]: the two together are the packers' LDS images in phase C
             uint32_t scan[ZHIP_ENT_THREADS + 8];
         };
-        struct {
-            uint32_t hist0_[256];         // = hist[0]
-            HufWork  huf;
-        };
+        HufWork  huf;
     };
     uint32_t code[256];           // huff0 code: value << 8 | nbBits
     uint32_t seqCount[3][64];     // LL / OF / ML code histograms
@@ -453,15 +451,26 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     // byte histogram of the literals the match finder left in lits[] (HIST_count_wksp, hist.c:154): 16 bytes per thread
     // per step, coalesced; one histogram per wavefront to spread the LDS atomics
     uint32_t const litSize = pm.litSize;
+#ifndef ZHIP_HUF_HISTSIZE
+#define ZHIP_HUF_HISTSIZE 1
+#endif
+    constexpr bool histSized = (NT == 256) && (ZHIP_HUF_HISTSIZE != 0);
     {   uint32_t* const myHist = sh->hist[wv];
-        uint32_t const strideB = 16u * NT;
-        for (uint32_t i0 = 16u * (uint32_t)t; i0 < litSize; i0 += 4 * strideB) {      // 4 loads in flight per thread
+        // histSized (round 6): with four streams (litSize >= 256, zstd_compress_literals.c:142 — a valid previous table's single stream is handled below)
+        // wavefront w takes segment w of huf_compress.c:1168-1215, so hist[w] is the histogram of stream w
+        bool const perStream = histSized && litSize >= 256;
+        uint32_t const segA = (litSize + 3) / 4;
+        uint32_t const lo = perStream ? (uint32_t)wv * segA : 0u;
+        uint32_t const hi = perStream ? ((uint32_t)wv < 3 ? lo + segA : litSize) : litSize;
+        uint32_t const tA = perStream ? (uint32_t)lane : (uint32_t)t;
+        uint32_t const strideB = perStream ? 16u * 64u : 16u * NT;
+        for (uint32_t i0 = lo + 16u * tA; i0 < hi; i0 += 4 * strideB) {      // 4 loads in flight per thread
             uint4 v[4];
-            for (int q = 0; q < 4; q++) { uint32_t const i = i0 + (uint32_t)q * strideB; if (i < litSize) __builtin_memcpy(&v[q], lits + i, 16); }   // lits has >= 64 bytes of slack
+            for (int q = 0; q < 4; q++) { uint32_t const i = i0 + (uint32_t)q * strideB; if (i < hi) __builtin_memcpy(&v[q], lits + i, 16); }   // lits has >= 64 bytes of slack
             for (int q = 0; q < 4; q++) {
                 uint32_t const i = i0 + (uint32_t)q * strideB;
-                if (i >= litSize) break;
-                uint32_t const c = litSize - i < 16 ? litSize - i : 16;
+                if (i >= hi) break;
+                uint32_t const c = hi - i < 16 ? hi - i : 16;
                 uint32_t const w[4] = { v[q].x, v[q].y, v[q].z, v[q].w };
                 for (uint32_t b = 0; b < 16; b++) if (b < c) atomicAdd(&myHist[(w[b >> 2] >> (8 * (b & 3))) & 0xFF], 1u);
             }
@@ -483,7 +492,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
     uint32_t const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     uint32_t const hufRep0 = de ? de->hufRepeat : 0;        // previous Huffman table: 0 none, 1 check, 2 valid (dictionary)
     bool const single = litSize < 256 || (hufRep0 == 2 && lhSize == 3);                // zstd_compress_literals.c:142, :170
-    bool const tryHuf0 = !(u.litMode) && litSize >= (hufRep0 == 2 ? 6u : 64u);        // :115-127 minLiteralsToCompress (strategy <= lazy2)
+#ifdef ZHIP_PROBE_NOHUF             /* timing probe, bytes wrong */
+    bool const tryHuf0 = false;
+#else
+    bool const tryHuf0 = !(u.litMode) && litSize >= (hufRep0 == 2 ? 6u : 64u);
+#endif        // :115-127 minLiteralsToCompress (strategy <= lazy2)
     bool const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);                      // zstd_compress.c:2918
     bool const sampling = tryHuf0 && suspect && litSize >= 40960;
     if (sampling) for (int i = t; i < 512; i += NT) (&sh->sampleHist[0][0])[i] = 0;
@@ -645,7 +658,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             // becomes (nbBits << 12 | value)
             // scratch for the slices' chunk states: the block's own output room, which nothing has written yet (3 x <= 8 KB of it)
             uint16_t* const ckpt = (uint16_t*)(((uintptr_t)body + 15) & ~(uintptr_t)15) + (size_t)k * fse_chain_ckpt_entries(nbSeq - 1);
+#ifdef ZHIP_PROBE_NOCHAIN          /* timing probe, bytes wrong */
+            uint32_t const fin = lastCode; (void)ckpt;
+#else
             uint32_t const fin = fse_chain_wave<64>(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt);
+#endif
             if (lane == 0) sh->finalState[k] = fin;
         }
         ZPROF_JOB_MARK(30);
@@ -688,7 +705,27 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
         constexpr bool staged = (NT == 256) && (ZHIP_HUF_STAGE != 0);
         constexpr bool sizeChunked = chunked || (staged && ZHIP_HUF_STAGE == 2);
         uint32_t segStart[SPW], segLenA[SPW], total[SPW], runStart[SPW], runLen[SPW], incl[SPW];
-        if constexpr (sizeChunked) {
+        if constexpr (staged && histSized) {
+            // no pass 1 (round 6): stream w's bits = sum over the symbols of hist[w][s] x nbBits(s); hist[0] holds the block's histogram by now, so stream 0 is
+            // the block minus the other three.  Every wavefront computes its own stream's; a single stream is the block's.
+            uint32_t const sI = (uint32_t)wv;
+            segStart[0] = 0; segLenA[0] = 0; total[0] = 0;
+            if (sI < nStreams) {
+                segStart[0] = sI * seg;
+                segLenA[0] = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
+                uint32_t mine = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    uint32_t const sy = (uint32_t)lane + 64u * q;
+                    uint32_t cnt = sh->hist[sI][sy];
+                    if (sI == 0 && !single) cnt -= sh->hist[1][sy] + sh->hist[2][sy] + sh->hist[3][sy];
+                    mine += cnt * (sh->code[sy] & 0xFF);
+                }
+                uint32_t const inclAll = wave_incl_scan(mine);
+                total[0] = __shfl(inclAll, 63);
+                if (lane == 0) { sh->streamBits[sI] = total[0]; sh->streamBytes[sI] = (total[0] >> 3) + 1; }
+            }
+        } else if constexpr (sizeChunked) {
             // pass 1: wavefront `wv` sizes stream `wv`.  Round 4: COALESCED — the wavefront walks the stream in chunks of 64 x 16 symbols, lane l takes
             // the 16 bytes at chunk + 16 l (one 1 KB stretch per load instruction; a lane used to own one contiguous run of the stream, i.e. 64 lines per
             // load).  (lits[] has ZHIP_LIT_STRIDE - ZHIP_UNIT_MAX bytes of slack, so a 16-byte read may run past the stream.)
@@ -993,41 +1030,69 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 uint8_t* const w8 = (uint8_t*)w32;
                 uint32_t const firstB = (uint32_t)((uintptr_t)bs & 3), endB = firstB + streamBytes;      // the stream's bytes are [firstB, endB) counted from w32
                 uint32_t* const tile = &sh->hist[0][0];                     // the literal histograms (dead by now): 1 536 words with sampleHist[] behind them
-                uint32_t const nTiles = (nbSeqU + NT - 1) / NT;
+#ifndef ZHIP_SEQ_SPT
+#define ZHIP_SEQ_SPT 2
+#endif
+                // a tile is SPT x NT sequences: thread t takes sequence t of each of the tile's SPT parts (coalesced), one scan (16 bits per part) places all of them,
+                // and the barriers of a tile are shared by SPT sequences per thread (SPT 2: at most 31 + 512 x 89 bits = 1 425 words of image)
+                constexpr uint32_t SPT = NT == 64 ? 1u : (uint32_t)ZHIP_SEQ_SPT, TS = SPT * NT;     // the one-wavefront form's image is its single histogram: 31 + 64 x 89 bits
+                uint32_t const nTiles = (nbSeqU + TS - 1) / TS;
                 uint32_t carry = 8u * firstB, wordBase = 0, cw = 0;         // bits of image word 0 in front of the tile's; image word 0 = w32[wordBase]; its value
-                ZhipSeq sqN = {}; uint32_t xN = 0, yN = 0, zN = 0;
-                {   uint32_t const i = (nTiles - 1) * NT + (uint32_t)t;
-                    if (i < nbSeqU) { sqN = seqs[i]; xN = bOF[i]; yN = bML[i]; zN = bLL[i]; }
+                ZhipSeq sqN[SPT]; uint32_t xN[SPT], yN[SPT], zN[SPT];
+#pragma unroll
+                for (uint32_t h = 0; h < SPT; h++) {
+                    uint32_t const i = (nTiles - 1) * TS + h * NT + (uint32_t)t;
+                    sqN[h] = ZhipSeq{}; xN[h] = yN[h] = zN[h] = 0;
+                    if (i < nbSeqU) { sqN[h] = seqs[i]; xN[h] = bOF[i]; yN[h] = bML[i]; zN[h] = bLL[i]; }
                 }
+#ifdef ZHIP_PROBE_NOSEQPACK        /* timing probe, bytes wrong */
+                for (uint32_t k = 0; k-- > 0; ) {
+#else
                 for (uint32_t k = nTiles; k-- > 0; ) {
-                    uint32_t const i = k * NT + (uint32_t)t;
-                    bool const on = i < nbSeqU;
-                    ZhipSeq const sq1 = sqN;
-                    uint32_t x = xN, y = yN, z = zN, ll = 0, mlb = 0, ob = 1, lb = 0, mb = 0, ofc = 0, nb = 0;
-                    if (k > 0) { uint32_t const j = i - NT; sqN = seqs[j]; xN = bOF[j]; yN = bML[j]; zN = bLL[j]; }      // every lower tile is full
-                    if (on) {
-                        seq_unpack(sq1, pm, i, ll, mlb, ob);
-                        lb = TB.llBits[ll_code(TB, ll)]; mb = TB.mlBits[ml_code(TB, mlb)]; ofc = hb32(ob);
-                        if (i + 1 >= nbSeqU) { x = 0; y = 0; z = 0; }      // the first-coded sequence carries no state bits
-                        nb = (x >> 12) + (y >> 12) + (z >> 12) + lb + mb + ofc;
+#endif
+                    uint32_t x[SPT], y[SPT], z[SPT], ll[SPT], mlb[SPT], ob[SPT], lb[SPT], mb[SPT], ofc[SPT], nb[SPT];
+                    ZhipSeq sq1[SPT];
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (uint32_t h = 0; h < SPT; h++) {
+                        uint32_t const i = k * TS + h * NT + (uint32_t)t;
+                        sq1[h] = sqN[h]; x[h] = xN[h]; y[h] = yN[h]; z[h] = zN[h];
+                        if (k > 0) { uint32_t const j = i - TS; sqN[h] = seqs[j]; xN[h] = bOF[j]; yN[h] = bML[j]; zN[h] = bLL[j]; }      // every lower tile is full
+                        ll[h] = 0; mlb[h] = 0; ob[h] = 1; lb[h] = 0; mb[h] = 0; ofc[h] = 0; nb[h] = 0;
+                        if (i < nbSeqU) {
+                            seq_unpack(sq1[h], pm, i, ll[h], mlb[h], ob[h]);
+                            lb[h] = TB.llBits[ll_code(TB, ll[h])]; mb[h] = TB.mlBits[ml_code(TB, mlb[h])]; ofc[h] = hb32(ob[h]);
+                            if (i + 1 >= nbSeqU) { x[h] = 0; y[h] = 0; z[h] = 0; }      // the first-coded sequence carries no state bits
+                            nb[h] = (x[h] >> 12) + (y[h] >> 12) + (z[h] >> 12) + lb[h] + mb[h] + ofc[h];
+                        }
+                        packed |= nb[h] << (16 * h);
                     }
-                    uint32_t tileBits;
-                    uint32_t const lower = block_excl_scan<NT, SH>(sh, nb, &tileBits);        // bits of the tile's sequences BELOW mine (its barriers also end the last flush)
+                    uint32_t partTot;
+                    uint32_t const lowerP = block_excl_scan<NT, SH>(sh, packed, &partTot);     // per part: bits of its sequences BELOW mine (the barriers also end the last flush)
+                    uint32_t tileBits = 0;
+#pragma unroll
+                    for (uint32_t h = 0; h < SPT; h++) tileBits += (partTot >> (16 * h)) & 0xFFFFu;
                     uint32_t const tot = carry + tileBits, full = tot >> 5, words = (tot + 31) >> 5;
                     for (uint32_t w = (uint32_t)t; w < words; w += NT) tile[w] = w ? 0u : cw;
                     __syncthreads();
-                    if (nb) {
-                        // my bits start behind those of the tile's higher sequences: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
-                        uint32_t pos = carry + (tileBits - lower - nb);
-                        uint32_t* wp = tile + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
-                        auto put = [&](uint32_t v, uint32_t n) {
-                            acc |= (uint64_t)v << have; have += n;
-                            if (have >= 32) { __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wp++; acc >>= 32; have -= 32; }
-                        };
-                        put(x & 0xFFF, x >> 12); put(y & 0xFFF, y >> 12); put(z & 0xFFF, z >> 12);
-                        put(ll & ((1u << lb) - 1), lb); put(mlb & ((1u << mb) - 1), mb);
-                        put(ob & (uint32_t)((1ull << ofc) - 1), ofc);
-                        if (have) __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t above = 0;                                     // bits of the tile's parts above part h (they come first in the stream)
+#pragma unroll
+                    for (uint32_t hh = SPT; hh-- > 0; ) {
+                        uint32_t const pT = (partTot >> (16 * hh)) & 0xFFFFu, lower = (lowerP >> (16 * hh)) & 0xFFFFu;
+                        if (nb[hh]) {
+                            // my bits start behind those of the higher sequences: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+                            uint32_t pos = carry + above + (pT - lower - nb[hh]);
+                            uint32_t* wp = tile + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
+                            auto put = [&](uint32_t v, uint32_t n) {
+                                acc |= (uint64_t)v << have; have += n;
+                                if (have >= 32) { __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); wp++; acc >>= 32; have -= 32; }
+                            };
+                            put(x[hh] & 0xFFF, x[hh] >> 12); put(y[hh] & 0xFFF, y[hh] >> 12); put(z[hh] & 0xFFF, z[hh] >> 12);
+                            put(ll[hh] & ((1u << lb[hh]) - 1), lb[hh]); put(mlb[hh] & ((1u << mb[hh]) - 1), mb[hh]);
+                            put(ob[hh] & (uint32_t)((1ull << ofc[hh]) - 1), ofc[hh]);
+                            if (have) __hip_atomic_fetch_or(wp, (uint32_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        above += pT;
                     }
                     __syncthreads();
                     for (uint32_t w = (uint32_t)t; w < full; w += NT) {
