@@ -85,6 +85,7 @@ struct EntShared {
     uint32_t encType[3];          // set_basic 0 / set_rle 1 / set_compressed 2 / set_repeat 3 (zstd_internal.h:102)
     uint32_t maxCode[3];
     uint32_t finalState[3];
+    uint32_t chainBits[3], extraBits[3];   // per table: the state bits of all chain records / the extra bits of all sequences (the bitstream's size without a pass over it)
     uint8_t  hufHdr[136];
     // scalars broadcast through LDS
     uint32_t litSize, hufHdrSize, huffLog, litMode /*0 raw,1 rle,2 huf*/, singleStream, litType /*2 compressed, 3 repeat*/, hufMaxSym /* of a new table */;
@@ -113,6 +114,7 @@ struct EntSharedSmall {
     uint32_t encType[3];
     uint32_t maxCode[3];
     uint32_t finalState[3];
+    uint32_t chainBits[3], extraBits[3];   // per table: the state bits of all chain records / the extra bits of all sequences (the bitstream's size without a pass over it)
     uint8_t  hufHdr[136];
     uint32_t litSize, hufHdrSize, huffLog, litMode, singleStream, litType, hufMaxSym;
     uint32_t streamBits[4], streamBytes[4], streamOff[4];
@@ -293,7 +295,7 @@ __device__ __forceinline__ uint32_t fse_chain_step(const FseCTable* ct, uint32_t
 // Then every slice is run once more from its true entering state, this time writing the records over the codes.
 // Entries move 8 at a time (16-byte loads / stores per lane).
 #define ZHIP_FSE_WARM 3u          /* warm-up, in 8-entry chunks */
-__device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* arr, uint32_t c, uint32_t M, uint4 w, uint32_t& state, bool record)
+__device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* arr, uint32_t c, uint32_t M, uint4 w, uint32_t& state, bool record, uint32_t& bits /* += nbBits of the records written */)
 {   // entries [8c, 8c+8) ∩ [0, M), highest first; w = the 16 bytes at arr + 8c
     uint32_t x[4] = { w.x, w.y, w.z, w.w };                                   // two 16-bit entries per word; all indices below are static
     uint32_t const top = M - 8u * c < 8 ? M - 8u * c : 8;
@@ -308,6 +310,7 @@ __device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* a
             uint32_t const sh16 = (q & 1) ? 16u : 0u;
             uint32_t const rec = fse_chain_step(ct, state, db[q], df[q]);
             x[q >> 1] = (x[q >> 1] & ~(0xFFFFu << sh16)) | (rec << sh16);
+            if (record) bits += rec >> 12;
         }
         if (record) { w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3]; __builtin_memcpy(arr + 8u * c, &w, 16); }
         return;
@@ -318,6 +321,7 @@ __device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* a
         uint32_t const sy = (x[q >> 1] >> sh16) & 0xFFFFu;
         uint32_t const rec = fse_chain_step(ct, state, ct->dBits[sy], ct->dFind[sy]);
         x[q >> 1] = (x[q >> 1] & ~(0xFFFFu << sh16)) | (rec << sh16);
+        if (record) bits += rec >> 12;
     }
     if (record) {
 #pragma unroll
@@ -329,7 +333,7 @@ __device__ __forceinline__ void fse_chain_chunk(const FseCTable* ct, uint16_t* a
 // earlier one, stop and return true — and replaces it; 3: records are written over the codes
 enum { ZC_DRY = 0, ZC_KEEP = 1, ZC_MEET = 2, ZC_RECORD = 3 };
 __device__ __forceinline__ bool fse_chain_run(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t hiC, uint32_t loC, uint32_t& state,
-                                              int mode, uint16_t* ckpt, uint32_t lane)
+                                              int mode, uint16_t* ckpt, uint32_t lane, uint32_t& bits)
 {
     if (hiC <= loC) return false;
     uint4 nxt; __builtin_memcpy(&nxt, arr + 8u * (hiC - 1), 16);
@@ -337,7 +341,7 @@ __device__ __forceinline__ bool fse_chain_run(const FseCTable* ct, uint16_t* arr
     for (uint32_t c = hiC; c > loC; c--, t++) {
         uint4 const cur = nxt;
         if (c - 1 > loC) __builtin_memcpy(&nxt, arr + 8u * (c - 2), 16);
-        fse_chain_chunk(ct, arr, c - 1, M, cur, state, mode == ZC_RECORD);
+        fse_chain_chunk(ct, arr, c - 1, M, cur, state, mode == ZC_RECORD, bits);
         if (mode == ZC_KEEP) ckpt[t * 64 + lane] = (uint16_t)state;
         else if (mode == ZC_MEET) {
             if (ckpt[t * 64 + lane] == (uint16_t)state) return true;
@@ -354,13 +358,14 @@ __host__ __device__ inline uint32_t fse_chain_ckpt_entries(uint32_t M, uint32_t 
 // lane passes its group's), M is the same for all.  ckpt: fse_chain_ckpt_entries(M, G) uint16 of scratch in global memory, private
 // to this wavefront (all groups index it by t * 64 + lane); touched only when a lane owns two or more chunks (M > 8 G).
 template <uint32_t G>
-__device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt)
+__device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt, uint32_t* recBits = nullptr /* G = 64: the records' nbBits, summed */)
 {
+    uint32_t bits = 0;
     uint32_t const lane = (uint32_t)(threadIdx.x & 63);
     uint32_t const grp = lane / G, gl = lane - grp * G;                     // group, lane inside the group
     bool const inGroup = G == 64 || grp < 64 / G;                           // G = 21: lane 63 belongs to no chain
     uint32_t const init = fse_init_state2(ct, lastCode);
-    if (M == 0) return init;
+    if (M == 0) { if (recBits) *recBits = 0; return init; }
     uint32_t const chunks = (M + 7) >> 3, cpl = (chunks + G - 1) / G;       // chunks per lane
     uint32_t const used = (chunks + cpl - 1) / cpl;                         // lanes of a group that own something; lane 0 of a group owns the TOP slice
     bool const mine = inGroup && gl < used;
@@ -371,11 +376,11 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
     if (mine && gl) {
         uint32_t w1 = topC + ZHIP_FSE_WARM;
         if (w1 >= chunks) w1 = chunks; else enter = 1u << ct->tableLog;
-        fse_chain_run(ct, arr, M, w1, topC, enter, ZC_DRY, ckpt, lane);
+        fse_chain_run(ct, arr, M, w1, topC, enter, ZC_DRY, ckpt, lane, bits);
     }
     uint32_t fin = enter;
     bool const keep = cpl >= 2;                                               // one chunk per lane: nothing to meet (and a small record's output room is not borrowed)
-    fse_chain_run(ct, arr, M, topC, botC, fin, keep ? ZC_KEEP : ZC_DRY, ckpt, lane);
+    fse_chain_run(ct, arr, M, topC, botC, fin, keep ? ZC_KEEP : ZC_DRY, ckpt, lane, bits);
     // hand-down rounds
     for (;;) {
         uint32_t const above = __shfl_up(fin, 1);
@@ -387,13 +392,14 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
         if (bad) {
             enter = above;
             uint32_t st = above;
-            if (!fse_chain_run(ct, arr, M, topC, botC, st, keep ? ZC_MEET : ZC_DRY, ckpt, lane)) fin = st;
+            if (!fse_chain_run(ct, arr, M, topC, botC, st, keep ? ZC_MEET : ZC_DRY, ckpt, lane, bits)) fin = st;
         }
     }
     __builtin_amdgcn_wave_barrier();                                          // all reads of pass 1 are done: records may replace codes
     // pass 2: every slice again from its (now true) entering state, records written in place
     uint32_t st = enter;
-    fse_chain_run(ct, arr, M, topC, botC, st, ZC_RECORD, ckpt, lane);
+    fse_chain_run(ct, arr, M, topC, botC, st, ZC_RECORD, ckpt, lane, bits);
+    if (G == 64 && recBits) *recBits = tw_sum(bits);
     return __shfl(fin, (int)(grp * G + used - 1));                            // the group's lowest slice holds the final state
 }
 
@@ -578,6 +584,11 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             const int16_t* defNorm = (k == 0) ? kLLnorm : (k == 1 ? kOFnorm : kMLnorm);
             uint32_t* cnt = sh->seqCount[k];
             uint32_t const myCnt = (uint32_t)lane <= maxPossible ? cnt[lane] : 0;        // lane = code
+            {   // the extra bits of all sequences in this field (zstd_internal.h:123-168; an offset code is its own number of extra bits), before the "-1" rule touches the counts
+                uint32_t const eb = (uint32_t)lane <= maxPossible ? (k == 0 ? TB.llBits[lane] : (k == 1 ? (uint32_t)lane : TB.mlBits[lane])) : 0u;
+                uint32_t const ext = tw_sum(myCnt * eb);
+                if (lane == 0) sh->extraBits[k] = ext;
+            }
             uint32_t const max = 63u - (uint32_t)__clzll((long long)__ballot(myCnt != 0));
             uint32_t const mostFrequent = tw_max(myCnt);
             bool const defaultAllowed = (k != 1) || (max <= 28);                       // zstd_compress.c:2814
@@ -661,7 +672,9 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
 #ifdef ZHIP_PROBE_NOCHAIN          /* timing probe, bytes wrong */
             uint32_t const fin = lastCode; (void)ckpt;
 #else
-            uint32_t const fin = fse_chain_wave<64>(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt);
+            uint32_t cb = 0;
+            uint32_t const fin = fse_chain_wave<64>(&sh->ct[k], arr, nbSeq - 1, lastCode, ckpt, &cb);
+            if (lane == 0) sh->chainBits[k] = cb;
 #endif
             if (lane == 0) sh->finalState[k] = fin;
         }
@@ -994,7 +1007,14 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             // Round 4: COALESCED.  Thread t takes the sequences t, t + NT, ... (one line per wavefront and array instead of 64); the old form gave
             // every thread a run of consecutive sequences, i.e. 64 lines per load instruction, and was 45 % of the stage on dense-match data.
             uint32_t const nbSeqU = ZHIP_UNIFORM(nbSeq);                 // the tile loop below holds barriers: its trip count is scalar
+#ifndef ZHIP_SEQ_BITS_FROM_TABLES
+#define ZHIP_SEQ_BITS_FROM_TABLES 1
+#endif
+            // Round 6 (four-wavefront form): the stream's size needs no pass over the sequences — the extra bits are sum(count x bits) per field, the state bits were
+            // summed by the chains as they wrote their records (entries 0 .. nbSeq-2: the first-coded sequence has none)
+            constexpr bool bitsFromTables = (NT == 256) && (ZHIP_SEQ_BITS_FROM_TABLES != 0);
             uint32_t myBits = 0;
+            if constexpr (!bitsFromTables)
             for (uint32_t i = (uint32_t)t; i < nbSeqU; i += NT) {
                 ZhipSeq const sq1 = seqs[i];
                 uint32_t const nb1 = (uint32_t)(bLL[i] >> 12) + (bOF[i] >> 12) + (bML[i] >> 12);
@@ -1003,7 +1023,8 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 if (i + 1 < nbSeqU) myBits += nb1;
             }
             uint32_t totalSeqBits;
-            (void)block_excl_scan<NT, SH>(sh, myBits, &totalSeqBits);
+            if constexpr (bitsFromTables) totalSeqBits = sh->extraBits[0] + sh->extraBits[1] + sh->extraBits[2] + sh->chainBits[0] + sh->chainBits[1] + sh->chainBits[2];
+            else (void)block_excl_scan<NT, SH>(sh, myBits, &totalSeqBits);
             uint32_t const tailBits = sh->ct[2].tableLog + sh->ct[1].tableLog + sh->ct[0].tableLog;
             uint32_t const streamBits = totalSeqBits + tailBits;                       // + 1 end mark
             uint32_t const streamBytes = (streamBits >> 3) + 1;
