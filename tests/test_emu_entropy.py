@@ -91,3 +91,33 @@ def test_frames_with_content_checksum(libs):
         r = lo.zo_compress_unit(_buf(dst), cap, _buf(a), len(a), 1)
         r = lo.zo_frame_add_checksum(_buf(dst), r, _buf(a), len(a))
         assert f == dst[:r].tobytes(), name
+
+
+def _unit_with(nseq, litrun, seed):
+    """a unit of about `nseq` sequences with literal runs of about `litrun` skewed bytes between short repeats of an earlier stretch"""
+    rng = np.random.default_rng(seed)
+    out = [(rng.geometric(0.25, size=64) % 61 + 32).astype(np.uint8)]
+    n = 64
+    for _ in range(nseq):
+        out.append((rng.geometric(0.25, size=litrun + int(rng.integers(0, 3))) % 61 + 32).astype(np.uint8))
+        n += len(out[-1])
+        flat = np.concatenate(out)
+        o = int(rng.integers(8, min(n - 8, 4000)))
+        ml = int(rng.integers(5, 24))
+        out = [flat, flat[n - o:n - o + ml].copy()]
+        n += len(out[-1])
+    return np.concatenate(out)[:131072]
+
+
+def test_staged_packers_at_their_boundaries(libs):
+    """round 6: huff0 streams go through LDS images in chunks of 64 x 16 symbols per stream, the sequence bitstream in tiles of 2 x 256 sequences, both carrying
+    their partial last word into the next chunk / tile, and a stream's first and last word leave byte by byte.  Units whose sequence count walks across the
+    tile size and whose literal count walks across four chunks (and across the 1 KB / 16 KB header sizes), against the oracle byte for byte."""
+    lo, le = libs
+    cases = []
+    for nseq in (250, 255, 256, 257, 510, 511, 512, 513, 514, 767, 768, 769, 1023, 1024, 1025, 1030):
+        cases.append((f"seq{nseq}", _unit_with(nseq, 3, nseq)))
+    for litrun in (1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33):               # 512 runs: literal counts around 4 x 1 024 at runs of 8, around 16 384 at runs of 32
+        cases.append((f"lit{litrun}", _unit_with(512, litrun, 7000 + litrun)))
+    check(lo, le, cases, 1)
+    check(lo, le, cases[::3], 3)

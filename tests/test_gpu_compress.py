@@ -82,6 +82,21 @@ def test_ragged_units_match_oracle_bytes(env, level):
             assert got == want, (name, level, first_diff(got, want))
 
 
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_staged_packers_at_their_boundaries(env, level):
+    """round 6: the entropy stage packs huff0 streams (chunks of 64 x 16 symbols) and the sequence bitstream (tiles of 2 x 256 sequences) through LDS images that
+    carry their partial last word; units whose sequence and literal counts walk across those sizes (tests/test_emu_entropy.py has the generator), byte for byte"""
+    lo, ctx, torch = env
+    from test_emu_entropy import _unit_with
+    cases = [(f"seq{k}", _unit_with(k, 3, k)) for k in (250, 255, 256, 257, 510, 511, 512, 513, 514, 767, 768, 769, 1023, 1024, 1025, 1030, 2047, 2048, 2049)]
+    cases += [(f"lit{r}", _unit_with(512, r, 7000 + r)) for r in (1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65)]
+    cases += [(f"big{r}", _unit_with(3000, r, 9000 + r)) for r in (5, 21, 40)]            # several tiles and chunks per stream, up to the full unit
+    for name, a in cases:
+        got = ctx.compress(a, level=level)
+        want, _ = oracle_chunks(lo, a, level)
+        assert got == want, (name, level, first_diff(got, want))
+
+
 @pytest.mark.parametrize("level,minseen", [(1, 200), (3, 100), (5, 200), (6, 200), (7, 200)])
 def test_golden_vectors_from_the_real_reference(env, level, minseen):
     lo, ctx, torch = env
