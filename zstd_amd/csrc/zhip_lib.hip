@@ -559,7 +559,6 @@ static size_t launch_parse(zhip_ctx* c, const uint8_t* srcDev, size_t nUnits, ui
         hipLaunchKernelGGL(zhip::k_parse_fast, dim3((unsigned)nUnits), dim3(64), smem, s,
                            srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dLits, c->dParse);
     if (c->strategy & 4) {
-        uint32_t const bpu = c->hcMaxLen ? (c->hcMaxLen + ZHIP_HC_SEARCH_THREADS - 1) / ZHIP_HC_SEARCH_THREADS : 1;   // an empty unit still gets a grid
         c->hcEvUsed = 0;
         for (size_t u0 = 0; u0 < nUnits; u0 += c->hcChunk) {
             unsigned const nu = (unsigned)(nUnits - u0 < c->hcChunk ? nUnits - u0 : c->hcChunk);
