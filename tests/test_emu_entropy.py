@@ -121,3 +121,35 @@ def test_staged_packers_at_their_boundaries(libs):
         cases.append((f"lit{litrun}", _unit_with(512, litrun, 7000 + litrun)))
     check(lo, le, cases, 1)
     check(lo, le, cases[::3], 3)
+
+
+def _unit_dominant(nseq, seed, rare=0.02):
+    """sequences that are nearly all alike (one literal length, one match length, a repeated offset) with a few strays: every FSE table has one dominant
+    symbol, i.e. states that forget slowly — the slices of the parallel state chains enter wrong and are redone"""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(97, 123, size=4096, dtype=np.uint8)
+    out = [base]
+    n = len(base)
+    for _ in range(nseq):
+        stray = rng.random() < rare
+        ll = int(rng.integers(1, 40)) if stray else 2
+        ml = int(rng.integers(4, 60)) if stray else 6
+        o = int(rng.integers(64, 4000)) if stray else 1024
+        out.append(rng.integers(33, 64, size=ll, dtype=np.uint8))
+        n += ll
+        flat = np.concatenate(out)
+        out = [flat, flat[n - o:n - o + ml].copy()]
+        n += ml
+        if n >= 131072:
+            break
+    return np.concatenate(out)[:131072]
+
+
+def test_state_chains_with_a_dominant_symbol(libs):
+    """round 6: a slice of an FSE state chain writes its records on its FIRST walk (the codes put aside) and is redone from the right state only as far as the two
+    trajectories differ; tables with one dominant symbol make most slices enter wrong"""
+    lo, le = libs
+    cases = [(f"dom{k}", _unit_dominant(k, 40 + k)) for k in (600, 2000, 6000, 16000)]
+    cases += [(f"dom_rare{k}", _unit_dominant(9000, 50 + k, rare=1.0 / k)) for k in (8, 200, 3000)]
+    check(lo, le, cases, 1)
+    check(lo, le, cases[1:4], 5)

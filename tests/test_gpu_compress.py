@@ -97,6 +97,23 @@ def test_staged_packers_at_their_boundaries(env, level):
         assert got == want, (name, level, first_diff(got, want))
 
 
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_state_chains_with_a_dominant_symbol(env, level):
+    """round 6: one walk per slice of the FSE state chains, redone only as far as a wrong entering state reaches (tests/test_emu_entropy.py has the generator and says why)"""
+    lo, ctx, torch = env
+    from test_emu_entropy import _unit_dominant
+    cases = [(f"dom{k}", _unit_dominant(k, 40 + k)) for k in (600, 2000, 6000, 16000, 30000)]
+    cases += [(f"dom_rare{k}", _unit_dominant(9000, 50 + k, rare=1.0 / k)) for k in (8, 200, 3000)]
+    flat = np.concatenate([np.concatenate([c[1], np.zeros(-len(c[1]) % 131072, dtype=np.uint8)]) for c in cases])      # one batch of full units (zero tails)
+    got = ctx.compress(flat, level=level)
+    want, _ = oracle_chunks(lo, flat, level)
+    assert got == want, (level, first_diff(got, want))
+    for name, a in cases:
+        got = ctx.compress(a, level=level)
+        want, _ = oracle_chunks(lo, a, level)
+        assert got == want, (name, level, first_diff(got, want))
+
+
 @pytest.mark.parametrize("level,minseen", [(1, 200), (3, 100), (5, 200), (6, 200), (7, 200)])
 def test_golden_vectors_from_the_real_reference(env, level, minseen):
     lo, ctx, torch = env
