@@ -77,7 +77,7 @@ struct EntShared {
     uint32_t seqCount[3][64];     // LL / OF / ML code histograms
     int16_t  norm[3][56];
     FseCTable ct[3];              // LL, OF, ML
-    uint8_t  symScratch[3][512];
+    alignas(16) uint8_t symScratch[3][512];       // fse_build_ctable_wave's scratch
     uint16_t cumul[3][64];
     uint8_t  ncount[3][64];       // NCount header bytes (or the RLE byte)
     uint32_t ncWords[3][16];      // their bit-level assembly area (fse_write_ncount_wave)
@@ -106,7 +106,7 @@ struct EntSharedSmall {
     uint32_t seqCount[3][64];
     union {
         HufWork huf;
-        struct { FseCTable ct[3]; int16_t norm[3][56]; uint8_t symScratch[3][512]; uint16_t cumul[3][64]; };
+        struct { FseCTable ct[3]; int16_t norm[3][56]; alignas(16) uint8_t symScratch[3][512]; uint16_t cumul[3][64]; };       // symScratch (dead after the table builds) is the literal packer's LDS image in phase C
     };
     uint8_t  ncount[3][64];
     uint32_t ncWords[3][16];
@@ -358,7 +358,7 @@ __host__ __device__ inline uint32_t fse_chain_ckpt_entries(uint32_t M, uint32_t 
 // lane passes its group's), M is the same for all.  ckpt: fse_chain_ckpt_entries(M, G) uint16 of scratch in global memory, private
 // to this wavefront (all groups index it by t * 64 + lane); touched only when a lane owns two or more chunks (M > 8 G).
 template <uint32_t G>
-__device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt, uint32_t* recBits = nullptr /* G = 64: the records' nbBits, summed */)
+__device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, uint32_t M, uint32_t lastCode, uint16_t* ckpt, uint32_t* recBits = nullptr /* the records' nbBits, summed over the wavefront (G = 21: the three chains together) */)
 {
     uint32_t bits = 0;
     uint32_t const lane = (uint32_t)(threadIdx.x & 63);
@@ -399,7 +399,7 @@ __device__ inline uint32_t fse_chain_wave(const FseCTable* ct, uint16_t* arr, ui
     // pass 2: every slice again from its (now true) entering state, records written in place
     uint32_t st = enter;
     fse_chain_run(ct, arr, M, topC, botC, st, ZC_RECORD, ckpt, lane, bits);
-    if (G == 64 && recBits) *recBits = tw_sum(bits);
+    if (recBits) *recBits = tw_sum(bits);                                     // G = 21: of the three chains together
     return __shfl(fin, (int)(grp * G + used - 1));                            // the group's lowest slice holds the final state
 }
 
@@ -689,7 +689,13 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             uint32_t const g = (uint32_t)lane / 21u, k3 = g < 3 ? g : 2;
             uint16_t* const arr3 = stBits + (size_t)k3 * seqCap;
             uint16_t* const ckpt = (uint16_t*)(((uintptr_t)body + 15) & ~(uintptr_t)15);
-            uint32_t const fin = fse_chain_wave<21>(&sh->ct[k3], arr3, nbSeq - 1, arr3[nbSeq - 1], ckpt);
+#ifdef ZHIP_PROBE_NOCHAIN          /* timing probe, bytes wrong */
+            uint32_t const fin = arr3[nbSeq - 1]; (void)ckpt;
+#else
+            uint32_t cb = 0;
+            uint32_t const fin = fse_chain_wave<21>(&sh->ct[k3], arr3, nbSeq - 1, arr3[nbSeq - 1], ckpt, &cb);
+            if (lane == 0) { sh->chainBits[0] = cb; sh->chainBits[1] = 0; sh->chainBits[2] = 0; }
+#endif
             if (lane == 0 || lane == 21 || lane == 42) sh->finalState[k3] = fin;
         }
     }
@@ -715,10 +721,15 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
 #ifndef ZHIP_HUF_STAGE
 #define ZHIP_HUF_STAGE 1
 #endif
-        constexpr bool staged = (NT == 256) && (ZHIP_HUF_STAGE != 0);
+#ifndef ZHIP_HUF_STAGE_SMALL
+#define ZHIP_HUF_STAGE_SMALL 1
+#endif
+        // (the one-wavefront form stages too: its image is symScratch[], 384 words, dead once the tables are built; a single stream — every record that codes its
+        // literals with the dictionary's table — is sized from the block's histogram, four streams by the chunked pass)
+        constexpr bool staged = (NT == 256) ? (ZHIP_HUF_STAGE != 0) : (ZHIP_HUF_STAGE_SMALL != 0);
         constexpr bool sizeChunked = chunked || (staged && ZHIP_HUF_STAGE == 2);
         uint32_t segStart[SPW], segLenA[SPW], total[SPW], runStart[SPW], runLen[SPW], incl[SPW];
-        if constexpr (staged && histSized) {
+        if constexpr (NT == 256 && staged && histSized) {
             // no pass 1 (round 6): stream w's bits = sum over the symbols of hist[w][s] x nbBits(s); hist[0] holds the block's histogram by now, so stream 0 is
             // the block minus the other three.  Every wavefront computes its own stream's; a single stream is the block's.
             uint32_t const sI = (uint32_t)wv;
@@ -747,6 +758,14 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 uint32_t const sI = (uint32_t)wv + q * NW;                      // stream of this wavefront's q-th turn
                 uint32_t myBits = 0;
                 segStart[q] = 0; segLenA[q] = 0;
+                if (NT == 64 && staged && single) {
+                    // one stream = the block: its bits are sum(count x code length) over the block's histogram, no pass over the literals
+                    if (sI == 0) {
+                        segLenA[q] = litSize;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) myBits += sh->hist[0][lane + 64u * k] * (sh->code[lane + 64u * k] & 0xFF);
+                    }
+                } else
                 if (sI < nStreams) {
                     segStart[q] = sI * seg;
                     uint32_t const segLen = single ? litSize : ((sI < 3) ? seg : litSize - 3 * seg);
@@ -825,16 +844,19 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             // pass 2: pack.  Symbols are emitted last -> first (huf_compress.c:1056-1118): the bit position of a run
             // is the number of bits of all LATER symbols of the stream = total - inclusive prefix.
             if constexpr (staged) {
-                uint32_t const sI = (uint32_t)wv;                                  // SPW == 1: wavefront = stream
+#pragma unroll 1
+                for (uint32_t q = 0; q < SPW; q++) {
+                uint32_t const sI = (uint32_t)wv + q * NW;                         // four wavefronts: wavefront = stream; one wavefront: the streams one after the other
                 if (sI < nStreams) {
                     uint8_t* const sbase = litDst + sh->streamOff[sI];
                     uint32_t* const w32 = (uint32_t*)((uintptr_t)sbase & ~(uintptr_t)3);
                     uint8_t* const w8 = (uint8_t*)w32;
                     uint32_t const firstB = (uint32_t)((uintptr_t)sbase & 3);      // the stream's bytes are [firstB, endB) counted from w32
                     uint32_t const endB = firstB + sh->streamBytes[sI];
-                    uint32_t* const img = &sh->hist[0][0] + 384u * (uint32_t)wv;   // 1 536 bytes per wavefront: hist[] + sampleHist[], dead since phase B (31 + 1 024 x 11 bits at most)
-                    const uint8_t* const p = lits + segStart[0];
-                    uint32_t const segLen = segLenA[0];
+                    // 1 536 bytes per wavefront (31 + 1 024 x 11 bits at most): hist[] + sampleHist[], dead since phase B; the one-wavefront form: symScratch[]
+                    uint32_t* const img = NT == 256 ? &sh->hist[0][0] + 384u * (uint32_t)wv : (uint32_t*)&sh->symScratch[0][0];
+                    const uint8_t* const p = lits + segStart[q];
+                    uint32_t const segLen = segLenA[q];
                     uint32_t const nChunks = (segLen + 1023u) >> 10;               // wave-uniform (stream geometry)
                     for (uint32_t w = (uint32_t)lane; w < 384u; w += 64u) img[w] = 0;
                     __threadfence_block();
@@ -890,6 +912,9 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                     __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
                     flush(1);
+                    __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                }
                 }
             } else if constexpr (chunked) {
 #pragma unroll
@@ -1010,9 +1035,9 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
 #ifndef ZHIP_SEQ_BITS_FROM_TABLES
 #define ZHIP_SEQ_BITS_FROM_TABLES 1
 #endif
-            // Round 6 (four-wavefront form): the stream's size needs no pass over the sequences — the extra bits are sum(count x bits) per field, the state bits were
+            // Round 6: the stream's size needs no pass over the sequences — the extra bits are sum(count x bits) per field, the state bits were
             // summed by the chains as they wrote their records (entries 0 .. nbSeq-2: the first-coded sequence has none)
-            constexpr bool bitsFromTables = (NT == 256) && (ZHIP_SEQ_BITS_FROM_TABLES != 0);
+            constexpr bool bitsFromTables = ZHIP_SEQ_BITS_FROM_TABLES != 0;            // (both forms; the one-wavefront form's three chains run side by side and sum together)
             uint32_t myBits = 0;
             if constexpr (!bitsFromTables)
             for (uint32_t i = (uint32_t)t; i < nbSeqU; i += NT) {
