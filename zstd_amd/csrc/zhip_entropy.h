@@ -106,7 +106,7 @@ struct EntSharedSmall {
     uint32_t seqCount[3][64];
     union {
         HufWork huf;
-        struct { FseCTable ct[3]; int16_t norm[3][56]; alignas(16) uint8_t symScratch[3][512]; uint16_t cumul[3][64]; };       // symScratch (dead after the table builds) is the literal packer's LDS image in phase C
+        struct { FseCTable ct[3]; int16_t norm[3][56]; alignas(16) uint8_t symScratch[1][512]; uint16_t cumul[3][64]; };       // ONE scratch: the single wavefront builds its tables one after the other
     };
     uint8_t  ncount[3][64];
     uint32_t ncWords[3][16];
@@ -641,7 +641,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
             } else if (type == 0) {
                 if ((uint32_t)lane <= defMax) sh->norm[k][lane] = defNorm[lane];
                 __builtin_amdgcn_wave_barrier();
-                fse_build_ctable_wave(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[k], sh->cumul[k]);
+                fse_build_ctable_wave(&sh->ct[k], sh->norm[k], defMax, defLog, sh->symScratch[NW == 1 ? 0 : k], sh->cumul[k]);
             } else {
                 uint32_t nbSeq1 = nbSeq;
                 uint32_t const tableLog = fse_optimal_table_log(fseLog, nbSeq, max, 2);
@@ -651,7 +651,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                 else {
                     hsz = fse_write_ncount_wave(sh->ncWords[k], sh->ncount[k], sh->norm[k], max, tableLog);
                     if (!hsz) fail = true;
-                    else fse_build_ctable_wave(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[k], sh->cumul[k]);
+                    else fse_build_ctable_wave(&sh->ct[k], sh->norm[k], max, tableLog, sh->symScratch[NW == 1 ? 0 : k], sh->cumul[k]);
                 }
             }
             if (lane == 0) { sh->encType[k] = fail ? 9 : type; sh->ncountSize[k] = hsz; sh->maxCode[k] = max; }
@@ -724,8 +724,9 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
 #ifndef ZHIP_HUF_STAGE_SMALL
 #define ZHIP_HUF_STAGE_SMALL 1
 #endif
-        // (the one-wavefront form stages too: its image is symScratch[], 384 words, dead once the tables are built; a single stream — every record that codes its
-        // literals with the dictionary's table — is sized from the block's histogram, four streams by the chunked pass)
+        // (the one-wavefront form stages too: its image is its one histogram, 256 words, dead once the stream sizes are known — chunks of 64 x 8 symbols there,
+        // 31 + 512 x 11 bits at most; a single stream — every record that codes its literals with the dictionary's table — is sized from the block's histogram, four
+        // streams by the chunked pass)
         constexpr bool staged = (NT == 256) ? (ZHIP_HUF_STAGE != 0) : (ZHIP_HUF_STAGE_SMALL != 0);
         constexpr bool sizeChunked = chunked || (staged && ZHIP_HUF_STAGE == 2);
         uint32_t segStart[SPW], segLenA[SPW], total[SPW], runStart[SPW], runLen[SPW], incl[SPW];
@@ -853,12 +854,13 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                     uint8_t* const w8 = (uint8_t*)w32;
                     uint32_t const firstB = (uint32_t)((uintptr_t)sbase & 3);      // the stream's bytes are [firstB, endB) counted from w32
                     uint32_t const endB = firstB + sh->streamBytes[sI];
-                    // 1 536 bytes per wavefront (31 + 1 024 x 11 bits at most): hist[] + sampleHist[], dead since phase B; the one-wavefront form: symScratch[]
-                    uint32_t* const img = NT == 256 ? &sh->hist[0][0] + 384u * (uint32_t)wv : (uint32_t*)&sh->symScratch[0][0];
+                    // 1 536 bytes per wavefront (31 + 1 024 x 11 bits at most): hist[] + sampleHist[], dead since phase B; the one-wavefront form: its histogram, 8 symbols per lane
+                    constexpr uint32_t SYM = NT == 256 ? 16u : 8u, CHLOG = NT == 256 ? 10u : 9u, IMGW = NT == 256 ? 384u : 256u;
+                    uint32_t* const img = NT == 256 ? &sh->hist[0][0] + 384u * (uint32_t)wv : &sh->hist[0][0];
                     const uint8_t* const p = lits + segStart[q];
                     uint32_t const segLen = segLenA[q];
-                    uint32_t const nChunks = (segLen + 1023u) >> 10;               // wave-uniform (stream geometry)
-                    for (uint32_t w = (uint32_t)lane; w < 384u; w += 64u) img[w] = 0;
+                    uint32_t const nChunks = (segLen + (1u << CHLOG) - 1u) >> CHLOG;   // wave-uniform (stream geometry)
+                    for (uint32_t w = (uint32_t)lane; w < IMGW; w += 64u) img[w] = 0;
                     __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
                     uint32_t carry = 8u * firstB;                                   // bits of image word 0 in front of this chunk's
@@ -872,14 +874,13 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                     };
                     for (uint32_t ch = nChunks; ch-- > 0; ) {
                         // chunks from the stream's end to its start; inside a chunk the higher lanes' symbols come first
-                        uint32_t const c0 = (ch << 10) + 16u * (uint32_t)lane;
-                        uint32_t const c = c0 < segLen ? (segLen - c0 < 16u ? segLen - c0 : 16u) : 0u;
-                        uint32_t cd[16]; uint32_t myBits = 0;
+                        uint32_t const c0 = (ch << CHLOG) + SYM * (uint32_t)lane;
+                        uint32_t const c = c0 < segLen ? (segLen - c0 < SYM ? segLen - c0 : SYM) : 0u;
+                        uint32_t cd[SYM]; uint32_t myBits = 0;
                         if (c) {
-                            uint4 va; __builtin_memcpy(&va, p + c0, 16);
-                            uint32_t const w[4] = { va.x, va.y, va.z, va.w };
+                            uint32_t w[SYM / 4]; __builtin_memcpy(w, p + c0, SYM);
 #pragma unroll
-                            for (uint32_t b = 0; b < 16; b++) { cd[b] = b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0u; myBits += cd[b] & 0xFF; }
+                            for (uint32_t b = 0; b < SYM; b++) { cd[b] = b < c ? sh->code[(w[b >> 2] >> (8 * (b & 3))) & 0xFF] : 0u; myBits += cd[b] & 0xFF; }
                         }
                         uint32_t const inclC = wave_incl_scan(myBits);
                         uint32_t const chunkBits = __shfl(inclC, 63);
@@ -887,7 +888,7 @@ __device__ inline uint32_t entropy_block(const uint8_t* __restrict__ src, uint32
                             uint32_t const pos = carry + chunkBits - inclC;
                             uint32_t* wp = img + (pos >> 5); uint64_t acc = 0; uint32_t have = pos & 31;
 #pragma unroll
-                            for (int b = 15; b >= 1; b -= 2) {                  // two symbols (<= 22 bits) per step, last -> first
+                            for (int b = (int)SYM - 1; b >= 1; b -= 2) {        // two symbols (<= 22 bits) per step, last -> first
                                 uint32_t const c1 = cd[b], c0v = cd[b - 1];
                                 uint32_t const n1 = c1 & 0xFF;
                                 acc |= (uint64_t)((c1 >> 8) | ((c0v >> 8) << n1)) << have; have += n1 + (c0v & 0xFF);

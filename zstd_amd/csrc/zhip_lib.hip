@@ -56,6 +56,9 @@ enum { ZE_GENERIC = 1, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 
 #ifndef ZHIP_FAST_DENSE_COST
 #define ZHIP_FAST_DENSE_COST 4000u      /* mean k_order_cost estimate (sequences + bytes / 128) from which a batch counts as dense: datagen -P50 ~ 1 900, Silesia-shaped ~ 6 500, text ~ 11 900 */
 #endif
+#ifndef ZHIP_ENT_SMALL_PAD
+#define ZHIP_ENT_SMALL_PAD 0          /* measurement only: extra dynamic LDS per record = fewer resident records per CU (occupancy slope) */
+#endif
 struct zhip_ctx_s {
     int device;
     size_t maxUnits;
@@ -631,7 +634,7 @@ static size_t launch_entropy_gather(zhip_ctx* c, const uint8_t* srcDev, size_t n
             hipLaunchKernelGGL(zhip::k_entropy, dim3((unsigned)nUnits), dim3(ZHIP_ENT_THREADS), sizeof(zhip::EntShared), s,
                                srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, ck, anySmall ? 1u : 0u);
         if (anySmall)
-            hipLaunchKernelGGL(zhip::k_entropy_small, dim3((unsigned)nUnits), dim3(64), sizeof(zhip::EntSharedSmall), s,
+            hipLaunchKernelGGL(zhip::k_entropy_small, dim3((unsigned)nUnits), dim3(64), sizeof(zhip::EntSharedSmall) + ZHIP_ENT_SMALL_PAD, s,
                                srcDev, c->dUnits, c->dSlots, (uint32_t)nUnits, c->dSeqs, c->dParse, c->dLits, c->dStBits, c->dOut, c->dOutSize, c->curDictEntropy, c->curDictID, ck);
     }
     HIPCHK(c, hipGetLastError());

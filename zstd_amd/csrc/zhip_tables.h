@@ -355,22 +355,31 @@ struct HufNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; 
 
 // wave 0's workspace while it builds the literals code; lives in LDS
 struct HufWork {
-    HufNode  node[514];           // [0] is the sentinel in front of the leaves (huf_compress.c:683)
+    // two phases that never overlap share the first 4 112 bytes (round 6: 8.6 -> 5.7 KB; the one-wavefront entropy form is bound by how many records a CU's LDS holds):
+    // huf_build_codes_wave works on the tree, huf_write_table_wave (afterwards, from code[] alone) on the weights and their FSE coder
+    union {
+        HufNode  node[514];           // [0] is the sentinel in front of the leaves (huf_compress.c:683)
+        struct {
+            uint8_t  weights[256];
+            // FSE coder of the weights (tableLog <= 6, 13 symbols)
+            uint32_t wCount[16];
+            int16_t  wNorm[16];
+            uint16_t wFirst[64];
+            uint8_t  wSym[64];
+            uint32_t wWords[16];
+            uint16_t wRec[256];           // per weight: nbBits << 12 | value of its FSE step
+            uint32_t wBits[72];           // the weights' bitstream before it is copied behind the NCount bytes
+            FseCTable wCt;
+        };
+    };
     uint16_t key[256];            // order keys (bucket << 8 | 255 - symbol), then scratch
     uint32_t bucketCount[192];
     uint8_t  stack[256];          // explicit quicksort stack (pairs)
-    uint8_t  weights[256];
     uint32_t perLen[16];          // symbols per code length, then the running canonical value per length
-    // FSE coder of the weights (tableLog <= 6, 13 symbols)
-    uint32_t wCount[16];
-    int16_t  wNorm[16];
-    uint16_t wFirst[64];
-    uint8_t  wSym[64];
-    uint32_t wWords[16];
-    uint16_t wRec[256];           // per weight: nbBits << 12 | value of its FSE step
-    uint32_t wBits[72];           // the weights' bitstream before it is copied behind the NCount bytes
-    FseCTable wCt;
+    uint32_t bcast[2];            // the builder's two wave-wide scalars (height limit result, last used symbol)
 };
+static_assert(sizeof(HufNode) * 514 >= 256 + 64 + 32 + 128 + 64 + 64 + 512 + 288 + sizeof(FseCTable), "the weights' phase fits under the tree");
+
 
 __device__ __forceinline__ uint32_t huf_bucket(uint32_t c) { return c < 165 ? c : hb32(c) + 158; }   // huf_compress.c:530 (HUF_getIndex)
 
@@ -492,10 +501,10 @@ __device__ inline uint32_t huf_build_codes_wave(HufWork* w, const uint32_t* coun
             node[a].parent = node[b].parent = (uint16_t)made;
             made++;
         }
-        w->wCount[15] = (uint32_t)last;
+        w->bcast[1] = (uint32_t)last;
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t const last = w->wCount[15], root = 256 + last - 1;
+    uint32_t const last = w->bcast[1], root = 256 + last - 1;
     // 3. depths from the parent links: internal nodes from the root downwards, 64 at a time (a parent has a higher index;
     //    one inside the same group is caught by repeating the group until nothing changes), then the leaves
     for (int hiN = (int)root - 1; hiN >= 256; hiN -= 64) {
@@ -512,9 +521,9 @@ __device__ inline uint32_t huf_build_codes_wave(HufWork* w, const uint32_t* coun
     for (uint32_t n = lane; n <= last; n += 64) node[n].nbBits = (uint8_t)(node[node[n].parent].nbBits + 1);
     __builtin_amdgcn_wave_barrier();
     // 4. height limit
-    if (lane == 0) w->wCount[14] = huf_limit_height_serial(node, last, maxNbBits);
+    if (lane == 0) w->bcast[0] = huf_limit_height_serial(node, last, maxNbBits);
     __builtin_amdgcn_wave_barrier();
-    maxNbBits = w->wCount[14];
+    maxNbBits = w->bcast[0];
     // 5. canonical values (HUF_buildCTableFromTree, :730-753): per length, values count up in symbol order
     for (uint32_t n = lane; n <= last; n += 64) atomicAdd(&w->perLen[node[n].nbBits], 1u);
     for (uint32_t s = lane; s < 256; s += 64) code[s] = 0;
