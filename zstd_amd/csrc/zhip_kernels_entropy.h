@@ -15,7 +15,7 @@
 #define ZHIP_LAZY_OCC
 #endif
 #ifndef ZHIP_ENT_OCC
-#define ZHIP_ENT_OCC
+#define ZHIP_ENT_OCC __attribute__((amdgpu_waves_per_eu(8)))    /* round 6, after the stage's LDS shrank to 19.3 KB (eight workgroups per CU): 64 registers = eight wavefronts per SIMD: datagen 1.08 -> 0.96 ms per GiB, Silesia-shaped 2.04 -> 1.89, text even (profiles/r06_ab_entropy_occupancy8.log; a wash on round 5's kernel) */
 #endif
 
 namespace zhip {

@@ -11,6 +11,9 @@
 #include "zhip_parse_ext.h"
 
 // register caps for more resident wavefronts (A/B-measured): empty = the compiler's own choice
+#ifndef ZHIP_DICT_OCC
+#define ZHIP_DICT_OCC __attribute__((amdgpu_waves_per_eu(7)))   /* the dictionary finders' queue kernels had grown to 87 / 88 VGPRs = five wavefronts per SIMD; at 72 = seven: 10 M-record stage -7 % (6: -5.6 %, 8: spills, even) — profiles/r06_ab_records_parser_occupancy.log */
+#endif
 #ifndef ZHIP_DFAST_OCC
 #define ZHIP_DFAST_OCC __attribute__((amdgpu_waves_per_eu(4)))   /* with the window (131 VGPRs as compiled): 4 waves per SIMD, A/B on 2 GiB: 3 / 4 / 5 / 6 -> text 195 / 169 / 188 / 252 ms */
 #endif
@@ -294,7 +297,7 @@ k_parse_dict(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units
 // with the record's tables in LDS (k_parse_dict_q, as many as the LDS admits) and, beside them on the same CUs, persistent wavefronts with
 // the tables in a per-wavefront region of global memory (k_parse_dict_g: `gtabs + blockIdx.x * gtabBytes`) — the stage is a chain of
 // dependent round trips per match, so what it lacks is wavefronts in flight, and 62 registers admit three times what the LDS does.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) ZHIP_DICT_OCC
 k_parse_dict_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
                ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, uint32_t* __restrict__ queue)
 {
@@ -311,7 +314,7 @@ k_parse_dict_q(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ uni
         }
     }
 }
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) ZHIP_DICT_OCC
 k_parse_dict_g(const uint8_t* __restrict__ src, const ZhipUnit* __restrict__ units, const ZhipSlot* __restrict__ slots, uint32_t nUnits,
                ZhipCDictDev cd, ZhipSeq* __restrict__ seqs, uint8_t* __restrict__ lits, ZhipParse* __restrict__ metas, uint32_t* __restrict__ queue,
                unsigned char* __restrict__ gtabs, uint32_t gtabBytes)
